@@ -1,0 +1,256 @@
+/*
+ * snapgpu.h -- C ABI of the MI355X-native seed-and-extend hot path.
+ *
+ * This is the drop-in boundary: everything SNAP's per-thread aligner objects do
+ * between "here is a Read" and "here is a SingleAlignmentResult" is behind these
+ * entry points.  Plain pointers and sizes only; no C++ or torch types cross the line.
+ *
+ * Reference interfaces each entry point replaces (paths relative to the reference tree):
+ *
+ *   snapgpu_create / snapgpu_destroy
+ *       GenomeIndex::loadFromDirectory          SNAPLib/GenomeIndex.cpp:1839-2093 (index blobs -> memory)
+ *       BaseAligner::BaseAligner                SNAPLib/BaseAligner.cpp:50-265   (per-thread scratch + options)
+ *   snapgpu_lookup_seeds
+ *       GenomeIndex::lookupSeed32               SNAPLib/GenomeIndex.cpp:2096-2157
+ *       GenomeIndex::fillInLookedUpResults32    SNAPLib/GenomeIndex.cpp:2160-2202
+ *       SNAPHashTable::GetFirstValueForKey      SNAPLib/HashTable.h:87-118
+ *       Seed::Seed                              SNAPLib/Seed.h:40-53
+ *   snapgpu_landau_vishkin
+ *       LandauVishkin<1|-1>::computeEditDistance SNAPLib/LandauVishkin.h:100-351
+ *   snapgpu_affine_gap
+ *       AffineGapVectorized<1|-1>::computeScore / computeScoreBanded
+ *                                               SNAPLib/AffineGapVectorized.h:821-1339 / 256-819
+ *   snapgpu_align_single
+ *       BaseAligner::AlignRead                  SNAPLib/BaseAligner.cpp:273-763 (decl BaseAligner.h:76-90)
+ *       called from SingleAlignerContext::runIterationThreadImpl SNAPLib/SingleAligner.cpp:250
+ *
+ * Error convention: every function returns 0 on success or a negative SNAPGPU_E_* code;
+ * snapgpu_last_error() returns a human readable message for the last failure on that
+ * context (or the last global failure when ctx is NULL).  Nothing here ever falls back to
+ * a CPU implementation: if no gfx950 device is usable, snapgpu_create fails.
+ */
+#ifndef SNAPGPU_H
+#define SNAPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNAPGPU_ABI_VERSION 1
+
+/* error codes */
+#define SNAPGPU_OK              0
+#define SNAPGPU_E_INVALID      -1   /* bad argument                                      */
+#define SNAPGPU_E_NODEVICE     -2   /* no usable HIP device / HIP runtime failure        */
+#define SNAPGPU_E_UNSUPPORTED  -3   /* index/options outside what this build implements  */
+#define SNAPGPU_E_NOMEM        -4
+#define SNAPGPU_E_LAUNCH       -5   /* kernel launch or execution failed                 */
+
+/* mirrors enum AlignmentResult, SNAPLib/AlignmentResult.h:33 */
+enum { SNAPGPU_NotFound = 0, SNAPGPU_SingleHit = 1, SNAPGPU_MultipleHits = 2 };
+
+/* sentinels, SNAPLib/LandauVishkin.h:14-15, BaseAligner.h:141, GenomeIndex.cpp:511-517 */
+#define SNAPGPU_ScoreAboveLimit     (-1)
+#define SNAPGPU_TooBigScoreValue    65536
+#define SNAPGPU_UnusedScoreValue    0xffff
+#define SNAPGPU_InvalidGenomeLocation32 0xffffffffLL
+#define SNAPGPU_MAX_K               127          /* LandauVishkin.h:11 */
+
+/*
+ * Read-only view of a loaded SNAP index (the four files of a SNAP index directory,
+ * SURVEY.md Appendix B).  Pointers may be host or device pointers; `on_device` says which.
+ * The bytes are exactly what the reference's index builder wrote, so probe sequences and
+ * results are identical to GenomeIndex::lookupSeed32.
+ */
+typedef struct snapgpu_index_view {
+    /* GenomeIndex text header (GenomeIndex.cpp:1879) */
+    uint32_t seed_len;
+    uint32_t key_bytes;            /* hashTableKeySize                                   */
+    uint32_t n_hash_tables;
+    uint32_t large_hash_table;     /* 1 = one entry holds fwd+rc values (valueCount 2)   */
+    uint32_t location_size;        /* must be 4 in this build                            */
+    uint32_t chromosome_padding;
+    uint64_t overflow_table_size;  /* in 32-bit words                                    */
+
+    /* concatenated hash tables: for table t, slots are at
+     * hash_blob + table_offset[t], table_size[t] slots of entry_bytes each
+     * (entry = value_count x 4-byte value, then key_bytes of key; HashTable.h:148-156)  */
+    const uint8_t  *hash_blob;
+    uint64_t        hash_blob_bytes;
+    const uint64_t *table_offset;   /* [n_hash_tables] byte offsets into hash_blob (always host) */
+    const uint64_t *table_size;     /* [n_hash_tables] slot counts (always host)                  */
+
+    const uint32_t *overflow;       /* [overflow_table_size]                              */
+
+    /* genome: n_bases bytes, upper-case ACGTN with 'n' padding (Genome.h:450).  The
+     * pointer addresses base 0; genome_pad bytes of 'n' are readable before and after.  */
+    const uint8_t  *genome;
+    uint64_t        n_bases;
+    uint32_t        genome_pad;     /* >= 1000 (Genome::N_PADDING)                        */
+
+    /* contig table (Genome.cpp:203-229): beginning location of each contig, ascending    */
+    const uint64_t *contig_begin;   /* [n_contigs] (always host)                          */
+    uint32_t        n_contigs;
+    uint64_t        first_alt_location; /* genomeLocationOfFirstALTContig; >= n_bases if none */
+
+    uint32_t on_device;             /* 0: blobs are host memory, copy them; 1: device ptrs */
+} snapgpu_index_view;
+
+/* Aligner options: the BaseAligner constructor arguments (BaseAligner.h:47-72) with the
+ * defaults of AlignerOptions::AlignerOptions (AlignerOptions.cpp:39-117).                */
+typedef struct snapgpu_params {
+    uint32_t max_hits;             /* -h, 300                                            */
+    uint32_t max_k;                /* -d, maxDist                                        */
+    uint32_t num_seeds;            /* -n, 25 for single-end (0 => use seed_coverage)     */
+    double   seed_coverage;        /* -sc                                                */
+    uint32_t min_weight_to_check;  /* 1                                                  */
+    uint32_t extra_search_depth;   /* -D, 1                                              */
+    uint32_t use_affine_gap;       /* 1 unless -G-                                       */
+    uint32_t match_reward;         /* 1                                                  */
+    uint32_t sub_penalty;          /* 4                                                  */
+    uint32_t gap_open_penalty;     /* 6                                                  */
+    uint32_t gap_extend_penalty;   /* 1                                                  */
+    uint32_t five_prime_end_bonus; /* 10                                                 */
+    uint32_t three_prime_end_bonus;/* 7                                                  */
+    uint32_t alt_awareness;        /* 1                                                  */
+    uint32_t emit_alt_alignments;  /* 0                                                  */
+    int32_t  max_score_gap_to_prefer_non_alt; /* 64                                      */
+    uint32_t max_read_len;         /* upper bound on read length in any batch (<= 1000)  */
+} snapgpu_params;
+
+/* POD mirror of SingleAlignmentResult (SNAPLib/AlignmentResult.h:48-76). */
+typedef struct snapgpu_single_result {
+    int32_t  status;               /* SNAPGPU_NotFound / SingleHit / MultipleHits        */
+    int32_t  direction;            /* 0 FORWARD, 1 RC (directions.h:22-29)               */
+    int64_t  location;             /* InvalidGenomeLocation32 when not found             */
+    int64_t  orig_location;
+    int32_t  score;
+    int32_t  score_prior_to_clipping;
+    int32_t  mapq;
+    int32_t  clipping_for_read_adjustment;
+    int32_t  used_affine_gap_scoring;
+    int32_t  bases_clipped_before;
+    int32_t  bases_clipped_after;
+    int32_t  ag_score;
+    int32_t  supplementary;
+    int32_t  seed_offset;
+    double   match_probability;
+    double   probability_all_candidates;
+    uint32_t popular_seeds_skipped;
+    uint32_t reserved;
+} snapgpu_single_result;
+
+/* per-call work counters (what BaseAligner exposes through getNHashTableLookups() etc.,
+ * BaseAligner.h:106-111), used for the algorithmic-bytes roofline model.                */
+typedef struct snapgpu_counters {
+    uint64_t n_reads;
+    uint64_t n_hash_table_lookups;      /* seed lookups (both strands count as one)      */
+    uint64_t n_hash_slots_probed;       /* hash-table slots examined                     */
+    uint64_t n_hits_consumed;           /* overflow/singleton hits fed to the candidate table */
+    uint64_t n_overflow_lists;          /* lookups that dereferenced the overflow table  */
+    uint64_t n_lv_locations;            /* nLocationsScoredWithLandauVishkin             */
+    uint64_t n_ag_locations;            /* nLocationsScoredWithAffineGap                 */
+    uint64_t n_lv_ref_bytes;            /* reference bytes the LV calls were entitled to */
+    uint64_t reserved[8];
+} snapgpu_counters;
+
+typedef struct snapgpu_ctx snapgpu_ctx;
+
+int         snapgpu_abi_version(void);
+const char *snapgpu_last_error(const snapgpu_ctx *ctx);
+
+/* Fill *p with the reference's single-end defaults (AlignerOptions.cpp:39-117).          */
+void        snapgpu_default_params(snapgpu_params *p);
+
+/* Create a context on HIP device `device`: uploads (or adopts, when idx->on_device) the
+ * index blobs, precomputes the probability tables on the host with host libm
+ * (LandauVishkin.cpp:716-763) and uploads them, and reserves per-wave scratch.           */
+int  snapgpu_create(const snapgpu_index_view *idx, const snapgpu_params *p, int device, snapgpu_ctx **out);
+void snapgpu_destroy(snapgpu_ctx *ctx);
+
+/* Device pointers of the context's index blobs, so that a caller that owns the
+ * collective (RCCL broadcast of the index) can fill them in place.
+ * Each pointer may be NULL if the caller does not want it.                               */
+int  snapgpu_index_device_ptrs(snapgpu_ctx *ctx, void **hash_blob, void **overflow, void **genome_with_pad);
+
+/*
+ * Seed lookup, GenomeIndex::lookupSeed32 for n seeds.
+ *   seeds:     n * seed_len bytes of ACGT text (host pointer)
+ *   n_hits:    [2n] out; n_hits[2i] forward, n_hits[2i+1] reverse-complement hit counts;
+ *              -1 for a seed whose text is not a seed (Seed::DoesTextRepresentASeed)
+ *   hits:      [2n * max_hits_out] out; row 2i+dir holds the first min(n_hits,max_hits_out)
+ *              locations in stored (descending) order
+ */
+int  snapgpu_lookup_seeds(snapgpu_ctx *ctx, uint32_t n, const char *seeds,
+                          int64_t *n_hits, uint32_t *hits, uint32_t max_hits_out);
+
+/*
+ * Batched LandauVishkin<dir>::computeEditDistance.  Problem i:
+ *   text    = texts + text_off[i], text_len[i] bytes readable in the direction of travel
+ *             (for dir -1 the pointer addresses one past the first compared byte, as in the reference)
+ *   pattern = patterns + pat_off[i], quality = quals + pat_off[i], pattern length pat_len[i]
+ *   k[i]    = edit distance limit
+ * Outputs (each [n]): score (ScoreAboveLimit if > k), match_probability, net_indel,
+ * total_indels, text_span.
+ */
+int  snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
+                            const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
+                            const char *patterns, const char *quals, uint64_t patterns_bytes,
+                            const uint32_t *pat_off, const int32_t *pat_len, const int32_t *k,
+                            int32_t *score, double *match_probability, int32_t *net_indel,
+                            int32_t *total_indels, int32_t *text_span);
+
+/*
+ * Batched AffineGapVectorized<dir>::computeScore (banded[i] == 0) / computeScoreBanded
+ * (banded[i] != 0).  Same string conventions as snapgpu_landau_vishkin; w[i] is the band
+ * / edit limit, score_init[i] the initial score, is_rc[i] selects the end bonus.
+ * Outputs (each [n]): ag_score (-1 when not better than score_init), text_offset,
+ * pattern_offset, n_edits, match_probability.
+ */
+int  snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
+                        const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
+                        const char *patterns, const char *quals, uint64_t patterns_bytes,
+                        const uint32_t *pat_off, const int32_t *pat_len,
+                        const int32_t *w, const int32_t *score_init, const uint8_t *is_rc,
+                        const uint8_t *banded, const uint8_t *use_clipping_optimizations,
+                        int32_t *ag_score, int32_t *text_offset, int32_t *pattern_offset,
+                        int32_t *n_edits, double *match_probability);
+
+/*
+ * BaseAligner::AlignRead for a batch of n reads.
+ *   bases/quals: concatenated read bytes (upper-case ACGTN / Phred+33), host pointers
+ *   offsets:     [n+1] byte offsets; read i is bases[offsets[i] .. offsets[i+1])
+ *   primary:     [n] out
+ *   first_alt:   [n] out or NULL (only status is meaningful unless emit_alt_alignments)
+ * Reads are independent; results do not depend on batch composition or order.
+ * Secondary alignments (-om) are not produced by this entry point (the reference default,
+ * maxSecondaryAlignmentAdditionalEditDistance = -1, AlignerOptions.cpp:70).
+ */
+int  snapgpu_align_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, const char *quals,
+                          const uint64_t *offsets, snapgpu_single_result *primary,
+                          snapgpu_single_result *first_alt);
+
+/*
+ * Same, but the caller has already placed bases/quals/offsets in device memory and wants
+ * results left in device memory (all four are device pointers).  This is the form the
+ * throughput metric is quoted on (inputs resident in HBM when the clock starts).
+ * `stream` is a hipStream_t (NULL = the context's own stream); the call is asynchronous
+ * with respect to the host when stream is non-NULL.
+ */
+int  snapgpu_align_single_device(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals,
+                                 const void *d_offsets, void *d_primary, void *d_first_alt, void *stream);
+
+/* Counters accumulated by snapgpu_align_single* since the last reset (device -> host). */
+int  snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int reset);
+
+/* Average duration in milliseconds of the last `align` kernel launches measured with
+ * hipEvents on the launch stream (bench.py roofline), and how many launches that covers. */
+int  snapgpu_kernel_time(snapgpu_ctx *ctx, double *total_ms, uint64_t *n_launches, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNAPGPU_H */

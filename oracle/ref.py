@@ -1,0 +1,163 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front end for oracle/_ref/libsnapref.so.
+
+libsnapref.so is the *unmodified* reference (SNAP 2.0.5) compiled by oracle/Makefile from
+the sources under /root/reference, plus oracle/ref_driver.cpp.  Only tests/, bench.py's
+cpu_baseline leg and __graft_entry__.smoke() may import this module, and only as the
+checker / reported baseline.  The product (snap_amd/) never imports it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from snap_amd.abi import RESULT_DTYPE, Params, ptr
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_DIR = os.path.join(HERE, "_ref")
+LIB_PATH = os.path.join(REF_DIR, "libsnapref.so")
+CLI_PATH = os.path.join(REF_DIR, "snap-aligner")
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libsnapref.so missing: run `make -C oracle ref` "
+                               "where /root/reference exists")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.snapref_load_index.restype = C.c_void_p
+        _lib.snapref_load_index.argtypes = [C.c_char_p]
+        _lib.snapref_init()
+    return _lib
+
+
+def build_index(fasta: str, out_dir: str, seed_len: int = 20, threads: int = 8, large: bool = False,
+                extra=()) -> None:
+    """`snap-aligner index <fasta> <dir> -s N` with the reference's own builder."""
+    cmd = [CLI_PATH, "index", fasta, out_dir, "-s", str(seed_len), "-t%d" % threads]
+    if large:
+        cmd.append("-large")
+    cmd += list(extra)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0 or not os.path.exists(os.path.join(out_dir, "GenomeIndex")):
+        raise RuntimeError("reference index build failed:\n" + r.stdout.decode(errors="replace")[-2000:])
+
+
+class RefIndex:
+    def __init__(self, directory: str):
+        self.handle = C.c_void_p(lib().snapref_load_index(directory.encode()))
+        if not self.handle:
+            raise RuntimeError("reference failed to load index " + directory)
+        self.directory = directory
+
+    def lookup_seeds(self, seeds: np.ndarray, max_hits_out: int = 512):
+        """seeds: uint8 [n, seed_len].  Returns (n_hits int64[n,2], hits uint32[n,2,max])."""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint8)
+        n = seeds.shape[0]
+        n_hits = np.zeros((n, 2), dtype=np.int64)
+        hits = np.zeros((n, 2, max_hits_out), dtype=np.uint32)
+        rc = lib().snapref_lookup_seeds(self.handle, C.c_uint32(n), ptr(seeds), ptr(n_hits), ptr(hits),
+                                        C.c_uint32(max_hits_out))
+        if rc != 0:
+            raise RuntimeError("snapref_lookup_seeds rc=%d" % rc)
+        return n_hits, hits
+
+    def align_single(self, params: Params, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray,
+                     threads: int = 1):
+        """BaseAligner::AlignRead over a batch; returns (primary, first_alt, counters, seconds)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        primary = np.zeros(n, dtype=RESULT_DTYPE)
+        first_alt = np.zeros(n, dtype=RESULT_DTYPE)
+        counters = np.zeros(3, dtype=np.int64)
+        secs = C.c_double(0)
+        rc = lib().snapref_align_single(self.handle, C.byref(params), C.c_uint32(n), ptr(bases), ptr(quals),
+                                        ptr(offsets), C.c_int(threads), ptr(primary), ptr(first_alt),
+                                        ptr(counters), C.byref(secs))
+        if rc != 0:
+            raise RuntimeError("snapref_align_single rc=%d" % rc)
+        return primary, first_alt, dict(lookups=int(counters[0]), lv=int(counters[1]), ag=int(counters[2])), secs.value
+
+
+def _pack(strings):
+    """list of bytes -> (uint8 buffer, uint32 offsets, int32 lengths)."""
+    lens = np.array([len(s) for s in strings], dtype=np.int32)
+    offs = np.zeros(len(strings), dtype=np.uint32)
+    if len(strings):
+        offs[1:] = np.cumsum(lens[:-1])
+    buf = np.frombuffer(b"".join(strings) + b"\0", dtype=np.uint8).copy()
+    return buf, offs, lens
+
+
+def landau_vishkin(direction: int, texts, patterns, quals, k):
+    """Batched LandauVishkin<direction>::computeEditDistance on python byte strings.
+
+    For direction -1, texts[i] is given in *memory order*; the reference travels it from its
+    last byte backwards (text pointer = one past the end).
+    """
+    n = len(texts)
+    tbuf, toff, tlen = _pack(texts)
+    if direction == -1:
+        toff = (toff + tlen.astype(np.uint32)).astype(np.uint32)
+    pbuf, poff, plen = _pack(patterns)
+    qbuf, _, _ = _pack(quals)
+    k = np.ascontiguousarray(k, dtype=np.int32)
+    score = np.zeros(n, np.int32); prob = np.zeros(n, np.float64)
+    net = np.zeros(n, np.int32); tot = np.zeros(n, np.int32); span = np.zeros(n, np.int32)
+    rc = lib().snapref_landau_vishkin(C.c_int(direction), C.c_uint32(n), ptr(tbuf), ptr(toff), ptr(tlen),
+                                      ptr(pbuf), ptr(qbuf), ptr(poff), ptr(plen), ptr(k),
+                                      ptr(score), ptr(prob), ptr(net), ptr(tot), ptr(span))
+    assert rc == 0
+    return dict(score=score, match_probability=prob, net_indel=net, total_indels=tot, text_span=span)
+
+
+def affine_gap(direction: int, texts, patterns, quals, w, score_init, is_rc, banded, use_clip=None,
+               agparams=(1, 4, 6, 1, 10, 7)):
+    n = len(texts)
+    tbuf, toff, tlen = _pack(texts)
+    if direction == -1:
+        toff = (toff + tlen.astype(np.uint32)).astype(np.uint32)
+    pbuf, poff, plen = _pack(patterns)
+    qbuf, _, _ = _pack(quals)
+    w = np.ascontiguousarray(w, dtype=np.int32)
+    score_init = np.ascontiguousarray(score_init, dtype=np.int32)
+    is_rc = np.ascontiguousarray(is_rc, dtype=np.uint8)
+    banded = np.ascontiguousarray(banded, dtype=np.uint8)
+    use_clip = np.zeros(n, np.uint8) if use_clip is None else np.ascontiguousarray(use_clip, dtype=np.uint8)
+    agp = np.array(agparams, dtype=np.int32)
+    ag = np.zeros(n, np.int32); to = np.zeros(n, np.int32); po = np.zeros(n, np.int32)
+    ne = np.zeros(n, np.int32); prob = np.zeros(n, np.float64)
+    rc = lib().snapref_affine_gap(C.c_int(direction), C.c_uint32(n), ptr(agp), ptr(tbuf), ptr(toff), ptr(tlen),
+                                  ptr(pbuf), ptr(qbuf), ptr(poff), ptr(plen), ptr(w), ptr(score_init),
+                                  ptr(is_rc), ptr(banded), ptr(use_clip),
+                                  ptr(ag), ptr(to), ptr(po), ptr(ne), ptr(prob))
+    assert rc == 0
+    return dict(ag_score=ag, text_offset=to, pattern_offset=po, n_edits=ne, match_probability=prob)
+
+
+def tables(n_indel: int = 1001, n_perfect: int = 1001):
+    phred = np.zeros(256); indel = np.zeros(n_indel); perfect = np.zeros(n_perfect)
+    lib().snapref_tables(ptr(phred), ptr(indel), C.c_uint32(n_indel), ptr(perfect), C.c_uint32(n_perfect))
+    return phred, indel, perfect
+
+
+def compute_mapq(p_all: float, p_best: float, score: int, popular_skipped: int) -> int:
+    f = lib().snapref_compute_mapq
+    f.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    return int(f(p_all, p_best, score, popular_skipped))
+
+
+def wrapped_next_seed(seed_len: int, wrap_count: int) -> int:
+    return int(lib().snapref_wrapped_next_seed(C.c_uint(seed_len), C.c_uint(wrap_count)))

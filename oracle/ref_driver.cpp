@@ -1,0 +1,356 @@
+/*
+ * ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ *
+ * A C-ABI driver written for this repo that links against the *unmodified* reference
+ * sources where they lie (/root/reference/SNAPLib/*.cpp, compiled by oracle/Makefile into
+ * oracle/_ref/).  It exposes the reference's own classes for the hot path so that tests
+ * and bench.py's cpu_baseline leg can run "the real thing":
+ *
+ *   snapref_lookup_seeds   -> GenomeIndex::lookupSeed32            (GenomeIndex.cpp:2096)
+ *   snapref_landau_vishkin -> LandauVishkin<+-1>::computeEditDistance (LandauVishkin.h:100)
+ *   snapref_affine_gap     -> AffineGapVectorized<+-1>::computeScore[Banded] (AffineGapVectorized.h:821/256)
+ *   snapref_align_single   -> BaseAligner::AlignRead               (BaseAligner.cpp:273), one
+ *                             aligner object per thread exactly as SingleAligner.cpp:145-173 builds it
+ *
+ * Nothing under snap_amd/ may link, import or call this file; only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() do, and only as the checker.
+ */
+#include "stdafx.h"
+#include "Compat.h"
+#include "BaseAligner.h"
+#include "GenomeIndex.h"
+#include "Genome.h"
+#include "SeedSequencer.h"
+#include "LandauVishkin.h"
+#include "AffineGapVectorized.h"
+#include "AlignerOptions.h"
+#include "BigAlloc.h"
+#include "Read.h"
+#include "Seed.h"
+#include "mapq.h"
+
+#include <pthread.h>
+#include <string.h>
+#include <stdlib.h>
+#include <time.h>
+#include <vector>
+
+#include "../include/snapgpu.h"
+
+extern "C" {
+
+static bool g_inited = false;
+
+int snapref_init(void)
+{
+    if (!g_inited) {
+        InitializeSeedSequencers();                    // CommandProcessor.cpp:196
+        initializeLVProbabilitiesToPhredPlus33();      // LandauVishkin.cpp:716 (also MAPQ tables)
+        g_inited = true;
+    }
+    return 0;
+}
+
+void *snapref_load_index(const char *dir)
+{
+    snapref_init();
+    char *d = strdup(dir);
+    GenomeIndex *index = GenomeIndex::loadFromDirectory(d, false /*map*/, false /*prefetch*/);
+    free(d);
+    return index;
+}
+
+struct snapref_index_info {
+    uint32_t seed_len;
+    uint32_t location_size_is_64;
+    uint64_t n_bases;
+    uint32_t n_contigs;
+    uint32_t chromosome_padding;
+};
+
+int snapref_index_info_get(void *vindex, snapref_index_info *out)
+{
+    GenomeIndex *index = (GenomeIndex *)vindex;
+    const Genome *genome = index->getGenome();
+    out->seed_len = index->getSeedLength();
+    out->location_size_is_64 = index->doesGenomeIndexHave64BitLocations() ? 1 : 0;
+    out->n_bases = (uint64_t)genome->getCountOfBases();
+    out->n_contigs = genome->getNumContigs();
+    out->chromosome_padding = genome->getChromosomePadding();
+    return 0;
+}
+
+/* probability tables as the reference computed them (for bit-equality checks of ours) */
+int snapref_tables(double *phred256, double *indel, uint32_t n_indel, double *perfect, uint32_t n_perfect)
+{
+    snapref_init();
+    for (int i = 0; i < 256; i++) phred256[i] = lv_phredToProbability[i];
+    for (uint32_t i = 0; i < n_indel; i++) indel[i] = lv_indelProbabilities[i];
+    for (uint32_t i = 0; i < n_perfect; i++) perfect[i] = lv_perfectMatchProbability[i];
+    return 0;
+}
+
+int snapref_compute_mapq(double pAll, double pBest, int score, int popularSeedsSkipped)
+{
+    return computeMAPQ(pAll, pBest, score, popularSeedsSkipped);
+}
+
+unsigned snapref_wrapped_next_seed(unsigned seedLen, unsigned wrapCount)
+{
+    snapref_init();
+    return GetWrappedNextSeedToTest(seedLen, wrapCount);
+}
+
+int snapref_lookup_seeds(void *vindex, uint32_t n, const char *seeds,
+                         int64_t *n_hits, uint32_t *hits, uint32_t max_hits_out)
+{
+    GenomeIndex *index = (GenomeIndex *)vindex;
+    if (index->doesGenomeIndexHave64BitLocations()) return SNAPGPU_E_UNSUPPORTED;
+    unsigned seedLen = index->getSeedLength();
+    for (uint32_t i = 0; i < n; i++) {
+        const char *text = seeds + (size_t)i * seedLen;
+        if (!Seed::DoesTextRepresentASeed(text, seedLen)) {
+            n_hits[2 * i] = n_hits[2 * i + 1] = -1;
+            continue;
+        }
+        Seed seed(text, seedLen);
+        _int64 nh[2] = {0, 0};
+        const unsigned *h[2] = {NULL, NULL};
+        index->lookupSeed32(seed, &nh[0], &h[0], &nh[1], &h[1]);
+        for (int d = 0; d < 2; d++) {
+            n_hits[2 * i + d] = nh[d];
+            _int64 lim = nh[d] < (_int64)max_hits_out ? nh[d] : (_int64)max_hits_out;
+            for (_int64 j = 0; j < lim; j++) {
+                hits[(size_t)(2 * i + d) * max_hits_out + j] = h[d][j];
+            }
+        }
+    }
+    return 0;
+}
+
+/*
+ * The reference's string kernels use unaligned 8-byte loads that run a few bytes past
+ * either string (harmless inside SNAP because of genome padding and read buffers).  To call
+ * them on arbitrary test strings we copy each problem into buffers with slack on both sides.
+ */
+static const int SLACK = 64;
+
+struct PaddedProblem {
+    std::vector<char> tbuf, pbuf, qbuf;
+    const char *text;
+    const char *pattern;
+    const char *quality;
+    void set(int dir, const char *t, int tlen, const char *p, const char *q, int plen) {
+        int tl = tlen > 0 ? tlen : 0;
+        tbuf.assign(tl + 2 * SLACK, 'n');
+        if (dir == 1) {
+            memcpy(&tbuf[SLACK], t, tl);
+            text = &tbuf[SLACK];
+        } else {
+            // bytes t[-tlen .. -1] are the text, travelled backwards
+            memcpy(&tbuf[SLACK], t - tl, tl);
+            text = &tbuf[SLACK] + tl;
+        }
+        pbuf.assign(plen + 2 * SLACK, 'N' + 1);   // a byte that matches nothing in the text slack
+        memcpy(&pbuf[SLACK], p, plen);
+        pattern = &pbuf[SLACK];
+        qbuf.assign(plen + 2 * SLACK, '!');
+        if (q) memcpy(&qbuf[SLACK], q, plen);
+        quality = &qbuf[SLACK];
+    }
+};
+
+int snapref_landau_vishkin(int dir, uint32_t n,
+                           const char *texts, const uint32_t *text_off, const int32_t *text_len,
+                           const char *patterns, const char *quals, const uint32_t *pat_off,
+                           const int32_t *pat_len, const int32_t *k,
+                           int32_t *score, double *match_probability, int32_t *net_indel,
+                           int32_t *total_indels, int32_t *text_span)
+{
+    snapref_init();
+    LandauVishkin<1> *fwd = new LandauVishkin<1>;
+    LandauVishkin<-1> *bwd = new LandauVishkin<-1>;
+    PaddedProblem pp;
+    for (uint32_t i = 0; i < n; i++) {
+        pp.set(dir, texts + text_off[i], text_len[i], patterns + pat_off[i], quals + pat_off[i], pat_len[i]);
+        double prob = 0; int ni = 0, ti = 0, ts = 0; int s;
+        if (dir == 1) {
+            s = fwd->computeEditDistance(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], k[i], &prob, &ni, &ti, &ts);
+        } else {
+            s = bwd->computeEditDistance(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], k[i], &prob, &ni, &ti, &ts);
+        }
+        score[i] = s; match_probability[i] = prob; net_indel[i] = ni; total_indels[i] = ti; text_span[i] = ts;
+    }
+    delete fwd;
+    delete bwd;
+    return 0;
+}
+
+struct AGParams { int match, sub, open, ext, five, three; };
+
+int snapref_affine_gap(int dir, uint32_t n, const int32_t *agparams /* match,sub,open,ext,5',3' */,
+                       const char *texts, const uint32_t *text_off, const int32_t *text_len,
+                       const char *patterns, const char *quals, const uint32_t *pat_off, const int32_t *pat_len,
+                       const int32_t *w, const int32_t *score_init, const uint8_t *is_rc,
+                       const uint8_t *banded, const uint8_t *use_clip,
+                       int32_t *ag_score, int32_t *text_offset, int32_t *pattern_offset,
+                       int32_t *n_edits, double *match_probability)
+{
+    snapref_init();
+    // 16-byte granularity exactly as SingleAligner.cpp:147 ("FIXME: Used larger allocation granularity for __m128i")
+    BigAllocator *alloc = new BigAllocator(AffineGapVectorized<1>::getBigAllocatorReservation() +
+                                           AffineGapVectorized<-1>::getBigAllocatorReservation() + 4096, 16);
+    AffineGapVectorized<1> *fwd = new (alloc) AffineGapVectorized<1>(agparams[0], agparams[1], agparams[2], agparams[3], agparams[4], agparams[5]);
+    AffineGapVectorized<-1> *bwd = new (alloc) AffineGapVectorized<-1>(agparams[0], agparams[1], agparams[2], agparams[3], agparams[4], agparams[5]);
+    PaddedProblem pp;
+    for (uint32_t i = 0; i < n; i++) {
+        pp.set(dir, texts + text_off[i], text_len[i], patterns + pat_off[i], quals + pat_off[i], pat_len[i]);
+        double prob = 0; int to = 0, po = 0, ne = 0; int s;
+        bool clip = use_clip && use_clip[i];
+        if (dir == 1) {
+            if (banded[i]) s = fwd->computeScoreBanded(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip);
+            else           s = fwd->computeScore(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip);
+        } else {
+            if (banded[i]) s = bwd->computeScoreBanded(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip);
+            else           s = bwd->computeScore(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip);
+        }
+        ag_score[i] = s; text_offset[i] = to; pattern_offset[i] = po; n_edits[i] = ne; match_probability[i] = prob;
+    }
+    fwd->~AffineGapVectorized();
+    bwd->~AffineGapVectorized();
+    delete alloc;
+    return 0;
+}
+
+static void fill_result(snapgpu_single_result *o, const SingleAlignmentResult *r)
+{
+    memset(o, 0, sizeof(*o));
+    o->status = (int32_t)r->status;
+    o->direction = (int32_t)r->direction;
+    o->location = (int64_t)GenomeLocationAsInt64(r->location);
+    o->orig_location = (int64_t)GenomeLocationAsInt64(r->origLocation);
+    o->score = r->score;
+    o->score_prior_to_clipping = r->scorePriorToClipping;
+    o->mapq = r->mapq;
+    o->clipping_for_read_adjustment = r->clippingForReadAdjustment;
+    o->used_affine_gap_scoring = r->usedAffineGapScoring ? 1 : 0;
+    o->bases_clipped_before = r->basesClippedBefore;
+    o->bases_clipped_after = r->basesClippedAfter;
+    o->ag_score = r->agScore;
+    o->supplementary = r->supplementary ? 1 : 0;
+    o->seed_offset = r->seedOffset;
+    o->match_probability = r->matchProbability;
+    o->probability_all_candidates = r->probabilityAllCandidates;
+    o->popular_seeds_skipped = r->popularSeedsSkipped;
+}
+
+struct AlignJob {
+    GenomeIndex *index;
+    const snapgpu_params *p;
+    uint32_t n;
+    const char *bases;
+    const char *quals;
+    const uint64_t *offsets;
+    snapgpu_single_result *primary;
+    snapgpu_single_result *first_alt;
+    volatile _int64 next;      // shared work cursor
+    uint32_t chunk;
+    // per-job counters, summed under lock
+    pthread_mutex_t lock;
+    _int64 lookups, lv, ag;
+};
+
+static void *align_thread(void *arg)
+{
+    AlignJob *job = (AlignJob *)arg;
+    const snapgpu_params *p = job->p;
+    GenomeIndex *index = job->index;
+    int maxReadSize = MAX_READ_LENGTH;
+
+    // mirror of SingleAligner.cpp:145-173
+    BigAllocator *allocator = new BigAllocator(
+        BaseAligner::getBigAllocatorReservation(index, true, p->max_hits, maxReadSize, index->getSeedLength(),
+                                                p->num_seeds, p->seed_coverage, -1, p->extra_search_depth) + 4096, 16);
+    BaseAligner *aligner = new (allocator) BaseAligner(
+        index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check,
+        p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0,
+        true /* ignoreAlignmentAdjustmentsForOm: the default, AlignerOptions.cpp:96 */,
+        p->alt_awareness != 0, p->emit_alt_alignments != 0, p->max_score_gap_to_prefer_non_alt,
+        -1 /* maxSecondaryAlignmentsPerContig */, NULL, NULL,
+        p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty,
+        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator);
+
+    // A read buffer with slack: the reference's LV over-reads a few bytes past the read.
+    std::vector<char> bbuf(MAX_READ_LENGTH + 2 * SLACK, 0), qbuf(MAX_READ_LENGTH + 2 * SLACK, 0);
+
+    for (;;) {
+        _int64 begin = __sync_fetch_and_add(&job->next, (_int64)job->chunk);
+        if (begin >= (_int64)job->n) break;
+        _int64 end = begin + job->chunk;
+        if (end > (_int64)job->n) end = job->n;
+        for (_int64 i = begin; i < end; i++) {
+            unsigned len = (unsigned)(job->offsets[i + 1] - job->offsets[i]);
+            memcpy(&bbuf[SLACK], job->bases + job->offsets[i], len);
+            memcpy(&qbuf[SLACK], job->quals + job->offsets[i], len);
+            Read read;
+            read.init("r", 1, &bbuf[SLACK], &qbuf[SLACK], len, NULL, 0);
+            SingleAlignmentResult r, alt;
+            memset(&r, 0, sizeof(r));
+            memset(&alt, 0, sizeof(alt));
+            alt.status = NotFound;
+            _int64 nSecondary = 0;
+            // same call shape as SingleAligner.cpp:250 with the default -om (none)
+            aligner->AlignRead(&read, &r, &alt, -1, 0, &nSecondary, 0, NULL, 0, NULL, NULL);
+            fill_result(&job->primary[i], &r);
+            if (job->first_alt) {
+                if (alt.status == NotFound) {
+                    memset(&job->first_alt[i], 0, sizeof(job->first_alt[i]));
+                    job->first_alt[i].status = NotFound;
+                } else {
+                    fill_result(&job->first_alt[i], &alt);
+                }
+            }
+        }
+    }
+
+    pthread_mutex_lock(&job->lock);
+    job->lookups += aligner->getNHashTableLookups();
+    job->lv += aligner->getLocationsScoredWithLandauVishkin();
+    job->ag += aligner->getLocationsScoredWithAffineGap();
+    pthread_mutex_unlock(&job->lock);
+
+    aligner->~BaseAligner();
+    delete allocator;
+    return NULL;
+}
+
+/* Returns 0; *seconds = wall time of the parallel align phase (index load excluded, as
+ * AlignerContext.cpp:420 measures it).  counters3 = {lookups, LV locations, AG locations}. */
+int snapref_align_single(void *vindex, const snapgpu_params *p, uint32_t n, const char *bases,
+                         const char *quals, const uint64_t *offsets, int n_threads,
+                         snapgpu_single_result *primary, snapgpu_single_result *first_alt,
+                         int64_t *counters3, double *seconds)
+{
+    snapref_init();
+    GenomeIndex *index = (GenomeIndex *)vindex;
+    if (index->doesGenomeIndexHave64BitLocations()) return SNAPGPU_E_UNSUPPORTED;
+    AlignJob job;
+    job.index = index; job.p = p; job.n = n; job.bases = bases; job.quals = quals; job.offsets = offsets;
+    job.primary = primary; job.first_alt = first_alt; job.next = 0; job.chunk = 256;
+    job.lookups = job.lv = job.ag = 0;
+    pthread_mutex_init(&job.lock, NULL);
+    if (n_threads < 1) n_threads = 1;
+
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    std::vector<pthread_t> th(n_threads);
+    for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, align_thread, &job);
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (seconds) *seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    if (counters3) { counters3[0] = job.lookups; counters3[1] = job.lv; counters3[2] = job.ag; }
+    pthread_mutex_destroy(&job.lock);
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,119 @@
+"""ctypes / numpy mirrors of the C-ABI structs declared in include/snapgpu.h."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+# snapgpu_single_result (POD mirror of SingleAlignmentResult, SNAPLib/AlignmentResult.h:48-76)
+RESULT_DTYPE = np.dtype([
+    ("status", np.int32),
+    ("direction", np.int32),
+    ("location", np.int64),
+    ("orig_location", np.int64),
+    ("score", np.int32),
+    ("score_prior_to_clipping", np.int32),
+    ("mapq", np.int32),
+    ("clipping_for_read_adjustment", np.int32),
+    ("used_affine_gap_scoring", np.int32),
+    ("bases_clipped_before", np.int32),
+    ("bases_clipped_after", np.int32),
+    ("ag_score", np.int32),
+    ("supplementary", np.int32),
+    ("seed_offset", np.int32),
+    ("match_probability", np.float64),
+    ("probability_all_candidates", np.float64),
+    ("popular_seeds_skipped", np.uint32),
+    ("reserved", np.uint32),
+], align=True)
+assert RESULT_DTYPE.itemsize == 88, RESULT_DTYPE.itemsize
+
+NOT_FOUND, SINGLE_HIT, MULTIPLE_HITS = 0, 1, 2
+SCORE_ABOVE_LIMIT = -1
+INVALID_GENOME_LOCATION_32 = 0xFFFFFFFF
+MAX_K = 127
+
+
+class IndexView(C.Structure):
+    _fields_ = [
+        ("seed_len", C.c_uint32),
+        ("key_bytes", C.c_uint32),
+        ("n_hash_tables", C.c_uint32),
+        ("large_hash_table", C.c_uint32),
+        ("location_size", C.c_uint32),
+        ("chromosome_padding", C.c_uint32),
+        ("overflow_table_size", C.c_uint64),
+        ("hash_blob", C.c_void_p),
+        ("hash_blob_bytes", C.c_uint64),
+        ("table_offset", C.c_void_p),
+        ("table_size", C.c_void_p),
+        ("overflow", C.c_void_p),
+        ("genome", C.c_void_p),
+        ("n_bases", C.c_uint64),
+        ("genome_pad", C.c_uint32),
+        ("contig_begin", C.c_void_p),
+        ("n_contigs", C.c_uint32),
+        ("first_alt_location", C.c_uint64),
+        ("on_device", C.c_uint32),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("max_hits", C.c_uint32),
+        ("max_k", C.c_uint32),
+        ("num_seeds", C.c_uint32),
+        ("seed_coverage", C.c_double),
+        ("min_weight_to_check", C.c_uint32),
+        ("extra_search_depth", C.c_uint32),
+        ("use_affine_gap", C.c_uint32),
+        ("match_reward", C.c_uint32),
+        ("sub_penalty", C.c_uint32),
+        ("gap_open_penalty", C.c_uint32),
+        ("gap_extend_penalty", C.c_uint32),
+        ("five_prime_end_bonus", C.c_uint32),
+        ("three_prime_end_bonus", C.c_uint32),
+        ("alt_awareness", C.c_uint32),
+        ("emit_alt_alignments", C.c_uint32),
+        ("max_score_gap_to_prefer_non_alt", C.c_int32),
+        ("max_read_len", C.c_uint32),
+    ]
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("n_reads", C.c_uint64),
+        ("n_hash_table_lookups", C.c_uint64),
+        ("n_hash_slots_probed", C.c_uint64),
+        ("n_hits_consumed", C.c_uint64),
+        ("n_overflow_lists", C.c_uint64),
+        ("n_lv_locations", C.c_uint64),
+        ("n_ag_locations", C.c_uint64),
+        ("n_lv_ref_bytes", C.c_uint64),
+        ("reserved", C.c_uint64 * 8),
+    ]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+def default_params(max_k: int = 27, max_read_len: int = 400, **overrides) -> Params:
+    """The reference's single-end defaults, AlignerOptions.cpp:39-117."""
+    p = Params(max_hits=300, max_k=max_k, num_seeds=25, seed_coverage=0.0, min_weight_to_check=1,
+               extra_search_depth=1, use_affine_gap=1, match_reward=1, sub_penalty=4,
+               gap_open_penalty=6, gap_extend_penalty=1, five_prime_end_bonus=10,
+               three_prime_end_bonus=7, alt_awareness=1, emit_alt_alignments=0,
+               max_score_gap_to_prefer_non_alt=64, max_read_len=max_read_len)
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def ptr(a: np.ndarray):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,141 @@
+"""Loader for a SNAP index directory (the reference's on-disk format, unchanged).
+
+Mirrors GenomeIndex::loadFromDirectory (SNAPLib/GenomeIndex.cpp:1839-2093),
+Genome::loadFromFile (SNAPLib/Genome.cpp:277-438) and SNAPHashTable::loadCommon
+(SNAPLib/HashTable.cpp:98-175); layout summary in SURVEY.md Appendix B.
+
+The four files are parsed into flat numpy arrays that are handed to the C ABI as a
+`snapgpu_index_view`.  The hash-table slot bytes are kept exactly as the reference's index
+builder wrote them, so the device probe sequence is the reference's probe sequence.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+HASH_MAGIC = 0xB111B010  # SNAPLib/HashTable.cpp:343
+GENOME_PAD = 1024        # >= Genome::N_PADDING (1000), SNAPLib/Genome.h:446; keeps 16-byte alignment
+
+
+@dataclass
+class Contig:
+    begin: int
+    is_alt: bool
+    original_number: int
+    name: str
+
+
+@dataclass
+class GenomeIndex:
+    """Host-side image of a SNAP index (32-bit locations only in this build)."""
+    seed_len: int
+    key_bytes: int
+    n_hash_tables: int
+    large: bool
+    location_size: int
+    chromosome_padding: int
+    overflow: np.ndarray              # uint32[overflow_table_size]
+    hash_blob: np.ndarray             # uint8[...] concatenated slot arrays (headers stripped)
+    table_offset: np.ndarray          # uint64[n_hash_tables] byte offsets into hash_blob
+    table_size: np.ndarray            # uint64[n_hash_tables] slots
+    genome_padded: np.ndarray         # uint8[GENOME_PAD + n_bases + GENOME_PAD], 'n' padded
+    n_bases: int
+    contigs: list = field(default_factory=list)
+    directory: str = ""
+
+    @property
+    def entry_bytes(self) -> int:
+        return 4 * (2 if self.large else 1) + self.key_bytes
+
+    @property
+    def genome(self) -> np.ndarray:
+        return self.genome_padded[GENOME_PAD:GENOME_PAD + self.n_bases]
+
+    @property
+    def contig_begin(self) -> np.ndarray:
+        return np.array([c.begin for c in self.contigs], dtype=np.uint64)
+
+    @property
+    def first_alt_location(self) -> int:
+        # Genome::sortContigsByName, SNAPLib/Genome.cpp:462-476
+        alts = [c.begin for c in self.contigs if c.is_alt]
+        return min(alts) if alts else (1 << 62)
+
+    def nbytes(self) -> int:
+        return self.overflow.nbytes + self.hash_blob.nbytes + self.genome_padded.nbytes
+
+    @staticmethod
+    def load_from_directory(directory: str) -> "GenomeIndex":
+        with open(os.path.join(directory, "GenomeIndex"), "rb") as f:
+            fields = f.read().split()
+        if len(fields) < 10:
+            raise ValueError("GenomeIndex header has %d fields, expected 10" % len(fields))
+        (major, minor, n_tables, overflow_size, seed_len, padding, key_bytes,
+         hash_file_size, small, location_size) = [int(x) for x in fields[:10]]
+        if major != 7:
+            raise ValueError("index major version %d != 7 (GenomeIndex.h:170)" % major)
+        if location_size != 4:
+            raise NotImplementedError(
+                "index has %d-byte genome locations; this build implements the 32-bit lookup "
+                "path (seed >= 20, GenomeIndex.cpp:446-453) only" % location_size)
+
+        # --- Genome ---------------------------------------------------------------
+        with open(os.path.join(directory, "Genome"), "rb") as f:
+            hdr = f.readline().split()
+            n_bases, n_contigs = int(hdr[0]), int(hdr[1])
+            contigs = []
+            for _ in range(n_contigs):
+                line = f.readline().rstrip(b"\n")
+                parts = line.split(b" ", 7)
+                begin = int(parts[0]); flags = int(parts[1], 16); orig = int(parts[2])
+                name_len = int(parts[5])
+                name = parts[7][:name_len].decode()
+                contigs.append(Contig(begin, bool(flags & 1), orig, name))
+            genome_padded = np.full(n_bases + 2 * GENOME_PAD, ord("n"), dtype=np.uint8)
+            got = f.readinto(memoryview(genome_padded)[GENOME_PAD:GENOME_PAD + n_bases])
+            if got != n_bases:
+                raise ValueError("Genome file truncated: %d of %d bases" % (got, n_bases))
+
+        # --- OverflowTable --------------------------------------------------------
+        overflow = np.fromfile(os.path.join(directory, "OverflowTable"), dtype=np.uint32)
+        if overflow.size != overflow_size:
+            raise ValueError("OverflowTable has %d words, header says %d" % (overflow.size, overflow_size))
+        if overflow.size == 0:
+            overflow = np.zeros(1, dtype=np.uint32)   # keep a valid pointer
+
+        # --- GenomeIndexHash ------------------------------------------------------
+        raw = np.fromfile(os.path.join(directory, "GenomeIndexHash"), dtype=np.uint8)
+        value_count = 1 if small else 2
+        entry = 4 * value_count + key_bytes
+        offs = np.zeros(n_tables, dtype=np.uint64)
+        sizes = np.zeros(n_tables, dtype=np.uint64)
+        pieces = []
+        pos = 0
+        out_pos = 0
+        for t in range(n_tables):
+            magic = int(raw[pos:pos + 4].view(np.uint32)[0])
+            if magic != HASH_MAGIC:
+                raise ValueError("hash table %d: bad magic %#x" % (t, magic))
+            table_size = int(raw[pos + 4:pos + 12].view(np.uint64)[0])
+            ks, vs, vc = [int(x) for x in raw[pos + 20:pos + 32].view(np.uint32)]
+            if ks != key_bytes or vs != 4 or vc != value_count:
+                raise ValueError("hash table %d: key/value sizes %d/%d/%d do not match header" % (t, ks, vs, vc))
+            pos += 32 + vs                          # header + invalidValue
+            nbytes = table_size * entry
+            pieces.append(raw[pos:pos + nbytes])
+            offs[t] = out_pos
+            sizes[t] = table_size
+            pos += nbytes
+            out_pos += nbytes
+        if pos != raw.size:
+            raise ValueError("GenomeIndexHash: %d trailing bytes" % (raw.size - pos))
+        # 16 bytes of slack so that 8-byte device loads of the last slot stay in bounds
+        hash_blob = np.concatenate(pieces + [np.zeros(16, dtype=np.uint8)])
+
+        return GenomeIndex(seed_len=seed_len, key_bytes=key_bytes, n_hash_tables=n_tables,
+                           large=not small, location_size=location_size,
+                           chromosome_padding=padding, overflow=overflow, hash_blob=hash_blob,
+                           table_offset=offs, table_size=sizes, genome_padded=genome_padded,
+                           n_bases=n_bases, contigs=contigs, directory=directory)
