@@ -161,3 +161,10 @@ def compute_mapq(p_all: float, p_best: float, score: int, popular_skipped: int) 
 
 def wrapped_next_seed(seed_len: int, wrap_count: int) -> int:
     return int(lib().snapref_wrapped_next_seed(C.c_uint(seed_len), C.c_uint(wrap_count)))
+
+
+def seed_prob(seed_len: int) -> float:
+    f = lib().snapref_seed_prob
+    f.restype = C.c_double
+    f.argtypes = [C.c_int]
+    return float(f(seed_len))

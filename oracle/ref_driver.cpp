@@ -95,6 +95,12 @@ int snapref_compute_mapq(double pAll, double pBest, int score, int popularSeedsS
     return computeMAPQ(pAll, pBest, score, popularSeedsSkipped);
 }
 
+/* pow(1 - SNP_PROB, seedLen) exactly as BaseAligner.cpp:1314 evaluates it (int seedLen, C++98 overloads) */
+double snapref_seed_prob(int seedLen)
+{
+    return pow(1 - SNP_PROB, seedLen);
+}
+
 unsigned snapref_wrapped_next_seed(unsigned seedLen, unsigned wrapCount)
 {
     snapref_init();

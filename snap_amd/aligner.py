@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference's interface for the hot path, over the C ABI.
+
+Class / method names follow the reference (SNAPLib/BaseAligner.h:44-90, GenomeIndex.h:33-80,
+LandauVishkin.h:100): `BaseAligner.AlignRead` here takes a *batch* of reads because a GPU
+aligner is fed batches, but argument meaning, result fields (SingleAlignmentResult) and error
+behaviour follow the reference.  All computation happens in libsnapgpu.so (HIP, gfx950);
+there is no CPU path -- if the library or a GPU is missing, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .abi import (Counters, IndexView, Params, RESULT_DTYPE, default_params, ptr)
+from .index import GENOME_PAD, GenomeIndex
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnapgpu.so")
+
+_lib = None
+
+
+class SnapGpuError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libsnapgpu.so (built by __graft_entry__.build()); fails loudly if missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SnapGpuError("%s not built: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        lib.snapgpu_last_error.restype = C.c_char_p
+        lib.snapgpu_last_error.argtypes = [C.c_void_p]
+        lib.snapgpu_create.argtypes = [C.POINTER(IndexView), C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
+        lib.snapgpu_destroy.argtypes = [C.c_void_p]
+        lib.snapgpu_destroy.restype = None
+        lib.snapgpu_align_single_device.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        _lib = lib
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "snapgpu_abi_version", "snapgpu_last_error", "snapgpu_default_params", "snapgpu_create",
+    "snapgpu_destroy", "snapgpu_index_device_ptrs", "snapgpu_lookup_seeds",
+    "snapgpu_landau_vishkin", "snapgpu_affine_gap", "snapgpu_align_single",
+    "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
+]
+
+
+def _pack(strings):
+    lens = np.array([len(s) for s in strings], dtype=np.int32)
+    offs = np.zeros(len(strings), dtype=np.uint32)
+    if len(strings):
+        offs[1:] = np.cumsum(lens[:-1])
+    buf = np.frombuffer(b"".join(strings) + b"\0" * 16, dtype=np.uint8).copy()
+    return buf, offs, lens
+
+
+class BaseAligner:
+    """One aligner context on one GPU (the analogue of one BaseAligner per CPU thread)."""
+
+    def __init__(self, index: GenomeIndex, params: Params | None = None, device: int = 0,
+                 device_index_ptrs=None):
+        self.lib = load_library()
+        self.index = index
+        self.params = params if params is not None else default_params()
+        self._keep = []
+        v = IndexView()
+        v.seed_len = index.seed_len
+        v.key_bytes = index.key_bytes
+        v.n_hash_tables = index.n_hash_tables
+        v.large_hash_table = 1 if index.large else 0
+        v.location_size = index.location_size
+        v.chromosome_padding = index.chromosome_padding
+        v.overflow_table_size = index.overflow.size
+        v.hash_blob_bytes = index.hash_blob.size
+        toff = np.ascontiguousarray(index.table_offset, dtype=np.uint64)
+        tsz = np.ascontiguousarray(index.table_size, dtype=np.uint64)
+        cb = np.ascontiguousarray(index.contig_begin, dtype=np.uint64)
+        self._keep += [toff, tsz, cb]
+        v.table_offset = toff.ctypes.data
+        v.table_size = tsz.ctypes.data
+        v.contig_begin = cb.ctypes.data
+        v.n_contigs = len(index.contigs)
+        v.n_bases = index.n_bases
+        v.genome_pad = GENOME_PAD
+        v.first_alt_location = index.first_alt_location
+        if device_index_ptrs is None:
+            v.hash_blob = index.hash_blob.ctypes.data
+            v.overflow = index.overflow.ctypes.data
+            v.genome = index.genome_padded.ctypes.data + GENOME_PAD
+            v.on_device = 0
+        else:                                   # (hash, overflow, genome_padded) device addresses
+            v.hash_blob, v.overflow = int(device_index_ptrs[0]), int(device_index_ptrs[1])
+            v.genome = int(device_index_ptrs[2]) + GENOME_PAD
+            v.on_device = 1
+        handle = C.c_void_p()
+        rc = self.lib.snapgpu_create(C.byref(v), C.byref(self.params), device, C.byref(handle))
+        if rc != 0:
+            raise SnapGpuError("snapgpu_create failed (%d): %s" % (rc, self.lib.snapgpu_last_error(None).decode()))
+        self.handle = handle
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.snapgpu_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise SnapGpuError("%s failed (%d): %s" % (what, rc, self.lib.snapgpu_last_error(self.handle).decode()))
+
+    # ---- GenomeIndex::lookupSeed32 ------------------------------------------------------
+    def lookupSeed32(self, seeds: np.ndarray, max_hits_out: int = 512):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint8)
+        n = seeds.shape[0]
+        n_hits = np.zeros((n, 2), dtype=np.int64)
+        hits = np.zeros((n, 2, max_hits_out), dtype=np.uint32)
+        self._check(self.lib.snapgpu_lookup_seeds(self.handle, C.c_uint32(n), ptr(seeds), ptr(n_hits), ptr(hits),
+                                                  C.c_uint32(max_hits_out)), "snapgpu_lookup_seeds")
+        return n_hits, hits
+
+    # ---- LandauVishkin<dir>::computeEditDistance ---------------------------------------
+    def computeEditDistance(self, direction: int, texts, patterns, quals, k):
+        n = len(texts)
+        tbuf, toff, tlen = _pack(texts)
+        if direction == -1:
+            toff = (toff + tlen.astype(np.uint32)).astype(np.uint32)
+        pbuf, poff, plen = _pack(patterns)
+        qbuf, _, _ = _pack(quals)
+        k = np.ascontiguousarray(k, dtype=np.int32)
+        score = np.zeros(n, np.int32); prob = np.zeros(n, np.float64)
+        net = np.zeros(n, np.int32); tot = np.zeros(n, np.int32); span = np.zeros(n, np.int32)
+        self._check(self.lib.snapgpu_landau_vishkin(
+            self.handle, C.c_int(direction), C.c_uint32(n), ptr(tbuf), C.c_uint64(tbuf.size), ptr(toff), ptr(tlen),
+            ptr(pbuf), ptr(qbuf), C.c_uint64(pbuf.size), ptr(poff), ptr(plen), ptr(k),
+            ptr(score), ptr(prob), ptr(net), ptr(tot), ptr(span)), "snapgpu_landau_vishkin")
+        return dict(score=score, match_probability=prob, net_indel=net, total_indels=tot, text_span=span)
+
+    # ---- AffineGapVectorized<dir>::computeScore[Banded] --------------------------------
+    def computeScoreAffine(self, direction: int, texts, patterns, quals, w, score_init, is_rc, banded, use_clip=None):
+        n = len(texts)
+        tbuf, toff, tlen = _pack(texts)
+        if direction == -1:
+            toff = (toff + tlen.astype(np.uint32)).astype(np.uint32)
+        pbuf, poff, plen = _pack(patterns)
+        qbuf, _, _ = _pack(quals)
+        w = np.ascontiguousarray(w, dtype=np.int32)
+        score_init = np.ascontiguousarray(score_init, dtype=np.int32)
+        is_rc = np.ascontiguousarray(is_rc, dtype=np.uint8)
+        banded = np.ascontiguousarray(banded, dtype=np.uint8)
+        use_clip = np.zeros(n, np.uint8) if use_clip is None else np.ascontiguousarray(use_clip, dtype=np.uint8)
+        ag = np.zeros(n, np.int32); to = np.zeros(n, np.int32); po = np.zeros(n, np.int32)
+        ne = np.zeros(n, np.int32); prob = np.zeros(n, np.float64)
+        self._check(self.lib.snapgpu_affine_gap(
+            self.handle, C.c_int(direction), C.c_uint32(n), ptr(tbuf), C.c_uint64(tbuf.size), ptr(toff), ptr(tlen),
+            ptr(pbuf), ptr(qbuf), C.c_uint64(pbuf.size), ptr(poff), ptr(plen), ptr(w), ptr(score_init),
+            ptr(is_rc), ptr(banded), ptr(use_clip), ptr(ag), ptr(to), ptr(po), ptr(ne), ptr(prob)), "snapgpu_affine_gap")
+        return dict(ag_score=ag, text_offset=to, pattern_offset=po, n_edits=ne, match_probability=prob)
+
+    # ---- BaseAligner::AlignRead over a batch -------------------------------------------
+    def AlignRead(self, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray):
+        """Returns (primaryResult[n], firstALTResult[n]) as RESULT_DTYPE arrays."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        primary = np.zeros(n, dtype=RESULT_DTYPE)
+        first_alt = np.zeros(n, dtype=RESULT_DTYPE)
+        self._check(self.lib.snapgpu_align_single(self.handle, C.c_uint32(n), ptr(bases), ptr(quals), ptr(offsets),
+                                                  ptr(primary), ptr(first_alt)), "snapgpu_align_single")
+        return primary, first_alt
+
+    def align_device(self, n: int, d_bases: int, d_quals: int, d_offsets: int, d_primary: int, d_first_alt: int = 0,
+                     stream: int = 0):
+        """Device-pointer form (inputs already in HBM, results left in HBM)."""
+        self._check(self.lib.snapgpu_align_single_device(self.handle, C.c_uint32(n), C.c_void_p(d_bases),
+                                                         C.c_void_p(d_quals), C.c_void_p(d_offsets), C.c_void_p(d_primary),
+                                                         C.c_void_p(d_first_alt) if d_first_alt else None,
+                                                         C.c_void_p(stream) if stream else None),
+                    "snapgpu_align_single_device")
+
+    def counters(self, reset: bool = False) -> dict:
+        c = Counters()
+        self._check(self.lib.snapgpu_get_counters(self.handle, C.byref(c), C.c_int(1 if reset else 0)), "snapgpu_get_counters")
+        return c.as_dict()
+
+    def kernel_time(self, reset: bool = False):
+        ms = C.c_double(0); nl = C.c_uint64(0)
+        self._check(self.lib.snapgpu_kernel_time(self.handle, C.byref(ms), C.byref(nl), C.c_int(1 if reset else 0)),
+                    "snapgpu_kernel_time")
+        return ms.value, int(nl.value)
+
+    def device_index_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self.lib.snapgpu_index_device_ptrs(self.handle, C.byref(a), C.byref(b), C.byref(c)),
+                    "snapgpu_index_device_ptrs")
+        return a.value, b.value, c.value
+
+    def debug_tables(self):
+        phred = np.zeros(256); indel = np.zeros(1001); perfect = np.zeros(1001)
+        sp = C.c_double(0); thr = np.zeros(72); wrapped = np.zeros(33, dtype=np.uint32)
+        self._check(self.lib.snapgpu_debug_tables(self.handle, ptr(phred), ptr(indel), C.c_uint32(1001), ptr(perfect),
+                                                  C.c_uint32(1001), C.byref(sp), ptr(thr), ptr(wrapped)), "snapgpu_debug_tables")
+        return dict(phred=phred, indel=indel, perfect=perfect, seed_prob=sp.value, mapq_threshold=thr, wrapped=wrapped)

@@ -1,0 +1,751 @@
+// align_single.h -- BaseAligner::AlignRead for one read per wavefront.
+//
+// Restates (file:line in the reference tree):
+//   BaseAligner::AlignRead                 SNAPLib/BaseAligner.cpp:273-763   adaptive seed loop
+//   BaseAligner::score                     SNAPLib/BaseAligner.cpp:918-1534  ordered candidate scoring
+//   ScoreSet::updateBestScore & friends    SNAPLib/BaseAligner.cpp:2132-2323
+//   findElement/findCandidate/allocateNewCandidate/incrementWeight/clearCandidates
+//                                          SNAPLib/BaseAligner.cpp:1811-1973, 2332-2379
+//   scoreLimit                             SNAPLib/BaseAligner.cpp:2556-2570
+//   Genome::getSubstring / isGenomeLocationALT / getContigAtLocation
+//                                          SNAPLib/Genome.h:339-367, 436; Genome.cpp:574-602
+//   computeMAPQ                            SNAPLib/mapq.h:31-68
+// (exact semantics that matter for bit-identical results are collected in SURVEY.md App. A.1-A.3)
+//
+// The algorithm is adaptive and sequential per read (which seed is looked up next, which
+// candidate is scored next and with what limit all depend on earlier scores), so one
+// wavefront owns one read and executes the control flow wave-uniformly, the way one CPU
+// thread owns one BaseAligner in the reference.  The 64 lanes are used inside the
+// primitives: 2x32 lanes walk the two hash-probe sequences, 64 lanes fetch an overflow list
+// line-coalesced, lanes are LV diagonals / affine-gap SSE lanes, and the reference window is
+// staged once per candidate into LDS with one coalesced load.
+//
+// Per-read state lives in LDS (read, its reverse complement, qualities, seed-used bitmap,
+// weight-list heads, LV triangle, reference window).  The candidate table -- a few hundred
+// bytes per 48-base bucket, up to max_hits*max_seeds buckets -- lives in a per-wave slab of
+// HBM scratch that stays L2-resident; it is indexed by a small open hash (u16 heads) that is
+// un-done bucket by bucket at the end of each read instead of the reference's epoch trick.
+#pragma once
+#include "dev_common.h"
+#include "probe.h"
+#include "lv.h"
+#include "ag.h"
+#include "../../include/snapgpu.h"
+
+#define BUCKET 48                      // hashTableElementSize == maxMergeDist, BaseAligner.h:177,213
+#define SENT_MIN 0xFC00u               // link values >= SENT_MIN denote weight-list sentinels
+#define WIN_PAD 128                    // reference bytes staged on either side of [loc, loc+readLen)
+
+struct AlignCfg {
+    uint32_t max_hits, max_k, num_seeds, min_weight, extra_depth, use_ag;
+    int32_t  match_reward, sub_penalty, gap_open, gap_extend, five_bonus, three_bonus;
+    uint32_t alt_aware, emit_alt;
+    int32_t  max_gap_alt;
+    double   seed_coverage;
+    uint32_t num_weight_lists;         // ctor: maxSeedsToUse + 1, BaseAligner.cpp:173-180
+    uint32_t RL;                       // per-wave read buffer length (max_read_len rounded up to 16)
+    uint32_t kmax;                     // largest score limit: min(126, max_k + extra_depth)
+    uint32_t pool_size;                // candidate buckets per wave
+    uint32_t ht_size;                  // power of two, u16 heads
+    uint64_t scratch_stride;           // bytes of HBM scratch per wave
+    uint32_t lds_per_wave;
+    uint32_t ag_numvec_max;            // ceil(RL/8)
+};
+
+struct __attribute__((aligned(16))) Elem {   // HashTableElement, BaseAligner.h:223-258
+    uint64_t used;                     // candidatesUsed
+    uint64_t scored;                   // candidatesScored
+    int64_t  base;                     // baseGenomeLocation
+    int64_t  best_loc;                 // bestScoreGenomeLocation
+    double   match_prob;               // matchProbabilityForBestScore
+    uint32_t weight;
+    uint32_t lps;                      // lowestPossibleScore
+    uint32_t best_score;               // unsigned, may hold (unsigned)ScoreAboveLimit
+    int32_t  ag_score;
+    int32_t  clip_before, clip_after, seed_offset;
+    uint16_t wnext, wprev, hnext;
+    uint8_t  dir;
+    uint8_t  flags;                    // bit0 allExtantCandidatesScored, bit1 usedAffineGapScoring
+    uint32_t pad0;
+    uint16_t cand_seed_offset[BUCKET]; // Candidate::seedOffset
+};
+static_assert(sizeof(Elem) == 176, "Elem layout");
+
+struct ScoreSet {                      // BaseAligner.h:260-329
+    int32_t  best_score;
+    int64_t  best_loc, best_orig_loc;
+    int32_t  dir;
+    int32_t  used_ag, clip_before, clip_after, ag_score, seed_offset;
+    double   best_match_prob;
+    double   p_all, p_best;
+    __device__ __forceinline__ void init() {
+        best_score = SNAPGPU_UnusedScoreValue; best_loc = SNAPGPU_InvalidGenomeLocation32;
+        best_orig_loc = SNAPGPU_InvalidGenomeLocation32; dir = 0; used_ag = 0; clip_before = 0;
+        clip_after = 0; ag_score = -1; seed_offset = 0; best_match_prob = 0.0; p_all = 0.0; p_best = 0.0;
+    }
+};
+
+struct WaveCounters {
+    uint64_t lookups, slots, hits, overflow_lists, lv, ag, lv_ref_bytes;
+};
+
+// computeMAPQ (mapq.h:31-68) with the log10 replaced by a threshold table built from the
+// host's log10 at context creation (DevTables::mapq_threshold), so (int)(-10*log10(x)) is
+// reproduced exactly.
+static __device__ __forceinline__ int compute_mapq(const DevTables *tab, double p_all, double p_best, int popular_skipped) {
+    if (p_all < p_best) p_all = p_best;
+    double correctness = p_best / p_all;
+    int base_mapq;
+    if (correctness >= 1) {
+        base_mapq = 70;
+    } else {
+        double x = 1 - correctness;
+        // largest m in [0,70] with x <= threshold[m]; thresholds are decreasing in m
+        int lo = 0, hi = 70;
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if (x <= tab->mapq_threshold[mid]) lo = mid; else hi = mid - 1;
+        }
+        base_mapq = lo;
+    }
+    int pen = popular_skipped - 10; if (pen < 0) pen = 0;
+    base_mapq -= pen / 2;
+    if (base_mapq < 0) base_mapq = 0;
+    return base_mapq;
+}
+
+struct Aligner {
+    // ---- constant for the launch
+    const DevIndex &ix;
+    const DevTables *tab;
+    const AlignCfg &cfg;
+    // ---- LDS carve-out for this wave
+    uint8_t  *rd[2];        // bases, forward / reverse complement
+    uint8_t  *ql[2];        // qualities in the same orientation
+    uint8_t  *gw;           // reference window: gw[x] = genome[win_loc - WIN_PAD + x]
+    uint32_t *seed_used;
+    uint16_t *wl_next, *wl_prev;
+    uint16_t *lv_tri;
+    // ---- HBM scratch for this wave
+    uint16_t *heads;
+    Elem     *pool;
+    uint8_t  *ag_scratch;
+    // ---- per-read state (wave-uniform)
+    int lane;
+    int read_len;
+    uint32_t n_used;
+    uint32_t highest_used_weight_list;
+    uint32_t wrap_count;
+    uint32_t lps_unseen[2];            // lowestPossibleScoreOfAnyUnseenLocation
+    uint32_t cur_round_lps[2];         // currRoundLowestPossibleScoreOfAnyUnseenLocation
+    uint32_t n_seeds_applied[2];
+    uint32_t popular_seeds_skipped;
+    ScoreSet all, non_alt;
+    snapgpu_single_result primary, first_alt;
+    WaveCounters cnt;
+
+    __device__ __forceinline__ Aligner(const DevIndex &ix_, const DevTables *tab_, const AlignCfg &cfg_)
+        : ix(ix_), tab(tab_), cfg(cfg_) {}
+
+    // ------------------------------------------------------------------ helpers
+    __device__ __forceinline__ bool is_alt(int64_t loc) const { return (uint64_t)loc >= ix.first_alt_location && loc >= 0; }
+
+    __device__ __forceinline__ int score_limit(bool for_alt) const {          // BaseAligner.cpp:2556-2570
+        int64_t inner;
+        if (for_alt) {
+            int64_t g = cfg.max_gap_alt < non_alt.best_score ? cfg.max_gap_alt : non_alt.best_score;
+            int64_t b = (int64_t)non_alt.best_score - g;
+            inner = all.best_score < b ? all.best_score : b;
+        } else {
+            int64_t a = (int64_t)all.best_score + cfg.max_gap_alt;
+            inner = a < non_alt.best_score ? a : non_alt.best_score;
+        }
+        int64_t m = (int64_t)cfg.max_k < inner ? (int64_t)cfg.max_k : inner;
+        int64_t v = (int64_t)cfg.extra_depth + m;
+        return (int)(v < 126 ? v : 126);
+    }
+
+    // Genome::getSubstring(location, lengthNeeded) != NULL  (Genome.h:339-367)
+    __device__ __forceinline__ bool substring_ok(int64_t loc, int64_t len) const {
+        int64_t nb = (int64_t)ix.n_bases;
+        if (loc > nb || loc + len > nb + 1000) return false;
+        if (loc < -(int64_t)ix.genome_pad) return false;                      // (cannot happen; keeps loads in bounds)
+        if (len <= (int64_t)ix.chromosome_padding && first_u32(ix.genome[loc]) != 'n') return true;
+        if (len == 0) return true;
+        // getContigAtLocation: last contig whose beginning <= loc
+        int lo = 0, hi = (int)ix.n_contigs - 1, found = -1;
+        while (lo <= hi) {
+            int mid = (lo + hi) >> 1;
+            uint64_t b = first_u64(ix.contig_begin[mid]);
+            if ((int64_t)b <= loc) { found = mid; lo = mid + 1; } else { hi = mid - 1; }
+        }
+        if (found < 0) return false;
+        int64_t cbeg = (int64_t)first_u64(ix.contig_begin[found]);
+        int64_t cend = found == (int)ix.n_contigs - 1 ? nb : (int64_t)first_u64(ix.contig_begin[found + 1]);
+        if (cend <= loc + len) return false;
+        (void)cbeg;
+        return true;
+    }
+
+    // ---- weight lists: doubly linked, FIFO, sentinel per weight (BaseAligner.cpp:1954-1957, 2366-2378)
+    __device__ __forceinline__ uint16_t sent(uint32_t w) const { return (uint16_t)(0xFFFFu - w); }
+    __device__ __forceinline__ uint16_t get_next(uint16_t i) const {
+        return i >= SENT_MIN ? wl_next[0xFFFFu - i] : (uint16_t)first_u32(pool[i].wnext);
+    }
+    __device__ __forceinline__ uint16_t get_prev(uint16_t i) const {
+        return i >= SENT_MIN ? wl_prev[0xFFFFu - i] : (uint16_t)first_u32(pool[i].wprev);
+    }
+    __device__ __forceinline__ void set_next(uint16_t i, uint16_t v) {
+        if (lane == 0) { if (i >= SENT_MIN) wl_next[0xFFFFu - i] = v; else pool[i].wnext = v; }
+        WAVE_SYNC();
+    }
+    __device__ __forceinline__ void set_prev(uint16_t i, uint16_t v) {
+        if (lane == 0) { if (i >= SENT_MIN) wl_prev[0xFFFFu - i] = v; else pool[i].wprev = v; }
+        WAVE_SYNC();
+    }
+    __device__ __forceinline__ void list_unlink(uint16_t e) {
+        uint16_t n = get_next(e), p = get_prev(e);
+        set_prev(n, p);
+        set_next(p, n);
+    }
+    __device__ __forceinline__ void list_push_tail(uint32_t w, uint16_t e) {
+        uint16_t s = sent(w);
+        uint16_t tail = get_prev(s);
+        if (lane == 0) { pool[e].wnext = s; pool[e].wprev = tail; }
+        WAVE_SYNC();
+        set_prev(s, e);
+        set_next(tail, e);
+    }
+
+    // ---- candidate hash: (bucket base, direction) -> element index
+    __device__ __forceinline__ uint32_t head_slot(int64_t base, int dir) const {
+        uint64_t k = ((uint64_t)base / BUCKET) * 2 + (uint64_t)dir;
+        k *= 0x9E3779B97F4A7C15ull;
+        return (uint32_t)(k >> 40) & (cfg.ht_size - 1);
+    }
+    // findElement (BaseAligner.cpp:1811-1840): returns element index or 0xFFFF
+    __device__ __forceinline__ uint16_t find_element(int64_t loc, int dir) const {
+        int64_t low = (int64_t)((uint64_t)loc % BUCKET);
+        int64_t base = loc - low;
+        uint16_t h = (uint16_t)first_u32(heads[head_slot(base, dir)]);
+        while (h != 0) {
+            const Elem *e = &pool[h - 1];
+            int64_t b = (int64_t)first_u64((uint64_t)e->base);
+            uint32_t d = first_u32(e->dir);
+            if (b == base && (int)d == dir) return (uint16_t)(h - 1);
+            h = (uint16_t)first_u32(e->hnext);
+        }
+        return 0xFFFF;
+    }
+
+    // ------------------------------------------------------------------ per read
+    __device__ __forceinline__ void clear_candidates() {                     // BaseAligner.cpp:2332-2339
+        n_used = 0;
+        highest_used_weight_list = 0;
+        for (uint32_t i = lane; i < cfg.num_weight_lists; i += WAVE) {
+            wl_next[i] = sent(i); wl_prev[i] = sent(i);
+        }
+        WAVE_SYNC();
+    }
+
+    // undo the head-table entries of this read (lane-parallel)
+    __device__ __forceinline__ void release_candidates() {
+        for (uint32_t i = lane; i < n_used; i += WAVE) {
+            heads[head_slot(pool[i].base, pool[i].dir)] = 0;
+        }
+        WAVE_SYNC();
+    }
+
+    __device__ __forceinline__ void increment_weight(uint16_t ei) {          // BaseAligner.cpp:2342-2379
+        Elem *e = &pool[ei];
+        uint32_t flags = first_u32(e->flags);
+        if (flags & 1) return;
+        uint32_t w = first_u32(e->weight);
+        if (w >= cfg.num_weight_lists - 1) return;
+        list_unlink(ei);
+        w++;
+        if (lane == 0) e->weight = w;
+        WAVE_SYNC();
+        if (w > highest_used_weight_list) highest_used_weight_list = w;
+        list_push_tail(w, ei);
+    }
+
+    __device__ __forceinline__ void allocate_new_candidate(int64_t loc, int dir, uint32_t lps, int seed_offset) {
+        // BaseAligner.cpp:1885-1973
+        int64_t low = (int64_t)((uint64_t)loc % BUCKET);
+        int64_t base = loc - low;
+        uint16_t ei = (uint16_t)n_used;
+        n_used++;
+        Elem *e = &pool[ei];
+        uint32_t hs = head_slot(base, dir);
+        uint16_t old_head = (uint16_t)first_u32(heads[hs]);
+        if (lane == 0) {
+            e->used = 1ull << low;
+            e->scored = 0;
+            e->lps = lps;
+            e->dir = (uint8_t)dir;
+            e->weight = 1;
+            e->base = base;
+            e->best_score = SNAPGPU_UnusedScoreValue;
+            e->flags = 0;
+            e->match_prob = 0;
+            e->clip_before = 0; e->clip_after = 0; e->ag_score = 0;
+            e->best_loc = 0; e->seed_offset = 0;
+            e->cand_seed_offset[low] = (uint16_t)seed_offset;
+            e->hnext = old_head;
+            heads[hs] = (uint16_t)(ei + 1);
+        }
+        WAVE_SYNC();
+        list_push_tail(1, ei);
+        if (highest_used_weight_list < 1) highest_used_weight_list = 1;
+    }
+
+    // One hit of a seed lookup (body of the loop at BaseAligner.cpp:629-667).
+    __device__ __forceinline__ void apply_hit(uint32_t hit, uint32_t offset, int dir) {
+        int64_t loc = (int64_t)(uint32_t)(hit - offset);                      // unsigned 32-bit arithmetic, :637
+        uint16_t ei = find_element(loc, dir);
+        if (ei != 0xFFFF) {
+            // findCandidate (:1873-1878) + :648-652
+            Elem *e = &pool[ei];
+            uint32_t low = (uint32_t)((uint64_t)loc % BUCKET);
+            uint64_t bit = 1ull << low;
+            uint64_t used = first_u64(e->used);
+            uint32_t flags = first_u32(e->flags);
+            uint32_t new_flags = (flags & ~1u) | (((flags & 1u) && (used & bit)) ? 1u : 0u);
+            if (lane == 0) {
+                e->flags = (uint8_t)new_flags;
+                e->used = used | bit;
+                e->cand_seed_offset[low] = (uint16_t)offset;
+            }
+            WAVE_SYNC();
+            increment_weight(ei);
+        } else {
+            bool cand_alt = cfg.alt_aware && is_alt(loc);
+            if ((int64_t)lps_unseen[dir] <= (int64_t)score_limit(cand_alt)) {
+                allocate_new_candidate(loc, dir, lps_unseen[dir], (int)offset);
+            }
+        }
+    }
+
+    // ScoreSet::updateBestScore without secondary / AG-candidate buffers (BaseAligner.cpp:2143-2299)
+    __device__ __forceinline__ bool update_best(ScoreSet &ss, int64_t loc, int64_t orig_loc, uint32_t score,
+                                                int ag_score, double mp, const Elem *e, int e_dir,
+                                                int e_used_ag, int e_clip_before, int e_clip_after, int e_seed_offset,
+                                                double e_match_prob) {
+        bool seen_new;
+        if (cfg.use_ag) {
+            seen_new = (ag_score > ss.ag_score) || (ss.ag_score == ag_score && mp > ss.p_best);
+        } else {
+            seen_new = (score < (uint32_t)ss.best_score) || (score == (uint32_t)ss.best_score && mp > ss.p_best);
+        }
+        if (seen_new) {
+            ss.best_score = (int32_t)score;
+            ss.ag_score = ag_score;
+            ss.p_best = mp;
+            ss.best_loc = loc;
+            ss.best_orig_loc = orig_loc;
+            ss.dir = e_dir;
+            ss.used_ag = e_used_ag;
+            ss.clip_before = e_clip_before;
+            ss.clip_after = e_clip_after;
+            ss.seed_offset = e_seed_offset;
+            ss.best_match_prob = e_match_prob;
+        }
+        (void)e;
+        return seen_new;
+    }
+
+    __device__ __forceinline__ void fill_result(const ScoreSet &ss, snapgpu_single_result &r) const {  // :2301-2323
+        r.ag_score = ss.ag_score;
+        r.bases_clipped_after = ss.clip_after;
+        r.bases_clipped_before = ss.clip_before;
+        r.clipping_for_read_adjustment = 0;
+        r.direction = ss.dir;
+        r.location = ss.best_loc;
+        r.orig_location = ss.best_orig_loc;
+        r.mapq = compute_mapq(tab, ss.p_all, ss.p_best, (int)popular_seeds_skipped);
+        r.score = ss.best_score;
+        r.used_affine_gap_scoring = ss.used_ag;
+        r.seed_offset = ss.seed_offset;
+        r.match_probability = ss.best_match_prob;
+        r.popular_seeds_skipped = popular_seeds_skipped;
+        r.status = r.mapq >= 10 ? SNAPGPU_SingleHit : SNAPGPU_MultipleHits;       // MAPQ_LIMIT_FOR_SINGLE_HIT
+        r.probability_all_candidates = ss.p_all;
+    }
+
+    // stage genome[loc - WIN_PAD, loc + read_len + WIN_PAD) into LDS with coalesced loads
+    __device__ __forceinline__ void stage_window(int64_t loc) {
+        const int total = read_len + 2 * WIN_PAD;
+        const uint8_t *src = ix.genome + (loc - WIN_PAD);
+        // 4 bytes per lane where the source is 4-byte aligned; byte loads at the ragged ends
+        uintptr_t a = (uintptr_t)src;
+        int head = (int)((4 - (a & 3)) & 3);
+        if (head > total) head = total;
+        if (lane < head) gw[lane] = src[lane];
+        int words = (total - head) >> 2;
+        const uint32_t *s32 = (const uint32_t *)(src + head);
+        for (int w = lane; w < words; w += WAVE) {
+            uint32_t v = s32[w];
+            uint8_t *d = gw + head + 4 * w;
+            d[0] = (uint8_t)v; d[1] = (uint8_t)(v >> 8); d[2] = (uint8_t)(v >> 16); d[3] = (uint8_t)(v >> 24);
+        }
+        int done = head + 4 * words;
+        if (done + lane < total) gw[done + lane] = src[done + lane];
+        WAVE_SYNC();
+    }
+
+    // ------------------------------------------------------------------ score()  (BaseAligner.cpp:918-1534)
+    // returns true when a final answer has been written to `primary`
+    __device__ __forceinline__ bool score(bool force_result) {
+        for (int dir = 0; dir < 2; dir++) {                                   // :995-1007 (EXACT_DISJOINT_MISS_COUNT)
+            if (cur_round_lps[dir] > lps_unseen[dir]) lps_unseen[dir] = cur_round_lps[dir];
+        }
+        uint32_t wl = highest_used_weight_list;
+        do {
+            while (wl > 0 && get_next(sent(wl)) == sent(wl)) {
+                wl--;
+                highest_used_weight_list = wl;
+            }
+            int lim_t = score_limit(true), lim_f = score_limit(false);
+            int lim_max = lim_t > lim_f ? lim_t : lim_f;
+            uint32_t lps_min = lps_unseen[0] < lps_unseen[1] ? lps_unseen[0] : lps_unseen[1];
+            if ((int64_t)lps_min > (int64_t)lim_max || force_result) {
+                if (wl < cfg.min_weight) {
+                    // :1034-1056
+                    const ScoreSet *fin;
+                    first_alt.status = SNAPGPU_NotFound;
+                    if (!cfg.alt_aware || non_alt.best_score > all.best_score + cfg.max_gap_alt) {
+                        fin = &all;
+                    } else {
+                        fin = &non_alt;
+                        if (cfg.emit_alt && all.best_score <= non_alt.best_score && all.best_loc != non_alt.best_loc) {
+                            fill_result(all, first_alt);
+                        }
+                    }
+                    primary.score = fin->best_score;
+                    if ((uint32_t)fin->best_score <= cfg.max_k) {
+                        fill_result(*fin, primary);
+                        primary.supplementary = 0;
+                    } else {
+                        primary.status = SNAPGPU_NotFound;
+                        primary.mapq = 0;
+                    }
+                    return true;
+                }
+                force_result = true;
+            } else if (wl == 0) {
+                return false;
+            }
+
+            uint16_t ei = get_next(sent(wl));
+            Elem *e = &pool[ei];
+            int64_t e_base = (int64_t)first_u64((uint64_t)e->base);
+            int e_dir = (int)first_u32(e->dir);
+            uint32_t e_lps = first_u32(e->lps);
+            int limit_e = score_limit(cfg.alt_aware && is_alt(e_base));      // :1084
+            if ((int64_t)e_lps <= (int64_t)limit_e) {
+                uint64_t mask = first_u64(e->used);                           // snapshot, :1088
+                while (mask) {
+                    int idx = __ffsll((long long)mask) - 1;
+                    uint64_t bit = 1ull << idx;
+                    mask &= ~bit;
+                    uint64_t scored = first_u64(e->scored);
+                    if (scored & bit) continue;
+                    bool any_nearby = scored != 0;
+                    if (lane == 0) e->scored = scored | bit;
+                    WAVE_SYNC();
+
+                    int64_t loc = e_base + idx;
+                    const int64_t orig_loc = loc, elem_loc = loc;
+                    bool loc_non_alt = !cfg.alt_aware || !is_alt(loc);
+
+                    uint32_t sc = (uint32_t)SNAPGPU_ScoreAboveLimit;
+                    double mp = 0.0;
+                    const int64_t glen = (int64_t)read_len + SNAPGPU_MAX_K;
+                    int used_ag = 0, clip_before = 0, clip_after = 0, ag_score = -1;
+                    int cand_seed_offset = (int)first_u32(e->cand_seed_offset[idx]);
+
+                    if (substring_ok(loc, glen)) {
+                        stage_window(loc);
+                        const uint8_t *data = gw + WIN_PAD;                   // data[i] = genome[loc + i]
+                        const int seed_len = (int)ix.seed_len;
+                        const int seed_offset = cand_seed_offset;
+                        const int tail_start = seed_offset + seed_len;
+                        int ag1 = seed_len, ag2 = 0;
+                        int score1 = 0, score2 = 0;
+                        double mp1 = 1.0, mp2 = 1.0;
+                        int loc_offset = 0;
+                        const int text_len = read_len + SNAPGPU_MAX_K - tail_start;
+
+                        // forward from the end of the seed (:1160)
+                        {
+                            ByteSeq P{rd[e_dir] + tail_start, 1}, Q{ql[e_dir] + tail_start, 1}, T{data + tail_start, 1};
+                            LVResult r1 = lv_compute(P, Q, read_len - tail_start, T, text_len, limit_e, lv_tri, cfg.kmax, tab);
+                            score1 = r1.score; mp1 = r1.match_probability;
+                            cnt.lv_ref_bytes += (uint64_t)(read_len - tail_start) + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e));
+                        }
+                        ag1 = (seed_len + read_len - tail_start - score1) * cfg.match_reward - score1 * cfg.sub_penalty;
+                        if (score1 != -1) {
+                            // backwards from the start of the seed over the reversed head of the read (:1169)
+                            int limit_left = limit_e - score1;
+                            ByteSeq P{rd[e_dir] + seed_offset - 1, -1}, Q{ql[e_dir] + seed_offset - 1, -1}, T{data + seed_offset - 1, -1};
+                            LVResult r2 = lv_compute(P, Q, seed_offset, T, seed_offset + SNAPGPU_MAX_K, limit_left, lv_tri, cfg.kmax, tab);
+                            score2 = r2.score; mp2 = r2.match_probability; loc_offset = r2.net_indel;
+                            ag2 = (seed_offset - score2) * cfg.match_reward - score2 * cfg.sub_penalty;
+                            cnt.lv_ref_bytes += (uint64_t)seed_offset;
+                        }
+                        cnt.lv++;
+
+                        if (score1 != -1 && score2 != -1) {
+                            int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);     // :1148
+                            if (cfg.use_ag && (score1 + score2 > max_k_same && e_lps <= (uint32_t)all.best_score)) {   // :1203
+                                score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0;
+                                used_ag = 1;
+                                cnt.ag++;
+                                AGParams agp{cfg.match_reward, cfg.sub_penalty, cfg.gap_open, cfg.gap_extend, cfg.five_bonus, cfg.three_bonus};
+                                if (tail_start != read_len) {
+                                    int pat_len = read_len - tail_start;
+                                    bool banded = pat_len >= 3 * (2 * limit_e + 1);
+                                    ByteSeq P{rd[e_dir] + tail_start, 1}, Q{ql[e_dir] + tail_start, 1}, T{data + tail_start, 1};
+                                    AGResult a1 = ag_compute(banded, 1, agp, P, Q, pat_len, T, text_len, limit_e, read_len, e_dir != 0,
+                                                             false, ag_scratch, cfg.ag_numvec_max, tab);
+                                    ag1 = a1.ag_score; clip_after = a1.pattern_offset; score1 = a1.n_edits; mp1 = a1.match_probability;
+                                    ag1 += (seed_len - read_len);
+                                }
+                                if (score1 != -1) {
+                                    if (seed_offset != 0) {
+                                        int limit_left = limit_e - score1;
+                                        bool banded = seed_offset >= 3 * (2 * limit_left + 1);
+                                        ByteSeq P{rd[e_dir] + seed_offset - 1, -1}, Q{ql[e_dir] + seed_offset - 1, -1}, T{data + seed_offset - 1, -1};
+                                        AGResult a2 = ag_compute(banded, -1, agp, P, Q, seed_offset, T, seed_offset + limit_left, limit_left, read_len,
+                                                                 e_dir != 0, false, ag_scratch, cfg.ag_numvec_max, tab);
+                                        ag2 = a2.ag_score; clip_before = a2.pattern_offset; score2 = a2.n_edits; mp2 = a2.match_probability;
+                                        loc_offset = a2.text_offset;
+                                        ag2 -= read_len;
+                                    }
+                                }
+                            }
+                        }
+
+                        bool found = (score1 != -1 && score2 != -1);
+                        if (found && loc_offset != 0 && !substring_ok(loc + loc_offset, glen)) found = false;   // :1295-1301
+                        if (found) {
+                            sc = (uint32_t)(score1 + score2);
+                            mp = mp1 * mp2 * tab->seed_prob;                  // :1314
+                            loc += loc_offset;
+                            ag_score = ag1 + ag2;
+                        } else {
+                            sc = (uint32_t)SNAPGPU_ScoreAboveLimit;
+                            ag_score = SNAPGPU_ScoreAboveLimit;
+                            mp = 0.0;
+                        }
+                    } else {
+                        mp = 0.0;
+                    }
+
+                    // ---- bookkeeping after scoring one candidate (:1349-1519)
+                    uint32_t e_best = first_u32(e->best_score);
+                    double e_mp = first_f64(e->match_prob);
+                    if (any_nearby) {
+                        if (e_best < sc || (e_best == sc && mp <= e_mp)) continue;            // :1366
+                    }
+                    const uint32_t e_flags = first_u32(e->flags);
+                    if (lane == 0) {
+                        e->best_loc = loc;
+                        e->flags = (uint8_t)((e_flags & 1u) | (used_ag ? 2u : 0u));
+                        e->clip_before = clip_before;
+                        e->clip_after = clip_after;
+                        e->ag_score = ag_score;
+                        e->seed_offset = cand_seed_offset;
+                    }
+                    WAVE_SYNC();
+
+                    // nearby bucket (the other half-bucket neighbour), :1396-1435
+                    uint16_t ni = 0xFFFF;
+                    if ((uint32_t)SNAPGPU_ScoreAboveLimit != sc && sc < 2) {
+                        int64_t half = (int64_t)(((uint64_t)elem_loc % BUCKET) / (BUCKET / 2));
+                        int64_t nearby_loc = elem_loc + (2 * half - 1) * (BUCKET / 2);
+                        ni = find_element(nearby_loc, e_dir);
+                    }
+                    if (ni != 0xFFFF) {
+                        Elem *ne = &pool[ni];
+                        uint64_t n_scored = first_u64(ne->scored);
+                        if (n_scored != 0) {
+                            int64_t n_best_loc = (int64_t)first_u64((uint64_t)ne->best_loc);
+                            int64_t dist = loc > n_best_loc ? loc - n_best_loc : n_best_loc - loc;
+                            if (dist <= BUCKET) {                                             // genomeLocationIsWithin(..., maxMergeDist)
+                                uint32_t n_best = first_u32(ne->best_score);
+                                double n_mp = first_f64(ne->match_prob);
+                                if (n_best < sc || (n_best == sc && n_mp >= mp)) continue;   // :1421
+                                double v = all.p_all - n_mp; all.p_all = v > 0.0 ? v : 0.0;    // updateProbabilitiesForNearbyMatch
+                                if (loc_non_alt) { double u = non_alt.p_all - n_mp; non_alt.p_all = u > 0.0 ? u : 0.0; }
+                                any_nearby = true;
+                                if (lane == 0) ne->match_prob = 0;
+                                WAVE_SYNC();
+                            }
+                        }
+                    }
+
+                    // updateProbabilitiesForNewMatch (:2137-2141): two separate FP64 operations
+                    {
+                        double v = all.p_all - e_mp; v = v > 0.0 ? v : 0.0; all.p_all = v + mp;
+                        if (loc_non_alt) { double u = non_alt.p_all - e_mp; u = u > 0.0 ? u : 0.0; non_alt.p_all = u + mp; }
+                    }
+                    if (lane == 0) { e->match_prob = mp; e->best_score = sc; }
+                    WAVE_SYNC();
+
+                    update_best(all, loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
+                    if (loc_non_alt) {
+                        update_best(non_alt, loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
+                    }
+
+                    // early out: nothing can rescue MAPQ once the candidates' total probability reaches 4.9 (:1512)
+                    double p_chk = cfg.alt_aware ? non_alt.p_all : all.p_all;
+                    if (p_chk >= 4.9) {
+                        fill_result(cfg.alt_aware ? non_alt : all, primary);
+                        first_alt.status = SNAPGPU_NotFound;
+                        return true;
+                    }
+                }
+            }
+
+            // remove the element from its weight list (:1526-1529)
+            {
+                const uint32_t fl = first_u32(e->flags);
+                if (lane == 0) e->flags = (uint8_t)(fl | 1u);
+                WAVE_SYNC();
+            }
+            list_unlink(ei);
+            if (lane == 0) { e->wnext = ei; e->wprev = ei; }
+            WAVE_SYNC();
+        } while (force_result);
+        return false;
+    }
+
+    // ------------------------------------------------------------------ AlignRead (BaseAligner.cpp:273-763)
+    __device__ __forceinline__ void seed_set_used(uint32_t i) {
+        if (lane == 0) seed_used[i >> 5] |= (1u << (i & 31));
+        WAVE_SYNC();
+    }
+    __device__ __forceinline__ bool seed_is_used(uint32_t i) const { return (seed_used[i >> 5] >> (i & 31)) & 1u; }
+
+    __device__ __forceinline__ void align_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
+        read_len = len;
+        // result = NotFound (:334-344); remaining fields as a zero-initialised struct
+        primary.status = SNAPGPU_NotFound; primary.direction = 0;
+        primary.location = SNAPGPU_InvalidGenomeLocation32; primary.orig_location = 0;
+        primary.score = SNAPGPU_UnusedScoreValue; primary.score_prior_to_clipping = 0; primary.mapq = 0;
+        primary.clipping_for_read_adjustment = 0; primary.used_affine_gap_scoring = 0;
+        primary.bases_clipped_before = 0; primary.bases_clipped_after = 0; primary.ag_score = 0;
+        primary.supplementary = 0; primary.seed_offset = 0; primary.match_probability = 0.0;
+        primary.probability_all_candidates = 0.0; primary.popular_seeds_skipped = 0; primary.reserved = 0;
+        first_alt = primary;
+        first_alt.location = 0; first_alt.score = 0;
+
+        const int seed_len = (int)ix.seed_len;
+        if (len < seed_len || len > (int)cfg.RL) return;                      // :360 (too long is rejected on the host)
+
+        // load the read, build the reverse complement (:388-396)
+        uint32_t n_count = 0;
+        for (int i0 = 0; i0 < len; i0 += WAVE) {
+            int i = i0 + lane;
+            uint8_t b = 0, q = 0;
+            if (i < len) {
+                b = g_bases[i]; q = g_quals[i];
+                rd[0][i] = b; ql[0][i] = q;
+                rd[1][len - 1 - i] = rc_base(b);
+                ql[1][len - 1 - i] = q;
+            }
+            n_count += (uint32_t)__popcll(__ballot(i < len && b == 'N'));
+        }
+        for (uint32_t i = lane; i < (cfg.RL + 31) / 32; i += WAVE) seed_used[i] = 0;
+        WAVE_SYNC();
+        if (n_count > cfg.max_k) return;                                      // :398
+
+        if (n_count > 0) {                                                    // :407-420 block seeds containing a non-ACGT base
+            int min_seed = 0;
+            for (int i = 0; i < len; i++) {
+                if (base_value(rd[0][i]) > 3) {
+                    int limit = i + seed_len - 1 < len - 1 ? i + seed_len - 1 : len - 1;
+                    int j0 = i - seed_len + 1; if (j0 < min_seed) j0 = min_seed;
+                    for (int j = j0; j <= limit; j++) seed_set_used((uint32_t)j);
+                    min_seed = limit + 1;
+                    if (min_seed >= len) break;
+                }
+            }
+        }
+
+        uint32_t max_seeds_to_use = cfg.num_seeds != 0 ? cfg.num_seeds
+                                  : (uint32_t)(int)(2 * cfg.seed_coverage * len / seed_len);    // :327-332
+        clear_candidates();
+        const uint32_t n_possible_seeds = (uint32_t)(len - seed_len + 1);
+        uint32_t next_seed = 0;
+        wrap_count = 0;
+        lps_unseen[0] = lps_unseen[1] = 0;
+        cur_round_lps[0] = cur_round_lps[1] = 0;
+        all.init();
+        non_alt.init();
+        if (!cfg.alt_aware) non_alt.best_score = SNAPGPU_TooBigScoreValue;    // :325 (never re-initialised without ALT awareness)
+        n_seeds_applied[0] = n_seeds_applied[1] = 0;
+        popular_seeds_skipped = 0;
+        bool finished = false;
+
+        while (n_seeds_applied[0] + n_seeds_applied[1] < max_seeds_to_use) {
+            if (next_seed >= n_possible_seeds) {                              // wrapping, :455-504
+                wrap_count++;
+                if (wrap_count >= (uint32_t)seed_len) {
+                    score(true);
+                    finished = true;
+                    break;
+                }
+                next_seed = tab->wrapped_seed[wrap_count];
+                cur_round_lps[0] = cur_round_lps[1] = 0;
+            }
+            while (next_seed < n_possible_seeds && seed_is_used(next_seed)) next_seed++;
+            if (next_seed >= n_possible_seeds) continue;
+            seed_set_used(next_seed);
+
+            SeedBits seed = pack_seed(rd[0] + next_seed, (uint32_t)seed_len);
+            if (!seed.valid) continue;                                        // :524
+
+            HitList hl[2];
+            lookup_seed(ix, seed, hl);
+            cnt.lookups++;
+            cnt.slots += hl[0].slots + hl[1].slots;
+
+            bool applied_either = false;
+            for (int dir = 0; dir < 2; dir++) {
+                if (hl[dir].n_hits > (int64_t)cfg.max_hits) {                 // too popular, :574-579
+                    popular_seeds_skipped++;
+                } else {
+                    uint32_t offset = dir == 0 ? next_seed : (uint32_t)(len - seed_len) - next_seed;   // :591-606
+                    int64_t limit = hl[dir].n_hits;
+                    if (limit > 1) cnt.overflow_lists++;
+                    cnt.hits += (uint64_t)limit;
+                    for (int64_t c0 = 0; c0 < limit; c0 += WAVE) {
+                        // one coalesced load of up to 64 hits, then consume them in stored order
+                        uint32_t mine = 0;
+                        int64_t i = c0 + lane;
+                        if (i < limit) mine = (hl[dir].n_hits == 1) ? hl[dir].singleton : hl[dir].hits[i];
+                        int n = (int)(limit - c0 < WAVE ? limit - c0 : WAVE);
+                        for (int j = 0; j < n; j++) {
+                            uint32_t h = first_u32((uint32_t)__shfl((int)mine, j));
+                            apply_hit(h, offset, dir);
+                        }
+                    }
+                    n_seeds_applied[dir]++;
+                    cur_round_lps[dir]++;
+                    applied_either = true;
+                }
+            }
+            next_seed += (uint32_t)seed_len;                                  // :676
+
+            if (applied_either) {
+                if (score(false)) { finished = true; break; }
+            }
+        }
+        if (!finished) score(true);                                           // :734
+        primary.score_prior_to_clipping = primary.score;                      // finalizeSecondaryResults, :2442
+        release_candidates();
+    }
+};

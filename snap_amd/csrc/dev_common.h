@@ -1,0 +1,85 @@
+// dev_common.h -- device-side structs and wave helpers shared by the gfx950 kernels.
+//
+// Execution model used throughout: one wavefront (64 lanes) owns one unit of work (one
+// read, one LV problem, ...).  Control flow is wave-uniform; lanes cooperate inside the
+// primitives (hash-slot probing, hit-list loads, LV diagonals, affine-gap SSE-lane
+// emulation).  State that the reference keeps in its per-thread aligner object lives in
+// LDS (hot) or in a per-wave slab of HBM scratch (large, L2-resident).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+
+// LLVM's gfx9 memory model executes one wavefront's memory operations in order, so a
+// wavefront-scope fence costs no instructions; it only stops the compiler from moving
+// accesses across the point where one lane's store is consumed by the other lanes.
+#define WAVE_SYNC()                                                   \
+    do {                                                              \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        \
+        __builtin_amdgcn_wave_barrier();                              \
+    } while (0)
+
+// Index blobs resident in HBM (see DESIGN.md "Data layout in HBM").
+struct DevIndex {
+    const uint8_t  *hash_blob;      // concatenated slot arrays, reference byte layout
+    const uint64_t *table_offset;   // [n_hash_tables] byte offset of table t
+    const uint64_t *table_size;     // [n_hash_tables] slots in table t
+    const uint32_t *overflow;       // overflow table: [count][loc0 > loc1 > ...]*
+    const uint8_t  *genome;         // base 0; genome_pad bytes of 'n' readable on both sides
+    const uint64_t *contig_begin;   // [n_contigs]
+    uint64_t n_bases;
+    uint64_t overflow_size;
+    uint64_t first_alt_location;
+    uint32_t n_contigs;
+    uint32_t seed_len;
+    uint32_t key_bytes;
+    uint32_t entry_bytes;           // 4*value_count + key_bytes
+    uint32_t large;                 // 1: entry carries {fwd value, rc value}
+    uint32_t n_hash_tables;
+    uint32_t chromosome_padding;
+    uint32_t genome_pad;
+};
+
+// Probability tables, computed on the host with host libm (LandauVishkin.cpp:716-763,
+// mapq.h:31-68) and uploaded, so that every FP64 value the kernels multiply is the value
+// the reference multiplies.
+#define N_INDEL_PROB   2048
+#define N_PERFECT_PROB 1001
+struct DevTables {
+    double phred[256];               // lv_phredToProbability
+    double indel[N_INDEL_PROB];      // lv_indelProbabilities
+    double perfect[N_PERFECT_PROB];  // lv_perfectMatchProbability
+    double mapq_threshold[72];       // x <= mapq_threshold[m]  <=>  (int)(-10*log10(x)) >= m  (host log10)
+    double seed_prob;                // pow(1 - SNP_PROB, seedLen), BaseAligner.cpp:1314
+    uint32_t wrapped_seed[33];       // GetWrappedNextSeedToTest(seedLen, wrapCount), SeedSequencer.cpp:36-109
+};
+
+static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
+
+static __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src_lane = 0) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, src_lane);
+}
+static __device__ __forceinline__ int bcast_i32(int v, int src_lane = 0) {
+    return __builtin_amdgcn_readlane(v, src_lane);
+}
+static __device__ __forceinline__ uint32_t first_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+static __device__ __forceinline__ uint64_t first_u64(uint64_t v) {
+    uint32_t lo = first_u32((uint32_t)v), hi = first_u32((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+static __device__ __forceinline__ double first_f64(double v) {
+    return __longlong_as_double((long long)first_u64((uint64_t)__double_as_longlong(v)));
+}
+
+// A0 G1 C2 T3, everything else 4 (Tables.cpp:52-58).
+static __device__ __forceinline__ uint32_t base_value(uint8_t c) {
+    return c == 'A' ? 0u : c == 'G' ? 1u : c == 'C' ? 2u : c == 'T' ? 3u : 4u;
+}
+// rcTranslationTable of BaseAligner.cpp:199-210: ACGT complemented, everything else 'N'.
+static __device__ __forceinline__ uint8_t rc_base(uint8_t c) {
+    return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+}

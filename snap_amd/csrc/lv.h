@@ -1,0 +1,188 @@
+// lv.h -- Landau-Vishkin edit distance with match probability, one problem per wavefront.
+//
+// Restates LandauVishkin<TEXT_DIRECTION>::computeEditDistance (SNAPLib/LandauVishkin.h:100-351)
+// and countPerfectMatch (:377-407); tie-breaking rules summarised in SURVEY.md Appendix A.3.
+//
+// GPU mapping: L[e][d] is the furthest-reaching pattern offset with e edits on diagonal d.
+// Lane r owns the diagonal with *iteration rank* r in the reference's visiting order
+// d = 0,+1,-1,+2,-2,... (rank(d) = 2d-1 for d>0, -2d otherwise), so "first diagonal in
+// visiting order that reaches the end" is simply the lowest set bit of a ballot.  All
+// 2e+1 diagonals of a level are extended concurrently; the level's results go to an LDS
+// triangle (row e starts at e*e) from which the next level and the backtrace read.
+// The text direction of the template parameter becomes an accessor stride, so the forward
+// (<1>) and backward (<-1>) variants are the same code.
+//
+// Outputs for e <= k do not depend on k (k only bounds the level loop), which is what lets
+// callers evaluate with one limit and threshold afterwards.
+#pragma once
+#include "dev_common.h"
+
+#define LV_ACT_X 0
+#define LV_ACT_D 1
+#define LV_ACT_I 2
+
+struct ByteSeq {                 // s(i) = p[i*stride]
+    const uint8_t *p;
+    int stride;
+    __device__ __forceinline__ uint8_t operator()(int i) const { return p[i * stride]; }
+};
+
+struct LVResult {
+    int    score;                // edit distance, or -1 (ScoreAboveLimit)
+    double match_probability;
+    int    net_indel;
+    int    total_indels;
+    int    text_span;
+};
+
+static __device__ __forceinline__ int lv_rank(int d) { return d > 0 ? 2 * d - 1 : -2 * d; }
+static __device__ __forceinline__ int lv_diag(int r) { return (r & 1) ? (r + 1) >> 1 : -(r >> 1); }
+
+// LDS needed: (kmax+1)^2 uint16 for L/A plus (kmax+1) uint32 for the backtrace.
+static __host__ __device__ __forceinline__ uint32_t lv_lds_bytes(uint32_t kmax) {
+    uint32_t tri = (kmax + 1) * (kmax + 1) * 2;
+    tri = (tri + 3) & ~3u;
+    return tri + (kmax + 1) * 4;
+}
+
+// cell = ((L + 2) << 2) | action ; unset cells read as L = -2
+static __device__ __forceinline__ uint16_t lv_pack(int L, int act) { return (uint16_t)(((L + 2) << 2) | act); }
+
+template <typename PSeq, typename TSeq, typename QSeq>
+static __device__ __forceinline__ LVResult lv_compute(
+    const PSeq &P, const QSeq &Q, int pattern_len, const TSeq &T, int text_len, int k,
+    uint16_t *lds_tri, uint32_t kmax, const DevTables *tab)
+{
+    const int lane = lane_id();
+    LVResult res;
+    res.score = -1; res.match_probability = 0.0; res.net_indel = 0; res.total_indels = 0; res.text_span = 0;
+    if (k < 0) return res;                                  // LandauVishkin.h:117
+    if (k > 126) k = 126;                                   // :142
+    if (k > (int)kmax) k = (int)kmax;
+    res.match_probability = 1.0;
+
+    uint32_t *bt = (uint32_t *)((uint8_t *)lds_tri + (((kmax + 1) * (kmax + 1) * 2 + 3) & ~3u));
+
+    // ---- e = 0: the perfect-match prefix, compared 64 bytes per step by the whole wave
+    const int end0 = pattern_len < text_len ? pattern_len : text_len;
+    int run0 = 0;
+    while (true) {
+        int i = run0 + lane;
+        bool same = (i < end0) && (P(i) == T(i));
+        uint64_t stopm = __ballot(!same);
+        if (stopm) { run0 += __ffsll((long long)stopm) - 1; break; }
+        run0 += WAVE;
+    }
+    if (run0 > end0) run0 = end0;
+    if (run0 == end0) {                                     // :170-185
+        int result = pattern_len > end0 ? pattern_len - end0 : 0;
+        res.match_probability = tab->perfect[pattern_len];
+        if (result > k) { res.score = -1; return res; }
+        res.text_span = pattern_len;
+        res.score = result;
+        return res;
+    }
+    if (lane == 0) lds_tri[0] = lv_pack(run0, LV_ACT_X);
+    WAVE_SYNC();
+
+    int last_best_rank = -1;
+    int e;
+    for (e = 1; e <= k; e++) {
+        const uint16_t *prev_row = lds_tri + (e - 1) * (e - 1);
+        uint16_t *row = lds_tri + e * e;
+        int x_rank = 1 << 30, any_rank = 1 << 30;
+        for (int r0 = 0; r0 <= 2 * e; r0 += WAVE) {
+            int r = r0 + lane;
+            bool live = r <= 2 * e;
+            int d = lv_diag(r);
+            bool reached = false; int act = LV_ACT_X;
+            if (live) {
+                int ad = d < 0 ? -d : d;
+                int Lc = (ad <= e - 1) ? ((int)(prev_row[lv_rank(d)] >> 2) - 2) : -2;
+                int dl = d - 1, dr = d + 1;
+                int adl = dl < 0 ? -dl : dl, adr = dr < 0 ? -dr : dr;
+                int Ll = (adl <= e - 1) ? ((int)(prev_row[lv_rank(dl)] >> 2) - 2) : -2;
+                int Lr = (adr <= e - 1) ? ((int)(prev_row[lv_rank(dr)] >> 2) - 2) : -2;
+                int tl = text_len - d;
+                const int end = pattern_len < tl ? pattern_len : tl;
+
+                int best = Lc + 1;                           // substitution ("up")
+                if (best >= 0) { while (best < end && P(best) == T(d + best)) best++; }
+                int left = Ll;                               // deletion
+                if (left >= 0) { while (left < end && P(left) == T(d + left)) left++; }
+                if (left > best) { best = left; act = LV_ACT_D; }
+                int right = Lr + 1;                          // insertion
+                if (right >= 0) { while (right < end && P(right) == T(d + right)) right++; }
+                if (right > best) { best = right; act = LV_ACT_I; }
+                reached = (best == pattern_len);
+                row[r] = lv_pack(best, act);
+            }
+            uint64_t mx = __ballot(reached && act == LV_ACT_X);
+            uint64_t ma = __ballot(reached);
+            if (mx && x_rank == (1 << 30)) x_rank = r0 + __ffsll((long long)mx) - 1;
+            if (ma && any_rank == (1 << 30)) any_rank = r0 + __ffsll((long long)ma) - 1;
+        }
+        WAVE_SYNC();
+        if (x_rank != (1 << 30)) { last_best_rank = x_rank; break; }       // :243-248 (goto got_answer)
+        if (any_rank != (1 << 30)) { last_best_rank = any_rank; break; }   // :253-264
+    }
+    if (last_best_rank < 0) { res.score = -1; return res; }                // :267-269 (probability stays 1.0)
+
+    // ---- backtrace (:286-304): uniform, every lane walks the same path
+    {
+        int cur_d = lv_diag(last_best_rank);
+        for (int cur_e = e; cur_e >= 1; cur_e--) {
+            uint16_t cell = lds_tri[cur_e * cur_e + lv_rank(cur_d)];
+            int act = cell & 3;
+            int Lcur = (int)(cell >> 2) - 2;
+            int pd = act == LV_ACT_I ? cur_d + 1 : act == LV_ACT_D ? cur_d - 1 : cur_d;
+            int apd = pd < 0 ? -pd : pd;
+            int Lprev = (apd <= cur_e - 1) ? ((int)(lds_tri[(cur_e - 1) * (cur_e - 1) + lv_rank(pd)] >> 2) - 2) : -2;
+            int matched = act == LV_ACT_D ? Lcur - Lprev : Lcur - Lprev - 1;
+            if (lane == 0) bt[cur_e] = ((uint32_t)(matched & 0xffff) << 2) | (uint32_t)act;
+            cur_d = pd;
+        }
+        WAVE_SYNC();
+    }
+
+    // ---- forward pass over the actions (:306-342): FP64 products in the reference's order
+    {
+        double prob = 1.0;
+        int net = 0, total = 0, span = 0;
+        int cur_e = 1;
+        int offset = run0;
+        while (cur_e <= e) {
+            uint32_t b = bt[cur_e];
+            int action = (int)(b & 3);
+            int matched = (int)(int16_t)(b >> 2);
+            int count = 1;
+            while (cur_e + 1 <= e && matched == 0 && (int)(bt[cur_e + 1] & 3) == action) {
+                count++;
+                cur_e++;
+                matched = (int)(int16_t)(bt[cur_e] >> 2);
+            }
+            if (action == LV_ACT_I) {
+                prob *= tab->indel[count];
+                offset += count; net += count; total += count;
+            } else if (action == LV_ACT_D) {
+                prob *= tab->indel[count];
+                offset -= count; net -= count; total += count; span += count;
+            } else {
+                for (int i = 0; i < count; i++) {
+                    int qi = offset < 0 ? 0 : offset;
+                    if (qi > pattern_len - 1) qi = pattern_len - 1;
+                    prob *= tab->phred[Q(qi)];
+                    offset++;
+                }
+            }
+            offset += matched;
+            cur_e++;
+        }
+        prob *= tab->perfect[pattern_len - e];
+        span += pattern_len;
+        res.match_probability = prob;
+        res.net_indel = net; res.total_indels = total; res.text_span = span;
+    }
+    res.score = e;
+    return res;
+}

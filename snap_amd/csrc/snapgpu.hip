@@ -1,0 +1,663 @@
+// snapgpu.hip -- gfx950 kernels and the C-ABI host side of libsnapgpu.so (include/snapgpu.h).
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared
+// There is deliberately no CPU fallback anywhere in this file: without a HIP device
+// snapgpu_create fails with SNAPGPU_E_NODEVICE.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include <deque>
+#include <mutex>
+
+#include "../../include/snapgpu.h"
+#include "dev_common.h"
+#include "probe.h"
+#include "lv.h"
+#include "ag.h"
+#include "align_single.h"
+
+// =====================================================================================
+// kernels
+// =====================================================================================
+
+struct AlignArgs {
+    DevIndex ix;
+    AlignCfg cfg;
+    const DevTables *tab;
+    uint8_t *scratch;                 // n_wave_slots * cfg.scratch_stride
+    const uint8_t *bases, *quals;
+    const uint64_t *offsets;
+    uint32_t n_reads;
+    snapgpu_single_result *primary, *first_alt;
+    uint32_t *work_counter;
+    unsigned long long *counters;     // snapgpu_counters layout
+};
+
+static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
+
+// LDS carve-out per wave; must match lds_bytes_per_wave() on the host.
+struct LdsLayout {
+    uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, total;
+};
+static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uint32_t num_weight_lists, uint32_t kmax) {
+    LdsLayout L; uint32_t o = 0;
+    L.rd0 = o; o += RL; L.rd1 = o; o += RL; L.ql0 = o; o += RL; L.ql1 = o; o += RL;
+    L.gw = o; o += (RL + 2 * WIN_PAD + 15) & ~15u;
+    L.seed_used = o; o += (((RL + 31) / 32) * 4 + 15) & ~15u;
+    L.wl_next = o; o += (num_weight_lists * 2 + 15) & ~15u;
+    L.wl_prev = o; o += (num_weight_lists * 2 + 15) & ~15u;
+    L.lv = o; o += (lv_lds_bytes(kmax) + 15) & ~15u;
+    L.total = o;
+    return L;
+}
+
+__global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    const int wave_in_block = (int)(threadIdx.x >> 6);
+    const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
+    const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax);
+    uint8_t *my = lds + (size_t)wave_in_block * L.total;
+
+    Aligner al(a.ix, a.tab, a.cfg);
+    al.lane = lane;
+    al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
+    al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
+    al.gw = my + L.gw;
+    al.seed_used = (uint32_t *)(my + L.seed_used);
+    al.wl_next = (uint16_t *)(my + L.wl_next);
+    al.wl_prev = (uint16_t *)(my + L.wl_prev);
+    al.lv_tri = (uint16_t *)(my + L.lv);
+    uint8_t *sc = a.scratch + (size_t)wave_slot * a.cfg.scratch_stride;
+    al.heads = (uint16_t *)sc;
+    al.pool = (Elem *)(sc + (size_t)a.cfg.ht_size * 2);
+    al.ag_scratch = sc + (size_t)a.cfg.ht_size * 2 + (size_t)a.cfg.pool_size * sizeof(Elem);
+    al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0};
+    uint64_t n_done = 0;
+
+    while (true) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
+        i = first_u32(i);
+        if (i >= a.n_reads) break;
+        uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
+        al.align_read(a.bases + b, a.quals + b, (int)(e - b));
+        if (lane == 0) {
+            a.primary[i] = al.primary;
+            if (a.first_alt) a.first_alt[i] = al.first_alt;
+        }
+        n_done++;
+    }
+    if (lane == 0) {
+        atomicAdd(&a.counters[0], (unsigned long long)n_done);
+        atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
+        atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
+        atomicAdd(&a.counters[3], (unsigned long long)al.cnt.hits);
+        atomicAdd(&a.counters[4], (unsigned long long)al.cnt.overflow_lists);
+        atomicAdd(&a.counters[5], (unsigned long long)al.cnt.lv);
+        atomicAdd(&a.counters[6], (unsigned long long)al.cnt.ag);
+        atomicAdd(&a.counters[7], (unsigned long long)al.cnt.lv_ref_bytes);
+    }
+}
+
+// One wave per seed: GenomeIndex::lookupSeed32 for a batch of seeds.
+__global__ __launch_bounds__(256) void k_lookup_seeds(DevIndex ix, uint32_t n, const uint8_t *seeds,
+                                                      long long *n_hits, uint32_t *hits, uint32_t max_hits_out)
+{
+    const int lane = lane_id();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < n; i += n_waves) {
+        SeedBits seed = pack_seed(seeds + (size_t)i * ix.seed_len, ix.seed_len);
+        if (!seed.valid) {
+            if (lane == 0) { n_hits[2 * i] = -1; n_hits[2 * i + 1] = -1; }
+            continue;
+        }
+        HitList hl[2];
+        lookup_seed(ix, seed, hl);
+        for (int d = 0; d < 2; d++) {
+            if (lane == 0) n_hits[2 * i + d] = hl[d].n_hits;
+            int64_t lim = hl[d].n_hits < (int64_t)max_hits_out ? hl[d].n_hits : (int64_t)max_hits_out;
+            uint32_t *dst = hits + (size_t)(2 * i + d) * max_hits_out;
+            for (int64_t j = lane; j < lim; j += WAVE) {
+                dst[j] = hl[d].n_hits == 1 ? hl[d].singleton : hl[d].hits[j];
+            }
+        }
+    }
+}
+
+struct LVBatchArgs {
+    int dir; uint32_t n; uint32_t kmax;
+    const uint8_t *texts; const uint32_t *text_off; const int32_t *text_len;
+    const uint8_t *patterns; const uint8_t *quals; const uint32_t *pat_off; const int32_t *pat_len; const int32_t *k;
+    int32_t *score; double *prob; int32_t *net_indel; int32_t *total_indels; int32_t *text_span;
+    const DevTables *tab;
+};
+
+// One wave per problem: LandauVishkin<dir>::computeEditDistance.
+__global__ __launch_bounds__(256) void k_lv_batch(LVBatchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    const int wave_in_block = (int)(threadIdx.x >> 6);
+    const uint32_t per_wave = (lv_lds_bytes(a.kmax) + 15) & ~15u;
+    uint16_t *tri = (uint16_t *)(lds + (size_t)wave_in_block * per_wave);
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < a.n; i += n_waves) {
+        int plen = a.pat_len[i], tlen = a.text_len[i], k = a.k[i];
+        const uint8_t *p = a.patterns + a.pat_off[i];
+        const uint8_t *q = a.quals + a.pat_off[i];
+        const uint8_t *t = a.texts + a.text_off[i];
+        LVResult r;
+        if (a.dir == 1) {
+            ByteSeq P{p, 1}, Q{q, 1}, T{t, 1};
+            r = lv_compute(P, Q, plen, T, tlen, k, tri, a.kmax, a.tab);
+        } else {
+            ByteSeq P{p, 1}, Q{q, 1}, T{t - 1, -1};     // the reference does text-- then walks backwards
+            r = lv_compute(P, Q, plen, T, tlen, k, tri, a.kmax, a.tab);
+        }
+        if (lane == 0) {
+            a.score[i] = r.score; a.prob[i] = r.match_probability; a.net_indel[i] = r.net_indel;
+            a.total_indels[i] = r.total_indels; a.text_span[i] = r.text_span;
+        }
+    }
+}
+
+// =====================================================================================
+// host side
+// =====================================================================================
+
+static thread_local std::string g_last_error;
+
+struct snapgpu_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    DevIndex ix{};
+    bool owns_index = true;
+    void *d_hash = nullptr, *d_overflow = nullptr, *d_genome_padded = nullptr;
+    void *d_table_offset = nullptr, *d_table_size = nullptr, *d_contig_begin = nullptr;
+    DevTables *d_tab = nullptr;
+    DevTables h_tab{};
+    snapgpu_params params{};
+    AlignCfg cfg{};
+    uint8_t *d_scratch = nullptr;
+    uint32_t n_wave_slots = 0;
+    uint32_t *d_work = nullptr;
+    unsigned long long *d_counters = nullptr;
+    // staging for the host-pointer entry points
+    void *d_stage[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t stage_cap[5] = {0, 0, 0, 0, 0};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double kernel_ms = 0.0;
+    uint64_t kernel_launches = 0;
+    int num_cus = 0;
+    std::string err;
+};
+
+#define HIPCHK(ctx, call, code)                                                                   \
+    do {                                                                                          \
+        hipError_t _e = (call);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            std::string m = std::string(#call) + ": " + hipGetErrorString(_e);                    \
+            if (ctx) (ctx)->err = m;                                                              \
+            g_last_error = m;                                                                     \
+            return (code);                                                                        \
+        }                                                                                         \
+    } while (0)
+
+static int fail(snapgpu_ctx *ctx, int code, const std::string &msg) {
+    if (ctx) ctx->err = msg;
+    g_last_error = msg;
+    return code;
+}
+
+extern "C" int snapgpu_abi_version(void) { return SNAPGPU_ABI_VERSION; }
+
+extern "C" const char *snapgpu_last_error(const snapgpu_ctx *ctx) {
+    if (ctx && !ctx->err.empty()) return ctx->err.c_str();
+    return g_last_error.c_str();
+}
+
+extern "C" void snapgpu_default_params(snapgpu_params *p) {      // AlignerOptions.cpp:39-117 (single-end)
+    memset(p, 0, sizeof(*p));
+    p->max_hits = 300; p->max_k = 27; p->num_seeds = 25; p->seed_coverage = 0.0;
+    p->min_weight_to_check = 1; p->extra_search_depth = 1; p->use_affine_gap = 1;
+    p->match_reward = 1; p->sub_penalty = 4; p->gap_open_penalty = 6; p->gap_extend_penalty = 1;
+    p->five_prime_end_bonus = 10; p->three_prime_end_bonus = 7;
+    p->alt_awareness = 1; p->emit_alt_alignments = 0; p->max_score_gap_to_prefer_non_alt = 64;
+    p->max_read_len = 400;
+}
+
+// __builtin_powi as libgcc evaluates it: the reference is built as C++98, where
+// pow(double, int) resolves to std::pow(double, int) == __builtin_powi (BaseAligner.cpp:1314).
+static double powi_like_libgcc(double x, int m) {
+    unsigned n = m < 0 ? -(unsigned)m : (unsigned)m;
+    double y = (n % 2) ? x : 1.0;
+    while (n >>= 1) {
+        x = x * x;
+        if (n % 2) y *= x;
+    }
+    return m < 0 ? 1.0 / y : y;
+}
+
+static void build_tables(DevTables &t, unsigned seed_len) {
+    const double SNP_PROB = 0.001, GAP_OPEN_PROB = 0.001, GAP_EXTEND_PROB = 0.5;   // BaseAligner.h:368-370
+    // LandauVishkin.cpp:734-760
+    t.indel[0] = 1.0;
+    t.indel[1] = GAP_OPEN_PROB;
+    for (int i = 2; i < N_INDEL_PROB; i++) t.indel[i] = t.indel[i - 1] * GAP_EXTEND_PROB;
+    const double mutationRate = SNP_PROB;
+    for (int i = 0; i < 33; i++) t.phred[i] = mutationRate;
+    for (int i = 33; i <= 93 + 33; i++) t.phred[i] = 1.0 - (1.0 - pow(10.0, -1.0 * (i - 33.0) / 10.0)) * (1.0 - mutationRate);
+    for (int i = 93 + 33 + 1; i < 256; i++) t.phred[i] = mutationRate;
+    t.perfect[0] = 1.0;
+    for (int i = 1; i < N_PERFECT_PROB; i++) t.perfect[i] = t.perfect[i - 1] * (1 - SNP_PROB);
+    t.seed_prob = powi_like_libgcc(1 - SNP_PROB, (int)seed_len);
+
+    // MAPQ thresholds: threshold[m] = largest x with (int)(-10*log10(x)) >= m, found by bisection
+    // over the ordered bit patterns of positive doubles with the HOST log10 (mapq.h:53-59).
+    t.mapq_threshold[0] = INFINITY;
+    for (int m = 1; m <= 70; m++) {
+        uint64_t lo, hi;                 // invariant: f(lo) >= m, f(hi) < m
+        double dlo = 1e-300, dhi = 1.0;
+        memcpy(&lo, &dlo, 8); memcpy(&hi, &dhi, 8);
+        while (hi - lo > 1) {
+            uint64_t mid = lo + (hi - lo) / 2;
+            double x; memcpy(&x, &mid, 8);
+            int f = (int)(-10 * log10(x));
+            if (f >= m) lo = mid; else hi = mid;
+        }
+        double x; memcpy(&x, &lo, 8);
+        t.mapq_threshold[m] = x;
+    }
+    t.mapq_threshold[71] = 0.0;
+
+    // GetWrappedNextSeedToTest: the table SeedSequencer builds with a FIFO of intervals
+    // (SeedSequencer.cpp:36-103), indexed by wrapCount exactly as SeedSequencer.h:40-43 does.
+    memset(t.wrapped_seed, 0, sizeof(t.wrapped_seed));
+    if (seed_len >= 2 && seed_len <= 32) {
+        std::vector<unsigned> offsets(seed_len, 0);
+        std::deque<std::pair<unsigned, unsigned>> work;
+        work.push_back({1u, seed_len - 1});
+        unsigned filled = 1;
+        while (!work.empty()) {
+            auto it = work.front(); work.pop_front();
+            unsigned sel = (it.first + it.second) / 2;
+            offsets[sel] = filled++;
+            if (it.second > sel) work.push_back({sel + 1, it.second});
+            if (it.first < sel) work.push_back({it.first, sel - 1});
+        }
+        for (unsigned i = 0; i < seed_len; i++) t.wrapped_seed[i] = offsets[i];
+    }
+}
+
+static uint32_t next_pow2(uint32_t v) { uint32_t p = 1; while (p < v) p <<= 1; return p; }
+
+static int ensure_stage(snapgpu_ctx *ctx, int which, size_t bytes) {
+    if (ctx->stage_cap[which] >= bytes) return 0;
+    if (ctx->d_stage[which]) (void)hipFree(ctx->d_stage[which]);
+    ctx->d_stage[which] = nullptr; ctx->stage_cap[which] = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(ctx, hipMalloc(&ctx->d_stage[which], cap), SNAPGPU_E_NOMEM);
+    ctx->stage_cap[which] = cap;
+    return 0;
+}
+
+extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->device >= 0) (void)hipSetDevice(ctx->device);
+    if (ctx->owns_index) {
+        if (ctx->d_hash) (void)hipFree(ctx->d_hash);
+        if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
+        if (ctx->d_genome_padded) (void)hipFree(ctx->d_genome_padded);
+    }
+    if (ctx->d_table_offset) (void)hipFree(ctx->d_table_offset);
+    if (ctx->d_table_size) (void)hipFree(ctx->d_table_size);
+    if (ctx->d_contig_begin) (void)hipFree(ctx->d_contig_begin);
+    if (ctx->d_tab) (void)hipFree(ctx->d_tab);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    for (int i = 0; i < 5; i++) if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_params *p, int device, snapgpu_ctx **out)
+{
+    if (!idx || !p || !out) return fail(nullptr, SNAPGPU_E_INVALID, "snapgpu_create: null argument");
+    *out = nullptr;
+    if (idx->location_size != 4)
+        return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "index uses 64-bit genome locations; only the 32-bit lookup path (seed >= 20) is implemented");
+    if (idx->seed_len < 2 || idx->seed_len > 32) return fail(nullptr, SNAPGPU_E_INVALID, "seed length out of range");
+    if (idx->key_bytes < 2 || idx->key_bytes > 8) return fail(nullptr, SNAPGPU_E_INVALID, "hash key size out of range");
+    if (idx->genome_pad < 1000) return fail(nullptr, SNAPGPU_E_INVALID, "genome_pad must be >= 1000");
+    if (p->max_read_len < idx->seed_len || p->max_read_len > 1000)
+        return fail(nullptr, SNAPGPU_E_INVALID, "max_read_len must be in [seed_len, 1000] (MAX_READ_LENGTH, Read.h:49)");
+    if (p->sub_penalty <= p->gap_extend_penalty) return fail(nullptr, SNAPGPU_E_INVALID, "sub_penalty must exceed gap_extend_penalty");
+    if (p->sub_penalty > p->gap_open_penalty + p->gap_extend_penalty)
+        return fail(nullptr, SNAPGPU_E_INVALID, "subPenalty > gapOpen + gapExtend (BaseAligner.cpp:141)");
+#ifndef SNAPGPU_HAVE_AG
+    if (p->use_affine_gap)
+        return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "affine-gap scoring is not built into this library yet; set use_affine_gap = 0 (-G-)");
+#endif
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, SNAPGPU_E_NODEVICE, "no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(nullptr, SNAPGPU_E_NODEVICE, "device index out of range");
+
+    snapgpu_ctx *ctx = new snapgpu_ctx();
+    ctx->device = device;
+    ctx->params = *p;
+#define CRCHK(call, code) do { hipError_t _e = (call); if (_e != hipSuccess) { \
+        fail(nullptr, code, std::string(#call) + ": " + hipGetErrorString(_e)); snapgpu_destroy(ctx); return code; } } while (0)
+    CRCHK(hipSetDevice(device), SNAPGPU_E_NODEVICE);
+    hipDeviceProp_t prop;
+    CRCHK(hipGetDeviceProperties(&prop, device), SNAPGPU_E_NODEVICE);
+    ctx->num_cus = prop.multiProcessorCount;
+    CRCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking), SNAPGPU_E_NODEVICE);
+    CRCHK(hipEventCreate(&ctx->ev0), SNAPGPU_E_NODEVICE);
+    CRCHK(hipEventCreate(&ctx->ev1), SNAPGPU_E_NODEVICE);
+
+    // ---- index blobs
+    DevIndex &ix = ctx->ix;
+    ix.n_bases = idx->n_bases; ix.overflow_size = idx->overflow_table_size;
+    ix.first_alt_location = idx->first_alt_location; ix.n_contigs = idx->n_contigs;
+    ix.seed_len = idx->seed_len; ix.key_bytes = idx->key_bytes; ix.large = idx->large_hash_table ? 1 : 0;
+    ix.entry_bytes = 4 * (ix.large ? 2 : 1) + ix.key_bytes; ix.n_hash_tables = idx->n_hash_tables;
+    ix.chromosome_padding = idx->chromosome_padding; ix.genome_pad = idx->genome_pad;
+    const size_t genome_total = (size_t)idx->n_bases + 2 * (size_t)idx->genome_pad;
+    const size_t overflow_words = idx->overflow_table_size ? (size_t)idx->overflow_table_size : 1;
+    if (idx->on_device) {
+        ctx->owns_index = false;
+        ctx->d_hash = (void *)idx->hash_blob;
+        ctx->d_overflow = (void *)idx->overflow;
+        ctx->d_genome_padded = (void *)(idx->genome - idx->genome_pad);
+    } else {
+        CRCHK(hipMalloc(&ctx->d_hash, (size_t)idx->hash_blob_bytes + 16), SNAPGPU_E_NOMEM);
+        CRCHK(hipMalloc(&ctx->d_overflow, overflow_words * 4 + 16), SNAPGPU_E_NOMEM);
+        CRCHK(hipMalloc(&ctx->d_genome_padded, genome_total + 16), SNAPGPU_E_NOMEM);
+        if (idx->hash_blob) CRCHK(hipMemcpy(ctx->d_hash, idx->hash_blob, (size_t)idx->hash_blob_bytes, hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+        if (idx->overflow) CRCHK(hipMemcpy(ctx->d_overflow, idx->overflow, overflow_words * 4, hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+        if (idx->genome) CRCHK(hipMemcpy(ctx->d_genome_padded, idx->genome - idx->genome_pad, genome_total, hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+    }
+    ix.hash_blob = (const uint8_t *)ctx->d_hash;
+    ix.overflow = (const uint32_t *)ctx->d_overflow;
+    ix.genome = (const uint8_t *)ctx->d_genome_padded + idx->genome_pad;
+    CRCHK(hipMalloc(&ctx->d_table_offset, (size_t)idx->n_hash_tables * 8), SNAPGPU_E_NOMEM);
+    CRCHK(hipMalloc(&ctx->d_table_size, (size_t)idx->n_hash_tables * 8), SNAPGPU_E_NOMEM);
+    CRCHK(hipMemcpy(ctx->d_table_offset, idx->table_offset, (size_t)idx->n_hash_tables * 8, hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+    CRCHK(hipMemcpy(ctx->d_table_size, idx->table_size, (size_t)idx->n_hash_tables * 8, hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+    size_t nc = idx->n_contigs ? idx->n_contigs : 1;
+    CRCHK(hipMalloc(&ctx->d_contig_begin, nc * 8), SNAPGPU_E_NOMEM);
+    if (idx->n_contigs) CRCHK(hipMemcpy(ctx->d_contig_begin, idx->contig_begin, (size_t)idx->n_contigs * 8, hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+    ix.table_offset = (const uint64_t *)ctx->d_table_offset;
+    ix.table_size = (const uint64_t *)ctx->d_table_size;
+    ix.contig_begin = (const uint64_t *)ctx->d_contig_begin;
+
+    // ---- tables
+    build_tables(ctx->h_tab, idx->seed_len);
+    CRCHK(hipMalloc((void **)&ctx->d_tab, sizeof(DevTables)), SNAPGPU_E_NOMEM);
+    CRCHK(hipMemcpy(ctx->d_tab, &ctx->h_tab, sizeof(DevTables), hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+
+    // ---- aligner configuration (BaseAligner ctor, BaseAligner.cpp:173-183, with maxReadSize = MAX_READ_LENGTH
+    //      as SingleAligner.cpp:138 passes it)
+    AlignCfg &c = ctx->cfg;
+    c.max_hits = p->max_hits; c.max_k = p->max_k; c.num_seeds = p->num_seeds;
+    c.min_weight = p->min_weight_to_check < 1 ? 1 : p->min_weight_to_check;   // max(1u, ...), BaseAligner.cpp:83
+    c.extra_depth = p->extra_search_depth; c.use_ag = p->use_affine_gap ? 1 : 0;
+    c.match_reward = (int)p->match_reward; c.sub_penalty = (int)p->sub_penalty;
+    c.gap_open = (int)p->gap_open_penalty; c.gap_extend = (int)p->gap_extend_penalty;
+    c.five_bonus = (int)p->five_prime_end_bonus; c.three_bonus = (int)p->three_prime_end_bonus;
+    c.alt_aware = p->alt_awareness ? 1 : 0; c.emit_alt = p->emit_alt_alignments ? 1 : 0;
+    c.max_gap_alt = p->max_score_gap_to_prefer_non_alt; c.seed_coverage = p->seed_coverage;
+    uint32_t max_seeds_ctor = p->num_seeds != 0 ? p->num_seeds : (uint32_t)(int)(p->seed_coverage * 1000 / idx->seed_len);
+    c.num_weight_lists = max_seeds_ctor + 1;
+    if (c.num_weight_lists < 2 || c.num_weight_lists > 0x3FF) { snapgpu_destroy(ctx); return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "number of seeds out of the supported range [1, 1022]"); }
+    c.RL = (p->max_read_len + 15) & ~15u;
+    uint32_t kmax = p->max_k + p->extra_search_depth; if (kmax > 126) kmax = 126;
+    c.kmax = kmax;
+    uint64_t pool = (uint64_t)p->max_hits * max_seeds_ctor;
+    if (pool < 64) pool = 64;
+    if (pool > 60000) { snapgpu_destroy(ctx); return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "max_hits * num_seeds > 60000 candidate buckets per read is not supported"); }
+    c.pool_size = (uint32_t)pool;
+    c.ht_size = next_pow2((uint32_t)pool * 2);
+    c.ag_numvec_max = (c.RL + 7) / 8;
+    size_t ag_bytes = ag_scratch_bytes(c.RL);
+    c.scratch_stride = ((size_t)c.ht_size * 2 + (size_t)c.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
+    LdsLayout L = lds_layout(c.RL, c.num_weight_lists, c.kmax);
+    c.lds_per_wave = L.total;
+
+    // waves in flight: a fixed number per CU, each with its own scratch slab
+    int waves_per_cu = 16;
+    if (const char *e = getenv("SNAPGPU_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) waves_per_cu = v; }
+    // LDS limit: 160 KiB per CU
+    while (waves_per_cu > 1 && (size_t)waves_per_cu * L.total > 160 * 1024) waves_per_cu--;
+    if ((size_t)4 * L.total > 64 * 1024 && (size_t)L.total > 160 * 1024) { snapgpu_destroy(ctx); return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "per-read LDS state exceeds 160 KiB"); }
+    ctx->n_wave_slots = (uint32_t)ctx->num_cus * (uint32_t)waves_per_cu;
+    ctx->n_wave_slots = (ctx->n_wave_slots + 3) & ~3u;
+    size_t scratch_total = (size_t)ctx->n_wave_slots * c.scratch_stride;
+    CRCHK(hipMalloc((void **)&ctx->d_scratch, scratch_total), SNAPGPU_E_NOMEM);
+    // only the head tables need to start zeroed
+    for (uint32_t w = 0; w < ctx->n_wave_slots; w++)
+        CRCHK(hipMemsetAsync(ctx->d_scratch + (size_t)w * c.scratch_stride, 0, (size_t)c.ht_size * 2, ctx->stream), SNAPGPU_E_NODEVICE);
+    CRCHK(hipMalloc((void **)&ctx->d_work, 256), SNAPGPU_E_NOMEM);
+    CRCHK(hipMalloc((void **)&ctx->d_counters, sizeof(snapgpu_counters)), SNAPGPU_E_NOMEM);
+    CRCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(snapgpu_counters), ctx->stream), SNAPGPU_E_NODEVICE);
+    CRCHK(hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
+#undef CRCHK
+    *out = ctx;
+    return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_index_device_ptrs(snapgpu_ctx *ctx, void **hash_blob, void **overflow, void **genome_with_pad) {
+    if (!ctx) return SNAPGPU_E_INVALID;
+    if (hash_blob) *hash_blob = ctx->d_hash;
+    if (overflow) *overflow = ctx->d_overflow;
+    if (genome_with_pad) *genome_with_pad = ctx->d_genome_padded;
+    return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_lookup_seeds(snapgpu_ctx *ctx, uint32_t n, const char *seeds, int64_t *n_hits,
+                                    uint32_t *hits, uint32_t max_hits_out)
+{
+    if (!ctx || !seeds || !n_hits || !hits || max_hits_out == 0) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_lookup_seeds: bad argument");
+    if (n == 0) return SNAPGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    size_t sb = (size_t)n * ctx->ix.seed_len, nb = (size_t)n * 2 * 8, hb = (size_t)n * 2 * max_hits_out * 4;
+    int rc;
+    if ((rc = ensure_stage(ctx, 0, sb)) || (rc = ensure_stage(ctx, 1, nb)) || (rc = ensure_stage(ctx, 2, hb))) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[0], seeds, sb, hipMemcpyHostToDevice, ctx->stream), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_stage[2], 0, hb, ctx->stream), SNAPGPU_E_LAUNCH);
+    uint32_t blocks = (n + 3) / 4; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(k_lookup_seeds, dim3(blocks), dim3(256), 0, ctx->stream, ctx->ix, n,
+                       (const uint8_t *)ctx->d_stage[0], (long long *)ctx->d_stage[1], (uint32_t *)ctx->d_stage[2], max_hits_out);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(n_hits, ctx->d_stage[1], nb, hipMemcpyDeviceToHost, ctx->stream), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(hits, ctx->d_stage[2], hb, hipMemcpyDeviceToHost, ctx->stream), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
+// small RAII helper for per-call device buffers of the (test-oriented) batch primitives
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t put(const void *src, size_t bytes, hipStream_t s) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        if (e != hipSuccess) return e;
+        if (src && bytes) return hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s);
+        return hipSuccess;
+    }
+};
+
+extern "C" int snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
+                                      const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
+                                      const char *patterns, const char *quals, uint64_t patterns_bytes,
+                                      const uint32_t *pat_off, const int32_t *pat_len, const int32_t *k,
+                                      int32_t *score, double *match_probability, int32_t *net_indel,
+                                      int32_t *total_indels, int32_t *text_span)
+{
+    if (!ctx || (dir != 1 && dir != -1)) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_landau_vishkin: bad argument");
+    if (n == 0) return SNAPGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    uint32_t kmax = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (pat_len[i] < 0 || pat_len[i] > 1000) return fail(ctx, SNAPGPU_E_INVALID, "pattern length out of range");
+        int kk = k[i] > 126 ? 126 : k[i];
+        if (kk > (int)kmax) kmax = (uint32_t)kk;
+    }
+    hipStream_t s = ctx->stream;
+    DevBuf dt, dto, dtl, dp, dq, dpo, dpl, dk, ds, dpr, dni, dti, dts;
+    HIPCHK(ctx, dt.put(texts, texts_bytes, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dto.put(text_off, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dtl.put(text_len, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dp.put(patterns, patterns_bytes, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dq.put(quals, patterns_bytes, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dpo.put(pat_off, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dpl.put(pat_len, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dk.put(k, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, ds.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dpr.put(nullptr, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dni.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dti.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dts.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    LVBatchArgs a;
+    a.dir = dir; a.n = n; a.kmax = kmax;
+    a.texts = (const uint8_t *)dt.p; a.text_off = (const uint32_t *)dto.p; a.text_len = (const int32_t *)dtl.p;
+    a.patterns = (const uint8_t *)dp.p; a.quals = (const uint8_t *)dq.p; a.pat_off = (const uint32_t *)dpo.p;
+    a.pat_len = (const int32_t *)dpl.p; a.k = (const int32_t *)dk.p;
+    a.score = (int32_t *)ds.p; a.prob = (double *)dpr.p; a.net_indel = (int32_t *)dni.p;
+    a.total_indels = (int32_t *)dti.p; a.text_span = (int32_t *)dts.p; a.tab = ctx->d_tab;
+    uint32_t per_wave = (lv_lds_bytes(kmax) + 15) & ~15u;
+    uint32_t waves_per_block = 4;
+    while (waves_per_block > 1 && (size_t)waves_per_block * per_wave > 64 * 1024) waves_per_block >>= 1;
+    if ((size_t)waves_per_block * per_wave > 64 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "k too large for the LDS triangle");
+    uint32_t blocks = (n + waves_per_block - 1) / waves_per_block; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;
+    hipLaunchKernelGGL(k_lv_batch, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * per_wave, s, a);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(score, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(match_probability, dpr.p, (size_t)n * 8, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(net_indel, dni.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(total_indels, dti.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(text_span, dts.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
+#ifndef SNAPGPU_HAVE_AG
+extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int, uint32_t, const char *, uint64_t, const uint32_t *, const int32_t *,
+                                  const char *, const char *, uint64_t, const uint32_t *, const int32_t *,
+                                  const int32_t *, const int32_t *, const uint8_t *, const uint8_t *, const uint8_t *,
+                                  int32_t *, int32_t *, int32_t *, int32_t *, double *)
+{
+    return fail(ctx, SNAPGPU_E_UNSUPPORTED, "affine-gap scoring is not built into this library yet");
+}
+#endif
+
+static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals, const void *d_offsets,
+                        void *d_primary, void *d_first_alt, hipStream_t s)
+{
+    AlignArgs a;
+    a.ix = ctx->ix; a.cfg = ctx->cfg; a.tab = ctx->d_tab; a.scratch = ctx->d_scratch;
+    a.bases = (const uint8_t *)d_bases; a.quals = (const uint8_t *)d_quals; a.offsets = (const uint64_t *)d_offsets;
+    a.n_reads = n; a.primary = (snapgpu_single_result *)d_primary; a.first_alt = (snapgpu_single_result *)d_first_alt;
+    a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    uint32_t blocks = ctx->n_wave_slots / 4;
+    uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    hipLaunchKernelGGL(k_align_single, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
+static int finish_timing(snapgpu_ctx *ctx) {
+    float ms = 0;
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1), SNAPGPU_E_LAUNCH);
+    ctx->kernel_ms += ms; ctx->kernel_launches++;
+    return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_align_single_device(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals,
+                                           const void *d_offsets, void *d_primary, void *d_first_alt, void *stream)
+{
+    if (!ctx || !d_bases || !d_quals || !d_offsets || !d_primary) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_single_device: null argument");
+    if (n == 0) return SNAPGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int rc = launch_align(ctx, n, d_bases, d_quals, d_offsets, d_primary, d_first_alt, s);
+    if (rc) return rc;
+    if (!stream) return finish_timing(ctx);      // own stream: synchronous, and the launch is timed
+    return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_align_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, const char *quals,
+                                    const uint64_t *offsets, snapgpu_single_result *primary, snapgpu_single_result *first_alt)
+{
+    if (!ctx || !bases || !quals || !offsets || !primary) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_single: null argument");
+    if (n == 0) return SNAPGPU_OK;
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, SNAPGPU_E_INVALID, "offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] > ctx->params.max_read_len)
+            return fail(ctx, SNAPGPU_E_INVALID, "read longer than max_read_len given at snapgpu_create (BaseAligner.cpp:354-358)");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    size_t nb = (size_t)offsets[n];
+    int rc;
+    if ((rc = ensure_stage(ctx, 0, nb + 16)) || (rc = ensure_stage(ctx, 1, nb + 16)) || (rc = ensure_stage(ctx, 2, ((size_t)n + 1) * 8)) ||
+        (rc = ensure_stage(ctx, 3, (size_t)n * sizeof(snapgpu_single_result))) || (rc = ensure_stage(ctx, 4, (size_t)n * sizeof(snapgpu_single_result)))) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[0], bases, nb, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[1], quals, nb, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[2], offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    rc = launch_align(ctx, n, ctx->d_stage[0], ctx->d_stage[1], ctx->d_stage[2], ctx->d_stage[3], first_alt ? ctx->d_stage[4] : nullptr, s);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(primary, ctx->d_stage[3], (size_t)n * sizeof(snapgpu_single_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    if (first_alt) HIPCHK(ctx, hipMemcpyAsync(first_alt, ctx->d_stage[4], (size_t)n * sizeof(snapgpu_single_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    return finish_timing(ctx);
+}
+
+extern "C" int snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int reset) {
+    if (!ctx || !out) return SNAPGPU_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_counters, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream), SNAPGPU_E_LAUNCH);
+    if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(*out), ctx->stream), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_kernel_time(snapgpu_ctx *ctx, double *total_ms, uint64_t *n_launches, int reset) {
+    if (!ctx) return SNAPGPU_E_INVALID;
+    if (total_ms) *total_ms = ctx->kernel_ms;
+    if (n_launches) *n_launches = ctx->kernel_launches;
+    if (reset) { ctx->kernel_ms = 0; ctx->kernel_launches = 0; }
+    return SNAPGPU_OK;
+}
+
+// Host-side copies of the tables the kernels use, for bit-equality tests against the reference's.
+extern "C" int snapgpu_debug_tables(snapgpu_ctx *ctx, double *phred256, double *indel, uint32_t n_indel,
+                                    double *perfect, uint32_t n_perfect, double *seed_prob, double *mapq_thresholds72,
+                                    uint32_t *wrapped33)
+{
+    if (!ctx) return SNAPGPU_E_INVALID;
+    if (phred256) memcpy(phred256, ctx->h_tab.phred, sizeof(double) * 256);
+    if (indel) memcpy(indel, ctx->h_tab.indel, sizeof(double) * (n_indel < N_INDEL_PROB ? n_indel : N_INDEL_PROB));
+    if (perfect) memcpy(perfect, ctx->h_tab.perfect, sizeof(double) * (n_perfect < N_PERFECT_PROB ? n_perfect : N_PERFECT_PROB));
+    if (seed_prob) *seed_prob = ctx->h_tab.seed_prob;
+    if (mapq_thresholds72) memcpy(mapq_thresholds72, ctx->h_tab.mapq_threshold, sizeof(double) * 72);
+    if (wrapped33) memcpy(wrapped33, ctx->h_tab.wrapped_seed, sizeof(uint32_t) * 33);
+    return SNAPGPU_OK;
+}
