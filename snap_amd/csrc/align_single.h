@@ -126,6 +126,7 @@ struct Aligner {
     uint32_t *seed_used;
     uint16_t *wl_next, *wl_prev;
     uint16_t *lv_tri;
+    int16_t  *ag_rows;      // H, H-1, E rows of the affine-gap DP
     // ---- HBM scratch for this wave
     uint16_t *heads;
     Elem     *pool;
@@ -508,7 +509,7 @@ struct Aligner {
                                     bool banded = pat_len >= 3 * (2 * limit_e + 1);
                                     ByteSeq P{rd[e_dir] + tail_start, 1}, Q{ql[e_dir] + tail_start, 1}, T{data + tail_start, 1};
                                     AGResult a1 = ag_compute(banded, 1, agp, P, Q, pat_len, T, text_len, limit_e, read_len, e_dir != 0,
-                                                             false, ag_scratch, cfg.ag_numvec_max, tab);
+                                                             false, ag_rows, ag_scratch, cfg.RL, tab);
                                     ag1 = a1.ag_score; clip_after = a1.pattern_offset; score1 = a1.n_edits; mp1 = a1.match_probability;
                                     ag1 += (seed_len - read_len);
                                 }
@@ -518,7 +519,7 @@ struct Aligner {
                                         bool banded = seed_offset >= 3 * (2 * limit_left + 1);
                                         ByteSeq P{rd[e_dir] + seed_offset - 1, -1}, Q{ql[e_dir] + seed_offset - 1, -1}, T{data + seed_offset - 1, -1};
                                         AGResult a2 = ag_compute(banded, -1, agp, P, Q, seed_offset, T, seed_offset + limit_left, limit_left, read_len,
-                                                                 e_dir != 0, false, ag_scratch, cfg.ag_numvec_max, tab);
+                                                                 e_dir != 0, false, ag_rows, ag_scratch, cfg.RL, tab);
                                         ag2 = a2.ag_score; clip_before = a2.pattern_offset; score2 = a2.n_edits; mp2 = a2.match_probability;
                                         loc_offset = a2.text_offset;
                                         ag2 -= read_len;

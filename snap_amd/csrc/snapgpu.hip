@@ -41,9 +41,9 @@ static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { re
 
 // LDS carve-out per wave; must match lds_bytes_per_wave() on the host.
 struct LdsLayout {
-    uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, total;
+    uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, ag, total;
 };
-static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uint32_t num_weight_lists, uint32_t kmax) {
+static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uint32_t num_weight_lists, uint32_t kmax, uint32_t use_ag) {
     LdsLayout L; uint32_t o = 0;
     L.rd0 = o; o += RL; L.rd1 = o; o += RL; L.ql0 = o; o += RL; L.ql1 = o; o += RL;
     L.gw = o; o += (RL + 2 * WIN_PAD + 15) & ~15u;
@@ -51,6 +51,7 @@ static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uin
     L.wl_next = o; o += (num_weight_lists * 2 + 15) & ~15u;
     L.wl_prev = o; o += (num_weight_lists * 2 + 15) & ~15u;
     L.lv = o; o += (lv_lds_bytes(kmax) + 15) & ~15u;
+    L.ag = o; if (use_ag) o += (ag_lds_bytes(RL) + 15) & ~15u;
     L.total = o;
     return L;
 }
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
     const int lane = lane_id();
     const int wave_in_block = (int)(threadIdx.x >> 6);
     const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
-    const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax);
+    const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax, a.cfg.use_ag);
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
     Aligner al(a.ix, a.tab, a.cfg);
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
     al.wl_next = (uint16_t *)(my + L.wl_next);
     al.wl_prev = (uint16_t *)(my + L.wl_prev);
     al.lv_tri = (uint16_t *)(my + L.lv);
+    al.ag_rows = (int16_t *)(my + L.ag);
     uint8_t *sc = a.scratch + (size_t)wave_slot * a.cfg.scratch_stride;
     al.heads = (uint16_t *)sc;
     al.pool = (Elem *)(sc + (size_t)a.cfg.ht_size * 2);
@@ -165,6 +167,46 @@ __global__ __launch_bounds__(256) void k_lv_batch(LVBatchArgs a)
         if (lane == 0) {
             a.score[i] = r.score; a.prob[i] = r.match_probability; a.net_indel[i] = r.net_indel;
             a.total_indels[i] = r.total_indels; a.text_span[i] = r.text_span;
+        }
+    }
+}
+
+struct AGBatchArgs {
+    int dir; uint32_t n; uint32_t RL;
+    AGParams prm;
+    const uint8_t *texts; const uint32_t *text_off; const int32_t *text_len;
+    const uint8_t *patterns; const uint8_t *quals; const uint32_t *pat_off; const int32_t *pat_len;
+    const int32_t *w; const int32_t *score_init; const uint8_t *is_rc; const uint8_t *banded; const uint8_t *use_clip;
+    uint8_t *scratch;
+    int32_t *ag_score; int32_t *text_offset; int32_t *pattern_offset; int32_t *n_edits; double *prob;
+    const DevTables *tab;
+};
+
+// One wave per problem: AffineGapVectorized<dir>::computeScore / computeScoreBanded.
+__global__ __launch_bounds__(64) void k_ag_batch(AGBatchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    int16_t *rows = (int16_t *)lds;
+    uint8_t *bt = a.scratch + (size_t)blockIdx.x * ag_scratch_bytes(a.RL);
+    for (uint32_t i = blockIdx.x; i < a.n; i += gridDim.x) {
+        int plen = a.pat_len[i], tlen = a.text_len[i];
+        const uint8_t *p = a.patterns + a.pat_off[i];
+        const uint8_t *q = a.quals + a.pat_off[i];
+        const uint8_t *t = a.texts + a.text_off[i];
+        AGResult r;
+        if (a.dir == 1) {
+            ByteSeq P{p, 1}, Q{q, 1}, T{t, 1};
+            r = ag_compute(a.banded[i] != 0, 1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
+                           a.use_clip[i] != 0, rows, bt, a.RL, a.tab);
+        } else {
+            ByteSeq P{p, 1}, Q{q, 1}, T{t - 1, -1};
+            r = ag_compute(a.banded[i] != 0, -1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
+                           a.use_clip[i] != 0, rows, bt, a.RL, a.tab);
+        }
+        if (lane == 0) {
+            a.ag_score[i] = r.ag_score; a.text_offset[i] = r.text_offset; a.pattern_offset[i] = r.pattern_offset;
+            a.n_edits[i] = r.n_edits; a.prob[i] = r.match_probability;
         }
     }
 }
@@ -345,10 +387,6 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     if (p->sub_penalty <= p->gap_extend_penalty) return fail(nullptr, SNAPGPU_E_INVALID, "sub_penalty must exceed gap_extend_penalty");
     if (p->sub_penalty > p->gap_open_penalty + p->gap_extend_penalty)
         return fail(nullptr, SNAPGPU_E_INVALID, "subPenalty > gapOpen + gapExtend (BaseAligner.cpp:141)");
-#ifndef SNAPGPU_HAVE_AG
-    if (p->use_affine_gap)
-        return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "affine-gap scoring is not built into this library yet; set use_affine_gap = 0 (-G-)");
-#endif
 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -432,9 +470,9 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     c.pool_size = (uint32_t)pool;
     c.ht_size = next_pow2((uint32_t)pool * 2);
     c.ag_numvec_max = (c.RL + 7) / 8;
-    size_t ag_bytes = ag_scratch_bytes(c.RL);
+    size_t ag_bytes = c.use_ag ? ag_scratch_bytes(c.RL) : 0;
     c.scratch_stride = ((size_t)c.ht_size * 2 + (size_t)c.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
-    LdsLayout L = lds_layout(c.RL, c.num_weight_lists, c.kmax);
+    LdsLayout L = lds_layout(c.RL, c.num_weight_lists, c.kmax, c.use_ag);
     c.lds_per_wave = L.total;
 
     // waves in flight: a fixed number per CU, each with its own scratch slab
@@ -554,15 +592,71 @@ extern "C" int snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
     return SNAPGPU_OK;
 }
 
-#ifndef SNAPGPU_HAVE_AG
-extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int, uint32_t, const char *, uint64_t, const uint32_t *, const int32_t *,
-                                  const char *, const char *, uint64_t, const uint32_t *, const int32_t *,
-                                  const int32_t *, const int32_t *, const uint8_t *, const uint8_t *, const uint8_t *,
-                                  int32_t *, int32_t *, int32_t *, int32_t *, double *)
+extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
+                                  const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
+                                  const char *patterns, const char *quals, uint64_t patterns_bytes,
+                                  const uint32_t *pat_off, const int32_t *pat_len,
+                                  const int32_t *w, const int32_t *score_init, const uint8_t *is_rc,
+                                  const uint8_t *banded, const uint8_t *use_clip,
+                                  int32_t *ag_score, int32_t *text_offset, int32_t *pattern_offset,
+                                  int32_t *n_edits, double *match_probability)
 {
-    return fail(ctx, SNAPGPU_E_UNSUPPORTED, "affine-gap scoring is not built into this library yet");
+    if (!ctx || (dir != 1 && dir != -1)) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_affine_gap: bad argument");
+    if (n == 0) return SNAPGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    uint32_t RL = 16;
+    for (uint32_t i = 0; i < n; i++) {
+        if (pat_len[i] < 1 || pat_len[i] > 1000) return fail(ctx, SNAPGPU_E_INVALID, "pattern length out of range");
+        if (text_len[i] < 0 || text_len[i] > pat_len[i] + 127) return fail(ctx, SNAPGPU_E_INVALID, "text length must be in [0, pattern_len + MAX_K]");
+        if (score_init[i] < 0 || score_init[i] > 16000) return fail(ctx, SNAPGPU_E_INVALID, "score_init out of range");
+        if ((uint32_t)pat_len[i] > RL) RL = (uint32_t)pat_len[i];
+    }
+    RL = (RL + 15) & ~15u;
+    hipStream_t s = ctx->stream;
+    const uint32_t waves_per_block = 1;
+    uint32_t blocks = n; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;
+    DevBuf dt, dto, dtl, dp, dq, dpo, dpl, dw, dsi, drc, dbd, dcl, dscratch, o1, o2, o3, o4, o5;
+    HIPCHK(ctx, dt.put(texts, texts_bytes, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dto.put(text_off, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dtl.put(text_len, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dp.put(patterns, patterns_bytes, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dq.put(quals, patterns_bytes, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dpo.put(pat_off, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dpl.put(pat_len, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dw.put(w, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dsi.put(score_init, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, drc.put(is_rc, (size_t)n, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dbd.put(banded, (size_t)n, s), SNAPGPU_E_NOMEM);
+    std::vector<uint8_t> zeros;
+    if (!use_clip) { zeros.assign(n, 0); use_clip = zeros.data(); }
+    HIPCHK(ctx, dcl.put(use_clip, (size_t)n, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dscratch.put(nullptr, (size_t)blocks * waves_per_block * ag_scratch_bytes(RL), s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, o1.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, o2.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, o3.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, o4.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, o5.put(nullptr, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    AGBatchArgs a;
+    a.dir = dir; a.n = n; a.RL = RL;
+    a.prm = AGParams{ctx->cfg.match_reward, ctx->cfg.sub_penalty, ctx->cfg.gap_open, ctx->cfg.gap_extend, ctx->cfg.five_bonus, ctx->cfg.three_bonus};
+    a.texts = (const uint8_t *)dt.p; a.text_off = (const uint32_t *)dto.p; a.text_len = (const int32_t *)dtl.p;
+    a.patterns = (const uint8_t *)dp.p; a.quals = (const uint8_t *)dq.p; a.pat_off = (const uint32_t *)dpo.p;
+    a.pat_len = (const int32_t *)dpl.p; a.w = (const int32_t *)dw.p; a.score_init = (const int32_t *)dsi.p;
+    a.is_rc = (const uint8_t *)drc.p; a.banded = (const uint8_t *)dbd.p; a.use_clip = (const uint8_t *)dcl.p;
+    a.scratch = (uint8_t *)dscratch.p;
+    a.ag_score = (int32_t *)o1.p; a.text_offset = (int32_t *)o2.p; a.pattern_offset = (int32_t *)o3.p;
+    a.n_edits = (int32_t *)o4.p; a.prob = (double *)o5.p; a.tab = ctx->d_tab;
+    uint32_t lds = (ag_lds_bytes(RL) + 15) & ~15u;
+    hipLaunchKernelGGL(k_ag_batch, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ag_score, o1.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(text_offset, o2.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(pattern_offset, o3.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(n_edits, o4.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(match_probability, o5.p, (size_t)n * 8, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
 }
-#endif
 
 static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals, const void *d_offsets,
                         void *d_primary, void *d_first_alt, hipStream_t s)
