@@ -140,7 +140,11 @@ typedef struct snapgpu_single_result {
     double   match_probability;
     double   probability_all_candidates;
     uint32_t popular_seeds_skipped;
-    uint32_t reserved;
+    uint32_t reserved;             /* not in the reference: number of banded affine-gap traceback steps that
+                                      left the computed band while scoring this read.  Non-zero means the
+                                      reference's own result for this read depends on what its aligner object
+                                      scored before (it reads stale traceback cells, AffineGapVectorized.h:743);
+                                      DESIGN.md "Reference nondeterminism". */
 } snapgpu_single_result;
 
 /* per-call work counters (what BaseAligner exposes through getNHashTableLookups() etc.,

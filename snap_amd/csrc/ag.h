@@ -36,6 +36,7 @@ struct AGResult {
     int    pattern_offset;
     int    n_edits;
     double match_probability;
+    int    stale_reads;      // traceback steps through cells this call never computed (reference result undefined)
 };
 
 // cells per row rounded up: a (possibly banded) row has at most pattern_len + seg_len cells
@@ -64,6 +65,7 @@ static __device__ __forceinline__ AGResult ag_compute(
     const int sl = lane & 7;            // SSE lane emulated by this wavefront lane
     const int kk = lane >> 3;           // vector within the current step of 8 vectors
     AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1; res.match_probability = 0.0;
+    res.stale_reads = 0;
     if (w > 126) w = 126;
     if (w < 0) return res;                                             // :325 / :890
     res.match_probability = 1.0;
@@ -300,6 +302,7 @@ static __device__ __forceinline__ AGResult ag_compute(
                 computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
             }
             int bits = computed ? (int)first_u32(bt_scratch[(size_t)row * row_cells + vi * 8 + li]) : 0;
+            if (!computed) res.stale_reads++;
             action = (bits >> (action << 1)) & 3;
             if (action == 0) {
                 if (P(col) != T(row)) { prob *= tab->phred[Q(col)]; n_mismatches++; }

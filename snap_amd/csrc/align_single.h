@@ -141,6 +141,7 @@ struct Aligner {
     uint32_t cur_round_lps[2];         // currRoundLowestPossibleScoreOfAnyUnseenLocation
     uint32_t n_seeds_applied[2];
     uint32_t popular_seeds_skipped;
+    uint32_t ag_stale;                 // affine-gap traceback steps outside the computed band (see ag.h)
     ScoreSet all, non_alt;
     snapgpu_single_result primary, first_alt;
     WaveCounters cnt;
@@ -511,6 +512,7 @@ struct Aligner {
                                     AGResult a1 = ag_compute(banded, 1, agp, P, Q, pat_len, T, text_len, limit_e, read_len, e_dir != 0,
                                                              false, ag_rows, ag_scratch, cfg.RL, tab);
                                     ag1 = a1.ag_score; clip_after = a1.pattern_offset; score1 = a1.n_edits; mp1 = a1.match_probability;
+                                    ag_stale += (uint32_t)a1.stale_reads;
                                     ag1 += (seed_len - read_len);
                                 }
                                 if (score1 != -1) {
@@ -521,6 +523,7 @@ struct Aligner {
                                         AGResult a2 = ag_compute(banded, -1, agp, P, Q, seed_offset, T, seed_offset + limit_left, limit_left, read_len,
                                                                  e_dir != 0, false, ag_rows, ag_scratch, cfg.RL, tab);
                                         ag2 = a2.ag_score; clip_before = a2.pattern_offset; score2 = a2.n_edits; mp2 = a2.match_probability;
+                                        ag_stale += (uint32_t)a2.stale_reads;
                                         loc_offset = a2.text_offset;
                                         ag2 -= read_len;
                                     }
@@ -689,6 +692,7 @@ struct Aligner {
         if (!cfg.alt_aware) non_alt.best_score = SNAPGPU_TooBigScoreValue;    // :325 (never re-initialised without ALT awareness)
         n_seeds_applied[0] = n_seeds_applied[1] = 0;
         popular_seeds_skipped = 0;
+        ag_stale = 0;
         bool finished = false;
 
         while (n_seeds_applied[0] + n_seeds_applied[1] < max_seeds_to_use) {
@@ -747,6 +751,7 @@ struct Aligner {
         }
         if (!finished) score(true);                                           // :734
         primary.score_prior_to_clipping = primary.score;                      // finalizeSecondaryResults, :2442
+        primary.reserved = ag_stale;
         release_candidates();
     }
 };

@@ -12,12 +12,16 @@
 
 #define WAVE 64
 
-// LLVM's gfx9 memory model executes one wavefront's memory operations in order, so a
-// wavefront-scope fence costs no instructions; it only stops the compiler from moving
-// accesses across the point where one lane's store is consumed by the other lanes.
+// One wavefront's LDS operations, and its vector-memory operations, are each executed in
+// issue order by the hardware (LLVM AMDGPU memory model: wavefront scope needs no cache
+// action), so a value stored by one lane is visible to the wave's later loads without any
+// wait.  What must be prevented is the *compiler* moving a load above the store it depends
+// on through another lane (per-thread alias analysis cannot see that dependence).  A pure
+// compiler barrier does that without emitting s_waitcnt vmcnt(0), which a
+// __builtin_amdgcn_fence would (it made every DP row wait for its traceback stores).
 #define WAVE_SYNC()                                                   \
     do {                                                              \
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        \
+        asm volatile("" ::: "memory");                                \
         __builtin_amdgcn_wave_barrier();                              \
     } while (0)
 

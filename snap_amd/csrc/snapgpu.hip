@@ -179,6 +179,7 @@ struct AGBatchArgs {
     const int32_t *w; const int32_t *score_init; const uint8_t *is_rc; const uint8_t *banded; const uint8_t *use_clip;
     uint8_t *scratch;
     int32_t *ag_score; int32_t *text_offset; int32_t *pattern_offset; int32_t *n_edits; double *prob;
+    int32_t *stale;
     const DevTables *tab;
 };
 
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(64) void k_ag_batch(AGBatchArgs a)
         if (lane == 0) {
             a.ag_score[i] = r.ag_score; a.text_offset[i] = r.text_offset; a.pattern_offset[i] = r.pattern_offset;
             a.n_edits[i] = r.n_edits; a.prob[i] = r.match_probability;
+            if (a.stale) a.stale[i] = r.stale_reads;
         }
     }
 }
@@ -645,7 +647,7 @@ extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
     a.is_rc = (const uint8_t *)drc.p; a.banded = (const uint8_t *)dbd.p; a.use_clip = (const uint8_t *)dcl.p;
     a.scratch = (uint8_t *)dscratch.p;
     a.ag_score = (int32_t *)o1.p; a.text_offset = (int32_t *)o2.p; a.pattern_offset = (int32_t *)o3.p;
-    a.n_edits = (int32_t *)o4.p; a.prob = (double *)o5.p; a.tab = ctx->d_tab;
+    a.n_edits = (int32_t *)o4.p; a.prob = (double *)o5.p; a.tab = ctx->d_tab; a.stale = nullptr;
     uint32_t lds = (ag_lds_bytes(RL) + 15) & ~15u;
     hipLaunchKernelGGL(k_ag_batch, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);

@@ -1,0 +1,224 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI
+(libsnapgpu.so); expectations come from the committed golden fixtures the compiled reference
+produced (scripts/make_golden.py) and, where oracle/_ref travelled to the box, from the
+reference itself on fresh seeded inputs.  Integer fields and FP64 probabilities must be
+bit-identical."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from snap_amd import abi, synth
+from tests import util
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+KATS = json.load(open(os.path.join(util.GOLDEN, "reference_kats.json")))
+
+
+@pytest.fixture(scope="module")
+def aligner(golden_index):
+    from snap_amd.aligner import BaseAligner
+    a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+    yield a
+    a.close()
+
+
+def _loaded_native(name="libsnapgpu.so"):
+    return any(name in line for line in open("/proc/self/maps"))
+
+
+def test_native_library_is_what_runs(aligner):
+    assert _loaded_native(), "libsnapgpu.so is not mapped into this process"
+
+
+def test_tables_match_restatement(aligner):
+    lib = util.oracle_lib()
+    t = aligner.debug_tables()
+    assert (t["phred"] == np.ctypeslib.as_array(lib.oracle_phred_table(), (256,))).all()
+    assert (t["indel"] == np.ctypeslib.as_array(lib.oracle_indel_table(), (1001,))).all()
+    assert (t["perfect"] == np.ctypeslib.as_array(lib.oracle_perfect_table(), (1001,))).all()
+    assert t["seed_prob"] == lib.oracle_seed_prob(20)
+    assert [int(x) for x in t["wrapped"][:20]] == [lib.oracle_wrapped_next_seed(20, i) for i in range(20)]
+    # MAPQ thresholds reproduce (int)(-10*log10(x)) of the host libm
+    rng = np.random.default_rng(1)
+    thr = t["mapq_threshold"]
+    for _ in range(5000):
+        pa = float(rng.random() * 5); pb = float(pa * rng.random() ** 3)
+        x = 1 - pb / pa
+        m = max(i for i in range(71) if x <= thr[i]) if pb / pa < 1 else 70
+        assert m == lib.oracle_compute_mapq(pa, pb, 0, 0)
+
+
+def test_lookup_seeds_vs_reference_fixture(aligner, golden_primitives):
+    z = golden_primitives
+    nh, hits = aligner.lookupSeed32(z["seeds"], z["seed_hits"].shape[2])
+    assert (nh == z["seed_n_hits"]).all()
+    assert (hits == z["seed_hits"]).all()
+
+
+def test_lv_known_answers_and_fixture(aligner, golden_primitives):
+    texts = [c["text"].encode() for c in KATS["lv"]]
+    pats = [c["pattern"].encode() for c in KATS["lv"]]
+    got = aligner.computeEditDistance(1, texts, pats, [b"2" * len(p) for p in pats], [c["k"] for c in KATS["lv"]])
+    assert got["score"].tolist() == [c["expect"] for c in KATS["lv"]]
+    z = golden_primitives
+    for d in (1, -1):
+        tt = [t if d == 1 else t[::-1] for t in z["lv_texts"]]
+        got = aligner.computeEditDistance(d, tt, list(z["lv_pats"]), list(z["lv_quals"]), z["lv_k"])
+        for key in ("score", "match_probability", "net_indel", "total_indels", "text_span"):
+            assert (got[key] == z["lv%+d_%s" % (d, key)]).all(), (d, key)
+
+
+def test_affine_gap_known_answers(golden_index):
+    from snap_amd.aligner import BaseAligner
+    # the reference's test fixture uses a 3' bonus of 5 (AffineGapVectorizedTest.cpp:9)
+    a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160, three_prime_end_bonus=5))
+    texts = [c["text"].encode() for c in KATS["ag"]]
+    pats = [c["pattern"].encode() for c in KATS["ag"]]
+    got = a.computeScoreAffine(1, texts, pats, [b"2" * len(p) for p in pats], [c["w"] for c in KATS["ag"]],
+                               [c["score_init"] for c in KATS["ag"]], [0] * len(texts), [0] * len(texts))
+    a.close()
+    assert got["ag_score"].tolist() == [c["expect"] for c in KATS["ag"]]
+
+
+def test_affine_gap_vs_reference_fixture(aligner, golden_primitives):
+    z = golden_primitives
+    n_checked = 0
+    for d in (1, -1):
+        tt = [t if d == 1 else t[::-1] for t in z["ag_texts"]]
+        got = aligner.computeScoreAffine(d, tt, list(z["ag_pats"]), list(z["ag_quals"]), z["ag_w"], z["ag_si"], z["ag_rc"],
+                                         z["ag_banded"], z["ag_clip"])
+        for i in range(len(tt)):
+            o = util.oracle_ag(d, z["ag_banded"][i], tt[i], z["ag_pats"][i], z["ag_quals"][i], z["ag_w"][i], z["ag_si"][i],
+                               z["ag_rc"][i], z["ag_clip"][i])
+            if o["stale_reads"]:
+                continue            # reference result undefined (depends on its object's history)
+            n_checked += 1
+            exp = z["ag%+d_ag_score" % d][i]
+            assert got["ag_score"][i] == exp, (d, i)
+            if exp != -1:
+                for key in ("text_offset", "pattern_offset", "n_edits", "match_probability"):
+                    assert got[key][i] == z["ag%+d_%s" % (d, key)][i], (d, i, key)
+    assert n_checked > 1000
+
+
+@pytest.mark.parametrize("name,kw", [("default_d8", dict(max_k=8)), ("lvonly_d8", dict(max_k=8, use_affine_gap=0)),
+                                     ("default_d27", dict(max_k=27)), ("emitalt_d8", dict(max_k=8, emit_alt_alignments=1))])
+def test_align_read_vs_reference_fixture(golden_index, golden_reads, name, kw):
+    from snap_amd.aligner import BaseAligner
+    z = golden_reads
+    a = BaseAligner(golden_index, abi.default_params(max_read_len=160, **kw))
+    for tag, L in (("100", 100), ("150", 150)):
+        b, q = z["b" + tag], z["q" + tag]
+        offs = np.arange(b.shape[0] + 1, dtype=np.uint64) * L
+        prim, alt = a.AlignRead(b, q, offs)
+        flagged = prim["reserved"] != 0        # reference result depends on its object's history there
+        assert flagged.sum() <= 0.005 * len(prim)
+        assert not (z["%s_%s_unstable" % (name, tag)] & ~flagged).any(), "reference-unstable read not flagged"
+        problems = util.compare_results(z["%s_%s_primary" % (name, tag)], prim, exclude=flagged)
+        ea = z["%s_%s_alt" % (name, tag)]
+        assert (ea["status"] == alt["status"])[~flagged].all()
+        sel = (ea["status"] != 0) & ~flagged
+        problems += util.compare_results(ea[sel], alt[sel], "firstALT")
+        assert not problems, problems
+        c = a.counters(reset=True)
+        exp = z["%s_%s_counters" % (name, tag)]
+        if not flagged.any():
+            assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == exp.tolist()
+    a.close()
+
+
+def test_results_do_not_depend_on_batch_order_or_size(golden_index, golden_reads):
+    from snap_amd.aligner import BaseAligner
+    z = golden_reads
+    a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+    b, q = z["b100"], z["q100"]
+    n = b.shape[0]
+    perm = np.random.default_rng(4).permutation(n)
+    offs = np.arange(n + 1, dtype=np.uint64) * 100
+    p1, _ = a.AlignRead(b, q, offs)
+    p2, _ = a.AlignRead(b[perm], q[perm], offs)
+    assert not util.compare_results(p1[perm], p2)
+    p3, _ = a.AlignRead(b[:17], q[:17], offs[:18])
+    assert not util.compare_results(p1[:17], p3)
+    a.close()
+
+
+def test_ragged_and_degenerate_reads(golden_index):
+    """Empty batch, reads shorter than a seed, mixed lengths, reads longer than max_read_len."""
+    from snap_amd.aligner import BaseAligner, SnapGpuError
+    a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+    g = golden_index.genome
+    c0 = golden_index.contigs[0].begin
+    lens = [0, 5, 19, 20, 21, 63, 64, 65, 100, 160]
+    bases = np.concatenate([g[c0 + 300:c0 + 300 + L] for L in lens]).astype(np.uint8)
+    quals = np.full(bases.size, ord("I"), dtype=np.uint8)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    prim, _ = a.AlignRead(bases, quals, offs)
+    for i, L in enumerate(lens):
+        if L < 20:
+            assert prim["status"][i] == abi.NOT_FOUND and prim["location"][i] == abi.INVALID_GENOME_LOCATION_32
+        else:
+            # an exact copy of the reference aligns where it came from with score 0
+            assert prim["status"][i] != abi.NOT_FOUND and prim["score"][i] == 0, (L, prim[i])
+            assert prim["location"][i] == c0 + 300 and prim["direction"][i] == 0
+    e, _ = a.AlignRead(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert e.size == 0
+    with pytest.raises(SnapGpuError):
+        a.AlignRead(np.full(200, ord("A"), np.uint8), np.full(200, ord("I"), np.uint8), np.array([0, 200], np.uint64))
+    a.close()
+
+
+def test_property_exact_copies_align_to_origin_at_scale(golden_index):
+    """Size-independent property on a large batch: error-free reads map to their origin, score 0,
+    and the reverse complement of a read maps to the same place on the other strand."""
+    from snap_amd.aligner import BaseAligner
+    ix = golden_index
+    rng = np.random.default_rng(8)
+    L, n = 150, 200_000
+    c = ix.contigs[1]
+    end = ix.contigs[2].begin - ix.chromosome_padding
+    pos = rng.integers(c.begin, end - L, size=n)
+    b = ix.genome[pos[:, None] + np.arange(L)[None, :]]
+    ok = (b != ord("N")).all(axis=1) & (b != ord("n")).all(axis=1)
+    b = np.ascontiguousarray(b[ok]); pos = pos[ok]
+    q = np.full(b.shape, ord("I"), dtype=np.uint8)
+    offs = np.arange(b.shape[0] + 1, dtype=np.uint64) * L
+    a = BaseAligner(ix, abi.default_params(max_k=8, max_read_len=160))
+    fwd, _ = a.AlignRead(b, q, offs)
+    rc, _ = a.AlignRead(np.ascontiguousarray(synth._COMP[b[:, ::-1]]), q, offs)
+    a.close()
+    assert (fwd["status"] != abi.NOT_FOUND).all() and (fwd["score"] == 0).all()
+    uniq = fwd["mapq"] >= 10
+    assert uniq.mean() > 0.3
+    assert (fwd["location"][uniq] == pos[uniq]).all() and (fwd["direction"][uniq] == 0).all()
+    assert (rc["score"] == 0).all()
+    assert (rc["location"][uniq] == pos[uniq]).all() and (rc["direction"][uniq] == 1).all()
+    assert (rc["mapq"] == fwd["mapq"]).all()
+
+
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+def test_align_read_vs_live_reference_on_fresh_genome(tmp_path):
+    """Fresh seeded genome with repeats, index built by the reference's builder on this box, 30k reads."""
+    from snap_amd.aligner import BaseAligner
+    from snap_amd.index import GenomeIndex
+    g = synth.make_genome(77, 3_000_000, n_contigs=3, repeat_frac=0.45, max_copies=400, n_run_frac=0.002)
+    fa = str(tmp_path / "ref.fa"); synth.write_fasta(fa, g)
+    ref.build_index(fa, str(tmp_path / "idx"), 20, threads=max(1, os.cpu_count() or 1))
+    ix = GenomeIndex.load_from_directory(str(tmp_path / "idx"))
+    ri = ref.RefIndex(str(tmp_path / "idx"))
+    for L, kw in ((150, dict(max_k=8)), (250, dict(max_k=20))):
+        p = abi.default_params(max_read_len=256, **kw)
+        rd = synth.make_reads(78 + L, g, 15000, L, sub=0.015, ins=0.002, dele=0.002, n_frac=0.0005)
+        pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=os.cpu_count() or 1)
+        a = BaseAligner(ix, p)
+        pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"])
+        c = a.counters()
+        a.close()
+        flagged = pg["reserved"] != 0
+        assert flagged.sum() <= 0.005 * len(pg)
+        assert not util.compare_results(pr, pg, exclude=flagged)
+        if not flagged.any():
+            assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == [cr["lookups"], cr["lv"], cr["ag"]]

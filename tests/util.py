@@ -1,0 +1,134 @@
+"""Shared helpers for the test-suite (test infrastructure; may use oracle/)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from snap_amd.index import Contig, GenomeIndex
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# fields of SingleAlignmentResult the reference leaves undefined when status == NotFound
+UNDEFINED_WHEN_NOT_FOUND = ("match_probability", "probability_all_candidates", "orig_location",
+                            "popular_seeds_skipped")
+
+
+def load_golden_index() -> GenomeIndex:
+    z = np.load(os.path.join(GOLDEN, "tiny_index.npz"))
+    m = z["meta"]
+    contigs = [Contig(int(b), bool(a), i, str(n)) for i, (b, a, n) in
+               enumerate(zip(z["contig_begin"], z["contig_is_alt"], z["contig_names"]))]
+    return GenomeIndex(seed_len=int(m[0]), key_bytes=int(m[1]), n_hash_tables=int(m[2]), large=bool(m[3]),
+                       location_size=int(m[4]), chromosome_padding=int(m[5]), overflow=z["overflow"],
+                       hash_blob=z["hash_blob"], table_offset=z["table_offset"], table_size=z["table_size"],
+                       genome_padded=z["genome_padded"], n_bases=int(m[6]), contigs=contigs)
+
+
+def compare_results(ref, got, what="primary", exclude=None):
+    """Field-by-field, bit-exact comparison of two RESULT_DTYPE arrays; returns list of problems.
+
+    `exclude` masks reads for which the reference's own answer is not a function of the read
+    (banded affine-gap traceback through stale cells; flagged by the GPU path in `reserved`)."""
+    problems = []
+    found = ref["status"] != 0
+    for f in ref.dtype.names:
+        if f == "reserved":
+            continue
+        ne = ref[f] != got[f]
+        if exclude is not None:
+            ne &= ~exclude
+        if f in UNDEFINED_WHEN_NOT_FOUND:
+            ne &= found
+        if ne.any():
+            i = int(np.nonzero(ne)[0][0])
+            problems.append("%s.%s differs for %d reads, first at %d: ref=%r got=%r" %
+                            (what, f, int(ne.sum()), i, ref[f][i], got[f][i]))
+    return problems
+
+
+# ---------------------------------------------------------------- C restatement (oracle/liboracle.so)
+class _AGP(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("m", "s", "o", "e", "f", "t")]
+
+
+class _OIndex(C.Structure):
+    _fields_ = [("seed_len", C.c_uint32), ("key_bytes", C.c_uint32), ("n_hash_tables", C.c_uint32),
+                ("large", C.c_uint32), ("hash_blob", C.c_void_p), ("table_offset", C.c_void_p),
+                ("table_size", C.c_void_p), ("overflow", C.c_void_p), ("n_bases", C.c_uint64)]
+
+
+_olib = None
+
+
+def oracle_lib():
+    global _olib
+    if _olib is None:
+        path = os.path.join(ROOT, "oracle", "liboracle.so")
+        if not os.path.exists(path):
+            raise RuntimeError("oracle/liboracle.so missing: run __graft_entry__.build()")
+        lib = C.CDLL(path)
+        lib.oracle_ag.restype = C.c_int
+        lib.oracle_lv.restype = C.c_int
+        lib.oracle_seed_prob.restype = C.c_double
+        lib.oracle_seed_prob.argtypes = [C.c_int]
+        lib.oracle_compute_mapq.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+        lib.oracle_phred_table.restype = C.POINTER(C.c_double)
+        lib.oracle_indel_table.restype = C.POINTER(C.c_double)
+        lib.oracle_perfect_table.restype = C.POINTER(C.c_double)
+        lib.oracle_init()
+        _olib = lib
+    return _olib
+
+
+def _padded(text: bytes, direction: int):
+    tb = b"n" * 64 + text + b"n" * 64
+    buf = C.create_string_buffer(tb, len(tb))
+    base = C.addressof(buf) + 64
+    return buf, (base if direction == 1 else base + len(text))
+
+
+def oracle_lv(direction, text, pattern, quality, k):
+    lib = oracle_lib()
+    buf, tp = _padded(text, direction)
+    pb = C.create_string_buffer(pattern + b"\0" * 8)
+    qb = C.create_string_buffer(quality + b"\0" * 8)
+    mp = C.c_double(); ni = C.c_int(); ti = C.c_int(); ts = C.c_int()
+    s = lib.oracle_lv(direction, C.c_void_p(tp), len(text), pb, qb, len(pattern), int(k), C.byref(mp), C.byref(ni),
+                      C.byref(ti), C.byref(ts))
+    return dict(score=s, match_probability=mp.value, net_indel=ni.value, total_indels=ti.value, text_span=ts.value)
+
+
+def oracle_ag(direction, banded, text, pattern, quality, w, score_init, is_rc, use_clip, params=(1, 4, 6, 1, 10, 7)):
+    lib = oracle_lib()
+    buf, tp = _padded(text, direction)
+    pb = C.create_string_buffer(pattern + b"\0" * 8)
+    qb = C.create_string_buffer(quality + b"\0" * 8)
+    to = C.c_int(); po = C.c_int(); ne = C.c_int(); mp = C.c_double(); st = C.c_int()
+    prm = _AGP(*params)
+    s = lib.oracle_ag(direction, int(banded), C.byref(prm), C.c_void_p(tp), len(text), pb, qb, len(pattern), int(w),
+                      int(score_init), int(is_rc), int(use_clip), C.byref(to), C.byref(po), C.byref(ne), C.byref(mp), C.byref(st))
+    return dict(ag_score=s, text_offset=to.value, pattern_offset=po.value, n_edits=ne.value,
+                match_probability=mp.value, stale_reads=st.value)
+
+
+def oracle_lookup(index: GenomeIndex, seed: bytes):
+    """GenomeIndex::lookupSeed32 through the C restatement; returns None if not a seed."""
+    lib = oracle_lib()
+    bases = C.c_uint64(); rc = C.c_uint64()
+    if not lib.oracle_pack_seed(seed, index.seed_len, C.byref(bases), C.byref(rc)):
+        return None
+    ix = _OIndex(index.seed_len, index.key_bytes, index.n_hash_tables, 1 if index.large else 0,
+                 index.hash_blob.ctypes.data, index.table_offset.ctypes.data, index.table_size.ctypes.data,
+                 index.overflow.ctypes.data, index.n_bases)
+    nh = (C.c_int64 * 2)(); hp = (C.c_void_p * 2)(); sg = (C.c_uint32 * 2)(); sl = (C.c_uint32 * 2)()
+    lib.oracle_lookup_seed(C.byref(ix), bases, rc, nh, hp, sg, sl)
+    out = []
+    for d in range(2):
+        n = int(nh[d])
+        if n <= 0:
+            hits = np.zeros(0, np.uint32)
+        else:
+            hits = np.ctypeslib.as_array(C.cast(hp[d], C.POINTER(C.c_uint32)), shape=(n,)).copy()
+        out.append((n, hits, int(sl[d])))
+    return out
