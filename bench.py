@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py -- aligned reads/s of the single-end hot path on N MI355X (BASELINE.json metric).
+
+One "step" = one pass of BaseAligner::AlignRead (reference defaults, -d 8, seed 20) over a batch
+of synthetic 150 bp reads whose bytes already sit in HBM when the clock starts; results stay in
+HBM.  Workload = BASELINE.json configs[1] ("1M synthetic 150 bp single-end reads vs GRCh38,
+seed=20, maxDist=8, 1xMI355X") with GRCh38 replaced by the seeded synthetic genome BASELINE.md
+prescribes when GRCh38 is unavailable (no network here): --genome-mb (default 256) Mb, 30 % of
+bases in planted repeat families (copy number 2-5000, 0-5 % divergence).
+
+N > 1: one process per GPU (torch.distributed.run), reads sharded (each rank aligns its own
+--reads reads: weak scaling), no data-path collective; the index is read by rank 0 and
+broadcast once over RCCL into every rank's HBM before the clock starts.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel (k_align_single) against the HBM roofline: algorithmic bytes per
+               launch (DESIGN.md "Algorithmic bytes") / average launch duration measured with
+               hipEvents on the launch stream inside libsnapgpu.so
+  cpu_baseline the compiled reference (oracle/_ref, unmodified SNAP 2.0.5) timed on this box's
+               host cores on a bounded sample of the same reads (N = 1, rank 0 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def ensure_index(args, rank):
+    """Genome + SNAP index directory under /tmp, built once per box with the reference's own
+    `snap-aligner index` (the index is an input artefact in the reference's on-disk format; this
+    repo only loads it -- SURVEY.md section 2 row 5)."""
+    from snap_amd import synth
+    tag = "g%d_s%d_seed%d" % (args.genome_mb, args.seed_len, args.seed)
+    work = os.path.join(args.workdir, tag)
+    done = os.path.join(work, "idx", "GenomeIndex")
+    t0 = time.time()
+    genome = synth.make_genome(args.seed, args.genome_mb * 1_000_000, n_contigs=max(1, min(24, args.genome_mb // 8)),
+                               repeat_frac=0.30, max_copies=5000, repeat_len=(200, 3000), max_divergence=0.05)
+    log("genome %d Mb generated in %.1fs" % (args.genome_mb, time.time() - t0))
+    if rank == 0 and not os.path.exists(done):
+        from oracle import ref          # reference index builder == the cpu_baseline's own set-up step
+        os.makedirs(work, exist_ok=True)
+        fa = os.path.join(work, "ref.fa")
+        synth.write_fasta(fa, genome)
+        t1 = time.time()
+        ref.build_index(fa, os.path.join(work, "idx"), args.seed_len, threads=os.cpu_count() or 8)
+        log("reference index build: %.1fs" % (time.time() - t1))
+        os.remove(fa)
+    return genome, os.path.join(work, "idx")
+
+
+def algorithmic_bytes(c, read_len, n_reads):
+    """SURVEY.md 8(d) / DESIGN.md: bytes the algorithm is entitled to move for the work done."""
+    probe = 8 * c["n_hash_slots_probed"] + 4 * c["n_overflow_lists"] + 4 * c["n_hits_consumed"]
+    lv = c["n_lv_ref_bytes"]
+    reads = (2 * read_len + 88) * n_reads
+    return probe + lv + reads, dict(probe=probe, lv_reference=lv, reads_and_results=reads)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome-mb", type=int, default=256)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--seed-len", type=int, default=20)
+    ap.add_argument("--max-k", type=int, default=8)
+    ap.add_argument("--seed", type=int, default=20260925)
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline (0 = auto, ~10-30 s)")
+    ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
+    args = ap.parse_args()
+
+    import torch
+    from snap_amd import abi, synth
+    from snap_amd import dist as sd
+    from snap_amd.aligner import BaseAligner
+    from snap_amd.index import GenomeIndex
+
+    rank, world, local_rank = sd.env_rank_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist = sd.init_process_group("nccl")
+
+    # ---------------------------------------------------------------- set-up (untimed)
+    genome, idx_dir = ensure_index(args, rank)
+    if dist is not None:
+        dist.barrier()
+    params = abi.default_params(max_k=args.max_k, max_read_len=((args.read_len + 15) // 16) * 16)
+    t0 = time.time()
+    if world == 1:
+        index = GenomeIndex.load_from_directory(idx_dir)
+        aligner = BaseAligner(index, params, device=local_rank)
+        keep = None
+    else:
+        index = GenomeIndex.load_from_directory(idx_dir) if rank == 0 else None
+        index, blobs = sd.broadcast_index(index, dev)          # RCCL broadcast HBM -> HBM
+        keep = blobs
+        aligner = BaseAligner(index, params, device=local_rank,
+                              device_index_ptrs=(blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr()))
+    index_bytes = sum(int(x) for x in getattr(index, "_device_sizes", (index.hash_blob.size, index.overflow.size, index.genome_padded.size)))
+    log("rank %d: index resident in HBM after %.1fs" % (rank, time.time() - t0))
+
+    reads = synth.make_reads(args.seed + 1000 + rank, genome, args.reads, args.read_len)   # 1% sub, .05% ins/del, 50% RC, Q20-40
+    n = args.reads
+    d_bases = torch.from_numpy(reads["bases"].reshape(-1)).to(dev)
+    d_quals = torch.from_numpy(reads["quals"].reshape(-1)).to(dev)
+    d_offs = torch.from_numpy(reads["offsets"].astype(np.int64)).to(dev)
+    d_prim = torch.zeros(n * abi.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        aligner.align_device(n, d_bases.data_ptr(), d_quals.data_ptr(), d_offs.data_ptr(), d_prim.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    aligner.counters(reset=True)
+    aligner.kernel_time(reset=True)
+
+    # ---------------------------------------------------------------- timed region
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        elapsed = sd.max_over_ranks(elapsed, dev)
+
+    counters = aligner.counters()
+    kernel_ms, launches = aligner.kernel_time()
+    prim = np.frombuffer(d_prim.cpu().numpy().tobytes(), dtype=abi.RESULT_DTYPE)
+    if rank != 0:
+        return
+
+    # ---------------------------------------------------------------- report (rank 0)
+    total_reads = n * world * args.steps
+    value = total_reads / elapsed
+    per_launch = {k: v / max(1, launches) for k, v in counters.items()}
+    alg_bytes, parts = algorithmic_bytes(per_launch, args.read_len, n)
+    avg_ms = kernel_ms / max(1, launches)
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "aligned reads/sec (whole node), 150 bp single-end vs synthetic %d Mb genome (GRCh38 unavailable), seed=20, maxDist=%d" % (args.genome_mb, args.max_k),
+        "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8 bases / int32 DP / f64 match probability", "data": "synthetic",
+        "config": {"workload": "configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
+                              % (n, args.read_len, args.max_k, args.seed_len, args.genome_mb),
+                   "reads_per_gpu": n, "read_len": args.read_len, "index_bytes_hbm": index_bytes,
+                   "parallelism": "reads sharded over %d GPU(s), index replicated%s" % (world, " by RCCL broadcast" if world > 1 else "")},
+        "roofline": {"kernel": "k_align_single", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "algorithmic_bytes_per_launch": alg_bytes, "bytes_breakdown": parts, "avg_launch_ms": avg_ms,
+                     "per_read": {"hash_lookups": per_launch["n_hash_table_lookups"] / n, "hash_slots": per_launch["n_hash_slots_probed"] / n,
+                                  "hits": per_launch["n_hits_consumed"] / n, "lv_locations": per_launch["n_lv_locations"] / n,
+                                  "ag_locations": per_launch["n_ag_locations"] / n}},
+        "aligned_fraction": float((prim["status"] != 0).mean()),
+    }
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc):
+        try:
+            t = json.load(open(pmc))
+            if t.get("reads_per_launch") == n and t.get("genome_mb") == args.genome_mb:
+                out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    if world == 1 and not args.skip_cpu:
+        from oracle import ref                                       # cpu_baseline leg only
+        cores = os.cpu_count() or 1
+        ri = ref.RefIndex(idx_dir)
+        sample = args.cpu_sample or min(n, 50_000)
+        pr, _, _, secs = ri.align_single(params, reads["bases"][:sample], reads["quals"][:sample],
+                                         reads["offsets"][:sample + 1], threads=cores)
+        if not args.cpu_sample:                                      # scale the sample to ~15 s of CPU work
+            rate = sample / secs
+            sample = int(min(n, max(sample, rate * 15)))
+            pr, _, _, secs = ri.align_single(params, reads["bases"][:sample], reads["quals"][:sample],
+                                             reads["offsets"][:sample + 1], threads=cores)
+        out["cpu_baseline"] = {"value": sample / secs, "unit": "reads/s", "cores": cores, "kind": "reference",
+                               "sample": "first %d reads of the same batch, BaseAligner::AlignRead via oracle/_ref (SNAP 2.0.5 built -O3), %d threads, align phase only" % (sample, cores)}
+        # the baseline's results double as a parity spot check of the timed GPU output
+        from tests.util import compare_results
+        flagged = prim["reserved"][:sample] != 0
+        problems = compare_results(pr, prim[:sample], exclude=flagged)
+        out["parity_check"] = {"reads": sample, "mismatching_fields": problems, "reference_unstable_flagged": int(flagged.sum())}
+    print(json.dumps(out))
+    aligner.close()
+    del keep
+
+
+if __name__ == "__main__":
+    main()

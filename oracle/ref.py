@@ -44,7 +44,7 @@ def lib():
 def build_index(fasta: str, out_dir: str, seed_len: int = 20, threads: int = 8, large: bool = False,
                 extra=()) -> None:
     """`snap-aligner index <fasta> <dir> -s N` with the reference's own builder."""
-    cmd = [CLI_PATH, "index", fasta, out_dir, "-s", str(seed_len), "-t%d" % threads]
+    cmd = [CLI_PATH, "index", fasta, out_dir, "-s", str(seed_len), "-t%d" % max(1, min(int(threads), 100))]   # GenomeIndex.cpp:213 caps -t at 100
     if large:
         cmd.append("-large")
     cmd += list(extra)

@@ -76,8 +76,9 @@ class BaseAligner:
         v.large_hash_table = 1 if index.large else 0
         v.location_size = index.location_size
         v.chromosome_padding = index.chromosome_padding
-        v.overflow_table_size = index.overflow.size
-        v.hash_blob_bytes = index.hash_blob.size
+        sizes = getattr(index, "_device_sizes", None)      # set by dist.broadcast_index on every rank
+        v.overflow_table_size = sizes[1] if sizes else index.overflow.size
+        v.hash_blob_bytes = sizes[0] if sizes else index.hash_blob.size
         toff = np.ascontiguousarray(index.table_offset, dtype=np.uint64)
         tsz = np.ascontiguousarray(index.table_size, dtype=np.uint64)
         cb = np.ascontiguousarray(index.contig_begin, dtype=np.uint64)

@@ -29,7 +29,7 @@
 #include "dev_common.h"
 #include "probe.h"
 #include "lv.h"
-#include "ag.h"
+#include "ag_reg.h"
 #include "../../include/snapgpu.h"
 
 #define BUCKET 48                      // hashTableElementSize == maxMergeDist, BaseAligner.h:177,213
@@ -114,6 +114,7 @@ static __device__ __forceinline__ int compute_mapq(const DevTables *tab, double 
     return base_mapq;
 }
 
+template <int AGC>
 struct Aligner {
     // ---- constant for the launch
     const DevIndex &ix;
@@ -479,22 +480,29 @@ struct Aligner {
                         int loc_offset = 0;
                         const int text_len = read_len + SNAPGPU_MAX_K - tail_start;
 
-                        // forward from the end of the seed (:1160)
-                        {
-                            ByteSeq P{rd[e_dir] + tail_start, 1}, Q{ql[e_dir] + tail_start, 1}, T{data + tail_start, 1};
-                            LVResult r1 = lv_compute(P, Q, read_len - tail_start, T, text_len, limit_e, lv_tri, cfg.kmax, tab);
-                            score1 = r1.score; mp1 = r1.match_probability;
-                            cnt.lv_ref_bytes += (uint64_t)(read_len - tail_start) + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e));
-                        }
-                        ag1 = (seed_len + read_len - tail_start - score1) * cfg.match_reward - score1 * cfg.sub_penalty;
-                        if (score1 != -1) {
-                            // backwards from the start of the seed over the reversed head of the read (:1169)
-                            int limit_left = limit_e - score1;
-                            ByteSeq P{rd[e_dir] + seed_offset - 1, -1}, Q{ql[e_dir] + seed_offset - 1, -1}, T{data + seed_offset - 1, -1};
-                            LVResult r2 = lv_compute(P, Q, seed_offset, T, seed_offset + SNAPGPU_MAX_K, limit_left, lv_tri, cfg.kmax, tab);
-                            score2 = r2.score; mp2 = r2.match_probability; loc_offset = r2.net_indel;
-                            ag2 = (seed_offset - score2) * cfg.match_reward - score2 * cfg.sub_penalty;
-                            cnt.lv_ref_bytes += (uint64_t)seed_offset;
+                        // Two halves, one call site each for LV and AG (half 0: forward from the end of the seed
+                        // over the tail of the read, :1160; half 1: backwards from the start of the seed over the
+                        // reversed head of the read, :1169).  The backward text/pattern are the same bytes walked
+                        // with stride -1, so LandauVishkin<1> and <-1> are one instantiation.
+                        const uint8_t *rdd = rd[e_dir], *qld = ql[e_dir];
+                        for (int half = 0; half < 2; half++) {
+                            if (half == 1 && score1 == -1) break;
+                            const int st = half == 0 ? 1 : -1;
+                            const int org = half == 0 ? tail_start : seed_offset - 1;
+                            const int plen = half == 0 ? read_len - tail_start : seed_offset;
+                            const int tlen = half == 0 ? text_len : seed_offset + SNAPGPU_MAX_K;
+                            const int lim = half == 0 ? limit_e : limit_e - score1;
+                            ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+                            LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab);
+                            if (half == 0) {
+                                score1 = r.score; mp1 = r.match_probability;
+                                ag1 = (seed_len + read_len - tail_start - score1) * cfg.match_reward - score1 * cfg.sub_penalty;
+                                cnt.lv_ref_bytes += (uint64_t)plen + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e));
+                            } else {
+                                score2 = r.score; mp2 = r.match_probability; loc_offset = r.net_indel;
+                                ag2 = (seed_offset - score2) * cfg.match_reward - score2 * cfg.sub_penalty;
+                                cnt.lv_ref_bytes += (uint64_t)plen;
+                            }
                         }
                         cnt.lv++;
 
@@ -505,27 +513,25 @@ struct Aligner {
                                 used_ag = 1;
                                 cnt.ag++;
                                 AGParams agp{cfg.match_reward, cfg.sub_penalty, cfg.gap_open, cfg.gap_extend, cfg.five_bonus, cfg.three_bonus};
-                                if (tail_start != read_len) {
-                                    int pat_len = read_len - tail_start;
-                                    bool banded = pat_len >= 3 * (2 * limit_e + 1);
-                                    ByteSeq P{rd[e_dir] + tail_start, 1}, Q{ql[e_dir] + tail_start, 1}, T{data + tail_start, 1};
-                                    AGResult a1 = ag_compute(banded, 1, agp, P, Q, pat_len, T, text_len, limit_e, read_len, e_dir != 0,
-                                                             false, ag_rows, ag_scratch, cfg.RL, tab);
-                                    ag1 = a1.ag_score; clip_after = a1.pattern_offset; score1 = a1.n_edits; mp1 = a1.match_probability;
-                                    ag_stale += (uint32_t)a1.stale_reads;
-                                    ag1 += (seed_len - read_len);
-                                }
-                                if (score1 != -1) {
-                                    if (seed_offset != 0) {
-                                        int limit_left = limit_e - score1;
-                                        bool banded = seed_offset >= 3 * (2 * limit_left + 1);
-                                        ByteSeq P{rd[e_dir] + seed_offset - 1, -1}, Q{ql[e_dir] + seed_offset - 1, -1}, T{data + seed_offset - 1, -1};
-                                        AGResult a2 = ag_compute(banded, -1, agp, P, Q, seed_offset, T, seed_offset + limit_left, limit_left, read_len,
-                                                                 e_dir != 0, false, ag_rows, ag_scratch, cfg.RL, tab);
-                                        ag2 = a2.ag_score; clip_before = a2.pattern_offset; score2 = a2.n_edits; mp2 = a2.match_probability;
-                                        ag_stale += (uint32_t)a2.stale_reads;
-                                        loc_offset = a2.text_offset;
-                                        ag2 -= read_len;
+                                for (int half = 0; half < 2; half++) {
+                                    if (half == 0 && tail_start == read_len) continue;               // :1208
+                                    if (half == 1 && (score1 == -1 || seed_offset == 0)) break;      // :1244-1245
+                                    const int st = half == 0 ? 1 : -1;
+                                    const int org = half == 0 ? tail_start : seed_offset - 1;
+                                    const int plen = half == 0 ? read_len - tail_start : seed_offset;
+                                    const int lim = half == 0 ? limit_e : limit_e - score1;
+                                    const int tlen = half == 0 ? text_len : seed_offset + lim;
+                                    const bool banded = plen >= 3 * (2 * lim + 1);                   // :1213 / :1251
+                                    ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+                                    AGResult a = ag_dispatch<AGC>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, e_dir != 0,
+                                                                  false, ag_rows, ag_scratch, cfg.RL, tab);
+                                    ag_stale += (uint32_t)a.stale_reads;
+                                    if (half == 0) {
+                                        ag1 = a.ag_score + (seed_len - read_len); clip_after = a.pattern_offset;
+                                        score1 = a.n_edits; mp1 = a.match_probability;
+                                    } else {
+                                        ag2 = a.ag_score - read_len; clip_before = a.pattern_offset;
+                                        score2 = a.n_edits; mp2 = a.match_probability; loc_offset = a.text_offset;
                                     }
                                 }
                             }

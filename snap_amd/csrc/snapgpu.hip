@@ -17,7 +17,7 @@
 #include "dev_common.h"
 #include "probe.h"
 #include "lv.h"
-#include "ag.h"
+#include "ag_reg.h"
 #include "align_single.h"
 
 // =====================================================================================
@@ -56,6 +56,7 @@ static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uin
     return L;
 }
 
+template <int AGC>
 __global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
     const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax, a.cfg.use_ag);
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
-    Aligner al(a.ix, a.tab, a.cfg);
+    Aligner<AGC> al(a.ix, a.tab, a.cfg);
     al.lane = lane;
     al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
     al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
@@ -184,6 +185,7 @@ struct AGBatchArgs {
 };
 
 // One wave per problem: AffineGapVectorized<dir>::computeScore / computeScoreBanded.
+template <int AGC>
 __global__ __launch_bounds__(64) void k_ag_batch(AGBatchArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -198,11 +200,11 @@ __global__ __launch_bounds__(64) void k_ag_batch(AGBatchArgs a)
         AGResult r;
         if (a.dir == 1) {
             ByteSeq P{p, 1}, Q{q, 1}, T{t, 1};
-            r = ag_compute(a.banded[i] != 0, 1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
+            r = ag_dispatch<AGC>(a.banded[i] != 0, 1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
                            a.use_clip[i] != 0, rows, bt, a.RL, a.tab);
         } else {
             ByteSeq P{p, 1}, Q{q, 1}, T{t - 1, -1};
-            r = ag_compute(a.banded[i] != 0, -1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
+            r = ag_dispatch<AGC>(a.banded[i] != 0, -1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
                            a.use_clip[i] != 0, rows, bt, a.RL, a.tab);
         }
         if (lane == 0) {
@@ -241,6 +243,7 @@ struct snapgpu_ctx {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     int num_cus = 0;
+    int ag_variant = 0;               // chunks of 64 striped positions the affine-gap kernel variant holds in registers (0 = LDS form)
     std::string err;
 };
 
@@ -472,6 +475,11 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     c.pool_size = (uint32_t)pool;
     c.ht_size = next_pow2((uint32_t)pool * 2);
     c.ag_numvec_max = (c.RL + 7) / 8;
+    {   // affine-gap kernel variant: patterns are at most max_read_len - seed_len long, limits at most kmax
+        int need = ag_max_positions((int)p->max_read_len - (int)idx->seed_len, (int)kmax);
+        ctx->ag_variant = need <= 192 ? 3 : need <= 256 ? 4 : need <= 384 ? 6 : 0;
+        if (getenv("SNAPGPU_AG_LDS")) ctx->ag_variant = 0;
+    }
     size_t ag_bytes = c.use_ag ? ag_scratch_bytes(c.RL) : 0;
     c.scratch_stride = ((size_t)c.ht_size * 2 + (size_t)c.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
     LdsLayout L = lds_layout(c.RL, c.num_weight_lists, c.kmax, c.use_ag);
@@ -487,9 +495,8 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     ctx->n_wave_slots = (ctx->n_wave_slots + 3) & ~3u;
     size_t scratch_total = (size_t)ctx->n_wave_slots * c.scratch_stride;
     CRCHK(hipMalloc((void **)&ctx->d_scratch, scratch_total), SNAPGPU_E_NOMEM);
-    // only the head tables need to start zeroed
-    for (uint32_t w = 0; w < ctx->n_wave_slots; w++)
-        CRCHK(hipMemsetAsync(ctx->d_scratch + (size_t)w * c.scratch_stride, 0, (size_t)c.ht_size * 2, ctx->stream), SNAPGPU_E_NODEVICE);
+    // the head tables must start zeroed (one fill of the whole slab is cheaper than a fill per wave)
+    CRCHK(hipMemsetAsync(ctx->d_scratch, 0, scratch_total, ctx->stream), SNAPGPU_E_NODEVICE);
     CRCHK(hipMalloc((void **)&ctx->d_work, 256), SNAPGPU_E_NOMEM);
     CRCHK(hipMalloc((void **)&ctx->d_counters, sizeof(snapgpu_counters)), SNAPGPU_E_NOMEM);
     CRCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(snapgpu_counters), ctx->stream), SNAPGPU_E_NODEVICE);
@@ -649,7 +656,18 @@ extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
     a.ag_score = (int32_t *)o1.p; a.text_offset = (int32_t *)o2.p; a.pattern_offset = (int32_t *)o3.p;
     a.n_edits = (int32_t *)o4.p; a.prob = (double *)o5.p; a.tab = ctx->d_tab; a.stale = nullptr;
     uint32_t lds = (ag_lds_bytes(RL) + 15) & ~15u;
-    hipLaunchKernelGGL(k_ag_batch, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
+    // variant by the largest striped layout in this batch (chunks of 64 positions)
+    int need = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        int nv, sl, ns; int ww = w[i] > 126 ? 126 : (w[i] < 0 ? 0 : w[i]);
+        ag_dims(banded[i] != 0, pat_len[i], ww, &nv, &sl, &ns);
+        if (ns * sl > need) need = ns * sl;
+    }
+    if (getenv("SNAPGPU_AG_LDS")) need = 1 << 20;
+    if (need <= 192)      hipLaunchKernelGGL(k_ag_batch<3>, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
+    else if (need <= 256) hipLaunchKernelGGL(k_ag_batch<4>, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
+    else if (need <= 384) hipLaunchKernelGGL(k_ag_batch<6>, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
+    else                  hipLaunchKernelGGL(k_ag_batch<0>, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(ag_score, o1.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(text_offset, o2.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
@@ -672,7 +690,12 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     uint32_t blocks = ctx->n_wave_slots / 4;
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
-    hipLaunchKernelGGL(k_align_single, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a);
+    switch (ctx->ag_variant) {
+    case 3:  hipLaunchKernelGGL(k_align_single<3>, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
+    case 4:  hipLaunchKernelGGL(k_align_single<4>, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
+    case 6:  hipLaunchKernelGGL(k_align_single<6>, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
+    default: hipLaunchKernelGGL(k_align_single<0>, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
+    }
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
     return SNAPGPU_OK;
