@@ -183,6 +183,10 @@ def main():
                                   "ag_locations": per_launch["n_ag_locations"] / n}},
         "aligned_fraction": float((prim["status"] != 0).mean()),
     }
+    tot = max(1, counters.get("cycles_total", 0))
+    out["roofline"]["wave_cycle_breakdown"] = {k[7:]: counters[k] / tot for k in
+                                              ("cycles_lookup", "cycles_hits", "cycles_lv", "cycles_ag") if k in counters}
+    out["roofline"]["wave_cycles_per_read"] = counters.get("cycles_total", 0) / max(1, counters["n_reads"])
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:

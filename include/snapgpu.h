@@ -158,7 +158,13 @@ typedef struct snapgpu_counters {
     uint64_t n_lv_locations;            /* nLocationsScoredWithLandauVishkin             */
     uint64_t n_ag_locations;            /* nLocationsScoredWithAffineGap                 */
     uint64_t n_lv_ref_bytes;            /* reference bytes the LV calls were entitled to */
-    uint64_t reserved[8];
+    /* wave-cycles (shader clock) summed over all waves, for profile breakdowns */
+    uint64_t cycles_lookup;             /* lookup_seed: hash probes + overflow header             */
+    uint64_t cycles_hits;               /* candidate-table updates for the hits of a lookup        */
+    uint64_t cycles_lv;                 /* Landau-Vishkin (both halves)                            */
+    uint64_t cycles_ag;                 /* affine gap (both halves)                                */
+    uint64_t cycles_total;              /* whole AlignRead                                         */
+    uint64_t reserved[3];
 } snapgpu_counters;
 
 typedef struct snapgpu_ctx snapgpu_ctx;

@@ -90,7 +90,12 @@ class Counters(C.Structure):
         ("n_lv_locations", C.c_uint64),
         ("n_ag_locations", C.c_uint64),
         ("n_lv_ref_bytes", C.c_uint64),
-        ("reserved", C.c_uint64 * 8),
+        ("cycles_lookup", C.c_uint64),
+        ("cycles_hits", C.c_uint64),
+        ("cycles_lv", C.c_uint64),
+        ("cycles_ag", C.c_uint64),
+        ("cycles_total", C.c_uint64),
+        ("reserved", C.c_uint64 * 3),
     ]
 
     def as_dict(self):

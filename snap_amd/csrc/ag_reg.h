@@ -2,25 +2,28 @@
 //
 // ag.h keeps the DP rows in LDS in the reference's striped order and moves data between lanes
 // through the LDS crossbar (ds_bpermute); a wave then spends its time waiting on ~100-cycle
-// cross-lane round trips, ~3 ms per call.  Here the same arithmetic is laid out in *pattern
-// order*: wavefront lane L of chunk c owns pattern position p = 64c + L for the whole call.
+// cross-lane round trips.  Here the same arithmetic is laid out in *pattern order*: wavefront
+// lane L of chunk c owns pattern position p = 64c + L for the whole call.
 //   * In striped terms position p is SSE lane (p % segLen) / numVec, vector (p % segLen) % numVec,
 //     and the striped code's "previous vector, same SSE lane" / "shifted last vector" inputs are
 //     always simply position p-1.  H(i-1, p-1) therefore arrives with one DPP wave_shr:1 of the
 //     register that holds the previous row -- no LDS, no bpermute.  H, H-1 and E live in VGPRs
-//     (AG_MAXC chunks of 64 positions), so stale out-of-band cells and the reference's H/H-1
-//     pointer swap are reproduced for free.
-//   * The first pass's F chain restarts at every stripe (sub-segment of numVec positions).  With
+//     (AGC chunks of 64 positions), so stale out-of-band cells and the reference's H/H-1 pointer
+//     swap are reproduced for free.
+//   * The first pass's F chain restarts at every stripe (numVec consecutive positions).  With
 //     g(p) = max(m-open,0) + p*ext + BIG*stripe(p), F is a plain 64-lane prefix max of g done with
 //     six DPP steps (row_shr 1/2/4/8, row_bcast 15/31): the BIG term makes earlier stripes lose.
-//   * Lazy F: the eight stripe-end F values sit in lanes 0-7 of one register; a round evaluates
-//     every position at once (each lane knows its vector index, hence how far F has decayed when
-//     the reference's walk reaches it).  The reference's "stop at the first vector where no SSE
-//     lane still has F > H - open" becomes: stop vector = first vector index with no such lane,
-//     found with a ballot (common case: vector 0) or a 64-bit LDS bitmap.
-//   * Traceback bytes are written once per cell, after lazy F, 64 consecutive bytes per store.
-// The choice between local and global alignment, the clipping heuristics and the traceback walk
-// are the same scalar code as ag.h.  Patterns longer than 64*AG_MAXC - stripe slack use ag.h.
+//   * Lazy F: "the F that leaves stripe l enters stripe l+1" is the same kind of tagged prefix
+//     max (stripe-end cells publish value + BIG*(l+1), every lane picks up the entry tagged with
+//     its own stripe).  A round evaluates every position at once -- each lane knows its vector
+//     index, hence how far F has decayed when the reference's walk reaches it -- and the
+//     reference's "stop at the first vector where no SSE lane still has F > H - open" becomes
+//     "first vector index with no such lane": a ballot in the common case, a 64-bit LDS bitmap
+//     otherwise.
+//   * Traceback bytes are written once per cell, after lazy F, 64 consecutive bytes per store,
+//     and read back 64 diagonal steps per load (one round trip per gap-free stretch).
+// The choice between local and global alignment and the clipping heuristics are the scalar code
+// of ag.h.
 #pragma once
 #include "ag.h"
 
@@ -57,9 +60,9 @@ struct AGPos {
     __device__ __forceinline__ bool valid() const { return (w >> 24) & 1; }
 };
 
-template <int AG_MAXC, typename PSeq, typename TSeq, typename QSeq>
+template <int AGC, bool BANDED, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_compute_reg(
-    bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
+    int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, bool use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
     int num_vec, int seg_len, int num_seg)
@@ -72,17 +75,16 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     const int tot = num_seg * seg_len;                  // positions that exist in the striped layout
     const int nch = (tot + 63) >> 6;
     const int row_stride = nch * 64;
-    int *lds_f = (int *)lds_rows;                       // [8] stripe-entry F of the current lazy round
-    unsigned long long *lds_bits = (unsigned long long *)(lds_f + 8);
+    unsigned long long *lds_bits = (unsigned long long *)lds_rows;
 
     int end_bonus;
     if (!is_rc) end_bonus = dir == -1 ? prm.five_bonus : prm.three_bonus;
     else        end_bonus = dir == -1 ? prm.three_bonus : prm.five_bonus;
 
-    AGPos pos[AG_MAXC];
-    int Hp[AG_MAXC], Hm[AG_MAXC], E[AG_MAXC];
+    AGPos pos[AGC];
+    int Hp[AGC], Hm[AGC], E[AGC];
 #pragma unroll
-    for (int c = 0; c < AG_MAXC; c++) {
+    for (int c = 0; c < AGC; c++) {
         const int p = c * 64 + lane;
         uint32_t wd = 0; int hv = 0;
         if (c < nch && p < tot) {
@@ -90,78 +92,94 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
             int pb = p < pattern_len ? (int)base_value(P(p)) : 5;
             wd = (uint32_t)k | ((uint32_t)l << 10) | ((uint32_t)j << 13) | ((uint32_t)pb << 21) | (1u << 24);
             // first row (:399-414 / :971-983) incl. the stale scoreFirstRow[] inheritance of padding lanes
-            int vi = j * num_vec + k;
-            for (int v = vi; v >= 0; v--) {
-                int pi = (v / num_vec) * seg_len + l * num_vec + (v % num_vec);
-                if (pi < pattern_len) { int x = score_init - gap_open - pi * gap_ext; hv = x > 0 ? x : 0; break; }
+            if (p < pattern_len) {
+                int x = score_init - gap_open - p * gap_ext; hv = x > 0 ? x : 0;
+            } else {
+                int vi = j * num_vec + k;
+                for (int v = vi - 1; v >= 0; v--) {
+                    int pi = (v / num_vec) * seg_len + l * num_vec + (v % num_vec);
+                    if (pi < pattern_len) { int x = score_init - gap_open - pi * gap_ext; hv = x > 0 ? x : 0; break; }
+                }
             }
         }
         pos[c].w = wd; Hp[c] = hv; Hm[c] = 0; E[c] = 0;
     }
 
     int best_global = -1, best_global_text = -1, best_local = -1, best_local_text = -1, best_local_pat = -1;
+    // band bookkeeping without per-row divisions: segment of band_beg / band_end advances monotonically
+    int seg_beg = 0, seg_end = 0;
+    const int pe_glob = pattern_len - 1, pe_glob_c = pe_glob >> 6, pe_glob_l = pe_glob & 63;
 
     for (int i = 0; i < text_len; i++) {
         const int tb = (int)base_value(T(i));
-        int band_beg = 0, band_end = pattern_len - 1, seg_beg = 0, seg_end = 0;
-        if (banded) {
+        int band_beg = 0, band_end = pattern_len - 1;
+        if (BANDED) {
             band_beg = i - w > 0 ? i - w : 0;
             band_end = i + w < pattern_len - 1 ? i + w : pattern_len - 1;
-            seg_beg = band_beg / seg_len; seg_end = band_end / seg_len;
+            while ((seg_beg + 1) * seg_len <= band_beg) seg_beg++;
+            while ((seg_end + 1) * seg_len <= band_end) seg_end++;
         }
         int h_init0 = score_init;
         if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
         int mxv = 0, X0 = 0, fin = 0;
-        int btr[AG_MAXC], fo[AG_MAXC];
-        bool did[AG_MAXC];
+        int btr[AGC];
+        bool did[AGC];
 #pragma unroll
-        for (int c = 0; c < AG_MAXC; c++) { btr[c] = 0; fo[c] = 0; did[c] = false; }
+        for (int c = 0; c < AGC; c++) { btr[c] = 0; did[c] = false; }
+        int row_c_lo = AGC, row_c_hi = -1;
 
         for (int j = seg_beg; j <= seg_end; j++) {
+            const int seg_start = j * seg_len;
             int nk = num_vec;
-            if (banded) { int lim = band_end - j * seg_len + 1; if (lim < nk) nk = lim; }
-            const int c_lo = (j * seg_len) >> 6;
-            int c_hi = ((j + 1) * seg_len - 1) >> 6; if (c_hi > nch - 1) c_hi = nch - 1;
-            const bool zero_seg_start = banded && j > 0 && band_beg > j * seg_len;
+            if (BANDED) { int lim = band_end - seg_start + 1; if (lim < nk) nk = lim; }
+            const int c_lo = seg_start >> 6;
+            int c_hi = (seg_start + seg_len - 1) >> 6; if (c_hi > nch - 1) c_hi = nch - 1;
+            if (c_lo < row_c_lo) row_c_lo = c_lo;
+            if (c_hi > row_c_hi) row_c_hi = c_hi;
+            const bool zero_seg_start = BANDED && j > 0 && band_beg > seg_start;
 
             // ---------------- first pass
+            int endv[AGC];                       // F leaving each cell (used at stripe-end cells)
+            bool ins[AGC], isend[AGC];
             int carry = AG_NEG;
 #pragma unroll
-            for (int c = 0; c < AG_MAXC; c++) {
+            for (int c = 0; c < AGC; c++) {
+                endv[c] = 0; ins[c] = false; isend[c] = false;
                 if (c >= c_lo && c <= c_hi) {
                     const int p = c * 64 + lane;
                     const AGPos ps = pos[c];
-                    const bool inseg = ps.valid() && ps.j() == j && ps.k() < nk;
+                    const int k = ps.k(), l = ps.l();
+                    const bool inseg = ps.valid() && ps.j() == j && k < nk;
+                    ins[c] = inseg; isend[c] = inseg && k == nk - 1;
                     int lane0_in = h_init0;
                     if (c > 0) lane0_in = __builtin_amdgcn_readlane(Hp[c > 0 ? c - 1 : 0], 63);
                     int h_in = ag_shr1(lane0_in, Hp[c]);
-                    if (zero_seg_start && p == j * seg_len) h_in = 0;
+                    if (zero_seg_start && p == seg_start) h_in = 0;
                     const int pb = ps.pb();
                     int prof = pb == 5 ? -32768 : ((tb > 3 || pb > 3) ? -1 : (tb == pb ? match : sub));
                     int m = h_in > 0 ? ag_sat16(h_in + prof) : 0;
                     int e = E[c];
                     int bt = e > m ? 1 : 0;
                     int hp = m > e ? m : e;
-                    int e2 = ag_sat16(e - gap_ext);
-                    int tmp = ag_sat16(m - gap_open); if (tmp < 0) tmp = 0;
+                    int e2 = e - gap_ext;
+                    int tmp = m - gap_open; if (tmp < 0) tmp = 0;
                     if (e2 > tmp) bt |= 4;
-                    const int stripe = ps.j() * 8 + ps.l();
-                    int g = inseg ? tmp + p * gap_ext + AG_BIG * stripe : AG_NEG;
+                    const int tag = AG_BIG * (j * 8 + l);
+                    int g = inseg ? tmp + p * gap_ext + tag : AG_NEG;
                     int inc = ag_prefix_max(g);
                     int exc = ag_shr1(carry, inc);
                     int pm = exc > carry ? exc : carry;
-                    const int k = ps.k();
-                    const int fin_cell = ps.l() == 0 ? fin : 0;
+                    const int fin_cell = l == 0 ? fin : 0;
                     int fk = fin_cell - k * gap_ext;
-                    if (k >= 1) { int a = pm - AG_BIG * stripe - (p - 1) * gap_ext; fk = a > fk ? a : fk; }
+                    if (k >= 1) { int a = pm - tag - (p - 1) * gap_ext; fk = a > fk ? a : fk; }
                     if (inseg) {
                         if (fk > hp) { bt |= 2; hp = fk; }
                         Hm[c] = hp;
                         E[c] = e2 > tmp ? e2 : tmp;
                         mxv = hp > mxv ? hp : mxv;
-                        int f2 = ag_sat16(fk - gap_ext);
+                        int f2 = fk - gap_ext;
                         if (f2 > tmp) bt |= 32;
-                        fo[c] = f2 > tmp ? f2 : tmp;
+                        endv[c] = f2 > tmp ? f2 : tmp;
                         btr[c] = bt; did[c] = true;
                     }
                     int last_inc = __builtin_amdgcn_readlane(inc, 63);
@@ -169,93 +187,93 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
                 }
             }
 
-            // ---------------- stripe-end F values -> lanes 0..7
-            int fvec = 0;
-#pragma unroll
-            for (int l = 0; l < 8; l++) {
-                const int pe = j * seg_len + l * num_vec + nk - 1;
-                const int pc = pe >> 6, pl = pe & 63;
-                int v = 0;
-#pragma unroll
-                for (int c = 0; c < AG_MAXC; c++) if (c == pc) v = __builtin_amdgcn_readlane(fo[c], pl);
-                if (lane == l) fvec = v;
-            }
-
-            // ---------------- lazy F
-            const int rounds = banded ? 7 : 8;
+            // ---------------- lazy F (:1080-1112 full: 8 rounds; :534-569 banded: 7 rounds + segment carry X)
+            const int pe7 = seg_start + 7 * num_vec + nk - 1;            // stripe 7's last computed cell
+            const int pe7_c = pe7 >> 6, pe7_l = pe7 & 63;
+            const int rounds = BANDED ? 7 : 8;
             for (int r = 0; r < rounds; r++) {
-                if (banded) { int f7 = __builtin_amdgcn_readlane(fvec, 7); if (f7 > X0) X0 = f7; }
-                fvec = ag_shr1(0, fvec);
-                if (lane < 8) lds_f[lane] = fvec;
-                if (lane == 8) *lds_bits = 0ull;
-                WAVE_SYNC();
-                int fj[AG_MAXC]; bool cont[AG_MAXC]; bool ins[AG_MAXC];
-                bool any_cont = false;
+                if (BANDED) {
+                    int f7 = 0;
 #pragma unroll
-                for (int c = 0; c < AG_MAXC; c++) {
-                    fj[c] = 0; cont[c] = false; ins[c] = false;
+                    for (int c = 0; c < AGC; c++) if (c == pe7_c) f7 = __builtin_amdgcn_readlane(endv[c], pe7_l);
+                    if (f7 > X0) X0 = f7;
+                }
+                int fj[AGC], fs[AGC]; bool cont[AGC];
+                unsigned long long any_cont = 0;
+                int carry2 = AG_NEG;
+#pragma unroll
+                for (int c = 0; c < AGC; c++) {
+                    fj[c] = 0; fs[c] = 0; cont[c] = false;
                     if (c >= c_lo && c <= c_hi) {
                         const AGPos ps = pos[c];
-                        ins[c] = ps.valid() && ps.j() == j && ps.k() < nk;
-                        int fv = lds_f[ps.l()];
-                        int f = fv - ps.k() * gap_ext; if (f < 0) f = 0;
+                        const int k = ps.k(), l = ps.l();
+                        // F entering this lane's stripe = F that left the previous stripe of the segment
+                        int v = isend[c] ? endv[c] + AG_BIG * (l + 1) : AG_NEG;
+                        int inc = ag_prefix_max(v);
+                        int exc = ag_shr1(carry2, inc);
+                        int pm = exc > carry2 ? exc : carry2;
+                        int last_inc = __builtin_amdgcn_readlane(inc, 63);
+                        carry2 = last_inc > carry2 ? last_inc : carry2;
+                        int f_in = pm - AG_BIG * l;
+                        if (l == 0 || f_in < 0 || f_in >= AG_BIG) f_in = 0;
+                        fs[c] = f_in;
+                        int f = f_in - k * gap_ext; if (f < 0) f = 0;
                         int hn = Hm[c] > f ? Hm[c] : f;
                         int t2 = hn > gap_open ? hn - gap_open : 0;
                         int f2 = f > gap_ext ? f - gap_ext : 0;
                         fj[c] = f;
                         cont[c] = ins[c] && (f2 > t2);
-                        if (__ballot(cont[c])) any_cont = true;
+                        any_cont |= __ballot(cont[c]);
                     }
                 }
                 int jstar = 0;
                 if (any_cont) {
+                    if (lane == 0) *lds_bits = 0ull;
+                    WAVE_SYNC();
 #pragma unroll
-                    for (int c = 0; c < AG_MAXC; c++)
+                    for (int c = 0; c < AGC; c++)
                         if (c >= c_lo && c <= c_hi && cont[c]) atomicOr(lds_bits, 1ull << pos[c].k());
                     WAVE_SYNC();
-                    unsigned long long bits = *lds_bits;
-                    bits = first_u64(bits);
+                    unsigned long long bits = first_u64(*lds_bits);
                     jstar = (~bits == 0ull) ? 64 : (__ffsll((long long)~bits) - 1);
                 }
                 const bool round_complete = jstar >= nk;        // never converged in this round
                 const int jlim = round_complete ? nk - 1 : jstar;
 #pragma unroll
-                for (int c = 0; c < AG_MAXC; c++) {
+                for (int c = 0; c < AGC; c++) {
                     if (c >= c_lo && c <= c_hi) {
                         if (ins[c] && pos[c].k() <= jlim) {
                             if (fj[c] > Hm[c]) { btr[c] |= 2; Hm[c] = fj[c]; }
                             mxv = Hm[c] > mxv ? Hm[c] : mxv;
                             if (cont[c]) btr[c] |= 32;
                         }
+                        // F of this stripe after walking all nk vectors (only consumed if the round completed)
+                        int dec = fs[c] - nk * gap_ext; endv[c] = dec > 0 ? dec : 0;
                     }
                 }
-                WAVE_SYNC();
                 if (!round_complete) break;
-                // F after walking all nk vectors of the stripe
-                int dec = fvec - nk * gap_ext; fvec = dec > 0 ? dec : 0;
             }
-            fin = banded ? X0 : 0;
+            fin = BANDED ? X0 : 0;
         }
 
         // ---------------- traceback bytes, row max, bookkeeping
         uint8_t *bt_row = bt_scratch + (size_t)i * row_stride;
 #pragma unroll
-        for (int c = 0; c < AG_MAXC; c++) if (c < nch && did[c]) bt_row[c * 64 + lane] = (uint8_t)btr[c];
+        for (int c = 0; c < AGC; c++) if (c >= row_c_lo && c <= row_c_hi && did[c]) bt_row[c * 64 + lane] = (uint8_t)btr[c];
         const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
 
-        if (!banded || band_end == pattern_len - 1) {
-            const int pe = pattern_len - 1, pc = pe >> 6, pl = pe & 63;
+        if (!BANDED || band_end == pattern_len - 1) {
             int gscore = 0;
 #pragma unroll
-            for (int c = 0; c < AG_MAXC; c++) if (c == pc) gscore = __builtin_amdgcn_readlane(Hm[c], pl);
+            for (int c = 0; c < AGC; c++) if (c == pe_glob_c) gscore = __builtin_amdgcn_readlane(Hm[c], pe_glob_l);
             if (gscore >= best_global) { best_global = gscore; best_global_text = i; }
         }
         if (max_row == 0) break;
         if (max_row > best_local) {
             int off = -1;
 #pragma unroll
-            for (int c = AG_MAXC - 1; c >= 0; c--) {
-                if (c < nch && off < 0) {
+            for (int c = AGC - 1; c >= 0; c--) {
+                if (c >= row_c_lo && c <= row_c_hi && off < 0) {
                     unsigned long long mk = __ballot(did[c] && Hm[c] == max_row);
                     if (mk) off = c * 64 + 63 - __clzll((long long)mk);
                 }
@@ -263,7 +281,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
             best_local_pat = off; best_local = max_row; best_local_text = i;
         }
 #pragma unroll
-        for (int c = 0; c < AG_MAXC; c++) { int t = Hm[c]; Hm[c] = Hp[c]; Hp[c] = t; }
+        for (int c = 0; c < AGC; c++) { int t = Hm[c]; Hm[c] = Hp[c]; Hp[c] = t; }
     }
     WAVE_SYNC();
 
@@ -301,29 +319,41 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
         int row = text_off, col = pat_off;
         int action = 0, prev_action = 0, action_count = 1, n_matches = 0, n_mismatches = 0, n_gaps = 0;
         while (row >= 0 && col >= 0) {
-            bool computed = true;
-            if (banded) {
-                int bb = row - w > 0 ? row - w : 0, be = row + w < pattern_len - 1 ? row + w : pattern_len - 1;
-                int cj = col / seg_len, ck = (col % seg_len) % num_vec;
+            // One load fetches the next 64 cells up the diagonal; they are consumed for as long as
+            // the path keeps stepping diagonally (a gap step leaves the diagonal -> refetch).
+            const int rt = row - lane, ct = col - lane;
+            const bool ok = rt >= 0 && ct >= 0;
+            bool computed = ok;
+            if (BANDED && ok) {
+                int bb = rt - w > 0 ? rt - w : 0, be = rt + w < pattern_len - 1 ? rt + w : pattern_len - 1;
+                int cj = ct / seg_len, ck = (ct - cj * seg_len) % num_vec;
                 computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
             }
-            int bits = computed ? (int)first_u32(bt_scratch[(size_t)row * row_stride + col]) : 0;
-            if (!computed) res.stale_reads++;
-            action = (bits >> (action << 1)) & 3;
-            if (action == 0) {
-                if (P(col) != T(row)) { prob *= tab->phred[Q(col)]; n_mismatches++; }
-                else n_matches++;
-                row--; col--;
-            } else if (action == 1) {
-                row--;
-            } else {
-                col--; action = 2;
+            int cell = computed ? (int)bt_scratch[(size_t)rt * row_stride + ct] : 0;
+            int pbyte = ok ? (int)P(ct) : 0, tbyte = ok ? (int)T(rt) : 0, qbyte = ok ? (int)Q(ct) : 0;
+            int info = cell | ((ok && !computed) ? 0x100 : 0) | ((pbyte != tbyte) ? 0x200 : 0) | (qbyte << 16);
+            int t = 0;
+            for (; t < WAVE && row >= 0 && col >= 0; t++) {
+                const int inf = __builtin_amdgcn_readlane(info, t);
+                if (inf & 0x100) res.stale_reads++;
+                action = ((inf & 0xff) >> (action << 1)) & 3;
+                bool left_diagonal = false;
+                if (action == 0) {
+                    if (inf & 0x200) { prob *= tab->phred[(inf >> 16) & 0xff]; n_mismatches++; }
+                    else n_matches++;
+                    row--; col--;
+                } else if (action == 1) {
+                    row--; left_diagonal = true;
+                } else {
+                    col--; action = 2; left_diagonal = true;
+                }
+                if (prev_action != 0) {
+                    if (prev_action == action) action_count++;
+                    else { n_gaps += action_count; prob *= tab->indel[action_count]; action_count = 1; }
+                }
+                prev_action = action;
+                if (left_diagonal) break;
             }
-            if (prev_action != 0) {
-                if (prev_action == action) action_count++;
-                else { n_gaps += action_count; prob *= tab->indel[action_count]; action_count = 1; }
-            }
-            prev_action = action;
         }
         if (row >= 0) { action_count = row + 1; n_gaps += action_count; prob *= tab->indel[action_count]; }
         if (col >= 0) { action_count = col + 1; n_gaps += action_count; prob *= tab->indel[action_count]; }
@@ -384,8 +414,11 @@ static __device__ __forceinline__ AGResult ag_dispatch(
             (size_t)text_len * (size_t)(((num_seg * seg_len + 63) >> 6) * 64) > ag_scratch_bytes(RL)) {
             __builtin_trap();                                             // host sizing bug: fail loudly
         }
-        return ag_compute_reg<AGC>(banded, dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                   lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+        if (banded)
+            return ag_compute_reg<AGC, true>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                             lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+        return ag_compute_reg<AGC, false>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                          lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
     } else {
         return ag_compute(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
                           lds_rows, bt_scratch, RL, tab);

@@ -87,7 +87,10 @@ struct ScoreSet {                      // BaseAligner.h:260-329
 
 struct WaveCounters {
     uint64_t lookups, slots, hits, overflow_lists, lv, ag, lv_ref_bytes;
+    // shader-clock cycles spent per phase (s_memtime), for the profile breakdown in profiles/
+    uint64_t cyc_lookup, cyc_hits, cyc_lv, cyc_ag, cyc_total;
 };
+static __device__ __forceinline__ uint64_t wave_clock() { return __builtin_amdgcn_s_memtime(); }
 
 // computeMAPQ (mapq.h:31-68) with the log10 replaced by a threshold table built from the
 // host's log10 at context creation (DevTables::mapq_threshold), so (int)(-10*log10(x)) is
@@ -111,15 +114,23 @@ static __device__ __forceinline__ int compute_mapq(const DevTables *tab, double 
     int pen = popular_skipped - 10; if (pen < 0) pen = 0;
     base_mapq -= pen / 2;
     if (base_mapq < 0) base_mapq = 0;
-    return base_mapq;
+    return (int)first_u32((uint32_t)base_mapq);
 }
+
+struct WaveShared {                    // per-wave LDS block (see Aligner)
+    ScoreSet all, non_alt;
+    snapgpu_single_result primary, first_alt;
+    WaveCounters cnt;
+};
 
 template <int AGC>
 struct Aligner {
     // ---- constant for the launch
-    const DevIndex &ix;
+    // held by value: a reference member would make the kernel-argument struct escape through a
+    // flat pointer and pin this whole object (ScoreSets, results, counters) in scratch memory
+    const DevIndex ix;
     const DevTables *tab;
-    const AlignCfg &cfg;
+    const AlignCfg cfg;
     // ---- LDS carve-out for this wave
     uint8_t  *rd[2];        // bases, forward / reverse complement
     uint8_t  *ql[2];        // qualities in the same orientation
@@ -143,12 +154,17 @@ struct Aligner {
     uint32_t n_seeds_applied[2];
     uint32_t popular_seeds_skipped;
     uint32_t ag_stale;                 // affine-gap traceback steps outside the computed band (see ag.h)
-    ScoreSet all, non_alt;
-    snapgpu_single_result primary, first_alt;
-    WaveCounters cnt;
+    // Cold, wave-uniform state lives in LDS (WaveShared), not in registers: it is touched a few
+    // times per candidate / per read, and keeping ~150 dwords of it live across the LV and
+    // affine-gap code is what pushed the kernel to 1-2 waves per SIMD.  Every lane executes the
+    // same stores with the same values (uniform control flow), so no lane guard is needed.
+    ScoreSet &all, &non_alt;
+    snapgpu_single_result &primary, &first_alt;
+    WaveCounters &cnt;
 
-    __device__ __forceinline__ Aligner(const DevIndex &ix_, const DevTables *tab_, const AlignCfg &cfg_)
-        : ix(ix_), tab(tab_), cfg(cfg_) {}
+    __device__ __forceinline__ Aligner(const DevIndex &ix_, const DevTables *tab_, const AlignCfg &cfg_, WaveShared *ws)
+        : ix(ix_), tab(tab_), cfg(cfg_), all(ws->all), non_alt(ws->non_alt), primary(ws->primary),
+          first_alt(ws->first_alt), cnt(ws->cnt) {}
 
     // ------------------------------------------------------------------ helpers
     __device__ __forceinline__ bool is_alt(int64_t loc) const { return (uint64_t)loc >= ix.first_alt_location && loc >= 0; }
@@ -324,8 +340,9 @@ struct Aligner {
             increment_weight(ei);
         } else {
             bool cand_alt = cfg.alt_aware && is_alt(loc);
-            if ((int64_t)lps_unseen[dir] <= (int64_t)score_limit(cand_alt)) {
-                allocate_new_candidate(loc, dir, lps_unseen[dir], (int)offset);
+            const uint32_t lps_d = dir ? lps_unseen[1] : lps_unseen[0];          // (no dynamic indexing: keeps the state in registers)
+            if ((int64_t)lps_d <= (int64_t)score_limit(cand_alt)) {
+                allocate_new_candidate(loc, dir, lps_d, (int)offset);
             }
         }
     }
@@ -400,9 +417,9 @@ struct Aligner {
     // ------------------------------------------------------------------ score()  (BaseAligner.cpp:918-1534)
     // returns true when a final answer has been written to `primary`
     __device__ __forceinline__ bool score(bool force_result) {
-        for (int dir = 0; dir < 2; dir++) {                                   // :995-1007 (EXACT_DISJOINT_MISS_COUNT)
-            if (cur_round_lps[dir] > lps_unseen[dir]) lps_unseen[dir] = cur_round_lps[dir];
-        }
+        // :995-1007 (EXACT_DISJOINT_MISS_COUNT)
+        if (cur_round_lps[0] > lps_unseen[0]) lps_unseen[0] = cur_round_lps[0];
+        if (cur_round_lps[1] > lps_unseen[1]) lps_unseen[1] = cur_round_lps[1];
         uint32_t wl = highest_used_weight_list;
         do {
             while (wl > 0 && get_next(sent(wl)) == sent(wl)) {
@@ -415,19 +432,20 @@ struct Aligner {
             if ((int64_t)lps_min > (int64_t)lim_max || force_result) {
                 if (wl < cfg.min_weight) {
                     // :1034-1056
-                    const ScoreSet *fin;
+                    bool fin_all;          // (a flag, not a pointer: selecting between &all and &non_alt would pin both in scratch)
                     first_alt.status = SNAPGPU_NotFound;
                     if (!cfg.alt_aware || non_alt.best_score > all.best_score + cfg.max_gap_alt) {
-                        fin = &all;
+                        fin_all = true;
                     } else {
-                        fin = &non_alt;
+                        fin_all = false;
                         if (cfg.emit_alt && all.best_score <= non_alt.best_score && all.best_loc != non_alt.best_loc) {
                             fill_result(all, first_alt);
                         }
                     }
-                    primary.score = fin->best_score;
-                    if ((uint32_t)fin->best_score <= cfg.max_k) {
-                        fill_result(*fin, primary);
+                    const int fin_best = fin_all ? all.best_score : non_alt.best_score;
+                    primary.score = fin_best;
+                    if ((uint32_t)fin_best <= cfg.max_k) {
+                        if (fin_all) fill_result(all, primary); else fill_result(non_alt, primary);
                         primary.supplementary = 0;
                     } else {
                         primary.status = SNAPGPU_NotFound;
@@ -484,7 +502,8 @@ struct Aligner {
                         // over the tail of the read, :1160; half 1: backwards from the start of the seed over the
                         // reversed head of the read, :1169).  The backward text/pattern are the same bytes walked
                         // with stride -1, so LandauVishkin<1> and <-1> are one instantiation.
-                        const uint8_t *rdd = rd[e_dir], *qld = ql[e_dir];
+                        const uint8_t *rdd = e_dir ? rd[1] : rd[0], *qld = e_dir ? ql[1] : ql[0];
+                        const uint64_t t_lv0 = wave_clock();
                         for (int half = 0; half < 2; half++) {
                             if (half == 1 && score1 == -1) break;
                             const int st = half == 0 ? 1 : -1;
@@ -494,6 +513,9 @@ struct Aligner {
                             const int lim = half == 0 ? limit_e : limit_e - score1;
                             ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
                             LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab);
+                            // results are wave-uniform; say so, so they (and everything derived from them) live in SGPRs
+                            r.score = (int)first_u32((uint32_t)r.score); r.net_indel = (int)first_u32((uint32_t)r.net_indel);
+                            r.match_probability = first_f64(r.match_probability);
                             if (half == 0) {
                                 score1 = r.score; mp1 = r.match_probability;
                                 ag1 = (seed_len + read_len - tail_start - score1) * cfg.match_reward - score1 * cfg.sub_penalty;
@@ -505,6 +527,7 @@ struct Aligner {
                             }
                         }
                         cnt.lv++;
+                        cnt.cyc_lv += wave_clock() - t_lv0;
 
                         if (score1 != -1 && score2 != -1) {
                             int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);     // :1148
@@ -512,6 +535,7 @@ struct Aligner {
                                 score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0;
                                 used_ag = 1;
                                 cnt.ag++;
+                                const uint64_t t_ag0 = wave_clock();
                                 AGParams agp{cfg.match_reward, cfg.sub_penalty, cfg.gap_open, cfg.gap_extend, cfg.five_bonus, cfg.three_bonus};
                                 for (int half = 0; half < 2; half++) {
                                     if (half == 0 && tail_start == read_len) continue;               // :1208
@@ -525,6 +549,9 @@ struct Aligner {
                                     ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
                                     AGResult a = ag_dispatch<AGC>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, e_dir != 0,
                                                                   false, ag_rows, ag_scratch, cfg.RL, tab);
+                                    a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
+                                    a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
+                                    a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
                                     ag_stale += (uint32_t)a.stale_reads;
                                     if (half == 0) {
                                         ag1 = a.ag_score + (seed_len - read_len); clip_after = a.pattern_offset;
@@ -534,6 +561,7 @@ struct Aligner {
                                         score2 = a.n_edits; mp2 = a.match_probability; loc_offset = a.text_offset;
                                     }
                                 }
+                                cnt.cyc_ag += wave_clock() - t_ag0;
                             }
                         }
 
@@ -612,7 +640,7 @@ struct Aligner {
                     // early out: nothing can rescue MAPQ once the candidates' total probability reaches 4.9 (:1512)
                     double p_chk = cfg.alt_aware ? non_alt.p_all : all.p_all;
                     if (p_chk >= 4.9) {
-                        fill_result(cfg.alt_aware ? non_alt : all, primary);
+                        if (cfg.alt_aware) fill_result(non_alt, primary); else fill_result(all, primary);
                         first_alt.status = SNAPGPU_NotFound;
                         return true;
                     }
@@ -640,6 +668,11 @@ struct Aligner {
     __device__ __forceinline__ bool seed_is_used(uint32_t i) const { return (seed_used[i >> 5] >> (i & 31)) & 1u; }
 
     __device__ __forceinline__ void align_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
+        const uint64_t t_read0 = wave_clock();
+        align_read_inner(g_bases, g_quals, len);
+        cnt.cyc_total += wave_clock() - t_read0;
+    }
+    __device__ __forceinline__ void align_read_inner(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         read_len = len;
         // result = NotFound (:334-344); remaining fields as a zero-initialised struct
         primary.status = SNAPGPU_NotFound; primary.direction = 0;
@@ -720,35 +753,41 @@ struct Aligner {
             if (!seed.valid) continue;                                        // :524
 
             HitList hl[2];
+            const uint64_t t_lk0 = wave_clock();
             lookup_seed(ix, seed, hl);
+            const uint64_t t_lk1 = wave_clock();
+            cnt.cyc_lookup += t_lk1 - t_lk0;
             cnt.lookups++;
             cnt.slots += hl[0].slots + hl[1].slots;
 
             bool applied_either = false;
             for (int dir = 0; dir < 2; dir++) {
-                if (hl[dir].n_hits > (int64_t)cfg.max_hits) {                 // too popular, :574-579
+                const int64_t dir_n_hits = dir ? hl[1].n_hits : hl[0].n_hits;
+                const uint32_t dir_singleton = dir ? hl[1].singleton : hl[0].singleton;
+                const uint32_t *dir_hits = dir ? hl[1].hits : hl[0].hits;
+                if (dir_n_hits > (int64_t)cfg.max_hits) {                 // too popular, :574-579
                     popular_seeds_skipped++;
                 } else {
                     uint32_t offset = dir == 0 ? next_seed : (uint32_t)(len - seed_len) - next_seed;   // :591-606
-                    int64_t limit = hl[dir].n_hits;
+                    int64_t limit = dir_n_hits;
                     if (limit > 1) cnt.overflow_lists++;
                     cnt.hits += (uint64_t)limit;
                     for (int64_t c0 = 0; c0 < limit; c0 += WAVE) {
                         // one coalesced load of up to 64 hits, then consume them in stored order
                         uint32_t mine = 0;
                         int64_t i = c0 + lane;
-                        if (i < limit) mine = (hl[dir].n_hits == 1) ? hl[dir].singleton : hl[dir].hits[i];
+                        if (i < limit) mine = (dir_n_hits == 1) ? dir_singleton : dir_hits[i];
                         int n = (int)(limit - c0 < WAVE ? limit - c0 : WAVE);
                         for (int j = 0; j < n; j++) {
                             uint32_t h = first_u32((uint32_t)__shfl((int)mine, j));
                             apply_hit(h, offset, dir);
                         }
                     }
-                    n_seeds_applied[dir]++;
-                    cur_round_lps[dir]++;
+                    if (dir) { n_seeds_applied[1]++; cur_round_lps[1]++; } else { n_seeds_applied[0]++; cur_round_lps[0]++; }
                     applied_either = true;
                 }
             }
+            cnt.cyc_hits += wave_clock() - t_lk1;
             next_seed += (uint32_t)seed_len;                                  // :676
 
             if (applied_either) {

@@ -41,7 +41,7 @@ static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { re
 
 // LDS carve-out per wave; must match lds_bytes_per_wave() on the host.
 struct LdsLayout {
-    uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, ag, total;
+    uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, ag, shared, total;
 };
 static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uint32_t num_weight_lists, uint32_t kmax, uint32_t use_ag) {
     LdsLayout L; uint32_t o = 0;
@@ -52,6 +52,7 @@ static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uin
     L.wl_prev = o; o += (num_weight_lists * 2 + 15) & ~15u;
     L.lv = o; o += (lv_lds_bytes(kmax) + 15) & ~15u;
     L.ag = o; if (use_ag) o += (ag_lds_bytes(RL) + 15) & ~15u;
+    L.shared = o; o += ((uint32_t)sizeof(WaveShared) + 15) & ~15u;
     L.total = o;
     return L;
 }
@@ -61,12 +62,13 @@ __global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id();
-    const int wave_in_block = (int)(threadIdx.x >> 6);
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: keeps the LDS/scratch pointers in SGPRs
     const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
     const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax, a.cfg.use_ag);
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
-    Aligner<AGC> al(a.ix, a.tab, a.cfg);
+    WaveShared *ws = (WaveShared *)(my + L.shared);
+    Aligner<AGC> al(a.ix, a.tab, a.cfg, ws);
     al.lane = lane;
     al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
     al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
     al.heads = (uint16_t *)sc;
     al.pool = (Elem *)(sc + (size_t)a.cfg.ht_size * 2);
     al.ag_scratch = sc + (size_t)a.cfg.ht_size * 2 + (size_t)a.cfg.pool_size * sizeof(Elem);
-    al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0};
+    al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t n_done = 0;
 
     while (true) {
@@ -90,10 +92,19 @@ __global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
         if (i >= a.n_reads) break;
         uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
         al.align_read(a.bases + b, a.quals + b, (int)(e - b));
-        if (lane == 0) {
-            a.primary[i] = al.primary;
-            if (a.first_alt) a.first_alt[i] = al.first_alt;
+        WAVE_SYNC();
+        {   // results: LDS -> global, one dword per lane
+            const uint32_t *src = (const uint32_t *)&ws->primary;
+            uint32_t *dst = (uint32_t *)&a.primary[i];
+            const int nd = (int)(sizeof(snapgpu_single_result) / 4);
+            if (lane < nd) dst[lane] = src[lane];
+            if (a.first_alt) {
+                const uint32_t *src2 = (const uint32_t *)&ws->first_alt;
+                uint32_t *dst2 = (uint32_t *)&a.first_alt[i];
+                if (lane < nd) dst2[lane] = src2[lane];
+            }
         }
+        WAVE_SYNC();
         n_done++;
     }
     if (lane == 0) {
@@ -105,6 +116,11 @@ __global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
         atomicAdd(&a.counters[5], (unsigned long long)al.cnt.lv);
         atomicAdd(&a.counters[6], (unsigned long long)al.cnt.ag);
         atomicAdd(&a.counters[7], (unsigned long long)al.cnt.lv_ref_bytes);
+        atomicAdd(&a.counters[8], (unsigned long long)al.cnt.cyc_lookup);
+        atomicAdd(&a.counters[9], (unsigned long long)al.cnt.cyc_hits);
+        atomicAdd(&a.counters[10], (unsigned long long)al.cnt.cyc_lv);
+        atomicAdd(&a.counters[11], (unsigned long long)al.cnt.cyc_ag);
+        atomicAdd(&a.counters[12], (unsigned long long)al.cnt.cyc_total);
     }
 }
 
