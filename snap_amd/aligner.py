@@ -17,7 +17,7 @@ from .abi import (Counters, IndexView, Params, RESULT_DTYPE, default_params, ptr
 from .index import GENOME_PAD, GenomeIndex
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnapgpu.so")
+LIB_PATH = os.environ.get("SNAPGPU_LIB", os.path.join(_HERE, "libsnapgpu.so"))   # override only for A/B experiments
 
 _lib = None
 

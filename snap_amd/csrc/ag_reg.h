@@ -395,32 +395,3 @@ static __host__ __forceinline__ int ag_max_positions(int max_pattern, int max_w)
     return best;
 }
 
-// AGC > 0: register formulation with AGC chunks of 64 positions (the host guarantees it fits);
-// AGC == 0: the LDS formulation of ag.h (any pattern length up to RL).
-template <int AGC, typename PSeq, typename TSeq, typename QSeq>
-static __device__ __forceinline__ AGResult ag_dispatch(
-    bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
-    const TSeq &T, int text_len, int w, int score_init, bool is_rc, bool use_clipping,
-    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
-{
-    if constexpr (AGC > 0) {
-        AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
-        res.match_probability = 0.0; res.stale_reads = 0;
-        int ww = w > 126 ? 126 : w;
-        if (ww < 0) return res;                                           // :325 / :890
-        int num_vec, seg_len, num_seg;
-        ag_dims(banded, pattern_len, ww, &num_vec, &seg_len, &num_seg);
-        if (num_seg * seg_len > 64 * AGC || num_vec > 1023 || num_seg > 255 ||
-            (size_t)text_len * (size_t)(((num_seg * seg_len + 63) >> 6) * 64) > ag_scratch_bytes(RL)) {
-            __builtin_trap();                                             // host sizing bug: fail loudly
-        }
-        if (banded)
-            return ag_compute_reg<AGC, true>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                             lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
-        return ag_compute_reg<AGC, false>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                          lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
-    } else {
-        return ag_compute(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
-                          lds_rows, bt_scratch, RL, tab);
-    }
-}

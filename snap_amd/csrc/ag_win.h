@@ -1,0 +1,312 @@
+// ag_win.h -- banded affine gap with a sliding 64-position window (same results as ag.h / ag_reg.h).
+//
+// computeScoreBanded (AffineGapVectorized.h:256-819) only ever touches the segments that
+// intersect the band [i-w, i+w]: at most two segments of segLen = 8*ceil((2w+1)/8) positions per
+// row.  When 2*segLen <= 64 (w <= 15: every call AlignRead makes with -d <= 14) those two
+// segments fit one wavefront, so instead of keeping all pattern positions resident (ag_reg.h) the
+// lanes follow the band: lane L holds position wbase + L, wbase = segLen * (band_beg / segLen).
+//   * a row is two masked passes (segment j, then j+1, because the reference carries F from the
+//     first segment's lazy-F loop into the second) over ONE register each of H, H-1, E -- no
+//     chunk loops, no carries between chunks;
+//   * when the band start crosses into the next segment the three registers slide down by segLen
+//     lanes (ds_bpermute, once every segLen rows) and the lanes that enter are initialised to what
+//     the reference's never-touched H / H-1 / E hold for those positions (row parity decides
+//     which of the two H buffers is being read);
+//   * positions behind the window are never read again by the reference (the band only moves
+//     forward) except H(i-1, wbase-1) on the row of the slide, which is kept in a scalar;
+//   * traceback bytes are 64 per row; the row's wbase goes to an LDS table for the traceback.
+#pragma once
+#include "ag_reg.h"
+
+template <typename PSeq, typename TSeq, typename QSeq>
+static __device__ __forceinline__ AGResult ag_banded_win(
+    int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
+    const TSeq &T, int text_len, int w, int score_init, bool is_rc, bool use_clipping,
+    int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
+    int num_vec, int seg_len, int num_seg)
+{
+    const int lane = lane_id();
+    AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
+    res.match_probability = 1.0; res.stale_reads = 0;
+    const int match = prm.match_reward, sub = -prm.sub_penalty;
+    const int gap_open = prm.gap_open + prm.gap_extend, gap_ext = prm.gap_extend;
+    const int tot = num_seg * seg_len;
+    unsigned long long *lds_bits = (unsigned long long *)lds_rows;
+    uint16_t *row_base = (uint16_t *)(lds_rows + 8);          // [text_len] window base of each row
+
+    int end_bonus;
+    if (!is_rc) end_bonus = dir == -1 ? prm.five_bonus : prm.three_bonus;
+    else        end_bonus = dir == -1 ? prm.three_bonus : prm.five_bonus;
+
+    // lane constants: which of the (up to) two window segments, stripe l and vector k inside it
+    const int segsel = lane / seg_len;                          // 0, 1 (>= 2: lane beyond the two segments)
+    const int rr = lane - segsel * seg_len;
+    const int l = rr / num_vec, k = rr - l * num_vec;
+
+    // value of the reference's first-row H at position p, incl. the stale scoreFirstRow[] inheritance
+    auto first_row = [&](int p) -> int {
+        if (p >= tot) return 0;
+        int pi = p;
+        if (p >= pattern_len) {
+            int j2 = p / seg_len, r2 = p - j2 * seg_len, l2 = r2 / num_vec, k2 = r2 - l2 * num_vec;
+            pi = -1;
+            for (int v = j2 * num_vec + k2 - 1; v >= 0; v--) {
+                int q = (v / num_vec) * seg_len + l2 * num_vec + (v % num_vec);
+                if (q < pattern_len) { pi = q; break; }
+            }
+            if (pi < 0) return 0;
+        }
+        int x = score_init - gap_open - pi * gap_ext;
+        return x > 0 ? x : 0;
+    };
+    auto pat_base = [&](int p) -> int { return p < pattern_len ? (int)base_value(P(p)) : 5; };
+
+    int wbase = 0, jbase = 0;
+    int Hp = first_row(lane), Hm = 0, E = 0;
+    int pbv = pat_base(lane);
+    int left_h = 0;
+    // H / H-1 of the global-alignment cell (position pattern_len-1) once it has left the window: the
+    // reference keeps reading its stale value on the row(s) after the band has passed the pattern end
+    int gl_p = 0, gl_m = 0;
+
+    int best_global = -1, best_global_text = -1, best_local = -1, best_local_text = -1, best_local_pat = -1;
+
+    for (int i = 0; i < text_len; i++) {
+        const int tb = (int)base_value(T(i));
+        const int band_beg = i - w > 0 ? i - w : 0;
+        const int band_end = i + w < pattern_len - 1 ? i + w : pattern_len - 1;
+        if ((jbase + 1) * seg_len <= band_beg) {                // slide the window by one segment
+            left_h = __builtin_amdgcn_readlane(Hp, seg_len - 1);
+            if (pattern_len - 1 >= wbase && pattern_len - 1 < wbase + seg_len) {
+                gl_p = __builtin_amdgcn_readlane(Hp, pattern_len - 1 - wbase);
+                gl_m = __builtin_amdgcn_readlane(Hm, pattern_len - 1 - wbase);
+            }
+            int nHp = __shfl_down(Hp, seg_len), nHm = __shfl_down(Hm, seg_len), nE = __shfl_down(E, seg_len);
+            int npb = __shfl_down(pbv, seg_len);
+            wbase += seg_len; jbase++;
+            if (lane >= WAVE - seg_len) {                       // positions entering the window
+                const int p = wbase + lane;
+                const int fr = first_row(p);
+                nHp = (i & 1) ? 0 : fr;                         // Hptr is H on even rows, Hminus1 on odd rows
+                nHm = (i & 1) ? fr : 0;
+                nE = 0;
+                npb = pat_base(p);
+            }
+            Hp = nHp; Hm = nHm; E = nE; pbv = npb;
+        }
+        const int p = wbase + lane;
+        const bool valid = p < tot;
+        const int seg_end_sel = ((jbase + 1) * seg_len <= band_end) ? 1 : 0;
+        int h_init0 = score_init;
+        if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
+        if (lane == 0) row_base[i] = (uint16_t)wbase;
+        int mxv = 0, X0 = 0, fin = 0, btr = 0;
+        bool did = false;
+        const int prof = pbv == 5 ? -32768 : ((tb > 3 || pbv > 3) ? -1 : (tb == pbv ? match : sub));
+
+        for (int s = 0; s <= seg_end_sel; s++) {
+            const int seg_start = wbase + s * seg_len;
+            int nk = band_end - seg_start + 1; if (nk > num_vec) nk = num_vec;
+            const bool inseg = valid && segsel == s && k < nk;
+            const bool isend = inseg && k == nk - 1;
+            // H(i-1, p-1): the lane to the left; window lane 0 follows the reference's segment-start rule (:461-476)
+            int lane0_in;
+            if (wbase == 0) lane0_in = h_init0;
+            else lane0_in = (band_beg > wbase) ? 0 : left_h;
+            int h_in = ag_shr1(lane0_in, Hp);
+            int m = h_in > 0 ? ag_sat16(h_in + prof) : 0;
+            int e = E;
+            int bt = e > m ? 1 : 0;
+            int hp = m > e ? m : e;
+            int e2 = e - gap_ext;
+            int tmp = m - gap_open; if (tmp < 0) tmp = 0;
+            if (e2 > tmp) bt |= 4;
+            const int tag = AG_BIG * (s * 8 + l);
+            int g = inseg ? tmp + p * gap_ext + tag : AG_NEG;
+            int inc = ag_prefix_max(g);
+            int pm = ag_shr1(AG_NEG, inc);
+            const int fin_cell = l == 0 ? fin : 0;
+            int fk = fin_cell - k * gap_ext;
+            if (k >= 1) { int a = pm - tag - (p - 1) * gap_ext; fk = a > fk ? a : fk; }
+            int endv = 0;
+            if (inseg) {
+                if (fk > hp) { bt |= 2; hp = fk; }
+                Hm = hp;
+                E = e2 > tmp ? e2 : tmp;
+                mxv = hp > mxv ? hp : mxv;
+                int f2 = fk - gap_ext;
+                if (f2 > tmp) bt |= 32;
+                endv = f2 > tmp ? f2 : tmp;
+                btr = bt; did = true;
+            }
+
+            // lazy F (:534-569): 7 rounds, F of stripe 7 accumulates into X (the next segment's incoming F)
+            const int pe7_lane = s * seg_len + 7 * num_vec + nk - 1;
+            for (int r = 0; r < 7; r++) {
+                int f7 = __builtin_amdgcn_readlane(endv, pe7_lane);
+                if (f7 > X0) X0 = f7;
+                int v = isend ? endv + AG_BIG * (l + 1) : AG_NEG;
+                int inc2 = ag_prefix_max(v);
+                int pm2 = ag_shr1(AG_NEG, inc2);
+                int f_in = pm2 - AG_BIG * l;
+                if (l == 0 || f_in < 0 || f_in >= AG_BIG) f_in = 0;
+                int f = f_in - k * gap_ext; if (f < 0) f = 0;
+                int hn = Hm > f ? Hm : f;
+                int t2 = hn > gap_open ? hn - gap_open : 0;
+                int f2 = f > gap_ext ? f - gap_ext : 0;
+                const bool cont = inseg && (f2 > t2);
+                const unsigned long long any_cont = __ballot(cont);
+                int jstar = 0;
+                if (any_cont) {
+                    if (lane == 0) *lds_bits = 0ull;
+                    WAVE_SYNC();
+                    if (cont) atomicOr(lds_bits, 1ull << k);
+                    WAVE_SYNC();
+                    unsigned long long bits = first_u64(*lds_bits);
+                    jstar = (~bits == 0ull) ? 64 : (__ffsll((long long)~bits) - 1);
+                }
+                const bool round_complete = jstar >= nk;
+                const int jlim = round_complete ? nk - 1 : jstar;
+                if (inseg && k <= jlim) {
+                    if (f > Hm) { btr |= 2; Hm = f; }
+                    mxv = Hm > mxv ? Hm : mxv;
+                    if (cont) btr |= 32;
+                }
+                if (!round_complete) break;
+                int dec = f_in - nk * gap_ext; endv = dec > 0 ? dec : 0;
+            }
+            fin = X0;
+        }
+
+        if (did) bt_scratch[(size_t)i * 64 + lane] = (uint8_t)btr;
+        const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
+        if (band_end == pattern_len - 1) {
+            int gscore = pattern_len - 1 >= wbase ? __builtin_amdgcn_readlane(Hm, pattern_len - 1 >= wbase ? pattern_len - 1 - wbase : 0) : gl_m;
+            if (gscore >= best_global) { best_global = gscore; best_global_text = i; }
+        }
+        if (max_row == 0) break;
+        if (max_row > best_local) {
+            unsigned long long mk = __ballot(did && Hm == max_row);
+            best_local_pat = mk ? wbase + 63 - __clzll((long long)mk) : -1;
+            best_local = max_row; best_local_text = i;
+        }
+        { int t = Hm; Hm = Hp; Hp = t; }
+        { int t = gl_m; gl_m = gl_p; gl_p = t; }
+    }
+    WAVE_SYNC();
+
+    // ---------------- local vs global (:643-730)
+    int score, pat_off, text_off;
+    if (best_local != best_global && best_local >= best_global + end_bonus) {
+        pat_off = best_local_pat; text_off = best_local_text; score = best_local;
+        if (use_clipping) {
+            int pa = pat_off - 1, ta = text_off, cnt = 0;
+            while (pa + 1 != pattern_len && P(pa + 1) == T(ta + 1)) { cnt++; pa++; ta++; }
+            if (cnt >= 3) { pat_off = pa; text_off = ta; }
+            else {
+                pa = pat_off + 1; ta = text_off; cnt = 0;
+                while (pa < pattern_len && P(pa) == T(ta)) { cnt++; pa++; ta++; }
+                if (cnt >= 3) { pat_off = pa - 1; text_off = ta - 1; }
+            }
+            if (pat_off == best_local_pat && text_off == best_local_text) {
+                pa = pat_off;
+                while (pa != pattern_len - 1 && Q(pa) >= 65 && Q(pa + 1) >= 65) pa++;
+                if (pa == pattern_len - 1) pat_off = pa;
+                else if (pa >= pat_off + 2) {
+                    int tmp_off = pa + 1, cnt_hq = 0, rem = pattern_len - tmp_off;
+                    while (tmp_off != pattern_len - 1) { if (Q(tmp_off) >= 65) cnt_hq++; tmp_off++; }
+                    if (((float)cnt_hq) / (float)rem < 0.1f) pat_off = pa;
+                }
+            }
+        }
+    } else {
+        pat_off = pattern_len - 1; text_off = best_global_text; score = best_global;
+    }
+    res.text_offset = text_off; res.pattern_offset = pat_off;
+
+    if (score > score_init) {                                          // traceback, :732-815
+        double prob = 1.0;
+        int row = text_off, col = pat_off;
+        int action = 0, prev_action = 0, action_count = 1, n_matches = 0, n_mismatches = 0, n_gaps = 0;
+        while (row >= 0 && col >= 0) {
+            const int rt = row - lane, ct = col - lane;
+            const bool ok = rt >= 0 && ct >= 0;
+            bool computed = false;
+            int wb = 0;
+            if (ok) {
+                int bb = rt - w > 0 ? rt - w : 0, be = rt + w < pattern_len - 1 ? rt + w : pattern_len - 1;
+                int cj = ct / seg_len, ck = (ct - cj * seg_len) % num_vec;
+                computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
+                wb = (int)row_base[rt];
+            }
+            int cell = computed ? (int)bt_scratch[(size_t)rt * 64 + (ct - wb)] : 0;
+            int pbyte = ok ? (int)P(ct) : 0, tbyte = ok ? (int)T(rt) : 0, qbyte = ok ? (int)Q(ct) : 0;
+            int info = cell | ((ok && !computed) ? 0x100 : 0) | ((pbyte != tbyte) ? 0x200 : 0) | (qbyte << 16);
+            for (int t = 0; t < WAVE && row >= 0 && col >= 0; t++) {
+                const int inf = __builtin_amdgcn_readlane(info, t);
+                if (inf & 0x100) res.stale_reads++;
+                action = ((inf & 0xff) >> (action << 1)) & 3;
+                bool left_diagonal = false;
+                if (action == 0) {
+                    if (inf & 0x200) { prob *= tab->phred[(inf >> 16) & 0xff]; n_mismatches++; }
+                    else n_matches++;
+                    row--; col--;
+                } else if (action == 1) {
+                    row--; left_diagonal = true;
+                } else {
+                    col--; action = 2; left_diagonal = true;
+                }
+                if (prev_action != 0) {
+                    if (prev_action == action) action_count++;
+                    else { n_gaps += action_count; prob *= tab->indel[action_count]; action_count = 1; }
+                }
+                prev_action = action;
+                if (left_diagonal) break;
+            }
+        }
+        if (row >= 0) { action_count = row + 1; n_gaps += action_count; prob *= tab->indel[action_count]; }
+        if (col >= 0) { action_count = col + 1; n_gaps += action_count; prob *= tab->indel[action_count]; }
+        res.n_edits = n_mismatches + n_gaps;
+        prob *= tab->perfect[n_matches];
+        text_off += 1; pat_off += 1;
+        res.text_offset = pattern_len - text_off;
+        res.pattern_offset = pattern_len - pat_off;
+        prob *= tab->indel[res.pattern_offset];
+        res.match_probability = prob;
+        res.ag_score = score;
+    }
+    return res;
+}
+
+// AGC > 0: register formulation with AGC chunks of 64 positions (the host guarantees it fits);
+// AGC == 0: the LDS formulation of ag.h (any pattern length up to RL).
+template <int AGC, typename PSeq, typename TSeq, typename QSeq>
+static __device__ __forceinline__ AGResult ag_dispatch(
+    bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
+    const TSeq &T, int text_len, int w, int score_init, bool is_rc, bool use_clipping,
+    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
+{
+    if constexpr (AGC > 0) {
+        AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
+        res.match_probability = 0.0; res.stale_reads = 0;
+        int ww = w > 126 ? 126 : w;
+        if (ww < 0) return res;                                           // :325 / :890
+        int num_vec, seg_len, num_seg;
+        ag_dims(banded, pattern_len, ww, &num_vec, &seg_len, &num_seg);
+        if (num_seg * seg_len > 64 * AGC || num_vec > 1023 || num_seg > 255 ||
+            (size_t)text_len * (size_t)(((num_seg * seg_len + 63) >> 6) * 64) > ag_scratch_bytes(RL)) {
+            __builtin_trap();                                             // host sizing bug: fail loudly
+        }
+        if (banded && 2 * seg_len <= 64)        // the band's two segments fit one wavefront: sliding-window form
+            return ag_banded_win(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                 lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+        if (banded)
+            return ag_compute_reg<AGC, true>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                             lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+        return ag_compute_reg<AGC, false>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                          lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+    } else {
+        return ag_compute(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
+                          lds_rows, bt_scratch, RL, tab);
+    }
+}

@@ -29,7 +29,7 @@
 #include "dev_common.h"
 #include "probe.h"
 #include "lv.h"
-#include "ag_reg.h"
+#include "ag_win.h"
 #include "../../include/snapgpu.h"
 
 #define BUCKET 48                      // hashTableElementSize == maxMergeDist, BaseAligner.h:177,213

@@ -17,7 +17,7 @@
 #include "dev_common.h"
 #include "probe.h"
 #include "lv.h"
-#include "ag_reg.h"
+#include "ag_win.h"
 #include "align_single.h"
 
 // =====================================================================================
@@ -57,8 +57,12 @@ static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uin
     return L;
 }
 
+// Latency-bound kernel: ask for 4 waves per SIMD (<= 128 VGPRs; costs ~24 spilled VGPRs of cold state).
+#ifndef SNAPGPU_WAVES_PER_SIMD
+#define SNAPGPU_WAVES_PER_SIMD 4
+#endif
 template <int AGC>
-__global__ __launch_bounds__(256) void k_align_single(AlignArgs a)
+__global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD) void k_align_single(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id();
