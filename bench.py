@@ -100,7 +100,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("SNAP_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ   # exercise the RCCL path on one GPU
+    if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist = sd.init_process_group("nccl")
 
@@ -110,7 +111,7 @@ def main():
         dist.barrier()
     params = abi.default_params(max_k=args.max_k, max_read_len=((args.read_len + 15) // 16) * 16)
     t0 = time.time()
-    if world == 1:
+    if dist is None:
         index = GenomeIndex.load_from_directory(idx_dir)
         aligner = BaseAligner(index, params, device=local_rank)
         keep = None

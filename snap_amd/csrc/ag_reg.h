@@ -32,7 +32,10 @@
 
 template <int CTRL, int ROW_MASK>
 static __device__ __forceinline__ int ag_dpp_max(int v) {
-    int t = __builtin_amdgcn_update_dpp(AG_NEG, v, CTRL, ROW_MASK, 0xF, false);
+    // old == v: lanes without a source keep their own value, for which max() is the identity; this
+    // is also the shape LLVM's DPP combiner folds into a single v_max_i32_dpp (no constant to
+    // materialise, one hazard nop instead of two)
+    int t = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
     return t > v ? t : v;
 }
 // inclusive prefix max over the 64 lanes (GFX9 DPP scan)

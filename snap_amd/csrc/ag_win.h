@@ -303,6 +303,9 @@ static __device__ __forceinline__ AGResult ag_dispatch(
         if (banded)
             return ag_compute_reg<AGC, true>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                              lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+        if (num_seg * seg_len <= 64)            // short pattern (e.g. the read's head before an early seed): one chunk, no chunk loops
+            return ag_compute_reg<1, false>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                            lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
         return ag_compute_reg<AGC, false>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                           lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
     } else {
