@@ -85,6 +85,12 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: anything libraries print to fd 1 (RCCL prints a version
+    # banner there) is sent to stderr instead; the JSON goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     from snap_amd import abi, synth
     from snap_amd import dist as sd
@@ -216,7 +222,7 @@ def main():
         flagged = prim["reserved"][:sample] != 0
         problems = compare_results(pr, prim[:sample], exclude=flagged)
         out["parity_check"] = {"reads": sample, "mismatching_fields": problems, "reference_unstable_flagged": int(flagged.sum())}
-    print(json.dumps(out))
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     aligner.close()
     del keep
 
