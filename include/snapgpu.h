@@ -181,6 +181,12 @@ void        snapgpu_default_params(snapgpu_params *p);
 int  snapgpu_create(const snapgpu_index_view *idx, const snapgpu_params *p, int device, snapgpu_ctx **out);
 void snapgpu_destroy(snapgpu_ctx *ctx);
 
+/* Same as snapgpu_create, but reads the four files of a SNAP index directory itself
+ * (GenomeIndex::loadFromDirectory, GenomeIndex.cpp:1839-2093; Genome::loadFromFile, Genome.cpp:277;
+ * SNAPHashTable::loadCommon, HashTable.cpp:98-175) and uploads them.  This is what a C/C++ host
+ * (e.g. the AlignerExtension shim of INTEGRATION.md) calls.                                      */
+int  snapgpu_create_from_directory(const char *index_dir, const snapgpu_params *p, int device, snapgpu_ctx **out);
+
 /* Device pointers of the context's index blobs, so that a caller that owns the
  * collective (RCCL broadcast of the index) can fill them in place.
  * Each pointer may be NULL if the caller does not want it.                               */

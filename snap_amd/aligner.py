@@ -45,7 +45,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "snapgpu_abi_version", "snapgpu_last_error", "snapgpu_default_params", "snapgpu_create",
-    "snapgpu_destroy", "snapgpu_index_device_ptrs", "snapgpu_lookup_seeds",
+    "snapgpu_destroy", "snapgpu_create_from_directory", "snapgpu_index_device_ptrs", "snapgpu_lookup_seeds",
     "snapgpu_landau_vishkin", "snapgpu_affine_gap", "snapgpu_align_single",
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
 ]

@@ -526,6 +526,96 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     return SNAPGPU_OK;
 }
 
+// ---- host-side index loader (C++ mirror of snap_amd/index.py; formats in SURVEY.md Appendix B)
+static bool read_file(const std::string &path, std::vector<uint8_t> &out, std::string &err) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "cannot open " + path; return false; }
+    fseek(f, 0, SEEK_END); long long n = ftell(f); fseek(f, 0, SEEK_SET);
+    out.resize((size_t)n);
+    size_t got = n ? fread(out.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    if ((long long)got != n) { err = "short read on " + path; return false; }
+    return true;
+}
+
+extern "C" int snapgpu_create_from_directory(const char *index_dir, const snapgpu_params *p, int device, snapgpu_ctx **out)
+{
+    if (!index_dir || !p || !out) return fail(nullptr, SNAPGPU_E_INVALID, "snapgpu_create_from_directory: null argument");
+    std::string dir(index_dir), err;
+    std::vector<uint8_t> hdr, gen, ovf, hash;
+    if (!read_file(dir + "/GenomeIndex", hdr, err) || !read_file(dir + "/Genome", gen, err) ||
+        !read_file(dir + "/OverflowTable", ovf, err) || !read_file(dir + "/GenomeIndexHash", hash, err))
+        return fail(nullptr, SNAPGPU_E_INVALID, err);
+    hdr.push_back(0);
+    int major = 0, minor = 0, n_tables = 0, seed_len = 0, padding = 0, key_bytes = 0, small = 0, loc_size = 0;
+    long long overflow_size = 0, hash_file_size = 0;
+    if (sscanf((const char *)hdr.data(), "%d %d %d %lld %d %d %d %lld %d %d", &major, &minor, &n_tables, &overflow_size, &seed_len,
+               &padding, &key_bytes, &hash_file_size, &small, &loc_size) != 10)               // GenomeIndex.cpp:1879
+        return fail(nullptr, SNAPGPU_E_INVALID, "malformed GenomeIndex header");
+    if (major != 7) return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "index major version is not 7 (GenomeIndex.h:170)");
+    if (loc_size != 4) return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "index uses 64-bit genome locations; only the 32-bit lookup path (seed >= 20) is implemented");
+    if ((long long)ovf.size() != overflow_size * 4) return fail(nullptr, SNAPGPU_E_INVALID, "OverflowTable size does not match the header");
+
+    // Genome: "nBases nContigs flags\n", one line per contig, then nBases raw bytes (Genome.cpp:203-229)
+    size_t pos = 0;
+    auto next_line = [&](std::string &line) -> bool {
+        size_t e = pos; while (e < gen.size() && gen[e] != '\n') e++;
+        if (e >= gen.size()) return false;
+        line.assign((const char *)gen.data() + pos, e - pos); pos = e + 1; return true;
+    };
+    std::string line;
+    long long n_bases = 0; int n_contigs = 0, gflags = 0;
+    if (!next_line(line) || sscanf(line.c_str(), "%lld %d %d", &n_bases, &n_contigs, &gflags) < 2)
+        return fail(nullptr, SNAPGPU_E_INVALID, "malformed Genome header");
+    std::vector<uint64_t> contig_begin((size_t)n_contigs);
+    uint64_t first_alt = ~0ull >> 2;
+    for (int i = 0; i < n_contigs; i++) {
+        long long begin = 0; int cflags = 0;
+        if (!next_line(line) || sscanf(line.c_str(), "%lld %x", &begin, &cflags) != 2)
+            return fail(nullptr, SNAPGPU_E_INVALID, "malformed contig line in Genome");
+        contig_begin[(size_t)i] = (uint64_t)begin;
+        if ((cflags & 1) && (uint64_t)begin < first_alt) first_alt = (uint64_t)begin;           // GENOME_FLAG_CONTIG_IS_ALT
+    }
+    if (gen.size() - pos < (size_t)n_bases) return fail(nullptr, SNAPGPU_E_INVALID, "Genome file truncated");
+    const uint32_t pad = 1024;
+    std::vector<uint8_t> genome_padded((size_t)n_bases + 2 * pad, (uint8_t)'n');
+    memcpy(genome_padded.data() + pad, gen.data() + pos, (size_t)n_bases);
+    std::vector<uint8_t>().swap(gen);
+
+    // GenomeIndexHash: per table a 36-byte header then tableSize slots (HashTable.cpp:98-175)
+    const uint32_t value_count = small ? 1 : 2, entry = 4 * value_count + (uint32_t)key_bytes;
+    std::vector<uint64_t> toff((size_t)n_tables), tsz((size_t)n_tables);
+    std::vector<uint8_t> blob; blob.reserve(hash.size());
+    size_t hp = 0;
+    for (int t = 0; t < n_tables; t++) {
+        if (hp + 36 > hash.size()) return fail(nullptr, SNAPGPU_E_INVALID, "GenomeIndexHash truncated");
+        uint32_t magic, ks, vs, vc; uint64_t table_size;
+        memcpy(&magic, &hash[hp], 4); memcpy(&table_size, &hash[hp + 4], 8);
+        memcpy(&ks, &hash[hp + 20], 4); memcpy(&vs, &hash[hp + 24], 4); memcpy(&vc, &hash[hp + 28], 4);
+        if (magic != 0xb111b010u || ks != (uint32_t)key_bytes || vs != 4 || vc != value_count)
+            return fail(nullptr, SNAPGPU_E_INVALID, "hash table header does not match the index header");
+        hp += 32 + vs;
+        size_t nbytes = (size_t)table_size * entry;
+        if (hp + nbytes > hash.size()) return fail(nullptr, SNAPGPU_E_INVALID, "GenomeIndexHash truncated");
+        toff[(size_t)t] = blob.size(); tsz[(size_t)t] = table_size;
+        blob.insert(blob.end(), hash.begin() + (long)hp, hash.begin() + (long)(hp + nbytes));
+        hp += nbytes;
+    }
+    std::vector<uint8_t>().swap(hash);
+    blob.resize(blob.size() + 16, 0);
+    if (ovf.empty()) ovf.resize(4, 0);
+
+    snapgpu_index_view v; memset(&v, 0, sizeof(v));
+    v.seed_len = (uint32_t)seed_len; v.key_bytes = (uint32_t)key_bytes; v.n_hash_tables = (uint32_t)n_tables;
+    v.large_hash_table = small ? 0 : 1; v.location_size = (uint32_t)loc_size; v.chromosome_padding = (uint32_t)padding;
+    v.overflow_table_size = (uint64_t)overflow_size;
+    v.hash_blob = blob.data(); v.hash_blob_bytes = blob.size(); v.table_offset = toff.data(); v.table_size = tsz.data();
+    v.overflow = (const uint32_t *)ovf.data(); v.genome = genome_padded.data() + pad; v.n_bases = (uint64_t)n_bases;
+    v.genome_pad = pad; v.contig_begin = contig_begin.data(); v.n_contigs = (uint32_t)n_contigs;
+    v.first_alt_location = first_alt; v.on_device = 0;
+    return snapgpu_create(&v, p, device, out);
+}
+
 extern "C" int snapgpu_index_device_ptrs(snapgpu_ctx *ctx, void **hash_blob, void **overflow, void **genome_with_pad) {
     if (!ctx) return SNAPGPU_E_INVALID;
     if (hash_blob) *hash_blob = ctx->d_hash;

@@ -1,0 +1,127 @@
+"""Drop-in test at the outermost boundary: SNAP's own CLI with shim/GpuAlignerExtension.cpp
+installed (oracle/_ref/snap-aligner-gpu: reference readers, filters and SAM writer, alignment by
+libsnapgpu.so through the C ABI) must write the same SAM records as the unmodified reference CLI
+(oracle/_ref/snap-aligner) on the same FASTQ and index.  Both binaries are prebuilt in the
+container (oracle/Makefile) and travel with the snapshot; nothing here reads /root/reference."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from snap_amd import abi, synth
+from snap_amd.index import GenomeIndex
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+REF_CLI = ref.CLI_PATH
+GPU_CLI = os.path.join(os.path.dirname(REF_CLI), "snap-aligner-gpu")
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=600)
+    assert r.returncode == 0, "%s failed:\n%s" % (cmd[0], r.stdout.decode(errors="replace")[-3000:])
+    return r.stdout.decode(errors="replace")
+
+
+def _sam(path):
+    header, records = [], []
+    for line in open(path):
+        if line.startswith("@"):
+            if not line.startswith("@PG"):                  # @PG carries the command line
+                header.append(line)
+        else:
+            records.append(line)
+    return header, sorted(records)
+
+
+@pytest.fixture(scope="module")
+def workload(tmp_path_factory):
+    if not (os.path.exists(REF_CLI) and os.path.exists(GPU_CLI)):
+        pytest.skip("oracle/_ref CLIs were not built (run __graft_entry__.build() in the container)")
+    d = str(tmp_path_factory.mktemp("shim"))
+    contigs = synth.make_genome(77, 3_000_000, n_contigs=3, repeat_frac=0.08)
+    fasta = os.path.join(d, "g.fa")
+    synth.write_fasta(fasta, contigs)
+    index_dir = os.path.join(d, "index")
+    ref.build_index(fasta, index_dir, seed_len=20, threads=8)
+    reads = synth.make_reads(5, contigs, 20000, 150, sub=0.015, ins=0.002, dele=0.002, n_frac=0.002)
+    rng = np.random.default_rng(9)
+    fastq = os.path.join(d, "r.fq")
+    names, seqs = [], []
+    with open(fastq, "wb") as f:
+        for i in range(reads["bases"].shape[0]):
+            b = reads["bases"][i].copy(); q = reads["quals"][i].copy()
+            kind = i % 50
+            L = 150
+            if kind == 1:
+                L = int(rng.integers(30, 150))              # ragged lengths, some below -mrl 50
+            elif kind == 2:
+                b[rng.integers(0, 150, size=12)] = ord("N")   # more Ns than -d: "useless" read
+            elif kind == 3:
+                q[150 - int(rng.integers(1, 40)):] = ord("#")   # '#' tail: back-clipped by the reader
+            elif kind == 4:
+                b = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=150)   # unalignable
+            f.write(b"@read%d\n" % i + b[:L].tobytes() + b"\n+\n" + q[:L].tobytes() + b"\n")
+            names.append("read%d" % i); seqs.append((b[:L], q[:L]))
+    return dict(dir=d, index=index_dir, fastq=fastq, names=names, seqs=seqs)
+
+
+def _unstable_names(workload, extra_params):
+    """Reads whose reference result depends on the aligner object's history (DESIGN.md
+    'Reference nondeterminism'): the device flags them in `reserved`."""
+    from snap_amd.aligner import BaseAligner
+    idx = GenomeIndex.load_from_directory(workload["index"])
+    p = abi.default_params(max_read_len=400, **extra_params)
+    a = BaseAligner(idx, p)
+    def clip(s):                                            # ClipBack (the CLI default, -C-+): drop the trailing '#' run
+        n = len(s[1])
+        while n > 0 and s[1][n - 1] == ord("#"):
+            n -= 1
+        return s[0][:n], s[1][:n]
+    keep = [(n, clip(s)) for n, s in zip(workload["names"], workload["seqs"])]
+    keep = [(n, s) for n, s in keep if len(s[0]) >= 50]
+    bases = np.concatenate([s[0] for _, s in keep]); quals = np.concatenate([s[1] for _, s in keep])
+    offs = np.concatenate([[0], np.cumsum([len(s[0]) for _, s in keep])]).astype(np.uint64)
+    prim, alt = a.AlignRead(bases, quals, offs)
+    a.close()
+    return {n for (n, _), r in zip(keep, prim["reserved"]) if r != 0}
+
+
+@pytest.mark.parametrize("opts,params", [
+    ([], {}),
+    (["-d", "12", "-G-"], {"max_k": 12, "use_affine_gap": 0}),
+    (["-ea", "-D", "2"], {"emit_alt_alignments": 1, "extra_search_depth": 2}),
+])
+def test_sam_identical_to_reference_cli(workload, opts, params):
+    d = workload["dir"]
+    tag = "_".join(o.strip("-") for o in opts) or "default"
+    out_ref = os.path.join(d, "ref_%s.sam" % tag)
+    out_gpu = os.path.join(d, "gpu_%s.sam" % tag)
+    _run([REF_CLI, "single", workload["index"], workload["fastq"], "-o", out_ref, "-t", "8"] + opts)
+    log = _run([GPU_CLI, "single", workload["index"], workload["fastq"], "-o", out_gpu, "-t", "4"] + opts)
+    h_ref, r_ref = _sam(out_ref)
+    h_gpu, r_gpu = _sam(out_gpu)
+    assert h_ref == h_gpu
+    assert len(r_ref) == len(r_gpu) and len(r_ref) >= len(workload["names"]), log[-2000:]
+    if r_ref != r_gpu:
+        def by_name(records):
+            m = {}
+            for line in records:
+                m.setdefault(line.split("\t")[0], []).append(line)
+            return m
+        m_ref, m_gpu = by_name(r_ref), by_name(r_gpu)
+        assert m_ref.keys() == m_gpu.keys()
+        differing = [n for n in m_ref if m_ref[n] != m_gpu[n]]
+        unstable = _unstable_names(workload, params)
+        bad = [n for n in differing if n not in unstable]
+        assert not bad, "first differing read %s:\nref: %sgpu: %s" % (bad[0], "".join(m_ref[bad[0]]), "".join(m_gpu[bad[0]]))
+        assert len(differing) <= 1 + len(m_ref) // 2000
+
+
+def test_shim_fails_loudly_on_unsupported_option(workload):
+    r = subprocess.run([GPU_CLI, "single", workload["index"], workload["fastq"], "-o", os.path.join(workload["dir"], "x.sam"),
+                        "-om", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=300)
+    assert r.returncode != 0
+    assert b"libsnapgpu" in r.stdout
