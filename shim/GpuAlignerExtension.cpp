@@ -29,6 +29,7 @@
 #include "exit.h"
 
 #include <vector>
+#include <new>
 #include <pthread.h>
 #include <string.h>
 
@@ -83,8 +84,10 @@ public:
         }
         ensureContext(c);
 
-        const unsigned BATCH = 32768;
-        std::vector<ReadWithOwnMemory> reads(BATCH);        // reads are only valid until the next getNextRead(): copy them
+        // Reads are only valid until the supplier moves on, so each batch is copied.  ReadWithOwnMemory
+        // points into its own body and has no copy-assignment: construct in place in raw storage.
+        const unsigned BATCH = 16384;
+        ReadWithOwnMemory *reads = (ReadWithOwnMemory *)BigAlloc((size_t)BATCH * sizeof(ReadWithOwnMemory));
         std::vector<char> bases, quals;
         std::vector<uint64_t> offs;
         std::vector<snapgpu_single_result> prim(BATCH), alt(BATCH);
@@ -113,7 +116,7 @@ public:
                     }
                     continue;
                 }
-                reads[n] = ReadWithOwnMemory(*read);
+                new (&reads[n]) ReadWithOwnMemory(*read);
                 bases.insert(bases.end(), read->getData(), read->getData() + read->getDataLength());
                 quals.insert(quals.end(), read->getQuality(), read->getQuality() + read->getDataLength());
                 offs.push_back((uint64_t)bases.size());
@@ -156,8 +159,10 @@ public:
                 } else {
                     c->stats->filtered++;
                 }
+                reads[i].dispose();
             }
         }
+        BigDealloc(reads);
         snapgpu_counters counters;
         pthread_mutex_lock(&g_gpuLock);
         if (snapgpu_get_counters(g_ctx, &counters, 1) == SNAPGPU_OK) {

@@ -122,6 +122,6 @@ def test_sam_identical_to_reference_cli(workload, opts, params):
 
 def test_shim_fails_loudly_on_unsupported_option(workload):
     r = subprocess.run([GPU_CLI, "single", workload["index"], workload["fastq"], "-o", os.path.join(workload["dir"], "x.sam"),
-                        "-om", "3"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=300)
+                        "-om", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=300)
     assert r.returncode != 0
     assert b"libsnapgpu" in r.stdout
