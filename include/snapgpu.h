@@ -147,6 +147,61 @@ typedef struct snapgpu_single_result {
                                       DESIGN.md "Reference nondeterminism". */
 } snapgpu_single_result;
 
+/* Paired-end options: PairedAlignerOptions (SNAPLib/PairedAligner.cpp:227-242) and the paired
+ * branch of AlignerOptions::AlignerOptions (AlignerOptions.cpp:103-110), i.e. what
+ * PairedAlignerContext passes to the IntersectingPairedEndAligner / ChimericPairedEndAligner
+ * constructors (PairedAligner.cpp:589-625).  The single-end aligner inside the chimeric
+ * fallback uses the context's snapgpu_params with max_k/2 (ChimericPairedEndAligner.cpp:81). */
+typedef struct snapgpu_paired_params {
+    int32_t  min_spacing;                 /* -s, 0                                        */
+    uint32_t max_spacing;                 /* -s, 1000                                     */
+    uint32_t force_spacing;               /* -fs, 0                                       */
+    uint32_t max_big_hits;                /* -H, intersectingAlignerMaxHits, 4000         */
+    uint32_t max_candidate_pool_size;     /* -mcp, 1000000                                */
+    uint32_t num_seeds;                   /* -n for the intersecting aligner, 8           */
+    double   seed_coverage;               /* -sc, 0                                       */
+    uint32_t max_k_for_indels;            /* -i, 40                                       */
+    uint32_t min_read_length;             /* -mrl, 50                                     */
+    uint32_t use_soft_clipping;           /* 1                                            */
+    int32_t  flatten_mapq_at_or_below;    /* 3                                            */
+    int32_t  min_score_realignment;       /* 3                                            */
+    int32_t  min_score_gap_realignment_alt; /* 3                                          */
+    int32_t  min_ag_score_improvement;    /* 24                                           */
+    uint32_t enable_hamming_scoring_base_aligner; /* 1                                    */
+    uint32_t max_single_seeds;            /* maxSeedsSingleEnd, 25 (PairedAligner.cpp:57) */
+} snapgpu_paired_params;
+
+/* POD mirror of PairedAlignmentResult (SNAPLib/AlignmentResult.h:87-128).                */
+typedef struct snapgpu_paired_result {
+    int32_t  status[2];
+    int32_t  direction[2];
+    int64_t  location[2];
+    int64_t  orig_location[2];
+    int32_t  score[2];
+    int32_t  score_prior_to_clipping[2];
+    int32_t  mapq[2];
+    int32_t  clipping_for_read_adjustment[2];
+    int32_t  used_affine_gap_scoring[2];
+    int32_t  bases_clipped_before[2];
+    int32_t  bases_clipped_after[2];
+    int32_t  ag_score[2];
+    int32_t  supplementary[2];
+    int32_t  seed_offset[2];
+    int32_t  lv_indels[2];
+    double   match_probability[2];
+    double   probability_all_pairs;
+    uint32_t popular_seeds_skipped[2];
+    int32_t  used_gapless_clipping[2];
+    int32_t  ref_span[2];
+    int32_t  liftover[2];
+    int32_t  aligned_as_pair;
+    int32_t  ag_forced_single_aligner_call;
+    uint32_t reserved;                    /* stale-traceback flag count, as in snapgpu_single_result */
+    uint32_t flags;                       /* SNAPGPU_PAIR_* bits                          */
+} snapgpu_paired_result;
+
+#define SNAPGPU_PAIR_POOL_OVERFLOW   1u   /* candidate pool / affine-gap candidate buffer too small: result invalid */
+
 /* per-call work counters (what BaseAligner exposes through getNHashTableLookups() etc.,
  * BaseAligner.h:106-111), used for the algorithmic-bytes roofline model.                */
 typedef struct snapgpu_counters {

@@ -91,6 +91,29 @@ class RefIndex:
         return primary, first_alt, dict(lookups=int(counters[0]), lv=int(counters[1]), ag=int(counters[2])), secs.value
 
 
+    def align_paired(self, params: Params, pparams, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray,
+                     threads: int = 1, stage: int = 0):
+        """ChimericPairedEndAligner::align (stage 0) or IntersectingPairedEndAligner::align only (stage 1)
+        over a batch of pairs; offsets has 2n+1 entries (read 0 and read 1 of each pair interleaved).
+        Returns (primary, first_alt, counters, seconds)."""
+        from snap_amd.abi import PAIRED_RESULT_DTYPE
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        assert (offsets.size - 1) % 2 == 0
+        n = (offsets.size - 1) // 2
+        primary = np.zeros(n, dtype=PAIRED_RESULT_DTYPE)
+        first_alt = np.zeros(n, dtype=PAIRED_RESULT_DTYPE)
+        counters = np.zeros(2, dtype=np.int64)
+        secs = C.c_double(0)
+        rc = lib().snapref_align_paired(self.handle, C.byref(params), C.byref(pparams), C.c_int(stage), C.c_uint32(n),
+                                        ptr(bases), ptr(quals), ptr(offsets), C.c_int(threads), ptr(primary),
+                                        ptr(first_alt), ptr(counters), C.byref(secs))
+        if rc != 0:
+            raise RuntimeError("snapref_align_paired rc=%d" % rc)
+        return primary, first_alt, dict(lv=int(counters[0]), ag=int(counters[1])), secs.value
+
+
 def _pack(strings):
     """list of bytes -> (uint8 buffer, uint32 offsets, int32 lengths)."""
     lens = np.array([len(s) for s in strings], dtype=np.int32)

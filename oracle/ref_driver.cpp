@@ -11,6 +11,9 @@
  *   snapref_affine_gap     -> AffineGapVectorized<+-1>::computeScore[Banded] (AffineGapVectorized.h:821/256)
  *   snapref_align_single   -> BaseAligner::AlignRead               (BaseAligner.cpp:273), one
  *                             aligner object per thread exactly as SingleAligner.cpp:145-173 builds it
+ *   snapref_align_paired   -> ChimericPairedEndAligner::align over IntersectingPairedEndAligner::align
+ *                             (ChimericPairedEndAligner.cpp:126, IntersectingPairedEndAligner.cpp:169),
+ *                             objects built as PairedAligner.cpp:556-625 builds them
  *
  * Nothing under snap_amd/ may link, import or call this file; only tests/, bench.py's
  * cpu_baseline leg and __graft_entry__.smoke() do, and only as the checker.
@@ -28,6 +31,8 @@
 #include "Read.h"
 #include "Seed.h"
 #include "mapq.h"
+#include "IntersectingPairedEndAligner.h"
+#include "ChimericPairedEndAligner.h"
 
 #include <pthread.h>
 #include <string.h>
@@ -36,6 +41,8 @@
 #include <vector>
 
 #include "../include/snapgpu.h"
+
+extern GenomeIndex *g_index;                 // SNAPLib/AlignerContext.cpp:58
 
 extern "C" {
 
@@ -355,6 +362,180 @@ int snapref_align_single(void *vindex, const snapgpu_params *p, uint32_t n, cons
     clock_gettime(CLOCK_MONOTONIC, &t1);
     if (seconds) *seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
     if (counters3) { counters3[0] = job.lookups; counters3[1] = job.lv; counters3[2] = job.ag; }
+    pthread_mutex_destroy(&job.lock);
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------- paired end
+
+static void fill_paired(snapgpu_paired_result *o, const PairedAlignmentResult *r)
+{
+    memset(o, 0, sizeof(*o));
+    for (int i = 0; i < 2; i++) {
+        o->status[i] = (int32_t)r->status[i];
+        o->direction[i] = (int32_t)r->direction[i];
+        o->location[i] = (int64_t)GenomeLocationAsInt64(r->location[i]);
+        o->orig_location[i] = (int64_t)GenomeLocationAsInt64(r->origLocation[i]);
+        o->score[i] = r->score[i];
+        o->score_prior_to_clipping[i] = r->scorePriorToClipping[i];
+        o->mapq[i] = r->mapq[i];
+        o->clipping_for_read_adjustment[i] = r->clippingForReadAdjustment[i];
+        o->used_affine_gap_scoring[i] = r->usedAffineGapScoring[i] ? 1 : 0;
+        o->bases_clipped_before[i] = r->basesClippedBefore[i];
+        o->bases_clipped_after[i] = r->basesClippedAfter[i];
+        o->ag_score[i] = r->agScore[i];
+        o->supplementary[i] = r->supplementary[i] ? 1 : 0;
+        o->seed_offset[i] = r->seedOffset[i];
+        o->lv_indels[i] = r->lvIndels[i];
+        o->match_probability[i] = r->matchProbability[i];
+        o->popular_seeds_skipped[i] = r->popularSeedsSkipped[i];
+        o->used_gapless_clipping[i] = r->usedGaplessClipping[i] ? 1 : 0;
+        o->ref_span[i] = r->refSpan[i];
+        o->liftover[i] = r->liftover[i] ? 1 : 0;
+    }
+    o->probability_all_pairs = r->probabilityAllPairs;
+    o->aligned_as_pair = r->alignedAsPair ? 1 : 0;
+    o->ag_forced_single_aligner_call = r->agForcedSingleAlignerCall ? 1 : 0;
+}
+
+struct PairedJob {
+    GenomeIndex *index;
+    const snapgpu_params *p;
+    const snapgpu_paired_params *pp;
+    int stage;                 // 0: ChimericPairedEndAligner::align; 1: IntersectingPairedEndAligner::align only
+    uint32_t n;                // pairs
+    const char *bases;
+    const char *quals;
+    const uint64_t *offsets;   // [2n+1]
+    snapgpu_paired_result *primary;
+    snapgpu_paired_result *first_alt;
+    volatile _int64 next;
+    uint32_t chunk;
+    pthread_mutex_t lock;
+    _int64 lv, ag;
+};
+
+static void *paired_thread(void *arg)
+{
+    PairedJob *job = (PairedJob *)arg;
+    const snapgpu_params *p = job->p;
+    const snapgpu_paired_params *pp = job->pp;
+    GenomeIndex *index = job->index;
+    int maxReadSize = MAX_READ_LENGTH;
+    const int maxSecondaryAlignmentsPerContig = -1;
+
+    // mirror of PairedAligner.cpp:556-640
+    size_t memoryPoolSize = IntersectingPairedEndAligner::getBigAllocatorReservation(index, pp->max_big_hits, maxReadSize, index->getSeedLength(),
+        pp->num_seeds, pp->seed_coverage, MAX_K, p->extra_search_depth, pp->max_candidate_pool_size, maxSecondaryAlignmentsPerContig);
+    memoryPoolSize += ChimericPairedEndAligner::getBigAllocatorReservation(index, maxReadSize, p->max_hits, index->getSeedLength(), pp->max_single_seeds,
+        p->seed_coverage, MAX_K, p->extra_search_depth, pp->max_candidate_pool_size, maxSecondaryAlignmentsPerContig);
+    _int64 maxPairedCand = p->use_affine_gap ? 4096 : 0, maxSingleCand = p->use_affine_gap ? 4096 : 0;
+    memoryPoolSize += 4096;
+    BigAllocator *allocator = new BigAllocator(memoryPoolSize, 16);
+
+    IntersectingPairedEndAligner *intersectingAligner = new (allocator) IntersectingPairedEndAligner(index, maxReadSize, p->max_hits, p->max_k,
+        pp->max_k_for_indels, pp->num_seeds, pp->seed_coverage, pp->min_spacing, pp->max_spacing, pp->max_big_hits, p->extra_search_depth,
+        pp->max_candidate_pool_size, maxSecondaryAlignmentsPerContig, allocator, DisabledOptimizations(), p->use_affine_gap != 0,
+        true /* ignoreAlignmentAdjustmentForOm */, p->alt_awareness != 0, p->max_score_gap_to_prefer_non_alt,
+        p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty, pp->use_soft_clipping != 0);
+
+    ChimericPairedEndAligner *aligner = new (allocator) ChimericPairedEndAligner(index, maxReadSize, p->max_hits, p->max_k, pp->max_single_seeds,
+        p->seed_coverage, p->min_weight_to_check, pp->force_spacing != 0, p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0,
+        true, p->alt_awareness != 0, p->emit_alt_alignments != 0, intersectingAligner, pp->min_read_length, maxSecondaryAlignmentsPerContig,
+        p->max_score_gap_to_prefer_non_alt, pp->flatten_mapq_at_or_below, pp->use_soft_clipping != 0, p->match_reward, p->sub_penalty,
+        p->gap_open_penalty, p->gap_extend_penalty, p->five_prime_end_bonus, p->three_prime_end_bonus, pp->min_score_realignment,
+        pp->min_score_gap_realignment_alt, pp->min_ag_score_improvement, pp->enable_hamming_scoring_base_aligner != 0, allocator);
+
+    PairedAlignmentResult *pairedCand = maxPairedCand ? (PairedAlignmentResult *)BigAlloc(maxPairedCand * sizeof(PairedAlignmentResult)) : NULL;
+    SingleAlignmentResult *singleCand = maxSingleCand ? (SingleAlignmentResult *)BigAlloc(maxSingleCand * sizeof(SingleAlignmentResult)) : NULL;
+
+    std::vector<char> bbuf[2], qbuf[2];
+    for (int r = 0; r < 2; r++) { bbuf[r].assign(MAX_READ_LENGTH + 2 * SLACK, 0); qbuf[r].assign(MAX_READ_LENGTH + 2 * SLACK, 0); }
+
+    for (;;) {
+        _int64 begin = __sync_fetch_and_add(&job->next, (_int64)job->chunk);
+        if (begin >= (_int64)job->n) break;
+        _int64 end = begin + job->chunk;
+        if (end > (_int64)job->n) end = job->n;
+        for (_int64 i = begin; i < end; i++) {
+            Read reads[2];
+            for (int r = 0; r < 2; r++) {
+                unsigned len = (unsigned)(job->offsets[2 * i + r + 1] - job->offsets[2 * i + r]);
+                memcpy(&bbuf[r][SLACK], job->bases + job->offsets[2 * i + r], len);
+                memcpy(&qbuf[r][SLACK], job->quals + job->offsets[2 * i + r], len);
+                reads[r].init("r", 1, &bbuf[r][SLACK], &qbuf[r][SLACK], len, NULL, 0);
+            }
+            PairedAlignmentResult result, alt;
+            memset(&result, 0, sizeof(result));
+            memset(&alt, 0, sizeof(alt));
+            _int64 nSecondary = 0, nPairedCand = 0, nSingleSecondary[2] = {0, 0}, nSingleCand[2] = {0, 0};
+            for (;;) {
+                bool ok;
+                if (job->stage == 1) {
+                    ok = intersectingAligner->align(&reads[0], &reads[1], &result, &alt, -1, 0, &nSecondary, NULL, 0, 0x7fffffff,
+                        &nSingleSecondary[0], &nSingleSecondary[1], NULL, maxPairedCand, &nPairedCand, pairedCand, maxSingleCand,
+                        &nSingleCand[0], &nSingleCand[1], singleCand, (int)p->max_k);
+                } else {
+                    // same call shape as PairedAligner.cpp:727 with the default -om (none)
+                    ok = aligner->align(&reads[0], &reads[1], &result, &alt, -1, 0, &nSecondary, NULL, 0, 0x7fffffff,
+                        &nSingleSecondary[0], &nSingleSecondary[1], NULL, maxPairedCand, &nPairedCand, pairedCand, maxSingleCand,
+                        &nSingleCand[0], &nSingleCand[1], singleCand, (int)p->max_k);
+                }
+                if (ok) break;
+                // PairedAligner.cpp:758-781: double whichever candidate buffer overflowed and call again
+                if (nPairedCand > maxPairedCand) {
+                    BigDealloc(pairedCand); maxPairedCand *= 2;
+                    pairedCand = (PairedAlignmentResult *)BigAlloc(maxPairedCand * sizeof(PairedAlignmentResult));
+                } else if (nSingleCand[0] > maxSingleCand) {
+                    BigDealloc(singleCand); maxSingleCand *= 2;
+                    singleCand = (SingleAlignmentResult *)BigAlloc(maxSingleCand * sizeof(SingleAlignmentResult));
+                } else {
+                    break;      // secondary buffers are not in use here
+                }
+            }
+            fill_paired(&job->primary[i], &result);
+            if (job->first_alt) fill_paired(&job->first_alt[i], &alt);
+        }
+    }
+
+    pthread_mutex_lock(&job->lock);
+    job->lv += aligner->getLocationsScoredWithLandauVishkin();
+    job->ag += aligner->getLocationsScoredWithAffineGap();
+    pthread_mutex_unlock(&job->lock);
+
+    if (pairedCand) BigDealloc(pairedCand);
+    if (singleCand) BigDealloc(singleCand);
+    aligner->~ChimericPairedEndAligner();
+    intersectingAligner->~IntersectingPairedEndAligner();
+    delete allocator;
+    return NULL;
+}
+
+/* offsets: [2n+1]; read r of pair i is bases[offsets[2i+r] .. offsets[2i+r+1]).
+ * counters2 = {LV locations, AG locations} (paired + single-end fallback).               */
+int snapref_align_paired(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp, int stage, uint32_t n,
+                         const char *bases, const char *quals, const uint64_t *offsets, int n_threads,
+                         snapgpu_paired_result *primary, snapgpu_paired_result *first_alt,
+                         int64_t *counters2, double *seconds)
+{
+    snapref_init();
+    GenomeIndex *index = (GenomeIndex *)vindex;
+    if (index->doesGenomeIndexHave64BitLocations()) return SNAPGPU_E_UNSUPPORTED;
+    g_index = index;                                   // AlignerContext.cpp:253 (used by compareByContigAndScore only)
+    PairedJob job;
+    job.index = index; job.p = p; job.pp = pp; job.stage = stage; job.n = n; job.bases = bases; job.quals = quals; job.offsets = offsets;
+    job.primary = primary; job.first_alt = first_alt; job.next = 0; job.chunk = 64; job.lv = job.ag = 0;
+    pthread_mutex_init(&job.lock, NULL);
+    if (n_threads < 1) n_threads = 1;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    std::vector<pthread_t> th(n_threads);
+    for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, paired_thread, &job);
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (seconds) *seconds = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    if (counters2) { counters2[0] = job.lv; counters2[1] = job.ag; }
     pthread_mutex_destroy(&job.lock);
     return 0;
 }

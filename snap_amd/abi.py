@@ -28,6 +28,36 @@ RESULT_DTYPE = np.dtype([
 ], align=True)
 assert RESULT_DTYPE.itemsize == 88, RESULT_DTYPE.itemsize
 
+# snapgpu_paired_result (POD mirror of PairedAlignmentResult, SNAPLib/AlignmentResult.h:87-128)
+PAIRED_RESULT_DTYPE = np.dtype([
+    ("status", np.int32, 2),
+    ("direction", np.int32, 2),
+    ("location", np.int64, 2),
+    ("orig_location", np.int64, 2),
+    ("score", np.int32, 2),
+    ("score_prior_to_clipping", np.int32, 2),
+    ("mapq", np.int32, 2),
+    ("clipping_for_read_adjustment", np.int32, 2),
+    ("used_affine_gap_scoring", np.int32, 2),
+    ("bases_clipped_before", np.int32, 2),
+    ("bases_clipped_after", np.int32, 2),
+    ("ag_score", np.int32, 2),
+    ("supplementary", np.int32, 2),
+    ("seed_offset", np.int32, 2),
+    ("lv_indels", np.int32, 2),
+    ("match_probability", np.float64, 2),
+    ("probability_all_pairs", np.float64),
+    ("popular_seeds_skipped", np.uint32, 2),
+    ("used_gapless_clipping", np.int32, 2),
+    ("ref_span", np.int32, 2),
+    ("liftover", np.int32, 2),
+    ("aligned_as_pair", np.int32),
+    ("ag_forced_single_aligner_call", np.int32),
+    ("reserved", np.uint32),
+    ("flags", np.uint32),
+], align=True)
+assert PAIRED_RESULT_DTYPE.itemsize == 208, PAIRED_RESULT_DTYPE.itemsize
+
 NOT_FOUND, SINGLE_HIT, MULTIPLE_HITS = 0, 1, 2
 SCORE_ABOVE_LIMIT = -1
 INVALID_GENOME_LOCATION_32 = 0xFFFFFFFF
@@ -78,6 +108,41 @@ class Params(C.Structure):
         ("max_score_gap_to_prefer_non_alt", C.c_int32),
         ("max_read_len", C.c_uint32),
     ]
+
+
+class PairedParams(C.Structure):
+    _fields_ = [
+        ("min_spacing", C.c_int32),
+        ("max_spacing", C.c_uint32),
+        ("force_spacing", C.c_uint32),
+        ("max_big_hits", C.c_uint32),
+        ("max_candidate_pool_size", C.c_uint32),
+        ("num_seeds", C.c_uint32),
+        ("seed_coverage", C.c_double),
+        ("max_k_for_indels", C.c_uint32),
+        ("min_read_length", C.c_uint32),
+        ("use_soft_clipping", C.c_uint32),
+        ("flatten_mapq_at_or_below", C.c_int32),
+        ("min_score_realignment", C.c_int32),
+        ("min_score_gap_realignment_alt", C.c_int32),
+        ("min_ag_score_improvement", C.c_int32),
+        ("enable_hamming_scoring_base_aligner", C.c_uint32),
+        ("max_single_seeds", C.c_uint32),
+    ]
+
+
+def default_paired_params(**overrides) -> PairedParams:
+    """PairedAlignerOptions defaults, PairedAligner.cpp:55-57, 227-242; AlignerOptions.cpp:103-110."""
+    p = PairedParams(min_spacing=0, max_spacing=1000, force_spacing=0, max_big_hits=4000,
+                     max_candidate_pool_size=1000000, num_seeds=8, seed_coverage=0.0, max_k_for_indels=40,
+                     min_read_length=50, use_soft_clipping=1, flatten_mapq_at_or_below=3,
+                     min_score_realignment=3, min_score_gap_realignment_alt=3, min_ag_score_improvement=24,
+                     enable_hamming_scoring_base_aligner=1, max_single_seeds=25)
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
 
 
 class Counters(C.Structure):

@@ -133,6 +133,67 @@ def make_reads(seed: int, contigs, n_reads: int, read_len: int, sub: float = 0.0
 _ACGT_SORTED = np.sort(_ACGT)
 
 
+def make_pairs(seed: int, contigs, n_pairs: int, read_len: int, insert_mean: float = 400.0, insert_sd: float = 50.0,
+               insert_min: int = 150, insert_max: int = 1000, sub: float = 0.01, ins: float = 0.0005,
+               dele: float = 0.0005, qmin: int = 20, qmax: int = 40, n_frac: float = 0.0,
+               long_indel_frac: float = 0.0, long_indel_max: int = 10):
+    """FR pairs: fragment length ~ N(insert_mean, insert_sd^2) clipped to
+    [insert_min, insert_max]; mate 0 is the fragment's left end on the fragment strand, mate 1 the
+    reverse complement of its right end; the fragment strand is forward for half of the pairs.
+    Returns a dict with interleaved reads: bases[2n, L], quals[2n, L], offsets[2n+1], plus truth."""
+    rng = np.random.default_rng(seed)
+    L = read_len
+    lens = np.array([len(g) for _, g in contigs], dtype=np.int64)
+    frag = np.clip(np.rint(rng.normal(insert_mean, insert_sd, size=n_pairs)), max(insert_min, L), insert_max).astype(np.int64)
+    span = frag + 32
+    w = np.where(lens > span.max() + 1, lens - span.max(), 0).astype(np.float64)
+    ci = rng.choice(len(contigs), size=n_pairs, p=w / w.sum())
+    pos = (rng.random(n_pairs) * (lens[ci] - span)).astype(np.int64)
+    cat = np.concatenate([g for _, g in contigs])
+    cstart = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    gpos = cstart[ci] + pos
+
+    def sample(start):
+        ev = np.zeros((n_pairs, L), dtype=np.int64)
+        r = rng.random((n_pairs, L))
+        ev[r < dele] = 1
+        is_ins = (r >= dele) & (r < dele + ins)
+        ev[is_ins] = -1
+        if long_indel_frac > 0:                       # one longer deletion in some reads (exercises affine gap)
+            who = rng.random(n_pairs) < long_indel_frac
+            at = rng.integers(L // 4, 3 * L // 4, size=n_pairs)
+            ln = rng.integers(2, long_indel_max + 1, size=n_pairs)
+            ev[who, at[who]] += ln[who]
+        ev[:, 0] = 0
+        is_ins[:, 0] = False
+        shift = np.cumsum(ev, axis=1)
+        idx = np.clip(start[:, None] + np.arange(L)[None, :] + shift, 0, len(cat) - 1)
+        b = cat[idx]
+        rnd = _ACGT[rng.integers(0, 4, size=(n_pairs, L), dtype=np.uint8)]
+        b = np.where(is_ins, rnd, b)
+        subm = rng.random((n_pairs, L)) < sub
+        alt = _ACGT_SORTED[(np.searchsorted(_ACGT_SORTED, np.where(b == ord("N"), ord("A"), b))
+                            + rng.integers(1, 4, size=(n_pairs, L))) % 4]
+        b = np.where(subm & (b != ord("N")), alt, b)
+        if n_frac > 0:
+            b = np.where(rng.random((n_pairs, L)) < n_frac, np.uint8(ord("N")), b)
+        return np.ascontiguousarray(b)
+
+    left = sample(gpos)                               # forward-strand bases of the fragment's left end
+    right = sample(gpos + frag - L)                   # forward-strand bases of its right end
+    right_rc = _COMP[right[:, ::-1]]
+    left_rc = _COMP[left[:, ::-1]]
+    flip = rng.random(n_pairs) < 0.5                  # fragment from the reverse strand: mates swap roles
+    m0 = np.where(flip[:, None], right_rc, left)
+    m1 = np.where(flip[:, None], left, right_rc)
+    bases = np.empty((2 * n_pairs, L), dtype=np.uint8)
+    bases[0::2] = m0
+    bases[1::2] = m1
+    quals = rng.integers(qmin + 33, qmax + 34, size=(2 * n_pairs, L), dtype=np.uint8)
+    return dict(bases=bases, quals=quals, offsets=np.arange(2 * n_pairs + 1, dtype=np.uint64) * L,
+                contig=ci, pos=pos, frag=frag, flip=flip)
+
+
 def write_fastq(path: str, reads, prefix: str = "r") -> None:
     bases, quals = reads["bases"], reads["quals"]
     with open(path, "wb") as f:
