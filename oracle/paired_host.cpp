@@ -1,0 +1,193 @@
+/*
+ * paired_host.cpp -- TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+ *
+ * Compiles the paired-end control flow of snap_amd/csrc/paired.h for the host (SNAP_PE_HOST) with
+ * the CPU restatement's primitives (snap_oracle.c: seed lookup, Landau-Vishkin, affine gap) plugged
+ * in where the device build uses the wavefront kernels, and -- for the chimeric fallback -- the
+ * reference's own single-end aligner (ref_driver.cpp: snapref_chimeric_single_*).  That lets the CPU
+ * test-suite diff the exact control flow the GPU executes against the reference's
+ * IntersectingPairedEndAligner / ChimericPairedEndAligner without a GPU.  The product never links this.
+ */
+#define SNAP_PE_HOST 1
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "../snap_amd/csrc/paired.h"
+#include "snap_oracle.h"
+
+extern "C" {
+void *snapref_chimeric_single_create(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp);
+int   snapref_chimeric_single_align(void *h, int max_k, int hamming, const char *bases, const char *quals, uint32_t len,
+                                    snapgpu_single_result *res, snapgpu_single_result *alt);
+void  snapref_chimeric_single_destroy(void *h);
+}
+
+struct HostPL {
+    const snapgpu_index_view *ix;
+    oracle_index oix;
+    oracle_ag_params agp;
+    const double *phred_t, *indel_t, *perfect_t;
+    double seed_prob_v;
+    int seed_len;
+    void *single;                         // reference single-end aligner (chimeric fallback), may be NULL for stage 1
+    const uint8_t *read_b[2], *read_q[2];
+    int read_l[2];
+    uint32_t stale_single;
+
+    template <class T> static T ld(const T &x) { return x; }
+    template <class T> static void st(T &x, T v) { x = v; }
+    static int i32(int v) { return v; }
+    static double f64(double v) { return v; }
+    static bool lane0() { return true; }
+    static void sync() {}
+
+    bool lookup(const uint8_t *text, PEHits out[2]) {
+        uint64_t bases, rc;
+        if (!oracle_pack_seed((const char *)text, (unsigned)seed_len, &bases, &rc)) return false;
+        int64_t n[2]; const uint32_t *h[2]; uint32_t single_v[2], slots[2];
+        oracle_lookup_seed(&oix, bases, rc, n, h, single_v, slots);
+        for (int d = 0; d < 2; d++) { out[d].n_hits = n[d]; out[d].hits = n[d] > 1 ? h[d] : NULL; out[d].singleton = single_v[d]; }
+        return true;
+    }
+    uint32_t wrapped_seed(uint32_t wrap) const { return oracle_wrapped_next_seed((unsigned)seed_len, wrap); }
+    uint32_t count_n(const uint8_t *b, int len) const { uint32_t n = 0; for (int i = 0; i < len; i++) n += b[i] == 'N'; return n; }
+    const uint8_t *window(int64_t loc, int) const { return ix->genome + loc; }
+    bool is_alt(int64_t loc) const { return loc >= 0 && (uint64_t)loc >= ix->first_alt_location; }
+
+    // Genome::getSubstring(loc, len) != NULL, SNAPLib/Genome.h:339-367
+    bool substring_ok(int64_t loc, int64_t len) const {
+        int64_t nb = (int64_t)ix->n_bases;
+        if (loc > nb || loc + len > nb + 1000) return false;
+        if (loc < -(int64_t)ix->genome_pad) return false;
+        if (len <= (int64_t)ix->chromosome_padding && ix->genome[loc] != 'n') return true;
+        if (len == 0) return true;
+        int lo = 0, hi = (int)ix->n_contigs - 1, found = -1;
+        while (lo <= hi) {
+            int mid = (lo + hi) >> 1;
+            if ((int64_t)ix->contig_begin[mid] <= loc) { found = mid; lo = mid + 1; } else hi = mid - 1;
+        }
+        if (found < 0) return false;
+        int64_t cend = found == (int)ix->n_contigs - 1 ? nb : (int64_t)ix->contig_begin[found + 1];
+        return cend > loc + len;
+    }
+    int mapq(double p_all, double p_best, int popular) const { return oracle_compute_mapq(p_all, p_best, 0, popular); }
+    double seed_prob() const { return seed_prob_v; }
+    double phred(uint8_t q) const { return phred_t[q]; }
+    double indel(int n) const { return indel_t[n]; }
+    double perfect(int n) const { return perfect_t[n]; }
+
+    // The core addresses pattern/quality/text of a backward problem at the first byte compared and walks with
+    // stride -1 (the device convention).  The oracle follows the reference: reversed pattern/quality arrays and a
+    // text pointer one past the first compared byte.
+    LVOut lv(int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int k) const {
+        LVOut o; o.score = -1; o.mp = 0; o.net_indel = 0; o.total_indels = 0; o.text_span = 0;
+        std::vector<char> pb(plen + 16), qb(plen + 16);
+        for (int i = 0; i < plen; i++) { pb[i] = (char)P[i * st]; qb[i] = (char)Q[i * st]; }
+        double mp = 1.0;
+        int net = 0, tot = 0, span = 0;
+        o.score = oracle_lv(st, (const char *)(st > 0 ? T : T + 1), tlen, &pb[0], &qb[0], plen, k, &mp, &net, &tot, &span);
+        o.mp = mp; o.net_indel = net; o.total_indels = tot; o.text_span = span;
+        return o;
+    }
+    AGOut ag(bool banded, int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int lim, int read_len,
+             bool is_rc, bool use_clip) const {
+        AGOut o;
+        std::vector<char> pb(plen + 16), qb(plen + 16);
+        for (int i = 0; i < plen; i++) { pb[i] = (char)P[i * st]; qb[i] = (char)Q[i * st]; }
+        int to = -1, po = -1, ne = -1, stale = 0;
+        double mp = 1.0;
+        o.ag_score = oracle_ag(st, banded ? 1 : 0, &agp, (const char *)(st > 0 ? T : T + 1), tlen, &pb[0], &qb[0], plen, lim, read_len,
+                               is_rc ? 1 : 0, use_clip ? 1 : 0, &to, &po, &ne, &mp, &stale);
+        o.text_offset = to; o.pattern_offset = po; o.n_edits = ne; o.mp = mp; o.stale = stale;
+        return o;
+    }
+    void align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt) {
+        snapref_chimeric_single_align(single, max_k, hamming ? 1 : 0, (const char *)read_b[r], (const char *)read_q[r], (uint32_t)read_l[r], &res, &alt);
+    }
+};
+
+static uint8_t rc_of(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+
+extern "C" int pairedhost_align(const snapgpu_index_view *ix, void *ref_index, const snapgpu_params *p, const snapgpu_paired_params *pp,
+                                int stage, uint32_t n, const char *bases, const char *quals, const uint64_t *offsets,
+                                snapgpu_paired_result *primary, snapgpu_paired_result *first_alt, int64_t *counters3)
+{
+    oracle_init();
+    HostPL pl;
+    pl.ix = ix;
+    pl.oix.seed_len = ix->seed_len; pl.oix.key_bytes = ix->key_bytes; pl.oix.n_hash_tables = ix->n_hash_tables; pl.oix.large = ix->large_hash_table;
+    pl.oix.hash_blob = ix->hash_blob; pl.oix.table_offset = ix->table_offset; pl.oix.table_size = ix->table_size; pl.oix.overflow = ix->overflow;
+    pl.oix.n_bases = ix->n_bases;
+    pl.agp.match_reward = (int)p->match_reward; pl.agp.sub_penalty = (int)p->sub_penalty; pl.agp.gap_open = (int)p->gap_open_penalty;
+    pl.agp.gap_extend = (int)p->gap_extend_penalty; pl.agp.five_bonus = (int)p->five_prime_end_bonus; pl.agp.three_bonus = (int)p->three_prime_end_bonus;
+    pl.phred_t = oracle_phred_table(); pl.indel_t = oracle_indel_table(); pl.perfect_t = oracle_perfect_table();
+    pl.seed_len = (int)ix->seed_len;
+    pl.seed_prob_v = oracle_seed_prob(pl.seed_len);
+    pl.single = (stage == 0 && ref_index) ? snapref_chimeric_single_create(ref_index, p, pp) : NULL;
+
+    PECfg cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.max_k = (int)p->max_k; cfg.extra_depth = (int)p->extra_search_depth; cfg.max_k_for_indels = (int)pp->max_k_for_indels;
+    cfg.max_gap_alt = p->max_score_gap_to_prefer_non_alt; cfg.use_ag = p->use_affine_gap; cfg.alt_aware = p->alt_awareness;
+    cfg.emit_alt = p->emit_alt_alignments; cfg.use_soft_clip = pp->use_soft_clipping; cfg.force_spacing = pp->force_spacing;
+    cfg.match_reward = (int)p->match_reward; cfg.sub_penalty = (int)p->sub_penalty; cfg.gap_open = (int)p->gap_open_penalty;
+    cfg.gap_extend = (int)p->gap_extend_penalty; cfg.five_bonus = (int)p->five_prime_end_bonus; cfg.three_bonus = (int)p->three_prime_end_bonus;
+    cfg.min_spacing = pp->min_spacing; cfg.max_spacing = pp->max_spacing; cfg.max_big_hits = pp->max_big_hits;
+    cfg.num_seeds = pp->num_seeds < PE_MAX_SEEDS ? pp->num_seeds : PE_MAX_SEEDS; cfg.seed_coverage = pp->seed_coverage;
+    cfg.min_read_length = pp->min_read_length; cfg.flatten_mapq = pp->flatten_mapq_at_or_below; cfg.min_score_realign = pp->min_score_realignment;
+    cfg.min_score_gap_realign_alt = pp->min_score_gap_realignment_alt; cfg.min_ag_improve = pp->min_ag_score_improvement;
+    cfg.enable_hamming_base = pp->enable_hamming_scoring_base_aligner; cfg.seed_len = (int)ix->seed_len;
+    uint32_t max_seeds = cfg.num_seeds ? cfg.num_seeds : PE_MAX_SEEDS;
+    uint64_t pool = (uint64_t)pp->max_big_hits * max_seeds * 2;
+    cfg.pool_size = (uint32_t)(pool < pp->max_candidate_pool_size ? pool : pp->max_candidate_pool_size);
+    cfg.ag_cand_cap = p->use_affine_gap ? 65536 : 0;
+    cfg.max_seeds = PE_MAX_SEEDS;
+
+    PairedCore<HostPL> core(pl, cfg);
+    std::vector<PELookup> lk(4 * cfg.max_seeds);
+    std::vector<uint32_t> exhausted(4 * cfg.max_seeds), miss(cfg.max_seeds), seed_used(64);
+    std::vector<PEHitSetHdr> hs(4);
+    std::vector<int32_t> list_head(SNAPGPU_MAX_K + 2);
+    std::vector<PECand> cand(cfg.pool_size);
+    std::vector<PEMate> mate0(cfg.pool_size / 2 + 1), mate1(cfg.pool_size / 2 + 1);
+    std::vector<PEAnchor> anchor(cfg.pool_size);
+    std::vector<snapgpu_paired_result> agc(cfg.ag_cand_cap + 1);
+    PEShared sh;
+    memset(&sh, 0, sizeof(sh));
+    core.lk = &lk[0]; core.exhausted = &exhausted[0]; core.miss = &miss[0]; core.hs = &hs[0]; core.list_head = &list_head[0];
+    core.seed_used = &seed_used[0]; core.sh = &sh; core.cand = &cand[0]; core.mate[0] = &mate0[0]; core.mate[1] = &mate1[0];
+    core.anchor = &anchor[0]; core.agc = &agc[0];
+
+    const int PAD = 160;
+    std::vector<uint8_t> buf[2][2], qbuf[2][2];
+    for (uint32_t i = 0; i < n; i++) {
+        for (int r = 0; r < 2; r++) {
+            int len = (int)(offsets[2 * i + r + 1] - offsets[2 * i + r]);
+            const uint8_t *b = (const uint8_t *)bases + offsets[2 * i + r], *q = (const uint8_t *)quals + offsets[2 * i + r];
+            for (int d = 0; d < 2; d++) { buf[r][d].assign(len + 2 * PAD, 0); qbuf[r][d].assign(len + 2 * PAD, 0); }
+            for (int j = 0; j < len; j++) {
+                buf[r][0][PAD + j] = b[j]; qbuf[r][0][PAD + j] = q[j];
+                buf[r][1][PAD + len - 1 - j] = rc_of(b[j]); qbuf[r][1][PAD + len - 1 - j] = q[j];
+            }
+            for (int d = 0; d < 2; d++) { core.rd[r][d] = &buf[r][d][PAD]; core.ql[r][d] = &qbuf[r][d][PAD]; }
+            core.read_len[r] = len;
+            pl.read_b[r] = b; pl.read_q[r] = q; pl.read_l[r] = len;
+        }
+        memset(&sh.res, 0, sizeof(sh.res));
+        memset(&sh.alt, 0, sizeof(sh.alt));
+        core.overflow = 0; core.stale = 0;
+        if (stage == 1) {
+            core.intersecting_align();
+        } else {
+            core.align_pair((int)p->max_k, (int)p->max_k / 2);
+        }
+        sh.res.flags = core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0;
+        sh.res.reserved = core.stale;
+        primary[i] = sh.res;
+        first_alt[i] = sh.alt;
+    }
+    if (counters3) { counters3[0] = (int64_t)sh.cnt.lv; counters3[1] = (int64_t)sh.cnt.ag; counters3[2] = (int64_t)sh.cnt.lookups; }
+    if (pl.single) snapref_chimeric_single_destroy(pl.single);
+    return 0;
+}

@@ -540,4 +540,78 @@ int snapref_align_paired(void *vindex, const snapgpu_params *p, const snapgpu_pa
     return 0;
 }
 
+
+// The single-end aligner inside ChimericPairedEndAligner (ChimericPairedEndAligner.cpp:81-88), on its own, so that the
+// host build of snap_amd/csrc/paired.h (oracle/paired_host.cpp) can plug the reference in for the fallback calls
+// (ChimericPairedEndAligner.cpp:304-360): AlignRead with a per-call maxK, and the Hamming retry + alignAffineGap.
+struct ChimericSingle {
+    BigAllocator *allocator;
+    BaseAligner *aligner;
+    SingleAlignmentResult *cand;
+    _int64 maxCand;
+    std::vector<char> b, q;
+};
+
+void *snapref_chimeric_single_create(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp)
+{
+    snapref_init();
+    GenomeIndex *index = (GenomeIndex *)vindex;
+    int maxReadSize = MAX_READ_LENGTH;
+    ChimericSingle *c = new ChimericSingle();
+    c->allocator = new BigAllocator(BaseAligner::getBigAllocatorReservation(index, true, p->max_hits, maxReadSize, index->getSeedLength(),
+                                    pp->max_single_seeds, p->seed_coverage, -1, p->extra_search_depth) + 4096, 16);
+    c->aligner = new (c->allocator) BaseAligner(index, p->max_hits, p->max_k / 2, maxReadSize, pp->max_single_seeds, p->seed_coverage,
+        p->min_weight_to_check, p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, true, p->alt_awareness != 0,
+        p->emit_alt_alignments != 0, p->max_score_gap_to_prefer_non_alt, -1, NULL, NULL, p->match_reward, p->sub_penalty,
+        p->gap_open_penalty, p->gap_extend_penalty, p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, c->allocator);
+    c->maxCand = 4096;
+    c->cand = (SingleAlignmentResult *)BigAlloc(c->maxCand * sizeof(SingleAlignmentResult));
+    c->b.assign(MAX_READ_LENGTH + 2 * SLACK, 0);
+    c->q.assign(MAX_READ_LENGTH + 2 * SLACK, 0);
+    return c;
+}
+
+int snapref_chimeric_single_align(void *h, int max_k, int hamming, const char *bases, const char *quals, uint32_t len,
+                                  snapgpu_single_result *res, snapgpu_single_result *alt)
+{
+    ChimericSingle *c = (ChimericSingle *)h;
+    memcpy(&c->b[SLACK], bases, len);
+    memcpy(&c->q[SLACK], quals, len);
+    Read read;
+    read.init("r", 1, &c->b[SLACK], &c->q[SLACK], len, NULL, 0);
+    SingleAlignmentResult r, a;
+    memset(&r, 0, sizeof(r));
+    memset(&a, 0, sizeof(a));
+    a.status = NotFound;
+    c->aligner->setMaxK(max_k);
+    _int64 nSecondary = 0, nCand = 0;
+    for (;;) {
+        nCand = 0;
+        bool ok = c->aligner->AlignRead(&read, &r, &a, -1, 0, &nSecondary, 0x7fffffff, NULL, c->maxCand, &nCand, c->cand, hamming != 0);
+        if (ok) break;
+        if (nCand > c->maxCand) {
+            BigDealloc(c->cand);
+            c->maxCand *= 2;
+            c->cand = (SingleAlignmentResult *)BigAlloc(c->maxCand * sizeof(SingleAlignmentResult));
+        } else {
+            break;
+        }
+    }
+    if (hamming) {
+        c->aligner->alignAffineGap(&read, &r, &a, nCand, c->cand);
+    }
+    fill_result(res, &r);
+    if (a.status == NotFound) { memset(alt, 0, sizeof(*alt)); alt->status = NotFound; } else fill_result(alt, &a);
+    return 0;
+}
+
+void snapref_chimeric_single_destroy(void *h)
+{
+    ChimericSingle *c = (ChimericSingle *)h;
+    BigDealloc(c->cand);
+    c->aligner->~BaseAligner();
+    delete c->allocator;
+    delete c;
+}
+
 } // extern "C"
