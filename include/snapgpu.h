@@ -314,6 +314,31 @@ int  snapgpu_align_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, const
 int  snapgpu_align_single_device(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals,
                                  const void *d_offsets, void *d_primary, void *d_first_alt, void *stream);
 
+/*
+ * Paired-end path.  snapgpu_enable_paired builds, on an existing context, the per-wave state of
+ *       IntersectingPairedEndAligner::IntersectingPairedEndAligner   SNAPLib/IntersectingPairedEndAligner.cpp:36-100
+ *       ChimericPairedEndAligner::ChimericPairedEndAligner           SNAPLib/ChimericPairedEndAligner.cpp:42-98
+ * as PairedAlignerContext::runIterationThreadImpl builds them (SNAPLib/PairedAligner.cpp:556-625); the context's
+ * snapgpu_params supply the options both aligners share (maxHits, maxDist, affine-gap scores, ALT handling).
+ * snapgpu_align_paired replaces
+ *       ChimericPairedEndAligner::align                               SNAPLib/ChimericPairedEndAligner.cpp:126-448
+ *         -> IntersectingPairedEndAligner::align                      SNAPLib/IntersectingPairedEndAligner.cpp:169-251
+ *         -> BaseAligner::AlignRead / alignAffineGap (fallback)       SNAPLib/BaseAligner.cpp:273, 1537
+ *       called from PairedAlignerContext::runIterationThreadImpl      SNAPLib/PairedAligner.cpp:727
+ * for a batch of n_pairs pairs: offsets has 2*n_pairs+1 entries, read r of pair i is
+ * bases[offsets[2i+r] .. offsets[2i+r+1]).  primary/first_alt: [n_pairs] out (first_alt may be NULL).
+ * Secondary alignments (-om) and ALT liftover (IntersectingPairedEndAligner.cpp:2890-2968) are not produced.
+ * A pair whose candidate pools overflowed is flagged (SNAPGPU_PAIR_POOL_OVERFLOW) and the call returns
+ * SNAPGPU_E_UNSUPPORTED after filling in every other pair.
+ */
+void snapgpu_default_paired_params(snapgpu_paired_params *pp);
+int  snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_params *pp);
+int  snapgpu_align_paired(snapgpu_ctx *ctx, uint32_t n_pairs, const char *bases, const char *quals,
+                          const uint64_t *offsets, snapgpu_paired_result *primary, snapgpu_paired_result *first_alt);
+/* device-pointer form, as snapgpu_align_single_device */
+int  snapgpu_align_paired_device(snapgpu_ctx *ctx, uint32_t n_pairs, const void *d_bases, const void *d_quals,
+                                 const void *d_offsets, void *d_primary, void *d_first_alt, void *stream);
+
 /* Counters accumulated by snapgpu_align_single* since the last reset (device -> host). */
 int  snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int reset);
 

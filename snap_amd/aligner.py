@@ -45,7 +45,8 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "snapgpu_abi_version", "snapgpu_last_error", "snapgpu_default_params", "snapgpu_create",
-    "snapgpu_destroy", "snapgpu_create_from_directory", "snapgpu_index_device_ptrs", "snapgpu_lookup_seeds",
+    "snapgpu_destroy", "snapgpu_create_from_directory", "snapgpu_default_paired_params", "snapgpu_enable_paired",
+    "snapgpu_align_paired", "snapgpu_align_paired_device", "snapgpu_index_device_ptrs", "snapgpu_lookup_seeds",
     "snapgpu_landau_vishkin", "snapgpu_affine_gap", "snapgpu_align_single",
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
 ]
@@ -213,3 +214,43 @@ class BaseAligner:
         self._check(self.lib.snapgpu_debug_tables(self.handle, ptr(phred), ptr(indel), C.c_uint32(1001), ptr(perfect),
                                                   C.c_uint32(1001), C.byref(sp), ptr(thr), ptr(wrapped)), "snapgpu_debug_tables")
         return dict(phred=phred, indel=indel, perfect=perfect, seed_prob=sp.value, mapq_threshold=thr, wrapped=wrapped)
+
+
+class ChimericPairedEndAligner(BaseAligner):
+    """Paired-end host mirror: ChimericPairedEndAligner over IntersectingPairedEndAligner
+    (SNAPLib/ChimericPairedEndAligner.cpp:126, SNAPLib/IntersectingPairedEndAligner.cpp:169), built the way
+    PairedAlignerContext builds them (SNAPLib/PairedAligner.cpp:556-625).  `params` are the options shared with the
+    single-end aligner (maxHits, maxDist, affine-gap scores ...), `paired_params` the PairedAlignerOptions."""
+
+    def __init__(self, index: GenomeIndex, params: Params | None = None, paired_params=None, device: int = 0,
+                 device_index_ptrs=None):
+        from .abi import PairedParams, default_paired_params
+        super().__init__(index, params, device, device_index_ptrs)
+        self.paired_params = paired_params if paired_params is not None else default_paired_params()
+        self.lib.snapgpu_enable_paired.argtypes = [C.c_void_p, C.POINTER(PairedParams)]
+        self.lib.snapgpu_align_paired_device.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        self._check(self.lib.snapgpu_enable_paired(self.handle, C.byref(self.paired_params)), "snapgpu_enable_paired")
+
+    def align(self, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray):
+        """ChimericPairedEndAligner::align over a batch: offsets has 2n+1 entries (read 0 / read 1 of each pair
+        interleaved).  Returns (result[n], firstALTResult[n]) as PAIRED_RESULT_DTYPE arrays."""
+        from .abi import PAIRED_RESULT_DTYPE
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if (offsets.size - 1) % 2:
+            raise ValueError("offsets must have 2*n_pairs + 1 entries")
+        n = (offsets.size - 1) // 2
+        primary = np.zeros(n, dtype=PAIRED_RESULT_DTYPE)
+        first_alt = np.zeros(n, dtype=PAIRED_RESULT_DTYPE)
+        self._check(self.lib.snapgpu_align_paired(self.handle, C.c_uint32(n), ptr(bases), ptr(quals), ptr(offsets),
+                                                  ptr(primary), ptr(first_alt)), "snapgpu_align_paired")
+        return primary, first_alt
+
+    def align_device(self, n_pairs: int, d_bases: int, d_quals: int, d_offsets: int, d_primary: int, d_first_alt: int = 0,
+                     stream: int = 0):
+        self._check(self.lib.snapgpu_align_paired_device(self.handle, C.c_uint32(n_pairs), C.c_void_p(d_bases),
+                                                         C.c_void_p(d_quals), C.c_void_p(d_offsets), C.c_void_p(d_primary),
+                                                         C.c_void_p(d_first_alt) if d_first_alt else None,
+                                                         C.c_void_p(stream) if stream else None),
+                    "snapgpu_align_paired_device")

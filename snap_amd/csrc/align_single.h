@@ -119,6 +119,7 @@ static __device__ __forceinline__ int compute_mapq(const DevTables *tab, double 
 
 struct WaveShared {                    // per-wave LDS block (see Aligner)
     ScoreSet all, non_alt;
+    ScoreSet ag_all, ag_non_alt;       // the local score sets of BaseAligner::alignAffineGap (paired-end fallback only)
     snapgpu_single_result primary, first_alt;
     WaveCounters cnt;
 };
@@ -154,6 +155,10 @@ struct Aligner {
     uint32_t n_seeds_applied[2];
     uint32_t popular_seeds_skipped;
     uint32_t ag_stale;                 // affine-gap traceback steps outside the computed band (see ag.h)
+    uint32_t max_k;                    // BaseAligner::maxK: cfg.max_k, or what setMaxK() last said (ChimericPairedEndAligner.cpp:278,301)
+    // candidates for BaseAligner::alignAffineGap, collected by the Hamming pass only (BaseAligner.cpp:1445-1456)
+    snapgpu_single_result *agc;
+    uint32_t agc_cap, n_agc, agc_overflow;
     // Cold, wave-uniform state lives in LDS (WaveShared), not in registers: it is touched a few
     // times per candidate / per read, and keeping ~150 dwords of it live across the LV and
     // affine-gap code is what pushed the kernel to 1-2 waves per SIMD.  Every lane executes the
@@ -163,8 +168,8 @@ struct Aligner {
     WaveCounters &cnt;
 
     __device__ __forceinline__ Aligner(const DevIndex &ix_, const DevTables *tab_, const AlignCfg &cfg_, WaveShared *ws)
-        : ix(ix_), tab(tab_), cfg(cfg_), all(ws->all), non_alt(ws->non_alt), primary(ws->primary),
-          first_alt(ws->first_alt), cnt(ws->cnt) {}
+        : ix(ix_), tab(tab_), cfg(cfg_), max_k(cfg_.max_k), agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0),
+          all(ws->all), non_alt(ws->non_alt), primary(ws->primary), first_alt(ws->first_alt), cnt(ws->cnt) {}
 
     // ------------------------------------------------------------------ helpers
     __device__ __forceinline__ bool is_alt(int64_t loc) const { return (uint64_t)loc >= ix.first_alt_location && loc >= 0; }
@@ -179,7 +184,7 @@ struct Aligner {
             int64_t a = (int64_t)all.best_score + cfg.max_gap_alt;
             inner = a < non_alt.best_score ? a : non_alt.best_score;
         }
-        int64_t m = (int64_t)cfg.max_k < inner ? (int64_t)cfg.max_k : inner;
+        int64_t m = (int64_t)max_k < inner ? (int64_t)max_k : inner;
         int64_t v = (int64_t)cfg.extra_depth + m;
         return (int)(v < 126 ? v : 126);
     }
@@ -347,7 +352,23 @@ struct Aligner {
         }
     }
 
-    // ScoreSet::updateBestScore without secondary / AG-candidate buffers (BaseAligner.cpp:2143-2299)
+    // one entry of candidatesForAffineGap (BaseAligner.cpp:2208-2225 / :2279-2296)
+    __device__ __forceinline__ void record_candidate(int dir, int64_t loc, int64_t orig_loc, int score, int used_ag, int clip_before,
+                                                     int clip_after, int ag_score, double mp, int seed_offset) {
+        if (n_agc >= agc_cap) { agc_overflow = 1; return; }
+        snapgpu_single_result *r = &agc[n_agc];
+        if (lane == 0) {
+            r->direction = dir; r->location = loc; r->orig_location = orig_loc; r->mapq = 0; r->score = score;
+            r->status = SNAPGPU_MultipleHits; r->clipping_for_read_adjustment = 0; r->used_affine_gap_scoring = used_ag;
+            r->bases_clipped_before = clip_before; r->bases_clipped_after = clip_after; r->ag_score = ag_score;
+            r->match_probability = mp; r->seed_offset = seed_offset; r->reserved = (uint32_t)score;      // reserved = sort key of alignAffineGap
+        }
+        WAVE_SYNC();
+        n_agc++;
+    }
+
+    // ScoreSet::updateBestScore without secondary results (BaseAligner.cpp:2143-2299); HAM keeps affine-gap candidates
+    template <bool HAM>
     __device__ __forceinline__ bool update_best(ScoreSet &ss, int64_t loc, int64_t orig_loc, uint32_t score,
                                                 int ag_score, double mp, const Elem *e, int e_dir,
                                                 int e_used_ag, int e_clip_before, int e_clip_after, int e_seed_offset,
@@ -357,6 +378,18 @@ struct Aligner {
             seen_new = (ag_score > ss.ag_score) || (ss.ag_score == ag_score && mp > ss.p_best);
         } else {
             seen_new = (score < (uint32_t)ss.best_score) || (score == (uint32_t)ss.best_score && mp > ss.p_best);
+        }
+        if constexpr (HAM) {
+            const uint32_t best = (uint32_t)ss.best_score;
+            if (seen_new) {
+                if (best >= score && (int)(best - score) <= (int)cfg.extra_depth) {                    // the displaced best, :2202
+                    record_candidate(ss.dir, ss.best_loc, ss.best_orig_loc, ss.best_score, ss.used_ag, ss.clip_before, ss.clip_after,
+                                     ss.ag_score, ss.best_match_prob, ss.seed_offset);
+                    if (agc_overflow) return false;
+                }
+            } else if ((int)(best - score) <= (int)cfg.extra_depth && score != (uint32_t)SNAPGPU_ScoreAboveLimit && best >= score) {   // :2273
+                record_candidate(e_dir, loc, orig_loc, (int)score, e_used_ag, e_clip_before, e_clip_after, ag_score, e_match_prob, e_seed_offset);
+            }
         }
         if (seen_new) {
             ss.best_score = (int32_t)score;
@@ -393,6 +426,39 @@ struct Aligner {
         r.probability_all_candidates = ss.p_all;
     }
 
+    // AffineGapVectorized::computeGaplessScore (AffineGapVectorized.h:139-254): Hamming walk away from the seed, the
+    // best-scoring prefix is kept and the rest of the pattern is clipped.  st = +1 / -1; T, P, Q address the first byte.
+    // Wave-uniform scalar code (all operands are LDS bytes); only used for reads nothing else could place.
+    __device__ __forceinline__ int gapless_score(int st, const uint8_t *T, const uint8_t *P, const uint8_t *Q, int plen, int score_init,
+                                                 int limit, int *n_edits, int *pattern_offset, double *mp, int *n_gapless) const {
+        *mp = 1.0;
+        if (limit < 0) { *n_edits = -1; *n_gapless = -1; return -1; }
+        int sc = score_init, best = score_init, best_i = 0;
+        for (int i = 0; i < plen; i++) {
+            sc += (P[i * st] == T[i * st]) ? cfg.match_reward : -cfg.sub_penalty;
+            if (sc > best) { best = sc; best_i = i; }
+        }
+        best = (int)first_u32((uint32_t)best); best_i = (int)first_u32((uint32_t)best_i);
+        if (best > score_init) {
+            int ne = 0, nm = 0;
+            double p = 1.0;
+            for (int i = 0; i <= best_i; i++) {
+                if (P[i * st] != T[i * st]) { ne++; p *= tab->phred[Q[i * st]]; } else nm++;
+            }
+            p *= tab->perfect[nm];
+            const int clipped = plen - (best_i + 1);
+            *pattern_offset = clipped;
+            ne = (int)first_u32((uint32_t)ne);
+            *n_gapless = ne <= limit ? ne : -1;
+            *n_edits = ne + clipped;
+            p *= tab->indel[clipped];
+            *mp = first_f64(p);
+            return best;
+        }
+        *n_edits = -1; *n_gapless = -1;
+        return -1;
+    }
+
     // stage genome[loc - WIN_PAD, loc + read_len + WIN_PAD) into LDS with coalesced loads
     __device__ __forceinline__ void stage_window(int64_t loc) {
         const int total = read_len + 2 * WIN_PAD;
@@ -415,7 +481,9 @@ struct Aligner {
     }
 
     // ------------------------------------------------------------------ score()  (BaseAligner.cpp:918-1534)
-    // returns true when a final answer has been written to `primary`
+    // returns true when a final answer has been written to `primary`.  HAM: the useHamming variant (gapless scoring with
+    // clipping, candidates kept for alignAffineGap), used only by the paired-end fallback (ChimericPairedEndAligner.cpp:340).
+    template <bool HAM>
     __device__ __forceinline__ bool score(bool force_result) {
         // :995-1007 (EXACT_DISJOINT_MISS_COUNT)
         if (cur_round_lps[0] > lps_unseen[0]) lps_unseen[0] = cur_round_lps[0];
@@ -444,7 +512,7 @@ struct Aligner {
                     }
                     const int fin_best = fin_all ? all.best_score : non_alt.best_score;
                     primary.score = fin_best;
-                    if ((uint32_t)fin_best <= cfg.max_k) {
+                    if ((uint32_t)fin_best <= max_k || (HAM && fin_best != SNAPGPU_UnusedScoreValue)) {          // :1048
                         if (fin_all) fill_result(all, primary); else fill_result(non_alt, primary);
                         primary.supplementary = 0;
                     } else {
@@ -503,8 +571,24 @@ struct Aligner {
                         // reversed head of the read, :1169).  The backward text/pattern are the same bytes walked
                         // with stride -1, so LandauVishkin<1> and <-1> are one instantiation.
                         const uint8_t *rdd = e_dir ? rd[1] : rd[0], *qld = e_dir ? ql[1] : ql[0];
+                        int g1 = 0, g2 = 0;                                     // score1Gapless / score2Gapless
+                        if constexpr (HAM) {                                    // :1177-1199
+                            if (tail_start != read_len) {
+                                int po;
+                                ag1 = gapless_score(+1, data + tail_start, rdd + tail_start, qld + tail_start, read_len - tail_start, read_len,
+                                                    limit_e, &score1, &po, &mp1, &g1);
+                                ag1 += seed_len - read_len;
+                            }
+                            if (g1 != -1 && seed_offset != 0) {
+                                int po = 0;
+                                ag2 = gapless_score(-1, data + seed_offset - 1, rdd + seed_offset - 1, qld + seed_offset - 1, seed_offset, read_len,
+                                                    limit_e - g1, &score2, &po, &mp2, &g2);
+                                ag2 -= read_len;
+                                loc_offset = g2 != -1 ? po : 0;
+                            }
+                        }
                         const uint64_t t_lv0 = wave_clock();
-                        for (int half = 0; half < 2; half++) {
+                        for (int half = 0; half < 2 && !HAM; half++) {
                             if (half == 1 && score1 == -1) break;
                             const int st = half == 0 ? 1 : -1;
                             const int org = half == 0 ? tail_start : seed_offset - 1;
@@ -526,10 +610,10 @@ struct Aligner {
                                 cnt.lv_ref_bytes += (uint64_t)plen;
                             }
                         }
-                        cnt.lv++;
+                        if (!HAM) cnt.lv++;
                         cnt.cyc_lv += wave_clock() - t_lv0;
 
-                        if (score1 != -1 && score2 != -1) {
+                        if (!HAM && score1 != -1 && score2 != -1) {
                             int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);     // :1148
                             if (cfg.use_ag && (score1 + score2 > max_k_same && e_lps <= (uint32_t)all.best_score)) {   // :1203
                                 score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0;
@@ -565,7 +649,7 @@ struct Aligner {
                             }
                         }
 
-                        bool found = (score1 != -1 && score2 != -1);
+                        bool found = HAM ? (g1 != -1 && g2 != -1) : (score1 != -1 && score2 != -1);               // :1293
                         if (found && loc_offset != 0 && !substring_ok(loc + loc_offset, glen)) found = false;   // :1295-1301
                         if (found) {
                             sc = (uint32_t)(score1 + score2);
@@ -585,6 +669,7 @@ struct Aligner {
                     uint32_t e_best = first_u32(e->best_score);
                     double e_mp = first_f64(e->match_prob);
                     if (any_nearby) {
+                        if (HAM && mp <= e_mp) continue;                                      // :1362
                         if (e_best < sc || (e_best == sc && mp <= e_mp)) continue;            // :1366
                     }
                     const uint32_t e_flags = first_u32(e->flags);
@@ -614,6 +699,7 @@ struct Aligner {
                             if (dist <= BUCKET) {                                             // genomeLocationIsWithin(..., maxMergeDist)
                                 uint32_t n_best = first_u32(ne->best_score);
                                 double n_mp = first_f64(ne->match_prob);
+                                if (HAM && n_mp >= mp) continue;                             // :1418
                                 if (n_best < sc || (n_best == sc && n_mp >= mp)) continue;   // :1421
                                 double v = all.p_all - n_mp; all.p_all = v > 0.0 ? v : 0.0;    // updateProbabilitiesForNearbyMatch
                                 if (loc_non_alt) { double u = non_alt.p_all - n_mp; non_alt.p_all = u > 0.0 ? u : 0.0; }
@@ -632,10 +718,11 @@ struct Aligner {
                     if (lane == 0) { e->match_prob = mp; e->best_score = sc; }
                     WAVE_SYNC();
 
-                    update_best(all, loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
+                    update_best<HAM>(all, loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
                     if (loc_non_alt) {
-                        update_best(non_alt, loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
+                        update_best<HAM>(non_alt, loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
                     }
+                    if (HAM && n_agc >= agc_cap) { agc_overflow = 1; return true; }           // :1475 (the caller grows the buffer and retries)
 
                     // early out: nothing can rescue MAPQ once the candidates' total probability reaches 4.9 (:1512)
                     double p_chk = cfg.alt_aware ? non_alt.p_all : all.p_all;
@@ -669,9 +756,10 @@ struct Aligner {
 
     __device__ __forceinline__ void align_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         const uint64_t t_read0 = wave_clock();
-        align_read_inner(g_bases, g_quals, len);
+        align_read_inner<false>(g_bases, g_quals, len);
         cnt.cyc_total += wave_clock() - t_read0;
     }
+    template <bool HAM>
     __device__ __forceinline__ void align_read_inner(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         read_len = len;
         // result = NotFound (:334-344); remaining fields as a zero-initialised struct
@@ -703,7 +791,7 @@ struct Aligner {
         }
         for (uint32_t i = lane; i < (cfg.RL + 31) / 32; i += WAVE) seed_used[i] = 0;
         WAVE_SYNC();
-        if (n_count > cfg.max_k) return;                                      // :398
+        if (n_count > max_k) return;                                          // :398
 
         if (n_count > 0) {                                                    // :407-420 block seeds containing a non-ACGT base
             int min_seed = 0;
@@ -732,13 +820,14 @@ struct Aligner {
         n_seeds_applied[0] = n_seeds_applied[1] = 0;
         popular_seeds_skipped = 0;
         ag_stale = 0;
+        n_agc = 0; agc_overflow = 0;
         bool finished = false;
 
         while (n_seeds_applied[0] + n_seeds_applied[1] < max_seeds_to_use) {
             if (next_seed >= n_possible_seeds) {                              // wrapping, :455-504
                 wrap_count++;
                 if (wrap_count >= (uint32_t)seed_len) {
-                    score(true);
+                    score<HAM>(true);
                     finished = true;
                     break;
                 }
@@ -791,12 +880,195 @@ struct Aligner {
             next_seed += (uint32_t)seed_len;                                  // :676
 
             if (applied_either) {
-                if (score(false)) { finished = true; break; }
+                if (score<HAM>(false)) { finished = true; break; }
             }
         }
-        if (!finished) score(true);                                           // :734
+        if (!finished) score<HAM>(true);                                      // :734
         primary.score_prior_to_clipping = primary.score;                      // finalizeSecondaryResults, :2442
         primary.reserved = ag_stale;
         release_candidates();
+    }
+
+    // ------------------------------------------------------------------ BaseAligner::scoreLocationWithAffineGap (BaseAligner.cpp:766-915)
+    // (the forward half asks for the clipping optimisations, the backward half does not: :827 vs :857)
+    __device__ __forceinline__ void score_location_ag(int dir, int64_t loc, int seed_offset, int limit, int *score, double *mp, int *offset,
+                                                      int *clip_before, int *clip_after, int *ag_score) {
+        const int64_t glen = (int64_t)read_len + SNAPGPU_MAX_K;
+        *offset = 0;
+        if (!substring_ok(loc, glen)) { *score = -1; *mp = 0; *ag_score = -1; return; }
+        *clip_before = 0; *clip_after = 0;
+        stage_window(loc);
+        const uint8_t *data = gw + WIN_PAD;
+        const int seed_len = (int)ix.seed_len;
+        const int tail_start = seed_offset + seed_len;
+        const uint8_t *rdd = dir ? rd[1] : rd[0], *qld = dir ? ql[1] : ql[0];
+        int score1 = 0, score2 = 0, ag1 = seed_len, ag2 = 0;
+        double mp1 = 1.0, mp2 = 1.0;
+        AGParams agp{cfg.match_reward, cfg.sub_penalty, cfg.gap_open, cfg.gap_extend, cfg.five_bonus, cfg.three_bonus};
+        for (int half = 0; half < 2; half++) {
+            if (half == 0 && tail_start == read_len) continue;
+            if (half == 1 && (score1 == -1 || seed_offset == 0)) break;
+            const int st = half == 0 ? 1 : -1;
+            const int org = half == 0 ? tail_start : seed_offset - 1;
+            const int plen = half == 0 ? read_len - tail_start : seed_offset;
+            const int lim = half == 0 ? limit : limit - score1;
+            const int tlen = half == 0 ? (int)(glen - tail_start) : seed_offset + lim;
+            const bool banded = plen >= 3 * (2 * lim + 1);
+            ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+            AGResult a = ag_dispatch<AGC>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, dir != 0, half == 0, ag_rows, ag_scratch, cfg.RL, tab);
+            a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
+            a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
+            a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
+            ag_stale += (uint32_t)a.stale_reads;
+            if (half == 0) {
+                ag1 = a.ag_score + (seed_len - read_len); *clip_after = a.pattern_offset; score1 = a.n_edits; mp1 = a.match_probability;
+            } else {
+                ag2 = a.ag_score - read_len; *clip_before = a.pattern_offset; score2 = a.n_edits; mp2 = a.match_probability; *offset = a.text_offset;
+                if (score2 == -1) *offset = 0;
+            }
+        }
+        if (score1 != -1 && score2 != -1) {
+            *score = score1 + score2;
+            *mp = mp1 * mp2 * tab->seed_prob;
+            *ag_score = ag1 + ag2;
+        } else {
+            *score = -1; *ag_score = -1; *mp = 0.0;
+        }
+    }
+
+    // ScoreSet::init(SingleAlignmentResult*) / updateBestScore(SingleAlignmentResult*) (BaseAligner.cpp:2116-2130, BaseAligner.h:310-328)
+    __device__ __forceinline__ void set_from_result(ScoreSet &ss, const snapgpu_single_result &r) const {
+        ss.best_score = r.score; ss.best_loc = r.location; ss.best_orig_loc = r.orig_location; ss.dir = r.direction;
+        ss.used_ag = r.used_affine_gap_scoring; ss.clip_before = r.bases_clipped_before; ss.clip_after = r.bases_clipped_after;
+        ss.ag_score = r.ag_score; ss.seed_offset = r.seed_offset; ss.best_match_prob = r.match_probability;
+        ss.p_all = r.probability_all_candidates; ss.p_best = r.match_probability;
+    }
+    __device__ __forceinline__ bool set_update_from(ScoreSet &ss, int64_t loc, int64_t orig, int dir, int score, int used_ag, int cb, int ca,
+                                                    int ag, int so, double mp) const {
+        ss.p_all += mp;
+        if (ag > ss.ag_score || (ag == ss.ag_score && mp > ss.best_match_prob)) {
+            ss.best_score = score; ss.ag_score = ag; ss.best_match_prob = mp; ss.best_loc = loc; ss.best_orig_loc = orig; ss.dir = dir;
+            ss.used_ag = used_ag; ss.clip_before = cb; ss.clip_after = ca; ss.seed_offset = so;
+            return true;
+        }
+        return false;
+    }
+    static __device__ __forceinline__ void set_sub_all(ScoreSet &ss, double old) { double v = ss.p_all - old; ss.p_all = v > 0.0 ? v : 0.0; }
+
+    // ------------------------------------------------------------------ BaseAligner::alignAffineGap (BaseAligner.cpp:1537-1792)
+    // Runs on `primary` / `first_alt` and the candidates the preceding Hamming pass collected; the read is still in LDS.
+    __device__ __forceinline__ void align_affine_gap(ScoreSet &A, ScoreSet &N) {
+        if (primary.status == SNAPGPU_NotFound) return;
+        uint32_t n_count = 0;
+        for (int i0 = 0; i0 < read_len; i0 += WAVE) {
+            int i = i0 + lane;
+            n_count += (uint32_t)__popcll(__ballot(i < read_len && rd[0][i] == 'N'));
+        }
+        if (n_count > max_k) return;
+        const int best_score = (int)first_u32((uint32_t)primary.score);
+        int limit = SNAPGPU_MAX_K - 1, limit_alt = SNAPGPU_MAX_K - 1;
+        int g_off = 0;
+        bool skip = false;
+        const double old_p = primary.match_probability;
+        const double old_p_alt = first_alt.status != SNAPGPU_NotFound ? first_alt.match_probability : 0.0;
+        const int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);
+
+        primary.used_affine_gap_scoring = 0;
+        if (primary.score > max_k_same) {
+            primary.used_affine_gap_scoring = 1;
+            int sc, cb = primary.bases_clipped_before, ca = primary.bases_clipped_after, ag = primary.ag_score;
+            double mp = primary.match_probability;
+            score_location_ag(primary.direction, primary.orig_location, primary.seed_offset, limit, &sc, &mp, &g_off, &cb, &ca, &ag);
+            primary.score = sc; primary.match_probability = mp; primary.bases_clipped_before = cb; primary.bases_clipped_after = ca; primary.ag_score = ag;
+            if (sc != -1) primary.location = primary.orig_location + g_off; else primary.status = SNAPGPU_NotFound;
+        } else {
+            skip = true;
+        }
+        if (first_alt.status != SNAPGPU_NotFound && first_alt.score > max_k_same) {
+            first_alt.used_affine_gap_scoring = 1;
+            int sc, cb = first_alt.bases_clipped_before, ca = first_alt.bases_clipped_after, ag = first_alt.ag_score;
+            double mp = first_alt.match_probability;
+            score_location_ag(first_alt.direction, first_alt.orig_location, first_alt.seed_offset, limit_alt, &sc, &mp, &g_off, &cb, &ca, &ag);
+            first_alt.score = sc; first_alt.match_probability = mp; first_alt.bases_clipped_before = cb; first_alt.bases_clipped_after = ca; first_alt.ag_score = ag;
+            if (sc != -1) first_alt.location = first_alt.orig_location + g_off; else first_alt.status = SNAPGPU_NotFound;
+        }
+        if (primary.status == SNAPGPU_NotFound || primary.score > SNAPGPU_MAX_K - 1) {
+            primary.location = SNAPGPU_InvalidGenomeLocation32; primary.mapq = 0; primary.score = -1; primary.status = SNAPGPU_NotFound;
+            primary.clipping_for_read_adjustment = 0; primary.used_affine_gap_scoring = 0; primary.bases_clipped_before = 0;
+            primary.bases_clipped_after = 0; primary.ag_score = -1; primary.seed_offset = 0; primary.match_probability = 0.0;
+            first_alt.status = SNAPGPU_NotFound;
+            return;
+        }
+
+        bool non_alt_aln = !cfg.alt_aware || !is_alt(primary.location);
+        set_from_result(A, primary);
+        bool alt_best = false;
+        if (first_alt.status != SNAPGPU_NotFound) {
+            alt_best = set_update_from(A, first_alt.location, first_alt.orig_location, first_alt.direction, first_alt.score,
+                                       first_alt.used_affine_gap_scoring, first_alt.bases_clipped_before, first_alt.bases_clipped_after,
+                                       first_alt.ag_score, first_alt.seed_offset, first_alt.match_probability);
+        }
+        if (non_alt_aln) set_from_result(N, primary); else N.init();
+        if (!skip) {
+            const double new_p = primary.match_probability;
+            if (alt_best) { set_sub_all(A, old_p_alt); A.p_best = first_alt.match_probability; A.p_all += first_alt.match_probability; }
+            else          { set_sub_all(A, old_p); A.p_best = new_p; A.p_all += new_p; }
+            if (non_alt_aln) { set_sub_all(N, old_p); N.p_best = new_p; N.p_all += new_p; }
+        }
+
+        if (n_agc > 0 && !skip) {
+            limit = (int)((max_k < (uint32_t)best_score ? max_k : (uint32_t)best_score) + cfg.extra_depth);      // :1714 (unsigned min, as in the reference)
+            // qsort(compareByScore): glibc's merge sort is stable, so candidates are visited by (score, insertion index)
+            int last_score = -0x7fffffff, last_idx = -1;
+            for (uint32_t done_n = 0; done_n < n_agc; done_n++) {
+                int bi = -1, bs = 0x7fffffff;
+                for (uint32_t j0 = 0; j0 < n_agc; j0 += WAVE) {
+                    uint32_t j = j0 + (uint32_t)lane;
+                    int sj = j < n_agc ? (int)agc[j].reserved : 0x7fffffff;
+                    bool ok = j < n_agc && (sj > last_score || (sj == last_score && (int)j > last_idx));
+                    int key = ok ? sj : 0x7fffffff;
+                    // wave minimum of (key, j)
+                    for (int o = 32; o >= 1; o >>= 1) {
+                        int ok2 = __shfl_xor(key, o), oj = __shfl_xor((int)j, o);
+                        if (ok2 < key || (ok2 == key && oj < (int)j)) { key = ok2; j = (uint32_t)oj; }
+                    }
+                    key = (int)first_u32((uint32_t)key); j = first_u32(j);
+                    if (key < bs) { bs = key; bi = (int)j; }
+                }
+                last_score = bs; last_idx = bi;
+                snapgpu_single_result *c = &agc[bi];
+                const int64_t c_loc = (int64_t)first_u64((uint64_t)c->location), c_orig = (int64_t)first_u64((uint64_t)c->orig_location);
+                const int c_dir = (int)first_u32((uint32_t)c->direction), c_so = (int)first_u32((uint32_t)c->seed_offset);
+                const bool c_non_alt = !cfg.alt_aware || !is_alt(c_loc);
+                const double c_old_p = first_f64(c->match_probability);
+                int sc, cb = (int)first_u32((uint32_t)c->bases_clipped_before), ca = (int)first_u32((uint32_t)c->bases_clipped_after);
+                int ag = (int)first_u32((uint32_t)c->ag_score);
+                double mp = c_old_p;
+                score_location_ag(c_dir, c_orig, c_so, limit, &sc, &mp, &g_off, &cb, &ca, &ag);
+                sc = (int)first_u32((uint32_t)sc);
+                if (sc != -1 && sc <= SNAPGPU_MAX_K - 1) {
+                    const int64_t new_loc = c_orig + g_off;
+                    if (primary.location == new_loc) continue;                                   // same alignment again: do not lower MAPQ
+                    set_sub_all(A, c_old_p);
+                    set_update_from(A, new_loc, c_orig, c_dir, sc, 1, cb, ca, ag, c_so, mp);
+                    if (c_non_alt) { set_sub_all(N, c_old_p); set_update_from(N, new_loc, c_orig, c_dir, sc, 1, cb, ca, ag, c_so, mp); }
+                    limit = score_limit(cfg.alt_aware && !c_non_alt);                             // the *member* score sets, as the reference does (:1756)
+                }
+            }
+        }
+
+        const bool emit_all = !cfg.alt_aware || N.best_score > A.best_score + cfg.max_gap_alt;
+        const uint32_t pop = primary.popular_seeds_skipped, pop_alt = first_alt.popular_seeds_skipped;
+        const uint32_t saved_pop = popular_seeds_skipped;
+        popular_seeds_skipped = pop;
+        if (emit_all) fill_result(A, primary); else fill_result(N, primary);
+        if (cfg.alt_aware && !emit_all && A.best_loc != N.best_loc) {
+            popular_seeds_skipped = pop_alt;
+            fill_result(A, first_alt);
+            first_alt.supplementary = 1;
+        } else {
+            first_alt.status = SNAPGPU_NotFound;
+        }
+        popular_seeds_skipped = saved_pop;
     }
 };

@@ -1128,8 +1128,13 @@ struct PairedCore {
     }
 
     PE_FN void align_pair(int max_k_paired, int max_k_single) {
-        snapgpu_paired_result &res = sh->res, &alt = sh->alt;
         overflow = 0; stale = 0;
+        align_pair_inner(max_k_paired, max_k_single);
+        sh->res.reserved = stale;                           // not in the reference: see snapgpu_paired_result.reserved
+    }
+
+    PE_FN void align_pair_inner(int max_k_paired, int max_k_single) {
+        snapgpu_paired_result &res = sh->res, &alt = sh->alt;
         res.status[0] = res.status[1] = SNAPGPU_NotFound;
         for (int r = 0; r < 2; r++) {
             res.used_affine_gap_scoring[r] = 0; res.bases_clipped_before[r] = 0; res.bases_clipped_after[r] = 0;
@@ -1193,11 +1198,14 @@ struct PairedCore {
                     max_k_read = max_k_single < a ? max_k_single : a;
                 }
                 pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r]);
+                stale += single[r].reserved & 0x7fffffffu;
                 bool used_hamming = false;
                 if (cfg.use_soft_clip && cfg.enable_hamming_base) {
                     if (single[r].status == SNAPGPU_NotFound && res.status[r] == SNAPGPU_NotFound) {                  // :330-360
                         used_hamming = true;
                         pl.align_single(r, PL::i32(max_k_read), true, single[r], single_alt[r]);
+                        stale += single[r].reserved & 0x7fffffffu;
+                        if (single[r].reserved & 0x80000000u) { overflow = 1; return; }      // candidate buffer of the single-end aligner overflowed
                     }
                 }
                 if (compare_single) {
@@ -1238,6 +1246,5 @@ struct PairedCore {
             }
             res.aligned_as_pair = 0;
         }
-        res.reserved = stale;
     }
 };

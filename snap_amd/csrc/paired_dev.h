@@ -1,0 +1,255 @@
+// paired_dev.h -- gfx950 instantiation of the paired-end path (paired.h): the device platform
+// that maps the core's primitives onto the wavefront kernels (probe.h, lv.h, ag_win.h) and onto
+// the single-end Aligner (align_single.h) for the chimeric fallback, plus the kernel itself.
+//
+// One wavefront owns one read pair.  LDS per wave = the single-end aligner's carve-out (its
+// window, LV triangle and affine-gap rows are shared with the paired code) + both reads in both
+// orientations + the four hit sets + the cold wave-uniform state (PEShared).  The candidate
+// pools (ScoringCandidate / ScoringMateCandidate / MergeAnchor, sized like the reference's:
+// min(-mcp, -H * seeds * 2) entries) and the Phase-4 candidate buffer live in a per-wave slab of
+// HBM scratch.
+#pragma once
+#include "align_single.h"
+#include "paired.h"
+
+template <int AGC>
+struct DevPL {
+    Aligner<AGC> *al;                  // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
+    const DevTables *tab;
+    AGParams agp;
+    uint32_t kmax_lv;                  // what the LV triangle was sized for
+    const uint8_t *g_bases[2], *g_quals[2];   // the pair's reads in global memory (for the single-end fallback)
+    int g_len[2];
+    WaveShared *ws;
+
+    template <class T> static __device__ __forceinline__ T ld(const T &x) {
+        if constexpr (sizeof(T) == 8) {
+            return __builtin_bit_cast(T, first_u64(__builtin_bit_cast(uint64_t, x)));
+        } else if constexpr (sizeof(T) == 4) {
+            return __builtin_bit_cast(T, first_u32(__builtin_bit_cast(uint32_t, x)));
+        } else {
+            return (T)first_u32((uint32_t)x);
+        }
+    }
+    template <class T> static __device__ __forceinline__ void st(T &x, T v) {
+        if (lane_id() == 0) x = v;
+        WAVE_SYNC();
+    }
+    static __device__ __forceinline__ int i32(int v) { return (int)first_u32((uint32_t)v); }
+    static __device__ __forceinline__ double f64(double v) { return first_f64(v); }
+    static __device__ __forceinline__ bool lane0() { return lane_id() == 0; }
+    static __device__ __forceinline__ void sync() { WAVE_SYNC(); }
+
+    __device__ __forceinline__ bool lookup(const uint8_t *text, PEHits out[2]) {
+        SeedBits seed = pack_seed(text, al->ix.seed_len);
+        if (!seed.valid) return false;
+        HitList hl[2];
+        lookup_seed(al->ix, seed, hl);
+        out[0].hits = hl[0].hits; out[0].n_hits = hl[0].n_hits; out[0].singleton = hl[0].singleton;
+        out[1].hits = hl[1].hits; out[1].n_hits = hl[1].n_hits; out[1].singleton = hl[1].singleton;
+        al->cnt.lookups++;
+        al->cnt.slots += hl[0].slots + hl[1].slots;
+        return true;
+    }
+    __device__ __forceinline__ uint32_t wrapped_seed(uint32_t wrap) const { return tab->wrapped_seed[wrap]; }
+    __device__ __forceinline__ uint32_t count_n(const uint8_t *b, int len) const {
+        uint32_t n = 0;
+        const int lane = lane_id();
+        for (int i0 = 0; i0 < len; i0 += WAVE) {
+            int i = i0 + lane;
+            n += (uint32_t)__popcll(__ballot(i < len && b[i] == 'N'));
+        }
+        return n;
+    }
+    // stage genome[loc - WIN_PAD, loc + read_len + WIN_PAD) into the shared LDS window
+    __device__ __forceinline__ const uint8_t *window(int64_t loc, int read_len) {
+        al->read_len = read_len;
+        al->stage_window(loc);
+        return al->gw + WIN_PAD;
+    }
+    __device__ __forceinline__ bool is_alt(int64_t loc) const { return al->is_alt(loc); }
+    __device__ __forceinline__ bool substring_ok(int64_t loc, int64_t len) const { return al->substring_ok(loc, len); }
+    __device__ __forceinline__ int mapq(double p_all, double p_best, int popular) const { return compute_mapq(tab, p_all, p_best, popular); }
+    __device__ __forceinline__ double seed_prob() const { return tab->seed_prob; }
+    __device__ __forceinline__ double phred(uint8_t q) const { return tab->phred[q]; }
+    __device__ __forceinline__ double indel(int n) const { return tab->indel[n]; }
+    __device__ __forceinline__ double perfect(int n) const { return tab->perfect[n]; }
+
+    __device__ __forceinline__ LVOut lv(int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int k) {
+        ByteSeq Ps{P, st}, Qs{Q, st}, Ts{T, st};
+        LVResult r = lv_compute(Ps, Qs, plen, Ts, tlen, k, al->lv_tri, kmax_lv, tab);
+        LVOut o;
+        o.score = i32(r.score); o.mp = f64(r.match_probability); o.net_indel = i32(r.net_indel);
+        o.total_indels = i32(r.total_indels); o.text_span = i32(r.text_span);
+        return o;
+    }
+    __device__ __forceinline__ AGOut ag(bool banded, int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int lim,
+                                        int read_len, bool is_rc, bool use_clip) {
+        ByteSeq Ps{P, st}, Qs{Q, st}, Ts{T, st};
+        AGResult a = ag_dispatch<AGC>(banded, st, agp, Ps, Qs, plen, Ts, tlen, lim, read_len, is_rc, use_clip, al->ag_rows, al->ag_scratch,
+                                      al->cfg.RL, tab);
+        AGOut o;
+        o.ag_score = i32(a.ag_score); o.text_offset = i32(a.text_offset); o.pattern_offset = i32(a.pattern_offset);
+        o.n_edits = i32(a.n_edits); o.mp = f64(a.match_probability); o.stale = i32(a.stale_reads);
+        return o;
+    }
+    // BaseAligner::AlignRead with setMaxK(max_k) (ChimericPairedEndAligner.cpp:278-310); hamming: the retry of :330-360
+    // (AlignRead(..., useHamming) followed by BaseAligner::alignAffineGap on the candidates it collected).
+    __device__ __forceinline__ void align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt) {
+        al->max_k = (uint32_t)max_k;
+        if (!hamming) {
+            al->template align_read_inner<false>(g_bases[r], g_quals[r], g_len[r]);
+        } else {
+            al->template align_read_inner<true>(g_bases[r], g_quals[r], g_len[r]);
+            if (!al->agc_overflow) al->align_affine_gap(ws->ag_all, ws->ag_non_alt);
+            al->primary.reserved = al->ag_stale;
+        }
+        WAVE_SYNC();
+        res = al->primary;
+        alt = al->first_alt;
+        if (al->agc_overflow) res.reserved |= 0x80000000u;
+        WAVE_SYNC();
+    }
+};
+
+struct PairedLds { uint32_t single_total, rd, ql, lk, exhausted, miss, hs, list_head, seed_used, sh, total; };
+static __host__ __device__ __forceinline__ PairedLds paired_lds_layout(uint32_t single_total, uint32_t RL, uint32_t max_seeds) {
+    PairedLds L; uint32_t o = (single_total + 15) & ~15u;
+    L.single_total = o;
+    L.rd = o; o += 4 * RL;                                   // [read][dir]
+    L.ql = o; o += 4 * RL;
+    L.lk = o; o += (4 * max_seeds * (uint32_t)sizeof(PELookup) + 15) & ~15u;
+    L.exhausted = o; o += (4 * max_seeds * 4 + 15) & ~15u;
+    L.miss = o; o += (max_seeds * 4 + 15) & ~15u;
+    L.hs = o; o += (4 * (uint32_t)sizeof(PEHitSetHdr) + 15) & ~15u;
+    L.list_head = o; o += ((SNAPGPU_MAX_K + 1) * 4 + 15) & ~15u;
+    L.seed_used = o; o += (((RL + 31) / 32) * 4 + 15) & ~15u;
+    L.sh = o; o += ((uint32_t)sizeof(PEShared) + 15) & ~15u;
+    L.total = o;
+    return L;
+}
+
+struct PairedArgs {
+    DevIndex ix;
+    AlignCfg scfg;                     // the single-end aligner of the chimeric fallback
+    PECfg pcfg;
+    const DevTables *tab;
+    uint8_t *scratch;                  // n_wave_slots * stride
+    uint64_t stride;
+    uint64_t off_single_agc, off_cand, off_mate0, off_mate1, off_anchor, off_agc;   // offsets inside a wave's slab (single-end scratch first)
+    uint32_t single_agc_cap;
+    const uint8_t *bases, *quals;
+    const uint64_t *offsets;           // [2n+1]
+    uint32_t n_pairs;
+    int32_t max_k_paired, max_k_single;
+    snapgpu_paired_result *primary, *first_alt;
+    uint32_t *work_counter;
+    unsigned long long *counters;      // snapgpu_counters layout
+    uint32_t kmax_lv;
+};
+
+// Scalar-heavy, latency-bound control flow: 2 waves per SIMD keeps 256 VGPRs available (no spills) and is what the LDS
+// footprint allows anyway.
+template <int AGC>
+__global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
+    const LdsLayout SL = lds_layout(a.scfg.RL, a.scfg.num_weight_lists, a.scfg.kmax, a.scfg.use_ag);
+    const PairedLds PLd = paired_lds_layout(SL.total, a.scfg.RL, a.pcfg.max_seeds);
+    uint8_t *my = lds + (size_t)wave_in_block * PLd.total;
+    uint8_t *sc = a.scratch + (size_t)wave_slot * a.stride;
+
+    WaveShared *ws = (WaveShared *)(my + SL.shared);
+    Aligner<AGC> al(a.ix, a.tab, a.scfg, ws);
+    al.lane = lane;
+    al.rd[0] = my + SL.rd0; al.rd[1] = my + SL.rd1;
+    al.ql[0] = my + SL.ql0; al.ql[1] = my + SL.ql1;
+    al.gw = my + SL.gw;
+    al.seed_used = (uint32_t *)(my + SL.seed_used);
+    al.wl_next = (uint16_t *)(my + SL.wl_next);
+    al.wl_prev = (uint16_t *)(my + SL.wl_prev);
+    al.lv_tri = (uint16_t *)(my + SL.lv);
+    al.ag_rows = (int16_t *)(my + SL.ag);
+    al.heads = (uint16_t *)sc;
+    al.pool = (Elem *)(sc + (size_t)a.scfg.ht_size * 2);
+    al.ag_scratch = sc + (size_t)a.scfg.ht_size * 2 + (size_t)a.scfg.pool_size * sizeof(Elem);
+    al.agc = (snapgpu_single_result *)(sc + a.off_single_agc);
+    al.agc_cap = a.single_agc_cap;
+    al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    DevPL<AGC> pl;
+    pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv;
+    pl.agp = AGParams{a.scfg.match_reward, a.scfg.sub_penalty, a.scfg.gap_open, a.scfg.gap_extend, a.scfg.five_bonus, a.scfg.three_bonus};
+
+    PairedCore<DevPL<AGC>> core(pl, a.pcfg);
+    core.lk = (PELookup *)(my + PLd.lk);
+    core.exhausted = (uint32_t *)(my + PLd.exhausted);
+    core.miss = (uint32_t *)(my + PLd.miss);
+    core.hs = (PEHitSetHdr *)(my + PLd.hs);
+    core.list_head = (int32_t *)(my + PLd.list_head);
+    core.seed_used = (uint32_t *)(my + PLd.seed_used);
+    core.sh = (PEShared *)(my + PLd.sh);
+    core.cand = (PECand *)(sc + a.off_cand);
+    core.mate[0] = (PEMate *)(sc + a.off_mate0);
+    core.mate[1] = (PEMate *)(sc + a.off_mate1);
+    core.anchor = (PEAnchor *)(sc + a.off_anchor);
+    core.agc = (snapgpu_paired_result *)(sc + a.off_agc);
+    core.sh->cnt = PECounters{0, 0, 0};
+    uint8_t *prd = my + PLd.rd, *pql = my + PLd.ql;
+    const uint32_t RL = a.scfg.RL;
+    uint64_t n_done = 0;
+
+    while (true) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
+        i = first_u32(i);
+        if (i >= a.n_pairs) break;
+        for (int r = 0; r < 2; r++) {
+            const uint64_t b = first_u64(a.offsets[2 * i + r]), e = first_u64(a.offsets[2 * i + r + 1]);
+            const int len = (int)(e - b);
+            uint8_t *f = prd + (2 * r) * RL, *rc = prd + (2 * r + 1) * RL, *qf = pql + (2 * r) * RL, *qr = pql + (2 * r + 1) * RL;
+            for (int j0 = 0; j0 < len; j0 += WAVE) {
+                int j = j0 + lane;
+                if (j < len) {
+                    uint8_t bb = a.bases[b + j], qq = a.quals[b + j];
+                    f[j] = bb; qf[j] = qq;
+                    rc[len - 1 - j] = rc_base(bb); qr[len - 1 - j] = qq;
+                }
+            }
+            core.rd[r][0] = f; core.rd[r][1] = rc; core.ql[r][0] = qf; core.ql[r][1] = qr;
+            core.read_len[r] = len;
+            pl.g_bases[r] = a.bases + b; pl.g_quals[r] = a.quals + b; pl.g_len[r] = len;
+        }
+        {   // zero both results (fields the reference leaves unset read as 0 here)
+            uint32_t *z0 = (uint32_t *)&core.sh->res, *z1 = (uint32_t *)&core.sh->alt;
+            const int nd = (int)(sizeof(snapgpu_paired_result) / 4);
+            if (lane < nd) { z0[lane] = 0; z1[lane] = 0; }
+        }
+        WAVE_SYNC();
+        core.align_pair(a.max_k_paired, a.max_k_single);
+        core.sh->res.flags = core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0;
+        WAVE_SYNC();
+        {
+            const uint32_t *src = (const uint32_t *)&core.sh->res, *src2 = (const uint32_t *)&core.sh->alt;
+            uint32_t *dst = (uint32_t *)&a.primary[i];
+            const int nd = (int)(sizeof(snapgpu_paired_result) / 4);
+            if (lane < nd) dst[lane] = src[lane];
+            if (a.first_alt) { uint32_t *dst2 = (uint32_t *)&a.first_alt[i]; if (lane < nd) dst2[lane] = src2[lane]; }
+        }
+        WAVE_SYNC();
+        n_done++;
+    }
+    if (lane == 0) {
+        atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
+        atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
+        atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
+        atomicAdd(&a.counters[3], (unsigned long long)al.cnt.hits);
+        atomicAdd(&a.counters[4], (unsigned long long)al.cnt.overflow_lists);
+        atomicAdd(&a.counters[5], (unsigned long long)(al.cnt.lv + core.sh->cnt.lv));
+        atomicAdd(&a.counters[6], (unsigned long long)(al.cnt.ag + core.sh->cnt.ag));
+        atomicAdd(&a.counters[7], (unsigned long long)al.cnt.lv_ref_bytes);
+    }
+}

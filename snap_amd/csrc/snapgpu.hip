@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD) void k_align_single(Al
     }
 }
 
+#include "paired_dev.h"               // k_align_paired: the paired-end path (needs LdsLayout above)
+
 // One wave per seed: GenomeIndex::lookupSeed32 for a batch of seeds.
 __global__ __launch_bounds__(256) void k_lookup_seeds(DevIndex ix, uint32_t n, const uint8_t *seeds,
                                                       long long *n_hits, uint32_t *hits, uint32_t max_hits_out)
@@ -264,6 +266,13 @@ struct snapgpu_ctx {
     uint64_t kernel_launches = 0;
     int num_cus = 0;
     int ag_variant = 0;               // chunks of 64 striped positions the affine-gap kernel variant holds in registers (0 = LDS form)
+    // paired-end path (snapgpu_enable_paired)
+    bool paired = false;
+    snapgpu_paired_params pparams{};
+    PairedArgs pargs{};               // everything but the per-call pointers
+    uint8_t *d_pscratch = nullptr;
+    uint32_t p_wave_slots = 0, p_lds_per_wave = 0;
+    int p_ag_variant = 0;
     std::string err;
 };
 
@@ -389,6 +398,7 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_contig_begin) (void)hipFree(ctx->d_contig_begin);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_pscratch) (void)hipFree(ctx->d_pscratch);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     for (int i = 0; i < 5; i++) if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
@@ -857,6 +867,193 @@ extern "C" int snapgpu_align_single(snapgpu_ctx *ctx, uint32_t n, const char *ba
     if (first_alt) HIPCHK(ctx, hipMemcpyAsync(first_alt, ctx->d_stage[4], (size_t)n * sizeof(snapgpu_single_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
     return finish_timing(ctx);
+}
+
+// =====================================================================================
+// paired end
+// =====================================================================================
+
+extern "C" void snapgpu_default_paired_params(snapgpu_paired_params *pp) {       // PairedAligner.cpp:55-57, 227-242; AlignerOptions.cpp:103-110
+    memset(pp, 0, sizeof(*pp));
+    pp->min_spacing = 0; pp->max_spacing = 1000; pp->force_spacing = 0; pp->max_big_hits = 4000; pp->max_candidate_pool_size = 1000000;
+    pp->num_seeds = 8; pp->seed_coverage = 0.0; pp->max_k_for_indels = 40; pp->min_read_length = 50; pp->use_soft_clipping = 1;
+    pp->flatten_mapq_at_or_below = 3; pp->min_score_realignment = 3; pp->min_score_gap_realignment_alt = 3; pp->min_ag_score_improvement = 24;
+    pp->enable_hamming_scoring_base_aligner = 1; pp->max_single_seeds = 25;
+}
+
+// Builds the per-wave state of IntersectingPairedEndAligner + ChimericPairedEndAligner (PairedAligner.cpp:556-625).
+extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_params *pp)
+{
+    if (!ctx || !pp) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_paired: null argument");
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    const snapgpu_params &p = ctx->params;
+    if (pp->max_spacing > 100000) return fail(ctx, SNAPGPU_E_INVALID, "max_spacing out of range");
+    if (ctx->d_pscratch) { (void)hipFree(ctx->d_pscratch); ctx->d_pscratch = nullptr; }
+    ctx->paired = false;
+    ctx->pparams = *pp;
+    PairedArgs &a = ctx->pargs;
+    memset(&a, 0, sizeof(a));
+    a.ix = ctx->ix; a.tab = ctx->d_tab;
+
+    // the single-end aligner inside ChimericPairedEndAligner: maxK/2, maxSeedsSingleEnd (ChimericPairedEndAligner.cpp:81-88)
+    AlignCfg sc = ctx->cfg;
+    sc.max_k = p.max_k / 2;
+    sc.num_seeds = pp->max_single_seeds;
+    uint32_t max_seeds_ctor = sc.num_seeds != 0 ? sc.num_seeds : (uint32_t)(int)(p.seed_coverage * 1000 / ctx->ix.seed_len);
+    sc.num_weight_lists = max_seeds_ctor + 1;
+    if (sc.num_weight_lists < 2 || sc.num_weight_lists > 0x3FF) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "number of single-end seeds out of the supported range [1, 1022]");
+    uint64_t spool = (uint64_t)p.max_hits * max_seeds_ctor;
+    if (spool < 64) spool = 64;
+    if (spool > 60000) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "max_hits * max_single_seeds > 60000 candidate buckets per read is not supported");
+    sc.pool_size = (uint32_t)spool;
+    sc.ht_size = next_pow2((uint32_t)spool * 2);
+    // LV limits: computeScoreLimit <= min(126, extraSearchDepth + maxK + maxKForIndels - 1) (IntersectingPairedEndAligner.cpp:3975-3988)
+    uint32_t kmax_lv = p.max_k + p.extra_search_depth + (pp->max_k_for_indels ? pp->max_k_for_indels - 1 : 0);
+    if (kmax_lv > 126) kmax_lv = 126;
+    sc.kmax = kmax_lv;
+    a.kmax_lv = kmax_lv;
+    a.scfg = sc;
+
+    PECfg &c = a.pcfg;
+    memset(&c, 0, sizeof(c));
+    c.max_k = (int)p.max_k; c.extra_depth = (int)p.extra_search_depth; c.max_k_for_indels = (int)pp->max_k_for_indels;
+    c.max_gap_alt = p.max_score_gap_to_prefer_non_alt; c.use_ag = p.use_affine_gap ? 1 : 0; c.alt_aware = p.alt_awareness ? 1 : 0;
+    c.emit_alt = p.emit_alt_alignments ? 1 : 0; c.use_soft_clip = pp->use_soft_clipping ? 1 : 0; c.force_spacing = pp->force_spacing ? 1 : 0;
+    c.match_reward = (int)p.match_reward; c.sub_penalty = (int)p.sub_penalty; c.gap_open = (int)p.gap_open_penalty;
+    c.gap_extend = (int)p.gap_extend_penalty; c.five_bonus = (int)p.five_prime_end_bonus; c.three_bonus = (int)p.three_prime_end_bonus;
+    c.min_spacing = pp->min_spacing; c.max_spacing = pp->max_spacing; c.max_big_hits = pp->max_big_hits;
+    c.num_seeds = pp->num_seeds < PE_MAX_SEEDS ? pp->num_seeds : PE_MAX_SEEDS;                       // __min(MAX_MAX_SEEDS, ...), :61
+    c.seed_coverage = pp->seed_coverage; c.min_read_length = pp->min_read_length; c.flatten_mapq = pp->flatten_mapq_at_or_below;
+    c.min_score_realign = pp->min_score_realignment; c.min_score_gap_realign_alt = pp->min_score_gap_realignment_alt;
+    c.min_ag_improve = pp->min_ag_score_improvement; c.enable_hamming_base = pp->enable_hamming_scoring_base_aligner ? 1 : 0;
+    c.seed_len = (int)ctx->ix.seed_len;
+    // maxSeedsToUse of the constructor (:69-74) sizes the pools (:141)
+    uint32_t ctor_seeds = c.num_seeds != 0 ? c.num_seeds : (uint32_t)(1000 * pp->seed_coverage / ctx->ix.seed_len);
+    if (ctor_seeds < 1) ctor_seeds = 1;
+    c.max_seeds = ctor_seeds < PE_MAX_SEEDS ? ctor_seeds : PE_MAX_SEEDS;
+    if (c.num_seeds == 0) c.max_seeds = PE_MAX_SEEDS;
+    uint64_t pool = (uint64_t)pp->max_big_hits * ctor_seeds * 2;
+    if (pool > pp->max_candidate_pool_size) pool = pp->max_candidate_pool_size;
+    if (const char *e = getenv("SNAPGPU_PAIRED_POOL")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 64 && v < pool) pool = v; }
+    if (pool < 64) pool = 64;
+    c.pool_size = (uint32_t)pool;
+    c.ag_cand_cap = p.use_affine_gap ? 4096 : 0;                                                    // PairedAligner.cpp:571 (the reference doubles on overflow; here overflow is reported)
+    a.single_agc_cap = 4096;
+    a.max_k_paired = (int32_t)p.max_k; a.max_k_single = (int32_t)(p.max_k / 2);
+
+    {   // affine-gap kernel variant: limits go up to MAX_K - 1 on this path (gapless-clipped reads, IntersectingPairedEndAligner.cpp:2577)
+        int need = ag_max_positions((int)p.max_read_len - (int)ctx->ix.seed_len, 126);
+        int need2 = ag_max_positions((int)p.max_read_len, 126);
+        if (need2 > need) need = need2;
+        ctx->p_ag_variant = need <= 192 ? 3 : need <= 256 ? 4 : need <= 384 ? 6 : 0;
+        if (getenv("SNAPGPU_AG_LDS")) ctx->p_ag_variant = 0;
+    }
+
+    // per-wave scratch slab: [single-end: heads | buckets | AG traceback] [single AG candidates] [cand] [mate0] [mate1] [anchor] [paired AG candidates]
+    size_t ag_bytes = sc.use_ag ? ag_scratch_bytes(sc.RL) : 0;
+    size_t off = ((size_t)sc.ht_size * 2 + (size_t)sc.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
+    a.off_single_agc = off; off += ((size_t)a.single_agc_cap * sizeof(snapgpu_single_result) + 255) & ~(size_t)255;
+    a.off_cand = off;   off += ((size_t)c.pool_size * sizeof(PECand) + 255) & ~(size_t)255;
+    a.off_mate0 = off;  off += ((size_t)(c.pool_size / 2 + 1) * sizeof(PEMate) + 255) & ~(size_t)255;
+    a.off_mate1 = off;  off += ((size_t)(c.pool_size / 2 + 1) * sizeof(PEMate) + 255) & ~(size_t)255;
+    a.off_anchor = off; off += ((size_t)c.pool_size * sizeof(PEAnchor) + 255) & ~(size_t)255;
+    a.off_agc = off;    off += ((size_t)(c.ag_cand_cap + 1) * sizeof(snapgpu_paired_result) + 255) & ~(size_t)255;
+    a.stride = off;
+
+    LdsLayout SL = lds_layout(sc.RL, sc.num_weight_lists, sc.kmax, sc.use_ag);
+    PairedLds PL = paired_lds_layout(SL.total, sc.RL, c.max_seeds);
+    ctx->p_lds_per_wave = PL.total;
+    if ((size_t)4 * PL.total > 160 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "per-pair LDS state exceeds 40 KiB per wave");
+    int waves_per_cu = 8;
+    if (const char *e = getenv("SNAPGPU_PAIRED_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 16) waves_per_cu = v & ~3; }
+    while (waves_per_cu > 4 && (size_t)waves_per_cu * PL.total > 160 * 1024) waves_per_cu -= 4;
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b), SNAPGPU_E_NODEVICE);
+    uint32_t slots = (uint32_t)ctx->num_cus * (uint32_t)waves_per_cu;
+    while (slots > 64 && (size_t)slots * a.stride > free_b / 2) slots /= 2;                        // never take more than half of what is free
+    slots &= ~3u;
+    if ((size_t)slots * a.stride > free_b / 2) return fail(ctx, SNAPGPU_E_NOMEM, "not enough device memory for the paired-end candidate pools (lower -H / -mcp or set SNAPGPU_PAIRED_POOL)");
+    ctx->p_wave_slots = slots;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_pscratch, (size_t)slots * a.stride), SNAPGPU_E_NOMEM);
+    // only the single-end head tables must start zeroed
+    for (uint32_t w = 0; w < slots; w++)
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_pscratch + (size_t)w * a.stride, 0, (size_t)sc.ht_size * 2, ctx->stream), SNAPGPU_E_NODEVICE);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
+    a.scratch = ctx->d_pscratch;
+    ctx->paired = true;
+    return SNAPGPU_OK;
+}
+
+static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals, const void *d_offsets,
+                         void *d_primary, void *d_first_alt, hipStream_t s)
+{
+    PairedArgs a = ctx->pargs;
+    a.bases = (const uint8_t *)d_bases; a.quals = (const uint8_t *)d_quals; a.offsets = (const uint64_t *)d_offsets;
+    a.n_pairs = n; a.primary = (snapgpu_paired_result *)d_primary; a.first_alt = (snapgpu_paired_result *)d_first_alt;
+    a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    uint32_t blocks = ctx->p_wave_slots / 4;
+    uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    const size_t lds = (size_t)4 * ctx->p_lds_per_wave;
+    switch (ctx->p_ag_variant) {
+    case 3:  hipLaunchKernelGGL(k_align_paired<3>, dim3(blocks), dim3(256), lds, s, a); break;
+    case 4:  hipLaunchKernelGGL(k_align_paired<4>, dim3(blocks), dim3(256), lds, s, a); break;
+    case 6:  hipLaunchKernelGGL(k_align_paired<6>, dim3(blocks), dim3(256), lds, s, a); break;
+    default: hipLaunchKernelGGL(k_align_paired<0>, dim3(blocks), dim3(256), lds, s, a); break;
+    }
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_align_paired_device(snapgpu_ctx *ctx, uint32_t n_pairs, const void *d_bases, const void *d_quals,
+                                           const void *d_offsets, void *d_primary, void *d_first_alt, void *stream)
+{
+    if (!ctx || !d_bases || !d_quals || !d_offsets || !d_primary) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_paired_device: null argument");
+    if (!ctx->paired) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_paired has not been called on this context");
+    if (n_pairs == 0) return SNAPGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int rc = launch_paired(ctx, n_pairs, d_bases, d_quals, d_offsets, d_primary, d_first_alt, s);
+    if (rc) return rc;
+    if (!stream) return finish_timing(ctx);
+    return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_align_paired(snapgpu_ctx *ctx, uint32_t n_pairs, const char *bases, const char *quals,
+                                    const uint64_t *offsets, snapgpu_paired_result *primary, snapgpu_paired_result *first_alt)
+{
+    if (!ctx || !bases || !quals || !offsets || !primary) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_paired: null argument");
+    if (!ctx->paired) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_paired has not been called on this context");
+    if (n_pairs == 0) return SNAPGPU_OK;
+    const size_t nr = (size_t)2 * n_pairs;
+    for (size_t i = 0; i < nr; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, SNAPGPU_E_INVALID, "offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] > ctx->params.max_read_len)
+            return fail(ctx, SNAPGPU_E_INVALID, "read longer than max_read_len given at snapgpu_create (IntersectingPairedEndAligner.cpp:361-365)");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    size_t nb = (size_t)offsets[nr];
+    int rc;
+    if ((rc = ensure_stage(ctx, 0, nb + 16)) || (rc = ensure_stage(ctx, 1, nb + 16)) || (rc = ensure_stage(ctx, 2, (nr + 1) * 8)) ||
+        (rc = ensure_stage(ctx, 3, (size_t)n_pairs * sizeof(snapgpu_paired_result))) ||
+        (rc = ensure_stage(ctx, 4, (size_t)n_pairs * sizeof(snapgpu_paired_result)))) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[0], bases, nb, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[1], quals, nb, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[2], offsets, (nr + 1) * 8, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    rc = launch_paired(ctx, n_pairs, ctx->d_stage[0], ctx->d_stage[1], ctx->d_stage[2], ctx->d_stage[3], first_alt ? ctx->d_stage[4] : nullptr, s);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(primary, ctx->d_stage[3], (size_t)n_pairs * sizeof(snapgpu_paired_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    if (first_alt) HIPCHK(ctx, hipMemcpyAsync(first_alt, ctx->d_stage[4], (size_t)n_pairs * sizeof(snapgpu_paired_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    rc = finish_timing(ctx);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < n_pairs; i++)
+        if (primary[i].flags & SNAPGPU_PAIR_POOL_OVERFLOW)
+            return fail(ctx, SNAPGPU_E_UNSUPPORTED, "a read pair needed more candidate entries than the per-wave pools hold (the reference would grow its buffers or ask for -mcp); its result is flagged");
+    return SNAPGPU_OK;
 }
 
 extern "C" int snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int reset) {
