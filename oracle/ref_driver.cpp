@@ -564,8 +564,8 @@ void *snapref_chimeric_single_create(void *vindex, const snapgpu_params *p, cons
         p->min_weight_to_check, p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, true, p->alt_awareness != 0,
         p->emit_alt_alignments != 0, p->max_score_gap_to_prefer_non_alt, -1, NULL, NULL, p->match_reward, p->sub_penalty,
         p->gap_open_penalty, p->gap_extend_penalty, p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, c->allocator);
-    c->maxCand = 4096;
-    c->cand = (SingleAlignmentResult *)BigAlloc(c->maxCand * sizeof(SingleAlignmentResult));
+    c->maxCand = p->use_affine_gap ? 4096 : 0;                        // PairedAligner.cpp:570-577: no candidate buffers without affine gap
+    c->cand = c->maxCand ? (SingleAlignmentResult *)BigAlloc(c->maxCand * sizeof(SingleAlignmentResult)) : NULL;
     c->b.assign(MAX_READ_LENGTH + 2 * SLACK, 0);
     c->q.assign(MAX_READ_LENGTH + 2 * SLACK, 0);
     return c;
@@ -589,7 +589,7 @@ int snapref_chimeric_single_align(void *h, int max_k, int hamming, const char *b
         nCand = 0;
         bool ok = c->aligner->AlignRead(&read, &r, &a, -1, 0, &nSecondary, 0x7fffffff, NULL, c->maxCand, &nCand, c->cand, hamming != 0);
         if (ok) break;
-        if (nCand > c->maxCand) {
+        if (c->cand != NULL && nCand > c->maxCand) {
             BigDealloc(c->cand);
             c->maxCand *= 2;
             c->cand = (SingleAlignmentResult *)BigAlloc(c->maxCand * sizeof(SingleAlignmentResult));
@@ -608,7 +608,7 @@ int snapref_chimeric_single_align(void *h, int max_k, int hamming, const char *b
 void snapref_chimeric_single_destroy(void *h)
 {
     ChimericSingle *c = (ChimericSingle *)h;
-    BigDealloc(c->cand);
+    if (c->cand) BigDealloc(c->cand);
     c->aligner->~BaseAligner();
     delete c->allocator;
     delete c;

@@ -61,6 +61,42 @@ def _pack(strings):
     return buf, offs, lens
 
 
+def make_index_view(index: GenomeIndex, device_index_ptrs=None):
+    """snapgpu_index_view over the arrays of a loaded index; returns (view, arrays to keep alive)."""
+    keep = []
+    v = IndexView()
+    v.seed_len = index.seed_len
+    v.key_bytes = index.key_bytes
+    v.n_hash_tables = index.n_hash_tables
+    v.large_hash_table = 1 if index.large else 0
+    v.location_size = index.location_size
+    v.chromosome_padding = index.chromosome_padding
+    sizes = getattr(index, "_device_sizes", None)      # set by dist.broadcast_index on every rank
+    v.overflow_table_size = sizes[1] if sizes else index.overflow.size
+    v.hash_blob_bytes = sizes[0] if sizes else index.hash_blob.size
+    toff = np.ascontiguousarray(index.table_offset, dtype=np.uint64)
+    tsz = np.ascontiguousarray(index.table_size, dtype=np.uint64)
+    cb = np.ascontiguousarray(index.contig_begin, dtype=np.uint64)
+    keep += [toff, tsz, cb]
+    v.table_offset = toff.ctypes.data
+    v.table_size = tsz.ctypes.data
+    v.contig_begin = cb.ctypes.data
+    v.n_contigs = len(index.contigs)
+    v.n_bases = index.n_bases
+    v.genome_pad = GENOME_PAD
+    v.first_alt_location = index.first_alt_location
+    if device_index_ptrs is None:
+        v.hash_blob = index.hash_blob.ctypes.data
+        v.overflow = index.overflow.ctypes.data
+        v.genome = index.genome_padded.ctypes.data + GENOME_PAD
+        v.on_device = 0
+    else:                                   # (hash, overflow, genome_padded) device addresses
+        v.hash_blob, v.overflow = int(device_index_ptrs[0]), int(device_index_ptrs[1])
+        v.genome = int(device_index_ptrs[2]) + GENOME_PAD
+        v.on_device = 1
+    return v, keep
+
+
 class BaseAligner:
     """One aligner context on one GPU (the analogue of one BaseAligner per CPU thread)."""
 
@@ -70,36 +106,8 @@ class BaseAligner:
         self.index = index
         self.params = params if params is not None else default_params()
         self._keep = []
-        v = IndexView()
-        v.seed_len = index.seed_len
-        v.key_bytes = index.key_bytes
-        v.n_hash_tables = index.n_hash_tables
-        v.large_hash_table = 1 if index.large else 0
-        v.location_size = index.location_size
-        v.chromosome_padding = index.chromosome_padding
-        sizes = getattr(index, "_device_sizes", None)      # set by dist.broadcast_index on every rank
-        v.overflow_table_size = sizes[1] if sizes else index.overflow.size
-        v.hash_blob_bytes = sizes[0] if sizes else index.hash_blob.size
-        toff = np.ascontiguousarray(index.table_offset, dtype=np.uint64)
-        tsz = np.ascontiguousarray(index.table_size, dtype=np.uint64)
-        cb = np.ascontiguousarray(index.contig_begin, dtype=np.uint64)
-        self._keep += [toff, tsz, cb]
-        v.table_offset = toff.ctypes.data
-        v.table_size = tsz.ctypes.data
-        v.contig_begin = cb.ctypes.data
-        v.n_contigs = len(index.contigs)
-        v.n_bases = index.n_bases
-        v.genome_pad = GENOME_PAD
-        v.first_alt_location = index.first_alt_location
-        if device_index_ptrs is None:
-            v.hash_blob = index.hash_blob.ctypes.data
-            v.overflow = index.overflow.ctypes.data
-            v.genome = index.genome_padded.ctypes.data + GENOME_PAD
-            v.on_device = 0
-        else:                                   # (hash, overflow, genome_padded) device addresses
-            v.hash_blob, v.overflow = int(device_index_ptrs[0]), int(device_index_ptrs[1])
-            v.genome = int(device_index_ptrs[2]) + GENOME_PAD
-            v.on_device = 1
+        v, keep = make_index_view(index, device_index_ptrs)
+        self._keep += keep
         handle = C.c_void_p()
         rc = self.lib.snapgpu_create(C.byref(v), C.byref(self.params), device, C.byref(handle))
         if rc != 0:

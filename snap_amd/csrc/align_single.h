@@ -355,6 +355,7 @@ struct Aligner {
     // one entry of candidatesForAffineGap (BaseAligner.cpp:2208-2225 / :2279-2296)
     __device__ __forceinline__ void record_candidate(int dir, int64_t loc, int64_t orig_loc, int score, int used_ag, int clip_before,
                                                      int clip_after, int ag_score, double mp, int seed_offset) {
+        if (agc == nullptr) return;                                        // no buffer: nothing is kept (:2202 NULL != candidatesForAffineGap)
         if (n_agc >= agc_cap) { agc_overflow = 1; return; }
         snapgpu_single_result *r = &agc[n_agc];
         if (lane == 0) {
@@ -722,7 +723,7 @@ struct Aligner {
                     if (loc_non_alt) {
                         update_best<HAM>(non_alt, loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
                     }
-                    if (HAM && n_agc >= agc_cap) { agc_overflow = 1; return true; }           // :1475 (the caller grows the buffer and retries)
+                    if (HAM && agc != nullptr && n_agc >= agc_cap) { agc_overflow = 1; return true; }   // :1475 (the caller grows the buffer and retries)
 
                     // early out: nothing can rescue MAPQ once the candidates' total probability reaches 4.9 (:1512)
                     double p_chk = cfg.alt_aware ? non_alt.p_all : all.p_all;

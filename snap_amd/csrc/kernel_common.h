@@ -1,0 +1,38 @@
+// kernel_common.h -- kernel argument structs and the per-wave LDS carve-out shared by the kernel
+// translation units (snapgpu.hip: single-end + batch primitives; paired_k.hip: paired end) and the host side.
+#pragma once
+#include "align_single.h"
+
+struct AlignArgs {
+    DevIndex ix;
+    AlignCfg cfg;
+    const DevTables *tab;
+    uint8_t *scratch;                 // n_wave_slots * cfg.scratch_stride
+    const uint8_t *bases, *quals;
+    const uint64_t *offsets;
+    uint32_t n_reads;
+    snapgpu_single_result *primary, *first_alt;
+    uint32_t *work_counter;
+    unsigned long long *counters;     // snapgpu_counters layout
+};
+
+static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
+
+// LDS carve-out per wave; must match lds_bytes_per_wave() on the host.
+struct LdsLayout {
+    uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, ag, shared, total;
+};
+static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uint32_t num_weight_lists, uint32_t kmax, uint32_t use_ag) {
+    LdsLayout L; uint32_t o = 0;
+    L.rd0 = o; o += RL; L.rd1 = o; o += RL; L.ql0 = o; o += RL; L.ql1 = o; o += RL;
+    L.gw = o; o += (RL + 2 * WIN_PAD + 15) & ~15u;
+    L.seed_used = o; o += (((RL + 31) / 32) * 4 + 15) & ~15u;
+    L.wl_next = o; o += (num_weight_lists * 2 + 15) & ~15u;
+    L.wl_prev = o; o += (num_weight_lists * 2 + 15) & ~15u;
+    L.lv = o; o += (lv_lds_bytes(kmax) + 15) & ~15u;
+    L.ag = o; if (use_ag) o += (ag_lds_bytes(RL) + 15) & ~15u;
+    L.shared = o; o += ((uint32_t)sizeof(WaveShared) + 15) & ~15u;
+    L.total = o;
+    return L;
+}
+

@@ -10,7 +10,9 @@
 // HBM scratch.
 #pragma once
 #include "align_single.h"
+#include "kernel_common.h"
 #include "paired.h"
+#include "paired_args.h"
 
 template <int AGC>
 struct DevPL {
@@ -112,42 +114,6 @@ struct DevPL {
     }
 };
 
-struct PairedLds { uint32_t single_total, rd, ql, lk, exhausted, miss, hs, list_head, seed_used, sh, total; };
-static __host__ __device__ __forceinline__ PairedLds paired_lds_layout(uint32_t single_total, uint32_t RL, uint32_t max_seeds) {
-    PairedLds L; uint32_t o = (single_total + 15) & ~15u;
-    L.single_total = o;
-    L.rd = o; o += 4 * RL;                                   // [read][dir]
-    L.ql = o; o += 4 * RL;
-    L.lk = o; o += (4 * max_seeds * (uint32_t)sizeof(PELookup) + 15) & ~15u;
-    L.exhausted = o; o += (4 * max_seeds * 4 + 15) & ~15u;
-    L.miss = o; o += (max_seeds * 4 + 15) & ~15u;
-    L.hs = o; o += (4 * (uint32_t)sizeof(PEHitSetHdr) + 15) & ~15u;
-    L.list_head = o; o += ((SNAPGPU_MAX_K + 1) * 4 + 15) & ~15u;
-    L.seed_used = o; o += (((RL + 31) / 32) * 4 + 15) & ~15u;
-    L.sh = o; o += ((uint32_t)sizeof(PEShared) + 15) & ~15u;
-    L.total = o;
-    return L;
-}
-
-struct PairedArgs {
-    DevIndex ix;
-    AlignCfg scfg;                     // the single-end aligner of the chimeric fallback
-    PECfg pcfg;
-    const DevTables *tab;
-    uint8_t *scratch;                  // n_wave_slots * stride
-    uint64_t stride;
-    uint64_t off_single_agc, off_cand, off_mate0, off_mate1, off_anchor, off_agc;   // offsets inside a wave's slab (single-end scratch first)
-    uint32_t single_agc_cap;
-    const uint8_t *bases, *quals;
-    const uint64_t *offsets;           // [2n+1]
-    uint32_t n_pairs;
-    int32_t max_k_paired, max_k_single;
-    snapgpu_paired_result *primary, *first_alt;
-    uint32_t *work_counter;
-    unsigned long long *counters;      // snapgpu_counters layout
-    uint32_t kmax_lv;
-};
-
 // Scalar-heavy, latency-bound control flow: 2 waves per SIMD keeps 256 VGPRs available (no spills) and is what the LDS
 // footprint allows anyway.
 template <int AGC>
@@ -176,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     al.heads = (uint16_t *)sc;
     al.pool = (Elem *)(sc + (size_t)a.scfg.ht_size * 2);
     al.ag_scratch = sc + (size_t)a.scfg.ht_size * 2 + (size_t)a.scfg.pool_size * sizeof(Elem);
-    al.agc = (snapgpu_single_result *)(sc + a.off_single_agc);
+    al.agc = a.single_agc_cap ? (snapgpu_single_result *)(sc + a.off_single_agc) : nullptr;    // no buffer without affine gap (PairedAligner.cpp:570-577)
     al.agc_cap = a.single_agc_cap;
     al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 

@@ -1,0 +1,17 @@
+// paired_k.hip -- one affine-gap variant of the paired-end kernel per translation unit.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DPAIRED_AGC=<3|4|6|0> -c paired_k.hip
+// (k_align_paired inlines the whole paired + single-end control flow; compiling the four variants in parallel keeps
+// the build at minutes instead of tens of minutes).
+#include <hip/hip_runtime.h>
+#include "paired_dev.h"
+
+#ifndef PAIRED_AGC
+#error "PAIRED_AGC must be defined (3, 4, 6 or 0)"
+#endif
+#define PE_CAT2(a, b) a##b
+#define PE_CAT(a, b) PE_CAT2(a, b)
+
+extern "C" void PE_CAT(snapgpu_launch_paired_, PAIRED_AGC)(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_align_paired<PAIRED_AGC>, dim3(blocks), dim3(256), lds_bytes, s, *a);
+}

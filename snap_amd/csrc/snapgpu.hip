@@ -19,43 +19,12 @@
 #include "lv.h"
 #include "ag_win.h"
 #include "align_single.h"
+#include "kernel_common.h"
+#include "paired_args.h"
 
 // =====================================================================================
 // kernels
 // =====================================================================================
-
-struct AlignArgs {
-    DevIndex ix;
-    AlignCfg cfg;
-    const DevTables *tab;
-    uint8_t *scratch;                 // n_wave_slots * cfg.scratch_stride
-    const uint8_t *bases, *quals;
-    const uint64_t *offsets;
-    uint32_t n_reads;
-    snapgpu_single_result *primary, *first_alt;
-    uint32_t *work_counter;
-    unsigned long long *counters;     // snapgpu_counters layout
-};
-
-static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
-
-// LDS carve-out per wave; must match lds_bytes_per_wave() on the host.
-struct LdsLayout {
-    uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, ag, shared, total;
-};
-static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uint32_t num_weight_lists, uint32_t kmax, uint32_t use_ag) {
-    LdsLayout L; uint32_t o = 0;
-    L.rd0 = o; o += RL; L.rd1 = o; o += RL; L.ql0 = o; o += RL; L.ql1 = o; o += RL;
-    L.gw = o; o += (RL + 2 * WIN_PAD + 15) & ~15u;
-    L.seed_used = o; o += (((RL + 31) / 32) * 4 + 15) & ~15u;
-    L.wl_next = o; o += (num_weight_lists * 2 + 15) & ~15u;
-    L.wl_prev = o; o += (num_weight_lists * 2 + 15) & ~15u;
-    L.lv = o; o += (lv_lds_bytes(kmax) + 15) & ~15u;
-    L.ag = o; if (use_ag) o += (ag_lds_bytes(RL) + 15) & ~15u;
-    L.shared = o; o += ((uint32_t)sizeof(WaveShared) + 15) & ~15u;
-    L.total = o;
-    return L;
-}
 
 // Latency-bound kernel: ask for 4 waves per SIMD (<= 128 VGPRs; costs ~24 spilled VGPRs of cold state).
 #ifndef SNAPGPU_WAVES_PER_SIMD
@@ -127,8 +96,6 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD) void k_align_single(Al
         atomicAdd(&a.counters[12], (unsigned long long)al.cnt.cyc_total);
     }
 }
-
-#include "paired_dev.h"               // k_align_paired: the paired-end path (needs LdsLayout above)
 
 // One wave per seed: GenomeIndex::lookupSeed32 for a batch of seeds.
 __global__ __launch_bounds__(256) void k_lookup_seeds(DevIndex ix, uint32_t n, const uint8_t *seeds,
@@ -888,6 +855,9 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
     const snapgpu_params &p = ctx->params;
     if (pp->max_spacing > 100000) return fail(ctx, SNAPGPU_E_INVALID, "max_spacing out of range");
+    if (p.alt_awareness && pp->use_soft_clipping && p.use_affine_gap && ctx->ix.first_alt_location < ctx->ix.n_bases)
+        return fail(ctx, SNAPGPU_E_UNSUPPORTED, "the index has ALT contigs: the paired-end path would need ALT liftover "
+                    "(IntersectingPairedEndAligner.cpp:2890-2968), which this build does not implement; use an index without ALT contigs or alt_awareness = 0");
     if (ctx->d_pscratch) { (void)hipFree(ctx->d_pscratch); ctx->d_pscratch = nullptr; }
     ctx->paired = false;
     ctx->pparams = *pp;
@@ -938,7 +908,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     if (pool < 64) pool = 64;
     c.pool_size = (uint32_t)pool;
     c.ag_cand_cap = p.use_affine_gap ? 4096 : 0;                                                    // PairedAligner.cpp:571 (the reference doubles on overflow; here overflow is reported)
-    a.single_agc_cap = 4096;
+    a.single_agc_cap = p.use_affine_gap ? 4096 : 0;
     a.max_k_paired = (int32_t)p.max_k; a.max_k_single = (int32_t)(p.max_k / 2);
 
     {   // affine-gap kernel variant: limits go up to MAX_K - 1 on this path (gapless-clipped reads, IntersectingPairedEndAligner.cpp:2577)
@@ -996,11 +966,11 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     const size_t lds = (size_t)4 * ctx->p_lds_per_wave;
-    switch (ctx->p_ag_variant) {
-    case 3:  hipLaunchKernelGGL(k_align_paired<3>, dim3(blocks), dim3(256), lds, s, a); break;
-    case 4:  hipLaunchKernelGGL(k_align_paired<4>, dim3(blocks), dim3(256), lds, s, a); break;
-    case 6:  hipLaunchKernelGGL(k_align_paired<6>, dim3(blocks), dim3(256), lds, s, a); break;
-    default: hipLaunchKernelGGL(k_align_paired<0>, dim3(blocks), dim3(256), lds, s, a); break;
+    switch (ctx->p_ag_variant) {           // one translation unit per affine-gap variant (paired_k.hip), compiled in parallel
+    case 3:  snapgpu_launch_paired_3(&a, blocks, lds, s); break;
+    case 4:  snapgpu_launch_paired_4(&a, blocks, lds, s); break;
+    case 6:  snapgpu_launch_paired_6(&a, blocks, lds, s); break;
+    default: snapgpu_launch_paired_0(&a, blocks, lds, s); break;
     }
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);

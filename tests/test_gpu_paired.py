@@ -1,0 +1,121 @@
+"""GPU parity tests of the paired-end path (run with -m gpu on an MI355X), through the C ABI
+(snapgpu_enable_paired / snapgpu_align_paired).  Expectations: the committed golden PairedAlignmentResults the compiled
+reference produced (scripts/make_golden_paired.py) and, where oracle/_ref travelled to the box, the reference itself on
+fresh seeded pairs.  Integer fields must be identical for every aligned read."""
+import os
+
+import numpy as np
+import pytest
+
+from snap_amd import abi, synth
+from snap_amd.index import GenomeIndex
+from tests import util
+from tests.pairs_util import compare_paired, hard_pairs
+from tests.test_paired_host import OPTS
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pindex():
+    return util.load_golden_index("paired_index.npz")
+
+
+@pytest.fixture(scope="module")
+def golden_pairs():
+    return np.load(os.path.join(util.GOLDEN, "paired_reads.npz"))
+
+
+def _aligner(index, kw, pkw, max_read_len=160):
+    from snap_amd.aligner import ChimericPairedEndAligner
+    return ChimericPairedEndAligner(index, abi.default_params(max_read_len=max_read_len, **kw), abi.default_paired_params(**pkw))
+
+
+@pytest.mark.parametrize("name", list(OPTS))
+def test_align_paired_matches_reference_fixture(pindex, golden_pairs, name):
+    kw, pkw = OPTS[name]
+    a = _aligner(pindex, kw, pkw)
+    z = golden_pairs
+    for tag in ("150", "100"):
+        key = "%s_%s_s0" % (name, tag)
+        a.counters(reset=True)
+        prim, alt = a.align(z["b" + tag], z["q" + tag], z["o" + tag])
+        bad = compare_paired(z[key + "_primary"], prim, verbose=3, exclude=z[key + "_unstable"])
+        assert not bad.any()
+        assert (alt["status"] == z[key + "_alt"]["status"]).all()
+        # pairs whose reference result depends on the aligner object's history are flagged, and only few are
+        assert (prim["reserved"] != 0).sum() <= 1 + prim.size // 200
+        c = a.counters()
+        if not z[key + "_unstable"].any() and not (prim["reserved"] != 0).any():
+            assert [c["n_lv_locations"], c["n_ag_locations"]] == z[key + "_counters"].tolist()
+    a.close()
+
+
+def test_results_do_not_depend_on_batch_composition(pindex, golden_pairs):
+    a = _aligner(pindex, dict(max_k=8), {})
+    z = golden_pairs
+    prim, _ = a.align(z["b150"], z["q150"], z["o150"])
+    n = prim.size
+    order = np.random.default_rng(3).permutation(n)[: n // 2]
+    o = z["o150"].astype(np.int64)
+    bb = np.concatenate([z["b150"][o[2 * i]:o[2 * i + 2]] for i in order])
+    qq = np.concatenate([z["q150"][o[2 * i]:o[2 * i + 2]] for i in order])
+    lens = np.concatenate([[o[2 * i + 1] - o[2 * i], o[2 * i + 2] - o[2 * i + 1]] for i in order])
+    oo = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    sub, _ = a.align(bb, qq, oo)
+    assert sub.tobytes() == prim[order].tobytes()
+    a.close()
+
+
+@pytest.mark.parametrize("maxk,L,npairs", [(8, 150, 4000), (20, 250, 1500), (27, 150, 1500)])
+def test_align_paired_vs_reference_live(tmp_path, maxk, L, npairs):
+    """C3 / C5-shaped inputs on a repeat-rich 3 Mb genome, diffed against the reference run on the box's host cores."""
+    if not ref.available():
+        pytest.skip("oracle/_ref did not travel to this box")
+    d = str(tmp_path)
+    contigs = synth.make_genome(21 + L, 3_000_000, n_contigs=3, repeat_frac=0.35, max_copies=400, n_run_frac=0.002)
+    synth.write_fasta(d + "/g.fa", contigs)
+    ref.build_index(d + "/g.fa", d + "/idx", seed_len=20, threads=16)
+    rix = ref.RefIndex(d + "/idx")
+    gi = GenomeIndex.load_from_directory(d + "/idx")
+    pr = hard_pairs(5 + maxk, contigs, npairs, L, insert_mean=400 if L < 200 else 600)
+    p = abi.default_params(max_k=maxk, max_read_len=L + 10)
+    pp = abi.default_paired_params()
+    rp, ra, rcnt, _ = rix.align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=16, stage=0)
+    from snap_amd.aligner import ChimericPairedEndAligner
+    a = ChimericPairedEndAligner(gi, p, pp)
+    gp, ga = a.align(pr["bases"], pr["quals"], pr["offsets"])
+    flagged = gp["reserved"] != 0
+    bad = compare_paired(rp, gp, verbose=3, exclude=flagged)
+    assert not bad.any()
+    assert flagged.sum() <= 1 + npairs // 200
+    c = a.counters()
+    if not flagged.any():
+        assert (c["n_lv_locations"], c["n_ag_locations"]) == (rcnt["lv"], rcnt["ag"])
+    a.close()
+
+
+def test_paired_error_behaviour(pindex, golden_index):
+    from snap_amd.aligner import BaseAligner, ChimericPairedEndAligner, SnapGpuError
+    import ctypes as C
+    # align before enable
+    b = BaseAligner(pindex, abi.default_params(max_k=8, max_read_len=160))
+    prim = np.zeros(1, dtype=abi.PAIRED_RESULT_DTYPE)
+    bases = np.frombuffer(b"ACGT" * 50, dtype=np.uint8).copy(); offs = np.array([0, 100, 200], dtype=np.uint64)
+    rc = b.lib.snapgpu_align_paired(b.handle, C.c_uint32(1), abi.ptr(bases), abi.ptr(bases), abi.ptr(offs), abi.ptr(prim), None)
+    assert rc == -1 and b"snapgpu_enable_paired" in b.lib.snapgpu_last_error(b.handle)
+    b.close()
+    # an index with ALT contigs needs ALT liftover, which is not built: refuse instead of returning different results
+    with pytest.raises(SnapGpuError, match="ALT"):
+        ChimericPairedEndAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+    # ... unless ALT awareness is off
+    a = ChimericPairedEndAligner(golden_index, abi.default_params(max_k=8, max_read_len=160, alt_awareness=0))
+    # reads longer than max_read_len are rejected before anything is launched
+    long_b = np.frombuffer(b"A" * 400, dtype=np.uint8).copy()
+    with pytest.raises(SnapGpuError, match="max_read_len"):
+        a.align(long_b, long_b, np.array([0, 200, 400], dtype=np.uint64))
+    # empty batch
+    p0, a0 = a.align(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert p0.size == 0
+    a.close()

@@ -1,0 +1,92 @@
+"""CPU tests of the paired-end control flow.  snap_amd/csrc/paired.h -- the code k_align_paired executes -- is compiled for
+the host by oracle/Makefile (oracle/_ref/libpairedhost.so: primitives from the C restatement, the reference's single-end
+aligner for the chimeric fallback) and compared with the committed golden PairedAlignmentResults the compiled reference
+produced (scripts/make_golden_paired.py).  Nothing here touches the product library or a GPU."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from snap_amd import abi, synth
+from snap_amd.aligner import make_index_view
+from snap_amd.index import GenomeIndex
+from oracle import ref
+from tests import util
+from tests.pairs_util import compare_paired
+
+HOSTLIB = os.path.join(util.ROOT, "oracle", "_ref", "libpairedhost.so")
+pytestmark = pytest.mark.skipif(not (os.path.exists(HOSTLIB) and ref.available()),
+                                reason="oracle/_ref was not built (needs /root/reference: run __graft_entry__.build() in the container)")
+
+OPTS = dict(default_d8=(dict(max_k=8), {}), default_d27=(dict(max_k=27), {}), lvonly_d12=(dict(max_k=12, use_affine_gap=0), {}),
+            spacing_d8=(dict(max_k=8), dict(min_spacing=100, max_spacing=600, num_seeds=12)))
+
+
+@pytest.fixture(scope="module")
+def golden_pairs():
+    return np.load(os.path.join(util.GOLDEN, "paired_reads.npz"))
+
+
+@pytest.fixture(scope="module")
+def ref_index(tmp_path_factory):
+    """The golden index, rebuilt as a directory the reference can load (same seeded genome as make_golden_paired.py)."""
+    d = str(tmp_path_factory.mktemp("pidx"))
+    g = synth.make_genome(20260926, 240_000, n_contigs=3, repeat_frac=0.35, max_copies=40, repeat_len=(150, 1500), n_run_frac=0.003)
+    synth.write_fasta(d + "/ref.fa", g)
+    ref.build_index(d + "/ref.fa", d + "/idx", 20, threads=4)
+    gi = GenomeIndex.load_from_directory(d + "/idx")
+    golden = util.load_golden_index("paired_index.npz")
+    assert (gi.genome_padded == golden.genome_padded).all() and (gi.contig_begin == golden.contig_begin).all()
+    return ref.RefIndex(d + "/idx"), gi
+
+
+def host_align(gi, rix, p, pp, bases, quals, offsets, stage):
+    lib = C.CDLL(HOSTLIB)
+    v, keep = make_index_view(gi)
+    n = (offsets.size - 1) // 2
+    prim = np.zeros(n, dtype=abi.PAIRED_RESULT_DTYPE)
+    alt = np.zeros(n, dtype=abi.PAIRED_RESULT_DTYPE)
+    cnt = np.zeros(3, dtype=np.int64)
+    b = np.ascontiguousarray(bases).reshape(-1); q = np.ascontiguousarray(quals).reshape(-1)
+    o = np.ascontiguousarray(offsets, dtype=np.uint64)
+    rc = lib.pairedhost_align(C.byref(v), rix.handle, C.byref(p), C.byref(pp), C.c_int(stage), C.c_uint32(n), abi.ptr(b), abi.ptr(q),
+                              abi.ptr(o), abi.ptr(prim), abi.ptr(alt), abi.ptr(cnt))
+    assert rc == 0
+    return prim, alt, cnt
+
+
+@pytest.mark.parametrize("name", list(OPTS))
+@pytest.mark.parametrize("tag", ["150", "100"])
+def test_chimeric_align_matches_reference_fixture(golden_pairs, ref_index, name, tag):
+    rix, gi = ref_index
+    kw, pkw = OPTS[name]
+    p = abi.default_params(max_read_len=160, **kw)
+    pp = abi.default_paired_params(**pkw)
+    z = golden_pairs
+    prim, alt, cnt = host_align(gi, rix, p, pp, z["b" + tag], z["q" + tag], z["o" + tag], 0)
+    key = "%s_%s_s0" % (name, tag)
+    bad = compare_paired(z[key + "_primary"], prim, verbose=3, exclude=z[key + "_unstable"])
+    assert not bad.any()
+    assert (alt["status"] == z[key + "_alt"]["status"]).all()
+    assert not prim["flags"].any()
+
+
+@pytest.mark.parametrize("name", ["default_d8", "spacing_d8", "lvonly_d12"])
+def test_intersecting_align_matches_reference_fixture(golden_pairs, ref_index, name):
+    """IntersectingPairedEndAligner::align alone (no chimeric fallback): every field it defines, and its work counters."""
+    rix, gi = ref_index
+    kw, pkw = OPTS[name]
+    p = abi.default_params(max_read_len=160, **kw)
+    pp = abi.default_paired_params(**pkw)
+    z = golden_pairs
+    prim, alt, cnt = host_align(gi, rix, p, pp, z["b150"], z["q150"], z["o150"], 1)
+    key = "%s_150_s1" % name
+    fields = ["status", "direction", "location", "orig_location", "score", "mapq", "used_affine_gap_scoring", "bases_clipped_before",
+              "bases_clipped_after", "ag_score", "seed_offset", "match_probability", "lv_indels", "used_gapless_clipping", "popular_seeds_skipped"]
+    bad = compare_paired(z[key + "_primary"], prim, verbose=3, exclude=z[key + "_unstable"], fields=fields)
+    assert not bad.any()
+    found = (z[key + "_primary"]["status"] != 0).all(axis=1) & ~z[key + "_unstable"]
+    assert (z[key + "_primary"]["probability_all_pairs"][found] == prim["probability_all_pairs"][found]).all()
+    if not z[key + "_unstable"].any():
+        assert [int(cnt[0]), int(cnt[1])] == z[key + "_counters"].tolist()      # LV / affine-gap locations scored

@@ -14,8 +14,8 @@ UNDEFINED_WHEN_NOT_FOUND = ("match_probability", "probability_all_candidates", "
                             "popular_seeds_skipped")
 
 
-def load_golden_index() -> GenomeIndex:
-    z = np.load(os.path.join(GOLDEN, "tiny_index.npz"))
+def load_golden_index(name: str = "tiny_index.npz") -> GenomeIndex:
+    z = np.load(os.path.join(GOLDEN, name))
     m = z["meta"]
     contigs = [Contig(int(b), bool(a), i, str(n)) for i, (b, a, n) in
                enumerate(zip(z["contig_begin"], z["contig_is_alt"], z["contig_names"]))]
