@@ -41,6 +41,13 @@ struct HostPL {
     static double f64(double v) { return v; }
     static bool lane0() { return true; }
     static void sync() {}
+    static uint64_t clock() { return 0; }
+    static const bool FAST_HITSET = false;
+    // (never called: the scalar definitions in paired.h are what the host runs)
+    bool hs_first(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *) { return true; }
+    bool hs_next_lower(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *) { return false; }
+    bool hs_next_le(PELookup *, PEHitSetHdr *, int64_t, int64_t *, uint32_t *) { return false; }
+    uint32_t hs_best_possible(PELookup *, PEHitSetHdr *, uint32_t *) { return 0; }
 
     bool lookup(const uint8_t *text, PEHits out[2]) {
         uint64_t bases, rc;

@@ -164,7 +164,9 @@ class Counters(C.Structure):
     ]
 
     def as_dict(self):
-        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+        d["cycles_single_fallback"] = int(self.reserved[0])      # paired-end path only
+        return d
 
 
 def default_params(max_k: int = 27, max_read_len: int = 400, **overrides) -> Params:

@@ -30,6 +30,8 @@
 //   substring_ok(loc,len)    Genome::getSubstring(loc,len) != NULL;   is_alt(loc)
 //   mapq(pAll,pBest,popular) computeMAPQ;   seed_prob()  pow(1-SNP_PROB, seedLen);  phred/indel/perfect tables
 //   align_single(...)        the single-end aligner of the chimeric fallback
+//   FAST_HITSET + hs_*(...)  optional lane-parallel versions of the four HashTableHitSet queries (the scalar ones below are
+//                            the definition; the device runs one lookup per lane)
 #pragma once
 #include <stdint.h>
 #include "../../include/snapgpu.h"
@@ -116,7 +118,7 @@ struct PESet {                         // ScoreSet, .h:614-700
     int32_t  best_pair_score, best_pair_ag;
 };
 
-struct PECounters { uint64_t lv, ag, lookups; };
+struct PECounters { uint64_t lv, ag, lookups; uint64_t cyc_lookup, cyc_intersect, cyc_lv, cyc_ag, cyc_single, cyc_total; };   // cycles: PL::clock()
 
 struct PEShared {                      // cold wave-uniform state (LDS on the device)
     PESet all, non_alt;
@@ -192,6 +194,7 @@ struct PairedCore {
 
     // returns true when the set is EMPTY (the reference returns !anyFound), :3720-3746
     PE_FN bool hs_first(int s, int64_t *loc, uint32_t *seed_offset) {
+        if constexpr (PL::FAST_HITSET) return pl.hs_first(lks(s), &hs[s], loc, seed_offset);
         bool any = false;
         *loc = 0;
         const uint32_t n = ld(hs[s].n_used);
@@ -208,6 +211,7 @@ struct PairedCore {
     }
 
     PE_FN bool hs_next_lower(int s, int64_t *loc, uint32_t *seed_offset) {                              // getNextLowerHit, :3750-3816
+        if constexpr (PL::FAST_HITSET) return pl.hs_next_lower(lks(s), &hs[s], loc, seed_offset);
         int64_t found = 0;
         bool any = false;
         const uint32_t n = ld(hs[s].n_used);
@@ -236,6 +240,7 @@ struct PairedCore {
     }
 
     PE_FN bool hs_next_le(int s, int64_t max_loc, int64_t *loc, uint32_t *seed_offset) {                // getNextHitLessThanOrEqualTo, :3628-3717
+        if constexpr (PL::FAST_HITSET) return pl.hs_next_le(lks(s), &hs[s], max_loc, loc, seed_offset);
         bool any = false;
         int64_t best = 0;
         const uint32_t n = ld(hs[s].n_used);
@@ -267,6 +272,7 @@ struct PairedCore {
     }
 
     PE_FN uint32_t hs_best_possible(int s) {                                                             // computeBestPossibleScoreForCurrentHit, :3585-3625
+        if constexpr (PL::FAST_HITSET) return pl.hs_best_possible(lks(s), &hs[s], exh(s));
         const int cd = ld(hs[s].cur_disjoint);
         for (int i = 0; i <= cd; i++) st(miss[i], ld(exh(s)[i]));
         const uint32_t n = ld(hs[s].n_used);
@@ -426,6 +432,7 @@ struct PairedCore {
         const uint8_t *R = rd[which][dir], *Qd = ql[which][dir];
         const int tail = seed_offset + sl;
         sh->cnt.lv++;
+        const uint64_t t_lv = PL::clock();
         LVOut a = pl.lv(+1, R + tail, Qd + tail, rl - tail, data + tail, (int)(glen - tail), limit);
         int score1 = a.score, score2 = 0, off = 0, ind2 = 0, span2 = 0;
         double mp1 = a.mp, mp2 = 1.0;
@@ -437,6 +444,7 @@ struct PairedCore {
         } else {
             mp1 = 1.0;                               // (unused)
         }
+        sh->cnt.cyc_lv += PL::clock() - t_lv;
         o.offset = off;
         if (off != 0 && !pl.substring_ok(loc + off, glen)) score2 = -1;                               // :3364-3375
         if (score1 != -1 && score2 != -1) {
@@ -498,6 +506,7 @@ struct PairedCore {
         int score1 = 0, score2 = 0, ag1 = sl, ag2 = 0;
         double mp1 = 1.0, mp2 = 1.0;
         int text_rem = rl - tail;
+        const uint64_t t_ag = PL::clock();
         if (tail != rl) {
             const int plen = rl - tail;
             const bool banded = plen >= 3 * (2 * limit + 1);
@@ -517,6 +526,7 @@ struct PairedCore {
                 if (score2 == -1) *offset = 0;
             }
         }
+        sh->cnt.cyc_ag += PL::clock() - t_ag;
         if (score1 != -1 && score2 != -1) {
             *score = score1 + score2;
             *mp = mp1 * mp2 * pl.seed_prob();
@@ -627,6 +637,7 @@ struct PairedCore {
         if ((int)n_count > cfg.max_k) return;                                                                         // :385
 
         // ---- Phase 1: seed lookups into the four hit sets (:417-502)
+        const uint64_t t_p1 = PL::clock();
         int64_t total_hits[2][2] = {{0, 0}, {0, 0}};
         for (int w = 0; w < 2; w++) {
             int next_seed = 0, lookups = 0;
@@ -670,6 +681,8 @@ struct PairedCore {
         fewer = 1 - more;
 
         // ---- Phase 2: walk both set pairs from high to low locations, collect candidates (:527-741)
+        const uint64_t t_p2 = PL::clock();
+        sh->cnt.cyc_lookup += t_p2 - t_p1;
         int max_used_list = 0;
         for (int sp = 0; sp < 2; sp++) {
             // set pair 0 = read0 FORWARD + read1 RC, set pair 1 = read0 RC + read1 FORWARD
@@ -763,6 +776,7 @@ struct PairedCore {
         }
 
         // ---- Phase 3: score candidates in order of their best possible score (:803-1190)
+        sh->cnt.cyc_intersect += PL::clock() - t_p2;
         int cur_list = 0;
         bool done = false;
         while (!done && cur_list <= max_used_list) {
@@ -1129,7 +1143,9 @@ struct PairedCore {
 
     PE_FN void align_pair(int max_k_paired, int max_k_single) {
         overflow = 0; stale = 0;
+        const uint64_t t_all = PL::clock();
         align_pair_inner(max_k_paired, max_k_single);
+        sh->cnt.cyc_total += PL::clock() - t_all;
         sh->res.reserved = stale;                           // not in the reference: see snapgpu_paired_result.reserved
     }
 
@@ -1197,7 +1213,9 @@ struct PairedCore {
                     int a = res.score[r] < limit_left ? res.score[r] : limit_left;
                     max_k_read = max_k_single < a ? max_k_single : a;
                 }
+                const uint64_t t_s = PL::clock();
                 pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r]);
+                sh->cnt.cyc_single += PL::clock() - t_s;
                 stale += single[r].reserved & 0x7fffffffu;
                 bool used_hamming = false;
                 if (cfg.use_soft_clip && cfg.enable_hamming_base) {

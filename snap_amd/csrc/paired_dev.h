@@ -41,6 +41,123 @@ struct DevPL {
     static __device__ __forceinline__ double f64(double v) { return first_f64(v); }
     static __device__ __forceinline__ bool lane0() { return lane_id() == 0; }
     static __device__ __forceinline__ void sync() { WAVE_SYNC(); }
+    static __device__ __forceinline__ uint64_t clock() { return wave_clock(); }
+
+    // ---- HashTableHitSet queries, one lookup per lane (lookups are few: <= 30).  Each reproduces the scalar loop of paired.h:
+    // those loops keep the FIRST lookup (lowest index) among equal best locations and only accept locations > 0.
+    // (off for the AGC == 0 variant -- reads longer than ~400 bp: with it ROCm 7.2's AMDGPU backend stops with "Illegal instruction
+    //  detected: Operand has incorrect register class  V_CMP_NE_U32_e32 0, $src_shared_base"; the scalar queries are used there)
+    static const bool FAST_HITSET = AGC != 0;
+    static __device__ __forceinline__ uint32_t lk_hit(const PELookup *l, int64_t i) { return l->is_single ? l->singleton : l->hits[i]; }
+    // wave arg-max of v over lanes with ok set; returns the winning lane (lowest lane among equals) or -1
+    static __device__ __forceinline__ int wave_argmax(bool ok, int64_t v, int64_t *best) {
+        int64_t m = ok ? v : -1;
+        for (int o = 32; o >= 1; o >>= 1) {
+            int64_t t = ((int64_t)__shfl_xor((int)(m >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)m, o);
+            m = t > m ? t : m;
+        }
+        m = (int64_t)first_u64((uint64_t)m);
+        uint64_t who = __ballot(ok && v == m);
+        *best = m;
+        return who ? __ffsll((long long)who) - 1 : -1;
+    }
+    __device__ __forceinline__ bool hs_first(PELookup *lk, PEHitSetHdr *h, int64_t *loc, uint32_t *seed_offset) {
+        const int lane = lane_id();
+        const uint32_t n = ld(h->n_used);
+        const PELookup *l = &lk[lane < (int)n ? lane : 0];
+        bool ok = lane < (int)n && l->n_hits > 0;
+        uint32_t so = l->seed_offset;
+        int64_t v = ok ? (int64_t)(uint32_t)(lk_hit(l, 0) - so) : -1;
+        ok = ok && v > 0;
+        int64_t best;
+        int w = wave_argmax(ok, v, &best);
+        *loc = 0;
+        if (w < 0) return true;
+        *loc = best;
+        *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)so, w);
+        st(h->most_recent, best);
+        return false;
+    }
+    __device__ __forceinline__ bool hs_next_lower(PELookup *lk, PEHitSetHdr *h, int64_t *loc, uint32_t *seed_offset) {
+        const int lane = lane_id();
+        const uint32_t n = ld(h->n_used);
+        const int64_t recent = ld(h->most_recent);
+        PELookup *l = &lk[lane < (int)n ? lane : 0];
+        const bool act = lane < (int)n;
+        int64_t cur = l->cur;
+        const int64_t nh = l->n_hits;
+        const uint32_t so = l->seed_offset;
+        bool live = act && cur != nh;
+        int64_t hv = live ? (int64_t)lk_hit(l, cur) : 0;
+        if (live && hv - so == recent) {
+            cur++;
+            l->cur = cur;
+            live = cur != nh;
+            if (live) hv = (int64_t)lk_hit(l, cur);
+        }
+        WAVE_SYNC();
+        bool ok = live && hv >= (int64_t)so && hv - so > 0;
+        int64_t best;
+        int w = wave_argmax(ok, hv - so, &best);
+        if (w < 0) return false;
+        *loc = best;
+        *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)so, w);
+        st(h->most_recent, best);
+        return true;
+    }
+    __device__ __forceinline__ bool hs_next_le(PELookup *lk, PEHitSetHdr *h, int64_t max_loc, int64_t *loc, uint32_t *seed_offset) {
+        const int lane = lane_id();
+        const uint32_t n = ld(h->n_used);
+        PELookup *l = &lk[lane < (int)n ? lane : 0];
+        const bool act = lane < (int)n;
+        const uint32_t so = l->seed_offset;
+        const int64_t max_this = max_loc + so;
+        int64_t lo = l->cur, hi = act ? l->n_hits - 1 : -1;
+        if (!act) lo = 0;
+        bool found = false;
+        int64_t v = 0;
+        while (__ballot(lo <= hi && !found)) {
+            if (lo <= hi && !found) {
+                int64_t probe = (lo + hi) / 2;
+                int64_t ph = (int64_t)lk_hit(l, probe);
+                if (ph <= max_this && (probe == 0 || (int64_t)lk_hit(l, probe - 1) > max_this)) {
+                    found = true; v = ph - so;
+                    l->cur = probe;
+                } else if (ph > max_this) lo = probe + 1; else hi = probe - 1;
+            }
+        }
+        if (act && !found) l->cur = l->n_hits;
+        WAVE_SYNC();
+        int64_t best;
+        int w = wave_argmax(found && v > 0, v, &best);
+        if (w < 0) return false;
+        *loc = best;
+        *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)so, w);
+        st(h->most_recent, best);
+        return true;
+    }
+    __device__ __forceinline__ uint32_t hs_best_possible(PELookup *lk, PEHitSetHdr *h, uint32_t *exhausted) {
+        const int lane = lane_id();
+        const uint32_t n = ld(h->n_used);
+        const int cd = ld(h->cur_disjoint);
+        const int64_t recent = ld(h->most_recent);
+        const PELookup *l = &lk[lane < (int)n ? lane : 0];
+        const bool act = lane < (int)n;
+        const int64_t cur = l->cur, nh = l->n_hits;
+        const int64_t target = recent + l->seed_offset;
+        bool close = false;
+        if (act) {
+            if (cur != nh) { int64_t a = (int64_t)lk_hit(l, cur); int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
+            if (!close && cur != 0) { int64_t a = (int64_t)lk_hit(l, cur - 1); int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
+        }
+        const uint32_t wd = l->which_disjoint;
+        uint32_t best = 0;
+        for (int d = 0; d <= cd; d++) {
+            uint32_t m = ld(exhausted[d]) + (uint32_t)__popcll(__ballot(act && !close && wd == (uint32_t)d));
+            if (m > best) best = m;
+        }
+        return best;
+    }
 
     __device__ __forceinline__ bool lookup(const uint8_t *text, PEHits out[2]) {
         SeedBits seed = pack_seed(text, al->ix.seed_len);
@@ -163,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     core.mate[1] = (PEMate *)(sc + a.off_mate1);
     core.anchor = (PEAnchor *)(sc + a.off_anchor);
     core.agc = (snapgpu_paired_result *)(sc + a.off_agc);
-    core.sh->cnt = PECounters{0, 0, 0};
+    core.sh->cnt = PECounters{0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint8_t *prd = my + PLd.rd, *pql = my + PLd.ql;
     const uint32_t RL = a.scfg.RL;
     uint64_t n_done = 0;
@@ -217,5 +334,13 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         atomicAdd(&a.counters[5], (unsigned long long)(al.cnt.lv + core.sh->cnt.lv));
         atomicAdd(&a.counters[6], (unsigned long long)(al.cnt.ag + core.sh->cnt.ag));
         atomicAdd(&a.counters[7], (unsigned long long)al.cnt.lv_ref_bytes);
+        // phase cycles of the paired path: lookup = Phase 1, hits = Phase 2 (intersection), lv / ag = paired scoring only,
+        // reserved[0] = the single-end fallback as a whole
+        atomicAdd(&a.counters[8], (unsigned long long)core.sh->cnt.cyc_lookup);
+        atomicAdd(&a.counters[9], (unsigned long long)core.sh->cnt.cyc_intersect);
+        atomicAdd(&a.counters[10], (unsigned long long)core.sh->cnt.cyc_lv);
+        atomicAdd(&a.counters[11], (unsigned long long)core.sh->cnt.cyc_ag);
+        atomicAdd(&a.counters[12], (unsigned long long)core.sh->cnt.cyc_total);
+        atomicAdd(&a.counters[13], (unsigned long long)core.sh->cnt.cyc_single);
     }
 }
