@@ -9,9 +9,13 @@
  * reference's own hook, AlignerExtension::runIterationThread (SNAPLib/AlignerContext.h:165,
  * called at SingleAligner.cpp:102), so no SNAPLib source is modified.
  *
+ * The paired hook (AlignerContext.h:165, called at PairedAligner.cpp:503) does the same for
+ * ChimericPairedEndAligner::align (PairedAligner.cpp:664-960) with snapgpu_align_paired.
+ *
  * Built by oracle/Makefile (target `ref`) into oracle/_ref/snap-aligner-gpu, because the
  * resulting binary contains the reference's objects.  Usage is SNAP's:
  *     snap-aligner-gpu single <index-dir> reads.fq -o out.sam [-d 8 ...]
+ *     snap-aligner-gpu paired <index-dir> r1.fq r2.fq -o out.sam [-d 8 ...]
  * Written in C++98 like the reference.
  */
 #include "stdafx.h"
@@ -39,6 +43,37 @@ extern const char *SNAP_VERSION;                                   // SNAPLib/Co
 
 static pthread_mutex_t g_gpuLock = PTHREAD_MUTEX_INITIALIZER;      // one context, calls serialised
 static snapgpu_ctx *g_ctx = NULL;
+static bool g_pairedEnabled = false;
+
+static void toSnapPaired(const snapgpu_paired_result &g, PairedAlignmentResult *r)
+{
+    memset(r, 0, sizeof(*r));
+    for (int i = 0; i < NUM_READS_PER_PAIR; i++) {
+        r->status[i] = (AlignmentResult)g.status[i];
+        r->direction[i] = g.direction[i];
+        r->location[i] = GenomeLocation(g.location[i]);
+        r->origLocation[i] = GenomeLocation(g.orig_location[i]);
+        r->score[i] = g.score[i];
+        r->scorePriorToClipping[i] = g.score_prior_to_clipping[i];
+        r->mapq[i] = g.mapq[i];
+        r->clippingForReadAdjustment[i] = g.clipping_for_read_adjustment[i];
+        r->usedAffineGapScoring[i] = g.used_affine_gap_scoring[i] != 0;
+        r->basesClippedBefore[i] = g.bases_clipped_before[i];
+        r->basesClippedAfter[i] = g.bases_clipped_after[i];
+        r->agScore[i] = g.ag_score[i];
+        r->supplementary[i] = g.supplementary[i] != 0;
+        r->seedOffset[i] = g.seed_offset[i];
+        r->lvIndels[i] = g.lv_indels[i];
+        r->matchProbability[i] = g.match_probability[i];
+        r->popularSeedsSkipped[i] = g.popular_seeds_skipped[i];
+        r->usedGaplessClipping[i] = g.used_gapless_clipping[i] != 0;
+        r->refSpan[i] = g.ref_span[i];
+        r->liftover[i] = false;
+    }
+    r->probabilityAllPairs = g.probability_all_pairs;
+    r->alignedAsPair = g.aligned_as_pair != 0;
+    r->agForcedSingleAlignerCall = g.ag_forced_single_aligner_call != 0;
+}
 
 static void toSnap(const snapgpu_single_result &g, SingleAlignmentResult *r)
 {
@@ -70,7 +105,135 @@ public:
     // (AlignerContext.cpp:225): without this override the hook would never run in the workers.
     virtual AlignerExtension *copy() { return new GpuAlignerExtension(); }
 
-    virtual bool runIterationThread(PairedReadSupplier *supplier, AlignerContext *c) { return false; }   // paired: reference path
+    virtual bool runIterationThread(PairedReadSupplier *supplier, AlignerContext *c)
+    {
+        if (c->index == NULL) {
+            return false;                                   // I/O-only mode: leave it to SNAP
+        }
+        PairedAlignerOptions *po = (PairedAlignerOptions *)c->options;
+        if (c->maxSecondaryAlignmentAdditionalEditDistance >= 0 || c->options->stopOnFirstHit || !c->ignoreAlignmentAdjustmentForOm ||
+            c->index->doesGenomeIndexHave64BitLocations() || po->inferSpacing) {
+            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-om, -f, -ins, -sa or a 64-bit index)\n");
+            soft_exit(1);
+        }
+        ensureContext(c, 25);
+        ensurePaired(c, po);
+
+        const unsigned BATCH = 8192;                        // pairs
+        ReadWithOwnMemory *reads = (ReadWithOwnMemory *)BigAlloc((size_t)2 * BATCH * sizeof(ReadWithOwnMemory));
+        bool *useful = new bool[2 * BATCH];
+        std::vector<char> bases, quals;
+        std::vector<uint64_t> offs;
+        std::vector<snapgpu_paired_result> prim(BATCH), alt(BATCH);
+        _int64 nSingleResults[2] = {0, 0};
+        bool more = true;
+        while (more) {
+            unsigned n = 0;
+            bases.clear(); quals.clear(); offs.clear(); offs.push_back(0);
+            Read *pr[NUM_READS_PER_PAIR];
+            while (n < BATCH) {
+                if (!supplier->getNextReadPair(&pr[0], &pr[1])) { more = false; break; }
+                if (!c->options->ignoreMismatchedIDs) {
+                    Read::checkIdMatch(pr[0], pr[1]);
+                }
+                c->stats->totalReads += 2;
+                // PairedAligner.cpp:681-710: both reads too short / too many Ns -> written unaligned, counted useless
+                bool useful0 = pr[0]->getDataLength() >= c->minReadLength && (int)pr[0]->countOfNs() <= (int)c->maxDist;
+                bool useful1 = pr[1]->getDataLength() >= c->minReadLength && (int)pr[1]->countOfNs() <= (int)c->maxDist;
+                if (!useful0 && !useful1) {
+                    PairedAlignmentResult result;
+                    memset(&result, 0, sizeof(result));
+                    result.status[0] = result.status[1] = NotFound;
+                    result.location[0] = result.location[1] = InvalidGenomeLocation;
+                    bool pass0 = c->options->passFilter(pr[0], result.status[0], true, false);
+                    bool pass1 = c->options->passFilter(pr[1], result.status[1], true, false);
+                    bool pass = (c->options->filterFlags & AlignerOptions::FilterBothMatesMatch) ? (pass0 && pass1) : (pass0 || pass1);
+                    if (pass) {
+                        if (NULL != c->readWriter) {
+                            c->readWriter->writePairs(c->readerContext, pr, &result, 1, NULL, nSingleResults, true, c->useAffineGap);
+                        }
+                        c->stats->uselessReads += 2;
+                    } else {
+                        c->stats->filtered += 2;
+                    }
+                    continue;
+                }
+                for (int r = 0; r < NUM_READS_PER_PAIR; r++) {
+                    new (&reads[2 * n + r]) ReadWithOwnMemory(*pr[r]);
+                    bases.insert(bases.end(), pr[r]->getData(), pr[r]->getData() + pr[r]->getDataLength());
+                    quals.insert(quals.end(), pr[r]->getQuality(), pr[r]->getQuality() + pr[r]->getDataLength());
+                    offs.push_back((uint64_t)bases.size());
+                }
+                useful[2 * n] = useful0; useful[2 * n + 1] = useful1;
+                n++;
+            }
+            if (0 == n) continue;
+            if (bases.empty()) { bases.push_back(0); quals.push_back(0); }
+
+            pthread_mutex_lock(&g_gpuLock);
+            int rc = snapgpu_align_paired(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
+            pthread_mutex_unlock(&g_gpuLock);
+            if (rc != SNAPGPU_OK) {
+                WriteErrorMessage("snapgpu_align_paired failed (%d): %s\n", rc, snapgpu_last_error(g_ctx));
+                soft_exit(1);
+            }
+
+            for (unsigned i = 0; i < n; i++) {
+                Read *two[NUM_READS_PER_PAIR] = {&reads[2 * i], &reads[2 * i + 1]};
+                PairedAlignmentResult result, altResult;
+                toSnapPaired(prim[i], &result);
+                if (po->forceSpacing && isOneLocation(result.status[0]) != isOneLocation(result.status[1])) {         // PairedAligner.cpp:833-841
+                    result.status[0] = result.status[1] = NotFound;
+                    result.location[0] = result.location[1] = InvalidGenomeLocation;
+                    result.usedAffineGapScoring[0] = result.usedAffineGapScoring[1] = false;
+                    result.basesClippedBefore[0] = result.basesClippedBefore[1] = 0;
+                    result.basesClippedAfter[0] = result.basesClippedAfter[1] = 0;
+                    result.agScore[0] = result.agScore[1] = 0;
+                }
+                bool pass0 = c->options->passFilter(two[0], result.status[0], !useful[2 * i], false);
+                bool pass1 = c->options->passFilter(two[1], result.status[1], !useful[2 * i + 1], false);
+                bool pass = (c->options->filterFlags & AlignerOptions::FilterBothMatesMatch) ? (pass0 && pass1) : (pass0 || pass1);
+                _int64 nResults = pass ? 1 : 0;
+                bool firstIsPrimary = pass;
+                if (NULL != c->readWriter) {
+                    SingleAlignmentResult *singleResults[2] = {NULL, NULL};
+                    c->readWriter->writePairs(c->readerContext, two, &result, nResults, singleResults, nSingleResults, firstIsPrimary, c->useAffineGap);
+                    if (c->emitALTAlignments && (alt[i].status[0] != SNAPGPU_NotFound || alt[i].status[1] != SNAPGPU_NotFound)) {
+                        toSnapPaired(alt[i], &altResult);
+                        c->readWriter->writePairs(c->readerContext, two, &altResult, 1, NULL, 0, true, c->useAffineGap);
+                    }
+                }
+                if (firstIsPrimary) {                               // PairedAlignerContext::updateStats, PairedAligner.cpp:962-1000 (base counters)
+                    for (int r = 0; r < NUM_READS_PER_PAIR; r++) {
+                        if (useful[2 * i + r]) {
+                            if (isOneLocation(result.status[r])) c->stats->singleHits++;
+                            else if (result.status[r] == MultipleHits) c->stats->multiHits++;
+                            else c->stats->notFound++;
+                            if (result.status[r] != NotFound) c->stats->mapqHistogram[result.mapq[r]]++;
+                        } else {
+                            c->stats->uselessReads++;
+                        }
+                    }
+                    if (result.direction[0] == result.direction[1]) c->stats->sameComplement++;
+                    if (result.alignedAsPair) c->stats->alignedAsPairs += 2;
+                } else {
+                    c->stats->filtered += 2;
+                }
+                reads[2 * i].dispose();
+                reads[2 * i + 1].dispose();
+            }
+        }
+        BigDealloc(reads);
+        delete[] useful;
+        snapgpu_counters counters;
+        pthread_mutex_lock(&g_gpuLock);
+        if (snapgpu_get_counters(g_ctx, &counters, 1) == SNAPGPU_OK) {
+            c->stats->lvCalls += (_int64)counters.n_lv_locations;
+            c->stats->affineGapCalls += (_int64)counters.n_ag_locations;
+        }
+        pthread_mutex_unlock(&g_gpuLock);
+        return true;
+    }
 
     virtual bool runIterationThread(ReadSupplier *supplier, AlignerContext *c)
     {
@@ -82,7 +245,7 @@ public:
             WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-om, -f, -x, -sa or a 64-bit index)\n");
             soft_exit(1);
         }
-        ensureContext(c);
+        ensureContext(c, c->numSeedsFromCommandLine);
 
         // Reads are only valid until the supplier moves on, so each batch is copied.  ReadWithOwnMemory
         // points into its own body and has no copy-assignment: construct in place in raw storage.
@@ -174,7 +337,31 @@ public:
     }
 
 private:
-    static void ensureContext(AlignerContext *c)
+    static void ensurePaired(AlignerContext *c, PairedAlignerOptions *po)
+    {
+        pthread_mutex_lock(&g_gpuLock);
+        if (!g_pairedEnabled) {
+            snapgpu_paired_params pp;
+            snapgpu_default_paired_params(&pp);
+            pp.min_spacing = po->minSpacing; pp.max_spacing = po->maxSpacing; pp.force_spacing = po->forceSpacing ? 1 : 0;
+            pp.max_big_hits = po->intersectingAlignerMaxHits; pp.max_candidate_pool_size = po->maxCandidatePoolSize;
+            pp.num_seeds = c->numSeedsFromCommandLine; pp.seed_coverage = c->seedCoverage; pp.max_k_for_indels = c->maxDistForIndels;
+            pp.min_read_length = c->minReadLength; pp.use_soft_clipping = c->options->useSoftClipping ? 1 : 0;
+            pp.flatten_mapq_at_or_below = c->options->flattenMAPQAtOrBelow; pp.min_score_realignment = po->minScoreRealignment;
+            pp.min_score_gap_realignment_alt = po->minScoreGapRealignmentALT; pp.min_ag_score_improvement = po->minAGScoreImprovement;
+            pp.enable_hamming_scoring_base_aligner = po->enableHammingScoringBaseAligner ? 1 : 0; pp.max_single_seeds = po->maxSeedsSingleEnd;
+            int rc = snapgpu_enable_paired(g_ctx, &pp);
+            if (rc != SNAPGPU_OK) {
+                WriteErrorMessage("snapgpu_enable_paired failed (%d): %s\n", rc, snapgpu_last_error(g_ctx));
+                soft_exit(1);
+            }
+            g_pairedEnabled = true;
+        }
+        pthread_mutex_unlock(&g_gpuLock);
+    }
+
+    // numSeeds: -n for the single-end aligner (the paired path hands its own -n to snapgpu_enable_paired)
+    static void ensureContext(AlignerContext *c, unsigned numSeeds)
     {
         pthread_mutex_lock(&g_gpuLock);
         if (NULL == g_ctx) {
@@ -182,7 +369,7 @@ private:
             snapgpu_default_params(&p);
             p.max_hits = (uint32_t)c->maxHits;
             p.max_k = c->maxDist;
-            p.num_seeds = c->numSeedsFromCommandLine;
+            p.num_seeds = numSeeds;
             p.seed_coverage = c->seedCoverage;
             p.min_weight_to_check = c->minWeightToCheck;
             p.extra_search_depth = c->extraSearchDepth;
@@ -212,16 +399,22 @@ private:
 // Mirror of ProcessNonDaemonCommands (SNAPLib/CommandProcessor.cpp:59-88) with the extension installed.
 int main(int argc, const char **argv)
 {
-    if (argc < 2 || (strcmp(argv[1], "single") != 0)) {
+    if (argc < 2 || (strcmp(argv[1], "single") != 0 && strcmp(argv[1], "paired") != 0)) {
         fprintf(stderr, "usage: snap-aligner-gpu single <index-dir> <reads> [SNAP options]\n"
-                        "       (index / paired / daemon: use the reference's snap-aligner)\n");
+                        "       snap-aligner-gpu paired <index-dir> <reads1> <reads2> [SNAP options]\n"
+                        "       (index / daemon: use the reference's snap-aligner)\n");
         return 1;
     }
     InitializeSeedSequencers();                                     // CommandProcessor.cpp:196
     unsigned nArgsConsumed = 0;
     GpuAlignerExtension *extension = new GpuAlignerExtension();
-    SingleAlignerContext single(extension);                         // SingleAligner.h:36
-    single.runAlignment(argc - 1, argv + 1, SNAP_VERSION, &nArgsConsumed);
+    if (strcmp(argv[1], "single") == 0) {
+        SingleAlignerContext single(extension);                     // SingleAligner.h:36
+        single.runAlignment(argc - 1, argv + 1, SNAP_VERSION, &nArgsConsumed);
+    } else {
+        PairedAlignerContext paired(extension);                     // PairedAligner.h:42
+        paired.runAlignment(argc - 1, argv + 1, SNAP_VERSION, &nArgsConsumed);
+    }
     if (g_ctx) snapgpu_destroy(g_ctx);
     return 0;
 }

@@ -125,3 +125,58 @@ def test_shim_fails_loudly_on_unsupported_option(workload):
                         "-om", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=300)
     assert r.returncode != 0
     assert b"libsnapgpu" in r.stdout
+
+
+# ---------------------------------------------------------------------------------------- paired end
+
+@pytest.fixture(scope="module")
+def paired_workload(workload):
+    from tests.pairs_util import hard_pairs
+    d = workload["dir"]
+    contigs = synth.make_genome(77, 3_000_000, n_contigs=3, repeat_frac=0.08)        # the genome of `workload`
+    pr = hard_pairs(11, contigs, 6000, 150, insert_mean=380)
+    o = pr["offsets"].astype(np.int64)
+    fq = [os.path.join(d, "p1.fq"), os.path.join(d, "p2.fq")]
+    with open(fq[0], "wb") as f0, open(fq[1], "wb") as f1:
+        for i in range(o.size // 2):
+            for r, f in ((0, f0), (1, f1)):
+                s, e = o[2 * i + r], o[2 * i + r + 1]
+                f.write(b"@pair%d\n" % i + pr["bases"][s:e].tobytes() + b"\n+\n" + pr["quals"][s:e].tobytes() + b"\n")
+    return dict(dir=d, index=workload["index"], fq=fq, pairs=pr)
+
+
+@pytest.mark.parametrize("opts,params,pparams", [
+    ([], {}, {}),
+    (["-d", "10", "-s", "50", "800", "-H", "2000"], {"max_k": 10}, {"min_spacing": 50, "max_spacing": 800, "max_big_hits": 2000}),
+])
+def test_paired_sam_identical_to_reference_cli(paired_workload, opts, params, pparams):
+    w = paired_workload
+    d = w["dir"]
+    tag = "_".join(o.strip("-") for o in opts) or "default"
+    out_ref = os.path.join(d, "pref_%s.sam" % tag)
+    out_gpu = os.path.join(d, "pgpu_%s.sam" % tag)
+    _run([REF_CLI, "paired", w["index"], w["fq"][0], w["fq"][1], "-o", out_ref, "-t", "8"] + opts)
+    log = _run([GPU_CLI, "paired", w["index"], w["fq"][0], w["fq"][1], "-o", out_gpu, "-t", "4"] + opts)
+    h_ref, r_ref = _sam(out_ref)
+    h_gpu, r_gpu = _sam(out_gpu)
+    assert h_ref == h_gpu
+    assert len(r_ref) == len(r_gpu) and len(r_ref) >= 2 * 6000, log[-2000:]
+    if r_ref != r_gpu:
+        def by_name(records):
+            m = {}
+            for line in records:
+                m.setdefault(line.split("\t")[0], []).append(line)
+            return m
+        m_ref, m_gpu = by_name(r_ref), by_name(r_gpu)
+        assert m_ref.keys() == m_gpu.keys()
+        differing = [n for n in m_ref if m_ref[n] != m_gpu[n]]
+        # pairs the device flags as depending on the reference aligner's history (DESIGN.md "Reference nondeterminism")
+        from snap_amd.aligner import ChimericPairedEndAligner
+        a = ChimericPairedEndAligner(GenomeIndex.load_from_directory(w["index"]), abi.default_params(max_read_len=400, **params),
+                                     abi.default_paired_params(**pparams))
+        prim, _ = a.align(w["pairs"]["bases"], w["pairs"]["quals"], w["pairs"]["offsets"])
+        a.close()
+        unstable = {"pair%d" % i for i in np.nonzero(prim["reserved"] != 0)[0]}
+        bad = [n for n in differing if n not in unstable]
+        assert not bad, "first differing pair %s:\nref: %sgpu: %s" % (bad[0], "".join(m_ref[bad[0]]), "".join(m_gpu[bad[0]]))
+        assert len(differing) <= 2 + len(m_ref) // 50
