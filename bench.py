@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline (0 = auto, ~10-30 s)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
+    ap.add_argument("--workload", choices=["single", "paired"], default="single",
+                    help="single = configs[1] (the metric's config); paired = configs[2], 2x150 bp FR pairs through the paired-end path")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: anything libraries print to fd 1 (RCCL prints a version
@@ -94,8 +96,13 @@ def main():
     import torch
     from snap_amd import abi, synth
     from snap_amd import dist as sd
-    from snap_amd.aligner import BaseAligner
+    from snap_amd.aligner import BaseAligner, ChimericPairedEndAligner
     from snap_amd.index import GenomeIndex
+    paired = args.workload == "paired"
+    pparams = abi.default_paired_params()
+
+    def make_aligner(index, params, **kw):
+        return ChimericPairedEndAligner(index, params, pparams, **kw) if paired else BaseAligner(index, params, **kw)
 
     rank, world, local_rank = sd.env_rank_world()
     if world != args.gpus:
@@ -119,27 +126,32 @@ def main():
     t0 = time.time()
     if dist is None:
         index = GenomeIndex.load_from_directory(idx_dir)
-        aligner = BaseAligner(index, params, device=local_rank)
+        aligner = make_aligner(index, params, device=local_rank)
         keep = None
     else:
         index = GenomeIndex.load_from_directory(idx_dir) if rank == 0 else None
         index, blobs = sd.broadcast_index(index, dev)          # RCCL broadcast HBM -> HBM
         keep = blobs
-        aligner = BaseAligner(index, params, device=local_rank,
-                              device_index_ptrs=(blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr()))
+        aligner = make_aligner(index, params, device=local_rank,
+                               device_index_ptrs=(blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr()))
     index_bytes = sum(int(x) for x in getattr(index, "_device_sizes", (index.hash_blob.size, index.overflow.size, index.genome_padded.size)))
     log("rank %d: index resident in HBM after %.1fs" % (rank, time.time() - t0))
 
-    reads = synth.make_reads(args.seed + 1000 + rank, genome, args.reads, args.read_len)   # 1% sub, .05% ins/del, 50% RC, Q20-40
-    n = args.reads
+    if paired:      # FR pairs, insert N(400, 50^2) clipped to [150, 1000]; same per-base error model
+        reads = synth.make_pairs(args.seed + 1000 + rank, genome, args.reads // 2, args.read_len)
+    else:
+        reads = synth.make_reads(args.seed + 1000 + rank, genome, args.reads, args.read_len)   # 1% sub, .05% ins/del, 50% RC, Q20-40
+    n = args.reads                      # reads per GPU per step (a pair is two reads)
+    n_units = n // 2 if paired else n   # alignment problems per launch
+    res_dtype = abi.PAIRED_RESULT_DTYPE if paired else abi.RESULT_DTYPE
     d_bases = torch.from_numpy(reads["bases"].reshape(-1)).to(dev)
     d_quals = torch.from_numpy(reads["quals"].reshape(-1)).to(dev)
     d_offs = torch.from_numpy(reads["offsets"].astype(np.int64)).to(dev)
-    d_prim = torch.zeros(n * abi.RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+    d_prim = torch.zeros(n_units * res_dtype.itemsize, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
 
     def step():
-        aligner.align_device(n, d_bases.data_ptr(), d_quals.data_ptr(), d_offs.data_ptr(), d_prim.data_ptr())
+        aligner.align_device(n_units, d_bases.data_ptr(), d_quals.data_ptr(), d_offs.data_ptr(), d_prim.data_ptr())
 
     for _ in range(args.warmup):
         step()
@@ -162,7 +174,7 @@ def main():
 
     counters = aligner.counters()
     kernel_ms, launches = aligner.kernel_time()
-    prim = np.frombuffer(d_prim.cpu().numpy().tobytes(), dtype=abi.RESULT_DTYPE)
+    prim = np.frombuffer(d_prim.cpu().numpy().tobytes(), dtype=res_dtype)
     if rank != 0:
         return
 
@@ -174,15 +186,18 @@ def main():
     avg_ms = kernel_ms / max(1, launches)
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     out = {
-        "metric": "aligned reads/sec (whole node), 150 bp single-end vs synthetic %d Mb genome (GRCh38 unavailable), seed=20, maxDist=%d" % (args.genome_mb, args.max_k),
+        "metric": "aligned reads/sec (whole node), 150 bp %s vs synthetic %d Mb genome (GRCh38 unavailable), seed=20, maxDist=%d"
+                  % ("paired-end (2x150 FR pairs)" if paired else "single-end", args.genome_mb, args.max_k),
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u8 bases / int32 DP / f64 match probability", "data": "synthetic",
-        "config": {"workload": "configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
-                              % (n, args.read_len, args.max_k, args.seed_len, args.genome_mb),
+        "config": {"workload": ("configs[2]: %d pairs of 2 x %d bp (FR, insert N(400,50^2)) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
+                                % (n_units, args.read_len, args.max_k, args.seed_len, args.genome_mb)) if paired else
+                               ("configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
+                                % (n, args.read_len, args.max_k, args.seed_len, args.genome_mb)),
                    "reads_per_gpu": n, "read_len": args.read_len, "index_bytes_hbm": index_bytes,
                    "parallelism": "reads sharded over %d GPU(s), index replicated%s" % (world, " by RCCL broadcast" if world > 1 else "")},
-        "roofline": {"kernel": "k_align_single", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"kernel": "k_align_paired" if paired else "k_align_single", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "bytes_breakdown": parts, "avg_launch_ms": avg_ms,
                      "per_read": {"hash_lookups": per_launch["n_hash_table_lookups"] / n, "hash_slots": per_launch["n_hash_slots_probed"] / n,
@@ -192,13 +207,14 @@ def main():
     }
     tot = max(1, counters.get("cycles_total", 0))
     out["roofline"]["wave_cycle_breakdown"] = {k[7:]: counters[k] / tot for k in
-                                              ("cycles_lookup", "cycles_hits", "cycles_lv", "cycles_ag") if k in counters}
+                                              ("cycles_lookup", "cycles_hits", "cycles_lv", "cycles_ag") + (("cycles_single_fallback",) if paired else ())
+                                              if k in counters}   # paired: lookup = Phase 1, hits = Phase 2 (set intersection), lv/ag = paired scoring
     out["roofline"]["wave_cycles_per_read"] = counters.get("cycles_total", 0) / max(1, counters["n_reads"])
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:
             t = json.load(open(pmc))
-            if t.get("reads_per_launch") == n and t.get("genome_mb") == args.genome_mb:
+            if t.get("reads_per_launch") == n and t.get("genome_mb") == args.genome_mb and t.get("workload", "single") == args.workload:
                 out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
         except Exception:
             pass
@@ -207,21 +223,32 @@ def main():
         from oracle import ref                                       # cpu_baseline leg only
         cores = os.cpu_count() or 1
         ri = ref.RefIndex(idx_dir)
-        sample = args.cpu_sample or min(n, 50_000)
-        pr, _, _, secs = ri.align_single(params, reads["bases"][:sample], reads["quals"][:sample],
-                                         reads["offsets"][:sample + 1], threads=cores)
+        L = args.read_len
+
+        def run_ref(k):             # k = alignment problems (reads, or pairs)
+            if paired:
+                return ri.align_paired(params, pparams, reads["bases"][:2 * k], reads["quals"][:2 * k], reads["offsets"][:2 * k + 1], threads=cores, stage=0)
+            return ri.align_single(params, reads["bases"][:k], reads["quals"][:k], reads["offsets"][:k + 1], threads=cores)
+        sample = args.cpu_sample or min(n_units, 50_000)
+        pr, _, _, secs = run_ref(sample)
         if not args.cpu_sample:                                      # scale the sample to ~15 s of CPU work
             rate = sample / secs
-            sample = int(min(n, max(sample, rate * 15)))
-            pr, _, _, secs = ri.align_single(params, reads["bases"][:sample], reads["quals"][:sample],
-                                             reads["offsets"][:sample + 1], threads=cores)
-        out["cpu_baseline"] = {"value": sample / secs, "unit": "reads/s", "cores": cores, "kind": "reference",
-                               "sample": "first %d reads of the same batch, BaseAligner::AlignRead via oracle/_ref (SNAP 2.0.5 built -O3), %d threads, align phase only" % (sample, cores)}
+            sample = int(min(n_units, max(sample, rate * 15)))
+            pr, _, _, secs = run_ref(sample)
+        per = 2 if paired else 1
+        out["cpu_baseline"] = {"value": per * sample / secs, "unit": "reads/s", "cores": cores, "kind": "reference",
+                               "sample": "first %d %s of the same batch, %s via oracle/_ref (SNAP 2.0.5 built -O3), %d threads, align phase only"
+                                         % (sample, "pairs" if paired else "reads", "ChimericPairedEndAligner::align" if paired else "BaseAligner::AlignRead", cores)}
         # the baseline's results double as a parity spot check of the timed GPU output
-        from tests.util import compare_results
         flagged = prim["reserved"][:sample] != 0
-        problems = compare_results(pr, prim[:sample], exclude=flagged)
-        out["parity_check"] = {"reads": sample, "mismatching_fields": problems, "reference_unstable_flagged": int(flagged.sum())}
+        if paired:
+            from tests.pairs_util import compare_paired
+            bad = compare_paired(pr, prim[:sample], verbose=0, exclude=flagged)
+            out["parity_check"] = {"pairs": sample, "mismatching_pairs": int(bad.sum()), "reference_unstable_flagged": int(flagged.sum())}
+        else:
+            from tests.util import compare_results
+            problems = compare_results(pr, prim[:sample], exclude=flagged)
+            out["parity_check"] = {"reads": sample, "mismatching_fields": problems, "reference_unstable_flagged": int(flagged.sum())}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     aligner.close()
     del keep

@@ -118,7 +118,7 @@ struct PESet {                         // ScoreSet, .h:614-700
     int32_t  best_pair_score, best_pair_ag;
 };
 
-struct PECounters { uint64_t lv, ag, lookups; uint64_t cyc_lookup, cyc_intersect, cyc_lv, cyc_ag, cyc_single, cyc_total; };   // cycles: PL::clock()
+struct PECounters { uint64_t lv, ag, lookups, hits, overflow_lists, lv_ref_bytes; uint64_t cyc_lookup, cyc_intersect, cyc_lv, cyc_ag, cyc_single, cyc_total; };   // cycles: PL::clock()
 
 struct PEShared {                      // cold wave-uniform state (LDS on the device)
     PESet all, non_alt;
@@ -445,6 +445,7 @@ struct PairedCore {
             mp1 = 1.0;                               // (unused)
         }
         sh->cnt.cyc_lv += PL::clock() - t_lv;
+        sh->cnt.lv_ref_bytes += (uint64_t)(rl - tail) + (uint64_t)(2 * (limit < 0 ? 0 : limit)) + (uint64_t)seed_offset;
         o.offset = off;
         if (off != 0 && !pl.substring_ok(loc + off, glen)) score2 = -1;                               // :3364-3375
         if (score1 != -1 && score2 != -1) {
@@ -664,6 +665,8 @@ struct PairedCore {
                     const int offset = d == 0 ? next_seed : read_len[w] - sl - next_seed;
                     if (h[d].n_hits < (int64_t)cfg.max_big_hits) {
                         total_hits[w][d] += h[d].n_hits;
+                        sh->cnt.hits += (uint64_t)h[d].n_hits;                 // the hit lists this pair is entitled to read (roofline byte model)
+                        if (h[d].n_hits > 1) sh->cnt.overflow_lists++;
                         hs_record(2 * w + d, (uint32_t)offset, h[d], begins[d]);
                         begins[d] = false;
                     } else {

@@ -39,6 +39,8 @@ struct PairedArgs {
     uint32_t *work_counter;
     unsigned long long *counters;      // snapgpu_counters layout
     uint32_t kmax_lv;
+    // second pass over the pairs whose candidate buffers overflowed in the first (see launch_paired): work item i is pair remap[i]
+    const uint32_t *remap, *n_remap;
 };
 
 
@@ -47,4 +49,5 @@ void snapgpu_launch_paired_3(const PairedArgs *a, uint32_t blocks, size_t lds_by
 void snapgpu_launch_paired_4(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_6(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, hipStream_t s);
 }

@@ -280,16 +280,18 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     core.mate[1] = (PEMate *)(sc + a.off_mate1);
     core.anchor = (PEAnchor *)(sc + a.off_anchor);
     core.agc = (snapgpu_paired_result *)(sc + a.off_agc);
-    core.sh->cnt = PECounters{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    core.sh->cnt = PECounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint8_t *prd = my + PLd.rd, *pql = my + PLd.ql;
     const uint32_t RL = a.scfg.RL;
     uint64_t n_done = 0;
 
+    const uint32_t n_total = a.remap ? first_u32(*a.n_remap) : a.n_pairs;
     while (true) {
         uint32_t i = 0;
         if (lane == 0) i = atomicAdd(a.work_counter, 1u);
         i = first_u32(i);
-        if (i >= a.n_pairs) break;
+        if (i >= n_total) break;
+        if (a.remap) i = first_u32(a.remap[i]);
         for (int r = 0; r < 2; r++) {
             const uint64_t b = first_u64(a.offsets[2 * i + r]), e = first_u64(a.offsets[2 * i + r + 1]);
             const int len = (int)(e - b);
@@ -326,14 +328,14 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         n_done++;
     }
     if (lane == 0) {
-        atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
+        if (!a.remap) atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
         atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
-        atomicAdd(&a.counters[3], (unsigned long long)al.cnt.hits);
-        atomicAdd(&a.counters[4], (unsigned long long)al.cnt.overflow_lists);
+        atomicAdd(&a.counters[3], (unsigned long long)(al.cnt.hits + core.sh->cnt.hits));
+        atomicAdd(&a.counters[4], (unsigned long long)(al.cnt.overflow_lists + core.sh->cnt.overflow_lists));
         atomicAdd(&a.counters[5], (unsigned long long)(al.cnt.lv + core.sh->cnt.lv));
         atomicAdd(&a.counters[6], (unsigned long long)(al.cnt.ag + core.sh->cnt.ag));
-        atomicAdd(&a.counters[7], (unsigned long long)al.cnt.lv_ref_bytes);
+        atomicAdd(&a.counters[7], (unsigned long long)(al.cnt.lv_ref_bytes + core.sh->cnt.lv_ref_bytes));
         // phase cycles of the paired path: lookup = Phase 1, hits = Phase 2 (intersection), lv / ag = paired scoring only,
         // reserved[0] = the single-end fallback as a whole
         atomicAdd(&a.counters[8], (unsigned long long)core.sh->cnt.cyc_lookup);
@@ -343,4 +345,12 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         atomicAdd(&a.counters[12], (unsigned long long)core.sh->cnt.cyc_total);
         atomicAdd(&a.counters[13], (unsigned long long)core.sh->cnt.cyc_single);
     }
+}
+
+// pairs flagged SNAPGPU_PAIR_POOL_OVERFLOW by the first pass -> list for the second pass
+template <int UNUSED>
+__global__ void k_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (primary[i].flags & SNAPGPU_PAIR_POOL_OVERFLOW)) list[atomicAdd(count, 1u)] = i;
 }

@@ -15,3 +15,10 @@ extern "C" void PE_CAT(snapgpu_launch_paired_, PAIRED_AGC)(const PairedArgs *a, 
 {
     hipLaunchKernelGGL(k_align_paired<PAIRED_AGC>, dim3(blocks), dim3(256), lds_bytes, s, *a);
 }
+
+#if PAIRED_AGC == 3
+extern "C" void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_collect_flagged<0>, dim3((n + 255) / 256), dim3(256), 0, s, primary, n, list, count);
+}
+#endif

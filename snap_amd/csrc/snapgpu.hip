@@ -237,8 +237,10 @@ struct snapgpu_ctx {
     bool paired = false;
     snapgpu_paired_params pparams{};
     PairedArgs pargs{};               // everything but the per-call pointers
-    uint8_t *d_pscratch = nullptr;
-    uint32_t p_wave_slots = 0, p_lds_per_wave = 0;
+    PairedArgs pargs_big{};           // second pass: a few waves with 32x larger candidate buffers
+    uint8_t *d_pscratch = nullptr, *d_pscratch_big = nullptr;
+    uint32_t *d_flag_list = nullptr; size_t flag_list_cap = 0;
+    uint32_t p_wave_slots = 0, p_big_slots = 0, p_lds_per_wave = 0;
     int p_ag_variant = 0;
     std::string err;
 };
@@ -366,6 +368,8 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_pscratch) (void)hipFree(ctx->d_pscratch);
+    if (ctx->d_pscratch_big) (void)hipFree(ctx->d_pscratch_big);
+    if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     for (int i = 0; i < 5; i++) if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
@@ -859,6 +863,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         return fail(ctx, SNAPGPU_E_UNSUPPORTED, "the index has ALT contigs: the paired-end path would need ALT liftover "
                     "(IntersectingPairedEndAligner.cpp:2890-2968), which this build does not implement; use an index without ALT contigs or alt_awareness = 0");
     if (ctx->d_pscratch) { (void)hipFree(ctx->d_pscratch); ctx->d_pscratch = nullptr; }
+    if (ctx->d_pscratch_big) { (void)hipFree(ctx->d_pscratch_big); ctx->d_pscratch_big = nullptr; }
     ctx->paired = false;
     ctx->pparams = *pp;
     PairedArgs &a = ctx->pargs;
@@ -920,15 +925,26 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     }
 
     // per-wave scratch slab: [single-end: heads | buckets | AG traceback] [single AG candidates] [cand] [mate0] [mate1] [anchor] [paired AG candidates]
-    size_t ag_bytes = sc.use_ag ? ag_scratch_bytes(sc.RL) : 0;
-    size_t off = ((size_t)sc.ht_size * 2 + (size_t)sc.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
-    a.off_single_agc = off; off += ((size_t)a.single_agc_cap * sizeof(snapgpu_single_result) + 255) & ~(size_t)255;
-    a.off_cand = off;   off += ((size_t)c.pool_size * sizeof(PECand) + 255) & ~(size_t)255;
-    a.off_mate0 = off;  off += ((size_t)(c.pool_size / 2 + 1) * sizeof(PEMate) + 255) & ~(size_t)255;
-    a.off_mate1 = off;  off += ((size_t)(c.pool_size / 2 + 1) * sizeof(PEMate) + 255) & ~(size_t)255;
-    a.off_anchor = off; off += ((size_t)c.pool_size * sizeof(PEAnchor) + 255) & ~(size_t)255;
-    a.off_agc = off;    off += ((size_t)(c.ag_cand_cap + 1) * sizeof(snapgpu_paired_result) + 255) & ~(size_t)255;
-    a.stride = off;
+    auto lay_out = [&](PairedArgs &x) {
+        size_t ag_bytes = sc.use_ag ? ag_scratch_bytes(sc.RL) : 0;
+        size_t off = ((size_t)sc.ht_size * 2 + (size_t)sc.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
+        x.off_single_agc = off; off += ((size_t)x.single_agc_cap * sizeof(snapgpu_single_result) + 255) & ~(size_t)255;
+        x.off_cand = off;   off += ((size_t)x.pcfg.pool_size * sizeof(PECand) + 255) & ~(size_t)255;
+        x.off_mate0 = off;  off += ((size_t)(x.pcfg.pool_size / 2 + 1) * sizeof(PEMate) + 255) & ~(size_t)255;
+        x.off_mate1 = off;  off += ((size_t)(x.pcfg.pool_size / 2 + 1) * sizeof(PEMate) + 255) & ~(size_t)255;
+        x.off_anchor = off; off += ((size_t)x.pcfg.pool_size * sizeof(PEAnchor) + 255) & ~(size_t)255;
+        x.off_agc = off;    off += ((size_t)(x.pcfg.ag_cand_cap + 1) * sizeof(snapgpu_paired_result) + 255) & ~(size_t)255;
+        x.stride = off;
+    };
+    lay_out(a);
+    // The reference doubles its affine-gap candidate buffers when they overflow and aligns the pair again
+    // (PairedAligner.cpp:727-779).  Here: pairs that overflow the first pass's buffers are redone by a second launch of a
+    // few waves whose buffers are 32x larger; only what still does not fit is reported.
+    PairedArgs &big = ctx->pargs_big;
+    big = a;
+    big.pcfg.ag_cand_cap = a.pcfg.ag_cand_cap * 32;
+    big.single_agc_cap = a.single_agc_cap * 32;
+    lay_out(big);
 
     LdsLayout SL = lds_layout(sc.RL, sc.num_weight_lists, sc.kmax, sc.use_ag);
     PairedLds PL = paired_lds_layout(SL.total, sc.RL, c.max_seeds);
@@ -950,6 +966,12 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         HIPCHK(ctx, hipMemsetAsync(ctx->d_pscratch + (size_t)w * a.stride, 0, (size_t)sc.ht_size * 2, ctx->stream), SNAPGPU_E_NODEVICE);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
     a.scratch = ctx->d_pscratch;
+    ctx->p_big_slots = 256;               // one wave per flagged pair in all but the worst batches (each such pair is seconds of serial work)
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_pscratch_big, (size_t)ctx->p_big_slots * big.stride), SNAPGPU_E_NOMEM);
+    for (uint32_t w = 0; w < ctx->p_big_slots; w++)
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_pscratch_big + (size_t)w * big.stride, 0, (size_t)sc.ht_size * 2, ctx->stream), SNAPGPU_E_NODEVICE);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
+    big.scratch = ctx->d_pscratch_big;
     ctx->paired = true;
     return SNAPGPU_OK;
 }
@@ -962,15 +984,35 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
     a.n_pairs = n; a.primary = (snapgpu_paired_result *)d_primary; a.first_alt = (snapgpu_paired_result *)d_first_alt;
     a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    if (ctx->flag_list_cap < n) {
+        if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
+        ctx->d_flag_list = nullptr; ctx->flag_list_cap = 0;
+        size_t cap = (size_t)n + n / 4 + 1024;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_flag_list, cap * 4), SNAPGPU_E_NOMEM);
+        ctx->flag_list_cap = cap;
+    }
     uint32_t blocks = ctx->p_wave_slots / 4;
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     const size_t lds = (size_t)4 * ctx->p_lds_per_wave;
-    switch (ctx->p_ag_variant) {           // one translation unit per affine-gap variant (paired_k.hip), compiled in parallel
-    case 3:  snapgpu_launch_paired_3(&a, blocks, lds, s); break;
-    case 4:  snapgpu_launch_paired_4(&a, blocks, lds, s); break;
-    case 6:  snapgpu_launch_paired_6(&a, blocks, lds, s); break;
-    default: snapgpu_launch_paired_0(&a, blocks, lds, s); break;
+    auto launch = [&](const PairedArgs &x, uint32_t nblocks) {
+        switch (ctx->p_ag_variant) {           // one translation unit per affine-gap variant (paired_k.hip), compiled in parallel
+        case 3:  snapgpu_launch_paired_3(&x, nblocks, lds, s); break;
+        case 4:  snapgpu_launch_paired_4(&x, nblocks, lds, s); break;
+        case 6:  snapgpu_launch_paired_6(&x, nblocks, lds, s); break;
+        default: snapgpu_launch_paired_0(&x, nblocks, lds, s); break;
+        }
+    };
+    launch(a, blocks);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    {   // second pass over the pairs the first flagged (usually none: the launch then ends at once)
+        uint32_t *d_count = ctx->d_work + 2, *d_work2 = ctx->d_work + 1;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 1, 0, 8, s), SNAPGPU_E_LAUNCH);
+        snapgpu_launch_collect_flagged((const snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count, s);
+        PairedArgs b = ctx->pargs_big;
+        b.bases = a.bases; b.quals = a.quals; b.offsets = a.offsets; b.n_pairs = n; b.primary = a.primary; b.first_alt = a.first_alt;
+        b.work_counter = d_work2; b.counters = a.counters; b.remap = ctx->d_flag_list; b.n_remap = d_count;
+        launch(b, ctx->p_big_slots / 4);
     }
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
