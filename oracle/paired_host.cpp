@@ -109,6 +109,12 @@ struct HostPL {
         o.text_offset = to; o.pattern_offset = po; o.n_edits = ne; o.mp = mp; o.stale = stale;
         return o;
     }
+    void sort_candidates(const snapgpu_paired_result *c, uint32_t n, uint32_t *order) const {     // stable counting sort by pair score
+        std::vector<uint32_t> base(1024, 0);
+        for (uint32_t j = 0; j < n; j++) base[(c[j].reserved & 511) + 1]++;
+        for (int k = 1; k < 1024; k++) base[k] += base[k - 1];
+        for (uint32_t j = 0; j < n; j++) order[base[c[j].reserved & 511]++] = j;
+    }
     void align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt) {
         snapref_chimeric_single_align(single, max_k, hamming ? 1 : 0, (const char *)read_b[r], (const char *)read_q[r], (uint32_t)read_l[r], &res, &alt);
     }
@@ -160,11 +166,12 @@ extern "C" int pairedhost_align(const snapgpu_index_view *ix, void *ref_index, c
     std::vector<PEMate> mate0(cfg.pool_size / 2 + 1), mate1(cfg.pool_size / 2 + 1);
     std::vector<PEAnchor> anchor(cfg.pool_size);
     std::vector<snapgpu_paired_result> agc(cfg.ag_cand_cap + 1);
+    std::vector<uint32_t> agc_order(cfg.ag_cand_cap + 1);
     PEShared sh;
     memset(&sh, 0, sizeof(sh));
     core.lk = &lk[0]; core.exhausted = &exhausted[0]; core.miss = &miss[0]; core.hs = &hs[0]; core.list_head = &list_head[0];
     core.seed_used = &seed_used[0]; core.sh = &sh; core.cand = &cand[0]; core.mate[0] = &mate0[0]; core.mate[1] = &mate1[0];
-    core.anchor = &anchor[0]; core.agc = &agc[0];
+    core.anchor = &anchor[0]; core.agc = &agc[0]; core.agc_order = &agc_order[0];
 
     const int PAD = 160;
     std::vector<uint8_t> buf[2][2], qbuf[2][2];

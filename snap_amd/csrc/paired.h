@@ -150,6 +150,7 @@ struct PairedCore {
     PEMate   *mate[2];                 // [cfg.pool_size / 2] each
     PEAnchor *anchor;                  // [cfg.pool_size]
     snapgpu_paired_result *agc;        // [cfg.ag_cand_cap]   lvCandidatesForAffineGap
+    uint32_t *agc_order;               // [cfg.ag_cand_cap]   the order Phase 4 visits them in
     // per-pair scalars
     uint32_t n_cand, n_mate[2], n_anchor;
     uint32_t n_agc;
@@ -1042,16 +1043,11 @@ struct PairedCore {
 
         if (n_agc > 0 && (!skip[0] || !skip[1])) {
             limit = (cfg.max_k < best_pair_score ? cfg.max_k : best_pair_score) + cfg.extra_depth;
-            // qsort(compareByScore) is glibc's stable merge sort here: visit candidates by (pair score, insertion index)
-            int last_score = -0x7fffffff, last_idx = -1;
-            for (uint32_t done_n = 0; done_n < n_agc; done_n++) {
-                int bi = -1, bs = 0x7fffffff;
-                for (uint32_t j = 0; j < n_agc; j++) {
-                    int s = (int)ld(agc[j].reserved);
-                    if ((s > last_score || (s == last_score && (int)j > last_idx)) && s < bs) { bs = s; bi = (int)j; }
-                }
-                last_score = bs; last_idx = bi;
-                snapgpu_paired_result *e = &agc[bi];
+            // qsort(compareByScore) is glibc's stable merge sort here: visit candidates by (pair score, insertion index).
+            // pl.sort_candidates writes that order (a stable counting sort on the key kept in `reserved`) to agc_order.
+            pl.sort_candidates(agc, n_agc, agc_order);
+            for (uint32_t t = 0; t < n_agc; t++) {
+                snapgpu_paired_result *e = &agc[ld(agc_order[t])];
                 phase4_candidate(e, limit, best_pair_score, skip, g_off);
             }
         }

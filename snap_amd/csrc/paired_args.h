@@ -29,7 +29,7 @@ struct PairedArgs {
     const DevTables *tab;
     uint8_t *scratch;                  // n_wave_slots * stride
     uint64_t stride;
-    uint64_t off_single_agc, off_cand, off_mate0, off_mate1, off_anchor, off_agc;   // offsets inside a wave's slab (single-end scratch first)
+    uint64_t off_single_agc, off_cand, off_mate0, off_mate1, off_anchor, off_agc, off_agc_order;   // offsets inside a wave's slab (single-end scratch first)
     uint32_t single_agc_cap;
     const uint8_t *bases, *quals;
     const uint64_t *offsets;           // [2n+1]

@@ -212,6 +212,47 @@ struct DevPL {
         o.n_edits = i32(a.n_edits); o.mp = f64(a.match_probability); o.stale = i32(a.stale_reads);
         return o;
     }
+    // Stable counting sort of the Phase-4 candidates by pair score (the key kept in `reserved`, < 512): histogram and
+    // running bases in LDS (the LV triangle is idle here), entries scattered 64 at a time in index order.
+    __device__ __forceinline__ void sort_candidates(const snapgpu_paired_result *c, uint32_t n, uint32_t *order) {
+        const int lane = lane_id();
+        uint32_t *base = (uint32_t *)al->lv_tri;                     // >= (kmax+1)^2 * 2 bytes >= 2 KB for kmax >= 31; 512 counters needed
+        uint32_t *hist = base;
+        for (int k = lane; k < 512; k += WAVE) hist[k] = 0;
+        WAVE_SYNC();
+        for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+            uint32_t j = j0 + (uint32_t)lane;
+            if (j < n) atomicAdd(&hist[c[j].reserved & 511u], 1u);
+        }
+        WAVE_SYNC();
+        // exclusive prefix over 512 counters: 8 per lane, then a wave scan
+        uint32_t loc[8], sum = 0;
+        for (int t = 0; t < 8; t++) { loc[t] = hist[lane * 8 + t]; sum += loc[t]; }
+        uint32_t incl = sum;
+        for (int o = 1; o < WAVE; o <<= 1) { uint32_t v = (uint32_t)__shfl_up((int)incl, o); if (lane >= o) incl += v; }
+        uint32_t run = incl - sum;
+        WAVE_SYNC();
+        for (int t = 0; t < 8; t++) { hist[lane * 8 + t] = run; run += loc[t]; }
+        WAVE_SYNC();
+        for (uint32_t j0 = 0; j0 < n; j0 += WAVE) {
+            uint32_t j = j0 + (uint32_t)lane;
+            const bool act = j < n;
+            const uint32_t key = act ? (c[j].reserved & 511u) : 0xffffffffu;
+            uint64_t todo = __ballot(act);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
+                const uint64_t same = __ballot(act && key == k);
+                const uint32_t b = base[k];
+                if (act && key == k) order[b + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = j;
+                WAVE_SYNC();
+                if (lane == 0) base[k] = b + (uint32_t)__popcll(same);
+                WAVE_SYNC();
+                todo &= ~same;
+            }
+        }
+        WAVE_SYNC();
+    }
     // BaseAligner::AlignRead with setMaxK(max_k) (ChimericPairedEndAligner.cpp:278-310); hamming: the retry of :330-360
     // (AlignRead(..., useHamming) followed by BaseAligner::alignAffineGap on the candidates it collected).
     __device__ __forceinline__ void align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt) {
@@ -280,6 +321,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     core.mate[1] = (PEMate *)(sc + a.off_mate1);
     core.anchor = (PEAnchor *)(sc + a.off_anchor);
     core.agc = (snapgpu_paired_result *)(sc + a.off_agc);
+    core.agc_order = (uint32_t *)(sc + a.off_agc_order);
     core.sh->cnt = PECounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint8_t *prd = my + PLd.rd, *pql = my + PLd.ql;
     const uint32_t RL = a.scfg.RL;

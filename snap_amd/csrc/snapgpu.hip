@@ -885,6 +885,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     // LV limits: computeScoreLimit <= min(126, extraSearchDepth + maxK + maxKForIndels - 1) (IntersectingPairedEndAligner.cpp:3975-3988)
     uint32_t kmax_lv = p.max_k + p.extra_search_depth + (pp->max_k_for_indels ? pp->max_k_for_indels - 1 : 0);
     if (kmax_lv > 126) kmax_lv = 126;
+    if (kmax_lv < 31) kmax_lv = 31;                              // the LV triangle doubles as 2 KB of counters for the Phase-4 counting sort
     sc.kmax = kmax_lv;
     a.kmax_lv = kmax_lv;
     a.scfg = sc;
@@ -934,6 +935,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         x.off_mate1 = off;  off += ((size_t)(x.pcfg.pool_size / 2 + 1) * sizeof(PEMate) + 255) & ~(size_t)255;
         x.off_anchor = off; off += ((size_t)x.pcfg.pool_size * sizeof(PEAnchor) + 255) & ~(size_t)255;
         x.off_agc = off;    off += ((size_t)(x.pcfg.ag_cand_cap + 1) * sizeof(snapgpu_paired_result) + 255) & ~(size_t)255;
+        x.off_agc_order = off; off += ((size_t)(x.pcfg.ag_cand_cap + 1) * 4 + 255) & ~(size_t)255;
         x.stride = off;
     };
     lay_out(a);
