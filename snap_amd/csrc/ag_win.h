@@ -31,8 +31,12 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     const int match = prm.match_reward, sub = -prm.sub_penalty;
     const int gap_open = prm.gap_open + prm.gap_extend, gap_ext = prm.gap_extend;
     const int tot = num_seg * seg_len;
-    unsigned long long *lds_bits = (unsigned long long *)lds_rows;
-    uint16_t *row_base = (uint16_t *)(lds_rows + 8);          // [text_len] window base of each row
+    // LDS tables (the H/E rows of the LDS formulation are not used here): window base of each row for the traceback, and
+    // what the row loop would otherwise recompute or reload -- first-row H per position, base codes of pattern and text
+    uint16_t *row_base = (uint16_t *)(lds_rows + 8);          // [text_len]
+    int16_t  *fr16 = (int16_t *)(row_base + ((text_len + 7) & ~7));        // [tot]   first_row(p)
+    uint8_t  *pcode = (uint8_t *)(fr16 + ((tot + 7) & ~7));                // [tot]   base_value(P(p)), 5 beyond the pattern
+    uint8_t  *tcode = pcode + ((tot + 15) & ~15);                          // [text_len] base_value(T(i))
 
     int end_bonus;
     if (!is_rc) end_bonus = dir == -1 ? prm.five_bonus : prm.three_bonus;
@@ -59,11 +63,22 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         int x = score_init - gap_open - pi * gap_ext;
         return x > 0 ? x : 0;
     };
-    auto pat_base = [&](int p) -> int { return p < pattern_len ? (int)base_value(P(p)) : 5; };
+    for (int p0 = 0; p0 < tot; p0 += WAVE) {
+        const int p = p0 + lane;
+        if (p < tot) {
+            fr16[p] = (int16_t)first_row(p);
+            pcode[p] = (uint8_t)(p < pattern_len ? base_value(P(p)) : 5u);
+        }
+    }
+    for (int i0 = 0; i0 < text_len; i0 += WAVE) {
+        const int i = i0 + lane;
+        if (i < text_len) tcode[i] = (uint8_t)base_value(T(i));
+    }
+    WAVE_SYNC();
 
     int wbase = 0, jbase = 0;
-    int Hp = first_row(lane), Hm = 0, E = 0;
-    int pbv = pat_base(lane);
+    int Hp = lane < tot ? (int)fr16[lane] : 0, Hm = 0, E = 0;
+    int pbv = lane < tot ? (int)pcode[lane] : 5;
     int left_h = 0;
     // H / H-1 of the global-alignment cell (position pattern_len-1) once it has left the window: the
     // reference keeps reading its stale value on the row(s) after the band has passed the pattern end
@@ -72,7 +87,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int best_global = -1, best_global_text = -1, best_local = -1, best_local_text = -1, best_local_pat = -1;
 
     for (int i = 0; i < text_len; i++) {
-        const int tb = (int)base_value(T(i));
+        const int tb = (int)first_u32(tcode[i]);
         const int band_beg = i - w > 0 ? i - w : 0;
         const int band_end = i + w < pattern_len - 1 ? i + w : pattern_len - 1;
         if ((jbase + 1) * seg_len <= band_beg) {                // slide the window by one segment
@@ -86,11 +101,11 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             wbase += seg_len; jbase++;
             if (lane >= WAVE - seg_len) {                       // positions entering the window
                 const int p = wbase + lane;
-                const int fr = first_row(p);
+                const int fr = p < tot ? (int)fr16[p] : 0;
                 nHp = (i & 1) ? 0 : fr;                         // Hptr is H on even rows, Hminus1 on odd rows
                 nHm = (i & 1) ? fr : 0;
                 nE = 0;
-                npb = pat_base(p);
+                npb = p < tot ? (int)pcode[p] : 5;
             }
             Hp = nHp; Hm = nHm; E = nE; pbv = npb;
         }
@@ -156,14 +171,14 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 int f2 = f > gap_ext ? f - gap_ext : 0;
                 const bool cont = inseg && (f2 > t2);
                 const unsigned long long any_cont = __ballot(cont);
+                // the reference stops the round at the first vector in which no SSE lane continues (:560); a window
+                // segment has at most 4 vectors, so that is at most 4 ballots
                 int jstar = 0;
                 if (any_cont) {
-                    if (lane == 0) *lds_bits = 0ull;
-                    WAVE_SYNC();
-                    if (cont) atomicOr(lds_bits, 1ull << k);
-                    WAVE_SYNC();
-                    unsigned long long bits = first_u64(*lds_bits);
-                    jstar = (~bits == 0ull) ? 64 : (__ffsll((long long)~bits) - 1);
+                    jstar = 64;
+                    for (int kk = 0; kk < 4; kk++) {
+                        if (kk < nk && !__ballot(cont && k == kk)) { jstar = kk; break; }
+                    }
                 }
                 const bool round_complete = jstar >= nk;
                 const int jlim = round_complete ? nk - 1 : jstar;
