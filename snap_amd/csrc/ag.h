@@ -216,12 +216,12 @@ static __device__ __forceinline__ AGResult ag_compute(
                             if (f2 > tmp) { add |= 32; any = true; }
                             f = f2;
                         }
-                        uint64_t chg = __ballot(add != 0);
+                        uint64_t chg = BALLOT(add != 0);
                         if (chg) {
                             if (add != 0) bt_row[cell] = (uint8_t)(bt_row[cell] | add);
                             WAVE_SYNC();
                         }
-                        if (!__ballot(any)) { converged = true; break; }
+                        if (!BALLOT(any)) { converged = true; break; }
                     }
                 }
                 WAVE_SYNC();

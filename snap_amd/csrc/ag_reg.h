@@ -226,7 +226,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
                         int f2 = f > gap_ext ? f - gap_ext : 0;
                         fj[c] = f;
                         cont[c] = ins[c] && (f2 > t2);
-                        any_cont |= __ballot(cont[c]);
+                        any_cont |= BALLOT(cont[c]);
                     }
                 }
                 int jstar = 0;
@@ -277,7 +277,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
 #pragma unroll
             for (int c = AGC - 1; c >= 0; c--) {
                 if (c >= row_c_lo && c <= row_c_hi && off < 0) {
-                    unsigned long long mk = __ballot(did[c] && Hm[c] == max_row);
+                    unsigned long long mk = BALLOT(did[c] && Hm[c] == max_row);
                     if (mk) off = c * 64 + 63 - __clzll((long long)mk);
                 }
             }

@@ -31,10 +31,10 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     const int match = prm.match_reward, sub = -prm.sub_penalty;
     const int gap_open = prm.gap_open + prm.gap_extend, gap_ext = prm.gap_extend;
     const int tot = num_seg * seg_len;
-    // LDS tables (the H/E rows of the LDS formulation are not used here): window base of each row for the traceback, and
-    // what the row loop would otherwise recompute or reload -- first-row H per position, base codes of pattern and text
-    uint16_t *row_base = (uint16_t *)(lds_rows + 8);          // [text_len]
-    int16_t  *fr16 = (int16_t *)(row_base + ((text_len + 7) & ~7));        // [tot]   first_row(p)
+    // LDS tables (the H/E rows of the LDS formulation are not used here): what the row loop would otherwise recompute or
+    // reload -- first-row H per position, base codes of pattern and text.  (The window base of row i needs no table: the
+    // window slides whenever the band start enters the next segment, so it is seg_len * (max(i - w, 0) / seg_len).)
+    int16_t  *fr16 = (int16_t *)(lds_rows + 8);                             // [tot]   first_row(p)
     uint8_t  *pcode = (uint8_t *)(fr16 + ((tot + 7) & ~7));                // [tot]   base_value(P(p)), 5 beyond the pattern
     uint8_t  *tcode = pcode + ((tot + 15) & ~15);                          // [text_len] base_value(T(i))
 
@@ -114,7 +114,6 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         const int seg_end_sel = ((jbase + 1) * seg_len <= band_end) ? 1 : 0;
         int h_init0 = score_init;
         if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
-        if (lane == 0) row_base[i] = (uint16_t)wbase;
         int mxv = 0, X0 = 0, fin = 0, btr = 0;
         bool did = false;
         const int prof = pbv == 5 ? -32768 : ((tb > 3 || pbv > 3) ? -1 : (tb == pbv ? match : sub));
@@ -136,64 +135,68 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             int e2 = e - gap_ext;
             int tmp = m - gap_open; if (tmp < 0) tmp = 0;
             if (e2 > tmp) bt |= 4;
-            const int tag = AG_BIG * (s * 8 + l);
-            int g = inseg ? tmp + p * gap_ext + tag : AG_NEG;
-            int inc = ag_prefix_max(g);
-            int pm = ag_shr1(AG_NEG, inc);
+            // first-pass F along the (at most 4) vectors of a stripe: F(k) = max_{j<k} (tmp_j - (k-1-j)*ext), a prefix max of
+            // tmp_j + p_j*ext over the lanes to the left that belong to the same stripe -- two shift-and-max steps
+            int g = inseg ? tmp + p * gap_ext : AG_NEG;
+            { int a = ag_shr1(AG_NEG, g); if (k >= 1) g = a > g ? a : g; }
+            { int b = ag_shr1(AG_NEG, ag_shr1(AG_NEG, g)); if (k >= 2) g = b > g ? b : g; }
+            int pm = ag_shr1(AG_NEG, g);
             const int fin_cell = l == 0 ? fin : 0;
             int fk = fin_cell - k * gap_ext;
-            if (k >= 1) { int a = pm - tag - (p - 1) * gap_ext; fk = a > fk ? a : fk; }
-            int endv = 0;
-            if (inseg) {
-                if (fk > hp) { bt |= 2; hp = fk; }
-                Hm = hp;
-                E = e2 > tmp ? e2 : tmp;
-                mxv = hp > mxv ? hp : mxv;
-                int f2 = fk - gap_ext;
-                if (f2 > tmp) bt |= 32;
-                endv = f2 > tmp ? f2 : tmp;
-                btr = bt; did = true;
-            }
+            if (k >= 1) { int a = pm - (p - 1) * gap_ext; fk = a > fk ? a : fk; }
+            // (selects, not branches: a divergent `if` costs more scalar exec-mask bookkeeping than the arithmetic it skips)
+            bt |= fk > hp ? 2 : 0;
+            hp = fk > hp ? fk : hp;
+            const int f2p = fk - gap_ext;
+            bt |= f2p > tmp ? 32 : 0;
+            const int endv = inseg ? (f2p > tmp ? f2p : tmp) : 0;
+            Hm = inseg ? hp : Hm;
+            E = inseg ? (e2 > tmp ? e2 : tmp) : E;
+            mxv = inseg && hp > mxv ? hp : mxv;
+            btr = inseg ? bt : btr;
+            did = did || inseg;
 
-            // lazy F (:534-569): 7 rounds, F of stripe 7 accumulates into X (the next segment's incoming F)
-            const int pe7_lane = s * seg_len + 7 * num_vec + nk - 1;
+            // lazy F (:534-569): up to 7 rounds; round r brings each stripe the F that left the stripe r+1 to its left in the
+            // first pass, decayed by r whole stripes (the reference's per-round  vF = max(vF - nk*ext, 0)  composes to that),
+            // so every round is one gather from the stripe-end lanes.  F of stripe 7 accumulates into X (the next segment's
+            // incoming F).
+            const int src_end = s * seg_len + nk - 1;             // lane of stripe 0's last vector
+            const int endv0 = endv;
             for (int r = 0; r < 7; r++) {
-                int f7 = __builtin_amdgcn_readlane(endv, pe7_lane);
-                if (f7 > X0) X0 = f7;
-                int v = isend ? endv + AG_BIG * (l + 1) : AG_NEG;
-                int inc2 = ag_prefix_max(v);
-                int pm2 = ag_shr1(AG_NEG, inc2);
-                int f_in = pm2 - AG_BIG * l;
-                if (l == 0 || f_in < 0 || f_in >= AG_BIG) f_in = 0;
+                const int decay = r * nk * gap_ext;
+                {
+                    int f7 = __builtin_amdgcn_readlane(endv0, src_end + (7 - r) * num_vec) - decay;
+                    if (f7 > X0) X0 = f7;
+                }
+                const int ls = l - 1 - r;
+                int f_in = __shfl(endv0, src_end + ls * num_vec) - decay;
+                if (ls < 0 || f_in < 0) f_in = 0;
                 int f = f_in - k * gap_ext; if (f < 0) f = 0;
                 int hn = Hm > f ? Hm : f;
                 int t2 = hn > gap_open ? hn - gap_open : 0;
                 int f2 = f > gap_ext ? f - gap_ext : 0;
                 const bool cont = inseg && (f2 > t2);
-                const unsigned long long any_cont = __ballot(cont);
-                // the reference stops the round at the first vector in which no SSE lane continues (:560); a window
-                // segment has at most 4 vectors, so that is at most 4 ballots
-                int jstar = 0;
-                if (any_cont) {
-                    jstar = 64;
-                    for (int kk = 0; kk < 4; kk++) {
-                        if (kk < nk && !__ballot(cont && k == kk)) { jstar = kk; break; }
-                    }
-                }
+                // The reference stops the round at the first vector in which no SSE lane continues (:560).  Lanes of one
+                // vector index sit num_vec apart, so OR-folding the continuation mask over the 8 stripes leaves "some lane
+                // of vector kk continues" in bit kk -- scalar work only.
+                unsigned long long cm = BALLOT(cont) >> (s * seg_len);
+                cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
+                const uint32_t full = (1u << nk) - 1u;
+                const uint32_t low = (uint32_t)cm & full;
+                const int jstar = low == full ? 64 : (int)__builtin_ctz(~low);
                 const bool round_complete = jstar >= nk;
                 const int jlim = round_complete ? nk - 1 : jstar;
-                if (inseg && k <= jlim) {
-                    if (f > Hm) { btr |= 2; Hm = f; }
-                    mxv = Hm > mxv ? Hm : mxv;
-                    if (cont) btr |= 32;
-                }
+                const bool upd = inseg && k <= jlim;
+                btr |= (upd && f > Hm) ? 2 : 0;
+                Hm = (upd && f > Hm) ? f : Hm;
+                mxv = (upd && Hm > mxv) ? Hm : mxv;
+                btr |= (upd && cont) ? 32 : 0;
                 if (!round_complete) break;
-                int dec = f_in - nk * gap_ext; endv = dec > 0 ? dec : 0;
             }
             fin = X0;
         }
 
-        if (did) bt_scratch[(size_t)i * 64 + lane] = (uint8_t)btr;
+        bt_scratch[(size_t)i * 64 + lane] = (uint8_t)btr;       // (lanes outside the band write 0; the traceback never reads them)
         const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
         if (band_end == pattern_len - 1) {
             int gscore = pattern_len - 1 >= wbase ? __builtin_amdgcn_readlane(Hm, pattern_len - 1 >= wbase ? pattern_len - 1 - wbase : 0) : gl_m;
@@ -201,7 +204,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         }
         if (max_row == 0) break;
         if (max_row > best_local) {
-            unsigned long long mk = __ballot(did && Hm == max_row);
+            unsigned long long mk = BALLOT(did && Hm == max_row);
             best_local_pat = mk ? wbase + 63 - __clzll((long long)mk) : -1;
             best_local = max_row; best_local_text = i;
         }
@@ -252,7 +255,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 int bb = rt - w > 0 ? rt - w : 0, be = rt + w < pattern_len - 1 ? rt + w : pattern_len - 1;
                 int cj = ct / seg_len, ck = (ct - cj * seg_len) % num_vec;
                 computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
-                wb = (int)row_base[rt];
+                wb = (bb / seg_len) * seg_len;
             }
             int cell = computed ? (int)bt_scratch[(size_t)rt * 64 + (ct - wb)] : 0;
             int pbyte = ok ? (int)P(ct) : 0, tbyte = ok ? (int)T(rt) : 0, qbyte = ok ? (int)Q(ct) : 0;

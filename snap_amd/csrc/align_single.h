@@ -788,7 +788,7 @@ struct Aligner {
                 rd[1][len - 1 - i] = rc_base(b);
                 ql[1][len - 1 - i] = q;
             }
-            n_count += (uint32_t)__popcll(__ballot(i < len && b == 'N'));
+            n_count += (uint32_t)__popcll(BALLOT(i < len && b == 'N'));
         }
         for (uint32_t i = lane; i < (cfg.RL + 31) / 32; i += WAVE) seed_used[i] = 0;
         WAVE_SYNC();
@@ -963,7 +963,7 @@ struct Aligner {
         uint32_t n_count = 0;
         for (int i0 = 0; i0 < read_len; i0 += WAVE) {
             int i = i0 + lane;
-            n_count += (uint32_t)__popcll(__ballot(i < read_len && rd[0][i] == 'N'));
+            n_count += (uint32_t)__popcll(BALLOT(i < read_len && rd[0][i] == 'N'));
         }
         if (n_count > max_k) return;
         const int best_score = (int)first_u32((uint32_t)primary.score);

@@ -60,6 +60,9 @@ struct DevTables {
     uint32_t wrapped_seed[33];       // GetWrappedNextSeedToTest(seedLen, wrapCount), SeedSequencer.cpp:36-109
 };
 
+// wave ballot as one compare into an SGPR pair (HIP's BALLOT() materialises the predicate in a VGPR first)
+#define BALLOT(pred) ((unsigned long long)__builtin_amdgcn_ballot_w64((bool)(pred)))
+
 static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 
 static __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src_lane = 0) {

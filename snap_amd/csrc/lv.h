@@ -69,7 +69,7 @@ static __device__ __forceinline__ LVResult lv_compute(
     while (true) {
         int i = run0 + lane;
         bool same = (i < end0) && (P(i) == T(i));
-        uint64_t stopm = __ballot(!same);
+        uint64_t stopm = BALLOT(!same);
         if (stopm) { run0 += __ffsll((long long)stopm) - 1; break; }
         run0 += WAVE;
     }
@@ -117,8 +117,8 @@ static __device__ __forceinline__ LVResult lv_compute(
                 reached = (best == pattern_len);
                 row[r] = lv_pack(best, act);
             }
-            uint64_t mx = __ballot(reached && act == LV_ACT_X);
-            uint64_t ma = __ballot(reached);
+            uint64_t mx = BALLOT(reached && act == LV_ACT_X);
+            uint64_t ma = BALLOT(reached);
             if (mx && x_rank == (1 << 30)) x_rank = r0 + __ffsll((long long)mx) - 1;
             if (ma && any_rank == (1 << 30)) any_rank = r0 + __ffsll((long long)ma) - 1;
         }

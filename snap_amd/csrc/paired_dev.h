@@ -57,7 +57,7 @@ struct DevPL {
             m = t > m ? t : m;
         }
         m = (int64_t)first_u64((uint64_t)m);
-        uint64_t who = __ballot(ok && v == m);
+        uint64_t who = BALLOT(ok && v == m);
         *best = m;
         return who ? __ffsll((long long)who) - 1 : -1;
     }
@@ -116,7 +116,7 @@ struct DevPL {
         if (!act) lo = 0;
         bool found = false;
         int64_t v = 0;
-        while (__ballot(lo <= hi && !found)) {
+        while (BALLOT(lo <= hi && !found)) {
             if (lo <= hi && !found) {
                 int64_t probe = (lo + hi) / 2;
                 int64_t ph = (int64_t)lk_hit(l, probe);
@@ -153,7 +153,7 @@ struct DevPL {
         const uint32_t wd = l->which_disjoint;
         uint32_t best = 0;
         for (int d = 0; d <= cd; d++) {
-            uint32_t m = ld(exhausted[d]) + (uint32_t)__popcll(__ballot(act && !close && wd == (uint32_t)d));
+            uint32_t m = ld(exhausted[d]) + (uint32_t)__popcll(BALLOT(act && !close && wd == (uint32_t)d));
             if (m > best) best = m;
         }
         return best;
@@ -176,7 +176,7 @@ struct DevPL {
         const int lane = lane_id();
         for (int i0 = 0; i0 < len; i0 += WAVE) {
             int i = i0 + lane;
-            n += (uint32_t)__popcll(__ballot(i < len && b[i] == 'N'));
+            n += (uint32_t)__popcll(BALLOT(i < len && b[i] == 'N'));
         }
         return n;
     }
@@ -238,11 +238,11 @@ struct DevPL {
             uint32_t j = j0 + (uint32_t)lane;
             const bool act = j < n;
             const uint32_t key = act ? (c[j].reserved & 511u) : 0xffffffffu;
-            uint64_t todo = __ballot(act);
+            uint64_t todo = BALLOT(act);
             while (todo) {
                 const int leader = __ffsll((long long)todo) - 1;
                 const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, leader);
-                const uint64_t same = __ballot(act && key == k);
+                const uint64_t same = BALLOT(act && key == k);
                 const uint32_t b = base[k];
                 if (act && key == k) order[b + (uint32_t)__popcll(same & ((1ull << lane) - 1ull))] = j;
                 WAVE_SYNC();

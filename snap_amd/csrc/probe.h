@@ -42,9 +42,9 @@ static __device__ __forceinline__ SeedBits pack_seed(const uint8_t *text, uint32
     uint32_t enc = 0;
     if ((uint32_t)lane < seed_len) enc = base_value(text[lane]);
     uint64_t in_seed = seed_len >= 64 ? ~0ull : ((1ull << seed_len) - 1);
-    uint64_t b0 = __ballot(enc & 1) & in_seed;
-    uint64_t b1 = __ballot(enc & 2) & in_seed;
-    uint64_t bad = __ballot(enc > 3) & in_seed;
+    uint64_t b0 = BALLOT(enc & 1) & in_seed;
+    uint64_t b1 = BALLOT(enc & 2) & in_seed;
+    uint64_t bad = BALLOT(enc > 3) & in_seed;
     SeedBits s;
     s.valid = (bad == 0);
     // reverse complement: base i (complemented) lands at bits 2i+1..2i
@@ -146,7 +146,7 @@ static __device__ __forceinline__ void lookup_seed(const DevIndex &ix, const See
             stop = (n == 0) ? (key_eq && !invalid) : (key_eq || invalid);
             hit = stop && !invalid;
         }
-        uint64_t stop_mask = __ballot(stop);
+        uint64_t stop_mask = BALLOT(stop);
         // each half looks at its own 32 bits
         uint32_t my_mask = half ? (uint32_t)(stop_mask >> 32) : (uint32_t)stop_mask;
         // A half that is already finished (or inactive) must not block the other one: handled by
