@@ -78,7 +78,13 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     const int tot = num_seg * seg_len;                  // positions that exist in the striped layout
     const int nch = (tot + 63) >> 6;
     const int row_stride = nch * 64;
-    unsigned long long *lds_bits = (unsigned long long *)lds_rows;
+    // LDS scratch of the lazy-F rounds: F leaving each of the 8 stripes in the first pass, and one "some lane of vector k
+    // continues" tag per vector (tags instead of a bitmap: no clearing, no atomics)
+    int *lds_end = (int *)lds_rows + 2;                  // [8]
+    uint32_t *lds_flag = (uint32_t *)lds_rows + 16;      // [num_vec <= 1023]
+    uint32_t flag_tag = 0;
+    for (int kz = lane_id(); kz < num_vec; kz += WAVE) lds_flag[kz] = 0;     // tags of an earlier call must not look current
+    WAVE_SYNC();
 
     int end_bonus;
     if (!is_rc) end_bonus = dir == -1 ? prm.five_bonus : prm.three_bonus;
@@ -191,35 +197,30 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
             }
 
             // ---------------- lazy F (:1080-1112 full: 8 rounds; :534-569 banded: 7 rounds + segment carry X)
-            const int pe7 = seg_start + 7 * num_vec + nk - 1;            // stripe 7's last computed cell
-            const int pe7_c = pe7 >> 6, pe7_l = pe7 & 63;
+            // Round r brings each stripe the F that left the stripe r+1 to its left in the first pass, decayed by r whole
+            // stripes (the reference's per-round  vF = max(vF - nk*ext, 0)  composes to exactly that), so the eight
+            // stripe-end values go to LDS once and every round is a table read.
+#pragma unroll
+            for (int c = 0; c < AGC; c++)
+                if (c >= c_lo && c <= c_hi && isend[c]) lds_end[pos[c].l()] = endv[c];
+            WAVE_SYNC();
             const int rounds = BANDED ? 7 : 8;
             for (int r = 0; r < rounds; r++) {
+                const int decay = r * nk * gap_ext;
                 if (BANDED) {
-                    int f7 = 0;
-#pragma unroll
-                    for (int c = 0; c < AGC; c++) if (c == pe7_c) f7 = __builtin_amdgcn_readlane(endv[c], pe7_l);
+                    int f7 = (int)first_u32((uint32_t)lds_end[7 - r]) - decay;
                     if (f7 > X0) X0 = f7;
                 }
-                int fj[AGC], fs[AGC]; bool cont[AGC];
+                int fj[AGC]; bool cont[AGC];
                 unsigned long long any_cont = 0;
-                int carry2 = AG_NEG;
 #pragma unroll
                 for (int c = 0; c < AGC; c++) {
-                    fj[c] = 0; fs[c] = 0; cont[c] = false;
+                    fj[c] = 0; cont[c] = false;
                     if (c >= c_lo && c <= c_hi) {
                         const AGPos ps = pos[c];
-                        const int k = ps.k(), l = ps.l();
-                        // F entering this lane's stripe = F that left the previous stripe of the segment
-                        int v = isend[c] ? endv[c] + AG_BIG * (l + 1) : AG_NEG;
-                        int inc = ag_prefix_max(v);
-                        int exc = ag_shr1(carry2, inc);
-                        int pm = exc > carry2 ? exc : carry2;
-                        int last_inc = __builtin_amdgcn_readlane(inc, 63);
-                        carry2 = last_inc > carry2 ? last_inc : carry2;
-                        int f_in = pm - AG_BIG * l;
-                        if (l == 0 || f_in < 0 || f_in >= AG_BIG) f_in = 0;
-                        fs[c] = f_in;
+                        const int k = ps.k(), ls = ps.l() - 1 - r;
+                        int f_in = lds_end[ls < 0 ? 0 : ls] - decay;
+                        if (ls < 0 || f_in < 0) f_in = 0;
                         int f = f_in - k * gap_ext; if (f < 0) f = 0;
                         int hn = Hm[c] > f ? Hm[c] : f;
                         int t2 = hn > gap_open ? hn - gap_open : 0;
@@ -229,29 +230,31 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
                         any_cont |= BALLOT(cont[c]);
                     }
                 }
+                // the reference stops the round at the first vector in which no SSE lane continues (:560 / :1104)
                 int jstar = 0;
                 if (any_cont) {
-                    if (lane == 0) *lds_bits = 0ull;
-                    WAVE_SYNC();
+                    flag_tag++;
 #pragma unroll
                     for (int c = 0; c < AGC; c++)
-                        if (c >= c_lo && c <= c_hi && cont[c]) atomicOr(lds_bits, 1ull << pos[c].k());
+                        if (c >= c_lo && c <= c_hi && cont[c]) lds_flag[pos[c].k()] = flag_tag;
                     WAVE_SYNC();
-                    unsigned long long bits = first_u64(*lds_bits);
-                    jstar = (~bits == 0ull) ? 64 : (__ffsll((long long)~bits) - 1);
+                    jstar = 64 * 16;
+                    for (int k0 = 0; k0 < nk; k0 += WAVE) {
+                        const int kq = k0 + lane;
+                        unsigned long long none = BALLOT(kq < nk && lds_flag[kq] != flag_tag);
+                        if (none) { jstar = k0 + __ffsll((long long)none) - 1; break; }
+                    }
                 }
                 const bool round_complete = jstar >= nk;        // never converged in this round
                 const int jlim = round_complete ? nk - 1 : jstar;
 #pragma unroll
                 for (int c = 0; c < AGC; c++) {
                     if (c >= c_lo && c <= c_hi) {
-                        if (ins[c] && pos[c].k() <= jlim) {
-                            if (fj[c] > Hm[c]) { btr[c] |= 2; Hm[c] = fj[c]; }
-                            mxv = Hm[c] > mxv ? Hm[c] : mxv;
-                            if (cont[c]) btr[c] |= 32;
-                        }
-                        // F of this stripe after walking all nk vectors (only consumed if the round completed)
-                        int dec = fs[c] - nk * gap_ext; endv[c] = dec > 0 ? dec : 0;
+                        const bool upd = ins[c] && pos[c].k() <= jlim;
+                        btr[c] |= (upd && fj[c] > Hm[c]) ? 2 : 0;
+                        Hm[c] = (upd && fj[c] > Hm[c]) ? fj[c] : Hm[c];
+                        mxv = (upd && Hm[c] > mxv) ? Hm[c] : mxv;
+                        btr[c] |= (upd && cont[c]) ? 32 : 0;
                     }
                 }
                 if (!round_complete) break;
