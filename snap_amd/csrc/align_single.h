@@ -597,7 +597,7 @@ struct Aligner {
                             const int tlen = half == 0 ? text_len : seed_offset + SNAPGPU_MAX_K;
                             const int lim = half == 0 ? limit_e : limit_e - score1;
                             ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
-                            LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab);
+                            LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab, cfg.RL);
                             // results are wave-uniform; say so, so they (and everything derived from them) live in SGPRs
                             r.score = (int)first_u32((uint32_t)r.score); r.net_indel = (int)first_u32((uint32_t)r.net_indel);
                             r.match_probability = first_f64(r.match_probability);

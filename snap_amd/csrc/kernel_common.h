@@ -29,7 +29,7 @@ static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uin
     L.seed_used = o; o += (((RL + 31) / 32) * 4 + 15) & ~15u;
     L.wl_next = o; o += (num_weight_lists * 2 + 15) & ~15u;
     L.wl_prev = o; o += (num_weight_lists * 2 + 15) & ~15u;
-    L.lv = o; o += (lv_lds_bytes(kmax) + 15) & ~15u;
+    L.lv = o; o += (lv_lds_bytes(kmax, RL) + 15) & ~15u;
     L.ag = o; if (use_ag) o += (ag_lds_bytes(RL) + 15) & ~15u;
     L.shared = o; o += ((uint32_t)sizeof(WaveShared) + 15) & ~15u;
     L.total = o;

@@ -38,11 +38,16 @@ struct LVResult {
 static __device__ __forceinline__ int lv_rank(int d) { return d > 0 ? 2 * d - 1 : -2 * d; }
 static __device__ __forceinline__ int lv_diag(int r) { return (r & 1) ? (r + 1) >> 1 : -(r >> 1); }
 
-// LDS needed: (kmax+1)^2 uint16 for L/A plus (kmax+1) uint32 for the backtrace.
-static __host__ __device__ __forceinline__ uint32_t lv_lds_bytes(uint32_t kmax) {
+// LDS needed: (kmax+1)^2 uint16 for L/A, (kmax+1) uint32 for the backtrace, and one mismatch bitmap of pcap bits per
+// diagonal (2*kmax+1 of them), pcap = the longest pattern.
+static __host__ __device__ __forceinline__ uint32_t lv_mask_words(uint32_t pcap) { return (pcap + 63) >> 6; }
+static __host__ __device__ __forceinline__ uint32_t lv_tri_bytes(uint32_t kmax) {
     uint32_t tri = (kmax + 1) * (kmax + 1) * 2;
     tri = (tri + 3) & ~3u;
-    return tri + (kmax + 1) * 4;
+    return (tri + (kmax + 1) * 4 + 7) & ~7u;
+}
+static __host__ __device__ __forceinline__ uint32_t lv_lds_bytes(uint32_t kmax, uint32_t pcap) {
+    return lv_tri_bytes(kmax) + (2 * kmax + 1) * lv_mask_words(pcap) * 8;
 }
 
 // cell = ((L + 2) << 2) | action ; unset cells read as L = -2
@@ -51,7 +56,7 @@ static __device__ __forceinline__ uint16_t lv_pack(int L, int act) { return (uin
 template <typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ LVResult lv_compute(
     const PSeq &P, const QSeq &Q, int pattern_len, const TSeq &T, int text_len, int k,
-    uint16_t *lds_tri, uint32_t kmax, const DevTables *tab)
+    uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap)
 {
     const int lane = lane_id();
     LVResult res;
@@ -62,6 +67,23 @@ static __device__ __forceinline__ LVResult lv_compute(
     res.match_probability = 1.0;
 
     uint32_t *bt = (uint32_t *)((uint8_t *)lds_tri + (((kmax + 1) * (kmax + 1) * 2 + 3) & ~3u));
+    // Mismatch bitmaps, one per diagonal (row = visiting rank), built as a level first needs the diagonal: bit i is set when
+    // pattern[i] != text[d+i] or i is past the end of the comparison, so "extend a run from x" is a count-trailing-zeros
+    // instead of a byte loop (the reference's countPerfectMatch compares 8 bytes at a time for the same reason, :377-407).
+    unsigned long long *mask = (unsigned long long *)((uint8_t *)lds_tri + lv_tri_bytes(kmax));
+    const int nw = (int)lv_mask_words(pcap);
+    const int nwu = (pattern_len + 63) >> 6;                // words that can hold a compared position
+    auto build_mask = [&](int r) {
+        const int d = lv_diag(r);
+        const int tl = text_len - d;
+        const int end = pattern_len < tl ? pattern_len : tl;
+        for (int w = 0; w < nwu; w++) {
+            const int i = w * 64 + lane;
+            const bool mm = i >= end || P(i) != T(d + i);
+            const unsigned long long m = BALLOT(mm);
+            if (lane == 0) mask[r * nw + w] = m;
+        }
+    };
 
     // ---- e = 0: the perfect-match prefix, compared 64 bytes per step by the whole wave
     const int end0 = pattern_len < text_len ? pattern_len : text_len;
@@ -91,6 +113,10 @@ static __device__ __forceinline__ LVResult lv_compute(
         const uint16_t *prev_row = lds_tri + (e - 1) * (e - 1);
         uint16_t *row = lds_tri + e * e;
         int x_rank = 1 << 30, any_rank = 1 << 30;
+        if (e == 1) build_mask(0);
+        build_mask(2 * e - 1);
+        build_mask(2 * e);
+        WAVE_SYNC();
         for (int r0 = 0; r0 <= 2 * e; r0 += WAVE) {
             int r = r0 + lane;
             bool live = r <= 2 * e;
@@ -105,15 +131,23 @@ static __device__ __forceinline__ LVResult lv_compute(
                 int Lr = (adr <= e - 1) ? ((int)(prev_row[lv_rank(dr)] >> 2) - 2) : -2;
                 int tl = text_len - d;
                 const int end = pattern_len < tl ? pattern_len : tl;
-
-                int best = Lc + 1;                           // substitution ("up")
-                if (best >= 0) { while (best < end && P(best) == T(d + best)) best++; }
+                const unsigned long long *m = mask + r * nw;
+                // position of the first mismatch at or after x on this diagonal (x itself when it cannot start a run)
+                auto extend = [&](int x) -> int {
+                    if (x < 0 || x >= end) return x;
+                    int w = x >> 6;
+                    unsigned long long v = m[w] >> (x & 63);
+                    if (v) return x + (int)__builtin_ctzll(v);
+                    for (w++; w < nwu; w++) { v = m[w]; if (v) return w * 64 + (int)__builtin_ctzll(v); }
+                    return end;
+                };
+                int best = extend(Lc + 1);                   // substitution ("up")
+                // a run started at or before `best` cannot end beyond it, so the other two moves only need extending
+                // when they start beyond it -- which is also exactly when the reference's `> best` tests can succeed
                 int left = Ll;                               // deletion
-                if (left >= 0) { while (left < end && P(left) == T(d + left)) left++; }
-                if (left > best) { best = left; act = LV_ACT_D; }
+                if (left > best) { left = extend(left); best = left; act = LV_ACT_D; }
                 int right = Lr + 1;                          // insertion
-                if (right >= 0) { while (right < end && P(right) == T(d + right)) right++; }
-                if (right > best) { best = right; act = LV_ACT_I; }
+                if (right > best) { right = extend(right); best = right; act = LV_ACT_I; }
                 reached = (best == pattern_len);
                 row[r] = lv_pack(best, act);
             }

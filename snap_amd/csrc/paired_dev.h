@@ -196,7 +196,7 @@ struct DevPL {
 
     __device__ __forceinline__ LVOut lv(int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int k) {
         ByteSeq Ps{P, st}, Qs{Q, st}, Ts{T, st};
-        LVResult r = lv_compute(Ps, Qs, plen, Ts, tlen, k, al->lv_tri, kmax_lv, tab);
+        LVResult r = lv_compute(Ps, Qs, plen, Ts, tlen, k, al->lv_tri, kmax_lv, tab, al->cfg.RL);
         LVOut o;
         o.score = i32(r.score); o.mp = f64(r.match_probability); o.net_indel = i32(r.net_indel);
         o.total_indels = i32(r.total_indels); o.text_span = i32(r.text_span);

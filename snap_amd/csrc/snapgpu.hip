@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void k_lookup_seeds(DevIndex ix, uint32_t n, c
 }
 
 struct LVBatchArgs {
-    int dir; uint32_t n; uint32_t kmax;
+    int dir; uint32_t n; uint32_t kmax; uint32_t pcap;
     const uint8_t *texts; const uint32_t *text_off; const int32_t *text_len;
     const uint8_t *patterns; const uint8_t *quals; const uint32_t *pat_off; const int32_t *pat_len; const int32_t *k;
     int32_t *score; double *prob; int32_t *net_indel; int32_t *total_indels; int32_t *text_span;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void k_lv_batch(LVBatchArgs a)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id();
     const int wave_in_block = (int)(threadIdx.x >> 6);
-    const uint32_t per_wave = (lv_lds_bytes(a.kmax) + 15) & ~15u;
+    const uint32_t per_wave = (lv_lds_bytes(a.kmax, a.pcap) + 15) & ~15u;
     uint16_t *tri = (uint16_t *)(lds + (size_t)wave_in_block * per_wave);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -149,10 +149,10 @@ __global__ __launch_bounds__(256) void k_lv_batch(LVBatchArgs a)
         LVResult r;
         if (a.dir == 1) {
             ByteSeq P{p, 1}, Q{q, 1}, T{t, 1};
-            r = lv_compute(P, Q, plen, T, tlen, k, tri, a.kmax, a.tab);
+            r = lv_compute(P, Q, plen, T, tlen, k, tri, a.kmax, a.tab, a.pcap);
         } else {
             ByteSeq P{p, 1}, Q{q, 1}, T{t - 1, -1};     // the reference does text-- then walks backwards
-            r = lv_compute(P, Q, plen, T, tlen, k, tri, a.kmax, a.tab);
+            r = lv_compute(P, Q, plen, T, tlen, k, tri, a.kmax, a.tab, a.pcap);
         }
         if (lane == 0) {
             a.score[i] = r.score; a.prob[i] = r.match_probability; a.net_indel[i] = r.net_indel;
@@ -671,12 +671,15 @@ extern "C" int snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
     HIPCHK(ctx, dts.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
     LVBatchArgs a;
     a.dir = dir; a.n = n; a.kmax = kmax;
+    uint32_t pcap = 64;
+    for (uint32_t i = 0; i < n; i++) if ((uint32_t)pat_len[i] > pcap) pcap = (uint32_t)pat_len[i];
+    a.pcap = (pcap + 63) & ~63u;
     a.texts = (const uint8_t *)dt.p; a.text_off = (const uint32_t *)dto.p; a.text_len = (const int32_t *)dtl.p;
     a.patterns = (const uint8_t *)dp.p; a.quals = (const uint8_t *)dq.p; a.pat_off = (const uint32_t *)dpo.p;
     a.pat_len = (const int32_t *)dpl.p; a.k = (const int32_t *)dk.p;
     a.score = (int32_t *)ds.p; a.prob = (double *)dpr.p; a.net_indel = (int32_t *)dni.p;
     a.total_indels = (int32_t *)dti.p; a.text_span = (int32_t *)dts.p; a.tab = ctx->d_tab;
-    uint32_t per_wave = (lv_lds_bytes(kmax) + 15) & ~15u;
+    uint32_t per_wave = (lv_lds_bytes(kmax, a.pcap) + 15) & ~15u;
     uint32_t waves_per_block = 4;
     while (waves_per_block > 1 && (size_t)waves_per_block * per_wave > 64 * 1024) waves_per_block >>= 1;
     if ((size_t)waves_per_block * per_wave > 64 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "k too large for the LDS triangle");
