@@ -162,14 +162,18 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             // incoming F).
             const int src_end = s * seg_len + nk - 1;             // lane of stripe 0's last vector
             const int endv0 = endv;
-            for (int r = 0; r < 7; r++) {
-                const int decay = r * nk * gap_ext;
+            const unsigned long long inseg_mask = BALLOT(inseg);
+            const int decay_step = nk * gap_ext;
+            int decay = 0;
+            int src7 = src_end + 7 * num_vec;                     // stripe 7's last vector
+            int src_addr = (src_end + (l - 1) * num_vec) * 4;     // byte address for ds_bpermute: the stripe to the left
+            int ls = l - 1;
+            for (int r = 0; r < 7; r++, decay += decay_step, src7 -= num_vec, src_addr -= num_vec * 4, ls--) {
                 {
-                    int f7 = __builtin_amdgcn_readlane(endv0, src_end + (7 - r) * num_vec) - decay;
+                    int f7 = __builtin_amdgcn_readlane(endv0, src7) - decay;
                     if (f7 > X0) X0 = f7;
                 }
-                const int ls = l - 1 - r;
-                int f_in = __shfl(endv0, src_end + ls * num_vec) - decay;
+                int f_in = __builtin_amdgcn_ds_bpermute(src_addr, endv0) - decay;
                 if (ls < 0 || f_in < 0) f_in = 0;
                 int f = f_in - k * gap_ext; if (f < 0) f = 0;
                 int hn = Hm > f ? Hm : f;
@@ -179,7 +183,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 // The reference stops the round at the first vector in which no SSE lane continues (:560).  Lanes of one
                 // vector index sit num_vec apart, so OR-folding the continuation mask over the 8 stripes leaves "some lane
                 // of vector kk continues" in bit kk -- scalar work only.
-                unsigned long long cm = BALLOT(cont) >> (s * seg_len);
+                unsigned long long cm = (__builtin_amdgcn_ballot_w64(f2 > t2) & inseg_mask) >> (s * seg_len);
                 cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
                 const uint32_t full = (1u << nk) - 1u;
                 const uint32_t low = (uint32_t)cm & full;

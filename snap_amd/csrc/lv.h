@@ -79,7 +79,7 @@ static __device__ __forceinline__ LVResult lv_compute(
         const int end = pattern_len < tl ? pattern_len : tl;
         for (int w = 0; w < nwu; w++) {
             const int i = w * 64 + lane;
-            const bool mm = i >= end || P(i) != T(d + i);
+            const bool mm = i >= end || d + i < 0 || P(i) != T(d + i);     // (text before its start is never part of a run: L(e,d) >= -d)
             const unsigned long long m = BALLOT(mm);
             if (lane == 0) mask[r * nw + w] = m;
         }
