@@ -68,7 +68,7 @@ def test_results_do_not_depend_on_batch_composition(pindex, golden_pairs):
     a.close()
 
 
-@pytest.mark.parametrize("maxk,L,npairs", [(8, 150, 4000), (20, 250, 1500), (27, 150, 1500)])
+@pytest.mark.parametrize("maxk,L,npairs", [(8, 150, 4000), (20, 250, 1500), (27, 150, 1500), (27, 420, 600)])   # 420 bp: the AGC = 0 kernel variant
 def test_align_paired_vs_reference_live(tmp_path, maxk, L, npairs):
     """C3 / C5-shaped inputs on a repeat-rich 3 Mb genome, diffed against the reference run on the box's host cores."""
     if not ref.available():
@@ -79,9 +79,9 @@ def test_align_paired_vs_reference_live(tmp_path, maxk, L, npairs):
     ref.build_index(d + "/g.fa", d + "/idx", seed_len=20, threads=16)
     rix = ref.RefIndex(d + "/idx")
     gi = GenomeIndex.load_from_directory(d + "/idx")
-    pr = hard_pairs(5 + maxk, contigs, npairs, L, insert_mean=400 if L < 200 else 600)
+    pr = hard_pairs(5 + maxk, contigs, npairs, L, insert_mean=400 if L < 200 else (600 if L < 400 else 900), insert_max=1000 if L < 400 else 1400)
     p = abi.default_params(max_k=maxk, max_read_len=L + 10)
-    pp = abi.default_paired_params()
+    pp = abi.default_paired_params(max_spacing=1000 if L < 400 else 1500)
     rp, ra, rcnt, _ = rix.align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=16, stage=0)
     from snap_amd.aligner import ChimericPairedEndAligner
     a = ChimericPairedEndAligner(gi, p, pp)

@@ -214,9 +214,10 @@ def test_align_read_vs_live_reference_on_fresh_genome(tmp_path):
     ref.build_index(fa, str(tmp_path / "idx"), 20, threads=max(1, os.cpu_count() or 1))
     ix = GenomeIndex.load_from_directory(str(tmp_path / "idx"))
     ri = ref.RefIndex(str(tmp_path / "idx"))
-    for L, kw in ((150, dict(max_k=8)), (250, dict(max_k=20))):
-        p = abi.default_params(max_read_len=256, **kw)
-        rd = synth.make_reads(78 + L, g, 15000, L, sub=0.015, ins=0.002, dele=0.002, n_frac=0.0005)
+    # 150 / 250 bp: register affine-gap variants (3 and 6 chunks); 500 bp: the LDS formulation (AGC = 0)
+    for L, kw, mrl, n in ((150, dict(max_k=8), 256, 15000), (250, dict(max_k=20), 256, 15000), (500, dict(max_k=27), 512, 3000)):
+        p = abi.default_params(max_read_len=mrl, **kw)
+        rd = synth.make_reads(78 + L, g, n, L, sub=0.015, ins=0.002, dele=0.002, n_frac=0.0005)
         pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=os.cpu_count() or 1)
         a = BaseAligner(ix, p)
         pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"])
