@@ -32,7 +32,7 @@ WORKER = textwrap.dedent("""
     t = sd.max_over_ranks(1.0 + rank, dev)
     assert t == float(world)
     d.barrier()
-    print("rank", rank, "ok")
+    os.write(1, ("rank " + str(rank) + " ok" + chr(10)).encode())      # one write(2): the two ranks share a pipe, print() can interleave
 """) % util.ROOT
 
 
