@@ -220,12 +220,13 @@ int snapref_affine_gap(int dir, uint32_t n, const int32_t *agparams /* match,sub
         pp.set(dir, texts + text_off[i], text_len[i], patterns + pat_off[i], quals + pat_off[i], pat_len[i]);
         double prob = 0; int to = 0, po = 0, ne = 0; int s;
         bool clip = use_clip && use_clip[i];
+        bool lift = use_clip && use_clip[i] == 2;          // 2 = clipping optimisations with useAltLiftover
         if (dir == 1) {
-            if (banded[i]) s = fwd->computeScoreBanded(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip);
-            else           s = fwd->computeScore(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip);
+            if (banded[i]) s = fwd->computeScoreBanded(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip, lift);
+            else           s = fwd->computeScore(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip, lift);
         } else {
-            if (banded[i]) s = bwd->computeScoreBanded(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip);
-            else           s = bwd->computeScore(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip);
+            if (banded[i]) s = bwd->computeScoreBanded(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip, lift);
+            else           s = bwd->computeScore(pp.text, text_len[i], pp.pattern, pp.quality, pat_len[i], w[i], score_init[i], is_rc[i] != 0, &to, &po, &ne, &prob, clip, lift);
         }
         ag_score[i] = s; text_offset[i] = to; pattern_offset[i] = po; n_edits[i] = ne; match_probability[i] = prob;
     }

@@ -461,7 +461,7 @@ int oracle_ag(int dir, int banded, const oracle_ag_params *prm, const char *text
                 while (pa < pattern_len && pattern[pa] == tx[(long)ta * dir]) { cnt++; pa++; ta++; }
                 if (cnt >= 3) { *pattern_offset = pa - 1; *text_offset = ta - 1; }
             }
-            if (*pattern_offset == best_local_pat && *text_offset == best_local_text) {
+            if (use_clipping != 2 && *pattern_offset == best_local_pat && *text_offset == best_local_text) {   /* 2 = useAltLiftover, :1212 */
                 pa = *pattern_offset;
                 while (pa != pattern_len - 1 && quality[pa] >= 65 && quality[pa + 1] >= 65) pa++;
                 if (pa == pattern_len - 1) *pattern_offset = pa;

@@ -21,7 +21,7 @@
 template <typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_banded_win(
     int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
-    const TSeq &T, int text_len, int w, int score_init, bool is_rc, bool use_clipping,
+    const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
     int num_vec, int seg_len, int num_seg)
 {
@@ -230,7 +230,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 while (pa < pattern_len && P(pa) == T(ta)) { cnt++; pa++; ta++; }
                 if (cnt >= 3) { pat_off = pa - 1; text_off = ta - 1; }
             }
-            if (pat_off == best_local_pat && text_off == best_local_text) {
+            if (use_clipping != 2 && pat_off == best_local_pat && text_off == best_local_text) {   // 2 = useAltLiftover: no quality-aware step (:1212)
                 pa = pat_off;
                 while (pa != pattern_len - 1 && Q(pa) >= 65 && Q(pa + 1) >= 65) pa++;
                 if (pa == pattern_len - 1) pat_off = pa;
@@ -305,7 +305,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
 template <int AGC, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_dispatch(
     bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
-    const TSeq &T, int text_len, int w, int score_init, bool is_rc, bool use_clipping,
+    const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
 {
     if constexpr (AGC > 0) {

@@ -190,11 +190,11 @@ __global__ __launch_bounds__(64) void k_ag_batch(AGBatchArgs a)
         if (a.dir == 1) {
             ByteSeq P{p, 1}, Q{q, 1}, T{t, 1};
             r = ag_dispatch<AGC>(a.banded[i] != 0, 1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
-                           a.use_clip[i] != 0, rows, bt, a.RL, a.tab);
+                           (int)a.use_clip[i], rows, bt, a.RL, a.tab);
         } else {
             ByteSeq P{p, 1}, Q{q, 1}, T{t - 1, -1};
             r = ag_dispatch<AGC>(a.banded[i] != 0, -1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
-                           a.use_clip[i] != 0, rows, bt, a.RL, a.tab);
+                           (int)a.use_clip[i], rows, bt, a.RL, a.tab);
         }
         if (lane == 0) {
             a.ag_score[i] = r.ag_score; a.text_offset[i] = r.text_offset; a.pattern_offset[i] = r.pattern_offset;

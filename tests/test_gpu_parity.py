@@ -104,6 +104,46 @@ def test_affine_gap_vs_reference_fixture(aligner, golden_primitives):
     assert n_checked > 1000
 
 
+def test_affine_gap_clipping_modes_vs_restatement(aligner):
+    """Seeded fuzz over the three clipping modes (0 off, 1 useClippingOptimizations, 2 = with useAltLiftover), banded/full and
+    window/register forms, both directions, against the C restatement (itself pinned to the reference by tests/test_oracle.py)."""
+    rng = np.random.default_rng(78)
+    texts, pats, quals, ws, sis, rcs, bands, clips = [], [], [], [], [], [], [], []
+    for _ in range(1500):
+        L = int(rng.integers(8, 150))
+        t = bytes(rng.choice(list(b"ACGT"), size=L + 60).astype(np.uint8))
+        p = bytearray(t[:L])
+        for _e in range(int(rng.integers(0, 5))):
+            j = int(rng.integers(0, len(p)))
+            r = rng.random()
+            if r < 0.5: p[j] = b"ACGT"[rng.integers(0, 4)]
+            elif r < 0.75 and len(p) > 1: del p[j]
+            else: p.insert(j, b"ACGT"[rng.integers(0, 4)])
+        if rng.random() < 0.3:
+            k = int(rng.integers(3, max(4, L // 3)))
+            p[len(p) - k:] = bytes(rng.choice(list(b"ACGT"), size=k).astype(np.uint8))
+        p = bytes(p[:L]) or b"A"
+        w = int(rng.integers(1, 30))
+        texts.append(t[:len(p) + w]); pats.append(p)
+        quals.append(bytes(rng.integers(35, 74, size=len(p), dtype=np.uint8)))
+        ws.append(w); sis.append(int(rng.integers(20, 200))); rcs.append(int(rng.integers(0, 2)))
+        bands.append(1 if len(p) >= 3 * (2 * w + 1) else 0); clips.append(int(rng.integers(0, 3)))
+    n_cmp = 0
+    for d in (1, -1):
+        tt = texts if d == 1 else [x[::-1] for x in texts]
+        got = aligner.computeScoreAffine(d, tt, pats, quals, ws, sis, rcs, bands, clips)
+        for i in range(len(tt)):
+            o = util.oracle_ag(d, bands[i], tt[i], pats[i], quals[i], ws[i], sis[i], rcs[i], clips[i])
+            if o["stale_reads"]:
+                continue
+            n_cmp += 1
+            assert got["ag_score"][i] == o["ag_score"], (d, i)
+            if o["ag_score"] != -1:
+                for key in ("text_offset", "pattern_offset", "n_edits", "match_probability"):
+                    assert got[key][i] == o[key], (d, i, key, clips[i])
+    assert n_cmp > 2500
+
+
 @pytest.mark.parametrize("name,kw", [("default_d8", dict(max_k=8)), ("lvonly_d8", dict(max_k=8, use_affine_gap=0)),
                                      ("default_d27", dict(max_k=27)), ("emitalt_d8", dict(max_k=8, emit_alt_alignments=1))])
 def test_align_read_vs_reference_fixture(golden_index, golden_reads, name, kw):

@@ -135,6 +135,46 @@ def test_restatement_vs_reference_fresh_fuzz():
 
 
 @have_ref
+def test_affine_gap_restatement_vs_reference_fresh_fuzz():
+    """All three clipping modes (0 off, 1 useClippingOptimizations, 2 = 1 + useAltLiftover), banded and full, both directions."""
+    rng = np.random.default_rng(77)
+    texts, pats, quals, ws, sis, rcs, bands, clips = [], [], [], [], [], [], [], []
+    for _ in range(1200):
+        L = int(rng.integers(8, 160))
+        t = bytes(rng.choice(list(b"ACGT"), size=L + 60).astype(np.uint8))
+        p = bytearray(t[:L])
+        for _e in range(int(rng.integers(0, 5))):
+            j = int(rng.integers(0, len(p)))
+            r = rng.random()
+            if r < 0.5: p[j] = b"ACGT"[rng.integers(0, 4)]
+            elif r < 0.75 and len(p) > 1: del p[j]
+            else: p.insert(j, b"ACGT"[rng.integers(0, 4)])
+        if rng.random() < 0.3:                              # garbage tail: something to clip
+            k = int(rng.integers(3, max(4, L // 3)))
+            p[len(p) - k:] = bytes(rng.choice(list(b"ACGT"), size=k).astype(np.uint8))
+        p = bytes(p[:L]) or b"A"
+        w = int(rng.integers(1, 30))
+        texts.append(t[:len(p) + w]); pats.append(p)
+        quals.append(bytes(rng.integers(35, 74, size=len(p), dtype=np.uint8)))
+        ws.append(w); sis.append(int(rng.integers(20, 200))); rcs.append(int(rng.integers(0, 2)))
+        bands.append(1 if len(p) >= 3 * (2 * w + 1) else 0); clips.append(int(rng.integers(0, 3)))
+    for d in (1, -1):
+        tt = texts if d == 1 else [x[::-1] for x in texts]
+        r = ref.affine_gap(d, tt, pats, quals, ws, sis, rcs, bands, clips)
+        n_cmp = 0
+        for i in range(len(tt)):
+            got = util.oracle_ag(d, bands[i], tt[i], pats[i], quals[i], ws[i], sis[i], rcs[i], clips[i])
+            if got["stale_reads"]:
+                continue                                    # the reference's answer depends on its object's history here
+            n_cmp += 1
+            assert got["ag_score"] == r["ag_score"][i], (d, i)
+            if got["ag_score"] != -1:
+                for key in ("text_offset", "pattern_offset", "n_edits", "match_probability"):
+                    assert got[key] == r[key][i], (d, i, key, clips[i])
+        assert n_cmp > 1000
+
+
+@have_ref
 def test_reference_reproduces_committed_alignread_fixtures(golden_reads, tmp_path):
     """The fixtures really are what the reference computes (guards against stale goldens)."""
     from snap_amd import abi
