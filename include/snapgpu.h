@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SNAPGPU_ABI_VERSION 1
+#define SNAPGPU_ABI_VERSION 2
 
 /* error codes */
 #define SNAPGPU_OK              0
@@ -97,6 +97,14 @@ typedef struct snapgpu_index_view {
     uint64_t        first_alt_location; /* genomeLocationOfFirstALTContig; >= n_bases if none */
 
     uint32_t on_device;             /* 0: blobs are host memory, copy them; 1: device ptrs */
+
+    /* ALT-to-primary projection of each contig (Genome::Contig::projBeginningLocation / isProjRC / projCigarOps, Genome.h:386-400,
+     * written by an index built with -altLiftoverFile; Genome.cpp:226, 362-392).  Always host pointers; NULL = no projection data
+     * (every contig then projects to location 0 with no CIGAR, which is what such an index file says).                          */
+    const uint64_t *contig_proj_begin;   /* [n_contigs]                                                  */
+    const uint8_t  *contig_proj_rc;      /* [n_contigs]                                                  */
+    const uint32_t *contig_cigar_start;  /* [n_contigs + 1] offsets into cigar_ops                       */
+    const uint32_t *cigar_ops;           /* (count << 8) | action, action in "MIDSH"                     */
 } snapgpu_index_view;
 
 /* Aligner options: the BaseAligner constructor arguments (BaseAligner.h:47-72) with the

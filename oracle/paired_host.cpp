@@ -98,14 +98,14 @@ struct HostPL {
         return o;
     }
     AGOut ag(bool banded, int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int lim, int read_len,
-             bool is_rc, bool use_clip) const {
+             bool is_rc, int use_clip) const {
         AGOut o;
         std::vector<char> pb(plen + 16), qb(plen + 16);
         for (int i = 0; i < plen; i++) { pb[i] = (char)P[i * st]; qb[i] = (char)Q[i * st]; }
         int to = -1, po = -1, ne = -1, stale = 0;
         double mp = 1.0;
         o.ag_score = oracle_ag(st, banded ? 1 : 0, &agp, (const char *)(st > 0 ? T : T + 1), tlen, &pb[0], &qb[0], plen, lim, read_len,
-                               is_rc ? 1 : 0, use_clip ? 1 : 0, &to, &po, &ne, &mp, &stale);
+                               is_rc ? 1 : 0, use_clip, &to, &po, &ne, &mp, &stale);
         o.text_offset = to; o.pattern_offset = po; o.n_edits = ne; o.mp = mp; o.stale = stale;
         return o;
     }
@@ -156,6 +156,12 @@ extern "C" int pairedhost_align(const snapgpu_index_view *ix, void *ref_index, c
     cfg.pool_size = (uint32_t)(pool < pp->max_candidate_pool_size ? pool : pp->max_candidate_pool_size);
     cfg.ag_cand_cap = p->use_affine_gap ? 65536 : 0;
     cfg.max_seeds = PE_MAX_SEEDS;
+    std::vector<uint64_t> zero_pb(ix->n_contigs + 1, 0); std::vector<uint8_t> zero_rc(ix->n_contigs + 1, 0); std::vector<uint32_t> zero_cs(ix->n_contigs + 2, 0), zero_op(1, 0);
+    cfg.proj.contig_begin = ix->contig_begin; cfg.proj.n_contigs = ix->n_contigs;
+    cfg.proj.proj_begin = ix->contig_proj_begin ? ix->contig_proj_begin : &zero_pb[0];
+    cfg.proj.proj_rc = ix->contig_proj_rc ? ix->contig_proj_rc : &zero_rc[0];
+    cfg.proj.cigar_start = ix->contig_cigar_start ? ix->contig_cigar_start : &zero_cs[0];
+    cfg.proj.cigar_ops = ix->cigar_ops ? ix->cigar_ops : &zero_op[0];
 
     PairedCore<HostPL> core(pl, cfg);
     std::vector<PELookup> lk(4 * cfg.max_seeds);

@@ -85,6 +85,10 @@ class IndexView(C.Structure):
         ("n_contigs", C.c_uint32),
         ("first_alt_location", C.c_uint64),
         ("on_device", C.c_uint32),
+        ("contig_proj_begin", C.c_void_p),
+        ("contig_proj_rc", C.c_void_p),
+        ("contig_cigar_start", C.c_void_p),
+        ("cigar_ops", C.c_void_p),
     ]
 
 

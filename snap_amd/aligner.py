@@ -85,6 +85,12 @@ def make_index_view(index: GenomeIndex, device_index_ptrs=None):
     v.n_bases = index.n_bases
     v.genome_pad = GENOME_PAD
     v.first_alt_location = index.first_alt_location
+    pb, prc, cst, cops = index.projection_arrays()
+    keep += [pb, prc, cst, cops]
+    v.contig_proj_begin = pb.ctypes.data
+    v.contig_proj_rc = prc.ctypes.data
+    v.contig_cigar_start = cst.ctypes.data
+    v.cigar_ops = cops.ctypes.data
     if device_index_ptrs is None:
         v.hash_blob = index.hash_blob.ctypes.data
         v.overflow = index.overflow.ctypes.data

@@ -5,7 +5,7 @@
 //   IntersectingPairedEndAligner::align               SNAPLib/IntersectingPairedEndAligner.cpp:169-251
 //     alignLandauVishkin  (Phases 1-3)                :254-1435
 //     alignHamming        (same walk, gapless scoring) :1441-2487
-//     alignAffineGap      (Phase 4)                   :2489-2970 (ALT liftover :2890-2968 not built)
+//     alignAffineGap      (Phase 4)                   :2489-2970, incl. the ALT liftover of :2866-2968 / :2971-3117
 //   scoreLocation / scoreLocationWithAffineGap / scoreLocationWithHammingDistance   :3283-3399 / :3119-3280 / :3402-3513
 //   HashTableHitSet::{init,recordLookup,getFirstHit,getNextLowerHit,getNextHitLessThanOrEqualTo,
 //                    computeBestPossibleScoreForCurrentHit}                          :3516-3810
@@ -53,7 +53,15 @@ struct PEHits {                        // one direction of a seed lookup
     uint32_t singleton;                // the hit when n_hits == 1
 };
 
+struct PEProj {                        // contig table with the ALT-to-primary projections (Genome.h:386-400), in the platform's memory
+    const uint64_t *contig_begin, *proj_begin;
+    const uint8_t  *proj_rc;
+    const uint32_t *cigar_start, *cigar_ops;       // ops: (count << 8) | action
+    uint32_t n_contigs;
+};
+
 struct PECfg {
+    PEProj   proj;
     int32_t  max_k;                    // maxK of the current align() call
     int32_t  extra_depth, max_k_for_indels, max_gap_alt;
     uint32_t use_ag, alt_aware, emit_alt, use_soft_clip, force_spacing;
@@ -122,7 +130,7 @@ struct PECounters { uint64_t lv, ag, lookups, hits, overflow_lists, lv_ref_bytes
 
 struct PEShared {                      // cold wave-uniform state (LDS on the device)
     PESet all, non_alt;
-    snapgpu_paired_result res, alt;
+    snapgpu_paired_result res, alt, saved;
     snapgpu_single_result single[2], single_alt[2];
     PECounters cnt;
 };
@@ -504,7 +512,7 @@ struct PairedCore {
         const uint8_t *data = pl.window(loc, rl);
         const uint8_t *R = rd[which][dir], *Qd = ql[which][dir];
         const int tail = seed_offset + sl;
-        const bool clip = cfg.use_soft_clip != 0;
+        const int clip = cfg.use_soft_clip ? 1 : 0;
         int score1 = 0, score2 = 0, ag1 = sl, ag2 = 0;
         double mp1 = 1.0, mp2 = 1.0;
         int text_rem = rl - tail;
@@ -1062,6 +1070,149 @@ struct PairedCore {
         } else {
             alt.status[0] = alt.status[1] = SNAPGPU_NotFound;
         }
+        if (cfg.use_soft_clip) alt_liftover();
+    }
+
+    // ------------------------------------------------------------------ ALT liftover (Genome.cpp:574-716, IntersectingPairedEndAligner.cpp:2870-2968)
+    // Genome::getContigNumAtLocation.  The reference returns pointer garbage for a location no contig holds (before the first
+    // contig, InvalidGenomeLocation); what matters to its callers is only that it differs from every real contig number.
+    PE_FN int contig_num(int64_t loc) const {
+        if (loc == SNAPGPU_InvalidGenomeLocation32) return -2;
+        int lo = 0, hi = (int)cfg.proj.n_contigs - 1;
+        while (lo <= hi) {
+            const int mid = (lo + hi) / 2;
+            const int64_t b = (int64_t)ld(cfg.proj.contig_begin[mid]);
+            if (b <= loc && (mid == (int)cfg.proj.n_contigs - 1 || (int64_t)ld(cfg.proj.contig_begin[mid + 1]) > loc)) return mid;
+            if (b <= loc) lo = mid + 1; else hi = mid - 1;
+        }
+        return -1;
+    }
+    PE_FN int64_t proj_span(int c) const {                                                    // getContigProjSpan, :640-659
+        const uint32_t a = ld(cfg.proj.cigar_start[c]), b = ld(cfg.proj.cigar_start[c + 1]);
+        int64_t off = 0;
+        for (uint32_t i = a; i < b; i++) {
+            const uint32_t op = ld(cfg.proj.cigar_ops[i]);
+            const char act = (char)(op & 0xff);
+            const int64_t cnt = (int64_t)(op >> 8);
+            if (i == a) { if (act != 'S' && act != 'H') off += cnt; }
+            else if (act == 'M' || act == 'I') off += cnt;
+        }
+        return off;
+    }
+    PE_FN int64_t proj_location(int64_t loc, int span) const {                                // getProjLocation, :661-710
+        const int c = contig_num(loc);
+        const int64_t cb = (int64_t)ld(cfg.proj.contig_begin[c]);
+        const bool rc = ld(cfg.proj.proj_rc[c]) != 0;
+        const int64_t offset = !rc ? loc - cb : proj_span(c) - (loc - cb + span);
+        int64_t proj_off = 0;
+        const uint32_t a = ld(cfg.proj.cigar_start[c]), b = ld(cfg.proj.cigar_start[c + 1]);
+        uint32_t start = a;
+        if (b > a) { const char act = (char)(ld(cfg.proj.cigar_ops[a]) & 0xff); if (act == 'S' || act == 'H') start = a + 1; }
+        int64_t x = 0, y = 0;                                  // x: primary, y: ALT
+        for (uint32_t i = start; i < b; i++) {
+            const uint32_t op = ld(cfg.proj.cigar_ops[i]);
+            const char act = (char)(op & 0xff);
+            const int64_t cnt = (int64_t)(op >> 8);
+            if (act == 'M') {
+                if (y <= offset && offset < y + cnt) { proj_off = x + (offset - y); break; }
+                x += cnt; y += cnt;
+            } else if (act == 'D') {
+                x += cnt;
+            } else if (act == 'I') {
+                if (y <= offset && offset < y + cnt) { proj_off = x; break; }
+                y += cnt;
+            } else if (act == 'S' || act == 'H') {
+                if (y <= offset && offset < y + cnt) { proj_off = -1; break; }
+                y += cnt;
+            }
+        }
+        if (proj_off == -1) return SNAPGPU_InvalidGenomeLocation32;
+        return (int64_t)ld(cfg.proj.proj_begin[c]) + proj_off;
+    }
+
+    // scoreLocationWithAffineGapLiftover (:2971-3117): the whole read against the projected location, no seed to anchor on
+    PE_FN void score_ag_liftover(int which, int dir, int64_t loc, int limit, int *score, double *mp, int *offset,
+                                 int *clip_before, int *clip_after, int *ag_score, int *ref_span) {
+        const int rl = read_len[which];
+        const int64_t glen = (int64_t)rl + SNAPGPU_MAX_K;
+        *offset = 0; *ref_span = 0;
+        if (!pl.substring_ok(loc, glen)) { *score = -1; *mp = 0; *ag_score = -1; return; }
+        *clip_before = 0; *clip_after = 0;
+        const uint8_t *data = pl.window(loc, rl);
+        const uint8_t *R = rd[which][dir], *Qd = ql[which][dir];
+        const int clip = 2;                                    // useSoftClip (the caller's condition) + useAltLiftover
+        int score1 = 0, score2 = 0;
+        double mp2 = 1.0;
+        AGOut a = pl.ag(rl >= 3 * (2 * limit + 1), +1, R, Qd, rl, data, (int)glen, limit, rl, dir != 0, clip);
+        stale += (uint32_t)a.stale;
+        const int text_rem = a.text_offset;
+        *clip_after = a.pattern_offset; score1 = a.n_edits;
+        if (score1 != -1 && score1 <= PE_MAXK1) {
+            const int left = score1;
+            const int plen = rl - *clip_after;
+            AGOut b = pl.ag(plen >= 3 * (2 * left + 1), -1, R + (rl - 1 - *clip_after), Qd + (rl - 1 - *clip_after), plen,
+                            data + (rl - text_rem - 1), rl - text_rem, left, rl, dir != 0, clip);
+            stale += (uint32_t)b.stale;
+            *clip_before = b.pattern_offset; score2 = b.n_edits; mp2 = b.mp;
+            if (score2 == -1 || score2 > PE_MAXK1) {
+                *score = -1; *offset = 0; *ag_score = -1;
+            } else {
+                *score = score2;
+                *ag_score = b.ag_score - rl;
+                *mp = mp2;
+                *offset = *clip_after + b.text_offset - text_rem;
+                *ref_span = rl - text_rem - *offset;
+            }
+        } else {
+            *score = -1; *offset = 0; *ag_score = -1;
+        }
+    }
+
+    // the tail of alignAffineGap (:2866-2968): project an ALT alignment onto the primary assembly and rescore it there
+    PE_FN void alt_liftover() {
+        snapgpu_paired_result &res = sh->res, &alt = sh->alt;
+        int best_alt = 0x7fffffff, best_res = 0x7fffffff, alt_proj_contig = -1, res_contig = -1;
+        bool res_is_alt = false;
+        if (alt.status[0] != SNAPGPU_NotFound && alt.status[1] != SNAPGPU_NotFound) {
+            best_alt = alt.score[0] + alt.score[1];
+            const int c = contig_num(alt.location[0]);
+            alt_proj_contig = c < 0 ? -3 : contig_num((int64_t)ld(cfg.proj.proj_begin[c]));                   // getProjContigNumAtLocation
+        }
+        if (res.status[0] != SNAPGPU_NotFound && res.status[1] != SNAPGPU_NotFound) {
+            best_res = res.score[0] + res.score[1];
+            res_contig = contig_num(res.location[0]);
+            res_is_alt = cfg.alt_aware && pl.is_alt(res.location[0]) && pl.is_alt(res.location[1]);
+        }
+        const bool use = cfg.alt_aware && ((best_alt < best_res && alt_proj_contig != res_contig) || res_is_alt);
+        if (!PL::i32(use ? 1 : 0)) return;
+
+        bool found[2] = {true, true};
+        int new_dir[2], new_so[2], new_mapq[2];
+        int64_t new_loc[2];
+        sh->saved = res;
+        const snapgpu_paired_result &src = res_is_alt ? res : alt;
+        const int cc = contig_num(src.location[0]);
+        const int proj_dir = (cc >= 0 && ld(cfg.proj.proj_rc[cc])) ? 1 : 0;                                   // isProjContigRC
+        for (int r = 0; r < 2; r++) {
+            new_dir[r] = (src.direction[r] != proj_dir) ? 1 : 0;
+            new_so[r] = new_dir[r] != src.direction[r] ? read_len[r] - src.seed_offset[r] - 1 : src.seed_offset[r];
+            new_loc[r] = proj_location(src.location[r], src.ref_span[r]);
+            found[r] = new_loc[r] != SNAPGPU_InvalidGenomeLocation32;
+            new_mapq[r] = res_is_alt ? (src.mapq[r] <= 3 ? 70 : src.mapq[r]) : src.mapq[r];
+        }
+        if (!(found[0] && found[1])) return;
+        for (int r = 0; r < 2; r++) {
+            res.used_affine_gap_scoring[r] = 1; res.liftover[r] = 1;
+            res.direction[r] = new_dir[r]; res.location[r] = new_loc[r]; res.seed_offset[r] = new_so[r]; res.mapq[r] = new_mapq[r];
+            int sc = res.score[r], off = 0, cb = res.bases_clipped_before[r], ca = res.bases_clipped_after[r], ag = res.ag_score[r], span = 0;
+            double mp = res.match_probability[r];
+            score_ag_liftover(r, new_dir[r], new_loc[r], PE_MAXK1, &sc, &mp, &off, &cb, &ca, &ag, &span);
+            sc = PL::i32(sc);
+            res.score[r] = sc; res.match_probability[r] = PL::f64(mp); res.bases_clipped_before[r] = cb; res.bases_clipped_after[r] = ca;
+            res.ag_score[r] = ag; res.ref_span[r] = span;
+            if (sc != -1 && sc <= PE_MAXK1) res.location[r] += off; else res.status[r] = SNAPGPU_NotFound;
+        }
+        if (res.status[0] == SNAPGPU_NotFound || res.status[1] == SNAPGPU_NotFound) res = sh->saved;          // no liftover alignment: keep the ALT one
     }
 
     // body of the candidate loop of alignAffineGap (:2736-2823)

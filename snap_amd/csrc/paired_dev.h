@@ -203,7 +203,7 @@ struct DevPL {
         return o;
     }
     __device__ __forceinline__ AGOut ag(bool banded, int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int lim,
-                                        int read_len, bool is_rc, bool use_clip) {
+                                        int read_len, bool is_rc, int use_clip) {
         ByteSeq Ps{P, st}, Qs{Q, st}, Ts{T, st};
         AGResult a = ag_dispatch<AGC>(banded, st, agp, Ps, Qs, plen, Ts, tlen, lim, read_len, is_rc, use_clip, al->ag_rows, al->ag_scratch,
                                       al->cfg.RL, tab);

@@ -217,6 +217,8 @@ struct snapgpu_ctx {
     bool owns_index = true;
     void *d_hash = nullptr, *d_overflow = nullptr, *d_genome_padded = nullptr;
     void *d_table_offset = nullptr, *d_table_size = nullptr, *d_contig_begin = nullptr;
+    void *d_proj = nullptr;           // [proj_begin u64 x n][cigar_start u32 x (n+1)][cigar_ops u32 x m][proj_rc u8 x n]
+    PEProj proj{};
     DevTables *d_tab = nullptr;
     DevTables h_tab{};
     snapgpu_params params{};
@@ -365,6 +367,7 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_table_offset) (void)hipFree(ctx->d_table_offset);
     if (ctx->d_table_size) (void)hipFree(ctx->d_table_size);
     if (ctx->d_contig_begin) (void)hipFree(ctx->d_contig_begin);
+    if (ctx->d_proj) (void)hipFree(ctx->d_proj);
     if (ctx->d_tab) (void)hipFree(ctx->d_tab);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_pscratch) (void)hipFree(ctx->d_pscratch);
@@ -447,6 +450,31 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     ix.table_offset = (const uint64_t *)ctx->d_table_offset;
     ix.table_size = (const uint64_t *)ctx->d_table_size;
     ix.contig_begin = (const uint64_t *)ctx->d_contig_begin;
+    {   // ALT-to-primary projections (used by the paired-end path's ALT liftover); absent data = "location 0, no CIGAR"
+        const size_t n = idx->n_contigs;
+        const uint32_t n_ops = (idx->contig_cigar_start && idx->cigar_ops && n) ? idx->contig_cigar_start[n] : 0;
+        std::vector<uint8_t> img(n * 8 + (n + 1) * 4 + ((size_t)n_ops + 1) * 4 + n + 16, 0);
+        uint64_t *pb = (uint64_t *)img.data();
+        uint32_t *cs = (uint32_t *)(img.data() + n * 8);
+        uint32_t *ops = cs + (n + 1);
+        uint8_t *rc = (uint8_t *)(ops + (size_t)n_ops + 1);
+        for (size_t i = 0; i < n; i++) {
+            pb[i] = idx->contig_proj_begin ? idx->contig_proj_begin[i] : 0;
+            rc[i] = idx->contig_proj_rc ? idx->contig_proj_rc[i] : 0;
+            cs[i] = n_ops ? idx->contig_cigar_start[i] : 0;
+        }
+        cs[n] = n_ops;
+        for (uint32_t i = 0; i < n_ops; i++) ops[i] = idx->cigar_ops[i];
+        CRCHK(hipMalloc(&ctx->d_proj, img.size()), SNAPGPU_E_NOMEM);
+        CRCHK(hipMemcpy(ctx->d_proj, img.data(), img.size(), hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+        uint8_t *d = (uint8_t *)ctx->d_proj;
+        ctx->proj.contig_begin = (const uint64_t *)ctx->d_contig_begin;
+        ctx->proj.proj_begin = (const uint64_t *)d;
+        ctx->proj.cigar_start = (const uint32_t *)(d + n * 8);
+        ctx->proj.cigar_ops = ctx->proj.cigar_start + (n + 1);
+        ctx->proj.proj_rc = (const uint8_t *)(ctx->proj.cigar_ops + (size_t)n_ops + 1);
+        ctx->proj.n_contigs = idx->n_contigs;
+    }
 
     // ---- tables
     build_tables(ctx->h_tab, idx->seed_len);
@@ -548,15 +576,32 @@ extern "C" int snapgpu_create_from_directory(const char *index_dir, const snapgp
     long long n_bases = 0; int n_contigs = 0, gflags = 0;
     if (!next_line(line) || sscanf(line.c_str(), "%lld %d %d", &n_bases, &n_contigs, &gflags) < 2)
         return fail(nullptr, SNAPGPU_E_INVALID, "malformed Genome header");
-    std::vector<uint64_t> contig_begin((size_t)n_contigs);
+    std::vector<uint64_t> contig_begin((size_t)n_contigs), proj_begin((size_t)n_contigs);
+    std::vector<uint8_t> proj_rc((size_t)n_contigs);
+    std::vector<uint32_t> cigar_start((size_t)n_contigs + 1, 0), cigar_ops;
     uint64_t first_alt = ~0ull >> 2;
     for (int i = 0; i < n_contigs; i++) {
-        long long begin = 0; int cflags = 0;
-        if (!next_line(line) || sscanf(line.c_str(), "%lld %x", &begin, &cflags) != 2)
+        // "begin flags originalNumber projBegin projFlags nameLen cigarLen name cigar" (Genome.cpp:226, 353-403)
+        long long begin = 0, pbegin = 0; int cflags = 0, orig = 0, pflags = 0, name_len = 0, cigar_len = 0, consumed = 0;
+        if (!next_line(line) || sscanf(line.c_str(), "%lld %x %d %lld %x %d %d %n", &begin, &cflags, &orig, &pbegin, &pflags, &name_len, &cigar_len, &consumed) < 7)
             return fail(nullptr, SNAPGPU_E_INVALID, "malformed contig line in Genome");
         contig_begin[(size_t)i] = (uint64_t)begin;
+        proj_begin[(size_t)i] = (uint64_t)pbegin;
+        proj_rc[(size_t)i] = (uint8_t)(pflags & 1);                                             // GENOME_FLAG_ALT_PROJ_CONTIG_IS_RC
         if ((cflags & 1) && (uint64_t)begin < first_alt) first_alt = (uint64_t)begin;           // GENOME_FLAG_CONTIG_IS_ALT
+        size_t cpos = (size_t)consumed + (size_t)name_len + 1;
+        if (cpos <= line.size()) {
+            const char *c = line.c_str() + cpos, *cend = line.c_str() + line.size();
+            while (c < cend) {                                                                  // repeated sscanf("%d%c")
+                int count = 0, used = 0; char act = 0;
+                if (sscanf(c, "%d%c%n", &count, &act, &used) != 2) break;
+                cigar_ops.push_back(((uint32_t)count << 8) | (uint32_t)(uint8_t)act);
+                c += used;
+            }
+        }
+        cigar_start[(size_t)i + 1] = (uint32_t)cigar_ops.size();
     }
+    if (cigar_ops.empty()) cigar_ops.push_back(0);
     if (gen.size() - pos < (size_t)n_bases) return fail(nullptr, SNAPGPU_E_INVALID, "Genome file truncated");
     const uint32_t pad = 1024;
     std::vector<uint8_t> genome_padded((size_t)n_bases + 2 * pad, (uint8_t)'n');
@@ -594,6 +639,7 @@ extern "C" int snapgpu_create_from_directory(const char *index_dir, const snapgp
     v.overflow = (const uint32_t *)ovf.data(); v.genome = genome_padded.data() + pad; v.n_bases = (uint64_t)n_bases;
     v.genome_pad = pad; v.contig_begin = contig_begin.data(); v.n_contigs = (uint32_t)n_contigs;
     v.first_alt_location = first_alt; v.on_device = 0;
+    v.contig_proj_begin = proj_begin.data(); v.contig_proj_rc = proj_rc.data(); v.contig_cigar_start = cigar_start.data(); v.cigar_ops = cigar_ops.data();
     return snapgpu_create(&v, p, device, out);
 }
 
@@ -862,9 +908,6 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
     const snapgpu_params &p = ctx->params;
     if (pp->max_spacing > 100000) return fail(ctx, SNAPGPU_E_INVALID, "max_spacing out of range");
-    if (p.alt_awareness && pp->use_soft_clipping && p.use_affine_gap && ctx->ix.first_alt_location < ctx->ix.n_bases)
-        return fail(ctx, SNAPGPU_E_UNSUPPORTED, "the index has ALT contigs: the paired-end path would need ALT liftover "
-                    "(IntersectingPairedEndAligner.cpp:2890-2968), which this build does not implement; use an index without ALT contigs or alt_awareness = 0");
     if (ctx->d_pscratch) { (void)hipFree(ctx->d_pscratch); ctx->d_pscratch = nullptr; }
     if (ctx->d_pscratch_big) { (void)hipFree(ctx->d_pscratch_big); ctx->d_pscratch_big = nullptr; }
     ctx->paired = false;
@@ -895,6 +938,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
 
     PECfg &c = a.pcfg;
     memset(&c, 0, sizeof(c));
+    c.proj = ctx->proj;
     c.max_k = (int)p.max_k; c.extra_depth = (int)p.extra_search_depth; c.max_k_for_indels = (int)pp->max_k_for_indels;
     c.max_gap_alt = p.max_score_gap_to_prefer_non_alt; c.use_ag = p.use_affine_gap ? 1 : 0; c.alt_aware = p.alt_awareness ? 1 : 0;
     c.emit_alt = p.emit_alt_alignments ? 1 : 0; c.use_soft_clip = pp->use_soft_clipping ? 1 : 0; c.force_spacing = pp->force_spacing ? 1 : 0;

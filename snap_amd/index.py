@@ -11,6 +11,7 @@ builder wrote them, so the device probe sequence is the reference's probe sequen
 from __future__ import annotations
 
 import os
+import re
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -25,6 +26,15 @@ class Contig:
     is_alt: bool
     original_number: int
     name: str
+    # ALT-to-primary projection (Genome.h:386-400): only meaningful for ALT contigs of an index built with -altLiftoverFile
+    proj_begin: int = 0
+    proj_rc: bool = False
+    proj_cigar: str = "*"
+
+
+def parse_proj_cigar(cigar: str):
+    """Genome.cpp:389-403: repeated sscanf("%d%c"); returns [(count, action), ...] ('*' gives none)."""
+    return [(int(c), a) for c, a in re.findall(r"(\d+)([A-Za-z=])", cigar)]
 
 
 @dataclass
@@ -56,6 +66,17 @@ class GenomeIndex:
     @property
     def contig_begin(self) -> np.ndarray:
         return np.array([c.begin for c in self.contigs], dtype=np.uint64)
+
+    def projection_arrays(self):
+        """(proj_begin u64[n], proj_rc u8[n], cigar_start u32[n+1], cigar_ops u32[...]) for snapgpu_index_view."""
+        pb = np.array([c.proj_begin for c in self.contigs], dtype=np.uint64)
+        rc = np.array([1 if c.proj_rc else 0 for c in self.contigs], dtype=np.uint8)
+        start = [0]; ops = []
+        for c in self.contigs:
+            for cnt, act in parse_proj_cigar(c.proj_cigar):
+                ops.append((cnt << 8) | ord(act))
+            start.append(len(ops))
+        return pb, rc, np.array(start, dtype=np.uint32), np.array(ops if ops else [0], dtype=np.uint32)
 
     @property
     def first_alt_location(self) -> int:
@@ -90,9 +111,11 @@ class GenomeIndex:
                 line = f.readline().rstrip(b"\n")
                 parts = line.split(b" ", 7)
                 begin = int(parts[0]); flags = int(parts[1], 16); orig = int(parts[2])
-                name_len = int(parts[5])
+                name_len = int(parts[5]); cigar_len = int(parts[6])
                 name = parts[7][:name_len].decode()
-                contigs.append(Contig(begin, bool(flags & 1), orig, name))
+                cigar = parts[7][name_len + 1:name_len + 1 + cigar_len].decode()       # "%s %s": name, blank, CIGAR (Genome.cpp:226)
+                contigs.append(Contig(begin, bool(flags & 1), orig, name, proj_begin=int(parts[3]),
+                                      proj_rc=bool(int(parts[4], 16) & 1), proj_cigar=cigar or "*"))
             genome_padded = np.full(n_bases + 2 * GENOME_PAD, ord("n"), dtype=np.uint8)
             got = f.readinto(memoryview(genome_padded)[GENOME_PAD:GENOME_PAD + n_bases])
             if got != n_bases:

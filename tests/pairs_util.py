@@ -68,3 +68,24 @@ def compare_paired(ref_r, got, verbose=3, exclude=None, fields=PAIR_FIELDS):
                 if not np.array_equal(ref_r[f][i], got[f][i]):
                     print("   ", f, "ref", ref_r[f][i], "got", got[f][i])
     return bad
+
+
+def alt_liftover_genome():
+    """The genome of tests/golden/paired_alt_index.npz: three primary contigs plus
+        chrA_alt1  forward copy of chrA[20000:32000] with a 10-base deletion and a 20-base insertion   5000M10D2990M20I4000M
+        chrB_alt2  reverse-complement copy of chrB[40000:49000] behind 100 novel bases                  100S9000M (flag 16)
+    Returns (contigs, text of the -altLiftoverFile, extra `snap-aligner index` arguments without the file name)."""
+    g = synth.make_genome(20260927, 240_000, n_contigs=3, repeat_frac=0.25, max_copies=30, repeat_len=(150, 1200))
+    rng = np.random.default_rng(5)
+
+    def mutate(a, rate):
+        a = a.copy(); m = rng.random(a.size) < rate
+        a[m] = synth._ACGT[rng.integers(0, 4, size=int(m.sum()))]
+        return a
+    A, B = g[0][1], g[1][1]
+    alt1 = np.concatenate([mutate(A[20000:25000], 0.01), mutate(A[25010:28000], 0.01), synth._ACGT[rng.integers(0, 4, size=20)],
+                           mutate(A[28000:32000], 0.01)])
+    alt2 = np.concatenate([synth._ACGT[rng.integers(0, 4, size=100)], synth._COMP[mutate(B[40000:49000], 0.012)[::-1]]])
+    sam = ("@HD\tVN:1.0\nchrA_alt1\t0\tchrA\t20001\t255\t5000M10D2990M20I4000M\t*\t0\t0\t*\t*\n"
+           "chrB_alt2\t16\tchrB\t40001\t255\t100S9000M\t*\t0\t0\t*\t*\n")
+    return g + [("chrA_alt1", alt1), ("chrB_alt2", alt2)], sam, ["-altContigName", "chrA_alt1", "-altContigName", "chrB_alt2"]

@@ -106,11 +106,7 @@ def test_paired_error_behaviour(pindex, golden_index):
     rc = b.lib.snapgpu_align_paired(b.handle, C.c_uint32(1), abi.ptr(bases), abi.ptr(bases), abi.ptr(offs), abi.ptr(prim), None)
     assert rc == -1 and b"snapgpu_enable_paired" in b.lib.snapgpu_last_error(b.handle)
     b.close()
-    # an index with ALT contigs needs ALT liftover, which is not built: refuse instead of returning different results
-    with pytest.raises(SnapGpuError, match="ALT"):
-        ChimericPairedEndAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
-    # ... unless ALT awareness is off
-    a = ChimericPairedEndAligner(golden_index, abi.default_params(max_k=8, max_read_len=160, alt_awareness=0))
+    a = ChimericPairedEndAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))          # (an ALT index without liftover data is fine)
     # reads longer than max_read_len are rejected before anything is launched
     long_b = np.frombuffer(b"A" * 400, dtype=np.uint8).copy()
     with pytest.raises(SnapGpuError, match="max_read_len"):
@@ -119,3 +115,51 @@ def test_paired_error_behaviour(pindex, golden_index):
     p0, a0 = a.align(np.zeros(0, np.uint8), np.zeros(0, np.uint8), np.zeros(1, np.uint64))
     assert p0.size == 0
     a.close()
+
+
+@pytest.mark.parametrize("name,kw", [("default_d8", dict(max_k=8)), ("default_d27", dict(max_k=27)), ("emitalt_d8", dict(max_k=8, emit_alt_alignments=1))])
+def test_alt_liftover_matches_reference_fixture(name, kw):
+    """ALT liftover (IntersectingPairedEndAligner.cpp:2866-2968) on an index built with -altLiftoverFile: see the CPU twin in
+    tests/test_paired_host.py."""
+    from snap_amd.aligner import ChimericPairedEndAligner
+    ix = util.load_golden_index("paired_alt_index.npz")
+    z = np.load(os.path.join(util.GOLDEN, "paired_alt_reads.npz"))
+    a = ChimericPairedEndAligner(ix, abi.default_params(max_read_len=160, **kw), abi.default_paired_params())
+    prim, alt = a.align(z["b"], z["q"], z["o"])
+    a.close()
+    key = "%s_s0" % name
+    fields = ["status", "direction", "location", "score", "mapq", "used_affine_gap_scoring", "bases_clipped_before", "bases_clipped_after",
+              "ag_score", "liftover", "aligned_as_pair"]
+    bad = compare_paired(z[key + "_primary"], prim, verbose=3, exclude=z[key + "_unstable"] | (prim["reserved"] != 0), fields=fields)
+    assert not bad.any()
+    assert (alt["status"] == z[key + "_alt"]["status"]).all()
+    assert prim["liftover"].all(axis=1).sum() == z[key + "_primary"]["liftover"].all(axis=1).sum()
+
+
+def test_alt_index_without_liftover_data(golden_index, golden_reads):
+    """The single-end golden index has an ALT contig but no projection data: pairs built from its reads must still equal the
+    reference (the liftover attempt projects to location 0, fails, and the ALT alignment is kept)."""
+    if not ref.available():
+        pytest.skip("oracle/_ref did not travel to this box")
+    pytest.importorskip("snap_amd")
+    # (needs the reference live: there is no committed paired fixture for this index)
+    import tempfile
+    from snap_amd.aligner import ChimericPairedEndAligner
+    cs = []
+    for i, c in enumerate(golden_index.contigs):
+        end = golden_index.contigs[i + 1].begin if i + 1 < len(golden_index.contigs) else golden_index.n_bases
+        g = golden_index.genome[c.begin:end]
+        cs.append((c.name, g[g != ord("n")].copy()))
+    d = tempfile.mkdtemp(prefix="altidx_", dir="/tmp")
+    synth.write_fasta(d + "/ref.fa", cs)
+    ref.build_index(d + "/ref.fa", d + "/idx", 20, threads=4, extra=["-altContigName", cs[-1][0]])
+    gi = GenomeIndex.load_from_directory(d + "/idx")
+    pr = hard_pairs(12, cs, 1500, 150, insert_mean=380)
+    p = abi.default_params(max_k=8, max_read_len=160); pp = abi.default_paired_params()
+    rp, ra, _, _ = ref.RefIndex(d + "/idx").align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=8, stage=0)
+    a = ChimericPairedEndAligner(gi, p, pp)
+    gp, ga = a.align(pr["bases"], pr["quals"], pr["offsets"])
+    a.close()
+    bad = compare_paired(rp, gp, verbose=3, exclude=gp["reserved"] != 0)
+    assert not bad.any()
+    assert (ra["status"] == ga["status"])[gp["reserved"] == 0].all()

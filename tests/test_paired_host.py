@@ -90,3 +90,40 @@ def test_intersecting_align_matches_reference_fixture(golden_pairs, ref_index, n
     assert (z[key + "_primary"]["probability_all_pairs"][found] == prim["probability_all_pairs"][found]).all()
     if not z[key + "_unstable"].any():
         assert [int(cnt[0]), int(cnt[1])] == z[key + "_counters"].tolist()      # LV / affine-gap locations scored
+
+
+# ---------------------------------------------------------------------------------------- ALT liftover
+
+@pytest.fixture(scope="module")
+def alt_ref_index(tmp_path_factory):
+    from tests.pairs_util import alt_liftover_genome
+    d = str(tmp_path_factory.mktemp("paltidx"))
+    g, sam, alt_args = alt_liftover_genome()
+    synth.write_fasta(d + "/ref.fa", g)
+    open(d + "/lift.sam", "w").write(sam)
+    ref.build_index(d + "/ref.fa", d + "/idx", 20, threads=4, extra=alt_args + ["-altLiftoverFile", d + "/lift.sam"])
+    gi = GenomeIndex.load_from_directory(d + "/idx")
+    golden = util.load_golden_index("paired_alt_index.npz")
+    assert (gi.genome_padded == golden.genome_padded).all()
+    assert [(c.proj_begin, c.proj_rc, c.proj_cigar) for c in gi.contigs] == [(c.proj_begin, c.proj_rc, c.proj_cigar) for c in golden.contigs]
+    return ref.RefIndex(d + "/idx"), gi
+
+
+@pytest.mark.parametrize("name,kw", [("default_d8", dict(max_k=8)), ("default_d27", dict(max_k=27)), ("emitalt_d8", dict(max_k=8, emit_alt_alignments=1))])
+@pytest.mark.parametrize("stage", [0, 1])
+def test_alt_liftover_matches_reference_fixture(alt_ref_index, name, kw, stage):
+    """Pairs drawn from two ALT contigs (one forward with indels in its projection CIGAR, one reverse-complemented behind a soft
+    clip) of an index built with -altLiftoverFile: the best ALT alignment is projected onto the primary assembly and rescored
+    there (IntersectingPairedEndAligner.cpp:2866-2968)."""
+    rix, gi = alt_ref_index
+    z = np.load(os.path.join(util.GOLDEN, "paired_alt_reads.npz"))
+    p = abi.default_params(max_read_len=160, **kw)
+    pp = abi.default_paired_params()
+    prim, alt, cnt = host_align(gi, rix, p, pp, z["b"], z["q"], z["o"], stage)
+    key = "%s_s%d" % (name, stage)
+    fields = ["status", "direction", "location", "score", "mapq", "used_affine_gap_scoring", "bases_clipped_before", "bases_clipped_after",
+              "ag_score", "liftover"] + (["aligned_as_pair"] if stage == 0 else [])
+    bad = compare_paired(z[key + "_primary"], prim, verbose=3, exclude=z[key + "_unstable"], fields=fields)
+    assert not bad.any()
+    assert (alt["status"] == z[key + "_alt"]["status"]).all()
+    assert z[key + "_primary"]["liftover"].all(axis=1).sum() > (100 if kw["max_k"] == 8 else 3)      # the path is exercised

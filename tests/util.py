@@ -19,6 +19,9 @@ def load_golden_index(name: str = "tiny_index.npz") -> GenomeIndex:
     m = z["meta"]
     contigs = [Contig(int(b), bool(a), i, str(n)) for i, (b, a, n) in
                enumerate(zip(z["contig_begin"], z["contig_is_alt"], z["contig_names"]))]
+    if "contig_proj_begin" in z.files:                      # index built with -altLiftoverFile
+        for c, pb, rc, cg in zip(contigs, z["contig_proj_begin"], z["contig_proj_rc"], z["contig_proj_cigar"]):
+            c.proj_begin, c.proj_rc, c.proj_cigar = int(pb), bool(rc), str(cg)
     return GenomeIndex(seed_len=int(m[0]), key_bytes=int(m[1]), n_hash_tables=int(m[2]), large=bool(m[3]),
                        location_size=int(m[4]), chromosome_padding=int(m[5]), overflow=z["overflow"],
                        hash_blob=z["hash_blob"], table_offset=z["table_offset"], table_size=z["table_size"],
