@@ -335,7 +335,8 @@ int  snapgpu_align_single_device(snapgpu_ctx *ctx, uint32_t n, const void *d_bas
  *       called from PairedAlignerContext::runIterationThreadImpl      SNAPLib/PairedAligner.cpp:727
  * for a batch of n_pairs pairs: offsets has 2*n_pairs+1 entries, read r of pair i is
  * bases[offsets[2i+r] .. offsets[2i+r+1]).  primary/first_alt: [n_pairs] out (first_alt may be NULL).
- * Secondary alignments (-om) and ALT liftover (IntersectingPairedEndAligner.cpp:2890-2968) are not produced.
+ * ALT alignments are lifted over to the primary assembly as the reference does (IntersectingPairedEndAligner.cpp:2866-2968) when the
+ * index view carries the contigs' projection data.  Secondary alignments (-om) are not produced.
  * A pair whose candidate pools overflowed is flagged (SNAPGPU_PAIR_POOL_OVERFLOW) and the call returns
  * SNAPGPU_E_UNSUPPORTED after filling in every other pair.
  */

@@ -180,3 +180,36 @@ def test_paired_sam_identical_to_reference_cli(paired_workload, opts, params, pp
         bad = [n for n in differing if n not in unstable]
         assert not bad, "first differing pair %s:\nref: %sgpu: %s" % (bad[0], "".join(m_ref[bad[0]]), "".join(m_gpu[bad[0]]))
         assert len(differing) <= 2 + len(m_ref) // 50
+
+
+def test_paired_sam_identical_on_alt_liftover_index(tmp_path):
+    """An index built with -altLiftoverFile, pairs drawn from its ALT contigs: exercises snapgpu_create_from_directory's parsing of the
+    projection data (Genome.cpp:353-403) and the reference SAM writer on lifted-over results."""
+    from tests.pairs_util import alt_liftover_genome, hard_pairs
+    if not (os.path.exists(REF_CLI) and os.path.exists(GPU_CLI)):
+        pytest.skip("oracle/_ref CLIs were not built")
+    d = str(tmp_path)
+    g, sam, alt_args = alt_liftover_genome()
+    synth.write_fasta(d + "/ref.fa", g)
+    open(d + "/lift.sam", "w").write(sam)
+    ref.build_index(d + "/ref.fa", d + "/idx", 20, threads=8, extra=alt_args + ["-altLiftoverFile", d + "/lift.sam"])
+    pa = hard_pairs(21, g[3:], 1200, 150, insert_mean=380)
+    pb = hard_pairs(22, g, 1200, 150, insert_mean=380)
+    fq = [d + "/p1.fq", d + "/p2.fq"]
+    with open(fq[0], "wb") as f0, open(fq[1], "wb") as f1:
+        i = 0
+        for pr in (pa, pb):
+            o = pr["offsets"].astype(np.int64)
+            for j in range(o.size // 2):
+                for r, f in ((0, f0), (1, f1)):
+                    s, e = o[2 * j + r], o[2 * j + r + 1]
+                    f.write(b"@pair%d\n" % i + pr["bases"][s:e].tobytes() + b"\n+\n" + pr["quals"][s:e].tobytes() + b"\n")
+                i += 1
+    _run([REF_CLI, "paired", d + "/idx", fq[0], fq[1], "-o", d + "/ref.sam", "-t", "8", "-d", "8"])
+    _run([GPU_CLI, "paired", d + "/idx", fq[0], fq[1], "-o", d + "/gpu.sam", "-t", "4", "-d", "8"])
+    h_ref, r_ref = _sam(d + "/ref.sam")
+    h_gpu, r_gpu = _sam(d + "/gpu.sam")
+    assert h_ref == h_gpu
+    differing = sum(a != b for a, b in zip(r_ref, r_gpu))
+    assert len(r_ref) == len(r_gpu) and differing <= 2 + len(r_ref) // 100, "first differing records:\n%s%s" % next(
+        ((a, b) for a, b in zip(r_ref, r_gpu) if a != b), ("", ""))
