@@ -960,7 +960,11 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     if (const char *e = getenv("SNAPGPU_PAIRED_POOL")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 64 && v < pool) pool = v; }
     if (pool < 64) pool = 64;
     c.pool_size = (uint32_t)pool;
-    c.ag_cand_cap = p.use_affine_gap ? 4096 : 0;                                                    // PairedAligner.cpp:571 (the reference doubles on overflow; here overflow is reported)
+    // PairedAligner.cpp:571 starts at 4096 and doubles on overflow.  First pass: 16384 (3.4 MB per wave), so that all but the very
+    // heaviest pairs finish alongside the rest of the batch instead of serially in the second pass; second pass: 8x that.
+    uint32_t first_cap = 16384;
+    if (const char *e = getenv("SNAPGPU_PAIRED_AGC_CAP")) { uint32_t v = (uint32_t)strtoul(e, nullptr, 10); if (v >= 64 && v <= (1u << 20)) first_cap = v; }
+    c.ag_cand_cap = p.use_affine_gap ? first_cap : 0;
     a.single_agc_cap = p.use_affine_gap ? 4096 : 0;
     a.max_k_paired = (int32_t)p.max_k; a.max_k_single = (int32_t)(p.max_k / 2);
 
@@ -991,7 +995,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     // few waves whose buffers are 32x larger; only what still does not fit is reported.
     PairedArgs &big = ctx->pargs_big;
     big = a;
-    big.pcfg.ag_cand_cap = a.pcfg.ag_cand_cap * 32;
+    big.pcfg.ag_cand_cap = a.pcfg.ag_cand_cap * 8;
     big.single_agc_cap = a.single_agc_cap * 32;
     lay_out(big);
 
