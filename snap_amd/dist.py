@@ -72,6 +72,20 @@ def broadcast_index(index, device, src: int = 0):
     ts = torch.from_numpy(small).to(device)
     dist.broadcast(ts, src)
     small = ts.cpu().numpy()
+    # ALT-to-primary projections of the contigs (paired-end ALT liftover): proj_begin, proj_rc, CIGAR op table
+    if is_src:
+        pb, prc, cst, cops = index.projection_arrays()
+        proj = np.concatenate([[cops.size], pb.astype(np.int64), prc.astype(np.int64), cst.astype(np.int64), cops.astype(np.int64)])
+        plen = np.array([proj.size], dtype=np.int64)
+    else:
+        plen = np.zeros(1, dtype=np.int64)
+    tl = torch.from_numpy(plen).to(device)
+    dist.broadcast(tl, src)
+    if not is_src:
+        proj = np.zeros(int(tl.cpu().numpy()[0]), dtype=np.int64)
+    tp = torch.from_numpy(proj).to(device)
+    dist.broadcast(tp, src)
+    proj = tp.cpu().numpy()
 
     blobs = []
     for name, n, dt in (("hash_blob", hash_n, torch.uint8), ("overflow", ovf_n, torch.int32), ("genome_padded", gen_n, torch.uint8)):
@@ -89,6 +103,13 @@ def broadcast_index(index, device, src: int = 0):
     else:
         contigs = [Contig(int(b), bool(a), i, "contig%d" % i) for i, (b, a) in
                    enumerate(zip(small[2 * n_tables:2 * n_tables + n_contigs], small[2 * n_tables + n_contigs:]))]
+        n_ops = int(proj[0])
+        pb = proj[1:1 + n_contigs]; prc = proj[1 + n_contigs:1 + 2 * n_contigs]
+        cst = proj[1 + 2 * n_contigs:2 + 3 * n_contigs]; cops = proj[2 + 3 * n_contigs:2 + 3 * n_contigs + n_ops]
+        for i, c in enumerate(contigs):
+            c.proj_begin, c.proj_rc = int(pb[i]), bool(prc[i])
+            ops = cops[int(cst[i]):int(cst[i + 1])]
+            c.proj_cigar = "".join("%d%s" % (int(o) >> 8, chr(int(o) & 0xff)) for o in ops) or "*"
         out_index = GenomeIndex(seed_len=int(meta["seed_len"]), key_bytes=int(meta["key_bytes"]), n_hash_tables=n_tables,
                                 large=bool(meta["large"]), location_size=int(meta["location_size"]),
                                 chromosome_padding=int(meta["chromosome_padding"]),

@@ -25,6 +25,11 @@ WORKER = textwrap.dedent("""
     assert (ix.table_offset == full.table_offset).all() and (ix.table_size == full.table_size).all()
     assert [c.begin for c in ix.contigs] == [c.begin for c in full.contigs]
     assert ix.first_alt_location == full.first_alt_location and ix.n_bases == full.n_bases
+    assert all((a == b).all() for a, b in zip(ix.projection_arrays(), full.projection_arrays()))
+    lift = load_golden_index("paired_alt_index.npz")
+    ix2, _ = sd.broadcast_index(lift if rank == 0 else None, dev)
+    assert all((a == b).all() for a, b in zip(ix2.projection_arrays(), lift.projection_arrays()))
+    assert [c.proj_cigar for c in ix2.contigs] == [c.proj_cigar for c in lift.contigs]
     n = 3001
     b, e = sd.shard_range(n, rank, world)
     total = sd.sum_over_ranks(float(e - b), dev)
