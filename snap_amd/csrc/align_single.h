@@ -30,6 +30,7 @@
 #include "probe.h"
 #include "lv.h"
 #include "ag_win.h"
+#include <stddef.h>
 #include "../../include/snapgpu.h"
 
 #define BUCKET 48                      // hashTableElementSize == maxMergeDist, BaseAligner.h:177,213
@@ -253,11 +254,13 @@ struct Aligner {
         int64_t base = loc - low;
         uint16_t h = (uint16_t)first_u32(heads[head_slot(base, dir)]);
         while (h != 0) {
-            const Elem *e = &pool[h - 1];
-            int64_t b = (int64_t)first_u64((uint64_t)e->base);
-            uint32_t d = first_u32(e->dir);
-            if (b == base && (int)d == dir) return (uint16_t)(h - 1);
-            h = (uint16_t)first_u32(e->hnext);
+            // base (dwords 4,5) and hnext|dir|flags (dword 18) of the chained element in one load instead of three dependent ones
+            const uint32_t *ew = (const uint32_t *)&pool[h - 1];
+            const uint32_t v = ew[lane == 0 ? 4 : (lane == 1 ? 5 : 18)];
+            const int64_t b = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 0));
+            const uint32_t w18 = (uint32_t)__builtin_amdgcn_readlane((int)v, 2);
+            if (b == base && (int)((w18 >> 16) & 0xffu) == dir) return (uint16_t)(h - 1);
+            h = (uint16_t)(w18 & 0xffffu);
         }
         return 0xFFFF;
     }
@@ -529,20 +532,33 @@ struct Aligner {
 
             uint16_t ei = get_next(sent(wl));
             Elem *e = &pool[ei];
-            int64_t e_base = (int64_t)first_u64((uint64_t)e->base);
-            int e_dir = (int)first_u32(e->dir);
-            uint32_t e_lps = first_u32(e->lps);
+            // The element (44 dwords) comes in with ONE coalesced load, lane i holding dword i; its fields are then lane reads.
+            // (Field by field it was ~10 dependent L2 round trips per candidate.)  Fields this loop changes are tracked in
+            // registers next to the stores.
+            const uint32_t ew = lane < (int)(sizeof(Elem) / 4) ? ((const uint32_t *)e)[lane] : 0u;
+            auto EW = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)ew, i); };
+            static_assert(offsetof(Elem, base) == 16 && offsetof(Elem, match_prob) == 32 && offsetof(Elem, lps) == 44 &&
+                          offsetof(Elem, best_score) == 48 && offsetof(Elem, hnext) == 72 && offsetof(Elem, dir) == 74 &&
+                          offsetof(Elem, flags) == 75 && offsetof(Elem, cand_seed_offset) == 80, "Elem layout");
+            int64_t e_base = (int64_t)(((uint64_t)EW(5) << 32) | EW(4));
+            int e_dir = (int)((EW(18) >> 16) & 0xffu);
+            uint32_t e_lps = EW(11);
+            uint64_t e_scored = ((uint64_t)EW(3) << 32) | EW(2);
+            uint32_t e_best_cur = EW(12);
+            double e_mp_cur = __longlong_as_double((long long)(((uint64_t)EW(9) << 32) | EW(8)));
+            uint32_t e_flags_cur = EW(18) >> 24;
             int limit_e = score_limit(cfg.alt_aware && is_alt(e_base));      // :1084
             if ((int64_t)e_lps <= (int64_t)limit_e) {
-                uint64_t mask = first_u64(e->used);                           // snapshot, :1088
+                uint64_t mask = ((uint64_t)EW(1) << 32) | EW(0);              // snapshot, :1088
                 while (mask) {
                     int idx = __ffsll((long long)mask) - 1;
                     uint64_t bit = 1ull << idx;
                     mask &= ~bit;
-                    uint64_t scored = first_u64(e->scored);
+                    uint64_t scored = e_scored;
                     if (scored & bit) continue;
                     bool any_nearby = scored != 0;
-                    if (lane == 0) e->scored = scored | bit;
+                    e_scored = scored | bit;
+                    if (lane == 0) e->scored = e_scored;
                     WAVE_SYNC();
 
                     int64_t loc = e_base + idx;
@@ -553,7 +569,7 @@ struct Aligner {
                     double mp = 0.0;
                     const int64_t glen = (int64_t)read_len + SNAPGPU_MAX_K;
                     int used_ag = 0, clip_before = 0, clip_after = 0, ag_score = -1;
-                    int cand_seed_offset = (int)first_u32(e->cand_seed_offset[idx]);
+                    int cand_seed_offset = (int)((EW(20 + (idx >> 1)) >> (16 * (idx & 1))) & 0xffffu);
 
                     if (substring_ok(loc, glen)) {
                         stage_window(loc);
@@ -667,16 +683,17 @@ struct Aligner {
                     }
 
                     // ---- bookkeeping after scoring one candidate (:1349-1519)
-                    uint32_t e_best = first_u32(e->best_score);
-                    double e_mp = first_f64(e->match_prob);
+                    uint32_t e_best = e_best_cur;
+                    double e_mp = e_mp_cur;
                     if (any_nearby) {
                         if (HAM && mp <= e_mp) continue;                                      // :1362
                         if (e_best < sc || (e_best == sc && mp <= e_mp)) continue;            // :1366
                     }
-                    const uint32_t e_flags = first_u32(e->flags);
+                    const uint32_t e_flags = e_flags_cur;
+                    e_flags_cur = (e_flags & 1u) | (used_ag ? 2u : 0u);
                     if (lane == 0) {
                         e->best_loc = loc;
-                        e->flags = (uint8_t)((e_flags & 1u) | (used_ag ? 2u : 0u));
+                        e->flags = (uint8_t)e_flags_cur;
                         e->clip_before = clip_before;
                         e->clip_after = clip_after;
                         e->ag_score = ag_score;
@@ -716,6 +733,7 @@ struct Aligner {
                         double v = all.p_all - e_mp; v = v > 0.0 ? v : 0.0; all.p_all = v + mp;
                         if (loc_non_alt) { double u = non_alt.p_all - e_mp; u = u > 0.0 ? u : 0.0; non_alt.p_all = u + mp; }
                     }
+                    e_mp_cur = mp; e_best_cur = sc;
                     if (lane == 0) { e->match_prob = mp; e->best_score = sc; }
                     WAVE_SYNC();
 
@@ -737,8 +755,7 @@ struct Aligner {
 
             // remove the element from its weight list (:1526-1529)
             {
-                const uint32_t fl = first_u32(e->flags);
-                if (lane == 0) e->flags = (uint8_t)(fl | 1u);
+                if (lane == 0) e->flags = (uint8_t)(e_flags_cur | 1u);
                 WAVE_SYNC();
             }
             list_unlink(ei);
