@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define SNAPGPU_ABI_VERSION 2
+#define SNAPGPU_ABI_VERSION 3
 
 /* error codes */
 #define SNAPGPU_OK              0
@@ -48,6 +48,7 @@ extern "C" {
 #define SNAPGPU_E_UNSUPPORTED  -3   /* index/options outside what this build implements  */
 #define SNAPGPU_E_NOMEM        -4
 #define SNAPGPU_E_LAUNCH       -5   /* kernel launch or execution failed                 */
+#define SNAPGPU_W_SECONDARY_TRUNCATED 1 /* some read has more secondary results than the caller's stride: see snapgpu_align_single_secondary */
 
 /* mirrors enum AlignmentResult, SNAPLib/AlignmentResult.h:33 */
 enum { SNAPGPU_NotFound = 0, SNAPGPU_SingleHit = 1, SNAPGPU_MultipleHits = 2 };
@@ -306,7 +307,8 @@ int  snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
  *   first_alt:   [n] out or NULL (only status is meaningful unless emit_alt_alignments)
  * Reads are independent; results do not depend on batch composition or order.
  * Secondary alignments (-om) are not produced by this entry point (the reference default,
- * maxSecondaryAlignmentAdditionalEditDistance = -1, AlignerOptions.cpp:70).
+ * maxSecondaryAlignmentAdditionalEditDistance = -1, AlignerOptions.cpp:70); see
+ * snapgpu_align_single_secondary.
  */
 int  snapgpu_align_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, const char *quals,
                           const uint64_t *offsets, snapgpu_single_result *primary,
@@ -321,6 +323,42 @@ int  snapgpu_align_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, const
  */
 int  snapgpu_align_single_device(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals,
                                  const void *d_offsets, void *d_primary, void *d_first_alt, void *stream);
+
+/*
+ * Secondary alignments: AlignRead's maxEditDistanceForSecondaryResults / secondaryResults / maxSecondaryResults arguments
+ * (BaseAligner.h:76-90; SingleAligner.cpp:250) and BaseAligner's maxSecondaryAlignmentsPerContig (BaseAligner.h:62),
+ * i.e. -om, -omax and -mpc (AlignerOptions.cpp:70-72).
+ */
+typedef struct snapgpu_secondary_params {
+    int32_t  max_edit_distance;    /* -om  maxSecondaryAlignmentAdditionalEditDistance, 0 <= om <= extra_search_depth   */
+    int32_t  max_per_contig;       /* -mpc maxSecondaryAlignmentsPerContig, -1 = no limit                                */
+    int64_t  max_results;          /* -omax maxSecondaryAlignments, 0x7fffffff                                           */
+    uint32_t adjust_alignments;    /* -ae (!ignoreAlignmentAdjustmentsForOm); must be 0 in this build                    */
+} snapgpu_secondary_params;
+
+/* Sizes the per-wavefront secondary-result lists of `ctx` (2 * seeds * max_hits entries each: they cannot overflow, so the
+ * reference's "buffer too small -> caller doubles and re-calls" path, SingleAligner.cpp:250-263, has no counterpart). */
+int  snapgpu_enable_secondary(snapgpu_ctx *ctx, const snapgpu_secondary_params *sp);
+
+/*
+ * BaseAligner::AlignRead with secondary results, including finalizeSecondaryResults (BaseAligner.cpp:2423-2553).
+ *   secondary:        [n * secondary_stride] out; read i's results are secondary[i*secondary_stride .. + min(n_secondary[i], stride)),
+ *                     in the reference's order.  Fields the reference leaves unset in a secondary result (probability of all
+ *                     candidates, popular seeds skipped) are 0.
+ *   n_secondary:      [n] out; the number of secondary results read i HAS.
+ * Returns SNAPGPU_OK, or SNAPGPU_W_SECONDARY_TRUNCATED (> 0) when some n_secondary[i] > secondary_stride: everything else is
+ * filled in, and the caller may call again with a larger stride (min(-omax, what n_secondary says) always suffices).
+ * primary / first_alt are what snapgpu_align_single returns, except that -- like the reference, BaseAligner.cpp:1512 -- the
+ * search does not stop early once the candidates' total probability reaches 4.9, so probability_all_candidates and mapq of
+ * repeat reads can differ from a run without -om.
+ */
+int  snapgpu_align_single_secondary(snapgpu_ctx *ctx, uint32_t n, const char *bases, const char *quals,
+                                    const uint64_t *offsets, snapgpu_single_result *primary, snapgpu_single_result *first_alt,
+                                    snapgpu_single_result *secondary, uint32_t secondary_stride, uint32_t *n_secondary);
+/* device-pointer form, as snapgpu_align_single_device */
+int  snapgpu_align_single_secondary_device(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals,
+                                           const void *d_offsets, void *d_primary, void *d_first_alt,
+                                           void *d_secondary, uint32_t secondary_stride, void *d_n_secondary, void *stream);
 
 /*
  * Paired-end path.  snapgpu_enable_paired builds, on an existing context, the per-wave state of

@@ -91,6 +91,29 @@ class RefIndex:
         return primary, first_alt, dict(lookups=int(counters[0]), lv=int(counters[1]), ag=int(counters[2])), secs.value
 
 
+    def align_single_secondary(self, params: Params, om: int, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray,
+                               omax: int = 0x7fffffff, mpc: int = -1, threads: int = 1, stride: int = 64):
+        """BaseAligner::AlignRead with -om/-omax/-mpc, called as SingleAligner.cpp:250 calls it.
+        Returns (primary, first_alt, secondary[n, stride], n_secondary[n])."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        primary = np.zeros(n, dtype=RESULT_DTYPE)
+        first_alt = np.zeros(n, dtype=RESULT_DTYPE)
+        while True:
+            secondary = np.zeros((n, stride), dtype=RESULT_DTYPE)
+            n_sec = np.zeros(n, dtype=np.uint32)
+            rc = lib().snapref_align_single_secondary(self.handle, C.byref(params), C.c_int(om), C.c_int64(omax), C.c_int(mpc),
+                                                      C.c_uint32(n), ptr(bases), ptr(quals), ptr(offsets), C.c_int(threads),
+                                                      ptr(primary), ptr(first_alt), ptr(secondary), C.c_uint32(stride), ptr(n_sec))
+            if rc != 0:
+                raise RuntimeError("snapref_align_single_secondary rc=%d" % rc)
+            if n and int(n_sec.max()) > stride:
+                stride = int(n_sec.max())
+                continue
+            return primary, first_alt, secondary, n_sec
+
     def align_paired(self, params: Params, pparams, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray,
                      threads: int = 1, stage: int = 0):
         """ChimericPairedEndAligner::align (stage 0) or IntersectingPairedEndAligner::align only (stage 1)

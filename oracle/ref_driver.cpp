@@ -368,6 +368,109 @@ int snapref_align_single(void *vindex, const snapgpu_params *p, uint32_t n, cons
 }
 
 
+// ---------------------------------------------------------------------------------------- secondary results (-om)
+
+struct SecJob {
+    GenomeIndex *index;
+    const snapgpu_params *p;
+    int om, mpc; _int64 omax;
+    uint32_t n;
+    const char *bases, *quals;
+    const uint64_t *offsets;
+    snapgpu_single_result *primary, *first_alt, *secondary;
+    uint32_t stride;
+    uint32_t *n_secondary;
+    volatile _int64 next;
+    uint32_t chunk;
+};
+
+static void *align_secondary_thread(void *arg)
+{
+    SecJob *job = (SecJob *)arg;
+    const snapgpu_params *p = job->p;
+    GenomeIndex *index = job->index;
+    int maxReadSize = MAX_READ_LENGTH;
+    // SingleAligner.cpp:145-173 with -om / -mpc set
+    BigAllocator *allocator = new BigAllocator(
+        BaseAligner::getBigAllocatorReservation(index, true, p->max_hits, maxReadSize, index->getSeedLength(),
+                                                p->num_seeds, p->seed_coverage, job->mpc, p->extra_search_depth) + 4096, 16);
+    BaseAligner *aligner = new (allocator) BaseAligner(
+        index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check,
+        p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0,
+        true /* ignoreAlignmentAdjustmentsForOm */, p->alt_awareness != 0, p->emit_alt_alignments != 0,
+        p->max_score_gap_to_prefer_non_alt, job->mpc, NULL, NULL,
+        p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty,
+        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator);
+    std::vector<char> bbuf(MAX_READ_LENGTH + 2 * SLACK, 0), qbuf(MAX_READ_LENGTH + 2 * SLACK, 0);
+    // the result buffer of SingleAligner.cpp:176-190: [0] primary, [1..] secondary; doubled when AlignRead says it is too small
+    _int64 bufCount = 32;
+    std::vector<SingleAlignmentResult> buf(bufCount);
+
+    for (;;) {
+        _int64 begin = __sync_fetch_and_add(&job->next, (_int64)job->chunk);
+        if (begin >= (_int64)job->n) break;
+        _int64 end = begin + job->chunk;
+        if (end > (_int64)job->n) end = job->n;
+        for (_int64 i = begin; i < end; i++) {
+            unsigned len = (unsigned)(job->offsets[i + 1] - job->offsets[i]);
+            memcpy(&bbuf[SLACK], job->bases + job->offsets[i], len);
+            memcpy(&qbuf[SLACK], job->quals + job->offsets[i], len);
+            Read read;
+            read.init("r", 1, &bbuf[SLACK], &qbuf[SLACK], len, NULL, 0);
+            SingleAlignmentResult alt;
+            memset(&alt, 0, sizeof(alt));
+            alt.status = NotFound;
+            _int64 nSecondary = 0;
+            for (;;) {
+                memset(&buf[0], 0, sizeof(SingleAlignmentResult) * bufCount);
+                if (aligner->AlignRead(&read, &buf[0], &alt, job->om, bufCount - 1, &nSecondary, job->omax, &buf[1], 0, NULL, NULL)) break;
+                bufCount *= 2;                                  // SingleAligner.cpp:250-263
+                buf.resize(bufCount);
+            }
+            fill_result(&job->primary[i], &buf[0]);
+            if (job->first_alt) {
+                if (alt.status == NotFound) {
+                    memset(&job->first_alt[i], 0, sizeof(job->first_alt[i]));
+                    job->first_alt[i].status = NotFound;
+                } else {
+                    fill_result(&job->first_alt[i], &alt);
+                }
+            }
+            job->n_secondary[i] = (uint32_t)nSecondary;
+            for (_int64 k = 0; k < nSecondary && k < (_int64)job->stride; k++) {
+                snapgpu_single_result *o = &job->secondary[(size_t)i * job->stride + k];
+                fill_result(o, &buf[1 + k]);
+                o->probability_all_candidates = 0; o->popular_seeds_skipped = 0;   // never written for a secondary result (BaseAligner.cpp:2182-2199)
+            }
+        }
+    }
+    aligner->~BaseAligner();
+    delete allocator;
+    return NULL;
+}
+
+/* BaseAligner::AlignRead with -om `om`, -omax `omax`, -mpc `mpc` (-1 = none), called as SingleAligner.cpp:250 calls it.
+ * secondary: [n * stride]; n_secondary[i] = count for read i (entries beyond stride are dropped). */
+int snapref_align_single_secondary(void *vindex, const snapgpu_params *p, int om, int64_t omax, int mpc, uint32_t n,
+                                   const char *bases, const char *quals, const uint64_t *offsets, int n_threads,
+                                   snapgpu_single_result *primary, snapgpu_single_result *first_alt,
+                                   snapgpu_single_result *secondary, uint32_t stride, uint32_t *n_secondary)
+{
+    snapref_init();
+    GenomeIndex *index = (GenomeIndex *)vindex;
+    if (index->doesGenomeIndexHave64BitLocations()) return SNAPGPU_E_UNSUPPORTED;
+    g_index = index;                                            // SingleAlignmentResult::compareByContigAndScore reads it (AlignmentResult.cpp:31)
+    SecJob job;
+    job.index = index; job.p = p; job.om = om; job.omax = omax; job.mpc = mpc; job.n = n; job.bases = bases; job.quals = quals;
+    job.offsets = offsets; job.primary = primary; job.first_alt = first_alt; job.secondary = secondary; job.stride = stride;
+    job.n_secondary = n_secondary; job.next = 0; job.chunk = 256;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<pthread_t> th(n_threads);
+    for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, align_secondary_thread, &job);
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------- paired end
 
 static void fill_paired(snapgpu_paired_result *o, const PairedAlignmentResult *r)

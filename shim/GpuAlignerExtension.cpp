@@ -44,6 +44,7 @@ extern const char *SNAP_VERSION;                                   // SNAPLib/Co
 static pthread_mutex_t g_gpuLock = PTHREAD_MUTEX_INITIALIZER;      // one context, calls serialised
 static snapgpu_ctx *g_ctx = NULL;
 static bool g_pairedEnabled = false;
+static bool g_secondaryEnabled = false;
 
 static void toSnapPaired(const snapgpu_paired_result &g, PairedAlignmentResult *r)
 {
@@ -240,12 +241,19 @@ public:
         if (c->index == NULL) {
             return false;                                   // I/O-only mode (SingleAligner.cpp:106-131): leave it to SNAP
         }
-        if (c->maxSecondaryAlignmentAdditionalEditDistance >= 0 || c->options->stopOnFirstHit || c->options->explorePopularSeeds ||
+        if (c->options->stopOnFirstHit || c->options->explorePopularSeeds ||
             !c->ignoreAlignmentAdjustmentForOm || c->index->doesGenomeIndexHave64BitLocations()) {
-            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-om, -f, -x, -sa or a 64-bit index)\n");
+            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-f, -x, -ae or a 64-bit index)\n");
             soft_exit(1);
         }
         ensureContext(c, c->numSeedsFromCommandLine);
+        const bool secondary = c->maxSecondaryAlignmentAdditionalEditDistance >= 0;      // -om
+        if (secondary) ensureSecondary(c);
+        uint32_t secStride = 8;
+        if ((_int64)secStride > (_int64)c->maxSecondaryAlignments) secStride = (uint32_t)c->maxSecondaryAlignments;
+        std::vector<snapgpu_single_result> sec;
+        std::vector<uint32_t> nSec;
+        std::vector<SingleAlignmentResult> results;
 
         // Reads are only valid until the supplier moves on, so each batch is copied.  ReadWithOwnMemory
         // points into its own body and has no copy-assignment: construct in place in raw storage.
@@ -288,7 +296,18 @@ public:
             if (0 == n) continue;
 
             pthread_mutex_lock(&g_gpuLock);
-            int rc = snapgpu_align_single(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
+            int rc;
+            if (secondary) {
+                // AlignRead with a secondary-result buffer; like SingleAligner.cpp:250-263, grow it and call again when it was too small
+                for (;;) {
+                    sec.resize((size_t)n * secStride); nSec.resize(n);
+                    rc = snapgpu_align_single_secondary(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0], &sec[0], secStride, &nSec[0]);
+                    if (rc != SNAPGPU_W_SECONDARY_TRUNCATED) break;
+                    for (unsigned i = 0; i < n; i++) if (nSec[i] > secStride) secStride = nSec[i];
+                }
+            } else {
+                rc = snapgpu_align_single(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
+            }
             pthread_mutex_unlock(&g_gpuLock);
             if (rc != SNAPGPU_OK) {
                 WriteErrorMessage("snapgpu_align_single failed (%d): %s\n", rc, snapgpu_last_error(g_ctx));
@@ -300,13 +319,21 @@ public:
                 toSnap(prim[i], &result);
                 bool containsPrimary = true;
                 if (NULL != c->readWriter) {
-                    // SingleAligner.cpp:300-322 with no secondary results
-                    _int64 nResults = 1;
-                    if (!c->options->passFilter(&reads[i], result.status, false, false)) {
-                        containsPrimary = false;
-                        nResults = 0;
+                    // SingleAligner.cpp:293-318: drop what the filter rejects (the last result moves into the hole), write the rest
+                    _int64 nSecondaryResults = secondary ? (_int64)nSec[i] : 0;
+                    results.resize((size_t)nSecondaryResults + 1);
+                    results[0] = result;
+                    for (_int64 k = 0; k < nSecondaryResults; k++) toSnap(sec[(size_t)i * secStride + k], &results[1 + k]);
+                    for (_int64 k = 0; k <= nSecondaryResults; k++) {
+                        if (!c->options->passFilter(&reads[i], results[k].status, false, k != 0 || !containsPrimary)) {
+                            if (k == 0) containsPrimary = false;
+                            results[k] = results[nSecondaryResults];
+                            nSecondaryResults--;
+                            k--;
+                        }
                     }
-                    c->readWriter->writeReads(c->readerContext, &reads[i], &result, nResults, containsPrimary, c->useAffineGap);
+                    c->stats->extraAlignments += nSecondaryResults + (containsPrimary ? 0 : 1);
+                    c->readWriter->writeReads(c->readerContext, &reads[i], &results[0], nSecondaryResults + 1, containsPrimary, c->useAffineGap);
                     if (c->altAwareness && alt[i].status != SNAPGPU_NotFound) {
                         toSnap(alt[i], &altResult);
                         if (c->options->passFilter(&reads[i], altResult.status, false, false)) {
@@ -361,6 +388,25 @@ private:
     }
 
     // numSeeds: -n for the single-end aligner (the paired path hands its own -n to snapgpu_enable_paired)
+    static void ensureSecondary(AlignerContext *c)
+    {
+        pthread_mutex_lock(&g_gpuLock);
+        if (!g_secondaryEnabled) {
+            snapgpu_secondary_params sp;
+            sp.max_edit_distance = c->maxSecondaryAlignmentAdditionalEditDistance;      // -om
+            sp.max_per_contig = c->maxSecondaryAlignmentsPerContig;                     // -mpc
+            sp.max_results = c->maxSecondaryAlignments;                                 // -omax
+            sp.adjust_alignments = c->ignoreAlignmentAdjustmentForOm ? 0 : 1;           // -ae
+            int rc = snapgpu_enable_secondary(g_ctx, &sp);
+            if (rc != SNAPGPU_OK) {
+                WriteErrorMessage("snapgpu_enable_secondary failed (%d): %s\n", rc, snapgpu_last_error(g_ctx));
+                soft_exit(1);
+            }
+            g_secondaryEnabled = true;
+        }
+        pthread_mutex_unlock(&g_gpuLock);
+    }
+
     static void ensureContext(AlignerContext *c, unsigned numSeeds)
     {
         pthread_mutex_lock(&g_gpuLock);

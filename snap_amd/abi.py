@@ -135,6 +135,22 @@ class PairedParams(C.Structure):
     ]
 
 
+class SecondaryParams(C.Structure):
+    """snapgpu_secondary_params: -om / -mpc / -omax / -ae (AlignerOptions.cpp:70-72, 96)."""
+    _fields_ = [
+        ("max_edit_distance", C.c_int32),
+        ("max_per_contig", C.c_int32),
+        ("max_results", C.c_int64),
+        ("adjust_alignments", C.c_uint32),
+    ]
+
+
+def secondary_params(max_edit_distance: int, max_results: int = 0x7fffffff, max_per_contig: int = -1,
+                     adjust_alignments: int = 0) -> SecondaryParams:
+    return SecondaryParams(max_edit_distance=max_edit_distance, max_per_contig=max_per_contig, max_results=max_results,
+                           adjust_alignments=adjust_alignments)
+
+
 def default_paired_params(**overrides) -> PairedParams:
     """PairedAlignerOptions defaults, PairedAligner.cpp:55-57, 227-242; AlignerOptions.cpp:103-110."""
     p = PairedParams(min_spacing=0, max_spacing=1000, force_spacing=0, max_big_hits=4000,

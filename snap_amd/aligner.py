@@ -49,6 +49,7 @@ EXPORTED_SYMBOLS = [
     "snapgpu_align_paired", "snapgpu_align_paired_device", "snapgpu_index_device_ptrs", "snapgpu_lookup_seeds",
     "snapgpu_landau_vishkin", "snapgpu_affine_gap", "snapgpu_align_single",
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
+    "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
 ]
 
 
@@ -195,6 +196,34 @@ class BaseAligner:
         self._check(self.lib.snapgpu_align_single(self.handle, C.c_uint32(n), ptr(bases), ptr(quals), ptr(offsets),
                                                   ptr(primary), ptr(first_alt)), "snapgpu_align_single")
         return primary, first_alt
+
+    # ---- BaseAligner::AlignRead with secondary results (-om / -omax / -mpc) --------------
+    def enable_secondary(self, max_edit_distance: int, max_results: int = 0x7fffffff, max_per_contig: int = -1,
+                         adjust_alignments: int = 0):
+        from .abi import secondary_params
+        sp = secondary_params(max_edit_distance, max_results, max_per_contig, adjust_alignments)
+        self._check(self.lib.snapgpu_enable_secondary(self.handle, C.byref(sp)), "snapgpu_enable_secondary")
+        self._sec_max = max_results
+
+    def AlignReadSecondary(self, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray, stride: int = 16):
+        """Returns (primary[n], firstALT[n], secondary[n, stride'], nSecondary[n]); like the reference's caller
+        (SingleAligner.cpp:250-263) it grows the buffer and calls again when a read has more results than fit."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = offsets.size - 1
+        primary = np.zeros(n, dtype=RESULT_DTYPE)
+        first_alt = np.zeros(n, dtype=RESULT_DTYPE)
+        while True:
+            secondary = np.zeros((n, stride), dtype=RESULT_DTYPE)
+            n_sec = np.zeros(n, dtype=np.uint32)
+            rc = self.lib.snapgpu_align_single_secondary(self.handle, C.c_uint32(n), ptr(bases), ptr(quals), ptr(offsets),
+                                                         ptr(primary), ptr(first_alt), ptr(secondary), C.c_uint32(stride), ptr(n_sec))
+            if rc == 1:                                   # SNAPGPU_W_SECONDARY_TRUNCATED
+                stride = int(n_sec.max())
+                continue
+            self._check(rc, "snapgpu_align_single_secondary")
+            return primary, first_alt, secondary, n_sec
 
     def align_device(self, n: int, d_bases: int, d_quals: int, d_offsets: int, d_primary: int, d_first_alt: int = 0,
                      stream: int = 0):

@@ -125,7 +125,16 @@ struct WaveShared {                    // per-wave LDS block (see Aligner)
     WaveCounters cnt;
 };
 
-template <int AGC>
+// Secondary alignments (-om / -omax / -mpc): what AlignRead's secondaryResults buffer and finalizeSecondaryResults do
+// (BaseAligner.cpp:2174-2200, 2245-2271, 2423-2553).  Per-wave HBM scratch, sized so that it cannot overflow.
+struct SecCfg {
+    int32_t  om;                       // maxEditDistanceForSecondaryResults (>= 0 when enabled)
+    int32_t  mpc;                      // maxSecondaryAlignmentsPerContig (-1: unlimited)
+    int64_t  omax;                     // maxSecondaryResults
+    uint32_t cap;                      // entries of per-wave scratch
+};
+
+template <int AGC, bool SEC = false>
 struct Aligner {
     // ---- constant for the launch
     // held by value: a reference member would make the kernel-argument struct escape through a
@@ -160,6 +169,11 @@ struct Aligner {
     // candidates for BaseAligner::alignAffineGap, collected by the Hamming pass only (BaseAligner.cpp:1445-1456)
     snapgpu_single_result *agc;
     uint32_t agc_cap, n_agc, agc_overflow;
+    // secondary results (SEC only): the list AlignRead appends to, then finalizeSecondaryResults' working arrays
+    SecCfg sec_cfg;
+    snapgpu_single_result *sec;        // [sec_cfg.cap]
+    uint32_t *sec_key, *sec_ord;       // [sec_cfg.cap] each
+    uint32_t n_sec, sec_overflow;
     // Cold, wave-uniform state lives in LDS (WaveShared), not in registers: it is touched a few
     // times per candidate / per read, and keeping ~150 dwords of it live across the LV and
     // affine-gap code is what pushed the kernel to 1-2 waves per SIMD.  Every lane executes the
@@ -371,7 +385,24 @@ struct Aligner {
         n_agc++;
     }
 
-    // ScoreSet::updateBestScore without secondary results (BaseAligner.cpp:2143-2299); HAM keeps affine-gap candidates
+    // one entry of secondaryResults (BaseAligner.cpp:2182-2199 / :2253-2270).  The scratch holds 2 entries per scored candidate,
+    // which is all updateBestScore can produce, so there is no overflow path (the reference doubles its buffer and re-runs).
+    __device__ __forceinline__ void record_secondary(int dir, int64_t loc, int64_t orig_loc, int score, int used_ag, int clip_before,
+                                                     int clip_after, int ag_score, double mp, int seed_offset) {
+        if (n_sec >= sec_cfg.cap) { sec_overflow = 1; return; }            // (sized so that it cannot happen, see snapgpu_enable_secondary)
+        snapgpu_single_result *r = &sec[n_sec];
+        if (lane == 0) {
+            r->status = SNAPGPU_MultipleHits; r->direction = dir; r->location = loc; r->orig_location = orig_loc; r->score = score;
+            r->score_prior_to_clipping = 0; r->mapq = 0; r->clipping_for_read_adjustment = 0; r->used_affine_gap_scoring = used_ag;
+            r->bases_clipped_before = clip_before; r->bases_clipped_after = clip_after; r->ag_score = ag_score; r->supplementary = 0;
+            r->seed_offset = seed_offset; r->match_probability = mp; r->probability_all_candidates = 0.0; r->popular_seeds_skipped = 0;
+            r->reserved = 0;
+        }
+        WAVE_SYNC();
+        n_sec++;
+    }
+
+    // ScoreSet::updateBestScore (BaseAligner.cpp:2143-2299); SEC keeps secondary results, HAM keeps affine-gap candidates
     template <bool HAM>
     __device__ __forceinline__ bool update_best(ScoreSet &ss, int64_t loc, int64_t orig_loc, uint32_t score,
                                                 int ag_score, double mp, const Elem *e, int e_dir,
@@ -382,6 +413,17 @@ struct Aligner {
             seen_new = (ag_score > ss.ag_score) || (ss.ag_score == ag_score && mp > ss.p_best);
         } else {
             seen_new = (score < (uint32_t)ss.best_score) || (score == (uint32_t)ss.best_score && mp > ss.p_best);
+        }
+        if constexpr (SEC) {
+            const uint32_t best = (uint32_t)ss.best_score;
+            if (seen_new) {
+                if (best >= score && (int)(best - score) <= sec_cfg.om) {                              // the displaced best, :2176
+                    record_secondary(ss.dir, ss.best_loc, ss.best_orig_loc, ss.best_score, ss.used_ag, ss.clip_before, ss.clip_after,
+                                     ss.ag_score, ss.best_match_prob, ss.seed_offset);
+                }
+            } else if ((int)(best - score) <= sec_cfg.om && score != (uint32_t)SNAPGPU_ScoreAboveLimit && best >= score) {              // :2247
+                record_secondary(e_dir, loc, orig_loc, (int)score, e_used_ag, e_clip_before, e_clip_after, ag_score, e_match_prob, e_seed_offset);
+            }
         }
         if constexpr (HAM) {
             const uint32_t best = (uint32_t)ss.best_score;
@@ -745,7 +787,7 @@ struct Aligner {
 
                     // early out: nothing can rescue MAPQ once the candidates' total probability reaches 4.9 (:1512)
                     double p_chk = cfg.alt_aware ? non_alt.p_all : all.p_all;
-                    if (p_chk >= 4.9) {
+                    if (!SEC && p_chk >= 4.9) {                                                 // (&& -1 == maxEditDistanceForSecondaryResults)
                         if (cfg.alt_aware) fill_result(non_alt, primary); else fill_result(all, primary);
                         first_alt.status = SNAPGPU_NotFound;
                         return true;
@@ -780,6 +822,7 @@ struct Aligner {
     template <bool HAM>
     __device__ __forceinline__ void align_read_inner(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         read_len = len;
+        if constexpr (SEC) { n_sec = 0; sec_overflow = 0; }                   // *nSecondaryResults = 0, :318-320
         // result = NotFound (:334-344); remaining fields as a zero-initialised struct
         primary.status = SNAPGPU_NotFound; primary.direction = 0;
         primary.location = SNAPGPU_InvalidGenomeLocation32; primary.orig_location = 0;
@@ -905,6 +948,108 @@ struct Aligner {
         primary.score_prior_to_clipping = primary.score;                      // finalizeSecondaryResults, :2442
         primary.reserved = ag_stale;
         release_candidates();
+        if constexpr (SEC) finalize_secondary();
+    }
+
+    // ------------------------------------------------------------------ BaseAligner::finalizeSecondaryResults (BaseAligner.cpp:2423-2553)
+    // with ignoreAlignmentAdjustmentsForOm (the default, AlignerOptions.cpp:96).  Works on an index list (sec_ord) and a key per
+    // entry (sec_key); the records themselves move once, when the kernel copies sec[sec_ord[k]] out.
+    __device__ __forceinline__ int contig_of(int64_t loc) const {             // Genome::getContigNumAtLocation (Genome.cpp:560-600)
+        int lo = 0, hi = (int)ix.n_contigs - 1;                               // last contig whose beginning <= loc
+        while (lo < hi) {
+            int mid = (lo + hi + 1) >> 1;
+            if ((int64_t)ix.contig_begin[mid] <= loc) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    }
+    // stable sort of sec_ord[0..n) by sec_key[sec_ord[.]] -- what glibc's merge-sorting qsort leaves (:2516, :2550).
+    // Rank by counting: O(n^2 / 64); n is a handful outside repeats.
+    __device__ __forceinline__ void sec_stable_sort(uint32_t n) {
+        uint32_t *tmp = sec_key + sec_cfg.cap;                                // second half of the key array: [cap, 2*cap)
+        for (uint32_t i0 = 0; i0 < n; i0 += WAVE) {
+            const uint32_t i = i0 + (uint32_t)lane;
+            if (i < n) {
+                const uint32_t me = sec_ord[i], k = sec_key[me];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < n; j++) {
+                    const uint32_t kj = sec_key[sec_ord[j]];
+                    rank += (kj < k || (kj == k && j < i)) ? 1u : 0u;
+                }
+                tmp[rank] = me;
+            }
+        }
+        WAVE_SYNC(); __threadfence_block();
+        for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) sec_ord[i] = tmp[i];
+        WAVE_SYNC(); __threadfence_block();
+    }
+    __device__ __forceinline__ void finalize_secondary() {
+        uint32_t n = n_sec;
+        if (n == 0) return;
+        const int best = (int)first_u32((uint32_t)primary.score);
+        int worst = best + sec_cfg.om; if (worst > (int)max_k) worst = (int)max_k;     // :2465
+        for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) { sec_ord[i] = i; sec_key[i] = (uint32_t)sec[i].score; }
+        WAVE_SYNC(); __threadfence_block();
+        // :2467-2485: drop what is now too far from the best, moving the last entry into the hole (order matters downstream)
+        if (lane == 0) {
+            uint32_t i = 0;
+            while (i < n) {
+                if ((int)sec_key[sec_ord[i]] > worst) { sec_ord[i] = sec_ord[n - 1]; n--; }
+                else i++;
+            }
+        }
+        n = first_u32(n);
+        WAVE_SYNC(); __threadfence_block();
+        for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
+            snapgpu_single_result *r = &sec[sec_ord[i]];
+            r->score_prior_to_clipping = r->score;
+            r->supplementary = (cfg.alt_aware && is_alt(r->location)) ? 1 : 0;
+        }
+        WAVE_SYNC(); __threadfence_block();
+        if (sec_cfg.mpc > 0 && primary.status != SNAPGPU_NotFound && n > 0) {           // :2487-2547
+            const int primary_contig = contig_of(primary.location);
+            // key = (contig, score); scores here are <= max_k <= 127
+            for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
+                const uint32_t me = sec_ord[i];
+                sec_key[me] = ((uint32_t)contig_of(sec[me].location) << 8) | (uint32_t)(sec[me].score & 0xff);
+            }
+            WAVE_SYNC(); __threadfence_block();
+            // does any contig hold more than mpc (the primary counts for its own)?
+            uint32_t too_many = 0;
+            for (uint32_t i0 = 0; i0 < n; i0 += WAVE) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                bool over = false;
+                if (i < n) {
+                    const uint32_t c = sec_key[sec_ord[i]] >> 8;
+                    int count = (int)c == primary_contig ? 1 : 0;
+                    for (uint32_t j = 0; j < n; j++) count += (sec_key[sec_ord[j]] >> 8) == c ? 1 : 0;
+                    over = count > sec_cfg.mpc;
+                }
+                too_many |= BALLOT(over) != 0 ? 1u : 0u;
+            }
+            if (too_many) {
+                sec_stable_sort(n);                                           // compareByContigAndScore
+                if (lane == 0) {
+                    int cur = -1, cur_count = 0; uint32_t dest = 0;
+                    for (uint32_t src = 0; src < n; src++) {
+                        const uint32_t me = sec_ord[src];
+                        const int c = (int)(sec_key[me] >> 8);
+                        if (c != cur) { cur = c; cur_count = c == primary_contig ? 1 : 0; }
+                        cur_count++;
+                        if (cur_count <= sec_cfg.mpc) sec_ord[dest++] = me;
+                    }
+                    n = dest;
+                }
+                n = first_u32(n);
+                WAVE_SYNC(); __threadfence_block();
+            }
+        }
+        if ((int64_t)n > sec_cfg.omax) {                                      // :2549-2552
+            for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) { const uint32_t me = sec_ord[i]; sec_key[me] = (uint32_t)sec[me].score; }
+            WAVE_SYNC(); __threadfence_block();
+            sec_stable_sort(n);                                               // compareByScore
+            n = (uint32_t)sec_cfg.omax;
+        }
+        n_sec = n;
     }
 
     // ------------------------------------------------------------------ BaseAligner::scoreLocationWithAffineGap (BaseAligner.cpp:766-915)

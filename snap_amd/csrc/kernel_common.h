@@ -14,7 +14,21 @@ struct AlignArgs {
     snapgpu_single_result *primary, *first_alt;
     uint32_t *work_counter;
     unsigned long long *counters;     // snapgpu_counters layout
+    // secondary results (k_align_single<.., true> only)
+    SecCfg sec_cfg;
+    uint8_t *sec_scratch;             // n_wave_slots * sec_stride_bytes
+    uint64_t sec_stride_bytes;
+    snapgpu_single_result *secondary; // [n_reads * sec_out_stride]
+    uint32_t sec_out_stride;
+    uint32_t *n_secondary;            // [n_reads]: how many the read has (may exceed sec_out_stride: only that many are stored)
 };
+
+extern "C" {
+void snapgpu_launch_single_sec_3(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_sec_4(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_sec_6(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_sec_0(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+}
 
 static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
 

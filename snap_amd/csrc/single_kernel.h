@@ -1,0 +1,100 @@
+// single_kernel.h -- the single-end kernel: one wavefront per read, persistent grid, atomic work counter.
+// SEC = with secondary results (-om); a separate instantiation so that the default kernel carries none of it.
+#pragma once
+#include "kernel_common.h"
+
+// Latency-bound kernel: ask for 4 waves per SIMD (<= 128 VGPRs; costs ~24 spilled VGPRs of cold state).
+#ifndef SNAPGPU_WAVES_PER_SIMD
+#define SNAPGPU_WAVES_PER_SIMD 4
+#endif
+template <int AGC, bool SEC>
+__global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD) void k_align_single(AlignArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: keeps the LDS/scratch pointers in SGPRs
+    const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
+    const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax, a.cfg.use_ag);
+    uint8_t *my = lds + (size_t)wave_in_block * L.total;
+
+    WaveShared *ws = (WaveShared *)(my + L.shared);
+    Aligner<AGC, SEC> al(a.ix, a.tab, a.cfg, ws);
+    al.lane = lane;
+    al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
+    al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
+    al.gw = my + L.gw;
+    al.seed_used = (uint32_t *)(my + L.seed_used);
+    al.wl_next = (uint16_t *)(my + L.wl_next);
+    al.wl_prev = (uint16_t *)(my + L.wl_prev);
+    al.lv_tri = (uint16_t *)(my + L.lv);
+    al.ag_rows = (int16_t *)(my + L.ag);
+    uint8_t *sc = a.scratch + (size_t)wave_slot * a.cfg.scratch_stride;
+    al.heads = (uint16_t *)sc;
+    al.pool = (Elem *)(sc + (size_t)a.cfg.ht_size * 2);
+    al.ag_scratch = sc + (size_t)a.cfg.ht_size * 2 + (size_t)a.cfg.pool_size * sizeof(Elem);
+    if constexpr (SEC) {            // secondary-result scratch of this wave (snapgpu_enable_secondary)
+        uint8_t *ss = a.sec_scratch + (size_t)wave_slot * a.sec_stride_bytes;
+        al.sec_cfg = a.sec_cfg;
+        al.sec = (snapgpu_single_result *)ss;
+        al.sec_key = (uint32_t *)(ss + (size_t)a.sec_cfg.cap * sizeof(snapgpu_single_result));
+        al.sec_ord = al.sec_key + 2 * (size_t)a.sec_cfg.cap;
+        al.n_sec = 0;
+    }
+    al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t n_done = 0;
+
+    while (true) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
+        i = first_u32(i);
+        if (i >= a.n_reads) break;
+        uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
+        al.align_read(a.bases + b, a.quals + b, (int)(e - b));
+        WAVE_SYNC();
+        {   // results: LDS -> global, one dword per lane
+            const uint32_t *src = (const uint32_t *)&ws->primary;
+            uint32_t *dst = (uint32_t *)&a.primary[i];
+            const int nd = (int)(sizeof(snapgpu_single_result) / 4);
+            if (lane < nd) dst[lane] = src[lane];
+            if (a.first_alt) {
+                const uint32_t *src2 = (const uint32_t *)&ws->first_alt;
+                uint32_t *dst2 = (uint32_t *)&a.first_alt[i];
+                if (lane < nd) dst2[lane] = src2[lane];
+            }
+        }
+        WAVE_SYNC();
+        if constexpr (SEC) {        // secondary results: sec[sec_ord[k]] -> secondary[i * stride + k], 22 dwords per record, two records per pass
+            const uint32_t n_sec = al.n_sec;
+            if (lane == 0) a.n_secondary[i] = al.sec_overflow ? 0xFFFFFFFFu : n_sec;       // (the host turns the marker into an error)
+            const uint32_t n_out = n_sec < a.sec_out_stride ? n_sec : a.sec_out_stride;
+            const int nd = (int)(sizeof(snapgpu_single_result) / 4);
+            for (uint32_t k0 = 0; k0 < n_out; k0 += 2) {
+                const uint32_t k = k0 + (uint32_t)(lane >> 5);
+                const int w = lane & 31;
+                if (k < n_out && w < nd) {
+                    const uint32_t *src = (const uint32_t *)&al.sec[al.sec_ord[k]];
+                    uint32_t *dst = (uint32_t *)&a.secondary[(size_t)i * a.sec_out_stride + k];
+                    dst[w] = src[w];
+                }
+            }
+            WAVE_SYNC();
+        }
+        n_done++;
+    }
+    if (lane == 0) {
+        atomicAdd(&a.counters[0], (unsigned long long)n_done);
+        atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
+        atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
+        atomicAdd(&a.counters[3], (unsigned long long)al.cnt.hits);
+        atomicAdd(&a.counters[4], (unsigned long long)al.cnt.overflow_lists);
+        atomicAdd(&a.counters[5], (unsigned long long)al.cnt.lv);
+        atomicAdd(&a.counters[6], (unsigned long long)al.cnt.ag);
+        atomicAdd(&a.counters[7], (unsigned long long)al.cnt.lv_ref_bytes);
+        atomicAdd(&a.counters[8], (unsigned long long)al.cnt.cyc_lookup);
+        atomicAdd(&a.counters[9], (unsigned long long)al.cnt.cyc_hits);
+        atomicAdd(&a.counters[10], (unsigned long long)al.cnt.cyc_lv);
+        atomicAdd(&a.counters[11], (unsigned long long)al.cnt.cyc_ag);
+        atomicAdd(&a.counters[12], (unsigned long long)al.cnt.cyc_total);
+    }
+}
+

@@ -20,82 +20,14 @@
 #include "ag_win.h"
 #include "align_single.h"
 #include "kernel_common.h"
+#include "single_kernel.h"
 #include "paired_args.h"
 
 // =====================================================================================
 // kernels
 // =====================================================================================
 
-// Latency-bound kernel: ask for 4 waves per SIMD (<= 128 VGPRs; costs ~24 spilled VGPRs of cold state).
-#ifndef SNAPGPU_WAVES_PER_SIMD
-#define SNAPGPU_WAVES_PER_SIMD 4
-#endif
-template <int AGC>
-__global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD) void k_align_single(AlignArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int lane = lane_id();
-    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: keeps the LDS/scratch pointers in SGPRs
-    const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
-    const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax, a.cfg.use_ag);
-    uint8_t *my = lds + (size_t)wave_in_block * L.total;
-
-    WaveShared *ws = (WaveShared *)(my + L.shared);
-    Aligner<AGC> al(a.ix, a.tab, a.cfg, ws);
-    al.lane = lane;
-    al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
-    al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
-    al.gw = my + L.gw;
-    al.seed_used = (uint32_t *)(my + L.seed_used);
-    al.wl_next = (uint16_t *)(my + L.wl_next);
-    al.wl_prev = (uint16_t *)(my + L.wl_prev);
-    al.lv_tri = (uint16_t *)(my + L.lv);
-    al.ag_rows = (int16_t *)(my + L.ag);
-    uint8_t *sc = a.scratch + (size_t)wave_slot * a.cfg.scratch_stride;
-    al.heads = (uint16_t *)sc;
-    al.pool = (Elem *)(sc + (size_t)a.cfg.ht_size * 2);
-    al.ag_scratch = sc + (size_t)a.cfg.ht_size * 2 + (size_t)a.cfg.pool_size * sizeof(Elem);
-    al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t n_done = 0;
-
-    while (true) {
-        uint32_t i = 0;
-        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
-        i = first_u32(i);
-        if (i >= a.n_reads) break;
-        uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
-        al.align_read(a.bases + b, a.quals + b, (int)(e - b));
-        WAVE_SYNC();
-        {   // results: LDS -> global, one dword per lane
-            const uint32_t *src = (const uint32_t *)&ws->primary;
-            uint32_t *dst = (uint32_t *)&a.primary[i];
-            const int nd = (int)(sizeof(snapgpu_single_result) / 4);
-            if (lane < nd) dst[lane] = src[lane];
-            if (a.first_alt) {
-                const uint32_t *src2 = (const uint32_t *)&ws->first_alt;
-                uint32_t *dst2 = (uint32_t *)&a.first_alt[i];
-                if (lane < nd) dst2[lane] = src2[lane];
-            }
-        }
-        WAVE_SYNC();
-        n_done++;
-    }
-    if (lane == 0) {
-        atomicAdd(&a.counters[0], (unsigned long long)n_done);
-        atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
-        atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
-        atomicAdd(&a.counters[3], (unsigned long long)al.cnt.hits);
-        atomicAdd(&a.counters[4], (unsigned long long)al.cnt.overflow_lists);
-        atomicAdd(&a.counters[5], (unsigned long long)al.cnt.lv);
-        atomicAdd(&a.counters[6], (unsigned long long)al.cnt.ag);
-        atomicAdd(&a.counters[7], (unsigned long long)al.cnt.lv_ref_bytes);
-        atomicAdd(&a.counters[8], (unsigned long long)al.cnt.cyc_lookup);
-        atomicAdd(&a.counters[9], (unsigned long long)al.cnt.cyc_hits);
-        atomicAdd(&a.counters[10], (unsigned long long)al.cnt.cyc_lv);
-        atomicAdd(&a.counters[11], (unsigned long long)al.cnt.cyc_ag);
-        atomicAdd(&a.counters[12], (unsigned long long)al.cnt.cyc_total);
-    }
-}
+// k_align_single: single_kernel.h
 
 // One wave per seed: GenomeIndex::lookupSeed32 for a batch of seeds.
 __global__ __launch_bounds__(256) void k_lookup_seeds(DevIndex ix, uint32_t n, const uint8_t *seeds,
@@ -235,6 +167,13 @@ struct snapgpu_ctx {
     uint64_t kernel_launches = 0;
     int num_cus = 0;
     int ag_variant = 0;               // chunks of 64 striped positions the affine-gap kernel variant holds in registers (0 = LDS form)
+    // secondary results (snapgpu_enable_secondary)
+    bool secondary = false;
+    SecCfg sec_cfg{};
+    uint8_t *d_sec_scratch = nullptr;
+    uint64_t sec_stride_bytes = 0;
+    void *d_sec_stage[2] = {nullptr, nullptr};       // secondary records, counts (host-pointer entry point)
+    size_t sec_stage_cap[2] = {0, 0};
     // paired-end path (snapgpu_enable_paired)
     bool paired = false;
     snapgpu_paired_params pparams{};
@@ -364,6 +303,8 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
         if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
         if (ctx->d_genome_padded) (void)hipFree(ctx->d_genome_padded);
     }
+    if (ctx->d_sec_scratch) (void)hipFree(ctx->d_sec_scratch);
+    for (int i = 0; i < 2; i++) if (ctx->d_sec_stage[i]) (void)hipFree(ctx->d_sec_stage[i]);
     if (ctx->d_table_offset) (void)hipFree(ctx->d_table_offset);
     if (ctx->d_table_size) (void)hipFree(ctx->d_table_size);
     if (ctx->d_contig_begin) (void)hipFree(ctx->d_contig_begin);
@@ -819,22 +760,34 @@ extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
 }
 
 static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals, const void *d_offsets,
-                        void *d_primary, void *d_first_alt, hipStream_t s)
+                        void *d_primary, void *d_first_alt, hipStream_t s,
+                        void *d_secondary = nullptr, uint32_t sec_out_stride = 0, void *d_n_secondary = nullptr)
 {
     AlignArgs a;
     a.ix = ctx->ix; a.cfg = ctx->cfg; a.tab = ctx->d_tab; a.scratch = ctx->d_scratch;
     a.bases = (const uint8_t *)d_bases; a.quals = (const uint8_t *)d_quals; a.offsets = (const uint64_t *)d_offsets;
     a.n_reads = n; a.primary = (snapgpu_single_result *)d_primary; a.first_alt = (snapgpu_single_result *)d_first_alt;
     a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
+    a.sec_cfg = SecCfg{-1, -1, 0, 0}; a.sec_scratch = nullptr; a.sec_stride_bytes = 0; a.secondary = nullptr; a.sec_out_stride = 0; a.n_secondary = nullptr;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
     uint32_t blocks = ctx->n_wave_slots / 4;
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    if (d_n_secondary) {
+        a.sec_cfg = ctx->sec_cfg; a.sec_scratch = ctx->d_sec_scratch; a.sec_stride_bytes = ctx->sec_stride_bytes;
+        a.secondary = (snapgpu_single_result *)d_secondary; a.sec_out_stride = sec_out_stride; a.n_secondary = (uint32_t *)d_n_secondary;
+        switch (ctx->ag_variant) {
+        case 3:  snapgpu_launch_single_sec_3(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
+        case 4:  snapgpu_launch_single_sec_4(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
+        case 6:  snapgpu_launch_single_sec_6(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
+        default: snapgpu_launch_single_sec_0(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
+        }
+    } else
     switch (ctx->ag_variant) {
-    case 3:  hipLaunchKernelGGL(k_align_single<3>, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
-    case 4:  hipLaunchKernelGGL(k_align_single<4>, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
-    case 6:  hipLaunchKernelGGL(k_align_single<6>, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
-    default: hipLaunchKernelGGL(k_align_single<0>, dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
+    case 3:  hipLaunchKernelGGL((k_align_single<3, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
+    case 4:  hipLaunchKernelGGL((k_align_single<4, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
+    case 6:  hipLaunchKernelGGL((k_align_single<6, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
+    default: hipLaunchKernelGGL((k_align_single<0, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
     }
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
@@ -887,6 +840,106 @@ extern "C" int snapgpu_align_single(snapgpu_ctx *ctx, uint32_t n, const char *ba
     if (first_alt) HIPCHK(ctx, hipMemcpyAsync(first_alt, ctx->d_stage[4], (size_t)n * sizeof(snapgpu_single_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
     return finish_timing(ctx);
+}
+
+// =====================================================================================
+// secondary results (-om / -omax / -mpc)
+// =====================================================================================
+
+extern "C" int snapgpu_enable_secondary(snapgpu_ctx *ctx, const snapgpu_secondary_params *sp)
+{
+    if (!ctx || !sp) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_secondary: null argument");
+    if (sp->max_edit_distance < 0) return fail(ctx, SNAPGPU_E_INVALID, "-om must be >= 0 (AlignerOptions.cpp:604)");
+    if (sp->max_edit_distance > (int)ctx->params.extra_search_depth)
+        return fail(ctx, SNAPGPU_E_INVALID, "the max edit distance for secondary alignments (-om) cannot be bigger than the extra search depth (-D) (AlignerContext.cpp:784)");
+    if (sp->max_results <= 0) return fail(ctx, SNAPGPU_E_INVALID, "-omax must be strictly positive (AlignerOptions.cpp:621)");
+    if (sp->max_per_contig == 0 || sp->max_per_contig < -1) return fail(ctx, SNAPGPU_E_INVALID, "-mpc must be strictly positive, or -1 for no limit (AlignerOptions.cpp:650)");
+    if (sp->adjust_alignments) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "-ae (AlignmentAdjuster before the -om filter, BaseAligner.cpp:2444-2463) is not implemented");
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    // updateBestScore appends at most one entry per ScoreSet per scored candidate, and a read scores at most one candidate per
+    // seed hit it applied: maxSeedsToUse * maxHits hits, two score sets (BaseAligner.cpp:451, 627, 1445-1468).
+    uint64_t seeds = ctx->params.num_seeds ? ctx->params.num_seeds
+                   : (uint64_t)(2 * ctx->params.seed_coverage * ctx->params.max_read_len / ctx->ix.seed_len) + 1;
+    // (the seed loop tests nSeedsApplied[F] + nSeedsApplied[RC] < maxSeedsToUse and one pass can apply both directions: seeds + 1)
+    uint64_t cap = 2 * (seeds + 1) * ctx->params.max_hits + 2;
+    if (cap > (1u << 20)) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "2 * seeds * max_hits > 2^20 secondary candidates per read is not supported");
+    uint64_t stride = cap * sizeof(snapgpu_single_result) + cap * 3 * 4;
+    stride = (stride + 255) & ~(uint64_t)255;
+    if (ctx->d_sec_scratch) { (void)hipFree(ctx->d_sec_scratch); ctx->d_sec_scratch = nullptr; }
+    ctx->secondary = false;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_sec_scratch, stride * ctx->n_wave_slots), SNAPGPU_E_NOMEM);
+    ctx->sec_cfg = SecCfg{sp->max_edit_distance, sp->max_per_contig, sp->max_results, (uint32_t)cap};
+    ctx->sec_stride_bytes = stride;
+    ctx->secondary = true;
+    return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_align_single_secondary_device(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals,
+                                                     const void *d_offsets, void *d_primary, void *d_first_alt,
+                                                     void *d_secondary, uint32_t secondary_stride, void *d_n_secondary, void *stream)
+{
+    if (!ctx || !d_bases || !d_quals || !d_offsets || !d_primary || !d_n_secondary || (secondary_stride && !d_secondary))
+        return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_single_secondary_device: null argument");
+    if (!ctx->secondary) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_secondary has not been called on this context");
+    if (n == 0) return SNAPGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    int rc = launch_align(ctx, n, d_bases, d_quals, d_offsets, d_primary, d_first_alt, s, d_secondary, secondary_stride, d_n_secondary);
+    if (rc) return rc;
+    if (!stream) return finish_timing(ctx);
+    return SNAPGPU_OK;
+}
+
+static int ensure_sec_stage(snapgpu_ctx *ctx, int which, size_t bytes) {
+    if (ctx->sec_stage_cap[which] >= bytes) return 0;
+    if (ctx->d_sec_stage[which]) (void)hipFree(ctx->d_sec_stage[which]);
+    ctx->d_sec_stage[which] = nullptr; ctx->sec_stage_cap[which] = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(ctx, hipMalloc(&ctx->d_sec_stage[which], cap), SNAPGPU_E_NOMEM);
+    ctx->sec_stage_cap[which] = cap;
+    return 0;
+}
+
+extern "C" int snapgpu_align_single_secondary(snapgpu_ctx *ctx, uint32_t n, const char *bases, const char *quals,
+                                              const uint64_t *offsets, snapgpu_single_result *primary, snapgpu_single_result *first_alt,
+                                              snapgpu_single_result *secondary, uint32_t secondary_stride, uint32_t *n_secondary)
+{
+    if (!ctx || !bases || !quals || !offsets || !primary || !n_secondary || (secondary_stride && !secondary))
+        return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_single_secondary: null argument");
+    if (!ctx->secondary) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_secondary has not been called on this context");
+    if (n == 0) return SNAPGPU_OK;
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, SNAPGPU_E_INVALID, "offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] > ctx->params.max_read_len)
+            return fail(ctx, SNAPGPU_E_INVALID, "read longer than max_read_len given at snapgpu_create (BaseAligner.cpp:354-358)");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    size_t nb = (size_t)offsets[n];
+    const size_t sec_bytes = (size_t)n * secondary_stride * sizeof(snapgpu_single_result);
+    int rc;
+    if ((rc = ensure_stage(ctx, 0, nb + 16)) || (rc = ensure_stage(ctx, 1, nb + 16)) || (rc = ensure_stage(ctx, 2, ((size_t)n + 1) * 8)) ||
+        (rc = ensure_stage(ctx, 3, (size_t)n * sizeof(snapgpu_single_result))) || (rc = ensure_stage(ctx, 4, (size_t)n * sizeof(snapgpu_single_result))) ||
+        (rc = ensure_sec_stage(ctx, 0, sec_bytes + 16)) || (rc = ensure_sec_stage(ctx, 1, (size_t)n * 4))) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[0], bases, nb, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[1], quals, nb, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[2], offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    if (sec_bytes) HIPCHK(ctx, hipMemsetAsync(ctx->d_sec_stage[0], 0, sec_bytes, s), SNAPGPU_E_LAUNCH);
+    rc = launch_align(ctx, n, ctx->d_stage[0], ctx->d_stage[1], ctx->d_stage[2], ctx->d_stage[3], first_alt ? ctx->d_stage[4] : nullptr, s,
+                      ctx->d_sec_stage[0], secondary_stride, ctx->d_sec_stage[1]);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(primary, ctx->d_stage[3], (size_t)n * sizeof(snapgpu_single_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    if (first_alt) HIPCHK(ctx, hipMemcpyAsync(first_alt, ctx->d_stage[4], (size_t)n * sizeof(snapgpu_single_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    if (sec_bytes) HIPCHK(ctx, hipMemcpyAsync(secondary, ctx->d_sec_stage[0], sec_bytes, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(n_secondary, ctx->d_sec_stage[1], (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    if ((rc = finish_timing(ctx))) return rc;
+    bool truncated = false;
+    for (uint32_t i = 0; i < n; i++) {
+        if (n_secondary[i] == 0xFFFFFFFFu) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "a read produced more secondary candidates than 2 * (seeds + 1) * max_hits");
+        if (n_secondary[i] > secondary_stride) truncated = true;
+    }
+    return truncated ? SNAPGPU_W_SECONDARY_TRUNCATED : SNAPGPU_OK;
 }
 
 // =====================================================================================

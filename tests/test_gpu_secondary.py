@@ -1,0 +1,104 @@
+"""GPU parity of BaseAligner::AlignRead WITH secondary results (-om / -omax / -mpc; BaseAligner.cpp:2143-2299, 2423-2553) against
+what the compiled reference returned for the same reads (tests/golden/secondary_reads.npz, scripts/make_golden_secondary.py).
+Order of the secondary results matters (it is the order the reference writes them to SAM), so records are compared position by
+position.  Bit-exact."""
+import ast
+
+import numpy as np
+import pytest
+
+from snap_amd import abi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+# fields of a secondary result the reference never writes (BaseAligner.cpp:2182-2199); both sides hold 0
+UNSET_IN_SECONDARY = ("probability_all_candidates", "popular_seeds_skipped", "reserved")
+
+
+@pytest.fixture(scope="module")
+def golden_secondary():
+    import os
+    return np.load(os.path.join(util.GOLDEN, "secondary_reads.npz"))
+
+
+def _sets(z):
+    return [(str(r[0]), ast.literal_eval(str(r[1])), int(r[2]), int(r[3]), int(r[4])) for r in z["sets"]]
+
+
+def compare_secondary(ref_sec, ref_n, got_sec, got_n, exclude):
+    problems = []
+    ne = (ref_n != got_n) & ~exclude
+    if ne.any():
+        i = int(np.nonzero(ne)[0][0])
+        problems.append("nSecondaryResults differs for %d reads, first at %d: ref=%d got=%d" % (int(ne.sum()), i, ref_n[i], got_n[i]))
+    width = min(ref_sec.shape[1], got_sec.shape[1])
+    live = (np.arange(width)[None, :] < np.minimum(ref_n, got_n)[:, None]) & ~exclude[:, None]
+    for f in ref_sec.dtype.names:
+        if f in UNSET_IN_SECONDARY:
+            continue
+        d = (ref_sec[f][:, :width] != got_sec[f][:, :width]) & live
+        if d.any():
+            i, k = [int(x[0]) for x in np.nonzero(d)]
+            problems.append("secondary[%d].%s differs for %d records, first at read %d: ref=%r got=%r" %
+                            (k, f, int(d.sum()), i, ref_sec[f][i, k], got_sec[f][i, k]))
+    return problems
+
+
+@pytest.mark.parametrize("tag", ["100", "150"])
+def test_secondary_results_vs_reference_fixture(golden_index, golden_reads, golden_secondary, tag):
+    from snap_amd.aligner import BaseAligner
+    z = golden_secondary
+    b, q = golden_reads["b" + tag], golden_reads["q" + tag]
+    n, L = b.shape
+    offs = np.arange(n + 1, dtype=np.uint64) * L
+    for name, kw, om, omax, mpc in _sets(z):
+        a = BaseAligner(golden_index, abi.default_params(max_read_len=160, **kw))
+        try:
+            a.enable_secondary(om, max_results=omax, max_per_contig=mpc)
+            prim, alt, sec, nsec = a.AlignReadSecondary(b, q, offs, stride=4)        # small stride: exercises the grow-and-recall path
+        finally:
+            a.close()
+        key = "%s_%s_" % (name, tag)
+        exclude = z[key + "unstable"] | (prim["reserved"] != 0)
+        assert int(exclude.sum()) <= 2 + n // 100
+        problems = util.compare_results(z[key + "primary"], prim, "primary", exclude=exclude)
+        problems += compare_secondary(z[key + "secondary"], z[key + "nsec"], sec, nsec, exclude)
+        assert not problems, (name, problems)
+        assert int(nsec.sum()) > 0
+
+
+def test_secondary_is_what_the_plain_call_returns_when_nothing_qualifies(golden_index, golden_reads):
+    """A read with one candidate has no secondary results, and then -om changes nothing (the 4.9 early-out cannot fire)."""
+    from snap_amd.aligner import BaseAligner
+    b, q = golden_reads["b100"][:600], golden_reads["q100"][:600]
+    offs = np.arange(b.shape[0] + 1, dtype=np.uint64) * 100
+    a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+    try:
+        plain, _ = a.AlignRead(b, q, offs)
+        a.enable_secondary(1)
+        prim, _, sec, nsec = a.AlignReadSecondary(b, q, offs)
+        again, _ = a.AlignRead(b, q, offs)                    # the default kernel is untouched by enable_secondary
+    finally:
+        a.close()
+    none = nsec == 0
+    assert none.sum() > 300
+    assert not util.compare_results(plain[none], prim[none], "primary of reads without secondary results")
+    assert not util.compare_results(plain, again, "plain call after enable_secondary")
+
+
+def test_secondary_argument_errors(golden_index):
+    from snap_amd.aligner import BaseAligner, SnapGpuError
+    a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+    try:
+        with pytest.raises(SnapGpuError):
+            a.enable_secondary(2)                             # -om > -D (AlignerContext.cpp:784)
+        with pytest.raises(SnapGpuError):
+            a.enable_secondary(1, max_results=0)
+        with pytest.raises(SnapGpuError):
+            a.enable_secondary(1, max_per_contig=0)
+        with pytest.raises(SnapGpuError):
+            a.enable_secondary(1, adjust_alignments=1)        # -ae: not built
+        with pytest.raises(SnapGpuError):                     # not enabled
+            a.AlignReadSecondary(np.zeros(100, np.uint8) + 65, np.zeros(100, np.uint8) + 70, np.array([0, 100], np.uint64))
+    finally:
+        a.close()

@@ -195,3 +195,33 @@ def test_reference_reproduces_committed_alignread_fixtures(golden_reads, tmp_pat
         if k.endswith("_100_unstable"):
             unstable |= z[k]
     assert not util.compare_results(z["default_d8_100_primary"], prim, exclude=unstable)
+
+
+def test_secondary_fixture_obeys_the_reference_contract():
+    """tests/golden/secondary_reads.npz (the compiled reference's answers with -om / -omax / -mpc): what
+    finalizeSecondaryResults promises (BaseAligner.cpp:2423-2553) holds for every read -- scores within min(maxK, best + om),
+    at most -omax results, at most -mpc per contig counting the primary, supplementary == is-ALT."""
+    import ast
+    z = np.load(os.path.join(util.GOLDEN, "secondary_reads.npz"))
+    ix = util.load_golden_index()
+    begins = np.array([c.begin for c in ix.contigs], dtype=np.int64)
+    first_alt = min(c.begin for c in ix.contigs if c.is_alt)
+    for name, kw, om, omax, mpc in [(str(r[0]), ast.literal_eval(str(r[1])), int(r[2]), int(r[3]), int(r[4])) for r in z["sets"]]:
+        for tag in ("100", "150"):
+            key = "%s_%s_" % (name, tag)
+            prim, sec, nsec = z[key + "primary"], z[key + "secondary"], z[key + "nsec"]
+            assert int(nsec.max()) <= min(omax, sec.shape[1]) and int(nsec.sum()) > 0
+            live = np.arange(sec.shape[1])[None, :] < nsec[:, None]
+            worst = np.minimum(kw["max_k"], prim["score"] + om)
+            assert (sec["score"][live] <= np.broadcast_to(worst[:, None], live.shape)[live]).all()
+            assert (sec["score_prior_to_clipping"][live] == sec["score"][live]).all()
+            assert (sec["status"][live] == 2).all() and (sec["mapq"][live] == 0).all()
+            if kw.get("alt_awareness", 1):
+                assert ((sec["supplementary"][live] != 0) == (sec["location"][live] >= first_alt)).all()
+            if mpc > 0:
+                for i in np.nonzero(nsec > 0)[0]:
+                    contigs = np.searchsorted(begins, sec["location"][i, :nsec[i]], side="right") - 1
+                    counts = np.bincount(contigs, minlength=len(begins))
+                    if prim["status"][i] != 0:
+                        counts[np.searchsorted(begins, prim["location"][i], side="right") - 1] += 1
+                        assert counts.max() <= mpc, (name, tag, int(i))

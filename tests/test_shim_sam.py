@@ -73,6 +73,8 @@ def _unstable_names(workload, extra_params):
     'Reference nondeterminism'): the device flags them in `reserved`."""
     from snap_amd.aligner import BaseAligner
     idx = GenomeIndex.load_from_directory(workload["index"])
+    extra_params = dict(extra_params)
+    secondary = extra_params.pop("secondary", None)         # (-om, -omax, -mpc)
     p = abi.default_params(max_read_len=400, **extra_params)
     a = BaseAligner(idx, p)
     def clip(s):                                            # ClipBack (the CLI default, -C-+): drop the trailing '#' run
@@ -84,7 +86,11 @@ def _unstable_names(workload, extra_params):
     keep = [(n, s) for n, s in keep if len(s[0]) >= 50]
     bases = np.concatenate([s[0] for _, s in keep]); quals = np.concatenate([s[1] for _, s in keep])
     offs = np.concatenate([[0], np.cumsum([len(s[0]) for _, s in keep])]).astype(np.uint64)
-    prim, alt = a.AlignRead(bases, quals, offs)
+    if secondary:
+        a.enable_secondary(secondary[0], max_results=secondary[1], max_per_contig=secondary[2])
+        prim = a.AlignReadSecondary(bases, quals, offs)[0]
+    else:
+        prim, alt = a.AlignRead(bases, quals, offs)
     a.close()
     return {n for (n, _), r in zip(keep, prim["reserved"]) if r != 0}
 
@@ -93,6 +99,8 @@ def _unstable_names(workload, extra_params):
     ([], {}),
     (["-d", "12", "-G-"], {"max_k": 12, "use_affine_gap": 0}),
     (["-ea", "-D", "2"], {"emit_alt_alignments": 1, "extra_search_depth": 2}),
+    (["-om", "1", "-omax", "4"], {"secondary": (1, 4, -1)}),                 # secondary alignments (SingleAligner.cpp:250-318)
+    (["-D", "2", "-om", "2", "-mpc", "2"], {"extra_search_depth": 2, "secondary": (2, 0x7fffffff, 2)}),
 ])
 def test_sam_identical_to_reference_cli(workload, opts, params):
     d = workload["dir"]
@@ -122,7 +130,7 @@ def test_sam_identical_to_reference_cli(workload, opts, params):
 
 def test_shim_fails_loudly_on_unsupported_option(workload):
     r = subprocess.run([GPU_CLI, "single", workload["index"], workload["fastq"], "-o", os.path.join(workload["dir"], "x.sam"),
-                        "-om", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=300)
+                        "-f"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=300)
     assert r.returncode != 0
     assert b"libsnapgpu" in r.stdout
 
