@@ -210,6 +210,11 @@ typedef struct snapgpu_paired_result {
 } snapgpu_paired_result;
 
 #define SNAPGPU_PAIR_POOL_OVERFLOW   1u   /* candidate pool / affine-gap candidate buffer too small: result invalid */
+#define SNAPGPU_PAIR_REF_BUFFER_DEPENDENT 2u /* (-om only) not an error.  The Hamming retry of the chimeric fallback produced more single-end
+                                                secondary candidates than the 32-entry buffer PairedAligner.cpp:566 starts with.  The reference
+                                                ignores that AlignRead's failure (ChimericPairedEndAligner.cpp:339 never assigns its return value),
+                                                so ITS answer for this pair -- an unaligned read plus a truncated, unfiltered list -- depends on how
+                                                far earlier pairs on the same thread had grown the buffer.  This library completes the call. */
 
 /* per-call work counters (what BaseAligner exposes through getNHashTableLookups() etc.,
  * BaseAligner.h:106-111), used for the algorithmic-bytes roofline model.                */

@@ -21,6 +21,11 @@ void *snapref_chimeric_single_create(void *vindex, const snapgpu_params *p, cons
 int   snapref_chimeric_single_align(void *h, int max_k, int hamming, const char *bases, const char *quals, uint32_t len,
                                     snapgpu_single_result *res, snapgpu_single_result *alt);
 void  snapref_chimeric_single_destroy(void *h);
+void *snapref_chimeric_single_create2(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp, int mpc);
+int   snapref_chimeric_single_align2(void *h, int max_k, int hamming, const char *bases, const char *quals, uint32_t len,
+                                     snapgpu_single_result *res, snapgpu_single_result *alt,
+                                     int om, int64_t omax, snapgpu_single_result *sec_out, uint32_t sec_room, uint32_t *n_sec,
+                                     uint32_t first_room, uint32_t *overflowed_first);
 }
 
 struct HostPL {
@@ -115,16 +120,55 @@ struct HostPL {
         for (int k = 1; k < 1024; k++) base[k] += base[k - 1];
         for (uint32_t j = 0; j < n; j++) order[base[c[j].reserved & 511]++] = j;
     }
-    void align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt) {
-        snapref_chimeric_single_align(single, max_k, hamming ? 1 : 0, (const char *)read_b[r], (const char *)read_q[r], (uint32_t)read_l[r], &res, &alt);
+    // returns the number of secondary results the read has; the first min(that, sec_room) go to sec_out
+    uint32_t align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt,
+                          bool want_secondary, snapgpu_single_result *sec_out, uint32_t sec_room, uint32_t room32) {
+        uint32_t n_sec = 0, over = 0;
+        // what the reference's caller would have had left of its initial 32-entry buffer (PairedAligner.cpp:566; ChimericPairedEndAligner.cpp:311)
+        const uint32_t first_room = room32;
+        snapref_chimeric_single_align2(single, max_k, hamming ? 1 : 0, (const char *)read_b[r], (const char *)read_q[r], (uint32_t)read_l[r], &res, &alt,
+                                       want_secondary ? om : -1, omax, sec_out, sec_room, &n_sec, first_room, &over);
+        last_raw = over ? first_room + 1 : 0;
+        return n_sec;
     }
+    // pre-filter count of the last align_single's secondary candidates, as far as the caller needs it: > room or not
+    uint32_t single_raw_secondary() const { return last_raw; }
+    int om; int64_t omax;
+    uint32_t last_raw;
 };
 
 static uint8_t rc_of(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
 
+static int host_align(const snapgpu_index_view *ix, void *ref_index, const snapgpu_params *p, const snapgpu_paired_params *pp,
+                      int stage, uint32_t n, const char *bases, const char *quals, const uint64_t *offsets,
+                      snapgpu_paired_result *primary, snapgpu_paired_result *first_alt, int64_t *counters3,
+                      const snapgpu_secondary_params *sp, snapgpu_paired_result *secondary, uint32_t sec_stride, uint32_t *n_secondary,
+                      snapgpu_single_result *single_secondary, uint32_t ssec_stride, uint32_t *n_single_secondary);
+
 extern "C" int pairedhost_align(const snapgpu_index_view *ix, void *ref_index, const snapgpu_params *p, const snapgpu_paired_params *pp,
                                 int stage, uint32_t n, const char *bases, const char *quals, const uint64_t *offsets,
                                 snapgpu_paired_result *primary, snapgpu_paired_result *first_alt, int64_t *counters3)
+{
+    return host_align(ix, ref_index, p, pp, stage, n, bases, quals, offsets, primary, first_alt, counters3, NULL, NULL, 0, NULL, NULL, 0, NULL);
+}
+
+/* ... with secondary results (-om / -omax / -mpc): secondary[i * sec_stride + k], k < n_secondary[i]; single_secondary[i * ssec_stride + k]:
+ * read 0's n_single_secondary[2i] results, then read 1's n_single_secondary[2i+1]. */
+extern "C" int pairedhost_align_secondary(const snapgpu_index_view *ix, void *ref_index, const snapgpu_params *p, const snapgpu_paired_params *pp,
+                                          const snapgpu_secondary_params *sp, int stage, uint32_t n, const char *bases, const char *quals,
+                                          const uint64_t *offsets, snapgpu_paired_result *primary, snapgpu_paired_result *first_alt,
+                                          snapgpu_paired_result *secondary, uint32_t sec_stride, uint32_t *n_secondary,
+                                          snapgpu_single_result *single_secondary, uint32_t ssec_stride, uint32_t *n_single_secondary)
+{
+    return host_align(ix, ref_index, p, pp, stage, n, bases, quals, offsets, primary, first_alt, NULL, sp, secondary, sec_stride, n_secondary,
+                      single_secondary, ssec_stride, n_single_secondary);
+}
+
+static int host_align(const snapgpu_index_view *ix, void *ref_index, const snapgpu_params *p, const snapgpu_paired_params *pp,
+                      int stage, uint32_t n, const char *bases, const char *quals, const uint64_t *offsets,
+                      snapgpu_paired_result *primary, snapgpu_paired_result *first_alt, int64_t *counters3,
+                      const snapgpu_secondary_params *sp, snapgpu_paired_result *secondary, uint32_t sec_stride, uint32_t *n_secondary,
+                      snapgpu_single_result *single_secondary, uint32_t ssec_stride, uint32_t *n_single_secondary)
 {
     oracle_init();
     HostPL pl;
@@ -137,7 +181,8 @@ extern "C" int pairedhost_align(const snapgpu_index_view *ix, void *ref_index, c
     pl.phred_t = oracle_phred_table(); pl.indel_t = oracle_indel_table(); pl.perfect_t = oracle_perfect_table();
     pl.seed_len = (int)ix->seed_len;
     pl.seed_prob_v = oracle_seed_prob(pl.seed_len);
-    pl.single = (stage == 0 && ref_index) ? snapref_chimeric_single_create(ref_index, p, pp) : NULL;
+    pl.single = (stage == 0 && ref_index) ? snapref_chimeric_single_create2(ref_index, p, pp, sp ? sp->max_per_contig : -1) : NULL;
+    pl.om = sp ? sp->max_edit_distance : -1; pl.omax = sp ? sp->max_results : 0x7fffffff;
 
     PECfg cfg;
     memset(&cfg, 0, sizeof(cfg));
@@ -156,6 +201,8 @@ extern "C" int pairedhost_align(const snapgpu_index_view *ix, void *ref_index, c
     cfg.pool_size = (uint32_t)(pool < pp->max_candidate_pool_size ? pool : pp->max_candidate_pool_size);
     cfg.ag_cand_cap = p->use_affine_gap ? 65536 : 0;
     cfg.max_seeds = PE_MAX_SEEDS;
+    cfg.om = sp ? sp->max_edit_distance : -1; cfg.mpc = sp ? sp->max_per_contig : -1; cfg.omax = sp ? sp->max_results : 0x7fffffff;
+    cfg.sec_cap = sp ? 65536 : 0;
     std::vector<uint64_t> zero_pb(ix->n_contigs + 1, 0); std::vector<uint8_t> zero_rc(ix->n_contigs + 1, 0); std::vector<uint32_t> zero_cs(ix->n_contigs + 2, 0), zero_op(1, 0);
     cfg.proj.contig_begin = ix->contig_begin; cfg.proj.n_contigs = ix->n_contigs;
     cfg.proj.proj_begin = ix->contig_proj_begin ? ix->contig_proj_begin : &zero_pb[0];
@@ -173,11 +220,15 @@ extern "C" int pairedhost_align(const snapgpu_index_view *ix, void *ref_index, c
     std::vector<PEAnchor> anchor(cfg.pool_size);
     std::vector<snapgpu_paired_result> agc(cfg.ag_cand_cap + 1);
     std::vector<uint32_t> agc_order(cfg.ag_cand_cap + 1);
+    std::vector<snapgpu_paired_result> sec(cfg.sec_cap + 1);
+    std::vector<uint32_t> sec_ord(cfg.sec_cap + 1), sec_key(2 * cfg.sec_cap + 1);
     PEShared sh;
     memset(&sh, 0, sizeof(sh));
     core.lk = &lk[0]; core.exhausted = &exhausted[0]; core.miss = &miss[0]; core.hs = &hs[0]; core.list_head = &list_head[0];
     core.seed_used = &seed_used[0]; core.sh = &sh; core.cand = &cand[0]; core.mate[0] = &mate0[0]; core.mate[1] = &mate1[0];
     core.anchor = &anchor[0]; core.agc = &agc[0]; core.agc_order = &agc_order[0];
+    core.sec = &sec[0]; core.sec_ord = &sec_ord[0]; core.sec_key = &sec_key[0]; core.n_sec = 0;
+    core.ssec_out = NULL; core.ssec_stride = 0; core.n_ssec[0] = core.n_ssec[1] = 0;
 
     const int PAD = 160;
     std::vector<uint8_t> buf[2][2], qbuf[2][2];
@@ -197,15 +248,22 @@ extern "C" int pairedhost_align(const snapgpu_index_view *ix, void *ref_index, c
         memset(&sh.res, 0, sizeof(sh.res));
         memset(&sh.alt, 0, sizeof(sh.alt));
         core.overflow = 0; core.stale = 0;
+        core.n_sec = 0; core.n_ssec[0] = core.n_ssec[1] = 0;
+        core.ssec_out = single_secondary ? single_secondary + (size_t)i * ssec_stride : NULL; core.ssec_stride = ssec_stride;
         if (stage == 1) {
             core.intersecting_align();
         } else {
             core.align_pair((int)p->max_k, (int)p->max_k / 2);
         }
-        sh.res.flags = core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0;
+        sh.res.flags = (core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0) | (core.ref_dep ? SNAPGPU_PAIR_REF_BUFFER_DEPENDENT : 0);
         sh.res.reserved = core.stale;
         primary[i] = sh.res;
         first_alt[i] = sh.alt;
+        if (n_secondary) {
+            n_secondary[i] = core.n_sec;
+            for (uint32_t k = 0; k < core.n_sec && k < sec_stride; k++) secondary[(size_t)i * sec_stride + k] = *core.secondary(k);
+            n_single_secondary[2 * i] = core.n_ssec[0]; n_single_secondary[2 * i + 1] = core.n_ssec[1];
+        }
     }
     if (counters3) { counters3[0] = (int64_t)sh.cnt.lv; counters3[1] = (int64_t)sh.cnt.ag; counters3[2] = (int64_t)sh.cnt.lookups; }
     if (pl.single) snapref_chimeric_single_destroy(pl.single);

@@ -114,6 +114,38 @@ class RefIndex:
                 continue
             return primary, first_alt, secondary, n_sec
 
+    def align_paired_secondary(self, params: Params, pparams, om: int, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray,
+                               omax: int = 0x7fffffff, mpc: int = -1, threads: int = 1, stage: int = 0, stride: int = 32,
+                               single_stride: int = 64):
+        """ChimericPairedEndAligner::align (stage 0) / IntersectingPairedEndAligner::align (stage 1) with -om / -omax / -mpc, called
+        as PairedAligner.cpp:727 calls it.  Returns (primary, first_alt, secondary[n, stride], n_secondary[n],
+        single_secondary[n, single_stride], n_single_secondary[n, 2])."""
+        from snap_amd.abi import PAIRED_RESULT_DTYPE
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = (offsets.size - 1) // 2
+        primary = np.zeros(n, dtype=PAIRED_RESULT_DTYPE)
+        first_alt = np.zeros(n, dtype=PAIRED_RESULT_DTYPE)
+        while True:
+            sec = np.zeros((n, stride), dtype=PAIRED_RESULT_DTYPE)
+            nsec = np.zeros(n, dtype=np.uint32)
+            ssec = np.zeros((n, single_stride), dtype=RESULT_DTYPE)
+            nssec = np.zeros((n, 2), dtype=np.uint32)
+            rc = lib().snapref_align_paired_secondary(self.handle, C.byref(params), C.byref(pparams), C.c_int(stage), C.c_int(om), C.c_int64(omax),
+                                                      C.c_int(mpc), C.c_uint32(n), ptr(bases), ptr(quals), ptr(offsets), C.c_int(threads),
+                                                      ptr(primary), ptr(first_alt), ptr(sec), C.c_uint32(stride), ptr(nsec),
+                                                      ptr(ssec), C.c_uint32(single_stride), ptr(nssec))
+            if rc != 0:
+                raise RuntimeError("snapref_align_paired_secondary rc=%d" % rc)
+            grow = False
+            if n and int(nsec.max()) > stride:
+                stride = int(nsec.max()); grow = True
+            if n and int(nssec.sum(axis=1).max()) > single_stride:
+                single_stride = int(nssec.sum(axis=1).max()); grow = True
+            if not grow:
+                return primary, first_alt, sec, nsec, ssec, nssec
+
     def align_paired(self, params: Params, pparams, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray,
                      threads: int = 1, stage: int = 0):
         """ChimericPairedEndAligner::align (stage 0) or IntersectingPairedEndAligner::align only (stage 1)

@@ -518,6 +518,10 @@ struct PairedJob {
     uint32_t chunk;
     pthread_mutex_t lock;
     _int64 lv, ag;
+    // secondary results (-om / -omax / -mpc); om = -1: none, as PairedAligner.cpp does by default
+    int om, mpc; _int64 omax;
+    snapgpu_paired_result *secondary; uint32_t sec_stride; uint32_t *n_secondary;                  // [n * sec_stride], [n]
+    snapgpu_single_result *single_secondary; uint32_t ssec_stride; uint32_t *n_single_secondary;   // [n * ssec_stride], [2n]
 };
 
 static void *paired_thread(void *arg)
@@ -527,7 +531,7 @@ static void *paired_thread(void *arg)
     const snapgpu_paired_params *pp = job->pp;
     GenomeIndex *index = job->index;
     int maxReadSize = MAX_READ_LENGTH;
-    const int maxSecondaryAlignmentsPerContig = -1;
+    const int maxSecondaryAlignmentsPerContig = job->mpc;
 
     // mirror of PairedAligner.cpp:556-640
     size_t memoryPoolSize = IntersectingPairedEndAligner::getBigAllocatorReservation(index, pp->max_big_hits, maxReadSize, index->getSeedLength(),
@@ -551,6 +555,10 @@ static void *paired_thread(void *arg)
         p->gap_open_penalty, p->gap_extend_penalty, p->five_prime_end_bonus, p->three_prime_end_bonus, pp->min_score_realignment,
         pp->min_score_gap_realignment_alt, pp->min_ag_score_improvement, pp->enable_hamming_scoring_base_aligner != 0, allocator);
 
+    // PairedAligner.cpp:556-566, 600-640: results[0] is the primary, results + 1 the paired secondary buffer
+    _int64 maxPairedSecondaryHits = job->om < 0 ? 0 : 32, maxSingleSecondaryHits = job->om < 0 ? 0 : 32;
+    PairedAlignmentResult *results = (PairedAlignmentResult *)BigAlloc((maxPairedSecondaryHits + 1) * sizeof(PairedAlignmentResult));
+    SingleAlignmentResult *singleSecondary = maxSingleSecondaryHits ? (SingleAlignmentResult *)BigAlloc(maxSingleSecondaryHits * sizeof(SingleAlignmentResult)) : NULL;
     PairedAlignmentResult *pairedCand = maxPairedCand ? (PairedAlignmentResult *)BigAlloc(maxPairedCand * sizeof(PairedAlignmentResult)) : NULL;
     SingleAlignmentResult *singleCand = maxSingleCand ? (SingleAlignmentResult *)BigAlloc(maxSingleCand * sizeof(SingleAlignmentResult)) : NULL;
 
@@ -570,36 +578,55 @@ static void *paired_thread(void *arg)
                 memcpy(&qbuf[r][SLACK], job->quals + job->offsets[2 * i + r], len);
                 reads[r].init("r", 1, &bbuf[r][SLACK], &qbuf[r][SLACK], len, NULL, 0);
             }
-            PairedAlignmentResult result, alt;
-            memset(&result, 0, sizeof(result));
+            PairedAlignmentResult alt;
             memset(&alt, 0, sizeof(alt));
             _int64 nSecondary = 0, nPairedCand = 0, nSingleSecondary[2] = {0, 0}, nSingleCand[2] = {0, 0};
             for (;;) {
                 bool ok;
+                memset(results, 0, (maxPairedSecondaryHits + 1) * sizeof(PairedAlignmentResult));
+                if (singleSecondary) memset(singleSecondary, 0, maxSingleSecondaryHits * sizeof(SingleAlignmentResult));
                 if (job->stage == 1) {
-                    ok = intersectingAligner->align(&reads[0], &reads[1], &result, &alt, -1, 0, &nSecondary, NULL, 0, 0x7fffffff,
-                        &nSingleSecondary[0], &nSingleSecondary[1], NULL, maxPairedCand, &nPairedCand, pairedCand, maxSingleCand,
-                        &nSingleCand[0], &nSingleCand[1], singleCand, (int)p->max_k);
+                    ok = intersectingAligner->align(&reads[0], &reads[1], results, &alt, job->om, maxPairedSecondaryHits, &nSecondary, results + 1,
+                        maxSingleSecondaryHits, job->omax, &nSingleSecondary[0], &nSingleSecondary[1], singleSecondary, maxPairedCand, &nPairedCand,
+                        pairedCand, maxSingleCand, &nSingleCand[0], &nSingleCand[1], singleCand, (int)p->max_k);
                 } else {
-                    // same call shape as PairedAligner.cpp:727 with the default -om (none)
-                    ok = aligner->align(&reads[0], &reads[1], &result, &alt, -1, 0, &nSecondary, NULL, 0, 0x7fffffff,
-                        &nSingleSecondary[0], &nSingleSecondary[1], NULL, maxPairedCand, &nPairedCand, pairedCand, maxSingleCand,
-                        &nSingleCand[0], &nSingleCand[1], singleCand, (int)p->max_k);
+                    // same call shape as PairedAligner.cpp:727
+                    ok = aligner->align(&reads[0], &reads[1], results, &alt, job->om, maxPairedSecondaryHits, &nSecondary, results + 1,
+                        maxSingleSecondaryHits, job->omax, &nSingleSecondary[0], &nSingleSecondary[1], singleSecondary, maxPairedCand, &nPairedCand,
+                        pairedCand, maxSingleCand, &nSingleCand[0], &nSingleCand[1], singleCand, (int)p->max_k);
                 }
                 if (ok) break;
-                // PairedAligner.cpp:758-781: double whichever candidate buffer overflowed and call again
-                if (nPairedCand > maxPairedCand) {
+                // PairedAligner.cpp:732-781: double whichever buffer overflowed and call again
+                if (nSecondary > maxPairedSecondaryHits) {
+                    BigDealloc(results); maxPairedSecondaryHits *= 2;
+                    results = (PairedAlignmentResult *)BigAlloc((maxPairedSecondaryHits + 1) * sizeof(PairedAlignmentResult));
+                } else if (nSingleSecondary[0] > maxSingleSecondaryHits) {
+                    BigDealloc(singleSecondary); maxSingleSecondaryHits *= 2;
+                    singleSecondary = (SingleAlignmentResult *)BigAlloc(maxSingleSecondaryHits * sizeof(SingleAlignmentResult));
+                } else if (nPairedCand > maxPairedCand) {
                     BigDealloc(pairedCand); maxPairedCand *= 2;
                     pairedCand = (PairedAlignmentResult *)BigAlloc(maxPairedCand * sizeof(PairedAlignmentResult));
                 } else if (nSingleCand[0] > maxSingleCand) {
                     BigDealloc(singleCand); maxSingleCand *= 2;
                     singleCand = (SingleAlignmentResult *)BigAlloc(maxSingleCand * sizeof(SingleAlignmentResult));
                 } else {
-                    break;      // secondary buffers are not in use here
+                    break;
                 }
             }
-            fill_paired(&job->primary[i], &result);
+            fill_paired(&job->primary[i], &results[0]);
             if (job->first_alt) fill_paired(&job->first_alt[i], &alt);
+            if (job->n_secondary) {
+                job->n_secondary[i] = (uint32_t)nSecondary;
+                for (_int64 k = 0; k < nSecondary && k < (_int64)job->sec_stride; k++)
+                    fill_paired(&job->secondary[(size_t)i * job->sec_stride + k], &results[1 + k]);
+                job->n_single_secondary[2 * i] = (uint32_t)nSingleSecondary[0];
+                job->n_single_secondary[2 * i + 1] = (uint32_t)nSingleSecondary[1];
+                for (_int64 k = 0; k < nSingleSecondary[0] + nSingleSecondary[1] && k < (_int64)job->ssec_stride; k++) {
+                    snapgpu_single_result *o = &job->single_secondary[(size_t)i * job->ssec_stride + k];
+                    fill_result(o, &singleSecondary[k]);
+                    o->probability_all_candidates = 0; o->popular_seeds_skipped = 0;   // never written for a secondary result
+                }
+            }
         }
     }
 
@@ -610,6 +637,8 @@ static void *paired_thread(void *arg)
 
     if (pairedCand) BigDealloc(pairedCand);
     if (singleCand) BigDealloc(singleCand);
+    BigDealloc(results);
+    if (singleSecondary) BigDealloc(singleSecondary);
     aligner->~ChimericPairedEndAligner();
     intersectingAligner->~IntersectingPairedEndAligner();
     delete allocator;
@@ -617,11 +646,14 @@ static void *paired_thread(void *arg)
 }
 
 /* offsets: [2n+1]; read r of pair i is bases[offsets[2i+r] .. offsets[2i+r+1]).
- * counters2 = {LV locations, AG locations} (paired + single-end fallback).               */
-int snapref_align_paired(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp, int stage, uint32_t n,
-                         const char *bases, const char *quals, const uint64_t *offsets, int n_threads,
-                         snapgpu_paired_result *primary, snapgpu_paired_result *first_alt,
-                         int64_t *counters2, double *seconds)
+ * counters2 = {LV locations, AG locations} (paired + single-end fallback).
+ * Secondary results (om >= 0): secondary[i * sec_stride + k] for k < n_secondary[i] (paired), single_secondary[i * ssec_stride + k]:
+ * read 0's n_single_secondary[2i] results, then read 1's n_single_secondary[2i+1] (the layout of PairedAligner.cpp:872).          */
+static int run_paired(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp, int stage, uint32_t n,
+                      const char *bases, const char *quals, const uint64_t *offsets, int n_threads,
+                      snapgpu_paired_result *primary, snapgpu_paired_result *first_alt, int64_t *counters2, double *seconds,
+                      int om, int64_t omax, int mpc, snapgpu_paired_result *secondary, uint32_t sec_stride, uint32_t *n_secondary,
+                      snapgpu_single_result *single_secondary, uint32_t ssec_stride, uint32_t *n_single_secondary)
 {
     snapref_init();
     GenomeIndex *index = (GenomeIndex *)vindex;
@@ -630,6 +662,8 @@ int snapref_align_paired(void *vindex, const snapgpu_params *p, const snapgpu_pa
     PairedJob job;
     job.index = index; job.p = p; job.pp = pp; job.stage = stage; job.n = n; job.bases = bases; job.quals = quals; job.offsets = offsets;
     job.primary = primary; job.first_alt = first_alt; job.next = 0; job.chunk = 64; job.lv = job.ag = 0;
+    job.om = om; job.omax = omax; job.mpc = mpc; job.secondary = secondary; job.sec_stride = sec_stride; job.n_secondary = n_secondary;
+    job.single_secondary = single_secondary; job.ssec_stride = ssec_stride; job.n_single_secondary = n_single_secondary;
     pthread_mutex_init(&job.lock, NULL);
     if (n_threads < 1) n_threads = 1;
     struct timespec t0, t1;
@@ -644,6 +678,25 @@ int snapref_align_paired(void *vindex, const snapgpu_params *p, const snapgpu_pa
     return 0;
 }
 
+int snapref_align_paired(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp, int stage, uint32_t n,
+                         const char *bases, const char *quals, const uint64_t *offsets, int n_threads,
+                         snapgpu_paired_result *primary, snapgpu_paired_result *first_alt,
+                         int64_t *counters2, double *seconds)
+{
+    return run_paired(vindex, p, pp, stage, n, bases, quals, offsets, n_threads, primary, first_alt, counters2, seconds,
+                      -1, 0x7fffffff, -1, NULL, 0, NULL, NULL, 0, NULL);
+}
+
+int snapref_align_paired_secondary(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp, int stage, int om, int64_t omax, int mpc,
+                                   uint32_t n, const char *bases, const char *quals, const uint64_t *offsets, int n_threads,
+                                   snapgpu_paired_result *primary, snapgpu_paired_result *first_alt,
+                                   snapgpu_paired_result *secondary, uint32_t sec_stride, uint32_t *n_secondary,
+                                   snapgpu_single_result *single_secondary, uint32_t ssec_stride, uint32_t *n_single_secondary)
+{
+    return run_paired(vindex, p, pp, stage, n, bases, quals, offsets, n_threads, primary, first_alt, NULL, NULL,
+                      om, omax, mpc, secondary, sec_stride, n_secondary, single_secondary, ssec_stride, n_single_secondary);
+}
+
 
 // The single-end aligner inside ChimericPairedEndAligner (ChimericPairedEndAligner.cpp:81-88), on its own, so that the
 // host build of snap_amd/csrc/paired.h (oracle/paired_host.cpp) can plug the reference in for the fallback calls
@@ -656,17 +709,22 @@ struct ChimericSingle {
     std::vector<char> b, q;
 };
 
+void *snapref_chimeric_single_create2(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp, int mpc);
 void *snapref_chimeric_single_create(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp)
+{
+    return snapref_chimeric_single_create2(vindex, p, pp, -1);
+}
+void *snapref_chimeric_single_create2(void *vindex, const snapgpu_params *p, const snapgpu_paired_params *pp, int mpc)
 {
     snapref_init();
     GenomeIndex *index = (GenomeIndex *)vindex;
     int maxReadSize = MAX_READ_LENGTH;
     ChimericSingle *c = new ChimericSingle();
     c->allocator = new BigAllocator(BaseAligner::getBigAllocatorReservation(index, true, p->max_hits, maxReadSize, index->getSeedLength(),
-                                    pp->max_single_seeds, p->seed_coverage, -1, p->extra_search_depth) + 4096, 16);
+                                    pp->max_single_seeds, p->seed_coverage, mpc, p->extra_search_depth) + 4096, 16);
     c->aligner = new (c->allocator) BaseAligner(index, p->max_hits, p->max_k / 2, maxReadSize, pp->max_single_seeds, p->seed_coverage,
         p->min_weight_to_check, p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, true, p->alt_awareness != 0,
-        p->emit_alt_alignments != 0, p->max_score_gap_to_prefer_non_alt, -1, NULL, NULL, p->match_reward, p->sub_penalty,
+        p->emit_alt_alignments != 0, p->max_score_gap_to_prefer_non_alt, mpc, NULL, NULL, p->match_reward, p->sub_penalty,
         p->gap_open_penalty, p->gap_extend_penalty, p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, c->allocator);
     c->maxCand = p->use_affine_gap ? 4096 : 0;                        // PairedAligner.cpp:570-577: no candidate buffers without affine gap
     c->cand = c->maxCand ? (SingleAlignmentResult *)BigAlloc(c->maxCand * sizeof(SingleAlignmentResult)) : NULL;
@@ -675,8 +733,21 @@ void *snapref_chimeric_single_create(void *vindex, const snapgpu_params *p, cons
     return c;
 }
 
+int snapref_chimeric_single_align2(void *h, int max_k, int hamming, const char *bases, const char *quals, uint32_t len,
+                                   snapgpu_single_result *res, snapgpu_single_result *alt,
+                                   int om, int64_t omax, snapgpu_single_result *sec_out, uint32_t sec_room, uint32_t *n_sec,
+                                   uint32_t first_room, uint32_t *overflowed_first);
 int snapref_chimeric_single_align(void *h, int max_k, int hamming, const char *bases, const char *quals, uint32_t len,
                                   snapgpu_single_result *res, snapgpu_single_result *alt)
+{
+    return snapref_chimeric_single_align2(h, max_k, hamming, bases, quals, len, res, alt, -1, 0x7fffffff, NULL, 0, NULL, 32, NULL);
+}
+/* ... with secondary results: AlignRead(read, ..., om, bufSize, &n, omax, buf, ...) as ChimericPairedEndAligner.cpp:310 calls it.
+ * first_room: the buffer size of the first attempt (the caller's remaining room); *overflowed_first says whether that was too small. */
+int snapref_chimeric_single_align2(void *h, int max_k, int hamming, const char *bases, const char *quals, uint32_t len,
+                                   snapgpu_single_result *res, snapgpu_single_result *alt,
+                                   int om, int64_t omax, snapgpu_single_result *sec_out, uint32_t sec_room, uint32_t *n_sec,
+                                   uint32_t first_room, uint32_t *overflowed_first)
 {
     ChimericSingle *c = (ChimericSingle *)h;
     memcpy(&c->b[SLACK], bases, len);
@@ -689,10 +760,21 @@ int snapref_chimeric_single_align(void *h, int max_k, int hamming, const char *b
     a.status = NotFound;
     c->aligner->setMaxK(max_k);
     _int64 nSecondary = 0, nCand = 0;
+    std::vector<SingleAlignmentResult> secbuf(om >= 0 ? (first_room > 64 ? first_room : 64) : 0);
+    _int64 secSize = om >= 0 ? (_int64)first_room : 0;
+    if (overflowed_first) *overflowed_first = 0;
     for (;;) {
         nCand = 0;
-        bool ok = c->aligner->AlignRead(&read, &r, &a, -1, 0, &nSecondary, 0x7fffffff, NULL, c->maxCand, &nCand, c->cand, hamming != 0);
+        if (!secbuf.empty()) memset(&secbuf[0], 0, secbuf.size() * sizeof(SingleAlignmentResult));
+        bool ok = c->aligner->AlignRead(&read, &r, &a, om, secSize, &nSecondary, omax, secbuf.empty() ? NULL : &secbuf[0],
+                                        c->maxCand, &nCand, c->cand, hamming != 0);
         if (ok) break;
+        if (om >= 0 && !(c->cand != NULL && nCand > c->maxCand)) {       // the secondary buffer overflowed: the caller doubles it (PairedAligner.cpp:746-756)
+            if (overflowed_first && secSize == (_int64)first_room) *overflowed_first = 1;
+            secSize = secSize < 32 ? 64 : secSize * 2;
+            if ((_int64)secbuf.size() < secSize) secbuf.resize(secSize);
+            continue;
+        }
         if (c->cand != NULL && nCand > c->maxCand) {
             BigDealloc(c->cand);
             c->maxCand *= 2;
@@ -706,6 +788,13 @@ int snapref_chimeric_single_align(void *h, int max_k, int hamming, const char *b
     }
     fill_result(res, &r);
     if (a.status == NotFound) { memset(alt, 0, sizeof(*alt)); alt->status = NotFound; } else fill_result(alt, &a);
+    if (n_sec) {
+        *n_sec = (uint32_t)nSecondary;
+        for (_int64 k = 0; k < nSecondary && k < (_int64)sec_room; k++) {
+            fill_result(&sec_out[k], &secbuf[k]);
+            sec_out[k].probability_all_candidates = 0; sec_out[k].popular_seeds_skipped = 0;
+        }
+    }
     return 0;
 }
 

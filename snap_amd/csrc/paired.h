@@ -76,6 +76,11 @@ struct PECfg {
     uint32_t pool_size;                // scoringCandidatePoolSize, :141
     uint32_t ag_cand_cap;              // capacity of the Phase-4 candidate buffer (PairedAligner.cpp:571)
     uint32_t max_seeds;                // lookups per hit set the LDS arrays are sized for
+    // secondary results (-om / -omax / -mpc; all zero / om = -1 when off)
+    int32_t  om;                       // maxEditDistanceForSecondaryResults, -1 = none
+    int32_t  mpc;                      // maxSecondaryAlignmentsPerContig, -1 = no limit
+    int64_t  omax;                     // maxSecondaryResultsToReturn
+    uint32_t sec_cap;                  // capacity of the paired secondary-result list of a wave
 };
 
 struct PELookup {                      // HashTableLookup<unsigned>, IntersectingPairedEndAligner.h:247
@@ -159,6 +164,14 @@ struct PairedCore {
     PEAnchor *anchor;                  // [cfg.pool_size]
     snapgpu_paired_result *agc;        // [cfg.ag_cand_cap]   lvCandidatesForAffineGap
     uint32_t *agc_order;               // [cfg.ag_cand_cap]   the order Phase 4 visits them in
+    snapgpu_paired_result *sec;        // [cfg.sec_cap]       secondaryResults of IntersectingPairedEndAligner::align
+    uint32_t *sec_ord, *sec_key;       // [cfg.sec_cap], [2 * cfg.sec_cap]   index list / sort keys of the final filtering
+    uint32_t n_sec;
+    // single-end secondary results of the chimeric fallback go straight to the caller's buffer (read 0's, then read 1's)
+    snapgpu_single_result *ssec_out;   // [ssec_stride] for this pair, or NULL
+    uint32_t ssec_stride;
+    uint32_t n_ssec[2];
+    uint32_t ref_dep;                  // SNAPGPU_PAIR_REF_BUFFER_DEPENDENT
     // per-pair scalars
     uint32_t n_cand, n_mate[2], n_anchor;
     uint32_t n_agc;
@@ -517,6 +530,9 @@ struct PairedCore {
         double mp1 = 1.0, mp2 = 1.0;
         int text_rem = rl - tail;
         const uint64_t t_ag = PL::clock();
+#ifdef PE_AG_STATS
+        pl.note_ag(which, dir, loc, seed_offset, limit);
+#endif
         if (tail != rl) {
             const int plen = rl - tail;
             const bool banded = plen >= 3 * (2 * limit + 1);
@@ -625,6 +641,7 @@ struct PairedCore {
             res.bases_clipped_after[r] = 0; res.ag_score[r] = 0; res.used_gapless_clipping[r] = 0;
         }
         n_agc = 0;
+        n_sec = 0;                                                                                                 // :294 / :1472
 
         const int sl = cfg.seed_len;
         int max_seeds;
@@ -914,6 +931,13 @@ struct PairedCore {
                                 // keep the displaced best as a Phase-4 candidate (:1027-1062)
                                 bool close = hamming ? (pair_score <= all.best_pair_score && cfg.extra_depth >= all.best_pair_score - pair_score)
                                                      : (cfg.extra_depth >= all.best_pair_score - pair_score);
+                                // ... and as a secondary result (:999-1034 / :2077-2112)
+                                if (cfg.om != -1 && pair_p > all.p_best && (!hamming || pair_score <= all.best_pair_score) &&
+                                    cfg.om >= all.best_pair_score - pair_score) {
+                                    if (n_sec >= cfg.sec_cap) { overflow = 1; return; }
+                                    agc_from_set(&sec[n_sec], all);
+                                    n_sec++;
+                                }
                                 if (!replaced && pair_p > all.p_best && cfg.ag_cand_cap > 0 && close) {
                                     if (n_agc >= cfg.ag_cand_cap) { overflow = 1; return; }
                                     agc_from_set(&agc[n_agc], all);
@@ -924,12 +948,19 @@ struct PairedCore {
 
                                 bool near = hamming ? (pair_score >= all.best_pair_score && cfg.extra_depth >= pair_score - all.best_pair_score)
                                                     : (pair_score <= cfg.max_k + cfg.extra_depth && cfg.extra_depth >= pair_score - all.best_pair_score);
+                                const bool near_sec = hamming ? (pair_score >= all.best_pair_score && cfg.om >= pair_score - all.best_pair_score)
+                                                              : (pair_score <= cfg.max_k + cfg.extra_depth && cfg.om >= pair_score - all.best_pair_score);
+                                if (!updated && cfg.om != -1 && near_sec) {                                        // :1082-1124 / :2157-2199
+                                    if (n_sec >= cfg.sec_cap) { overflow = 1; return; }
+                                    agc_from_pair(&sec[n_sec], ci, (int)mi, sp, fewer_score, fewer_off);
+                                    n_sec++;
+                                }
                                 if (!updated && cfg.ag_cand_cap > 0 && near) {                                     // :1126-1166
                                     if (n_agc >= cfg.ag_cand_cap) { overflow = 1; return; }
                                     agc_from_pair(&agc[n_agc], ci, (int)mi, sp, fewer_score, fewer_off);
                                     n_agc++;
                                 }
-                                if ((cfg.alt_aware ? non_alt.p_all : all.p_all) >= 4.9) { done = true; break; }    // :1183
+                                if ((cfg.alt_aware ? non_alt.p_all : all.p_all) >= 4.9 && cfg.om == -1) { done = true; break; }    // :1181
                             }
                         }
                     }
@@ -956,7 +987,78 @@ struct PairedCore {
             }
         }
         for (int w = 0; w < 2; w++) res.score_prior_to_clipping[w] = res.score[w];                                 // :1273-1275
+        if (cfg.om != -1) finalize_secondary(emit_best, res);
     }
+
+    // ------------------------------------------------------------------ the tail of alignLandauVishkin / alignHamming (:1289-1411 / :2364-2483)
+    // with ignoreAlignmentAdjustmentsForOm (the default).  Works on an index list; the records move once, when they are emitted.
+    // stable sort of sec_ord[0..n) by sec_key[sec_ord[.]]: what glibc's merge-sorting qsort leaves.
+    PE_FN void sec_stable_sort(uint32_t n) {
+        uint32_t *tmp = sec_key + cfg.sec_cap;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t me = ld(sec_ord[i]), k = ld(sec_key[me]);
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t kj = ld(sec_key[ld(sec_ord[j])]);
+                rank += (kj < k || (kj == k && j < i)) ? 1u : 0u;
+            }
+            st(tmp[rank], me);
+        }
+        for (uint32_t i = 0; i < n; i++) st(sec_ord[i], ld(tmp[i]));
+    }
+    PE_FN void finalize_secondary(int best_pair_score, const snapgpu_paired_result &res) {
+        uint32_t n = n_sec;
+        for (uint32_t i = 0; i < n; i++) {
+            snapgpu_paired_result *e = &sec[i];
+            const int s0 = ld(e->score[0]), s1 = ld(e->score[1]);
+            if (PL::lane0()) { e->score_prior_to_clipping[0] = s0; e->score_prior_to_clipping[1] = s1; }
+            st(sec_ord[i], i); st(sec_key[i], (uint32_t)(s0 + s1));
+        }
+        PL::sync();
+        {   // too far from the best now: the last entry moves into the hole (:1320-1331)
+            uint32_t i = 0;
+            while (i < n) {
+                if ((int)ld(sec_key[ld(sec_ord[i])]) > best_pair_score + cfg.om) { st(sec_ord[i], ld(sec_ord[n - 1])); n--; }
+                else i++;
+            }
+        }
+        if (cfg.mpc > 0 && res.status[0] != SNAPGPU_NotFound && n > 0) {                                            // :1336-1404
+            const int primary_contig = contig_num(res.location[0]);
+            // PairedAlignmentResult::compareByContigAndScore compares the ADDRESSES of the score arrays (AlignmentResult.cpp:82-85),
+            // and qsort sorts records this large through pointers to the originals: contig, then position in the list
+            bool too_many = false;
+            for (uint32_t i = 0; i < n; i++) st(sec_key[ld(sec_ord[i])], (uint32_t)contig_num(ld(sec[ld(sec_ord[i])].location[0])));
+            for (uint32_t i = 0; i < n && !too_many; i++) {
+                const uint32_t c = ld(sec_key[ld(sec_ord[i])]);
+                int count = (int)c == primary_contig ? 1 : 0;
+                for (uint32_t j = 0; j < n; j++) count += ld(sec_key[ld(sec_ord[j])]) == c ? 1 : 0;
+                if (count > cfg.mpc) too_many = true;
+            }
+            if (too_many) {
+                sec_stable_sort(n);
+                int cur = -1, cur_count = 0; uint32_t dest = 0;
+                for (uint32_t src = 0; src < n; src++) {
+                    const uint32_t me = ld(sec_ord[src]);
+                    const int c = (int)ld(sec_key[me]);
+                    if (c != cur) { cur = c; cur_count = c == primary_contig ? 1 : 0; }
+                    cur_count++;
+                    if (cur_count <= cfg.mpc) { st(sec_ord[dest], me); dest++; }
+                }
+                n = dest;
+            }
+        }
+        if ((int64_t)n > cfg.omax) {                                                                                // :1407-1410
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t me = ld(sec_ord[i]);
+                st(sec_key[me], (uint32_t)(ld(sec[me].score[0]) + ld(sec[me].score[1])));
+            }
+            sec_stable_sort(n);                                                                                    // compareByScore
+            n = (uint32_t)cfg.omax;
+        }
+        n_sec = n;
+    }
+    // secondary result k of this pair, after the filtering
+    PE_FN const snapgpu_paired_result *secondary(uint32_t k) const { return &sec[ld(sec_ord[k])]; }
 
     // ------------------------------------------------------------------ Phase 4 (alignAffineGap, :2489-2970)
     PE_FN void phase4() {
@@ -1293,6 +1395,7 @@ struct PairedCore {
 
     PE_FN void align_pair(int max_k_paired, int max_k_single) {
         overflow = 0; stale = 0;
+        n_sec = 0; n_ssec[0] = n_ssec[1] = 0; ref_dep = 0;                                                              // :151-153
         const uint64_t t_all = PL::clock();
         align_pair_inner(max_k_paired, max_k_single);
         sh->cnt.cyc_total += PL::clock() - t_all;
@@ -1364,18 +1467,26 @@ struct PairedCore {
                     max_k_read = max_k_single < a ? max_k_single : a;
                 }
                 const uint64_t t_s = PL::clock();
-                pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r]);
+                // single-end secondary results land behind read 0's (ChimericPairedEndAligner.cpp:308-312: "it's either 0 or all we've seen")
+                const uint32_t sec_base = n_ssec[0];
+                snapgpu_single_result *sec_dst = nullptr; uint32_t sec_room = 0;
+                if (cfg.om != -1 && ssec_out != nullptr && sec_base < ssec_stride) { sec_dst = ssec_out + sec_base; sec_room = ssec_stride - sec_base; }
+                const uint32_t room32 = sec_base < 32u ? 32u - sec_base : 0u;       // what PairedAligner.cpp:566's initial buffer would have left
+                uint32_t n_this = pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r], cfg.om != -1, sec_dst, sec_room, room32);
                 sh->cnt.cyc_single += PL::clock() - t_s;
                 stale += single[r].reserved & 0x7fffffffu;
                 bool used_hamming = false;
                 if (cfg.use_soft_clip && cfg.enable_hamming_base) {
                     if (single[r].status == SNAPGPU_NotFound && res.status[r] == SNAPGPU_NotFound) {                  // :330-360
                         used_hamming = true;
-                        pl.align_single(r, PL::i32(max_k_read), true, single[r], single_alt[r]);
+                        n_this = pl.align_single(r, PL::i32(max_k_read), true, single[r], single_alt[r], cfg.om != -1, sec_dst, sec_room, room32);
+                        // the reference drops this call's "buffer too small" on the floor (:339-343): see SNAPGPU_PAIR_REF_BUFFER_DEPENDENT
+                        if (cfg.om != -1 && pl.single_raw_secondary() > room32) ref_dep = 1;
                         stale += single[r].reserved & 0x7fffffffu;
                         if (single[r].reserved & 0x80000000u) { overflow = 1; return; }      // candidate buffer of the single-end aligner overflowed
                     }
                 }
+                n_ssec[r] = n_this;                                                                                   // :365
                 if (compare_single) {
                     if (!used_hamming) {
                         if (single[r].score != -1 && single[r].score != SNAPGPU_UnusedScoreValue) limit_left -= single[r].score;
