@@ -379,7 +379,7 @@ int  snapgpu_align_single_secondary_device(snapgpu_ctx *ctx, uint32_t n, const v
  * for a batch of n_pairs pairs: offsets has 2*n_pairs+1 entries, read r of pair i is
  * bases[offsets[2i+r] .. offsets[2i+r+1]).  primary/first_alt: [n_pairs] out (first_alt may be NULL).
  * ALT alignments are lifted over to the primary assembly as the reference does (IntersectingPairedEndAligner.cpp:2866-2968) when the
- * index view carries the contigs' projection data.  Secondary alignments (-om) are not produced.
+ * index view carries the contigs' projection data.  Secondary alignments (-om): snapgpu_align_paired_secondary.
  * A pair whose candidate pools overflowed is flagged (SNAPGPU_PAIR_POOL_OVERFLOW) and the call returns
  * SNAPGPU_E_UNSUPPORTED after filling in every other pair.
  */
@@ -390,6 +390,27 @@ int  snapgpu_align_paired(snapgpu_ctx *ctx, uint32_t n_pairs, const char *bases,
 /* device-pointer form, as snapgpu_align_single_device */
 int  snapgpu_align_paired_device(snapgpu_ctx *ctx, uint32_t n_pairs, const void *d_bases, const void *d_quals,
                                  const void *d_offsets, void *d_primary, void *d_first_alt, void *stream);
+
+/*
+ * ... with secondary results (both snapgpu_enable_paired and snapgpu_enable_secondary called on the context, in either order):
+ * ChimericPairedEndAligner::align's maxEditDistanceForSecondaryResults / secondaryResults / singleEndSecondaryResults arguments
+ * (ChimericPairedEndAligner.cpp:126-148), called as PairedAligner.cpp:727 calls it.
+ *   secondary:          [n_pairs * secondary_stride] paired secondary results, in the reference's order (IntersectingPairedEndAligner.cpp:
+ *                       999-1034, 1082-1124, final filtering 1289-1411); n_secondary[i] = how many pair i HAS
+ *   single_secondary:   [n_pairs * single_stride] single-end secondary results of the chimeric fallback: read 0's
+ *                       n_single_secondary[2i] results, then read 1's n_single_secondary[2i+1] (the layout of PairedAligner.cpp:872)
+ * Fields the reference leaves unset in a secondary result read as 0.  Returns SNAPGPU_W_SECONDARY_TRUNCATED when a pair has more than
+ * fits a stride (as snapgpu_align_single_secondary).  SNAPGPU_PAIR_REF_BUFFER_DEPENDENT marks the pairs on which the reference's own
+ * answer is an accident of its buffer size.
+ */
+int  snapgpu_align_paired_secondary(snapgpu_ctx *ctx, uint32_t n_pairs, const char *bases, const char *quals, const uint64_t *offsets,
+                                    snapgpu_paired_result *primary, snapgpu_paired_result *first_alt,
+                                    snapgpu_paired_result *secondary, uint32_t secondary_stride, uint32_t *n_secondary,
+                                    snapgpu_single_result *single_secondary, uint32_t single_stride, uint32_t *n_single_secondary);
+int  snapgpu_align_paired_secondary_device(snapgpu_ctx *ctx, uint32_t n_pairs, const void *d_bases, const void *d_quals,
+                                           const void *d_offsets, void *d_primary, void *d_first_alt,
+                                           void *d_secondary, uint32_t secondary_stride, void *d_n_secondary,
+                                           void *d_single_secondary, uint32_t single_stride, void *d_n_single_secondary, void *stream);
 
 /* Counters accumulated by snapgpu_align_single* since the last reset (device -> host). */
 int  snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int reset);

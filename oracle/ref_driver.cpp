@@ -718,6 +718,7 @@ void *snapref_chimeric_single_create2(void *vindex, const snapgpu_params *p, con
 {
     snapref_init();
     GenomeIndex *index = (GenomeIndex *)vindex;
+    g_index = index;                                   // SingleAlignmentResult::compareByContigAndScore reads it (-mpc)
     int maxReadSize = MAX_READ_LENGTH;
     ChimericSingle *c = new ChimericSingle();
     c->allocator = new BigAllocator(BaseAligner::getBigAllocatorReservation(index, true, p->max_hits, maxReadSize, index->getSeedLength(),

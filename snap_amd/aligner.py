@@ -50,6 +50,7 @@ EXPORTED_SYMBOLS = [
     "snapgpu_landau_vishkin", "snapgpu_affine_gap", "snapgpu_align_single",
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
     "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
+    "snapgpu_align_paired_secondary", "snapgpu_align_paired_secondary_device",
 ]
 
 
@@ -289,6 +290,34 @@ class ChimericPairedEndAligner(BaseAligner):
         self._check(self.lib.snapgpu_align_paired(self.handle, C.c_uint32(n), ptr(bases), ptr(quals), ptr(offsets),
                                                   ptr(primary), ptr(first_alt)), "snapgpu_align_paired")
         return primary, first_alt
+
+    def align_secondary(self, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray, stride: int = 8, single_stride: int = 16):
+        """ChimericPairedEndAligner::align with secondary results (after enable_secondary(...)): returns
+        (result[n], firstALT[n], secondary[n, stride'], nSecondary[n], singleSecondary[n, single_stride'], nSingleSecondary[n, 2]).
+        Like PairedAligner.cpp:727-779 it grows a buffer and calls again when a pair has more results than fit."""
+        from .abi import PAIRED_RESULT_DTYPE
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        if (offsets.size - 1) % 2:
+            raise ValueError("offsets must have 2*n_pairs + 1 entries")
+        n = (offsets.size - 1) // 2
+        primary = np.zeros(n, dtype=PAIRED_RESULT_DTYPE)
+        first_alt = np.zeros(n, dtype=PAIRED_RESULT_DTYPE)
+        while True:
+            sec = np.zeros((n, stride), dtype=PAIRED_RESULT_DTYPE)
+            nsec = np.zeros(n, dtype=np.uint32)
+            ssec = np.zeros((n, single_stride), dtype=RESULT_DTYPE)
+            nssec = np.zeros((n, 2), dtype=np.uint32)
+            rc = self.lib.snapgpu_align_paired_secondary(self.handle, C.c_uint32(n), ptr(bases), ptr(quals), ptr(offsets), ptr(primary),
+                                                         ptr(first_alt), ptr(sec), C.c_uint32(stride), ptr(nsec),
+                                                         ptr(ssec), C.c_uint32(single_stride), ptr(nssec))
+            if rc == 1:                                   # SNAPGPU_W_SECONDARY_TRUNCATED
+                stride = max(stride, int(nsec.max()))
+                single_stride = max(single_stride, int(nssec.sum(axis=1).max()))
+                continue
+            self._check(rc, "snapgpu_align_paired_secondary")
+            return primary, first_alt, sec, nsec, ssec, nssec
 
     def align_device(self, n_pairs: int, d_bases: int, d_quals: int, d_offsets: int, d_primary: int, d_first_alt: int = 0,
                      stream: int = 0):

@@ -173,7 +173,7 @@ struct Aligner {
     SecCfg sec_cfg;
     snapgpu_single_result *sec;        // [sec_cfg.cap]
     uint32_t *sec_key, *sec_ord;       // [sec_cfg.cap] each
-    uint32_t n_sec, sec_overflow;
+    uint32_t n_sec, n_sec_raw, sec_overflow;
     // Cold, wave-uniform state lives in LDS (WaveShared), not in registers: it is touched a few
     // times per candidate / per read, and keeping ~150 dwords of it live across the LV and
     // affine-gap code is what pushed the kernel to 1-2 waves per SIMD.  Every lane executes the
@@ -822,7 +822,7 @@ struct Aligner {
     template <bool HAM>
     __device__ __forceinline__ void align_read_inner(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         read_len = len;
-        if constexpr (SEC) { n_sec = 0; sec_overflow = 0; }                   // *nSecondaryResults = 0, :318-320
+        if constexpr (SEC) { n_sec = 0; n_sec_raw = 0; sec_overflow = 0; }    // *nSecondaryResults = 0, :318-320
         // result = NotFound (:334-344); remaining fields as a zero-initialised struct
         primary.status = SNAPGPU_NotFound; primary.direction = 0;
         primary.location = SNAPGPU_InvalidGenomeLocation32; primary.orig_location = 0;
@@ -948,7 +948,7 @@ struct Aligner {
         primary.score_prior_to_clipping = primary.score;                      // finalizeSecondaryResults, :2442
         primary.reserved = ag_stale;
         release_candidates();
-        if constexpr (SEC) finalize_secondary();
+        if constexpr (SEC) { n_sec_raw = n_sec; finalize_secondary(); }
     }
 
     // ------------------------------------------------------------------ BaseAligner::finalizeSecondaryResults (BaseAligner.cpp:2423-2553)

@@ -184,6 +184,9 @@ struct PairedCore {
     template <class T> static PE_FN T ld(const T &x) { return PL::ld(x); }
     template <class T, class V> static PE_FN void st(T &x, V v) { PL::st(x, (T)v); }
 
+    // secondary results wanted?  Compile-time off in the default kernel (PL::SECONDARY), so that it carries none of that code.
+    PE_FN bool want_sec() const { return PL::SECONDARY && cfg.om != -1; }
+
     static PE_FN int64_t dist(int64_t a, int64_t b) { return a > b ? a - b : b - a; }                 // DistanceBetweenGenomeLocations
     static PE_FN bool within(int64_t a, int64_t b, int64_t d) { return dist(a, b) <= d; }             // genomeLocationIsWithin
     static PE_FN int set_dir(int set_pair, int which_read) { return (set_pair == 0) ? which_read : 1 - which_read; }   // setPairDirection
@@ -932,7 +935,7 @@ struct PairedCore {
                                 bool close = hamming ? (pair_score <= all.best_pair_score && cfg.extra_depth >= all.best_pair_score - pair_score)
                                                      : (cfg.extra_depth >= all.best_pair_score - pair_score);
                                 // ... and as a secondary result (:999-1034 / :2077-2112)
-                                if (cfg.om != -1 && pair_p > all.p_best && (!hamming || pair_score <= all.best_pair_score) &&
+                                if (want_sec() && pair_p > all.p_best && (!hamming || pair_score <= all.best_pair_score) &&
                                     cfg.om >= all.best_pair_score - pair_score) {
                                     if (n_sec >= cfg.sec_cap) { overflow = 1; return; }
                                     agc_from_set(&sec[n_sec], all);
@@ -950,7 +953,7 @@ struct PairedCore {
                                                     : (pair_score <= cfg.max_k + cfg.extra_depth && cfg.extra_depth >= pair_score - all.best_pair_score);
                                 const bool near_sec = hamming ? (pair_score >= all.best_pair_score && cfg.om >= pair_score - all.best_pair_score)
                                                               : (pair_score <= cfg.max_k + cfg.extra_depth && cfg.om >= pair_score - all.best_pair_score);
-                                if (!updated && cfg.om != -1 && near_sec) {                                        // :1082-1124 / :2157-2199
+                                if (!updated && want_sec() && near_sec) {                                        // :1082-1124 / :2157-2199
                                     if (n_sec >= cfg.sec_cap) { overflow = 1; return; }
                                     agc_from_pair(&sec[n_sec], ci, (int)mi, sp, fewer_score, fewer_off);
                                     n_sec++;
@@ -960,7 +963,7 @@ struct PairedCore {
                                     agc_from_pair(&agc[n_agc], ci, (int)mi, sp, fewer_score, fewer_off);
                                     n_agc++;
                                 }
-                                if ((cfg.alt_aware ? non_alt.p_all : all.p_all) >= 4.9 && cfg.om == -1) { done = true; break; }    // :1181
+                                if ((cfg.alt_aware ? non_alt.p_all : all.p_all) >= 4.9 && !want_sec()) { done = true; break; }    // :1181
                             }
                         }
                     }
@@ -987,7 +990,7 @@ struct PairedCore {
             }
         }
         for (int w = 0; w < 2; w++) res.score_prior_to_clipping[w] = res.score[w];                                 // :1273-1275
-        if (cfg.om != -1) finalize_secondary(emit_best, res);
+        if (want_sec()) finalize_secondary(emit_best, res);
     }
 
     // ------------------------------------------------------------------ the tail of alignLandauVishkin / alignHamming (:1289-1411 / :2364-2483)
@@ -1470,18 +1473,18 @@ struct PairedCore {
                 // single-end secondary results land behind read 0's (ChimericPairedEndAligner.cpp:308-312: "it's either 0 or all we've seen")
                 const uint32_t sec_base = n_ssec[0];
                 snapgpu_single_result *sec_dst = nullptr; uint32_t sec_room = 0;
-                if (cfg.om != -1 && ssec_out != nullptr && sec_base < ssec_stride) { sec_dst = ssec_out + sec_base; sec_room = ssec_stride - sec_base; }
+                if (want_sec() && ssec_out != nullptr && sec_base < ssec_stride) { sec_dst = ssec_out + sec_base; sec_room = ssec_stride - sec_base; }
                 const uint32_t room32 = sec_base < 32u ? 32u - sec_base : 0u;       // what PairedAligner.cpp:566's initial buffer would have left
-                uint32_t n_this = pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r], cfg.om != -1, sec_dst, sec_room, room32);
+                uint32_t n_this = pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
                 sh->cnt.cyc_single += PL::clock() - t_s;
                 stale += single[r].reserved & 0x7fffffffu;
                 bool used_hamming = false;
                 if (cfg.use_soft_clip && cfg.enable_hamming_base) {
                     if (single[r].status == SNAPGPU_NotFound && res.status[r] == SNAPGPU_NotFound) {                  // :330-360
                         used_hamming = true;
-                        n_this = pl.align_single(r, PL::i32(max_k_read), true, single[r], single_alt[r], cfg.om != -1, sec_dst, sec_room, room32);
+                        n_this = pl.align_single(r, PL::i32(max_k_read), true, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
                         // the reference drops this call's "buffer too small" on the floor (:339-343): see SNAPGPU_PAIR_REF_BUFFER_DEPENDENT
-                        if (cfg.om != -1 && pl.single_raw_secondary() > room32) ref_dep = 1;
+                        if (want_sec() && pl.single_raw_secondary() > room32) ref_dep = 1;
                         stale += single[r].reserved & 0x7fffffffu;
                         if (single[r].reserved & 0x80000000u) { overflow = 1; return; }      // candidate buffer of the single-end aligner overflowed
                     }

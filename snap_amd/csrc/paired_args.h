@@ -41,6 +41,11 @@ struct PairedArgs {
     uint32_t kmax_lv;
     // second pass over the pairs whose candidate buffers overflowed in the first (see launch_paired): work item i is pair remap[i]
     const uint32_t *remap, *n_remap;
+    // secondary results (k_align_paired<.., true> only): extra sections of a wave's slab, and the caller's buffers
+    uint64_t off_sec, off_sec_ord, off_sec_key, off_ssec;
+    SecCfg ssec_cfg;                   // the single-end aligner's lists
+    snapgpu_paired_result *secondary; uint32_t sec_out_stride; uint32_t *n_secondary;                     // [n * stride], [n]
+    snapgpu_single_result *single_secondary; uint32_t ssec_out_stride; uint32_t *n_single_secondary;      // [n * stride], [2n]
 };
 
 
@@ -49,5 +54,7 @@ void snapgpu_launch_paired_3(const PairedArgs *a, uint32_t blocks, size_t lds_by
 void snapgpu_launch_paired_4(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_6(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_paired_sec_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_paired_sec_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, hipStream_t s);
 }

@@ -14,9 +14,9 @@
 #include "paired.h"
 #include "paired_args.h"
 
-template <int AGC>
+template <int AGC, bool SEC = false>
 struct DevPL {
-    Aligner<AGC> *al;                  // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
+    Aligner<AGC, SEC> *al;             // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
     const DevTables *tab;
     AGParams agp;
     uint32_t kmax_lv;                  // what the LV triangle was sized for
@@ -48,6 +48,7 @@ struct DevPL {
     // (off for the AGC == 0 variant -- reads longer than ~400 bp: with it ROCm 7.2's AMDGPU backend stops with "Illegal instruction
     //  detected: Operand has incorrect register class  V_CMP_NE_U32_e32 0, $src_shared_base"; the scalar queries are used there)
     static const bool FAST_HITSET = AGC != 0;
+    static const bool SECONDARY = SEC;
     static __device__ __forceinline__ uint32_t lk_hit(const PELookup *l, int64_t i) { return l->is_single ? l->singleton : l->hits[i]; }
     // wave arg-max of v over lanes with ok set; returns the winning lane (lowest lane among equals) or -1
     static __device__ __forceinline__ int wave_argmax(bool ok, int64_t v, int64_t *best) {
@@ -255,7 +256,10 @@ struct DevPL {
     }
     // BaseAligner::AlignRead with setMaxK(max_k) (ChimericPairedEndAligner.cpp:278-310); hamming: the retry of :330-360
     // (AlignRead(..., useHamming) followed by BaseAligner::alignAffineGap on the candidates it collected).
-    __device__ __forceinline__ void align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt) {
+    // Returns the number of secondary results the read has (SEC only); the first min(that, sec_room) are copied to sec_out.
+    __device__ __forceinline__ uint32_t align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt,
+                                                     bool want_secondary, snapgpu_single_result *sec_out, uint32_t sec_room, uint32_t room32) {
+        (void)want_secondary; (void)room32;
         al->max_k = (uint32_t)max_k;
         if (!hamming) {
             al->template align_read_inner<false>(g_bases[r], g_quals[r], g_len[r]);
@@ -269,12 +273,33 @@ struct DevPL {
         alt = al->first_alt;
         if (al->agc_overflow) res.reserved |= 0x80000000u;
         WAVE_SYNC();
+        if constexpr (SEC) {
+            if (al->sec_overflow) res.reserved |= 0x80000000u;                   // (sized so that it cannot happen)
+            const uint32_t n = al->n_sec;
+            const uint32_t n_out = n < sec_room ? n : sec_room;
+            const int lane = lane_id();
+            const int nd = (int)(sizeof(snapgpu_single_result) / 4);
+            for (uint32_t k0 = 0; k0 < n_out; k0 += 2) {                         // two 22-dword records per pass
+                const uint32_t k = k0 + (uint32_t)(lane >> 5);
+                const int w = lane & 31;
+                if (k < n_out && w < nd) ((uint32_t *)&sec_out[k])[w] = ((const uint32_t *)&al->sec[al->sec_ord[k]])[w];
+            }
+            WAVE_SYNC();
+            return n;
+        } else {
+            (void)sec_out; (void)sec_room;
+            return 0;
+        }
+    }
+    // secondary candidates the last align_single collected before finalizeSecondaryResults filtered them
+    __device__ __forceinline__ uint32_t single_raw_secondary() const {
+        if constexpr (SEC) return al->n_sec_raw; else return 0;
     }
 };
 
 // Scalar-heavy, latency-bound control flow: 2 waves per SIMD keeps 256 VGPRs available (no spills) and is what the LDS
 // footprint allows anyway.
-template <int AGC>
+template <int AGC, bool SEC>
 __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -287,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     uint8_t *sc = a.scratch + (size_t)wave_slot * a.stride;
 
     WaveShared *ws = (WaveShared *)(my + SL.shared);
-    Aligner<AGC> al(a.ix, a.tab, a.scfg, ws);
+    Aligner<AGC, SEC> al(a.ix, a.tab, a.scfg, ws);
     al.lane = lane;
     al.rd[0] = my + SL.rd0; al.rd[1] = my + SL.rd1;
     al.ql[0] = my + SL.ql0; al.ql[1] = my + SL.ql1;
@@ -304,11 +329,18 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     al.agc_cap = a.single_agc_cap;
     al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
-    DevPL<AGC> pl;
+    if constexpr (SEC) {            // secondary-result lists of the single-end aligner (as k_align_single<.., true> lays them out)
+        al.sec_cfg = a.ssec_cfg;
+        al.sec = (snapgpu_single_result *)(sc + a.off_ssec);
+        al.sec_key = (uint32_t *)(sc + a.off_ssec + (size_t)a.ssec_cfg.cap * sizeof(snapgpu_single_result));
+        al.sec_ord = al.sec_key + 2 * (size_t)a.ssec_cfg.cap;
+        al.n_sec = 0; al.n_sec_raw = 0; al.sec_overflow = 0;
+    }
+    DevPL<AGC, SEC> pl;
     pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv;
     pl.agp = AGParams{a.scfg.match_reward, a.scfg.sub_penalty, a.scfg.gap_open, a.scfg.gap_extend, a.scfg.five_bonus, a.scfg.three_bonus};
 
-    PairedCore<DevPL<AGC>> core(pl, a.pcfg);
+    PairedCore<DevPL<AGC, SEC>> core(pl, a.pcfg);
     core.lk = (PELookup *)(my + PLd.lk);
     core.exhausted = (uint32_t *)(my + PLd.exhausted);
     core.miss = (uint32_t *)(my + PLd.miss);
@@ -322,6 +354,13 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     core.anchor = (PEAnchor *)(sc + a.off_anchor);
     core.agc = (snapgpu_paired_result *)(sc + a.off_agc);
     core.agc_order = (uint32_t *)(sc + a.off_agc_order);
+    core.sec = nullptr; core.sec_ord = nullptr; core.sec_key = nullptr; core.n_sec = 0;
+    core.ssec_out = nullptr; core.ssec_stride = 0; core.n_ssec[0] = core.n_ssec[1] = 0; core.ref_dep = 0;
+    if constexpr (SEC) {
+        core.sec = (snapgpu_paired_result *)(sc + a.off_sec);
+        core.sec_ord = (uint32_t *)(sc + a.off_sec_ord);
+        core.sec_key = (uint32_t *)(sc + a.off_sec_key);
+    }
     core.sh->cnt = PECounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint8_t *prd = my + PLd.rd, *pql = my + PLd.ql;
     const uint32_t RL = a.scfg.RL;
@@ -356,9 +395,29 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
             if (lane < nd) { z0[lane] = 0; z1[lane] = 0; }
         }
         WAVE_SYNC();
+        if constexpr (SEC) {
+            core.ssec_out = a.ssec_out_stride ? a.single_secondary + (size_t)i * a.ssec_out_stride : nullptr;
+            core.ssec_stride = a.ssec_out_stride;
+        }
         core.align_pair(a.max_k_paired, a.max_k_single);
-        core.sh->res.flags = core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0;
+        core.sh->res.flags = (core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0) | (core.ref_dep ? SNAPGPU_PAIR_REF_BUFFER_DEPENDENT : 0);
         WAVE_SYNC();
+        if constexpr (SEC) {        // paired secondary results: sec[sec_ord[k]] -> secondary[i * stride + k]
+            const uint32_t n_sec = core.overflow ? 0u : core.n_sec;
+            if (lane == 0) {
+                a.n_secondary[i] = n_sec;
+                a.n_single_secondary[2 * (size_t)i] = core.overflow ? 0u : core.n_ssec[0];
+                a.n_single_secondary[2 * (size_t)i + 1] = core.overflow ? 0u : core.n_ssec[1];
+            }
+            const uint32_t n_out = n_sec < a.sec_out_stride ? n_sec : a.sec_out_stride;
+            const int nd = (int)(sizeof(snapgpu_paired_result) / 4);       // 52 dwords
+            for (uint32_t k = 0; k < n_out; k++) {
+                const uint32_t *src = (const uint32_t *)core.secondary(k);
+                uint32_t *dst = (uint32_t *)&a.secondary[(size_t)i * a.sec_out_stride + k];
+                if (lane < nd) dst[lane] = src[lane];
+            }
+            WAVE_SYNC();
+        }
         {
             const uint32_t *src = (const uint32_t *)&core.sh->res, *src2 = (const uint32_t *)&core.sh->alt;
             uint32_t *dst = (uint32_t *)&a.primary[i];

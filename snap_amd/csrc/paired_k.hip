@@ -1,5 +1,5 @@
 // paired_k.hip -- one affine-gap variant of the paired-end kernel per translation unit.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DPAIRED_AGC=<3|4|6|0> -c paired_k.hip
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -DPAIRED_AGC=<3|4|6|0> [-DPAIRED_SEC] -c paired_k.hip
 // (k_align_paired inlines the whole paired + single-end control flow; compiling the four variants in parallel keeps
 // the build at minutes instead of tens of minutes).
 #include <hip/hip_runtime.h>
@@ -11,12 +11,19 @@
 #define PE_CAT2(a, b) a##b
 #define PE_CAT(a, b) PE_CAT2(a, b)
 
+#ifdef PAIRED_SEC       // the variant that also produces secondary results (-om)
+extern "C" void PE_CAT(snapgpu_launch_paired_sec_, PAIRED_AGC)(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_align_paired<PAIRED_AGC, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
+}
+#else
 extern "C" void PE_CAT(snapgpu_launch_paired_, PAIRED_AGC)(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_align_paired<PAIRED_AGC>, dim3(blocks), dim3(256), lds_bytes, s, *a);
+    hipLaunchKernelGGL((k_align_paired<PAIRED_AGC, false>), dim3(blocks), dim3(256), lds_bytes, s, *a);
 }
+#endif
 
-#if PAIRED_AGC == 3
+#if PAIRED_AGC == 3 && !defined(PAIRED_SEC)
 extern "C" void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, hipStream_t s)
 {
     hipLaunchKernelGGL(k_collect_flagged<0>, dim3((n + 255) / 256), dim3(256), 0, s, primary, n, list, count);

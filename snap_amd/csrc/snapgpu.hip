@@ -183,6 +183,13 @@ struct snapgpu_ctx {
     uint32_t *d_flag_list = nullptr; size_t flag_list_cap = 0;
     uint32_t p_wave_slots = 0, p_big_slots = 0, p_lds_per_wave = 0;
     int p_ag_variant = 0;
+    // paired-end path with secondary results (both snapgpu_enable_paired and snapgpu_enable_secondary called): its own slabs
+    bool paired_sec = false;
+    PairedArgs pargs_sec{}, pargs_sec_big{};
+    uint8_t *d_pscratch_sec = nullptr, *d_pscratch_sec_big = nullptr;
+    uint32_t p_sec_slots = 0, p_sec_big_slots = 0;
+    void *d_psec_stage[4] = {nullptr, nullptr, nullptr, nullptr};      // paired secondary, counts, single secondary, counts
+    size_t psec_stage_cap[4] = {0, 0, 0, 0};
     std::string err;
 };
 
@@ -313,6 +320,9 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_pscratch) (void)hipFree(ctx->d_pscratch);
     if (ctx->d_pscratch_big) (void)hipFree(ctx->d_pscratch_big);
+    if (ctx->d_pscratch_sec) (void)hipFree(ctx->d_pscratch_sec);
+    if (ctx->d_pscratch_sec_big) (void)hipFree(ctx->d_pscratch_sec_big);
+    for (int i = 0; i < 4; i++) if (ctx->d_psec_stage[i]) (void)hipFree(ctx->d_psec_stage[i]);
     if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
@@ -846,6 +856,8 @@ extern "C" int snapgpu_align_single(snapgpu_ctx *ctx, uint32_t n, const char *ba
 // secondary results (-om / -omax / -mpc)
 // =====================================================================================
 
+static int setup_paired_secondary(snapgpu_ctx *ctx);
+
 extern "C" int snapgpu_enable_secondary(snapgpu_ctx *ctx, const snapgpu_secondary_params *sp)
 {
     if (!ctx || !sp) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_secondary: null argument");
@@ -871,7 +883,7 @@ extern "C" int snapgpu_enable_secondary(snapgpu_ctx *ctx, const snapgpu_secondar
     ctx->sec_cfg = SecCfg{sp->max_edit_distance, sp->max_per_contig, sp->max_results, (uint32_t)cap};
     ctx->sec_stride_bytes = stride;
     ctx->secondary = true;
-    return SNAPGPU_OK;
+    return setup_paired_secondary(ctx);       // (if the paired-end path is enabled too)
 }
 
 extern "C" int snapgpu_align_single_secondary_device(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals,
@@ -955,6 +967,74 @@ extern "C" void snapgpu_default_paired_params(snapgpu_paired_params *pp) {      
 }
 
 // Builds the per-wave state of IntersectingPairedEndAligner + ChimericPairedEndAligner (PairedAligner.cpp:556-625).
+// per-wave scratch slab of the paired-end kernel:
+// [single-end: heads | buckets | AG traceback] [single AG candidates] [cand] [mate0] [mate1] [anchor] [paired AG candidates]
+// and, for the secondary-result variant, [paired secondary list | order | keys] [single-end secondary list | keys | order]
+static void paired_lay_out(PairedArgs &x, bool sec) {
+    const AlignCfg &sc = x.scfg;
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t ag_bytes = sc.use_ag ? ag_scratch_bytes(sc.RL) : 0;
+    size_t off = up((size_t)sc.ht_size * 2 + (size_t)sc.pool_size * sizeof(Elem) + ag_bytes);
+    x.off_single_agc = off; off += up((size_t)x.single_agc_cap * sizeof(snapgpu_single_result));
+    x.off_cand = off;   off += up((size_t)x.pcfg.pool_size * sizeof(PECand));
+    x.off_mate0 = off;  off += up((size_t)(x.pcfg.pool_size / 2 + 1) * sizeof(PEMate));
+    x.off_mate1 = off;  off += up((size_t)(x.pcfg.pool_size / 2 + 1) * sizeof(PEMate));
+    x.off_anchor = off; off += up((size_t)x.pcfg.pool_size * sizeof(PEAnchor));
+    x.off_agc = off;    off += up((size_t)(x.pcfg.ag_cand_cap + 1) * sizeof(snapgpu_paired_result));
+    x.off_agc_order = off; off += up((size_t)(x.pcfg.ag_cand_cap + 1) * 4);
+    if (sec) {
+        x.off_sec = off;     off += up((size_t)(x.pcfg.sec_cap + 1) * sizeof(snapgpu_paired_result));
+        x.off_sec_ord = off; off += up((size_t)(x.pcfg.sec_cap + 1) * 4);
+        x.off_sec_key = off; off += up((size_t)(2 * x.pcfg.sec_cap + 2) * 4);
+        x.off_ssec = off;    off += up((size_t)x.ssec_cfg.cap * (sizeof(snapgpu_single_result) + 12));
+    }
+    x.stride = off;
+}
+
+// The paired-end kernel with secondary results has its own (fewer, larger) slabs, so that the default path is untouched.
+static int setup_paired_secondary(snapgpu_ctx *ctx)
+{
+    if (ctx->d_pscratch_sec) { (void)hipFree(ctx->d_pscratch_sec); ctx->d_pscratch_sec = nullptr; }
+    if (ctx->d_pscratch_sec_big) { (void)hipFree(ctx->d_pscratch_sec_big); ctx->d_pscratch_sec_big = nullptr; }
+    ctx->paired_sec = false;
+    if (!ctx->paired || !ctx->secondary) return SNAPGPU_OK;
+    PairedArgs &a = ctx->pargs_sec;
+    a = ctx->pargs;
+    a.pcfg.om = ctx->sec_cfg.om; a.pcfg.mpc = ctx->sec_cfg.mpc; a.pcfg.omax = ctx->sec_cfg.omax;
+    a.pcfg.sec_cap = 4096;
+    // the single-end aligner of the chimeric fallback: at most one entry per ScoreSet per scored candidate (see snapgpu_enable_secondary)
+    uint64_t seeds = a.scfg.num_seeds ? a.scfg.num_seeds : (uint64_t)(2 * a.scfg.seed_coverage * ctx->params.max_read_len / ctx->ix.seed_len) + 1;
+    uint64_t cap = 2 * (seeds + 1) * a.scfg.max_hits + 2;
+    if (cap > (1u << 20)) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "2 * seeds * max_hits > 2^20 secondary candidates per read is not supported");
+    a.ssec_cfg = SecCfg{ctx->sec_cfg.om, ctx->sec_cfg.mpc, ctx->sec_cfg.omax, (uint32_t)cap};
+    paired_lay_out(a, true);
+    PairedArgs &big = ctx->pargs_sec_big;
+    big = a;
+    big.pcfg.ag_cand_cap = a.pcfg.ag_cand_cap * 8;
+    big.single_agc_cap = a.single_agc_cap * 32;
+    big.pcfg.sec_cap = a.pcfg.sec_cap * 32;
+    paired_lay_out(big, true);
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(ctx, hipMemGetInfo(&free_b, &total_b), SNAPGPU_E_NODEVICE);
+    uint32_t slots = ctx->p_wave_slots;
+    while (slots > 64 && (size_t)slots * a.stride > free_b / 2) slots /= 2;
+    slots &= ~3u;
+    if ((size_t)slots * a.stride > free_b / 2) return fail(ctx, SNAPGPU_E_NOMEM, "not enough device memory for the paired-end secondary-result lists");
+    ctx->p_sec_slots = slots;
+    ctx->p_sec_big_slots = 64;
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_pscratch_sec, (size_t)slots * a.stride), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, hipMalloc((void **)&ctx->d_pscratch_sec_big, (size_t)ctx->p_sec_big_slots * big.stride), SNAPGPU_E_NOMEM);
+    for (uint32_t w = 0; w < slots; w++)              // only the single-end head tables must start zeroed
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_pscratch_sec + (size_t)w * a.stride, 0, (size_t)a.scfg.ht_size * 2, ctx->stream), SNAPGPU_E_NODEVICE);
+    for (uint32_t w = 0; w < ctx->p_sec_big_slots; w++)
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_pscratch_sec_big + (size_t)w * big.stride, 0, (size_t)a.scfg.ht_size * 2, ctx->stream), SNAPGPU_E_NODEVICE);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
+    a.scratch = ctx->d_pscratch_sec;
+    big.scratch = ctx->d_pscratch_sec_big;
+    ctx->paired_sec = true;
+    return SNAPGPU_OK;
+}
+
 extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_params *pp)
 {
     if (!ctx || !pp) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_paired: null argument");
@@ -1003,6 +1083,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     c.min_score_realign = pp->min_score_realignment; c.min_score_gap_realign_alt = pp->min_score_gap_realignment_alt;
     c.min_ag_improve = pp->min_ag_score_improvement; c.enable_hamming_base = pp->enable_hamming_scoring_base_aligner ? 1 : 0;
     c.seed_len = (int)ctx->ix.seed_len;
+    c.om = -1; c.mpc = -1; c.omax = 0x7fffffff; c.sec_cap = 0;              // no secondary results on the default path (setup_paired_secondary)
     // maxSeedsToUse of the constructor (:69-74) sizes the pools (:141)
     uint32_t ctor_seeds = c.num_seeds != 0 ? c.num_seeds : (uint32_t)(1000 * pp->seed_coverage / ctx->ix.seed_len);
     if (ctor_seeds < 1) ctor_seeds = 1;
@@ -1029,20 +1110,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         if (getenv("SNAPGPU_AG_LDS")) ctx->p_ag_variant = 0;
     }
 
-    // per-wave scratch slab: [single-end: heads | buckets | AG traceback] [single AG candidates] [cand] [mate0] [mate1] [anchor] [paired AG candidates]
-    auto lay_out = [&](PairedArgs &x) {
-        size_t ag_bytes = sc.use_ag ? ag_scratch_bytes(sc.RL) : 0;
-        size_t off = ((size_t)sc.ht_size * 2 + (size_t)sc.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
-        x.off_single_agc = off; off += ((size_t)x.single_agc_cap * sizeof(snapgpu_single_result) + 255) & ~(size_t)255;
-        x.off_cand = off;   off += ((size_t)x.pcfg.pool_size * sizeof(PECand) + 255) & ~(size_t)255;
-        x.off_mate0 = off;  off += ((size_t)(x.pcfg.pool_size / 2 + 1) * sizeof(PEMate) + 255) & ~(size_t)255;
-        x.off_mate1 = off;  off += ((size_t)(x.pcfg.pool_size / 2 + 1) * sizeof(PEMate) + 255) & ~(size_t)255;
-        x.off_anchor = off; off += ((size_t)x.pcfg.pool_size * sizeof(PEAnchor) + 255) & ~(size_t)255;
-        x.off_agc = off;    off += ((size_t)(x.pcfg.ag_cand_cap + 1) * sizeof(snapgpu_paired_result) + 255) & ~(size_t)255;
-        x.off_agc_order = off; off += ((size_t)(x.pcfg.ag_cand_cap + 1) * 4 + 255) & ~(size_t)255;
-        x.stride = off;
-    };
-    lay_out(a);
+    paired_lay_out(a, false);
     // The reference doubles its affine-gap candidate buffers when they overflow and aligns the pair again
     // (PairedAligner.cpp:727-779).  Here: pairs that overflow the first pass's buffers are redone by a second launch of a
     // few waves whose buffers are 32x larger; only what still does not fit is reported.
@@ -1050,7 +1118,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     big = a;
     big.pcfg.ag_cand_cap = a.pcfg.ag_cand_cap * 8;
     big.single_agc_cap = a.single_agc_cap * 32;
-    lay_out(big);
+    paired_lay_out(big, false);
 
     LdsLayout SL = lds_layout(sc.RL, sc.num_weight_lists, sc.kmax, sc.use_ag);
     PairedLds PL = paired_lds_layout(SL.total, sc.RL, c.max_seeds);
@@ -1079,13 +1147,23 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
     big.scratch = ctx->d_pscratch_big;
     ctx->paired = true;
-    return SNAPGPU_OK;
+    return setup_paired_secondary(ctx);
 }
 
+struct PairedSecOut {          // device buffers of a call that wants secondary results
+    void *secondary; uint32_t stride; void *n_secondary;
+    void *single_secondary; uint32_t single_stride; void *n_single_secondary;
+};
+
 static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals, const void *d_offsets,
-                         void *d_primary, void *d_first_alt, hipStream_t s)
+                         void *d_primary, void *d_first_alt, hipStream_t s, const PairedSecOut *so = nullptr)
 {
-    PairedArgs a = ctx->pargs;
+    PairedArgs a = so ? ctx->pargs_sec : ctx->pargs;
+    if (so) {
+        a.secondary = (snapgpu_paired_result *)so->secondary; a.sec_out_stride = so->stride; a.n_secondary = (uint32_t *)so->n_secondary;
+        a.single_secondary = (snapgpu_single_result *)so->single_secondary; a.ssec_out_stride = so->single_stride;
+        a.n_single_secondary = (uint32_t *)so->n_single_secondary;
+    }
     a.bases = (const uint8_t *)d_bases; a.quals = (const uint8_t *)d_quals; a.offsets = (const uint64_t *)d_offsets;
     a.n_pairs = n; a.primary = (snapgpu_paired_result *)d_primary; a.first_alt = (snapgpu_paired_result *)d_first_alt;
     a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
@@ -1097,11 +1175,16 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_flag_list, cap * 4), SNAPGPU_E_NOMEM);
         ctx->flag_list_cap = cap;
     }
-    uint32_t blocks = ctx->p_wave_slots / 4;
+    uint32_t blocks = (so ? ctx->p_sec_slots : ctx->p_wave_slots) / 4;
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     const size_t lds = (size_t)4 * ctx->p_lds_per_wave;
     auto launch = [&](const PairedArgs &x, uint32_t nblocks) {
+        if (so) {                              // secondary results: the 192-position register variant, or the LDS form for everything longer
+            if (ctx->p_ag_variant == 3) snapgpu_launch_paired_sec_3(&x, nblocks, lds, s);
+            else snapgpu_launch_paired_sec_0(&x, nblocks, lds, s);
+            return;
+        }
         switch (ctx->p_ag_variant) {           // one translation unit per affine-gap variant (paired_k.hip), compiled in parallel
         case 3:  snapgpu_launch_paired_3(&x, nblocks, lds, s); break;
         case 4:  snapgpu_launch_paired_4(&x, nblocks, lds, s); break;
@@ -1115,10 +1198,12 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         uint32_t *d_count = ctx->d_work + 2, *d_work2 = ctx->d_work + 1;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 1, 0, 8, s), SNAPGPU_E_LAUNCH);
         snapgpu_launch_collect_flagged((const snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count, s);
-        PairedArgs b = ctx->pargs_big;
+        PairedArgs b = so ? ctx->pargs_sec_big : ctx->pargs_big;
+        b.secondary = a.secondary; b.sec_out_stride = a.sec_out_stride; b.n_secondary = a.n_secondary;
+        b.single_secondary = a.single_secondary; b.ssec_out_stride = a.ssec_out_stride; b.n_single_secondary = a.n_single_secondary;
         b.bases = a.bases; b.quals = a.quals; b.offsets = a.offsets; b.n_pairs = n; b.primary = a.primary; b.first_alt = a.first_alt;
         b.work_counter = d_work2; b.counters = a.counters; b.remap = ctx->d_flag_list; b.n_remap = d_count;
-        launch(b, ctx->p_big_slots / 4);
+        launch(b, (so ? ctx->p_sec_big_slots : ctx->p_big_slots) / 4);
     }
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
@@ -1172,6 +1257,88 @@ extern "C" int snapgpu_align_paired(snapgpu_ctx *ctx, uint32_t n_pairs, const ch
         if (primary[i].flags & SNAPGPU_PAIR_POOL_OVERFLOW)
             return fail(ctx, SNAPGPU_E_UNSUPPORTED, "a read pair needed more candidate entries than the per-wave pools hold (the reference would grow its buffers or ask for -mcp); its result is flagged");
     return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_align_paired_secondary_device(snapgpu_ctx *ctx, uint32_t n_pairs, const void *d_bases, const void *d_quals,
+                                                     const void *d_offsets, void *d_primary, void *d_first_alt,
+                                                     void *d_secondary, uint32_t secondary_stride, void *d_n_secondary,
+                                                     void *d_single_secondary, uint32_t single_stride, void *d_n_single_secondary, void *stream)
+{
+    if (!ctx || !d_bases || !d_quals || !d_offsets || !d_primary || !d_n_secondary || !d_n_single_secondary ||
+        (secondary_stride && !d_secondary) || (single_stride && !d_single_secondary))
+        return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_paired_secondary_device: null argument");
+    if (!ctx->paired_sec) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_paired and snapgpu_enable_secondary must both have been called on this context");
+    if (n_pairs == 0) return SNAPGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    PairedSecOut so{d_secondary, secondary_stride, d_n_secondary, d_single_secondary, single_stride, d_n_single_secondary};
+    int rc = launch_paired(ctx, n_pairs, d_bases, d_quals, d_offsets, d_primary, d_first_alt, s, &so);
+    if (rc) return rc;
+    if (!stream) return finish_timing(ctx);
+    return SNAPGPU_OK;
+}
+
+static int ensure_psec_stage(snapgpu_ctx *ctx, int which, size_t bytes) {
+    if (ctx->psec_stage_cap[which] >= bytes) return 0;
+    if (ctx->d_psec_stage[which]) (void)hipFree(ctx->d_psec_stage[which]);
+    ctx->d_psec_stage[which] = nullptr; ctx->psec_stage_cap[which] = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIPCHK(ctx, hipMalloc(&ctx->d_psec_stage[which], cap), SNAPGPU_E_NOMEM);
+    ctx->psec_stage_cap[which] = cap;
+    return 0;
+}
+
+extern "C" int snapgpu_align_paired_secondary(snapgpu_ctx *ctx, uint32_t n_pairs, const char *bases, const char *quals, const uint64_t *offsets,
+                                              snapgpu_paired_result *primary, snapgpu_paired_result *first_alt,
+                                              snapgpu_paired_result *secondary, uint32_t secondary_stride, uint32_t *n_secondary,
+                                              snapgpu_single_result *single_secondary, uint32_t single_stride, uint32_t *n_single_secondary)
+{
+    if (!ctx || !bases || !quals || !offsets || !primary || !n_secondary || !n_single_secondary ||
+        (secondary_stride && !secondary) || (single_stride && !single_secondary))
+        return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_paired_secondary: null argument");
+    if (!ctx->paired_sec) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_paired and snapgpu_enable_secondary must both have been called on this context");
+    if (n_pairs == 0) return SNAPGPU_OK;
+    const size_t nr = (size_t)2 * n_pairs;
+    for (size_t i = 0; i < nr; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(ctx, SNAPGPU_E_INVALID, "offsets must be non-decreasing");
+        if (offsets[i + 1] - offsets[i] > ctx->params.max_read_len)
+            return fail(ctx, SNAPGPU_E_INVALID, "read longer than max_read_len given at snapgpu_create (IntersectingPairedEndAligner.cpp:361-365)");
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    size_t nb = (size_t)offsets[nr];
+    const size_t sec_bytes = (size_t)n_pairs * secondary_stride * sizeof(snapgpu_paired_result);
+    const size_t ssec_bytes = (size_t)n_pairs * single_stride * sizeof(snapgpu_single_result);
+    int rc;
+    if ((rc = ensure_stage(ctx, 0, nb + 16)) || (rc = ensure_stage(ctx, 1, nb + 16)) || (rc = ensure_stage(ctx, 2, (nr + 1) * 8)) ||
+        (rc = ensure_stage(ctx, 3, (size_t)n_pairs * sizeof(snapgpu_paired_result))) ||
+        (rc = ensure_stage(ctx, 4, (size_t)n_pairs * sizeof(snapgpu_paired_result))) ||
+        (rc = ensure_psec_stage(ctx, 0, sec_bytes + 16)) || (rc = ensure_psec_stage(ctx, 1, (size_t)n_pairs * 4)) ||
+        (rc = ensure_psec_stage(ctx, 2, ssec_bytes + 16)) || (rc = ensure_psec_stage(ctx, 3, nr * 4))) return rc;
+    hipStream_t s = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[0], bases, nb, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[1], quals, nb, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[2], offsets, (nr + 1) * 8, hipMemcpyHostToDevice, s), SNAPGPU_E_LAUNCH);
+    if (sec_bytes) HIPCHK(ctx, hipMemsetAsync(ctx->d_psec_stage[0], 0, sec_bytes, s), SNAPGPU_E_LAUNCH);
+    if (ssec_bytes) HIPCHK(ctx, hipMemsetAsync(ctx->d_psec_stage[2], 0, ssec_bytes, s), SNAPGPU_E_LAUNCH);
+    PairedSecOut so{ctx->d_psec_stage[0], secondary_stride, ctx->d_psec_stage[1], ctx->d_psec_stage[2], single_stride, ctx->d_psec_stage[3]};
+    rc = launch_paired(ctx, n_pairs, ctx->d_stage[0], ctx->d_stage[1], ctx->d_stage[2], ctx->d_stage[3], first_alt ? ctx->d_stage[4] : nullptr, s, &so);
+    if (rc) return rc;
+    HIPCHK(ctx, hipMemcpyAsync(primary, ctx->d_stage[3], (size_t)n_pairs * sizeof(snapgpu_paired_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    if (first_alt) HIPCHK(ctx, hipMemcpyAsync(first_alt, ctx->d_stage[4], (size_t)n_pairs * sizeof(snapgpu_paired_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    if (sec_bytes) HIPCHK(ctx, hipMemcpyAsync(secondary, ctx->d_psec_stage[0], sec_bytes, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(n_secondary, ctx->d_psec_stage[1], (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    if (ssec_bytes) HIPCHK(ctx, hipMemcpyAsync(single_secondary, ctx->d_psec_stage[2], ssec_bytes, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(n_single_secondary, ctx->d_psec_stage[3], nr * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    rc = finish_timing(ctx);
+    if (rc) return rc;
+    bool truncated = false;
+    for (uint32_t i = 0; i < n_pairs; i++) {
+        if (primary[i].flags & SNAPGPU_PAIR_POOL_OVERFLOW)
+            return fail(ctx, SNAPGPU_E_UNSUPPORTED, "a read pair needed more candidate entries than the per-wave pools hold (the reference would grow its buffers or ask for -mcp); its result is flagged");
+        if (n_secondary[i] > secondary_stride || (uint64_t)n_single_secondary[2 * (size_t)i] + n_single_secondary[2 * (size_t)i + 1] > single_stride) truncated = true;
+    }
+    return truncated ? SNAPGPU_W_SECONDARY_TRUNCATED : SNAPGPU_OK;
 }
 
 extern "C" int snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int reset) {

@@ -89,3 +89,52 @@ def alt_liftover_genome():
     sam = ("@HD\tVN:1.0\nchrA_alt1\t0\tchrA\t20001\t255\t5000M10D2990M20I4000M\t*\t0\t0\t*\t*\n"
            "chrB_alt2\t16\tchrB\t40001\t255\t100S9000M\t*\t0\t0\t*\t*\n")
     return g + [("chrA_alt1", alt1), ("chrB_alt2", alt2)], sam, ["-altContigName", "chrA_alt1", "-altContigName", "chrB_alt2"]
+
+
+# ---- secondary results (-om): comparison of (primary, alt, secondary, nsec, single_secondary, nssec) tuples
+# fields of a secondary result the reference never writes: they hold whatever its buffer held (0 on this side)
+PAIRED_SECONDARY_UNSET = ("ref_span", "reserved", "flags", "probability_all_pairs", "liftover", "supplementary",
+                          "clipping_for_read_adjustment", "aligned_as_pair", "ag_forced_single_aligner_call")
+SINGLE_SECONDARY_UNSET = ("reserved", "probability_all_candidates", "popular_seeds_skipped")
+
+
+def load_paired_secondary_sets(z):
+    import ast
+    return [(str(r[0]), ast.literal_eval(str(r[1])), ast.literal_eval(str(r[2])), int(r[3]), int(r[4]), int(r[5])) for r in z["sets"]]
+
+
+def compare_paired_secondary(ref_t, got_t, exclude):
+    """Position-by-position comparison of the secondary results of two runs; returns a list of problems."""
+    _, _, rsec, rn, rssec, rns = ref_t
+    _, _, gsec, gn, gssec, gns = got_t
+    problems = []
+    m = (rn != gn) & ~exclude
+    if m.any():
+        i = int(np.nonzero(m)[0][0])
+        problems.append("nSecondaryResults differs for %d pairs, first %d: ref %d got %d" % (int(m.sum()), i, rn[i], gn[i]))
+    m = (rns != gns).any(axis=1) & ~exclude
+    if m.any():
+        i = int(np.nonzero(m)[0][0])
+        problems.append("nSingleEndSecondaryResults differs for %d pairs, first %d: ref %s got %s" % (int(m.sum()), i, rns[i], gns[i]))
+    w = min(rsec.shape[1], gsec.shape[1])
+    live = (np.arange(w)[None, :] < np.minimum(rn, gn)[:, None]) & ~exclude[:, None]
+    for f in rsec.dtype.names:
+        if f in PAIRED_SECONDARY_UNSET:
+            continue
+        d = rsec[f][:, :w] != gsec[f][:, :w]
+        if d.ndim == 3:
+            d = d.any(axis=2)
+        d &= live
+        if d.any():
+            i, k = [int(x[0]) for x in np.nonzero(d)]
+            problems.append("secondary[%d].%s differs for %d records, first at pair %d: ref %r got %r" % (k, f, int(d.sum()), i, rsec[f][i, k], gsec[f][i, k]))
+    w = min(rssec.shape[1], gssec.shape[1])
+    live = (np.arange(w)[None, :] < np.minimum(rns.sum(axis=1), gns.sum(axis=1))[:, None]) & ~exclude[:, None]
+    for f in rssec.dtype.names:
+        if f in SINGLE_SECONDARY_UNSET:
+            continue
+        d = (rssec[f][:, :w] != gssec[f][:, :w]) & live
+        if d.any():
+            i, k = [int(x[0]) for x in np.nonzero(d)]
+            problems.append("single_secondary[%d].%s differs for %d records, first at pair %d: ref %r got %r" % (k, f, int(d.sum()), i, rssec[f][i, k], gssec[f][i, k]))
+    return problems

@@ -163,3 +163,47 @@ def test_alt_index_without_liftover_data(golden_index, golden_reads):
     bad = compare_paired(rp, gp, verbose=3, exclude=gp["reserved"] != 0)
     assert not bad.any()
     assert (ra["status"] == ga["status"])[gp["reserved"] == 0].all()
+
+
+# ---------------------------------------------------------------------------------------- secondary results (-om / -omax / -mpc)
+
+@pytest.mark.parametrize("tag", ["150", "100"])
+def test_paired_secondary_results_vs_reference_fixture(tag):
+    """ChimericPairedEndAligner::align with secondary results through the C ABI against tests/golden/paired_secondary.npz:
+    primary, paired secondary results (order included) and the single-end secondary results of the chimeric fallback."""
+    from snap_amd.aligner import ChimericPairedEndAligner
+    from tests.pairs_util import compare_paired_secondary, load_paired_secondary_sets
+    z = np.load(os.path.join(util.GOLDEN, "paired_secondary.npz"))
+    gp = np.load(os.path.join(util.GOLDEN, "paired_reads.npz"))
+    gi = util.load_golden_index("paired_index.npz")
+    b, q, o = gp["b" + tag], gp["q" + tag], gp["o" + tag]
+    if tag == "150":
+        o = o[:1201]; b = b[:int(o[-1])]; q = q[:int(o[-1])]
+    for name, kw, pkw, om, omax, mpc in load_paired_secondary_sets(z):
+        key = "%s_%s_" % (name, tag)
+        ref_t = tuple(z[key + k] for k in ("primary", "alt", "secondary", "nsec", "single_secondary", "nssec"))
+        a = ChimericPairedEndAligner(gi, abi.default_params(max_read_len=160, **kw), abi.default_paired_params(**pkw))
+        try:
+            a.enable_secondary(om, max_results=omax, max_per_contig=mpc)
+            got = a.align_secondary(b, q, o, stride=2, single_stride=4)          # small strides: exercises the grow-and-recall path
+            plain, _ = a.align(b[:int(o[200])], q[:int(o[200])], o[:201])         # the default kernel still runs on the same context
+        finally:
+            a.close()
+        exclude = z[key + "unstable"] | (got[0]["reserved"] != 0) | ((got[0]["flags"] & 2) != 0)
+        assert int(exclude.sum()) <= 2 + got[0].size // 100, name
+        assert not compare_paired(ref_t[0], got[0], verbose=3, exclude=exclude).any(), name
+        problems = compare_paired_secondary(ref_t, got, exclude)
+        assert not problems, (name, problems)
+        assert int(got[3].sum()) > 0 and int(got[5].sum()) > 0
+        assert not (plain["flags"] & 1).any()
+
+
+def test_paired_secondary_needs_both_enabled():
+    from snap_amd.aligner import ChimericPairedEndAligner, SnapGpuError
+    gi = util.load_golden_index("paired_index.npz")
+    a = ChimericPairedEndAligner(gi, abi.default_params(max_k=8, max_read_len=160), abi.default_paired_params())
+    try:
+        with pytest.raises(SnapGpuError):
+            a.align_secondary(np.zeros(200, np.uint8) + 65, np.zeros(200, np.uint8) + 70, np.array([0, 100, 200], np.uint64))
+    finally:
+        a.close()
