@@ -112,13 +112,21 @@ public:
             return false;                                   // I/O-only mode: leave it to SNAP
         }
         PairedAlignerOptions *po = (PairedAlignerOptions *)c->options;
-        if (c->maxSecondaryAlignmentAdditionalEditDistance >= 0 || c->options->stopOnFirstHit || !c->ignoreAlignmentAdjustmentForOm ||
+        if (c->options->stopOnFirstHit || !c->ignoreAlignmentAdjustmentForOm ||
             c->index->doesGenomeIndexHave64BitLocations() || po->inferSpacing) {
-            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-om, -f, -ins, -sa or a 64-bit index)\n");
+            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-f, -ae, -ins or a 64-bit index)\n");
             soft_exit(1);
         }
         ensureContext(c, 25);
         ensurePaired(c, po);
+        const bool secondary = c->maxSecondaryAlignmentAdditionalEditDistance >= 0;      // -om
+        if (secondary) ensureSecondary(c);
+        uint32_t secStride = 8, singleStride = 16;
+        std::vector<snapgpu_paired_result> sec;
+        std::vector<snapgpu_single_result> ssec;
+        std::vector<uint32_t> nSec, nSingleSec;
+        std::vector<PairedAlignmentResult> results;
+        std::vector<SingleAlignmentResult> singles;
 
         const unsigned BATCH = 8192;                        // pairs
         ReadWithOwnMemory *reads = (ReadWithOwnMemory *)BigAlloc((size_t)2 * BATCH * sizeof(ReadWithOwnMemory));
@@ -151,7 +159,8 @@ public:
                     bool pass = (c->options->filterFlags & AlignerOptions::FilterBothMatesMatch) ? (pass0 && pass1) : (pass0 || pass1);
                     if (pass) {
                         if (NULL != c->readWriter) {
-                            c->readWriter->writePairs(c->readerContext, pr, &result, 1, NULL, nSingleResults, true, c->useAffineGap);
+                            _int64 noSingles[2] = {0, 0};
+                            c->readWriter->writePairs(c->readerContext, pr, &result, 1, NULL, noSingles, true, c->useAffineGap);
                         }
                         c->stats->uselessReads += 2;
                     } else {
@@ -172,7 +181,22 @@ public:
             if (bases.empty()) { bases.push_back(0); quals.push_back(0); }
 
             pthread_mutex_lock(&g_gpuLock);
-            int rc = snapgpu_align_paired(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
+            int rc;
+            if (secondary) {
+                // align() with secondary-result buffers; like PairedAligner.cpp:727-756, grow what was too small and call again
+                for (;;) {
+                    sec.resize((size_t)n * secStride); nSec.resize(n); ssec.resize((size_t)n * singleStride); nSingleSec.resize((size_t)2 * n);
+                    rc = snapgpu_align_paired_secondary(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0], &sec[0], secStride, &nSec[0],
+                                                        &ssec[0], singleStride, &nSingleSec[0]);
+                    if (rc != SNAPGPU_W_SECONDARY_TRUNCATED) break;
+                    for (unsigned i = 0; i < n; i++) {
+                        if (nSec[i] > secStride) secStride = nSec[i];
+                        if (nSingleSec[2 * i] + nSingleSec[2 * i + 1] > singleStride) singleStride = nSingleSec[2 * i] + nSingleSec[2 * i + 1];
+                    }
+                }
+            } else {
+                rc = snapgpu_align_paired(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
+            }
             pthread_mutex_unlock(&g_gpuLock);
             if (rc != SNAPGPU_OK) {
                 WriteErrorMessage("snapgpu_align_paired failed (%d): %s\n", rc, snapgpu_last_error(g_ctx));
@@ -191,14 +215,41 @@ public:
                     result.basesClippedAfter[0] = result.basesClippedAfter[1] = 0;
                     result.agScore[0] = result.agScore[1] = 0;
                 }
-                bool pass0 = c->options->passFilter(two[0], result.status[0], !useful[2 * i], false);
-                bool pass1 = c->options->passFilter(two[1], result.status[1], !useful[2 * i + 1], false);
-                bool pass = (c->options->filterFlags & AlignerOptions::FilterBothMatesMatch) ? (pass0 && pass1) : (pass0 || pass1);
-                _int64 nResults = pass ? 1 : 0;
-                bool firstIsPrimary = pass;
+                // PairedAligner.cpp:843-890: the primary and the paired secondary results go through the filter (the last one moves into
+                // a hole), then the single-end secondary results of each read, then everything is written
+                _int64 nSecondaryResults = secondary ? (_int64)nSec[i] : 0;
+                results.resize((size_t)nSecondaryResults + 1);
+                results[0] = result;
+                for (_int64 k = 0; k < nSecondaryResults; k++) toSnapPaired(sec[(size_t)i * secStride + k], &results[1 + k]);
+                bool firstIsPrimary = true;
+                for (_int64 k = 0; k <= nSecondaryResults; k++) {
+                    bool pass0 = c->options->passFilter(two[0], results[k].status[0], !useful[2 * i], k != 0 || !firstIsPrimary);
+                    bool pass1 = c->options->passFilter(two[1], results[k].status[1], !useful[2 * i + 1], k != 0 || !firstIsPrimary);
+                    bool pass = (c->options->filterFlags & AlignerOptions::FilterBothMatesMatch) ? (pass0 && pass1) : (pass0 || pass1);
+                    if (!pass) {
+                        results[k] = results[nSecondaryResults];
+                        nSecondaryResults--;
+                        if (0 == k) firstIsPrimary = false;
+                        k--;
+                    }
+                }
+                nSingleResults[0] = secondary ? (_int64)nSingleSec[2 * i] : 0;
+                nSingleResults[1] = secondary ? (_int64)nSingleSec[2 * i + 1] : 0;
+                singles.resize((size_t)(nSingleResults[0] + nSingleResults[1]) + 1);
+                for (_int64 k = 0; k < nSingleResults[0] + nSingleResults[1]; k++) toSnap(ssec[(size_t)i * singleStride + k], &singles[k]);
+                SingleAlignmentResult *singleResults[2] = {&singles[0], &singles[0] + nSingleResults[0]};
+                for (int r = 0; r < NUM_READS_PER_PAIR; r++) {
+                    for (_int64 k = 0; k < nSingleResults[r]; k++) {
+                        if (!c->options->passFilter(two[r], singleResults[r][k].status, false, true)) {
+                            singleResults[r][k] = singleResults[r][nSingleResults[r] - 1];
+                            nSingleResults[r]--;
+                            k--;
+                        }
+                    }
+                }
+                c->stats->extraAlignments += nSecondaryResults + (firstIsPrimary ? 0 : 1);
                 if (NULL != c->readWriter) {
-                    SingleAlignmentResult *singleResults[2] = {NULL, NULL};
-                    c->readWriter->writePairs(c->readerContext, two, &result, nResults, singleResults, nSingleResults, firstIsPrimary, c->useAffineGap);
+                    c->readWriter->writePairs(c->readerContext, two, &results[0], nSecondaryResults + 1, singleResults, nSingleResults, firstIsPrimary, c->useAffineGap);
                     if (c->emitALTAlignments && (alt[i].status[0] != SNAPGPU_NotFound || alt[i].status[1] != SNAPGPU_NotFound)) {
                         toSnapPaired(alt[i], &altResult);
                         c->readWriter->writePairs(c->readerContext, two, &altResult, 1, NULL, 0, true, c->useAffineGap);

@@ -156,6 +156,7 @@ def paired_workload(workload):
 @pytest.mark.parametrize("opts,params,pparams", [
     ([], {}, {}),
     (["-d", "10", "-s", "50", "800", "-H", "2000"], {"max_k": 10}, {"min_spacing": 50, "max_spacing": 800, "max_big_hits": 2000}),
+    (["-om", "1", "-omax", "3"], {"secondary": (1, 3, -1)}, {}),            # paired + single-end secondary alignments (PairedAligner.cpp:843-890)
 ])
 def test_paired_sam_identical_to_reference_cli(paired_workload, opts, params, pparams):
     w = paired_workload
@@ -168,7 +169,7 @@ def test_paired_sam_identical_to_reference_cli(paired_workload, opts, params, pp
     h_ref, r_ref = _sam(out_ref)
     h_gpu, r_gpu = _sam(out_gpu)
     assert h_ref == h_gpu
-    assert len(r_ref) == len(r_gpu) and len(r_ref) >= 2 * 6000, log[-2000:]
+    assert min(len(r_ref), len(r_gpu)) >= 2 * 6000, log[-2000:]       # (record counts are compared per pair below)
     if r_ref != r_gpu:
         def by_name(records):
             m = {}
@@ -180,11 +181,17 @@ def test_paired_sam_identical_to_reference_cli(paired_workload, opts, params, pp
         differing = [n for n in m_ref if m_ref[n] != m_gpu[n]]
         # pairs the device flags as depending on the reference aligner's history (DESIGN.md "Reference nondeterminism")
         from snap_amd.aligner import ChimericPairedEndAligner
+        params = dict(params)
+        secondary = params.pop("secondary", None)
         a = ChimericPairedEndAligner(GenomeIndex.load_from_directory(w["index"]), abi.default_params(max_read_len=400, **params),
                                      abi.default_paired_params(**pparams))
-        prim, _ = a.align(w["pairs"]["bases"], w["pairs"]["quals"], w["pairs"]["offsets"])
+        if secondary:       # ... or on the size its secondary-result buffer happened to have (SNAPGPU_PAIR_REF_BUFFER_DEPENDENT)
+            a.enable_secondary(secondary[0], max_results=secondary[1], max_per_contig=secondary[2])
+            prim = a.align_secondary(w["pairs"]["bases"], w["pairs"]["quals"], w["pairs"]["offsets"])[0]
+        else:
+            prim, _ = a.align(w["pairs"]["bases"], w["pairs"]["quals"], w["pairs"]["offsets"])
         a.close()
-        unstable = {"pair%d" % i for i in np.nonzero(prim["reserved"] != 0)[0]}
+        unstable = {"pair%d" % i for i in np.nonzero((prim["reserved"] != 0) | ((prim["flags"] & 2) != 0))[0]}
         bad = [n for n in differing if n not in unstable]
         assert not bad, "first differing pair %s:\nref: %sgpu: %s" % (bad[0], "".join(m_ref[bad[0]]), "".join(m_gpu[bad[0]]))
         assert len(differing) <= 2 + len(m_ref) // 50
