@@ -216,6 +216,15 @@ def main():
             t = json.load(open(pmc))
             if t.get("reads_per_launch") == n and t.get("genome_mb") == args.genome_mb and t.get("workload", "single") == args.workload:
                 out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+                if t.get("valu_insts_per_launch"):
+                    # the LV / affine-gap work is integer VALU, not HBM.  Wave-level VALU instructions of one launch
+                    # (rocprofv3 --pmc SQ_INSTS_VALU, profiles/) over this run's launch time, against the issue peak of the chip:
+                    # 256 CUs x 4 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz (MI355X_MICROARCH.md)
+                    peak = 256 * 4 * 2.4e9 / 4 / 1e9
+                    ach = t["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
+                    out["roofline"]["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+                                                     "valu_insts_per_read": t["valu_insts_per_launch"] / n,
+                                                     "salu_insts_per_read": t.get("salu_insts_per_launch", 0) / n}
         except Exception:
             pass
 

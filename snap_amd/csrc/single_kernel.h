@@ -3,12 +3,14 @@
 #pragma once
 #include "kernel_common.h"
 
-// Latency-bound kernel: ask for 4 waves per SIMD (<= 128 VGPRs; costs ~24 spilled VGPRs of cold state).
+// Latency-bound kernel.  The 192-position affine-gap variant (reads up to ~170 bp) asks for 6 waves per SIMD (80 VGPRs, ~75 dwords
+// of cold state spilled): measured 3.96 M reads/s against 3.74-3.80 M at 4 and 3.79 M at 5 waves (profiles/r01g).  The variants
+// with more affine-gap state in registers stay at 4 (128 VGPRs); their LDS footprint caps occupancy first anyway.
 #ifndef SNAPGPU_WAVES_PER_SIMD
-#define SNAPGPU_WAVES_PER_SIMD 4
+#define SNAPGPU_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 6 : 4)
 #endif
 template <int AGC, bool SEC>
-__global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD) void k_align_single(AlignArgs a)
+__global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_single(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id();
