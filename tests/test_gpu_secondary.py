@@ -9,10 +9,9 @@ import pytest
 
 from snap_amd import abi
 from tests import util
+from tests.util import compare_secondary
 
 pytestmark = pytest.mark.gpu
-# fields of a secondary result the reference never writes (BaseAligner.cpp:2182-2199); both sides hold 0
-UNSET_IN_SECONDARY = ("probability_all_candidates", "popular_seeds_skipped", "reserved")
 
 
 @pytest.fixture(scope="module")
@@ -23,25 +22,6 @@ def golden_secondary():
 
 def _sets(z):
     return [(str(r[0]), ast.literal_eval(str(r[1])), int(r[2]), int(r[3]), int(r[4])) for r in z["sets"]]
-
-
-def compare_secondary(ref_sec, ref_n, got_sec, got_n, exclude):
-    problems = []
-    ne = (ref_n != got_n) & ~exclude
-    if ne.any():
-        i = int(np.nonzero(ne)[0][0])
-        problems.append("nSecondaryResults differs for %d reads, first at %d: ref=%d got=%d" % (int(ne.sum()), i, ref_n[i], got_n[i]))
-    width = min(ref_sec.shape[1], got_sec.shape[1])
-    live = (np.arange(width)[None, :] < np.minimum(ref_n, got_n)[:, None]) & ~exclude[:, None]
-    for f in ref_sec.dtype.names:
-        if f in UNSET_IN_SECONDARY:
-            continue
-        d = (ref_sec[f][:, :width] != got_sec[f][:, :width]) & live
-        if d.any():
-            i, k = [int(x[0]) for x in np.nonzero(d)]
-            problems.append("secondary[%d].%s differs for %d records, first at read %d: ref=%r got=%r" %
-                            (k, f, int(d.sum()), i, ref_sec[f][i, k], got_sec[f][i, k]))
-    return problems
 
 
 @pytest.mark.parametrize("tag", ["100", "150"])

@@ -225,3 +225,91 @@ def test_secondary_fixture_obeys_the_reference_contract():
                     if prim["status"][i] != 0:
                         counts[np.searchsorted(begins, prim["location"][i], side="right") - 1] += 1
                         assert counts.max() <= mpc, (name, tag, int(i))
+
+
+# ---------------------------------------------------------------------------------------- the restatement of AlignRead (oracle/align_oracle.c)
+
+RESTATEMENT_SETS = dict(default_d8=dict(max_k=8), lvonly_d8=dict(max_k=8, use_affine_gap=0), default_d27=dict(max_k=27),
+                        emitalt_d8=dict(max_k=8, emit_alt_alignments=1))
+
+
+@pytest.mark.parametrize("name", list(RESTATEMENT_SETS))
+def test_align_read_restatement_vs_reference_fixture(golden_index, golden_reads, name):
+    """oracle_align_read -- the plain-C restatement of BaseAligner::AlignRead -- against what the compiled reference returned
+    for the 4 000 golden reads (tests/golden/tiny_reads.npz): every field of the primary result, bit for bit."""
+    from snap_amd import abi
+    for tag in ("100", "150"):
+        b, q = golden_reads["b" + tag], golden_reads["q" + tag]
+        n, L = b.shape
+        prim, alt = util.oracle_align_reads(golden_index, abi.default_params(max_read_len=160, **RESTATEMENT_SETS[name]), b, q,
+                                            np.arange(n + 1, dtype=np.uint64) * L)
+        key = "%s_%s_" % (name, tag)
+        exclude = golden_reads[key + "unstable"] | (prim["reserved"] != 0)     # stale affine-gap traceback cells: DESIGN.md section 2
+        assert int(exclude.sum()) <= 4
+        assert not util.compare_results(golden_reads[key + "primary"], prim, exclude=exclude)
+        assert (golden_reads[key + "alt"]["status"] == alt["status"]).all()
+        if name == "emitalt_d8":
+            assert not util.compare_results(golden_reads[key + "alt"], alt, "first ALT", exclude=exclude | (alt["status"] == 0))
+
+
+def test_align_read_restatement_with_secondary_results_vs_reference_fixture(golden_index, golden_reads):
+    """... and with -om / -omax / -mpc: secondary results, order included (tests/golden/secondary_reads.npz)."""
+    import ast
+    from snap_amd import abi
+    z = np.load(os.path.join(util.GOLDEN, "secondary_reads.npz"))
+    for r in z["sets"]:
+        name, kw, om, omax, mpc = str(r[0]), ast.literal_eval(str(r[1])), int(r[2]), int(r[3]), int(r[4])
+        for tag in ("100", "150"):
+            b, q = golden_reads["b" + tag], golden_reads["q" + tag]
+            n, L = b.shape
+            key = "%s_%s_" % (name, tag)
+            prim, alt, sec, nsec = util.oracle_align_reads(golden_index, abi.default_params(max_read_len=160, **kw), b, q,
+                                                           np.arange(n + 1, dtype=np.uint64) * L, secondary=abi.secondary_params(om, omax, mpc),
+                                                           sec_stride=max(64, z[key + "secondary"].shape[1]))
+            exclude = z[key + "unstable"] | (prim["reserved"] != 0)
+            problems = util.compare_results(z[key + "primary"], prim, exclude=exclude)
+            problems += util.compare_secondary(z[key + "secondary"], z[key + "nsec"], sec, nsec, exclude)
+            assert not problems, (name, tag, problems)
+
+
+@have_ref
+def test_align_read_restatement_vs_live_reference_on_fresh_reads(tmp_path):
+    """Fresh seeded reads (ragged lengths, N-rich, reads at contig ends, unalignable) on a fresh repeat-rich genome with an ALT contig:
+    the restatement against the compiled reference, run here."""
+    from snap_amd import abi, synth
+    from snap_amd.index import GenomeIndex
+    d = str(tmp_path)
+    g = synth.make_genome(4242, 300_000, n_contigs=3, repeat_frac=0.4, max_copies=80, repeat_len=(120, 1500), n_run_frac=0.003)
+    rng = np.random.default_rng(17)
+    altc = g[1][1][30_000:38_000].copy()
+    m = rng.random(altc.size) < 0.012
+    altc[m] = synth._ACGT[rng.integers(0, 4, size=int(m.sum()))]
+    g.append(("chrB_alt", altc))
+    synth.write_fasta(d + "/ref.fa", g)
+    ref.build_index(d + "/ref.fa", d + "/idx", 20, threads=4, extra=["-altContigName", "chrB_alt"])
+    gi = GenomeIndex.load_from_directory(d + "/idx")
+    ri = ref.RefIndex(d + "/idx")
+    rd = synth.make_reads(5, g, 1500, 130, sub=0.02, ins=0.004, dele=0.004, n_frac=0.002)
+    bases, quals, offs = [], [], [0]
+    cat0 = g[0][1]
+    for i in range(rd["bases"].shape[0]):
+        L = int(rng.integers(18, 131))                       # ragged, some shorter than the seed
+        b, q = rd["bases"][i, :L].copy(), rd["quals"][i, :L].copy()
+        if i % 97 == 0:
+            b[rng.integers(0, L, size=min(L, 10))] = ord("N")
+        if i % 131 == 0:
+            b = cat0[:L].copy()                              # the very start of a contig
+        if i % 137 == 0:
+            b = cat0[-L:].copy()                             # ... and its end
+        if i % 89 == 0:
+            b = synth._ACGT[rng.integers(0, 4, size=L)]      # unalignable
+        bases.append(b); quals.append(q); offs.append(offs[-1] + L)
+    bases = np.concatenate(bases); quals = np.concatenate(quals); offs = np.array(offs, dtype=np.uint64)
+    for kw in (dict(max_k=8), dict(max_k=14, extra_search_depth=2), dict(max_k=8, use_affine_gap=0, num_seeds=0, seed_coverage=4.0)):
+        p = abi.default_params(max_read_len=160, **kw)
+        rp, ra, _, _ = ri.align_single(p, bases, quals, offs, threads=1)
+        op, oa = util.oracle_align_reads(gi, p, bases, quals, offs)
+        exclude = op["reserved"] != 0
+        assert int(exclude.sum()) <= 6
+        assert not util.compare_results(rp, op, exclude=exclude), kw
+        assert (ra["status"] == oa["status"]).all()

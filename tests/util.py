@@ -135,3 +135,64 @@ def oracle_lookup(index: GenomeIndex, seed: bytes):
             hits = np.ctypeslib.as_array(C.cast(hp[d], C.POINTER(C.c_uint32)), shape=(n,)).copy()
         out.append((n, hits, int(sl[d])))
     return out
+
+
+class _OGenome(C.Structure):
+    _fields_ = [("genome", C.c_void_p), ("n_bases", C.c_uint64), ("genome_pad", C.c_uint32), ("chromosome_padding", C.c_uint32),
+                ("contig_begin", C.c_void_p), ("n_contigs", C.c_uint32), ("first_alt_location", C.c_uint64)]
+
+
+def oracle_align_reads(index: GenomeIndex, params, bases, quals, offsets, secondary=None, sec_stride: int = 64):
+    """BaseAligner::AlignRead through the C restatement (oracle/align_oracle.c), one read after the other.
+    secondary = snap_amd.abi.SecondaryParams or None.  Returns (primary, first_alt[, secondary, n_secondary])."""
+    from snap_amd.abi import RESULT_DTYPE
+    lib = oracle_lib()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1)
+    quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offsets.size - 1
+    ix = _OIndex(index.seed_len, index.key_bytes, index.n_hash_tables, 1 if index.large else 0,
+                 index.hash_blob.ctypes.data, index.table_offset.ctypes.data, index.table_size.ctypes.data,
+                 index.overflow.ctypes.data, index.n_bases)
+    pad = (index.genome_padded.size - index.n_bases) // 2
+    cb = np.ascontiguousarray(index.contig_begin, dtype=np.uint64)
+    alts = [c.begin for c in index.contigs if c.is_alt]
+    g = _OGenome(index.genome_padded.ctypes.data + pad, index.n_bases, pad, index.chromosome_padding, cb.ctypes.data, len(index.contigs),
+                 min(alts) if alts else index.n_bases + (1 << 40))
+    prim = np.zeros(n, dtype=RESULT_DTYPE); alt = np.zeros(n, dtype=RESULT_DTYPE)
+    if secondary is None:
+        rc = lib.oracle_align_reads(C.byref(ix), C.byref(g), C.byref(params), C.c_uint32(n), C.c_void_p(bases.ctypes.data),
+                                    C.c_void_p(quals.ctypes.data), C.c_void_p(offsets.ctypes.data), C.c_void_p(prim.ctypes.data),
+                                    C.c_void_p(alt.ctypes.data), None, None, C.c_uint32(0), None)
+        assert rc == 0
+        return prim, alt
+    sec = np.zeros((n, sec_stride), dtype=RESULT_DTYPE); nsec = np.zeros(n, dtype=np.uint32)
+    rc = lib.oracle_align_reads(C.byref(ix), C.byref(g), C.byref(params), C.c_uint32(n), C.c_void_p(bases.ctypes.data),
+                                C.c_void_p(quals.ctypes.data), C.c_void_p(offsets.ctypes.data), C.c_void_p(prim.ctypes.data),
+                                C.c_void_p(alt.ctypes.data), C.byref(secondary), C.c_void_p(sec.ctypes.data), C.c_uint32(sec_stride),
+                                C.c_void_p(nsec.ctypes.data))
+    assert rc == 0
+    return prim, alt, sec, nsec
+
+
+# fields of a secondary result the reference never writes (BaseAligner.cpp:2182-2199); both sides hold 0
+UNSET_IN_SECONDARY = ("probability_all_candidates", "popular_seeds_skipped", "reserved")
+
+
+def compare_secondary(ref_sec, ref_n, got_sec, got_n, exclude):
+    problems = []
+    ne = (ref_n != got_n) & ~exclude
+    if ne.any():
+        i = int(np.nonzero(ne)[0][0])
+        problems.append("nSecondaryResults differs for %d reads, first at %d: ref=%d got=%d" % (int(ne.sum()), i, ref_n[i], got_n[i]))
+    width = min(ref_sec.shape[1], got_sec.shape[1])
+    live = (np.arange(width)[None, :] < np.minimum(ref_n, got_n)[:, None]) & ~exclude[:, None]
+    for f in ref_sec.dtype.names:
+        if f in UNSET_IN_SECONDARY:
+            continue
+        d = (ref_sec[f][:, :width] != got_sec[f][:, :width]) & live
+        if d.any():
+            i, k = [int(x[0]) for x in np.nonzero(d)]
+            problems.append("secondary[%d].%s differs for %d records, first at read %d: ref=%r got=%r" %
+                            (k, f, int(d.sum()), i, ref_sec[f][i, k], got_sec[f][i, k]))
+    return problems
