@@ -368,6 +368,19 @@ int snapref_align_single(void *vindex, const snapgpu_params *p, uint32_t n, cons
 }
 
 
+// ---------------------------------------------------------------------------------------- CIGAR (SAM writer side)
+
+/* LandauVishkinWithCigar::computeEditDistance, COMPACT_CIGAR_STRING format (LandauVishkin.cpp:141).  The caller places text and
+ * pattern inside larger buffers: the reference compares 8 bytes at a time and looks past both ends. */
+int snapref_lv_cigar(const char *text, int text_len, const char *pattern, int pattern_len, int k, int use_m,
+                     char *cigar, int cigar_cap, int *text_used, int *net_indel)
+{
+    static LandauVishkinWithCigar *lvc = NULL;           /* one object, as one SAM writer thread has (not thread safe: tests only) */
+    if (lvc == NULL) lvc = new LandauVishkinWithCigar();
+    int used = 0;
+    return lvc->computeEditDistance(text, text_len, pattern, pattern_len, k, cigar, cigar_cap, use_m != 0, COMPACT_CIGAR_STRING, &used, text_used, net_indel);
+}
+
 // ---------------------------------------------------------------------------------------- secondary results (-om)
 
 struct SecJob {

@@ -8,6 +8,7 @@
 3. When oracle/_ref is present (this container): the restatement against the reference itself on
    fresh seeded fuzz, and the reference against the committed AlignRead fixtures.
 """
+import ctypes as C
 import json
 import os
 
@@ -313,3 +314,65 @@ def test_align_read_restatement_vs_live_reference_on_fresh_reads(tmp_path):
         assert int(exclude.sum()) <= 6
         assert not util.compare_results(rp, op, exclude=exclude), kw
         assert (ra["status"] == oa["status"]).all()
+
+
+# ---------------------------------------------------------------------------------------- CIGAR (first piece of SURVEY.md 8(f) rank 1)
+
+def _lv_cigar(lib, fn_ref, text_buf, t0, text_len, pat_buf, p0, pattern_len, k, use_m):
+    """oracle_lv_cigar (or, fn_ref set, the reference's LandauVishkinWithCigar::computeEditDistance) on strings placed inside
+    larger buffers -- the reference looks past both ends, so both sides must see the same neighbours."""
+    tb = C.create_string_buffer(bytes(text_buf), len(text_buf)); pb = C.create_string_buffer(bytes(pat_buf), len(pat_buf))
+    out = C.create_string_buffer(1024); tu = C.c_int(-1); ni = C.c_int(0)
+    tp, pp = C.c_void_p(C.addressof(tb) + t0), C.c_void_p(C.addressof(pb) + p0)
+    if fn_ref is not None:
+        r = fn_ref(tp, text_len, pp, pattern_len, k, use_m, out, 1024, C.byref(tu), C.byref(ni))
+    else:
+        r = lib.oracle_lv_cigar(tp, text_len, -t0, len(text_buf) - t0, pp, pattern_len, -p0, len(pat_buf) - p0, k, use_m, out, 1024,
+                                C.byref(tu), C.byref(ni))
+    return r, out.value.decode(), (tu.value if r >= 0 else None), (ni.value if r > 0 else 0)
+
+
+def test_lv_cigar_restatement_on_the_references_own_vectors():
+    """tests/LandauVishkinTest.cpp:34-121: 15 string pairs x {=/X, M} CIGARs."""
+    lib = util.oracle_lib()
+    for c in KATS["lv_cigar"]:
+        t, p = c["text"].encode(), c["pattern"].encode()
+        for use_m, key in ((0, "cigar"), (1, "cigar_m")):
+            got = _lv_cigar(lib, None, b"\x01" * 16 + t + b"\x00" * 16, 16, len(t), b"\x02" * 16 + p + b"\x00" * 16, 16, len(p), c["k"], use_m)
+            assert got[1] == c[key], (c, use_m, got)
+
+
+@have_ref
+def test_lv_cigar_restatement_vs_live_reference_fuzz():
+    """Seeded mutated / indel'd / truncated strings: edit distance, CIGAR, text used and net indel equal the reference's."""
+    lib = util.oracle_lib()
+    rlib = ref.lib()
+    rng = np.random.default_rng(2026)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n_checked = 0
+    for it in range(3000):
+        L = int(rng.integers(1, 160))
+        g = rng.choice(acgt, size=L + 220)
+        if it % 3 == 0:
+            g[60:60 + L // 2] = g[60 + L // 2:60 + 2 * (L // 2)][:L // 2]       # low-complexity: tandem duplication (ambiguous indel placement)
+        text0 = 40
+        pat = bytearray(g[text0:text0 + L].tobytes())
+        for _ in range(int(rng.integers(0, 5))):                                 # substitutions
+            pat[int(rng.integers(0, len(pat)))] = int(rng.choice(acgt))
+        for _ in range(int(rng.integers(0, 3))):                                 # indels
+            pos = int(rng.integers(0, len(pat)))
+            if rng.random() < 0.5 and len(pat) > 2:
+                del pat[pos:pos + int(rng.integers(1, 4))]
+            else:
+                pat[pos:pos] = bytes(rng.choice(acgt, size=int(rng.integers(1, 4))).tolist())
+        pat = bytes(pat) or b"A"
+        text_len = len(pat) + int(rng.integers(-6, 20)) if it % 7 == 0 else len(pat) + 30      # sometimes shorter than the pattern
+        text_len = max(0, min(text_len, g.size - text0 - 8))
+        k = int(rng.integers(0, 14))
+        pbuf = bytes(rng.choice(acgt, size=24).tolist()) + pat + bytes(rng.choice(acgt, size=24).tolist())
+        for use_m in (0, 1):
+            a = _lv_cigar(lib, None, g.tobytes(), text0, text_len, pbuf, 24, len(pat), k, use_m)
+            b = _lv_cigar(lib, rlib.snapref_lv_cigar, g.tobytes(), text0, text_len, pbuf, 24, len(pat), k, use_m)
+            assert a == b, (it, use_m, k, text_len, pat, a, b)
+            n_checked += a[0] > 0
+    assert n_checked > 1500
