@@ -66,6 +66,9 @@ typedef struct {
     /* secondary results */
     int om, mpc; int64_t omax;
     snapgpu_single_result *sec; uint32_t n_sec, sec_cap; int sec_overflow;
+    /* useHamming: gapless scoring, candidates kept for alignAffineGap (only the paired-end fallback asks for it) */
+    int ham;
+    snapgpu_single_result *agc; uint32_t n_agc, agc_cap; int keep_agc;
     uint32_t stale;
 } A;
 
@@ -190,6 +193,16 @@ static void record_secondary(A *a, int dir, int64_t loc, int64_t orig, int score
     r->match_probability = mp; r->seed_offset = so;
 }
 
+static void record_candidate(A *a, int dir, int64_t loc, int64_t orig, int score, int used_ag, int cb, int ca, int ag, double mp, int so) {
+    if (!a->keep_agc) return;                                           /* no buffer: nothing is kept (:2202 NULL != candidatesForAffineGap) */
+    if (a->n_agc >= a->agc_cap) { a->agc_cap *= 2; a->agc = (snapgpu_single_result *)realloc(a->agc, sizeof(*a->agc) * a->agc_cap); }   /* (the caller doubles and re-calls) */
+    snapgpu_single_result *r = &a->agc[a->n_agc++];
+    memset(r, 0, sizeof(*r));
+    r->status = SNAPGPU_MultipleHits; r->direction = dir; r->location = loc; r->orig_location = orig; r->score = score;
+    r->used_affine_gap_scoring = used_ag; r->bases_clipped_before = cb; r->bases_clipped_after = ca; r->ag_score = ag;
+    r->match_probability = mp; r->seed_offset = so;
+}
+
 static void update_best(A *a, ScoreSet *s, int64_t loc, int64_t orig, uint32_t score, int ag, double mp, int e_dir, int used_ag,
                         int cb, int ca, int so) {
     int seen_new;
@@ -203,6 +216,15 @@ static void update_best(A *a, ScoreSet *s, int64_t loc, int64_t orig, uint32_t s
                                  s->ag_score, s->best_match_prob, s->seed_offset);
         } else if ((int)(best - score) <= a->om && score != (uint32_t)SNAPGPU_ScoreAboveLimit && best >= score) {   /* :2247 */
             record_secondary(a, e_dir, loc, orig, (int)score, used_ag, cb, ca, ag, mp, so);
+        }
+    }
+    if (a->ham) {                                                                                                   /* :2202-2228, :2273-2297 */
+        if (seen_new) {
+            if (best >= score && (int)(best - score) <= (int)a->p->extra_search_depth)
+                record_candidate(a, s->dir, s->best_loc, s->best_orig_loc, s->best_score, s->used_ag, s->clip_before, s->clip_after,
+                                 s->ag_score, s->best_match_prob, s->seed_offset);
+        } else if ((int)(best - score) <= (int)a->p->extra_search_depth && score != (uint32_t)SNAPGPU_ScoreAboveLimit && best >= score) {
+            record_candidate(a, e_dir, loc, orig, (int)score, used_ag, cb, ca, ag, mp, so);
         }
     }
     if (seen_new) {
@@ -222,6 +244,36 @@ static void fill_result(const A *a, const ScoreSet *s, snapgpu_single_result *r)
 }
 
 static void reversed(const char *src, int n, char *dst) { for (int i = 0; i < n; i++) dst[i] = src[n - 1 - i]; }
+
+/* AffineGapVectorized::computeGaplessScore (AffineGapVectorized.h:139-254): Hamming walk away from the seed; the best-scoring
+ * prefix is kept, the rest of the pattern is clipped.  st = +1 / -1; T, P, Q address the first byte compared. */
+static int gapless_score(const A *a, int st, const char *T, const char *P, const char *Q, int plen, int score_init, int limit,
+                         int *n_edits, int *pattern_offset, double *mp, int *n_gapless) {
+    *mp = 1.0;
+    if (limit < 0) { *n_edits = -1; *n_gapless = -1; return -1; }
+    int sc = score_init, best = score_init, best_i = 0;
+    for (int i = 0; i < plen; i++) {
+        sc += P[i * st] == T[i * st] ? (int)a->p->match_reward : -(int)a->p->sub_penalty;
+        if (sc > best) { best = sc; best_i = i; }
+    }
+    if (best > score_init) {
+        int ne = 0, nm = 0;
+        double pr = 1.0;
+        for (int i = 0; i <= best_i; i++) {
+            if (P[i * st] != T[i * st]) { ne++; pr *= oracle_phred_table()[(uint8_t)Q[i * st]]; } else nm++;
+        }
+        pr *= oracle_perfect_table()[nm];
+        const int clipped = plen - (best_i + 1);
+        *pattern_offset = clipped;
+        *n_gapless = ne <= limit ? ne : -1;
+        *n_edits = ne + clipped;
+        pr *= oracle_indel_table()[clipped];
+        *mp = pr;
+        return best;
+    }
+    *n_edits = -1; *n_gapless = -1;
+    return -1;
+}
 
 /* ---- score(), :918-1534.  Returns 1 when a final answer has been written. */
 static int score(A *a, int force_result) {
@@ -249,7 +301,7 @@ static int score(A *a, int force_result) {
                         fill_result(a, &a->all, a->first_alt);
                 }
                 a->primary->score = fin->best_score;
-                if ((uint32_t)fin->best_score <= (uint32_t)a->max_k) {
+                if ((uint32_t)fin->best_score <= (uint32_t)a->max_k || (a->ham && fin->best_score != SNAPGPU_UnusedScoreValue)) {   /* :1048 */
                     fill_result(a, fin, a->primary);
                     a->primary->supplementary = 0;
                 } else {
@@ -292,8 +344,24 @@ static int score(A *a, int force_result) {
                     int score1 = 0, score2 = 0, ag1 = seed_len, ag2 = 0, loc_offset = 0;
                     double mp1 = 1.0, mp2 = 1.0;
                     const int text_len = read_len + MAXK - tail_start;
+                    int g1 = 0, g2 = 0;                                                                                       /* score1Gapless / score2Gapless */
+                    if (a->ham) {                                                                                              /* :1177-1199 */
+                        if (tail_start != read_len) {
+                            int po;
+                            ag1 = gapless_score(a, +1, data + tail_start, rdd + tail_start, qld + tail_start, read_len - tail_start, read_len, limit_e,
+                                                &score1, &po, &mp1, &g1);
+                            ag1 += seed_len - read_len;
+                        }
+                        if (g1 != -1 && seed_offset != 0) {
+                            int po = 0;
+                            ag2 = gapless_score(a, -1, data + seed_offset - 1, rdd + seed_offset - 1, qld + seed_offset - 1, seed_offset, read_len,
+                                                limit_e - g1, &score2, &po, &mp2, &g2);
+                            ag2 -= read_len;
+                            loc_offset = g2 != -1 ? po : 0;
+                        }
+                    }
                     /* Landau-Vishkin forward over the tail of the read (:1160), then backward over the reversed head (:1169) */
-                    {
+                    if (!a->ham) {
                         int net = 0, tot = 0, span = 0;
                         score1 = oracle_lv(1, data + tail_start, text_len, rdd + tail_start, qld + tail_start, read_len - tail_start, limit_e, &mp1, &net, &tot, &span);
                         ag1 = (seed_len + read_len - tail_start - score1) * (int)p->match_reward - score1 * (int)p->sub_penalty;
@@ -304,7 +372,7 @@ static int score(A *a, int force_result) {
                             ag2 = (seed_offset - score2) * (int)p->match_reward - score2 * (int)p->sub_penalty;
                         }
                     }
-                    if (score1 != -1 && score2 != -1) {
+                    if (!a->ham && score1 != -1 && score2 != -1) {
                         const int max_k_same = (int)p->gap_open_penalty / ((int)p->sub_penalty - (int)p->gap_extend_penalty);    /* :1148 */
                         if (p->use_affine_gap && score1 + score2 > max_k_same && e->lps <= (uint32_t)a->all.best_score) {          /* :1203 */
                             score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0; used_ag = 1;
@@ -327,7 +395,7 @@ static int score(A *a, int force_result) {
                             }
                         }
                     }
-                    int found = score1 != -1 && score2 != -1;                                                                  /* :1293 */
+                    int found = a->ham ? (g1 != -1 && g2 != -1) : (score1 != -1 && score2 != -1);                              /* :1293 */
                     if (found && loc_offset != 0 && !substring_ok(a->g, loc + loc_offset, glen)) found = 0;                    /* :1295-1301 */
                     if (found) {
                         sc = (uint32_t)(score1 + score2);
@@ -341,6 +409,7 @@ static int score(A *a, int force_result) {
 
                 /* ---- bookkeeping after scoring one candidate, :1349-1519 */
                 if (any_nearby) {
+                    if (a->ham && mp <= e->match_prob) continue;                                                               /* :1362 */
                     if (e->best_score < sc || (e->best_score == sc && mp <= e->match_prob)) continue;                          /* :1366 */
                 }
                 e->best_loc = loc; e->used_ag = used_ag; e->clip_before = clip_before; e->clip_after = clip_after;
@@ -354,6 +423,7 @@ static int score(A *a, int force_result) {
                         if (ne->scored != 0) {
                             int64_t d = loc > ne->best_loc ? loc - ne->best_loc : ne->best_loc - loc;
                             if (d <= BUCKET) {                                                                                /* genomeLocationIsWithin(.., maxMergeDist) */
+                                if (a->ham && ne->match_prob >= mp) continue;                                                   /* :1418 */
                                 if (ne->best_score < sc || (ne->best_score == sc && ne->match_prob >= mp)) continue;           /* :1421 */
                                 double v = a->all.p_all - ne->match_prob; a->all.p_all = v > 0.0 ? v : 0.0;                   /* updateProbabilitiesForNearbyMatch */
                                 if (loc_non_alt) { double u = a->non_alt.p_all - ne->match_prob; a->non_alt.p_all = u > 0.0 ? u : 0.0; }
@@ -450,22 +520,210 @@ static void finalize_secondary(A *a) {
 
 static char rc_base(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
 
+/* ---- BaseAligner::scoreLocationWithAffineGap (:766-915): the forward half asks for the clipping optimisations, the backward half
+ * does not (:827 vs :857) */
+static void score_location_ag(A *a, int dir, int64_t loc, int seed_offset, int limit, int *score, double *mp, int *offset,
+                              int *clip_before, int *clip_after, int *ag_score) {
+    const snapgpu_params *p = a->p;
+    const int read_len = a->read_len, seed_len = (int)a->ix->seed_len;
+    const int64_t glen = (int64_t)read_len + MAXK;
+    *offset = 0;
+    if (!substring_ok(a->g, loc, glen)) { *score = -1; *mp = 0; *ag_score = -1; return; }
+    *clip_before = 0; *clip_after = 0;
+    const char *data = (const char *)a->g->genome + loc;
+    const int tail_start = seed_offset + seed_len;
+    const char *rdd = a->rd[dir], *qld = a->ql[dir];
+    oracle_ag_params agp = { (int)p->match_reward, (int)p->sub_penalty, (int)p->gap_open_penalty, (int)p->gap_extend_penalty,
+                             (int)p->five_prime_end_bonus, (int)p->three_prime_end_bonus };
+    int score1 = 0, score2 = 0, ag1 = seed_len, ag2 = 0;
+    double mp1 = 1.0, mp2 = 1.0;
+    char pbuf[1024 + 16], qbuf[1024 + 16];
+    if (tail_start != read_len) {
+        const int plen = read_len - tail_start;
+        int to = -1, po = -1, ne = -1, st = 0; double m = 1.0;
+        int s1 = oracle_ag(1, plen >= 3 * (2 * limit + 1), &agp, data + tail_start, (int)(glen - tail_start), rdd + tail_start, qld + tail_start,
+                           plen, limit, read_len, dir, 1, &to, &po, &ne, &m, &st);
+        a->stale += (uint32_t)st;
+        ag1 = s1 + (seed_len - read_len); *clip_after = po; score1 = ne; mp1 = m;
+    }
+    if (score1 != -1 && seed_offset != 0) {
+        const int lim = limit - score1;
+        int to = -1, po = -1, ne = -1, st = 0; double m = 1.0;
+        reversed(rdd, seed_offset, pbuf); reversed(qld, seed_offset, qbuf);
+        int s2 = oracle_ag(-1, seed_offset >= 3 * (2 * lim + 1), &agp, data + seed_offset, seed_offset + lim, pbuf, qbuf, seed_offset, lim, read_len,
+                           dir, 0, &to, &po, &ne, &m, &st);
+        a->stale += (uint32_t)st;
+        ag2 = s2 - read_len; *clip_before = po; score2 = ne; mp2 = m; *offset = to;
+        if (score2 == -1) *offset = 0;
+    }
+    if (score1 != -1 && score2 != -1) {
+        *score = score1 + score2; *mp = mp1 * mp2 * oracle_seed_prob(seed_len); *ag_score = ag1 + ag2;
+    } else {
+        *score = -1; *ag_score = -1; *mp = 0.0;
+    }
+}
+
+/* ScoreSet::init(SingleAlignmentResult*) / updateBestScore(SingleAlignmentResult*), :2116-2130, BaseAligner.h:310-328 */
+static void set_from_result(ScoreSet *s, const snapgpu_single_result *r) {
+    s->best_score = r->score; s->best_loc = r->location; s->best_orig_loc = r->orig_location; s->dir = r->direction;
+    s->used_ag = r->used_affine_gap_scoring; s->clip_before = r->bases_clipped_before; s->clip_after = r->bases_clipped_after;
+    s->ag_score = r->ag_score; s->seed_offset = r->seed_offset; s->best_match_prob = r->match_probability;
+    s->p_all = r->probability_all_candidates; s->p_best = r->match_probability;
+}
+static int set_update_from(ScoreSet *s, int64_t loc, int64_t orig, int dir, int score, int used_ag, int cb, int ca, int ag, int so, double mp) {
+    s->p_all += mp;
+    if (ag > s->ag_score || (ag == s->ag_score && mp > s->best_match_prob)) {
+        s->best_score = score; s->ag_score = ag; s->best_match_prob = mp; s->best_loc = loc; s->best_orig_loc = orig; s->dir = dir;
+        s->used_ag = used_ag; s->clip_before = cb; s->clip_after = ca; s->seed_offset = so;
+        return 1;
+    }
+    return 0;
+}
+static void set_sub_all(ScoreSet *s, double old) { double v = s->p_all - old; s->p_all = v > 0.0 ? v : 0.0; }
+
+static int cmp_agc(const void *x, const void *y, void *ctx) {
+    (void)ctx;
+    const snapgpu_single_result *f = (const snapgpu_single_result *)x, *s = (const snapgpu_single_result *)y;
+    return f->score < s->score ? -1 : f->score > s->score ? 1 : 0;
+}
+static void stable_sort(snapgpu_single_result *v, uint32_t n, int (*cmp)(const void *, const void *, void *), void *ctx);
+
+/* ---- BaseAligner::alignAffineGap (:1537-1792): affine-gap rescoring of the result of a Hamming pass and of the candidates it kept */
+static void align_affine_gap(A *a) {
+    const snapgpu_params *p = a->p;
+    snapgpu_single_result *primary = a->primary, *first_alt = a->first_alt;
+    if (primary->status == SNAPGPU_NotFound) return;
+    int n_count = 0;
+    for (int i = 0; i < a->read_len; i++) n_count += a->rd[0][i] == 'N';
+    if (n_count > a->max_k) return;
+    const int best_score = primary->score;
+    int limit = MAXK - 1, limit_alt = MAXK - 1, g_off = 0, skip = 0;
+    const double old_p = primary->match_probability;
+    const double old_p_alt = first_alt->status != SNAPGPU_NotFound ? first_alt->match_probability : 0.0;
+    const int max_k_same = (int)p->gap_open_penalty / ((int)p->sub_penalty - (int)p->gap_extend_penalty);
+
+    primary->used_affine_gap_scoring = 0;
+    if (primary->score > max_k_same) {
+        primary->used_affine_gap_scoring = 1;
+        int sc, cb = primary->bases_clipped_before, ca = primary->bases_clipped_after, ag = primary->ag_score;
+        double mp = primary->match_probability;
+        score_location_ag(a, primary->direction, primary->orig_location, primary->seed_offset, limit, &sc, &mp, &g_off, &cb, &ca, &ag);
+        primary->score = sc; primary->match_probability = mp; primary->bases_clipped_before = cb; primary->bases_clipped_after = ca; primary->ag_score = ag;
+        if (sc != -1) primary->location = primary->orig_location + g_off; else primary->status = SNAPGPU_NotFound;
+    } else {
+        skip = 1;
+    }
+    if (first_alt->status != SNAPGPU_NotFound && first_alt->score > max_k_same) {
+        first_alt->used_affine_gap_scoring = 1;
+        int sc, cb = first_alt->bases_clipped_before, ca = first_alt->bases_clipped_after, ag = first_alt->ag_score;
+        double mp = first_alt->match_probability;
+        score_location_ag(a, first_alt->direction, first_alt->orig_location, first_alt->seed_offset, limit_alt, &sc, &mp, &g_off, &cb, &ca, &ag);
+        first_alt->score = sc; first_alt->match_probability = mp; first_alt->bases_clipped_before = cb; first_alt->bases_clipped_after = ca; first_alt->ag_score = ag;
+        if (sc != -1) first_alt->location = first_alt->orig_location + g_off; else first_alt->status = SNAPGPU_NotFound;
+    }
+    if (primary->status == SNAPGPU_NotFound || primary->score > MAXK - 1) {
+        primary->location = SNAPGPU_InvalidGenomeLocation32; primary->mapq = 0; primary->score = -1; primary->status = SNAPGPU_NotFound;
+        primary->clipping_for_read_adjustment = 0; primary->used_affine_gap_scoring = 0; primary->bases_clipped_before = 0;
+        primary->bases_clipped_after = 0; primary->ag_score = -1; primary->seed_offset = 0; primary->match_probability = 0.0;
+        first_alt->status = SNAPGPU_NotFound;
+        return;
+    }
+
+    /* the function's own score sets (:1670-1690); scoreLimit below still reads the aligner's members, as the reference does (:1756) */
+    ScoreSet SA, SN;
+    const int non_alt_aln = !p->alt_awareness || !is_alt(a, primary->location);
+    set_from_result(&SA, primary);
+    int alt_best = 0;
+    if (first_alt->status != SNAPGPU_NotFound)
+        alt_best = set_update_from(&SA, first_alt->location, first_alt->orig_location, first_alt->direction, first_alt->score, first_alt->used_affine_gap_scoring,
+                                   first_alt->bases_clipped_before, first_alt->bases_clipped_after, first_alt->ag_score, first_alt->seed_offset,
+                                   first_alt->match_probability);
+    if (non_alt_aln) set_from_result(&SN, primary); else set_init(&SN);
+    if (!skip) {
+        const double new_p = primary->match_probability;
+        if (alt_best) { set_sub_all(&SA, old_p_alt); SA.p_best = first_alt->match_probability; SA.p_all += first_alt->match_probability; }
+        else          { set_sub_all(&SA, old_p); SA.p_best = new_p; SA.p_all += new_p; }
+        if (non_alt_aln) { set_sub_all(&SN, old_p); SN.p_best = new_p; SN.p_all += new_p; }
+    }
+    if (a->n_agc > 0 && !skip) {
+        limit = (int)(((uint32_t)a->max_k < (uint32_t)best_score ? (uint32_t)a->max_k : (uint32_t)best_score) + p->extra_search_depth);   /* :1714 */
+        stable_sort(a->agc, a->n_agc, cmp_agc, NULL);                                                                    /* qsort(compareByScore), :1719 */
+        for (uint32_t t = 0; t < a->n_agc; t++) {
+            snapgpu_single_result *c = &a->agc[t];
+            const int c_non_alt = !p->alt_awareness || !is_alt(a, c->location);
+            const double c_old_p = c->match_probability;
+            int sc, cb = c->bases_clipped_before, ca = c->bases_clipped_after, ag = c->ag_score;
+            double mp = c_old_p;
+            score_location_ag(a, c->direction, c->orig_location, c->seed_offset, limit, &sc, &mp, &g_off, &cb, &ca, &ag);
+            if (sc != -1 && sc <= MAXK - 1) {
+                const int64_t new_loc = c->orig_location + g_off;
+                if (primary->location == new_loc) continue;                                                              /* same alignment again */
+                set_sub_all(&SA, c_old_p);
+                set_update_from(&SA, new_loc, c->orig_location, c->direction, sc, 1, cb, ca, ag, c->seed_offset, mp);
+                if (c_non_alt) { set_sub_all(&SN, c_old_p); set_update_from(&SN, new_loc, c->orig_location, c->direction, sc, 1, cb, ca, ag, c->seed_offset, mp); }
+                limit = score_limit(a, p->alt_awareness && !c_non_alt);
+            }
+        }
+    }
+    const int emit_all = !p->alt_awareness || SN.best_score > SA.best_score + p->max_score_gap_to_prefer_non_alt;
+    const uint32_t pop = primary->popular_seeds_skipped, pop_alt = first_alt->popular_seeds_skipped, saved = a->popular_skipped;
+    a->popular_skipped = pop;
+    fill_result(a, emit_all ? &SA : &SN, primary);
+    if (p->alt_awareness && !emit_all && SA.best_loc != SN.best_loc) {
+        a->popular_skipped = pop_alt;
+        fill_result(a, &SA, first_alt);
+        first_alt->supplementary = 1;
+    } else {
+        first_alt->status = SNAPGPU_NotFound;
+    }
+    a->popular_skipped = saved;
+}
+
 /*
  * BaseAligner::AlignRead (:273-763) for one read.  sp == NULL: no secondary results (the reference default).
  * *n_secondary = how many the read has; the first min(that, sec_room) are stored.  *stale = affine-gap traceback steps
  * through cells this call never wrote (the reference's own answer for such a read depends on its history).
+ * max_k: BaseAligner::maxK for this call (setMaxK; p->max_k for the plain single-end path).  ctor_max_k: the maxK the object was
+ * built with (it sizes nothing here, but documents the chimeric fallback's maxK / 2).  hamming: AlignRead(..., useHamming = true)
+ * followed by alignAffineGap on the candidates it kept, as ChimericPairedEndAligner.cpp:339-360 does.
  * Returns 0, or -1 for a read longer than 1000 bases / an invalid option set.
  */
+static int align_read_ex(const oracle_index *ix, const oracle_genome *g, const snapgpu_params *p, int max_k, int hamming,
+                         const char *bases, const char *quals, int len,
+                         snapgpu_single_result *primary, snapgpu_single_result *first_alt,
+                         const snapgpu_secondary_params *sp, snapgpu_single_result *secondary, uint32_t sec_room, uint32_t *n_secondary,
+                         uint32_t *stale, uint32_t *raw_secondary);
+
 int oracle_align_read(const oracle_index *ix, const oracle_genome *g, const snapgpu_params *p, const char *bases, const char *quals, int len,
                       snapgpu_single_result *primary, snapgpu_single_result *first_alt,
                       const snapgpu_secondary_params *sp, snapgpu_single_result *secondary, uint32_t sec_room, uint32_t *n_secondary,
                       uint32_t *stale)
 {
+    return align_read_ex(ix, g, p, (int)p->max_k, 0, bases, quals, len, primary, first_alt, sp, secondary, sec_room, n_secondary, stale, NULL);
+}
+
+/* the single-end aligner inside ChimericPairedEndAligner: `p` holds its constructor arguments (maxK / 2, maxSeedsSingleEnd) */
+int oracle_align_read_chimeric(const oracle_index *ix, const oracle_genome *g, const snapgpu_params *p, int max_k, int hamming,
+                               const char *bases, const char *quals, int len, snapgpu_single_result *primary, snapgpu_single_result *first_alt,
+                               const snapgpu_secondary_params *sp, snapgpu_single_result *secondary, uint32_t sec_room, uint32_t *n_secondary,
+                               uint32_t *stale, uint32_t *raw_secondary)
+{
+    return align_read_ex(ix, g, p, max_k, hamming, bases, quals, len, primary, first_alt, sp, secondary, sec_room, n_secondary, stale, raw_secondary);
+}
+
+static int align_read_ex(const oracle_index *ix, const oracle_genome *g, const snapgpu_params *p, int max_k, int hamming,
+                         const char *bases, const char *quals, int len,
+                         snapgpu_single_result *primary, snapgpu_single_result *first_alt,
+                         const snapgpu_secondary_params *sp, snapgpu_single_result *secondary, uint32_t sec_room, uint32_t *n_secondary,
+                         uint32_t *stale, uint32_t *raw_secondary)
+{
     oracle_init();
     if (len > 1000 || len < 0) return -1;
     A a;
     memset(&a, 0, sizeof(a));
-    a.ix = ix; a.g = g; a.p = p; a.max_k = (int)p->max_k; a.read_len = len; a.primary = primary; a.first_alt = first_alt;
+    a.ix = ix; a.g = g; a.p = p; a.max_k = max_k; a.read_len = len; a.primary = primary; a.first_alt = first_alt;
+    a.ham = hamming; a.keep_agc = hamming && p->use_affine_gap;        /* no candidate buffer without affine gap (PairedAligner.cpp:570-577) */
+    if (raw_secondary) *raw_secondary = 0;
     a.om = sp ? sp->max_edit_distance : -1; a.mpc = sp ? sp->max_per_contig : -1; a.omax = sp ? sp->max_results : 0x7fffffff;
     if (n_secondary) *n_secondary = 0;
     if (stale) *stale = 0;
@@ -511,6 +769,7 @@ int oracle_align_read(const oracle_index *ix, const oracle_genome *g, const snap
     a.wl_next = (int *)malloc(sizeof(int) * (size_t)a.n_wl); a.wl_prev = (int *)malloc(sizeof(int) * (size_t)a.n_wl);
     for (int w = 0; w < a.n_wl; w++) a.wl_next[w] = a.wl_prev[w] = -(w + 1);                                            /* clearCandidates, :2332-2339 */
     if (sp) { a.sec_cap = (uint32_t)(2 * (uint64_t)(max_seeds + 1) * p->max_hits + 2); a.sec = (snapgpu_single_result *)malloc(sizeof(*a.sec) * a.sec_cap); }
+    if (a.keep_agc) { a.agc_cap = 4096; a.agc = (snapgpu_single_result *)malloc(sizeof(*a.agc) * a.agc_cap); }
 
     const uint32_t n_possible = (uint32_t)(len - seed_len + 1);
     uint32_t next_seed = 0, wrap_count = 0, n_applied[2] = {0, 0};
@@ -548,16 +807,19 @@ int oracle_align_read(const oracle_index *ix, const oracle_genome *g, const snap
     }
     if (!finished) score(&a, 1);                                                                                        /* :734 */
     primary->score_prior_to_clipping = primary->score;                                                                  /* finalizeSecondaryResults, :2442 */
-    primary->reserved = a.stale;
-    if (stale) *stale = a.stale;
     int rc_ret = 0;
     if (sp) {
         if (a.sec_overflow) rc_ret = -1;
+        if (raw_secondary) *raw_secondary = a.n_sec;
         finalize_secondary(&a);
         if (n_secondary) *n_secondary = a.n_sec;
         for (uint32_t k = 0; k < a.n_sec && k < sec_room; k++) secondary[k] = a.sec[k];
         free(a.sec);
     }
+    if (hamming) align_affine_gap(&a);                                                                                  /* ChimericPairedEndAligner.cpp:358-360 */
+    primary->reserved = a.stale;
+    if (stale) *stale = a.stale;
+    if (a.agc) free(a.agc);
     free(a.pool); free(a.heads); free(a.wl_next); free(a.wl_prev);
     return rc_ret;
 }

@@ -28,6 +28,18 @@ int   snapref_chimeric_single_align2(void *h, int max_k, int hamming, const char
                                      uint32_t first_room, uint32_t *overflowed_first);
 }
 
+extern "C" {
+typedef struct oracle_genome {
+    const uint8_t *genome; uint64_t n_bases; uint32_t genome_pad, chromosome_padding; const uint64_t *contig_begin; uint32_t n_contigs; uint64_t first_alt_location;
+} oracle_genome;
+int oracle_align_read_chimeric(const oracle_index *ix, const oracle_genome *g, const snapgpu_params *p, int max_k, int hamming,
+                               const char *bases, const char *quals, int len, snapgpu_single_result *primary, snapgpu_single_result *first_alt,
+                               const snapgpu_secondary_params *sp, snapgpu_single_result *secondary, uint32_t sec_room, uint32_t *n_secondary,
+                               uint32_t *stale, uint32_t *raw_secondary);
+}
+static int g_use_restatement = 0;
+extern "C" void pairedhost_use_restatement(int on) { g_use_restatement = on; }
+
 struct HostPL {
     const snapgpu_index_view *ix;
     oracle_index oix;
@@ -124,6 +136,14 @@ struct HostPL {
     // returns the number of secondary results the read has; the first min(that, sec_room) go to sec_out
     uint32_t align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt,
                           bool want_secondary, snapgpu_single_result *sec_out, uint32_t sec_room, uint32_t room32) {
+        if (use_restatement) {            // oracle/align_oracle.c instead of the compiled reference's BaseAligner
+            uint32_t n_sec = 0, stale = 0, raw = 0;
+            snapgpu_secondary_params sp; sp.max_edit_distance = om; sp.max_per_contig = mpc; sp.max_results = omax; sp.adjust_alignments = 0;
+            oracle_align_read_chimeric(&oix, &og, &single_params, max_k, hamming ? 1 : 0, (const char *)read_b[r], (const char *)read_q[r], read_l[r],
+                                       &res, &alt, (want_secondary && om >= 0) ? &sp : NULL, sec_out, sec_room, &n_sec, &stale, &raw);
+            last_raw = raw;
+            return n_sec;
+        }
         uint32_t n_sec = 0, over = 0;
         // what the reference's caller would have had left of its initial 32-entry buffer (PairedAligner.cpp:566; ChimericPairedEndAligner.cpp:311)
         const uint32_t first_room = room32;
@@ -136,6 +156,10 @@ struct HostPL {
     uint32_t single_raw_secondary() const { return last_raw; }
     int om; int64_t omax;
     uint32_t last_raw;
+    // the restatement of the single-end aligner, for runs that must not depend on the compiled reference
+    int use_restatement, mpc;
+    oracle_genome og;
+    snapgpu_params single_params;
 };
 
 static uint8_t rc_of(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
@@ -182,7 +206,12 @@ static int host_align(const snapgpu_index_view *ix, void *ref_index, const snapg
     pl.phred_t = oracle_phred_table(); pl.indel_t = oracle_indel_table(); pl.perfect_t = oracle_perfect_table();
     pl.seed_len = (int)ix->seed_len;
     pl.seed_prob_v = oracle_seed_prob(pl.seed_len);
-    pl.single = (stage == 0 && ref_index) ? snapref_chimeric_single_create2(ref_index, p, pp, sp ? sp->max_per_contig : -1) : NULL;
+    pl.use_restatement = g_use_restatement;
+    pl.single = (stage == 0 && ref_index && !pl.use_restatement) ? snapref_chimeric_single_create2(ref_index, p, pp, sp ? sp->max_per_contig : -1) : NULL;
+    pl.mpc = sp ? sp->max_per_contig : -1;
+    pl.og.genome = ix->genome; pl.og.n_bases = ix->n_bases; pl.og.genome_pad = ix->genome_pad; pl.og.chromosome_padding = ix->chromosome_padding;
+    pl.og.contig_begin = ix->contig_begin; pl.og.n_contigs = ix->n_contigs; pl.og.first_alt_location = ix->first_alt_location;
+    pl.single_params = *p; pl.single_params.max_k = p->max_k / 2; pl.single_params.num_seeds = pp->max_single_seeds;     // ChimericPairedEndAligner.cpp:81-88
     pl.om = sp ? sp->max_edit_distance : -1; pl.omax = sp ? sp->max_results : 0x7fffffff;
 
     PECfg cfg;

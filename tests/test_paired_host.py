@@ -171,3 +171,46 @@ def test_secondary_results_match_reference_fixture(golden_pairs, ref_index, tag)
         problems = compare_paired_secondary(ref_t, got, exclude)
         assert not problems, (name, problems)
         assert int(got[3].sum()) > 0 and int(got[5].sum()) > 0
+
+
+# ---------------------------------------------------------------------------------------- without the compiled reference in the loop
+
+@pytest.fixture
+def restatement_single_aligner():
+    """Plug oracle/align_oracle.c (the C restatement of BaseAligner, Hamming pass and alignAffineGap included) into the chimeric
+    fallback instead of the compiled reference's BaseAligner: the whole paired-end path then runs on restatements only."""
+    lib = C.CDLL(HOSTLIB)
+    lib.pairedhost_use_restatement(1)
+    yield
+    lib.pairedhost_use_restatement(0)
+
+
+@pytest.mark.parametrize("name", ["default_d8", "lvonly_d12", "spacing_d8"])
+def test_chimeric_align_on_restatements_only(golden_pairs, ref_index, restatement_single_aligner, name):
+    rix, gi = ref_index
+    kw, pkw = OPTS[name]
+    z = golden_pairs
+    for tag in ("150", "100"):
+        prim, alt, cnt = host_align(gi, rix, abi.default_params(max_read_len=160, **kw), abi.default_paired_params(**pkw),
+                                    z["b" + tag], z["q" + tag], z["o" + tag], 0)
+        key = "%s_%s_s0" % (name, tag)
+        exclude = z[key + "_unstable"] | (prim["reserved"] != 0)
+        assert int(exclude.sum()) <= 2 + prim.size // 100
+        assert not compare_paired(z[key + "_primary"], prim, verbose=3, exclude=exclude).any()
+        assert (alt["status"] == z[key + "_alt"]["status"]).all()
+
+
+def test_secondary_results_on_restatements_only(golden_pairs, ref_index, restatement_single_aligner):
+    from tests.pairs_util import compare_paired_secondary, load_paired_secondary_sets
+    rix, gi = ref_index
+    z = np.load(os.path.join(util.GOLDEN, "paired_secondary.npz"))
+    b, q, o = golden_pairs["b100"], golden_pairs["q100"], golden_pairs["o100"]
+    for name, kw, pkw, om, omax, mpc in load_paired_secondary_sets(z):
+        key = "%s_100_" % name
+        ref_t = tuple(z[key + k] for k in ("primary", "alt", "secondary", "nsec", "single_secondary", "nssec"))
+        got = host_align_secondary(gi, rix, abi.default_params(max_read_len=160, **kw), abi.default_paired_params(**pkw),
+                                   abi.secondary_params(om, omax, mpc), b, q, o, 0, ref_t[2].shape[1], ref_t[4].shape[1])
+        exclude = z[key + "unstable"] | (got[0]["reserved"] != 0) | ((got[0]["flags"] & 2) != 0)
+        assert int(exclude.sum()) <= 2 + got[0].size // 100, name
+        assert not compare_paired(ref_t[0], got[0], verbose=3, exclude=exclude).any(), name
+        assert not compare_paired_secondary(ref_t, got, exclude), name
