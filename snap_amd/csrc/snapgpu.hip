@@ -184,6 +184,9 @@ struct snapgpu_ctx {
     uint32_t p_wave_slots = 0, p_big_slots = 0, p_lds_per_wave = 0;
     int p_ag_variant = 0;
     // paired-end path with secondary results (both snapgpu_enable_paired and snapgpu_enable_secondary called): its own slabs
+    // experimental: dequeue heavy pairs first (SNAPGPU_PAIRED_HEAVY_FIRST=1 at snapgpu_enable_paired; paired_dev.h)
+    bool heavy_first = false;
+    uint32_t *d_order = nullptr, *d_wbucket = nullptr, *d_whist = nullptr; size_t order_cap = 0;
     bool paired_sec = false;
     PairedArgs pargs_sec{}, pargs_sec_big{};
     uint8_t *d_pscratch_sec = nullptr, *d_pscratch_sec_big = nullptr;
@@ -324,6 +327,9 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_pscratch_sec_big) (void)hipFree(ctx->d_pscratch_sec_big);
     for (int i = 0; i < 4; i++) if (ctx->d_psec_stage[i]) (void)hipFree(ctx->d_psec_stage[i]);
     if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
+    if (ctx->d_order) (void)hipFree(ctx->d_order);
+    if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
+    if (ctx->d_whist) (void)hipFree(ctx->d_whist);
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     for (int i = 0; i < 5; i++) if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
@@ -1146,6 +1152,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         HIPCHK(ctx, hipMemsetAsync(ctx->d_pscratch_big + (size_t)w * big.stride, 0, (size_t)sc.ht_size * 2, ctx->stream), SNAPGPU_E_NODEVICE);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
     big.scratch = ctx->d_pscratch_big;
+    ctx->heavy_first = getenv("SNAPGPU_PAIRED_HEAVY_FIRST") != nullptr && atoi(getenv("SNAPGPU_PAIRED_HEAVY_FIRST")) != 0;
     ctx->paired = true;
     return setup_paired_secondary(ctx);
 }
@@ -1192,6 +1199,21 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         default: snapgpu_launch_paired_0(&x, nblocks, lds, s); break;
         }
     };
+    if (ctx->heavy_first && !so) {         // experimental (paired_dev.h): heaviest pairs first, through the remap list
+        if (ctx->order_cap < n) {
+            if (ctx->d_order) (void)hipFree(ctx->d_order);
+            if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
+            ctx->d_order = ctx->d_wbucket = nullptr; ctx->order_cap = 0;
+            size_t cap = (size_t)n + n / 4 + 1024;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_order, cap * 4), SNAPGPU_E_NOMEM);
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_wbucket, cap * 4), SNAPGPU_E_NOMEM);
+            ctx->order_cap = cap;
+        }
+        if (!ctx->d_whist) HIPCHK(ctx, hipMalloc((void **)&ctx->d_whist, 64 * 4), SNAPGPU_E_NOMEM);
+        snapgpu_launch_pair_order(&a.ix, a.bases, a.offsets, n, a.pcfg.max_big_hits, ctx->d_wbucket, ctx->d_whist, ctx->d_order, a.counters,
+                                  (uint32_t)ctx->num_cus * 4, s);
+        a.remap = ctx->d_order; a.n_remap = ctx->d_whist + 33;
+    }
     launch(a, blocks);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     {   // second pass over the pairs the first flagged (usually none: the launch then ends at once)
