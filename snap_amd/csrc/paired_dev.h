@@ -457,7 +457,7 @@ __global__ void k_collect_flagged(const snapgpu_paired_result *primary, uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// EXPERIMENTAL, off unless SNAPGPU_PAIRED_HEAVY_FIRST=1 when snapgpu_enable_paired runs; not yet measured on a GPU (DESIGN.md
+// EXPERIMENTAL, off unless SNAPGPU_PAIRED_HEAVY_FIRST=1 when snapgpu_enable_paired runs (results verified identical; no gain measured yet, DESIGN.md
 // section 10).  A launch lasts until its slowest pair is done and the top 1 % of the pairs are ~90 % of the work, so the pairs
 // are dequeued heaviest first: weight = total hits of a pair's non-overlapping seeds (seeds the aligner would skip as too
 // popular count 0), bucketed by log2; a counting sort in descending bucket order gives the `remap` list of the main launch.
