@@ -27,7 +27,7 @@
 #define __global__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ thread_local
+#define __shared__ __thread      /* (GNU TLS: no dynamic-initialisation wrapper call) */
 #define __restrict__ __restrict
 
 struct uint3 { unsigned x, y, z; };

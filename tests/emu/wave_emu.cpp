@@ -14,6 +14,9 @@
 #include <stdio.h>
 #include <sys/mman.h>
 #include <dlfcn.h>
+#include <signal.h>
+#include <ucontext.h>
+#include <unistd.h>
 #include <atomic>
 #include <chrono>
 #include <thread>
@@ -33,7 +36,7 @@ asm(".text\n"
     ".size emu_switch, .-emu_switch\n");
 
 // the kernels' dynamic LDS: `extern __shared__ uint8_t lds[]` resolves to this (one per host thread = one per running block)
-thread_local __attribute__((aligned(64))) uint8_t lds[160 * 1024];
+__thread __attribute__((aligned(64))) uint8_t lds[160 * 1024];
 
 namespace emu {
 
@@ -255,12 +258,53 @@ static void run_wave(Wave *w, int n_lanes)
     if ((w->done & w->live) != w->live) { fprintf(stderr, "wave_emu: wave ended with unfinished lanes\n"); abort(); }
 }
 
+// diagnostics for a fault inside emulated device code: which lane, what address, where
+static void segv_handler(int, siginfo_t *si, void *uc_)
+{
+    ucontext_t *uc = (ucontext_t *)uc_;
+    Wave *w = g_wave;
+    void *pc = (void *)uc->uc_mcontext.gregs[REG_RIP];
+    Dl_info di; uintptr_t rel = (uintptr_t)pc;
+    if (dladdr(pc, &di) && di.dli_fbase) rel -= (uintptr_t)di.dli_fbase;
+    fprintf(stderr, "wave_emu: SIGSEGV at address %p, pc %p (library offset 0x%lx), lane %d, block %u\n", si->si_addr, pc, (unsigned long)rel,
+            w ? w->cur : -1, w ? w->bidx.x : 0u);
+    if (w && w->cur >= 0) {
+        uint8_t *lo = w->stacks + (size_t)w->cur * STACK_BYTES;
+        void **sp = (void **)uc->uc_mcontext.gregs[REG_RSP];
+        fprintf(stderr, "wave_emu: lane stack [%p, %p), rsp %p\n", lo, lo + STACK_BYTES, (void *)sp);
+        if ((uint8_t *)sp >= lo && (uint8_t *)sp < lo + STACK_BYTES) {          // words on the stack that point into this library: return addresses
+            for (int i = 0, shown = 0; i < 4096 && (uint8_t *)(sp + i) < lo + STACK_BYTES && shown < 12; i++) {
+                Dl_info d2;
+                if (dladdr(sp[i], &d2) && d2.dli_fbase == di.dli_fbase + 0 && d2.dli_fbase) {}
+                if (dladdr(sp[i], &d2) && d2.dli_fname && strstr(d2.dli_fname, "libsnapgpu_emu")) {
+                    fprintf(stderr, "wave_emu:   [rsp+%d] library offset 0x%lx\n", i * 8, (unsigned long)((uintptr_t)sp[i] - (uintptr_t)d2.dli_fbase));
+                    shown++;
+                }
+            }
+        }
+    }
+    _exit(139);
+}
+static void install_segv_handler()
+{
+    static std::once_flag once;
+    std::call_once(once, []() {
+        static uint8_t alt[1 << 16];
+        stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof(alt); ss.ss_flags = 0;
+        sigaltstack(&ss, nullptr);
+        struct sigaction sa; memset(&sa, 0, sizeof(sa));
+        sa.sa_sigaction = segv_handler; sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+        sigaction(SIGSEGV, &sa, nullptr);
+    });
+}
+
 static int env_int(const char *name, int dflt) { const char *s = getenv(name); return s && *s ? atoi(s) : dflt; }
 
 void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body)
 {
     if (lds_bytes > sizeof(lds)) { fprintf(stderr, "wave_emu: %zu bytes of LDS asked for\n", lds_bytes); abort(); }
     const unsigned n_blocks = grid.x;
+    if (env_int("SNAPGPU_EMU_SEGV_HANDLER", 0)) install_segv_handler();
     int n_threads = env_int("SNAPGPU_EMU_THREADS", (int)std::thread::hardware_concurrency());
     if (n_threads < 1) n_threads = 1;
     if ((unsigned)n_threads > n_blocks) n_threads = (int)n_blocks;
