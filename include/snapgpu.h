@@ -17,6 +17,9 @@
  *       Seed::Seed                              SNAPLib/Seed.h:40-53
  *   snapgpu_landau_vishkin
  *       LandauVishkin<1|-1>::computeEditDistance SNAPLib/LandauVishkin.h:100-351
+ *   snapgpu_compute_cigar_lv
+ *       SAMFormat::computeCigar (LV variant)    SNAPLib/SAM.cpp:2354-2467
+ *       LandauVishkinWithCigar::computeEditDistanceNormalized / computeEditDistance  SNAPLib/LandauVishkin.cpp:507-648 / 141-505
  *   snapgpu_affine_gap
  *       AffineGapVectorized<1|-1>::computeScore / computeScoreBanded
  *                                               SNAPLib/AffineGapVectorized.h:821-1339 / 256-819
@@ -287,6 +290,29 @@ int  snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
                             const uint32_t *pat_off, const int32_t *pat_len, const int32_t *k,
                             int32_t *score, double *match_probability, int32_t *net_indel,
                             int32_t *total_indels, int32_t *text_span);
+
+/*
+ * The CIGAR of a written read (first step of result -> SAM record on the device):
+ * SAMFormat::computeCigar, Landau-Vishkin variant (SNAPLib/SAM.cpp:2354-2467), over
+ * LandauVishkinWithCigar::computeEditDistanceNormalized (SNAPLib/LandauVishkin.cpp:507-648, BAM_CIGAR_OPS format) -- what
+ * SAMFormat::writeRead runs per record (SAM.cpp:1976-1983) and writePairs runs for a read aligned without affine gap (:1687).
+ * Item i: the clipped read in REFERENCE orientation, data + off[i], len[i] bases, aligned at genome location loc[i], with
+ * extra_before[i] leading bases to soft-clip because the alignment starts before its contig (createSAMLine's
+ * extraBasesClippedBefore).  k = MAX_K - 1 as in the reference.
+ * Outputs per item:
+ *   ops[i * ops_stride ..]   BAM cigar ops (count << 4 | code; codes M0 I1 D2 =7 X8); use_m != 0: M instead of = / X
+ *   n_ops[i]                 ops written; -1 = the "*" cigar (the read falls off its contig, SAM.cpp:2397-2408)
+ *   edit_distance[i]         NM; -1 above the limit, -2 when ops_stride is too small (the reference's "cigarBuf too small")
+ *   add_front_clipping[i]    > 0: the alignment starts with that many deleted reference bases -- no cigar is returned, the
+ *                            caller moves the location and calls again (SAM.cpp:1660-1684); < 0: leading insertion of that
+ *                            many bases (cigar returned; the caller soft-clips them and calls again)
+ *   extra_clipped_after[i]   bases hanging off the end of the contig, to be soft-clipped (iterated as :2434-2460 does)
+ * Host pointers; the genome is the one resident on the device.  Returns SNAPGPU_OK or a negative error.
+ */
+int  snapgpu_compute_cigar_lv(snapgpu_ctx *ctx, uint32_t n, const char *data, uint64_t data_bytes, const uint64_t *off,
+                              const int32_t *len, const int64_t *loc, const int32_t *extra_before, int use_m,
+                              uint32_t *ops, uint32_t ops_stride, int32_t *n_ops, int32_t *edit_distance,
+                              int32_t *add_front_clipping, int64_t *extra_clipped_after);
 
 /*
  * Batched AffineGapVectorized<dir>::computeScore (banded[i] == 0) / computeScoreBanded

@@ -23,14 +23,7 @@
 #define BUCKET 48                       /* hashTableElementSize = maxMergeDist, BaseAligner.h:177, 213 */
 #define MAXK   SNAPGPU_MAX_K
 
-typedef struct oracle_genome {          /* what Genome holds for this path */
-    const uint8_t *genome;              /* base 0; genome_pad readable bytes before and after */
-    uint64_t n_bases;
-    uint32_t genome_pad, chromosome_padding;
-    const uint64_t *contig_begin;
-    uint32_t n_contigs;
-    uint64_t first_alt_location;
-} oracle_genome;
+/* oracle_genome (what Genome holds for this path): snap_oracle.h */
 
 typedef struct {                        /* HashTableElement, BaseAligner.h:223-258 */
     uint64_t used, scored;

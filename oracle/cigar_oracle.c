@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdint.h>
 #include "snap_oracle.h"
 
 #define MAXK 127                                    /* MAX_K, LandauVishkin.h:11 */
@@ -33,9 +34,15 @@ static int eq_run(const mem_t *pat, int pi, const mem_t *txt, int ti) {
     return n;
 }
 
-typedef struct { char *buf; int cap, used; } out_t;
-static int write_cigar(out_t *o, int count, char code) {       /* writeCigar, COMPACT_CIGAR_STRING (:77-82, :100-113) */
+typedef struct { char *buf; int cap, used; uint32_t *ops; int ops_cap, n_ops; } out_t;
+static int bam_code(char c) { return c == 'M' ? 0 : c == 'I' ? 1 : c == 'D' ? 2 : c == '=' ? 7 : c == 'X' ? 8 : 15; }   /* BAMAlignment::CigarToCode */
+static int write_cigar(out_t *o, int count, char code) {       /* writeCigar, COMPACT_CIGAR_STRING (:77-82, :100-113) / BAM_CIGAR_OPS (:124-131) */
     if (count <= 0) return 1;
+    if (o->ops) {
+        if (o->n_ops >= o->ops_cap || count >= (1 << 28)) return 0;
+        o->ops[o->n_ops++] = ((uint32_t)count << 4) | (uint32_t)bam_code(code);
+        return 1;
+    }
     if (o->cap - o->used == 0) return 0;
     char tmp[32];
     int w = snprintf(tmp, sizeof(tmp), "%d%c", count, code);
@@ -49,15 +56,25 @@ static int write_cigar(out_t *o, int count, char code) {       /* writeCigar, CO
  * Returns the edit distance, -1 (ScoreAboveLimit) or -2 (cigar buffer too small).
  * text_lo / text_hi: readable range around text (text_lo <= 0, text_hi >= text_len); likewise for the pattern.
  */
+static int lv_cigar_core(const char *text, int text_len, int text_lo, int text_hi, const char *pattern, int pattern_len, int pat_lo, int pat_hi,
+                         int k, int use_m, out_t *outp, int *o_text_used, int *o_net_indel);
+
 int oracle_lv_cigar(const char *text, int text_len, int text_lo, int text_hi, const char *pattern, int pattern_len, int pat_lo, int pat_hi,
                     int k, int use_m, char *cigar, int cigar_cap, int *o_text_used, int *o_net_indel)
 {
+    out_t out = { cigar, cigar_cap, 0, NULL, 0, 0 };
+    if (cigar_cap > 0) cigar[0] = '\0';
+    return lv_cigar_core(text, text_len, text_lo, text_hi, pattern, pattern_len, pat_lo, pat_hi, k, use_m, &out, o_text_used, o_net_indel);
+}
+
+static int lv_cigar_core(const char *text, int text_len, int text_lo, int text_hi, const char *pattern, int pattern_len, int pat_lo, int pat_hi,
+                         int k, int use_m, out_t *outp, int *o_text_used, int *o_net_indel)
+{
     static const int PrevDelta[3][3] = { {0, +1, -1}, {0, +1, -1}, {0, -1, +1} };    /* least absolute indels, :66-69 */
     const mem_t txt = { text, text_lo, text_hi }, pat = { pattern, pat_lo, pat_hi };
-    out_t out = { cigar, cigar_cap, 0 };
+#define out (*outp)
     int net_indel = 0;
     if (o_net_indel) *o_net_indel = 0;
-    if (cigar_cap > 0) cigar[0] = '\0';
     if (text == NULL) return -1;
     if (k >= MAXK) k = MAXK - 1;
 
@@ -196,4 +213,74 @@ done:
 #undef LL
 #undef TT
 #undef AA
+#undef out
+}
+
+/*
+ * LandauVishkinWithCigar::computeEditDistanceNormalized with BAM_CIGAR_OPS output (LandauVishkin.cpp:507-648): the edit
+ * distance, the op list (count << 4 | BAM code), and the "leading indel" convention -- a leading D is reported as
+ * *add_front_clipping = count with return value 0 and NO cigar (the caller moves the alignment and calls again, SAM.cpp:1660-1684);
+ * a leading I as -count with the cigar still returned.
+ */
+int oracle_lv_cigar_normalized(const char *text, int text_len, int text_lo, int text_hi, const char *pattern, int pattern_len, int pat_lo, int pat_hi,
+                               int k, int use_m, uint32_t *ops, int ops_cap, int *n_ops, int *add_front_clipping, int *o_net_indel)
+{
+    uint32_t *tmp = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(ops_cap > 0 ? ops_cap : 1));
+    out_t out = { NULL, 0, 0, tmp, ops_cap, 0 };
+    int text_used = 0;
+    *n_ops = 0; *add_front_clipping = 0;
+    int score = lv_cigar_core(text, text_len, text_lo, text_hi, pattern, pattern_len, pat_lo, pat_hi, k, use_m, &out, &text_used, o_net_indel);
+    if (score < 0) { free(tmp); return score; }
+    if (out.n_ops > 0) {
+        const uint32_t code = tmp[0] & 0xf, cnt = tmp[0] >> 4;
+        if (code == 2) { *add_front_clipping = (int)cnt; if (cnt != 0) { free(tmp); return 0; } }      /* :611-616 */
+        else if (code == 1) *add_front_clipping = -(int)cnt;                                            /* :617-618 */
+    }
+    memcpy(ops, tmp, sizeof(uint32_t) * (size_t)out.n_ops);
+    *n_ops = out.n_ops;
+    free(tmp);
+    return score;
+}
+
+/*
+ * SAMFormat::computeCigar, Landau-Vishkin variant (SAM.cpp:2354-2467): the reference window comes from the genome, a read that
+ * hangs off the end of its contig is soft-clipped there (iterating when the alignment's net indel changes how much hangs off),
+ * k = MAX_K - 1.  data = the clipped read in reference orientation.  *n_ops = -1 stands for the "*" cigar of :2399-2408.
+ */
+int oracle_compute_cigar_lv(const oracle_genome *g, const char *data, int64_t data_len, int64_t extra_clipped_before, int64_t genome_location,
+                            int use_m, uint32_t *ops, int ops_cap, int *n_ops, int *edit_distance, int *add_front_clipping,
+                            int64_t *extra_clipped_after)
+{
+    int net_indel = 0;
+    *extra_clipped_after = 0; *n_ops = 0; *edit_distance = 0; *add_front_clipping = 0;
+    genome_location += extra_clipped_before; data += extra_clipped_before; data_len -= extra_clipped_before;     /* :2381-2383 */
+    /* getContigAtLocation (Genome.cpp:574) */
+    int lo = 0, hi = (int)g->n_contigs - 1, c = -1;
+    while (lo <= hi) { int mid = (lo + hi) >> 1; if ((int64_t)g->contig_begin[mid] <= genome_location) { c = mid; lo = mid + 1; } else hi = mid - 1; }
+    if (c < 0) return -1;
+    const int64_t cend = c == (int)g->n_contigs - 1 ? (int64_t)g->n_bases : (int64_t)g->contig_begin[c + 1];      /* beginningLocation + length */
+    const int64_t real_end = cend - (int64_t)g->chromosome_padding;
+    if (genome_location + data_len > real_end) *extra_clipped_after = genome_location + data_len - real_end;       /* :2387-2395 */
+    {   /* getSubstring(genomeLocation, dataLength), Genome.h:339-367 */
+        const int64_t nb = (int64_t)g->n_bases;
+        int ok;
+        if (genome_location > nb || genome_location + data_len > nb + 1000) ok = 0;
+        else if (data_len <= (int64_t)g->chromosome_padding && g->genome[genome_location] != 'n') ok = 1;
+        else if (data_len == 0) ok = 1;
+        else ok = cend > genome_location + data_len;
+        if (!ok) { *n_ops = -1; return 0; }                                                                        /* :2398-2408 */
+    }
+    const char *reference = (const char *)g->genome + genome_location;
+    const int64_t pad = (int64_t)g->genome_pad;
+    for (int64_t pass = 0; pass <= data_len; pass++) {                                                              /* first call + the loop of :2435-2460 */
+        const int plen = (int)(data_len - *extra_clipped_after);
+        const int tlen = plen + MAXK;
+        *edit_distance = oracle_lv_cigar_normalized(reference, tlen, (int)(-genome_location - pad), (int)((int64_t)g->n_bases + pad - genome_location),
+                                                    data, plen, 0, plen, MAXK - 1, use_m, ops, ops_cap, n_ops, add_front_clipping, &net_indel);
+        if (pass == 0 && *add_front_clipping != 0) return 0;                                                        /* :2425-2431 */
+        int64_t nw = genome_location + data_len + net_indel - real_end; if (nw < 0) nw = 0;                         /* :2434 / :2459 */
+        if (nw == *extra_clipped_after) return 0;
+        *extra_clipped_after = nw;
+    }
+    return 0;
 }

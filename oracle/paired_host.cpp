@@ -29,9 +29,7 @@ int   snapref_chimeric_single_align2(void *h, int max_k, int hamming, const char
 }
 
 extern "C" {
-typedef struct oracle_genome {
-    const uint8_t *genome; uint64_t n_bases; uint32_t genome_pad, chromosome_padding; const uint64_t *contig_begin; uint32_t n_contigs; uint64_t first_alt_location;
-} oracle_genome;
+/* oracle_genome: snap_oracle.h */
 int oracle_align_read_chimeric(const oracle_index *ix, const oracle_genome *g, const snapgpu_params *p, int max_k, int hamming,
                                const char *bases, const char *quals, int len, snapgpu_single_result *primary, snapgpu_single_result *first_alt,
                                const snapgpu_secondary_params *sp, snapgpu_single_result *secondary, uint32_t sec_room, uint32_t *n_secondary,

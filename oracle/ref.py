@@ -72,6 +72,22 @@ class RefIndex:
             raise RuntimeError("snapref_lookup_seeds rc=%d" % rc)
         return n_hits, hits
 
+    def compute_cigar_lv(self, data: np.ndarray, off: np.ndarray, length: np.ndarray, loc: np.ndarray, extra_before: np.ndarray,
+                         use_m: bool, ops_stride: int = 64):
+        """SAMFormat::computeCigar (Landau-Vishkin variant, BAM_CIGAR_OPS) for a batch; see snapref_compute_cigar_lv."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(off, dtype=np.uint64); length = np.ascontiguousarray(length, dtype=np.int32)
+        loc = np.ascontiguousarray(loc, dtype=np.int64); extra_before = np.ascontiguousarray(extra_before, dtype=np.int32)
+        n = off.size
+        ops = np.zeros((n, ops_stride), dtype=np.uint32); n_ops = np.zeros(n, dtype=np.int32)
+        ed = np.zeros(n, dtype=np.int32); afc = np.zeros(n, dtype=np.int32); after = np.zeros(n, dtype=np.int64)
+        rc = lib().snapref_compute_cigar_lv(self.handle, C.c_uint32(n), ptr(data), ptr(off), ptr(length), ptr(loc), ptr(extra_before),
+                                            C.c_int(1 if use_m else 0), ptr(ops), C.c_uint32(ops_stride), ptr(n_ops), ptr(ed), ptr(afc),
+                                            ptr(after))
+        if rc != 0:
+            raise RuntimeError("snapref_compute_cigar_lv rc=%d" % rc)
+        return dict(ops=ops, n_ops=n_ops, edit_distance=ed, add_front_clipping=afc, extra_clipped_after=after)
+
     def align_single(self, params: Params, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray,
                      threads: int = 1):
         """BaseAligner::AlignRead over a batch; returns (primary, first_alt, counters, seconds)."""

@@ -33,6 +33,7 @@
 #include "mapq.h"
 #include "IntersectingPairedEndAligner.h"
 #include "ChimericPairedEndAligner.h"
+#include "SAM.h"
 
 #include <pthread.h>
 #include <string.h>
@@ -379,6 +380,31 @@ int snapref_lv_cigar(const char *text, int text_len, const char *pattern, int pa
     if (lvc == NULL) lvc = new LandauVishkinWithCigar();
     int used = 0;
     return lvc->computeEditDistance(text, text_len, pattern, pattern_len, k, cigar, cigar_cap, use_m != 0, COMPACT_CIGAR_STRING, &used, text_used, net_indel);
+}
+
+/* SAMFormat::computeCigar, Landau-Vishkin variant (SAM.cpp:2354-2467), BAM_CIGAR_OPS output, for a batch: item i is the clipped read
+ * data[off[i] .. off[i] + len[i]) in reference orientation at genome location loc[i] with extra_before[i] bases to clip in front.
+ * Outputs per item: ops[i * ops_stride ..] (count << 4 | code), n_ops (-1 for the "*" cigar), edit distance, addFrontClipping,
+ * extraBasesClippedAfter. */
+int snapref_compute_cigar_lv(void *vindex, uint32_t n, const char *data, const uint64_t *off, const int32_t *len, const int64_t *loc,
+                             const int32_t *extra_before, int use_m, uint32_t *ops, uint32_t ops_stride, int32_t *n_ops,
+                             int32_t *edit_distance, int32_t *add_front_clipping, int64_t *extra_after)
+{
+    GenomeIndex *index = (GenomeIndex *)vindex;
+    const Genome *genome = index->getGenome();
+    static LandauVishkinWithCigar *lvc = NULL;
+    if (lvc == NULL) lvc = new LandauVishkinWithCigar();
+    for (uint32_t i = 0; i < n; i++) {
+        char *buf = (char *)(ops + (size_t)i * ops_stride);
+        int used = 0, afc = 0, ed = 0;
+        GenomeDistance after = 0;
+        buf[0] = 0;
+        SAMFormat::computeCigar(BAM_CIGAR_OPS, genome, lvc, buf, (int)(ops_stride * 4), data + off[i], (GenomeDistance)len[i], 0,
+                                (GenomeDistance)extra_before[i], 0, &after, GenomeLocation(loc[i]), use_m != 0, &ed, &used, &afc);
+        n_ops[i] = (used == 0 && buf[0] == '*') ? -1 : used / 4;
+        edit_distance[i] = ed; add_front_clipping[i] = afc; extra_after[i] = (int64_t)after;
+    }
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------- secondary results (-om)

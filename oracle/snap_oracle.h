@@ -47,6 +47,15 @@ int    oracle_ag(int dir, int banded, const oracle_ag_params *prm, const char *t
                  int is_rc, int use_clipping, int *text_offset, int *pattern_offset, int *n_edits,
                  double *match_probability, int *stale_reads);
 
+typedef struct oracle_genome {          /* what Genome holds for the aligner and the CIGAR writer */
+    const uint8_t *genome;              /* base 0; genome_pad readable bytes before and after */
+    uint64_t n_bases;
+    uint32_t genome_pad, chromosome_padding;
+    const uint64_t *contig_begin;
+    uint32_t n_contigs;
+    uint64_t first_alt_location;
+} oracle_genome;
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,7 @@ EXPORTED_SYMBOLS = [
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
     "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
     "snapgpu_align_paired_secondary", "snapgpu_align_paired_secondary_device",
+    "snapgpu_compute_cigar_lv",
 ]
 
 
@@ -184,6 +185,23 @@ class BaseAligner:
             ptr(pbuf), ptr(qbuf), C.c_uint64(pbuf.size), ptr(poff), ptr(plen), ptr(w), ptr(score_init),
             ptr(is_rc), ptr(banded), ptr(use_clip), ptr(ag), ptr(to), ptr(po), ptr(ne), ptr(prob)), "snapgpu_affine_gap")
         return dict(ag_score=ag, text_offset=to, pattern_offset=po, n_edits=ne, match_probability=prob)
+
+    # ---- SAMFormat::computeCigar (Landau-Vishkin variant) over a batch ------------------
+    def computeCigar(self, data, off, length, loc, extra_before, use_m: bool = False, ops_stride: int = 64):
+        """SAM.cpp:2354-2467 for a batch of written reads (see snapgpu_compute_cigar_lv in include/snapgpu.h): data = the clipped
+        reads in reference orientation (one uint8 buffer), item i = data[off[i] : off[i] + length[i]] at genome location loc[i].
+        Returns dict(ops uint32[n, ops_stride], n_ops, edit_distance, add_front_clipping, extra_clipped_after)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(off, dtype=np.uint64); length = np.ascontiguousarray(length, dtype=np.int32)
+        loc = np.ascontiguousarray(loc, dtype=np.int64); extra_before = np.ascontiguousarray(extra_before, dtype=np.int32)
+        n = off.size
+        ops = np.zeros((n, ops_stride), dtype=np.uint32); n_ops = np.zeros(n, np.int32); ed = np.zeros(n, np.int32)
+        afc = np.zeros(n, np.int32); after = np.zeros(n, np.int64)
+        self._check(self.lib.snapgpu_compute_cigar_lv(
+            self.handle, C.c_uint32(n), ptr(data), C.c_uint64(data.size), ptr(off), ptr(length), ptr(loc), ptr(extra_before),
+            C.c_int(1 if use_m else 0), ptr(ops), C.c_uint32(ops_stride), ptr(n_ops), ptr(ed), ptr(afc), ptr(after)),
+            "snapgpu_compute_cigar_lv")
+        return dict(ops=ops, n_ops=n_ops, edit_distance=ed, add_front_clipping=afc, extra_clipped_after=after)
 
     # ---- BaseAligner::AlignRead over a batch -------------------------------------------
     def AlignRead(self, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray):

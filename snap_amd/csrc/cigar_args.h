@@ -1,0 +1,14 @@
+// cigar_args.h -- kernel arguments of k_cigar_lv (cigar_k.hip), shared with the host side (snapgpu.hip).
+#pragma once
+#include "dev_common.h"
+
+struct CigarArgs {
+    DevIndex ix;
+    uint32_t n, RL, ops_stride, use_m;
+    const uint8_t *data; const uint64_t *off; const int32_t *len; const int64_t *loc; const int32_t *extra_before;
+    uint8_t *scratch;                 // waves * lvc_scratch_bytes()
+    uint32_t *work_counter;
+    uint32_t *ops; int32_t *n_ops; int32_t *edit_distance; int32_t *add_front_clipping; int64_t *extra_after;
+};
+
+extern "C" void snapgpu_launch_cigar_lv(const CigarArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);

@@ -18,7 +18,7 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fno-reorder-blocks", "-fno-reorder-
 
 
 def units():
-    u = [("snapgpu.o", os.path.join(CSRC, "snapgpu.hip"), [])]
+    u = [("snapgpu.o", os.path.join(CSRC, "snapgpu.hip"), []), ("cigar_k.o", os.path.join(CSRC, "cigar_k.hip"), [])]
     u += [("paired_k%d.o" % v, os.path.join(CSRC, "paired_k.hip"), ["-DPAIRED_AGC=%d" % v]) for v in (3, 4, 6, 0)]
     u += [("single_sec_k%d.o" % v, os.path.join(CSRC, "single_sec_k.hip"), ["-DSINGLE_AGC=%d" % v]) for v in (3, 4, 6, 0)]
     u += [("paired_sec_k%d.o" % v, os.path.join(CSRC, "paired_k.hip"), ["-DPAIRED_AGC=%d" % v, "-DPAIRED_SEC"]) for v in (3, 0)]

@@ -40,7 +40,7 @@ __thread __attribute__((aligned(64))) uint8_t lds[160 * 1024];
 
 namespace emu {
 
-static const size_t STACK_BYTES = 1u << 20;
+static const size_t STACK_BYTES = 8u << 20;     // per lane; untouched pages cost nothing (MAP_NORESERVE)
 
 struct Pending {
     void *site;
@@ -326,6 +326,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()>
             }
         }
         munmap(w->stacks, 64 * STACK_BYTES);
+        g_wave = nullptr;                                // (the worker may be the calling thread: host code runs the store hook too)
         delete w;
     };
     if (n_threads == 1) worker();

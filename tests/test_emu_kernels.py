@@ -1,0 +1,143 @@
+"""The device kernels, executed on the host by the wavefront emulator (tests/emu/), against the same fixtures and with the
+same test bodies as the `-m gpu` parity tests.
+
+What this adds to the CPU suite: the *device* code -- lane-parallel probes, Landau-Vishkin, the DPP/bpermute affine-gap
+rows, the candidate table, the whole `k_align_single` / `k_align_paired` control flow -- runs here without a GPU, one fiber
+per lane, so a change to a kernel is checked for parity before any GPU time is spent on it.  What it does not replace: the
+`-m gpu` tests (the real compiler, the real hardware), which remain the parity gate.
+
+Test infrastructure only: the emulator library is built from snap_amd/csrc by tests/emu/build.py into tests/emu/_build and
+is loaded here by swapping the handle inside snap_amd.aligner for the duration of this module; the product never sees it."""
+import ctypes as C
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from snap_amd import abi
+from tests import util
+
+pytestmark = pytest.mark.skipif(shutil.which("g++") is None, reason="g++ needed to build the wavefront emulator")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    import snap_amd.aligner as al
+    from tests.emu.build import build
+    path = build()
+    saved = (al._lib, al.LIB_PATH)
+    os.environ.setdefault("SNAPGPU_EMU_CUS", "4")         # 4 "compute units": 32 waves in flight over the host threads
+    al._lib, al.LIB_PATH = None, path
+    try:
+        lib = al.load_library()
+        for f in ("emu_total_ops", "emu_partial_ops", "emu_inactive_reads"):
+            getattr(lib, f).restype = C.c_ulonglong
+        yield lib
+    finally:
+        al._lib, al.LIB_PATH = saved
+
+
+@pytest.fixture(scope="module")
+def emu_aligner(emu, golden_index):
+    from snap_amd.aligner import BaseAligner
+    a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+    yield a
+    a.close()
+
+
+def test_emulated_library_exports_the_c_abi(emu):
+    from snap_amd.aligner import EXPORTED_SYMBOLS
+    for s in EXPORTED_SYMBOLS:
+        assert hasattr(emu, s), s
+    assert emu.snapgpu_abi_version() == 3
+
+
+def test_emu_tables_and_seed_lookup(emu_aligner, golden_primitives):
+    import tests.test_gpu_parity as gp
+    gp.test_tables_match_restatement(emu_aligner)
+    gp.test_lookup_seeds_vs_reference_fixture(emu_aligner, golden_primitives)
+
+
+def test_emu_landau_vishkin(emu_aligner, golden_primitives):
+    import tests.test_gpu_parity as gp
+    gp.test_lv_known_answers_and_fixture(emu_aligner, golden_primitives)
+
+
+def test_emu_affine_gap(emu, emu_aligner, golden_index, golden_primitives):
+    import tests.test_gpu_parity as gp
+    gp.test_affine_gap_known_answers(golden_index)
+    gp.test_affine_gap_vs_reference_fixture(emu_aligner, golden_primitives)
+    gp.test_affine_gap_clipping_modes_vs_restatement(emu_aligner)
+
+
+@pytest.mark.parametrize("name,kw", [("default_d8", dict(max_k=8)), ("lvonly_d8", dict(max_k=8, use_affine_gap=0))])
+def test_emu_align_read_vs_reference_fixture(emu, golden_index, golden_reads, name, kw):
+    """All 4 000 golden reads (100 and 150 bp) through the emulated k_align_single, every field against the reference's."""
+    import tests.test_gpu_parity as gp
+    partial0, inactive0 = emu.emu_partial_ops(), emu.emu_inactive_reads()
+    gp.test_align_read_vs_reference_fixture(golden_index, golden_reads, name, kw)
+    # the single-end kernel's control flow is wave-uniform: no cross-lane operation was ever resolved with part of a wave,
+    # and no lane read a lane that was not taking part
+    assert emu.emu_partial_ops() == partial0
+    assert emu.emu_inactive_reads() == inactive0
+
+
+def test_emu_ragged_and_degenerate_reads(emu, golden_index):
+    import tests.test_gpu_parity as gp
+    gp.test_ragged_and_degenerate_reads(golden_index)
+
+
+def test_emu_secondary_results(emu, golden_index, golden_reads):
+    """-om / -omax / -mpc: the first 250 reads of two option sets through k_align_single<., true>, record order included."""
+    import tests.test_gpu_secondary as gs
+    from snap_amd.aligner import BaseAligner
+    z = np.load(os.path.join(util.GOLDEN, "secondary_reads.npz"))
+    n = 250
+    b, q = golden_reads["b100"][:n], golden_reads["q100"][:n]
+    offs = np.arange(n + 1, dtype=np.uint64) * b.shape[1]
+    for name, kw, om, omax, mpc in gs._sets(z)[:2]:
+        a = BaseAligner(golden_index, abi.default_params(max_read_len=160, **kw))
+        try:
+            a.enable_secondary(om, max_results=omax, max_per_contig=mpc)
+            prim, alt, sec, nsec = a.AlignReadSecondary(b, q, offs, stride=4)
+        finally:
+            a.close()
+        key = "%s_100_" % name
+        exclude = z[key + "unstable"][:n] | (prim["reserved"] != 0)
+        problems = util.compare_results(z[key + "primary"][:n], prim, "primary", exclude=exclude)
+        problems += gs.compare_secondary(z[key + "secondary"][:n], z[key + "nsec"][:n], sec, nsec, exclude)
+        assert not problems, (name, problems)
+
+
+def test_emu_compute_cigar(emu, emu_aligner, golden_index):
+    """SAMFormat::computeCigar (Landau-Vishkin variant) on the emulated device: every item of the reference fixture, both
+    op alphabets; 1 500 fresh reads against the C restatement; argument errors."""
+    import tests.test_zz_gpu_cigar as gc
+    z = np.load(os.path.join(util.GOLDEN, "cigar_lv.npz"))
+    for use_m in (0, 1):
+        got = gc.check_against_fixture(emu_aligner, z, use_m)
+        gc.cigar_properties(got, z["length"], z["extra_before"])
+    gc.test_compute_cigar_argument_errors(emu_aligner, golden_index)
+
+
+def test_emu_paired_end(emu):
+    """ChimericPairedEndAligner::align over IntersectingPairedEndAligner::align on the emulated device (k_align_paired): the first
+    200 golden pairs (2 x 150 bp) of the default option set, every field of every aligned read against the reference's."""
+    import tests.test_gpu_paired as gp
+    from tests.pairs_util import compare_paired
+    from tests.test_paired_host import OPTS
+    name = list(OPTS)[0]
+    kw, pkw = OPTS[name]
+    z = np.load(os.path.join(util.GOLDEN, "paired_reads.npz"))
+    n = 200
+    o = z["o150"][:2 * n + 1]
+    a = gp._aligner(util.load_golden_index("paired_index.npz"), kw, pkw)
+    try:
+        prim, alt = a.align(z["b150"].reshape(-1)[:int(o[-1])], z["q150"].reshape(-1)[:int(o[-1])], o)
+    finally:
+        a.close()
+    key = "%s_150_s0" % name
+    bad = compare_paired(z[key + "_primary"][:n], prim, verbose=3, exclude=z[key + "_unstable"][:n])
+    assert not bad.any()
+    assert (alt["status"] == z[key + "_alt"]["status"][:n]).all()

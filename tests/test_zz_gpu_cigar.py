@@ -1,0 +1,114 @@
+"""SAMFormat::computeCigar (Landau-Vishkin variant) on the device, through the C ABI (snapgpu_compute_cigar_lv), against the
+reference's answers (tests/golden/cigar_lv.npz, scripts/make_golden_cigar.py) and against the C restatement on fresh items.
+
+Written in a round that had no GPU time left: the kernel was verified on the wavefront emulator (tests/test_emu_kernels.py) and
+compiled for gfx950, not yet run on hardware -- hence the file name, which makes it the last module of the `-m gpu` run."""
+import numpy as np
+import pytest
+
+from snap_amd import abi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def check_against_fixture(aligner, z, use_m, sel=slice(None)):
+    got = aligner.computeCigar(z["data"], z["off"][sel], z["length"][sel], z["loc"][sel], z["extra_before"][sel], bool(use_m), ops_stride=256)
+    pre = "m%d_" % use_m
+    for k in ("n_ops", "edit_distance", "add_front_clipping", "extra_clipped_after"):
+        bad = np.nonzero(got[k] != z[pre + k][sel])[0]
+        assert bad.size == 0, (k, bad[:5], got[k][bad[:5]], z[pre + k][sel][bad[:5]])
+    exp_ops, exp_n = z[pre + "ops"][sel], z[pre + "n_ops"][sel]
+    for i in range(len(exp_n)):
+        assert util.cigar_text(got["ops"][i], got["n_ops"][i]) == util.cigar_text(exp_ops[i], exp_n[i]), i
+    return got
+
+
+def cigar_properties(got, length, extra_before):
+    """What any CIGAR of a read of that length satisfies: query-consuming ops (M I = X) add up to the bases that were aligned,
+    no two neighbouring ops share a code, never a leading D or a trailing I / D."""
+    for i in range(len(length)):
+        n = int(got["n_ops"][i])
+        if n <= 0:
+            continue
+        ops = got["ops"][i, :n]
+        codes, counts = ops & 15, ops >> 4
+        assert (counts > 0).all()
+        assert (codes[1:] != codes[:-1]).all(), i
+        q = int(counts[np.isin(codes, (0, 1, 7, 8))].sum())
+        assert q == int(length[i]) - int(extra_before[i]) - int(got["extra_clipped_after"][i]), i
+        assert codes[0] != 2 and codes[-1] not in (1, 2), i
+        assert int(got["edit_distance"][i]) == int(counts[np.isin(codes, (1, 2, 8))].sum()) or (codes == 0).any(), i
+
+
+@pytest.fixture(scope="module")
+def cig_aligner(golden_index):
+    from snap_amd.aligner import BaseAligner
+    a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+    yield a
+    a.close()
+
+
+@pytest.fixture(scope="module")
+def golden_cigar():
+    import os
+    return np.load(os.path.join(util.GOLDEN, "cigar_lv.npz"))
+
+
+@pytest.mark.parametrize("use_m", [0, 1])
+def test_compute_cigar_vs_reference_fixture(cig_aligner, golden_cigar, use_m):
+    z = golden_cigar
+    got = check_against_fixture(cig_aligner, z, use_m)
+    cigar_properties(got, z["length"], z["extra_before"])
+
+
+def test_compute_cigar_vs_restatement_on_fresh_reads(cig_aligner, golden_index):
+    """20 000 reads cut from the golden genome with substitutions and indels (up to 12 edits), half of them shifted by a few
+    bases: device == C restatement, and the CIGAR properties hold."""
+    ix = golden_index
+    rng = np.random.default_rng(77)
+    pad = (ix.genome_padded.size - ix.n_bases) // 2
+    G = ix.genome_padded[pad:]
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    cb = [int(x) for x in ix.contig_begin] + [int(ix.n_bases)]
+    items, locs = [], []
+    while len(items) < 20000:
+        c = int(rng.integers(0, len(cb) - 1)); L = int(rng.choice([100, 150, 250]))
+        lo, hi = cb[c], cb[c + 1] - ix.chromosome_padding - L - 20
+        if hi <= lo:
+            continue
+        p = int(rng.integers(lo, hi))
+        r = list(G[p:p + L + 16])
+        for _ in range(int(rng.integers(0, 13))):
+            j = int(rng.integers(0, L)); t = rng.random()
+            if t < 0.6: r[j] = int(acgt[rng.integers(0, 4)])
+            elif t < 0.8: del r[j]
+            else: r.insert(j, int(acgt[rng.integers(0, 4)]))
+        items.append(bytes(r[:L])); locs.append(p + (int(rng.integers(-3, 4)) if rng.random() < 0.5 else 0))
+    data = np.frombuffer(b"".join(items), dtype=np.uint8)
+    length = np.array([len(x) for x in items], dtype=np.int32)
+    off = np.zeros(len(items), dtype=np.uint64); off[1:] = np.cumsum(length)[:-1]
+    loc = np.array(locs, dtype=np.int64); xb = np.zeros(len(items), dtype=np.int32)
+    for use_m in (False, True):
+        got = cig_aligner.computeCigar(data, off, length, loc, xb, use_m, ops_stride=64)
+        cigar_properties(got, length, xb)
+        sub = np.arange(0, len(items), 10)                       # the scalar restatement on every tenth item
+        exp = util.oracle_compute_cigar_lv(ix, data, off[sub], length[sub], loc[sub], xb[sub], use_m, ops_stride=64)
+        for k in ("n_ops", "edit_distance", "add_front_clipping", "extra_clipped_after"):
+            assert (got[k][sub] == exp[k]).all(), k
+        for j, i in enumerate(sub):
+            assert util.cigar_text(got["ops"][i], got["n_ops"][i]) == util.cigar_text(exp["ops"][j], exp["n_ops"][j]), i
+
+
+def test_compute_cigar_argument_errors(cig_aligner, golden_index):
+    from snap_amd.aligner import SnapGpuError
+    d = np.frombuffer(b"ACGT" * 25, dtype=np.uint8)
+    one = lambda **kw: cig_aligner.computeCigar(d, kw.get("off", [0]), kw.get("length", [100]), kw.get("loc", [2000]), kw.get("xb", [0]))
+    with pytest.raises(SnapGpuError):
+        one(off=[50])                                            # read runs past the data buffer
+    with pytest.raises(SnapGpuError):
+        one(loc=[int(golden_index.n_bases) + 5])                 # location outside the genome
+    with pytest.raises(SnapGpuError):
+        one(xb=[101])
+    r = cig_aligner.computeCigar(d, [0], [100], [2000], [0], ops_stride=2)      # far too few op slots: the reference's -2
+    assert int(r["edit_distance"][0]) in (-2, -1) or int(r["n_ops"][0]) <= 2

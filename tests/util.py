@@ -175,6 +175,44 @@ def oracle_align_reads(index: GenomeIndex, params, bases, quals, offsets, second
     return prim, alt, sec, nsec
 
 
+def oracle_genome(index: GenomeIndex):
+    """(struct, keep-alive tuple) for the C restatement's oracle_genome."""
+    pad = (index.genome_padded.size - index.n_bases) // 2
+    cb = np.ascontiguousarray(index.contig_begin, dtype=np.uint64)
+    alts = [c.begin for c in index.contigs if c.is_alt]
+    g = _OGenome(index.genome_padded.ctypes.data + pad, index.n_bases, pad, index.chromosome_padding, cb.ctypes.data, len(index.contigs),
+                 min(alts) if alts else index.n_bases + (1 << 40))
+    return g, (cb, index.genome_padded)
+
+
+def oracle_compute_cigar_lv(index: GenomeIndex, data, off, length, loc, extra_before, use_m, ops_stride: int = 64):
+    """SAMFormat::computeCigar (Landau-Vishkin variant) through the C restatement (oracle/cigar_oracle.c), item by item."""
+    lib = oracle_lib()
+    g, keep = oracle_genome(index)
+    data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    n = len(off)
+    ops = np.zeros((n, ops_stride), dtype=np.uint32); n_ops = np.zeros(n, dtype=np.int32)
+    ed = np.zeros(n, dtype=np.int32); afc = np.zeros(n, dtype=np.int32); after = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        no, e, a, x = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int64(0)
+        rc = lib.oracle_compute_cigar_lv(C.byref(g), C.c_void_p(data.ctypes.data + int(off[i])), C.c_int64(int(length[i])),
+                                         C.c_int64(int(extra_before[i])), C.c_int64(int(loc[i])), C.c_int(1 if use_m else 0),
+                                         C.c_void_p(ops[i].ctypes.data), C.c_int(ops_stride), C.byref(no), C.byref(e), C.byref(a), C.byref(x))
+        assert rc == 0
+        n_ops[i], ed[i], afc[i], after[i] = no.value, e.value, a.value, x.value
+    return dict(ops=ops, n_ops=n_ops, edit_distance=ed, add_front_clipping=afc, extra_clipped_after=after)
+
+
+CIGAR_CODES = "MIDNSHP=X"
+
+
+def cigar_text(ops, n_ops):
+    """BAMAlignment::decodeCigar (Bam.cpp:350-376): "%u%c" per op; "*" for n_ops < 0."""
+    if n_ops < 0:
+        return "*"
+    return "".join("%d%s" % (int(o) >> 4, CIGAR_CODES[int(o) & 15]) for o in ops[:n_ops])
+
+
 # fields of a secondary result the reference never writes (BaseAligner.cpp:2182-2199); both sides hold 0
 UNSET_IN_SECONDARY = ("probability_all_candidates", "popular_seeds_skipped", "reserved")
 
