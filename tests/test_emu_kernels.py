@@ -141,3 +141,14 @@ def test_emu_paired_end(emu):
     bad = compare_paired(z[key + "_primary"][:n], prim, verbose=3, exclude=z[key + "_unstable"][:n])
     assert not bad.any()
     assert (alt["status"] == z[key + "_alt"]["status"][:n]).all()
+
+
+@pytest.mark.parametrize("seed_len,large", [(24, False), (22, True)])
+def test_emu_other_index_shapes(emu, tmp_path, seed_len, large):
+    """Key bytes 5, `-large` entries, 16 hash tables: the probe takes other paths than with the north star's -s 20 index.
+    600 fresh reads against the compiled reference, work counters included."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.test_zz_gpu_index_shapes import align_and_compare
+    align_and_compare(str(tmp_path), seed_len, large, 600)

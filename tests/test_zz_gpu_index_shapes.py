@@ -1,0 +1,51 @@
+"""Index shapes other than the north star's (-s 20, small hash tables): longer seeds (key bytes 5 and 7), `-large` hash tables
+(one entry serves both strands), 16 instead of 256 tables -- SNAPHashTable / lookupSeed32 take a different path for each
+(GenomeIndex.cpp:2096-2202, HashTable.h:72-118).  Against the compiled reference on a fresh genome, work counters included.
+
+Written in a round that had no GPU time left: verified on the wavefront emulator (tests/test_emu_kernels.py), not yet on
+hardware -- hence the file name, which puts it at the end of the `-m gpu` run."""
+import os
+
+import numpy as np
+import pytest
+
+from snap_amd import abi, synth
+from tests import util
+from oracle import ref
+
+SHAPES = [(24, False), (20, True), (22, True), (32, False)]
+
+
+def align_and_compare(tmp, seed_len, large, n_reads, genome_bases=400_000):
+    from snap_amd.aligner import BaseAligner
+    from snap_amd.index import GenomeIndex
+    g = synth.make_genome(91, genome_bases, n_contigs=2, repeat_frac=0.4, max_copies=100, n_run_frac=0.002)
+    fa = os.path.join(tmp, "ref.fa"); synth.write_fasta(fa, g)
+    d = os.path.join(tmp, "idx")
+    ref.build_index(fa, d, seed_len, threads=max(1, min(8, os.cpu_count() or 1)), large=large)
+    ix = GenomeIndex.load_from_directory(d)
+    assert ix.seed_len == seed_len and ix.large == large
+    ri = ref.RefIndex(d)
+    p = abi.default_params(max_read_len=160, max_k=8)
+    rd = synth.make_reads(5, g, n_reads, 150, sub=0.015, ins=0.002, dele=0.002, n_frac=0.0005)
+    pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
+    a = BaseAligner(ix, p)
+    try:
+        pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"])
+        c = a.counters()
+    finally:
+        a.close()
+    flagged = pg["reserved"] != 0
+    assert flagged.sum() <= 2 + 0.005 * len(pg)
+    assert (pr["status"] != 0).sum() > 0.9 * n_reads
+    problems = util.compare_results(pr, pg, exclude=flagged)
+    assert not problems, problems
+    if not flagged.any():
+        assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == [cr["lookups"], cr["lv"], cr["ag"]]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+@pytest.mark.parametrize("seed_len,large", SHAPES)
+def test_index_shapes_vs_live_reference(tmp_path, seed_len, large):
+    align_and_compare(str(tmp_path), seed_len, large, 20000, genome_bases=2_000_000)
