@@ -20,6 +20,9 @@
  *   snapgpu_compute_cigar_lv
  *       SAMFormat::computeCigar (LV variant)    SNAPLib/SAM.cpp:2354-2467
  *       LandauVishkinWithCigar::computeEditDistanceNormalized / computeEditDistance  SNAPLib/LandauVishkin.cpp:507-648 / 141-505
+ *   snapgpu_compute_cigar_ag
+ *       SAMFormat::computeCigar (affine-gap variant)  SNAPLib/SAM.cpp:2470-2588
+ *       AffineGapVectorizedWithCigar::computeGlobalScoreNormalized / Banded / computeGlobalScore  SNAPLib/AffineGapVectorized.cpp:1043 / 520 / 159
  *   snapgpu_affine_gap
  *       AffineGapVectorized<1|-1>::computeScore / computeScoreBanded
  *                                               SNAPLib/AffineGapVectorized.h:821-1339 / 256-819
@@ -313,6 +316,26 @@ int  snapgpu_compute_cigar_lv(snapgpu_ctx *ctx, uint32_t n, const char *data, ui
                               const int32_t *len, const int64_t *loc, const int32_t *extra_before, int use_m,
                               uint32_t *ops, uint32_t ops_stride, int32_t *n_ops, int32_t *edit_distance,
                               int32_t *add_front_clipping, int64_t *extra_clipped_after);
+
+/*
+ * The CIGAR of a read that was scored with affine gap: SAMFormat::computeCigar, affine-gap variant (SNAPLib/SAM.cpp:2470-2588),
+ * over AffineGapVectorizedWithCigar::computeGlobalScoreNormalized (SNAPLib/AffineGapVectorized.cpp:1043-1128: the banded global
+ * alignment when patternLen >= 3 (2k + 1), the full one otherwise or when the band failed) -- what SAMFormat::writePairs /
+ * writeReads run for a read with usedAffineGapScoring or score > 0 (SAM.cpp:1653, :2200).  Scoring parameters are the context's
+ * (snapgpu_params: match / substitution / gap open / gap extend).  Inputs as snapgpu_compute_cigar_lv plus quals (the clipped
+ * read's qualities, same offsets; indexed from the clipped read's first base even when extra_before[i] > 0, as the reference
+ * does) and score[i] = the alignment's edit distance (SingleAlignmentResult::score), the k of the band.
+ * Additional outputs:
+ *   back_clipping_missed[i]          bases of a tail insertion that the caller soft-clips (computeCigarString, SAM.cpp:2725-2727)
+ *   reference_history_dependent[i]   1: the banded traceback stepped through a cell this call did not evaluate; the reference
+ *                                    reads there what an earlier call left in its object (AffineGapVectorized.cpp:811 over
+ *                                    AffineGapVectorized.h:1441), this library reads 0
+ */
+int  snapgpu_compute_cigar_ag(snapgpu_ctx *ctx, uint32_t n, const char *data, const char *quals, uint64_t data_bytes,
+                              const uint64_t *off, const int32_t *len, const int64_t *loc, const int32_t *extra_before,
+                              const int32_t *score, int use_m, uint32_t *ops, uint32_t ops_stride, int32_t *n_ops,
+                              int32_t *edit_distance, int32_t *add_front_clipping, int64_t *extra_clipped_after,
+                              int32_t *back_clipping_missed, int32_t *reference_history_dependent);
 
 /*
  * Batched AffineGapVectorized<dir>::computeScore (banded[i] == 0) / computeScoreBanded

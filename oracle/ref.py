@@ -88,6 +88,23 @@ class RefIndex:
             raise RuntimeError("snapref_compute_cigar_lv rc=%d" % rc)
         return dict(ops=ops, n_ops=n_ops, edit_distance=ed, add_front_clipping=afc, extra_clipped_after=after)
 
+    def compute_cigar_ag(self, data, quals, off, length, loc, extra_before, score, use_m: bool, fresh_object: bool = False,
+                         ops_stride: int = 64, agparams=(1, 4, 6, 1)):
+        """SAMFormat::computeCigar (affine-gap variant, BAM_CIGAR_OPS) for a batch; see snapref_compute_cigar_ag."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1); quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(off, dtype=np.uint64); length = np.ascontiguousarray(length, dtype=np.int32)
+        loc = np.ascontiguousarray(loc, dtype=np.int64); extra_before = np.ascontiguousarray(extra_before, dtype=np.int32)
+        score = np.ascontiguousarray(score, dtype=np.int32); agp = np.array(agparams, dtype=np.int32)
+        n = off.size
+        ops = np.zeros((n, ops_stride), dtype=np.uint32); n_ops = np.zeros(n, dtype=np.int32)
+        ed = np.zeros(n, dtype=np.int32); afc = np.zeros(n, dtype=np.int32); after = np.zeros(n, dtype=np.int64); tail = np.zeros(n, dtype=np.int32)
+        rc = lib().snapref_compute_cigar_ag(self.handle, ptr(agp), C.c_uint32(n), ptr(data), ptr(quals), ptr(off), ptr(length), ptr(loc),
+                                            ptr(extra_before), ptr(score), C.c_int(1 if use_m else 0), C.c_int(1 if fresh_object else 0),
+                                            ptr(ops), C.c_uint32(ops_stride), ptr(n_ops), ptr(ed), ptr(afc), ptr(after), ptr(tail))
+        if rc != 0:
+            raise RuntimeError("snapref_compute_cigar_ag rc=%d" % rc)
+        return dict(ops=ops, n_ops=n_ops, edit_distance=ed, add_front_clipping=afc, extra_clipped_after=after, back_clipping_missed=tail)
+
     def align_single(self, params: Params, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray,
                      threads: int = 1):
         """BaseAligner::AlignRead over a batch; returns (primary, first_alt, counters, seconds)."""

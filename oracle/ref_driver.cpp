@@ -40,6 +40,7 @@
 #include <stdlib.h>
 #include <time.h>
 #include <vector>
+#include <new>
 
 #include "../include/snapgpu.h"
 
@@ -380,6 +381,38 @@ int snapref_lv_cigar(const char *text, int text_len, const char *pattern, int pa
     if (lvc == NULL) lvc = new LandauVishkinWithCigar();
     int used = 0;
     return lvc->computeEditDistance(text, text_len, pattern, pattern_len, k, cigar, cigar_cap, use_m != 0, COMPACT_CIGAR_STRING, &used, text_used, net_indel);
+}
+
+/* SAMFormat::computeCigar, affine-gap variant (SAM.cpp:2470-2588), BAM_CIGAR_OPS output, for a batch.  agparams = match, sub, open,
+ * extend as given to AffineGapVectorizedWithCigar's constructor.  fresh_object != 0: a new, zero-filled object per item (the answer
+ * is then a function of the item alone); otherwise one object serves the whole batch, as one SAM writer thread's does. */
+int snapref_compute_cigar_ag(void *vindex, const int32_t *agparams, uint32_t n, const char *data, const char *quals, const uint64_t *off,
+                             const int32_t *len, const int64_t *loc, const int32_t *extra_before, const int32_t *score, int use_m,
+                             int fresh_object, uint32_t *ops, uint32_t ops_stride, int32_t *n_ops, int32_t *edit_distance,
+                             int32_t *add_front_clipping, int64_t *extra_after, int32_t *tail_ins)
+{
+    GenomeIndex *index = (GenomeIndex *)vindex;
+    const Genome *genome = index->getGenome();
+    AffineGapVectorizedWithCigar *agc = NULL;
+    void *mem = NULL;
+    for (uint32_t i = 0; i < n; i++) {
+        if (agc == NULL || fresh_object) {
+            if (agc) { agc->~AffineGapVectorizedWithCigar(); free(mem); }
+            mem = calloc(1, sizeof(AffineGapVectorizedWithCigar) + 64);
+            void *al = (void *)(((uintptr_t)mem + 15) & ~(uintptr_t)15);
+            agc = new (al) AffineGapVectorizedWithCigar(agparams[0], agparams[1], agparams[2], agparams[3]);
+        }
+        char *buf = (char *)(ops + (size_t)i * ops_stride);
+        int used = 0, afc = 0, ed = 0, tail = 0;
+        GenomeDistance after = 0;
+        buf[0] = 0;
+        SAMFormat::computeCigar(BAM_CIGAR_OPS, genome, agc, buf, (int)(ops_stride * 4), data + off[i], quals + off[i], (GenomeDistance)len[i], score[i], 0,
+                                (GenomeDistance)extra_before[i], 0, &after, GenomeLocation(loc[i]), use_m != 0, &ed, &used, &afc, &tail);
+        n_ops[i] = (used == 0 && buf[0] == '*') ? -1 : used / 4;
+        edit_distance[i] = ed; add_front_clipping[i] = afc; extra_after[i] = (int64_t)after; tail_ins[i] = tail;
+    }
+    if (agc) { agc->~AffineGapVectorizedWithCigar(); free(mem); }
+    return 0;
 }
 
 /* SAMFormat::computeCigar, Landau-Vishkin variant (SAM.cpp:2354-2467), BAM_CIGAR_OPS output, for a batch: item i is the clipped read

@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
     "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
     "snapgpu_align_paired_secondary", "snapgpu_align_paired_secondary_device",
-    "snapgpu_compute_cigar_lv",
+    "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag",
 ]
 
 
@@ -202,6 +202,25 @@ class BaseAligner:
             C.c_int(1 if use_m else 0), ptr(ops), C.c_uint32(ops_stride), ptr(n_ops), ptr(ed), ptr(afc), ptr(after)),
             "snapgpu_compute_cigar_lv")
         return dict(ops=ops, n_ops=n_ops, edit_distance=ed, add_front_clipping=afc, extra_clipped_after=after)
+
+    def computeCigarAffineGap(self, data, quals, off, length, loc, extra_before, score, use_m: bool = False, ops_stride: int = 64):
+        """SAM.cpp:2470-2588 (the CIGAR of a read scored with affine gap) for a batch; see snapgpu_compute_cigar_ag.  score = the
+        alignment's edit distance.  Returns the fields of computeCigar plus back_clipping_missed and stale (the reference's answer
+        for that item depends on what its object computed before)."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(off, dtype=np.uint64); length = np.ascontiguousarray(length, dtype=np.int32)
+        loc = np.ascontiguousarray(loc, dtype=np.int64); extra_before = np.ascontiguousarray(extra_before, dtype=np.int32)
+        score = np.ascontiguousarray(score, dtype=np.int32)
+        n = off.size
+        ops = np.zeros((n, ops_stride), dtype=np.uint32); n_ops = np.zeros(n, np.int32); ed = np.zeros(n, np.int32)
+        afc = np.zeros(n, np.int32); after = np.zeros(n, np.int64); tail = np.zeros(n, np.int32); stale = np.zeros(n, np.int32)
+        self._check(self.lib.snapgpu_compute_cigar_ag(
+            self.handle, C.c_uint32(n), ptr(data), ptr(quals), C.c_uint64(data.size), ptr(off), ptr(length), ptr(loc), ptr(extra_before),
+            ptr(score), C.c_int(1 if use_m else 0), ptr(ops), C.c_uint32(ops_stride), ptr(n_ops), ptr(ed), ptr(afc), ptr(after),
+            ptr(tail), ptr(stale)), "snapgpu_compute_cigar_ag")
+        return dict(ops=ops, n_ops=n_ops, edit_distance=ed, add_front_clipping=afc, extra_clipped_after=after,
+                    back_clipping_missed=tail, stale=stale)
 
     # ---- BaseAligner::AlignRead over a batch -------------------------------------------
     def AlignRead(self, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray):

@@ -2,6 +2,8 @@
 #pragma once
 #include "dev_common.h"
 
+struct AGCParamsPOD { int match, sub, gap_open, gap_ext; };
+
 struct CigarArgs {
     DevIndex ix;
     uint32_t n, RL, ops_stride, use_m;
@@ -11,4 +13,16 @@ struct CigarArgs {
     uint32_t *ops; int32_t *n_ops; int32_t *edit_distance; int32_t *add_front_clipping; int64_t *extra_after;
 };
 
+struct CigarAGArgs {
+    DevIndex ix;
+    AGCParamsPOD prm;
+    uint32_t n, RL, ops_stride, use_m;
+    const uint8_t *data; const uint8_t *quals; const uint64_t *off; const int32_t *len; const int64_t *loc; const int32_t *extra_before;
+    const int32_t *score;             // the alignment's edit distance: k of computeGlobalScoreNormalized
+    uint8_t *scratch; uint64_t scratch_stride;
+    uint32_t *work_counter;
+    uint32_t *ops; int32_t *n_ops; int32_t *edit_distance; int32_t *add_front_clipping; int64_t *extra_after; int32_t *tail_ins; int32_t *stale;
+};
+
+extern "C" void snapgpu_launch_cigar_ag(const CigarAGArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 extern "C" void snapgpu_launch_cigar_lv(const CigarArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);

@@ -3,6 +3,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -c cigar_k.hip
 #include <hip/hip_runtime.h>
 #include "cigar_lv.h"
+#include "cigar_ag.h"
 #include "cigar_args.h"
 
 __global__ __launch_bounds__(256) void k_cigar_lv(CigarArgs a)
@@ -37,4 +38,39 @@ __global__ __launch_bounds__(256) void k_cigar_lv(CigarArgs a)
 extern "C" void snapgpu_launch_cigar_lv(const CigarArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
 {
     hipLaunchKernelGGL(k_cigar_lv, dim3(blocks), dim3(256), lds_bytes, s, *a);
+}
+
+// SAMFormat::computeCigar, affine-gap variant: one wavefront per read (cigar_ag.h)
+__global__ __launch_bounds__(256) void k_cigar_ag(CigarAGArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
+    uint8_t *my = lds + (size_t)wave_in_block * agc_lds_bytes(a.RL);
+    uint8_t *scratch = a.scratch + (size_t)wave_slot * a.scratch_stride;
+    AGCParams prm; prm.match = a.prm.match; prm.sub = a.prm.sub; prm.gap_open = a.prm.gap_open; prm.gap_ext = a.prm.gap_ext;
+    while (true) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
+        i = first_u32(i);
+        if (i >= a.n) break;
+        const uint64_t off = first_u64(a.off[i]);
+        const long long len = (long long)(int)first_u32((uint32_t)a.len[i]);
+        const long long loc = (long long)first_u64((uint64_t)a.loc[i]);
+        const long long xb = (long long)(int)first_u32((uint32_t)a.extra_before[i]);
+        const int k = (int)first_u32((uint32_t)a.score[i]);
+        uint32_t *ops = a.ops + (size_t)i * a.ops_stride;
+        const CigarAGItemOut o = cigar_ag_item(a.ix, prm, a.data + off, a.quals + off, len, k, xb, loc, a.use_m != 0, my, a.RL, scratch, ops, (int)a.ops_stride);
+        if (lane == 0) {
+            a.n_ops[i] = o.n_ops; a.edit_distance[i] = o.edit_distance; a.add_front_clipping[i] = o.add_front_clipping;
+            a.extra_after[i] = o.extra_after; a.tail_ins[i] = o.tail_ins; a.stale[i] = o.stale;
+        }
+        WAVE_SYNC();
+    }
+}
+
+extern "C" void snapgpu_launch_cigar_ag(const CigarAGArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cigar_ag, dim3(blocks), dim3(256), lds_bytes, s, *a);
 }

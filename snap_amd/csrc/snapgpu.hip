@@ -23,6 +23,7 @@
 #include "single_kernel.h"
 #include "paired_args.h"
 #include "cigar_lv.h"
+#include "cigar_ag.h"
 #include "cigar_args.h"
 
 // =====================================================================================
@@ -750,6 +751,77 @@ extern "C" int snapgpu_compute_cigar_lv(snapgpu_ctx *ctx, uint32_t n, const char
     HIPCHK(ctx, hipMemcpyAsync(edit_distance, ded.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(add_front_clipping, dafc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(extra_clipped_after, dxa.p, (size_t)n * 8, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
+// SAMFormat::computeCigar, affine-gap variant, for a batch of written reads (cigar_ag.h, cigar_k.hip).
+extern "C" int snapgpu_compute_cigar_ag(snapgpu_ctx *ctx, uint32_t n, const char *data, const char *quals, uint64_t data_bytes,
+                                        const uint64_t *off, const int32_t *len, const int64_t *loc, const int32_t *extra_before,
+                                        const int32_t *score, int use_m, uint32_t *ops, uint32_t ops_stride, int32_t *n_ops,
+                                        int32_t *edit_distance, int32_t *add_front_clipping, int64_t *extra_clipped_after,
+                                        int32_t *back_clipping_missed, int32_t *reference_history_dependent)
+{
+    if (!ctx || (n && (!data || !quals || !off || !len || !loc || !extra_before || !score || !ops || !n_ops || !edit_distance ||
+                       !add_front_clipping || !extra_clipped_after || !back_clipping_missed || !reference_history_dependent)))
+        return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_compute_cigar_ag: null argument");
+    if (ops_stride == 0) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_compute_cigar_ag: ops_stride must be positive");
+    if (n == 0) return SNAPGPU_OK;
+    uint32_t RL = 64;
+    for (uint32_t i = 0; i < n; i++) {
+        if (len[i] < 0 || len[i] > AGC_MAX_READ_LENGTH) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_compute_cigar_ag: read length out of range");
+        if (extra_before[i] < 0 || extra_before[i] > len[i]) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_compute_cigar_ag: extra_before out of range");
+        if (off[i] + (uint64_t)len[i] > data_bytes) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_compute_cigar_ag: read outside the data buffer");
+        if (loc[i] < 0 || (uint64_t)loc[i] >= ctx->ix.n_bases) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_compute_cigar_ag: location outside the genome");
+        if (score[i] < 0) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_compute_cigar_ag: negative score");
+        if ((uint32_t)len[i] > RL) RL = (uint32_t)len[i];
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = ctx->stream;
+    const uint32_t per_wave = agc_lds_bytes(RL);
+    uint32_t waves_per_block = 4;
+    if ((size_t)waves_per_block * per_wave > 64 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "snapgpu_compute_cigar_ag: reads too long for the LDS rows");
+    uint32_t blocks = (uint32_t)ctx->num_cus * 4;
+    const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
+    const uint64_t scratch_stride = (agc_scratch_bytes(RL) + 255) & ~(uint64_t)255;
+    DevBuf dd, dq, doff, dlen, dloc, dxb, dsc, dscr, dops, dno, ded, dafc, dxa, dti, dst;
+    HIPCHK(ctx, dd.put(data, data_bytes, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dq.put(quals, data_bytes, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, doff.put(off, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dlen.put(len, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dloc.put(loc, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dxb.put(extra_before, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dsc.put(score, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dscr.put(nullptr, (size_t)blocks * 4 * scratch_stride, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dops.put(nullptr, (size_t)n * ops_stride * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dno.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, ded.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dafc.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dxa.put(nullptr, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dti.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dst.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, hipMemsetAsync(dops.p, 0, (size_t)n * ops_stride * 4, s), SNAPGPU_E_LAUNCH);
+    CigarAGArgs a;
+    a.ix = ctx->ix;
+    // AffineGapVectorizedWithCigar's constructor (AffineGapVectorized.cpp:15-23): subPenalty negated, gapOpen = open + extend
+    a.prm.match = (int)ctx->params.match_reward; a.prm.sub = -(int)ctx->params.sub_penalty;
+    a.prm.gap_open = (int)ctx->params.gap_open_penalty + (int)ctx->params.gap_extend_penalty; a.prm.gap_ext = (int)ctx->params.gap_extend_penalty;
+    a.n = n; a.RL = RL; a.ops_stride = ops_stride; a.use_m = use_m ? 1u : 0u;
+    a.data = (const uint8_t *)dd.p; a.quals = (const uint8_t *)dq.p; a.off = (const uint64_t *)doff.p; a.len = (const int32_t *)dlen.p;
+    a.loc = (const int64_t *)dloc.p; a.extra_before = (const int32_t *)dxb.p; a.score = (const int32_t *)dsc.p;
+    a.scratch = (uint8_t *)dscr.p; a.scratch_stride = scratch_stride; a.work_counter = ctx->d_work;
+    a.ops = (uint32_t *)dops.p; a.n_ops = (int32_t *)dno.p; a.edit_distance = (int32_t *)ded.p; a.add_front_clipping = (int32_t *)dafc.p;
+    a.extra_after = (int64_t *)dxa.p; a.tail_ins = (int32_t *)dti.p; a.stale = (int32_t *)dst.p;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    snapgpu_launch_cigar_ag(&a, blocks, (size_t)waves_per_block * per_wave, s);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ops, dops.p, (size_t)n * ops_stride * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(n_ops, dno.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(edit_distance, ded.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(add_front_clipping, dafc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(extra_clipped_after, dxa.p, (size_t)n * 8, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(back_clipping_missed, dti.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(reference_history_dependent, dst.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
     return SNAPGPU_OK;
 }

@@ -152,3 +152,12 @@ def test_emu_other_index_shapes(emu, tmp_path, seed_len, large):
         pytest.skip("oracle/_ref not built here")
     from tests.test_zz_gpu_index_shapes import align_and_compare
     align_and_compare(str(tmp_path), seed_len, large, 600)
+
+
+def test_emu_compute_cigar_affine_gap(emu, emu_aligner):
+    """SAMFormat::computeCigar, affine-gap variant (banded and full global alignment with traceback), on the emulated device: every
+    third item of the reference fixture (tests/golden/cigar_ag.npz), both op alphabets."""
+    import tests.test_zz_gpu_cigar as gc
+    z = np.load(os.path.join(util.GOLDEN, "cigar_ag.npz"))
+    for use_m in (0, 1):
+        gc.check_ag_against_fixture(emu_aligner, z, use_m, step=3)

@@ -112,3 +112,97 @@ def test_compute_cigar_argument_errors(cig_aligner, golden_index):
         one(xb=[101])
     r = cig_aligner.computeCigar(d, [0], [100], [2000], [0], ops_stride=2)      # far too few op slots: the reference's -2
     assert int(r["edit_distance"][0]) in (-2, -1) or int(r["n_ops"][0]) <= 2
+
+
+# ---------------------------------------------------------------------------------------------- affine-gap variant
+AG_KEYS = ("n_ops", "edit_distance", "add_front_clipping", "extra_clipped_after", "back_clipping_missed")
+
+
+def check_ag_against_fixture(aligner, z, use_m, step=1):
+    """Device == a fresh reference object (the answer that is a function of the item alone); every item the reference answers
+    differently depending on its object's history must be flagged by the device."""
+    sel = slice(0, None, step)
+    got = aligner.computeCigarAffineGap(z["data"], z["quals"], z["off"][sel], z["length"][sel], z["loc"][sel], z["extra_before"][sel],
+                                        z["score"][sel], bool(use_m), ops_stride=256)
+    pre = "m%d_" % use_m
+    for k in AG_KEYS:
+        bad = np.nonzero(got[k] != z[pre + k][sel])[0]
+        assert bad.size == 0, (k, bad[:5], got[k][bad[:5]], z[pre + k][sel][bad[:5]])
+    exp_ops, exp_n = z[pre + "ops"][sel], z[pre + "n_ops"][sel]
+    for i in range(len(exp_n)):
+        assert util.cigar_text(got["ops"][i], got["n_ops"][i]) == util.cigar_text(exp_ops[i], exp_n[i]), i
+    assert not (z[pre + "unstable"][sel] & (got["stale"] == 0)).any(), "history-dependent item not flagged"
+    return got
+
+
+@pytest.fixture(scope="module")
+def golden_cigar_ag():
+    import os
+    return np.load(os.path.join(util.GOLDEN, "cigar_ag.npz"))
+
+
+@pytest.mark.parametrize("use_m", [0, 1])
+def test_compute_cigar_ag_vs_reference_fixture(cig_aligner, golden_cigar_ag, use_m):
+    z = golden_cigar_ag
+    got = check_ag_against_fixture(cig_aligner, z, use_m)
+    # query-consuming ops never exceed the bases that were aligned (a tail insertion is left to the caller to soft-clip)
+    for i in range(len(z["off"])):
+        n = int(got["n_ops"][i])
+        if n <= 0:
+            continue
+        ops = got["ops"][i, :n]; codes, counts = ops & 15, ops >> 4
+        q = int(counts[np.isin(codes, (0, 1, 7, 8))].sum())
+        assert q <= int(z["length"][i]) - int(z["extra_before"][i]) - int(got["extra_clipped_after"][i]), i
+        assert (counts > 0).all()
+
+
+def test_compute_cigar_ag_vs_live_reference(cig_aligner, golden_index, tmp_path):
+    """Fresh reads with indels against the compiled reference (a fresh AffineGapVectorizedWithCigar per item), where oracle/_ref
+    is on the box: needs the index directory, which is rebuilt here from the golden genome."""
+    import os
+    from oracle import ref
+    from snap_amd import synth
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not on this box")
+    ix = golden_index
+    pad = (ix.genome_padded.size - ix.n_bases) // 2
+    G = ix.genome_padded[pad:]
+    cb = [int(x) for x in ix.contig_begin] + [int(ix.n_bases)]
+    contigs = [(c.name, G[cb[i]:cb[i + 1] - (ix.chromosome_padding if i + 1 < len(cb) - 1 or True else 0)].copy()) for i, c in enumerate(ix.contigs)]
+    # strip the padding the index added after each contig: bases are ACGTN, padding is 'n'
+    contigs = [(n, s[:int(np.nonzero(s != ord('n'))[0][-1]) + 1]) for n, s in contigs]
+    fa = str(tmp_path / "ref.fa"); synth.write_fasta(fa, contigs)
+    alt = [c.name for c in ix.contigs if c.is_alt]
+    ref.build_index(fa, str(tmp_path / "idx"), ix.seed_len, threads=4, extra=sum((["-altContigName", a] for a in alt), []))
+    from snap_amd.index import GenomeIndex
+    ix2 = GenomeIndex.load_from_directory(str(tmp_path / "idx"))
+    assert (ix2.contig_begin == ix.contig_begin).all() and (ix2.genome_padded == ix.genome_padded).all()
+    ri = ref.RefIndex(str(tmp_path / "idx"))
+    rng = np.random.default_rng(123)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    items, quals, locs, ks = [], [], [], []
+    while len(items) < 4000:
+        c = int(rng.integers(0, len(cb) - 1)); L = int(rng.choice([100, 150, 250]))
+        lo, hi = cb[c], cb[c + 1] - ix.chromosome_padding - L - 20
+        if hi <= lo:
+            continue
+        p = int(rng.integers(lo, hi))
+        r = list(G[p:p + L + 16]); ne = int(rng.integers(0, 10))
+        for _ in range(ne):
+            j = int(rng.integers(0, L)); t = rng.random()
+            if t < 0.5: r[j] = int(acgt[rng.integers(0, 4)])
+            elif t < 0.75: del r[j]
+            else: r.insert(j, int(acgt[rng.integers(0, 4)]))
+        items.append(bytes(r[:L])); quals.append(rng.integers(35, 74, size=L).astype(np.uint8).tobytes())
+        locs.append(p + (int(rng.integers(-3, 4)) if rng.random() < 0.3 else 0)); ks.append(ne + int(rng.integers(0, 3)))
+    data = np.frombuffer(b"".join(items), dtype=np.uint8); q = np.frombuffer(b"".join(quals), dtype=np.uint8)
+    length = np.array([len(x) for x in items], dtype=np.int32)
+    off = np.zeros(len(items), dtype=np.uint64); off[1:] = np.cumsum(length)[:-1]
+    loc = np.array(locs, dtype=np.int64); xb = np.zeros(len(items), dtype=np.int32); k = np.array(ks, dtype=np.int32)
+    for use_m in (False, True):
+        exp = ri.compute_cigar_ag(data, q, off, length, loc, xb, k, use_m, fresh_object=True, ops_stride=128)
+        got = cig_aligner.computeCigarAffineGap(data, q, off, length, loc, xb, k, use_m, ops_stride=128)
+        for key in AG_KEYS:
+            assert (got[key] == exp[key]).all(), key
+        for i in range(len(items)):
+            assert util.cigar_text(got["ops"][i], got["n_ops"][i]) == util.cigar_text(exp["ops"][i], exp["n_ops"][i]), i
