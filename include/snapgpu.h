@@ -20,6 +20,9 @@
  *   snapgpu_compute_cigar_lv
  *       SAMFormat::computeCigar (LV variant)    SNAPLib/SAM.cpp:2354-2467
  *       LandauVishkinWithCigar::computeEditDistanceNormalized / computeEditDistance  SNAPLib/LandauVishkin.cpp:507-648 / 141-505
+ *   snapgpu_sam_fields_single
+ *       SimpleReadWriter::writeReads            SNAPLib/ReadWriter.cpp:170-330
+ *       SAMFormat::writeRead / createSAMLine / computeCigarString  SNAPLib/SAM.cpp:1898-2352 / 1424-1572 / 2595-2766
  *   snapgpu_compute_cigar_ag
  *       SAMFormat::computeCigar (affine-gap variant)  SNAPLib/SAM.cpp:2470-2588
  *       AffineGapVectorizedWithCigar::computeGlobalScoreNormalized / Banded / computeGlobalScore  SNAPLib/AffineGapVectorized.cpp:1043 / 520 / 159
@@ -336,6 +339,25 @@ int  snapgpu_compute_cigar_ag(snapgpu_ctx *ctx, uint32_t n, const char *data, co
                               const int32_t *score, int use_m, uint32_t *ops, uint32_t ops_stride, int32_t *n_ops,
                               int32_t *edit_distance, int32_t *add_front_clipping, int64_t *extra_clipped_after,
                               int32_t *back_clipping_missed, int32_t *reference_history_dependent);
+
+/*
+ * From alignment results to the computed fields of their SAM records, on the device: for the primary
+ * result of each single-end read, what SimpleReadWriter::writeReads (SNAPLib/ReadWriter.cpp:170-330) and SAMFormat::writeRead
+ * (SNAPLib/SAM.cpp:1898-2352; createSAMLine :1424-1572, computeCigarString :2595-2766) compute before they print: orientation,
+ * clipping bookkeeping, contig and position (Genome::getContigForRead), the CIGAR through the Landau-Vishkin or the affine-gap
+ * variant (use_affine_gap of the context && (usedAffineGapScoring || score > 0), ReadWriter.cpp:232), the retry loop around a
+ * leading indel (move the alignment / soft-clip the read / give the read up across a contig boundary), the soft clips around the
+ * cigar and NM.  Printing names, sequence and tags stays with the caller.
+ * Inputs: the reads as they came from the file (bases, quals, offsets[n + 1]), Read::clip's outcome for each (front_clip[i] bases
+ * clipped in front, data_len[i] bases kept: what BaseAligner::AlignRead was given), and its result.
+ * Outputs per read: flag (0x4 unmapped, 0x10 reverse strand), contig (index into the index's contig table, -1 unmapped), pos
+ * (1-based, 0 unmapped), mapq, ops / n_ops (BAM cigar ops incl. S = 4; n_ops = -1: "*"), nm (NM:i, -1 unmapped),
+ * reference_history_dependent (see snapgpu_compute_cigar_ag).
+ */
+int  snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, const char *quals, const uint64_t *offsets,
+                               const int32_t *front_clip, const int32_t *data_len, const snapgpu_single_result *results, int use_m,
+                               int32_t *flag, int32_t *contig, int64_t *pos, int32_t *mapq, uint32_t *ops, uint32_t ops_stride,
+                               int32_t *n_ops, int32_t *nm, int32_t *reference_history_dependent);
 
 /*
  * Batched AffineGapVectorized<dir>::computeScore (banded[i] == 0) / computeScoreBanded

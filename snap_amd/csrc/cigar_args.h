@@ -1,6 +1,7 @@
 // cigar_args.h -- kernel arguments of k_cigar_lv (cigar_k.hip), shared with the host side (snapgpu.hip).
 #pragma once
 #include "dev_common.h"
+#include "../../include/snapgpu.h"
 
 struct AGCParamsPOD { int match, sub, gap_open, gap_ext; };
 
@@ -24,5 +25,18 @@ struct CigarAGArgs {
     uint32_t *ops; int32_t *n_ops; int32_t *edit_distance; int32_t *add_front_clipping; int64_t *extra_after; int32_t *tail_ins; int32_t *stale;
 };
 
+struct SamFieldsArgs {
+    DevIndex ix;
+    AGCParamsPOD prm;
+    uint32_t n, RL, ops_stride, use_m, use_affine_gap;
+    const uint8_t *bases; const uint8_t *quals; const uint64_t *offsets;       // the reads as they came from the file (unclipped)
+    const int32_t *front_clip; const int32_t *data_len;                          // Read::clip's result: bases clipped in front, bases kept
+    const snapgpu_single_result *results;
+    uint8_t *scratch; uint64_t scratch_stride;
+    uint32_t *work_counter;
+    int32_t *flag; int32_t *contig; int64_t *pos; int32_t *mapq; uint32_t *ops; int32_t *n_ops; int32_t *nm; int32_t *stale;
+};
+
+extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 extern "C" void snapgpu_launch_cigar_ag(const CigarAGArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 extern "C" void snapgpu_launch_cigar_lv(const CigarArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);

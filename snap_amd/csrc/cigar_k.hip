@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include "cigar_lv.h"
 #include "cigar_ag.h"
+#include "sam_fields.h"
 #include "cigar_args.h"
 
 __global__ __launch_bounds__(256) void k_cigar_lv(CigarArgs a)
@@ -73,4 +74,47 @@ __global__ __launch_bounds__(256) void k_cigar_ag(CigarAGArgs a)
 extern "C" void snapgpu_launch_cigar_ag(const CigarAGArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
 {
     hipLaunchKernelGGL(k_cigar_ag, dim3(blocks), dim3(256), lds_bytes, s, *a);
+}
+
+// result -> computed fields of the SAM record (sam_fields.h): one wavefront per read
+__global__ __launch_bounds__(256) void k_sam_fields(SamFieldsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
+    uint8_t *my = lds + (size_t)wave_in_block * agc_lds_bytes(a.RL);
+    uint8_t *scratch = a.scratch + (size_t)wave_slot * a.scratch_stride;
+    uint8_t *oriented = scratch;                                                      // 2 * RL bytes
+    uint32_t *lv_cells = (uint32_t *)(scratch + ((2 * a.RL + 255) & ~255u));
+    uint8_t *ag_scratch = (uint8_t *)lv_cells + ((lvc_scratch_bytes() + 255) & ~255u);
+    AGCParams prm; prm.match = a.prm.match; prm.sub = a.prm.sub; prm.gap_open = a.prm.gap_open; prm.gap_ext = a.prm.gap_ext;
+    while (true) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
+        i = first_u32(i);
+        if (i >= a.n) break;
+        const uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
+        snapgpu_single_result r;
+        {   // the result record, one dword per lane, then lane reads (22 dwords)
+            const uint32_t *src = (const uint32_t *)&a.results[i];
+            uint32_t *dst = (uint32_t *)&r;
+            const int nd = (int)(sizeof(snapgpu_single_result) / 4);
+            const uint32_t w = lane < nd ? src[lane] : 0u;
+            for (int k = 0; k < nd; k++) dst[k] = (uint32_t)__builtin_amdgcn_readlane((int)w, k);
+        }
+        uint32_t *ops = a.ops + (size_t)i * a.ops_stride;
+        const int F0 = (int)first_u32((uint32_t)a.front_clip[i]), D0 = (int)first_u32((uint32_t)a.data_len[i]);
+        const SamFieldsOut o = sam_fields_single_item(a.ix, prm, a.use_affine_gap != 0, a.use_m != 0, a.bases + b, a.quals + b, (int)(e - b), F0, D0, r,
+                                                      my, a.RL, oriented, lv_cells, ag_scratch, ops, (int)a.ops_stride);
+        if (lane == 0) {
+            a.flag[i] = o.flag; a.contig[i] = o.contig; a.pos[i] = o.pos; a.mapq[i] = o.mapq; a.n_ops[i] = o.n_ops; a.nm[i] = o.nm; a.stale[i] = o.stale;
+        }
+        WAVE_SYNC();
+    }
+}
+
+extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sam_fields, dim3(blocks), dim3(256), lds_bytes, s, *a);
 }

@@ -1,0 +1,159 @@
+// sam_fields.h -- from an alignment result to the computed fields of its SAM record (FLAG, RNAME index, POS, MAPQ, CIGAR, NM),
+// one wavefront per read.
+//
+// Restates, for the primary result of a single-end read:
+//   SimpleReadWriter::writeReads   SNAPLib/ReadWriter.cpp:170-330  (the retry loop around a leading indel: move the alignment or
+//                                  soft-clip the read and format again; give up across a contig boundary)
+//   SAMFormat::writeRead           SNAPLib/SAM.cpp:1898-2112 (Landau-Vishkin cigar) and :2115-2352 (affine-gap cigar)
+//   SAMFormat::createSAMLine       SNAPLib/SAM.cpp:1424-1572  (orientation, clipping bookkeeping, contig and position)
+//   SAMFormat::computeCigarString  SNAPLib/SAM.cpp:2595-2674 / :2678-2766 (soft clips around the cigar)
+//   Genome::getContigForRead       SNAPLib/Genome.cpp:734-758
+// over cigar_lv.h / cigar_ag.h.  Text formatting (names, sequence, tags) stays with the caller.
+#pragma once
+#include "dev_common.h"
+#include "cigar_lv.h"
+#include "cigar_ag.h"
+#include "../../include/snapgpu.h"
+
+#define SAMF_UNMAPPED 0x4                    // SAM_UNMAPPED, SAM_REVERSE_COMPLEMENT (SAM.h)
+#define SAMF_RC 0x10
+#define SAMF_OP_S 4u                         // BAM code of 'S'
+
+struct SamFieldsOut {
+    int flag, contig, mapq, n_ops, nm, stale;
+    long long pos;                           // 1-based position in the contig, 0 when unmapped
+};
+
+static __device__ __forceinline__ int samf_contig_at(const DevIndex &ix, long long loc) {      // Genome::getContigAtLocation, Genome.cpp:574-594
+    int lo = 0, hi = (int)ix.n_contigs - 1, c = -1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)first_u64(ix.contig_begin[mid]) <= loc) { c = mid; lo = mid + 1; } else hi = mid - 1;
+    }
+    return c;
+}
+static __device__ __forceinline__ long long samf_contig_end(const DevIndex &ix, int c) {       // beginningLocation + length (length includes the padding)
+    return c == (int)ix.n_contigs - 1 ? (long long)ix.n_bases : (long long)first_u64(ix.contig_begin[c + 1]);
+}
+
+// `oriented`: 2 * U bytes of per-wave HBM scratch (the read and its qualities as SAM prints them: reverse-complemented for an RC hit)
+static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
+    const DevIndex &ix, const AGCParams &agp, bool use_affine_gap, bool use_m,
+    const uint8_t *bases, const uint8_t *quals, int U, int F0, int D0, const snapgpu_single_result &res,
+    uint8_t *lds, uint32_t RL, uint8_t *oriented, uint32_t *lv_cells, uint8_t *ag_scratch, uint32_t *ops, int ops_cap)
+{
+    const int lane = lane_id();
+    SamFieldsOut o; o.flag = 0; o.contig = -1; o.mapq = 0; o.n_ops = -1; o.nm = -1; o.stale = 0; o.pos = 0;
+    // the Read's clipping state (Read.h:508-553): front = F0 + addF, dataLength = D0 - addF - addB
+    int addF = res.clipping_for_read_adjustment, addB = 0;                                       // ReadWriter.cpp:225
+    int status = res.status, direction = res.direction;
+    long long location = status == SNAPGPU_NotFound ? -1 : res.location;                        // :185-189 (InvalidGenomeLocation)
+    long long final_loc = location;                                                             // :228
+    const bool ag_branch = use_affine_gap && (res.used_affine_gap_scoring != 0 || res.score > 0);   // :232
+    int cum = 0, n_adj = 0;
+    int oriented_dir = -1;
+
+    for (int attempt = 0; attempt < 2 * RL + 8; attempt++) {
+        const int front = F0 + addF, dlen = D0 - addF - addB;
+        // ---------------- createSAMLine (SAM.cpp:1424-1572)
+        long long loc = final_loc;
+        if (status == SNAPGPU_NotFound) loc = -1;
+        int dir = loc < 0 ? 0 : direction;
+        int clipped_len = dlen;
+        int bcb, bca;
+        if (dir == 1) { bcb = U - clipped_len - front; bca = front; }
+        else { bcb = front; bca = U - clipped_len - bcb; }
+        if (ag_branch) {                                                                        // soft clipping from seed extension (:1541-1546; the
+            bcb += res.bases_clipped_before; bca += res.bases_clipped_after;                    //  Landau-Vishkin writeRead passes none, ReadWriter.cpp:276)
+            clipped_len -= res.bases_clipped_before + res.bases_clipped_after;
+        }
+        int flag = 0, contig = -1, mapq = 0;
+        long long pos = 0, extra = 0;
+        if (loc >= 0) {
+            if (dir == 1) flag |= SAMF_RC;
+            // getContigForRead(genomeLocation, read->getDataLength(), &extra)  (Genome.cpp:734-758)
+            contig = samf_contig_at(ix, loc);
+            if (contig < 0 || loc + dlen > samf_contig_end(ix, contig)) {
+                contig = contig + 1;                                                            // getNextContigAfterLocation
+                if (contig >= (int)ix.n_contigs) contig = (int)ix.n_contigs - 1;
+                extra = (long long)first_u64(ix.contig_begin[contig]) - loc;
+            }
+            pos = loc + extra - (long long)first_u64(ix.contig_begin[contig]) + 1;
+            mapq = res.mapq < 0 ? 0 : (res.mapq > 70 ? 70 : res.mapq);
+        } else flag |= SAMF_UNMAPPED;
+        int afc = 0, nm = -1, n_ops = -1;
+        bool star = true;
+        long long clip_before = 0, clip_after = 0;
+        if (ag_branch && extra != 0) afc = (int)extra;                                          // SAM.cpp:2193-2196
+        else if (loc >= 0) {
+            if (oriented_dir != dir) {                                                          // the read as SAM prints it (:1520-1538)
+                for (int i = lane; i < U; i += WAVE) {
+                    if (dir == 1) { oriented[U - 1 - i] = rc_base(bases[i]); oriented[U + U - 1 - i] = quals[i]; }
+                    else { oriented[i] = bases[i]; oriented[U + i] = quals[i]; }
+                }
+                WAVE_SYNC();
+                oriented_dir = dir;
+            }
+            const uint8_t *cd = oriented + bcb, *cq = oriented + U + bcb;
+            long long extra_after = 0;
+            int ed;
+            int tail = 0;
+            if (ag_branch) {
+                const CigarAGItemOut r = cigar_ag_item(ix, agp, cd, cq, clipped_len, res.score, 0, loc, use_m, lds, RL, ag_scratch, ops, ops_cap);
+                ed = r.edit_distance; afc = r.add_front_clipping; extra_after = r.extra_after; tail = r.tail_ins; n_ops = r.n_ops;
+                if (r.stale) o.stale = 1;
+            } else {
+                const CigarItemOut r = cigar_lv_item(ix, cd, clipped_len, extra, loc, use_m, lds, lds + ((RL + 15) & ~15u), lv_cells, ops, ops_cap);
+                ed = r.edit_distance; afc = r.add_front_clipping; extra_after = r.extra_after; n_ops = r.n_ops;
+            }
+            WAVE_SYNC();
+            if (afc == 0 || (n_ops < 0)) {                                                      // computeCigarString (:2621-2674 / :2709-2766)
+                afc = n_ops < 0 ? 0 : afc;
+                nm = n_ops < 0 ? 0 : ed;                                                        // the "*" of computeCigar leaves editDistance 0 (:2403)
+                if (n_ops >= 0 && ed >= 0) {
+                    star = false;
+                    if (ag_branch) bca += tail;                                                 // :2725
+                    clip_before = bcb + extra; clip_after = bca + extra_after;
+                }
+            }
+        }
+        if (afc == 0) {                                                                         // the record is complete
+            o.flag = flag; o.contig = loc >= 0 ? contig : -1; o.pos = pos; o.mapq = mapq; o.nm = nm;
+            if (loc < 0) { o.n_ops = -1; return o; }
+            if (star) { o.n_ops = -1; return o; }
+            // soft clips around the ops: shift right by one when there is a leading clip
+            int n = n_ops;
+            if (clip_before > 0) {
+                if (n + 1 > ops_cap) { o.n_ops = -1; o.nm = -2; return o; }
+                for (int i = n - 1; i >= 0; i--) { const uint32_t v = first_u32(ops[i]); WAVE_SYNC(); if (lane == 0) ops[i + 1] = v; WAVE_SYNC(); }
+                if (lane == 0) ops[0] = ((uint32_t)clip_before << 4) | SAMF_OP_S;
+                n++;
+            }
+            if (clip_after > 0) {
+                if (n + 1 > ops_cap) { o.n_ops = -1; o.nm = -2; return o; }
+                if (lane == 0) ops[n] = ((uint32_t)clip_after << 4) | SAMF_OP_S;
+                n++;
+            }
+            WAVE_SYNC();
+            o.n_ops = n;
+            return o;
+        }
+        // ---------------- the caller's reaction to a leading indel (ReadWriter.cpp:240-274 / :282-311)
+        n_adj++;
+        const int c_orig = status == SNAPGPU_NotFound ? -1 : samf_contig_at(ix, location);
+        const int c_new = status == SNAPGPU_NotFound ? -1 : samf_contig_at(ix, location + afc);
+        const int c_lim = ag_branch ? c_new : c_orig;
+        bool give_up = c_new < 0 || c_new != c_orig || n_adj > dlen;
+        if (!give_up) give_up = final_loc + afc > samf_contig_end(ix, c_lim) - (long long)ix.chromosome_padding;
+        if (give_up) { status = SNAPGPU_NotFound; location = -1; direction = 0; final_loc = -1; continue; }
+        if (ag_branch) {
+            if (afc < 0) { cum += afc; if (direction == 0) addF = -cum; else addB = -cum; }      // insertion: soft-clip (:263-269)
+            else final_loc = location + afc;                                                    // deletion (:271)
+        } else {
+            if (afc > 0) { cum += afc; addF = cum; }                                            // :305-308
+            final_loc += afc;                                                                   // :309
+        }
+    }
+    o.flag = SAMF_UNMAPPED; o.n_ops = -1; o.nm = -1;
+    return o;
+}

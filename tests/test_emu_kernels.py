@@ -161,3 +161,12 @@ def test_emu_compute_cigar_affine_gap(emu, emu_aligner):
     z = np.load(os.path.join(util.GOLDEN, "cigar_ag.npz"))
     for use_m in (0, 1):
         gc.check_ag_against_fixture(emu_aligner, z, use_m, step=3)
+
+
+@pytest.mark.parametrize("tag", ["default", "lvonly_eqx"])
+def test_emu_sam_fields(emu, golden_index, tag):
+    """Results -> FLAG / RNAME / POS / MAPQ / CIGAR / NM on the emulated device (k_sam_fields: the writeReads retry loop, createSAMLine,
+    both cigar variants, soft clips), against what the unmodified reference CLI printed: every second read of the fixture."""
+    import tests.test_zz_gpu_cigar as gc
+    z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
+    gc.check_sam_fields_against_reference_cli(golden_index, z, tag, step=2)

@@ -206,3 +206,40 @@ def test_compute_cigar_ag_vs_live_reference(cig_aligner, golden_index, tmp_path)
             assert (got[key] == exp[key]).all(), key
         for i in range(len(items)):
             assert util.cigar_text(got["ops"][i], got["n_ops"][i]) == util.cigar_text(exp["ops"][i], exp["n_ops"][i]), i
+
+
+# ---------------------------------------------------------------------------------------------- result -> SAM record fields
+SAMF_SETS = ["default", "lvonly", "eqx", "lvonly_eqx"]
+
+
+def check_sam_fields_against_reference_cli(golden_index, z, tag, step=1):
+    """FLAG / RNAME / POS / MAPQ / CIGAR / NM as the unmodified reference CLI printed them (tests/golden/sam_fields.npz,
+    scripts/make_golden_sam_fields.py) from the reads, Read::clip's outcome and the reference aligner's results."""
+    from snap_amd.aligner import BaseAligner
+    kw = dict(use_affine_gap=0) if tag.startswith("lvonly") else {}
+    a = BaseAligner(golden_index, abi.default_params(max_k=14, max_read_len=400, **kw))
+    try:
+        n = len(z["front_clip"])
+        sel = np.arange(0, n, step)
+        offs = z["offsets"]
+        lens = (offs[1:] - offs[:-1])[sel]
+        o2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        take = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in sel]).astype(np.int64)
+        got = a.samFields(z["bases"][take], z["quals"][take], o2, z["front_clip"][sel], z["data_len"][sel], z[tag + "_results"][sel],
+                          bool(z[tag + "_use_m"]))
+    finally:
+        a.close()
+    for k in ("flag", "contig", "pos", "mapq", "nm", "n_ops"):
+        bad = np.nonzero(got[k] != z[tag + "_" + k][sel])[0]
+        assert bad.size == 0, (tag, k, sel[bad[:5]], got[k][bad[:5]], z[tag + "_" + k][sel][bad[:5]])
+    for j, i in enumerate(sel):
+        assert util.cigar_text(got["ops"][j], got["n_ops"][j]) == util.cigar_text(z[tag + "_ops"][i], z[tag + "_n_ops"][i]), (tag, i)
+    return got
+
+
+@pytest.mark.parametrize("tag", SAMF_SETS)
+def test_sam_fields_vs_reference_cli_fixture(golden_index, tag):
+    import os
+    z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
+    got = check_sam_fields_against_reference_cli(golden_index, z, tag)
+    assert int((got["flag"] & 4 != 0).sum()) > 100 and int((got["flag"] & 16 != 0).sum()) > 1000
