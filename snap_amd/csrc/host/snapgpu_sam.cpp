@@ -1,0 +1,203 @@
+// snapgpu_sam.cpp -- FASTQ batcher + SAM writer over the C ABI: the host side of
+//     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-mrl minReadLength] [-b readsPerBatch]
+// Streams FASTQ records in batches across include/snapgpu.h -- snapgpu_align_single (BaseAligner::AlignRead) and
+// snapgpu_sam_fields_single (what SimpleReadWriter::writeReads / SAMFormat::writeRead compute before they print) -- and prints the
+// records the way the reference does.  What is restated here is host-side text handling only:
+//   FASTQReader::getReadFromBuffer   SNAPLib/FASTQ.cpp:148-260   (4-line records, '\r' tolerated)
+//   Read::clip (ClipBack)            SNAPLib/Read.h:567-620      (the CLI default -C-+: drop the trailing run of '#' qualities)
+//   the "useless read" filter        SNAPLib/SingleAligner.cpp:211-232 (dataLength < -mrl or more Ns than -d: written unaligned)
+//   SAMFormat::writeHeader           SNAPLib/SAM.cpp:1204-1305   (@HD, default @RG, @PG, one @SQ per contig)
+//   SAMFormat::writeRead's snprintf  SNAPLib/SAM.cpp:2078-2098   (field order, PG:Z:SNAP, NM:i, default read-group aux)
+// No alignment arithmetic happens on the host: without a GPU snapgpu_create_from_directory fails and so does this program.
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../../include/snapgpu.h"
+
+static void die(const char *msg, const char *arg = "") { fprintf(stderr, "snapgpu-sam: %s%s\n", msg, arg); exit(1); }
+
+struct Contig { std::string name; uint64_t begin; bool is_alt; };
+
+// the contig table of the index directory: names for RNAME / @SQ (Genome.cpp:203-229, 353-403; GenomeIndex.cpp:1879)
+static void load_contigs(const std::string &dir, std::vector<Contig> &contigs, uint64_t &n_bases, uint32_t &padding)
+{
+    FILE *f = fopen((dir + "/GenomeIndex").c_str(), "r");
+    if (!f) die("cannot open GenomeIndex in ", dir.c_str());
+    unsigned major = 0, minor = 0, n_tables = 0, seed_len = 0, pad = 0; unsigned long long ovf = 0;
+    if (fscanf(f, "%u %u %u %llu %u %u", &major, &minor, &n_tables, &ovf, &seed_len, &pad) != 6) die("malformed GenomeIndex header");
+    fclose(f);
+    padding = pad;
+    f = fopen((dir + "/Genome").c_str(), "rb");
+    if (!f) die("cannot open Genome in ", dir.c_str());
+    char line[8192];
+    long long nb = 0; int nc = 0;
+    if (!fgets(line, sizeof(line), f) || sscanf(line, "%lld %d", &nb, &nc) != 2) die("malformed Genome header");
+    n_bases = (uint64_t)nb;
+    for (int i = 0; i < nc; i++) {
+        long long begin = 0, pbegin = 0; int cflags = 0, orig = 0, pflags = 0, name_len = 0, cigar_len = 0, consumed = 0;
+        if (!fgets(line, sizeof(line), f) ||
+            sscanf(line, "%lld %x %d %lld %x %d %d %n", &begin, &cflags, &orig, &pbegin, &pflags, &name_len, &cigar_len, &consumed) < 7)
+            die("malformed contig line in Genome");
+        Contig c; c.begin = (uint64_t)begin; c.is_alt = (cflags & 1) != 0; c.name.assign(line + consumed, (size_t)name_len);
+        contigs.push_back(c);
+    }
+    fclose(f);
+}
+
+struct Batch {
+    std::vector<std::string> names;
+    std::vector<char> bases, quals;          // unclipped, concatenated
+    std::vector<uint64_t> offsets;           // n + 1
+    void clear() { names.clear(); bases.clear(); quals.clear(); offsets.assign(1, 0); }
+};
+
+static bool get_line(FILE *f, std::string &s)
+{
+    s.clear();
+    int c;
+    while ((c = fgetc(f)) != EOF) { if (c == '\n') { if (!s.empty() && s.back() == '\r') s.pop_back(); return true; } s.push_back((char)c); }
+    return !s.empty();
+}
+
+// one FASTQ record; false at end of file
+static bool next_read(FILE *f, std::string &id, std::string &seq, std::string &qual)
+{
+    std::string plus;
+    if (!get_line(f, id)) return false;
+    if (id.empty() || id[0] != '@') die("FASTQ record does not start with '@': ", id.c_str());
+    if (!get_line(f, seq) || !get_line(f, plus) || !get_line(f, qual)) die("truncated FASTQ record: ", id.c_str());
+    if (plus.empty() || plus[0] != '+') die("FASTQ record without '+' line: ", id.c_str());
+    if (seq.size() != qual.size()) die("FASTQ sequence and quality lengths differ: ", id.c_str());
+    id.erase(0, 1);
+    return true;
+}
+
+static char complement(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }      // COMPLEMENT[], Tables.cpp
+
+int main(int argc, char **argv)
+{
+    if (argc < 4 || strcmp(argv[1], "single") != 0) die("usage: snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d N] [-G-] [-=] [-M] [-mrl N] [-b N]");
+    const std::string index_dir = argv[2], fastq = argv[3];
+    std::string out_path;
+    snapgpu_params p; snapgpu_default_params(&p);
+    p.max_read_len = 400;
+    bool use_m = true;                                                     // AlignerOptions.cpp:58
+    unsigned min_read_len = 50;                                            // -mrl, AlignerOptions.cpp
+    size_t batch_reads = 65536;
+    std::string cl = "single";
+    for (int i = 2; i < argc; i++) { cl += " "; cl += argv[i]; }
+    for (int i = 4; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "-o" && i + 1 < argc) out_path = argv[++i];
+        else if (a == "-d" && i + 1 < argc) p.max_k = (uint32_t)atoi(argv[++i]);
+        else if (a == "-G-") p.use_affine_gap = 0;
+        else if (a == "-=") use_m = false;
+        else if (a == "-M") use_m = true;
+        else if (a == "-mrl" && i + 1 < argc) min_read_len = (unsigned)atoi(argv[++i]);
+        else if (a == "-b" && i + 1 < argc) batch_reads = (size_t)atoll(argv[++i]);
+        else if (a == "-t" && i + 1 < argc) ++i;                           // host threads: nothing to do here
+        else die("option not supported: ", a.c_str());
+    }
+    if (out_path.empty()) die("-o <out.sam> is required");
+
+    std::vector<Contig> contigs; uint64_t n_bases = 0; uint32_t padding = 0;
+    load_contigs(index_dir, contigs, n_bases, padding);
+    snapgpu_ctx *ctx = NULL;
+    int rc = snapgpu_create_from_directory(index_dir.c_str(), &p, 0, &ctx);
+    if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_create_from_directory failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+
+    FILE *in = fopen(fastq.c_str(), "rb");
+    if (!in) die("cannot open ", fastq.c_str());
+    FILE *out = fopen(out_path.c_str(), "wb");
+    if (!out) die("cannot create ", out_path.c_str());
+    // header (SAM.cpp:1232-1295)
+    fprintf(out, "@HD\tVN:1.6\tGO:query\n@RG\tID:FASTQ\tPL:Illumina\tPU:pu\tLB:lb\tSM:sm\n@PG\tID:SNAP\tPN:SNAP\tCL:%s\tVN:2.0.5\n", cl.c_str());
+    for (size_t c = 0; c < contigs.size(); c++) {
+        const uint64_t end = c + 1 < contigs.size() ? contigs[c + 1].begin : n_bases;
+        fprintf(out, "@SQ\tSN:%s\tLN:%llu%s\n", contigs[c].name.c_str(), (unsigned long long)(end - contigs[c].begin - padding), contigs[c].is_alt ? "\tAH:*" : "");
+    }
+
+    Batch b; b.clear();
+    std::string id, seq, qual;
+    const uint32_t ops_stride = 64;
+    unsigned long long total = 0, aligned = 0;
+    bool eof = false;
+    while (!eof) {
+        b.clear();
+        while (b.names.size() < batch_reads) {
+            if (!next_read(in, id, seq, qual)) { eof = true; break; }
+            if (seq.size() > p.max_read_len) die("read longer than the 400 bases this build was sized for: ", id.c_str());
+            b.names.push_back(id);
+            b.bases.insert(b.bases.end(), seq.begin(), seq.end());
+            b.quals.insert(b.quals.end(), qual.begin(), qual.end());
+            b.offsets.push_back(b.bases.size());
+        }
+        const size_t n = b.names.size();
+        if (n == 0) break;
+        // Read::clip (ClipBack) and the useless-read filter; the reads that go to the aligner, clipped, in one buffer
+        std::vector<int32_t> front_clip(n, 0), data_len(n, 0);
+        std::vector<uint32_t> to_align;
+        std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
+        for (size_t i = 0; i < n; i++) {
+            const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
+            size_t m = (size_t)(b.offsets[i + 1] - b.offsets[i]);
+            while (m > 0 && q[m - 1] == '#') m--;
+            data_len[i] = (int32_t)m;
+            unsigned n_count = 0;
+            for (size_t j = 0; j < m; j++) n_count += s[j] == 'N';
+            if (m >= min_read_len && n_count <= p.max_k) {
+                to_align.push_back((uint32_t)i);
+                ab.insert(ab.end(), s, s + m); aq.insert(aq.end(), q, q + m); ao.push_back(ab.size());
+            }
+        }
+        std::vector<snapgpu_single_result> results(n), aligned_res(to_align.size()), alt_res(to_align.size());
+        for (size_t i = 0; i < n; i++) {                                   // SingleAligner.cpp:215-225
+            memset(&results[i], 0, sizeof(results[i]));
+            results[i].status = SNAPGPU_NotFound; results[i].location = SNAPGPU_InvalidGenomeLocation32; results[i].score = -1;
+        }
+        if (!to_align.empty()) {
+            rc = snapgpu_align_single(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data());
+            if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_align_single failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+            for (size_t k = 0; k < to_align.size(); k++) results[to_align[k]] = aligned_res[k];
+        }
+        std::vector<int32_t> flag(n), contig(n), mapq(n), n_ops(n), nm(n), stale(n);
+        std::vector<int64_t> pos(n);
+        std::vector<uint32_t> ops(n * ops_stride);
+        rc = snapgpu_sam_fields_single(ctx, (uint32_t)n, b.bases.data(), b.quals.data(), b.offsets.data(), front_clip.data(), data_len.data(),
+                                       results.data(), use_m ? 1 : 0, flag.data(), contig.data(), pos.data(), mapq.data(), ops.data(), ops_stride,
+                                       n_ops.data(), nm.data(), stale.data());
+        if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_sam_fields_single failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+        std::string rec, sq, ql;
+        for (size_t i = 0; i < n; i++) {
+            const char *s = b.bases.data() + b.offsets[i], *q = b.quals.data() + b.offsets[i];
+            const size_t U = (size_t)(b.offsets[i + 1] - b.offsets[i]);
+            const std::string &nmq = b.names[i];
+            const size_t sp = nmq.find(' ');                               // "illegal in SAM: truncate at the space" (SAM.cpp:2001-2004)
+            sq.assign(s, U); ql.assign(q, U);
+            if (flag[i] & 0x10) { for (size_t j = 0; j < U; j++) { sq[U - 1 - j] = complement(s[j]); ql[U - 1 - j] = q[j]; } }
+            std::string cigar = "*";
+            if (n_ops[i] >= 0) {
+                cigar.clear();
+                char tmp[32];
+                for (int k = 0; k < n_ops[i]; k++) {
+                    const uint32_t op = ops[i * ops_stride + (size_t)k];
+                    snprintf(tmp, sizeof(tmp), "%u%c", op >> 4, "MIDNSHP=X"[op & 15]);
+                    cigar += tmp;
+                }
+            }
+            fprintf(out, "%.*s\t%d\t%s\t%lld\t%d\t%s\t*\t0\t0\t%s\t%s\tPG:Z:SNAP\tNM:i:%d\tRG:Z:FASTQ\tPL:Z:Illumina\tPU:Z:pu\tLB:Z:lb\tSM:Z:sm\n",
+                    (int)(sp == std::string::npos ? nmq.size() : sp), nmq.c_str(), flag[i], contig[i] >= 0 ? contigs[(size_t)contig[i]].name.c_str() : "*",
+                    (long long)pos[i], mapq[i], cigar.c_str(), sq.c_str(), ql.c_str(), nm[i]);
+            aligned += (flag[i] & 0x4) == 0;
+        }
+        total += n;
+    }
+    fclose(out); fclose(in);
+    snapgpu_destroy(ctx);
+    fprintf(stderr, "snapgpu-sam: %llu reads, %llu aligned\n", total, aligned);
+    return 0;
+}

@@ -11,6 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "snap_amd", "csrc")
 BDIR = os.path.join(HERE, "_build")
 LIB = os.path.join(BDIR, "libsnapgpu_emu.so")
+TOOL = os.path.join(BDIR, "snapgpu-sam-emu")
 CXX = os.environ.get("CXX", "g++")
 # -fno-reorder-blocks: the emulator orders divergent lanes by code address (see wave_emu.cpp)
 FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fno-reorder-blocks", "-fno-reorder-blocks-and-partition", "-ffp-contract=off",
@@ -56,6 +57,10 @@ def build(verbose=False):
             list(ex.map(lambda u: _run([CXX] + FLAGS + u[2] + ["-c", u[1], "-o", os.path.join(BDIR, u[0])]), stale))
     if stale or not os.path.exists(LIB):
         _run([CXX, "-shared", "-fPIC", "-o", LIB] + [os.path.join(BDIR, u[0]) for u in us] + ["-lpthread"])
+    # the native FASTQ -> SAM host program, linked against the emulated library (same source as snap_amd/snapgpu-sam)
+    tool_src = os.path.join(CSRC, "host", "snapgpu_sam.cpp")
+    if not os.path.exists(TOOL) or os.path.getmtime(TOOL) < max(os.path.getmtime(tool_src), os.path.getmtime(LIB)):
+        _run([CXX, "-O2", "-std=c++17", "-o", TOOL, tool_src, "-L" + BDIR, "-lsnapgpu_emu", "-Wl,-rpath," + BDIR, "-lpthread"])
     return LIB
 
 

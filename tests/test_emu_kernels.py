@@ -170,3 +170,17 @@ def test_emu_sam_fields(emu, golden_index, tag):
     import tests.test_zz_gpu_cigar as gc
     z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
     gc.check_sam_fields_against_reference_cli(golden_index, z, tag, step=2)
+
+
+@pytest.mark.parametrize("opts", [[], ["-G-", "-="]])
+def test_emu_native_fastq_to_sam(emu, tmp_path, opts):
+    """FASTQ in, SAM out: the native host program (snap_amd/csrc/host/snapgpu_sam.cpp, linked against the emulated library) writes the
+    same file as the unmodified reference CLI, every line but @PG; 800 reads incl. ragged / '#'-clipped / N-rich / unalignable ones."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.emu.build import TOOL
+    from tests.test_zz_gpu_native_sam import make_workload, run_and_compare
+    index_dir, fastq = make_workload(str(tmp_path), 800, genome_bases=300_000)
+    env = dict(os.environ, SNAPGPU_EMU_CUS="4")
+    assert run_and_compare(TOOL, str(tmp_path), index_dir, fastq, opts, env=env) > 800

@@ -1,0 +1,72 @@
+"""The native FASTQ -> SAM path end to end: snap_amd/snapgpu-sam (C++ host program over the C ABI: FASTQ batcher, snapgpu_align_single,
+snapgpu_sam_fields_single, SAM text) must write the same file as the unmodified reference CLI (oracle/_ref/snap-aligner) -- every line
+but @PG -- on the same FASTQ and index, under several option sets.
+
+Written in a round that had no GPU time left: verified with the program linked against the wavefront emulator
+(tests/test_emu_kernels.py::test_emu_native_fastq_to_sam), not yet on hardware -- hence the file name (last in the `-m gpu` run)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from snap_amd import synth
+from oracle import ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "snap_amd", "snapgpu-sam")
+
+
+def make_workload(d, n_reads, genome_bases=600_000):
+    """A genome with repeats, its index (the reference's builder) and a FASTQ with the awkward cases: ragged lengths, '#' tails, reads
+    with too many Ns, unalignable reads, bases prepended / dropped at the start, names with a comment."""
+    contigs = synth.make_genome(177, genome_bases, n_contigs=3, repeat_frac=0.1)
+    fasta = os.path.join(d, "g.fa"); synth.write_fasta(fasta, contigs)
+    index_dir = os.path.join(d, "index")
+    ref.build_index(fasta, index_dir, seed_len=20, threads=max(1, min(8, os.cpu_count() or 1)))
+    reads = synth.make_reads(15, contigs, n_reads, 150, sub=0.015, ins=0.003, dele=0.003, n_frac=0.002)
+    rng = np.random.default_rng(19)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    fastq = os.path.join(d, "r.fq")
+    with open(fastq, "wb") as f:
+        for i in range(n_reads):
+            b = reads["bases"][i].copy(); q = reads["quals"][i].copy()
+            kind = i % 40
+            L = 150
+            name = b"read%d" % i
+            if kind == 1: L = int(rng.integers(30, 150))
+            elif kind == 2: b[rng.integers(0, 150, size=16)] = ord("N")
+            elif kind == 3: q[150 - int(rng.integers(1, 40)):] = ord("#")
+            elif kind == 4: b = rng.choice(acgt, size=150)
+            elif kind == 5: k = int(rng.integers(1, 4)); b = np.concatenate([rng.choice(acgt, size=k), b])[:150]
+            elif kind == 6: k = int(rng.integers(1, 4)); b = np.concatenate([b[k:], rng.choice(acgt, size=k)])
+            elif kind == 7: name += b" some comment"
+            f.write(b"@" + name + b"\n" + b[:L].tobytes() + b"\n+\n" + q[:L].tobytes() + b"\n")
+    return index_dir, fastq
+
+
+def sam_lines(path):
+    return sorted(line for line in open(path) if not line.startswith("@PG"))
+
+
+def run_and_compare(tool, d, index_dir, fastq, opts, env=None):
+    tag = "_".join(o.strip("-") or "eq" for o in opts) or "default"
+    out_ref, out_new = os.path.join(d, "ref_%s.sam" % tag), os.path.join(d, "new_%s.sam" % tag)
+    for cmd, e in (([ref.CLI_PATH, "single", index_dir, fastq, "-o", out_ref, "-t", "1"] + opts, None), ([tool, "single", index_dir, fastq, "-o", out_new] + opts, env)):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=1800, env=e)
+        assert r.returncode == 0, "%s failed:\n%s" % (cmd[0], r.stdout.decode(errors="replace")[-3000:])
+    a, b = sam_lines(out_ref), sam_lines(out_new)
+    assert len(a) == len(b)
+    diff = [(x, y) for x, y in zip(a, b) if x != y]
+    assert not diff, "%d of %d lines differ, first:\n%s%s" % (len(diff), len(a), diff[0][0], diff[0][1])
+    return len(a)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"]])
+def test_native_fastq_to_sam_identical_to_reference_cli(tmp_path_factory, opts):
+    assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
+    d = str(tmp_path_factory.mktemp("native"))
+    index_dir, fastq = make_workload(d, 20000, genome_bases=3_000_000)
+    assert run_and_compare(TOOL, d, index_dir, fastq, opts) > 20000
