@@ -95,13 +95,19 @@ __global__ __launch_bounds__(256) void k_sam_fields(SamFieldsArgs a)
         i = first_u32(i);
         if (i >= a.n) break;
         const uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
-        snapgpu_single_result r;
-        {   // the result record, one dword per lane, then lane reads (22 dwords)
-            const uint32_t *src = (const uint32_t *)&a.results[i];
-            uint32_t *dst = (uint32_t *)&r;
-            const int nd = (int)(sizeof(snapgpu_single_result) / 4);
-            const uint32_t w = lane < nd ? src[lane] : 0u;
-            for (int k = 0; k < nd; k++) dst[k] = (uint32_t)__builtin_amdgcn_readlane((int)w, k);
+        snapgpu_single_result r;                                                  // the fields the writer looks at, as wave-uniform values
+        {
+            const snapgpu_single_result *rp = &a.results[i];
+            r.status = (int32_t)first_u32((uint32_t)rp->status); r.direction = (int32_t)first_u32((uint32_t)rp->direction);
+            r.location = (int64_t)first_u64((uint64_t)rp->location); r.orig_location = 0;
+            r.score = (int32_t)first_u32((uint32_t)rp->score); r.score_prior_to_clipping = 0;
+            r.mapq = (int32_t)first_u32((uint32_t)rp->mapq);
+            r.clipping_for_read_adjustment = (int32_t)first_u32((uint32_t)rp->clipping_for_read_adjustment);
+            r.used_affine_gap_scoring = (int32_t)first_u32((uint32_t)rp->used_affine_gap_scoring);
+            r.bases_clipped_before = (int32_t)first_u32((uint32_t)rp->bases_clipped_before);
+            r.bases_clipped_after = (int32_t)first_u32((uint32_t)rp->bases_clipped_after);
+            r.ag_score = 0; r.supplementary = 0; r.seed_offset = 0; r.match_probability = 0.0; r.probability_all_candidates = 0.0;
+            r.popular_seeds_skipped = 0; r.reserved = 0;
         }
         uint32_t *ops = a.ops + (size_t)i * a.ops_stride;
         const int F0 = (int)first_u32((uint32_t)a.front_clip[i]), D0 = (int)first_u32((uint32_t)a.data_len[i]);

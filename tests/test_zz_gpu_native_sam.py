@@ -49,10 +49,10 @@ def sam_lines(path):
     return sorted(line for line in open(path) if not line.startswith("@PG"))
 
 
-def run_and_compare(tool, d, index_dir, fastq, opts, env=None):
+def run_and_compare(tool, d, index_dir, fastq, opts, env=None, ref_opts=None):
     tag = "_".join(o.strip("-") or "eq" for o in opts) or "default"
     out_ref, out_new = os.path.join(d, "ref_%s.sam" % tag), os.path.join(d, "new_%s.sam" % tag)
-    for cmd, e in (([ref.CLI_PATH, "single", index_dir, fastq, "-o", out_ref, "-t", "1"] + opts, None), ([tool, "single", index_dir, fastq, "-o", out_new] + opts, env)):
+    for cmd, e in (([ref.CLI_PATH, "single", index_dir, fastq, "-o", out_ref, "-t", "1"] + (opts if ref_opts is None else ref_opts), None), ([tool, "single", index_dir, fastq, "-o", out_new] + opts, env)):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=1800, env=e)
         assert r.returncode == 0, "%s failed:\n%s" % (cmd[0], r.stdout.decode(errors="replace")[-3000:])
     a, b = sam_lines(out_ref), sam_lines(out_new)
