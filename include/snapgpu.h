@@ -20,6 +20,8 @@
  *   snapgpu_compute_cigar_lv
  *       SAMFormat::computeCigar (LV variant)    SNAPLib/SAM.cpp:2354-2467
  *       LandauVishkinWithCigar::computeEditDistanceNormalized / computeEditDistance  SNAPLib/LandauVishkin.cpp:507-648 / 141-505
+ *   snapgpu_sam_fields_paired
+ *       SAMFormat::writePairs / fillMateInfo    SNAPLib/SAM.cpp:1575-1895 / 1308-1421; SimpleReadWriter::writePairs SNAPLib/ReadWriter.cpp:345-520
  *   snapgpu_sam_fields_single
  *       SimpleReadWriter::writeReads            SNAPLib/ReadWriter.cpp:170-330
  *       SAMFormat::writeRead / createSAMLine / computeCigarString  SNAPLib/SAM.cpp:1898-2352 / 1424-1572 / 2595-2766
@@ -358,6 +360,21 @@ int  snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, 
                                const int32_t *front_clip, const int32_t *data_len, const snapgpu_single_result *results, int use_m,
                                int32_t *flag, int32_t *contig, int64_t *pos, int32_t *mapq, uint32_t *ops, uint32_t ops_stride,
                                int32_t *n_ops, int32_t *nm, int32_t *reference_history_dependent);
+
+/*
+ * The paired-end writer: for the primary PairedAlignmentResult of each pair, the computed fields of BOTH SAM records -- what
+ * SAMFormat::writePairs (SNAPLib/SAM.cpp:1575-1895: createSAMLine and the cigar with its leading-indel loop per mate, :1636-1715) and
+ * SAMFormat::fillMateInfo (:1308-1421: pairing flags, RNEXT / PNEXT, the signed template length from the clipped starts and the cigars'
+ * reference spans, the "unmapped mate takes its partner's RNAME / POS" rule) compute, and the order SimpleReadWriter::writePairs prints the
+ * two records in (ReadWriter.cpp:453-461: by final location).  Reads 2 i and 2 i + 1 are read 0 and read 1 of pair i.
+ * Per read: the outputs of snapgpu_sam_fields_single (flag now with 0x1 / 0x2 / 0x8 / 0x20 / 0x40 / 0x80) plus rnext (-1 "*", -2 "=",
+ * else a contig index), pnext, tlen.  Per pair: first_written (0 / 1).
+ */
+int  snapgpu_sam_fields_paired(snapgpu_ctx *ctx, uint32_t n_pairs, const char *bases, const char *quals, const uint64_t *offsets,
+                               const int32_t *front_clip, const int32_t *data_len, const snapgpu_paired_result *results, int use_m,
+                               int32_t *flag, int32_t *contig, int64_t *pos, int32_t *mapq, uint32_t *ops, uint32_t ops_stride,
+                               int32_t *n_ops, int32_t *nm, int32_t *rnext, int64_t *pnext, int64_t *tlen, int32_t *first_written,
+                               int32_t *reference_history_dependent);
 
 /*
  * Batched AffineGapVectorized<dir>::computeScore (banded[i] == 0) / computeScoreBanded

@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
     "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
     "snapgpu_align_paired_secondary", "snapgpu_align_paired_secondary_device",
-    "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag", "snapgpu_sam_fields_single",
+    "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag", "snapgpu_sam_fields_single", "snapgpu_sam_fields_paired",
 ]
 
 
@@ -238,6 +238,25 @@ class BaseAligner:
             C.c_int(1 if use_m else 0), ptr(flag), ptr(contig), ptr(pos), ptr(mapq), ptr(ops), C.c_uint32(ops_stride), ptr(n_ops), ptr(nm),
             ptr(stale)), "snapgpu_sam_fields_single")
         return dict(flag=flag, contig=contig, pos=pos, mapq=mapq, ops=ops, n_ops=n_ops, nm=nm, stale=stale)
+
+    def samFieldsPaired(self, bases, quals, offsets, front_clip, data_len, results, use_m: bool = False, ops_stride: int = 64):
+        """SAMFormat::writePairs + fillMateInfo up to the point of printing (see snapgpu_sam_fields_paired).  offsets has 2 n + 1
+        entries (read 0 and read 1 of each pair); results: PAIRED_RESULT_DTYPE array of n."""
+        from .abi import PAIRED_RESULT_DTYPE
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1); quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        front_clip = np.ascontiguousarray(front_clip, dtype=np.int32); data_len = np.ascontiguousarray(data_len, dtype=np.int32)
+        results = np.ascontiguousarray(results, dtype=PAIRED_RESULT_DTYPE)
+        n = offsets.size - 1; npairs = n // 2
+        flag = np.zeros(n, np.int32); contig = np.zeros(n, np.int32); pos = np.zeros(n, np.int64); mapq = np.zeros(n, np.int32)
+        ops = np.zeros((n, ops_stride), dtype=np.uint32); n_ops = np.zeros(n, np.int32); nm = np.zeros(n, np.int32); stale = np.zeros(n, np.int32)
+        rnext = np.zeros(n, np.int32); pnext = np.zeros(n, np.int64); tlen = np.zeros(n, np.int64); first = np.zeros(npairs, np.int32)
+        self._check(self.lib.snapgpu_sam_fields_paired(
+            self.handle, C.c_uint32(npairs), ptr(bases), ptr(quals), ptr(offsets), ptr(front_clip), ptr(data_len), ptr(results),
+            C.c_int(1 if use_m else 0), ptr(flag), ptr(contig), ptr(pos), ptr(mapq), ptr(ops), C.c_uint32(ops_stride), ptr(n_ops), ptr(nm),
+            ptr(rnext), ptr(pnext), ptr(tlen), ptr(first), ptr(stale)), "snapgpu_sam_fields_paired")
+        return dict(flag=flag, contig=contig, pos=pos, mapq=mapq, ops=ops, n_ops=n_ops, nm=nm, rnext=rnext, pnext=pnext, tlen=tlen,
+                    first_written=first, stale=stale)
 
     # ---- BaseAligner::AlignRead over a batch -------------------------------------------
     def AlignRead(self, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray):

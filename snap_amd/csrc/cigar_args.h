@@ -37,6 +37,21 @@ struct SamFieldsArgs {
     int32_t *flag; int32_t *contig; int64_t *pos; int32_t *mapq; uint32_t *ops; int32_t *n_ops; int32_t *nm; int32_t *stale;
 };
 
+struct SamFieldsPairedArgs {
+    DevIndex ix;
+    AGCParamsPOD prm;
+    uint32_t n_pairs, RL, ops_stride, use_m, use_affine_gap;
+    const uint8_t *bases; const uint8_t *quals; const uint64_t *offsets;       // 2 * n_pairs + 1: read 0 and read 1 of each pair, unclipped
+    const int32_t *front_clip; const int32_t *data_len;                          // [2 * n_pairs]
+    const snapgpu_paired_result *results;                                        // [n_pairs]
+    uint8_t *scratch; uint64_t scratch_stride;
+    uint32_t *work_counter;
+    // per read [2 * n_pairs]
+    int32_t *flag; int32_t *contig; int64_t *pos; int32_t *mapq; uint32_t *ops; int32_t *n_ops; int32_t *nm; int32_t *rnext; int64_t *pnext; int64_t *tlen; int32_t *stale;
+    int32_t *first_written;                                                      // [n_pairs]: which read's record comes first in the file
+};
+
+extern "C" void snapgpu_launch_sam_fields_paired(const SamFieldsPairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 extern "C" void snapgpu_launch_cigar_ag(const CigarAGArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 extern "C" void snapgpu_launch_cigar_lv(const CigarArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);

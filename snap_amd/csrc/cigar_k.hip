@@ -124,3 +124,64 @@ extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t block
 {
     hipLaunchKernelGGL(k_sam_fields, dim3(blocks), dim3(256), lds_bytes, s, *a);
 }
+
+// paired-end writer: both reads of a pair by one wavefront, then SAMFormat::fillMateInfo for each (sam_fields.h)
+__global__ __launch_bounds__(256) void k_sam_fields_paired(SamFieldsPairedArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
+    uint8_t *my = lds + (size_t)wave_in_block * agc_lds_bytes(a.RL);
+    uint8_t *scratch = a.scratch + (size_t)wave_slot * a.scratch_stride;
+    uint8_t *oriented = scratch;
+    uint32_t *lv_cells = (uint32_t *)(scratch + ((2 * a.RL + 255) & ~255u));
+    uint8_t *ag_scratch = (uint8_t *)lv_cells + ((lvc_scratch_bytes() + 255) & ~255u);
+    AGCParams prm; prm.match = a.prm.match; prm.sub = a.prm.sub; prm.gap_open = a.prm.gap_open; prm.gap_ext = a.prm.gap_ext;
+    while (true) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
+        i = first_u32(i);
+        if (i >= a.n_pairs) break;
+        const snapgpu_paired_result *pr = &a.results[i];
+        const bool aligned_as_pair = first_u32((uint32_t)pr->aligned_as_pair) != 0;
+        SamFieldsOut o[2];
+        for (int w = 0; w < 2; w++) {
+            const uint32_t ri = 2 * i + (uint32_t)w;
+            const uint64_t b = first_u64(a.offsets[ri]), e = first_u64(a.offsets[ri + 1]);
+            snapgpu_single_result r;                                              // this mate's part of the PairedAlignmentResult
+            r.status = (int32_t)first_u32((uint32_t)pr->status[w]); r.direction = (int32_t)first_u32((uint32_t)pr->direction[w]);
+            r.location = (int64_t)first_u64((uint64_t)pr->location[w]); r.orig_location = 0;
+            r.score = (int32_t)first_u32((uint32_t)pr->score[w]); r.score_prior_to_clipping = 0;
+            r.mapq = (int32_t)first_u32((uint32_t)pr->mapq[w]);
+            r.clipping_for_read_adjustment = (int32_t)first_u32((uint32_t)pr->clipping_for_read_adjustment[w]);
+            r.used_affine_gap_scoring = (int32_t)first_u32((uint32_t)pr->used_affine_gap_scoring[w]);
+            r.bases_clipped_before = (int32_t)first_u32((uint32_t)pr->bases_clipped_before[w]);
+            r.bases_clipped_after = (int32_t)first_u32((uint32_t)pr->bases_clipped_after[w]);
+            r.ag_score = 0; r.supplementary = 0; r.seed_offset = 0; r.match_probability = 0.0; r.probability_all_candidates = 0.0;
+            r.popular_seeds_skipped = 0; r.reserved = 0;
+            const int F0 = (int)first_u32((uint32_t)a.front_clip[ri]), D0 = (int)first_u32((uint32_t)a.data_len[ri]);
+            o[w] = sam_fields_single_item(a.ix, prm, a.use_affine_gap != 0, a.use_m != 0, a.bases + b, a.quals + b, (int)(e - b), F0, D0, r,
+                                          my, a.RL, oriented, lv_cells, ag_scratch, a.ops + (size_t)ri * a.ops_stride, (int)a.ops_stride, true);
+            WAVE_SYNC();
+        }
+        for (int w = 0; w < 2; w++) {
+            const SamMateOut m = sam_fill_mate_info(a.ix, o[w], o[1 - w], w == 0, aligned_as_pair);
+            const uint32_t ri = 2 * i + (uint32_t)w;
+            if (lane == 0) {
+                a.flag[ri] = m.flag; a.contig[ri] = m.contig; a.pos[ri] = m.pos; a.mapq[ri] = o[w].mapq; a.n_ops[ri] = o[w].n_ops; a.nm[ri] = o[w].nm;
+                a.rnext[ri] = m.rnext; a.pnext[ri] = m.pnext; a.tlen[ri] = m.tlen; a.stale[ri] = o[w].stale;
+            }
+        }
+        if (lane == 0) {                                                          // ReadWriter.cpp:481-488: numerical order of the final locations
+            const unsigned long long l0 = o[0].final_loc < 0 ? ~0ull : (unsigned long long)o[0].final_loc, l1 = o[1].final_loc < 0 ? ~0ull : (unsigned long long)o[1].final_loc;
+            a.first_written[i] = l0 <= l1 ? 0 : 1;
+        }
+        WAVE_SYNC();
+    }
+}
+
+extern "C" void snapgpu_launch_sam_fields_paired(const SamFieldsPairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_sam_fields_paired, dim3(blocks), dim3(256), lds_bytes, s, *a);
+}

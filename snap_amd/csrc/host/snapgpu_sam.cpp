@@ -1,5 +1,6 @@
 // snapgpu_sam.cpp -- FASTQ batcher + SAM writer over the C ABI: the host side of
 //     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-mrl minReadLength] [-b readsPerBatch]
+//     snapgpu-sam paired <index-dir> <reads1.fq> <reads2.fq> -o <out.sam> [same options]
 // Streams FASTQ records in batches across include/snapgpu.h -- snapgpu_align_single (BaseAligner::AlignRead) and
 // snapgpu_sam_fields_single (what SimpleReadWriter::writeReads / SAMFormat::writeRead compute before they print) -- and prints the
 // records the way the reference does.  What is restated here is host-side text handling only:
@@ -8,6 +9,8 @@
 //   the "useless read" filter        SNAPLib/SingleAligner.cpp:211-232 (dataLength < -mrl or more Ns than -d: written unaligned)
 //   SAMFormat::writeHeader           SNAPLib/SAM.cpp:1204-1305   (@HD, default @RG, @PG, one @SQ per contig)
 //   SAMFormat::writeRead's snprintf  SNAPLib/SAM.cpp:2078-2098   (field order, PG:Z:SNAP, NM:i, default read-group aux)
+//   paired: the both-mates-useless rule (PairedAligner.cpp:680-707), the /1 /2 suffix rule (ReadWriter.cpp:392-404), the mate's quality
+//   sum QS:i (SAM.cpp:1826-1837) and writePairs' snprintf (:1855-1877); pairing arithmetic is snapgpu_sam_fields_paired's
 // No alignment arithmetic happens on the host: without a GPU snapgpu_create_from_directory fails and so does this program.
 #include <stdint.h>
 #include <stdio.h>
@@ -80,17 +83,19 @@ static char complement(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == '
 
 int main(int argc, char **argv)
 {
-    if (argc < 4 || strcmp(argv[1], "single") != 0) die("usage: snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d N] [-G-] [-=] [-M] [-mrl N] [-b N]");
-    const std::string index_dir = argv[2], fastq = argv[3];
+    const bool paired = argc >= 2 && strcmp(argv[1], "paired") == 0;
+    if (argc < (paired ? 5 : 4) || (!paired && strcmp(argv[1], "single") != 0))
+        die("usage: snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> | paired <index-dir> <r1.fq> <r2.fq> -o <out.sam>  [-d N] [-G-] [-=] [-M] [-mrl N] [-b N]");
+    const std::string index_dir = argv[2], fastq = argv[3], fastq2 = paired ? argv[4] : "";
     std::string out_path;
     snapgpu_params p; snapgpu_default_params(&p);
     p.max_read_len = 400;
     bool use_m = true;                                                     // AlignerOptions.cpp:58
     unsigned min_read_len = 50;                                            // -mrl, AlignerOptions.cpp
     size_t batch_reads = 65536;
-    std::string cl = "single";
+    std::string cl = argv[1];
     for (int i = 2; i < argc; i++) { cl += " "; cl += argv[i]; }
-    for (int i = 4; i < argc; i++) {
+    for (int i = paired ? 5 : 4; i < argc; i++) {
         const std::string a = argv[i];
         if (a == "-o" && i + 1 < argc) out_path = argv[++i];
         else if (a == "-d" && i + 1 < argc) p.max_k = (uint32_t)atoi(argv[++i]);
@@ -112,6 +117,15 @@ int main(int argc, char **argv)
 
     FILE *in = fopen(fastq.c_str(), "rb");
     if (!in) die("cannot open ", fastq.c_str());
+    FILE *in2 = NULL;
+    if (paired) {
+        in2 = fopen(fastq2.c_str(), "rb");
+        if (!in2) die("cannot open ", fastq2.c_str());
+        snapgpu_paired_params pp; snapgpu_default_paired_params(&pp);
+        pp.min_read_length = min_read_len;
+        rc = snapgpu_enable_paired(ctx, &pp);
+        if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_enable_paired failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+    }
     FILE *out = fopen(out_path.c_str(), "wb");
     if (!out) die("cannot create ", out_path.c_str());
     // header (SAM.cpp:1232-1295)
@@ -126,7 +140,95 @@ int main(int argc, char **argv)
     const uint32_t ops_stride = 64;
     unsigned long long total = 0, aligned = 0;
     bool eof = false;
-    while (!eof) {
+    while (paired && !eof) {
+        b.clear();
+        while (b.names.size() < 2 * (batch_reads / 2)) {
+            if (!next_read(in, id, seq, qual)) { eof = true; break; }
+            std::string id2, seq2, qual2;
+            if (!next_read(in2, id2, seq2, qual2)) die("the second FASTQ file has fewer reads than the first");
+            if (seq.size() > p.max_read_len || seq2.size() > p.max_read_len) die("read longer than the 400 bases this build was sized for: ", id.c_str());
+            b.names.push_back(id); b.bases.insert(b.bases.end(), seq.begin(), seq.end()); b.quals.insert(b.quals.end(), qual.begin(), qual.end()); b.offsets.push_back(b.bases.size());
+            b.names.push_back(id2); b.bases.insert(b.bases.end(), seq2.begin(), seq2.end()); b.quals.insert(b.quals.end(), qual2.begin(), qual2.end()); b.offsets.push_back(b.bases.size());
+        }
+        const size_t n = b.names.size(), np = n / 2;
+        if (n == 0) break;
+        std::vector<int32_t> front_clip(n, 0), data_len(n, 0);
+        std::vector<char> useful(n, 0);
+        for (size_t i = 0; i < n; i++) {
+            const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
+            size_t m = (size_t)(b.offsets[i + 1] - b.offsets[i]);
+            while (m > 0 && q[m - 1] == '#') m--;
+            data_len[i] = (int32_t)m;
+            unsigned n_count = 0;
+            for (size_t j = 0; j < m; j++) n_count += s[j] == 'N';
+            useful[i] = m >= min_read_len && n_count <= p.max_k;
+        }
+        std::vector<uint32_t> to_align;                                     // pairs with at least one useful mate (PairedAligner.cpp:680-682)
+        std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
+        for (size_t k = 0; k < np; k++) {
+            if (!useful[2 * k] && !useful[2 * k + 1]) continue;
+            to_align.push_back((uint32_t)k);
+            for (size_t i = 2 * k; i < 2 * k + 2; i++) {
+                const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
+                ab.insert(ab.end(), s, s + data_len[i]); aq.insert(aq.end(), q, q + data_len[i]); ao.push_back(ab.size());
+            }
+        }
+        std::vector<snapgpu_paired_result> results(np), ares(to_align.size()), aalt(to_align.size());
+        for (size_t k = 0; k < np; k++) {
+            memset(&results[k], 0, sizeof(results[k]));
+            for (int w = 0; w < 2; w++) { results[k].status[w] = SNAPGPU_NotFound; results[k].location[w] = SNAPGPU_InvalidGenomeLocation32; results[k].score[w] = -1; }
+        }
+        if (!to_align.empty()) {
+            rc = snapgpu_align_paired(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), ares.data(), aalt.data());
+            if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_align_paired failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+            for (size_t k = 0; k < to_align.size(); k++) results[to_align[k]] = ares[k];
+        }
+        std::vector<int32_t> flag(n), contig(n), mapq(n), n_ops(n), nm(n), stale(n), rnext(n), first_written(np);
+        std::vector<int64_t> pos(n), pnext(n), tlen(n);
+        std::vector<uint32_t> ops(n * ops_stride);
+        rc = snapgpu_sam_fields_paired(ctx, (uint32_t)np, b.bases.data(), b.quals.data(), b.offsets.data(), front_clip.data(), data_len.data(), results.data(),
+                                       use_m ? 1 : 0, flag.data(), contig.data(), pos.data(), mapq.data(), ops.data(), ops_stride, n_ops.data(), nm.data(),
+                                       rnext.data(), pnext.data(), tlen.data(), first_written.data(), stale.data());
+        if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_sam_fields_paired failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+        std::string sq, ql;
+        for (size_t k = 0; k < np; k++) {
+            // QNAME: the /1 /2 suffixes go when both names carry them (ReadWriter.cpp:392-404)
+            size_t idl[2] = { b.names[2 * k].size(), b.names[2 * k + 1].size() };
+            const std::string &n0 = b.names[2 * k], &n1 = b.names[2 * k + 1];
+            if (idl[0] == idl[1] && idl[0] > 2 && n0[idl[0] - 2] == '/' && n1[idl[0] - 2] == '/') {
+                const char c0 = n0[idl[0] - 1], c1 = n1[idl[1] - 1];
+                if ((c0 == '1' || c0 == '2') && (c1 == '1' || c1 == '2') && c0 != c1) { idl[0] -= 2; idl[1] -= 2; }
+            }
+            for (int o = 0; o < 2; o++) {
+                const int w = o == 0 ? first_written[k] : 1 - first_written[k];
+                const size_t i = 2 * k + (size_t)w, im = 2 * k + (size_t)(1 - w);
+                const char *s = b.bases.data() + b.offsets[i], *q = b.quals.data() + b.offsets[i];
+                const size_t U = (size_t)(b.offsets[i + 1] - b.offsets[i]);
+                const std::string &nmq = b.names[i];
+                size_t qn = idl[w];
+                const size_t sp = nmq.substr(0, qn).find(' ');
+                if (sp != std::string::npos) qn = sp;
+                sq.assign(s, U); ql.assign(q, U);
+                if (flag[i] & 0x10) { for (size_t j = 0; j < U; j++) { sq[U - 1 - j] = complement(s[j]); ql[U - 1 - j] = q[j]; } }
+                std::string cigar = "*";
+                if (n_ops[i] >= 0) {
+                    cigar.clear();
+                    char tmp[32];
+                    for (int c = 0; c < n_ops[i]; c++) { const uint32_t op = ops[i * ops_stride + (size_t)c]; snprintf(tmp, sizeof(tmp), "%u%c", op >> 4, "MIDNSHP=X"[op & 15]); cigar += tmp; }
+                }
+                int mqs = 0;                                                // QS: the mate's qualities >= 15, summed (SAM.cpp:1826-1837)
+                { const unsigned char *mq = (const unsigned char *)b.quals.data() + b.offsets[im]; const size_t mu = (size_t)(b.offsets[im + 1] - b.offsets[im]);
+                  for (size_t j = 0; j < mu; j++) { const int v = (int)mq[j] - '!'; mqs += v >= 15 ? (v != 255) * v : 0; } }
+                const char *rn = rnext[i] == -2 ? "=" : (rnext[i] >= 0 ? contigs[(size_t)rnext[i]].name.c_str() : "*");
+                fprintf(out, "%.*s\t%d\t%s\t%lld\t%d\t%s\t%s\t%lld\t%d\t%s\t%s\tPG:Z:SNAP\tNM:i:%d\tRG:Z:FASTQ\tPL:Z:Illumina\tPU:Z:pu\tLB:Z:lb\tSM:Z:sm\tQS:i:%d\n",
+                        (int)qn, nmq.c_str(), flag[i], contig[i] >= 0 ? contigs[(size_t)contig[i]].name.c_str() : "*", (long long)pos[i], mapq[i], cigar.c_str(),
+                        rn, (long long)pnext[i], (int)tlen[i], sq.c_str(), ql.c_str(), nm[i], mqs);
+                aligned += (flag[i] & 0x4) == 0;
+            }
+        }
+        total += n;
+    }
+    while (!paired && !eof) {
         b.clear();
         while (b.names.size() < batch_reads) {
             if (!next_read(in, id, seq, qual)) { eof = true; break; }
@@ -196,7 +298,7 @@ int main(int argc, char **argv)
         }
         total += n;
     }
-    fclose(out); fclose(in);
+    fclose(out); fclose(in); if (in2) fclose(in2);
     snapgpu_destroy(ctx);
     fprintf(stderr, "snapgpu-sam: %llu reads, %llu aligned\n", total, aligned);
     return 0;

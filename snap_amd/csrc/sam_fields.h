@@ -22,6 +22,9 @@
 struct SamFieldsOut {
     int flag, contig, mapq, n_ops, nm, stale;
     long long pos;                           // 1-based position in the contig, 0 when unmapped
+    // what SAMFormat::fillMateInfo needs from this read (paired-end writer)
+    long long final_loc;                     // the location the record was written at (-1: unmapped)
+    int final_dir, bases_clipped_before, ref_span, data_len;
 };
 
 static __device__ __forceinline__ int samf_contig_at(const DevIndex &ix, long long loc) {      // Genome::getContigAtLocation, Genome.cpp:574-594
@@ -40,10 +43,11 @@ static __device__ __forceinline__ long long samf_contig_end(const DevIndex &ix, 
 static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
     const DevIndex &ix, const AGCParams &agp, bool use_affine_gap, bool use_m,
     const uint8_t *bases, const uint8_t *quals, int U, int F0, int D0, const snapgpu_single_result &res,
-    uint8_t *lds, uint32_t RL, uint8_t *oriented, uint32_t *lv_cells, uint8_t *ag_scratch, uint32_t *ops, int ops_cap)
+    uint8_t *lds, uint32_t RL, uint8_t *oriented, uint32_t *lv_cells, uint8_t *ag_scratch, uint32_t *ops, int ops_cap, bool paired = false)
 {
     const int lane = lane_id();
     SamFieldsOut o; o.flag = 0; o.contig = -1; o.mapq = 0; o.n_ops = -1; o.nm = -1; o.stale = 0; o.pos = 0;
+    o.final_loc = -1; o.final_dir = 0; o.bases_clipped_before = 0; o.ref_span = 0; o.data_len = 0;
     // the Read's clipping state (Read.h:508-553): front = F0 + addF, dataLength = D0 - addF - addB
     int addF = res.clipping_for_read_adjustment, addB = 0;                                       // ReadWriter.cpp:225
     int status = res.status, direction = res.direction;
@@ -63,7 +67,7 @@ static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
         int bcb, bca;
         if (dir == 1) { bcb = U - clipped_len - front; bca = front; }
         else { bcb = front; bca = U - clipped_len - bcb; }
-        if (ag_branch) {                                                                        // soft clipping from seed extension (:1541-1546; the
+        if (ag_branch || paired) {                                                              // soft clipping from seed extension (:1541-1546; the
             bcb += res.bases_clipped_before; bca += res.bases_clipped_after;                    //  Landau-Vishkin writeRead passes none, ReadWriter.cpp:276)
             clipped_len -= res.bases_clipped_before + res.bases_clipped_after;
         }
@@ -84,7 +88,7 @@ static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
         int afc = 0, nm = -1, n_ops = -1;
         bool star = true;
         long long clip_before = 0, clip_after = 0;
-        if (ag_branch && extra != 0) afc = (int)extra;                                          // SAM.cpp:2193-2196
+        if (ag_branch && !paired && extra != 0) afc = (int)extra;                               // SAM.cpp:2193-2196 (writePairs passes extra on, :1654)
         else if (loc >= 0) {
             if (oriented_dir != dir) {                                                          // the read as SAM prints it (:1520-1538)
                 for (int i = lane; i < U; i += WAVE) {
@@ -99,7 +103,7 @@ static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
             int ed;
             int tail = 0;
             if (ag_branch) {
-                const CigarAGItemOut r = cigar_ag_item(ix, agp, cd, cq, clipped_len, res.score, 0, loc, use_m, lds, RL, ag_scratch, ops, ops_cap);
+                const CigarAGItemOut r = cigar_ag_item(ix, agp, cd, cq, clipped_len, res.score, extra, loc, use_m, lds, RL, ag_scratch, ops, ops_cap);
                 ed = r.edit_distance; afc = r.add_front_clipping; extra_after = r.extra_after; tail = r.tail_ins; n_ops = r.n_ops;
                 if (r.stale) o.stale = 1;
             } else {
@@ -119,6 +123,7 @@ static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
         }
         if (afc == 0) {                                                                         // the record is complete
             o.flag = flag; o.contig = loc >= 0 ? contig : -1; o.pos = pos; o.mapq = mapq; o.nm = nm;
+            o.final_loc = loc; o.final_dir = dir; o.bases_clipped_before = bcb; o.data_len = dlen;
             if (loc < 0) { o.n_ops = -1; return o; }
             if (star) { o.n_ops = -1; return o; }
             // soft clips around the ops: shift right by one when there is a leading clip
@@ -136,10 +141,33 @@ static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
             }
             WAVE_SYNC();
             o.n_ops = n;
+            {   // getRefSpanFromCigar (SAM.cpp:2769-2800): the first op counts unless it is S / H, every later op unless it is I
+                int span = 0;
+                for (int i = 0; i < n; i++) {
+                    const uint32_t v = first_u32(ops[i]);
+                    const uint32_t code = v & 15u;
+                    if (i == 0 ? (code != SAMF_OP_S && code != 5u) : (code != LVC_OP_I)) span += (int)(v >> 4);
+                }
+                o.ref_span = span;
+            }
             return o;
         }
         // ---------------- the caller's reaction to a leading indel (ReadWriter.cpp:240-274 / :282-311)
         n_adj++;
+        if (paired) {                                                                           // SAMFormat::writePairs, SAM.cpp:1660-1684 / :1694-1713
+            const int co = samf_contig_at(ix, final_loc), cn = samf_contig_at(ix, final_loc + afc);
+            if (cn != co || cn < 0 || final_loc + afc > samf_contig_end(ix, co) - (long long)ix.chromosome_padding || n_adj > 2 * (int)RL) {
+                status = SNAPGPU_NotFound; location = -1; direction = 0; final_loc = -1; continue;
+            }
+            if (ag_branch) {
+                if (afc < 0) { cum += afc; if (direction == 0) addF = -cum; else addB = -cum; }
+                else final_loc += afc;
+            } else {
+                if (afc > 0) { cum += afc; addF = cum; }
+                final_loc += afc;
+            }
+            continue;
+        }
         const int c_orig = status == SNAPGPU_NotFound ? -1 : samf_contig_at(ix, location);
         const int c_new = status == SNAPGPU_NotFound ? -1 : samf_contig_at(ix, location + afc);
         const int c_lim = ag_branch ? c_new : c_orig;
@@ -156,4 +184,52 @@ static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
     }
     o.flag = SAMF_UNMAPPED; o.n_ops = -1; o.nm = -1;
     return o;
+}
+
+// SAMFormat::fillMateInfo (SAM.cpp:1308-1421) for one read of a pair, from the two reads' own records.
+// rnext: -1 "*", -2 "=", otherwise a contig index.
+struct SamMateOut { int flag, contig, rnext; long long pos, pnext, tlen; };
+
+static __device__ __forceinline__ SamMateOut sam_fill_mate_info(const DevIndex &ix, const SamFieldsOut &me, const SamFieldsOut &mate, bool first_in_pair, bool aligned_as_pair)
+{
+    SamMateOut m; m.flag = me.flag | 0x1 | (first_in_pair ? 0x40 : 0x80); m.contig = me.contig; m.pos = me.pos; m.rnext = -1; m.pnext = 0; m.tlen = 0;
+    auto contig_for_read = [&](long long loc, int data_len, long long *extra) -> int {          // Genome::getContigForRead, Genome.cpp:734-758
+        int c = samf_contig_at(ix, loc);
+        *extra = 0;
+        if (c < 0 || loc + data_len > samf_contig_end(ix, c)) {
+            c = c + 1; if (c >= (int)ix.n_contigs) c = (int)ix.n_contigs - 1;
+            *extra = (long long)first_u64(ix.contig_begin[c]) - loc;
+        }
+        return c;
+    };
+    long long mate_loc = mate.final_loc, mate_extra = 0;
+    bool rnext_eq = false;
+    if (mate_loc >= 0) {
+        const int mc = contig_for_read(mate_loc, mate.data_len, &mate_extra);
+        mate_loc += mate_extra;
+        m.rnext = mc; m.pnext = mate_loc - (long long)first_u64(ix.contig_begin[mc]) + 1;
+        if (mate.final_dir == 1) m.flag |= 0x20;
+        if (me.final_loc < 0) { m.contig = mc; rnext_eq = true; m.pos = m.pnext; }                // :1347-1356
+    } else {
+        m.flag |= 0x8;
+        rnext_eq = true; m.pnext = m.pos;                                                       // :1358-1365
+    }
+    if (me.final_loc >= 0 && mate.final_loc >= 0) {
+        if (aligned_as_pair) m.flag |= 0x2;
+        long long extra = 0;
+        const int c = contig_for_read(me.final_loc, me.data_len, &extra);
+        const long long loc = me.final_loc + extra;
+        const long long my_start = loc - me.bases_clipped_before - extra, my_end = loc + me.ref_span;
+        const long long mate_start = mate_loc - mate.bases_clipped_before - mate_extra, mate_end = mate_loc + mate.ref_span;
+        m.contig = c;
+        if (my_start < mate_start) {
+            if (me.final_dir == 0) m.tlen = mate.final_dir == 1 ? mate_end - my_start : mate_start - my_start;
+            else m.tlen = mate.final_dir == 0 ? mate_start - my_end : mate_end - my_end;
+        } else {
+            if (me.final_dir == 1) m.tlen = mate.final_dir == 0 ? -(my_end - mate_start) : -(my_end - mate_end);
+            else m.tlen = mate.final_dir == 0 ? -(my_start - mate_start) : -(my_start - mate_end);
+        }
+    }
+    if (rnext_eq || (m.rnext >= 0 && m.rnext == m.contig)) m.rnext = -2;                          // :1418-1420 (pointer equality of the names)
+    return m;
 }

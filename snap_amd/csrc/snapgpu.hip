@@ -898,6 +898,84 @@ extern "C" int snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const cha
     return SNAPGPU_OK;
 }
 
+// paired-end writer: results -> the computed fields of both SAM records of each pair (sam_fields.h, cigar_k.hip)
+extern "C" int snapgpu_sam_fields_paired(snapgpu_ctx *ctx, uint32_t n_pairs, const char *bases, const char *quals, const uint64_t *offsets,
+                                         const int32_t *front_clip, const int32_t *data_len, const snapgpu_paired_result *results, int use_m,
+                                         int32_t *flag, int32_t *contig, int64_t *pos, int32_t *mapq, uint32_t *ops, uint32_t ops_stride,
+                                         int32_t *n_ops, int32_t *nm, int32_t *rnext, int64_t *pnext, int64_t *tlen, int32_t *first_written,
+                                         int32_t *reference_history_dependent)
+{
+    if (!ctx || (n_pairs && (!bases || !quals || !offsets || !front_clip || !data_len || !results || !flag || !contig || !pos || !mapq || !ops ||
+                             !n_ops || !nm || !rnext || !pnext || !tlen || !first_written || !reference_history_dependent)))
+        return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_sam_fields_paired: null argument");
+    if (ops_stride < 3) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_sam_fields_paired: ops_stride must be at least 3");
+    if (n_pairs == 0) return SNAPGPU_OK;
+    const uint32_t n = 2 * n_pairs;
+    uint32_t RL = 64;
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > AGC_MAX_READ_LENGTH)
+            return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_sam_fields_paired: read length out of range");
+        const int64_t U = (int64_t)(offsets[i + 1] - offsets[i]);
+        if (front_clip[i] < 0 || data_len[i] < 0 || (int64_t)front_clip[i] + data_len[i] > U)
+            return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_sam_fields_paired: clipping outside the read");
+        const snapgpu_paired_result &r = results[i >> 1];
+        if (r.status[i & 1] != SNAPGPU_NotFound && (r.location[i & 1] < 0 || (uint64_t)r.location[i & 1] >= ctx->ix.n_bases))
+            return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_sam_fields_paired: location outside the genome");
+        if ((uint32_t)U > RL) RL = (uint32_t)U;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = ctx->stream;
+    const uint32_t per_wave = agc_lds_bytes(RL);
+    if ((size_t)4 * per_wave > 64 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "snapgpu_sam_fields_paired: reads too long for the LDS rows");
+    uint32_t blocks = (uint32_t)ctx->num_cus * 4;
+    const uint32_t need = (n_pairs + 3) / 4; if (blocks > need) blocks = need;
+    const uint64_t scratch_stride = ((2 * (uint64_t)RL + 255) & ~(uint64_t)255) + ((lvc_scratch_bytes() + 255) & ~255u) + ((agc_scratch_bytes(RL) + 255) & ~(uint64_t)255);
+    const uint64_t total = offsets[n];
+    DevBuf db, dq, doff, dfc, ddl, dres, dscr, dflag, dctg, dpos, dmq, dops, dno, dnm, drn, dpn, dtl, dfw, dst;
+    HIPCHK(ctx, db.put(bases, total, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dq.put(quals, total, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, doff.put(offsets, (size_t)(n + 1) * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dfc.put(front_clip, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, ddl.put(data_len, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dres.put(results, (size_t)n_pairs * sizeof(snapgpu_paired_result), s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dscr.put(nullptr, (size_t)blocks * 4 * scratch_stride, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dflag.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dctg.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dpos.put(nullptr, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dmq.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dops.put(nullptr, (size_t)n * ops_stride * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dno.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dnm.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, drn.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dpn.put(nullptr, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dtl.put(nullptr, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dfw.put(nullptr, (size_t)n_pairs * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dst.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, hipMemsetAsync(dops.p, 0, (size_t)n * ops_stride * 4, s), SNAPGPU_E_LAUNCH);
+    SamFieldsPairedArgs a;
+    a.ix = ctx->ix;
+    a.prm.match = (int)ctx->params.match_reward; a.prm.sub = -(int)ctx->params.sub_penalty;
+    a.prm.gap_open = (int)ctx->params.gap_open_penalty + (int)ctx->params.gap_extend_penalty; a.prm.gap_ext = (int)ctx->params.gap_extend_penalty;
+    a.n_pairs = n_pairs; a.RL = RL; a.ops_stride = ops_stride; a.use_m = use_m ? 1u : 0u; a.use_affine_gap = ctx->params.use_affine_gap ? 1u : 0u;
+    a.bases = (const uint8_t *)db.p; a.quals = (const uint8_t *)dq.p; a.offsets = (const uint64_t *)doff.p;
+    a.front_clip = (const int32_t *)dfc.p; a.data_len = (const int32_t *)ddl.p; a.results = (const snapgpu_paired_result *)dres.p;
+    a.scratch = (uint8_t *)dscr.p; a.scratch_stride = scratch_stride; a.work_counter = ctx->d_work;
+    a.flag = (int32_t *)dflag.p; a.contig = (int32_t *)dctg.p; a.pos = (int64_t *)dpos.p; a.mapq = (int32_t *)dmq.p;
+    a.ops = (uint32_t *)dops.p; a.n_ops = (int32_t *)dno.p; a.nm = (int32_t *)dnm.p; a.rnext = (int32_t *)drn.p; a.pnext = (int64_t *)dpn.p;
+    a.tlen = (int64_t *)dtl.p; a.first_written = (int32_t *)dfw.p; a.stale = (int32_t *)dst.p;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    snapgpu_launch_sam_fields_paired(&a, blocks, (size_t)4 * per_wave, s);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    struct { void *h; void *d; size_t b; } outs[] = {
+        {flag, dflag.p, (size_t)n * 4}, {contig, dctg.p, (size_t)n * 4}, {pos, dpos.p, (size_t)n * 8}, {mapq, dmq.p, (size_t)n * 4},
+        {ops, dops.p, (size_t)n * ops_stride * 4}, {n_ops, dno.p, (size_t)n * 4}, {nm, dnm.p, (size_t)n * 4}, {rnext, drn.p, (size_t)n * 4},
+        {pnext, dpn.p, (size_t)n * 8}, {tlen, dtl.p, (size_t)n * 8}, {first_written, dfw.p, (size_t)n_pairs * 4},
+        {reference_history_dependent, dst.p, (size_t)n * 4}};
+    for (auto &o : outs) HIPCHK(ctx, hipMemcpyAsync(o.h, o.d, o.b, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
 extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
                                   const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
                                   const char *patterns, const char *quals, uint64_t patterns_bytes,

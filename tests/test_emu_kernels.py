@@ -184,3 +184,23 @@ def test_emu_native_fastq_to_sam(emu, tmp_path, opts):
     index_dir, fastq = make_workload(str(tmp_path), 800, genome_bases=300_000)
     env = dict(os.environ, SNAPGPU_EMU_CUS="4")
     assert run_and_compare(TOOL, str(tmp_path), index_dir, fastq, opts, env=env, ref_opts=[o for o in opts if o not in ("-b", "97")]) > 800
+
+
+def test_emu_sam_fields_paired(emu):
+    """The paired-end writer on the emulated device (k_sam_fields_paired: both mates' records + SAMFormat::fillMateInfo + print order):
+    the first 400 pairs of the fixture parsed from the unmodified reference CLI's `paired` output, all 9 computed fields."""
+    import tests.test_zz_gpu_cigar as gc
+    z = np.load(os.path.join(util.GOLDEN, "sam_fields_paired.npz"))
+    gc.check_sam_fields_paired_against_reference_cli(z, "default", n_pairs=400)
+
+
+def test_emu_native_paired_fastq_to_sam(emu, tmp_path):
+    """Two FASTQ files in, SAM out, paired end: the native host program on the emulated device writes the same file as `snap-aligner paired`,
+    line for line and in the same order (every line but @PG); 300 hard pairs incl. '#'-clipped mates and pairs too short to align."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.emu.build import TOOL
+    from tests.test_zz_gpu_native_sam import make_paired_workload, run_and_compare_paired
+    index_dir, fq = make_paired_workload(str(tmp_path), 300, genome_bases=300_000)
+    assert run_and_compare_paired(TOOL, str(tmp_path), index_dir, fq, [], env=dict(os.environ, SNAPGPU_EMU_CUS="4")) > 600

@@ -243,3 +243,35 @@ def test_sam_fields_vs_reference_cli_fixture(golden_index, tag):
     z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
     got = check_sam_fields_against_reference_cli(golden_index, z, tag)
     assert int((got["flag"] & 4 != 0).sum()) > 100 and int((got["flag"] & 16 != 0).sum()) > 1000
+
+
+# ---------------------------------------------------------------------------------------------- paired-end writer
+def check_sam_fields_paired_against_reference_cli(z, tag, n_pairs=None):
+    """All 9 computed fields of both records of each pair and the order of the two records, as the unmodified reference CLI printed them
+    (tests/golden/sam_fields_paired.npz, scripts/make_golden_sam_fields_paired.py)."""
+    from snap_amd.aligner import BaseAligner
+    kw = dict(use_affine_gap=0) if tag.startswith("lvonly") else {}
+    a = BaseAligner(util.load_golden_index("paired_index.npz"), abi.default_params(max_read_len=400, **kw))
+    try:
+        npairs = len(z[tag + "_first_written"]) if n_pairs is None else n_pairs
+        n = 2 * npairs
+        offs = z["offsets"][:n + 1]
+        got = a.samFieldsPaired(z["bases"][:int(offs[-1])], z["quals"][:int(offs[-1])], offs, z["front_clip"][:n], z["data_len"][:n],
+                                z[tag + "_results"][:npairs], bool(z[tag + "_use_m"]))
+    finally:
+        a.close()
+    for k in ("flag", "contig", "pos", "mapq", "nm", "n_ops", "rnext", "pnext", "tlen"):
+        bad = np.nonzero(got[k] != z[tag + "_" + k][:n])[0]
+        assert bad.size == 0, (tag, k, bad[:5], got[k][bad[:5]], z[tag + "_" + k][:n][bad[:5]])
+    for i in range(n):
+        assert util.cigar_text(got["ops"][i], got["n_ops"][i]) == util.cigar_text(z[tag + "_ops"][i], z[tag + "_n_ops"][i]), (tag, i)
+    assert (got["first_written"] == z[tag + "_first_written"][:npairs]).all()
+    return got
+
+
+@pytest.mark.parametrize("tag", ["default", "lvonly", "eqx"])
+def test_sam_fields_paired_vs_reference_cli_fixture(tag):
+    import os
+    z = np.load(os.path.join(util.GOLDEN, "sam_fields_paired.npz"))
+    got = check_sam_fields_paired_against_reference_cli(z, tag)
+    assert int((got["flag"] & 2 != 0).sum()) > 1500 and int((got["first_written"] == 1).sum()) > 300

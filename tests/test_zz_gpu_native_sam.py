@@ -70,3 +70,50 @@ def test_native_fastq_to_sam_identical_to_reference_cli(tmp_path_factory, opts):
     d = str(tmp_path_factory.mktemp("native"))
     index_dir, fastq = make_workload(d, 20000, genome_bases=3_000_000)
     assert run_and_compare(TOOL, d, index_dir, fastq, opts) > 20000
+
+
+def make_paired_workload(d, n_pairs, genome_bases=600_000):
+    from tests.pairs_util import hard_pairs
+    contigs = synth.make_genome(178, genome_bases, n_contigs=3, repeat_frac=0.15)
+    fasta = os.path.join(d, "g.fa"); synth.write_fasta(fasta, contigs)
+    index_dir = os.path.join(d, "index")
+    ref.build_index(fasta, index_dir, seed_len=20, threads=max(1, min(8, os.cpu_count() or 1)))
+    pr = hard_pairs(27, contigs, n_pairs, 150, insert_mean=380)
+    o = pr["offsets"].astype(np.int64)
+    rng = np.random.default_rng(29)
+    fq = [os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")]
+    files = [open(f, "wb") for f in fq]
+    for i in range(n_pairs):
+        short = i % 53 == 7                                    # both mates below -mrl: the pair is written unaligned
+        for w in (0, 1):
+            b = pr["bases"][o[2 * i + w]:o[2 * i + w + 1]].copy(); q = pr["quals"][o[2 * i + w]:o[2 * i + w + 1]].copy()
+            if (2 * i + w) % 19 == 3: q[len(q) - int(rng.integers(1, 30)):] = ord("#")
+            if short: b, q = b[:40], q[:40]
+            files[w].write(b"@pair%d/%d\n" % (i, w + 1) + b.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
+    for f in files:
+        f.close()
+    return index_dir, fq
+
+
+def run_and_compare_paired(tool, d, index_dir, fq, opts, env=None):
+    tag = "_".join(o.strip("-") or "eq" for o in opts) or "default"
+    out_ref, out_new = os.path.join(d, "pref_%s.sam" % tag), os.path.join(d, "pnew_%s.sam" % tag)
+    for cmd, e in (([ref.CLI_PATH, "paired", index_dir, fq[0], fq[1], "-o", out_ref, "-t", "1"] + opts, None), ([tool, "paired", index_dir, fq[0], fq[1], "-o", out_new] + opts, env)):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=3000, env=e)
+        assert r.returncode == 0, "%s failed:\n%s" % (cmd[0], r.stdout.decode(errors="replace")[-3000:])
+    a = [line for line in open(out_ref) if not line.startswith("@PG")]          # not sorted: with -t 1 the reference keeps the input order,
+    b = [line for line in open(out_new) if not line.startswith("@PG")]          # and the order of the two records of a pair is part of the contract
+    assert len(a) == len(b)
+    diff = [(x, y) for x, y in zip(a, b) if x != y]
+    assert not diff, "%d of %d lines differ, first:\n%s%s" % (len(diff), len(a), diff[0][0], diff[0][1])
+    return len(a)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="]])
+def test_native_paired_fastq_to_sam_identical_to_reference_cli(tmp_path_factory, opts):
+    assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
+    d = str(tmp_path_factory.mktemp("nativep"))
+    index_dir, fq = make_paired_workload(d, 6000, genome_bases=3_000_000)
+    assert run_and_compare_paired(TOOL, d, index_dir, fq, opts) > 12000
