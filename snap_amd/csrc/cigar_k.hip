@@ -77,7 +77,7 @@ extern "C" void snapgpu_launch_cigar_ag(const CigarAGArgs *a, uint32_t blocks, s
 }
 
 // result -> computed fields of the SAM record (sam_fields.h): one wavefront per read
-__global__ __launch_bounds__(256) void k_sam_fields(SamFieldsArgs a)
+__global__ __launch_bounds__(256, 4) void k_sam_fields(SamFieldsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id();
@@ -126,7 +126,7 @@ extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t block
 }
 
 // paired-end writer: both reads of a pair by one wavefront, then SAMFormat::fillMateInfo for each (sam_fields.h)
-__global__ __launch_bounds__(256) void k_sam_fields_paired(SamFieldsPairedArgs a)
+__global__ __launch_bounds__(256, 4) void k_sam_fields_paired(SamFieldsPairedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id();

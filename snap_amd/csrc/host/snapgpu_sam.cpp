@@ -4,7 +4,7 @@
 // Streams FASTQ records in batches across include/snapgpu.h -- snapgpu_align_single (BaseAligner::AlignRead) and
 // snapgpu_sam_fields_single (what SimpleReadWriter::writeReads / SAMFormat::writeRead compute before they print) -- and prints the
 // records the way the reference does.  What is restated here is host-side text handling only:
-//   FASTQReader::getReadFromBuffer   SNAPLib/FASTQ.cpp:148-260   (4-line records, '\r' tolerated)
+//   FASTQReader::getReadFromBuffer   SNAPLib/FASTQ.cpp:148-260   (4-line records, '\r' tolerated; plain or gzip input through zlib)
 //   Read::clip (ClipBack)            SNAPLib/Read.h:567-620      (the CLI default -C-+: drop the trailing run of '#' qualities)
 //   the "useless read" filter        SNAPLib/SingleAligner.cpp:211-232 (dataLength < -mrl or more Ns than -d: written unaligned)
 //   SAMFormat::writeHeader           SNAPLib/SAM.cpp:1204-1305   (@HD, default @RG, @PG, one @SQ per contig)
@@ -18,6 +18,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <zlib.h>                        // gzopen reads plain and gzip-compressed FASTQ alike (the reference takes .gz input too)
 
 #include "../../../include/snapgpu.h"
 
@@ -58,16 +59,20 @@ struct Batch {
     void clear() { names.clear(); bases.clear(); quals.clear(); offsets.assign(1, 0); }
 };
 
-static bool get_line(FILE *f, std::string &s)
+static bool get_line(gzFile f, std::string &s)
 {
     s.clear();
-    int c;
-    while ((c = fgetc(f)) != EOF) { if (c == '\n') { if (!s.empty() && s.back() == '\r') s.pop_back(); return true; } s.push_back((char)c); }
+    char buf[4096];
+    while (gzgets(f, buf, (int)sizeof(buf)) != NULL) {
+        const size_t n = strlen(buf);
+        s.append(buf, n);
+        if (n > 0 && buf[n - 1] == '\n') { s.pop_back(); if (!s.empty() && s.back() == '\r') s.pop_back(); return true; }
+    }
     return !s.empty();
 }
 
 // one FASTQ record; false at end of file
-static bool next_read(FILE *f, std::string &id, std::string &seq, std::string &qual)
+static bool next_read(gzFile f, std::string &id, std::string &seq, std::string &qual)
 {
     std::string plus;
     if (!get_line(f, id)) return false;
@@ -115,11 +120,12 @@ int main(int argc, char **argv)
     int rc = snapgpu_create_from_directory(index_dir.c_str(), &p, 0, &ctx);
     if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_create_from_directory failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
 
-    FILE *in = fopen(fastq.c_str(), "rb");
+    gzFile in = gzopen(fastq.c_str(), "rb");
     if (!in) die("cannot open ", fastq.c_str());
-    FILE *in2 = NULL;
+    gzbuffer(in, 1 << 20);
+    gzFile in2 = NULL;
     if (paired) {
-        in2 = fopen(fastq2.c_str(), "rb");
+        in2 = gzopen(fastq2.c_str(), "rb");
         if (!in2) die("cannot open ", fastq2.c_str());
         snapgpu_paired_params pp; snapgpu_default_paired_params(&pp);
         pp.min_read_length = min_read_len;
@@ -298,7 +304,7 @@ int main(int argc, char **argv)
         }
         total += n;
     }
-    fclose(out); fclose(in); if (in2) fclose(in2);
+    fclose(out); gzclose(in); if (in2) gzclose(in2);
     snapgpu_destroy(ctx);
     fprintf(stderr, "snapgpu-sam: %llu reads, %llu aligned\n", total, aligned);
     return 0;

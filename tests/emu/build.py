@@ -60,7 +60,7 @@ def build(verbose=False):
     # the native FASTQ -> SAM host program, linked against the emulated library (same source as snap_amd/snapgpu-sam)
     tool_src = os.path.join(CSRC, "host", "snapgpu_sam.cpp")
     if not os.path.exists(TOOL) or os.path.getmtime(TOOL) < max(os.path.getmtime(tool_src), os.path.getmtime(LIB)):
-        _run([CXX, "-O2", "-std=c++17", "-o", TOOL, tool_src, "-L" + BDIR, "-lsnapgpu_emu", "-Wl,-rpath," + BDIR, "-lpthread"])
+        _run([CXX, "-O2", "-std=c++17", "-o", TOOL, tool_src, "-L" + BDIR, "-lsnapgpu_emu", "-Wl,-rpath," + BDIR, "-lpthread", "-lz"])
     return LIB
 
 
