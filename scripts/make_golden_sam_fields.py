@@ -2,7 +2,8 @@
 (oracle/_ref/snap-aligner single ... -o out.sam), together with what snapgpu_sam_fields_single needs to compute them: the reads
 as written to the FASTQ, Read::clip's outcome (ClipBack of '#', the CLI default) and the reference aligner's result for each read
 (oracle/_ref/libsnapref.so, same options).  Genome = the golden genome of make_golden.py (locations are tiny_index.npz's).
-Four option sets: default (affine-gap cigars, M), -G- (Landau-Vishkin cigars only), and both with -= (= / X instead of M)."""
+Six option sets: default (affine-gap cigars, M), -G- (Landau-Vishkin cigars only), both with -= (= / X instead of M), and both with -C++ (the reader
+also clips a leading run of '#': front_clip > 0)."""
 import os, sys, shutil, subprocess
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -44,6 +45,8 @@ for tag, n in (('100', 1400), ('150', 1000)):
         elif kind == 6: j = int(rng.integers(2, 8)); bb = np.delete(bb, j); qq = qq[:len(bb)]         # deletion right after the start
         elif kind == 7: j = int(rng.integers(2, 8)); bb = np.insert(bb, j, ACGT[rng.integers(0, 4)])[:len(qq)]   # insertion right after the start
         elif kind == 8: lowq = rng.random(len(qq)) < 0.4; qq[lowq] = rng.integers(35, 64, size=int(lowq.sum()))
+        elif kind == 9: qq[:int(rng.integers(1, 25))] = ord('#')                                   # '#' head: clipped only with -C++
+        elif kind == 10: qq[:int(rng.integers(1, 15))] = ord('#'); qq[len(qq) - int(rng.integers(1, 15)):] = ord('#')
         reads.append((bb, qq))
 # reads around contig boundaries: starting before the first base of a contig (the aligner may place them in the padding), ending past the last
 nb = idx.n_bases
@@ -67,24 +70,34 @@ with open(W + '/r.fq', 'wb') as f:
 
 bases = np.concatenate([r[0] for r in reads]); quals = np.concatenate([r[1] for r in reads])
 offsets = np.concatenate([[0], np.cumsum([len(r[0]) for r in reads])]).astype(np.uint64)
-front_clip = np.zeros(n, dtype=np.int32); data_len = np.zeros(n, dtype=np.int32)
-for i, (b, q) in enumerate(reads):                       # Read::clip, ClipBack (Read.h:567-620): drop the trailing run of '#'
-    m = len(q)
-    while m > 0 and q[m - 1] == ord('#'):
-        m -= 1
-    data_len[i] = m
-out = dict(bases=bases, quals=quals, offsets=offsets, front_clip=front_clip, data_len=data_len,
-           contig_names=np.array([c.name for c in idx.contigs]))
+def clip_all(front_too):                                 # Read::clip (Read.h:567-620): ClipBack drops the trailing run of '#', ClipFrontAndBack then the leading one
+    fc = np.zeros(n, dtype=np.int32); dl = np.zeros(n, dtype=np.int32)
+    for i, (b, q) in enumerate(reads):
+        m = len(q)
+        while m > 0 and q[m - 1] == ord('#'):
+            m -= 1
+        f = 0
+        if front_too:
+            while f < m and q[f] == ord('#'):
+                f += 1
+        fc[i] = f; dl[i] = m - f
+    return fc, dl
+
+
+out = dict(bases=bases, quals=quals, offsets=offsets, contig_names=np.array([c.name for c in idx.contigs]))
 contig_of = {c.name: i for i, c in enumerate(idx.contigs)}
 CIG = {c: i for i, c in enumerate('MIDNSHP=X')}
-for tag, cli, kw, use_m in (('default', [], {}, 1), ('lvonly', ['-G-'], dict(use_affine_gap=0), 1), ('eqx', ['-='], {}, 0), ('lvonly_eqx', ['-G-', '-='], dict(use_affine_gap=0), 0)):
+for tag, cli, kw, use_m in (('default', [], {}, 1), ('lvonly', ['-G-'], dict(use_affine_gap=0), 1), ('eqx', ['-='], {}, 0), ('lvonly_eqx', ['-G-', '-='], dict(use_affine_gap=0), 0),
+                            ('clipfront', ['-C++'], {}, 1), ('clipfront_lvonly', ['-C++', '-G-'], dict(use_affine_gap=0), 1)):
+    front_clip, data_len = clip_all(tag.startswith('clipfront'))
+    out['%s_front_clip' % tag] = front_clip; out['%s_data_len' % tag] = data_len
     sam = W + '/out_%s.sam' % tag
     r = subprocess.run([ref.CLI_PATH, 'single', W + '/idx', W + '/r.fq', '-o', sam, '-t', '1'] + cli, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     # what the CLI's aligner saw: clipped reads that pass the filters (SingleAligner.cpp:213-233: -mrl 50, more Ns than -d 14? no: maxDist)
     p = abi.default_params(max_read_len=400, **kw)
-    keep = [i for i in range(n) if data_len[i] >= 50 and int((reads[i][0][:data_len[i]] == ord('N')).sum()) <= int(p.max_k)]
-    kb = np.concatenate([reads[i][0][:data_len[i]] for i in keep]); kq = np.concatenate([reads[i][1][:data_len[i]] for i in keep])
+    keep = [i for i in range(n) if data_len[i] >= 50 and int((reads[i][0][front_clip[i]:front_clip[i] + data_len[i]] == ord('N')).sum()) <= int(p.max_k)]
+    kb = np.concatenate([reads[i][0][front_clip[i]:front_clip[i] + data_len[i]] for i in keep]); kq = np.concatenate([reads[i][1][front_clip[i]:front_clip[i] + data_len[i]] for i in keep])
     ko = np.concatenate([[0], np.cumsum([data_len[i] for i in keep])]).astype(np.uint64)
     prim, _, _, _ = ri.align_single(p, kb, kq, ko, threads=1)
     results = np.zeros(n, dtype=abi.RESULT_DTYPE)

@@ -1,5 +1,5 @@
 // snapgpu_sam.cpp -- FASTQ batcher + SAM writer over the C ABI: the host side of
-//     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-mrl minReadLength] [-b readsPerBatch]
+//     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-Cxx] [-mrl minReadLength] [-b readsPerBatch]
 //     snapgpu-sam paired <index-dir> <reads1.fq> <reads2.fq> -o <out.sam> [same options]
 // Streams FASTQ records in batches across include/snapgpu.h -- snapgpu_align_single (BaseAligner::AlignRead) and
 // snapgpu_sam_fields_single (what SimpleReadWriter::writeReads / SAMFormat::writeRead compute before they print) -- and prints the
@@ -98,6 +98,7 @@ int main(int argc, char **argv)
     bool use_m = true;                                                     // AlignerOptions.cpp:58
     unsigned min_read_len = 50;                                            // -mrl, AlignerOptions.cpp
     size_t batch_reads = 65536;
+    bool clip_front = false, clip_back = true;                             // -C-+ (ClipBack) is the default
     std::string cl = argv[1];
     for (int i = 2; i < argc; i++) { cl += " "; cl += argv[i]; }
     for (int i = paired ? 5 : 4; i < argc; i++) {
@@ -107,6 +108,7 @@ int main(int argc, char **argv)
         else if (a == "-G-") p.use_affine_gap = 0;
         else if (a == "-=") use_m = false;
         else if (a == "-M") use_m = true;
+        else if (a.size() == 4 && a.compare(0, 2, "-C") == 0 && strchr("+-", a[2]) && strchr("+-", a[3])) { clip_front = a[2] == '+'; clip_back = a[3] == '+'; }   // AlignerOptions.cpp: -Cxx
         else if (a == "-mrl" && i + 1 < argc) min_read_len = (unsigned)atoi(argv[++i]);
         else if (a == "-b" && i + 1 < argc) batch_reads = (size_t)atoll(argv[++i]);
         else if (a == "-t" && i + 1 < argc) ++i;                           // host threads: nothing to do here
@@ -162,11 +164,13 @@ int main(int argc, char **argv)
         std::vector<char> useful(n, 0);
         for (size_t i = 0; i < n; i++) {
             const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
-            size_t m = (size_t)(b.offsets[i + 1] - b.offsets[i]);
-            while (m > 0 && q[m - 1] == '#') m--;
+            size_t m = (size_t)(b.offsets[i + 1] - b.offsets[i]), fc = 0;
+            if (clip_back) while (m > 0 && q[m - 1] == '#') m--;               // Read::clip, Read.h:586-608: back first, then front
+            if (clip_front) while (fc < m && q[fc] == '#') fc++;
+            front_clip[i] = (int32_t)fc; m -= fc;
             data_len[i] = (int32_t)m;
             unsigned n_count = 0;
-            for (size_t j = 0; j < m; j++) n_count += s[j] == 'N';
+            for (size_t j = 0; j < m; j++) n_count += s[fc + j] == 'N';
             useful[i] = m >= min_read_len && n_count <= p.max_k;
         }
         std::vector<uint32_t> to_align;                                     // pairs with at least one useful mate (PairedAligner.cpp:680-682)
@@ -176,7 +180,7 @@ int main(int argc, char **argv)
             to_align.push_back((uint32_t)k);
             for (size_t i = 2 * k; i < 2 * k + 2; i++) {
                 const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
-                ab.insert(ab.end(), s, s + data_len[i]); aq.insert(aq.end(), q, q + data_len[i]); ao.push_back(ab.size());
+                ab.insert(ab.end(), s + front_clip[i], s + front_clip[i] + data_len[i]); aq.insert(aq.end(), q + front_clip[i], q + front_clip[i] + data_len[i]); ao.push_back(ab.size());
             }
         }
         std::vector<snapgpu_paired_result> results(np), ares(to_align.size()), aalt(to_align.size());
@@ -252,14 +256,16 @@ int main(int argc, char **argv)
         std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
         for (size_t i = 0; i < n; i++) {
             const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
-            size_t m = (size_t)(b.offsets[i + 1] - b.offsets[i]);
-            while (m > 0 && q[m - 1] == '#') m--;
+            size_t m = (size_t)(b.offsets[i + 1] - b.offsets[i]), fc = 0;
+            if (clip_back) while (m > 0 && q[m - 1] == '#') m--;               // Read::clip, Read.h:586-608: back first, then front
+            if (clip_front) while (fc < m && q[fc] == '#') fc++;
+            front_clip[i] = (int32_t)fc; m -= fc;
             data_len[i] = (int32_t)m;
             unsigned n_count = 0;
-            for (size_t j = 0; j < m; j++) n_count += s[j] == 'N';
+            for (size_t j = 0; j < m; j++) n_count += s[fc + j] == 'N';
             if (m >= min_read_len && n_count <= p.max_k) {
                 to_align.push_back((uint32_t)i);
-                ab.insert(ab.end(), s, s + m); aq.insert(aq.end(), q, q + m); ao.push_back(ab.size());
+                ab.insert(ab.end(), s + fc, s + fc + m); aq.insert(aq.end(), q + fc, q + fc + m); ao.push_back(ab.size());
             }
         }
         std::vector<snapgpu_single_result> results(n), aligned_res(to_align.size()), alt_res(to_align.size());

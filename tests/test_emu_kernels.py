@@ -163,16 +163,17 @@ def test_emu_compute_cigar_affine_gap(emu, emu_aligner):
         gc.check_ag_against_fixture(emu_aligner, z, use_m, step=3)
 
 
-@pytest.mark.parametrize("tag", ["default", "lvonly_eqx"])
+@pytest.mark.parametrize("tag", ["default", "lvonly_eqx", "clipfront"])
 def test_emu_sam_fields(emu, golden_index, tag):
     """Results -> FLAG / RNAME / POS / MAPQ / CIGAR / NM on the emulated device (k_sam_fields: the writeReads retry loop, createSAMLine,
-    both cigar variants, soft clips), against what the unmodified reference CLI printed: every second read of the fixture."""
+    both cigar variants, soft clips), against what the unmodified reference CLI printed: every third read of the fixture
+    (clipfront: the CLI run with -C++, so that Read::clip also removed a leading run of '#')."""
     import tests.test_zz_gpu_cigar as gc
     z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
-    gc.check_sam_fields_against_reference_cli(golden_index, z, tag, step=2)
+    gc.check_sam_fields_against_reference_cli(golden_index, z, tag, step=3)
 
 
-@pytest.mark.parametrize("opts", [[], ["-G-", "-=", "-b", "97"]])          # -b 97: nine batches, the last one short
+@pytest.mark.parametrize("opts", [[], ["-G-", "-=", "-C++", "-b", "97"]])     # -b 97: nine batches, the last one short; -C++: '#' heads clipped too
 def test_emu_native_fastq_to_sam(emu, tmp_path, opts):
     """FASTQ in, SAM out: the native host program (snap_amd/csrc/host/snapgpu_sam.cpp, linked against the emulated library) writes the
     same file as the unmodified reference CLI, every line but @PG; 800 reads incl. ragged / '#'-clipped / N-rich / unalignable ones."""

@@ -209,23 +209,23 @@ def test_compute_cigar_ag_vs_live_reference(cig_aligner, golden_index, tmp_path)
 
 
 # ---------------------------------------------------------------------------------------------- result -> SAM record fields
-SAMF_SETS = ["default", "lvonly", "eqx", "lvonly_eqx"]
+SAMF_SETS = ["default", "lvonly", "eqx", "lvonly_eqx", "clipfront", "clipfront_lvonly"]
 
 
 def check_sam_fields_against_reference_cli(golden_index, z, tag, step=1):
     """FLAG / RNAME / POS / MAPQ / CIGAR / NM as the unmodified reference CLI printed them (tests/golden/sam_fields.npz,
     scripts/make_golden_sam_fields.py) from the reads, Read::clip's outcome and the reference aligner's results."""
     from snap_amd.aligner import BaseAligner
-    kw = dict(use_affine_gap=0) if tag.startswith("lvonly") else {}
+    kw = dict(use_affine_gap=0) if "lvonly" in tag else {}
     a = BaseAligner(golden_index, abi.default_params(max_k=14, max_read_len=400, **kw))
     try:
-        n = len(z["front_clip"])
+        n = len(z[tag + "_front_clip"])
         sel = np.arange(0, n, step)
         offs = z["offsets"]
         lens = (offs[1:] - offs[:-1])[sel]
         o2 = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
         take = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in sel]).astype(np.int64)
-        got = a.samFields(z["bases"][take], z["quals"][take], o2, z["front_clip"][sel], z["data_len"][sel], z[tag + "_results"][sel],
+        got = a.samFields(z["bases"][take], z["quals"][take], o2, z[tag + "_front_clip"][sel], z[tag + "_data_len"][sel], z[tag + "_results"][sel],
                           bool(z[tag + "_use_m"]))
     finally:
         a.close()

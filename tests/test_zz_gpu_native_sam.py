@@ -64,7 +64,7 @@ def run_and_compare(tool, d, index_dir, fastq, opts, env=None, ref_opts=None):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
-@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"]])
+@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"], ["-C++"]])
 def test_native_fastq_to_sam_identical_to_reference_cli(tmp_path_factory, opts):
     assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
     d = str(tmp_path_factory.mktemp("native"))
