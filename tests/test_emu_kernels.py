@@ -150,7 +150,7 @@ def test_emu_other_index_shapes(emu, tmp_path, seed_len, large):
     from oracle import ref
     if not ref.available() or not os.path.exists(ref.CLI_PATH):
         pytest.skip("oracle/_ref not built here")
-    from tests.test_zz_gpu_index_shapes import align_and_compare
+    from tests.test_zy_gpu_index_shapes import align_and_compare
     align_and_compare(str(tmp_path), seed_len, large, 600)
 
 

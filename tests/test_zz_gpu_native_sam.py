@@ -62,13 +62,18 @@ def run_and_compare(tool, d, index_dir, fastq, opts, env=None, ref_opts=None):
     return len(a)
 
 
+@pytest.fixture(scope="module")
+def single_workload(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("native"))
+    return (d,) + make_workload(d, 20000, genome_bases=3_000_000)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
 @pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"], ["-C++"]])
-def test_native_fastq_to_sam_identical_to_reference_cli(tmp_path_factory, opts):
+def test_native_fastq_to_sam_identical_to_reference_cli(single_workload, opts):
     assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
-    d = str(tmp_path_factory.mktemp("native"))
-    index_dir, fastq = make_workload(d, 20000, genome_bases=3_000_000)
+    d, index_dir, fastq = single_workload
     assert run_and_compare(TOOL, d, index_dir, fastq, opts) > 20000
 
 
@@ -109,11 +114,16 @@ def run_and_compare_paired(tool, d, index_dir, fq, opts, env=None):
     return len(a)
 
 
+@pytest.fixture(scope="module")
+def paired_workload(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("nativep"))
+    return (d,) + make_paired_workload(d, 6000, genome_bases=3_000_000)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
 @pytest.mark.parametrize("opts", [[], ["-G-"], ["-="]])
-def test_native_paired_fastq_to_sam_identical_to_reference_cli(tmp_path_factory, opts):
+def test_native_paired_fastq_to_sam_identical_to_reference_cli(paired_workload, opts):
     assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
-    d = str(tmp_path_factory.mktemp("nativep"))
-    index_dir, fq = make_paired_workload(d, 6000, genome_bases=3_000_000)
+    d, index_dir, fq = paired_workload
     assert run_and_compare_paired(TOOL, d, index_dir, fq, opts) > 12000
