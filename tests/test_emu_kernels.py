@@ -205,3 +205,15 @@ def test_emu_native_paired_fastq_to_sam(emu, tmp_path):
     from tests.test_zz_gpu_native_sam import make_paired_workload, run_and_compare_paired
     index_dir, fq = make_paired_workload(str(tmp_path), 300, genome_bases=300_000)
     assert run_and_compare_paired(TOOL, str(tmp_path), index_dir, fq, [], env=dict(os.environ, SNAPGPU_EMU_CUS="4")) > 600
+
+
+def test_emu_option_sets(emu, tmp_path):
+    """Option sets no fixture pins (-h 16, seed coverage instead of -n, -D 3, other scoring parameters and end bonuses), 250 reads of a
+    repeat-rich genome with an ALT contig against the compiled reference, work counters included."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.test_zy_gpu_index_shapes import OPTION_SETS, option_workload, check_option_set
+    ix, ri, rd = option_workload(str(tmp_path), 250)
+    for kw in (OPTION_SETS[0], OPTION_SETS[4], OPTION_SETS[7], OPTION_SETS[12], OPTION_SETS[14]):
+        check_option_set(ix, ri, rd, kw)

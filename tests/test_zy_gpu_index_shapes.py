@@ -49,3 +49,52 @@ def align_and_compare(tmp, seed_len, large, n_reads, genome_bases=400_000):
 @pytest.mark.parametrize("seed_len,large", SHAPES)
 def test_index_shapes_vs_live_reference(tmp_path, seed_len, large):
     align_and_compare(str(tmp_path), seed_len, large, 20000, genome_bases=2_000_000)
+
+
+# ---- option sets beyond the ones the fixtures pin (-h, -n, -sc, -D, -d, scoring parameters, end bonuses, ALT gap), against the live reference
+OPTION_SETS = [dict(max_hits=16), dict(max_hits=2000, max_k=12), dict(num_seeds=5), dict(num_seeds=0, seed_coverage=2.0),
+               dict(num_seeds=0, seed_coverage=0.5, max_k=20), dict(min_weight_to_check=2), dict(extra_search_depth=0),
+               dict(extra_search_depth=3, max_k=10), dict(max_k=4), dict(max_k=30), dict(max_score_gap_to_prefer_non_alt=0),
+               dict(max_score_gap_to_prefer_non_alt=8, emit_alt_alignments=1),
+               dict(match_reward=2, sub_penalty=3, gap_open_penalty=5, gap_extend_penalty=2), dict(five_prime_end_bonus=0, three_prime_end_bonus=0),
+               dict(five_prime_end_bonus=20, three_prime_end_bonus=3, max_k=15), dict(use_affine_gap=0, max_hits=50, num_seeds=40)]
+
+
+def option_workload(tmp, n_reads):
+    from snap_amd.index import GenomeIndex
+    g = synth.make_genome(311, 500_000, n_contigs=3, repeat_frac=0.45, max_copies=300, n_run_frac=0.002)
+    rng = np.random.default_rng(3)
+    alt = g[0][1][30_000:42_000].copy(); m = rng.random(alt.size) < 0.01; alt[m] = synth._ACGT[rng.integers(0, 4, size=int(m.sum()))]
+    g.append(("alt1", alt))
+    fa = os.path.join(tmp, "ref.fa"); synth.write_fasta(fa, g)
+    d = os.path.join(tmp, "idx")
+    ref.build_index(fa, d, 20, threads=max(1, min(8, os.cpu_count() or 1)), extra=["-altContigName", "alt1"])
+    return GenomeIndex.load_from_directory(d), ref.RefIndex(d), synth.make_reads(5, g, n_reads, 150, sub=0.02, ins=0.004, dele=0.004, n_frac=0.001)
+
+
+def check_option_set(ix, ri, rd, kw):
+    from snap_amd.aligner import BaseAligner
+    p = abi.default_params(max_read_len=160, **kw)
+    pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
+    a = BaseAligner(ix, p)
+    try:
+        pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"]); c = a.counters()
+    finally:
+        a.close()
+    flagged = pg["reserved"] != 0
+    assert flagged.sum() <= 2 + 0.005 * len(pg)
+    problems = util.compare_results(pr, pg, exclude=flagged)
+    assert (ar["status"] == ag["status"])[~flagged].all()
+    sel = (ar["status"] != 0) & ~flagged
+    problems += util.compare_results(ar[sel], ag[sel], "firstALT")
+    assert not problems, (kw, problems)
+    if not flagged.any():
+        assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == [cr["lookups"], cr["lv"], cr["ag"]], kw
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+def test_option_sets_vs_live_reference(tmp_path):
+    ix, ri, rd = option_workload(str(tmp_path), 8000)
+    for kw in OPTION_SETS:
+        check_option_set(ix, ri, rd, kw)
