@@ -352,7 +352,8 @@ int  snapgpu_compute_cigar_ag(snapgpu_ctx *ctx, uint32_t n, const char *data, co
  * cigar and NM.  Printing names, sequence and tags stays with the caller.
  * Inputs: the reads as they came from the file (bases, quals, offsets[n + 1]), Read::clip's outcome for each (front_clip[i] bases
  * clipped in front, data_len[i] bases kept: what BaseAligner::AlignRead was given), and its result.
- * Outputs per read: flag (0x4 unmapped, 0x10 reverse strand), contig (index into the index's contig table, -1 unmapped), pos
+ * Outputs per read: flag (0x4 unmapped, 0x10 reverse strand, 0x800 when the result says supplementary; a caller that writes a secondary
+ * result ORs 0x100 in itself, as createSAMLine does from its argument), contig (index into the index's contig table, -1 unmapped), pos
  * (1-based, 0 unmapped), mapq, ops / n_ops (BAM cigar ops incl. S = 4; n_ops = -1: "*"), nm (NM:i, -1 unmapped),
  * reference_history_dependent (see snapgpu_compute_cigar_ag).
  */
@@ -503,8 +504,9 @@ int  snapgpu_align_paired_secondary_device(snapgpu_ctx *ctx, uint32_t n_pairs, c
 /* Counters accumulated by snapgpu_align_single* since the last reset (device -> host). */
 int  snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int reset);
 
-/* Average duration in milliseconds of the last `align` kernel launches measured with
- * hipEvents on the launch stream (bench.py roofline), and how many launches that covers. */
+/* Total duration in milliseconds of the kernel launches since the last reset, measured with hipEvents on the launch stream
+ * (bench.py roofline), and how many launches that covers: the align kernels and the SAM-side kernels (snapgpu_compute_cigar_*,
+ * snapgpu_sam_fields_*) share the accumulator, so reset before the call you want to time. */
 int  snapgpu_kernel_time(snapgpu_ctx *ctx, double *total_ms, uint64_t *n_launches, int reset);
 
 #ifdef __cplusplus

@@ -23,8 +23,11 @@ fc = np.zeros(n, np.int32); dl = np.full(n, 150, np.int32)
 out = {"reads": n, "align_s_incl_copies": t_align}
 for use_m in (True, False):
     a.samFields(rd["bases"], rd["quals"], rd["offsets"], fc, dl, prim, use_m)          # warm-up
+    a.kernel_time(reset=True)
     t0 = time.time(); r = a.samFields(rd["bases"], rd["quals"], rd["offsets"], fc, dl, prim, use_m); dt = time.time() - t0
-    out["sam_fields_%s" % ("M" if use_m else "eqx")] = {"s_incl_copies": dt, "reads_per_s": n / dt, "mapped": int((r["flag"] & 4 == 0).sum()),
+    kms, kn = a.kernel_time(reset=True)
+    out["sam_fields_%s" % ("M" if use_m else "eqx")] = {"s_incl_copies": dt, "reads_per_s": n / dt, "kernel_ms": kms, "kernel_reads_per_s": n / (kms / 1e3) if kms else None,
+                                                          "algorithmic_GBps": (n * (3 * 150 + 127 + 4 * float(r["n_ops"][r["n_ops"] > 0].mean()) + 32)) / (kms / 1e3) / 1e9 if kms else None, "mapped": int((r["flag"] & 4 == 0).sum()),
                                                           "mean_ops": float(r["n_ops"][r["n_ops"] > 0].mean())}
 a.close()
 print(json.dumps(out))

@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256, 4) void k_sam_fields(SamFieldsArgs a)
             r.used_affine_gap_scoring = (int32_t)first_u32((uint32_t)rp->used_affine_gap_scoring);
             r.bases_clipped_before = (int32_t)first_u32((uint32_t)rp->bases_clipped_before);
             r.bases_clipped_after = (int32_t)first_u32((uint32_t)rp->bases_clipped_after);
-            r.ag_score = 0; r.supplementary = 0; r.seed_offset = 0; r.match_probability = 0.0; r.probability_all_candidates = 0.0;
-            r.popular_seeds_skipped = 0; r.reserved = 0;
+            r.ag_score = 0; r.supplementary = (int32_t)first_u32((uint32_t)rp->supplementary); r.seed_offset = 0; r.match_probability = 0.0;
+            r.probability_all_candidates = 0.0; r.popular_seeds_skipped = 0; r.reserved = 0;
         }
         uint32_t *ops = a.ops + (size_t)i * a.ops_stride;
         const int F0 = (int)first_u32((uint32_t)a.front_clip[i]), D0 = (int)first_u32((uint32_t)a.data_len[i]);
@@ -158,8 +158,8 @@ __global__ __launch_bounds__(256, 4) void k_sam_fields_paired(SamFieldsPairedArg
             r.used_affine_gap_scoring = (int32_t)first_u32((uint32_t)pr->used_affine_gap_scoring[w]);
             r.bases_clipped_before = (int32_t)first_u32((uint32_t)pr->bases_clipped_before[w]);
             r.bases_clipped_after = (int32_t)first_u32((uint32_t)pr->bases_clipped_after[w]);
-            r.ag_score = 0; r.supplementary = 0; r.seed_offset = 0; r.match_probability = 0.0; r.probability_all_candidates = 0.0;
-            r.popular_seeds_skipped = 0; r.reserved = 0;
+            r.ag_score = 0; r.supplementary = (int32_t)first_u32((uint32_t)pr->supplementary[w]); r.seed_offset = 0; r.match_probability = 0.0;
+            r.probability_all_candidates = 0.0; r.popular_seeds_skipped = 0; r.reserved = 0;
             const int F0 = (int)first_u32((uint32_t)a.front_clip[ri]), D0 = (int)first_u32((uint32_t)a.data_len[ri]);
             o[w] = sam_fields_single_item(a.ix, prm, a.use_affine_gap != 0, a.use_m != 0, a.bases + b, a.quals + b, (int)(e - b), F0, D0, r,
                                           my, a.RL, oriented, lv_cells, ag_scratch, a.ops + (size_t)ri * a.ops_stride, (int)a.ops_stride, true);

@@ -71,8 +71,8 @@ static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
             bcb += res.bases_clipped_before; bca += res.bases_clipped_after;                    //  Landau-Vishkin writeRead passes none, ReadWriter.cpp:276)
             clipped_len -= res.bases_clipped_before + res.bases_clipped_after;
         }
-        int flag = 0, contig = -1, mapq = 0;
-        long long pos = 0, extra = 0;
+        int flag = res.supplementary ? 0x800 : 0, contig = -1, mapq = 0;                         // SAM_SUPPLEMENTARY (:1481-1483); a caller writing a
+        long long pos = 0, extra = 0;                                                           //  secondary result ORs 0x100 into the flag itself (:1477-1479)
         if (loc >= 0) {
             if (dir == 1) flag |= SAMF_RC;
             // getContigForRead(genomeLocation, read->getDataLength(), &extra)  (Genome.cpp:734-758)

@@ -701,6 +701,16 @@ extern "C" int snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
     return SNAPGPU_OK;
 }
 
+// kernel time of the SAM-side launches, into the same accumulator snapgpu_kernel_time reads (events recorded around the launch)
+static int sam_side_kernel_time(snapgpu_ctx *ctx)
+{
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventSynchronize(ctx->ev1), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1), SNAPGPU_E_LAUNCH);
+    ctx->kernel_ms += ms; ctx->kernel_launches++;
+    return SNAPGPU_OK;
+}
+
 // SAMFormat::computeCigar, Landau-Vishkin variant, for a batch of written reads (cigar_lv.h, cigar_k.hip).
 extern "C" int snapgpu_compute_cigar_lv(snapgpu_ctx *ctx, uint32_t n, const char *data, uint64_t data_bytes, const uint64_t *off,
                                         const int32_t *len, const int64_t *loc, const int32_t *extra_before, int use_m,
@@ -744,15 +754,17 @@ extern "C" int snapgpu_compute_cigar_lv(snapgpu_ctx *ctx, uint32_t n, const char
     a.ops = (uint32_t *)dops.p; a.n_ops = (int32_t *)dno.p; a.edit_distance = (int32_t *)ded.p;
     a.add_front_clipping = (int32_t *)dafc.p; a.extra_after = (int64_t *)dxa.p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     snapgpu_launch_cigar_lv(&a, blocks, (size_t)4 * per_wave, s);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(ops, dops.p, (size_t)n * ops_stride * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(n_ops, dno.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(edit_distance, ded.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(add_front_clipping, dafc.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(extra_clipped_after, dxa.p, (size_t)n * 8, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
-    return SNAPGPU_OK;
+    return sam_side_kernel_time(ctx);
 }
 
 // SAMFormat::computeCigar, affine-gap variant, for a batch of written reads (cigar_ag.h, cigar_k.hip).
@@ -813,8 +825,10 @@ extern "C" int snapgpu_compute_cigar_ag(snapgpu_ctx *ctx, uint32_t n, const char
     a.ops = (uint32_t *)dops.p; a.n_ops = (int32_t *)dno.p; a.edit_distance = (int32_t *)ded.p; a.add_front_clipping = (int32_t *)dafc.p;
     a.extra_after = (int64_t *)dxa.p; a.tail_ins = (int32_t *)dti.p; a.stale = (int32_t *)dst.p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     snapgpu_launch_cigar_ag(&a, blocks, (size_t)waves_per_block * per_wave, s);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(ops, dops.p, (size_t)n * ops_stride * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(n_ops, dno.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(edit_distance, ded.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
@@ -823,7 +837,7 @@ extern "C" int snapgpu_compute_cigar_ag(snapgpu_ctx *ctx, uint32_t n, const char
     HIPCHK(ctx, hipMemcpyAsync(back_clipping_missed, dti.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(reference_history_dependent, dst.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
-    return SNAPGPU_OK;
+    return sam_side_kernel_time(ctx);
 }
 
 // result -> FLAG / RNAME index / POS / MAPQ / CIGAR / NM of the SAM record (sam_fields.h, cigar_k.hip)
@@ -884,8 +898,10 @@ extern "C" int snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const cha
     a.flag = (int32_t *)dflag.p; a.contig = (int32_t *)dctg.p; a.pos = (int64_t *)dpos.p; a.mapq = (int32_t *)dmq.p;
     a.ops = (uint32_t *)dops.p; a.n_ops = (int32_t *)dno.p; a.nm = (int32_t *)dnm.p; a.stale = (int32_t *)dst.p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     snapgpu_launch_sam_fields(&a, blocks, (size_t)4 * per_wave, s);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(flag, dflag.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(contig, dctg.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(pos, dpos.p, (size_t)n * 8, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
@@ -895,7 +911,7 @@ extern "C" int snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const cha
     HIPCHK(ctx, hipMemcpyAsync(nm, dnm.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(reference_history_dependent, dst.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
-    return SNAPGPU_OK;
+    return sam_side_kernel_time(ctx);
 }
 
 // paired-end writer: results -> the computed fields of both SAM records of each pair (sam_fields.h, cigar_k.hip)
@@ -964,8 +980,10 @@ extern "C" int snapgpu_sam_fields_paired(snapgpu_ctx *ctx, uint32_t n_pairs, con
     a.ops = (uint32_t *)dops.p; a.n_ops = (int32_t *)dno.p; a.nm = (int32_t *)dnm.p; a.rnext = (int32_t *)drn.p; a.pnext = (int64_t *)dpn.p;
     a.tlen = (int64_t *)dtl.p; a.first_written = (int32_t *)dfw.p; a.stale = (int32_t *)dst.p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     snapgpu_launch_sam_fields_paired(&a, blocks, (size_t)4 * per_wave, s);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
     struct { void *h; void *d; size_t b; } outs[] = {
         {flag, dflag.p, (size_t)n * 4}, {contig, dctg.p, (size_t)n * 4}, {pos, dpos.p, (size_t)n * 8}, {mapq, dmq.p, (size_t)n * 4},
         {ops, dops.p, (size_t)n * ops_stride * 4}, {n_ops, dno.p, (size_t)n * 4}, {nm, dnm.p, (size_t)n * 4}, {rnext, drn.p, (size_t)n * 4},
@@ -973,7 +991,7 @@ extern "C" int snapgpu_sam_fields_paired(snapgpu_ctx *ctx, uint32_t n_pairs, con
         {reference_history_dependent, dst.p, (size_t)n * 4}};
     for (auto &o : outs) HIPCHK(ctx, hipMemcpyAsync(o.h, o.d, o.b, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
-    return SNAPGPU_OK;
+    return sam_side_kernel_time(ctx);
 }
 
 extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,

@@ -98,3 +98,36 @@ def test_option_sets_vs_live_reference(tmp_path):
     ix, ri, rd = option_workload(str(tmp_path), 8000)
     for kw in OPTION_SETS:
         check_option_set(ix, ri, rd, kw)
+
+
+# ---- paired-end option sets beyond the fixtures (-s, -n, -H as max_big_hits, -i, soft clipping off, ...), against the live reference
+PAIRED_OPTION_SETS = [({}, dict(min_spacing=200, max_spacing=500)), ({}, dict(num_seeds=4)), ({}, dict(max_big_hits=200)), (dict(max_k=15), dict(max_k_for_indels=10)),
+                      ({}, dict(use_soft_clipping=0)), (dict(use_affine_gap=0), dict(num_seeds=16)), (dict(max_hits=50), {}), ({}, dict(num_seeds=0, seed_coverage=1.5)),
+                      (dict(extra_search_depth=3), dict(max_single_seeds=10))]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+def test_paired_option_sets_vs_live_reference(tmp_path):
+    """(Run once on the wavefront emulator with 160 pairs per set: all nine identical.)"""
+    from snap_amd.aligner import ChimericPairedEndAligner
+    from snap_amd.index import GenomeIndex
+    from tests.pairs_util import compare_paired, hard_pairs
+    d = str(tmp_path)
+    g = synth.make_genome(411, 400_000, n_contigs=3, repeat_frac=0.3, max_copies=60, repeat_len=(150, 1500), n_run_frac=0.002)
+    synth.write_fasta(d + "/ref.fa", g)
+    ref.build_index(d + "/ref.fa", d + "/idx", 20, threads=max(1, min(8, os.cpu_count() or 1)))
+    ix = GenomeIndex.load_from_directory(d + "/idx"); ri = ref.RefIndex(d + "/idx")
+    pr = hard_pairs(31, g, 1500, 150, insert_mean=380)
+    for kw, pkw in PAIRED_OPTION_SETS:
+        p = abi.default_params(max_read_len=160, **kw); pp = abi.default_paired_params(**pkw)
+        prim, alt, cnt, _ = ri.align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=1, stage=0)
+        a = ChimericPairedEndAligner(ix, p, pp)
+        try:
+            got, galt = a.align(pr["bases"], pr["quals"], pr["offsets"])
+        finally:
+            a.close()
+        flagged = got["reserved"] != 0
+        assert flagged.sum() <= 2 + got.size // 50
+        bad = compare_paired(prim, got, verbose=3, exclude=flagged)
+        assert not bad.any(), (kw, pkw, int(bad.sum()))
