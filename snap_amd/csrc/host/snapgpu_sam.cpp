@@ -1,5 +1,5 @@
 // snapgpu_sam.cpp -- FASTQ batcher + SAM writer over the C ABI: the host side of
-//     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-Cxx] [-mrl minReadLength] [-b readsPerBatch]
+//     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-Cxx] [-D n] [-om n [-omax n] [-mpc n]] [-mrl minReadLength] [-b readsPerBatch]
 //     snapgpu-sam paired <index-dir> <reads1.fq> <reads2.fq> -o <out.sam> [same options]
 // Streams FASTQ records in batches across include/snapgpu.h -- snapgpu_align_single (BaseAligner::AlignRead) and
 // snapgpu_sam_fields_single (what SimpleReadWriter::writeReads / SAMFormat::writeRead compute before they print) -- and prints the
@@ -99,6 +99,7 @@ int main(int argc, char **argv)
     unsigned min_read_len = 50;                                            // -mrl, AlignerOptions.cpp
     size_t batch_reads = 65536;
     bool clip_front = false, clip_back = true;                             // -C-+ (ClipBack) is the default
+    int om = -1, mpc = -1; long long omax = 0x7fffffff;
     std::string cl = argv[1];
     for (int i = 2; i < argc; i++) { cl += " "; cl += argv[i]; }
     for (int i = paired ? 5 : 4; i < argc; i++) {
@@ -109,6 +110,10 @@ int main(int argc, char **argv)
         else if (a == "-=") use_m = false;
         else if (a == "-M") use_m = true;
         else if (a.size() == 4 && a.compare(0, 2, "-C") == 0 && strchr("+-", a[2]) && strchr("+-", a[3])) { clip_front = a[2] == '+'; clip_back = a[3] == '+'; }   // AlignerOptions.cpp: -Cxx
+        else if (a == "-om" && i + 1 < argc) om = atoi(argv[++i]);                       // secondary alignments (AlignerOptions.cpp:70-72)
+        else if (a == "-omax" && i + 1 < argc) omax = atoll(argv[++i]);
+        else if (a == "-mpc" && i + 1 < argc) mpc = atoi(argv[++i]);
+        else if (a == "-D" && i + 1 < argc) p.extra_search_depth = (uint32_t)atoi(argv[++i]);
         else if (a == "-mrl" && i + 1 < argc) min_read_len = (unsigned)atoi(argv[++i]);
         else if (a == "-b" && i + 1 < argc) batch_reads = (size_t)atoll(argv[++i]);
         else if (a == "-t" && i + 1 < argc) ++i;                           // host threads: nothing to do here
@@ -133,6 +138,13 @@ int main(int argc, char **argv)
         pp.min_read_length = min_read_len;
         rc = snapgpu_enable_paired(ctx, &pp);
         if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_enable_paired failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+    }
+    if (om >= 0) {
+        if (paired) die("-om with `paired` is not supported by this program yet");
+        snapgpu_secondary_params sp; memset(&sp, 0, sizeof(sp));
+        sp.max_edit_distance = om; sp.max_per_contig = mpc; sp.max_results = omax; sp.adjust_alignments = 0;
+        rc = snapgpu_enable_secondary(ctx, &sp);
+        if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_enable_secondary failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
     }
     FILE *out = fopen(out_path.c_str(), "wb");
     if (!out) die("cannot create ", out_path.c_str());
@@ -273,23 +285,55 @@ int main(int argc, char **argv)
             memset(&results[i], 0, sizeof(results[i]));
             results[i].status = SNAPGPU_NotFound; results[i].location = SNAPGPU_InvalidGenomeLocation32; results[i].score = -1;
         }
+        // records to write: every read's primary, then its secondary results in the aligner's order (SingleAligner.cpp:300-318 -> writeReads)
+        std::vector<uint32_t> rec_read;                                     // record -> read of the batch
+        std::vector<char> rec_secondary;
+        std::vector<snapgpu_single_result> rec_res;
         if (!to_align.empty()) {
-            rc = snapgpu_align_single(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data());
-            if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_align_single failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
-            for (size_t k = 0; k < to_align.size(); k++) results[to_align[k]] = aligned_res[k];
+            std::vector<snapgpu_single_result> sec; std::vector<uint32_t> nsec(to_align.size(), 0);
+            uint32_t stride = 0;
+            if (om >= 0) {
+                stride = 8;
+                for (;;) {
+                    sec.assign((size_t)to_align.size() * stride, snapgpu_single_result());
+                    rc = snapgpu_align_single_secondary(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data(),
+                                                        sec.data(), stride, nsec.data());
+                    if (rc != SNAPGPU_W_SECONDARY_TRUNCATED) break;
+                    uint32_t need = stride; for (uint32_t v : nsec) if (v > need) need = v;
+                    stride = need;
+                }
+            } else rc = snapgpu_align_single(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data());
+            if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: alignment failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+            std::vector<uint32_t> slot(n, 0xffffffffu);
+            for (size_t k = 0; k < to_align.size(); k++) { results[to_align[k]] = aligned_res[k]; slot[to_align[k]] = (uint32_t)k; }
+            for (size_t i = 0; i < n; i++) {
+                rec_read.push_back((uint32_t)i); rec_secondary.push_back(0); rec_res.push_back(results[i]);
+                if (om >= 0 && slot[i] != 0xffffffffu)
+                    for (uint32_t j = 0; j < nsec[slot[i]]; j++) { rec_read.push_back((uint32_t)i); rec_secondary.push_back(1); rec_res.push_back(sec[(size_t)slot[i] * stride + j]); }
+            }
+        } else for (size_t i = 0; i < n; i++) { rec_read.push_back((uint32_t)i); rec_secondary.push_back(0); rec_res.push_back(results[i]); }
+        const size_t nr = rec_read.size();
+        // the record batch: a read with secondary results appears once per record
+        std::vector<char> rb, rq; std::vector<uint64_t> ro(1, 0); std::vector<int32_t> rfc(nr), rdl(nr);
+        for (size_t r = 0; r < nr; r++) {
+            const size_t i = rec_read[r];
+            rb.insert(rb.end(), b.bases.begin() + (long)b.offsets[i], b.bases.begin() + (long)b.offsets[i + 1]);
+            rq.insert(rq.end(), b.quals.begin() + (long)b.offsets[i], b.quals.begin() + (long)b.offsets[i + 1]);
+            ro.push_back(rb.size()); rfc[r] = front_clip[i]; rdl[r] = data_len[i];
         }
-        std::vector<int32_t> flag(n), contig(n), mapq(n), n_ops(n), nm(n), stale(n);
-        std::vector<int64_t> pos(n);
-        std::vector<uint32_t> ops(n * ops_stride);
-        rc = snapgpu_sam_fields_single(ctx, (uint32_t)n, b.bases.data(), b.quals.data(), b.offsets.data(), front_clip.data(), data_len.data(),
-                                       results.data(), use_m ? 1 : 0, flag.data(), contig.data(), pos.data(), mapq.data(), ops.data(), ops_stride,
-                                       n_ops.data(), nm.data(), stale.data());
+        std::vector<int32_t> flag(nr), contig(nr), mapq(nr), n_ops(nr), nm(nr), stale(nr);
+        std::vector<int64_t> pos(nr);
+        std::vector<uint32_t> ops(nr * ops_stride);
+        rc = snapgpu_sam_fields_single(ctx, (uint32_t)nr, rb.data(), rq.data(), ro.data(), rfc.data(), rdl.data(), rec_res.data(), use_m ? 1 : 0,
+                                       flag.data(), contig.data(), pos.data(), mapq.data(), ops.data(), ops_stride, n_ops.data(), nm.data(), stale.data());
         if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_sam_fields_single failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
-        std::string rec, sq, ql;
-        for (size_t i = 0; i < n; i++) {
-            const char *s = b.bases.data() + b.offsets[i], *q = b.quals.data() + b.offsets[i];
-            const size_t U = (size_t)(b.offsets[i + 1] - b.offsets[i]);
-            const std::string &nmq = b.names[i];
+        for (size_t r = 0; r < nr; r++) if (rec_secondary[r]) flag[r] |= 0x100;                  // SAM_SECONDARY (createSAMLine, SAM.cpp:1477-1479)
+        std::string sq, ql;
+        for (size_t i = 0; i < nr; i++) {
+            const size_t rd = rec_read[i];
+            const char *s = b.bases.data() + b.offsets[rd], *q = b.quals.data() + b.offsets[rd];
+            const size_t U = (size_t)(b.offsets[rd + 1] - b.offsets[rd]);
+            const std::string &nmq = b.names[rd];
             const size_t sp = nmq.find(' ');                               // "illegal in SAM: truncate at the space" (SAM.cpp:2001-2004)
             sq.assign(s, U); ql.assign(q, U);
             if (flag[i] & 0x10) { for (size_t j = 0; j < U; j++) { sq[U - 1 - j] = complement(s[j]); ql[U - 1 - j] = q[j]; } }
@@ -312,6 +356,6 @@ int main(int argc, char **argv)
     }
     fclose(out); gzclose(in); if (in2) gzclose(in2);
     snapgpu_destroy(ctx);
-    fprintf(stderr, "snapgpu-sam: %llu reads, %llu aligned\n", total, aligned);
+    fprintf(stderr, "snapgpu-sam: %llu reads, %llu mapped records\n", total, aligned);
     return 0;
 }

@@ -70,11 +70,11 @@ def single_workload(tmp_path_factory):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
-@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"], ["-C++"]])
+@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"], ["-C++"], ["-om", "1", "-omax", "4"], ["-D", "2", "-om", "2", "-mpc", "2"]])
 def test_native_fastq_to_sam_identical_to_reference_cli(single_workload, opts):
     assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
     d, index_dir, fastq = single_workload
-    assert run_and_compare(TOOL, d, index_dir, fastq, opts) > 20000
+    assert run_and_compare(TOOL, d, index_dir, fastq, opts) > 20000          # (with -om: secondary records too, flag 0x100)
 
 
 def make_paired_workload(d, n_pairs, genome_bases=600_000):
