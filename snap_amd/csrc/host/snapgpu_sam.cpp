@@ -1,5 +1,5 @@
 // snapgpu_sam.cpp -- FASTQ batcher + SAM writer over the C ABI: the host side of
-//     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-Cxx] [-D n] [-om n [-omax n] [-mpc n]] [-mrl minReadLength] [-b readsPerBatch]
+//     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-Cxx] [-ea] [-D n] [-om n [-omax n] [-mpc n]] [-mrl minReadLength] [-b readsPerBatch]
 //     snapgpu-sam paired <index-dir> <reads1.fq> <reads2.fq> -o <out.sam> [same options]
 // Streams FASTQ records in batches across include/snapgpu.h -- snapgpu_align_single (BaseAligner::AlignRead) and
 // snapgpu_sam_fields_single (what SimpleReadWriter::writeReads / SAMFormat::writeRead compute before they print) -- and prints the
@@ -113,6 +113,7 @@ int main(int argc, char **argv)
         else if (a == "-om" && i + 1 < argc) om = atoi(argv[++i]);                       // secondary alignments (AlignerOptions.cpp:70-72)
         else if (a == "-omax" && i + 1 < argc) omax = atoll(argv[++i]);
         else if (a == "-mpc" && i + 1 < argc) mpc = atoi(argv[++i]);
+        else if (a == "-ea") p.emit_alt_alignments = 1;                                  // the first ALT alignment as an extra record (SingleAligner.cpp:320-322)
         else if (a == "-D" && i + 1 < argc) p.extra_search_depth = (uint32_t)atoi(argv[++i]);
         else if (a == "-mrl" && i + 1 < argc) min_read_len = (unsigned)atoi(argv[++i]);
         else if (a == "-b" && i + 1 < argc) batch_reads = (size_t)atoll(argv[++i]);
@@ -310,6 +311,9 @@ int main(int argc, char **argv)
                 rec_read.push_back((uint32_t)i); rec_secondary.push_back(0); rec_res.push_back(results[i]);
                 if (om >= 0 && slot[i] != 0xffffffffu)
                     for (uint32_t j = 0; j < nsec[slot[i]]; j++) { rec_read.push_back((uint32_t)i); rec_secondary.push_back(1); rec_res.push_back(sec[(size_t)slot[i] * stride + j]); }
+                if (p.alt_awareness && slot[i] != 0xffffffffu && alt_res[slot[i]].status != SNAPGPU_NotFound) {      // writeReads(&firstALTResult, 1, firstIsPrimary = false)
+                    rec_read.push_back((uint32_t)i); rec_secondary.push_back(1); rec_res.push_back(alt_res[slot[i]]);
+                }
             }
         } else for (size_t i = 0; i < n; i++) { rec_read.push_back((uint32_t)i); rec_secondary.push_back(0); rec_res.push_back(results[i]); }
         const size_t nr = rec_read.size();

@@ -21,9 +21,13 @@ def make_workload(d, n_reads, genome_bases=600_000):
     """A genome with repeats, its index (the reference's builder) and a FASTQ with the awkward cases: ragged lengths, '#' tails, reads
     with too many Ns, unalignable reads, bases prepended / dropped at the start, names with a comment."""
     contigs = synth.make_genome(177, genome_bases, n_contigs=3, repeat_frac=0.1)
+    rng0 = np.random.default_rng(7)                                   # an ALT contig: a 1 % diverged copy of a stretch of the first contig (-ea, ALT-aware scoring)
+    alt = contigs[0][1][genome_bases // 20:genome_bases // 20 + genome_bases // 25].copy()
+    m = rng0.random(alt.size) < 0.01; alt[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng0.integers(0, 4, size=int(m.sum()))]
+    contigs.append(("alt1", alt))
     fasta = os.path.join(d, "g.fa"); synth.write_fasta(fasta, contigs)
     index_dir = os.path.join(d, "index")
-    ref.build_index(fasta, index_dir, seed_len=20, threads=max(1, min(8, os.cpu_count() or 1)))
+    ref.build_index(fasta, index_dir, seed_len=20, threads=max(1, min(8, os.cpu_count() or 1)), extra=["-altContigName", "alt1"])
     reads = synth.make_reads(15, contigs, n_reads, 150, sub=0.015, ins=0.003, dele=0.003, n_frac=0.002)
     rng = np.random.default_rng(19)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -45,8 +49,20 @@ def make_workload(d, n_reads, genome_bases=600_000):
     return index_dir, fastq
 
 
-def sam_lines(path):
-    return sorted(line for line in open(path) if not line.startswith("@PG"))
+def sam_lines(path, mask_0x800_on_secondary=False):
+    """mask_0x800_on_secondary: with -ea the reference writes `firstALTResult` as one more (secondary) record, but nothing on that path ever
+    assigns firstALTResult.supplementary (BaseAligner.cpp:1041 -> fillInSingleAlignmentResult :2301-2323; the variable is an uninitialised
+    stack object, SingleAligner.cpp:249), so bit 0x800 of that record is whatever the stack held.  Not compared."""
+    out = []
+    for line in open(path):
+        if line.startswith("@PG"):
+            continue
+        if mask_0x800_on_secondary and not line.startswith("@"):
+            t = line.split("\t")
+            if int(t[1]) & 0x100:
+                t[1] = str(int(t[1]) & ~0x800); line = "\t".join(t)
+        out.append(line)
+    return sorted(out)
 
 
 def run_and_compare(tool, d, index_dir, fastq, opts, env=None, ref_opts=None):
@@ -55,7 +71,7 @@ def run_and_compare(tool, d, index_dir, fastq, opts, env=None, ref_opts=None):
     for cmd, e in (([ref.CLI_PATH, "single", index_dir, fastq, "-o", out_ref, "-t", "1"] + (opts if ref_opts is None else ref_opts), None), ([tool, "single", index_dir, fastq, "-o", out_new] + opts, env)):
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=1800, env=e)
         assert r.returncode == 0, "%s failed:\n%s" % (cmd[0], r.stdout.decode(errors="replace")[-3000:])
-    a, b = sam_lines(out_ref), sam_lines(out_new)
+    a, b = sam_lines(out_ref, "-ea" in opts), sam_lines(out_new, "-ea" in opts)
     assert len(a) == len(b)
     diff = [(x, y) for x, y in zip(a, b) if x != y]
     assert not diff, "%d of %d lines differ, first:\n%s%s" % (len(diff), len(a), diff[0][0], diff[0][1])
@@ -70,7 +86,7 @@ def single_workload(tmp_path_factory):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
-@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"], ["-C++"], ["-om", "1", "-omax", "4"], ["-D", "2", "-om", "2", "-mpc", "2"]])
+@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"], ["-C++"], ["-om", "1", "-omax", "4"], ["-D", "2", "-om", "2", "-mpc", "2"], ["-ea", "-om", "1"]])
 def test_native_fastq_to_sam_identical_to_reference_cli(single_workload, opts):
     assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
     d, index_dir, fastq = single_workload
