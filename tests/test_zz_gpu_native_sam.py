@@ -110,6 +110,8 @@ def make_paired_workload(d, n_pairs, genome_bases=600_000):
             b = pr["bases"][o[2 * i + w]:o[2 * i + w + 1]].copy(); q = pr["quals"][o[2 * i + w]:o[2 * i + w + 1]].copy()
             if (2 * i + w) % 19 == 3: q[len(q) - int(rng.integers(1, 30)):] = ord("#")
             if short: b, q = b[:40], q[:40]
+            if i % 59 == 11 and w == 1: b, q = b[:35], q[:35]                                   # exactly one useless mate: the pair is still aligned (PairedAligner.cpp:680-682)
+            if i % 61 == 13 and w == 0: b[rng.integers(0, len(b), size=min(40, len(b)))] = ord("N")
             files[w].write(b"@pair%d/%d\n" % (i, w + 1) + b.tobytes() + b"\n+\n" + q.tobytes() + b"\n")
     for f in files:
         f.close()
