@@ -1,5 +1,5 @@
 O=gpurun_out/r01g; mkdir -p $O
-timeout 200 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+timeout 1200 python -m pytest tests -m gpu -x -q --durations=15 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python bench.py --steps 3 --warmup 1 > $O/bench_stats.json 2> $O/bench_stats.err < /dev/null
 tail -c 900 $O/bench_stats.json; head -3 $O/stats/bench_kernel_stats.csv

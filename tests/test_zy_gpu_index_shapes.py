@@ -48,7 +48,7 @@ def align_and_compare(tmp, seed_len, large, n_reads, genome_bases=400_000):
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
 @pytest.mark.parametrize("seed_len,large", SHAPES)
 def test_index_shapes_vs_live_reference(tmp_path, seed_len, large):
-    align_and_compare(str(tmp_path), seed_len, large, 20000, genome_bases=2_000_000)
+    align_and_compare(str(tmp_path), seed_len, large, 8000, genome_bases=1_000_000)
 
 
 # ---- option sets beyond the ones the fixtures pin (-h, -n, -sc, -D, -d, scoring parameters, end bonuses, ALT gap), against the live reference
@@ -95,7 +95,7 @@ def check_option_set(ix, ri, rd, kw):
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
 def test_option_sets_vs_live_reference(tmp_path):
-    ix, ri, rd = option_workload(str(tmp_path), 8000)
+    ix, ri, rd = option_workload(str(tmp_path), 3000)
     for kw in OPTION_SETS:
         check_option_set(ix, ri, rd, kw)
 
@@ -118,7 +118,7 @@ def test_paired_option_sets_vs_live_reference(tmp_path):
     synth.write_fasta(d + "/ref.fa", g)
     ref.build_index(d + "/ref.fa", d + "/idx", 20, threads=max(1, min(8, os.cpu_count() or 1)))
     ix = GenomeIndex.load_from_directory(d + "/idx"); ri = ref.RefIndex(d + "/idx")
-    pr = hard_pairs(31, g, 1500, 150, insert_mean=380)
+    pr = hard_pairs(31, g, 600, 150, insert_mean=380)
     for kw, pkw in PAIRED_OPTION_SETS:
         p = abi.default_params(max_read_len=160, **kw); pp = abi.default_paired_params(**pkw)
         prim, alt, cnt, _ = ri.align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=1, stage=0)

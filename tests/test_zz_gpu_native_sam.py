@@ -81,7 +81,7 @@ def run_and_compare(tool, d, index_dir, fastq, opts, env=None, ref_opts=None):
 @pytest.fixture(scope="module")
 def single_workload(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("native"))
-    return (d,) + make_workload(d, 20000, genome_bases=3_000_000)
+    return (d,) + make_workload(d, 8000, genome_bases=2_000_000)
 
 
 @pytest.mark.gpu
@@ -90,7 +90,7 @@ def single_workload(tmp_path_factory):
 def test_native_fastq_to_sam_identical_to_reference_cli(single_workload, opts):
     assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
     d, index_dir, fastq = single_workload
-    assert run_and_compare(TOOL, d, index_dir, fastq, opts) > 20000          # (with -om: secondary records too, flag 0x100)
+    assert run_and_compare(TOOL, d, index_dir, fastq, opts) > 8000           # (with -om: secondary records too, flag 0x100)
 
 
 def make_paired_workload(d, n_pairs, genome_bases=600_000):
@@ -135,7 +135,7 @@ def run_and_compare_paired(tool, d, index_dir, fq, opts, env=None):
 @pytest.fixture(scope="module")
 def paired_workload(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("nativep"))
-    return (d,) + make_paired_workload(d, 6000, genome_bases=3_000_000)
+    return (d,) + make_paired_workload(d, 2500, genome_bases=2_000_000)
 
 
 @pytest.mark.gpu
@@ -144,4 +144,4 @@ def paired_workload(tmp_path_factory):
 def test_native_paired_fastq_to_sam_identical_to_reference_cli(paired_workload, opts):
     assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
     d, index_dir, fq = paired_workload
-    assert run_and_compare_paired(TOOL, d, index_dir, fq, opts) > 12000
+    assert run_and_compare_paired(TOOL, d, index_dir, fq, opts) > 5000
