@@ -131,3 +131,43 @@ def test_paired_option_sets_vs_live_reference(tmp_path):
         assert flagged.sum() <= 2 + got.size // 50
         bad = compare_paired(prim, got, verbose=3, exclude=flagged)
         assert not bad.any(), (kw, pkw, int(bad.sum()))
+
+
+# ---- read lengths at the boundaries of the affine-gap kernel variants (64 / 192 / 256 / 384 striped positions) and of max_read_len
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+def test_read_length_boundaries_and_paired_index_shapes_vs_live_reference(tmp_path):
+    """(Run once on the wavefront emulator with 150 reads per length / 200 pairs per shape: all identical.)"""
+    from snap_amd.aligner import BaseAligner, ChimericPairedEndAligner
+    from snap_amd.index import GenomeIndex
+    from tests.pairs_util import compare_paired, hard_pairs
+    g = synth.make_genome(511, 400_000, n_contigs=3, repeat_frac=0.3, max_copies=60, repeat_len=(150, 1500), n_run_frac=0.002)
+    fa = str(tmp_path / "ref.fa"); synth.write_fasta(fa, g)
+    threads = max(1, min(8, os.cpu_count() or 1))
+    ref.build_index(fa, str(tmp_path / "idx20"), 20, threads=threads)
+    ix = GenomeIndex.load_from_directory(str(tmp_path / "idx20")); ri = ref.RefIndex(str(tmp_path / "idx20"))
+    for L, mk, mrl in ((50, 4, 64), (63, 6, 64), (64, 6, 64), (65, 8, 128), (191, 12, 192), (192, 12, 192), (193, 12, 256), (300, 20, 320), (400, 27, 400)):
+        rd = synth.make_reads(100 + L, g, 1500, L, sub=0.02, ins=0.004, dele=0.004, n_frac=0.001)
+        p = abi.default_params(max_k=mk, max_read_len=mrl)
+        pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
+        a = BaseAligner(ix, p)
+        try:
+            pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"])
+        finally:
+            a.close()
+        problems = util.compare_results(pr, pg, exclude=pg["reserved"] != 0)
+        assert not problems, (L, problems)
+    for seed_len, large in ((24, False), (22, True)):                      # the paired-end hit sets over other key sizes / table layouts
+        dd = str(tmp_path / ("idx%d%d" % (seed_len, large)))
+        ref.build_index(fa, dd, seed_len, threads=threads, large=large)
+        ixp = GenomeIndex.load_from_directory(dd); rip = ref.RefIndex(dd)
+        prs = hard_pairs(33, g, 600, 150, insert_mean=380)
+        p = abi.default_params(max_read_len=160); pp = abi.default_paired_params()
+        prim, alt, cnt, _ = rip.align_paired(p, pp, prs["bases"], prs["quals"], prs["offsets"], threads=1, stage=0)
+        a = ChimericPairedEndAligner(ixp, p, pp)
+        try:
+            got, galt = a.align(prs["bases"], prs["quals"], prs["offsets"])
+        finally:
+            a.close()
+        bad = compare_paired(prim, got, verbose=3, exclude=(got["reserved"] != 0))
+        assert not bad.any(), (seed_len, large, int(bad.sum()))
