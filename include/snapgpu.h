@@ -362,6 +362,14 @@ int  snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, 
                                int32_t *flag, int32_t *contig, int64_t *pos, int32_t *mapq, uint32_t *ops, uint32_t ops_stride,
                                int32_t *n_ops, int32_t *nm, int32_t *reference_history_dependent);
 
+/* Device-pointer form of snapgpu_sam_fields_single: every array already in HBM (reads, Read::clip's outcome, the results
+ * snapgpu_align_single_device left there), outputs left in HBM.  max_read_len >= the longest read of the batch (it sizes the LDS rows and
+ * the per-wave scratch, which this call still allocates and frees itself).  Synchronous on `stream` (NULL: the context's). */
+int  snapgpu_sam_fields_single_device(snapgpu_ctx *ctx, uint32_t n, uint32_t max_read_len, const void *d_bases, const void *d_quals,
+                                      const void *d_offsets, const void *d_front_clip, const void *d_data_len, const void *d_results, int use_m,
+                                      void *d_flag, void *d_contig, void *d_pos, void *d_mapq, void *d_ops, uint32_t ops_stride,
+                                      void *d_n_ops, void *d_nm, void *d_reference_history_dependent, void *stream);
+
 /*
  * The paired-end writer: for the primary PairedAlignmentResult of each pair, the computed fields of BOTH SAM records -- what
  * SAMFormat::writePairs (SNAPLib/SAM.cpp:1575-1895: createSAMLine and the cigar with its leading-indel loop per mate, :1636-1715) and

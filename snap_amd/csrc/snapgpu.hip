@@ -914,6 +914,49 @@ extern "C" int snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const cha
     return sam_side_kernel_time(ctx);
 }
 
+// device-pointer form of snapgpu_sam_fields_single: reads, clipping and results already in HBM (e.g. right after
+// snapgpu_align_single_device), outputs left in HBM.  max_read_len sizes the per-wave LDS rows and the scratch slab.
+extern "C" int snapgpu_sam_fields_single_device(snapgpu_ctx *ctx, uint32_t n, uint32_t max_read_len, const void *d_bases, const void *d_quals,
+                                                const void *d_offsets, const void *d_front_clip, const void *d_data_len, const void *d_results, int use_m,
+                                                void *d_flag, void *d_contig, void *d_pos, void *d_mapq, void *d_ops, uint32_t ops_stride,
+                                                void *d_n_ops, void *d_nm, void *d_reference_history_dependent, void *stream)
+{
+    if (!ctx || (n && (!d_bases || !d_quals || !d_offsets || !d_front_clip || !d_data_len || !d_results || !d_flag || !d_contig || !d_pos || !d_mapq ||
+                       !d_ops || !d_n_ops || !d_nm || !d_reference_history_dependent)))
+        return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_sam_fields_single_device: null argument");
+    if (ops_stride < 3) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_sam_fields_single_device: ops_stride must be at least 3");
+    if (max_read_len == 0 || max_read_len > AGC_MAX_READ_LENGTH) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_sam_fields_single_device: max_read_len out of range");
+    if (n == 0) return SNAPGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const uint32_t RL = max_read_len < 64 ? 64 : max_read_len;
+    const uint32_t per_wave = agc_lds_bytes(RL);
+    if ((size_t)4 * per_wave > 64 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "snapgpu_sam_fields_single_device: reads too long for the LDS rows");
+    uint32_t blocks = (uint32_t)ctx->num_cus * 4;
+    const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
+    const uint64_t scratch_stride = ((2 * (uint64_t)RL + 255) & ~(uint64_t)255) + ((lvc_scratch_bytes() + 255) & ~255u) + ((agc_scratch_bytes(RL) + 255) & ~(uint64_t)255);
+    DevBuf dscr;
+    HIPCHK(ctx, dscr.put(nullptr, (size_t)blocks * 4 * scratch_stride, s), SNAPGPU_E_NOMEM);
+    SamFieldsArgs a;
+    a.ix = ctx->ix;
+    a.prm.match = (int)ctx->params.match_reward; a.prm.sub = -(int)ctx->params.sub_penalty;
+    a.prm.gap_open = (int)ctx->params.gap_open_penalty + (int)ctx->params.gap_extend_penalty; a.prm.gap_ext = (int)ctx->params.gap_extend_penalty;
+    a.n = n; a.RL = RL; a.ops_stride = ops_stride; a.use_m = use_m ? 1u : 0u; a.use_affine_gap = ctx->params.use_affine_gap ? 1u : 0u;
+    a.bases = (const uint8_t *)d_bases; a.quals = (const uint8_t *)d_quals; a.offsets = (const uint64_t *)d_offsets;
+    a.front_clip = (const int32_t *)d_front_clip; a.data_len = (const int32_t *)d_data_len; a.results = (const snapgpu_single_result *)d_results;
+    a.scratch = (uint8_t *)dscr.p; a.scratch_stride = scratch_stride; a.work_counter = ctx->d_work;
+    a.flag = (int32_t *)d_flag; a.contig = (int32_t *)d_contig; a.pos = (int64_t *)d_pos; a.mapq = (int32_t *)d_mapq;
+    a.ops = (uint32_t *)d_ops; a.n_ops = (int32_t *)d_n_ops; a.nm = (int32_t *)d_nm; a.stale = (int32_t *)d_reference_history_dependent;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemsetAsync(d_ops, 0, (size_t)n * ops_stride * 4, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    snapgpu_launch_sam_fields(&a, blocks, (size_t)4 * per_wave, s);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);           // (the scratch slab is freed on return; a caller-owned slab is the next step)
+    return sam_side_kernel_time(ctx);
+}
+
 // paired-end writer: results -> the computed fields of both SAM records of each pair (sam_fields.h, cigar_k.hip)
 extern "C" int snapgpu_sam_fields_paired(snapgpu_ctx *ctx, uint32_t n_pairs, const char *bases, const char *quals, const uint64_t *offsets,
                                          const int32_t *front_clip, const int32_t *data_len, const snapgpu_paired_result *results, int use_m,

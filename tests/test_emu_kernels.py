@@ -218,3 +218,25 @@ def test_emu_option_sets(emu, tmp_path):
     ix, ri, rd = option_workload(str(tmp_path), 250)
     for kw in (OPTION_SETS[0], OPTION_SETS[4], OPTION_SETS[7], OPTION_SETS[12], OPTION_SETS[14]):
         check_option_set(ix, ri, rd, kw)
+
+
+def test_emu_sam_fields_device_pointer_form(emu, golden_index):
+    """snapgpu_sam_fields_single_device (all arrays "in device memory", which on the emulated device is host memory): same answers as the
+    reference CLI printed, first 600 reads of the fixture."""
+    import tests.test_zz_gpu_cigar as gc
+    from snap_amd.aligner import BaseAligner
+    z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
+    n = 600
+    keep = []
+    def to_dev(x):
+        t = np.ascontiguousarray(x).copy(); keep.append(t)
+        return (t, t.ctypes.data)
+    a = BaseAligner(golden_index, abi.default_params(max_k=14, max_read_len=400))
+    try:
+        flag, contig, pos, mapq, ops, n_ops, nm, stale = gc.run_sam_fields_device_form(a, z, "default", n, to_dev, lambda t, like: t[0])
+    finally:
+        a.close()
+    for k, v in (("flag", flag), ("contig", contig), ("pos", pos), ("mapq", mapq), ("nm", nm), ("n_ops", n_ops)):
+        assert (v == z["default_" + k][:n]).all(), k
+    for i in range(n):
+        assert util.cigar_text(ops[i], n_ops[i]) == util.cigar_text(z["default_ops"][i], z["default_n_ops"][i]), i

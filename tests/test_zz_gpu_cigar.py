@@ -275,3 +275,45 @@ def test_sam_fields_paired_vs_reference_cli_fixture(tag):
     z = np.load(os.path.join(util.GOLDEN, "sam_fields_paired.npz"))
     got = check_sam_fields_paired_against_reference_cli(z, tag)
     assert int((got["flag"] & 2 != 0).sum()) > 1500 and int((got["first_written"] == 1).sum()) > 300
+
+
+def run_sam_fields_device_form(aligner, z, tag, n, to_dev, to_host):
+    """snapgpu_sam_fields_single_device with every array in device memory (to_dev / to_host move numpy arrays there and back)."""
+    import ctypes as C
+    offs = z["offsets"][:n + 1]
+    tot = int(offs[-1])
+    ins = [z["bases"][:tot], z["quals"][:tot], offs.astype(np.uint64), z[tag + "_front_clip"][:n].astype(np.int32), z[tag + "_data_len"][:n].astype(np.int32),
+           np.ascontiguousarray(z[tag + "_results"][:n])]
+    stride = 64
+    outs = [np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.int32), np.zeros((n, stride), np.uint32),
+            np.zeros(n, np.int32), np.zeros(n, np.int32), np.zeros(n, np.int32)]
+    d_in = [to_dev(x) for x in ins]; d_out = [to_dev(x) for x in outs]
+    ptr = lambda t: C.c_void_p(t[1])
+    rc = aligner.lib.snapgpu_sam_fields_single_device(aligner.handle, C.c_uint32(n), C.c_uint32(160), *[ptr(t) for t in d_in], C.c_int(int(z[tag + "_use_m"])),
+                                                      *[ptr(t) for t in d_out[:5]], C.c_uint32(stride), *[ptr(t) for t in d_out[5:]], None)
+    assert rc == 0, rc
+    return [to_host(t, o) for t, o in zip(d_out, outs)]
+
+
+def test_sam_fields_device_pointer_form(golden_index):
+    """Same answers as the host-pointer form, with everything resident in HBM (torch tensors on cuda:0)."""
+    import os
+    import torch
+    from snap_amd.aligner import BaseAligner
+    z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
+    n = 1200
+    def to_dev(x):
+        t = torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1).copy()).cuda()
+        return (t, t.data_ptr())
+    def to_host(t, like):
+        torch.cuda.synchronize()
+        return t[0].cpu().numpy().view(like.dtype).reshape(like.shape)
+    a = BaseAligner(golden_index, abi.default_params(max_k=14, max_read_len=400))
+    try:
+        flag, contig, pos, mapq, ops, n_ops, nm, stale = run_sam_fields_device_form(a, z, "default", n, to_dev, to_host)
+    finally:
+        a.close()
+    for k, v in (("flag", flag), ("contig", contig), ("pos", pos), ("mapq", mapq), ("nm", nm), ("n_ops", n_ops)):
+        assert (v == z["default_" + k][:n]).all(), k
+    for i in range(n):
+        assert util.cigar_text(ops[i], n_ops[i]) == util.cigar_text(z["default_ops"][i], z["default_n_ops"][i]), i
