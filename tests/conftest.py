@@ -10,6 +10,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # TEST INFRASTRUCTURE: SNAPGPU_TEST_LIB=<path> makes the Python mirror used BY THE TESTS open another build of the C ABI -- the
+    # wavefront emulator's (tests/emu/_build/libsnapgpu_emu.so), to run the `-m gpu` tests on the host, or an A/B build.  The product
+    # itself has no such switch: snap_amd.aligner opens snap_amd/libsnapgpu.so only.
+    alt = os.environ.get("SNAPGPU_TEST_LIB")
+    if alt:
+        import snap_amd.aligner as al
+        al.LIB_PATH = os.path.abspath(alt)
+        al._lib = None
 
 
 @pytest.fixture(scope="session")
