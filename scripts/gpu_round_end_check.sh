@@ -1,4 +1,4 @@
-O=gpurun_out/r01g; mkdir -p $O
+O=gpurun_out/${1:-r02a}; mkdir -p $O      # copy what should be judged into profiles/<same name>/
 timeout 1200 python -m pytest tests -m gpu -x -q --durations=15 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python bench.py --steps 3 --warmup 1 > $O/bench_stats.json 2> $O/bench_stats.err < /dev/null
