@@ -17,8 +17,7 @@ from .abi import (Counters, IndexView, Params, RESULT_DTYPE, default_params, ptr
 from .index import GENOME_PAD, GenomeIndex
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnapgpu.so")      # the product opens this file and nothing else (the test-suite can point its own copy of
-                                                     # this variable elsewhere: tests/conftest.py, SNAPGPU_TEST_LIB)
+LIB_PATH = os.path.join(_HERE, "libsnapgpu.so")      # the product opens this file and nothing else
 
 _lib = None
 

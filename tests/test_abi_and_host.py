@@ -126,3 +126,24 @@ def test_read_sharding_covers_every_read_once():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_product_code_never_reaches_for_the_oracle_or_the_emulator():
+    """The oracle (oracle/) and the wavefront emulator (tests/emu/) are test infrastructure.  No product source may import, include, open or
+    link them: Python under snap_amd/, the HIP / C++ sources under snap_amd/csrc/, the build hook's product part."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bad = []
+    pats = [re.compile(r"^\s*(from|import)\s+(oracle|tests)\b"), re.compile(r"#include\s+[\"<][^\">]*(oracle|tests)/"), re.compile(r"libsnapgpu_emu|liboracle|libsnapref|wave_emu|SNAPGPU_TEST_LIB")]
+    for sub in ("snap_amd", os.path.join("snap_amd", "csrc"), os.path.join("snap_amd", "csrc", "host")):
+        d = os.path.join(root, sub)
+        for f in sorted(os.listdir(d)):
+            p = os.path.join(d, f)
+            if not os.path.isfile(p) or not f.endswith((".py", ".h", ".hip", ".cpp")):
+                continue
+            for ln, line in enumerate(open(p, errors="replace"), 1):
+                if any(r.search(line) for r in pats):
+                    bad.append("%s:%d: %s" % (os.path.relpath(p, root), ln, line.strip()))
+    assert not bad, bad
+    from snap_amd import aligner
+    assert aligner.LIB_PATH == os.path.join(root, "snap_amd", "libsnapgpu.so") or os.environ.get("SNAPGPU_TEST_LIB")
