@@ -46,6 +46,11 @@ def make_workload(d, n_reads, genome_bases=600_000):
             elif kind == 6: k = int(rng.integers(1, 4)); b = np.concatenate([b[k:], rng.choice(acgt, size=k)])
             elif kind == 7: name += b" some comment"
             f.write(b"@" + name + b"\n" + b[:L].tobytes() + b"\n+\n" + q[:L].tobytes() + b"\n")
+        k = n_reads
+        for L2 in (250, 380, 60):                                      # other lengths in the same file: other affine-gap kernel variants, longer cigars
+            extra = synth.make_reads(20 + L2, contigs, max(10, n_reads // 25), L2, sub=0.02, ins=0.004, dele=0.004, n_frac=0.001)
+            for i in range(extra["bases"].shape[0]):
+                f.write(b"@read%d\n" % k + extra["bases"][i].tobytes() + b"\n+\n" + extra["quals"][i].tobytes() + b"\n"); k += 1
     return index_dir, fastq
 
 
