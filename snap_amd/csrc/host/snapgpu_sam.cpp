@@ -94,7 +94,8 @@ int main(int argc, char **argv)
     const std::string index_dir = argv[2], fastq = argv[3], fastq2 = paired ? argv[4] : "";
     std::string out_path;
     snapgpu_params p; snapgpu_default_params(&p);
-    p.max_read_len = 400;
+    p.max_read_len = 400;                                                  // per-wave buffers; SNAPGPU_MAX_READ_LEN raises it (<= 1000), as for snap-aligner-gpu
+    if (const char *e = getenv("SNAPGPU_MAX_READ_LEN")) { const int v = atoi(e); if (v >= 50 && v <= 1000) p.max_read_len = (uint32_t)v; }
     bool use_m = true;                                                     // AlignerOptions.cpp:58
     unsigned min_read_len = 50;                                            // -mrl, AlignerOptions.cpp
     size_t batch_reads = 65536;
@@ -167,7 +168,7 @@ int main(int argc, char **argv)
             if (!next_read(in, id, seq, qual)) { eof = true; break; }
             std::string id2, seq2, qual2;
             if (!next_read(in2, id2, seq2, qual2)) die("the second FASTQ file has fewer reads than the first");
-            if (seq.size() > p.max_read_len || seq2.size() > p.max_read_len) die("read longer than the 400 bases this build was sized for: ", id.c_str());
+            if (seq.size() > p.max_read_len || seq2.size() > p.max_read_len) die("read longer than max_read_len (400; set SNAPGPU_MAX_READ_LEN, at most 1000): ", id.c_str());
             b.names.push_back(id); b.bases.insert(b.bases.end(), seq.begin(), seq.end()); b.quals.insert(b.quals.end(), qual.begin(), qual.end()); b.offsets.push_back(b.bases.size());
             b.names.push_back(id2); b.bases.insert(b.bases.end(), seq2.begin(), seq2.end()); b.quals.insert(b.quals.end(), qual2.begin(), qual2.end()); b.offsets.push_back(b.bases.size());
         }
@@ -255,7 +256,7 @@ int main(int argc, char **argv)
         b.clear();
         while (b.names.size() < batch_reads) {
             if (!next_read(in, id, seq, qual)) { eof = true; break; }
-            if (seq.size() > p.max_read_len) die("read longer than the 400 bases this build was sized for: ", id.c_str());
+            if (seq.size() > p.max_read_len) die("read longer than max_read_len (400; set SNAPGPU_MAX_READ_LEN, at most 1000): ", id.c_str());
             b.names.push_back(id);
             b.bases.insert(b.bases.end(), seq.begin(), seq.end());
             b.quals.insert(b.quals.end(), qual.begin(), qual.end());
