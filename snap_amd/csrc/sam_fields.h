@@ -57,7 +57,7 @@ static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
     int cum = 0, n_adj = 0;
     int oriented_dir = -1;
 
-    for (int attempt = 0; attempt < 2 * RL + 8; attempt++) {
+    for (int attempt = 0; attempt < 2 * (int)RL + 8; attempt++) {
         const int front = F0 + addF, dlen = D0 - addF - addB;
         // ---------------- createSAMLine (SAM.cpp:1424-1572)
         long long loc = final_loc;
