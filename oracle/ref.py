@@ -41,6 +41,24 @@ def lib():
     return _lib
 
 
+class fresh_objects:
+    """`with ref.fresh_objects():` -- every read / pair is aligned by reference aligner objects newly constructed in zero-filled memory
+    (oracle/ref_driver.cpp: ZeroedArena), so the reference's answer is a function of the read alone and EVERY read can be compared
+    (no exclusion of reads whose banded affine-gap traceback walks through cells an earlier read left behind)."""
+
+    def __init__(self, on: bool = True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = lib().snapref_get_fresh_objects()
+        lib().snapref_set_fresh_objects(1 if self.on else 0)
+        return self
+
+    def __exit__(self, *a):
+        lib().snapref_set_fresh_objects(self.prev)
+        return False
+
+
 def build_index(fasta: str, out_dir: str, seed_len: int = 20, threads: int = 8, large: bool = False,
                 extra=()) -> None:
     """`snap-aligner index <fasta> <dir> -s N` with the reference's own builder."""

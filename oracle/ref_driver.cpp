@@ -260,6 +260,28 @@ static void fill_result(snapgpu_single_result *o, const SingleAlignmentResult *r
     o->popular_seeds_skipped = r->popularSeedsSkipped;
 }
 
+/* "Fresh object" mode (parity exclusion): with snapref_set_fresh_objects(1) every read / pair is aligned by aligner objects
+ * that were constructed, just before the call, inside a ZERO-FILLED arena -- what a newly started reference thread would use for its first
+ * read.  The reference's answer is then a function of the read alone (its banded affine gap can trace back through cells an earlier call
+ * left in the object, AffineGapVectorized.h:740-788 over :1374; see DESIGN.md "Reference nondeterminism"), so every read can be compared,
+ * none excluded.  BigAllocator::allocate is virtual (BigAlloc.h:95): the arena below hands out zeroed memory it can take back. */
+class ZeroedArena : public BigAllocator {
+public:
+    ZeroedArena(size_t cap_) : BigAllocator(0, 16), cap(cap_ + 4096), used(0) { base = (char *)calloc(cap, 1); }
+    ~ZeroedArena() { free(base); }
+    virtual void *allocate(size_t amount) {
+        size_t a = (amount + 63) & ~(size_t)63;
+        if (used + a > cap) { fprintf(stderr, "ref_driver: ZeroedArena overflow (%zu + %zu > %zu)\n", used, a, cap); abort(); }
+        void *r = base + used; used += a; return r;
+    }
+    void reset() { memset(base, 0, used); used = 0; }          // everything handed out since the last reset reads as zero again
+private:
+    char *base; size_t cap, used;
+};
+static volatile int g_fresh_objects = 0;
+void snapref_set_fresh_objects(int on) { g_fresh_objects = on; }
+int snapref_get_fresh_objects(void) { return g_fresh_objects; }
+
 struct AlignJob {
     GenomeIndex *index;
     const snapgpu_params *p;
@@ -284,17 +306,21 @@ static void *align_thread(void *arg)
     int maxReadSize = MAX_READ_LENGTH;
 
     // mirror of SingleAligner.cpp:145-173
-    BigAllocator *allocator = new BigAllocator(
-        BaseAligner::getBigAllocatorReservation(index, true, p->max_hits, maxReadSize, index->getSeedLength(),
-                                                p->num_seeds, p->seed_coverage, -1, p->extra_search_depth) + 4096, 16);
-    BaseAligner *aligner = new (allocator) BaseAligner(
-        index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check,
-        p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0,
-        true /* ignoreAlignmentAdjustmentsForOm: the default, AlignerOptions.cpp:96 */,
-        p->alt_awareness != 0, p->emit_alt_alignments != 0, p->max_score_gap_to_prefer_non_alt,
-        -1 /* maxSecondaryAlignmentsPerContig */, NULL, NULL,
-        p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty,
-        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator);
+    const bool fresh = g_fresh_objects != 0;
+    const size_t reservation = BaseAligner::getBigAllocatorReservation(index, true, p->max_hits, maxReadSize, index->getSeedLength(),
+                                                p->num_seeds, p->seed_coverage, -1, p->extra_search_depth) + 4096;
+    ZeroedArena *arena = fresh ? new ZeroedArena(reservation + (1 << 20)) : NULL;
+    BigAllocator *allocator = fresh ? (BigAllocator *)arena : new BigAllocator(reservation, 16);
+#define NEW_SINGLE_ALIGNER() new (allocator) BaseAligner( \
+        index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check, \
+        p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, \
+        true /* ignoreAlignmentAdjustmentsForOm: the default, AlignerOptions.cpp:96 */, \
+        p->alt_awareness != 0, p->emit_alt_alignments != 0, p->max_score_gap_to_prefer_non_alt, \
+        -1 /* maxSecondaryAlignmentsPerContig */, NULL, NULL, \
+        p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty, \
+        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator)
+    BaseAligner *aligner = NEW_SINGLE_ALIGNER();
+    _int64 acc_lookups = 0, acc_lv = 0, acc_ag = 0;
 
     // A read buffer with slack: the reference's LV over-reads a few bytes past the read.
     std::vector<char> bbuf(MAX_READ_LENGTH + 2 * SLACK, 0), qbuf(MAX_READ_LENGTH + 2 * SLACK, 0);
@@ -315,6 +341,11 @@ static void *align_thread(void *arg)
             memset(&alt, 0, sizeof(alt));
             alt.status = NotFound;
             _int64 nSecondary = 0;
+            if (fresh) {                                    // a newly constructed aligner in zero-filled memory for every read
+                acc_lookups += aligner->getNHashTableLookups(); acc_lv += aligner->getLocationsScoredWithLandauVishkin();
+                acc_ag += aligner->getLocationsScoredWithAffineGap();
+                aligner->~BaseAligner(); arena->reset(); aligner = NEW_SINGLE_ALIGNER();
+            }
             // same call shape as SingleAligner.cpp:250 with the default -om (none)
             aligner->AlignRead(&read, &r, &alt, -1, 0, &nSecondary, 0, NULL, 0, NULL, NULL);
             fill_result(&job->primary[i], &r);
@@ -330,13 +361,14 @@ static void *align_thread(void *arg)
     }
 
     pthread_mutex_lock(&job->lock);
-    job->lookups += aligner->getNHashTableLookups();
-    job->lv += aligner->getLocationsScoredWithLandauVishkin();
-    job->ag += aligner->getLocationsScoredWithAffineGap();
+    job->lookups += acc_lookups + aligner->getNHashTableLookups();
+    job->lv += acc_lv + aligner->getLocationsScoredWithLandauVishkin();
+    job->ag += acc_ag + aligner->getLocationsScoredWithAffineGap();
     pthread_mutex_unlock(&job->lock);
 
     aligner->~BaseAligner();
-    delete allocator;
+    if (fresh) delete arena; else delete allocator;
+#undef NEW_SINGLE_ALIGNER
     return NULL;
 }
 
@@ -463,16 +495,19 @@ static void *align_secondary_thread(void *arg)
     GenomeIndex *index = job->index;
     int maxReadSize = MAX_READ_LENGTH;
     // SingleAligner.cpp:145-173 with -om / -mpc set
-    BigAllocator *allocator = new BigAllocator(
-        BaseAligner::getBigAllocatorReservation(index, true, p->max_hits, maxReadSize, index->getSeedLength(),
-                                                p->num_seeds, p->seed_coverage, job->mpc, p->extra_search_depth) + 4096, 16);
-    BaseAligner *aligner = new (allocator) BaseAligner(
-        index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check,
-        p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0,
-        true /* ignoreAlignmentAdjustmentsForOm */, p->alt_awareness != 0, p->emit_alt_alignments != 0,
-        p->max_score_gap_to_prefer_non_alt, job->mpc, NULL, NULL,
-        p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty,
-        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator);
+    const bool fresh = g_fresh_objects != 0;
+    const size_t reservation = BaseAligner::getBigAllocatorReservation(index, true, p->max_hits, maxReadSize, index->getSeedLength(),
+                                                p->num_seeds, p->seed_coverage, job->mpc, p->extra_search_depth) + 4096;
+    ZeroedArena *arena = fresh ? new ZeroedArena(reservation + (1 << 20)) : NULL;
+    BigAllocator *allocator = fresh ? (BigAllocator *)arena : new BigAllocator(reservation, 16);
+#define NEW_SEC_ALIGNER() new (allocator) BaseAligner( \
+        index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check, \
+        p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, \
+        true /* ignoreAlignmentAdjustmentsForOm */, p->alt_awareness != 0, p->emit_alt_alignments != 0, \
+        p->max_score_gap_to_prefer_non_alt, job->mpc, NULL, NULL, \
+        p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty, \
+        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator)
+    BaseAligner *aligner = NEW_SEC_ALIGNER();
     std::vector<char> bbuf(MAX_READ_LENGTH + 2 * SLACK, 0), qbuf(MAX_READ_LENGTH + 2 * SLACK, 0);
     // the result buffer of SingleAligner.cpp:176-190: [0] primary, [1..] secondary; doubled when AlignRead says it is too small
     _int64 bufCount = 32;
@@ -495,6 +530,7 @@ static void *align_secondary_thread(void *arg)
             _int64 nSecondary = 0;
             for (;;) {
                 memset(&buf[0], 0, sizeof(SingleAlignmentResult) * bufCount);
+                if (fresh) { aligner->~BaseAligner(); arena->reset(); aligner = NEW_SEC_ALIGNER(); }
                 if (aligner->AlignRead(&read, &buf[0], &alt, job->om, bufCount - 1, &nSecondary, job->omax, &buf[1], 0, NULL, NULL)) break;
                 bufCount *= 2;                                  // SingleAligner.cpp:250-263
                 buf.resize(bufCount);
@@ -517,7 +553,8 @@ static void *align_secondary_thread(void *arg)
         }
     }
     aligner->~BaseAligner();
-    delete allocator;
+    if (fresh) delete arena; else delete allocator;
+#undef NEW_SEC_ALIGNER
     return NULL;
 }
 
@@ -612,20 +649,24 @@ static void *paired_thread(void *arg)
         p->seed_coverage, MAX_K, p->extra_search_depth, pp->max_candidate_pool_size, maxSecondaryAlignmentsPerContig);
     _int64 maxPairedCand = p->use_affine_gap ? 4096 : 0, maxSingleCand = p->use_affine_gap ? 4096 : 0;
     memoryPoolSize += 4096;
-    BigAllocator *allocator = new BigAllocator(memoryPoolSize, 16);
+    const bool fresh = g_fresh_objects != 0;
+    ZeroedArena *arena = fresh ? new ZeroedArena(memoryPoolSize + (4 << 20)) : NULL;
+    BigAllocator *allocator = fresh ? (BigAllocator *)arena : new BigAllocator(memoryPoolSize, 16);
 
-    IntersectingPairedEndAligner *intersectingAligner = new (allocator) IntersectingPairedEndAligner(index, maxReadSize, p->max_hits, p->max_k,
-        pp->max_k_for_indels, pp->num_seeds, pp->seed_coverage, pp->min_spacing, pp->max_spacing, pp->max_big_hits, p->extra_search_depth,
-        pp->max_candidate_pool_size, maxSecondaryAlignmentsPerContig, allocator, DisabledOptimizations(), p->use_affine_gap != 0,
-        true /* ignoreAlignmentAdjustmentForOm */, p->alt_awareness != 0, p->max_score_gap_to_prefer_non_alt,
-        p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty, pp->use_soft_clipping != 0);
-
-    ChimericPairedEndAligner *aligner = new (allocator) ChimericPairedEndAligner(index, maxReadSize, p->max_hits, p->max_k, pp->max_single_seeds,
-        p->seed_coverage, p->min_weight_to_check, pp->force_spacing != 0, p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0,
-        true, p->alt_awareness != 0, p->emit_alt_alignments != 0, intersectingAligner, pp->min_read_length, maxSecondaryAlignmentsPerContig,
-        p->max_score_gap_to_prefer_non_alt, pp->flatten_mapq_at_or_below, pp->use_soft_clipping != 0, p->match_reward, p->sub_penalty,
-        p->gap_open_penalty, p->gap_extend_penalty, p->five_prime_end_bonus, p->three_prime_end_bonus, pp->min_score_realignment,
-        pp->min_score_gap_realignment_alt, pp->min_ag_score_improvement, pp->enable_hamming_scoring_base_aligner != 0, allocator);
+#define NEW_INTERSECTING() new (allocator) IntersectingPairedEndAligner(index, maxReadSize, p->max_hits, p->max_k, \
+        pp->max_k_for_indels, pp->num_seeds, pp->seed_coverage, pp->min_spacing, pp->max_spacing, pp->max_big_hits, p->extra_search_depth, \
+        pp->max_candidate_pool_size, maxSecondaryAlignmentsPerContig, allocator, DisabledOptimizations(), p->use_affine_gap != 0, \
+        true /* ignoreAlignmentAdjustmentForOm */, p->alt_awareness != 0, p->max_score_gap_to_prefer_non_alt, \
+        p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty, pp->use_soft_clipping != 0)
+#define NEW_CHIMERIC() new (allocator) ChimericPairedEndAligner(index, maxReadSize, p->max_hits, p->max_k, pp->max_single_seeds, \
+        p->seed_coverage, p->min_weight_to_check, pp->force_spacing != 0, p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, \
+        true, p->alt_awareness != 0, p->emit_alt_alignments != 0, intersectingAligner, pp->min_read_length, maxSecondaryAlignmentsPerContig, \
+        p->max_score_gap_to_prefer_non_alt, pp->flatten_mapq_at_or_below, pp->use_soft_clipping != 0, p->match_reward, p->sub_penalty, \
+        p->gap_open_penalty, p->gap_extend_penalty, p->five_prime_end_bonus, p->three_prime_end_bonus, pp->min_score_realignment, \
+        pp->min_score_gap_realignment_alt, pp->min_ag_score_improvement, pp->enable_hamming_scoring_base_aligner != 0, allocator)
+    IntersectingPairedEndAligner *intersectingAligner = NEW_INTERSECTING();
+    ChimericPairedEndAligner *aligner = NEW_CHIMERIC();
+    _int64 acc_lv = 0, acc_ag = 0;
 
     // PairedAligner.cpp:556-566, 600-640: results[0] is the primary, results + 1 the paired secondary buffer
     _int64 maxPairedSecondaryHits = job->om < 0 ? 0 : 32, maxSingleSecondaryHits = job->om < 0 ? 0 : 32;
@@ -655,6 +696,12 @@ static void *paired_thread(void *arg)
             _int64 nSecondary = 0, nPairedCand = 0, nSingleSecondary[2] = {0, 0}, nSingleCand[2] = {0, 0};
             for (;;) {
                 bool ok;
+                if (fresh) {                                // newly constructed aligners in zero-filled memory for every call
+                    acc_lv += aligner->getLocationsScoredWithLandauVishkin(); acc_ag += aligner->getLocationsScoredWithAffineGap();
+                    aligner->~ChimericPairedEndAligner(); intersectingAligner->~IntersectingPairedEndAligner();
+                    arena->reset();
+                    intersectingAligner = NEW_INTERSECTING(); aligner = NEW_CHIMERIC();
+                }
                 memset(results, 0, (maxPairedSecondaryHits + 1) * sizeof(PairedAlignmentResult));
                 if (singleSecondary) memset(singleSecondary, 0, maxSingleSecondaryHits * sizeof(SingleAlignmentResult));
                 if (job->stage == 1) {
@@ -703,8 +750,8 @@ static void *paired_thread(void *arg)
     }
 
     pthread_mutex_lock(&job->lock);
-    job->lv += aligner->getLocationsScoredWithLandauVishkin();
-    job->ag += aligner->getLocationsScoredWithAffineGap();
+    job->lv += acc_lv + aligner->getLocationsScoredWithLandauVishkin();
+    job->ag += acc_ag + aligner->getLocationsScoredWithAffineGap();
     pthread_mutex_unlock(&job->lock);
 
     if (pairedCand) BigDealloc(pairedCand);
@@ -713,7 +760,9 @@ static void *paired_thread(void *arg)
     if (singleSecondary) BigDealloc(singleSecondary);
     aligner->~ChimericPairedEndAligner();
     intersectingAligner->~IntersectingPairedEndAligner();
-    delete allocator;
+    if (fresh) delete arena; else delete allocator;
+#undef NEW_INTERSECTING
+#undef NEW_CHIMERIC
     return NULL;
 }
 

@@ -296,22 +296,23 @@ def run_sam_fields_device_form(aligner, z, tag, n, to_dev, to_host):
 
 
 def test_sam_fields_device_pointer_form(golden_index):
-    """Same answers as the host-pointer form, with everything resident in HBM (torch tensors on cuda:0)."""
+    """Same answers as the host-pointer form, with everything resident in HBM.  Device buffers come from hipMalloc / hipMemcpy of the HIP
+    runtime libsnapgpu.so itself is linked against (tests/util.py: HipBuffers) -- not from torch, whose bundled runtime cannot be
+    initialised once another copy of libamdhip64 owns the device (GPUTEST_r01: 'No HIP GPUs are available')."""
     import os
-    import torch
     from snap_amd.aligner import BaseAligner
     z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
     n = 1200
+    hip = util.HipBuffers()
     def to_dev(x):
-        t = torch.from_numpy(np.ascontiguousarray(x).view(np.uint8).reshape(-1).copy()).cuda()
-        return (t, t.data_ptr())
+        return (None, hip.upload(x))
     def to_host(t, like):
-        torch.cuda.synchronize()
-        return t[0].cpu().numpy().view(like.dtype).reshape(like.shape)
+        return hip.download(t[1], like)
     a = BaseAligner(golden_index, abi.default_params(max_k=14, max_read_len=400))
     try:
         flag, contig, pos, mapq, ops, n_ops, nm, stale = run_sam_fields_device_form(a, z, "default", n, to_dev, to_host)
     finally:
+        hip.free_all()
         a.close()
     for k, v in (("flag", flag), ("contig", contig), ("pos", pos), ("mapq", mapq), ("nm", nm), ("n_ops", n_ops)):
         assert (v == z["default_" + k][:n]).all(), k
