@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20260925)
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline (0 = auto, ~10-30 s)")
     ap.add_argument("--skip-cpu", action="store_true")
+    ap.add_argument("--skip-probe", action="store_true", help="skip the stand-alone index-probe measurement (roofline.probe)")
     ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
     ap.add_argument("--workload", choices=["single", "paired"], default="single",
                     help="single = configs[1] (the metric's config); paired = configs[2], 2x150 bp FR pairs through the paired-end path")
@@ -178,6 +179,38 @@ def main():
     if rank != 0:
         return
 
+    # ---------------------------------------------------------------- the index-probe kernel on its own (north_star: HBM roofline of the probe)
+    # k_lookup_seeds over >= 10^7 seeds drawn from the bench reads (every 13th offset of every read), hit lists read as BaseAligner
+    # consumes them (at most -h 300 per direction) but not stored; timed with hipEvents on the launch stream inside libsnapgpu.so.
+    probe = None
+    if not paired and not args.skip_probe:
+        L, S = args.read_len, args.seed_len
+        offs13 = np.arange(0, L - S + 1, 13)
+        rb = reads["bases"].reshape(n, L)
+        seeds = np.ascontiguousarray(np.stack([rb[:, o:o + S] for o in offs13], axis=1).reshape(-1, S))
+        n_seeds = seeds.shape[0]
+        d_seeds = torch.from_numpy(seeds.reshape(-1)).to(dev)
+        d_nh = torch.zeros(2 * n_seeds, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        aligner.lookup_device(n_seeds, d_seeds.data_ptr(), d_nh.data_ptr(), 0, 300)          # warm-up
+        aligner.counters(reset=True); aligner.kernel_time(reset=True)
+        reps = 5
+        for _ in range(reps):
+            aligner.lookup_device(n_seeds, d_seeds.data_ptr(), d_nh.data_ptr(), 0, 300)
+        pc = aligner.counters(reset=True); pms, pl = aligner.kernel_time(reset=True)
+        pb = (8 * pc["n_hash_slots_probed"] + 4 * pc["n_overflow_lists"] + 4 * pc["n_hits_consumed"] + S * n_seeds * reps + 16 * n_seeds * reps) / reps
+        pavg = pms / max(1, pl)
+        probe = {"kernel": "k_lookup_seeds", "seeds_per_launch": n_seeds, "avg_launch_ms": pavg, "lookups_per_s": n_seeds / (pavg * 1e-3),
+                 "algorithmic_bytes_per_launch": pb, "achieved": pb / (pavg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": pb / (pavg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "slots_per_lookup": pc["n_hash_slots_probed"] / max(1, pc["n_hash_table_lookups"]),
+                 "hits_per_lookup": pc["n_hits_consumed"] / max(1, pc["n_hash_table_lookups"]),
+                 # the sector-level figure SURVEY.md 8(d) asks for next to the algorithmic one: every slot walk touches whole 64 B lines.
+                 # Lower bound on lines: one per direction for the walk + one per 16 hits read + one for the seed text / counts
+                 "min_64B_lines_per_lookup": 2 + pc["n_hits_consumed"] / max(1, pc["n_hash_table_lookups"]) / 16 + pc["n_overflow_lists"] / max(1, pc["n_hash_table_lookups"]),
+                 "note": "algorithmic bytes = 8 B per slot examined + 4 B per overflow count word + 4 B per hit read + seed text in + hit counts out"}
+        del d_seeds, d_nh
+
     # ---------------------------------------------------------------- report (rank 0)
     total_reads = n * world * args.steps
     value = total_reads / elapsed
@@ -205,6 +238,8 @@ def main():
                                   "ag_locations": per_launch["n_ag_locations"] / n}},
         "aligned_fraction": float((prim["status"] != 0).mean()),
     }
+    if probe is not None:
+        out["roofline"]["probe"] = probe
     tot = max(1, counters.get("cycles_total", 0))
     out["roofline"]["wave_cycle_breakdown"] = {k[7:]: counters[k] / tot for k in
                                               ("cycles_lookup", "cycles_hits", "cycles_lv", "cycles_ag") + (("cycles_single_fallback",) if paired else ())
@@ -215,16 +250,21 @@ def main():
         try:
             t = json.load(open(pmc))
             if t.get("reads_per_launch") == n and t.get("genome_mb") == args.genome_mb and t.get("workload", "single") == args.workload:
+                # PMC counters need their own rocprofv3 --pmc passes (scripts/gpu_pmc_traffic.sh); what is reported here is REPLAYED from
+                # the committed summary of the last such pass and says which build / profile directory it came from
                 out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = "replayed from profiles/pmc_latest.json (rocprofv3 --pmc pass '%s'), not measured in this run" % t.get("source", "?")
                 if t.get("valu_insts_per_launch"):
                     # the LV / affine-gap work is integer VALU, not HBM.  Wave-level VALU instructions of one launch
                     # (rocprofv3 --pmc SQ_INSTS_VALU, profiles/) over this run's launch time, against the issue peak of the chip:
-                    # 256 CUs x 4 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz (MI355X_MICROARCH.md)
-                    peak = 256 * 4 * 2.4e9 / 4 / 1e9
+                    # 256 CUs x 4 SIMD32s, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: v_fma_f32 wave64 =
+                    # 2 cycles), 2.4 GHz  =>  256 * 4 * 2.4e9 / 2 = 1228.8 G wave-instructions/s
+                    peak = 256 * 4 * 2.4e9 / 2 / 1e9
                     ach = t["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
                     out["roofline"]["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
                                                      "valu_insts_per_read": t["valu_insts_per_launch"] / n,
-                                                     "salu_insts_per_read": t.get("salu_insts_per_launch", 0) / n}
+                                                     "salu_insts_per_read": t.get("salu_insts_per_launch", 0) / n,
+                                                     "source": "instruction counts replayed from profiles/pmc_latest.json ('%s'); launch time of this run" % t.get("source", "?")}
         except Exception:
             pass
 
@@ -248,16 +288,43 @@ def main():
         out["cpu_baseline"] = {"value": per * sample / secs, "unit": "reads/s", "cores": cores, "kind": "reference",
                                "sample": "first %d %s of the same batch, %s via oracle/_ref (SNAP 2.0.5 built -O3), %d threads, align phase only"
                                          % (sample, "pairs" if paired else "reads", "ChimericPairedEndAligner::align" if paired else "BaseAligner::AlignRead", cores)}
-        # the baseline's results double as a parity spot check of the timed GPU output
+        # The baseline's results double as a parity check of the timed GPU output: EVERY unit of the sample is compared, none excluded.
+        # The reads / pairs whose banded affine-gap traceback left the band (`reserved` != 0) were redone on the GPU the way a newly
+        # constructed reference aligner does them (exact replay); for those the expectation is the reference run with fresh objects
+        # (oracle/ref_driver.cpp: ZeroedArena), because the long-lived objects of the timed run answer such reads from their history.
         flagged = prim["reserved"][:sample] != 0
+        fi = np.nonzero(flagged)[0]
+        history_dependent = 0
+        if fi.size:
+            per_unit = 2 if paired else 1
+            ro = reads["offsets"].astype(np.int64)
+            sel = np.concatenate([np.arange(per_unit * i, per_unit * i + per_unit) for i in fi])
+            fb = np.concatenate([reads["bases"].reshape(-1)[ro[j]:ro[j + 1]] for j in sel])
+            fq = np.concatenate([reads["quals"].reshape(-1)[ro[j]:ro[j + 1]] for j in sel])
+            fo = np.concatenate([[0], np.cumsum([ro[j + 1] - ro[j] for j in sel])]).astype(np.uint64)
+            with ref.fresh_objects():
+                if paired:
+                    fr = ri.align_paired(params, pparams, fb, fq, fo, threads=min(cores, 16), stage=0)[0]
+                else:
+                    fr = ri.align_single(params, fb, fq, fo, threads=min(cores, 16))[0]
+            pr = pr.copy()
+            if paired:
+                from tests.pairs_util import compare_paired as _cp
+                history_dependent = int(_cp(pr[fi], fr, verbose=0).sum())
+            else:
+                from tests.util import compare_results as _cr
+                history_dependent = sum(1 for i, j in enumerate(fi) if _cr(pr[j:j + 1], fr[i:i + 1]))
+            pr[fi] = fr
         if paired:
             from tests.pairs_util import compare_paired
-            bad = compare_paired(pr, prim[:sample], verbose=0, exclude=flagged)
-            out["parity_check"] = {"pairs": sample, "mismatching_pairs": int(bad.sum()), "reference_unstable_flagged": int(flagged.sum())}
+            bad = compare_paired(pr, prim[:sample], verbose=0)
+            out["parity_check"] = {"pairs": sample, "mismatching_pairs": int(bad.sum()), "excluded": 0, "exact_replayed": int(flagged.sum()),
+                                   "of_which_reference_history_dependent": history_dependent}
         else:
             from tests.util import compare_results
-            problems = compare_results(pr, prim[:sample], exclude=flagged)
-            out["parity_check"] = {"reads": sample, "mismatching_fields": problems, "reference_unstable_flagged": int(flagged.sum())}
+            problems = compare_results(pr, prim[:sample])
+            out["parity_check"] = {"reads": sample, "mismatching_fields": problems, "excluded": 0, "exact_replayed": int(flagged.sum()),
+                                   "of_which_reference_history_dependent": history_dependent}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     aligner.close()
     del keep

@@ -267,6 +267,24 @@ void snapgpu_destroy(snapgpu_ctx *ctx);
  * (e.g. the AlignerExtension shim of INTEGRATION.md) calls.                                      */
 int  snapgpu_create_from_directory(const char *index_dir, const snapgpu_params *p, int device, snapgpu_ctx **out);
 
+/*
+ * Several contexts over ONE index: the reference runs one aligner object per thread over the shared, read-only g_index
+ * (SNAPLib/ParallelTask.h:128-138, SingleAligner.cpp:145-173, AlignerContext.cpp:253-266).  Here a context is the unit of concurrency: calls on
+ * one context are serial (one launch in flight, shared per-wave scratch), different contexts run concurrently on their own streams.
+ *   snapgpu_device_count       visible HIP devices (0 without a GPU)
+ *   snapgpu_create_replica     another context with src's options over src's index, on `device`:
+ *                                share_index != 0  device must be src's: the new context ADOPTS src's index blobs in HBM (a second feeder
+ *                                                  thread on the same GPU; destroy it before src)
+ *                                share_index == 0  same-size blobs are allocated on `device` and left unfilled for snapgpu_broadcast_index
+ *                              (snapgpu_enable_paired / _secondary are per context: call them on the replica as on src)
+ *   snapgpu_broadcast_index    fills the blobs of ctxs[1 .. n) from ctxs[0] (the one that read the index) with one RCCL broadcast per blob
+ *                              over xGMI -- the only collective of the whole path; reads never cross GPUs.  n == 1 is a no-op.
+ *                              SNAPGPU_E_UNSUPPORTED when librccl cannot be loaded (the caller may then load the directory per device).
+ */
+int  snapgpu_device_count(void);
+int  snapgpu_create_replica(const snapgpu_ctx *src, int device, int share_index, snapgpu_ctx **out);
+int  snapgpu_broadcast_index(snapgpu_ctx **ctxs, int n);
+
 /* Device pointers of the context's index blobs, so that a caller that owns the
  * collective (RCCL broadcast of the index) can fill them in place.
  * Each pointer may be NULL if the caller does not want it.                               */
@@ -282,6 +300,13 @@ int  snapgpu_index_device_ptrs(snapgpu_ctx *ctx, void **hash_blob, void **overfl
  */
 int  snapgpu_lookup_seeds(snapgpu_ctx *ctx, uint32_t n, const char *seeds,
                           int64_t *n_hits, uint32_t *hits, uint32_t max_hits_out);
+
+/* Device-pointer form: d_seeds (n * seed_len bytes), d_n_hits ([2n] int64) and d_hits ([2n * max_hits_out] uint32, or NULL: hit counts
+ * only -- the lists are then read, up to max_hits_out entries each as BaseAligner consumes them, but not stored) are device pointers.
+ * The launch is timed (snapgpu_kernel_time) and counted (snapgpu_get_counters: lookups, slots examined, hits, overflow lists), which
+ * makes it the stand-alone index-probe kernel whose HBM roofline bench.py reports.  `stream` as in snapgpu_align_single_device. */
+int  snapgpu_lookup_seeds_device(snapgpu_ctx *ctx, uint32_t n, const void *d_seeds, void *d_n_hits, void *d_hits,
+                                 uint32_t max_hits_out, void *stream);
 
 /*
  * Batched LandauVishkin<dir>::computeEditDistance.  Problem i:

@@ -692,7 +692,19 @@ int oracle_align_read(const oracle_index *ix, const oracle_genome *g, const snap
                       const snapgpu_secondary_params *sp, snapgpu_single_result *secondary, uint32_t sec_room, uint32_t *n_secondary,
                       uint32_t *stale)
 {
-    return align_read_ex(ix, g, p, (int)p->max_k, 0, bases, quals, len, primary, first_alt, sp, secondary, sec_room, n_secondary, stale, NULL);
+    /* a NEWLY CONSTRUCTED BaseAligner for this read: its affineGap / reverseAffineGap traceback arrays start zero-filled and persist
+       over the calls of the read (unless the caller bound the arrays of a longer-lived aligner itself) */
+    uint8_t *f0, *b0; size_t c0;
+    oracle_ag_bound_objects(&f0, &b0, &c0);
+    uint8_t *mine = NULL;
+    if (!f0) {
+        const size_t cap = ((size_t)len + 128) * ((size_t)len + 264);
+        mine = calloc(2 * cap, 1);
+        oracle_ag_bind_objects(mine, mine + cap, cap);
+    }
+    int rc = align_read_ex(ix, g, p, (int)p->max_k, 0, bases, quals, len, primary, first_alt, sp, secondary, sec_room, n_secondary, stale, NULL);
+    if (mine) { oracle_ag_bind_objects(NULL, NULL, 0); free(mine); }
+    return rc;
 }
 
 /* the single-end aligner inside ChimericPairedEndAligner: `p` holds its constructor arguments (maxK / 2, maxSeedsSingleEnd) */

@@ -17,6 +17,7 @@
  */
 #include "snap_oracle.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -283,6 +284,16 @@ int oracle_lv(int dir, const char *text, int text_len, const char *pattern, cons
  * carries F/H across segments, and the banded variant only touches vectors inside the band. */
 typedef struct { int16_t v[8]; } vec8;
 
+/* One reference AffineGapVectorized object keeps its traceback array between calls (backtraceAction, AffineGapVectorized.h:1374), and
+ * the banded traceback can step onto cells of an earlier call (:740-788).  oracle_ag_bind_objects gives the calling thread the images
+ * of the two objects of ONE aligner (affineGap: dir 1, reverseAffineGap: dir -1), zero-filled by the caller when "the aligner is
+ * constructed": oracle_ag then writes and reads them with the reference's flat addressing, so its answers are those of a newly
+ * constructed reference aligner scoring the same sequence of calls.  Unbound (NULL): every call is its own zero-filled object. */
+static __thread uint8_t *g_ag_object[2] = {NULL, NULL};
+static __thread size_t g_ag_object_cap = 0;
+void oracle_ag_bind_objects(uint8_t *fwd, uint8_t *bwd, size_t cap_each) { g_ag_object[0] = fwd; g_ag_object[1] = bwd; g_ag_object_cap = cap_each; }
+void oracle_ag_bound_objects(uint8_t **fwd, uint8_t **bwd, size_t *cap_each) { *fwd = g_ag_object[0]; *bwd = g_ag_object[1]; *cap_each = g_ag_object_cap; }
+
 static int16_t sat16(int x) { return (int16_t)(x > 32767 ? 32767 : x < -32768 ? -32768 : x); }
 
 int oracle_ag(int dir, int banded, const oracle_ag_params *prm, const char *text, int text_len,
@@ -322,8 +333,9 @@ int oracle_ag(int dir, int banded, const oracle_ag_params *prm, const char *text
 
     vec8 *H = calloc(nv_tot, sizeof(vec8)), *Hm1 = calloc(nv_tot, sizeof(vec8)), *E = calloc(nv_tot, sizeof(vec8));
     size_t bt_cells = (size_t)text_len * nv_tot * 8;
-    uint8_t *BT = malloc(bt_cells ? bt_cells : 1), *BTw = calloc(bt_cells ? bt_cells : 1, 1);
-    memset(BT, 0xff, bt_cells ? bt_cells : 1);
+    uint8_t *bound = g_ag_object[dir == -1 ? 1 : 0];
+    if (bound && bt_cells > g_ag_object_cap) { fprintf(stderr, "oracle_ag: bound traceback object too small (%zu > %zu)\n", bt_cells, g_ag_object_cap); abort(); }
+    uint8_t *BT = bound ? bound : calloc(bt_cells ? bt_cells : 1, 1), *BTw = calloc(bt_cells ? bt_cells : 1, 1);
 
     /* first row (:399-414 / :971-983): note scoreFirstRow[] keeps stale lane values for padding lanes */
     {
@@ -510,6 +522,6 @@ int oracle_ag(int dir, int banded, const oracle_ag_params *prm, const char *text
         *match_probability *= g_indel[*pattern_offset];
         ret = score;
     }
-    free(H); free(Hm1); free(E); free(BT); free(BTw);
+    free(H); free(Hm1); free(E); if (!bound) free(BT); free(BTw);
     return ret;
 }

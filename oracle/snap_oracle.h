@@ -4,6 +4,7 @@
  */
 #ifndef SNAP_ORACLE_H
 #define SNAP_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -42,6 +43,8 @@ typedef struct oracle_ag_params { int match_reward, sub_penalty, gap_open, gap_e
 /* AffineGapVectorized<dir>::computeScore (banded == 0) / computeScoreBanded (banded != 0).
  * *stale_reads (if non-NULL) counts traceback reads of cells this call never wrote (the reference
  * would read whatever an earlier call left there). */
+void   oracle_ag_bind_objects(uint8_t *fwd, uint8_t *bwd, size_t cap_each);      /* see snap_oracle.c: the traceback arrays of ONE aligner's two objects */
+void   oracle_ag_bound_objects(uint8_t **fwd, uint8_t **bwd, size_t *cap_each);
 int    oracle_ag(int dir, int banded, const oracle_ag_params *prm, const char *text, int text_len,
                  const char *pattern, const char *quality, int pattern_len, int w, int score_init,
                  int is_rc, int use_clipping, int *text_offset, int *pattern_offset, int *n_edits,

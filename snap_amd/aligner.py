@@ -45,9 +45,9 @@ def load_library():
 
 EXPORTED_SYMBOLS = [
     "snapgpu_abi_version", "snapgpu_last_error", "snapgpu_default_params", "snapgpu_create",
-    "snapgpu_destroy", "snapgpu_create_from_directory", "snapgpu_default_paired_params", "snapgpu_enable_paired",
+    "snapgpu_destroy", "snapgpu_create_from_directory", "snapgpu_device_count", "snapgpu_create_replica", "snapgpu_broadcast_index", "snapgpu_default_paired_params", "snapgpu_enable_paired",
     "snapgpu_align_paired", "snapgpu_align_paired_device", "snapgpu_index_device_ptrs", "snapgpu_lookup_seeds",
-    "snapgpu_landau_vishkin", "snapgpu_affine_gap", "snapgpu_align_single",
+    "snapgpu_lookup_seeds_device", "snapgpu_landau_vishkin", "snapgpu_affine_gap", "snapgpu_align_single",
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
     "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
     "snapgpu_align_paired_secondary", "snapgpu_align_paired_secondary_device",
@@ -147,6 +147,13 @@ class BaseAligner:
         self._check(self.lib.snapgpu_lookup_seeds(self.handle, C.c_uint32(n), ptr(seeds), ptr(n_hits), ptr(hits),
                                                   C.c_uint32(max_hits_out)), "snapgpu_lookup_seeds")
         return n_hits, hits
+
+    def lookup_device(self, n: int, d_seeds: int, d_n_hits: int, d_hits: int = 0, max_hits_out: int = 300, stream: int = 0):
+        """GenomeIndex::lookupSeed32 for n seeds already in HBM (device pointers); d_hits = 0: hit counts only (lists read, not stored).
+        Timed and counted like the align kernels: the stand-alone index-probe kernel."""
+        self._check(self.lib.snapgpu_lookup_seeds_device(self.handle, C.c_uint32(n), C.c_void_p(d_seeds), C.c_void_p(d_n_hits),
+                                                         C.c_void_p(d_hits) if d_hits else None, C.c_uint32(max_hits_out),
+                                                         C.c_void_p(stream) if stream else None), "snapgpu_lookup_seeds_device")
 
     # ---- LandauVishkin<dir>::computeEditDistance ---------------------------------------
     def computeEditDistance(self, direction: int, texts, patterns, quals, k):

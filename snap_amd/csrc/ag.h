@@ -55,7 +55,11 @@ static __device__ __forceinline__ int wave_max_i32(int v) {
     return v;
 }
 
-template <typename PSeq, typename TSeq, typename QSeq>
+// EXACT: the replay mode of flagged reads (DESIGN.md "Reference nondeterminism"): bt_scratch is then the wave's image of ONE reference
+// object's backtraceAction array (AffineGapVectorized.h:1374) -- same flat addressing (row * numVec * numSeg + vector, SSE element), zeroed
+// when the read starts and kept across the calls of the read -- and the traceback reads whatever that array holds, so a step outside the
+// band of this call sees what an EARLIER call for the same read left there, exactly as a newly constructed reference aligner does.
+template <bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_compute(
     bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
@@ -301,7 +305,7 @@ static __device__ __forceinline__ AGResult ag_compute(
                 int cj = col / seg_len, ck = (col % seg_len) % num_vec;
                 computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
             }
-            int bits = computed ? (int)first_u32(bt_scratch[(size_t)row * row_cells + vi * 8 + li]) : 0;
+            int bits = (EXACT || computed) ? (int)first_u32(bt_scratch[(size_t)row * row_cells + vi * 8 + li]) : 0;
             if (!computed) res.stale_reads++;
             action = (bits >> (action << 1)) & 3;
             if (action == 0) {

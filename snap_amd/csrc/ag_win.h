@@ -46,6 +46,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     const int segsel = lane / seg_len;                          // 0, 1 (>= 2: lane beyond the two segments)
     const int rr = lane - segsel * seg_len;
     const int l = rr / num_vec, k = rr - l * num_vec;
+    const bool is_x_lane = segsel == 1 && l == 0;                // stripe 0 of the window's second segment: where the F carried over enters
 
     // value of the reference's first-row H at position p, incl. the stale scoreFirstRow[] inheritance
     auto first_row = [&](int p) -> int {
@@ -111,93 +112,154 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         }
         const int p = wbase + lane;
         const bool valid = p < tot;
-        const int seg_end_sel = ((jbase + 1) * seg_len <= band_end) ? 1 : 0;
         int h_init0 = score_init;
         if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
-        int mxv = 0, X0 = 0, fin = 0, btr = 0;
-        bool did = false;
+        int mxv = 0, X0 = 0, btr = 0;
         const int prof = pbv == 5 ? -32768 : ((tb > 3 || pbv > 3) ? -1 : (tb == pbv ? match : sub));
+        // The reference finishes segment j (first pass, then lazy F) before it starts segment j + 1, and the only thing that crosses
+        // over is X, the F that left segment j's last stripe, which enters stripe 0 of segment j + 1.  Everything else of the two
+        // first passes is independent, so both segments go through ONE first pass (each lane knows its segment), the few stripe-0
+        // lanes of the second segment take X in afterwards (F only ever raises the values derived from it), and the first lazy-F round
+        // -- the only one in all but a few rows -- runs for both segments at once.
+        const int two = ((jbase + 1) * seg_len <= band_end) ? 1 : 0;
+        int nk0 = band_end - wbase + 1; if (nk0 > num_vec) nk0 = num_vec;
+        int nk1 = 0;
+        if (two) { nk1 = band_end - (wbase + seg_len) + 1; if (nk1 > num_vec) nk1 = num_vec; }
+        const int nkl = segsel == 0 ? nk0 : nk1;
+        const bool inseg = valid && segsel <= two && k < nkl;
+        const unsigned long long inseg_mask = BALLOT(inseg);
 
-        for (int s = 0; s <= seg_end_sel; s++) {
-            const int seg_start = wbase + s * seg_len;
-            int nk = band_end - seg_start + 1; if (nk > num_vec) nk = num_vec;
-            const bool inseg = valid && segsel == s && k < nk;
-            const bool isend = inseg && k == nk - 1;
-            // H(i-1, p-1): the lane to the left; window lane 0 follows the reference's segment-start rule (:461-476)
-            int lane0_in;
-            if (wbase == 0) lane0_in = h_init0;
-            else lane0_in = (band_beg > wbase) ? 0 : left_h;
-            int h_in = ag_shr1(lane0_in, Hp);
-            int m = h_in > 0 ? ag_sat16(h_in + prof) : 0;
-            int e = E;
-            int bt = e > m ? 1 : 0;
-            int hp = m > e ? m : e;
-            int e2 = e - gap_ext;
-            int tmp = m - gap_open; if (tmp < 0) tmp = 0;
-            if (e2 > tmp) bt |= 4;
-            // first-pass F along the (at most 4) vectors of a stripe: F(k) = max_{j<k} (tmp_j - (k-1-j)*ext), a prefix max of
-            // tmp_j + p_j*ext over the lanes to the left that belong to the same stripe -- two shift-and-max steps
-            int g = inseg ? tmp + p * gap_ext : AG_NEG;
-            { int a = ag_shr1(AG_NEG, g); if (k >= 1) g = a > g ? a : g; }
-            { int b = ag_shr1(AG_NEG, ag_shr1(AG_NEG, g)); if (k >= 2) g = b > g ? b : g; }
-            int pm = ag_shr1(AG_NEG, g);
-            const int fin_cell = l == 0 ? fin : 0;
-            int fk = fin_cell - k * gap_ext;
-            if (k >= 1) { int a = pm - (p - 1) * gap_ext; fk = a > fk ? a : fk; }
-            // (selects, not branches: a divergent `if` costs more scalar exec-mask bookkeeping than the arithmetic it skips)
-            bt |= fk > hp ? 2 : 0;
-            hp = fk > hp ? fk : hp;
-            const int f2p = fk - gap_ext;
-            bt |= f2p > tmp ? 32 : 0;
-            const int endv = inseg ? (f2p > tmp ? f2p : tmp) : 0;
-            Hm = inseg ? hp : Hm;
-            E = inseg ? (e2 > tmp ? e2 : tmp) : E;
-            mxv = inseg && hp > mxv ? hp : mxv;
-            btr = inseg ? bt : btr;
-            did = did || inseg;
+        // ---------------- first pass, both segments (:483-531)
+        int lane0_in;                                              // H(i-1, p-1) of window lane 0: the reference's segment-start rule (:461-476)
+        if (wbase == 0) lane0_in = h_init0;
+        else lane0_in = (band_beg > wbase) ? 0 : left_h;
+        const int h_in = ag_shr1(lane0_in, Hp);
+        const int m = h_in > 0 ? ag_sat16(h_in + prof) : 0;
+        const int e = E;
+        const int bt_e0 = e > m ? 1 : 0;
+        const int hpp = m > e ? m : e;
+        const int e2 = e - gap_ext;
+        int tmp = m - gap_open; if (tmp < 0) tmp = 0;
+        const int bt_e = bt_e0 | (e2 > tmp ? 4 : 0);
+        // first-pass F along the (at most 4) vectors of a stripe: F(k) = max_{j<k} (tmp_j - (k-1-j)*ext), a prefix max of
+        // tmp_j + p_j*ext over the lanes to the left that belong to the same stripe -- two shift-and-max steps
+        int g = inseg ? tmp + p * gap_ext : AG_NEG;
+        { int a = ag_shr1(AG_NEG, g); if (k >= 1) g = a > g ? a : g; }
+        { int b = ag_shr1(AG_NEG, ag_shr1(AG_NEG, g)); if (k >= 2) g = b > g ? b : g; }
+        const int pm = ag_shr1(AG_NEG, g);
+        int fk = -k * gap_ext;                                      // F entering the segment is 0 for now
+        if (k >= 1) { int a = pm - (p - 1) * gap_ext; fk = a > fk ? a : fk; }
+        if (two) {
+            // X after the first segment's lazy F, assuming -- as in all but a few rows -- that its first round is also its last:
+            // the F that left stripe 7 in the first pass (:538).  It enters stripe 0 of the second segment (f = X, :571).
+            const int f2p0 = fk - gap_ext;
+            const int endv_a = f2p0 > tmp ? f2p0 : tmp;
+            const int f7 = __builtin_amdgcn_readlane(endv_a, nk0 - 1 + 7 * num_vec);
+            X0 = f7 > 0 ? f7 : 0;
+            const int fkp = X0 - k * gap_ext;
+            fk = (is_x_lane && fkp > fk) ? fkp : fk;
+        }
+        int bt = bt_e | (fk > hpp ? 2 : 0);
+        int hp = fk > hpp ? fk : hpp;
+        int f2p = fk - gap_ext;
+        bt |= f2p > tmp ? 32 : 0;
+        int endv = inseg ? (f2p > tmp ? f2p : tmp) : 0;
+        Hm = inseg ? hp : Hm;
+        E = inseg ? (e2 > tmp ? e2 : tmp) : E;
+        mxv = inseg ? hp : 0;
+        btr = inseg ? bt : 0;
+        const bool did = inseg;
 
-            // lazy F (:534-569): up to 7 rounds; round r brings each stripe the F that left the stripe r+1 to its left in the
-            // first pass, decayed by r whole stripes (the reference's per-round  vF = max(vF - nk*ext, 0)  composes to that),
-            // so every round is one gather from the stripe-end lanes.  F of stripe 7 accumulates into X (the next segment's
-            // incoming F).
-            const int src_end = s * seg_len + nk - 1;             // lane of stripe 0's last vector
-            const int endv0 = endv;
-            const unsigned long long inseg_mask = BALLOT(inseg);
+        // ---------------- lazy F (:534-569): up to 7 rounds per segment; round r brings each stripe the F that left the stripe r+1 to
+        // its left in the first pass, decayed by r whole stripes (the reference's per-round  vF = max(vF - nk*ext, 0)  composes to
+        // that), so every round is one gather from the stripe-end lanes.  The reference leaves the loop at the first vector in which no
+        // SSE lane continues (:560): lanes of one vector index sit num_vec apart, so OR-folding the continuation mask over the 8
+        // stripes leaves "some lane of vector kk continues" in bit kk -- scalar work only.
+        auto fold = [&](unsigned long long cm, int nk, int *jlim) -> bool {          // returns round_complete
+            cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
+            const uint32_t full = (1u << nk) - 1u;
+            const uint32_t low = (uint32_t)cm & full;
+            const int jstar = low == full ? 64 : (int)__builtin_ctz(~low);
+            const bool complete = jstar >= nk;
+            *jlim = complete ? nk - 1 : jstar;
+            return complete;
+        };
+        // rounds r0 .. 6 of segment s alone (the rare continuation): endv still holds the first-pass values
+        auto more_rounds = [&](int s, int nk, int r0) {
+            const bool ins = inseg && segsel == s;
+            const unsigned long long ins_mask = BALLOT(ins);
+            const int src_end = s * seg_len + nk - 1;                 // lane of stripe 0's last vector
             const int decay_step = nk * gap_ext;
-            int decay = 0;
-            int src7 = src_end + 7 * num_vec;                     // stripe 7's last vector
-            int src_addr = (src_end + (l - 1) * num_vec) * 4;     // byte address for ds_bpermute: the stripe to the left
-            int ls = l - 1;
-            for (int r = 0; r < 7; r++, decay += decay_step, src7 -= num_vec, src_addr -= num_vec * 4, ls--) {
-                {
-                    int f7 = __builtin_amdgcn_readlane(endv0, src7) - decay;
+            int decay = r0 * decay_step;
+            int src7 = src_end + (7 - r0) * num_vec;                  // stripe 7 - r's last vector
+            int src_addr = (src_end + (l - 1 - r0) * num_vec) * 4;    // byte address for ds_bpermute: the stripe r+1 to the left
+            int ls = l - 1 - r0;
+            for (int r = r0; r < 7; r++, decay += decay_step, src7 -= num_vec, src_addr -= num_vec * 4, ls--) {
+                if (s == 0) {
+                    int f7 = __builtin_amdgcn_readlane(endv, src7) - decay;
                     if (f7 > X0) X0 = f7;
                 }
-                int f_in = __builtin_amdgcn_ds_bpermute(src_addr, endv0) - decay;
+                int f_in = __builtin_amdgcn_ds_bpermute(src_addr, endv) - decay;
                 if (ls < 0 || f_in < 0) f_in = 0;
                 int f = f_in - k * gap_ext; if (f < 0) f = 0;
                 int hn = Hm > f ? Hm : f;
                 int t2 = hn > gap_open ? hn - gap_open : 0;
                 int f2 = f > gap_ext ? f - gap_ext : 0;
-                const bool cont = inseg && (f2 > t2);
-                // The reference stops the round at the first vector in which no SSE lane continues (:560).  Lanes of one
-                // vector index sit num_vec apart, so OR-folding the continuation mask over the 8 stripes leaves "some lane
-                // of vector kk continues" in bit kk -- scalar work only.
-                unsigned long long cm = (__builtin_amdgcn_ballot_w64(f2 > t2) & inseg_mask) >> (s * seg_len);
-                cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
-                const uint32_t full = (1u << nk) - 1u;
-                const uint32_t low = (uint32_t)cm & full;
-                const int jstar = low == full ? 64 : (int)__builtin_ctz(~low);
-                const bool round_complete = jstar >= nk;
-                const int jlim = round_complete ? nk - 1 : jstar;
-                const bool upd = inseg && k <= jlim;
+                const bool cont = ins && (f2 > t2);
+                int jlim;
+                const bool complete = fold((__builtin_amdgcn_ballot_w64(f2 > t2) & ins_mask) >> (s * seg_len), nk, &jlim);
+                const bool upd = ins && k <= jlim;
                 btr |= (upd && f > Hm) ? 2 : 0;
                 Hm = (upd && f > Hm) ? f : Hm;
                 mxv = (upd && Hm > mxv) ? Hm : mxv;
                 btr |= (upd && cont) ? 32 : 0;
-                if (!round_complete) break;
+                if (!complete) break;
             }
-            fin = X0;
+        };
+        {   // round 0 of both segments
+            const int src_addr = (segsel * seg_len + nkl - 1 + (l - 1) * num_vec) * 4;
+            int f_in = __builtin_amdgcn_ds_bpermute(src_addr, endv);
+            if (l == 0 || f_in < 0) f_in = 0;
+            int f = f_in - k * gap_ext; if (f < 0) f = 0;
+            int hn = Hm > f ? Hm : f;
+            int t2 = hn > gap_open ? hn - gap_open : 0;
+            int f2 = f > gap_ext ? f - gap_ext : 0;
+            const bool cont = inseg && (f2 > t2);
+            const unsigned long long cb = __builtin_amdgcn_ballot_w64(f2 > t2) & inseg_mask;
+            int jlim0 = 0, jlim1 = 0;
+            const bool complete0 = fold(cb, nk0, &jlim0);
+            const bool complete1 = two ? fold(cb >> seg_len, nk1, &jlim1) : false;
+            if (!complete0) {
+                const int jl = segsel == 0 ? jlim0 : jlim1;
+                const bool upd = inseg && k <= jl;
+                btr |= (upd && f > Hm) ? 2 : 0;
+                Hm = (upd && f > Hm) ? f : Hm;
+                mxv = (upd && Hm > mxv) ? Hm : mxv;
+                btr |= (upd && cont) ? 32 : 0;
+                if (complete1) more_rounds(1, nk1, 1);
+            } else {
+                // the first segment's lazy F goes on: X can still grow, so the second segment waits for it
+                const bool upd = inseg && segsel == 0;              // (a complete round updates every vector of the segment)
+                btr |= (upd && f > Hm) ? 2 : 0;
+                Hm = (upd && f > Hm) ? f : Hm;
+                mxv = (upd && Hm > mxv) ? Hm : mxv;
+                btr |= (upd && cont) ? 32 : 0;
+                more_rounds(0, nk0, 1);
+                if (two) {
+                    // stripe 0 of the second segment again, with the final X (values derived from F only go up with it)
+                    const bool xl = is_x_lane && inseg;
+                    const int fkp = X0 - k * gap_ext;
+                    const int fkx = fkp > fk ? fkp : fk;
+                    const int btx = bt_e | (fkx > hpp ? 2 : 0) | ((fkx - gap_ext) > tmp ? 32 : 0);
+                    const int hpx = fkx > hpp ? fkx : hpp;
+                    const int evx = (fkx - gap_ext) > tmp ? (fkx - gap_ext) : tmp;
+                    btr = xl ? btx : btr;
+                    Hm = xl ? hpx : Hm;
+                    mxv = (xl && hpx > mxv) ? hpx : mxv;
+                    endv = xl ? evx : endv;
+                    more_rounds(1, nk1, 0);
+                }
+            }
         }
 
         bt_scratch[(size_t)i * 64 + lane] = (uint8_t)btr;       // (lanes outside the band write 0; the traceback never reads them)
@@ -302,13 +364,13 @@ static __device__ __forceinline__ AGResult ag_banded_win(
 
 // AGC > 0: register formulation with AGC chunks of 64 positions (the host guarantees it fits);
 // AGC == 0: the LDS formulation of ag.h (any pattern length up to RL).
-template <int AGC, typename PSeq, typename TSeq, typename QSeq>
+template <int AGC, bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_dispatch(
     bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
 {
-    if constexpr (AGC > 0) {
+    if constexpr (AGC > 0 && !EXACT) {
         AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
         res.match_probability = 0.0; res.stale_reads = 0;
         int ww = w > 126 ? 126 : w;
@@ -331,7 +393,7 @@ static __device__ __forceinline__ AGResult ag_dispatch(
         return ag_compute_reg<AGC, false>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                           lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
     } else {
-        return ag_compute(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
-                          lds_rows, bt_scratch, RL, tab);
+        return ag_compute<EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
+                                 lds_rows, bt_scratch, RL, tab);
     }
 }

@@ -134,7 +134,10 @@ struct SecCfg {
     uint32_t cap;                      // entries of per-wave scratch
 };
 
-template <int AGC, bool SEC = false>
+// EXACT: the replay instantiation for reads whose banded affine-gap traceback left the band (`reserved` != 0 after the fast pass): every
+// affine-gap call goes through the layout-literal form of ag.h over ag_persist[0 / 1], the wave's images of the reference aligner's
+// affineGap / reverseAffineGap traceback arrays, zeroed by the kernel before the read -- the answer of a newly constructed reference aligner.
+template <int AGC, bool SEC = false, bool EXACT = false>
 struct Aligner {
     // ---- constant for the launch
     // held by value: a reference member would make the kernel-argument struct escape through a
@@ -154,6 +157,7 @@ struct Aligner {
     uint16_t *heads;
     Elem     *pool;
     uint8_t  *ag_scratch;
+    uint8_t  *ag_persist[2];    // EXACT only: [0] forward object (affineGap), [1] backward object (reverseAffineGap)
     // ---- per-read state (wave-uniform)
     int lane;
     int read_len;
@@ -690,8 +694,8 @@ struct Aligner {
                                     const int tlen = half == 0 ? text_len : seed_offset + lim;
                                     const bool banded = plen >= 3 * (2 * lim + 1);                   // :1213 / :1251
                                     ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
-                                    AGResult a = ag_dispatch<AGC>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, e_dir != 0,
-                                                                  false, ag_rows, ag_scratch, cfg.RL, tab);
+                                    AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, e_dir != 0,
+                                                                  false, ag_rows, EXACT ? ag_persist[half] : ag_scratch, cfg.RL, tab);
                                     a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
                                     a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
                                     a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
@@ -1078,7 +1082,8 @@ struct Aligner {
             const int tlen = half == 0 ? (int)(glen - tail_start) : seed_offset + lim;
             const bool banded = plen >= 3 * (2 * lim + 1);
             ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
-            AGResult a = ag_dispatch<AGC>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, dir != 0, half == 0, ag_rows, ag_scratch, cfg.RL, tab);
+            AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, dir != 0, half == 0, ag_rows,
+                                                 EXACT ? ag_persist[half] : ag_scratch, cfg.RL, tab);
             a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
             a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
             a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);

@@ -71,6 +71,14 @@ static __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src_lane = 
 static __device__ __forceinline__ int bcast_i32(int v, int src_lane = 0) {
     return __builtin_amdgcn_readlane(v, src_lane);
 }
+// wave-wide fill of n bytes at a 16-byte aligned address with zero (n a multiple of 16)
+static __device__ __forceinline__ void wave_zero16(uint8_t *p, size_t n) {
+    struct alignas(16) Z16 { uint64_t a, b; };
+    Z16 *q = (Z16 *)p;
+    const size_t nq = n >> 4;
+    for (size_t i = (size_t)lane_id(); i < nq; i += WAVE) q[i] = Z16{0ull, 0ull};
+}
+
 static __device__ __forceinline__ uint32_t first_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }

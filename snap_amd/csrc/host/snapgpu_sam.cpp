@@ -1,13 +1,24 @@
-// snapgpu_sam.cpp -- FASTQ batcher + SAM writer over the C ABI (SURVEY.md section 8(f) rank 1): the host side of
-//     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-Cxx] [-ea] [-D n] [-om n [-omax n] [-mpc n]] [-mrl minReadLength] [-b readsPerBatch]
+// snapgpu_sam.cpp -- FASTQ batcher + SAM writer over the C ABI (SURVEY.md section 8(f) rank 1, 8(e)): the host side of
+//     snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> [-d maxDist] [-G-] [-=] [-M] [-Cxx] [-ea] [-D n] [-om n [-omax n] [-mpc n]] [-mrl minReadLength]
+//                        [-b readsPerBatch] [-gpus n] [-q contextsPerGpu] [-t formatterThreads]
 //     snapgpu-sam paired <index-dir> <reads1.fq> <reads2.fq> -o <out.sam> [same options]
-// Streams FASTQ records in batches across include/snapgpu.h -- snapgpu_align_single (BaseAligner::AlignRead) and
-// snapgpu_sam_fields_single (what SimpleReadWriter::writeReads / SAMFormat::writeRead compute before they print) -- and prints the
-// records the way the reference does.  What is restated here is host-side text handling only:
+// Streams FASTQ records in batches across include/snapgpu.h -- snapgpu_align_single / snapgpu_align_paired (BaseAligner::AlignRead,
+// ChimericPairedEndAligner::align) and snapgpu_sam_fields_single / _paired (what SimpleReadWriter::writeReads / writePairs compute before
+// they print) -- and prints the records the way the reference does.
+//
+// Shape (the reference's: SNAPLib/ParallelTask.h:128-138 runs one aligner per thread over a shared read supplier, SingleAligner.cpp:197-330):
+//     reader thread  ->  [batches]  ->  GPU feeder threads  ->  [aligned batches]  ->  formatter threads  ->  writer (batch order)
+//   * one context per (GPU, feeder thread), `-q` feeders per GPU (default 2): while one feeder's batch is in the kernel the other's is being
+//     copied in / out, so H2D, kernel and D2H of consecutive batches overlap on separate streams without a global lock; the feeders of one GPU
+//     share its index blobs (snapgpu_create_replica(..., share_index = 1));
+//   * `-gpus n` (default: every visible device): the index is read from disk ONCE, into GPU 0, and replicated into the other GPUs' HBM by
+//     snapgpu_broadcast_index (RCCL broadcast over xGMI); batches go to whichever feeder is free, reads never cross GPUs;
+//   * results are re-ordered by batch number before they are written, so the file is what a single-threaded run writes.
+// What is restated here is host-side text handling only:
 //   FASTQReader::getReadFromBuffer   SNAPLib/FASTQ.cpp:148-260   (4-line records, '\r' tolerated; plain or gzip input through zlib)
 //   Read::clip (ClipBack)            SNAPLib/Read.h:567-620      (the CLI default -C-+: drop the trailing run of '#' qualities)
 //   the "useless read" filter        SNAPLib/SingleAligner.cpp:211-232 (dataLength < -mrl or more Ns than -d: written unaligned)
-//   SAMFormat::writeHeader           SNAPLib/SAM.cpp:1204-1305   (@HD, default @RG, @PG, one @SQ per contig)
+//   SAMFormat::writeHeader           SNAPLib/SAM.cpp:1204-1305   (@HD, default @RG, @PG, one @SQ per contig in ORIGINAL FASTA order, :1291)
 //   SAMFormat::writeRead's snprintf  SNAPLib/SAM.cpp:2078-2098   (field order, PG:Z:SNAP, NM:i, default read-group aux)
 //   paired: the both-mates-useless rule (PairedAligner.cpp:680-707), the /1 /2 suffix rule (ReadWriter.cpp:392-404), the mate's quality
 //   sum QS:i (SAM.cpp:1826-1837) and writePairs' snprintf (:1855-1877); pairing arithmetic is snapgpu_sam_fields_paired's
@@ -16,15 +27,21 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
-#include <zlib.h>                        // gzopen reads plain and gzip-compressed FASTQ alike (the reference takes .gz input too)
+#include <zlib.h>                        // gzread reads plain and gzip-compressed FASTQ alike (the reference takes .gz input too)
 
 #include "../../../include/snapgpu.h"
 
 static void die(const char *msg, const char *arg = "") { fprintf(stderr, "snapgpu-sam: %s%s\n", msg, arg); exit(1); }
 
-struct Contig { std::string name; uint64_t begin; bool is_alt; };
+struct Contig { std::string name; uint64_t begin; bool is_alt; int orig; };
 
 // the contig table of the index directory: names for RNAME / @SQ (Genome.cpp:203-229, 353-403; GenomeIndex.cpp:1879)
 static void load_contigs(const std::string &dir, std::vector<Contig> &contigs, uint64_t &n_bases, uint32_t &padding)
@@ -46,321 +63,509 @@ static void load_contigs(const std::string &dir, std::vector<Contig> &contigs, u
         if (!fgets(line, sizeof(line), f) ||
             sscanf(line, "%lld %x %d %lld %x %d %d %n", &begin, &cflags, &orig, &pbegin, &pflags, &name_len, &cigar_len, &consumed) < 7)
             die("malformed contig line in Genome");
-        Contig c; c.begin = (uint64_t)begin; c.is_alt = (cflags & 1) != 0; c.name.assign(line + consumed, (size_t)name_len);
+        Contig c; c.begin = (uint64_t)begin; c.is_alt = (cflags & 1) != 0; c.orig = orig; c.name.assign(line + consumed, (size_t)name_len);
         contigs.push_back(c);
     }
     fclose(f);
 }
 
-struct Batch {
-    std::vector<std::string> names;
-    std::vector<char> bases, quals;          // unclipped, concatenated
-    std::vector<uint64_t> offsets;           // n + 1
-    void clear() { names.clear(); bases.clear(); quals.clear(); offsets.assign(1, 0); }
+// ---------------------------------------------------------------------------------------- FASTQ input
+struct LineReader {                      // lines out of a gz / plain file through one large buffer (gzgets is several times slower)
+    gzFile f = NULL;
+    std::vector<char> buf; size_t pos = 0, end = 0; bool eof = false;
+    void open(const char *path) { f = gzopen(path, "rb"); if (!f) die("cannot open ", path); gzbuffer(f, 1 << 20); buf.resize(8u << 20); }
+    void close() { if (f) gzclose(f); f = NULL; }
+    bool fill() {
+        if (eof) return false;
+        if (pos > 0) { memmove(buf.data(), buf.data() + pos, end - pos); end -= pos; pos = 0; }
+        if (end == buf.size()) buf.resize(buf.size() * 2);
+        const int n = gzread(f, buf.data() + end, (unsigned)(buf.size() - end));
+        if (n < 0) die("read error in FASTQ input");
+        if (n == 0) { eof = true; return false; }
+        end += (size_t)n;
+        return true;
+    }
+    // next line without its terminator ('\r' tolerated); false at end of file
+    bool line(const char *&s, size_t &n) {
+        for (;;) {
+            const char *nl = (const char *)memchr(buf.data() + pos, '\n', end - pos);
+            if (nl) {
+                s = buf.data() + pos; n = (size_t)(nl - s); pos += n + 1;
+                if (n > 0 && s[n - 1] == '\r') n--;
+                return true;
+            }
+            if (!fill()) {
+                if (pos == end) return false;
+                s = buf.data() + pos; n = end - pos; pos = end;
+                if (n > 0 && s[n - 1] == '\r') n--;
+                return true;
+            }
+        }
+    }
 };
 
-static bool get_line(gzFile f, std::string &s)
-{
-    s.clear();
-    char buf[4096];
-    while (gzgets(f, buf, (int)sizeof(buf)) != NULL) {
-        const size_t n = strlen(buf);
-        s.append(buf, n);
-        if (n > 0 && buf[n - 1] == '\n') { s.pop_back(); if (!s.empty() && s.back() == '\r') s.pop_back(); return true; }
-    }
-    return !s.empty();
-}
+struct Batch {
+    uint64_t seq = 0;
+    std::vector<uint32_t> name_off;          // n + 1 offsets into names
+    std::string names;
+    std::vector<char> bases, quals;          // unclipped, concatenated
+    std::vector<uint64_t> offsets;           // n + 1
+    size_t n() const { return offsets.size() - 1; }
+    void clear() { name_off.assign(1, 0); names.clear(); bases.clear(); quals.clear(); offsets.assign(1, 0); }
+};
 
-// one FASTQ record; false at end of file
-static bool next_read(gzFile f, std::string &id, std::string &seq, std::string &qual)
+// one FASTQ record appended to the batch; false at end of file (blank lines between records are skipped)
+static bool next_read(LineReader &in, Batch &b, uint32_t max_read_len)
 {
-    std::string plus;
-    if (!get_line(f, id)) return false;
-    if (id.empty() || id[0] != '@') die("FASTQ record does not start with '@': ", id.c_str());
-    if (!get_line(f, seq) || !get_line(f, plus) || !get_line(f, qual)) die("truncated FASTQ record: ", id.c_str());
-    if (plus.empty() || plus[0] != '+') die("FASTQ record without '+' line: ", id.c_str());
-    if (seq.size() != qual.size()) die("FASTQ sequence and quality lengths differ: ", id.c_str());
-    id.erase(0, 1);
+    const char *s; size_t n;
+    do { if (!in.line(s, n)) return false; } while (n == 0);
+    if (s[0] != '@') die("FASTQ record does not start with '@': ", std::string(s, n).c_str());
+    b.names.append(s + 1, n - 1); b.name_off.push_back((uint32_t)b.names.size());
+    const std::string id(s + 1, n - 1);
+    if (!in.line(s, n)) die("truncated FASTQ record: ", id.c_str());
+    const size_t len = n;
+    if (len > max_read_len) die("read longer than max_read_len (400; set SNAPGPU_MAX_READ_LEN, at most 1000): ", id.c_str());
+    b.bases.insert(b.bases.end(), s, s + n);
+    if (!in.line(s, n)) die("truncated FASTQ record: ", id.c_str());
+    if (n == 0 || s[0] != '+') die("FASTQ record without '+' line: ", id.c_str());
+    if (!in.line(s, n)) die("truncated FASTQ record: ", id.c_str());
+    if (n != len) die("FASTQ sequence and quality lengths differ: ", id.c_str());
+    b.quals.insert(b.quals.end(), s, s + n);
+    b.offsets.push_back(b.bases.size());
     return true;
 }
 
-static char complement(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }      // COMPLEMENT[], Tables.cpp
-
-int main(int argc, char **argv)
-{
-    const bool paired = argc >= 2 && strcmp(argv[1], "paired") == 0;
-    if (argc < (paired ? 5 : 4) || (!paired && strcmp(argv[1], "single") != 0))
-        die("usage: snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> | paired <index-dir> <r1.fq> <r2.fq> -o <out.sam>  [-d N] [-G-] [-=] [-M] [-mrl N] [-b N]");
-    const std::string index_dir = argv[2], fastq = argv[3], fastq2 = paired ? argv[4] : "";
-    std::string out_path;
-    snapgpu_params p; snapgpu_default_params(&p);
-    p.max_read_len = 400;                                                  // per-wave buffers; SNAPGPU_MAX_READ_LEN raises it (<= 1000), as for snap-aligner-gpu
-    if (const char *e = getenv("SNAPGPU_MAX_READ_LEN")) { const int v = atoi(e); if (v >= 50 && v <= 1000) p.max_read_len = (uint32_t)v; }
+// ---------------------------------------------------------------------------------------- options, shared state
+struct Options {
+    bool paired = false;
+    snapgpu_params p;
+    snapgpu_paired_params pp;
     bool use_m = true;                                                     // AlignerOptions.cpp:58
-    unsigned min_read_len = 50;                                            // -mrl, AlignerOptions.cpp
+    unsigned min_read_len = 50;                                            // -mrl
     size_t batch_reads = 65536;
     bool clip_front = false, clip_back = true;                             // -C-+ (ClipBack) is the default
     int om = -1, mpc = -1; long long omax = 0x7fffffff;
-    std::string cl = argv[1];
-    for (int i = 2; i < argc; i++) { cl += " "; cl += argv[i]; }
-    for (int i = paired ? 5 : 4; i < argc; i++) {
-        const std::string a = argv[i];
-        if (a == "-o" && i + 1 < argc) out_path = argv[++i];
-        else if (a == "-d" && i + 1 < argc) p.max_k = (uint32_t)atoi(argv[++i]);
-        else if (a == "-G-") p.use_affine_gap = 0;
-        else if (a == "-=") use_m = false;
-        else if (a == "-M") use_m = true;
-        else if (a.size() == 4 && a.compare(0, 2, "-C") == 0 && strchr("+-", a[2]) && strchr("+-", a[3])) { clip_front = a[2] == '+'; clip_back = a[3] == '+'; }   // AlignerOptions.cpp: -Cxx
-        else if (a == "-om" && i + 1 < argc) om = atoi(argv[++i]);                       // secondary alignments (AlignerOptions.cpp:70-72)
-        else if (a == "-omax" && i + 1 < argc) omax = atoll(argv[++i]);
-        else if (a == "-mpc" && i + 1 < argc) mpc = atoi(argv[++i]);
-        else if (a == "-ea") p.emit_alt_alignments = 1;                                  // the first ALT alignment as an extra record (SingleAligner.cpp:320-322)
-        else if (a == "-D" && i + 1 < argc) p.extra_search_depth = (uint32_t)atoi(argv[++i]);
-        else if (a == "-mrl" && i + 1 < argc) min_read_len = (unsigned)atoi(argv[++i]);
-        else if (a == "-b" && i + 1 < argc) batch_reads = (size_t)atoll(argv[++i]);
-        else if (a == "-t" && i + 1 < argc) ++i;                           // host threads: nothing to do here
-        else die("option not supported: ", a.c_str());
-    }
-    if (out_path.empty()) die("-o <out.sam> is required");
+    int n_gpus = 0, ctx_per_gpu = 2, n_format = 0;
+    uint32_t ops_stride = 64;
+};
 
-    std::vector<Contig> contigs; uint64_t n_bases = 0; uint32_t padding = 0;
-    load_contigs(index_dir, contigs, n_bases, padding);
-    snapgpu_ctx *ctx = NULL;
-    int rc = snapgpu_create_from_directory(index_dir.c_str(), &p, 0, &ctx);
-    if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_create_from_directory failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+struct Work {                                // a batch on its way through the pipeline
+    Batch b;
+    // single-end: one entry per RECORD (a read with secondary results appears once per record); paired: one per read
+    std::vector<uint32_t> rec_read; std::vector<char> rec_secondary;
+    std::vector<int32_t> flag, contig, mapq, n_ops, nm, rnext, first_written;
+    std::vector<int64_t> pos, pnext, tlen;
+    std::vector<uint32_t> ops; uint32_t ops_stride = 64;
+    std::string text;                        // the formatted records
+    unsigned long long mapped = 0;
+};
 
-    gzFile in = gzopen(fastq.c_str(), "rb");
-    if (!in) die("cannot open ", fastq.c_str());
-    gzbuffer(in, 1 << 20);
-    gzFile in2 = NULL;
-    if (paired) {
-        in2 = gzopen(fastq2.c_str(), "rb");
-        if (!in2) die("cannot open ", fastq2.c_str());
-        snapgpu_paired_params pp; snapgpu_default_paired_params(&pp);
-        pp.min_read_length = min_read_len;
-        rc = snapgpu_enable_paired(ctx, &pp);
-        if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_enable_paired failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
+template <class T> struct Queue {            // bounded multi-producer multi-consumer queue; close() lets consumers drain and stop
+    std::mutex m; std::condition_variable not_empty, not_full; std::deque<T> q; size_t cap; bool closed = false;
+    explicit Queue(size_t c) : cap(c) {}
+    void push(T v) { std::unique_lock<std::mutex> l(m); not_full.wait(l, [&] { return q.size() < cap; }); q.push_back(std::move(v)); not_empty.notify_one(); }
+    bool pop(T &v) {
+        std::unique_lock<std::mutex> l(m); not_empty.wait(l, [&] { return !q.empty() || closed; });
+        if (q.empty()) return false;
+        v = std::move(q.front()); q.pop_front(); not_full.notify_one(); return true;
     }
-    if (om >= 0) {
-        if (paired) die("-om with `paired` is not supported by this program yet");
-        snapgpu_secondary_params sp; memset(&sp, 0, sizeof(sp));
-        sp.max_edit_distance = om; sp.max_per_contig = mpc; sp.max_results = omax; sp.adjust_alignments = 0;
-        rc = snapgpu_enable_secondary(ctx, &sp);
-        if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_enable_secondary failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
-    }
-    FILE *out = fopen(out_path.c_str(), "wb");
-    if (!out) die("cannot create ", out_path.c_str());
-    // header (SAM.cpp:1232-1295)
-    fprintf(out, "@HD\tVN:1.6\tGO:query\n@RG\tID:FASTQ\tPL:Illumina\tPU:pu\tLB:lb\tSM:sm\n@PG\tID:SNAP\tPN:SNAP\tCL:%s\tVN:2.0.5\n", cl.c_str());
-    for (size_t c = 0; c < contigs.size(); c++) {
-        const uint64_t end = c + 1 < contigs.size() ? contigs[c + 1].begin : n_bases;
-        fprintf(out, "@SQ\tSN:%s\tLN:%llu%s\n", contigs[c].name.c_str(), (unsigned long long)(end - contigs[c].begin - padding), contigs[c].is_alt ? "\tAH:*" : "");
-    }
+    void close() { std::lock_guard<std::mutex> l(m); closed = true; not_empty.notify_all(); }
+};
 
-    Batch b; b.clear();
-    std::string id, seq, qual;
-    const uint32_t ops_stride = 64;
-    unsigned long long total = 0, aligned = 0;
-    bool eof = false;
-    while (paired && !eof) {
-        b.clear();
-        while (b.names.size() < 2 * (batch_reads / 2)) {
-            if (!next_read(in, id, seq, qual)) { eof = true; break; }
-            std::string id2, seq2, qual2;
-            if (!next_read(in2, id2, seq2, qual2)) die("the second FASTQ file has fewer reads than the first");
-            if (seq.size() > p.max_read_len || seq2.size() > p.max_read_len) die("read longer than max_read_len (400; set SNAPGPU_MAX_READ_LEN, at most 1000): ", id.c_str());
-            b.names.push_back(id); b.bases.insert(b.bases.end(), seq.begin(), seq.end()); b.quals.insert(b.quals.end(), qual.begin(), qual.end()); b.offsets.push_back(b.bases.size());
-            b.names.push_back(id2); b.bases.insert(b.bases.end(), seq2.begin(), seq2.end()); b.quals.insert(b.quals.end(), qual2.begin(), qual2.end()); b.offsets.push_back(b.bases.size());
+static char complement(char c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }      // COMPLEMENT[], Tables.cpp
+
+static inline void put_uint(std::string &o, unsigned long long v) { char t[24]; int n = 0; do { t[n++] = (char)('0' + v % 10); v /= 10; } while (v); while (n) o.push_back(t[--n]); }
+static inline void put_int(std::string &o, long long v) { if (v < 0) { o.push_back('-'); put_uint(o, (unsigned long long)(-(v + 1)) + 1ull); } else put_uint(o, (unsigned long long)v); }
+
+static void fail_rc(snapgpu_ctx *ctx, const char *what, int rc) { fprintf(stderr, "snapgpu-sam: %s failed (%d): %s\n", what, rc, snapgpu_last_error(ctx)); exit(1); }
+
+// Read::clip and the useless-read test for read i of the batch (Read.h:586-608: back first, then front; SingleAligner.cpp:211-232)
+static inline bool clip_read(const Options &o, const Batch &b, size_t i, int32_t &front_clip, int32_t &data_len)
+{
+    const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
+    size_t m = (size_t)(b.offsets[i + 1] - b.offsets[i]), fc = 0;
+    if (o.clip_back) while (m > 0 && q[m - 1] == '#') m--;
+    if (o.clip_front) while (fc < m && q[fc] == '#') fc++;
+    m -= fc;
+    front_clip = (int32_t)fc; data_len = (int32_t)m;
+    unsigned n_count = 0;
+    for (size_t j = 0; j < m; j++) n_count += s[fc + j] == 'N';
+    return m >= o.min_read_len && n_count <= o.p.max_k;
+}
+
+// ---------------------------------------------------------------------------------------- GPU stage
+// A cigar that does not fit ops_stride comes back as n_ops = -1 with nm = -2 (the reference's "cigarBuf too small" never happens: its
+// buffer is large): call again with a larger stride rather than print a wrong record.
+template <class F> static void with_growing_stride(Work &w, size_t n_rec, F call)
+{
+    for (;;) {
+        w.ops.assign(n_rec * (size_t)w.ops_stride, 0);
+        call();
+        bool too_small = false;
+        for (size_t i = 0; i < n_rec; i++) if (w.nm[i] == -2) { too_small = true; break; }
+        if (!too_small) return;
+        if (w.ops_stride >= 4096) die("a cigar needs more than 4096 operations");
+        w.ops_stride *= 4;
+    }
+}
+
+static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
+{
+    const Batch &b = w.b;
+    const size_t n = b.n();
+    std::vector<int32_t> front_clip(n, 0), data_len(n, 0);
+    std::vector<uint32_t> to_align;
+    std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (clip_read(o, b, i, front_clip[i], data_len[i])) {
+            to_align.push_back((uint32_t)i);
+            const char *q = b.quals.data() + b.offsets[i] + front_clip[i], *s = b.bases.data() + b.offsets[i] + front_clip[i];
+            ab.insert(ab.end(), s, s + data_len[i]); aq.insert(aq.end(), q, q + data_len[i]); ao.push_back(ab.size());
         }
-        const size_t n = b.names.size(), np = n / 2;
-        if (n == 0) break;
-        std::vector<int32_t> front_clip(n, 0), data_len(n, 0);
-        std::vector<char> useful(n, 0);
+    }
+    std::vector<snapgpu_single_result> results(n), aligned_res(to_align.size()), alt_res(to_align.size());
+    for (size_t i = 0; i < n; i++) {                                       // SingleAligner.cpp:215-225
+        memset(&results[i], 0, sizeof(results[i]));
+        results[i].status = SNAPGPU_NotFound; results[i].location = SNAPGPU_InvalidGenomeLocation32; results[i].score = -1;
+    }
+    // records to write: every read's primary, then its secondary results in the aligner's order (SingleAligner.cpp:300-318 -> writeReads)
+    std::vector<snapgpu_single_result> rec_res;
+    w.rec_read.clear(); w.rec_secondary.clear();
+    int rc;
+    if (!to_align.empty()) {
+        std::vector<snapgpu_single_result> sec; std::vector<uint32_t> nsec(to_align.size(), 0);
+        uint32_t stride = 0;
+        if (o.om >= 0) {
+            stride = 8;
+            for (;;) {
+                sec.assign((size_t)to_align.size() * stride, snapgpu_single_result());
+                rc = snapgpu_align_single_secondary(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data(),
+                                                    sec.data(), stride, nsec.data());
+                if (rc != SNAPGPU_W_SECONDARY_TRUNCATED) break;
+                uint32_t need = stride; for (uint32_t v : nsec) if (v > need) need = v;
+                stride = need;
+            }
+        } else rc = snapgpu_align_single(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data());
+        if (rc != SNAPGPU_OK) fail_rc(ctx, "alignment", rc);
+        std::vector<uint32_t> slot(n, 0xffffffffu);
+        for (size_t k = 0; k < to_align.size(); k++) { results[to_align[k]] = aligned_res[k]; slot[to_align[k]] = (uint32_t)k; }
         for (size_t i = 0; i < n; i++) {
-            const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
-            size_t m = (size_t)(b.offsets[i + 1] - b.offsets[i]), fc = 0;
-            if (clip_back) while (m > 0 && q[m - 1] == '#') m--;               // Read::clip, Read.h:586-608: back first, then front
-            if (clip_front) while (fc < m && q[fc] == '#') fc++;
-            front_clip[i] = (int32_t)fc; m -= fc;
-            data_len[i] = (int32_t)m;
-            unsigned n_count = 0;
-            for (size_t j = 0; j < m; j++) n_count += s[fc + j] == 'N';
-            useful[i] = m >= min_read_len && n_count <= p.max_k;
-        }
-        std::vector<uint32_t> to_align;                                     // pairs with at least one useful mate (PairedAligner.cpp:680-682)
-        std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
-        for (size_t k = 0; k < np; k++) {
-            if (!useful[2 * k] && !useful[2 * k + 1]) continue;
-            to_align.push_back((uint32_t)k);
-            for (size_t i = 2 * k; i < 2 * k + 2; i++) {
-                const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
-                ab.insert(ab.end(), s + front_clip[i], s + front_clip[i] + data_len[i]); aq.insert(aq.end(), q + front_clip[i], q + front_clip[i] + data_len[i]); ao.push_back(ab.size());
+            w.rec_read.push_back((uint32_t)i); w.rec_secondary.push_back(0); rec_res.push_back(results[i]);
+            if (o.om >= 0 && slot[i] != 0xffffffffu)
+                for (uint32_t j = 0; j < nsec[slot[i]]; j++) { w.rec_read.push_back((uint32_t)i); w.rec_secondary.push_back(1); rec_res.push_back(sec[(size_t)slot[i] * stride + j]); }
+            if (o.p.alt_awareness && slot[i] != 0xffffffffu && alt_res[slot[i]].status != SNAPGPU_NotFound) {      // writeReads(&firstALTResult, 1, firstIsPrimary = false)
+                w.rec_read.push_back((uint32_t)i); w.rec_secondary.push_back(1); rec_res.push_back(alt_res[slot[i]]);
             }
         }
-        std::vector<snapgpu_paired_result> results(np), ares(to_align.size()), aalt(to_align.size());
-        for (size_t k = 0; k < np; k++) {
-            memset(&results[k], 0, sizeof(results[k]));
-            for (int w = 0; w < 2; w++) { results[k].status[w] = SNAPGPU_NotFound; results[k].location[w] = SNAPGPU_InvalidGenomeLocation32; results[k].score[w] = -1; }
-        }
-        if (!to_align.empty()) {
-            rc = snapgpu_align_paired(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), ares.data(), aalt.data());
-            if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_align_paired failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
-            for (size_t k = 0; k < to_align.size(); k++) results[to_align[k]] = ares[k];
-        }
-        std::vector<int32_t> flag(n), contig(n), mapq(n), n_ops(n), nm(n), stale(n), rnext(n), first_written(np);
-        std::vector<int64_t> pos(n), pnext(n), tlen(n);
-        std::vector<uint32_t> ops(n * ops_stride);
-        rc = snapgpu_sam_fields_paired(ctx, (uint32_t)np, b.bases.data(), b.quals.data(), b.offsets.data(), front_clip.data(), data_len.data(), results.data(),
-                                       use_m ? 1 : 0, flag.data(), contig.data(), pos.data(), mapq.data(), ops.data(), ops_stride, n_ops.data(), nm.data(),
-                                       rnext.data(), pnext.data(), tlen.data(), first_written.data(), stale.data());
-        if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_sam_fields_paired failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
-        std::string sq, ql;
-        for (size_t k = 0; k < np; k++) {
-            // QNAME: the /1 /2 suffixes go when both names carry them (ReadWriter.cpp:392-404)
-            size_t idl[2] = { b.names[2 * k].size(), b.names[2 * k + 1].size() };
-            const std::string &n0 = b.names[2 * k], &n1 = b.names[2 * k + 1];
-            if (idl[0] == idl[1] && idl[0] > 2 && n0[idl[0] - 2] == '/' && n1[idl[0] - 2] == '/') {
-                const char c0 = n0[idl[0] - 1], c1 = n1[idl[1] - 1];
-                if ((c0 == '1' || c0 == '2') && (c1 == '1' || c1 == '2') && c0 != c1) { idl[0] -= 2; idl[1] -= 2; }
-            }
-            for (int o = 0; o < 2; o++) {
-                const int w = o == 0 ? first_written[k] : 1 - first_written[k];
-                const size_t i = 2 * k + (size_t)w, im = 2 * k + (size_t)(1 - w);
-                const char *s = b.bases.data() + b.offsets[i], *q = b.quals.data() + b.offsets[i];
-                const size_t U = (size_t)(b.offsets[i + 1] - b.offsets[i]);
-                const std::string &nmq = b.names[i];
-                size_t qn = idl[w];
-                const size_t sp = nmq.substr(0, qn).find(' ');
-                if (sp != std::string::npos) qn = sp;
-                sq.assign(s, U); ql.assign(q, U);
-                if (flag[i] & 0x10) { for (size_t j = 0; j < U; j++) { sq[U - 1 - j] = complement(s[j]); ql[U - 1 - j] = q[j]; } }
-                std::string cigar = "*";
-                if (n_ops[i] >= 0) {
-                    cigar.clear();
-                    char tmp[32];
-                    for (int c = 0; c < n_ops[i]; c++) { const uint32_t op = ops[i * ops_stride + (size_t)c]; snprintf(tmp, sizeof(tmp), "%u%c", op >> 4, "MIDNSHP=X"[op & 15]); cigar += tmp; }
-                }
-                int mqs = 0;                                                // QS: the mate's qualities >= 15, summed (SAM.cpp:1826-1837)
-                { const unsigned char *mq = (const unsigned char *)b.quals.data() + b.offsets[im]; const size_t mu = (size_t)(b.offsets[im + 1] - b.offsets[im]);
-                  for (size_t j = 0; j < mu; j++) { const int v = (int)mq[j] - '!'; mqs += v >= 15 ? (v != 255) * v : 0; } }
-                const char *rn = rnext[i] == -2 ? "=" : (rnext[i] >= 0 ? contigs[(size_t)rnext[i]].name.c_str() : "*");
-                fprintf(out, "%.*s\t%d\t%s\t%lld\t%d\t%s\t%s\t%lld\t%d\t%s\t%s\tPG:Z:SNAP\tNM:i:%d\tRG:Z:FASTQ\tPL:Z:Illumina\tPU:Z:pu\tLB:Z:lb\tSM:Z:sm\tQS:i:%d\n",
-                        (int)qn, nmq.c_str(), flag[i], contig[i] >= 0 ? contigs[(size_t)contig[i]].name.c_str() : "*", (long long)pos[i], mapq[i], cigar.c_str(),
-                        rn, (long long)pnext[i], (int)tlen[i], sq.c_str(), ql.c_str(), nm[i], mqs);
-                aligned += (flag[i] & 0x4) == 0;
-            }
-        }
-        total += n;
-    }
-    while (!paired && !eof) {
-        b.clear();
-        while (b.names.size() < batch_reads) {
-            if (!next_read(in, id, seq, qual)) { eof = true; break; }
-            if (seq.size() > p.max_read_len) die("read longer than max_read_len (400; set SNAPGPU_MAX_READ_LEN, at most 1000): ", id.c_str());
-            b.names.push_back(id);
-            b.bases.insert(b.bases.end(), seq.begin(), seq.end());
-            b.quals.insert(b.quals.end(), qual.begin(), qual.end());
-            b.offsets.push_back(b.bases.size());
-        }
-        const size_t n = b.names.size();
-        if (n == 0) break;
-        // Read::clip (ClipBack) and the useless-read filter; the reads that go to the aligner, clipped, in one buffer
-        std::vector<int32_t> front_clip(n, 0), data_len(n, 0);
-        std::vector<uint32_t> to_align;
-        std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
-        for (size_t i = 0; i < n; i++) {
-            const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
-            size_t m = (size_t)(b.offsets[i + 1] - b.offsets[i]), fc = 0;
-            if (clip_back) while (m > 0 && q[m - 1] == '#') m--;               // Read::clip, Read.h:586-608: back first, then front
-            if (clip_front) while (fc < m && q[fc] == '#') fc++;
-            front_clip[i] = (int32_t)fc; m -= fc;
-            data_len[i] = (int32_t)m;
-            unsigned n_count = 0;
-            for (size_t j = 0; j < m; j++) n_count += s[fc + j] == 'N';
-            if (m >= min_read_len && n_count <= p.max_k) {
-                to_align.push_back((uint32_t)i);
-                ab.insert(ab.end(), s + fc, s + fc + m); aq.insert(aq.end(), q + fc, q + fc + m); ao.push_back(ab.size());
-            }
-        }
-        std::vector<snapgpu_single_result> results(n), aligned_res(to_align.size()), alt_res(to_align.size());
-        for (size_t i = 0; i < n; i++) {                                   // SingleAligner.cpp:215-225
-            memset(&results[i], 0, sizeof(results[i]));
-            results[i].status = SNAPGPU_NotFound; results[i].location = SNAPGPU_InvalidGenomeLocation32; results[i].score = -1;
-        }
-        // records to write: every read's primary, then its secondary results in the aligner's order (SingleAligner.cpp:300-318 -> writeReads)
-        std::vector<uint32_t> rec_read;                                     // record -> read of the batch
-        std::vector<char> rec_secondary;
-        std::vector<snapgpu_single_result> rec_res;
-        if (!to_align.empty()) {
-            std::vector<snapgpu_single_result> sec; std::vector<uint32_t> nsec(to_align.size(), 0);
-            uint32_t stride = 0;
-            if (om >= 0) {
-                stride = 8;
-                for (;;) {
-                    sec.assign((size_t)to_align.size() * stride, snapgpu_single_result());
-                    rc = snapgpu_align_single_secondary(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data(),
-                                                        sec.data(), stride, nsec.data());
-                    if (rc != SNAPGPU_W_SECONDARY_TRUNCATED) break;
-                    uint32_t need = stride; for (uint32_t v : nsec) if (v > need) need = v;
-                    stride = need;
-                }
-            } else rc = snapgpu_align_single(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data());
-            if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: alignment failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
-            std::vector<uint32_t> slot(n, 0xffffffffu);
-            for (size_t k = 0; k < to_align.size(); k++) { results[to_align[k]] = aligned_res[k]; slot[to_align[k]] = (uint32_t)k; }
-            for (size_t i = 0; i < n; i++) {
-                rec_read.push_back((uint32_t)i); rec_secondary.push_back(0); rec_res.push_back(results[i]);
-                if (om >= 0 && slot[i] != 0xffffffffu)
-                    for (uint32_t j = 0; j < nsec[slot[i]]; j++) { rec_read.push_back((uint32_t)i); rec_secondary.push_back(1); rec_res.push_back(sec[(size_t)slot[i] * stride + j]); }
-                if (p.alt_awareness && slot[i] != 0xffffffffu && alt_res[slot[i]].status != SNAPGPU_NotFound) {      // writeReads(&firstALTResult, 1, firstIsPrimary = false)
-                    rec_read.push_back((uint32_t)i); rec_secondary.push_back(1); rec_res.push_back(alt_res[slot[i]]);
-                }
-            }
-        } else for (size_t i = 0; i < n; i++) { rec_read.push_back((uint32_t)i); rec_secondary.push_back(0); rec_res.push_back(results[i]); }
-        const size_t nr = rec_read.size();
-        // the record batch: a read with secondary results appears once per record
-        std::vector<char> rb, rq; std::vector<uint64_t> ro(1, 0); std::vector<int32_t> rfc(nr), rdl(nr);
+    } else for (size_t i = 0; i < n; i++) { w.rec_read.push_back((uint32_t)i); w.rec_secondary.push_back(0); rec_res.push_back(results[i]); }
+    const size_t nr = w.rec_read.size();
+    // the record batch: a read with secondary results appears once per record
+    std::vector<char> rb, rq; std::vector<uint64_t> ro(1, 0); std::vector<int32_t> rfc(nr), rdl(nr);
+    const bool one_to_one = nr == n;
+    if (!one_to_one) {
         for (size_t r = 0; r < nr; r++) {
-            const size_t i = rec_read[r];
+            const size_t i = w.rec_read[r];
             rb.insert(rb.end(), b.bases.begin() + (long)b.offsets[i], b.bases.begin() + (long)b.offsets[i + 1]);
             rq.insert(rq.end(), b.quals.begin() + (long)b.offsets[i], b.quals.begin() + (long)b.offsets[i + 1]);
             ro.push_back(rb.size()); rfc[r] = front_clip[i]; rdl[r] = data_len[i];
         }
-        std::vector<int32_t> flag(nr), contig(nr), mapq(nr), n_ops(nr), nm(nr), stale(nr);
-        std::vector<int64_t> pos(nr);
-        std::vector<uint32_t> ops(nr * ops_stride);
-        rc = snapgpu_sam_fields_single(ctx, (uint32_t)nr, rb.data(), rq.data(), ro.data(), rfc.data(), rdl.data(), rec_res.data(), use_m ? 1 : 0,
-                                       flag.data(), contig.data(), pos.data(), mapq.data(), ops.data(), ops_stride, n_ops.data(), nm.data(), stale.data());
-        if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_sam_fields_single failed (%d): %s\n", rc, snapgpu_last_error(ctx)); return 1; }
-        for (size_t r = 0; r < nr; r++) if (rec_secondary[r]) flag[r] |= 0x100;                  // SAM_SECONDARY (createSAMLine, SAM.cpp:1477-1479)
-        std::string sq, ql;
-        for (size_t i = 0; i < nr; i++) {
-            const size_t rd = rec_read[i];
-            const char *s = b.bases.data() + b.offsets[rd], *q = b.quals.data() + b.offsets[rd];
-            const size_t U = (size_t)(b.offsets[rd + 1] - b.offsets[rd]);
-            const std::string &nmq = b.names[rd];
-            const size_t sp = nmq.find(' ');                               // "illegal in SAM: truncate at the space" (SAM.cpp:2001-2004)
-            sq.assign(s, U); ql.assign(q, U);
-            if (flag[i] & 0x10) { for (size_t j = 0; j < U; j++) { sq[U - 1 - j] = complement(s[j]); ql[U - 1 - j] = q[j]; } }
-            std::string cigar = "*";
-            if (n_ops[i] >= 0) {
-                cigar.clear();
-                char tmp[32];
-                for (int k = 0; k < n_ops[i]; k++) {
-                    const uint32_t op = ops[i * ops_stride + (size_t)k];
-                    snprintf(tmp, sizeof(tmp), "%u%c", op >> 4, "MIDNSHP=X"[op & 15]);
-                    cigar += tmp;
-                }
-            }
-            fprintf(out, "%.*s\t%d\t%s\t%lld\t%d\t%s\t*\t0\t0\t%s\t%s\tPG:Z:SNAP\tNM:i:%d\tRG:Z:FASTQ\tPL:Z:Illumina\tPU:Z:pu\tLB:Z:lb\tSM:Z:sm\n",
-                    (int)(sp == std::string::npos ? nmq.size() : sp), nmq.c_str(), flag[i], contig[i] >= 0 ? contigs[(size_t)contig[i]].name.c_str() : "*",
-                    (long long)pos[i], mapq[i], cigar.c_str(), sq.c_str(), ql.c_str(), nm[i]);
-            aligned += (flag[i] & 0x4) == 0;
-        }
-        total += n;
     }
-    fclose(out); gzclose(in); if (in2) gzclose(in2);
-    snapgpu_destroy(ctx);
-    fprintf(stderr, "snapgpu-sam: %llu reads, %llu mapped records\n", total, aligned);
+    w.flag.assign(nr, 0); w.contig.assign(nr, 0); w.mapq.assign(nr, 0); w.n_ops.assign(nr, 0); w.nm.assign(nr, 0); w.pos.assign(nr, 0);
+    std::vector<int32_t> stale(nr);
+    w.ops_stride = o.ops_stride;
+    with_growing_stride(w, nr, [&] {
+        int rc2 = one_to_one
+            ? snapgpu_sam_fields_single(ctx, (uint32_t)nr, b.bases.data(), b.quals.data(), b.offsets.data(), front_clip.data(), data_len.data(), rec_res.data(),
+                                        o.use_m ? 1 : 0, w.flag.data(), w.contig.data(), w.pos.data(), w.mapq.data(), w.ops.data(), w.ops_stride, w.n_ops.data(),
+                                        w.nm.data(), stale.data())
+            : snapgpu_sam_fields_single(ctx, (uint32_t)nr, rb.data(), rq.data(), ro.data(), rfc.data(), rdl.data(), rec_res.data(), o.use_m ? 1 : 0,
+                                        w.flag.data(), w.contig.data(), w.pos.data(), w.mapq.data(), w.ops.data(), w.ops_stride, w.n_ops.data(), w.nm.data(), stale.data());
+        if (rc2 != SNAPGPU_OK) fail_rc(ctx, "snapgpu_sam_fields_single", rc2);
+    });
+    for (size_t r = 0; r < nr; r++) if (w.rec_secondary[r]) w.flag[r] |= 0x100;                  // SAM_SECONDARY (createSAMLine, SAM.cpp:1477-1479)
+}
+
+static void gpu_paired(const Options &o, snapgpu_ctx *ctx, Work &w)
+{
+    const Batch &b = w.b;
+    const size_t n = b.n(), np = n / 2;
+    std::vector<int32_t> front_clip(n, 0), data_len(n, 0);
+    std::vector<char> useful(n, 0);
+    for (size_t i = 0; i < n; i++) useful[i] = clip_read(o, b, i, front_clip[i], data_len[i]);
+    std::vector<uint32_t> to_align;                                     // pairs with at least one useful mate (PairedAligner.cpp:680-682)
+    std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
+    for (size_t k = 0; k < np; k++) {
+        if (!useful[2 * k] && !useful[2 * k + 1]) continue;
+        to_align.push_back((uint32_t)k);
+        for (size_t i = 2 * k; i < 2 * k + 2; i++) {
+            const char *q = b.quals.data() + b.offsets[i], *s = b.bases.data() + b.offsets[i];
+            ab.insert(ab.end(), s + front_clip[i], s + front_clip[i] + data_len[i]); aq.insert(aq.end(), q + front_clip[i], q + front_clip[i] + data_len[i]); ao.push_back(ab.size());
+        }
+    }
+    std::vector<snapgpu_paired_result> results(np), ares(to_align.size()), aalt(to_align.size());
+    for (size_t k = 0; k < np; k++) {
+        memset(&results[k], 0, sizeof(results[k]));
+        for (int v = 0; v < 2; v++) { results[k].status[v] = SNAPGPU_NotFound; results[k].location[v] = SNAPGPU_InvalidGenomeLocation32; results[k].score[v] = -1; }
+    }
+    if (!to_align.empty()) {
+        int rc = snapgpu_align_paired(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), ares.data(), aalt.data());
+        if (rc != SNAPGPU_OK) fail_rc(ctx, "snapgpu_align_paired", rc);
+        for (size_t k = 0; k < to_align.size(); k++) results[to_align[k]] = ares[k];
+    }
+    w.flag.assign(n, 0); w.contig.assign(n, 0); w.mapq.assign(n, 0); w.n_ops.assign(n, 0); w.nm.assign(n, 0); w.rnext.assign(n, 0);
+    w.first_written.assign(np, 0); w.pos.assign(n, 0); w.pnext.assign(n, 0); w.tlen.assign(n, 0);
+    std::vector<int32_t> stale(n);
+    w.ops_stride = o.ops_stride;
+    with_growing_stride(w, n, [&] {
+        int rc = snapgpu_sam_fields_paired(ctx, (uint32_t)np, b.bases.data(), b.quals.data(), b.offsets.data(), front_clip.data(), data_len.data(), results.data(),
+                                           o.use_m ? 1 : 0, w.flag.data(), w.contig.data(), w.pos.data(), w.mapq.data(), w.ops.data(), w.ops_stride, w.n_ops.data(),
+                                           w.nm.data(), w.rnext.data(), w.pnext.data(), w.tlen.data(), w.first_written.data(), stale.data());
+        if (rc != SNAPGPU_OK) fail_rc(ctx, "snapgpu_sam_fields_paired", rc);
+    });
+}
+
+// ---------------------------------------------------------------------------------------- formatting stage
+static inline void put_cigar(std::string &o, const Work &w, size_t i)
+{
+    if (w.n_ops[i] < 0) { o.push_back('*'); return; }
+    for (int c = 0; c < w.n_ops[i]; c++) { const uint32_t op = w.ops[i * (size_t)w.ops_stride + (size_t)c]; put_uint(o, op >> 4); o.push_back("MIDNSHP=X"[op & 15]); }
+}
+static inline void put_seq_qual(std::string &o, const char *s, const char *q, size_t U, bool rc)
+{
+    const size_t at = o.size();
+    o.resize(at + 2 * U + 1);
+    char *d = &o[at];
+    if (rc) { for (size_t j = 0; j < U; j++) { d[U - 1 - j] = complement(s[j]); d[U + 1 + U - 1 - j] = q[j]; } }
+    else { memcpy(d, s, U); memcpy(d + U + 1, q, U); }
+    d[U] = '\t';
+}
+static const char AUX_TAIL[] = "\tRG:Z:FASTQ\tPL:Z:Illumina\tPU:Z:pu\tLB:Z:lb\tSM:Z:sm";
+
+static void format_single(const std::vector<Contig> &contigs, Work &w)
+{
+    const Batch &b = w.b;
+    std::string &o = w.text;
+    o.clear(); o.reserve(w.rec_read.size() * 420);
+    for (size_t i = 0; i < w.rec_read.size(); i++) {
+        const size_t rd = w.rec_read[i];
+        const char *s = b.bases.data() + b.offsets[rd], *q = b.quals.data() + b.offsets[rd];
+        const size_t U = (size_t)(b.offsets[rd + 1] - b.offsets[rd]);
+        const char *nm = b.names.data() + b.name_off[rd]; size_t nl = b.name_off[rd + 1] - b.name_off[rd];
+        const void *sp = memchr(nm, ' ', nl);                              // "illegal in SAM: truncate at the space" (SAM.cpp:2001-2004)
+        if (sp) nl = (size_t)((const char *)sp - nm);
+        o.append(nm, nl); o.push_back('\t'); put_int(o, w.flag[i]); o.push_back('\t');
+        if (w.contig[i] >= 0) o += contigs[(size_t)w.contig[i]].name; else o.push_back('*');
+        o.push_back('\t'); put_int(o, w.pos[i]); o.push_back('\t'); put_int(o, w.mapq[i]); o.push_back('\t');
+        put_cigar(o, w, i);
+        o += "\t*\t0\t0\t";
+        put_seq_qual(o, s, q, U, (w.flag[i] & 0x10) != 0);
+        o += "\tPG:Z:SNAP\tNM:i:"; put_int(o, w.nm[i]); o += AUX_TAIL; o.push_back('\n');
+        w.mapped += (w.flag[i] & 0x4) == 0;
+    }
+}
+
+static void format_paired(const std::vector<Contig> &contigs, Work &w)
+{
+    const Batch &b = w.b;
+    const size_t np = b.n() / 2;
+    std::string &o = w.text;
+    o.clear(); o.reserve(b.n() * 440);
+    for (size_t k = 0; k < np; k++) {
+        // QNAME: the /1 /2 suffixes go when both names carry them (ReadWriter.cpp:392-404)
+        const char *n0 = b.names.data() + b.name_off[2 * k], *n1 = b.names.data() + b.name_off[2 * k + 1];
+        size_t idl[2] = { (size_t)(b.name_off[2 * k + 1] - b.name_off[2 * k]), (size_t)(b.name_off[2 * k + 2] - b.name_off[2 * k + 1]) };
+        if (idl[0] == idl[1] && idl[0] > 2 && n0[idl[0] - 2] == '/' && n1[idl[0] - 2] == '/') {
+            const char c0 = n0[idl[0] - 1], c1 = n1[idl[1] - 1];
+            if ((c0 == '1' || c0 == '2') && (c1 == '1' || c1 == '2') && c0 != c1) { idl[0] -= 2; idl[1] -= 2; }
+        }
+        for (int ord = 0; ord < 2; ord++) {
+            const int v = ord == 0 ? w.first_written[k] : 1 - w.first_written[k];
+            const size_t i = 2 * k + (size_t)v, im = 2 * k + (size_t)(1 - v);
+            const char *s = b.bases.data() + b.offsets[i], *q = b.quals.data() + b.offsets[i];
+            const size_t U = (size_t)(b.offsets[i + 1] - b.offsets[i]);
+            const char *nm = v == 0 ? n0 : n1;
+            size_t qn = idl[v];
+            const void *sp = memchr(nm, ' ', qn);
+            if (sp) qn = (size_t)((const char *)sp - nm);
+            int mqs = 0;                                                // QS: the mate's qualities >= 15, summed (SAM.cpp:1826-1837)
+            { const unsigned char *mq = (const unsigned char *)b.quals.data() + b.offsets[im]; const size_t mu = (size_t)(b.offsets[im + 1] - b.offsets[im]);
+              for (size_t j = 0; j < mu; j++) { const int x = (int)mq[j] - '!'; mqs += x >= 15 ? (x != 255) * x : 0; } }
+            o.append(nm, qn); o.push_back('\t'); put_int(o, w.flag[i]); o.push_back('\t');
+            if (w.contig[i] >= 0) o += contigs[(size_t)w.contig[i]].name; else o.push_back('*');
+            o.push_back('\t'); put_int(o, w.pos[i]); o.push_back('\t'); put_int(o, w.mapq[i]); o.push_back('\t');
+            put_cigar(o, w, i); o.push_back('\t');
+            if (w.rnext[i] == -2) o.push_back('='); else if (w.rnext[i] >= 0) o += contigs[(size_t)w.rnext[i]].name; else o.push_back('*');
+            o.push_back('\t'); put_int(o, w.pnext[i]); o.push_back('\t'); put_int(o, (int)w.tlen[i]); o.push_back('\t');
+            put_seq_qual(o, s, q, U, (w.flag[i] & 0x10) != 0);
+            o += "\tPG:Z:SNAP\tNM:i:"; put_int(o, w.nm[i]); o += AUX_TAIL; o += "\tQS:i:"; put_int(o, mqs); o.push_back('\n');
+            w.mapped += (w.flag[i] & 0x4) == 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------- main
+int main(int argc, char **argv)
+{
+    Options o;
+    o.paired = argc >= 2 && strcmp(argv[1], "paired") == 0;
+    if (argc < (o.paired ? 5 : 4) || (!o.paired && strcmp(argv[1], "single") != 0))
+        die("usage: snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> | paired <index-dir> <r1.fq> <r2.fq> -o <out.sam>  [-d N] [-G-] [-=] [-M] [-mrl N] [-b N] [-gpus N] [-q N] [-t N]");
+    const std::string index_dir = argv[2], fastq = argv[3], fastq2 = o.paired ? argv[4] : "";
+    std::string out_path;
+    snapgpu_default_params(&o.p);
+    o.p.max_read_len = 400;                                                // per-wave buffers; SNAPGPU_MAX_READ_LEN raises it (<= 1000), as for snap-aligner-gpu
+    if (const char *e = getenv("SNAPGPU_MAX_READ_LEN")) { const int v = atoi(e); if (v >= 50 && v <= 1000) o.p.max_read_len = (uint32_t)v; }
+    std::string cl = argv[1];
+    for (int i = 2; i < argc; i++) { cl += " "; cl += argv[i]; }
+    for (int i = o.paired ? 5 : 4; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "-o" && i + 1 < argc) out_path = argv[++i];
+        else if (a == "-d" && i + 1 < argc) o.p.max_k = (uint32_t)atoi(argv[++i]);
+        else if (a == "-G-") o.p.use_affine_gap = 0;
+        else if (a == "-=") o.use_m = false;
+        else if (a == "-M") o.use_m = true;
+        else if (a.size() == 4 && a.compare(0, 2, "-C") == 0 && strchr("+-", a[2]) && strchr("+-", a[3])) { o.clip_front = a[2] == '+'; o.clip_back = a[3] == '+'; }   // AlignerOptions.cpp: -Cxx
+        else if (a == "-om" && i + 1 < argc) o.om = atoi(argv[++i]);                       // secondary alignments (AlignerOptions.cpp:70-72)
+        else if (a == "-omax" && i + 1 < argc) o.omax = atoll(argv[++i]);
+        else if (a == "-mpc" && i + 1 < argc) o.mpc = atoi(argv[++i]);
+        else if (a == "-ea") o.p.emit_alt_alignments = 1;                                  // the first ALT alignment as an extra record (SingleAligner.cpp:320-322)
+        else if (a == "-D" && i + 1 < argc) o.p.extra_search_depth = (uint32_t)atoi(argv[++i]);
+        else if (a == "-mrl" && i + 1 < argc) o.min_read_len = (unsigned)atoi(argv[++i]);
+        else if (a == "-b" && i + 1 < argc) o.batch_reads = (size_t)atoll(argv[++i]);
+        else if (a == "-gpus" && i + 1 < argc) o.n_gpus = atoi(argv[++i]);
+        else if (a == "-q" && i + 1 < argc) o.ctx_per_gpu = atoi(argv[++i]);
+        else if (a == "-t" && i + 1 < argc) o.n_format = atoi(argv[++i]);  // host threads that format records (the reference's -t counts aligner threads)
+        else die("option not supported: ", a.c_str());
+    }
+    if (out_path.empty()) die("-o <out.sam> is required");
+    if (o.batch_reads < (o.paired ? 2u : 1u)) die("-b must be at least 1 (2 for paired)");
+    if (o.paired) o.batch_reads &= ~(size_t)1;
+    if (o.ctx_per_gpu < 1 || o.ctx_per_gpu > 8) die("-q must be in [1, 8]");
+    // cigar ops per record: about 2 * edits + soft clips; grown on demand when a record needs more (with_growing_stride)
+    { uint32_t need = 2 * (o.p.max_k + o.p.extra_search_depth) + 8; o.ops_stride = 64; while (o.ops_stride < need) o.ops_stride *= 2; }
+
+    std::vector<Contig> contigs; uint64_t n_bases = 0; uint32_t padding = 0;
+    load_contigs(index_dir, contigs, n_bases, padding);
+
+    // ---- contexts: GPU 0 reads the index, the other GPUs get it over RCCL, every further feeder on a GPU shares that GPU's blobs
+    int visible = snapgpu_device_count();
+    if (visible <= 0) { snapgpu_ctx *none = NULL; int rc = snapgpu_create_from_directory(index_dir.c_str(), &o.p, 0, &none); fail_rc(none, "snapgpu_create_from_directory", rc); }
+    if (o.n_gpus <= 0 || o.n_gpus > visible) o.n_gpus = visible;
+    std::vector<snapgpu_ctx *> primary((size_t)o.n_gpus, NULL);
+    int rc = snapgpu_create_from_directory(index_dir.c_str(), &o.p, 0, &primary[0]);
+    if (rc != SNAPGPU_OK) fail_rc(primary[0], "snapgpu_create_from_directory", rc);
+    for (int g = 1; g < o.n_gpus; g++) {
+        rc = snapgpu_create_replica(primary[0], g, 0, &primary[(size_t)g]);
+        if (rc != SNAPGPU_OK) fail_rc(primary[0], "snapgpu_create_replica", rc);
+    }
+    if (o.n_gpus > 1) {
+        rc = snapgpu_broadcast_index(primary.data(), o.n_gpus);
+        if (rc != SNAPGPU_OK) fail_rc(primary[0], "snapgpu_broadcast_index", rc);
+    }
+    std::vector<snapgpu_ctx *> ctxs;                                        // one per feeder thread
+    for (int g = 0; g < o.n_gpus; g++) {
+        ctxs.push_back(primary[(size_t)g]);
+        for (int k = 1; k < o.ctx_per_gpu; k++) {
+            snapgpu_ctx *c = NULL;
+            rc = snapgpu_create_replica(primary[(size_t)g], g, 1, &c);
+            if (rc != SNAPGPU_OK) fail_rc(primary[(size_t)g], "snapgpu_create_replica", rc);
+            ctxs.push_back(c);
+        }
+    }
+    snapgpu_default_paired_params(&o.pp);
+    o.pp.min_read_length = o.min_read_len;
+    for (snapgpu_ctx *c : ctxs) {
+        if (o.paired) { rc = snapgpu_enable_paired(c, &o.pp); if (rc != SNAPGPU_OK) fail_rc(c, "snapgpu_enable_paired", rc); }
+        if (o.om >= 0) {
+            if (o.paired) die("-om with `paired` is not supported by this program yet");
+            snapgpu_secondary_params sp; memset(&sp, 0, sizeof(sp));
+            sp.max_edit_distance = o.om; sp.max_per_contig = o.mpc; sp.max_results = o.omax; sp.adjust_alignments = 0;
+            rc = snapgpu_enable_secondary(c, &sp);
+            if (rc != SNAPGPU_OK) fail_rc(c, "snapgpu_enable_secondary", rc);
+        }
+    }
+    if (o.n_format <= 0) { unsigned hc = std::thread::hardware_concurrency(); o.n_format = (int)(hc > 16 ? 16 : (hc ? hc : 4)); }
+
+    FILE *out = fopen(out_path.c_str(), "wb");
+    if (!out) die("cannot create ", out_path.c_str());
+    setvbuf(out, NULL, _IOFBF, 8u << 20);
+    // header (SAM.cpp:1232-1295); @SQ lines go by ORIGINAL contig number: the index builder moves ALT contigs behind the regular ones
+    // (FASTA.cpp:359-384), the header keeps the FASTA's order (getContigByOriginalContigNumber, SAM.cpp:1291)
+    fprintf(out, "@HD\tVN:1.6\tGO:query\n@RG\tID:FASTQ\tPL:Illumina\tPU:pu\tLB:lb\tSM:sm\n@PG\tID:SNAP\tPN:SNAP\tCL:%s\tVN:2.0.5\n", cl.c_str());
+    {
+        std::vector<size_t> by_orig(contigs.size());
+        bool perm = true;
+        std::vector<char> seen(contigs.size(), 0);
+        for (size_t c = 0; c < contigs.size(); c++) { if (contigs[c].orig < 0 || (size_t)contigs[c].orig >= contigs.size() || seen[(size_t)contigs[c].orig]) { perm = false; break; } seen[(size_t)contigs[c].orig] = 1; by_orig[(size_t)contigs[c].orig] = c; }
+        for (size_t k = 0; k < contigs.size(); k++) {
+            const size_t c = perm ? by_orig[k] : k;
+            const uint64_t end = c + 1 < contigs.size() ? contigs[c + 1].begin : n_bases;
+            fprintf(out, "@SQ\tSN:%s\tLN:%llu%s\n", contigs[c].name.c_str(), (unsigned long long)(end - contigs[c].begin - padding), contigs[c].is_alt ? "\tAH:*" : "");
+        }
+    }
+
+    // ---- the pipeline
+    Queue<Work *> q_parsed(ctxs.size() * 2 + 2), q_aligned((size_t)o.n_format * 2 + 2);
+    std::mutex done_m; std::condition_variable done_cv; std::map<uint64_t, Work *> done;
+    std::atomic<uint64_t> n_batches(0); std::atomic<bool> reader_done(false);
+    unsigned long long total = 0, mapped = 0;
+
+    std::thread reader([&] {
+        LineReader in, in2;
+        in.open(fastq.c_str());
+        if (o.paired) in2.open(fastq2.c_str());
+        uint64_t seq = 0;
+        bool eof = false;
+        while (!eof) {
+            Work *w = new Work();
+            w->b.clear(); w->b.seq = seq;
+            while (w->b.n() < o.batch_reads) {
+                if (!next_read(in, w->b, o.p.max_read_len)) { eof = true; break; }
+                if (o.paired && !next_read(in2, w->b, o.p.max_read_len)) die("the second FASTQ file has fewer reads than the first");
+            }
+            if (eof && o.paired) { Batch probe; probe.clear(); if (next_read(in2, probe, o.p.max_read_len)) die("the second FASTQ file has more reads than the first"); }
+            if (w->b.n() == 0) { delete w; break; }
+            seq++;
+            q_parsed.push(w);
+        }
+        in.close(); in2.close();
+        n_batches = seq; reader_done = true;
+        q_parsed.close();
+        { std::lock_guard<std::mutex> l(done_m); done_cv.notify_all(); }
+    });
+    std::vector<std::thread> feeders, formatters;
+    std::atomic<int> feeders_left((int)ctxs.size());
+    for (size_t t = 0; t < ctxs.size(); t++)
+        feeders.emplace_back([&, t] {
+            Work *w;
+            while (q_parsed.pop(w)) { if (o.paired) gpu_paired(o, ctxs[t], *w); else gpu_single(o, ctxs[t], *w); q_aligned.push(w); }
+            if (--feeders_left == 0) q_aligned.close();
+        });
+    for (int t = 0; t < o.n_format; t++)
+        formatters.emplace_back([&] {
+            Work *w;
+            while (q_aligned.pop(w)) {
+                if (o.paired) format_paired(contigs, *w); else format_single(contigs, *w);
+                std::lock_guard<std::mutex> l(done_m); done[w->b.seq] = w; done_cv.notify_all();
+            }
+        });
+    for (uint64_t next = 0;; next++) {                                      // the writer: batches in input order
+        Work *w = NULL;
+        {
+            std::unique_lock<std::mutex> l(done_m);
+            done_cv.wait(l, [&] { return done.count(next) || (reader_done && next >= n_batches); });
+            if (!done.count(next)) break;
+            w = done[next]; done.erase(next);
+        }
+        if (fwrite(w->text.data(), 1, w->text.size(), out) != w->text.size()) die("write error on ", out_path.c_str());
+        total += w->b.n(); mapped += w->mapped;
+        delete w;
+    }
+    reader.join();
+    for (auto &t : feeders) t.join();
+    for (auto &t : formatters) t.join();
+    if (fclose(out) != 0) die("write error on ", out_path.c_str());
+    for (size_t t = ctxs.size(); t-- > 0;) snapgpu_destroy(ctxs[t]);        // sharers before the owner of the blobs they share
+    fprintf(stderr, "snapgpu-sam: %llu reads, %llu mapped records, %d GPU(s) x %d feeder(s), %d formatter thread(s)\n", total, mapped, o.n_gpus, o.ctx_per_gpu, o.n_format);
     return 0;
 }

@@ -21,6 +21,12 @@ struct AlignArgs {
     snapgpu_single_result *secondary; // [n_reads * sec_out_stride]
     uint32_t sec_out_stride;
     uint32_t *n_secondary;            // [n_reads]: how many the read has (may exceed sec_out_stride: only that many are stored)
+    // exact replay of flagged reads (DESIGN.md "Reference nondeterminism"): the fast pass appends every read whose banded affine-gap
+    // traceback left the band to flag_list; k_align_single<0, SEC, true> then redoes exactly those (work item i = read remap[i]) with
+    // the reference's traceback arrays kept per wave in `persist` (2 x ag_scratch_bytes(RL) per wave slot)
+    uint32_t *flag_list, *flag_count;
+    const uint32_t *remap, *n_remap;
+    uint8_t *persist; uint64_t persist_stride;
 };
 
 extern "C" {
@@ -28,6 +34,7 @@ void snapgpu_launch_single_sec_3(const AlignArgs *a, uint32_t blocks, size_t lds
 void snapgpu_launch_single_sec_4(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_sec_6(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_sec_0(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_exact(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 }
 
 static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }

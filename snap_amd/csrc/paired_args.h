@@ -46,6 +46,8 @@ struct PairedArgs {
     SecCfg ssec_cfg;                   // the single-end aligner's lists
     snapgpu_paired_result *secondary; uint32_t sec_out_stride; uint32_t *n_secondary;                     // [n * stride], [n]
     snapgpu_single_result *single_secondary; uint32_t ssec_out_stride; uint32_t *n_single_secondary;      // [n * stride], [2n]
+    // exact replay of pairs whose affine-gap traceback left the band (k_align_paired<0, SEC, true>): 4 x ag_scratch_bytes(RL) per wave slot
+    uint8_t *persist; uint64_t persist_stride;
 };
 
 
@@ -58,5 +60,7 @@ void snapgpu_launch_paired_sec_3(const PairedArgs *a, uint32_t blocks, size_t ld
 void snapgpu_launch_paired_sec_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_pair_order(const DevIndex *ix, const uint8_t *bases, const uint64_t *offsets, uint32_t n_pairs, uint32_t max_big_hits,
                                uint32_t *bucket, uint32_t *hist, uint32_t *order, unsigned long long *counters, uint32_t blocks, hipStream_t s);
-void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, hipStream_t s);
+void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale, hipStream_t s);
+void snapgpu_launch_paired_exact(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_paired_sec_exact(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 }

@@ -14,9 +14,13 @@
 #include "paired.h"
 #include "paired_args.h"
 
-template <int AGC, bool SEC = false>
+// EXACT: the replay instantiation for pairs whose banded affine-gap traceback left the band (align_single.h: Aligner<.., EXACT>):
+// ag_persist[0 / 1] are the wave's images of IntersectingPairedEndAligner's affineGap / reverseAffineGap traceback arrays, the
+// single-end aligner of the chimeric fallback has its own two; the kernel zeroes all four before each pair.
+template <int AGC, bool SEC = false, bool EXACT = false>
 struct DevPL {
-    Aligner<AGC, SEC> *al;             // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
+    Aligner<AGC, SEC, EXACT> *al;      // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
+    uint8_t *ag_persist[2];
     const DevTables *tab;
     AGParams agp;
     uint32_t kmax_lv;                  // what the LV triangle was sized for
@@ -206,8 +210,8 @@ struct DevPL {
     __device__ __forceinline__ AGOut ag(bool banded, int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int lim,
                                         int read_len, bool is_rc, int use_clip) {
         ByteSeq Ps{P, st}, Qs{Q, st}, Ts{T, st};
-        AGResult a = ag_dispatch<AGC>(banded, st, agp, Ps, Qs, plen, Ts, tlen, lim, read_len, is_rc, use_clip, al->ag_rows, al->ag_scratch,
-                                      al->cfg.RL, tab);
+        AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, Ps, Qs, plen, Ts, tlen, lim, read_len, is_rc, use_clip, al->ag_rows,
+                                             EXACT ? ag_persist[st == 1 ? 0 : 1] : al->ag_scratch, al->cfg.RL, tab);
         AGOut o;
         o.ag_score = i32(a.ag_score); o.text_offset = i32(a.text_offset); o.pattern_offset = i32(a.pattern_offset);
         o.n_edits = i32(a.n_edits); o.mp = f64(a.match_probability); o.stale = i32(a.stale_reads);
@@ -299,7 +303,7 @@ struct DevPL {
 
 // Scalar-heavy, latency-bound control flow: 2 waves per SIMD keeps 256 VGPRs available (no spills) and is what the LDS
 // footprint allows anyway.
-template <int AGC, bool SEC>
+template <int AGC, bool SEC, bool EXACT = false>
 __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -312,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     uint8_t *sc = a.scratch + (size_t)wave_slot * a.stride;
 
     WaveShared *ws = (WaveShared *)(my + SL.shared);
-    Aligner<AGC, SEC> al(a.ix, a.tab, a.scfg, ws);
+    Aligner<AGC, SEC, EXACT> al(a.ix, a.tab, a.scfg, ws);
     al.lane = lane;
     al.rd[0] = my + SL.rd0; al.rd[1] = my + SL.rd1;
     al.ql[0] = my + SL.ql0; al.ql[1] = my + SL.ql1;
@@ -336,11 +340,17 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         al.sec_ord = al.sec_key + 2 * (size_t)a.ssec_cfg.cap;
         al.n_sec = 0; al.n_sec_raw = 0; al.sec_overflow = 0;
     }
-    DevPL<AGC, SEC> pl;
+    DevPL<AGC, SEC, EXACT> pl;
     pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv;
+    al.ag_persist[0] = al.ag_persist[1] = pl.ag_persist[0] = pl.ag_persist[1] = nullptr;
+    if constexpr (EXACT) {
+        uint8_t *pb = a.persist + (size_t)wave_slot * a.persist_stride;
+        const size_t q = (size_t)(a.persist_stride / 4);
+        pl.ag_persist[0] = pb; pl.ag_persist[1] = pb + q; al.ag_persist[0] = pb + 2 * q; al.ag_persist[1] = pb + 3 * q;
+    }
     pl.agp = AGParams{a.scfg.match_reward, a.scfg.sub_penalty, a.scfg.gap_open, a.scfg.gap_extend, a.scfg.five_bonus, a.scfg.three_bonus};
 
-    PairedCore<DevPL<AGC, SEC>> core(pl, a.pcfg);
+    PairedCore<DevPL<AGC, SEC, EXACT>> core(pl, a.pcfg);
     core.lk = (PELookup *)(my + PLd.lk);
     core.exhausted = (uint32_t *)(my + PLd.exhausted);
     core.miss = (uint32_t *)(my + PLd.miss);
@@ -373,6 +383,10 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         i = first_u32(i);
         if (i >= n_total) break;
         if (a.remap) i = first_u32(a.remap[i]);
+        if constexpr (EXACT) {          // newly constructed reference aligners: all four traceback arrays read as zero
+            wave_zero16(pl.ag_persist[0], (size_t)a.persist_stride);
+            WAVE_SYNC();
+        }
         for (int r = 0; r < 2; r++) {
             const uint64_t b = first_u64(a.offsets[2 * i + r]), e = first_u64(a.offsets[2 * i + r + 1]);
             const int len = (int)(e - b);
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         WAVE_SYNC();
         n_done++;
     }
-    if (lane == 0) {
+    if (lane == 0 && !EXACT) {          // (a replayed pair was already counted)
         if (!a.remap) atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
         atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
@@ -449,11 +463,14 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
 }
 
 // pairs flagged SNAPGPU_PAIR_POOL_OVERFLOW by the first pass -> list for the second pass
+// (stale != 0: instead the pairs whose traceback left the band and whose pools did not overflow -> list for the exact pass)
 template <int UNUSED>
-__global__ void k_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count)
+__global__ void k_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && (primary[i].flags & SNAPGPU_PAIR_POOL_OVERFLOW)) list[atomicAdd(count, 1u)] = i;
+    if (i >= n) return;
+    const bool ov = (primary[i].flags & SNAPGPU_PAIR_POOL_OVERFLOW) != 0;
+    if (stale ? (!ov && primary[i].reserved != 0) : ov) list[atomicAdd(count, 1u)] = i;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -24,9 +24,9 @@ extern "C" void PE_CAT(snapgpu_launch_paired_, PAIRED_AGC)(const PairedArgs *a, 
 #endif
 
 #if PAIRED_AGC == 3 && !defined(PAIRED_SEC)
-extern "C" void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, hipStream_t s)
+extern "C" void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_collect_flagged<0>, dim3((n + 255) / 256), dim3(256), 0, s, primary, n, list, count);
+    hipLaunchKernelGGL(k_collect_flagged<0>, dim3((n + 255) / 256), dim3(256), 0, s, primary, n, list, count, stale);
 }
 
 // experimental heavy-first ordering (paired_dev.h): order[0 .. n) and hist[33] = n are ready when these three have run
@@ -38,4 +38,18 @@ extern "C" void snapgpu_launch_pair_order(const DevIndex *ix, const uint8_t *bas
     hipLaunchKernelGGL(k_pair_weight_prefix<0>, dim3(1), dim3(64), 0, s, hist, counters, n_pairs);
     hipLaunchKernelGGL(k_pair_weight_scatter<0>, dim3((n_pairs + 255) / 256), dim3(256), 0, s, (const uint32_t *)bucket, n_pairs, hist, order);
 }
+#endif
+
+#if PAIRED_AGC == 0     // exact replay of flagged pairs (paired_args.h: PairedArgs::persist): always the layout-literal affine-gap form
+#ifdef PAIRED_SEC
+extern "C" void snapgpu_launch_paired_sec_exact(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_align_paired<0, true, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
+}
+#else
+extern "C" void snapgpu_launch_paired_exact(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_align_paired<0, false, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
+}
+#endif
 #endif

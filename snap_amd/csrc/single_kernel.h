@@ -9,7 +9,7 @@
 #ifndef SNAPGPU_WAVES_PER_SIMD
 #define SNAPGPU_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 6 : 4)
 #endif
-template <int AGC, bool SEC>
+template <int AGC, bool SEC, bool EXACT = false>
 __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_single(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
     WaveShared *ws = (WaveShared *)(my + L.shared);
-    Aligner<AGC, SEC> al(a.ix, a.tab, a.cfg, ws);
+    Aligner<AGC, SEC, EXACT> al(a.ix, a.tab, a.cfg, ws);
     al.lane = lane;
     al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
     al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
@@ -34,6 +34,11 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     al.heads = (uint16_t *)sc;
     al.pool = (Elem *)(sc + (size_t)a.cfg.ht_size * 2);
     al.ag_scratch = sc + (size_t)a.cfg.ht_size * 2 + (size_t)a.cfg.pool_size * sizeof(Elem);
+    al.ag_persist[0] = al.ag_persist[1] = nullptr;
+    if constexpr (EXACT) {
+        al.ag_persist[0] = a.persist + (size_t)wave_slot * a.persist_stride;
+        al.ag_persist[1] = al.ag_persist[0] + a.persist_stride / 2;
+    }
     if constexpr (SEC) {            // secondary-result scratch of this wave (snapgpu_enable_secondary)
         uint8_t *ss = a.sec_scratch + (size_t)wave_slot * a.sec_stride_bytes;
         al.sec_cfg = a.sec_cfg;
@@ -45,14 +50,23 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t n_done = 0;
 
+    const uint32_t n_total = EXACT ? first_u32(*a.n_remap) : a.n_reads;
     while (true) {
         uint32_t i = 0;
         if (lane == 0) i = atomicAdd(a.work_counter, 1u);
         i = first_u32(i);
-        if (i >= a.n_reads) break;
+        if (i >= n_total) break;
+        if constexpr (EXACT) {          // a newly constructed reference aligner: both traceback arrays read as zero
+            i = first_u32(a.remap[i]);
+            wave_zero16(al.ag_persist[0], (size_t)a.persist_stride);
+            WAVE_SYNC();
+        }
         uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
         al.align_read(a.bases + b, a.quals + b, (int)(e - b));
         WAVE_SYNC();
+        if constexpr (!EXACT) {         // traceback left the band somewhere: the exact pass redoes this read
+            if (a.flag_list && ws->primary.reserved != 0 && lane == 0) a.flag_list[atomicAdd(a.flag_count, 1u)] = i;
+        }
         {   // results: LDS -> global, one dword per lane
             const uint32_t *src = (const uint32_t *)&ws->primary;
             uint32_t *dst = (uint32_t *)&a.primary[i];
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         }
         n_done++;
     }
-    if (lane == 0) {
+    if (lane == 0 && !EXACT) {          // (a replayed read was already counted by the fast pass)
         atomicAdd(&a.counters[0], (unsigned long long)n_done);
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
         atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);

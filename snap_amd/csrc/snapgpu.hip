@@ -33,12 +33,17 @@
 // k_align_single: single_kernel.h
 
 // One wave per seed: GenomeIndex::lookupSeed32 for a batch of seeds.
+// hits == NULL: hit counts only, and the hit lists are still READ (max_hits_out of them at most, as BaseAligner consumes them) so that the
+// launch moves the bytes a lookup is entitled to -- the probe-only roofline measurement of bench.py.  counters (snapgpu_counters layout,
+// may be NULL): lookups, slots examined, hits read, overflow lists dereferenced.
 __global__ __launch_bounds__(256) void k_lookup_seeds(DevIndex ix, uint32_t n, const uint8_t *seeds,
-                                                      long long *n_hits, uint32_t *hits, uint32_t max_hits_out)
+                                                      long long *n_hits, uint32_t *hits, uint32_t max_hits_out, unsigned long long *counters)
 {
     const int lane = lane_id();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    unsigned long long c_lookups = 0, c_slots = 0, c_hits = 0, c_lists = 0;
+    uint32_t sink = 0;
     for (uint32_t i = wave; i < n; i += n_waves) {
         SeedBits seed = pack_seed(seeds + (size_t)i * ix.seed_len, ix.seed_len);
         if (!seed.valid) {
@@ -47,14 +52,22 @@ __global__ __launch_bounds__(256) void k_lookup_seeds(DevIndex ix, uint32_t n, c
         }
         HitList hl[2];
         lookup_seed(ix, seed, hl);
+        c_lookups++; c_slots += hl[0].slots + hl[1].slots;
         for (int d = 0; d < 2; d++) {
             if (lane == 0) n_hits[2 * i + d] = hl[d].n_hits;
             int64_t lim = hl[d].n_hits < (int64_t)max_hits_out ? hl[d].n_hits : (int64_t)max_hits_out;
-            uint32_t *dst = hits + (size_t)(2 * i + d) * max_hits_out;
+            if (hl[d].n_hits > 1) c_lists++;
+            c_hits += (unsigned long long)lim;
+            uint32_t *dst = hits ? hits + (size_t)(2 * i + d) * max_hits_out : nullptr;
             for (int64_t j = lane; j < lim; j += WAVE) {
-                dst[j] = hl[d].n_hits == 1 ? hl[d].singleton : hl[d].hits[j];
+                const uint32_t v = hl[d].n_hits == 1 ? hl[d].singleton : hl[d].hits[j];
+                if (dst) dst[j] = v; else sink ^= v;
             }
         }
+    }
+    if (sink == 0xDEADBEEFu && n == 0xFFFFFFFFu) n_hits[0] = (long long)sink;       // keeps the hit loads alive when nothing is stored
+    if (counters && lane == 0) {
+        atomicAdd(&counters[1], c_lookups); atomicAdd(&counters[2], c_slots); atomicAdd(&counters[3], c_hits); atomicAdd(&counters[4], c_lists);
     }
 }
 
@@ -184,6 +197,9 @@ struct snapgpu_ctx {
     PairedArgs pargs_big{};           // second pass: a few waves with 32x larger candidate buffers
     uint8_t *d_pscratch = nullptr, *d_pscratch_big = nullptr;
     uint32_t *d_flag_list = nullptr; size_t flag_list_cap = 0;
+    // exact replay of flagged reads / pairs: the reference's traceback arrays per replay wave (2 per read, 4 per pair)
+    uint8_t *d_exact_persist = nullptr; uint64_t exact_persist_stride = 0; uint32_t exact_slots = 0;
+    uint8_t *d_pexact_persist = nullptr; uint64_t pexact_persist_stride = 0; uint32_t pexact_slots = 0;
     uint32_t p_wave_slots = 0, p_big_slots = 0, p_lds_per_wave = 0;
     int p_ag_variant = 0;
     // paired-end path with secondary results (both snapgpu_enable_paired and snapgpu_enable_secondary called): its own slabs
@@ -196,6 +212,10 @@ struct snapgpu_ctx {
     uint32_t p_sec_slots = 0, p_sec_big_slots = 0;
     void *d_psec_stage[4] = {nullptr, nullptr, nullptr, nullptr};      // paired secondary, counts, single secondary, counts
     size_t psec_stage_cap[4] = {0, 0, 0, 0};
+    // what snapgpu_create was given, minus the blobs: lets snapgpu_create_replica build another context over the same index
+    snapgpu_index_view view_meta{};
+    std::vector<uint64_t> h_table_offset, h_table_size, h_contig_begin, h_proj_begin;
+    std::vector<uint8_t> h_proj_rc; std::vector<uint32_t> h_cigar_start, h_cigar_ops;
     std::string err;
 };
 
@@ -330,6 +350,8 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_pscratch_sec_big) (void)hipFree(ctx->d_pscratch_sec_big);
     for (int i = 0; i < 4; i++) if (ctx->d_psec_stage[i]) (void)hipFree(ctx->d_psec_stage[i]);
     if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
+    if (ctx->d_exact_persist) (void)hipFree(ctx->d_exact_persist);
+    if (ctx->d_pexact_persist) (void)hipFree(ctx->d_pexact_persist);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
     if (ctx->d_whist) (void)hipFree(ctx->d_whist);
@@ -436,6 +458,24 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         ctx->proj.n_contigs = idx->n_contigs;
     }
 
+    {   // keep the description of the index (not the blobs) for snapgpu_create_replica
+        ctx->view_meta = *idx;
+        const size_t n = idx->n_contigs;
+        ctx->h_table_offset.assign(idx->table_offset, idx->table_offset + idx->n_hash_tables);
+        ctx->h_table_size.assign(idx->table_size, idx->table_size + idx->n_hash_tables);
+        if (n) ctx->h_contig_begin.assign(idx->contig_begin, idx->contig_begin + n);
+        if (idx->contig_proj_begin && n) ctx->h_proj_begin.assign(idx->contig_proj_begin, idx->contig_proj_begin + n);
+        if (idx->contig_proj_rc && n) ctx->h_proj_rc.assign(idx->contig_proj_rc, idx->contig_proj_rc + n);
+        if (idx->contig_cigar_start && idx->cigar_ops && n) {
+            ctx->h_cigar_start.assign(idx->contig_cigar_start, idx->contig_cigar_start + n + 1);
+            ctx->h_cigar_ops.assign(idx->cigar_ops, idx->cigar_ops + idx->contig_cigar_start[n]);
+        }
+        ctx->view_meta.hash_blob = nullptr; ctx->view_meta.overflow = nullptr; ctx->view_meta.genome = nullptr;
+        ctx->view_meta.table_offset = nullptr; ctx->view_meta.table_size = nullptr; ctx->view_meta.contig_begin = nullptr;
+        ctx->view_meta.contig_proj_begin = nullptr; ctx->view_meta.contig_proj_rc = nullptr; ctx->view_meta.contig_cigar_start = nullptr;
+        ctx->view_meta.cigar_ops = nullptr;
+    }
+
     // ---- tables
     build_tables(ctx->h_tab, idx->seed_len);
     CRCHK(hipMalloc((void **)&ctx->d_tab, sizeof(DevTables)), SNAPGPU_E_NOMEM);
@@ -486,12 +526,123 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     CRCHK(hipMalloc((void **)&ctx->d_scratch, scratch_total), SNAPGPU_E_NOMEM);
     // the head tables must start zeroed (one fill of the whole slab is cheaper than a fill per wave)
     CRCHK(hipMemsetAsync(ctx->d_scratch, 0, scratch_total, ctx->stream), SNAPGPU_E_NODEVICE);
+    if (c.use_ag) {                     // exact replay (kernel_common.h: AlignArgs::persist): 64 waves are plenty for a handful of reads per batch
+        ctx->exact_slots = ctx->n_wave_slots < 64 ? ctx->n_wave_slots : 64;
+        ctx->exact_persist_stride = 2 * (uint64_t)((ag_bytes + 255) & ~(size_t)255);
+        CRCHK(hipMalloc((void **)&ctx->d_exact_persist, (size_t)ctx->exact_slots * ctx->exact_persist_stride), SNAPGPU_E_NOMEM);
+    }
     CRCHK(hipMalloc((void **)&ctx->d_work, 256), SNAPGPU_E_NOMEM);
     CRCHK(hipMalloc((void **)&ctx->d_counters, sizeof(snapgpu_counters)), SNAPGPU_E_NOMEM);
     CRCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(snapgpu_counters), ctx->stream), SNAPGPU_E_NODEVICE);
     CRCHK(hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
 #undef CRCHK
     *out = ctx;
+    return SNAPGPU_OK;
+}
+
+// ---- several contexts over one index: more feeder threads per GPU, more GPUs (SNAPLib/ParallelTask.h:128-138 is the
+// reference's equivalent: one aligner per thread over the shared g_index)
+extern "C" int snapgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int snapgpu_create_replica(const snapgpu_ctx *src, int device, int share_index, snapgpu_ctx **out)
+{
+    if (!src || !out) return fail(nullptr, SNAPGPU_E_INVALID, "snapgpu_create_replica: null argument");
+    *out = nullptr;
+    if (share_index && device != src->device) return fail(nullptr, SNAPGPU_E_INVALID, "snapgpu_create_replica: index blobs can only be shared on the device that holds them");
+    snapgpu_index_view v = src->view_meta;
+    v.table_offset = src->h_table_offset.data(); v.table_size = src->h_table_size.data();
+    v.contig_begin = src->h_contig_begin.empty() ? nullptr : src->h_contig_begin.data();
+    v.contig_proj_begin = src->h_proj_begin.empty() ? nullptr : src->h_proj_begin.data();
+    v.contig_proj_rc = src->h_proj_rc.empty() ? nullptr : src->h_proj_rc.data();
+    v.contig_cigar_start = src->h_cigar_start.empty() ? nullptr : src->h_cigar_start.data();
+    v.cigar_ops = src->h_cigar_ops.empty() ? nullptr : src->h_cigar_ops.data();
+    if (share_index) {          // a second feeder context on the same GPU: adopt the blobs, own streams / scratch / staging
+        v.on_device = 1;
+        v.hash_blob = (const uint8_t *)src->d_hash; v.overflow = (const uint32_t *)src->d_overflow;
+        v.genome = (const uint8_t *)src->d_genome_padded + src->view_meta.genome_pad;
+    } else {                    // same-size blobs on `device`, left for snapgpu_broadcast_index to fill
+        v.on_device = 0;
+        v.hash_blob = nullptr; v.overflow = nullptr; v.genome = nullptr;
+    }
+    return snapgpu_create(&v, &src->params, device, out);
+}
+
+// RCCL through dlopen: libsnapgpu.so must load on a box without librccl (single-GPU use); the symbols are resolved on first use.
+// (the handful of RCCL declarations used, spelled out here instead of #include <rccl/rccl.h>: values as in rccl.h of ROCm 7.2)
+#include <dlfcn.h>
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+static const ncclResult_t ncclSuccess = 0;
+static const ncclDataType_t ncclUint8 = 1;
+struct RcclApi {
+    void *h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string &why) {
+        if (h) return true;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { h = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (h) break; }
+        if (!h) { why = std::string("dlopen(librccl): ") + dlerror(); return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll"); CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart"); GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
+        Broadcast = (decltype(Broadcast))dlsym(h, "ncclBroadcast"); GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+        if (!CommInitAll || !CommDestroy || !GroupStart || !GroupEnd || !Broadcast || !GetErrorString) { why = "librccl lacks an expected symbol"; return false; }
+        return true;
+    }
+};
+static RcclApi g_rccl;
+
+// The index of ctxs[0] into the (same-size, so far unfilled) blobs of ctxs[1 .. n): one ncclBroadcast per blob, root 0, all ranks driven
+// from this thread inside one group call (ncclCommInitAll communicators: one process, one rank per GPU).  Over xGMI a ring broadcast is
+// bound by one link (~153 GB/s peak), i.e. ~0.2-0.3 s for GRCh38's ~30 GB.
+extern "C" int snapgpu_broadcast_index(snapgpu_ctx **ctxs, int n)
+{
+    if (!ctxs || n < 1) return fail(nullptr, SNAPGPU_E_INVALID, "snapgpu_broadcast_index: bad argument");
+    for (int i = 0; i < n; i++) if (!ctxs[i]) return fail(nullptr, SNAPGPU_E_INVALID, "snapgpu_broadcast_index: null context");
+    snapgpu_ctx *root = ctxs[0];
+    const size_t hash_bytes = (size_t)root->view_meta.hash_blob_bytes;
+    const size_t ovf_bytes = (size_t)(root->view_meta.overflow_table_size ? root->view_meta.overflow_table_size : 1) * 4;
+    const size_t gen_bytes = (size_t)root->view_meta.n_bases + 2 * (size_t)root->view_meta.genome_pad;
+    for (int i = 1; i < n; i++) {
+        const snapgpu_index_view &a = root->view_meta, &b = ctxs[i]->view_meta;
+        if (a.hash_blob_bytes != b.hash_blob_bytes || a.overflow_table_size != b.overflow_table_size || a.n_bases != b.n_bases ||
+            a.genome_pad != b.genome_pad || a.seed_len != b.seed_len || a.n_hash_tables != b.n_hash_tables)
+            return fail(root, SNAPGPU_E_INVALID, "snapgpu_broadcast_index: context " + std::to_string(i) + " was not created over the same index (snapgpu_create_replica)");
+        if (!ctxs[i]->owns_index) return fail(root, SNAPGPU_E_INVALID, "snapgpu_broadcast_index: context " + std::to_string(i) + " shares another context's blobs");
+        for (int j = 0; j < i; j++) if (ctxs[j]->device == ctxs[i]->device) return fail(root, SNAPGPU_E_INVALID, "snapgpu_broadcast_index: two contexts on one device");
+    }
+    if (n == 1) return SNAPGPU_OK;
+    std::string why;
+    if (!g_rccl.load(why)) return fail(root, SNAPGPU_E_UNSUPPORTED, "snapgpu_broadcast_index: RCCL is not available (" + why + ")");
+    std::vector<int> devs((size_t)n); std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    for (int i = 0; i < n; i++) devs[(size_t)i] = ctxs[i]->device;
+#define NCCLCHK(call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) { \
+        std::string m = std::string(#call) + ": " + g_rccl.GetErrorString(_r); for (auto c : comms) if (c) g_rccl.CommDestroy(c); return fail(root, SNAPGPU_E_LAUNCH, m); } } while (0)
+    NCCLCHK(g_rccl.CommInitAll(comms.data(), n, devs.data()));
+    struct Blob { void *snapgpu_ctx::*p; size_t bytes; };
+    const Blob blobs[3] = {{&snapgpu_ctx::d_hash, hash_bytes}, {&snapgpu_ctx::d_overflow, ovf_bytes}, {&snapgpu_ctx::d_genome_padded, gen_bytes}};
+    for (const Blob &b : blobs) {
+        NCCLCHK(g_rccl.GroupStart());
+        for (int i = 0; i < n; i++) {
+            HIPCHK(root, hipSetDevice(ctxs[i]->device), SNAPGPU_E_NODEVICE);
+            NCCLCHK(g_rccl.Broadcast(ctxs[i]->*(b.p), ctxs[i]->*(b.p), b.bytes, ncclUint8, 0, comms[(size_t)i], ctxs[i]->stream));
+        }
+        NCCLCHK(g_rccl.GroupEnd());
+    }
+    for (int i = 0; i < n; i++) {
+        HIPCHK(root, hipSetDevice(ctxs[i]->device), SNAPGPU_E_NODEVICE);
+        HIPCHK(root, hipStreamSynchronize(ctxs[i]->stream), SNAPGPU_E_LAUNCH);
+    }
+    for (auto c : comms) g_rccl.CommDestroy(c);
+#undef NCCLCHK
     return SNAPGPU_OK;
 }
 
@@ -624,11 +775,33 @@ extern "C" int snapgpu_lookup_seeds(snapgpu_ctx *ctx, uint32_t n, const char *se
     HIPCHK(ctx, hipMemsetAsync(ctx->d_stage[2], 0, hb, ctx->stream), SNAPGPU_E_LAUNCH);
     uint32_t blocks = (n + 3) / 4; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;
     hipLaunchKernelGGL(k_lookup_seeds, dim3(blocks), dim3(256), 0, ctx->stream, ctx->ix, n,
-                       (const uint8_t *)ctx->d_stage[0], (long long *)ctx->d_stage[1], (uint32_t *)ctx->d_stage[2], max_hits_out);
+                       (const uint8_t *)ctx->d_stage[0], (long long *)ctx->d_stage[1], (uint32_t *)ctx->d_stage[2], max_hits_out,
+                       (unsigned long long *)nullptr);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(n_hits, ctx->d_stage[1], nb, hipMemcpyDeviceToHost, ctx->stream), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(hits, ctx->d_stage[2], hb, hipMemcpyDeviceToHost, ctx->stream), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
+static int finish_timing(snapgpu_ctx *ctx);
+// Device-pointer form of snapgpu_lookup_seeds: seeds, hit counts and (optionally) hits already in HBM.  d_hits == NULL: counts only
+// (the lists are read, not stored).  Timed with hipEvents like the align kernels (snapgpu_kernel_time) and counted into
+// snapgpu_counters (lookups, slots, hits, overflow lists): the index-probe kernel on its own, for its HBM roofline (bench.py).
+extern "C" int snapgpu_lookup_seeds_device(snapgpu_ctx *ctx, uint32_t n, const void *d_seeds, void *d_n_hits, void *d_hits,
+                                           uint32_t max_hits_out, void *stream)
+{
+    if (!ctx || !d_seeds || !d_n_hits || max_hits_out == 0) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_lookup_seeds_device: bad argument");
+    if (n == 0) return SNAPGPU_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    uint32_t blocks = (n + 3) / 4; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    hipLaunchKernelGGL(k_lookup_seeds, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
+                       (uint32_t *)d_hits, max_hits_out, ctx->d_counters);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
+    if (!stream) return finish_timing(ctx);
     return SNAPGPU_OK;
 }
 
@@ -1124,7 +1297,19 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.n_reads = n; a.primary = (snapgpu_single_result *)d_primary; a.first_alt = (snapgpu_single_result *)d_first_alt;
     a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.sec_cfg = SecCfg{-1, -1, 0, 0}; a.sec_scratch = nullptr; a.sec_stride_bytes = 0; a.secondary = nullptr; a.sec_out_stride = 0; a.n_secondary = nullptr;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    a.flag_list = nullptr; a.flag_count = nullptr; a.remap = nullptr; a.n_remap = nullptr; a.persist = nullptr; a.persist_stride = 0;
+    const bool exact = ctx->d_exact_persist != nullptr && !getenv("SNAPGPU_NO_EXACT_REPLAY");
+    if (exact) {
+        if (ctx->flag_list_cap < n) {
+            if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
+            ctx->d_flag_list = nullptr; ctx->flag_list_cap = 0;
+            size_t cap = (size_t)n + n / 4 + 1024;
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_flag_list, cap * 4), SNAPGPU_E_NOMEM);
+            ctx->flag_list_cap = cap;
+        }
+        a.flag_list = ctx->d_flag_list; a.flag_count = ctx->d_work + 4;
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 32, s), SNAPGPU_E_LAUNCH);
     uint32_t blocks = ctx->n_wave_slots / 4;
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
@@ -1145,6 +1330,13 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     default: hipLaunchKernelGGL((k_align_single<0, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
     }
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    if (exact) {        // redo the flagged reads (usually none: the launch then ends at once) as a newly constructed reference aligner would
+        AlignArgs x = a;
+        x.flag_list = nullptr; x.flag_count = nullptr; x.remap = ctx->d_flag_list; x.n_remap = ctx->d_work + 4; x.work_counter = ctx->d_work + 3;
+        x.persist = ctx->d_exact_persist; x.persist_stride = ctx->exact_persist_stride;
+        snapgpu_launch_single_exact(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
+        HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    }
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
     return SNAPGPU_OK;
 }
@@ -1491,6 +1683,12 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         HIPCHK(ctx, hipMemsetAsync(ctx->d_pscratch_big + (size_t)w * big.stride, 0, (size_t)sc.ht_size * 2, ctx->stream), SNAPGPU_E_NODEVICE);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
     big.scratch = ctx->d_pscratch_big;
+    if (ctx->d_pexact_persist) { (void)hipFree(ctx->d_pexact_persist); ctx->d_pexact_persist = nullptr; }
+    if (p.use_affine_gap) {             // exact replay of flagged pairs: four traceback arrays per replay wave
+        ctx->pexact_slots = 64;
+        ctx->pexact_persist_stride = 4 * (uint64_t)((ag_scratch_bytes(sc.RL) + 255) & ~(size_t)255);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_pexact_persist, (size_t)ctx->pexact_slots * ctx->pexact_persist_stride), SNAPGPU_E_NOMEM);
+    }
     ctx->heavy_first = getenv("SNAPGPU_PAIRED_HEAVY_FIRST") != nullptr && atoi(getenv("SNAPGPU_PAIRED_HEAVY_FIRST")) != 0;
     ctx->paired = true;
     return setup_paired_secondary(ctx);
@@ -1558,13 +1756,27 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
     {   // second pass over the pairs the first flagged (usually none: the launch then ends at once)
         uint32_t *d_count = ctx->d_work + 2, *d_work2 = ctx->d_work + 1;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 1, 0, 8, s), SNAPGPU_E_LAUNCH);
-        snapgpu_launch_collect_flagged((const snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count, s);
+        snapgpu_launch_collect_flagged((const snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count, 0, s);
         PairedArgs b = so ? ctx->pargs_sec_big : ctx->pargs_big;
         b.secondary = a.secondary; b.sec_out_stride = a.sec_out_stride; b.n_secondary = a.n_secondary;
         b.single_secondary = a.single_secondary; b.ssec_out_stride = a.ssec_out_stride; b.n_single_secondary = a.n_single_secondary;
         b.bases = a.bases; b.quals = a.quals; b.offsets = a.offsets; b.n_pairs = n; b.primary = a.primary; b.first_alt = a.first_alt;
         b.work_counter = d_work2; b.counters = a.counters; b.remap = ctx->d_flag_list; b.n_remap = d_count;
         launch(b, (so ? ctx->p_sec_big_slots : ctx->p_big_slots) / 4);
+        HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+        // third pass: pairs whose banded affine-gap traceback left the band are redone the way a newly constructed reference aligner
+        // would do them (paired_dev.h: EXACT), in the large slabs of the second pass
+        if (ctx->d_pexact_persist && !getenv("SNAPGPU_NO_EXACT_REPLAY")) {
+            uint32_t *d_count3 = ctx->d_work + 4, *d_work3 = ctx->d_work + 3;
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 3, 0, 8, s), SNAPGPU_E_LAUNCH);
+            snapgpu_launch_collect_flagged((const snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count3, 1, s);
+            PairedArgs x = b;
+            x.work_counter = d_work3; x.remap = ctx->d_flag_list; x.n_remap = d_count3;
+            x.persist = ctx->d_pexact_persist; x.persist_stride = ctx->pexact_persist_stride;
+            uint32_t slots = so ? ctx->p_sec_big_slots : ctx->p_big_slots;
+            if (slots > ctx->pexact_slots) slots = ctx->pexact_slots;
+            if (so) snapgpu_launch_paired_sec_exact(&x, slots / 4, lds, s); else snapgpu_launch_paired_exact(&x, slots / 4, lds, s);
+        }
     }
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);

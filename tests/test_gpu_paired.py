@@ -41,14 +41,17 @@ def test_align_paired_matches_reference_fixture(pindex, golden_pairs, name):
         key = "%s_%s_s0" % (name, tag)
         a.counters(reset=True)
         prim, alt = a.align(z["b" + tag], z["q" + tag], z["o" + tag])
-        bad = compare_paired(z[key + "_primary"], prim, verbose=3, exclude=z[key + "_unstable"])
+        # every pair, none excluded: the expectation is what reference aligners newly constructed in zero-filled memory answer for
+        # the pair (util.with_fresh_overrides); pairs whose answer moves with the reference objects' history must be flagged
+        exp, patched = util.with_fresh_overrides(z[key + "_primary"], "pe_" + key + "_primary")
+        bad = compare_paired(exp, prim, verbose=3)
         assert not bad.any()
-        assert (alt["status"] == z[key + "_alt"]["status"]).all()
-        # pairs whose reference result depends on the aligner object's history are flagged, and only few are
-        assert (prim["reserved"] != 0).sum() <= 2 + prim.size // 50
+        moved = z[key + "_unstable"] | compare_paired(z[key + "_primary"], exp, verbose=0)
+        assert not (moved & (prim["reserved"] == 0)).any(), "reference-unstable pair not flagged"
+        e_alt, _ = util.with_fresh_overrides(z[key + "_alt"], "pe_" + key + "_alt")
+        assert (alt["status"] == e_alt["status"]).all()
         c = a.counters()
-        if not z[key + "_unstable"].any() and not (prim["reserved"] != 0).any():
-            assert [c["n_lv_locations"], c["n_ag_locations"]] == z[key + "_counters"].tolist()
+        assert [c["n_lv_locations"], c["n_ag_locations"]] == z[key + "_counters"].tolist()
     a.close()
 
 
@@ -82,17 +85,15 @@ def test_align_paired_vs_reference_live(tmp_path, maxk, L, npairs):
     pr = hard_pairs(5 + maxk, contigs, npairs, L, insert_mean=400 if L < 200 else (600 if L < 400 else 900), insert_max=1000 if L < 400 else 1400)
     p = abi.default_params(max_k=maxk, max_read_len=L + 10)
     pp = abi.default_paired_params(max_spacing=1000 if L < 400 else 1500)
-    rp, ra, rcnt, _ = rix.align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=16, stage=0)
+    with ref.fresh_objects():           # newly constructed reference aligners per pair: the answer is a function of the pair alone
+        rp, ra, rcnt, _ = rix.align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=16, stage=0)
     from snap_amd.aligner import ChimericPairedEndAligner
     a = ChimericPairedEndAligner(gi, p, pp)
     gp, ga = a.align(pr["bases"], pr["quals"], pr["offsets"])
-    flagged = gp["reserved"] != 0
-    bad = compare_paired(rp, gp, verbose=3, exclude=flagged)
+    bad = compare_paired(rp, gp, verbose=3)                          # every pair, no exclusion
     assert not bad.any()
-    assert flagged.sum() <= 2 + npairs // 50
     c = a.counters()
-    if not flagged.any():
-        assert (c["n_lv_locations"], c["n_ag_locations"]) == (rcnt["lv"], rcnt["ag"])
+    assert (c["n_lv_locations"], c["n_ag_locations"]) == (rcnt["lv"], rcnt["ag"])
     a.close()
 
 
@@ -130,9 +131,11 @@ def test_alt_liftover_matches_reference_fixture(name, kw):
     key = "%s_s0" % name
     fields = ["status", "direction", "location", "score", "mapq", "used_affine_gap_scoring", "bases_clipped_before", "bases_clipped_after",
               "ag_score", "liftover", "aligned_as_pair"]
-    bad = compare_paired(z[key + "_primary"], prim, verbose=3, exclude=z[key + "_unstable"] | (prim["reserved"] != 0), fields=fields)
+    exp, _ = util.with_fresh_overrides(z[key + "_primary"], "pealt_" + key + "_primary")
+    bad = compare_paired(exp, prim, verbose=3, fields=fields)        # every pair, no exclusion
     assert not bad.any()
-    assert (alt["status"] == z[key + "_alt"]["status"]).all()
+    e_alt, _ = util.with_fresh_overrides(z[key + "_alt"], "pealt_" + key + "_alt")
+    assert (alt["status"] == e_alt["status"]).all()
     assert prim["liftover"].all(axis=1).sum() == z[key + "_primary"]["liftover"].all(axis=1).sum()
 
 
@@ -156,13 +159,14 @@ def test_alt_index_without_liftover_data(golden_index, golden_reads):
     gi = GenomeIndex.load_from_directory(d + "/idx")
     pr = hard_pairs(12, cs, 1500, 150, insert_mean=380)
     p = abi.default_params(max_k=8, max_read_len=160); pp = abi.default_paired_params()
-    rp, ra, _, _ = ref.RefIndex(d + "/idx").align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=8, stage=0)
+    with ref.fresh_objects():
+        rp, ra, _, _ = ref.RefIndex(d + "/idx").align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=8, stage=0)
     a = ChimericPairedEndAligner(gi, p, pp)
     gp, ga = a.align(pr["bases"], pr["quals"], pr["offsets"])
     a.close()
-    bad = compare_paired(rp, gp, verbose=3, exclude=gp["reserved"] != 0)
+    bad = compare_paired(rp, gp, verbose=3)
     assert not bad.any()
-    assert (ra["status"] == ga["status"])[gp["reserved"] == 0].all()
+    assert (ra["status"] == ga["status"]).all()
 
 
 # ---------------------------------------------------------------------------------------- secondary results (-om / -omax / -mpc)
@@ -181,7 +185,7 @@ def test_paired_secondary_results_vs_reference_fixture(tag):
         o = o[:1201]; b = b[:int(o[-1])]; q = q[:int(o[-1])]
     for name, kw, pkw, om, omax, mpc in load_paired_secondary_sets(z):
         key = "%s_%s_" % (name, tag)
-        ref_t = tuple(z[key + k] for k in ("primary", "alt", "secondary", "nsec", "single_secondary", "nssec"))
+        ref_t = tuple(util.with_fresh_overrides(z[key + k], "pesec_" + key + k)[0] for k in ("primary", "alt", "secondary", "nsec", "single_secondary", "nssec"))
         a = ChimericPairedEndAligner(gi, abi.default_params(max_read_len=160, **kw), abi.default_paired_params(**pkw))
         try:
             a.enable_secondary(om, max_results=omax, max_per_contig=mpc)
@@ -189,7 +193,9 @@ def test_paired_secondary_results_vs_reference_fixture(tag):
             plain, _ = a.align(b[:int(o[200])], q[:int(o[200])], o[:201])         # the default kernel still runs on the same context
         finally:
             a.close()
-        exclude = z[key + "unstable"] | (got[0]["reserved"] != 0) | ((got[0]["flags"] & 2) != 0)
+        # excluded: only SNAPGPU_PAIR_REF_BUFFER_DEPENDENT pairs -- a reference bug (the ignored return value of ChimericPairedEndAligner.cpp:339)
+        # whose outcome is decided by how far earlier pairs had grown the caller's buffer, not by the pair (include/snapgpu.h)
+        exclude = (got[0]["flags"] & 2) != 0
         assert int(exclude.sum()) <= 2 + got[0].size // 100, name
         assert not compare_paired(ref_t[0], got[0], verbose=3, exclude=exclude).any(), name
         problems = compare_paired_secondary(ref_t, got, exclude)

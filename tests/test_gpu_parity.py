@@ -154,19 +154,24 @@ def test_align_read_vs_reference_fixture(golden_index, golden_reads, name, kw):
         b, q = z["b" + tag], z["q" + tag]
         offs = np.arange(b.shape[0] + 1, dtype=np.uint64) * L
         prim, alt = a.AlignRead(b, q, offs)
-        flagged = prim["reserved"] != 0        # reference result depends on its object's history there
-        assert flagged.sum() <= 0.005 * len(prim)
-        assert not (z["%s_%s_unstable" % (name, tag)] & ~flagged).any(), "reference-unstable read not flagged"
-        problems = util.compare_results(z["%s_%s_primary" % (name, tag)], prim, exclude=flagged)
-        ea = z["%s_%s_alt" % (name, tag)]
-        assert (ea["status"] == alt["status"])[~flagged].all()
-        sel = (ea["status"] != 0) & ~flagged
+        # EVERY read is compared, none excluded: the expectation is what a reference aligner newly constructed in zero-filled memory
+        # answers for the read (tests/golden/fresh_overrides.npz over the committed shared-object run; util.with_fresh_overrides).
+        # `reserved` != 0 marks the reads whose banded affine-gap traceback left the band (redone by the exact pass): every read on
+        # which the shared-object reference run differs from the fresh one, or moved with its history, must be among them.
+        key = "%s_%s_" % (name, tag)
+        flagged = prim["reserved"] != 0
+        exp_prim, patched = util.with_fresh_overrides(z[key + "primary"], key + "primary")
+        history_dependent = z[key + "unstable"].copy(); history_dependent[patched] = True
+        assert not (history_dependent & ~flagged).any(), "reference-unstable read not flagged"
+        problems = util.compare_results(exp_prim, prim)
+        ea, _ = util.with_fresh_overrides(z[key + "alt"], key + "alt")
+        assert (ea["status"] == alt["status"]).all()
+        sel = ea["status"] != 0
         problems += util.compare_results(ea[sel], alt[sel], "firstALT")
         assert not problems, problems
         c = a.counters(reset=True)
-        exp = z["%s_%s_counters" % (name, tag)]
-        if not flagged.any():
-            assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == exp.tolist()
+        exp = z[key + "counters"]
+        assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == exp.tolist()
     a.close()
 
 
@@ -258,13 +263,18 @@ def test_align_read_vs_live_reference_on_fresh_genome(tmp_path):
     for L, kw, mrl, n in ((150, dict(max_k=8), 256, 15000), (250, dict(max_k=20), 256, 15000), (500, dict(max_k=27), 512, 3000)):
         p = abi.default_params(max_read_len=mrl, **kw)
         rd = synth.make_reads(78 + L, g, n, L, sub=0.015, ins=0.002, dele=0.002, n_frac=0.0005)
-        pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=os.cpu_count() or 1)
+        with ref.fresh_objects():       # a newly constructed reference aligner per read: its answer is a function of the read alone
+            pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=os.cpu_count() or 1)
+        ps, _, _, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=2)     # ... and the usual long-lived objects
         a = BaseAligner(ix, p)
         pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"])
         c = a.counters()
         a.close()
+        assert not util.compare_results(pr, pg)                      # every read, no exclusion
         flagged = pg["reserved"] != 0
-        assert flagged.sum() <= 0.005 * len(pg)
-        assert not util.compare_results(pr, pg, exclude=flagged)
-        if not flagged.any():
-            assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == [cr["lookups"], cr["lv"], cr["ag"]]
+        shared_differs = np.zeros(len(pg), bool)
+        for f in pr.dtype.names:
+            if f != "reserved":
+                shared_differs |= (pr[f] != ps[f]) & ((pr["status"] != 0) | (f not in util.UNDEFINED_WHEN_NOT_FOUND))
+        assert not (shared_differs & ~flagged).any(), "the reference's answer depends on its object's history for a read that is not flagged"
+        assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == [cr["lookups"], cr["lv"], cr["ag"]]

@@ -39,10 +39,14 @@ def test_secondary_results_vs_reference_fixture(golden_index, golden_reads, gold
         finally:
             a.close()
         key = "%s_%s_" % (name, tag)
-        exclude = z[key + "unstable"] | (prim["reserved"] != 0)
-        assert int(exclude.sum()) <= 2 + n // 100
-        problems = util.compare_results(z[key + "primary"], prim, "primary", exclude=exclude)
-        problems += compare_secondary(z[key + "secondary"], z[key + "nsec"], sec, nsec, exclude)
+        # every read, none excluded: the expectation is the fresh-object reference (util.with_fresh_overrides)
+        e_prim, patched = util.with_fresh_overrides(z[key + "primary"], "sec_" + key + "primary")
+        e_sec, p2 = util.with_fresh_overrides(z[key + "secondary"], "sec_" + key + "secondary")
+        e_nsec, p3 = util.with_fresh_overrides(z[key + "nsec"], "sec_" + key + "nsec")
+        moved = z[key + "unstable"].copy(); moved[patched] = True; moved[p2] = True; moved[p3] = True
+        assert not (moved & (prim["reserved"] == 0)).any(), "reference-unstable read not flagged"
+        problems = util.compare_results(e_prim, prim, "primary")
+        problems += compare_secondary(e_sec, e_nsec, sec, nsec, np.zeros(n, bool))
         assert not problems, (name, problems)
         assert int(nsec.sum()) > 0
 

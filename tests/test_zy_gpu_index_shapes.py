@@ -28,20 +28,18 @@ def align_and_compare(tmp, seed_len, large, n_reads, genome_bases=400_000):
     ri = ref.RefIndex(d)
     p = abi.default_params(max_read_len=160, max_k=8)
     rd = synth.make_reads(5, g, n_reads, 150, sub=0.015, ins=0.002, dele=0.002, n_frac=0.0005)
-    pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
+    with ref.fresh_objects():           # the reference's answer as a function of the read alone: every read is compared
+        pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
     a = BaseAligner(ix, p)
     try:
         pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"])
         c = a.counters()
     finally:
         a.close()
-    flagged = pg["reserved"] != 0
-    assert flagged.sum() <= 2 + 0.005 * len(pg)
     assert (pr["status"] != 0).sum() > 0.9 * n_reads
-    problems = util.compare_results(pr, pg, exclude=flagged)
+    problems = util.compare_results(pr, pg)
     assert not problems, problems
-    if not flagged.any():
-        assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == [cr["lookups"], cr["lv"], cr["ag"]]
+    assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == [cr["lookups"], cr["lv"], cr["ag"]]
 
 
 @pytest.mark.gpu
@@ -75,21 +73,19 @@ def option_workload(tmp, n_reads):
 def check_option_set(ix, ri, rd, kw):
     from snap_amd.aligner import BaseAligner
     p = abi.default_params(max_read_len=160, **kw)
-    pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
+    with ref.fresh_objects():
+        pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
     a = BaseAligner(ix, p)
     try:
         pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"]); c = a.counters()
     finally:
         a.close()
-    flagged = pg["reserved"] != 0
-    assert flagged.sum() <= 2 + 0.005 * len(pg)
-    problems = util.compare_results(pr, pg, exclude=flagged)
-    assert (ar["status"] == ag["status"])[~flagged].all()
-    sel = (ar["status"] != 0) & ~flagged
+    problems = util.compare_results(pr, pg)
+    assert (ar["status"] == ag["status"]).all()
+    sel = ar["status"] != 0
     problems += util.compare_results(ar[sel], ag[sel], "firstALT")
     assert not problems, (kw, problems)
-    if not flagged.any():
-        assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == [cr["lookups"], cr["lv"], cr["ag"]], kw
+    assert [c["n_hash_table_lookups"], c["n_lv_locations"], c["n_ag_locations"]] == [cr["lookups"], cr["lv"], cr["ag"]], kw
 
 
 @pytest.mark.gpu
@@ -121,15 +117,14 @@ def test_paired_option_sets_vs_live_reference(tmp_path):
     pr = hard_pairs(31, g, 600, 150, insert_mean=380)
     for kw, pkw in PAIRED_OPTION_SETS:
         p = abi.default_params(max_read_len=160, **kw); pp = abi.default_paired_params(**pkw)
-        prim, alt, cnt, _ = ri.align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=1, stage=0)
+        with ref.fresh_objects():
+            prim, alt, cnt, _ = ri.align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=max(1, os.cpu_count() or 1), stage=0)
         a = ChimericPairedEndAligner(ix, p, pp)
         try:
             got, galt = a.align(pr["bases"], pr["quals"], pr["offsets"])
         finally:
             a.close()
-        flagged = got["reserved"] != 0
-        assert flagged.sum() <= 2 + got.size // 50
-        bad = compare_paired(prim, got, verbose=3, exclude=flagged)
+        bad = compare_paired(prim, got, verbose=3)
         assert not bad.any(), (kw, pkw, int(bad.sum()))
 
 
@@ -149,13 +144,14 @@ def test_read_length_boundaries_and_paired_index_shapes_vs_live_reference(tmp_pa
     for L, mk, mrl in ((50, 4, 64), (63, 6, 64), (64, 6, 64), (65, 8, 128), (191, 12, 192), (192, 12, 192), (193, 12, 256), (300, 20, 320), (400, 27, 400)):
         rd = synth.make_reads(100 + L, g, 1500, L, sub=0.02, ins=0.004, dele=0.004, n_frac=0.001)
         p = abi.default_params(max_k=mk, max_read_len=mrl)
-        pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
+        with ref.fresh_objects():
+            pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
         a = BaseAligner(ix, p)
         try:
             pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"])
         finally:
             a.close()
-        problems = util.compare_results(pr, pg, exclude=pg["reserved"] != 0)
+        problems = util.compare_results(pr, pg)
         assert not problems, (L, problems)
     for seed_len, large in ((24, False), (22, True)):                      # the paired-end hit sets over other key sizes / table layouts
         dd = str(tmp_path / ("idx%d%d" % (seed_len, large)))
@@ -163,11 +159,12 @@ def test_read_length_boundaries_and_paired_index_shapes_vs_live_reference(tmp_pa
         ixp = GenomeIndex.load_from_directory(dd); rip = ref.RefIndex(dd)
         prs = hard_pairs(33, g, 600, 150, insert_mean=380)
         p = abi.default_params(max_read_len=160); pp = abi.default_paired_params()
-        prim, alt, cnt, _ = rip.align_paired(p, pp, prs["bases"], prs["quals"], prs["offsets"], threads=1, stage=0)
+        with ref.fresh_objects():
+            prim, alt, cnt, _ = rip.align_paired(p, pp, prs["bases"], prs["quals"], prs["offsets"], threads=max(1, os.cpu_count() or 1), stage=0)
         a = ChimericPairedEndAligner(ixp, p, pp)
         try:
             got, galt = a.align(prs["bases"], prs["quals"], prs["offsets"])
         finally:
             a.close()
-        bad = compare_paired(prim, got, verbose=3, exclude=(got["reserved"] != 0))
+        bad = compare_paired(prim, got, verbose=3)
         assert not bad.any(), (seed_len, large, int(bad.sum()))
