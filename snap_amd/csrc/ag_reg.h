@@ -63,7 +63,8 @@ struct AGPos {
     __device__ __forceinline__ bool valid() const { return (w >> 24) & 1; }
 };
 
-template <int AGC, bool BANDED, typename PSeq, typename TSeq, typename QSeq>
+// EXACT: see ag_win.h / ag.h -- cells at the reference's own byte addresses in a traceback array that persists over the calls of a read.
+template <int AGC, bool BANDED, bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_compute_reg(
     int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
@@ -77,7 +78,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     const int gap_open = prm.gap_open + prm.gap_extend, gap_ext = prm.gap_extend;
     const int tot = num_seg * seg_len;                  // positions that exist in the striped layout
     const int nch = (tot + 63) >> 6;
-    const int row_stride = nch * 64;
+    const int row_stride = EXACT ? tot : nch * 64;      // EXACT: numVec * numSeg * 8 bytes per row, as in the reference
     // LDS scratch of the lazy-F rounds: F leaving each of the 8 stripes in the first pass, and one "some lane of vector k
     // continues" tag per vector (tags instead of a bitmap: no clearing, no atomics)
     int *lds_end = (int *)lds_rows + 2;                  // [8]
@@ -265,7 +266,10 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
         // ---------------- traceback bytes, row max, bookkeeping
         uint8_t *bt_row = bt_scratch + (size_t)i * row_stride;
 #pragma unroll
-        for (int c = 0; c < AGC; c++) if (c >= row_c_lo && c <= row_c_hi && did[c]) bt_row[c * 64 + lane] = (uint8_t)btr[c];
+        for (int c = 0; c < AGC; c++) if (c >= row_c_lo && c <= row_c_hi && did[c]) {
+            if constexpr (EXACT) store_byte_sbase(bt_row, (uint32_t)((pos[c].j() * num_vec + pos[c].k()) * 8 + pos[c].l()), (uint32_t)btr[c]);
+            else store_byte_sbase(bt_row, (uint32_t)(c * 64 + lane), (uint32_t)btr[c]);
+        }
         const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
 
         if (!BANDED || band_end == pattern_len - 1) {
@@ -335,7 +339,14 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
                 int cj = ct / seg_len, ck = (ct - cj * seg_len) % num_vec;
                 computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
             }
-            int cell = computed ? (int)bt_scratch[(size_t)rt * row_stride + ct] : 0;
+            int cell;
+            if constexpr (EXACT) {
+                int vi = 0, li = 0;
+                if (ok) { const int cj = ct / seg_len, cr = ct - cj * seg_len; vi = cj * num_vec + cr % num_vec; li = cr / num_vec; }
+                cell = ok ? (int)bt_scratch[(size_t)rt * row_stride + (size_t)(vi * 8 + li)] : 0;
+            } else {
+                cell = computed ? (int)bt_scratch[(size_t)rt * row_stride + ct] : 0;
+            }
             int pbyte = ok ? (int)P(ct) : 0, tbyte = ok ? (int)T(rt) : 0, qbyte = ok ? (int)Q(ct) : 0;
             int info = cell | ((ok && !computed) ? 0x100 : 0) | ((pbyte != tbyte) ? 0x200 : 0) | (qbyte << 16);
             int t = 0;

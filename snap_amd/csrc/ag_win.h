@@ -18,7 +18,10 @@
 #pragma once
 #include "ag_reg.h"
 
-template <typename PSeq, typename TSeq, typename QSeq>
+// EXACT (replay of flagged reads, ag.h): bt_scratch_in is the wave's image of one reference object's traceback array; cells go where the
+// reference puts them -- byte (row * numVec * numSeg + vector) * 8 + SSE element -- only evaluated cells are written, and the traceback
+// reads whatever the array holds.
+template <bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_banded_win(
     int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
@@ -47,6 +50,8 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     const int rr = lane - segsel * seg_len;
     const int l = rr / num_vec, k = rr - l * num_vec;
     const bool is_x_lane = segsel == 1 && l == 0;                // stripe 0 of the window's second segment: where the F carried over enters
+    const int nv_tot8 = num_vec * num_seg * 8;                   // EXACT: bytes per row of the reference's array
+    const int flat_lane = segsel * seg_len + k * 8 + l;          // EXACT: byte of this lane's cell inside the window's two segments
 
     // value of the reference's first-row H at position p, incl. the stale scoreFirstRow[] inheritance
     auto first_row = [&](int p) -> int {
@@ -262,7 +267,15 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             }
         }
 
-        bt_scratch[(size_t)i * 64 + lane] = (uint8_t)btr;       // (lanes outside the band write 0; the traceback never reads them)
+        // (uniform row pointer + zero-extended 32-bit lane offset: the form that selects the SGPR-base store; with a sign-extended
+        //  lane the address lives in a VGPR pair, which the 80-VGPR build spills and reloads -- with a vmcnt(0) wait -- every row)
+        if constexpr (EXACT) {
+            uint8_t *rowp = bt_scratch + ((size_t)i * (size_t)nv_tot8 + (size_t)(jbase * seg_len));
+            if (did) store_byte_sbase(rowp, (uint32_t)flat_lane, (uint32_t)btr);
+        } else {
+            uint8_t *rowp = bt_scratch + (size_t)i * 64;
+            store_byte_sbase(rowp, (uint32_t)lane, (uint32_t)btr);      // (lanes outside the band write 0; the traceback never reads them)
+        }
         const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
         if (band_end == pattern_len - 1) {
             int gscore = pattern_len - 1 >= wbase ? __builtin_amdgcn_readlane(Hm, pattern_len - 1 >= wbase ? pattern_len - 1 - wbase : 0) : gl_m;
@@ -323,7 +336,14 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
                 wb = (bb / seg_len) * seg_len;
             }
-            int cell = computed ? (int)bt_scratch[(size_t)rt * 64 + (ct - wb)] : 0;
+            int cell;
+            if constexpr (EXACT) {
+                int vi = 0, li = 0;
+                if (ok) { const int cj = ct / seg_len, cr = ct - cj * seg_len; vi = cj * num_vec + cr % num_vec; li = cr / num_vec; }
+                cell = ok ? (int)bt_scratch[(size_t)rt * nv_tot8 + (size_t)(vi * 8 + li)] : 0;
+            } else {
+                cell = computed ? (int)bt_scratch[(size_t)rt * 64 + (ct - wb)] : 0;
+            }
             int pbyte = ok ? (int)P(ct) : 0, tbyte = ok ? (int)T(rt) : 0, qbyte = ok ? (int)Q(ct) : 0;
             int info = cell | ((ok && !computed) ? 0x100 : 0) | ((pbyte != tbyte) ? 0x200 : 0) | (qbyte << 16);
             for (int t = 0; t < WAVE && row >= 0 && col >= 0; t++) {
@@ -370,7 +390,7 @@ static __device__ __forceinline__ AGResult ag_dispatch(
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
 {
-    if constexpr (AGC > 0 && !EXACT) {
+    if constexpr (AGC > 0) {
         AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
         res.match_probability = 0.0; res.stale_reads = 0;
         int ww = w > 126 ? 126 : w;
@@ -378,20 +398,21 @@ static __device__ __forceinline__ AGResult ag_dispatch(
         int num_vec, seg_len, num_seg;
         ag_dims(banded, pattern_len, ww, &num_vec, &seg_len, &num_seg);
         if (num_seg * seg_len > 64 * AGC || num_vec > 1023 || num_seg > 255 ||
-            (size_t)text_len * (size_t)(((num_seg * seg_len + 63) >> 6) * 64) > ag_scratch_bytes(RL)) {
+            (size_t)text_len * (size_t)(((num_seg * seg_len + 63) >> 6) * 64) > ag_scratch_bytes(RL) ||
+            (EXACT && (size_t)text_len * (size_t)(num_seg * seg_len) > ag_scratch_bytes(RL))) {
             __builtin_trap();                                             // host sizing bug: fail loudly
         }
         if (banded && 2 * seg_len <= 64)        // the band's two segments fit one wavefront: sliding-window form
-            return ag_banded_win(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                 lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+            return ag_banded_win<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                        lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
         if (banded)
-            return ag_compute_reg<AGC, true>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                             lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+            return ag_compute_reg<AGC, true, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                                    lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
         if (num_seg * seg_len <= 64)            // short pattern (e.g. the read's head before an early seed): one chunk, no chunk loops
-            return ag_compute_reg<1, false>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                            lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
-        return ag_compute_reg<AGC, false>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                          lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+            return ag_compute_reg<1, false, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                                   lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+        return ag_compute_reg<AGC, false, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                                 lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
     } else {
         return ag_compute<EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
                                  lds_rows, bt_scratch, RL, tab);

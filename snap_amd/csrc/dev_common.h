@@ -86,6 +86,18 @@ static __device__ __forceinline__ uint64_t first_u64(uint64_t v) {
     uint32_t lo = first_u32((uint32_t)v), hi = first_u32((uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
+// One byte per lane to ubase[voff]: ubase wave-uniform, voff a 32-bit per-lane offset.  Spelled as the SGPR-base form of the store
+// because the compiler, left alone, hoists "base + lane" into a 64-bit VGPR pair -- which the 80-VGPR builds spill, so that every row of
+// the affine-gap loop reloaded it from scratch and waited on vmcnt(0) (i.e. on the previous row's store as well) before it could store.
+static __device__ __forceinline__ void store_byte_sbase(uint8_t *ubase, uint32_t voff, uint32_t val) {
+#ifdef SNAPGPU_WAVE_EMU
+    ubase[voff] = (uint8_t)val;
+#else
+    const uint64_t b = first_u64((uint64_t)(uintptr_t)ubase);
+    asm volatile("global_store_byte %0, %1, %2" : : "v"(voff), "v"(val), "s"(b) : "memory");
+#endif
+}
+
 static __device__ __forceinline__ double first_f64(double v) {
     return __longlong_as_double((long long)first_u64((uint64_t)__double_as_longlong(v)));
 }

@@ -34,7 +34,8 @@ void snapgpu_launch_single_sec_3(const AlignArgs *a, uint32_t blocks, size_t lds
 void snapgpu_launch_single_sec_4(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_sec_6(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_sec_0(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
-void snapgpu_launch_single_exact(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_exact_3(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_exact_0(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 }
 
 static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }

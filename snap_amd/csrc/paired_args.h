@@ -61,6 +61,8 @@ void snapgpu_launch_paired_sec_0(const PairedArgs *a, uint32_t blocks, size_t ld
 void snapgpu_launch_pair_order(const DevIndex *ix, const uint8_t *bases, const uint64_t *offsets, uint32_t n_pairs, uint32_t max_big_hits,
                                uint32_t *bucket, uint32_t *hist, uint32_t *order, unsigned long long *counters, uint32_t blocks, hipStream_t s);
 void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale, hipStream_t s);
-void snapgpu_launch_paired_exact(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
-void snapgpu_launch_paired_sec_exact(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_paired_exact_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_paired_exact_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_paired_sec_exact_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_paired_sec_exact_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 }

@@ -40,16 +40,16 @@ extern "C" void snapgpu_launch_pair_order(const DevIndex *ix, const uint8_t *bas
 }
 #endif
 
-#if PAIRED_AGC == 0     // exact replay of flagged pairs (paired_args.h: PairedArgs::persist): always the layout-literal affine-gap form
+#if PAIRED_AGC == 0 || PAIRED_AGC == 3     // exact replay of flagged pairs (paired_args.h: PairedArgs::persist): the 192-position register variant, or the LDS form
 #ifdef PAIRED_SEC
-extern "C" void snapgpu_launch_paired_sec_exact(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+extern "C" void PE_CAT(snapgpu_launch_paired_sec_exact_, PAIRED_AGC)(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_align_paired<0, true, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
+    hipLaunchKernelGGL((k_align_paired<PAIRED_AGC, true, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
 }
 #else
-extern "C" void snapgpu_launch_paired_exact(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+extern "C" void PE_CAT(snapgpu_launch_paired_exact_, PAIRED_AGC)(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_align_paired<0, false, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
+    hipLaunchKernelGGL((k_align_paired<PAIRED_AGC, false, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
 }
 #endif
 #endif

@@ -1334,7 +1334,8 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
         AlignArgs x = a;
         x.flag_list = nullptr; x.flag_count = nullptr; x.remap = ctx->d_flag_list; x.n_remap = ctx->d_work + 4; x.work_counter = ctx->d_work + 3;
         x.persist = ctx->d_exact_persist; x.persist_stride = ctx->exact_persist_stride;
-        snapgpu_launch_single_exact(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
+        if (ctx->ag_variant == 3) snapgpu_launch_single_exact_3(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
+        else snapgpu_launch_single_exact_0(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
         HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     }
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
@@ -1775,7 +1776,8 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
             x.persist = ctx->d_pexact_persist; x.persist_stride = ctx->pexact_persist_stride;
             uint32_t slots = so ? ctx->p_sec_big_slots : ctx->p_big_slots;
             if (slots > ctx->pexact_slots) slots = ctx->pexact_slots;
-            if (so) snapgpu_launch_paired_sec_exact(&x, slots / 4, lds, s); else snapgpu_launch_paired_exact(&x, slots / 4, lds, s);
+            if (ctx->p_ag_variant == 3) { if (so) snapgpu_launch_paired_sec_exact_3(&x, slots / 4, lds, s); else snapgpu_launch_paired_exact_3(&x, slots / 4, lds, s); }
+            else { if (so) snapgpu_launch_paired_sec_exact_0(&x, slots / 4, lds, s); else snapgpu_launch_paired_exact_0(&x, slots / 4, lds, s); }
         }
     }
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
