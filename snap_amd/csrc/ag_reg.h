@@ -79,6 +79,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     const int tot = num_seg * seg_len;                  // positions that exist in the striped layout
     const int nch = (tot + 63) >> 6;
     const int row_stride = EXACT ? tot : nch * 64;      // EXACT: numVec * numSeg * 8 bytes per row, as in the reference
+    const BtSink sink = bt_sink(bt_scratch);
     // LDS scratch of the lazy-F rounds: F leaving each of the 8 stripes in the first pass, and one "some lane of vector k
     // continues" tag per vector (tags instead of a bitmap: no clearing, no atomics)
     int *lds_end = (int *)lds_rows + 2;                  // [8]
@@ -264,11 +265,11 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
         }
 
         // ---------------- traceback bytes, row max, bookkeeping
-        uint8_t *bt_row = bt_scratch + (size_t)i * row_stride;
+
 #pragma unroll
         for (int c = 0; c < AGC; c++) if (c >= row_c_lo && c <= row_c_hi && did[c]) {
-            if constexpr (EXACT) store_byte_sbase(bt_row, (uint32_t)((pos[c].j() * num_vec + pos[c].k()) * 8 + pos[c].l()), (uint32_t)btr[c]);
-            else store_byte_sbase(bt_row, (uint32_t)(c * 64 + lane), (uint32_t)btr[c]);
+            if constexpr (EXACT) bt_store(sink, (uint32_t)(i * row_stride), (uint32_t)((pos[c].j() * num_vec + pos[c].k()) * 8 + pos[c].l()), (uint32_t)btr[c]);
+            else bt_store(sink, (uint32_t)(i * row_stride), (uint32_t)(c * 64 + lane), (uint32_t)btr[c]);
         }
         const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
 

@@ -50,6 +50,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     const int rr = lane - segsel * seg_len;
     const int l = rr / num_vec, k = rr - l * num_vec;
     const bool is_x_lane = segsel == 1 && l == 0;                // stripe 0 of the window's second segment: where the F carried over enters
+    const BtSink sink = bt_sink(bt_scratch);
     const int nv_tot8 = num_vec * num_seg * 8;                   // EXACT: bytes per row of the reference's array
     const int flat_lane = segsel * seg_len + k * 8 + l;          // EXACT: byte of this lane's cell inside the window's two segments
 
@@ -270,11 +271,9 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         // (uniform row pointer + zero-extended 32-bit lane offset: the form that selects the SGPR-base store; with a sign-extended
         //  lane the address lives in a VGPR pair, which the 80-VGPR build spills and reloads -- with a vmcnt(0) wait -- every row)
         if constexpr (EXACT) {
-            uint8_t *rowp = bt_scratch + ((size_t)i * (size_t)nv_tot8 + (size_t)(jbase * seg_len));
-            if (did) store_byte_sbase(rowp, (uint32_t)flat_lane, (uint32_t)btr);
+            if (did) bt_store(sink, (uint32_t)(i * nv_tot8 + jbase * seg_len), (uint32_t)flat_lane, (uint32_t)btr);
         } else {
-            uint8_t *rowp = bt_scratch + (size_t)i * 64;
-            store_byte_sbase(rowp, (uint32_t)lane, (uint32_t)btr);      // (lanes outside the band write 0; the traceback never reads them)
+            bt_store(sink, (uint32_t)i * 64u, (uint32_t)lane, (uint32_t)btr);       // (lanes outside the band write 0; the traceback never reads them)
         }
         const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
         if (band_end == pattern_len - 1) {

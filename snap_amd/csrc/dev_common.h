@@ -44,6 +44,10 @@ struct DevIndex {
     uint32_t n_hash_tables;
     uint32_t chromosome_padding;
     uint32_t genome_pad;
+    // device-native hash layout (bucket.h); bucket_blob == NULL: this index shape keeps the reference's slot walk
+    const uint8_t  *bucket_blob;
+    const uint64_t *bucket_offset;  // [n_hash_tables] byte offset of table t's buckets
+    const uint64_t *n_buckets;      // [n_hash_tables]
 };
 
 // Probability tables, computed on the host with host libm (LandauVishkin.cpp:716-763,
@@ -86,15 +90,33 @@ static __device__ __forceinline__ uint64_t first_u64(uint64_t v) {
     uint32_t lo = first_u32((uint32_t)v), hi = first_u32((uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
-// One byte per lane to ubase[voff]: ubase wave-uniform, voff a 32-bit per-lane offset.  Spelled as the SGPR-base form of the store
-// because the compiler, left alone, hoists "base + lane" into a 64-bit VGPR pair -- which the 80-VGPR builds spill, so that every row of
-// the affine-gap loop reloaded it from scratch and waited on vmcnt(0) (i.e. on the previous row's store as well) before it could store.
-static __device__ __forceinline__ void store_byte_sbase(uint8_t *ubase, uint32_t voff, uint32_t val) {
-#ifdef SNAPGPU_WAVE_EMU
-    ubase[voff] = (uint8_t)val;
+// Byte stores of the affine-gap traceback rows: a wave-uniform slab, a wave-uniform row offset and a 32-bit per-lane offset.  Spelled as a
+// raw buffer store (descriptor + scalar offset in SGPRs, lane offset in one VGPR) because the compiler, left with a plain pointer, hoists
+// "base + lane" into a 64-bit VGPR pair -- which the 80-VGPR builds spill, so that every row of the affine-gap loop reloaded it from scratch
+// and waited on vmcnt(0) (i.e. on the previous row's store as well) before it could store.  (An inline-asm global_store with an SGPR base
+// faulted on hardware: nothing pads the wait states between such a store and the next write of its address registers.)
+struct BtSink {
+#if defined(SNAPGPU_WAVE_EMU)
+    uint8_t *base;
 #else
-    const uint64_t b = first_u64((uint64_t)(uintptr_t)ubase);
-    asm volatile("global_store_byte %0, %1, %2" : : "v"(voff), "v"(val), "s"(b) : "memory");
+    __amdgpu_buffer_rsrc_t rsrc;
+#endif
+};
+static __device__ __forceinline__ BtSink bt_sink(uint8_t *ubase) {
+    BtSink s;
+#if defined(SNAPGPU_WAVE_EMU)
+    s.base = ubase;
+#else
+    s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)first_u64((uint64_t)(uintptr_t)ubase), (short)0, 0x7ffff000, 0x00020000);
+#endif
+    return s;
+}
+// sink[uoff + voff] = val   (uoff wave-uniform, voff per lane)
+static __device__ __forceinline__ void bt_store(const BtSink &s, uint32_t uoff, uint32_t voff, uint32_t val) {
+#if defined(SNAPGPU_WAVE_EMU)
+    s.base[(size_t)uoff + voff] = (uint8_t)val;
+#else
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)val, s.rsrc, (int)voff, (int)first_u32(uoff), 0);
 #endif
 }
 

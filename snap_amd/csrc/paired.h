@@ -131,6 +131,20 @@ struct PESet {                         // ScoreSet, .h:614-700
     int32_t  best_pair_score, best_pair_ag;
 };
 
+// Phase 4 of a heavy pair, shared with idle wavefronts (paired_dev.h: the help slots).  The two affine-gap problems of a Phase-4 candidate
+// depend on the other candidates only through the running score limit, so a candidate can be scored SPECULATIVELY under a predicted limit
+// by any wave that holds the pair's reads; PEHelpSpec keeps what scoreLocationWithAffineGap returned for each mate together with the limit
+// argument the call was made with.  The owner then walks the candidates in the reference's order exactly as before and, wherever the limit it
+// arrives with equals the one a speculative call used, takes the stored answer instead of computing it again -- same inputs, same answer;
+// anything else it computes itself.  FP64 sums and score-set updates happen only in that ordered walk.
+struct PEHelpSpec {
+    int32_t  lim[2];                   // limit argument of the call for mate r; PE_SPEC_NONE: no call was made
+    int32_t  score[2], g_off[2], cb[2], ca[2], ag[2], span[2];
+    uint32_t stale[2], n_ag[2];
+    double   mp[2];
+};
+#define PE_SPEC_NONE (-0x7fffffff)
+
 struct PECounters { uint64_t lv, ag, lookups, hits, overflow_lists, lv_ref_bytes; uint64_t cyc_lookup, cyc_intersect, cyc_lv, cyc_ag, cyc_single, cyc_total; };   // cycles: PL::clock()
 
 struct PEShared {                      // cold wave-uniform state (LDS on the device)
@@ -178,6 +192,9 @@ struct PairedCore {
     uint32_t popular[2];
     int more, fewer;                   // readWithMoreHits / readWithFewerHits
     uint32_t stale, overflow;
+    bool spec_mode = false;            // speculative scoring of Phase-4 candidates: work counters are left to the ordered walk
+    uint32_t spec_n_ag = 0;
+    uint32_t help_min = 0xffffffffu;   // Phase-4 lists at least this long are offered to idle waves (PL::HELP only)
 
     PE_FN PairedCore(PL &pl_, const PECfg &c) : pl(pl_), cfg(c) {}
 
@@ -542,7 +559,7 @@ struct PairedCore {
             AGOut a = pl.ag(banded, +1, R + tail, Qd + tail, plen, data + tail, (int)(glen - tail), limit, rl, dir != 0, clip);
             stale += (uint32_t)a.stale;
             ag1 = a.ag_score + (sl - rl); text_rem = a.text_offset; *clip_after = a.pattern_offset; score1 = a.n_edits; mp1 = a.mp;
-            sh->cnt.ag++;
+            if (spec_mode) spec_n_ag++; else sh->cnt.ag++;
         }
         if (score1 != -1) {
             if (seed_offset != 0) {
@@ -1159,10 +1176,17 @@ struct PairedCore {
             // qsort(compareByScore) is glibc's stable merge sort here: visit candidates by (pair score, insertion index).
             // pl.sort_candidates writes that order (a stable counting sort on the key kept in `reserved`) to agc_order.
             pl.sort_candidates(agc, n_agc, agc_order);
+            PEHelpSpec *spec = nullptr;
+            if constexpr (PL::HELP) {
+                // a long list: every candidate is scored speculatively under the limit the walk starts with -- by this wave and by
+                // whichever waves are idle -- before the ordered walk below consumes the answers (struct PEHelpSpec)
+                if (n_agc >= help_min) spec = pl.help_phase4(*this, n_agc, PL::i32(limit), best_pair_score, skip);
+            }
             for (uint32_t t = 0; t < n_agc; t++) {
                 snapgpu_paired_result *e = &agc[ld(agc_order[t])];
-                phase4_candidate(e, limit, best_pair_score, skip, g_off);
+                phase4_candidate(e, limit, best_pair_score, skip, g_off, spec ? &spec[t] : nullptr);
             }
+            if constexpr (PL::HELP) { if (spec) pl.help_done(); }
         }
 
         const bool emit_all = !cfg.alt_aware || N.best_pair_score > A.best_pair_score + cfg.max_gap_alt;
@@ -1321,7 +1345,60 @@ struct PairedCore {
     }
 
     // body of the candidate loop of alignAffineGap (:2736-2823)
-    PE_FN void phase4_candidate(snapgpu_paired_result *e, int &limit, int best_pair_score, const bool skip[2], int g_off[2]) {
+    // One candidate scored ahead of the ordered walk: the limit bookkeeping of phase4_candidate up to its two scoreLocationWithAffineGap
+    // calls, entered with limit `L`; nothing but *sp is written (the candidate record, the score sets and the work counters stay as they are).
+    PE_FN void spec_candidate(const snapgpu_paired_result *e, PEHelpSpec *sp, int L, int best_pair_score, bool skip0, bool skip1) {
+        int limit = L;
+        int s0 = ld(e->score[0]), s1 = ld(e->score[1]);
+        const int lv_pair_score = s0 + s1;
+        const int lv_pair_indels = ld(e->lv_indels[0]) + ld(e->lv_indels[1]);
+        const bool gl0 = ld(e->used_gapless_clipping[0]) != 0, gl1 = ld(e->used_gapless_clipping[1]) != 0;
+        int lim0 = PE_SPEC_NONE, lim1 = PE_SPEC_NONE;
+        int o_s[2] = {0, 0}, o_g[2] = {0, 0}, o_cb[2] = {0, 0}, o_ca[2] = {0, 0}, o_ag[2] = {0, 0}, o_span[2] = {0, 0};
+        uint32_t o_stale[2] = {0, 0}, o_nag[2] = {0, 0};
+        double o_mp[2] = {0.0, 0.0};
+        if (gl0 || gl1) limit = PE_MAXK1;
+        else if (lv_pair_score > best_pair_score + cfg.extra_depth && lv_pair_indels > 1) limit = cfg.max_k + cfg.extra_depth;
+        if (lv_pair_score <= best_pair_score + cfg.extra_depth || lv_pair_indels > 1 || gl0 || gl1) {
+            const uint32_t stale_keep = stale;
+            const bool mode_keep = spec_mode;
+            spec_mode = true;
+            if (!skip0) {
+                if (!gl0) limit = limit > s0 ? limit : s0;
+                int cb = ld(e->bases_clipped_before[0]), ca = ld(e->bases_clipped_after[0]), span = 0, ag = ld(e->ag_score[0]), off = 0;
+                double mp = ld(e->match_probability[0]);
+                lim0 = PL::i32(limit);
+                stale = 0; spec_n_ag = 0;
+                score_ag(0, ld(e->direction[0]), ld(e->orig_location[0]), ld(e->seed_offset[0]), lim0, &s0, &mp, &off, &cb, &ca, &ag, &span);
+                s0 = PL::i32(s0);
+                o_s[0] = s0; o_g[0] = PL::i32(off); o_cb[0] = PL::i32(cb); o_ca[0] = PL::i32(ca); o_ag[0] = PL::i32(ag); o_span[0] = PL::i32(span);
+                o_mp[0] = PL::f64(mp); o_stale[0] = stale; o_nag[0] = spec_n_ag;
+            }
+            if (s0 != -1 && s0 <= PE_MAXK1 && !skip1) {
+                limit = limit - s0;
+                if (!gl1) limit = limit > s1 ? limit : s1;
+                int cb = ld(e->bases_clipped_before[1]), ca = ld(e->bases_clipped_after[1]), span = 0, ag = ld(e->ag_score[1]), off = 0;
+                double mp = ld(e->match_probability[1]);
+                lim1 = PL::i32(limit);
+                stale = 0; spec_n_ag = 0;
+                score_ag(1, ld(e->direction[1]), ld(e->orig_location[1]), ld(e->seed_offset[1]), lim1, &s1, &mp, &off, &cb, &ca, &ag, &span);
+                o_s[1] = PL::i32(s1); o_g[1] = PL::i32(off); o_cb[1] = PL::i32(cb); o_ca[1] = PL::i32(ca); o_ag[1] = PL::i32(ag); o_span[1] = PL::i32(span);
+                o_mp[1] = PL::f64(mp); o_stale[1] = stale; o_nag[1] = spec_n_ag;
+            }
+            stale = stale_keep; spec_mode = mode_keep;
+        }
+        if (PL::lane0()) {
+            for (int r = 0; r < 2; r++) {
+                sp->score[r] = o_s[r]; sp->g_off[r] = o_g[r]; sp->cb[r] = o_cb[r]; sp->ca[r] = o_ca[r]; sp->ag[r] = o_ag[r]; sp->span[r] = o_span[r];
+                sp->stale[r] = o_stale[r]; sp->n_ag[r] = o_nag[r]; sp->mp[r] = o_mp[r];
+            }
+            sp->lim[0] = lim0; sp->lim[1] = lim1;
+        }
+        PL::sync();
+    }
+
+    PE_FN void phase4_candidate(snapgpu_paired_result *e, int &limit, int best_pair_score, const bool skip[2], int g_off[2],
+                                const PEHelpSpec *sp = nullptr) {
         snapgpu_paired_result &res = sh->res;
         PESet &A = sh->all, &N = sh->non_alt;
         int s0 = ld(e->score[0]), s1 = ld(e->score[1]);
@@ -1341,7 +1418,12 @@ struct PairedCore {
             st(e->used_affine_gap_scoring[0], 1);
             if (!gl0) limit = limit > s0 ? limit : s0;
             int cb = ld(e->bases_clipped_before[0]), ca = ld(e->bases_clipped_after[0]), span = 0;
-            score_ag(0, ld(e->direction[0]), ld(e->orig_location[0]), ld(e->seed_offset[0]), PL::i32(limit), &s0, &mp0, &g_off[0], &cb, &ca, &ag0, &span);
+            if (sp != nullptr && ld(sp->lim[0]) == PL::i32(limit)) {      // scored ahead of time with exactly these arguments
+                s0 = ld(sp->score[0]); mp0 = ld(sp->mp[0]); g_off[0] = ld(sp->g_off[0]); cb = ld(sp->cb[0]); ca = ld(sp->ca[0]); ag0 = ld(sp->ag[0]);
+                span = ld(sp->span[0]); stale += ld(sp->stale[0]); sh->cnt.ag += ld(sp->n_ag[0]);
+            } else {
+                score_ag(0, ld(e->direction[0]), ld(e->orig_location[0]), ld(e->seed_offset[0]), PL::i32(limit), &s0, &mp0, &g_off[0], &cb, &ca, &ag0, &span);
+            }
             s0 = PL::i32(s0); mp0 = PL::f64(mp0);
             if (PL::lane0()) { e->score[0] = s0; e->match_probability[0] = mp0; e->bases_clipped_before[0] = cb; e->bases_clipped_after[0] = ca; e->ag_score[0] = ag0; e->ref_span[0] = span; }
             PL::sync();
@@ -1354,7 +1436,12 @@ struct PairedCore {
                 limit = limit - s0;
                 if (!gl1) limit = limit > s1 ? limit : s1;
                 int cb = ld(e->bases_clipped_before[1]), ca = ld(e->bases_clipped_after[1]), span = 0;
-                score_ag(1, ld(e->direction[1]), ld(e->orig_location[1]), ld(e->seed_offset[1]), PL::i32(limit), &s1, &mp1, &g_off[1], &cb, &ca, &ag1, &span);
+                if (sp != nullptr && ld(sp->lim[1]) == PL::i32(limit)) {
+                    s1 = ld(sp->score[1]); mp1 = ld(sp->mp[1]); g_off[1] = ld(sp->g_off[1]); cb = ld(sp->cb[1]); ca = ld(sp->ca[1]); ag1 = ld(sp->ag[1]);
+                    span = ld(sp->span[1]); stale += ld(sp->stale[1]); sh->cnt.ag += ld(sp->n_ag[1]);
+                } else {
+                    score_ag(1, ld(e->direction[1]), ld(e->orig_location[1]), ld(e->seed_offset[1]), PL::i32(limit), &s1, &mp1, &g_off[1], &cb, &ca, &ag1, &span);
+                }
                 s1 = PL::i32(s1); mp1 = PL::f64(mp1);
                 if (PL::lane0()) { e->score[1] = s1; e->match_probability[1] = mp1; e->bases_clipped_before[1] = cb; e->bases_clipped_after[1] = ca; e->ag_score[1] = ag1; e->ref_span[1] = span; }
                 PL::sync();

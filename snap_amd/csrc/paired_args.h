@@ -22,6 +22,21 @@ static __host__ __device__ __forceinline__ PairedLds paired_lds_layout(uint32_t 
     return L;
 }
 
+// A heavy pair's Phase 4 offered to idle wavefronts (paired.h: PEHelpSpec).  One slot per pair being helped; the owner publishes it, takes
+// chunks of candidates like everyone else, waits until all are scored and then walks the list in order.  Waves that have run out of pairs
+// poll the slots until every pair of the launch is done.  All cross-wave traffic goes through device-scope atomics on the slot plus a
+// __threadfence() between the data and the flag on both sides.
+struct PEHelpSlot {
+    uint32_t state;                    // 0 free, 3 being filled, 1 open, 2 closing (no new helpers)
+    uint32_t pair, n, next, done, helpers;
+    int32_t  limit, best;
+    uint32_t skip0, skip1, pad0, pad1;
+    const snapgpu_paired_result *agc;
+    const uint32_t *order;
+    PEHelpSpec *spec;
+};
+#define PE_HELP_CHUNK 4u
+
 struct PairedArgs {
     DevIndex ix;
     AlignCfg scfg;                     // the single-end aligner of the chimeric fallback
@@ -48,6 +63,8 @@ struct PairedArgs {
     snapgpu_single_result *single_secondary; uint32_t ssec_out_stride; uint32_t *n_single_secondary;      // [n * stride], [2n]
     // exact replay of pairs whose affine-gap traceback left the band (k_align_paired<0, SEC, true>): 4 x ag_scratch_bytes(RL) per wave slot
     uint8_t *persist; uint64_t persist_stride;
+    // Phase-4 help (paired_dev.h: PEHelpSlot): slots, one PEHelpSpec array of help_spec_cap entries per slot, the launch's done-pair counter
+    struct PEHelpSlot *help; uint32_t n_help; PEHelpSpec *help_spec; uint32_t help_spec_cap; uint32_t *help_done; uint32_t help_min;
 };
 
 

@@ -21,6 +21,68 @@ template <int AGC, bool SEC = false, bool EXACT = false>
 struct DevPL {
     Aligner<AGC, SEC, EXACT> *al;      // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
     uint8_t *ag_persist[2];
+    // Phase-4 help (not in the exact replay: there the affine-gap calls of a pair are ordered through the traceback arrays they share)
+    static const bool HELP = !EXACT;
+    PEHelpSlot *help; uint32_t n_help; PEHelpSpec *help_spec; uint32_t help_spec_cap;
+    uint32_t cur_pair; int my_slot;
+    static __device__ __forceinline__ uint32_t aload(uint32_t *p) { return first_u32(lane_id() == 0 ? atomicAdd(p, 0u) : 0u); }
+    static __device__ __forceinline__ void nap() {
+#ifdef SNAPGPU_WAVE_EMU
+        emu_yield();
+#else
+        __builtin_amdgcn_s_sleep(20);
+#endif
+    }
+    // chunks of the slot's candidates, scored speculatively by this wave (which holds the pair's reads) until none are left
+    template <class Core> __device__ __forceinline__ void help_work(Core &core, PEHelpSlot *slot) {
+        const uint32_t n = ld(slot->n);
+        const int L = ld(slot->limit), best = ld(slot->best);
+        const bool s0 = ld(slot->skip0) != 0, s1 = ld(slot->skip1) != 0;
+        const snapgpu_paired_result *agc = (const snapgpu_paired_result *)first_u64((uint64_t)(uintptr_t)slot->agc);
+        const uint32_t *order = (const uint32_t *)first_u64((uint64_t)(uintptr_t)slot->order);
+        PEHelpSpec *spec = (PEHelpSpec *)first_u64((uint64_t)(uintptr_t)slot->spec);
+        for (;;) {
+            uint32_t c0 = 0;
+            if (lane_id() == 0) c0 = atomicAdd(&slot->next, PE_HELP_CHUNK);
+            c0 = first_u32(c0);
+            if (c0 >= n) break;
+            const uint32_t c1 = c0 + PE_HELP_CHUNK < n ? c0 + PE_HELP_CHUNK : n;
+            for (uint32_t t = c0; t < c1; t++) core.spec_candidate(&agc[ld(order[t])], &spec[t], L, best, s0, s1);
+            __threadfence();
+            if (lane_id() == 0) atomicAdd(&slot->done, c1 - c0);
+        }
+    }
+    template <class Core> __device__ __forceinline__ PEHelpSpec *help_phase4(Core &core, uint32_t n, int limit, int best, const bool skip[2]) {
+        my_slot = -1;
+        if (help == nullptr || n > help_spec_cap) return nullptr;
+        int s = -1;
+        if (lane_id() == 0) {
+            for (uint32_t i = 0; i < n_help; i++) if (atomicCAS(&help[i].state, 0u, 3u) == 0u) { s = (int)i; break; }
+        }
+        s = (int)first_u32((uint32_t)s);
+        if (s < 0) return nullptr;                          // every slot is taken: this pair goes through its list alone
+        PEHelpSlot *slot = &help[s];
+        PEHelpSpec *spec = help_spec + (size_t)s * help_spec_cap;
+        if (lane_id() == 0) {
+            slot->pair = cur_pair; slot->n = n; slot->next = 0; slot->done = 0; slot->limit = limit; slot->best = best;
+            slot->skip0 = skip[0] ? 1u : 0u; slot->skip1 = skip[1] ? 1u : 0u;
+            slot->agc = core.agc; slot->order = core.agc_order; slot->spec = spec;
+            __threadfence();
+            atomicExch(&slot->state, 1u);
+        }
+        WAVE_SYNC();
+        my_slot = s;
+        help_work(core, slot);
+        while (aload(&slot->done) < n) nap();
+        if (lane_id() == 0) atomicExch(&slot->state, 2u);
+        while (aload(&slot->helpers) != 0u) nap();
+        __threadfence();
+        return spec;
+    }
+    __device__ __forceinline__ void help_done() {
+        if (my_slot >= 0 && lane_id() == 0) atomicExch(&help[my_slot].state, 0u);
+        my_slot = -1;
+    }
     const DevTables *tab;
     AGParams agp;
     uint32_t kmax_lv;                  // what the LV triangle was sized for
@@ -343,6 +405,8 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     DevPL<AGC, SEC, EXACT> pl;
     pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv;
     al.ag_persist[0] = al.ag_persist[1] = pl.ag_persist[0] = pl.ag_persist[1] = nullptr;
+    pl.help = EXACT ? nullptr : a.help; pl.n_help = a.n_help; pl.help_spec = a.help_spec; pl.help_spec_cap = a.help_spec_cap;
+    pl.cur_pair = 0; pl.my_slot = -1;
     if constexpr (EXACT) {
         uint8_t *pb = a.persist + (size_t)wave_slot * a.persist_stride;
         const size_t q = (size_t)(a.persist_stride / 4);
@@ -351,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     pl.agp = AGParams{a.scfg.match_reward, a.scfg.sub_penalty, a.scfg.gap_open, a.scfg.gap_extend, a.scfg.five_bonus, a.scfg.three_bonus};
 
     PairedCore<DevPL<AGC, SEC, EXACT>> core(pl, a.pcfg);
+    core.help_min = a.help_min;
     core.lk = (PELookup *)(my + PLd.lk);
     core.exhausted = (uint32_t *)(my + PLd.exhausted);
     core.miss = (uint32_t *)(my + PLd.miss);
@@ -377,18 +442,10 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     uint64_t n_done = 0;
 
     const uint32_t n_total = a.remap ? first_u32(*a.n_remap) : a.n_pairs;
-    while (true) {
-        uint32_t i = 0;
-        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
-        i = first_u32(i);
-        if (i >= n_total) break;
-        if (a.remap) i = first_u32(a.remap[i]);
-        if constexpr (EXACT) {          // newly constructed reference aligners: all four traceback arrays read as zero
-            wave_zero16(pl.ag_persist[0], (size_t)a.persist_stride);
-            WAVE_SYNC();
-        }
+    // both reads of pair i, both orientations, into this wave's LDS
+    auto load_pair = [&](uint32_t i) {
         for (int r = 0; r < 2; r++) {
-            const uint64_t b = first_u64(a.offsets[2 * i + r]), e = first_u64(a.offsets[2 * i + r + 1]);
+            const uint64_t b = first_u64(a.offsets[2 * (size_t)i + r]), e = first_u64(a.offsets[2 * (size_t)i + r + 1]);
             const int len = (int)(e - b);
             uint8_t *f = prd + (2 * r) * RL, *rc = prd + (2 * r + 1) * RL, *qf = pql + (2 * r) * RL, *qr = pql + (2 * r + 1) * RL;
             for (int j0 = 0; j0 < len; j0 += WAVE) {
@@ -403,6 +460,20 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
             core.read_len[r] = len;
             pl.g_bases[r] = a.bases + b; pl.g_quals[r] = a.quals + b; pl.g_len[r] = len;
         }
+        WAVE_SYNC();
+    };
+    while (true) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
+        i = first_u32(i);
+        if (i >= n_total) break;
+        if (a.remap) i = first_u32(a.remap[i]);
+        if constexpr (EXACT) {          // newly constructed reference aligners: all four traceback arrays read as zero
+            wave_zero16(pl.ag_persist[0], (size_t)a.persist_stride);
+            WAVE_SYNC();
+        }
+        load_pair(i);
+        pl.cur_pair = i;
         {   // zero both results (fields the reference leaves unset read as 0 here)
             uint32_t *z0 = (uint32_t *)&core.sh->res, *z1 = (uint32_t *)&core.sh->alt;
             const int nd = (int)(sizeof(snapgpu_paired_result) / 4);
@@ -441,6 +512,35 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         }
         WAVE_SYNC();
         n_done++;
+        if (!EXACT && a.help_done != nullptr && lane == 0) atomicAdd(a.help_done, 1u);
+    }
+    if constexpr (!EXACT) {
+        // Out of pairs: until every pair of the launch is done, score Phase-4 candidates of the pairs that asked for help.
+        if (a.help != nullptr && a.help_done != nullptr) {
+            for (;;) {
+                if (DevPL<AGC, SEC, EXACT>::aload(a.help_done) >= n_total) break;
+                bool any = false;
+                for (uint32_t s = 0; s < a.n_help; s++) {
+                    PEHelpSlot *slot = &a.help[s];
+                    // (every cross-wave read of the slot goes through an L2 atomic until the acquire fence below: a plain load may be
+                    //  served by this CU's L1 with what the slot held for an earlier pair)
+                    if (DevPL<AGC, SEC, EXACT>::aload(&slot->state) != 1u) continue;
+                    if (DevPL<AGC, SEC, EXACT>::aload(&slot->next) >= DevPL<AGC, SEC, EXACT>::aload(&slot->n)) continue;
+                    if (lane == 0) atomicAdd(&slot->helpers, 1u);
+                    if (DevPL<AGC, SEC, EXACT>::aload(&slot->state) == 1u) {
+                        __threadfence();
+                        load_pair(DevPL<AGC, SEC, EXACT>::aload(&slot->pair));
+                        pl.help_work(core, slot);
+                        any = true;
+                    }
+                    if (lane == 0) atomicSub(&slot->helpers, 1u);
+                }
+#ifdef SNAPGPU_WAVE_EMU
+                break;      // (emulator: the waves of a block run one after the other -- a wave that waits would keep the next from starting)
+#endif
+                if (!any) DevPL<AGC, SEC, EXACT>::nap();
+            }
+        }
     }
     if (lane == 0 && !EXACT) {          // (a replayed pair was already counted)
         if (!a.remap) atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));

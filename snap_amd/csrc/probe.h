@@ -16,6 +16,7 @@
 // dependent HBM round trips overlap.
 #pragma once
 #include "dev_common.h"
+#include "bucket.h"
 
 struct SeedBits {
     uint64_t bases;      // 2 bits/base, first base most significant (Seed.h:48)
@@ -80,9 +81,24 @@ static __device__ __forceinline__ uint32_t load_u32_bytes(const uint8_t *p) {
 // out[0] = forward, out[1] = reverse complement.
 static __device__ __forceinline__ void lookup_seed(const DevIndex &ix, const SeedBits &seed, HitList out[2]) {
     const int lane = lane_id();
+    const uint32_t key_bits = ix.key_bytes * 8;
+    uint32_t sub_entry[2]; bool have[2]; uint32_t sl[2];
+    if (ix.bucket_blob != nullptr) {
+        // device-native layout (bucket.h): lanes 0-7 read the forward key's bucket, lanes 8-15 the reverse complement's -- one line each
+        const int g = lane >> 3;
+        const uint64_t bases_g = g == 0 ? seed.bases : seed.rc;
+        const uint32_t key = (uint32_t)(bases_g & ((1ull << key_bits) - 1));
+        const uint32_t table = (uint32_t)(bases_g >> key_bits);
+        uint32_t lines = 0;
+        const uint32_t v = bucket_probe8(ix.bucket_blob, ix.bucket_offset, ix.n_buckets, table, key, g < 2, &lines);
+        for (int d = 0; d < 2; d++) {
+            sub_entry[d] = (uint32_t)__builtin_amdgcn_readlane((int)v, 8 * d);
+            have[d] = sub_entry[d] != BUCKET_INVALID;
+            sl[d] = 8u * (uint32_t)__builtin_amdgcn_readlane((int)lines, 8 * d);      // 8 dword pairs = 64 bytes per bucket read
+        }
+    } else {
     const int half = lane >> 5;          // which probe this lane works on
     const int sub = lane & 31;           // position within the probe sequence window
-    const uint32_t key_bits = ix.key_bytes * 8;
     const uint32_t value_count = ix.large ? 2u : 1u;
 
     // Which 2-bit strings get probed (GenomeIndex.cpp:2105-2155).
@@ -175,7 +191,7 @@ static __device__ __forceinline__ void lookup_seed(const DevIndex &ix, const See
     }
 
     // Hand each half's answer to the whole wave.
-    uint32_t fv[2][2]; bool fnd[2]; uint32_t sl[2];
+    uint32_t fv[2][2]; bool fnd[2];
     for (int p = 0; p < 2; p++) {
         int src = p << 5;
         fnd[p] = __shfl((int)found, src) != 0;
@@ -185,7 +201,6 @@ static __device__ __forceinline__ void lookup_seed(const DevIndex &ix, const See
     }
 
     // Map probe results to (forward, rc) sub-entries (GenomeIndex.cpp:2130-2153).
-    uint32_t sub_entry[2]; bool have[2];
     if (ix.large) {
         have[0] = have[1] = fnd[0];
         sub_entry[0] = looked_up_complement ? fv[0][1] : fv[0][0];
@@ -195,6 +210,7 @@ static __device__ __forceinline__ void lookup_seed(const DevIndex &ix, const See
         have[0] = fnd[0]; have[1] = fnd[1];
         sub_entry[0] = fv[0][0]; sub_entry[1] = fv[1][0];
     }
+    }   // (reference slot walk)
 
     const uint32_t n_bases32 = (uint32_t)ix.n_bases;
     for (int d = 0; d < 2; d++) {

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(64) void k_ag_batch(AGBatchArgs a)
 // =====================================================================================
 
 static thread_local std::string g_last_error;
+static thread_local const struct snapgpu_ctx *g_share_buckets_from = nullptr;      // snapgpu_create_replica(share_index): adopt these bucket tables
 
 struct snapgpu_ctx {
     int device = -1;
@@ -165,6 +166,8 @@ struct snapgpu_ctx {
     bool owns_index = true;
     void *d_hash = nullptr, *d_overflow = nullptr, *d_genome_padded = nullptr;
     void *d_table_offset = nullptr, *d_table_size = nullptr, *d_contig_begin = nullptr;
+    void *d_bucket_blob = nullptr, *d_bucket_offset = nullptr, *d_n_buckets = nullptr;      // device-native hash layout (bucket.h)
+    bool owns_buckets = true; uint64_t bucket_bytes = 0;
     void *d_proj = nullptr;           // [proj_begin u64 x n][cigar_start u32 x (n+1)][cigar_ops u32 x m][proj_rc u8 x n]
     PEProj proj{};
     DevTables *d_tab = nullptr;
@@ -200,6 +203,8 @@ struct snapgpu_ctx {
     // exact replay of flagged reads / pairs: the reference's traceback arrays per replay wave (2 per read, 4 per pair)
     uint8_t *d_exact_persist = nullptr; uint64_t exact_persist_stride = 0; uint32_t exact_slots = 0;
     uint8_t *d_pexact_persist = nullptr; uint64_t pexact_persist_stride = 0; uint32_t pexact_slots = 0;
+    // Phase-4 help (paired_dev.h): [done counter | slots] and the per-slot PEHelpSpec arrays
+    uint8_t *d_help = nullptr; size_t help_bytes = 0; uint32_t n_help = 0; PEHelpSpec *d_help_spec = nullptr; uint32_t help_spec_cap = 0; uint32_t help_min = 0;
     uint32_t p_wave_slots = 0, p_big_slots = 0, p_lds_per_wave = 0;
     int p_ag_variant = 0;
     // paired-end path with secondary results (both snapgpu_enable_paired and snapgpu_enable_secondary called): its own slabs
@@ -336,6 +341,11 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
         if (ctx->d_overflow) (void)hipFree(ctx->d_overflow);
         if (ctx->d_genome_padded) (void)hipFree(ctx->d_genome_padded);
     }
+    if (ctx->owns_buckets) {
+        if (ctx->d_bucket_blob) (void)hipFree(ctx->d_bucket_blob);
+        if (ctx->d_bucket_offset) (void)hipFree(ctx->d_bucket_offset);
+        if (ctx->d_n_buckets) (void)hipFree(ctx->d_n_buckets);
+    }
     if (ctx->d_sec_scratch) (void)hipFree(ctx->d_sec_scratch);
     for (int i = 0; i < 2; i++) if (ctx->d_sec_stage[i]) (void)hipFree(ctx->d_sec_stage[i]);
     if (ctx->d_table_offset) (void)hipFree(ctx->d_table_offset);
@@ -352,6 +362,8 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
     if (ctx->d_exact_persist) (void)hipFree(ctx->d_exact_persist);
     if (ctx->d_pexact_persist) (void)hipFree(ctx->d_pexact_persist);
+    if (ctx->d_help) (void)hipFree(ctx->d_help);
+    if (ctx->d_help_spec) (void)hipFree(ctx->d_help_spec);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
     if (ctx->d_whist) (void)hipFree(ctx->d_whist);
@@ -362,6 +374,40 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+// Device-native hash layout (bucket.h): built on the GPU from the reference's slot arrays once they are in HBM
+// (snapgpu_create for uploaded / adopted blobs, snapgpu_broadcast_index for the replicas it fills).
+static int build_buckets(snapgpu_ctx *ctx)
+{
+    DevIndex &ix = ctx->ix;
+    if (ix.large || ix.entry_bytes != 8 || ix.key_bytes > 4 || getenv("SNAPGPU_NO_BUCKETS")) return SNAPGPU_OK;      // this shape keeps the slot walk
+    const uint32_t nt = ix.n_hash_tables;
+    std::vector<uint64_t> nb(nt), boff(nt);
+    uint64_t total = 0;
+    for (uint32_t t = 0; t < nt; t++) { nb[t] = bucket_count_for(ctx->h_table_size[t]); boff[t] = total * BUCKET_BYTES; total += nb[t]; }
+    if (!ctx->d_bucket_blob) {
+        ctx->bucket_bytes = total * BUCKET_BYTES;
+        HIPCHK(ctx, hipMalloc(&ctx->d_bucket_blob, (size_t)ctx->bucket_bytes + 64), SNAPGPU_E_NOMEM);
+        HIPCHK(ctx, hipMalloc(&ctx->d_bucket_offset, (size_t)nt * 8), SNAPGPU_E_NOMEM);
+        HIPCHK(ctx, hipMalloc(&ctx->d_n_buckets, (size_t)nt * 8), SNAPGPU_E_NOMEM);
+        HIPCHK(ctx, hipMemcpy(ctx->d_bucket_offset, boff.data(), (size_t)nt * 8, hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+        HIPCHK(ctx, hipMemcpy(ctx->d_n_buckets, nb.data(), (size_t)nt * 8, hipMemcpyHostToDevice), SNAPGPU_E_NODEVICE);
+    }
+    const uint32_t key_mask = ix.key_bytes >= 4 ? 0xffffffffu : ((1u << (8 * ix.key_bytes)) - 1u);
+    hipLaunchKernelGGL(k_bucket_init, dim3((unsigned)ctx->num_cus * 8), dim3(256), 0, ctx->stream, (uint32_t *)ctx->d_bucket_blob, total);
+    for (uint32_t t = 0; t < nt; t++) {
+        if (ctx->h_table_size[t] == 0) continue;
+        hipLaunchKernelGGL(k_bucket_build, dim3((unsigned)ctx->num_cus * 4), dim3(256), 0, ctx->stream,
+                           (const uint32_t *)((const uint8_t *)ctx->d_hash + ctx->h_table_offset[t]), ctx->h_table_size[t], key_mask,
+                           (uint32_t *)((uint8_t *)ctx->d_bucket_blob + boff[t]), nb[t]);
+    }
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_LAUNCH);
+    ix.bucket_blob = (const uint8_t *)ctx->d_bucket_blob;
+    ix.bucket_offset = (const uint64_t *)ctx->d_bucket_offset;
+    ix.n_buckets = (const uint64_t *)ctx->d_n_buckets;
+    return SNAPGPU_OK;
 }
 
 extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_params *p, int device, snapgpu_ctx **out)
@@ -432,6 +478,7 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     ix.table_offset = (const uint64_t *)ctx->d_table_offset;
     ix.table_size = (const uint64_t *)ctx->d_table_size;
     ix.contig_begin = (const uint64_t *)ctx->d_contig_begin;
+    ix.bucket_blob = nullptr; ix.bucket_offset = nullptr; ix.n_buckets = nullptr;
     {   // ALT-to-primary projections (used by the paired-end path's ALT liftover); absent data = "location 0, no CIGAR"
         const size_t n = idx->n_contigs;
         const uint32_t n_ops = (idx->contig_cigar_start && idx->cigar_ops && n) ? idx->contig_cigar_start[n] : 0;
@@ -474,6 +521,17 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         ctx->view_meta.table_offset = nullptr; ctx->view_meta.table_size = nullptr; ctx->view_meta.contig_begin = nullptr;
         ctx->view_meta.contig_proj_begin = nullptr; ctx->view_meta.contig_proj_rc = nullptr; ctx->view_meta.contig_cigar_start = nullptr;
         ctx->view_meta.cigar_ops = nullptr;
+    }
+
+    if (g_share_buckets_from && g_share_buckets_from->d_bucket_blob && idx->on_device) {     // second feeder context on this GPU: adopt
+        ctx->owns_buckets = false;
+        ctx->d_bucket_blob = g_share_buckets_from->d_bucket_blob; ctx->d_bucket_offset = g_share_buckets_from->d_bucket_offset;
+        ctx->d_n_buckets = g_share_buckets_from->d_n_buckets; ctx->bucket_bytes = g_share_buckets_from->bucket_bytes;
+        ix.bucket_blob = (const uint8_t *)ctx->d_bucket_blob; ix.bucket_offset = (const uint64_t *)ctx->d_bucket_offset;
+        ix.n_buckets = (const uint64_t *)ctx->d_n_buckets;
+    } else if (idx->on_device || idx->hash_blob != nullptr) {      // (blobs left unfilled wait for snapgpu_broadcast_index)
+        const int brc = build_buckets(ctx);
+        if (brc != SNAPGPU_OK) { snapgpu_destroy(ctx); return brc; }
     }
 
     // ---- tables
@@ -568,7 +626,10 @@ extern "C" int snapgpu_create_replica(const snapgpu_ctx *src, int device, int sh
         v.on_device = 0;
         v.hash_blob = nullptr; v.overflow = nullptr; v.genome = nullptr;
     }
-    return snapgpu_create(&v, &src->params, device, out);
+    g_share_buckets_from = share_index ? src : nullptr;
+    const int rc = snapgpu_create(&v, &src->params, device, out);
+    g_share_buckets_from = nullptr;
+    return rc;
 }
 
 // RCCL through dlopen: libsnapgpu.so must load on a box without librccl (single-GPU use); the symbols are resolved on first use.
@@ -643,6 +704,11 @@ extern "C" int snapgpu_broadcast_index(snapgpu_ctx **ctxs, int n)
     }
     for (auto c : comms) g_rccl.CommDestroy(c);
 #undef NCCLCHK
+    for (int i = 1; i < n; i++) {           // the replicas' own device-native tables, now that their slot arrays are there
+        HIPCHK(root, hipSetDevice(ctxs[i]->device), SNAPGPU_E_NODEVICE);
+        const int brc = build_buckets(ctxs[i]);
+        if (brc != SNAPGPU_OK) return brc;
+    }
     return SNAPGPU_OK;
 }
 
@@ -1685,6 +1751,17 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
     big.scratch = ctx->d_pscratch_big;
     if (ctx->d_pexact_persist) { (void)hipFree(ctx->d_pexact_persist); ctx->d_pexact_persist = nullptr; }
+    if (ctx->d_help) { (void)hipFree(ctx->d_help); ctx->d_help = nullptr; }
+    if (ctx->d_help_spec) { (void)hipFree(ctx->d_help_spec); ctx->d_help_spec = nullptr; }
+    ctx->help_min = 192;                // Phase-4 lists at least this long are offered to idle waves; 0 = off (SNAPGPU_PAIRED_HELP_MIN)
+    if (const char *e = getenv("SNAPGPU_PAIRED_HELP_MIN")) ctx->help_min = (uint32_t)strtoul(e, nullptr, 10);
+    if (p.use_affine_gap && ctx->help_min != 0) {
+        ctx->n_help = 32;
+        ctx->help_spec_cap = big.pcfg.ag_cand_cap;
+        ctx->help_bytes = 64 + (size_t)ctx->n_help * sizeof(PEHelpSlot);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_help, ctx->help_bytes), SNAPGPU_E_NOMEM);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_help_spec, (size_t)ctx->n_help * ctx->help_spec_cap * sizeof(PEHelpSpec)), SNAPGPU_E_NOMEM);
+    }
     if (p.use_affine_gap) {             // exact replay of flagged pairs: four traceback arrays per replay wave
         ctx->pexact_slots = 64;
         ctx->pexact_persist_stride = 4 * (uint64_t)((ag_scratch_bytes(sc.RL) + 255) & ~(size_t)255);
@@ -1704,6 +1781,7 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
                          void *d_primary, void *d_first_alt, hipStream_t s, const PairedSecOut *so = nullptr)
 {
     PairedArgs a = so ? ctx->pargs_sec : ctx->pargs;
+    a.ix = ctx->ix;                    // (the device-native tables may have been (re)built since snapgpu_enable_paired)
     if (so) {
         a.secondary = (snapgpu_paired_result *)so->secondary; a.sec_out_stride = so->stride; a.n_secondary = (uint32_t *)so->n_secondary;
         a.single_secondary = (snapgpu_single_result *)so->single_secondary; a.ssec_out_stride = so->single_stride;
@@ -1752,6 +1830,14 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
                                   (uint32_t)ctx->num_cus * 4, s);
         a.remap = ctx->d_order; a.n_remap = ctx->d_whist + 33;
     }
+    auto with_help = [&](PairedArgs &x) -> hipError_t {       // fresh help state for the launch that is about to start
+        x.help = nullptr; x.n_help = 0; x.help_spec = nullptr; x.help_spec_cap = 0; x.help_done = nullptr; x.help_min = 0xffffffffu;
+        if (!ctx->d_help || so) return hipSuccess;
+        x.help = (PEHelpSlot *)(ctx->d_help + 64); x.n_help = ctx->n_help; x.help_spec = ctx->d_help_spec; x.help_spec_cap = ctx->help_spec_cap;
+        x.help_done = (uint32_t *)ctx->d_help; x.help_min = ctx->help_min;
+        return hipMemsetAsync(ctx->d_help, 0, ctx->help_bytes, s);
+    };
+    HIPCHK(ctx, with_help(a), SNAPGPU_E_LAUNCH);
     launch(a, blocks);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     {   // second pass over the pairs the first flagged (usually none: the launch then ends at once)
@@ -1759,10 +1845,12 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 1, 0, 8, s), SNAPGPU_E_LAUNCH);
         snapgpu_launch_collect_flagged((const snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count, 0, s);
         PairedArgs b = so ? ctx->pargs_sec_big : ctx->pargs_big;
+        b.ix = ctx->ix;
         b.secondary = a.secondary; b.sec_out_stride = a.sec_out_stride; b.n_secondary = a.n_secondary;
         b.single_secondary = a.single_secondary; b.ssec_out_stride = a.ssec_out_stride; b.n_single_secondary = a.n_single_secondary;
         b.bases = a.bases; b.quals = a.quals; b.offsets = a.offsets; b.n_pairs = n; b.primary = a.primary; b.first_alt = a.first_alt;
         b.work_counter = d_work2; b.counters = a.counters; b.remap = ctx->d_flag_list; b.n_remap = d_count;
+        HIPCHK(ctx, with_help(b), SNAPGPU_E_LAUNCH);
         launch(b, (so ? ctx->p_sec_big_slots : ctx->p_big_slots) / 4);
         HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
         // third pass: pairs whose banded affine-gap traceback left the band are redone the way a newly constructed reference aligner
@@ -1774,6 +1862,7 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
             PairedArgs x = b;
             x.work_counter = d_work3; x.remap = ctx->d_flag_list; x.n_remap = d_count3;
             x.persist = ctx->d_pexact_persist; x.persist_stride = ctx->pexact_persist_stride;
+            x.help = nullptr; x.n_help = 0; x.help_done = nullptr; x.help_min = 0xffffffffu;
             uint32_t slots = so ? ctx->p_sec_big_slots : ctx->p_big_slots;
             if (slots > ctx->pexact_slots) slots = ctx->pexact_slots;
             if (ctx->p_ag_variant == 3) { if (so) snapgpu_launch_paired_sec_exact_3(&x, slots / 4, lds, s); else snapgpu_launch_paired_exact_3(&x, slots / 4, lds, s); }

@@ -383,6 +383,7 @@ void __tsan_write_range(void *a, unsigned long) { emu::store_hook(a, EMU_RA()); 
 void __tsan_vptr_update(void **, void *) {}
 void __tsan_vptr_read(void **) {}
 int __tsan_atomic32_fetch_add(volatile int *p, int v, int) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+int __tsan_atomic32_fetch_sub(volatile int *p, int v, int) { return __atomic_fetch_sub(p, v, __ATOMIC_SEQ_CST); }
 long __tsan_atomic64_fetch_add(volatile long *p, long v, int) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 int __tsan_atomic32_fetch_or(volatile int *p, int v, int) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 int __tsan_atomic32_exchange(volatile int *p, int v, int) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
