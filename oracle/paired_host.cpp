@@ -59,6 +59,8 @@ struct HostPL {
     static uint64_t clock() { return 0; }
     static const bool FAST_HITSET = false;
     static const bool HELP = false;                     // (Phase-4 help slots are a device-side scheduling matter)
+    template <class T> static void spec_st(T &x, T v) { x = v; }
+    template <class T> static T spec_ld(const T &x) { return x; }
     static const bool SECONDARY = true;
     // (never called: the scalar definitions in paired.h are what the host runs)
     bool hs_first(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *) { return true; }

@@ -186,6 +186,8 @@ class Counters(C.Structure):
     def as_dict(self):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
         d["cycles_single_fallback"] = int(self.reserved[0])      # paired-end path only
+        d["help_watchdog_events"] = int(self.reserved[1])        # Phase-4 help waits that were given up (paired_dev.h); 0 in a healthy run
+        d["help_watchdog_last"] = int(self.reserved[2])
         return d
 
 

@@ -1387,12 +1387,13 @@ struct PairedCore {
             }
             stale = stale_keep; spec_mode = mode_keep;
         }
-        if (PL::lane0()) {
+        if (PL::lane0()) {              // (PL::spec_st / spec_ld: stores and loads that other wavefronts see without a cache-wide fence)
             for (int r = 0; r < 2; r++) {
-                sp->score[r] = o_s[r]; sp->g_off[r] = o_g[r]; sp->cb[r] = o_cb[r]; sp->ca[r] = o_ca[r]; sp->ag[r] = o_ag[r]; sp->span[r] = o_span[r];
-                sp->stale[r] = o_stale[r]; sp->n_ag[r] = o_nag[r]; sp->mp[r] = o_mp[r];
+                PL::spec_st(sp->score[r], (int32_t)o_s[r]); PL::spec_st(sp->g_off[r], (int32_t)o_g[r]); PL::spec_st(sp->cb[r], (int32_t)o_cb[r]);
+                PL::spec_st(sp->ca[r], (int32_t)o_ca[r]); PL::spec_st(sp->ag[r], (int32_t)o_ag[r]); PL::spec_st(sp->span[r], (int32_t)o_span[r]);
+                PL::spec_st(sp->stale[r], o_stale[r]); PL::spec_st(sp->n_ag[r], o_nag[r]); PL::spec_st(sp->mp[r], o_mp[r]);
             }
-            sp->lim[0] = lim0; sp->lim[1] = lim1;
+            PL::spec_st(sp->lim[0], (int32_t)lim0); PL::spec_st(sp->lim[1], (int32_t)lim1);
         }
         PL::sync();
     }
@@ -1418,9 +1419,10 @@ struct PairedCore {
             st(e->used_affine_gap_scoring[0], 1);
             if (!gl0) limit = limit > s0 ? limit : s0;
             int cb = ld(e->bases_clipped_before[0]), ca = ld(e->bases_clipped_after[0]), span = 0;
-            if (sp != nullptr && ld(sp->lim[0]) == PL::i32(limit)) {      // scored ahead of time with exactly these arguments
-                s0 = ld(sp->score[0]); mp0 = ld(sp->mp[0]); g_off[0] = ld(sp->g_off[0]); cb = ld(sp->cb[0]); ca = ld(sp->ca[0]); ag0 = ld(sp->ag[0]);
-                span = ld(sp->span[0]); stale += ld(sp->stale[0]); sh->cnt.ag += ld(sp->n_ag[0]);
+            if (sp != nullptr && PL::spec_ld(sp->lim[0]) == PL::i32(limit)) {      // scored ahead of time with exactly these arguments
+                s0 = PL::spec_ld(sp->score[0]); mp0 = PL::spec_ld(sp->mp[0]); g_off[0] = PL::spec_ld(sp->g_off[0]); cb = PL::spec_ld(sp->cb[0]);
+                ca = PL::spec_ld(sp->ca[0]); ag0 = PL::spec_ld(sp->ag[0]); span = PL::spec_ld(sp->span[0]); stale += PL::spec_ld(sp->stale[0]);
+                sh->cnt.ag += PL::spec_ld(sp->n_ag[0]);
             } else {
                 score_ag(0, ld(e->direction[0]), ld(e->orig_location[0]), ld(e->seed_offset[0]), PL::i32(limit), &s0, &mp0, &g_off[0], &cb, &ca, &ag0, &span);
             }
@@ -1436,9 +1438,10 @@ struct PairedCore {
                 limit = limit - s0;
                 if (!gl1) limit = limit > s1 ? limit : s1;
                 int cb = ld(e->bases_clipped_before[1]), ca = ld(e->bases_clipped_after[1]), span = 0;
-                if (sp != nullptr && ld(sp->lim[1]) == PL::i32(limit)) {
-                    s1 = ld(sp->score[1]); mp1 = ld(sp->mp[1]); g_off[1] = ld(sp->g_off[1]); cb = ld(sp->cb[1]); ca = ld(sp->ca[1]); ag1 = ld(sp->ag[1]);
-                    span = ld(sp->span[1]); stale += ld(sp->stale[1]); sh->cnt.ag += ld(sp->n_ag[1]);
+                if (sp != nullptr && PL::spec_ld(sp->lim[1]) == PL::i32(limit)) {
+                    s1 = PL::spec_ld(sp->score[1]); mp1 = PL::spec_ld(sp->mp[1]); g_off[1] = PL::spec_ld(sp->g_off[1]); cb = PL::spec_ld(sp->cb[1]);
+                    ca = PL::spec_ld(sp->ca[1]); ag1 = PL::spec_ld(sp->ag[1]); span = PL::spec_ld(sp->span[1]); stale += PL::spec_ld(sp->stale[1]);
+                    sh->cnt.ag += PL::spec_ld(sp->n_ag[1]);
                 } else {
                     score_ag(1, ld(e->direction[1]), ld(e->orig_location[1]), ld(e->seed_offset[1]), PL::i32(limit), &s1, &mp1, &g_off[1], &cb, &ca, &ag1, &span);
                 }

@@ -35,7 +35,7 @@ struct PEHelpSlot {
     const uint32_t *order;
     PEHelpSpec *spec;
 };
-#define PE_HELP_CHUNK 4u
+#define PE_HELP_CHUNK 16u
 
 struct PairedArgs {
     DevIndex ix;

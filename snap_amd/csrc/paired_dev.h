@@ -25,22 +25,65 @@ struct DevPL {
     static const bool HELP = !EXACT;
     PEHelpSlot *help; uint32_t n_help; PEHelpSpec *help_spec; uint32_t help_spec_cap;
     uint32_t cur_pair; int my_slot;
+    unsigned long long *diag;          // snapgpu_counters::reserved: [1] waits that ran into the watchdog, [2] what the last one saw
+    // Cross-wave traffic is kept off the cache-wide fences (an agent-scope release writes back the whole L2 of the XCD, an acquire
+    // invalidates it -- once per helped pair / per attach is fine, once per chunk of candidates is not): the speculative answers travel
+    // in device-scope (sc1, write-through) stores and loads, ordered against the chunk's `done` count by a plain vmcnt(0) wait.
     static __device__ __forceinline__ uint32_t aload(uint32_t *p) { return first_u32(lane_id() == 0 ? atomicAdd(p, 0u) : 0u); }
+    template <class T> static __device__ __forceinline__ void spec_st(T &x, T v) {
+#ifdef SNAPGPU_WAVE_EMU
+        if constexpr (sizeof(T) == 8) __atomic_store_n((uint64_t *)&x, __builtin_bit_cast(uint64_t, v), __ATOMIC_SEQ_CST);
+        else __atomic_store_n((uint32_t *)&x, __builtin_bit_cast(uint32_t, v), __ATOMIC_SEQ_CST);
+#else
+        if constexpr (sizeof(T) == 8) __hip_atomic_store((uint64_t *)&x, __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store((uint32_t *)&x, __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
+    template <class T> static __device__ __forceinline__ T spec_ld(const T &x) {
+#ifdef SNAPGPU_WAVE_EMU
+        if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, first_u64(__atomic_load_n((const uint64_t *)&x, __ATOMIC_SEQ_CST)));
+        else return __builtin_bit_cast(T, first_u32(__atomic_load_n((const uint32_t *)&x, __ATOMIC_SEQ_CST)));
+#else
+        if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, first_u64(__hip_atomic_load((const uint64_t *)&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        else return __builtin_bit_cast(T, first_u32(__hip_atomic_load((const uint32_t *)&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+#endif
+    }
+    static __device__ __forceinline__ void stores_done() {                 // every store this wave has issued has been acknowledged
+#ifndef SNAPGPU_WAVE_EMU
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                 // vmcnt(0), expcnt / lgkmcnt untouched
+#endif
+    }
+    static __device__ __forceinline__ void fence_release() {
+#ifdef SNAPGPU_WAVE_EMU
+        __threadfence();
+#else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+    }
+    static __device__ __forceinline__ void fence_acquire() {
+#ifdef SNAPGPU_WAVE_EMU
+        __threadfence();
+#else
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+    }
     static __device__ __forceinline__ void nap() {
 #ifdef SNAPGPU_WAVE_EMU
         emu_yield();
 #else
-        __builtin_amdgcn_s_sleep(20);
+        __builtin_amdgcn_s_sleep(127);
 #endif
     }
     // chunks of the slot's candidates, scored speculatively by this wave (which holds the pair's reads) until none are left
+    // (the slot's fields are read with device-scope loads: a plain load may be served by this CU's L1 with what the slot held for an
+    //  earlier pair -- even in the wave that has just stored them, if another wave of the CU had the line cached)
     template <class Core> __device__ __forceinline__ void help_work(Core &core, PEHelpSlot *slot) {
-        const uint32_t n = ld(slot->n);
-        const int L = ld(slot->limit), best = ld(slot->best);
-        const bool s0 = ld(slot->skip0) != 0, s1 = ld(slot->skip1) != 0;
-        const snapgpu_paired_result *agc = (const snapgpu_paired_result *)first_u64((uint64_t)(uintptr_t)slot->agc);
-        const uint32_t *order = (const uint32_t *)first_u64((uint64_t)(uintptr_t)slot->order);
-        PEHelpSpec *spec = (PEHelpSpec *)first_u64((uint64_t)(uintptr_t)slot->spec);
+        const uint32_t n = spec_ld(slot->n);
+        const int L = spec_ld(slot->limit), best = spec_ld(slot->best);
+        const bool s0 = spec_ld(slot->skip0) != 0, s1 = spec_ld(slot->skip1) != 0;
+        const snapgpu_paired_result *agc = (const snapgpu_paired_result *)(uintptr_t)spec_ld(*(const uint64_t *)&slot->agc);
+        const uint32_t *order = (const uint32_t *)(uintptr_t)spec_ld(*(const uint64_t *)&slot->order);
+        PEHelpSpec *spec = (PEHelpSpec *)(uintptr_t)spec_ld(*(const uint64_t *)&slot->spec);
         for (;;) {
             uint32_t c0 = 0;
             if (lane_id() == 0) c0 = atomicAdd(&slot->next, PE_HELP_CHUNK);
@@ -48,7 +91,7 @@ struct DevPL {
             if (c0 >= n) break;
             const uint32_t c1 = c0 + PE_HELP_CHUNK < n ? c0 + PE_HELP_CHUNK : n;
             for (uint32_t t = c0; t < c1; t++) core.spec_candidate(&agc[ld(order[t])], &spec[t], L, best, s0, s1);
-            __threadfence();
+            stores_done();
             if (lane_id() == 0) atomicAdd(&slot->done, c1 - c0);
         }
     }
@@ -64,20 +107,44 @@ struct DevPL {
         PEHelpSlot *slot = &help[s];
         PEHelpSpec *spec = help_spec + (size_t)s * help_spec_cap;
         if (lane_id() == 0) {
-            slot->pair = cur_pair; slot->n = n; slot->next = 0; slot->done = 0; slot->limit = limit; slot->best = best;
-            slot->skip0 = skip[0] ? 1u : 0u; slot->skip1 = skip[1] ? 1u : 0u;
-            slot->agc = core.agc; slot->order = core.agc_order; slot->spec = spec;
-            __threadfence();
+            spec_st(slot->pair, cur_pair); spec_st(slot->n, n); spec_st(slot->next, 0u); spec_st(slot->done, 0u);
+            spec_st(slot->limit, (int32_t)limit); spec_st(slot->best, (int32_t)best);
+            spec_st(slot->skip0, skip[0] ? 1u : 0u); spec_st(slot->skip1, skip[1] ? 1u : 0u);
+            spec_st(*(uint64_t *)&slot->agc, (uint64_t)(uintptr_t)core.agc); spec_st(*(uint64_t *)&slot->order, (uint64_t)(uintptr_t)core.agc_order);
+            spec_st(*(uint64_t *)&slot->spec, (uint64_t)(uintptr_t)spec);
+            fence_release();                                // the candidate records and their order, for the other XCDs
             atomicExch(&slot->state, 1u);
         }
         WAVE_SYNC();
         my_slot = s;
         help_work(core, slot);
-        while (aload(&slot->done) < n) nap();
-        if (lane_id() == 0) atomicExch(&slot->state, 2u);
-        while (aload(&slot->helpers) != 0u) nap();
-        __threadfence();
-        return spec;
+        // Watchdog: a wait that lasts longer than ~1 s of shader clock is given up -- the slot is retired for the rest of the launch, the
+        // pair goes through its list alone (the speculative answers are simply not used), and the event is counted; nothing can hang.
+        const uint64_t t0 = wave_clock();
+        bool gave_up = false;
+        for (;;) {
+            const uint32_t d = aload(&slot->done);
+            if (d >= n) break;
+            nap();
+            if (wave_clock() - t0 > 2400000000ull) {
+                if (lane_id() == 0 && diag) { atomicAdd(&diag[1], 1ull); diag[2] = ((unsigned long long)n << 32) | d; }
+                gave_up = true; break;
+            }
+        }
+        if (lane_id() == 0) atomicExch(&slot->state, gave_up ? 4u : 2u);
+        if (!gave_up) {
+            for (;;) {
+                if (aload(&slot->helpers) == 0u) break;
+                nap();
+                if (wave_clock() - t0 > 4800000000ull) {
+                    if (lane_id() == 0 && diag) { atomicAdd(&diag[1], 1ull); diag[2] = 0xffffffff00000000ull | aload(&slot->helpers); }
+                    gave_up = true; break;
+                }
+            }
+            if (gave_up && lane_id() == 0) atomicExch(&slot->state, 4u);
+        }
+        if (gave_up) { my_slot = -1; return nullptr; }
+        return spec;                                            // (read with spec_ld: no acquire fence needed)
     }
     __device__ __forceinline__ void help_done() {
         if (my_slot >= 0 && lane_id() == 0) atomicExch(&help[my_slot].state, 0u);
@@ -406,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv;
     al.ag_persist[0] = al.ag_persist[1] = pl.ag_persist[0] = pl.ag_persist[1] = nullptr;
     pl.help = EXACT ? nullptr : a.help; pl.n_help = a.n_help; pl.help_spec = a.help_spec; pl.help_spec_cap = a.help_spec_cap;
-    pl.cur_pair = 0; pl.my_slot = -1;
+    pl.cur_pair = 0; pl.my_slot = -1; pl.diag = a.counters + 13;
     if constexpr (EXACT) {
         uint8_t *pb = a.persist + (size_t)wave_slot * a.persist_stride;
         const size_t q = (size_t)(a.persist_stride / 4);
@@ -517,8 +584,8 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     if constexpr (!EXACT) {
         // Out of pairs: until every pair of the launch is done, score Phase-4 candidates of the pairs that asked for help.
         if (a.help != nullptr && a.help_done != nullptr) {
-            for (;;) {
-                if (DevPL<AGC, SEC, EXACT>::aload(a.help_done) >= n_total) break;
+            for (uint32_t round = 0;; round++) {
+                if ((round & 7u) == 0u && DevPL<AGC, SEC, EXACT>::aload(a.help_done) >= n_total) break;
                 bool any = false;
                 for (uint32_t s = 0; s < a.n_help; s++) {
                     PEHelpSlot *slot = &a.help[s];
@@ -528,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
                     if (DevPL<AGC, SEC, EXACT>::aload(&slot->next) >= DevPL<AGC, SEC, EXACT>::aload(&slot->n)) continue;
                     if (lane == 0) atomicAdd(&slot->helpers, 1u);
                     if (DevPL<AGC, SEC, EXACT>::aload(&slot->state) == 1u) {
-                        __threadfence();
+                        DevPL<AGC, SEC, EXACT>::fence_acquire();
                         load_pair(DevPL<AGC, SEC, EXACT>::aload(&slot->pair));
                         pl.help_work(core, slot);
                         any = true;
@@ -536,9 +603,11 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
                     if (lane == 0) atomicSub(&slot->helpers, 1u);
                 }
 #ifdef SNAPGPU_WAVE_EMU
-                break;      // (emulator: the waves of a block run one after the other -- a wave that waits would keep the next from starting)
+                // (emulator: the waves of a block run one after the other and blocks beyond the host-thread pool wait for a free thread, so a
+                //  wave that waits can keep the pairs it waits for from ever starting; SNAPGPU_EMU_HELP_SPIN=1 for grids that fit the pool)
+                if (!getenv("SNAPGPU_EMU_HELP_SPIN")) break;
 #endif
-                if (!any) DevPL<AGC, SEC, EXACT>::nap();
+                if (!any) { DevPL<AGC, SEC, EXACT>::nap(); DevPL<AGC, SEC, EXACT>::nap(); }
             }
         }
     }

@@ -44,6 +44,63 @@ __global__ __launch_bounds__(256) void k_lookup_seeds(DevIndex ix, uint32_t n, c
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
     unsigned long long c_lookups = 0, c_slots = 0, c_hits = 0, c_lists = 0;
     uint32_t sink = 0;
+    if (ix.bucket_blob != nullptr) {
+        // Device-native layout (bucket.h): FOUR seeds per wavefront pass -- lanes 16 s + 8 d + e read dword pair e of the bucket of seed s,
+        // strand d, so the eight probes of a pass are eight independent 64-byte lines in flight; the eight overflow headers follow as
+        // one load, then each list is read 64 hits per load.
+        const int g = lane >> 3, e = lane & 7, sidx = g >> 1, dir = g & 1;
+        const uint32_t key_bits = ix.key_bytes * 8;
+        const uint32_t n_bases32 = (uint32_t)ix.n_bases;
+        for (uint32_t base = wave * 4; base < n; base += n_waves * 4) {
+            uint64_t my_bases = 0; bool my_valid = false;
+            for (int s = 0; s < 4; s++) {
+                if (base + (uint32_t)s >= n) break;
+                SeedBits sb = pack_seed(seeds + (size_t)(base + (uint32_t)s) * ix.seed_len, ix.seed_len);
+                if (sidx == s) { my_bases = dir ? sb.rc : sb.bases; my_valid = sb.valid; }
+            }
+            const uint32_t seed_i = base + (uint32_t)sidx;
+            const bool in_range = seed_i < n;
+            const bool active = in_range && my_valid;
+            const uint32_t key = (uint32_t)(my_bases & ((1ull << key_bits) - 1));
+            const uint32_t table = (uint32_t)(my_bases >> key_bits);
+            uint32_t lines = 0;
+            const uint32_t v = bucket_probe8(ix.bucket_blob, ix.bucket_offset, ix.n_buckets, table, key, active, &lines);
+            // decode (GenomeIndex.cpp:2160-2202): singleton / absent / overflow list; the group leader fetches the list's count word
+            long long nh = active ? 0 : -1;
+            uint32_t ofs = 0; bool is_list = false;
+            if (active && v != BUCKET_INVALID) {
+                if ((uint64_t)v < ix.n_bases) nh = 1;
+                else if (v != 0xfffffffeu) { ofs = v - n_bases32; is_list = true; }
+            }
+            uint32_t cnt = 0;
+            if (is_list && e == 0) cnt = ix.overflow[ofs];
+            cnt = (uint32_t)__shfl((int)cnt, g * 8);
+            if (is_list) nh = (long long)(int32_t)cnt;
+            if (in_range && e == 0) n_hits[2 * (size_t)seed_i + dir] = nh;
+            const unsigned long long leaders = BALLOT(active && e == 0);
+            c_lookups += (unsigned long long)__popcll(BALLOT(active && e == 0 && dir == 0));
+            // bytes model: one 64-byte line = 8 slots of 8 bytes per bucket read
+            for (int gg = 0; gg < 8; gg++) {
+                const bool g_act = (leaders >> (gg * 8)) & 1ull;
+                if (!g_act) continue;
+                c_slots += 8ull * (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lines, gg * 8);
+                const long long g_nh = ((long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)nh >> 32), gg * 8) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)nh, gg * 8);
+                const uint32_t g_v = (uint32_t)__builtin_amdgcn_readlane((int)v, gg * 8);
+                const uint32_t g_ofs = (uint32_t)__builtin_amdgcn_readlane((int)ofs, gg * 8);
+                const uint32_t g_seed = base + (uint32_t)(gg >> 1);
+                if (g_nh > 1) c_lists++;
+                const long long lim = g_nh < (long long)max_hits_out ? g_nh : (long long)max_hits_out;
+                if (lim <= 0) continue;
+                c_hits += (unsigned long long)lim;
+                uint32_t *dst = hits ? hits + (size_t)(2 * (size_t)g_seed + (uint32_t)(gg & 1)) * max_hits_out : nullptr;
+                for (long long j = lane; j < lim; j += WAVE) {
+                    const uint32_t hv = g_nh == 1 ? g_v : ix.overflow[g_ofs + 1 + (uint32_t)j];
+                    if (dst) dst[j] = hv; else sink ^= hv;
+                }
+            }
+        }
+    } else
     for (uint32_t i = wave; i < n; i += n_waves) {
         SeedBits seed = pack_seed(seeds + (size_t)i * ix.seed_len, ix.seed_len);
         if (!seed.valid) {
@@ -861,7 +918,7 @@ extern "C" int snapgpu_lookup_seeds_device(snapgpu_ctx *ctx, uint32_t n, const v
     if (n == 0) return SNAPGPU_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    uint32_t blocks = (n + 3) / 4; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;
+    uint32_t blocks = (n + 3) / 4; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;      // 32 waves per CU
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     hipLaunchKernelGGL(k_lookup_seeds, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
                        (uint32_t *)d_hits, max_hits_out, ctx->d_counters);
