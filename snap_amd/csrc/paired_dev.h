@@ -29,7 +29,11 @@ struct DevPL {
     // Cross-wave traffic is kept off the cache-wide fences (an agent-scope release writes back the whole L2 of the XCD, an acquire
     // invalidates it -- once per helped pair / per attach is fine, once per chunk of candidates is not): the speculative answers travel
     // in device-scope (sc1, write-through) stores and loads, ordered against the chunk's `done` count by a plain vmcnt(0) wait.
-    static __device__ __forceinline__ uint32_t aload(uint32_t *p) { return first_u32(lane_id() == 0 ? atomicAdd(p, 0u) : 0u); }
+    // Words that are the target of read-modify-write atomics (state, next, done, helpers, the launch's done-pair count) are only ever
+    // touched by read-modify-write atomics: set with an exchange whose return value is waited for, read with a compare-and-swap that
+    // cannot succeed (`atomicAdd(p, 0)` is folded into an atomic LOAD by the compiler, and a load or a store may take another road to
+    // memory than the atomic unit: a store followed by an add on the same word was seen to be applied after it).
+    static __device__ __forceinline__ uint32_t aload(uint32_t *p) { return first_u32(lane_id() == 0 ? atomicCAS(p, 0xFFFFFFF5u, 0xFFFFFFF5u) : 0u); }
     template <class T> static __device__ __forceinline__ void spec_st(T &x, T v) {
 #ifdef SNAPGPU_WAVE_EMU
         if constexpr (sizeof(T) == 8) __atomic_store_n((uint64_t *)&x, __builtin_bit_cast(uint64_t, v), __ATOMIC_SEQ_CST);
@@ -77,6 +81,7 @@ struct DevPL {
     // chunks of the slot's candidates, scored speculatively by this wave (which holds the pair's reads) until none are left
     // (the slot's fields are read with device-scope loads: a plain load may be served by this CU's L1 with what the slot held for an
     //  earlier pair -- even in the wave that has just stored them, if another wave of the CU had the line cached)
+    // a helper's view of the slot (the owner passes its own values: it never reads back what it has just published)
     template <class Core> __device__ __forceinline__ void help_work(Core &core, PEHelpSlot *slot) {
         const uint32_t n = spec_ld(slot->n);
         const int L = spec_ld(slot->limit), best = spec_ld(slot->best);
@@ -84,7 +89,11 @@ struct DevPL {
         const snapgpu_paired_result *agc = (const snapgpu_paired_result *)(uintptr_t)spec_ld(*(const uint64_t *)&slot->agc);
         const uint32_t *order = (const uint32_t *)(uintptr_t)spec_ld(*(const uint64_t *)&slot->order);
         PEHelpSpec *spec = (PEHelpSpec *)(uintptr_t)spec_ld(*(const uint64_t *)&slot->spec);
-        for (;;) {
+        help_chunks(core, slot, n, L, best, s0, s1, agc, order, spec);
+    }
+    template <class Core> __device__ __forceinline__ void help_chunks(Core &core, PEHelpSlot *slot, uint32_t n, int L, int best, bool s0, bool s1,
+                                                                      const snapgpu_paired_result *agc, const uint32_t *order, PEHelpSpec *spec) {
+        for (uint32_t it = 0; it <= n / PE_HELP_CHUNK + 1u; it++) {
             uint32_t c0 = 0;
             if (lane_id() == 0) c0 = atomicAdd(&slot->next, PE_HELP_CHUNK);
             c0 = first_u32(c0);
@@ -107,7 +116,9 @@ struct DevPL {
         PEHelpSlot *slot = &help[s];
         PEHelpSpec *spec = help_spec + (size_t)s * help_spec_cap;
         if (lane_id() == 0) {
-            spec_st(slot->pair, cur_pair); spec_st(slot->n, n); spec_st(slot->next, 0u); spec_st(slot->done, 0u);
+            const uint32_t w0 = atomicExch(&slot->next, 0u), w1 = atomicExch(&slot->done, 0u);
+            if ((w0 ^ w1) == 0xFFFFFFF5u) atomicExch(&slot->done, 0u);          // (uses both return values: the exchanges have completed)
+            spec_st(slot->pair, cur_pair); spec_st(slot->n, n);
             spec_st(slot->limit, (int32_t)limit); spec_st(slot->best, (int32_t)best);
             spec_st(slot->skip0, skip[0] ? 1u : 0u); spec_st(slot->skip1, skip[1] ? 1u : 0u);
             spec_st(*(uint64_t *)&slot->agc, (uint64_t)(uintptr_t)core.agc); spec_st(*(uint64_t *)&slot->order, (uint64_t)(uintptr_t)core.agc_order);
@@ -117,7 +128,7 @@ struct DevPL {
         }
         WAVE_SYNC();
         my_slot = s;
-        help_work(core, slot);
+        help_chunks(core, slot, n, limit, best, skip[0], skip[1], core.agc, core.agc_order, spec);
         // Watchdog: a wait that lasts longer than ~1 s of shader clock is given up -- the slot is retired for the rest of the launch, the
         // pair goes through its list alone (the speculative answers are simply not used), and the event is counted; nothing can hang.
         const uint64_t t0 = wave_clock();
@@ -127,17 +138,22 @@ struct DevPL {
             if (d >= n) break;
             nap();
             if (wave_clock() - t0 > 2400000000ull) {
-                if (lane_id() == 0 && diag) { atomicAdd(&diag[1], 1ull); diag[2] = ((unsigned long long)n << 32) | d; }
+                if (lane_id() == 0 && diag) { atomicAdd(&diag[1], 1ull); diag[2] = 0x1000000000000000ull | ((unsigned long long)n << 32) | d; }
                 gave_up = true; break;
             }
         }
-        if (lane_id() == 0) atomicExch(&slot->state, gave_up ? 4u : 2u);
+        {   // close, THEN look at the attach count (see the helper loop): the exchange's return value is waited for first
+            uint32_t was = 0;
+            if (lane_id() == 0) was = atomicExch(&slot->state, gave_up ? 4u : 2u);
+            was = first_u32(was);
+            if (was != 1u) gave_up = true;                  // (cannot happen)
+        }
         if (!gave_up) {
             for (;;) {
                 if (aload(&slot->helpers) == 0u) break;
                 nap();
                 if (wave_clock() - t0 > 4800000000ull) {
-                    if (lane_id() == 0 && diag) { atomicAdd(&diag[1], 1ull); diag[2] = 0xffffffff00000000ull | aload(&slot->helpers); }
+                    if (lane_id() == 0 && diag) { atomicAdd(&diag[1], 1ull << 16); diag[2] = 0x2000000000000000ull | aload(&slot->helpers); }
                     gave_up = true; break;
                 }
             }
@@ -513,7 +529,8 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     auto load_pair = [&](uint32_t i) {
         for (int r = 0; r < 2; r++) {
             const uint64_t b = first_u64(a.offsets[2 * (size_t)i + r]), e = first_u64(a.offsets[2 * (size_t)i + r + 1]);
-            const int len = (int)(e - b);
+            int len = (int)(e - b);
+            if (len < 0 || len > (int)RL) len = 0;          // (the host rejects such batches; never write past the LDS buffers)
             uint8_t *f = prd + (2 * r) * RL, *rc = prd + (2 * r + 1) * RL, *qf = pql + (2 * r) * RL, *qr = pql + (2 * r + 1) * RL;
             for (int j0 = 0; j0 < len; j0 += WAVE) {
                 int j = j0 + lane;
@@ -584,17 +601,30 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     if constexpr (!EXACT) {
         // Out of pairs: until every pair of the launch is done, score Phase-4 candidates of the pairs that asked for help.
         if (a.help != nullptr && a.help_done != nullptr) {
+            const uint64_t t_idle0 = wave_clock();
             for (uint32_t round = 0;; round++) {
-                if ((round & 7u) == 0u && DevPL<AGC, SEC, EXACT>::aload(a.help_done) >= n_total) break;
+                if ((round & 7u) == 0u) {
+                    const uint32_t dn = DevPL<AGC, SEC, EXACT>::aload(a.help_done);
+                    if (dn >= n_total) break;
+                    if (wave_clock() - t_idle0 > 24000000000ull) {        // ~10 s without the launch finishing: stop waiting, leave a trace
+                        if (lane == 0) { atomicAdd(&a.counters[14], 1ull << 32); a.counters[15] = 0x3000000000000000ull | ((unsigned long long)n_total << 32) | dn; }
+                        break;
+                    }
+                }
                 bool any = false;
                 for (uint32_t s = 0; s < a.n_help; s++) {
                     PEHelpSlot *slot = &a.help[s];
+                    if (DevPL<AGC, SEC, EXACT>::aload(&slot->pair) >= a.n_pairs) continue;
                     // (every cross-wave read of the slot goes through an L2 atomic until the acquire fence below: a plain load may be
                     //  served by this CU's L1 with what the slot held for an earlier pair)
                     if (DevPL<AGC, SEC, EXACT>::aload(&slot->state) != 1u) continue;
                     if (DevPL<AGC, SEC, EXACT>::aload(&slot->next) >= DevPL<AGC, SEC, EXACT>::aload(&slot->n)) continue;
-                    if (lane == 0) atomicAdd(&slot->helpers, 1u);
-                    if (DevPL<AGC, SEC, EXACT>::aload(&slot->state) == 1u) {
+                    // attach, THEN look at the state again -- and the look must not overtake the attach (the owner does the mirror image:
+                    // close, then look at the attach count): the increment's return value is waited for before the state is read
+                    uint32_t before = 0;
+                    if (lane == 0) before = atomicAdd(&slot->helpers, 1u);
+                    before = first_u32(before);
+                    if (before < 0x7fffffffu && DevPL<AGC, SEC, EXACT>::aload(&slot->state) == 1u) {
                         DevPL<AGC, SEC, EXACT>::fence_acquire();
                         load_pair(DevPL<AGC, SEC, EXACT>::aload(&slot->pair));
                         pl.help_work(core, slot);

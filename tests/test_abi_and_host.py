@@ -147,3 +147,45 @@ def test_product_code_never_reaches_for_the_oracle_or_the_emulator():
     assert not bad, bad
     from snap_amd import aligner
     assert aligner.LIB_PATH == os.path.join(root, "snap_amd", "libsnapgpu.so") or os.environ.get("SNAPGPU_TEST_LIB")
+
+
+def _multi_ctx_contract_worker(rank, q):
+    """One of two processes (the shape the 8-GPU driver run has: one process per GPU) driving the argument contract of the multi-context
+    exports without a GPU: every call must come back with the documented error, none may crash or block."""
+    import ctypes as C
+    from snap_amd.aligner import load_library
+    lib = load_library()
+    lib.snapgpu_device_count.restype = C.c_int
+    lib.snapgpu_create_replica.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.snapgpu_broadcast_index.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    out = C.c_void_p(1234)
+    res = dict(rank=rank, n_dev=lib.snapgpu_device_count(),
+               replica_null=lib.snapgpu_create_replica(None, rank, 0, C.byref(out)), replica_out=out.value,
+               bcast_null=lib.snapgpu_broadcast_index(None, 2), bcast_zero=lib.snapgpu_broadcast_index((C.c_void_p * 2)(), 0),
+               bcast_null_ctx=lib.snapgpu_broadcast_index((C.c_void_p * 2)(None, None), 2),
+               err=lib.snapgpu_last_error(None).decode())
+    q.put(res)
+
+
+def test_multi_context_exports_argument_contract_two_processes():
+    """snapgpu_device_count / snapgpu_create_replica / snapgpu_broadcast_index (include/snapgpu.h) from two processes at once: the error
+    convention (negative code + message, nothing created) holds where there is no GPU; the GPU side of the same exports is
+    tests/test_gpu_multi_ctx.py."""
+    import multiprocessing as mp
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by tests/test_gpu_multi_ctx.py")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_multi_ctx_contract_worker, args=(r, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in ps), key=lambda d: d["rank"])
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for d in got:
+        assert d["n_dev"] == 0
+        assert d["replica_null"] == -1 and d["replica_out"] in (None, 1234)          # SNAPGPU_E_INVALID, *out untouched or NULL
+        assert d["bcast_null"] == -1 and d["bcast_zero"] == -1 and d["bcast_null_ctx"] == -1
+        assert "snapgpu_broadcast_index" in d["err"]
