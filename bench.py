@@ -245,6 +245,8 @@ def main():
                                               ("cycles_lookup", "cycles_hits", "cycles_lv", "cycles_ag") + (("cycles_single_fallback",) if paired else ())
                                               if k in counters}   # paired: lookup = Phase 1, hits = Phase 2 (set intersection), lv/ag = paired scoring
     out["roofline"]["wave_cycles_per_read"] = counters.get("cycles_total", 0) / max(1, counters["n_reads"])
+    if paired:
+        out["roofline"]["phase4_help"] = {"watchdog_events": counters.get("help_watchdog_events", 0), "min_candidates": os.environ.get("SNAPGPU_PAIRED_HELP_MIN", "192 (default)")}
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:
@@ -292,7 +294,8 @@ def main():
         # The reads / pairs whose banded affine-gap traceback left the band (`reserved` != 0) were redone on the GPU the way a newly
         # constructed reference aligner does them (exact replay); for those the expectation is the reference run with fresh objects
         # (oracle/ref_driver.cpp: ZeroedArena), because the long-lived objects of the timed run answer such reads from their history.
-        flagged = prim["reserved"][:sample] != 0
+        flagged = (prim["reserved"][:sample] & 0x3fffffff) != 0         # any traceback step outside the band (superset of what was replayed)
+        replayed = ((prim["flags"][:sample] & 4) != 0) if paired else ((prim["reserved"][:sample] & 0x80000000) != 0)
         fi = np.nonzero(flagged)[0]
         history_dependent = 0
         if fi.size:
@@ -318,12 +321,12 @@ def main():
         if paired:
             from tests.pairs_util import compare_paired
             bad = compare_paired(pr, prim[:sample], verbose=0)
-            out["parity_check"] = {"pairs": sample, "mismatching_pairs": int(bad.sum()), "excluded": 0, "exact_replayed": int(flagged.sum()),
+            out["parity_check"] = {"pairs": sample, "mismatching_pairs": int(bad.sum()), "excluded": 0, "exact_replayed": int(replayed.sum()), "left_the_band": int(flagged.sum()),
                                    "of_which_reference_history_dependent": history_dependent}
         else:
             from tests.util import compare_results
             problems = compare_results(pr, prim[:sample])
-            out["parity_check"] = {"reads": sample, "mismatching_fields": problems, "excluded": 0, "exact_replayed": int(flagged.sum()),
+            out["parity_check"] = {"reads": sample, "mismatching_fields": problems, "excluded": 0, "exact_replayed": int(replayed.sum()), "left_the_band": int(flagged.sum()),
                                    "of_which_reference_history_dependent": history_dependent}
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     aligner.close()

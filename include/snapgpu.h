@@ -160,11 +160,13 @@ typedef struct snapgpu_single_result {
     double   match_probability;
     double   probability_all_candidates;
     uint32_t popular_seeds_skipped;
-    uint32_t reserved;             /* not in the reference: number of banded affine-gap traceback steps that
-                                      left the computed band while scoring this read.  Non-zero means the
-                                      reference's own result for this read depends on what its aligner object
-                                      scored before (it reads stale traceback cells, AffineGapVectorized.h:743);
-                                      DESIGN.md "Reference nondeterminism". */
+    uint32_t reserved;             /* not in the reference.  Bits 0-29: banded affine-gap traceback steps that left the computed
+                                      band while scoring this read; non-zero means the reference's own result for this read can
+                                      depend on what its aligner object scored before (stale traceback cells,
+                                      AffineGapVectorized.h:743).  Bit 30: such a step happened in a call that was not its
+                                      object's first for this read, where even a newly constructed aligner reads what its own
+                                      earlier calls left; bit 31: this record is the exact pass's answer (the read was redone
+                                      with the reference's traceback arrays kept across its calls).  DESIGN.md section 2 / 14. */
 } snapgpu_single_result;
 
 /* Paired-end options: PairedAlignerOptions (SNAPLib/PairedAligner.cpp:227-242) and the paired
@@ -220,6 +222,8 @@ typedef struct snapgpu_paired_result {
     uint32_t flags;                       /* SNAPGPU_PAIR_* bits                          */
 } snapgpu_paired_result;
 
+#define SNAPGPU_PAIR_EXACT_REPLAY    4u   /* not an error: the pair's banded affine-gap traceback left the band in a call whose answer can depend on
+                                             the object's earlier calls for the same pair, so the exact pass redid (or must redo) it -- informational */
 #define SNAPGPU_PAIR_POOL_OVERFLOW   1u   /* candidate pool / affine-gap candidate buffer too small: result invalid */
 #define SNAPGPU_PAIR_REF_BUFFER_DEPENDENT 2u /* (-om only) not an error.  The Hamming retry of the chimeric fallback produced more single-end
                                                 secondary candidates than the 32-entry buffer PairedAligner.cpp:566 starts with.  The reference

@@ -59,6 +59,7 @@ struct HostPL {
     static uint64_t clock() { return 0; }
     static const bool FAST_HITSET = false;
     static const bool HELP = false;                     // (Phase-4 help slots are a device-side scheduling matter)
+    static const bool ALWAYS_COUNT_STALE = true;        // (the host build keeps the conservative count: its tests exclude by it)
     template <class T> static void spec_st(T &x, T v) { x = v; }
     template <class T> static T spec_ld(const T &x) { return x; }
     static const bool SECONDARY = true;

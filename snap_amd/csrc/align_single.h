@@ -157,7 +157,8 @@ struct Aligner {
     uint16_t *heads;
     Elem     *pool;
     uint8_t  *ag_scratch;
-    uint8_t  *ag_persist[2];    // EXACT only: [0] forward object (affineGap), [1] backward object (reverseAffineGap)
+    uint8_t  *ag_persist0, *ag_persist1;   // EXACT only: images of the forward object's (affineGap) and the backward object's (reverseAffineGap) array
+    uint32_t ag_hw0, ag_hw1;               // EXACT only: bytes of each image written since it was last zeroed (what the next read must clear)
     // ---- per-read state (wave-uniform)
     int lane;
     int read_len;
@@ -169,6 +170,9 @@ struct Aligner {
     uint32_t n_seeds_applied[2];
     uint32_t popular_seeds_skipped;
     uint32_t ag_stale;                 // affine-gap traceback steps outside the computed band (see ag.h)
+    uint32_t ag_replay;                // ... of which in a call that was not its object's first: those can matter (note_ag_call)
+    uint32_t ag_obj_used0, ag_obj_used1;   // has affineGap / reverseAffineGap scored anything yet for this read (this pair, for the fallback)?
+                                       // (two scalars, not an array: an index that is not a compile-time constant would pin the object in scratch)
     uint32_t max_k;                    // BaseAligner::maxK: cfg.max_k, or what setMaxK() last said (ChimericPairedEndAligner.cpp:278,301)
     // candidates for BaseAligner::alignAffineGap, collected by the Hamming pass only (BaseAligner.cpp:1445-1456)
     snapgpu_single_result *agc;
@@ -189,6 +193,26 @@ struct Aligner {
     __device__ __forceinline__ Aligner(const DevIndex &ix_, const DevTables *tab_, const AlignCfg &cfg_, WaveShared *ws)
         : ix(ix_), tab(tab_), cfg(cfg_), max_k(cfg_.max_k), agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0),
           all(ws->all), non_alt(ws->non_alt), primary(ws->primary), first_alt(ws->first_alt), cnt(ws->cnt) {}
+
+    // A traceback step outside the band reads what the reference object's array holds there.  For the FIRST call an object serves after
+    // its construction that is zero -- exactly what the kernels read -- so only steps of later calls make the answer depend on the
+    // earlier ones and send the read to the exact replay (in the replay itself the array is real and every step is simply counted).
+    __device__ __forceinline__ void note_ag_call(int obj, uint32_t stale_steps) {
+        ag_stale += stale_steps;
+        const uint32_t used = obj == 0 ? ag_obj_used0 : ag_obj_used1;
+        if (EXACT || used) ag_replay += stale_steps;
+        if (obj == 0) ag_obj_used0 = 1; else ag_obj_used1 = 1;
+    }
+
+    // EXACT: how far into its object's array a call can write: text_len rows of numVec * numSeg * 8 bytes (ag_dims)
+    __device__ __forceinline__ void note_ag_extent(int obj, bool banded, int plen, int w, int tlen) {
+        if constexpr (EXACT) {
+            int nv, sl, ns;
+            ag_dims(banded, plen, w > 126 ? 126 : (w < 0 ? 0 : w), &nv, &sl, &ns);
+            const uint32_t ext = (uint32_t)tlen * (uint32_t)(ns * sl);
+            if (obj == 0) ag_hw0 = ext > ag_hw0 ? ext : ag_hw0; else ag_hw1 = ext > ag_hw1 ? ext : ag_hw1;
+        }
+    }
 
     // ------------------------------------------------------------------ helpers
     __device__ __forceinline__ bool is_alt(int64_t loc) const { return (uint64_t)loc >= ix.first_alt_location && loc >= 0; }
@@ -694,12 +718,13 @@ struct Aligner {
                                     const int tlen = half == 0 ? text_len : seed_offset + lim;
                                     const bool banded = plen >= 3 * (2 * lim + 1);                   // :1213 / :1251
                                     ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+                                    note_ag_extent(half, banded, plen, lim, tlen);
                                     AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, e_dir != 0,
-                                                                  false, ag_rows, EXACT ? ag_persist[half] : ag_scratch, cfg.RL, tab);
+                                                                  false, ag_rows, EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab);
                                     a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
                                     a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
                                     a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
-                                    ag_stale += (uint32_t)a.stale_reads;
+                                    note_ag_call(half, (uint32_t)a.stale_reads);
                                     if (half == 0) {
                                         ag1 = a.ag_score + (seed_len - read_len); clip_after = a.pattern_offset;
                                         score1 = a.n_edits; mp1 = a.match_probability;
@@ -820,6 +845,7 @@ struct Aligner {
 
     __device__ __forceinline__ void align_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         const uint64_t t_read0 = wave_clock();
+        ag_obj_used0 = ag_obj_used1 = 0;                                      // a newly constructed aligner for every read
         align_read_inner<false>(g_bases, g_quals, len);
         cnt.cyc_total += wave_clock() - t_read0;
     }
@@ -884,7 +910,7 @@ struct Aligner {
         if (!cfg.alt_aware) non_alt.best_score = SNAPGPU_TooBigScoreValue;    // :325 (never re-initialised without ALT awareness)
         n_seeds_applied[0] = n_seeds_applied[1] = 0;
         popular_seeds_skipped = 0;
-        ag_stale = 0;
+        ag_stale = 0; ag_replay = 0;
         n_agc = 0; agc_overflow = 0;
         bool finished = false;
 
@@ -950,7 +976,7 @@ struct Aligner {
         }
         if (!finished) score<HAM>(true);                                      // :734
         primary.score_prior_to_clipping = primary.score;                      // finalizeSecondaryResults, :2442
-        primary.reserved = ag_stale;
+        primary.reserved = (ag_stale & 0x3fffffffu) | (ag_replay ? 0x40000000u : 0u);      // bit 30: the exact pass must redo this read
         release_candidates();
         if constexpr (SEC) { n_sec_raw = n_sec; finalize_secondary(); }
     }
@@ -1082,12 +1108,13 @@ struct Aligner {
             const int tlen = half == 0 ? (int)(glen - tail_start) : seed_offset + lim;
             const bool banded = plen >= 3 * (2 * lim + 1);
             ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+            note_ag_extent(half, banded, plen, lim, tlen);
             AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, dir != 0, half == 0, ag_rows,
-                                                 EXACT ? ag_persist[half] : ag_scratch, cfg.RL, tab);
+                                                 EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab);
             a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
             a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
             a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
-            ag_stale += (uint32_t)a.stale_reads;
+            note_ag_call(half, (uint32_t)a.stale_reads);
             if (half == 0) {
                 ag1 = a.ag_score + (seed_len - read_len); *clip_after = a.pattern_offset; score1 = a.n_edits; mp1 = a.match_probability;
             } else {

@@ -192,6 +192,8 @@ struct PairedCore {
     uint32_t popular[2];
     int more, fewer;                   // readWithMoreHits / readWithFewerHits
     uint32_t stale, overflow;
+    uint32_t stale_later = 0;          // steps outside the band in calls that were not their object's first (or speculative): the pair needs the exact pass
+    uint32_t ag_obj_used0 = 0, ag_obj_used1 = 0;  // has affineGap / reverseAffineGap of the intersecting aligner scored anything yet for this pair?
     bool spec_mode = false;            // speculative scoring of Phase-4 candidates: work counters are left to the ordered walk
     uint32_t spec_n_ag = 0;
     uint32_t help_min = 0xffffffffu;   // Phase-4 lists at least this long are offered to idle waves (PL::HELP only)
@@ -534,6 +536,15 @@ struct PairedCore {
         }
     }
 
+    // (see Aligner::note_ag_call: the first call an affine-gap object serves for a pair reads zeros outside its band, as the kernels do;
+    //  speculative calls have no place in the order of calls, so their steps always count)
+    PE_FN void note_ag_call(int obj, uint32_t stale_steps) {
+        stale += stale_steps;
+        const uint32_t used = obj == 0 ? ag_obj_used0 : ag_obj_used1;
+        if (PL::ALWAYS_COUNT_STALE || spec_mode || used) stale_later += stale_steps;
+        if (!spec_mode) { if (obj == 0) ag_obj_used0 = 1; else ag_obj_used1 = 1; }
+    }
+
     // scoreLocationWithAffineGap (:3119-3280).  clip_before/clip_after/ag/ref_span are in/out like the reference's pointers.
     PE_FN void score_ag(int which, int dir, int64_t loc, int seed_offset, int limit, int *score, double *mp, int *offset,
                         int *clip_before, int *clip_after, int *ag_score, int *ref_span) {
@@ -557,7 +568,7 @@ struct PairedCore {
             const int plen = rl - tail;
             const bool banded = plen >= 3 * (2 * limit + 1);
             AGOut a = pl.ag(banded, +1, R + tail, Qd + tail, plen, data + tail, (int)(glen - tail), limit, rl, dir != 0, clip);
-            stale += (uint32_t)a.stale;
+            note_ag_call(0, (uint32_t)a.stale);
             ag1 = a.ag_score + (sl - rl); text_rem = a.text_offset; *clip_after = a.pattern_offset; score1 = a.n_edits; mp1 = a.mp;
             if (spec_mode) spec_n_ag++; else sh->cnt.ag++;
         }
@@ -567,7 +578,7 @@ struct PairedCore {
                 const bool banded = seed_offset >= 3 * (2 * left + 1);
                 AGOut b = pl.ag(banded, -1, R + seed_offset - 1, Qd + seed_offset - 1, seed_offset, data + seed_offset - 1, seed_offset + left, left,
                                 rl, dir != 0, clip);
-                stale += (uint32_t)b.stale;
+                note_ag_call(1, (uint32_t)b.stale);
                 ag2 = b.ag_score - rl; *offset = b.text_offset; *clip_before = b.pattern_offset; score2 = b.n_edits; mp2 = b.mp;
                 if (score2 == -1) *offset = 0;
             }
@@ -1273,7 +1284,7 @@ struct PairedCore {
         int score1 = 0, score2 = 0;
         double mp2 = 1.0;
         AGOut a = pl.ag(rl >= 3 * (2 * limit + 1), +1, R, Qd, rl, data, (int)glen, limit, rl, dir != 0, clip);
-        stale += (uint32_t)a.stale;
+        note_ag_call(0, (uint32_t)a.stale);
         const int text_rem = a.text_offset;
         *clip_after = a.pattern_offset; score1 = a.n_edits;
         if (score1 != -1 && score1 <= PE_MAXK1) {
@@ -1281,7 +1292,7 @@ struct PairedCore {
             const int plen = rl - *clip_after;
             AGOut b = pl.ag(plen >= 3 * (2 * left + 1), -1, R + (rl - 1 - *clip_after), Qd + (rl - 1 - *clip_after), plen,
                             data + (rl - text_rem - 1), rl - text_rem, left, rl, dir != 0, clip);
-            stale += (uint32_t)b.stale;
+            note_ag_call(1, (uint32_t)b.stale);
             *clip_before = b.pattern_offset; score2 = b.n_edits; mp2 = b.mp;
             if (score2 == -1 || score2 > PE_MAXK1) {
                 *score = -1; *offset = 0; *ag_score = -1;
@@ -1360,7 +1371,7 @@ struct PairedCore {
         if (gl0 || gl1) limit = PE_MAXK1;
         else if (lv_pair_score > best_pair_score + cfg.extra_depth && lv_pair_indels > 1) limit = cfg.max_k + cfg.extra_depth;
         if (lv_pair_score <= best_pair_score + cfg.extra_depth || lv_pair_indels > 1 || gl0 || gl1) {
-            const uint32_t stale_keep = stale;
+            const uint32_t stale_keep = stale, later_keep = stale_later;
             const bool mode_keep = spec_mode;
             spec_mode = true;
             if (!skip0) {
@@ -1385,7 +1396,7 @@ struct PairedCore {
                 o_s[1] = PL::i32(s1); o_g[1] = PL::i32(off); o_cb[1] = PL::i32(cb); o_ca[1] = PL::i32(ca); o_ag[1] = PL::i32(ag); o_span[1] = PL::i32(span);
                 o_mp[1] = PL::f64(mp); o_stale[1] = stale; o_nag[1] = spec_n_ag;
             }
-            stale = stale_keep; spec_mode = mode_keep;
+            stale = stale_keep; stale_later = later_keep; spec_mode = mode_keep;
         }
         if (PL::lane0()) {              // (PL::spec_st / spec_ld: stores and loads that other wavefronts see without a cache-wide fence)
             for (int r = 0; r < 2; r++) {
@@ -1421,7 +1432,7 @@ struct PairedCore {
             int cb = ld(e->bases_clipped_before[0]), ca = ld(e->bases_clipped_after[0]), span = 0;
             if (sp != nullptr && PL::spec_ld(sp->lim[0]) == PL::i32(limit)) {      // scored ahead of time with exactly these arguments
                 s0 = PL::spec_ld(sp->score[0]); mp0 = PL::spec_ld(sp->mp[0]); g_off[0] = PL::spec_ld(sp->g_off[0]); cb = PL::spec_ld(sp->cb[0]);
-                ca = PL::spec_ld(sp->ca[0]); ag0 = PL::spec_ld(sp->ag[0]); span = PL::spec_ld(sp->span[0]); stale += PL::spec_ld(sp->stale[0]);
+                ca = PL::spec_ld(sp->ca[0]); ag0 = PL::spec_ld(sp->ag[0]); span = PL::spec_ld(sp->span[0]); { const uint32_t ss = PL::spec_ld(sp->stale[0]); stale += ss; stale_later += ss; }
                 sh->cnt.ag += PL::spec_ld(sp->n_ag[0]);
             } else {
                 score_ag(0, ld(e->direction[0]), ld(e->orig_location[0]), ld(e->seed_offset[0]), PL::i32(limit), &s0, &mp0, &g_off[0], &cb, &ca, &ag0, &span);
@@ -1440,7 +1451,7 @@ struct PairedCore {
                 int cb = ld(e->bases_clipped_before[1]), ca = ld(e->bases_clipped_after[1]), span = 0;
                 if (sp != nullptr && PL::spec_ld(sp->lim[1]) == PL::i32(limit)) {
                     s1 = PL::spec_ld(sp->score[1]); mp1 = PL::spec_ld(sp->mp[1]); g_off[1] = PL::spec_ld(sp->g_off[1]); cb = PL::spec_ld(sp->cb[1]);
-                    ca = PL::spec_ld(sp->ca[1]); ag1 = PL::spec_ld(sp->ag[1]); span = PL::spec_ld(sp->span[1]); stale += PL::spec_ld(sp->stale[1]);
+                    ca = PL::spec_ld(sp->ca[1]); ag1 = PL::spec_ld(sp->ag[1]); span = PL::spec_ld(sp->span[1]); { const uint32_t ss = PL::spec_ld(sp->stale[1]); stale += ss; stale_later += ss; }
                     sh->cnt.ag += PL::spec_ld(sp->n_ag[1]);
                 } else {
                     score_ag(1, ld(e->direction[1]), ld(e->orig_location[1]), ld(e->seed_offset[1]), PL::i32(limit), &s1, &mp1, &g_off[1], &cb, &ca, &ag1, &span);
@@ -1487,7 +1498,7 @@ struct PairedCore {
     }
 
     PE_FN void align_pair(int max_k_paired, int max_k_single) {
-        overflow = 0; stale = 0;
+        overflow = 0; stale = 0; stale_later = 0; ag_obj_used0 = ag_obj_used1 = 0;
         n_sec = 0; n_ssec[0] = n_ssec[1] = 0; ref_dep = 0;                                                              // :151-153
         const uint64_t t_all = PL::clock();
         align_pair_inner(max_k_paired, max_k_single);
@@ -1567,7 +1578,7 @@ struct PairedCore {
                 const uint32_t room32 = sec_base < 32u ? 32u - sec_base : 0u;       // what PairedAligner.cpp:566's initial buffer would have left
                 uint32_t n_this = pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
                 sh->cnt.cyc_single += PL::clock() - t_s;
-                stale += single[r].reserved & 0x7fffffffu;
+                stale += single[r].reserved & 0x3fffffffu; stale_later += (single[r].reserved & 0x40000000u) ? 1u : 0u;
                 bool used_hamming = false;
                 if (cfg.use_soft_clip && cfg.enable_hamming_base) {
                     if (single[r].status == SNAPGPU_NotFound && res.status[r] == SNAPGPU_NotFound) {                  // :330-360
@@ -1575,7 +1586,7 @@ struct PairedCore {
                         n_this = pl.align_single(r, PL::i32(max_k_read), true, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
                         // the reference drops this call's "buffer too small" on the floor (:339-343): see SNAPGPU_PAIR_REF_BUFFER_DEPENDENT
                         if (want_sec() && pl.single_raw_secondary() > room32) ref_dep = 1;
-                        stale += single[r].reserved & 0x7fffffffu;
+                        stale += single[r].reserved & 0x3fffffffu; stale_later += (single[r].reserved & 0x40000000u) ? 1u : 0u;
                         if (single[r].reserved & 0x80000000u) { overflow = 1; return; }      // candidate buffer of the single-end aligner overflowed
                     }
                 }

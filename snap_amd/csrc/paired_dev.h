@@ -20,9 +20,11 @@
 template <int AGC, bool SEC = false, bool EXACT = false>
 struct DevPL {
     Aligner<AGC, SEC, EXACT> *al;      // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
-    uint8_t *ag_persist[2];
+    uint8_t *ag_persist0, *ag_persist1;
+    uint32_t ag_hw0, ag_hw1;           // EXACT: bytes of each image written since it was last zeroed
     // Phase-4 help (not in the exact replay: there the affine-gap calls of a pair are ordered through the traceback arrays they share)
     static const bool HELP = !EXACT;
+    static const bool ALWAYS_COUNT_STALE = EXACT;
     PEHelpSlot *help; uint32_t n_help; PEHelpSpec *help_spec; uint32_t help_spec_cap;
     uint32_t cur_pair; int my_slot;
     unsigned long long *diag;          // snapgpu_counters::reserved: [1] waits that ran into the watchdog, [2] what the last one saw
@@ -355,8 +357,14 @@ struct DevPL {
     __device__ __forceinline__ AGOut ag(bool banded, int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int lim,
                                         int read_len, bool is_rc, int use_clip) {
         ByteSeq Ps{P, st}, Qs{Q, st}, Ts{T, st};
+        if constexpr (EXACT) {
+            int nv, sl, ns;
+            ag_dims(banded, plen, lim > 126 ? 126 : (lim < 0 ? 0 : lim), &nv, &sl, &ns);
+            const uint32_t ext = (uint32_t)tlen * (uint32_t)(ns * sl);
+            if (st == 1) ag_hw0 = ext > ag_hw0 ? ext : ag_hw0; else ag_hw1 = ext > ag_hw1 ? ext : ag_hw1;
+        }
         AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, Ps, Qs, plen, Ts, tlen, lim, read_len, is_rc, use_clip, al->ag_rows,
-                                             EXACT ? ag_persist[st == 1 ? 0 : 1] : al->ag_scratch, al->cfg.RL, tab);
+                                             EXACT ? (st == 1 ? ag_persist0 : ag_persist1) : al->ag_scratch, al->cfg.RL, tab);
         AGOut o;
         o.ag_score = i32(a.ag_score); o.text_offset = i32(a.text_offset); o.pattern_offset = i32(a.pattern_offset);
         o.n_edits = i32(a.n_edits); o.mp = f64(a.match_probability); o.stale = i32(a.stale_reads);
@@ -415,7 +423,7 @@ struct DevPL {
         } else {
             al->template align_read_inner<true>(g_bases[r], g_quals[r], g_len[r]);
             if (!al->agc_overflow) al->align_affine_gap(ws->ag_all, ws->ag_non_alt);
-            al->primary.reserved = al->ag_stale;
+            al->primary.reserved = (al->ag_stale & 0x3fffffffu) | (al->ag_replay ? 0x40000000u : 0u);
         }
         WAVE_SYNC();
         res = al->primary;
@@ -487,13 +495,14 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     }
     DevPL<AGC, SEC, EXACT> pl;
     pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv;
-    al.ag_persist[0] = al.ag_persist[1] = pl.ag_persist[0] = pl.ag_persist[1] = nullptr;
+    al.ag_persist0 = al.ag_persist1 = pl.ag_persist0 = pl.ag_persist1 = nullptr;
+    al.ag_hw0 = al.ag_hw1 = pl.ag_hw0 = pl.ag_hw1 = 0;
     pl.help = EXACT ? nullptr : a.help; pl.n_help = a.n_help; pl.help_spec = a.help_spec; pl.help_spec_cap = a.help_spec_cap;
     pl.cur_pair = 0; pl.my_slot = -1; pl.diag = a.counters + 13;
     if constexpr (EXACT) {
         uint8_t *pb = a.persist + (size_t)wave_slot * a.persist_stride;
         const size_t q = (size_t)(a.persist_stride / 4);
-        pl.ag_persist[0] = pb; pl.ag_persist[1] = pb + q; al.ag_persist[0] = pb + 2 * q; al.ag_persist[1] = pb + 3 * q;
+        pl.ag_persist0 = pb; pl.ag_persist1 = pb + q; al.ag_persist0 = pb + 2 * q; al.ag_persist1 = pb + 3 * q;
     }
     pl.agp = AGParams{a.scfg.match_reward, a.scfg.sub_penalty, a.scfg.gap_open, a.scfg.gap_extend, a.scfg.five_bonus, a.scfg.three_bonus};
 
@@ -553,11 +562,16 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         if (i >= n_total) break;
         if (a.remap) i = first_u32(a.remap[i]);
         if constexpr (EXACT) {          // newly constructed reference aligners: all four traceback arrays read as zero
-            wave_zero16(pl.ag_persist[0], (size_t)a.persist_stride);
+            if (pl.ag_hw0) wave_zero16(pl.ag_persist0, ((size_t)pl.ag_hw0 + 15) & ~(size_t)15);
+            if (pl.ag_hw1) wave_zero16(pl.ag_persist1, ((size_t)pl.ag_hw1 + 15) & ~(size_t)15);
+            if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
+            if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
+            pl.ag_hw0 = pl.ag_hw1 = al.ag_hw0 = al.ag_hw1 = 0;
             WAVE_SYNC();
         }
         load_pair(i);
         pl.cur_pair = i;
+        al.ag_obj_used0 = al.ag_obj_used1 = 0;          // the chimeric fallback's single-end aligner is one object for the whole pair
         {   // zero both results (fields the reference leaves unset read as 0 here)
             uint32_t *z0 = (uint32_t *)&core.sh->res, *z1 = (uint32_t *)&core.sh->alt;
             const int nd = (int)(sizeof(snapgpu_paired_result) / 4);
@@ -569,7 +583,8 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
             core.ssec_stride = a.ssec_out_stride;
         }
         core.align_pair(a.max_k_paired, a.max_k_single);
-        core.sh->res.flags = (core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0) | (core.ref_dep ? SNAPGPU_PAIR_REF_BUFFER_DEPENDENT : 0);
+        core.sh->res.flags = (core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0) | (core.ref_dep ? SNAPGPU_PAIR_REF_BUFFER_DEPENDENT : 0) |
+                             ((EXACT || core.stale_later) ? SNAPGPU_PAIR_EXACT_REPLAY : 0);
         WAVE_SYNC();
         if constexpr (SEC) {        // paired secondary results: sec[sec_ord[k]] -> secondary[i * stride + k]
             const uint32_t n_sec = core.overflow ? 0u : core.n_sec;
@@ -641,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
             }
         }
     }
-    if (lane == 0 && !EXACT) {          // (a replayed pair was already counted)
+    if (lane == 0 && (!EXACT || !a.remap)) {          // (a replayed pair was already counted)
         if (!a.remap) atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
         atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
@@ -669,7 +684,7 @@ __global__ void k_collect_flagged(const snapgpu_paired_result *primary, uint32_t
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool ov = (primary[i].flags & SNAPGPU_PAIR_POOL_OVERFLOW) != 0;
-    if (stale ? (!ov && primary[i].reserved != 0) : ov) list[atomicAdd(count, 1u)] = i;
+    if (stale ? (!ov && (primary[i].flags & SNAPGPU_PAIR_EXACT_REPLAY) != 0) : ov) list[atomicAdd(count, 1u)] = i;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

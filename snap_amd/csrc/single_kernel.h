@@ -34,10 +34,10 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     al.heads = (uint16_t *)sc;
     al.pool = (Elem *)(sc + (size_t)a.cfg.ht_size * 2);
     al.ag_scratch = sc + (size_t)a.cfg.ht_size * 2 + (size_t)a.cfg.pool_size * sizeof(Elem);
-    al.ag_persist[0] = al.ag_persist[1] = nullptr;
-    if constexpr (EXACT) {
-        al.ag_persist[0] = a.persist + (size_t)wave_slot * a.persist_stride;
-        al.ag_persist[1] = al.ag_persist[0] + a.persist_stride / 2;
+    al.ag_persist0 = al.ag_persist1 = nullptr; al.ag_hw0 = al.ag_hw1 = 0;
+    if constexpr (EXACT) {              // (the host zeroes the images when it allocates them; from then on each unit clears what the last one wrote)
+        al.ag_persist0 = a.persist + (size_t)wave_slot * a.persist_stride;
+        al.ag_persist1 = al.ag_persist0 + a.persist_stride / 2;
     }
     if constexpr (SEC) {            // secondary-result scratch of this wave (snapgpu_enable_secondary)
         uint8_t *ss = a.sec_scratch + (size_t)wave_slot * a.sec_stride_bytes;
@@ -50,23 +50,29 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t n_done = 0;
 
-    const uint32_t n_total = EXACT ? first_u32(*a.n_remap) : a.n_reads;
+    // EXACT kernels run either over a list of flagged reads (remap: the replay pass behind the register variants for long reads) or, as
+    // the main pass of the 192-position variant, over the whole batch
+    const uint32_t n_total = a.remap ? first_u32(*a.n_remap) : a.n_reads;
     while (true) {
         uint32_t i = 0;
         if (lane == 0) i = atomicAdd(a.work_counter, 1u);
         i = first_u32(i);
         if (i >= n_total) break;
         if constexpr (EXACT) {          // a newly constructed reference aligner: both traceback arrays read as zero
-            i = first_u32(a.remap[i]);
-            wave_zero16(al.ag_persist[0], (size_t)a.persist_stride);
+            if (a.remap) i = first_u32(a.remap[i]);
+            if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
+            if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
+            al.ag_hw0 = al.ag_hw1 = 0;
             WAVE_SYNC();
         }
         uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
         al.align_read(a.bases + b, a.quals + b, (int)(e - b));
         WAVE_SYNC();
         if constexpr (!EXACT) {         // traceback left the band somewhere: the exact pass redoes this read
-            if (a.flag_list && ws->primary.reserved != 0 && lane == 0) a.flag_list[atomicAdd(a.flag_count, 1u)] = i;
+            if (a.flag_list && (ws->primary.reserved & 0x40000000u) && lane == 0) a.flag_list[atomicAdd(a.flag_count, 1u)] = i;
         }
+        if (EXACT && lane == 0) ws->primary.reserved |= 0x80000000u;       // this record is the exact pass's answer
+        WAVE_SYNC();
         {   // results: LDS -> global, one dword per lane
             const uint32_t *src = (const uint32_t *)&ws->primary;
             uint32_t *dst = (uint32_t *)&a.primary[i];
@@ -97,7 +103,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         }
         n_done++;
     }
-    if (lane == 0 && !EXACT) {          // (a replayed read was already counted by the fast pass)
+    if (lane == 0 && (!EXACT || !a.remap)) {          // (a replayed read was already counted by the fast pass)
         atomicAdd(&a.counters[0], (unsigned long long)n_done);
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
         atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);

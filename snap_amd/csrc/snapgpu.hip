@@ -260,6 +260,8 @@ struct snapgpu_ctx {
     // exact replay of flagged reads / pairs: the reference's traceback arrays per replay wave (2 per read, 4 per pair)
     uint8_t *d_exact_persist = nullptr; uint64_t exact_persist_stride = 0; uint32_t exact_slots = 0;
     uint8_t *d_pexact_persist = nullptr; uint64_t pexact_persist_stride = 0; uint32_t pexact_slots = 0;
+    // 192-position variant: the exact kernels ARE the main pass (every wave keeps the images; each unit clears what the last one wrote)
+    bool always_exact = false, p_always_exact = false;
     // Phase-4 help (paired_dev.h): [done counter | slots] and the per-slot PEHelpSpec arrays
     uint8_t *d_help = nullptr; size_t help_bytes = 0; uint32_t n_help = 0; PEHelpSpec *d_help_spec = nullptr; uint32_t help_spec_cap = 0; uint32_t help_min = 0;
     uint32_t p_wave_slots = 0, p_big_slots = 0, p_lds_per_wave = 0;
@@ -641,10 +643,15 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     CRCHK(hipMalloc((void **)&ctx->d_scratch, scratch_total), SNAPGPU_E_NOMEM);
     // the head tables must start zeroed (one fill of the whole slab is cheaper than a fill per wave)
     CRCHK(hipMemsetAsync(ctx->d_scratch, 0, scratch_total, ctx->stream), SNAPGPU_E_NODEVICE);
-    if (c.use_ag) {                     // exact replay (kernel_common.h: AlignArgs::persist): 64 waves are plenty for a handful of reads per batch
-        ctx->exact_slots = ctx->n_wave_slots < 64 ? ctx->n_wave_slots : 64;
+    if (c.use_ag) {
+        // Exactness of the banded affine-gap traceback.  192-position variant (reads up to ~170 bp): every wave keeps
+        // the images of the reference objects' traceback arrays and the exact kernel is the only pass.  Longer reads: fast pass with the
+        // arrays forgotten between calls + a replay of the flagged reads on 64 waves (kernel_common.h: AlignArgs::persist).
+        ctx->always_exact = ctx->ag_variant == 3 && !getenv("SNAPGPU_NO_ALWAYS_EXACT");
+        ctx->exact_slots = ctx->always_exact ? ctx->n_wave_slots : (ctx->n_wave_slots < 64 ? ctx->n_wave_slots : 64);
         ctx->exact_persist_stride = 2 * (uint64_t)((ag_bytes + 255) & ~(size_t)255);
         CRCHK(hipMalloc((void **)&ctx->d_exact_persist, (size_t)ctx->exact_slots * ctx->exact_persist_stride), SNAPGPU_E_NOMEM);
+        CRCHK(hipMemsetAsync(ctx->d_exact_persist, 0, (size_t)ctx->exact_slots * ctx->exact_persist_stride, ctx->stream), SNAPGPU_E_NODEVICE);
     }
     CRCHK(hipMalloc((void **)&ctx->d_work, 256), SNAPGPU_E_NOMEM);
     CRCHK(hipMalloc((void **)&ctx->d_counters, sizeof(snapgpu_counters)), SNAPGPU_E_NOMEM);
@@ -1421,7 +1428,8 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.sec_cfg = SecCfg{-1, -1, 0, 0}; a.sec_scratch = nullptr; a.sec_stride_bytes = 0; a.secondary = nullptr; a.sec_out_stride = 0; a.n_secondary = nullptr;
     a.flag_list = nullptr; a.flag_count = nullptr; a.remap = nullptr; a.n_remap = nullptr; a.persist = nullptr; a.persist_stride = 0;
-    const bool exact = ctx->d_exact_persist != nullptr && !getenv("SNAPGPU_NO_EXACT_REPLAY");
+    const bool always_exact = ctx->always_exact && ctx->d_exact_persist != nullptr;
+    const bool exact = !always_exact && ctx->d_exact_persist != nullptr && !getenv("SNAPGPU_NO_EXACT_REPLAY");
     if (exact) {
         if (ctx->flag_list_cap < n) {
             if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
@@ -1439,6 +1447,11 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     if (d_n_secondary) {
         a.sec_cfg = ctx->sec_cfg; a.sec_scratch = ctx->d_sec_scratch; a.sec_stride_bytes = ctx->sec_stride_bytes;
         a.secondary = (snapgpu_single_result *)d_secondary; a.sec_out_stride = sec_out_stride; a.n_secondary = (uint32_t *)d_n_secondary;
+    }
+    if (always_exact) {                 // one pass, exact by construction
+        a.persist = ctx->d_exact_persist; a.persist_stride = ctx->exact_persist_stride;
+        snapgpu_launch_single_exact_3(&a, d_n_secondary ? 1 : 0, blocks, 4 * ctx->cfg.lds_per_wave, s);
+    } else if (d_n_secondary) {
         switch (ctx->ag_variant) {
         case 3:  snapgpu_launch_single_sec_3(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
         case 4:  snapgpu_launch_single_sec_4(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
@@ -1819,10 +1832,13 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_help, ctx->help_bytes), SNAPGPU_E_NOMEM);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_help_spec, (size_t)ctx->n_help * ctx->help_spec_cap * sizeof(PEHelpSpec)), SNAPGPU_E_NOMEM);
     }
-    if (p.use_affine_gap) {             // exact replay of flagged pairs: four traceback arrays per replay wave
-        ctx->pexact_slots = 64;
+    if (p.use_affine_gap) {             // four traceback-array images per wave: every wave (192-position variant) or 64 replay waves
+        ctx->p_always_exact = ctx->p_ag_variant == 3 && !getenv("SNAPGPU_NO_ALWAYS_EXACT");
+        ctx->pexact_slots = ctx->p_always_exact ? (ctx->p_wave_slots > ctx->p_big_slots ? ctx->p_wave_slots : ctx->p_big_slots) : 64;
         ctx->pexact_persist_stride = 4 * (uint64_t)((ag_scratch_bytes(sc.RL) + 255) & ~(size_t)255);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_pexact_persist, (size_t)ctx->pexact_slots * ctx->pexact_persist_stride), SNAPGPU_E_NOMEM);
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_pexact_persist, 0, (size_t)ctx->pexact_slots * ctx->pexact_persist_stride, ctx->stream), SNAPGPU_E_NODEVICE);
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
     }
     ctx->heavy_first = getenv("SNAPGPU_PAIRED_HEAVY_FIRST") != nullptr && atoi(getenv("SNAPGPU_PAIRED_HEAVY_FIRST")) != 0;
     ctx->paired = true;
@@ -1859,7 +1875,16 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     const size_t lds = (size_t)4 * ctx->p_lds_per_wave;
-    auto launch = [&](const PairedArgs &x, uint32_t nblocks) {
+    // (the secondary-results kernels have fewer slots of their own: they keep the fast pass + replay scheme)
+    const bool p_always = ctx->p_always_exact && ctx->d_pexact_persist != nullptr && !so;
+    auto launch = [&](const PairedArgs &x0, uint32_t nblocks) {
+        if (p_always) {                        // one exact pass (plus the large-buffer pass for pairs that overflowed), nothing to replay
+            PairedArgs x = x0;
+            x.persist = ctx->d_pexact_persist; x.persist_stride = ctx->pexact_persist_stride;
+            snapgpu_launch_paired_exact_3(&x, nblocks, lds, s);
+            return;
+        }
+        const PairedArgs &x = x0;
         if (so) {                              // secondary results: the 192-position register variant, or the LDS form for everything longer
             if (ctx->p_ag_variant == 3) snapgpu_launch_paired_sec_3(&x, nblocks, lds, s);
             else snapgpu_launch_paired_sec_0(&x, nblocks, lds, s);
@@ -1912,7 +1937,7 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
         // third pass: pairs whose banded affine-gap traceback left the band are redone the way a newly constructed reference aligner
         // would do them (paired_dev.h: EXACT), in the large slabs of the second pass
-        if (ctx->d_pexact_persist && !getenv("SNAPGPU_NO_EXACT_REPLAY")) {
+        if (!p_always && ctx->d_pexact_persist && !getenv("SNAPGPU_NO_EXACT_REPLAY")) {
             uint32_t *d_count3 = ctx->d_work + 4, *d_work3 = ctx->d_work + 3;
             HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 3, 0, 8, s), SNAPGPU_E_LAUNCH);
             snapgpu_launch_collect_flagged((const snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count3, 1, s);
