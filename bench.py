@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--max-k", type=int, default=8)
     ap.add_argument("--seed", type=int, default=20260925)
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline (0 = auto, ~10-30 s)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every GPU aligns --reads reads per step; strong: --reads is the whole job's batch, split evenly over the GPUs")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-probe", action="store_true", help="skip the stand-alone index-probe measurement (roofline.probe)")
     ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
@@ -111,6 +113,8 @@ def main():
             raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    if args.scaling == "strong":        # the whole job's batch split over the ranks (each rank still draws its own reads: they are i.i.d.)
+        args.reads = max(2, (args.reads // max(1, world)) & ~1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -222,7 +226,7 @@ def main():
         "metric": "aligned reads/sec (whole node), 150 bp %s vs synthetic %d Mb genome (GRCh38 unavailable), seed=20, maxDist=%d"
                   % ("paired-end (2x150 FR pairs)" if paired else "single-end", args.genome_mb, args.max_k),
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8 bases / int32 DP / f64 match probability", "data": "synthetic",
         "config": {"workload": ("configs[2]: %d pairs of 2 x %d bp (FR, insert N(400,50^2)) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
                                 % (n_units, args.read_len, args.max_k, args.seed_len, args.genome_mb)) if paired else

@@ -69,7 +69,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
-    int num_vec, int seg_len, int num_seg)
+    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes)
 {
     const int lane = lane_id();
     AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
@@ -79,7 +79,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     const int tot = num_seg * seg_len;                  // positions that exist in the striped layout
     const int nch = (tot + 63) >> 6;
     const int row_stride = EXACT ? tot : nch * 64;      // EXACT: numVec * numSeg * 8 bytes per row, as in the reference
-    const BtSink sink = bt_sink(bt_scratch);
+    const BtSink sink = bt_sink(bt_scratch, bt_bytes);
     // LDS scratch of the lazy-F rounds: F leaving each of the 8 stripes in the first pass, and one "some lane of vector k
     // continues" tag per vector (tags instead of a bitmap: no clearing, no atomics)
     int *lds_end = (int *)lds_rows + 2;                  // [8]
@@ -344,7 +344,8 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
             if constexpr (EXACT) {
                 int vi = 0, li = 0;
                 if (ok) { const int cj = ct / seg_len, cr = ct - cj * seg_len; vi = cj * num_vec + cr % num_vec; li = cr / num_vec; }
-                cell = ok ? (int)bt_scratch[(size_t)rt * row_stride + (size_t)(vi * 8 + li)] : 0;
+                const uint32_t at = (uint32_t)rt * (uint32_t)row_stride + (uint32_t)(vi * 8 + li);
+                cell = (ok && at < bt_bytes) ? (int)bt_scratch[at] : 0;
             } else {
                 cell = computed ? (int)bt_scratch[(size_t)rt * row_stride + ct] : 0;
             }

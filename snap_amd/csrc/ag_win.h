@@ -26,7 +26,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
-    int num_vec, int seg_len, int num_seg)
+    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes)
 {
     const int lane = lane_id();
     AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
@@ -50,7 +50,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     const int rr = lane - segsel * seg_len;
     const int l = rr / num_vec, k = rr - l * num_vec;
     const bool is_x_lane = segsel == 1 && l == 0;                // stripe 0 of the window's second segment: where the F carried over enters
-    const BtSink sink = bt_sink(bt_scratch);
+    const BtSink sink = bt_sink(bt_scratch, bt_bytes);
     const int nv_tot8 = num_vec * num_seg * 8;                   // EXACT: bytes per row of the reference's array
     const int flat_lane = segsel * seg_len + k * 8 + l;          // EXACT: byte of this lane's cell inside the window's two segments
 
@@ -339,7 +339,8 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             if constexpr (EXACT) {
                 int vi = 0, li = 0;
                 if (ok) { const int cj = ct / seg_len, cr = ct - cj * seg_len; vi = cj * num_vec + cr % num_vec; li = cr / num_vec; }
-                cell = ok ? (int)bt_scratch[(size_t)rt * nv_tot8 + (size_t)(vi * 8 + li)] : 0;
+                const uint32_t at = (uint32_t)rt * (uint32_t)nv_tot8 + (uint32_t)(vi * 8 + li);
+                cell = (ok && at < bt_bytes) ? (int)bt_scratch[at] : 0;
             } else {
                 cell = computed ? (int)bt_scratch[(size_t)rt * 64 + (ct - wb)] : 0;
             }
@@ -403,15 +404,15 @@ static __device__ __forceinline__ AGResult ag_dispatch(
         }
         if (banded && 2 * seg_len <= 64)        // the band's two segments fit one wavefront: sliding-window form
             return ag_banded_win<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                        lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+                                        lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
         if (banded)
             return ag_compute_reg<AGC, true, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                                    lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+                                                    lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
         if (num_seg * seg_len <= 64)            // short pattern (e.g. the read's head before an early seed): one chunk, no chunk loops
             return ag_compute_reg<1, false, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                                   lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+                                                   lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
         return ag_compute_reg<AGC, false, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                                 lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg);
+                                                 lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
     } else {
         return ag_compute<EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
                                  lds_rows, bt_scratch, RL, tab);

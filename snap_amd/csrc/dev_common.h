@@ -102,12 +102,13 @@ struct BtSink {
     __amdgpu_buffer_rsrc_t rsrc;
 #endif
 };
-static __device__ __forceinline__ BtSink bt_sink(uint8_t *ubase) {
+// (n_bytes = size of the slab: the descriptor's range check drops a store that would land outside it)
+static __device__ __forceinline__ BtSink bt_sink(uint8_t *ubase, uint32_t n_bytes) {
     BtSink s;
 #if defined(SNAPGPU_WAVE_EMU)
-    s.base = ubase;
+    s.base = ubase; (void)n_bytes;
 #else
-    s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)first_u64((uint64_t)(uintptr_t)ubase), (short)0, 0x7ffff000, 0x00020000);
+    s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)first_u64((uint64_t)(uintptr_t)ubase), (short)0, (int)first_u32(n_bytes), 0x00020000);
 #endif
     return s;
 }

@@ -656,6 +656,12 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
             }
         }
     }
+    if constexpr (EXACT) {              // leave the images zeroed for the next launch (the high-water marks live in registers)
+        if (pl.ag_hw0) wave_zero16(pl.ag_persist0, ((size_t)pl.ag_hw0 + 15) & ~(size_t)15);
+        if (pl.ag_hw1) wave_zero16(pl.ag_persist1, ((size_t)pl.ag_hw1 + 15) & ~(size_t)15);
+        if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
+        if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
+    }
     if (lane == 0 && (!EXACT || !a.remap)) {          // (a replayed pair was already counted)
         if (!a.remap) atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);

@@ -103,6 +103,10 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         }
         n_done++;
     }
+    if constexpr (EXACT) {              // leave the images zeroed for the next launch (the high-water marks live in registers)
+        if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
+        if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
+    }
     if (lane == 0 && (!EXACT || !a.remap)) {          // (a replayed read was already counted by the fast pass)
         atomicAdd(&a.counters[0], (unsigned long long)n_done);
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
