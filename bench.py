@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline (0 = auto, ~10-30 s)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): every GPU aligns --reads reads per step; strong: --reads is the whole job's batch, split evenly over the GPUs")
+    ap.add_argument("--feeders", type=int, default=0,
+                    help="contexts per GPU, each with its own stream and result buffer, that take the steps in turn so that consecutive "
+                         "batches overlap on the GPU (what snapgpu-sam's feeder threads do).  0 = auto: 1 for single-end, 2 for paired-end "
+                         "(where a launch ends with a tail of few, heavy pairs that leaves most of the chip idle)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-probe", action="store_true", help="skip the stand-alone index-probe measurement (roofline.probe)")
     ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
@@ -152,24 +156,51 @@ def main():
     d_bases = torch.from_numpy(reads["bases"].reshape(-1)).to(dev)
     d_quals = torch.from_numpy(reads["quals"].reshape(-1)).to(dev)
     d_offs = torch.from_numpy(reads["offsets"].astype(np.int64)).to(dev)
-    d_prim = torch.zeros(n_units * res_dtype.itemsize, dtype=torch.uint8, device=dev)
+    # Feeders: contexts over the one resident index (snapgpu_create_replica, share_index), each with its own stream, slabs and result
+    # buffer.  Feeder f runs steps f, f + F, f + 2F, ... from a host thread of its own (the C ABI call blocks until its batch is done),
+    # so the tail of one batch -- a few heavy pairs on a few wavefronts -- overlaps the bulk of the next.  A step is still one pass of
+    # the hot path over one batch, and exactly --steps of them are inside the timed region.
+    n_feed = args.feeders if args.feeders > 0 else (2 if paired else 1)
+    n_feed = max(1, min(n_feed, max(1, args.steps)))
+    feeders = [aligner] + [aligner.replica() for _ in range(n_feed - 1)]
+    d_prims = [torch.zeros(n_units * res_dtype.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_feed)]
+    d_prim = d_prims[0]
     torch.cuda.synchronize()
 
-    def step():
-        aligner.align_device(n_units, d_bases.data_ptr(), d_quals.data_ptr(), d_offs.data_ptr(), d_prim.data_ptr())
+    def run_steps(k_steps):
+        def feed(f):
+            for _ in range(f, k_steps, n_feed):
+                feeders[f].align_device(n_units, d_bases.data_ptr(), d_quals.data_ptr(), d_offs.data_ptr(), d_prims[f].data_ptr())
+        if n_feed == 1:
+            feed(0)
+            return
+        import threading
+        errs = []
 
-    for _ in range(args.warmup):
-        step()
-    aligner.counters(reset=True)
-    aligner.kernel_time(reset=True)
+        def guarded(f):
+            try:
+                feed(f)
+            except BaseException as e:          # noqa: BLE001 -- re-raised in the main thread
+                errs.append(e)
+        ts = [threading.Thread(target=guarded, args=(f,)) for f in range(n_feed)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+
+    run_steps(max(args.warmup, n_feed if args.warmup else 0))      # (every feeder gets at least one warm-up batch)
+    for a_ in feeders:
+        a_.counters(reset=True)
+        a_.kernel_time(reset=True)
 
     # ---------------------------------------------------------------- timed region
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -177,9 +208,17 @@ def main():
     if dist is not None:
         elapsed = sd.max_over_ranks(elapsed, dev)
 
-    counters = aligner.counters()
-    kernel_ms, launches = aligner.kernel_time()
+    counters = {}
+    kernel_ms, launches = 0.0, 0
+    for a_ in feeders:
+        for k_, v_ in a_.counters().items():
+            counters[k_] = counters.get(k_, 0) + v_
+        ms_, nl_ = a_.kernel_time()
+        kernel_ms += ms_; launches += nl_
     prim = np.frombuffer(d_prim.cpu().numpy().tobytes(), dtype=res_dtype)
+    for d_other in d_prims[1:]:                 # every feeder aligned the same batch: their results must be the same bytes
+        if not torch.equal(d_other, d_prim):
+            raise SystemExit("bench.py: two feeders disagree on the same batch")
     if rank != 0:
         return
 
@@ -221,7 +260,9 @@ def main():
     per_launch = {k: v / max(1, launches) for k, v in counters.items()}
     alg_bytes, parts = algorithmic_bytes(per_launch, args.read_len, n)
     avg_ms = kernel_ms / max(1, launches)
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    # (with several feeders the launches overlap, so each one's hipEvent time is longer than its share of the chip: the rate is then
+    #  taken over the step time, bytes of one batch / (elapsed / steps))
+    achieved = alg_bytes / ((avg_ms if n_feed == 1 else 1e3 * elapsed / args.steps) * 1e-3) / 1e9
     out = {
         "metric": "aligned reads/sec (whole node), 150 bp %s vs synthetic %d Mb genome (GRCh38 unavailable), seed=20, maxDist=%d"
                   % ("paired-end (2x150 FR pairs)" if paired else "single-end", args.genome_mb, args.max_k),
@@ -233,7 +274,8 @@ def main():
                                ("configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
                                 % (n, args.read_len, args.max_k, args.seed_len, args.genome_mb)),
                    "reads_per_gpu": n, "read_len": args.read_len, "index_bytes_hbm": index_bytes,
-                   "parallelism": "reads sharded over %d GPU(s), index replicated%s" % (world, " by RCCL broadcast" if world > 1 else "")},
+                   "parallelism": "reads sharded over %d GPU(s), index replicated%s" % (world, " by RCCL broadcast" if world > 1 else ""),
+                   "feeders_per_gpu": n_feed},
         "roofline": {"kernel": "k_align_paired" if paired else "k_align_single", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "bytes_breakdown": parts, "avg_launch_ms": avg_ms,
@@ -250,7 +292,7 @@ def main():
                                               if k in counters}   # paired: lookup = Phase 1, hits = Phase 2 (set intersection), lv/ag = paired scoring
     out["roofline"]["wave_cycles_per_read"] = counters.get("cycles_total", 0) / max(1, counters["n_reads"])
     if paired:
-        out["roofline"]["phase4_help"] = {"watchdog_events": counters.get("help_watchdog_events", 0), "min_candidates": os.environ.get("SNAPGPU_PAIRED_HELP_MIN", "192 (default)")}
+        out["roofline"]["phase4_help"] = {"watchdog_events": counters.get("help_watchdog_events", 0), "min_candidates": os.environ.get("SNAPGPU_PAIRED_HELP_MIN", "0 (default: off)")}
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:

@@ -122,6 +122,28 @@ class BaseAligner:
         if rc != 0:
             raise SnapGpuError("snapgpu_create failed (%d): %s" % (rc, self.lib.snapgpu_last_error(None).decode()))
         self.handle = handle
+        self.device = device
+
+    def replica(self, device: int | None = None, share_index: bool = True):
+        """Another context over the same index (include/snapgpu.h: snapgpu_create_replica): on this GPU sharing the resident blobs -- a
+        second feeder, so that two batches can be in flight -- or on another GPU with blobs of its own (to be filled by
+        snapgpu_broadcast_index).  The analogue of the reference's one-aligner-per-thread over one shared GenomeIndex
+        (SNAPLib/AlignerContext.cpp: runTask)."""
+        self.lib.snapgpu_create_replica.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        dev = self.device if device is None else device
+        rc = self.lib.snapgpu_create_replica(self.handle, C.c_int(dev), C.c_int(1 if share_index else 0), C.byref(h))
+        if rc != 0:
+            raise SnapGpuError("snapgpu_create_replica failed (%d): %s" % (rc, self.lib.snapgpu_last_error(self.handle).decode()))
+        other = type(self).__new__(type(self))
+        other.__dict__.update(self.__dict__)
+        other.handle = h
+        other.device = dev
+        other._after_replica()
+        return other
+
+    def _after_replica(self):
+        pass
 
     def close(self):
         if getattr(self, "handle", None):
@@ -353,6 +375,9 @@ class ChimericPairedEndAligner(BaseAligner):
         self.paired_params = paired_params if paired_params is not None else default_paired_params()
         self.lib.snapgpu_enable_paired.argtypes = [C.c_void_p, C.POINTER(PairedParams)]
         self.lib.snapgpu_align_paired_device.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        self._check(self.lib.snapgpu_enable_paired(self.handle, C.byref(self.paired_params)), "snapgpu_enable_paired")
+
+    def _after_replica(self):               # (a replica starts as a single-end context)
         self._check(self.lib.snapgpu_enable_paired(self.handle, C.byref(self.paired_params)), "snapgpu_enable_paired")
 
     def align(self, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray):

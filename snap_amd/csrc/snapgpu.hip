@@ -1823,7 +1823,10 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     if (ctx->d_pexact_persist) { (void)hipFree(ctx->d_pexact_persist); ctx->d_pexact_persist = nullptr; }
     if (ctx->d_help) { (void)hipFree(ctx->d_help); ctx->d_help = nullptr; }
     if (ctx->d_help_spec) { (void)hipFree(ctx->d_help_spec); ctx->d_help_spec = nullptr; }
-    ctx->help_min = 192;                // Phase-4 lists at least this long are offered to idle waves; 0 = off (SNAPGPU_PAIRED_HELP_MIN)
+    // Phase-4 lists at least this long are offered to idle waves (SNAPGPU_PAIRED_HELP_MIN=<n>).  Off unless asked for: measured on the
+    // bench workload (profiles/r02f) it gains nothing -- 32 slots are always held by pairs that are merely long, the heaviest pair of
+    // the launch rarely gets one, and every pair scored speculatively counts its out-of-band traceback steps as "later call" ones.
+    ctx->help_min = 0;
     if (const char *e = getenv("SNAPGPU_PAIRED_HELP_MIN")) ctx->help_min = (uint32_t)strtoul(e, nullptr, 10);
     if (p.use_affine_gap && ctx->help_min != 0) {
         ctx->n_help = 32;
@@ -1833,7 +1836,9 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_help_spec, (size_t)ctx->n_help * ctx->help_spec_cap * sizeof(PEHelpSpec)), SNAPGPU_E_NOMEM);
     }
     if (p.use_affine_gap) {             // four traceback-array images per wave: every wave (192-position variant) or 64 replay waves
-        ctx->p_always_exact = ctx->p_ag_variant == 3 && !getenv("SNAPGPU_NO_ALWAYS_EXACT");
+        // (SNAPGPU_PAIRED_ALWAYS_EXACT=1: the exact kernel as the main pass, as on the single-end path.  Not the default: on the 256 Mb /
+        //  500 k-pair bench batch it stops with a memory access fault that smaller batches and genomes do not show -- profiles/r02g.)
+        ctx->p_always_exact = ctx->p_ag_variant == 3 && getenv("SNAPGPU_PAIRED_ALWAYS_EXACT") != nullptr && atoi(getenv("SNAPGPU_PAIRED_ALWAYS_EXACT")) != 0;
         ctx->pexact_slots = ctx->p_always_exact ? (ctx->p_wave_slots > ctx->p_big_slots ? ctx->p_wave_slots : ctx->p_big_slots) : 64;
         ctx->pexact_persist_stride = 4 * (uint64_t)((ag_scratch_bytes(sc.RL) + 255) & ~(size_t)255);
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_pexact_persist, (size_t)ctx->pexact_slots * ctx->pexact_persist_stride), SNAPGPU_E_NOMEM);

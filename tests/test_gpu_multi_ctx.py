@@ -56,3 +56,35 @@ def test_replica_sharing_the_index_answers_like_the_original(golden_index, golde
         lib.snapgpu_destroy(h2)
         b.handle = None                     # (b borrowed a's Python state; its context is gone)
         a.close()
+
+
+@pytest.mark.gpu
+def test_paired_feeders_two_batches_in_flight():
+    """bench.py --feeders 2 / snapgpu-sam's two feeders per GPU on the paired-end path: a replica made by the Python mirror
+    (BaseAligner.replica -> snapgpu_create_replica + snapgpu_enable_paired) aligns the same pairs, at the same time, to the same bytes."""
+    from snap_amd.aligner import ChimericPairedEndAligner
+    from tests.pairs_util import compare_paired
+    import os
+    zp = np.load(os.path.join(util.GOLDEN, "paired_reads.npz"))
+    a = ChimericPairedEndAligner(util.load_golden_index("paired_index.npz"), abi.default_params(max_k=8, max_read_len=160),
+                                 abi.default_paired_params())
+    b = a.replica()
+    try:
+        n_pairs = 200
+        o = zp["o150"][:2 * n_pairs + 1]
+        bases, quals = zp["b150"][:int(o[-1])], zp["q150"][:int(o[-1])]
+        out = {}
+
+        def run(al, key):
+            out[key] = al.align(bases, quals, o)[0]
+        ts = [threading.Thread(target=run, args=(a, "a")), threading.Thread(target=run, args=(b, "b"))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert out["a"].tobytes() == out["b"].tobytes()
+        exp, _ = util.with_fresh_overrides(zp["default_d8_150_s0_primary"], "pe_default_d8_150_s0_primary")
+        assert not compare_paired(exp[:n_pairs], out["b"], verbose=0).any()
+    finally:
+        b.close()
+        a.close()
