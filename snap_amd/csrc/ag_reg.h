@@ -82,10 +82,17 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     const BtSink sink = bt_sink(bt_scratch, bt_bytes);
     // LDS scratch of the lazy-F rounds: F leaving each of the 8 stripes in the first pass, and one "some lane of vector k
     // continues" tag per vector (tags instead of a bitmap: no clearing, no atomics)
-    int *lds_end = (int *)lds_rows + 2;                  // [8]
-    uint32_t *lds_flag = (uint32_t *)lds_rows + 16;      // [num_vec <= 1023]
+    LDS_AS int *lds_end = (LDS_AS int *)lds_rows + 2;                  // [8]
+    LDS_AS uint32_t *lds_flag = (LDS_AS uint32_t *)lds_rows + 16;      // [num_vec <= 1023]
     uint32_t flag_tag = 0;
     for (int kz = lane_id(); kz < num_vec; kz += WAVE) lds_flag[kz] = 0;     // tags of an earlier call must not look current
+    // base codes of the text, staged once: a per-row read of T(i) is a FLAT load of a generic pointer, and its wait (vmcnt) is also a
+    // wait for the previous row's traceback store.  (64 + 4 * num_vec + text_len <= 384 + RL < ag_lds_bytes(RL) for every AGC > 0.)
+    LDS_AS uint8_t *tcode = (LDS_AS uint8_t *)(lds_flag + num_vec);
+    for (int i0 = 0; i0 < text_len; i0 += WAVE) {
+        const int i = i0 + lane;
+        if (i < text_len) tcode[i] = (uint8_t)base_value(T(i));
+    }
     WAVE_SYNC();
 
     int end_bonus;
@@ -122,7 +129,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     const int pe_glob = pattern_len - 1, pe_glob_c = pe_glob >> 6, pe_glob_l = pe_glob & 63;
 
     for (int i = 0; i < text_len; i++) {
-        const int tb = (int)base_value(T(i));
+        const int tb = (int)first_u32(tcode[i]);
         int band_beg = 0, band_end = pattern_len - 1;
         if (BANDED) {
             band_beg = i - w > 0 ? i - w : 0;

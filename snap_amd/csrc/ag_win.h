@@ -37,9 +37,9 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     // LDS tables (the H/E rows of the LDS formulation are not used here): what the row loop would otherwise recompute or
     // reload -- first-row H per position, base codes of pattern and text.  (The window base of row i needs no table: the
     // window slides whenever the band start enters the next segment, so it is seg_len * (max(i - w, 0) / seg_len).)
-    int16_t  *fr16 = (int16_t *)(lds_rows + 8);                             // [tot]   first_row(p)
-    uint8_t  *pcode = (uint8_t *)(fr16 + ((tot + 7) & ~7));                // [tot]   base_value(P(p)), 5 beyond the pattern
-    uint8_t  *tcode = pcode + ((tot + 15) & ~15);                          // [text_len] base_value(T(i))
+    LDS_AS int16_t  *fr16 = (LDS_AS int16_t *)(lds_rows + 8);               // [tot]   first_row(p)
+    LDS_AS uint8_t  *pcode = (LDS_AS uint8_t *)(fr16 + ((tot + 7) & ~7));  // [tot]   base_value(P(p)), 5 beyond the pattern
+    LDS_AS uint8_t  *tcode = pcode + ((tot + 15) & ~15);                   // [text_len] base_value(T(i))
 
     int end_bonus;
     if (!is_rc) end_bonus = dir == -1 ? prm.five_bonus : prm.three_bonus;
@@ -384,8 +384,8 @@ static __device__ __forceinline__ AGResult ag_banded_win(
 
 // AGC > 0: register formulation with AGC chunks of 64 positions (the host guarantees it fits);
 // AGC == 0: the LDS formulation of ag.h (any pattern length up to RL).
-template <int AGC, bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
-static __device__ __forceinline__ AGResult ag_dispatch(
+template <int AGC, bool EXACT, typename PSeq, typename TSeq, typename QSeq>
+static __device__ __forceinline__ AGResult ag_dispatch_inl(
     bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
@@ -417,4 +417,48 @@ static __device__ __forceinline__ AGResult ag_dispatch(
         return ag_compute<EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
                                  lds_rows, bt_scratch, RL, tab);
     }
+}
+
+// The affine-gap code as ONE function per kernel instead of one inlined copy per call site.  k_align_paired reaches ag_dispatch from 24
+// places (Phases 3 and 4, the speculative Phase-4 scoring, the single-end aligner of the chimeric fallback ...), each copy ~40 KB of code:
+// 1.3 MB of kernel against a 64 KB instruction cache shared by two CUs, every copy allocated out of the caller's 256 VGPRs (1 600 bytes of
+// scratch per lane, 4 500 SGPR spills).  A call costs a few hundred cycles against the ~10^5 of the work it starts.  Arguments arrive in
+// VGPRs under the device calling convention, so everything wave-uniform is made scalar again on entry.
+
+template <int AGC, bool EXACT, typename PSeq, typename TSeq, typename QSeq>
+static __device__ __attribute__((noinline)) AGResult ag_dispatch_fn(
+    uint32_t flags, AGParams prm_in, PSeq P_in, QSeq Q_in, int pattern_len,
+    TSeq T_in, int text_len, int w, int score_init, int use_clipping,
+    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
+{
+    flags = first_u32(flags);
+    const bool banded = (flags & 1u) != 0, is_rc = (flags & 2u) != 0;
+    const int dir = (flags & 4u) ? -1 : 1;
+    AGParams prm;
+    prm.match_reward = (int)first_u32((uint32_t)prm_in.match_reward); prm.sub_penalty = (int)first_u32((uint32_t)prm_in.sub_penalty);
+    prm.gap_open = (int)first_u32((uint32_t)prm_in.gap_open); prm.gap_extend = (int)first_u32((uint32_t)prm_in.gap_extend);
+    prm.five_bonus = (int)first_u32((uint32_t)prm_in.five_bonus); prm.three_bonus = (int)first_u32((uint32_t)prm_in.three_bonus);
+    const PSeq P = seq_uniform(P_in); const QSeq Q = seq_uniform(Q_in); const TSeq T = seq_uniform(T_in);
+    pattern_len = (int)first_u32((uint32_t)pattern_len); text_len = (int)first_u32((uint32_t)text_len);
+    w = (int)first_u32((uint32_t)w); score_init = (int)first_u32((uint32_t)score_init); use_clipping = (int)first_u32((uint32_t)use_clipping);
+    lds_rows = (int16_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)lds_rows);
+    bt_scratch = (uint8_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)bt_scratch);
+    RL = first_u32(RL);
+    tab = (const DevTables *)(uintptr_t)first_u64((uint64_t)(uintptr_t)tab);
+    return ag_dispatch_inl<AGC, EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
+                                       lds_rows, bt_scratch, RL, tab);
+}
+
+template <int AGC, bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
+static __device__ __forceinline__ AGResult ag_dispatch(
+    bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
+    const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
+    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
+{
+#if !defined(SNAPGPU_AG_LV_FUNCTIONS)
+    return ag_dispatch_inl<AGC, EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping, lds_rows, bt_scratch, RL, tab);
+#else
+    const uint32_t flags = (banded ? 1u : 0u) | (is_rc ? 2u : 0u) | (dir == -1 ? 4u : 0u);
+    return ag_dispatch_fn<AGC, EXACT, PSeq, TSeq, QSeq>(flags, prm, P, Q, pattern_len, T, text_len, w, score_init, use_clipping, lds_rows, bt_scratch, RL, tab);
+#endif
 }

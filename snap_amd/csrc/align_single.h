@@ -209,7 +209,9 @@ struct Aligner {
         if constexpr (EXACT) {
             int nv, sl, ns;
             ag_dims(banded, plen, w > 126 ? 126 : (w < 0 ? 0 : w), &nv, &sl, &ns);
-            const uint32_t ext = (uint32_t)tlen * (uint32_t)(ns * sl);
+            uint32_t ext = (w >= 0 && tlen > 0) ? (uint32_t)tlen * (uint32_t)(ns * sl) : 0u;      // (see DevPL::ag)
+            const uint32_t image = (uint32_t)ag_scratch_bytes(cfg.RL);
+            if (ext > image) ext = image;
             if (obj == 0) ag_hw0 = ext > ag_hw0 ? ext : ag_hw0; else ag_hw1 = ext > ag_hw1 ? ext : ag_hw1;
         }
     }

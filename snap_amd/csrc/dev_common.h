@@ -11,6 +11,13 @@
 #include <stdint.h>
 
 #define WAVE 64
+// Pointers known to point into LDS: inside a function that is NOT inlined into the kernel the compiler cannot see that a generic
+// pointer came from the kernel's LDS block and emits FLAT loads (both counters, slower) -- the explicit address space gives ds_read / ds_write.
+#if defined(SNAPGPU_WAVE_EMU)
+#define LDS_AS
+#else
+#define LDS_AS __attribute__((address_space(3)))
+#endif
 
 // One wavefront's LDS operations, and its vector-memory operations, are each executed in
 // issue order by the hardware (LLVM AMDGPU memory model: wavefront scope needs no cache

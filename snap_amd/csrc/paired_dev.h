@@ -360,7 +360,11 @@ struct DevPL {
         if constexpr (EXACT) {
             int nv, sl, ns;
             ag_dims(banded, plen, lim > 126 ? 126 : (lim < 0 ? 0 : lim), &nv, &sl, &ns);
-            const uint32_t ext = (uint32_t)tlen * (uint32_t)(ns * sl);
+            // (a call with a negative limit or an empty text writes nothing -- and its text length must not be trusted; nothing is ever
+            //  written past the image either: ag_dispatch stops the kernel first)
+            uint32_t ext = (lim >= 0 && tlen > 0) ? (uint32_t)tlen * (uint32_t)(ns * sl) : 0u;
+            const uint32_t image = (uint32_t)ag_scratch_bytes(al->cfg.RL);
+            if (ext > image) ext = image;
             if (st == 1) ag_hw0 = ext > ag_hw0 ? ext : ag_hw0; else ag_hw1 = ext > ag_hw1 ? ext : ag_hw1;
         }
         AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, Ps, Qs, plen, Ts, tlen, lim, read_len, is_rc, use_clip, al->ag_rows,

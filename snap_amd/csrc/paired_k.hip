@@ -3,6 +3,10 @@
 // (k_align_paired inlines the whole paired + single-end control flow; compiling the four variants in parallel keeps
 // the build at minutes instead of tens of minutes).
 #include <hip/hip_runtime.h>
+// The affine-gap and Landau-Vishkin code as one function each instead of an inlined copy per call site (ag_win.h: ag_dispatch_fn): this
+// kernel runs 2 waves per SIMD, so the functions have all the registers they want.  The single-end kernels (6 waves per SIMD, two call
+// sites) keep the inlined form: a callee cannot be given the kernel's register budget from HIP source.
+#define SNAPGPU_AG_LV_FUNCTIONS 1
 #include "paired_dev.h"
 
 #ifndef PAIRED_AGC
