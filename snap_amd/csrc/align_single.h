@@ -51,6 +51,10 @@ struct AlignCfg {
     uint64_t scratch_stride;           // bytes of HBM scratch per wave
     uint32_t lds_per_wave;
     uint32_t ag_numvec_max;            // ceil(RL/8)
+    // The affine-gap LDS rows and traceback slab exist: use_ag, or the paired-end path with soft clipping, whose Hamming retry calls
+    // BaseAligner::alignAffineGap whatever useAffineGap says (ChimericPairedEndAligner.cpp:330-360: the _ASSERT(useAffineGap) there is
+    // compiled out of a release build).
+    uint32_t ag_buffers;
 };
 
 struct __attribute__((aligned(16))) Elem {   // HashTableElement, BaseAligner.h:223-258

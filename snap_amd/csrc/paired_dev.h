@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     const int lane = lane_id();
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
-    const LdsLayout SL = lds_layout(a.scfg.RL, a.scfg.num_weight_lists, a.scfg.kmax, a.scfg.use_ag);
+    const LdsLayout SL = lds_layout(a.scfg.RL, a.scfg.num_weight_lists, a.scfg.kmax, a.scfg.ag_buffers);
     const PairedLds PLd = paired_lds_layout(SL.total, a.scfg.RL, a.pcfg.max_seeds);
     uint8_t *my = lds + (size_t)wave_in_block * PLd.total;
     uint8_t *sc = a.scratch + (size_t)wave_slot * a.stride;

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     const int lane = lane_id();
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: keeps the LDS/scratch pointers in SGPRs
     const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
-    const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax, a.cfg.use_ag);
+    const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax, a.cfg.ag_buffers);
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
     WaveShared *ws = (WaveShared *)(my + L.shared);

@@ -603,7 +603,7 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     AlignCfg &c = ctx->cfg;
     c.max_hits = p->max_hits; c.max_k = p->max_k; c.num_seeds = p->num_seeds;
     c.min_weight = p->min_weight_to_check < 1 ? 1 : p->min_weight_to_check;   // max(1u, ...), BaseAligner.cpp:83
-    c.extra_depth = p->extra_search_depth; c.use_ag = p->use_affine_gap ? 1 : 0;
+    c.extra_depth = p->extra_search_depth; c.use_ag = p->use_affine_gap ? 1 : 0; c.ag_buffers = c.use_ag;
     c.match_reward = (int)p->match_reward; c.sub_penalty = (int)p->sub_penalty;
     c.gap_open = (int)p->gap_open_penalty; c.gap_extend = (int)p->gap_extend_penalty;
     c.five_bonus = (int)p->five_prime_end_bonus; c.three_bonus = (int)p->three_prime_end_bonus;
@@ -626,9 +626,9 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         ctx->ag_variant = need <= 192 ? 3 : need <= 256 ? 4 : need <= 384 ? 6 : 0;
         if (getenv("SNAPGPU_AG_LDS")) ctx->ag_variant = 0;
     }
-    size_t ag_bytes = c.use_ag ? ag_scratch_bytes(c.RL) : 0;
+    size_t ag_bytes = c.ag_buffers ? ag_scratch_bytes(c.RL) : 0;
     c.scratch_stride = ((size_t)c.ht_size * 2 + (size_t)c.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
-    LdsLayout L = lds_layout(c.RL, c.num_weight_lists, c.kmax, c.use_ag);
+    LdsLayout L = lds_layout(c.RL, c.num_weight_lists, c.kmax, c.ag_buffers);
     c.lds_per_wave = L.total;
 
     // waves in flight: a fixed number per CU, each with its own scratch slab
@@ -1647,7 +1647,7 @@ extern "C" void snapgpu_default_paired_params(snapgpu_paired_params *pp) {      
 static void paired_lay_out(PairedArgs &x, bool sec) {
     const AlignCfg &sc = x.scfg;
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    size_t ag_bytes = sc.use_ag ? ag_scratch_bytes(sc.RL) : 0;
+    size_t ag_bytes = sc.ag_buffers ? ag_scratch_bytes(sc.RL) : 0;
     size_t off = up((size_t)sc.ht_size * 2 + (size_t)sc.pool_size * sizeof(Elem) + ag_bytes);
     x.off_single_agc = off; off += up((size_t)x.single_agc_cap * sizeof(snapgpu_single_result));
     x.off_cand = off;   off += up((size_t)x.pcfg.pool_size * sizeof(PECand));
@@ -1741,6 +1741,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     if (kmax_lv < 31) kmax_lv = 31;                              // the LV triangle doubles as 2 KB of counters for the Phase-4 counting sort
     sc.kmax = kmax_lv;
     a.kmax_lv = kmax_lv;
+    sc.ag_buffers = (sc.use_ag || (pp->use_soft_clipping && pp->enable_hamming_scoring_base_aligner)) ? 1u : 0u;
     a.scfg = sc;
 
     PECfg &c = a.pcfg;
@@ -1794,7 +1795,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     big.single_agc_cap = a.single_agc_cap * 32;
     paired_lay_out(big, false);
 
-    LdsLayout SL = lds_layout(sc.RL, sc.num_weight_lists, sc.kmax, sc.use_ag);
+    LdsLayout SL = lds_layout(sc.RL, sc.num_weight_lists, sc.kmax, sc.ag_buffers);
     PairedLds PL = paired_lds_layout(SL.total, sc.RL, c.max_seeds);
     ctx->p_lds_per_wave = PL.total;
     if ((size_t)4 * PL.total > 160 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "per-pair LDS state exceeds 40 KiB per wave");
