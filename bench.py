@@ -72,7 +72,7 @@ def algorithmic_bytes(c, read_len, n_reads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = auto: 4 single-end, 6 paired-end: a multiple of the feeders)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mb", type=int, default=256)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
@@ -85,14 +85,17 @@ def main():
                     help="weak (default): every GPU aligns --reads reads per step; strong: --reads is the whole job's batch, split evenly over the GPUs")
     ap.add_argument("--feeders", type=int, default=0,
                     help="contexts per GPU, each with its own stream and result buffer, that take the steps in turn so that consecutive "
-                         "batches overlap on the GPU (what snapgpu-sam's feeder threads do).  0 = auto: 1 for single-end, 2 for paired-end "
-                         "(where a launch ends with a tail of few, heavy pairs that leaves most of the chip idle)")
+                         "batches overlap on the GPU (what snapgpu-sam's feeder threads do).  0 = auto: 2 for single-end, 3 for paired-end "
+                         "(a launch ends with a tail of few, heavy reads / pairs that leaves most of the chip idle: measured, profiles/r02i, "
+                         "1 -> 2 feeders: 4.20 -> 6.28 M reads/s single-end; 1 / 2 / 3 / 4 feeders: 119 / 174 / 210 / 189 k reads/s paired-end)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-probe", action="store_true", help="skip the stand-alone index-probe measurement (roofline.probe)")
     ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
     ap.add_argument("--workload", choices=["single", "paired"], default="single",
                     help="single = configs[1] (the metric's config); paired = configs[2], 2x150 bp FR pairs through the paired-end path")
     args = ap.parse_args()
+    if args.steps <= 0:
+        args.steps = 6 if args.workload == "paired" else 4
 
     # stdout carries exactly ONE JSON line: anything libraries print to fd 1 (RCCL prints a version
     # banner there) is sent to stderr instead; the JSON goes to the saved descriptor at the end.
@@ -160,7 +163,7 @@ def main():
     # buffer.  Feeder f runs steps f, f + F, f + 2F, ... from a host thread of its own (the C ABI call blocks until its batch is done),
     # so the tail of one batch -- a few heavy pairs on a few wavefronts -- overlaps the bulk of the next.  A step is still one pass of
     # the hot path over one batch, and exactly --steps of them are inside the timed region.
-    n_feed = args.feeders if args.feeders > 0 else (2 if paired else 1)
+    n_feed = args.feeders if args.feeders > 0 else (3 if paired else 2)
     n_feed = max(1, min(n_feed, max(1, args.steps)))
     feeders = [aligner] + [aligner.replica() for _ in range(n_feed - 1)]
     d_prims = [torch.zeros(n_units * res_dtype.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_feed)]
@@ -279,6 +282,10 @@ def main():
         "roofline": {"kernel": "k_align_paired" if paired else "k_align_single", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "bytes_breakdown": parts, "avg_launch_ms": avg_ms,
+                     # with F feeders F launches share the chip, so one launch's hipEvent duration (= rocprofv3's kernel average) is ~F x
+                     # its share: `achieved` is then bytes per batch / time per batch; the per-launch figure is kept beside it
+                     "achieved_basis": "bytes per launch / hipEvent launch duration" if n_feed == 1 else "bytes per batch / (elapsed / steps): %d launches overlap" % n_feed,
+                     "achieved_per_overlapped_launch": alg_bytes / (avg_ms * 1e-3) / 1e9,
                      "per_read": {"hash_lookups": per_launch["n_hash_table_lookups"] / n, "hash_slots": per_launch["n_hash_slots_probed"] / n,
                                   "hits": per_launch["n_hits_consumed"] / n, "lv_locations": per_launch["n_lv_locations"] / n,
                                   "ag_locations": per_launch["n_ag_locations"] / n}},
@@ -308,11 +315,11 @@ def main():
                     # 256 CUs x 4 SIMD32s, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: v_fma_f32 wave64 =
                     # 2 cycles), 2.4 GHz  =>  256 * 4 * 2.4e9 / 2 = 1228.8 G wave-instructions/s
                     peak = 256 * 4 * 2.4e9 / 2 / 1e9
-                    ach = t["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
+                    ach = t["valu_insts_per_launch"] / ((avg_ms if n_feed == 1 else 1e3 * elapsed / args.steps) * 1e-3) / 1e9
                     out["roofline"]["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
                                                      "valu_insts_per_read": t["valu_insts_per_launch"] / n,
                                                      "salu_insts_per_read": t.get("salu_insts_per_launch", 0) / n,
-                                                     "source": "instruction counts replayed from profiles/pmc_latest.json ('%s'); launch time of this run" % t.get("source", "?")}
+                                                     "source": "instruction counts replayed from profiles/pmc_latest.json ('%s'); time per batch of this run" % t.get("source", "?")}
         except Exception:
             pass
 
