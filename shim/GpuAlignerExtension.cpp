@@ -41,8 +41,16 @@
 
 extern const char *SNAP_VERSION;                                   // SNAPLib/CommandProcessor.cpp:39
 
-static pthread_mutex_t g_gpuLock = PTHREAD_MUTEX_INITIALIZER;      // one context, calls serialised
-static snapgpu_ctx *g_ctx = NULL;
+// One context per (GPU, feeder): the counterpart of the reference's one aligner object per thread over one shared GenomeIndex
+// (SNAPLib/ParallelTask.h:128-138, SNAPLib/SingleAligner.cpp:197).  The first context loads the index; every further GPU gets
+// same-size blobs filled by snapgpu_broadcast_index (RCCL over xGMI); every GPU gets SNAPGPU_SHIM_FEEDERS (default 2) contexts that share
+// its blobs, so that the batch of one worker thread is on the GPU while another's finishes.  Worker thread t uses context t mod N; only
+// workers that share a context wait for each other (g_setupLock covers set-up alone).
+struct GpuSlot { snapgpu_ctx *ctx; pthread_mutex_t lock; };
+static pthread_mutex_t g_setupLock = PTHREAD_MUTEX_INITIALIZER;
+static GpuSlot *g_slots = NULL;
+static int g_nSlots = 0;
+static volatile int g_nextWorker = 0;
 static bool g_pairedEnabled = false;
 static bool g_secondaryEnabled = false;
 
@@ -100,7 +108,7 @@ static void toSnap(const snapgpu_single_result &g, SingleAlignmentResult *r)
 
 class GpuAlignerExtension : public AlignerExtension {
 public:
-    GpuAlignerExtension() {}
+    GpuAlignerExtension() : slot_(NULL) {}
 
     // The base copy() returns a plain AlignerExtension and is invoked once per worker thread
     // (AlignerContext.cpp:225): without this override the hook would never run in the workers.
@@ -121,6 +129,7 @@ public:
         ensurePaired(c, po);
         const bool secondary = c->maxSecondaryAlignmentAdditionalEditDistance >= 0;      // -om
         if (secondary) ensureSecondary(c);
+        GpuSlot *slot = mySlot();
         uint32_t secStride = 8, singleStride = 16;
         std::vector<snapgpu_paired_result> sec;
         std::vector<snapgpu_single_result> ssec;
@@ -180,13 +189,13 @@ public:
             if (0 == n) continue;
             if (bases.empty()) { bases.push_back(0); quals.push_back(0); }
 
-            pthread_mutex_lock(&g_gpuLock);
+            pthread_mutex_lock(&slot->lock);
             int rc;
             if (secondary) {
                 // align() with secondary-result buffers; like PairedAligner.cpp:727-756, grow what was too small and call again
                 for (;;) {
                     sec.resize((size_t)n * secStride); nSec.resize(n); ssec.resize((size_t)n * singleStride); nSingleSec.resize((size_t)2 * n);
-                    rc = snapgpu_align_paired_secondary(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0], &sec[0], secStride, &nSec[0],
+                    rc = snapgpu_align_paired_secondary(slot->ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0], &sec[0], secStride, &nSec[0],
                                                         &ssec[0], singleStride, &nSingleSec[0]);
                     if (rc != SNAPGPU_W_SECONDARY_TRUNCATED) break;
                     for (unsigned i = 0; i < n; i++) {
@@ -195,11 +204,11 @@ public:
                     }
                 }
             } else {
-                rc = snapgpu_align_paired(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
+                rc = snapgpu_align_paired(slot->ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
             }
-            pthread_mutex_unlock(&g_gpuLock);
+            pthread_mutex_unlock(&slot->lock);
             if (rc != SNAPGPU_OK) {
-                WriteErrorMessage("snapgpu_align_paired failed (%d): %s\n", rc, snapgpu_last_error(g_ctx));
+                WriteErrorMessage("snapgpu_align_paired failed (%d): %s\n", rc, snapgpu_last_error(slot->ctx));
                 soft_exit(1);
             }
 
@@ -277,13 +286,13 @@ public:
         }
         BigDealloc(reads);
         delete[] useful;
-        snapgpu_counters counters;
-        pthread_mutex_lock(&g_gpuLock);
-        if (snapgpu_get_counters(g_ctx, &counters, 1) == SNAPGPU_OK) {
+        snapgpu_counters counters;          // (workers that share a context: whoever ends first takes what has accumulated; the sums are the same)
+        pthread_mutex_lock(&slot->lock);
+        if (snapgpu_get_counters(slot->ctx, &counters, 1) == SNAPGPU_OK) {
             c->stats->lvCalls += (_int64)counters.n_lv_locations;
             c->stats->affineGapCalls += (_int64)counters.n_ag_locations;
         }
-        pthread_mutex_unlock(&g_gpuLock);
+        pthread_mutex_unlock(&slot->lock);
         return true;
     }
 
@@ -300,6 +309,7 @@ public:
         ensureContext(c, c->numSeedsFromCommandLine);
         const bool secondary = c->maxSecondaryAlignmentAdditionalEditDistance >= 0;      // -om
         if (secondary) ensureSecondary(c);
+        GpuSlot *slot = mySlot();
         uint32_t secStride = 8;
         if ((_int64)secStride > (_int64)c->maxSecondaryAlignments) secStride = (uint32_t)c->maxSecondaryAlignments;
         std::vector<snapgpu_single_result> sec;
@@ -346,22 +356,22 @@ public:
             }
             if (0 == n) continue;
 
-            pthread_mutex_lock(&g_gpuLock);
+            pthread_mutex_lock(&slot->lock);
             int rc;
             if (secondary) {
                 // AlignRead with a secondary-result buffer; like SingleAligner.cpp:250-263, grow it and call again when it was too small
                 for (;;) {
                     sec.resize((size_t)n * secStride); nSec.resize(n);
-                    rc = snapgpu_align_single_secondary(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0], &sec[0], secStride, &nSec[0]);
+                    rc = snapgpu_align_single_secondary(slot->ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0], &sec[0], secStride, &nSec[0]);
                     if (rc != SNAPGPU_W_SECONDARY_TRUNCATED) break;
                     for (unsigned i = 0; i < n; i++) if (nSec[i] > secStride) secStride = nSec[i];
                 }
             } else {
-                rc = snapgpu_align_single(g_ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
+                rc = snapgpu_align_single(slot->ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
             }
-            pthread_mutex_unlock(&g_gpuLock);
+            pthread_mutex_unlock(&slot->lock);
             if (rc != SNAPGPU_OK) {
-                WriteErrorMessage("snapgpu_align_single failed (%d): %s\n", rc, snapgpu_last_error(g_ctx));
+                WriteErrorMessage("snapgpu_align_single failed (%d): %s\n", rc, snapgpu_last_error(slot->ctx));
                 soft_exit(1);
             }
 
@@ -404,20 +414,20 @@ public:
             }
         }
         BigDealloc(reads);
-        snapgpu_counters counters;
-        pthread_mutex_lock(&g_gpuLock);
-        if (snapgpu_get_counters(g_ctx, &counters, 1) == SNAPGPU_OK) {
+        snapgpu_counters counters;          // (workers that share a context: whoever ends first takes what has accumulated; the sums are the same)
+        pthread_mutex_lock(&slot->lock);
+        if (snapgpu_get_counters(slot->ctx, &counters, 1) == SNAPGPU_OK) {
             c->stats->lvCalls += (_int64)counters.n_lv_locations;
             c->stats->affineGapCalls += (_int64)counters.n_ag_locations;
         }
-        pthread_mutex_unlock(&g_gpuLock);
+        pthread_mutex_unlock(&slot->lock);
         return true;                                            // we ran the whole per-thread loop
     }
 
 private:
     static void ensurePaired(AlignerContext *c, PairedAlignerOptions *po)
     {
-        pthread_mutex_lock(&g_gpuLock);
+        pthread_mutex_lock(&g_setupLock);
         if (!g_pairedEnabled) {
             snapgpu_paired_params pp;
             snapgpu_default_paired_params(&pp);
@@ -428,40 +438,44 @@ private:
             pp.flatten_mapq_at_or_below = c->options->flattenMAPQAtOrBelow; pp.min_score_realignment = po->minScoreRealignment;
             pp.min_score_gap_realignment_alt = po->minScoreGapRealignmentALT; pp.min_ag_score_improvement = po->minAGScoreImprovement;
             pp.enable_hamming_scoring_base_aligner = po->enableHammingScoringBaseAligner ? 1 : 0; pp.max_single_seeds = po->maxSeedsSingleEnd;
-            int rc = snapgpu_enable_paired(g_ctx, &pp);
-            if (rc != SNAPGPU_OK) {
-                WriteErrorMessage("snapgpu_enable_paired failed (%d): %s\n", rc, snapgpu_last_error(g_ctx));
-                soft_exit(1);
+            for (int i = 0; i < g_nSlots; i++) {
+                int rc = snapgpu_enable_paired(g_slots[i].ctx, &pp);
+                if (rc != SNAPGPU_OK) {
+                    WriteErrorMessage("snapgpu_enable_paired failed (%d): %s\n", rc, snapgpu_last_error(g_slots[i].ctx));
+                    soft_exit(1);
+                }
             }
             g_pairedEnabled = true;
         }
-        pthread_mutex_unlock(&g_gpuLock);
+        pthread_mutex_unlock(&g_setupLock);
     }
 
     // numSeeds: -n for the single-end aligner (the paired path hands its own -n to snapgpu_enable_paired)
     static void ensureSecondary(AlignerContext *c)
     {
-        pthread_mutex_lock(&g_gpuLock);
+        pthread_mutex_lock(&g_setupLock);
         if (!g_secondaryEnabled) {
             snapgpu_secondary_params sp;
             sp.max_edit_distance = c->maxSecondaryAlignmentAdditionalEditDistance;      // -om
             sp.max_per_contig = c->maxSecondaryAlignmentsPerContig;                     // -mpc
             sp.max_results = c->maxSecondaryAlignments;                                 // -omax
             sp.adjust_alignments = c->ignoreAlignmentAdjustmentForOm ? 0 : 1;           // -ae
-            int rc = snapgpu_enable_secondary(g_ctx, &sp);
-            if (rc != SNAPGPU_OK) {
-                WriteErrorMessage("snapgpu_enable_secondary failed (%d): %s\n", rc, snapgpu_last_error(g_ctx));
-                soft_exit(1);
+            for (int i = 0; i < g_nSlots; i++) {
+                int rc = snapgpu_enable_secondary(g_slots[i].ctx, &sp);
+                if (rc != SNAPGPU_OK) {
+                    WriteErrorMessage("snapgpu_enable_secondary failed (%d): %s\n", rc, snapgpu_last_error(g_slots[i].ctx));
+                    soft_exit(1);
+                }
             }
             g_secondaryEnabled = true;
         }
-        pthread_mutex_unlock(&g_gpuLock);
+        pthread_mutex_unlock(&g_setupLock);
     }
 
     static void ensureContext(AlignerContext *c, unsigned numSeeds)
     {
-        pthread_mutex_lock(&g_gpuLock);
-        if (NULL == g_ctx) {
+        pthread_mutex_lock(&g_setupLock);
+        if (NULL == g_slots) {
             snapgpu_params p;
             snapgpu_default_params(&p);
             p.max_hits = (uint32_t)c->maxHits;
@@ -483,14 +497,68 @@ private:
             p.max_read_len = 400;                               // per-wave buffers; raise for longer reads (<= MAX_READ_LENGTH)
             const char *env = getenv("SNAPGPU_MAX_READ_LEN");
             if (env) p.max_read_len = (uint32_t)atoi(env);
-            int rc = snapgpu_create_from_directory(c->options->indexDir, &p, 0, &g_ctx);
+            // GPUs: all that are visible (SNAPGPU_SHIM_GPUS=<n> for fewer); feeders per GPU: SNAPGPU_SHIM_FEEDERS (default 2)
+            int nDev = snapgpu_device_count();
+            if (nDev < 1) nDev = 1;
+            env = getenv("SNAPGPU_SHIM_GPUS");
+            if (env && atoi(env) >= 1 && atoi(env) < nDev) nDev = atoi(env);
+            int nFeed = 2;
+            env = getenv("SNAPGPU_SHIM_FEEDERS");
+            if (env && atoi(env) >= 1 && atoi(env) <= 8) nFeed = atoi(env);
+            GpuSlot *slots = new GpuSlot[(size_t)nDev * nFeed];
+            snapgpu_ctx **first = new snapgpu_ctx *[nDev];
+            int rc = snapgpu_create_from_directory(c->options->indexDir, &p, 0, &first[0]);
             if (rc != SNAPGPU_OK) {
                 WriteErrorMessage("snapgpu_create_from_directory(%s) failed (%d): %s\n", c->options->indexDir, rc, snapgpu_last_error(NULL));
                 soft_exit(1);
             }
+            for (int d = 1; d < nDev; d++) {
+                rc = snapgpu_create_replica(first[0], d, 0, &first[d]);
+                if (rc != SNAPGPU_OK) {
+                    WriteErrorMessage("snapgpu_create_replica(device %d) failed (%d): %s\n", d, rc, snapgpu_last_error(first[0]));
+                    soft_exit(1);
+                }
+            }
+            if (nDev > 1) {
+                rc = snapgpu_broadcast_index(first, nDev);
+                if (rc != SNAPGPU_OK) {
+                    WriteErrorMessage("snapgpu_broadcast_index over %d GPUs failed (%d): %s\n", nDev, rc, snapgpu_last_error(first[0]));
+                    soft_exit(1);
+                }
+            }
+            int n = 0;
+            for (int f = 0; f < nFeed; f++) {                  // slot order: GPU 0, GPU 1, ..., then the second feeder of each
+                for (int d = 0; d < nDev; d++) {
+                    snapgpu_ctx *ctx = first[d];
+                    if (f > 0) {
+                        rc = snapgpu_create_replica(first[d], d, 1, &ctx);
+                        if (rc != SNAPGPU_OK) {
+                            WriteErrorMessage("snapgpu_create_replica(feeder %d of device %d) failed (%d): %s\n", f, d, rc, snapgpu_last_error(first[d]));
+                            soft_exit(1);
+                        }
+                    }
+                    slots[n].ctx = ctx;
+                    pthread_mutex_init(&slots[n].lock, NULL);
+                    n++;
+                }
+            }
+            delete[] first;
+            g_nSlots = n;
+            g_slots = slots;
         }
-        pthread_mutex_unlock(&g_gpuLock);
+        pthread_mutex_unlock(&g_setupLock);
     }
+
+    // this worker thread's context (the extension object is one per worker: AlignerContext.cpp:226 calls copy())
+    GpuSlot *mySlot()
+    {
+        if (NULL == slot_) {
+            int t = __sync_fetch_and_add(&g_nextWorker, 1);
+            slot_ = &g_slots[t % g_nSlots];
+        }
+        return slot_;
+    }
+    GpuSlot *slot_;
 };
 
 // Mirror of ProcessNonDaemonCommands (SNAPLib/CommandProcessor.cpp:59-88) with the extension installed.
@@ -512,6 +580,6 @@ int main(int argc, const char **argv)
         PairedAlignerContext paired(extension);                     // PairedAligner.h:42
         paired.runAlignment(argc - 1, argv + 1, SNAP_VERSION, &nArgsConsumed);
     }
-    if (g_ctx) snapgpu_destroy(g_ctx);
+    for (int i = g_nSlots - 1; i >= 0; i--) snapgpu_destroy(g_slots[i].ctx);       // (sharing contexts before the ones that own the blobs)
     return 0;
 }

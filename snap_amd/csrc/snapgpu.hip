@@ -636,7 +636,8 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     if (const char *e = getenv("SNAPGPU_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) waves_per_cu = v; }
     // LDS limit: 160 KiB per CU
     while (waves_per_cu > 1 && (size_t)waves_per_cu * L.total > 160 * 1024) waves_per_cu--;
-    if ((size_t)4 * L.total > 64 * 1024 && (size_t)L.total > 160 * 1024) { snapgpu_destroy(ctx); return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "per-read LDS state exceeds 160 KiB"); }
+    // (every align kernel is launched as 4 waves per workgroup with 4 * L.total bytes of dynamic LDS: refuse here, not with an opaque launch error)
+    if ((size_t)4 * L.total > 160 * 1024) { snapgpu_destroy(ctx); return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "per-read LDS state exceeds 40 KiB per wave (max_read_len / num_seeds / max_k too large)"); }
     ctx->n_wave_slots = (uint32_t)ctx->num_cus * (uint32_t)waves_per_cu;
     ctx->n_wave_slots = (ctx->n_wave_slots + 3) & ~3u;
     size_t scratch_total = (size_t)ctx->n_wave_slots * c.scratch_stride;

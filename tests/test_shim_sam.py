@@ -16,7 +16,8 @@ from oracle import ref
 pytestmark = pytest.mark.gpu
 
 REF_CLI = ref.CLI_PATH
-GPU_CLI = os.path.join(os.path.dirname(REF_CLI), "snap-aligner-gpu")
+# (SNAPGPU_TEST_SHIM: the same objects linked against the wavefront emulator's build of the C ABI -- tests/emu/README.md -- to run this file on the host)
+GPU_CLI = os.environ.get("SNAPGPU_TEST_SHIM") or os.path.join(os.path.dirname(REF_CLI), "snap-aligner-gpu")
 
 
 def _run(cmd):
