@@ -19,5 +19,6 @@ for rep in range(2):
     c = a.counters()
     ref, _ = util.with_fresh_overrides(zp[key + "_primary"], "pe_" + key + "_primary")
     bad = compare_paired(ref[:np_], prim, verbose=0)
-    print("rep", rep, "pairs", prim.size, "bad", int(bad.sum()), "%.2fs" % dt, "watchdog", c["help_watchdog_events"], hex(c["help_watchdog_last"]), flush=True)
+    print("rep", rep, "pairs", prim.size, "bad", int(bad.sum()), "%.2fs" % dt, "watchdog", c["help_watchdog_events"], hex(c["help_watchdog_last"]),
+          "lists published", c["help_lists_published"], "answers used", c["help_answers_used"], "of", c["n_ag_locations"], "affine-gap locations", flush=True)
 a.close()

@@ -187,7 +187,11 @@ class Counters(C.Structure):
         d = {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
         d["cycles_single_fallback"] = int(self.reserved[0])      # paired-end path only
         d["help_watchdog_events"] = int(self.reserved[1])        # Phase-4 help waits that were given up (paired_dev.h); 0 in a healthy run
-        d["help_watchdog_last"] = int(self.reserved[2])
+        # reserved[2]: lists published << 32 | speculative answers the ordered walks took; after a watchdog event (top nibble set) what it saw
+        r2 = int(self.reserved[2])
+        d["help_watchdog_last"] = r2 if (r2 >> 60) else 0
+        d["help_lists_published"] = 0 if (r2 >> 60) else (r2 >> 32)
+        d["help_answers_used"] = 0 if (r2 >> 60) else (r2 & 0xffffffff)
         return d
 
 

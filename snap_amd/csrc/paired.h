@@ -196,6 +196,7 @@ struct PairedCore {
     uint32_t ag_obj_used0 = 0, ag_obj_used1 = 0;  // has affineGap / reverseAffineGap of the intersecting aligner scored anything yet for this pair?
     bool spec_mode = false;            // speculative scoring of Phase-4 candidates: work counters are left to the ordered walk
     uint32_t spec_n_ag = 0;
+    uint32_t spec_used = 0;            // answers the ordered walk took from speculative scoring (this pair)
     uint32_t help_min = 0xffffffffu;   // Phase-4 lists at least this long are offered to idle waves (PL::HELP only)
 
     PE_FN PairedCore(PL &pl_, const PECfg &c) : pl(pl_), cfg(c) {}
@@ -1188,16 +1189,24 @@ struct PairedCore {
             // pl.sort_candidates writes that order (a stable counting sort on the key kept in `reserved`) to agc_order.
             pl.sort_candidates(agc, n_agc, agc_order);
             PEHelpSpec *spec = nullptr;
-            if constexpr (PL::HELP) {
-                // a long list: every candidate is scored speculatively under the limit the walk starts with -- by this wave and by
-                // whichever waves are idle -- before the ordered walk below consumes the answers (struct PEHelpSpec)
-                if (n_agc >= help_min) spec = pl.help_phase4(*this, n_agc, PL::i32(limit), best_pair_score, skip);
-            }
+            uint32_t spec_from = 0;
+            spec_used = 0;
             for (uint32_t t = 0; t < n_agc; t++) {
+                if constexpr (PL::HELP) {
+                    // A long rest of the list is published ON DEMAND -- once waves that have run out of pairs exist (or at once, in the
+                    // eager mode the tests use) -- so that the help slots are held by the pairs that ARE the tail of the launch, not by
+                    // whichever long pair came first while every wave was still busy.  Candidates t .. n_agc - 1 are then scored
+                    // speculatively under the limit the walk has arrived with, by this wave and the idle ones, before the walk goes on
+                    // and consumes the answers (struct PEHelpSpec).  Looked at every 16 candidates.
+                    if (spec == nullptr && (t & 15u) == 0u && n_agc - t >= help_min && pl.help_wanted()) {
+                        spec = pl.help_phase4(*this, n_agc, t, PL::i32(limit), best_pair_score, skip);
+                        spec_from = t;
+                    }
+                }
                 snapgpu_paired_result *e = &agc[ld(agc_order[t])];
-                phase4_candidate(e, limit, best_pair_score, skip, g_off, spec ? &spec[t] : nullptr);
+                phase4_candidate(e, limit, best_pair_score, skip, g_off, (spec && t >= spec_from) ? &spec[t] : nullptr);
             }
-            if constexpr (PL::HELP) { if (spec) pl.help_done(); }
+            if constexpr (PL::HELP) { if (spec) pl.help_done(spec_used); }
         }
 
         const bool emit_all = !cfg.alt_aware || N.best_pair_score > A.best_pair_score + cfg.max_gap_alt;
@@ -1433,7 +1442,7 @@ struct PairedCore {
             if (sp != nullptr && PL::spec_ld(sp->lim[0]) == PL::i32(limit)) {      // scored ahead of time with exactly these arguments
                 s0 = PL::spec_ld(sp->score[0]); mp0 = PL::spec_ld(sp->mp[0]); g_off[0] = PL::spec_ld(sp->g_off[0]); cb = PL::spec_ld(sp->cb[0]);
                 ca = PL::spec_ld(sp->ca[0]); ag0 = PL::spec_ld(sp->ag[0]); span = PL::spec_ld(sp->span[0]); { const uint32_t ss = PL::spec_ld(sp->stale[0]); stale += ss; stale_later += ss; }
-                sh->cnt.ag += PL::spec_ld(sp->n_ag[0]);
+                sh->cnt.ag += PL::spec_ld(sp->n_ag[0]); spec_used++;
             } else {
                 score_ag(0, ld(e->direction[0]), ld(e->orig_location[0]), ld(e->seed_offset[0]), PL::i32(limit), &s0, &mp0, &g_off[0], &cb, &ca, &ag0, &span);
             }
@@ -1452,7 +1461,7 @@ struct PairedCore {
                 if (sp != nullptr && PL::spec_ld(sp->lim[1]) == PL::i32(limit)) {
                     s1 = PL::spec_ld(sp->score[1]); mp1 = PL::spec_ld(sp->mp[1]); g_off[1] = PL::spec_ld(sp->g_off[1]); cb = PL::spec_ld(sp->cb[1]);
                     ca = PL::spec_ld(sp->ca[1]); ag1 = PL::spec_ld(sp->ag[1]); span = PL::spec_ld(sp->span[1]); { const uint32_t ss = PL::spec_ld(sp->stale[1]); stale += ss; stale_later += ss; }
-                    sh->cnt.ag += PL::spec_ld(sp->n_ag[1]);
+                    sh->cnt.ag += PL::spec_ld(sp->n_ag[1]); spec_used++;
                 } else {
                     score_ag(1, ld(e->direction[1]), ld(e->orig_location[1]), ld(e->seed_offset[1]), PL::i32(limit), &s1, &mp1, &g_off[1], &cb, &ca, &ag1, &span);
                 }

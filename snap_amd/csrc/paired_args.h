@@ -64,7 +64,10 @@ struct PairedArgs {
     // exact replay of pairs whose affine-gap traceback left the band (k_align_paired<0, SEC, true>): 4 x ag_scratch_bytes(RL) per wave slot
     uint8_t *persist; uint64_t persist_stride;
     // Phase-4 help (paired_dev.h: PEHelpSlot): slots, one PEHelpSpec array of help_spec_cap entries per slot, the launch's done-pair counter
+    // (help_done[0]: pairs of the launch that are done; help_done[1]: waves that have run out of pairs -- the idle count a pair looks at
+    //  before it publishes; help_eager: publish whether or not anybody is idle)
     struct PEHelpSlot *help; uint32_t n_help; PEHelpSpec *help_spec; uint32_t help_spec_cap; uint32_t *help_done; uint32_t help_min;
+    uint32_t help_eager;
 };
 
 

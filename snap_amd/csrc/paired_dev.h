@@ -26,6 +26,7 @@ struct DevPL {
     static const bool HELP = !EXACT;
     static const bool ALWAYS_COUNT_STALE = EXACT;
     PEHelpSlot *help; uint32_t n_help; PEHelpSpec *help_spec; uint32_t help_spec_cap;
+    const uint32_t *help_idle; bool help_eager;      // waves of the launch that have run out of pairs (nullptr: no helpers); publish regardless
     uint32_t cur_pair; int my_slot;
     unsigned long long *diag;          // snapgpu_counters::reserved: [1] waits that ran into the watchdog, [2] what the last one saw
     // Cross-wave traffic is kept off the cache-wide fences (an agent-scope release writes back the whole L2 of the XCD, an acquire
@@ -106,7 +107,14 @@ struct DevPL {
             if (lane_id() == 0) atomicAdd(&slot->done, c1 - c0);
         }
     }
-    template <class Core> __device__ __forceinline__ PEHelpSpec *help_phase4(Core &core, uint32_t n, int limit, int best, const bool skip[2]) {
+    // is there anybody to publish for?  (a device-scope load of a word that only ever grows: a stale 0 just postpones the question)
+    __device__ __forceinline__ bool help_wanted() const {
+        if (help == nullptr) return false;
+        if (help_eager) return true;
+        return help_idle != nullptr && spec_ld(*help_idle) != 0u;
+    }
+    // candidates first .. n - 1 of the sorted list (spec is indexed by position in the list, so spec[first ..] are the ones filled in)
+    template <class Core> __device__ __forceinline__ PEHelpSpec *help_phase4(Core &core, uint32_t n, uint32_t first, int limit, int best, const bool skip[2]) {
         my_slot = -1;
         if (help == nullptr || n > help_spec_cap) return nullptr;
         int s = -1;
@@ -118,7 +126,7 @@ struct DevPL {
         PEHelpSlot *slot = &help[s];
         PEHelpSpec *spec = help_spec + (size_t)s * help_spec_cap;
         if (lane_id() == 0) {
-            const uint32_t w0 = atomicExch(&slot->next, 0u), w1 = atomicExch(&slot->done, 0u);
+            const uint32_t w0 = atomicExch(&slot->next, first), w1 = atomicExch(&slot->done, 0u);
             if ((w0 ^ w1) == 0xFFFFFFF5u) atomicExch(&slot->done, 0u);          // (uses both return values: the exchanges have completed)
             spec_st(slot->pair, cur_pair); spec_st(slot->n, n);
             spec_st(slot->limit, (int32_t)limit); spec_st(slot->best, (int32_t)best);
@@ -137,7 +145,7 @@ struct DevPL {
         bool gave_up = false;
         for (;;) {
             const uint32_t d = aload(&slot->done);
-            if (d >= n) break;
+            if (d >= n - first) break;
             nap();
             if (wave_clock() - t0 > 2400000000ull) {
                 if (lane_id() == 0 && diag) { atomicAdd(&diag[1], 1ull); diag[2] = 0x1000000000000000ull | ((unsigned long long)n << 32) | d; }
@@ -164,8 +172,12 @@ struct DevPL {
         if (gave_up) { my_slot = -1; return nullptr; }
         return spec;                                            // (read with spec_ld: no acquire fence needed)
     }
-    __device__ __forceinline__ void help_done() {
-        if (my_slot >= 0 && lane_id() == 0) atomicExch(&help[my_slot].state, 0u);
+    // (diag[2], = snapgpu_counters::reserved[2]: lists published << 32 | answers the ordered walks took from speculative scoring)
+    __device__ __forceinline__ void help_done(uint32_t answers_used) {
+        if (my_slot >= 0 && lane_id() == 0) {
+            atomicExch(&help[my_slot].state, 0u);
+            if (diag) atomicAdd(&diag[2], (1ull << 32) | (unsigned long long)answers_used);
+        }
         my_slot = -1;
     }
     const DevTables *tab;
@@ -502,6 +514,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     al.ag_persist0 = al.ag_persist1 = pl.ag_persist0 = pl.ag_persist1 = nullptr;
     al.ag_hw0 = al.ag_hw1 = pl.ag_hw0 = pl.ag_hw1 = 0;
     pl.help = EXACT ? nullptr : a.help; pl.n_help = a.n_help; pl.help_spec = a.help_spec; pl.help_spec_cap = a.help_spec_cap;
+    pl.help_idle = a.help_done ? a.help_done + 1 : nullptr; pl.help_eager = a.help_eager != 0;
     pl.cur_pair = 0; pl.my_slot = -1; pl.diag = a.counters + 13;
     if constexpr (EXACT) {
         uint8_t *pb = a.persist + (size_t)wave_slot * a.persist_stride;
@@ -620,6 +633,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
     if constexpr (!EXACT) {
         // Out of pairs: until every pair of the launch is done, score Phase-4 candidates of the pairs that asked for help.
         if (a.help != nullptr && a.help_done != nullptr) {
+            if (lane == 0) atomicAdd(a.help_done + 1, 1u);                // one more idle wave: pairs in Phase 4 start publishing
             const uint64_t t_idle0 = wave_clock();
             for (uint32_t round = 0;; round++) {
                 if ((round & 7u) == 0u) {

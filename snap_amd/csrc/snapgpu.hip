@@ -1920,10 +1920,11 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         a.remap = ctx->d_order; a.n_remap = ctx->d_whist + 33;
     }
     auto with_help = [&](PairedArgs &x) -> hipError_t {       // fresh help state for the launch that is about to start
-        x.help = nullptr; x.n_help = 0; x.help_spec = nullptr; x.help_spec_cap = 0; x.help_done = nullptr; x.help_min = 0xffffffffu;
+        x.help = nullptr; x.n_help = 0; x.help_spec = nullptr; x.help_spec_cap = 0; x.help_done = nullptr; x.help_min = 0xffffffffu; x.help_eager = 0;
         if (!ctx->d_help || so) return hipSuccess;
         x.help = (PEHelpSlot *)(ctx->d_help + 64); x.n_help = ctx->n_help; x.help_spec = ctx->d_help_spec; x.help_spec_cap = ctx->help_spec_cap;
         x.help_done = getenv("SNAPGPU_PAIRED_HELP_NOHELPERS") ? nullptr : (uint32_t *)ctx->d_help; x.help_min = ctx->help_min;      // (debug: owner-only speculation)
+        x.help_eager = (getenv("SNAPGPU_PAIRED_HELP_EAGER") != nullptr && atoi(getenv("SNAPGPU_PAIRED_HELP_EAGER")) != 0) || x.help_done == nullptr;
         return hipMemsetAsync(ctx->d_help, 0, ctx->help_bytes, s);
     };
     HIPCHK(ctx, with_help(a), SNAPGPU_E_LAUNCH);
