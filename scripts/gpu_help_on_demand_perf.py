@@ -14,13 +14,18 @@ from tests.pairs_util import compare_paired
 
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 d = tempfile.mkdtemp(prefix="helpod")
-g = synth.make_genome(11, 3_000_000, n_contigs=2, repeat_frac=0.8, max_copies=2500, repeat_len=(400, 1500), max_divergence=0.012)
+if len(sys.argv) > 2:            # "bench:<Mb>": the bench genome's recipe (30 % planted repeats, copy numbers up to 5 000) at another size
+    mb = int(sys.argv[2].split(":")[1])
+    g = synth.make_genome(20260925, mb * 1_000_000, n_contigs=max(1, min(24, mb // 8)), repeat_frac=0.30, max_copies=5000, repeat_len=(200, 3000), max_divergence=0.05)
+else:
+    g = synth.make_genome(11, 3_000_000, n_contigs=2, repeat_frac=0.8, max_copies=2500, repeat_len=(400, 1500), max_divergence=0.012)
+out_genome = sys.argv[2] if len(sys.argv) > 2 else "3 Mb, 80 % repeats"
 synth.write_fasta(d + "/g.fa", g)
 ref.build_index(d + "/g.fa", d + "/idx", 20, threads=os.cpu_count() or 8)
 ix = GenomeIndex.load_from_directory(d + "/idx")
 pairs = synth.make_pairs(5, g, n_pairs, 150)
 params, pparams = abi.default_params(max_k=8, max_read_len=160), abi.default_paired_params()
-out = {"pairs": n_pairs}
+out = {"pairs": n_pairs, "genome": out_genome}
 res = {}
 for tag, env in (("help_off", None), ("help_on_demand_64", "64")):
     if env is None:
@@ -37,7 +42,7 @@ for tag, env in (("help_off", None), ("help_on_demand_64", "64")):
                 "answers_used": c["help_answers_used"], "watchdog": c["help_watchdog_events"], "replayed": int(((got["flags"] & 4) != 0).sum())}
     a.close()
 out["same_bytes"] = res["help_off"].tobytes() == res["help_on_demand_64"].tobytes()
-k = min(n_pairs, 1500)
+k = min(n_pairs, 1500 if len(sys.argv) <= 2 else 20000)
 ri = ref.RefIndex(d + "/idx")
 with ref.fresh_objects():
     exp = ri.align_paired(params, pparams, pairs["bases"][:2 * k], pairs["quals"][:2 * k], pairs["offsets"][:2 * k + 1], threads=os.cpu_count() or 8, stage=0)[0]
