@@ -146,6 +146,70 @@ def test_emu_paired_end(emu):
     assert (alt["status"] == z[key + "_alt"]["status"][:n]).all()
 
 
+def test_emu_paired_end_lv_only_hamming_retry_uses_affine_gap(emu):
+    """`use_affine_gap = 0` with soft clipping: the Hamming retry of the chimeric fallback still calls alignAffineGap
+    (ChimericPairedEndAligner.cpp:330-360), so the affine-gap LDS rows and traceback slab must exist in that configuration
+    (AlignCfg::ag_buffers; round 2: with size 0 the staged text codes ran into the per-pair result).  First 300 pairs of the LV-only set."""
+    import tests.test_gpu_paired as gp
+    from tests.pairs_util import compare_paired
+    from tests.test_paired_host import OPTS
+    kw, pkw = OPTS["lvonly_d12"]
+    z = np.load(os.path.join(util.GOLDEN, "paired_reads.npz"))
+    n = 300
+    o = z["o150"][:2 * n + 1]
+    a = gp._aligner(util.load_golden_index("paired_index.npz"), kw, pkw)
+    try:
+        prim, _ = a.align(z["b150"].reshape(-1)[:int(o[-1])], z["q150"].reshape(-1)[:int(o[-1])], o)
+    finally:
+        a.close()
+    exp, _ = util.with_fresh_overrides(z["lvonly_d12_150_s0_primary"], "pe_lvonly_d12_150_s0_primary")
+    assert (exp["used_affine_gap_scoring"][:n] != 0).any()                        # the case is in the sample
+    assert not compare_paired(exp[:n], prim, verbose=3).any()
+
+
+def test_emu_feeders_share_one_index(emu):
+    """BaseAligner.replica (snapgpu_create_replica, share_index): tests/test_gpu_multi_ctx.py on the emulated device."""
+    import tests.test_gpu_multi_ctx as mc
+    mc.test_paired_feeders_two_batches_in_flight()
+
+
+@pytest.mark.parametrize("eager", [False, True])
+def test_emu_phase4_help_on_demand(emu, monkeypatch, eager):
+    """The Phase-4 help slots (paired_dev.h), published on demand / eagerly, on pairs that have long candidate lists (a genome built of
+    high-copy repeats): every pair equals the reference with fresh aligner objects, and -- eager mode -- speculative answers were used."""
+    from oracle import ref
+    if not os.path.exists(ref.LIB_PATH):
+        pytest.skip("oracle/_ref not built")
+    from snap_amd import synth
+    from snap_amd.aligner import ChimericPairedEndAligner
+    from snap_amd.index import GenomeIndex
+    from tests.pairs_util import compare_paired
+    import tempfile
+    d = tempfile.mkdtemp(prefix="emuhelp")
+    g = synth.make_genome(11, 1_200_000, n_contigs=2, repeat_frac=0.8, max_copies=1200, repeat_len=(400, 1200), max_divergence=0.012)
+    synth.write_fasta(d + "/g.fa", g)
+    ref.build_index(d + "/g.fa", d + "/idx", 20, threads=8)
+    pairs = synth.make_pairs(5, g, 40, 150)
+    params, pparams = abi.default_params(max_k=8, max_read_len=160), abi.default_paired_params()
+    with ref.fresh_objects():
+        exp = ref.RefIndex(d + "/idx").align_paired(params, pparams, pairs["bases"], pairs["quals"], pairs["offsets"], threads=4, stage=0)[0]
+    monkeypatch.setenv("SNAPGPU_PAIRED_HELP_MIN", "16")
+    if eager:
+        monkeypatch.setenv("SNAPGPU_PAIRED_HELP_EAGER", "1")
+    a = ChimericPairedEndAligner(GenomeIndex.load_from_directory(d + "/idx"), params, pparams)
+    try:
+        a.counters(reset=True)
+        got, _ = a.align(pairs["bases"], pairs["quals"], pairs["offsets"])
+        c = a.counters()
+    finally:
+        a.close()
+        shutil.rmtree(d, ignore_errors=True)
+    assert not compare_paired(exp, got, verbose=3).any()
+    assert c["help_watchdog_events"] == 0
+    if eager:
+        assert c["help_lists_published"] > 0 and c["help_answers_used"] > 0
+
+
 @pytest.mark.parametrize("seed_len,large", [(24, False), (22, True)])
 def test_emu_other_index_shapes(emu, tmp_path, seed_len, large):
     """Key bytes 5, `-large` entries, 16 hash tables: the probe takes other paths than with the north star's -s 20 index.
