@@ -9,6 +9,10 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#if defined(SNAPGPU_WAVE_EMU)
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #define WAVE 64
 // Pointers known to point into LDS: inside a function that is NOT inlined into the kernel the compiler cannot see that a generic
@@ -104,7 +108,7 @@ static __device__ __forceinline__ uint64_t first_u64(uint64_t v) {
 // faulted on hardware: nothing pads the wait states between such a store and the next write of its address registers.)
 struct BtSink {
 #if defined(SNAPGPU_WAVE_EMU)
-    uint8_t *base;
+    uint8_t *base; uint32_t n_bytes;     // (the emulator checks what the hardware descriptor silently drops)
 #else
     __amdgpu_buffer_rsrc_t rsrc;
 #endif
@@ -113,7 +117,7 @@ struct BtSink {
 static __device__ __forceinline__ BtSink bt_sink(uint8_t *ubase, uint32_t n_bytes) {
     BtSink s;
 #if defined(SNAPGPU_WAVE_EMU)
-    s.base = ubase; (void)n_bytes;
+    s.base = ubase; s.n_bytes = n_bytes;
 #else
     s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(uintptr_t)first_u64((uint64_t)(uintptr_t)ubase), (short)0, (int)first_u32(n_bytes), 0x00020000);
 #endif
@@ -122,6 +126,7 @@ static __device__ __forceinline__ BtSink bt_sink(uint8_t *ubase, uint32_t n_byte
 // sink[uoff + voff] = val   (uoff wave-uniform, voff per lane)
 static __device__ __forceinline__ void bt_store(const BtSink &s, uint32_t uoff, uint32_t voff, uint32_t val) {
 #if defined(SNAPGPU_WAVE_EMU)
+    if ((size_t)uoff + voff >= s.n_bytes) { fprintf(stderr, "emulator: traceback store at %zu outside a slab of %u bytes\n", (size_t)uoff + voff, s.n_bytes); abort(); }
     s.base[(size_t)uoff + voff] = (uint8_t)val;
 #else
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)val, s.rsrc, (int)voff, (int)first_u32(uoff), 0);

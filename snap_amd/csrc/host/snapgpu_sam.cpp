@@ -147,6 +147,7 @@ struct Options {
     int om = -1, mpc = -1; long long omax = 0x7fffffff;
     int n_gpus = 0, ctx_per_gpu = 2, n_format = 0;
     uint32_t ops_stride = 64;
+    bool bam = false;                                                      // -o x.bam: BAM records in BGZF blocks (SNAPLib/Bam.cpp)
 };
 
 struct Work {                                // a batch on its way through the pipeline
@@ -156,7 +157,8 @@ struct Work {                                // a batch on its way through the p
     std::vector<int32_t> flag, contig, mapq, n_ops, nm, rnext, first_written;
     std::vector<int64_t> pos, pnext, tlen;
     std::vector<uint32_t> ops; uint32_t ops_stride = 64;
-    std::string text;                        // the formatted records
+    std::string text;                        // the formatted records (BAM: BGZF blocks)
+    bool bam = false;
     unsigned long long mapped = 0;
 };
 
@@ -325,6 +327,9 @@ static void gpu_paired(const Options &o, snapgpu_ctx *ctx, Work &w)
 }
 
 // ---------------------------------------------------------------------------------------- formatting stage
+static void put_bam_record(std::string &o, const std::vector<Contig> &contigs, const char *qname, size_t qn, int flag, int contig, long long pos1,
+                           int mapq, const uint32_t *ops, int n_ops, int mate_contig, long long pnext1, long long tlen,
+                           const char *s, const char *q, size_t U, int nm, bool with_qs, int qs);
 static inline void put_cigar(std::string &o, const Work &w, size_t i)
 {
     if (w.n_ops[i] < 0) { o.push_back('*'); return; }
@@ -353,6 +358,11 @@ static void format_single(const std::vector<Contig> &contigs, Work &w)
         const char *nm = b.names.data() + b.name_off[rd]; size_t nl = b.name_off[rd + 1] - b.name_off[rd];
         const void *sp = memchr(nm, ' ', nl);                              // "illegal in SAM: truncate at the space" (SAM.cpp:2001-2004)
         if (sp) nl = (size_t)((const char *)sp - nm);
+        if (w.bam) {
+            put_bam_record(o, contigs, nm, nl, w.flag[i], w.contig[i], w.pos[i], w.mapq[i], w.ops.data() + i * (size_t)w.ops_stride, w.n_ops[i], -1, 0, 0, s, q, U, w.nm[i], false, 0);
+            w.mapped += (w.flag[i] & 0x4) == 0;
+            continue;
+        }
         o.append(nm, nl); o.push_back('\t'); put_int(o, w.flag[i]); o.push_back('\t');
         if (w.contig[i] >= 0) o += contigs[(size_t)w.contig[i]].name; else o.push_back('*');
         o.push_back('\t'); put_int(o, w.pos[i]); o.push_back('\t'); put_int(o, w.mapq[i]); o.push_back('\t');
@@ -390,6 +400,13 @@ static void format_paired(const std::vector<Contig> &contigs, Work &w)
             int mqs = 0;                                                // QS: the mate's qualities >= 15, summed (SAM.cpp:1826-1837)
             { const unsigned char *mq = (const unsigned char *)b.quals.data() + b.offsets[im]; const size_t mu = (size_t)(b.offsets[im + 1] - b.offsets[im]);
               for (size_t j = 0; j < mu; j++) { const int x = (int)mq[j] - '!'; mqs += x >= 15 ? (x != 255) * x : 0; } }
+            if (w.bam) {
+                const int mate_contig = w.rnext[i] == -2 ? w.contig[i] : w.rnext[i];
+                put_bam_record(o, contigs, nm, qn, w.flag[i], w.contig[i], w.pos[i], w.mapq[i], w.ops.data() + i * (size_t)w.ops_stride, w.n_ops[i],
+                               mate_contig, w.pnext[i], w.tlen[i], s, q, U, w.nm[i], true, mqs);
+                w.mapped += (w.flag[i] & 0x4) == 0;
+                continue;
+            }
             o.append(nm, qn); o.push_back('\t'); put_int(o, w.flag[i]); o.push_back('\t');
             if (w.contig[i] >= 0) o += contigs[(size_t)w.contig[i]].name; else o.push_back('*');
             o.push_back('\t'); put_int(o, w.pos[i]); o.push_back('\t'); put_int(o, w.mapq[i]); o.push_back('\t');
@@ -403,13 +420,105 @@ static void format_paired(const std::vector<Contig> &contigs, Work &w)
     }
 }
 
+// ---------------------------------------------------------------------------------------- BAM (SNAPLib/Bam.cpp)
+// One record as BAMFormat::writeRead / writePairs lay it out (Bam.cpp:1312-1508, 1033-1309): the same computed fields as the SAM line, binary.
+//   refID / next_refID are ORIGINAL contig numbers (the header lists the contigs in the FASTA's order, Bam.cpp:1003-1021),
+//   bin = reg2bin over the reference span of the cigar (an unmapped read: its mate's position, else -1; Bam.cpp:1473-1477),
+//   aux: the default read group's fields (RG PL PU LB SM, Z), PG:Z:SNAP, NM:C (one byte: -1 reads as 255), and QS:i for mates (Bam.cpp:1510-1650).
+static int bam_reg2bin(int beg, int end)                                   // Bam.cpp:523-535
+{
+    --end;
+    if (beg >> 14 == end >> 14) return ((1 << 15) - 1) / 7 + (beg >> 14);
+    if (beg >> 17 == end >> 17) return ((1 << 12) - 1) / 7 + (beg >> 17);
+    if (beg >> 20 == end >> 20) return ((1 << 9) - 1) / 7 + (beg >> 20);
+    if (beg >> 23 == end >> 23) return ((1 << 6) - 1) / 7 + (beg >> 23);
+    if (beg >> 26 == end >> 26) return ((1 << 3) - 1) / 7 + (beg >> 26);
+    return 0;
+}
+static inline void put_le32(std::string &o, uint32_t v) { char c[4] = {(char)(v & 0xff), (char)((v >> 8) & 0xff), (char)((v >> 16) & 0xff), (char)(v >> 24)}; o.append(c, 4); }
+static const char BAM_RG_AUX[] = "RGZFASTQ\0PLZIllumina\0PUZpu\0LBZlb\0SMZsm";            // (+ the terminating NUL of the literal)
+struct BamSeqCode { uint8_t c[256]; BamSeqCode() { memset(c, 0xf, 256); const char *t = "=ACMGRSVTWYHKDBN"; for (int i = 1; i < 16; i++) c[(unsigned char)t[i]] = (uint8_t)i; } };
+static const BamSeqCode BAM_SEQ;                                             // Bam.cpp:505-510: anything unknown is N
+
+static void put_bam_record(std::string &o, const std::vector<Contig> &contigs, const char *qname, size_t qn, int flag, int contig, long long pos1,
+                           int mapq, const uint32_t *ops, int n_ops, int mate_contig, long long pnext1, long long tlen,
+                           const char *s, const char *q, size_t U, int nm, bool with_qs, int qs)
+{
+    if (qn > 254) die("BAM format: QNAME must be shorter than 255 characters");
+    const bool rc = (flag & 0x10) != 0;
+    const int n_cig = n_ops > 0 ? n_ops : 0;
+    static const int ref_base[16] = {1, 0, 1, 1, 0, 0, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};       // Bam.cpp:270
+    int ref_len = n_cig > 0 ? 0 : (int)U;
+    for (int c = 0; c < n_cig; c++) ref_len += ref_base[ops[c] & 0xf] * (int)(ops[c] >> 4);
+    int bin;
+    if (!(flag & 0x4)) bin = bam_reg2bin((int)pos1 - 1, (int)pos1 - 1 + ref_len);
+    else if (with_qs && !(flag & 0x8)) bin = bam_reg2bin((int)pnext1 - 1, (int)pnext1);
+    else bin = bam_reg2bin(-1, 0);
+    const size_t aux_len = sizeof(BAM_RG_AUX) + 8 + 4 + (with_qs ? 7 : 0);
+    const size_t block = 32 + (qn + 1) + 4 * (size_t)n_cig + (U + 1) / 2 + U + aux_len;     // without the block_size word itself
+    const size_t at = o.size();
+    o.reserve(at + 4 + block);
+    put_le32(o, (uint32_t)block);
+    put_le32(o, (uint32_t)(contig >= 0 ? contigs[(size_t)contig].orig : -1));
+    put_le32(o, (uint32_t)((int)pos1 - 1));
+    put_le32(o, ((uint32_t)bin << 16) | ((uint32_t)(mapq & 0xff) << 8) | (uint32_t)(qn + 1));
+    put_le32(o, ((uint32_t)flag << 16) | (uint32_t)n_cig);
+    put_le32(o, (uint32_t)U);
+    put_le32(o, (uint32_t)(mate_contig >= 0 ? contigs[(size_t)mate_contig].orig : -1));
+    put_le32(o, (uint32_t)((int)pnext1 - 1));
+    put_le32(o, (uint32_t)(int)(tlen >= 0 ? (tlen & 0x7fffffff) : -((-tlen) & 0x7fffffff)));
+    o.append(qname, qn); o.push_back('\0');
+    for (int c = 0; c < n_cig; c++) put_le32(o, ops[c]);
+    {   // SEQ (4 bits per base) and QUAL (Phred), in the record's orientation
+        const size_t a0 = o.size();
+        o.resize(a0 + (U + 1) / 2 + U);
+        uint8_t *sq = (uint8_t *)&o[a0], *ql = sq + (U + 1) / 2;
+        for (size_t j = 0; j < U; j++) {
+            const char base = rc ? complement(s[U - 1 - j]) : s[j];
+            const uint8_t code = BAM_SEQ.c[(unsigned char)base];
+            if (j & 1) sq[j >> 1] |= code; else sq[j >> 1] = (uint8_t)(code << 4);
+            ql[j] = (uint8_t)((rc ? q[U - 1 - j] : q[j]) - '!');
+        }
+    }
+    o.append(BAM_RG_AUX, sizeof(BAM_RG_AUX));
+    o.append("PGZSNAP", 8);
+    o.append("NMC", 3); o.push_back((char)(uint8_t)nm);
+    if (with_qs) { o.append("QSi", 3); put_le32(o, (uint32_t)qs); }
+    if (o.size() - at != 4 + block) die("internal error: BAM record size");
+}
+
+// BGZF (SAM/BAM specification, section 4.1): gzip members of at most 64 KiB with the block size in an extra field; concatenated members
+// are a valid gzip file, which is what lets every formatter thread compress its own batch.
+static void bgzf_append(std::string &out, const char *data, size_t n)
+{
+    const size_t CHUNK = 0xff00;
+    for (size_t at = 0; at < n || (n == 0 && at == 0); at += CHUNK) {
+        const size_t len = n - at < CHUNK ? n - at : CHUNK;
+        z_stream zs; memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) die("deflateInit2 failed");
+        std::vector<unsigned char> buf(len + len / 8 + 64);
+        zs.next_in = (Bytef *)(data + at); zs.avail_in = (uInt)len; zs.next_out = buf.data(); zs.avail_out = (uInt)buf.size();
+        if (deflate(&zs, Z_FINISH) != Z_STREAM_END) die("deflate failed");
+        const size_t clen = buf.size() - zs.avail_out;
+        deflateEnd(&zs);
+        const size_t bsize = 18 + clen + 8;
+        if (bsize > 0x10000) die("internal error: BGZF block too large");
+        const unsigned char hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (unsigned char)((bsize - 1) & 0xff), (unsigned char)((bsize - 1) >> 8)};
+        out.append((const char *)hdr, 18);
+        out.append((const char *)buf.data(), clen);
+        put_le32(out, (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)(data + at), (uInt)len));
+        put_le32(out, (uint32_t)len);
+        if (n == 0) break;
+    }
+}
+
 // ---------------------------------------------------------------------------------------- main
 int main(int argc, char **argv)
 {
     Options o;
     o.paired = argc >= 2 && strcmp(argv[1], "paired") == 0;
     if (argc < (o.paired ? 5 : 4) || (!o.paired && strcmp(argv[1], "single") != 0))
-        die("usage: snapgpu-sam single <index-dir> <reads.fq> -o <out.sam> | paired <index-dir> <r1.fq> <r2.fq> -o <out.sam>  [-d N] [-G-] [-=] [-M] [-mrl N] [-b N] [-gpus N] [-q N] [-t N]");
+        die("usage: snapgpu-sam single <index-dir> <reads.fq> -o <out.sam|out.bam> | paired <index-dir> <r1.fq> <r2.fq> -o <out.sam|out.bam>  [-d N] [-G-] [-=] [-M] [-mrl N] [-b N] [-gpus N] [-q N] [-t N]");
     const std::string index_dir = argv[2], fastq = argv[3], fastq2 = o.paired ? argv[4] : "";
     std::string out_path;
     snapgpu_default_params(&o.p);
@@ -437,7 +546,8 @@ int main(int argc, char **argv)
         else if (a == "-t" && i + 1 < argc) o.n_format = atoi(argv[++i]);  // host threads that format records (the reference's -t counts aligner threads)
         else die("option not supported: ", a.c_str());
     }
-    if (out_path.empty()) die("-o <out.sam> is required");
+    if (out_path.empty()) die("-o <out.sam | out.bam> is required");
+    o.bam = out_path.size() > 4 && out_path.compare(out_path.size() - 4, 4, ".bam") == 0;     // by extension, like the reference (AlignerOptions.cpp)
     if (o.batch_reads < (o.paired ? 2u : 1u)) die("-b must be at least 1 (2 for paired)");
     if (o.paired) o.batch_reads &= ~(size_t)1;
     if (o.ctx_per_gpu < 1 || o.ctx_per_gpu > 8) die("-q must be in [1, 8]");
@@ -491,17 +601,28 @@ int main(int argc, char **argv)
     setvbuf(out, NULL, _IOFBF, 8u << 20);
     // header (SAM.cpp:1232-1295); @SQ lines go by ORIGINAL contig number: the index builder moves ALT contigs behind the regular ones
     // (FASTA.cpp:359-384), the header keeps the FASTA's order (getContigByOriginalContigNumber, SAM.cpp:1291)
-    fprintf(out, "@HD\tVN:1.6\tGO:query\n@RG\tID:FASTQ\tPL:Illumina\tPU:pu\tLB:lb\tSM:sm\n@PG\tID:SNAP\tPN:SNAP\tCL:%s\tVN:2.0.5\n", cl.c_str());
+    // The BAM header is the same text inside the binary header, followed by the contig table in the same (original) order (Bam.cpp:970-1031).
     {
+        std::string text = "@HD\tVN:1.6\tGO:query\n@RG\tID:FASTQ\tPL:Illumina\tPU:pu\tLB:lb\tSM:sm\n@PG\tID:SNAP\tPN:SNAP\tCL:" + cl + "\tVN:2.0.5\n";
+        std::string refs;
         std::vector<size_t> by_orig(contigs.size());
         bool perm = true;
         std::vector<char> seen(contigs.size(), 0);
         for (size_t c = 0; c < contigs.size(); c++) { if (contigs[c].orig < 0 || (size_t)contigs[c].orig >= contigs.size() || seen[(size_t)contigs[c].orig]) { perm = false; break; } seen[(size_t)contigs[c].orig] = 1; by_orig[(size_t)contigs[c].orig] = c; }
+        if (o.bam && !perm) die("the index's original contig numbers are not a permutation: cannot number the BAM reference sequences");
         for (size_t k = 0; k < contigs.size(); k++) {
             const size_t c = perm ? by_orig[k] : k;
             const uint64_t end = c + 1 < contigs.size() ? contigs[c + 1].begin : n_bases;
-            fprintf(out, "@SQ\tSN:%s\tLN:%llu%s\n", contigs[c].name.c_str(), (unsigned long long)(end - contigs[c].begin - padding), contigs[c].is_alt ? "\tAH:*" : "");
+            const unsigned long long len = (unsigned long long)(end - contigs[c].begin - padding);
+            text += "@SQ\tSN:" + contigs[c].name + "\tLN:" + std::to_string(len) + (contigs[c].is_alt ? "\tAH:*" : "") + "\n";
+            put_le32(refs, (uint32_t)contigs[c].name.size() + 1); refs += contigs[c].name; refs.push_back('\0'); put_le32(refs, (uint32_t)len);
         }
+        if (o.bam) {
+            std::string h = "BAM\1";
+            put_le32(h, (uint32_t)text.size()); h += text; put_le32(h, (uint32_t)contigs.size()); h += refs;
+            std::string z; bgzf_append(z, h.data(), h.size());
+            if (fwrite(z.data(), 1, z.size(), out) != z.size()) die("write error on ", out_path.c_str());
+        } else if (fwrite(text.data(), 1, text.size(), out) != text.size()) die("write error on ", out_path.c_str());
     }
 
     // ---- the pipeline
@@ -518,7 +639,7 @@ int main(int argc, char **argv)
         bool eof = false;
         while (!eof) {
             Work *w = new Work();
-            w->b.clear(); w->b.seq = seq;
+            w->b.clear(); w->b.seq = seq; w->bam = o.bam;
             while (w->b.n() < o.batch_reads) {
                 if (!next_read(in, w->b, o.p.max_read_len)) { eof = true; break; }
                 if (o.paired && !next_read(in2, w->b, o.p.max_read_len)) die("the second FASTQ file has fewer reads than the first");
@@ -546,6 +667,7 @@ int main(int argc, char **argv)
             Work *w;
             while (q_aligned.pop(w)) {
                 if (o.paired) format_paired(contigs, *w); else format_single(contigs, *w);
+                if (o.bam) { std::string z; z.reserve(w->text.size() / 3 + 64); bgzf_append(z, w->text.data(), w->text.size()); w->text.swap(z); }
                 std::lock_guard<std::mutex> l(done_m); done[w->b.seq] = w; done_cv.notify_all();
             }
         });
@@ -564,6 +686,7 @@ int main(int argc, char **argv)
     reader.join();
     for (auto &t : feeders) t.join();
     for (auto &t : formatters) t.join();
+    if (o.bam) { std::string eof; bgzf_append(eof, "", 0); if (fwrite(eof.data(), 1, eof.size(), out) != eof.size()) die("write error on ", out_path.c_str()); }     // the empty end-of-file block
     if (fclose(out) != 0) die("write error on ", out_path.c_str());
     for (size_t t = ctxs.size(); t-- > 0;) snapgpu_destroy(ctxs[t]);        // sharers before the owner of the blobs they share
     fprintf(stderr, "snapgpu-sam: %llu reads, %llu mapped records, %d GPU(s) x %d feeder(s), %d formatter thread(s)\n", total, mapped, o.n_gpus, o.ctx_per_gpu, o.n_format);

@@ -275,6 +275,23 @@ def test_emu_native_paired_fastq_to_sam(emu, tmp_path):
     assert run_and_compare_paired(TOOL, str(tmp_path), index_dir, fq, [], env=dict(os.environ, SNAPGPU_EMU_CUS="4")) > 600
 
 
+def test_emu_native_fastq_to_bam(emu, tmp_path):
+    """`-o x.bam`: header, reference table and records of the native program's BAM (decompressed) equal the reference CLI's, single end
+    (with secondary records) and paired end."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.emu.build import TOOL
+    from tests.test_zz_gpu_native_sam import make_workload, make_paired_workload, run_and_compare_bam
+    env = dict(os.environ, SNAPGPU_EMU_CUS="4")
+    ds, dp = str(tmp_path / "s"), str(tmp_path / "p")
+    os.makedirs(ds); os.makedirs(dp)
+    index_dir, fastq = make_workload(ds, 400, genome_bases=300_000)
+    assert run_and_compare_bam(TOOL, ds, "single", index_dir, [fastq], ["-om", "1", "-omax", "3"], env=env) > 400
+    index_dir, fq = make_paired_workload(dp, 150, genome_bases=300_000)
+    assert run_and_compare_bam(TOOL, dp, "paired", index_dir, fq, [], env=env) == 300
+
+
 def test_emu_option_sets(emu, tmp_path):
     """Option sets no fixture pins (-h 16, seed coverage instead of -n, -D 3, other scoring parameters and end bonuses), 250 reads of a
     repeat-rich genome with an ALT contig against the compiled reference, work counters included."""

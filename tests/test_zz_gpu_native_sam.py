@@ -2,8 +2,8 @@
 snapgpu_sam_fields_single, SAM text) must write the same file as the unmodified reference CLI (oracle/_ref/snap-aligner) -- every line
 but @PG -- on the same FASTQ and index, under several option sets.
 
-Written in a round that had no GPU time left: verified with the program linked against the wavefront emulator
-(tests/test_emu_kernels.py::test_emu_native_fastq_to_sam), not yet on hardware -- hence the file name (last in the `-m gpu` run)."""
+Also `-o x.bam`: the BAM header, reference table and records (decompressed BGZF) must equal the reference CLI's (SNAPLib/Bam.cpp).
+First verified with the program linked against the wavefront emulator (tests/test_emu_kernels.py::test_emu_native_*), on hardware since round 2."""
 import os
 import subprocess
 
@@ -14,7 +14,8 @@ from snap_amd import synth
 from oracle import ref
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TOOL = os.path.join(ROOT, "snap_amd", "snapgpu-sam")
+# (SNAPGPU_TEST_TOOL: the same program linked against the wavefront emulator, to run this file on the host -- tests/emu/README.md)
+TOOL = os.environ.get("SNAPGPU_TEST_TOOL") or os.path.join(ROOT, "snap_amd", "snapgpu-sam")
 
 
 def make_workload(d, n_reads, genome_bases=600_000):
@@ -150,3 +151,56 @@ def test_native_paired_fastq_to_sam_identical_to_reference_cli(paired_workload, 
     assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
     d, index_dir, fq = paired_workload
     assert run_and_compare_paired(TOOL, d, index_dir, fq, opts) > 5000
+
+
+# ---------------------------------------------------------------------------------------- BAM (-o x.bam)
+def bam_parts(path):
+    """(header text without @PG, [(name, length)] of the reference table, [record bytes]) of a BAM file; BGZF is concatenated gzip members."""
+    import gzip
+    import struct
+    raw = gzip.open(path, "rb").read()
+    assert raw[:4] == b"BAM\1"
+    lt = struct.unpack_from("<i", raw, 4)[0]
+    text = b"\n".join(l for l in raw[8:8 + lt].split(b"\n") if not l.startswith(b"@PG"))
+    at = 8 + lt
+    n_ref = struct.unpack_from("<i", raw, at)[0]; at += 4
+    refs = []
+    for _ in range(n_ref):
+        ln = struct.unpack_from("<i", raw, at)[0]
+        refs.append((raw[at + 4:at + 4 + ln], struct.unpack_from("<i", raw, at + 4 + ln)[0])); at += 8 + ln
+    recs = []
+    while at < len(raw):
+        bs = struct.unpack_from("<i", raw, at)[0]
+        recs.append(raw[at:at + 4 + bs]); at += 4 + bs
+    return text, refs, recs
+
+
+def run_and_compare_bam(tool, d, mode, index_dir, fqs, opts, env=None):
+    """Both programs write BAM; header text, reference table and every record (bin, cigar ops, 4-bit SEQ, QUAL, aux tags ...) must be the
+    same bytes, in the same order (`-t 1` keeps the input order in the reference)."""
+    tag = mode + "_" + ("_".join(o.strip("-") or "eq" for o in opts) or "default")
+    out_ref, out_new = os.path.join(d, "ref_%s.bam" % tag), os.path.join(d, "new_%s.bam" % tag)
+    for cmd, e in (([ref.CLI_PATH, mode, index_dir] + fqs + ["-o", out_ref, "-t", "1"] + opts, None), ([tool, mode, index_dir] + fqs + ["-o", out_new] + opts, env)):
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=3000, env=e)
+        assert r.returncode == 0, "%s failed:\n%s" % (cmd[0], r.stdout.decode(errors="replace")[-3000:])
+    a, b = bam_parts(out_ref), bam_parts(out_new)
+    assert a[0] == b[0] and a[1] == b[1]
+    assert len(a[2]) == len(b[2])
+    diff = [k for k, (x, y) in enumerate(zip(a[2], b[2])) if x != y]
+    assert not diff, "%d of %d BAM records differ, first: %r vs %r" % (len(diff), len(a[2]), a[2][diff[0]][:80], b[2][diff[0]][:80])
+    return len(a[2])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+@pytest.mark.parametrize("opts", [[], ["-=", "-om", "1", "-omax", "3"]])
+def test_native_fastq_to_bam_identical_to_reference_cli(single_workload, opts):
+    d, index_dir, fastq = single_workload
+    assert run_and_compare_bam(TOOL, d, "single", index_dir, [fastq], opts) > 8000
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+def test_native_paired_fastq_to_bam_identical_to_reference_cli(paired_workload):
+    d, index_dir, fq = paired_workload
+    assert run_and_compare_bam(TOOL, d, "paired", index_dir, fq, []) == 5000
