@@ -157,6 +157,14 @@ struct Work {                                // a batch on its way through the p
     std::vector<int32_t> flag, contig, mapq, n_ops, nm, rnext, first_written;
     std::vector<int64_t> pos, pnext, tlen;
     std::vector<uint32_t> ops; uint32_t ops_stride = 64;
+    // paired end: what to write, in order.  A "pair unit" is one PairedAlignmentResult of a pair (the primary, a secondary one, the first
+    // ALT one): two records, fields at [2u], [2u + 1] of the arrays above, first_written[u].  A "single unit" is one single-end secondary
+    // result of a mate (ReadWriter.cpp:508-590): one record, fields in the s_* arrays.
+    struct Emit { uint32_t unit; uint8_t single; };
+    std::vector<Emit> emit;
+    std::vector<uint32_t> pu_pair; std::vector<char> pu_secondary;       // per pair unit: the pair it belongs to, flag 0x100
+    std::vector<uint32_t> su_read;                                       // per single unit: the read (2 * pair + mate)
+    std::vector<int32_t> s_flag, s_contig, s_mapq, s_n_ops, s_nm; std::vector<int64_t> s_pos; std::vector<uint32_t> s_ops; uint32_t s_ops_stride = 64;
     std::string text;                        // the formatted records (BAM: BGZF blocks)
     bool bam = false;
     unsigned long long mapped = 0;
@@ -309,21 +317,167 @@ static void gpu_paired(const Options &o, snapgpu_ctx *ctx, Work &w)
         memset(&results[k], 0, sizeof(results[k]));
         for (int v = 0; v < 2; v++) { results[k].status[v] = SNAPGPU_NotFound; results[k].location[v] = SNAPGPU_InvalidGenomeLocation32; results[k].score[v] = -1; }
     }
+    // secondary results (-om): paired ones and each mate's single-end ones (PairedAligner.cpp:727-779)
+    std::vector<snapgpu_paired_result> sec; std::vector<uint32_t> nsec(to_align.size(), 0), nssec(2 * to_align.size(), 0);
+    std::vector<snapgpu_single_result> ssec;
+    uint32_t sec_stride = 0, ssec_stride = 0;
     if (!to_align.empty()) {
-        int rc = snapgpu_align_paired(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), ares.data(), aalt.data());
+        int rc;
+        if (o.om >= 0) {
+            sec_stride = 8; ssec_stride = 16;
+            for (;;) {
+                sec.assign(to_align.size() * (size_t)sec_stride, snapgpu_paired_result()); ssec.assign(to_align.size() * (size_t)ssec_stride, snapgpu_single_result());
+                rc = snapgpu_align_paired_secondary(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), ares.data(), aalt.data(),
+                                                    sec.data(), sec_stride, nsec.data(), ssec.data(), ssec_stride, nssec.data());
+                if (rc != SNAPGPU_W_SECONDARY_TRUNCATED) break;
+                for (size_t k = 0; k < to_align.size(); k++) {
+                    if (nsec[k] > sec_stride) sec_stride = nsec[k];
+                    if (nssec[2 * k] + nssec[2 * k + 1] > ssec_stride) ssec_stride = nssec[2 * k] + nssec[2 * k + 1];
+                }
+            }
+        } else rc = snapgpu_align_paired(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), ares.data(), aalt.data());
         if (rc != SNAPGPU_OK) fail_rc(ctx, "snapgpu_align_paired", rc);
         for (size_t k = 0; k < to_align.size(); k++) results[to_align[k]] = ares[k];
     }
-    w.flag.assign(n, 0); w.contig.assign(n, 0); w.mapq.assign(n, 0); w.n_ops.assign(n, 0); w.nm.assign(n, 0); w.rnext.assign(n, 0);
-    w.first_written.assign(np, 0); w.pos.assign(n, 0); w.pnext.assign(n, 0); w.tlen.assign(n, 0);
-    std::vector<int32_t> stale(n);
-    w.ops_stride = o.ops_stride;
-    with_growing_stride(w, n, [&] {
-        int rc = snapgpu_sam_fields_paired(ctx, (uint32_t)np, b.bases.data(), b.quals.data(), b.offsets.data(), front_clip.data(), data_len.data(), results.data(),
-                                           o.use_m ? 1 : 0, w.flag.data(), w.contig.data(), w.pos.data(), w.mapq.data(), w.ops.data(), w.ops_stride, w.n_ops.data(),
-                                           w.nm.data(), w.rnext.data(), w.pnext.data(), w.tlen.data(), w.first_written.data(), stale.data());
-        if (rc != SNAPGPU_OK) fail_rc(ctx, "snapgpu_sam_fields_paired", rc);
-    });
+    // what gets written, in the reference's order (PairedAligner.cpp:874-880 -> SimpleReadWriter::writePairs): the pair's results (primary first),
+    // read 0's single-end secondary results, read 1's, then -- with -ea -- the first ALT result as a pair of its own
+    std::vector<snapgpu_paired_result> pu_res; std::vector<snapgpu_single_result> su_res;
+    w.emit.clear(); w.pu_pair.clear(); w.pu_secondary.clear(); w.su_read.clear();
+    {
+        std::vector<uint32_t> slot(np, 0xffffffffu);
+        for (size_t k = 0; k < to_align.size(); k++) slot[to_align[k]] = (uint32_t)k;
+        auto add_pair_unit = [&](size_t k, const snapgpu_paired_result &r, bool secondary) {
+            w.emit.push_back(Work::Emit{(uint32_t)pu_res.size(), 0}); w.pu_pair.push_back((uint32_t)k); w.pu_secondary.push_back(secondary ? 1 : 0); pu_res.push_back(r);
+        };
+        for (size_t k = 0; k < np; k++) {
+            add_pair_unit(k, results[k], false);
+            const uint32_t a = slot[k];
+            if (a == 0xffffffffu) continue;
+            if (o.om >= 0) {
+                for (uint32_t j = 0; j < nsec[a]; j++) add_pair_unit(k, sec[(size_t)a * sec_stride + j], true);
+                uint32_t at = 0;
+                for (int v = 0; v < 2; v++) {
+                    // (the reference applies the FIRST single result's clippingForReadAdjustment to every one of the mate's single records:
+                    //  `singleResults[whichRead]->clippingForReadAdjustment`, ReadWriter.cpp:516)
+                    const int32_t first_adj = nssec[2 * a + v] ? ssec[(size_t)a * ssec_stride + at].clipping_for_read_adjustment : 0;
+                    for (uint32_t j = 0; j < nssec[2 * a + v]; j++, at++) {
+                        snapgpu_single_result r = ssec[(size_t)a * ssec_stride + at];
+                        r.clipping_for_read_adjustment = first_adj;
+                        w.emit.push_back(Work::Emit{(uint32_t)su_res.size(), 1}); w.su_read.push_back((uint32_t)(2 * k + (size_t)v)); su_res.push_back(r);
+                    }
+                }
+            }
+            if (o.p.emit_alt_alignments && (aalt[a].status[0] != SNAPGPU_NotFound || aalt[a].status[1] != SNAPGPU_NotFound)) add_pair_unit(k, aalt[a], false);
+        }
+    }
+    const size_t nu = pu_res.size(), nrec = 2 * nu, ns = su_res.size();
+    w.flag.assign(nrec, 0); w.contig.assign(nrec, 0); w.mapq.assign(nrec, 0); w.n_ops.assign(nrec, 0); w.nm.assign(nrec, 0); w.rnext.assign(nrec, 0);
+    w.first_written.assign(nu, 0); w.pos.assign(nrec, 0); w.pnext.assign(nrec, 0); w.tlen.assign(nrec, 0);
+    w.s_flag.assign(ns, 0); w.s_contig.assign(ns, 0); w.s_mapq.assign(ns, 0); w.s_n_ops.assign(ns, 0); w.s_nm.assign(ns, 0); w.s_pos.assign(ns, 0);
+    w.ops_stride = w.s_ops_stride = o.ops_stride;
+    if (nu == np && ns == 0) {                                          // one result per pair: one call over the batch as it is
+        std::vector<int32_t> stale(nrec);
+        with_growing_stride(w, nrec, [&] {
+            int rc = snapgpu_sam_fields_paired(ctx, (uint32_t)nu, b.bases.data(), b.quals.data(), b.offsets.data(), front_clip.data(), data_len.data(), pu_res.data(),
+                                               o.use_m ? 1 : 0, w.flag.data(), w.contig.data(), w.pos.data(), w.mapq.data(), w.ops.data(), w.ops_stride, w.n_ops.data(),
+                                               w.nm.data(), w.rnext.data(), w.pnext.data(), w.tlen.data(), w.first_written.data(), stale.data());
+            if (rc != SNAPGPU_OK) fail_rc(ctx, "snapgpu_sam_fields_paired", rc);
+        });
+        return;
+    }
+    // Several results per pair.  The reference writes them one after the other through the SAME two Read objects, and one piece of their state
+    // survives from record to record: the additional BACK clipping that the affine-gap writer sets when it turns a leading insertion of a
+    // reverse-complement alignment into a soft clip (SAM.cpp:1676-1680 / ReadWriter.cpp:545-551; setAdditionalFrontClipping is re-set for every
+    // result, setAdditionalBackClipping never is: Read.h:537-553).  So the j-th entries of all pairs are computed together (round j), and what a
+    // record leaves behind -- readable off its leading soft clip -- shortens the data length the next entry of the same read is given.
+    std::vector<std::vector<Work::Emit>> per_pair(np);
+    for (const Work::Emit &e : w.emit) per_pair[e.single ? w.su_read[e.unit] / 2 : w.pu_pair[e.unit]].push_back(e);
+    size_t n_rounds = 0;
+    for (size_t k = 0; k < np; k++) if (per_pair[k].size() > n_rounds) n_rounds = per_pair[k].size();
+    for (;;) {                                                           // (again with a larger stride when a cigar did not fit)
+        bool too_small = false;
+        std::vector<int32_t> carry(n, 0);
+        w.ops.assign(nrec * (size_t)w.ops_stride, 0); w.s_ops.assign(ns * (size_t)w.s_ops_stride, 0);
+        auto ag_branch = [&](int used_ag, int score) { return o.p.use_affine_gap && (used_ag != 0 || score > 0); };
+        // the state a written record leaves on its Read: `passed_len` is the data length the record was computed with
+        auto leave_behind = [&](size_t rd, bool more, bool ag, int status_in, int flag, int64_t pos, int n_ops, const uint32_t *ops, int clipped_before, int passed_len) {
+            if (!more || !ag) return;
+            const size_t U = (size_t)(b.offsets[rd + 1] - b.offsets[rd]);
+            if ((flag & 0x4) && status_in != SNAPGPU_NotFound) die("paired -om / -ea: a record was given up after clipping adjustments and the read has further records (unsupported corner)");
+            if (!(flag & 0x10) || n_ops <= 0) return;
+            if (pos == 1) die("paired -om / -ea: a reverse-complement record at the first base of a contig followed by further records of the read (unsupported corner)");
+            const int lead = (ops[0] & 15u) == 4u ? (int)(ops[0] >> 4) : 0;
+            const int left = lead - ((int)U - passed_len - front_clip[rd]) - clipped_before;
+            if (left < 0) die("internal error: leading soft clip shorter than the read's own clipping");
+            if (left > 0 && carry[rd] > 0) die("paired -om / -ea: two records of one read both soft-clip a leading insertion (unsupported corner)");
+            if (left > 0) carry[rd] = left;
+        };
+        for (size_t j = 0; j < n_rounds; j++) {
+            std::vector<uint32_t> pus, sus;                              // this round's pair units / single units
+            for (size_t k = 0; k < np; k++) if (j < per_pair[k].size()) (per_pair[k][j].single ? sus : pus).push_back(per_pair[k][j].unit);
+            if (!pus.empty()) {
+                const size_t m = pus.size();
+                std::vector<char> rb, rq; std::vector<uint64_t> ro(1, 0); std::vector<int32_t> rfc(2 * m), rdl(2 * m), stale(2 * m);
+                std::vector<snapgpu_paired_result> rr(m);
+                for (size_t x = 0; x < m; x++) {
+                    rr[x] = pu_res[pus[x]];
+                    for (size_t v = 0; v < 2; v++) {
+                        const size_t i = 2 * (size_t)w.pu_pair[pus[x]] + v;
+                        rb.insert(rb.end(), b.bases.begin() + (long)b.offsets[i], b.bases.begin() + (long)b.offsets[i + 1]);
+                        rq.insert(rq.end(), b.quals.begin() + (long)b.offsets[i], b.quals.begin() + (long)b.offsets[i + 1]);
+                        ro.push_back(rb.size()); rfc[2 * x + v] = front_clip[i]; rdl[2 * x + v] = data_len[i] - carry[i];
+                    }
+                }
+                std::vector<int32_t> f(2 * m), c(2 * m), mq(2 * m), no(2 * m), nm(2 * m), rn(2 * m), fw(m); std::vector<int64_t> ps(2 * m), pn(2 * m), tl(2 * m);
+                std::vector<uint32_t> ops(2 * m * (size_t)w.ops_stride);
+                int rc = snapgpu_sam_fields_paired(ctx, (uint32_t)m, rb.data(), rq.data(), ro.data(), rfc.data(), rdl.data(), rr.data(), o.use_m ? 1 : 0,
+                                                   f.data(), c.data(), ps.data(), mq.data(), ops.data(), w.ops_stride, no.data(), nm.data(), rn.data(), pn.data(), tl.data(), fw.data(), stale.data());
+                if (rc != SNAPGPU_OK) fail_rc(ctx, "snapgpu_sam_fields_paired", rc);
+                for (size_t x = 0; x < m; x++) {
+                    const size_t u = pus[x], k = w.pu_pair[u];
+                    w.first_written[u] = fw[x];
+                    for (size_t v = 0; v < 2; v++) {
+                        const size_t src = 2 * x + v, dst = 2 * u + v;
+                        if (nm[src] == -2) too_small = true;
+                        w.flag[dst] = f[src] | (w.pu_secondary[u] ? 0x100 : 0); w.contig[dst] = c[src]; w.pos[dst] = ps[src]; w.mapq[dst] = mq[src]; w.n_ops[dst] = no[src];
+                        w.nm[dst] = nm[src]; w.rnext[dst] = rn[src]; w.pnext[dst] = pn[src]; w.tlen[dst] = tl[src];
+                        memcpy(&w.ops[dst * (size_t)w.ops_stride], &ops[src * (size_t)w.ops_stride], (size_t)w.ops_stride * 4);
+                        leave_behind(2 * k + v, j + 1 < per_pair[k].size(), ag_branch(rr[x].used_affine_gap_scoring[v], rr[x].score[v]), rr[x].status[v], f[src], ps[src], no[src],
+                                     &ops[src * (size_t)w.ops_stride], rr[x].bases_clipped_before[v], rdl[src]);
+                    }
+                }
+            }
+            if (!sus.empty()) {                                          // records of their own, without mate information (format->writeRead, ReadWriter.cpp:521-527)
+                const size_t m = sus.size();
+                std::vector<char> sb, sq; std::vector<uint64_t> so(1, 0); std::vector<int32_t> sfc(m), sdl(m), stale(m);
+                std::vector<snapgpu_single_result> rr(m);
+                for (size_t x = 0; x < m; x++) {
+                    const size_t i = w.su_read[sus[x]];
+                    rr[x] = su_res[sus[x]];
+                    sb.insert(sb.end(), b.bases.begin() + (long)b.offsets[i], b.bases.begin() + (long)b.offsets[i + 1]);
+                    sq.insert(sq.end(), b.quals.begin() + (long)b.offsets[i], b.quals.begin() + (long)b.offsets[i + 1]);
+                    so.push_back(sb.size()); sfc[x] = front_clip[i]; sdl[x] = data_len[i] - carry[i];
+                }
+                std::vector<int32_t> f(m), c(m), mq(m), no(m), nm(m); std::vector<int64_t> ps(m);
+                std::vector<uint32_t> ops(m * (size_t)w.s_ops_stride);
+                int rc = snapgpu_sam_fields_single(ctx, (uint32_t)m, sb.data(), sq.data(), so.data(), sfc.data(), sdl.data(), rr.data(), o.use_m ? 1 : 0,
+                                                   f.data(), c.data(), ps.data(), mq.data(), ops.data(), w.s_ops_stride, no.data(), nm.data(), stale.data());
+                if (rc != SNAPGPU_OK) fail_rc(ctx, "snapgpu_sam_fields_single", rc);
+                for (size_t x = 0; x < m; x++) {
+                    const size_t r = sus[x], rd = w.su_read[r], k = rd / 2;
+                    if (nm[x] == -2) too_small = true;
+                    w.s_flag[r] = f[x] | 0x100; w.s_contig[r] = c[x]; w.s_pos[r] = ps[x]; w.s_mapq[r] = mq[x]; w.s_n_ops[r] = no[x]; w.s_nm[r] = nm[x];
+                    memcpy(&w.s_ops[r * (size_t)w.s_ops_stride], &ops[x * (size_t)w.s_ops_stride], (size_t)w.s_ops_stride * 4);
+                    // (a single-end record is written without the aligner's soft clipping unless it went through the affine-gap writer: sam_fields.h)
+                    const bool ag = ag_branch(rr[x].used_affine_gap_scoring, rr[x].score);
+                    leave_behind(rd, j + 1 < per_pair[k].size(), ag, rr[x].status, f[x], ps[x], no[x], &ops[x * (size_t)w.s_ops_stride], ag ? rr[x].bases_clipped_before : 0, sdl[x]);
+                }
+            }
+        }
+        if (!too_small) break;
+        if (w.ops_stride >= 4096) die("a cigar needs more than 4096 operations");
+        w.ops_stride *= 4; w.s_ops_stride = w.ops_stride;
+    }
 }
 
 // ---------------------------------------------------------------------------------------- formatting stage
@@ -377,10 +531,34 @@ static void format_single(const std::vector<Contig> &contigs, Work &w)
 static void format_paired(const std::vector<Contig> &contigs, Work &w)
 {
     const Batch &b = w.b;
-    const size_t np = b.n() / 2;
     std::string &o = w.text;
-    o.clear(); o.reserve(b.n() * 440);
-    for (size_t k = 0; k < np; k++) {
+    o.clear(); o.reserve(w.emit.size() * 880);
+    for (const Work::Emit &e : w.emit) {
+        if (e.single) {
+            // a mate's single-end secondary result: SAMFormat::writeRead without a mate -- the whole read id (the "/1" stays: the call is given
+            // getIdLength(), ReadWriter.cpp:521), no mate fields, no QS
+            const size_t r = e.unit, rd = w.su_read[r];
+            const char *s = b.bases.data() + b.offsets[rd], *q = b.quals.data() + b.offsets[rd];
+            const size_t U = (size_t)(b.offsets[rd + 1] - b.offsets[rd]);
+            const char *nm = b.names.data() + b.name_off[rd]; size_t nl = b.name_off[rd + 1] - b.name_off[rd];
+            const void *sp = memchr(nm, ' ', nl);
+            if (sp) nl = (size_t)((const char *)sp - nm);
+            if (w.bam) {
+                put_bam_record(o, contigs, nm, nl, w.s_flag[r], w.s_contig[r], w.s_pos[r], w.s_mapq[r], w.s_ops.data() + r * (size_t)w.s_ops_stride, w.s_n_ops[r], -1, 0, 0, s, q, U, w.s_nm[r], false, 0);
+            } else {
+                o.append(nm, nl); o.push_back('\t'); put_int(o, w.s_flag[r]); o.push_back('\t');
+                if (w.s_contig[r] >= 0) o += contigs[(size_t)w.s_contig[r]].name; else o.push_back('*');
+                o.push_back('\t'); put_int(o, w.s_pos[r]); o.push_back('\t'); put_int(o, w.s_mapq[r]); o.push_back('\t');
+                if (w.s_n_ops[r] < 0) o.push_back('*');
+                else for (int c = 0; c < w.s_n_ops[r]; c++) { const uint32_t op = w.s_ops[r * (size_t)w.s_ops_stride + (size_t)c]; put_uint(o, op >> 4); o.push_back("MIDNSHP=X"[op & 15]); }
+                o += "\t*\t0\t0\t";
+                put_seq_qual(o, s, q, U, (w.s_flag[r] & 0x10) != 0);
+                o += "\tPG:Z:SNAP\tNM:i:"; put_int(o, w.s_nm[r]); o += AUX_TAIL; o.push_back('\n');
+            }
+            w.mapped += (w.s_flag[r] & 0x4) == 0;
+            continue;
+        }
+        const size_t u = e.unit, k = w.pu_pair[u];
         // QNAME: the /1 /2 suffixes go when both names carry them (ReadWriter.cpp:392-404)
         const char *n0 = b.names.data() + b.name_off[2 * k], *n1 = b.names.data() + b.name_off[2 * k + 1];
         size_t idl[2] = { (size_t)(b.name_off[2 * k + 1] - b.name_off[2 * k]), (size_t)(b.name_off[2 * k + 2] - b.name_off[2 * k + 1]) };
@@ -389,16 +567,17 @@ static void format_paired(const std::vector<Contig> &contigs, Work &w)
             if ((c0 == '1' || c0 == '2') && (c1 == '1' || c1 == '2') && c0 != c1) { idl[0] -= 2; idl[1] -= 2; }
         }
         for (int ord = 0; ord < 2; ord++) {
-            const int v = ord == 0 ? w.first_written[k] : 1 - w.first_written[k];
-            const size_t i = 2 * k + (size_t)v, im = 2 * k + (size_t)(1 - v);
-            const char *s = b.bases.data() + b.offsets[i], *q = b.quals.data() + b.offsets[i];
-            const size_t U = (size_t)(b.offsets[i + 1] - b.offsets[i]);
+            const int v = ord == 0 ? w.first_written[u] : 1 - w.first_written[u];
+            const size_t i = 2 * u + (size_t)v;                                             // fields
+            const size_t rd = 2 * k + (size_t)v, rm = 2 * k + (size_t)(1 - v);              // the read and its mate in the batch
+            const char *s = b.bases.data() + b.offsets[rd], *q = b.quals.data() + b.offsets[rd];
+            const size_t U = (size_t)(b.offsets[rd + 1] - b.offsets[rd]);
             const char *nm = v == 0 ? n0 : n1;
             size_t qn = idl[v];
             const void *sp = memchr(nm, ' ', qn);
             if (sp) qn = (size_t)((const char *)sp - nm);
             int mqs = 0;                                                // QS: the mate's qualities >= 15, summed (SAM.cpp:1826-1837)
-            { const unsigned char *mq = (const unsigned char *)b.quals.data() + b.offsets[im]; const size_t mu = (size_t)(b.offsets[im + 1] - b.offsets[im]);
+            { const unsigned char *mq = (const unsigned char *)b.quals.data() + b.offsets[rm]; const size_t mu = (size_t)(b.offsets[rm + 1] - b.offsets[rm]);
               for (size_t j = 0; j < mu; j++) { const int x = (int)mq[j] - '!'; mqs += x >= 15 ? (x != 255) * x : 0; } }
             if (w.bam) {
                 const int mate_contig = w.rnext[i] == -2 ? w.contig[i] : w.rnext[i];
@@ -587,7 +766,6 @@ int main(int argc, char **argv)
     for (snapgpu_ctx *c : ctxs) {
         if (o.paired) { rc = snapgpu_enable_paired(c, &o.pp); if (rc != SNAPGPU_OK) fail_rc(c, "snapgpu_enable_paired", rc); }
         if (o.om >= 0) {
-            if (o.paired) die("-om with `paired` is not supported by this program yet");
             snapgpu_secondary_params sp; memset(&sp, 0, sizeof(sp));
             sp.max_edit_distance = o.om; sp.max_per_contig = o.mpc; sp.max_results = o.omax; sp.adjust_alignments = 0;
             rc = snapgpu_enable_secondary(c, &sp);

@@ -275,6 +275,23 @@ def test_emu_native_paired_fastq_to_sam(emu, tmp_path):
     assert run_and_compare_paired(TOOL, str(tmp_path), index_dir, fq, [], env=dict(os.environ, SNAPGPU_EMU_CUS="4")) > 600
 
 
+def test_emu_native_paired_secondary_and_alt_records(emu, tmp_path):
+    """`snapgpu-sam paired -om 1` (further pair results + the mates' single-end secondary results as records) and `-ea` (the first ALT pair)
+    on the emulated device: the reference CLI's file, line for line in its order."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.emu.build import TOOL
+    from tests.test_zz_gpu_native_sam import make_paired_workload, make_paired_alt_workload, run_and_compare_paired
+    env = dict(os.environ, SNAPGPU_EMU_CUS="4")
+    d1, d2 = str(tmp_path / "om"), str(tmp_path / "ea")
+    os.makedirs(d1); os.makedirs(d2)
+    index_dir, fq = make_paired_workload(d1, 150, genome_bases=300_000)
+    assert run_and_compare_paired(TOOL, d1, index_dir, fq, ["-om", "1"], env=env) > 300
+    index_dir, fq = make_paired_alt_workload(d2, 120, genome_bases=300_000)
+    assert run_and_compare_paired(TOOL, d2, index_dir, fq, ["-ea"], env=env) > 240
+
+
 def test_emu_native_fastq_to_bam(emu, tmp_path):
     """`-o x.bam`: header, reference table and records of the native program's BAM (decompressed) equal the reference CLI's, single end
     (with secondary records) and paired end."""

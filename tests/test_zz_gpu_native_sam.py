@@ -153,6 +153,59 @@ def test_native_paired_fastq_to_sam_identical_to_reference_cli(paired_workload, 
     assert run_and_compare_paired(TOOL, d, index_dir, fq, opts) > 5000
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+def test_native_paired_secondary_records_identical_to_reference_cli(paired_workload):
+    """-om with `paired`: every further PairedAlignmentResult of a pair as two more records (flag 0x100), then each mate's single-end secondary
+    results as records of their own -- unpaired flags, the whole read id -- in the order SimpleReadWriter::writePairs writes them
+    (ReadWriter.cpp:345-590)."""
+    opts = ["-D", "2", "-om", "2", "-omax", "3", "-mpc", "2", "-="]
+    d, index_dir, fq = paired_workload
+    n = run_and_compare_paired(TOOL, d, index_dir, fq, opts)
+    tag = "_".join(o.strip("-") or "eq" for o in opts)
+    flags = [int(line.split("\t")[1]) for line in open(os.path.join(d, "pnew_%s.sam" % tag)) if not line.startswith("@")]
+    assert n > 5000 and any(f & 0x100 and f & 0x1 for f in flags) and any(f & 0x100 and not f & 0x1 for f in flags)      # both kinds are in the workload
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+def test_native_paired_secondary_records_om1_small_genome(tmp_path):
+    """`-om 1` on 800 hard pairs of a 400 kb genome.  (On the 2 500 pairs of the module's 2 Mb workload `-om 1` runs into the one corner the
+    program refuses: two records of one read that both soft-clip a leading insertion -- the reference's additional back clipping is then
+    REPLACED, not added to, which cannot be reproduced from outside the device call; it stops with a message instead.  DESIGN.md section 14.)"""
+    d = str(tmp_path)
+    index_dir, fq = make_paired_workload(d, 800, genome_bases=400_000)
+    assert run_and_compare_paired(TOOL, d, index_dir, fq, ["-om", "1"]) > 2000
+
+
+def make_paired_alt_workload(d, n_pairs, genome_bases=500_000):
+    """Pairs over a genome whose first contig has a 1 % diverged ALT copy of one stretch (index built with -altContigName)."""
+    contigs = synth.make_genome(177, genome_bases, n_contigs=2, repeat_frac=0.1)
+    rng0 = np.random.default_rng(7)
+    alt = contigs[0][1][genome_bases // 20:genome_bases // 20 + genome_bases // 10].copy()
+    m = rng0.random(alt.size) < 0.01; alt[m] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng0.integers(0, 4, size=int(m.sum()))]
+    contigs.append(("alt1", alt))
+    fasta = os.path.join(d, "g.fa"); synth.write_fasta(fasta, contigs)
+    index_dir = os.path.join(d, "index")
+    ref.build_index(fasta, index_dir, seed_len=20, threads=max(1, min(8, os.cpu_count() or 1)), extra=["-altContigName", "alt1"])
+    p = synth.make_pairs(5, [contigs[0], contigs[2]], n_pairs, 150)
+    fq = [os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")]
+    with open(fq[0], "wb") as f1, open(fq[1], "wb") as f2:
+        for k in range(n_pairs):
+            f1.write(b"@p%d/1\n" % k + p["bases"][2 * k].tobytes() + b"\n+\n" + p["quals"][2 * k].tobytes() + b"\n")
+            f2.write(b"@p%d/2\n" % k + p["bases"][2 * k + 1].tobytes() + b"\n+\n" + p["quals"][2 * k + 1].tobytes() + b"\n")
+    return index_dir, fq
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+def test_native_paired_first_alt_records_identical_to_reference_cli(tmp_path):
+    """-ea with `paired`: the first ALT result of a pair is written as a pair of its own after the pair's other records (PairedAligner.cpp:877-879)."""
+    d = str(tmp_path)
+    index_dir, fq = make_paired_alt_workload(d, 1500)
+    assert run_and_compare_paired(TOOL, d, index_dir, fq, ["-ea"]) > 3000
+
+
 # ---------------------------------------------------------------------------------------- BAM (-o x.bam)
 def bam_parts(path):
     """(header text without @PG, [(name, length)] of the reference table, [record bytes]) of a BAM file; BGZF is concatenated gzip members."""
