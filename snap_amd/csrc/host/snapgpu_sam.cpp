@@ -203,6 +203,146 @@ static inline bool clip_read(const Options &o, const Batch &b, size_t i, int32_t
     return m >= o.min_read_len && n_count <= o.p.max_k;
 }
 
+// ---------------------------------------------------------------------------------------- the record loop on the host (rare path)
+// SAMFormat::writePairs / writeRead's attempt loop (SAM.cpp:1630-1721, ReadWriter.cpp:228-311 / :508-590) with the Read's clipping state as an
+// INPUT: what sam_fields.h does on the device for a record that starts from a fresh Read, done here for the records that do not -- a later
+// result of a read whose earlier record left additional back clipping behind (Read.h:547-553).  One snapgpu_compute_cigar_* call per attempt;
+// the arithmetic is sam_fields.h's (createSAMLine, computeCigarString, getRefSpanFromCigar, fillMateInfo), line for line.
+static const std::vector<Contig> *g_contigs = NULL; static uint64_t g_n_bases = 0; static uint32_t g_padding = 0;
+static int h_contig_at(long long loc) { int lo = 0, hi = (int)g_contigs->size() - 1, c = -1; while (lo <= hi) { const int mid = (lo + hi) >> 1; if ((long long)(*g_contigs)[(size_t)mid].begin <= loc) { c = mid; lo = mid + 1; } else hi = mid - 1; } return c; }
+static long long h_contig_end(int c) { return c == (int)g_contigs->size() - 1 ? (long long)g_n_bases : (long long)(*g_contigs)[(size_t)c + 1].begin; }
+struct HostRec {
+    int flag = 0, contig = -1, mapq = 0, n_ops = -1, nm = -1; long long pos = 0;
+    long long final_loc = -1; int final_dir = 0, bases_clipped_before = 0, ref_span = 0, data_len = 0;
+    std::vector<uint32_t> ops;
+    int back_after = 0;                      // the Read's additional back clipping once the record is written
+};
+struct HostRes { int status, direction, score, mapq, adj, used_ag, bcb, bca, supplementary; long long location; };
+
+static HostRec host_record(const Options &o, snapgpu_ctx *ctx, const char *bases, const char *quals, int U, int F0, int D0, int back0, const HostRes &res, bool paired)
+{
+    HostRec out; out.back_after = back0;
+    int addF = res.adj, addB = back0;
+    int status = res.status, direction = res.direction;
+    long long location = status == SNAPGPU_NotFound ? -1 : res.location, final_loc = location;
+    const bool ag_branch = o.p.use_affine_gap && (res.used_ag != 0 || res.score > 0);
+    int cum = 0, n_adj = 0;
+    std::vector<char> od((size_t)U), oq((size_t)U);
+    int oriented_dir = -1;
+    uint32_t stride = 256;
+    for (int attempt = 0; attempt < 2 * (int)o.p.max_read_len + 8; attempt++) {
+        const int front = F0 + addF, dlen = D0 - addF - addB;
+        long long loc = final_loc;
+        if (status == SNAPGPU_NotFound) loc = -1;
+        const int dir = loc < 0 ? 0 : direction;
+        int clipped_len = dlen, bcb, bca;
+        if (dir == 1) { bcb = U - clipped_len - front; bca = front; } else { bcb = front; bca = U - clipped_len - bcb; }
+        if (ag_branch || paired) { bcb += res.bcb; bca += res.bca; clipped_len -= res.bcb + res.bca; }
+        int flag = res.supplementary ? 0x800 : 0, contig = -1, mapq = 0;
+        long long pos = 0, extra = 0;
+        if (loc >= 0) {
+            if (dir == 1) flag |= 0x10;
+            contig = h_contig_at(loc);
+            if (contig < 0 || loc + dlen > h_contig_end(contig)) {
+                contig = contig + 1; if (contig >= (int)g_contigs->size()) contig = (int)g_contigs->size() - 1;
+                extra = (long long)(*g_contigs)[(size_t)contig].begin - loc;
+            }
+            pos = loc + extra - (long long)(*g_contigs)[(size_t)contig].begin + 1;
+            mapq = res.mapq < 0 ? 0 : (res.mapq > 70 ? 70 : res.mapq);
+        } else flag |= 0x4;
+        int afc = 0, nm = -1, n_ops = -1; bool star = true;
+        long long clip_before = 0, clip_after = 0;
+        std::vector<uint32_t> ops;
+        if (ag_branch && !paired && extra != 0) afc = (int)extra;
+        else if (loc >= 0) {
+            if (oriented_dir != dir) {
+                for (int i = 0; i < U; i++) { if (dir == 1) { od[(size_t)(U - 1 - i)] = complement(bases[i]); oq[(size_t)(U - 1 - i)] = quals[i]; } else { od[(size_t)i] = bases[i]; oq[(size_t)i] = quals[i]; } }
+                oriented_dir = dir;
+            }
+            if (clipped_len < 0 || bcb < 0 || bcb + clipped_len > U) die("paired -om / -ea: clipping arithmetic out of range in the host record loop");
+            const uint64_t off[2] = {0, (uint64_t)clipped_len};
+            const int32_t len = clipped_len, xb = (int32_t)extra, sc = res.score; const int64_t l64 = loc;
+            int32_t r_nops = -1, r_ed = -1, r_afc = 0, r_tail = 0, r_hist = 0; int64_t r_xa = 0;
+            for (;;) {
+                ops.assign(stride, 0);
+                int rc = ag_branch
+                    ? snapgpu_compute_cigar_ag(ctx, 1, od.data() + bcb, oq.data() + bcb, (uint64_t)clipped_len, off, &len, &l64, &xb, &sc, o.use_m ? 1 : 0, ops.data(), stride, &r_nops, &r_ed, &r_afc, &r_xa, &r_tail, &r_hist)
+                    : snapgpu_compute_cigar_lv(ctx, 1, od.data() + bcb, (uint64_t)clipped_len, off, &len, &l64, &xb, o.use_m ? 1 : 0, ops.data(), stride, &r_nops, &r_ed, &r_afc, &r_xa);
+                if (rc != SNAPGPU_OK) fail_rc(ctx, "snapgpu_compute_cigar", rc);
+                if (r_nops >= 0 || r_ed != -2 || stride >= 4096) break;          // (-2: the ops did not fit the stride)
+                stride *= 4;
+            }
+            n_ops = r_nops; afc = r_afc;
+            if (afc == 0 || n_ops < 0) {
+                afc = n_ops < 0 ? 0 : afc;
+                nm = n_ops < 0 ? 0 : r_ed;
+                if (n_ops >= 0 && r_ed >= 0) { star = false; if (ag_branch) bca += r_tail; clip_before = bcb + extra; clip_after = bca + r_xa; }
+            }
+        }
+        if (afc == 0) {
+            out.flag = flag; out.contig = loc >= 0 ? contig : -1; out.pos = pos; out.mapq = mapq; out.nm = nm;
+            out.final_loc = loc; out.final_dir = dir; out.bases_clipped_before = bcb; out.data_len = dlen; out.back_after = addB;
+            if (loc < 0 || star) { out.n_ops = -1; return out; }
+            if (clip_before > 0) out.ops.push_back(((uint32_t)clip_before << 4) | 4u);
+            out.ops.insert(out.ops.end(), ops.begin(), ops.begin() + n_ops);
+            if (clip_after > 0) out.ops.push_back(((uint32_t)clip_after << 4) | 4u);
+            out.n_ops = (int)out.ops.size();
+            int span = 0;
+            for (int i = 0; i < out.n_ops; i++) { const uint32_t code = out.ops[(size_t)i] & 15u; if (i == 0 ? (code != 4u && code != 5u) : (code != 1u)) span += (int)(out.ops[(size_t)i] >> 4); }
+            out.ref_span = span;
+            return out;
+        }
+        n_adj++;
+        if (paired) {
+            const int co = h_contig_at(final_loc), cn = h_contig_at(final_loc + afc);
+            if (cn != co || cn < 0 || final_loc + afc > h_contig_end(co) - (long long)g_padding || n_adj > 2 * (int)o.p.max_read_len) { status = SNAPGPU_NotFound; location = -1; direction = 0; final_loc = -1; continue; }
+            if (ag_branch) { if (afc < 0) { cum += afc; if (direction == 0) addF = -cum; else addB = -cum; } else final_loc += afc; }
+            else { if (afc > 0) { cum += afc; addF = cum; } final_loc += afc; }
+            continue;
+        }
+        const int c_orig = status == SNAPGPU_NotFound ? -1 : h_contig_at(location), c_new = status == SNAPGPU_NotFound ? -1 : h_contig_at(location + afc);
+        const int c_lim = ag_branch ? c_new : c_orig;
+        bool give_up = c_new < 0 || c_new != c_orig || n_adj > dlen;
+        if (!give_up) give_up = final_loc + afc > h_contig_end(c_lim) - (long long)g_padding;
+        if (give_up) { status = SNAPGPU_NotFound; location = -1; direction = 0; final_loc = -1; continue; }
+        if (ag_branch) { if (afc < 0) { cum += afc; if (direction == 0) addF = -cum; else addB = -cum; } else final_loc = location + afc; }
+        else { if (afc > 0) { cum += afc; addF = cum; } final_loc += afc; }
+    }
+    out.flag = 0x4; out.n_ops = -1; out.nm = -1; out.back_after = addB;
+    return out;
+}
+
+// SAMFormat::fillMateInfo (SAM.cpp:1308-1421) from the two mates' own records; rnext: -1 "*", -2 "=", otherwise a contig index
+static void host_mate_info(const HostRec &me, const HostRec &mate, bool first_in_pair, bool aligned_as_pair, int &flag, int &contig, long long &pos, int &rnext, long long &pnext, long long &tlen)
+{
+    flag = me.flag | 0x1 | (first_in_pair ? 0x40 : 0x80); contig = me.contig; pos = me.pos; rnext = -1; pnext = 0; tlen = 0;
+    auto contig_for_read = [&](long long loc, int data_len, long long *extra) -> int {
+        int c = h_contig_at(loc); *extra = 0;
+        if (c < 0 || loc + data_len > h_contig_end(c)) { c = c + 1; if (c >= (int)g_contigs->size()) c = (int)g_contigs->size() - 1; *extra = (long long)(*g_contigs)[(size_t)c].begin - loc; }
+        return c;
+    };
+    long long mate_loc = mate.final_loc, mate_extra = 0; bool rnext_eq = false;
+    if (mate_loc >= 0) {
+        const int mc = contig_for_read(mate_loc, mate.data_len, &mate_extra);
+        mate_loc += mate_extra;
+        rnext = mc; pnext = mate_loc - (long long)(*g_contigs)[(size_t)mc].begin + 1;
+        if (mate.final_dir == 1) flag |= 0x20;
+        if (me.final_loc < 0) { contig = mc; rnext_eq = true; pos = pnext; }
+    } else { flag |= 0x8; rnext_eq = true; pnext = pos; }
+    if (me.final_loc >= 0 && mate.final_loc >= 0) {
+        if (aligned_as_pair) flag |= 0x2;
+        long long extra = 0;
+        const int c = contig_for_read(me.final_loc, me.data_len, &extra);
+        const long long loc = me.final_loc + extra;
+        const long long my_start = loc - me.bases_clipped_before - extra, my_end = loc + me.ref_span;
+        const long long mate_start = mate_loc - mate.bases_clipped_before - mate_extra, mate_end = mate_loc + mate.ref_span;
+        contig = c;
+        if (my_start < mate_start) { if (me.final_dir == 0) tlen = mate.final_dir == 1 ? mate_end - my_start : mate_start - my_start; else tlen = mate.final_dir == 0 ? mate_start - my_end : mate_end - my_end; }
+        else { if (me.final_dir == 1) tlen = mate.final_dir == 0 ? -(my_end - mate_start) : -(my_end - mate_end); else tlen = mate.final_dir == 0 ? -(my_start - mate_start) : -(my_start - mate_end); }
+    }
+    if (rnext_eq || (rnext >= 0 && rnext == contig)) rnext = -2;
+}
+
 // ---------------------------------------------------------------------------------------- GPU stage
 // A cigar that does not fit ops_stride comes back as n_ops = -1 with nm = -2 (the reference's "cigarBuf too small" never happens: its
 // buffer is large): call again with a larger stride rather than print a wrong record.
@@ -394,6 +534,7 @@ static void gpu_paired(const Options &o, snapgpu_ctx *ctx, Work &w)
     for (const Work::Emit &e : w.emit) per_pair[e.single ? w.su_read[e.unit] / 2 : w.pu_pair[e.unit]].push_back(e);
     size_t n_rounds = 0;
     for (size_t k = 0; k < np; k++) if (per_pair[k].size() > n_rounds) n_rounds = per_pair[k].size();
+    const bool host_all = getenv("SNAPGPU_SAM_HOST_LOOP") != NULL;      // (tests: every record of a multi-result batch through the host loop)
     for (;;) {                                                           // (again with a larger stride when a cigar did not fit)
         bool too_small = false;
         std::vector<int32_t> carry(n, 0);
@@ -409,12 +550,50 @@ static void gpu_paired(const Options &o, snapgpu_ctx *ctx, Work &w)
             const int lead = (ops[0] & 15u) == 4u ? (int)(ops[0] >> 4) : 0;
             const int left = lead - ((int)U - passed_len - front_clip[rd]) - clipped_before;
             if (left < 0) die("internal error: leading soft clip shorter than the read's own clipping");
-            if (left > 0 && carry[rd] > 0) die("paired -om / -ea: two records of one read both soft-clip a leading insertion (unsupported corner)");
-            if (left > 0) carry[rd] = left;
+            if (left > 0) carry[rd] = left;                             // (device-computed records start from carry == 0: the others go through host_record)
         };
         for (size_t j = 0; j < n_rounds; j++) {
-            std::vector<uint32_t> pus, sus;                              // this round's pair units / single units
-            for (size_t k = 0; k < np; k++) if (j < per_pair[k].size()) (per_pair[k][j].single ? sus : pus).push_back(per_pair[k][j].unit);
+            std::vector<uint32_t> pus, sus, pus_host, sus_host;          // this round's pair units / single units; `_host`: a read arrives with back clipping
+            for (size_t k = 0; k < np; k++) {
+                if (j >= per_pair[k].size()) continue;
+                const Work::Emit &e = per_pair[k][j];
+                if (e.single) (host_all || carry[w.su_read[e.unit]] > 0 ? sus_host : sus).push_back(e.unit);
+                else (host_all || carry[2 * k] > 0 || carry[2 * k + 1] > 0 ? pus_host : pus).push_back(e.unit);
+            }
+            for (uint32_t u : pus_host) {                                 // the record loop on the host, with the Reads' state as it is (exact)
+                const size_t k = w.pu_pair[u];
+                const snapgpu_paired_result &r = pu_res[u];
+                HostRec rec[2];
+                for (size_t v = 0; v < 2; v++) {
+                    const size_t i = 2 * k + v;
+                    const HostRes hr = {r.status[v], r.direction[v], r.score[v], r.mapq[v], r.clipping_for_read_adjustment[v], r.used_affine_gap_scoring[v],
+                                        r.bases_clipped_before[v], r.bases_clipped_after[v], r.supplementary[v], (long long)r.location[v]};
+                    rec[v] = host_record(o, ctx, b.bases.data() + b.offsets[i], b.quals.data() + b.offsets[i], (int)(b.offsets[i + 1] - b.offsets[i]), front_clip[i], data_len[i], carry[i], hr, true);
+                    carry[i] = rec[v].back_after;
+                }
+                for (size_t v = 0; v < 2; v++) {
+                    const size_t dst = 2 * u + v;
+                    int fl, ct, rn; long long ps, pn, tl;
+                    host_mate_info(rec[v], rec[1 - v], v == 0, r.aligned_as_pair != 0, fl, ct, ps, rn, pn, tl);
+                    if ((uint32_t)(rec[v].n_ops > 0 ? rec[v].n_ops : 0) > w.ops_stride) { too_small = true; continue; }
+                    w.flag[dst] = fl | (w.pu_secondary[u] ? 0x100 : 0); w.contig[dst] = ct; w.pos[dst] = ps; w.mapq[dst] = rec[v].mapq; w.n_ops[dst] = rec[v].n_ops; w.nm[dst] = rec[v].nm;
+                    w.rnext[dst] = rn; w.pnext[dst] = pn; w.tlen[dst] = tl;
+                    for (int c2 = 0; c2 < rec[v].n_ops; c2++) w.ops[dst * (size_t)w.ops_stride + (size_t)c2] = rec[v].ops[(size_t)c2];
+                }
+                const unsigned long long l0 = rec[0].final_loc < 0 ? ~0ull : (unsigned long long)rec[0].final_loc, l1 = rec[1].final_loc < 0 ? ~0ull : (unsigned long long)rec[1].final_loc;
+                w.first_written[u] = l0 <= l1 ? 0 : 1;                    // ReadWriter.cpp:481-488
+            }
+            for (uint32_t r : sus_host) {
+                const size_t rd = w.su_read[r];
+                const snapgpu_single_result &sr = su_res[r];
+                const HostRes hr = {sr.status, sr.direction, sr.score, sr.mapq, sr.clipping_for_read_adjustment, sr.used_affine_gap_scoring, sr.bases_clipped_before, sr.bases_clipped_after,
+                                    sr.supplementary, (long long)sr.location};
+                const HostRec rec = host_record(o, ctx, b.bases.data() + b.offsets[rd], b.quals.data() + b.offsets[rd], (int)(b.offsets[rd + 1] - b.offsets[rd]), front_clip[rd], data_len[rd], carry[rd], hr, false);
+                carry[rd] = rec.back_after;
+                if ((uint32_t)(rec.n_ops > 0 ? rec.n_ops : 0) > w.s_ops_stride) { too_small = true; continue; }
+                w.s_flag[r] = rec.flag | 0x100; w.s_contig[r] = rec.contig; w.s_pos[r] = rec.pos; w.s_mapq[r] = rec.mapq; w.s_n_ops[r] = rec.n_ops; w.s_nm[r] = rec.nm;
+                for (int c2 = 0; c2 < rec.n_ops; c2++) w.s_ops[r * (size_t)w.s_ops_stride + (size_t)c2] = rec.ops[(size_t)c2];
+            }
             if (!pus.empty()) {
                 const size_t m = pus.size();
                 std::vector<char> rb, rq; std::vector<uint64_t> ro(1, 0); std::vector<int32_t> rfc(2 * m), rdl(2 * m), stale(2 * m);
@@ -735,6 +914,7 @@ int main(int argc, char **argv)
 
     std::vector<Contig> contigs; uint64_t n_bases = 0; uint32_t padding = 0;
     load_contigs(index_dir, contigs, n_bases, padding);
+    g_contigs = &contigs; g_n_bases = n_bases; g_padding = padding;
 
     // ---- contexts: GPU 0 reads the index, the other GPUs get it over RCCL, every further feeder on a GPU shares that GPU's blobs
     int visible = snapgpu_device_count();

@@ -155,11 +155,12 @@ def test_native_paired_fastq_to_sam_identical_to_reference_cli(paired_workload, 
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
-def test_native_paired_secondary_records_identical_to_reference_cli(paired_workload):
+@pytest.mark.parametrize("opts", [["-om", "1"], ["-D", "2", "-om", "2", "-omax", "3", "-mpc", "2", "-="]])
+def test_native_paired_secondary_records_identical_to_reference_cli(paired_workload, opts):
     """-om with `paired`: every further PairedAlignmentResult of a pair as two more records (flag 0x100), then each mate's single-end secondary
     results as records of their own -- unpaired flags, the whole read id -- in the order SimpleReadWriter::writePairs writes them
-    (ReadWriter.cpp:345-590)."""
-    opts = ["-D", "2", "-om", "2", "-omax", "3", "-mpc", "2", "-="]
+    (ReadWriter.cpp:345-590).  The workload has the reads whose earlier record leaves additional back clipping on the Read, incl. the ones
+    where a later record of the same read clips a leading insertion again (`-om 1`): those go through the host record loop."""
     d, index_dir, fq = paired_workload
     n = run_and_compare_paired(TOOL, d, index_dir, fq, opts)
     tag = "_".join(o.strip("-") or "eq" for o in opts)
@@ -169,13 +170,12 @@ def test_native_paired_secondary_records_identical_to_reference_cli(paired_workl
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
-def test_native_paired_secondary_records_om1_small_genome(tmp_path):
-    """`-om 1` on 800 hard pairs of a 400 kb genome.  (On the 2 500 pairs of the module's 2 Mb workload `-om 1` runs into the one corner the
-    program refuses: two records of one read that both soft-clip a leading insertion -- the reference's additional back clipping is then
-    REPLACED, not added to, which cannot be reproduced from outside the device call; it stops with a message instead.  DESIGN.md section 14.)"""
+def test_native_paired_secondary_records_host_record_loop(tmp_path):
+    """SNAPGPU_SAM_HOST_LOOP=1: every record of a multi-result batch through the host record loop (the path a read takes when an earlier record
+    left back clipping on it) instead of the device's: same file as the reference CLI, so the two loops agree record for record."""
     d = str(tmp_path)
     index_dir, fq = make_paired_workload(d, 800, genome_bases=400_000)
-    assert run_and_compare_paired(TOOL, d, index_dir, fq, ["-om", "1"]) > 2000
+    assert run_and_compare_paired(TOOL, d, index_dir, fq, ["-om", "1"], env=dict(os.environ, SNAPGPU_SAM_HOST_LOOP="1")) > 2000
 
 
 def make_paired_alt_workload(d, n_pairs, genome_bases=500_000):
