@@ -248,6 +248,10 @@ typedef struct snapgpu_counters {
     uint64_t cycles_lv;                 /* Landau-Vishkin (both halves)                            */
     uint64_t cycles_ag;                 /* affine gap (both halves)                                */
     uint64_t cycles_total;              /* whole AlignRead                                         */
+    /* paired-end path only.  [0]: wave-cycles of the chimeric fallback's single-end aligner.  [1]: Phase-4 help waits that were given
+     * up by a watchdog (0 in a healthy run; bits 0-15 owner waits for answers, 16-31 owner waits for helpers to leave, 32+ idle waves).
+     * [2]: lists published << 32 | speculative answers the ordered walks used (SNAPGPU_PAIRED_HELP_MIN; both 0 with the help off);
+     * after a watchdog event -- top nibble set -- what the watchdog saw instead. */
     uint64_t reserved[3];
 } snapgpu_counters;
 
