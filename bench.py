@@ -61,12 +61,18 @@ def ensure_index(args, rank):
     return genome, os.path.join(work, "idx")
 
 
-def algorithmic_bytes(c, read_len, n_reads):
-    """SURVEY.md 8(d) / DESIGN.md: bytes the algorithm is entitled to move for the work done."""
-    probe = 8 * c["n_hash_slots_probed"] + 4 * c["n_overflow_lists"] + 4 * c["n_hits_consumed"]
+def algorithmic_bytes(c, read_len, n_reads, ref_walk_slots=None):
+    """SURVEY.md 8(d) / DESIGN.md: bytes the algorithm is entitled to move for the work done.  The probe term is that of the REFERENCE's
+    slot walk (8 B per slot its quadratic / linear probe examines), whatever layout the kernel actually reads: `ref_walk_slots` is that
+    count for this batch (bench.py counts it with one launch on a context that keeps the reference layout); the kernel's own counter
+    (with the bucket tables: 8 x the 64-byte lines read) is reported separately as `probe_layout_bytes`."""
+    slots = c["n_hash_slots_probed"] if ref_walk_slots is None else ref_walk_slots
+    probe = 8 * slots + 4 * c["n_overflow_lists"] + 4 * c["n_hits_consumed"]
     lv = c["n_lv_ref_bytes"]
     reads = (2 * read_len + 88) * n_reads
-    return probe + lv + reads, dict(probe=probe, lv_reference=lv, reads_and_results=reads)
+    return probe + lv + reads, dict(probe=probe, lv_reference=lv, reads_and_results=reads,
+                                    probe_layout_bytes=8 * c["n_hash_slots_probed"] + 4 * c["n_overflow_lists"] + 4 * c["n_hits_consumed"],
+                                    probe_basis="reference slot walk, counted" if ref_walk_slots is not None else "the kernel's own table layout")
 
 
 def main():
@@ -88,6 +94,12 @@ def main():
                          "batches overlap on the GPU (what snapgpu-sam's feeder threads do).  0 = auto: 2 for single-end, 3 for paired-end "
                          "(a launch ends with a tail of few, heavy reads / pairs that leaves most of the chip idle: measured, profiles/r02i, "
                          "1 -> 2 feeders: 4.20 -> 6.28 M reads/s single-end; 1 / 2 / 3 / 4 feeders: 119 / 174 / 210 / 189 k reads/s paired-end)")
+    ap.add_argument("--batches", type=int, default=4, help="distinct read batches rotated through the timed steps")
+    ap.add_argument("--insert-mean", type=float, default=400.0, help="paired: insert size mean (C3: 400; C5 as SURVEY.md 8(d) defines it: 600)")
+    ap.add_argument("--insert-sd", type=float, default=50.0, help="paired: insert size s.d. (C3: 50; C5: 80)")
+    ap.add_argument("--long-indel-frac", type=float, default=0.0, help="paired: fraction of reads with one extra indel event of length 1-10 (C5: 0.002)")
+    ap.add_argument("--skip-refwalk", action="store_true", help="skip the untimed launches that count the reference's slot walk (roofline numerator)")
+    ap.add_argument("--skip-breakdown", action="store_true", help="skip the untimed launch with phase timers (roofline.wave_cycle_breakdown)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-probe", action="store_true", help="skip the stand-alone index-probe measurement (roofline.probe)")
     ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
@@ -126,13 +138,16 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     force_dist = os.environ.get("SNAP_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ   # exercise the RCCL path on one GPU
+
+    # ---------------------------------------------------------------- set-up (untimed)
+    # The index directory is built BEFORE the process group exists: a build can take minutes at GRCh38 scale, and a rank that sits in
+    # a collective that long runs into the NCCL watchdog.  Ranks other than 0 wait for the directory's last file on the file system.
+    genome, idx_dir = ensure_index(args, rank)
+    while rank != 0 and not os.path.exists(os.path.join(idx_dir, "GenomeIndex")):
+        time.sleep(1.0)
     if world > 1 or force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist = sd.init_process_group("nccl")
-
-    # ---------------------------------------------------------------- set-up (untimed)
-    genome, idx_dir = ensure_index(args, rank)
-    if dist is not None:
         dist.barrier()
     params = abi.default_params(max_k=args.max_k, max_read_len=((args.read_len + 15) // 16) * 16)
     t0 = time.time()
@@ -149,16 +164,26 @@ def main():
     index_bytes = sum(int(x) for x in getattr(index, "_device_sizes", (index.hash_blob.size, index.overflow.size, index.genome_padded.size)))
     log("rank %d: index resident in HBM after %.1fs" % (rank, time.time() - t0))
 
-    if paired:      # FR pairs, insert N(400, 50^2) clipped to [150, 1000]; same per-base error model
-        reads = synth.make_pairs(args.seed + 1000 + rank, genome, args.reads // 2, args.read_len)
-    else:
-        reads = synth.make_reads(args.seed + 1000 + rank, genome, args.reads, args.read_len)   # 1% sub, .05% ins/del, 50% RC, Q20-40
+    # --batches DISTINCT read batches rotate through the timed steps (step k aligns batch k mod B), so that no step finds the previous
+    # step's probes / reference windows in L2 or MALL by construction.  Batch 0 is the one the parity check and the CPU baseline use.
+    n_batches = max(1, min(args.batches, args.steps))
+
+    def make_batch(b):
+        sd_ = args.seed + 1000 + rank + 7919 * b
+        if paired:      # FR pairs; C3: insert N(400, 50^2) clipped to [150, 1000]; C5: N(600, 80^2) + 0.2 % indel events of length 1-10
+            return synth.make_pairs(sd_, genome, args.reads // 2, args.read_len, insert_mean=args.insert_mean, insert_sd=args.insert_sd,
+                                    long_indel_frac=args.long_indel_frac)
+        return synth.make_reads(sd_, genome, args.reads, args.read_len)   # 1% sub, .05% ins/del, 50% RC, Q20-40
+    t0 = time.time()
+    batches = [make_batch(b) for b in range(n_batches)]
+    log("%d read batch(es) generated in %.1fs" % (n_batches, time.time() - t0))
+    reads = batches[0]
     n = args.reads                      # reads per GPU per step (a pair is two reads)
     n_units = n // 2 if paired else n   # alignment problems per launch
     res_dtype = abi.PAIRED_RESULT_DTYPE if paired else abi.RESULT_DTYPE
-    d_bases = torch.from_numpy(reads["bases"].reshape(-1)).to(dev)
-    d_quals = torch.from_numpy(reads["quals"].reshape(-1)).to(dev)
-    d_offs = torch.from_numpy(reads["offsets"].astype(np.int64)).to(dev)
+    d_batches = [(torch.from_numpy(b_["bases"].reshape(-1)).to(dev), torch.from_numpy(b_["quals"].reshape(-1)).to(dev),
+                  torch.from_numpy(b_["offsets"].astype(np.int64)).to(dev)) for b_ in batches]
+    d_bases, d_quals, d_offs = d_batches[0]
     # Feeders: contexts over the one resident index (snapgpu_create_replica, share_index), each with its own stream, slabs and result
     # buffer.  Feeder f runs steps f, f + F, f + 2F, ... from a host thread of its own (the C ABI call blocks until its batch is done),
     # so the tail of one batch -- a few heavy pairs on a few wavefronts -- overlaps the bulk of the next.  A step is still one pass of
@@ -170,10 +195,11 @@ def main():
     d_prim = d_prims[0]
     torch.cuda.synchronize()
 
-    def run_steps(k_steps):
+    def run_steps(k_steps, only_batch=None):
         def feed(f):
-            for _ in range(f, k_steps, n_feed):
-                feeders[f].align_device(n_units, d_bases.data_ptr(), d_quals.data_ptr(), d_offs.data_ptr(), d_prims[f].data_ptr())
+            for k in range(f, k_steps, n_feed):
+                db, dq, do = d_batches[(k % n_batches) if only_batch is None else only_batch]
+                feeders[f].align_device(n_units, db.data_ptr(), dq.data_ptr(), do.data_ptr(), d_prims[f].data_ptr())
         if n_feed == 1:
             feed(0)
             return
@@ -218,12 +244,50 @@ def main():
             counters[k_] = counters.get(k_, 0) + v_
         ms_, nl_ = a_.kernel_time()
         kernel_ms += ms_; launches += nl_
+    # a dedicated, untimed step: EVERY feeder aligns batch 0 -- their results must be the same bytes, and they are what the parity check
+    # below compares with the reference
+    run_steps(n_feed, only_batch=0)
+    torch.cuda.synchronize()
     prim = np.frombuffer(d_prim.cpu().numpy().tobytes(), dtype=res_dtype)
-    for d_other in d_prims[1:]:                 # every feeder aligned the same batch: their results must be the same bytes
+    for d_other in d_prims[1:]:
         if not torch.equal(d_other, d_prim):
             raise SystemExit("bench.py: two feeders disagree on the same batch")
     if rank != 0:
         return
+
+    # ---------------------------------------------------------------- the reference's slot walk, counted (the numerator SURVEY.md 8(d) defines)
+    # The timed contexts probe the device-native bucket tables (one 64-byte line per strand); the ALGORITHMIC bytes of a lookup are those of
+    # the reference's walk over its own slot arrays (8 B per slot examined).  One untimed launch per distinct batch on a context that keeps
+    # the reference layout (SNAPGPU_NO_BUCKETS=1) counts exactly those slots for exactly these reads.
+    ref_walk_slots = None
+    if not args.skip_refwalk:
+        os.environ["SNAPGPU_NO_BUCKETS"] = "1"
+        try:
+            walker = aligner.replica()
+        finally:
+            del os.environ["SNAPGPU_NO_BUCKETS"]
+        walker.counters(reset=True)
+        for db, dq, do in d_batches:
+            walker.align_device(n_units, db.data_ptr(), dq.data_ptr(), do.data_ptr(), d_prims[0].data_ptr())
+        wc = walker.counters(reset=True)
+        ref_walk_slots = wc["n_hash_slots_probed"] / len(d_batches)
+        walker.close()
+    # ---------------------------------------------------------------- where the wave cycles go: one launch of the instantiation that carries the phase timers
+    breakdown = None
+    if not args.skip_breakdown and not paired:
+        os.environ["SNAPGPU_PHASE_TIMERS"] = "1"
+        try:
+            timed = aligner.replica()
+        finally:
+            del os.environ["SNAPGPU_PHASE_TIMERS"]
+        timed.counters(reset=True)
+        timed.align_device(n_units, d_bases.data_ptr(), d_quals.data_ptr(), d_offs.data_ptr(), d_prims[0].data_ptr())
+        tc = timed.counters(reset=True)
+        tot_c = max(1, tc.get("cycles_total", 0))
+        breakdown = {"fractions": {k[7:]: tc[k] / tot_c for k in ("cycles_lookup", "cycles_hits", "cycles_lv", "cycles_ag") if k in tc},
+                     "wave_cycles_per_read": tc.get("cycles_total", 0) / max(1, tc["n_reads"]),
+                     "source": "one untimed launch of k_align_single<3, false, true, TIMED> (SNAPGPU_PHASE_TIMERS=1) on batch 0; the timed kernels carry no timers"}
+        timed.close()
 
     # ---------------------------------------------------------------- the index-probe kernel on its own (north_star: HBM roofline of the probe)
     # k_lookup_seeds over >= 10^7 seeds drawn from the bench reads (every 13th offset of every read), hit lists read as BaseAligner
@@ -261,7 +325,7 @@ def main():
     total_reads = n * world * args.steps
     value = total_reads / elapsed
     per_launch = {k: v / max(1, launches) for k, v in counters.items()}
-    alg_bytes, parts = algorithmic_bytes(per_launch, args.read_len, n)
+    alg_bytes, parts = algorithmic_bytes(per_launch, args.read_len, n, ref_walk_slots)
     avg_ms = kernel_ms / max(1, launches)
     # (with several feeders the launches overlap, so each one's hipEvent time is longer than its share of the chip: the rate is then
     #  taken over the step time, bytes of one batch / (elapsed / steps))
@@ -272,8 +336,8 @@ def main():
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8 bases / int32 DP / f64 match probability", "data": "synthetic",
-        "config": {"workload": ("configs[2]: %d pairs of 2 x %d bp (FR, insert N(400,50^2)) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
-                                % (n_units, args.read_len, args.max_k, args.seed_len, args.genome_mb)) if paired else
+        "config": {"workload": ("configs[2]: %d pairs of 2 x %d bp (FR, insert N(%g,%g^2), long-indel fraction %g) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
+                                % (n_units, args.read_len, args.insert_mean, args.insert_sd, args.long_indel_frac, args.max_k, args.seed_len, args.genome_mb)) if paired else
                                ("configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
                                 % (n, args.read_len, args.max_k, args.seed_len, args.genome_mb)),
                    "reads_per_gpu": n, "read_len": args.read_len, "index_bytes_hbm": index_bytes,
@@ -286,6 +350,9 @@ def main():
                      # its share: `achieved` is then bytes per batch / time per batch; the per-launch figure is kept beside it
                      "achieved_basis": "bytes per launch / hipEvent launch duration" if n_feed == 1 else "bytes per batch / (elapsed / steps): %d launches overlap" % n_feed,
                      "achieved_per_overlapped_launch": alg_bytes / (avg_ms * 1e-3) / 1e9,
+                     # the same bytes over ONE launch's own duration (hipEvents = rocprofv3's kernel average), whatever else shares the chip
+                     "frac_per_launch": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "batches_rotated": n_batches,
                      "per_read": {"hash_lookups": per_launch["n_hash_table_lookups"] / n, "hash_slots": per_launch["n_hash_slots_probed"] / n,
                                   "hits": per_launch["n_hits_consumed"] / n, "lv_locations": per_launch["n_lv_locations"] / n,
                                   "ag_locations": per_launch["n_ag_locations"] / n}},
@@ -293,13 +360,18 @@ def main():
     }
     if probe is not None:
         out["roofline"]["probe"] = probe
-    tot = max(1, counters.get("cycles_total", 0))
-    out["roofline"]["wave_cycle_breakdown"] = {k[7:]: counters[k] / tot for k in
-                                              ("cycles_lookup", "cycles_hits", "cycles_lv", "cycles_ag") + (("cycles_single_fallback",) if paired else ())
-                                              if k in counters}   # paired: lookup = Phase 1, hits = Phase 2 (set intersection), lv/ag = paired scoring
-    out["roofline"]["wave_cycles_per_read"] = counters.get("cycles_total", 0) / max(1, counters["n_reads"])
+    if breakdown is not None:
+        out["roofline"]["wave_cycle_breakdown"] = breakdown["fractions"]
+        out["roofline"]["wave_cycles_per_read"] = breakdown["wave_cycles_per_read"]
+        out["roofline"]["wave_cycle_breakdown_source"] = breakdown["source"]
+    elif counters.get("cycles_total", 0):      # (a -DSNAPGPU_PHASE_TIMERS build of the paired kernels)
+        tot = counters["cycles_total"]
+        out["roofline"]["wave_cycle_breakdown"] = {k[7:]: counters[k] / tot for k in
+                                                  ("cycles_lookup", "cycles_hits", "cycles_lv", "cycles_ag") + (("cycles_single_fallback",) if paired else ())
+                                                  if k in counters}   # paired: lookup = Phase 1, hits = Phase 2 (set intersection), lv/ag = paired scoring
+        out["roofline"]["wave_cycles_per_read"] = counters["cycles_total"] / max(1, counters["n_reads"])
     if paired:
-        out["roofline"]["phase4_help"] = {"watchdog_events": counters.get("help_watchdog_events", 0), "min_candidates": os.environ.get("SNAPGPU_PAIRED_HELP_MIN", "0 (default: off)")}
+        out["roofline"]["phase4_help"] = {"watchdog_events": counters.get("help_watchdog_events", 0), "min_candidates": os.environ.get("SNAPGPU_PAIRED_HELP_MIN", "64 (default)")}
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:

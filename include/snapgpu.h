@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define SNAPGPU_ABI_VERSION 3
+#define SNAPGPU_ABI_VERSION 4
 
 /* error codes */
 #define SNAPGPU_OK              0
@@ -549,6 +549,64 @@ int  snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int reset);
  * (bench.py roofline), and how many launches that covers: the align kernels and the SAM-side kernels (snapgpu_compute_cigar_*,
  * snapgpu_sam_fields_*) share the accumulator, so reset before the call you want to time. */
 int  snapgpu_kernel_time(snapgpu_ctx *ctx, double *total_ms, uint64_t *n_launches, int reset);
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * The index builder on the GPU.  Replaces, for the index shape the north star uses (4-byte locations, 4-byte
+ * hash keys, small tables: `snap-aligner index <fasta> <dir> -s 16..24 [-keysize 4]`, in particular the default -s 20),
+ *   GenomeIndex::runIndexer            SNAPLib/GenomeIndex.cpp:126-506   options, FASTA -> Genome
+ *   ReadFASTAGenome                    SNAPLib/FASTA.cpp:188-409         contigs, 'n' padding, ALT contigs last, upper-casing
+ *   GenomeIndex::BuildIndexToDirectory SNAPLib/GenomeIndex.cpp:527-1022  hash tables + overflow table, the four files
+ * The result is an index in the REFERENCE'S format: the directory snapgpu_built_index_save writes is loaded by the reference's
+ * GenomeIndex::loadFromDirectory (and by snapgpu_create_from_directory), its `Genome` file is byte-identical to the reference's, and every
+ * seed lookup returns what it returns on an index the reference built (hit lists are sorted, so they are equal; slot placement inside a
+ * table depends on insertion order in both builders).  Hash-table sizes follow the reference's formula with exact distinct-seed counts
+ * (its -exact mode; its default estimates them with approximate counters).
+ * The build itself (seeds of all locations, radix sort, overflow lists, closed-hash insertion) runs on the device: index_build.h.
+ * Anything outside that shape (-large, -locationSize > 4, key sizes other than 4) returns SNAPGPU_E_UNSUPPORTED: use the reference's indexer.
+ */
+typedef struct snapgpu_built_index snapgpu_built_index;
+
+typedef struct snapgpu_index_build_params {
+    uint32_t seed_len;              /* -s, default 20 (DEFAULT_SEED_SIZE)                                              */
+    double   slack;                 /* -h, default 0.3 (DEFAULT_SLACK): tables are sized distinct seeds x (1 + slack)  */
+    uint32_t key_bytes;             /* -keysize; 0 = auto: max(2, (seed_len + 2) / 4 - 1) (GenomeIndex.cpp:437)         */
+    uint32_t chromosome_padding;    /* -p, default 2000 (DEFAULT_PADDING)                                              */
+    /* FASTA -> Genome (snapgpu_index_build_from_fasta only) */
+    uint32_t space_terminates_name; /* -bSpace (default 1) / -bSpace-                                                  */
+    const char *name_terminators;   /* -B<chars>, NULL = none                                                          */
+    uint32_t auto_alt;              /* default 1; -AutoAlt- = 0: contigs named *_alt or HLA-* are ALT (FASTA.cpp:64)    */
+    int64_t  max_alt_contig_size;   /* -maxAltContigSize, default -1                                                   */
+    const char *const *alt_contig_names;     uint32_t n_alt_contig_names;       /* -altContigName / -altContigFile       */
+    const char *const *non_alt_contig_names; uint32_t n_non_alt_contig_names;   /* -nonAltContigName / -nonAltContigFile */
+    const char *alt_liftover_file;  /* -altLiftoverFile, NULL = none                                                   */
+} snapgpu_index_build_params;
+
+/* what one build did, for logs and the bench line */
+typedef struct snapgpu_index_build_stats {
+    uint64_t n_bases, n_seed_locations, n_distinct_seeds, n_repeated_seeds, overflow_table_size, hash_table_slots, hash_blob_bytes;
+    double   ms_keys, ms_sort, ms_runs, ms_tables, ms_total_device;
+    double   s_fasta;               /* host: reading the FASTA into the genome image                                   */
+} snapgpu_index_build_stats;
+
+void snapgpu_default_index_build_params(snapgpu_index_build_params *bp);
+
+/* A genome as Genome::saveToFile describes it (host memory): n_bases bytes (contigs separated by chromosome_padding bytes of 'n', upper-case
+ * ACGTN), and the contig table in genome order.  proj_* may be NULL (no liftover data). */
+typedef struct snapgpu_genome_view {
+    const uint8_t *bases; uint64_t n_bases;
+    uint32_t n_contigs;
+    const uint64_t *contig_begin; const char *const *contig_name; const uint8_t *contig_is_alt; const int32_t *contig_original_number;
+    const uint64_t *contig_proj_begin; const uint8_t *contig_proj_rc; const char *const *contig_proj_cigar;
+} snapgpu_genome_view;
+
+int  snapgpu_index_build(const snapgpu_genome_view *genome, const snapgpu_index_build_params *bp, int device, snapgpu_built_index **out);
+int  snapgpu_index_build_from_fasta(const char *fasta_path, const snapgpu_index_build_params *bp, int device, snapgpu_built_index **out);
+/* The built index as a view with on_device = 1 (feed it to snapgpu_create: no copy, no files); valid until snapgpu_built_index_destroy. */
+int  snapgpu_built_index_view(const snapgpu_built_index *bi, snapgpu_index_view *view);
+/* The four files of a SNAP index directory (GenomeIndex, Genome, OverflowTable, GenomeIndexHash). */
+int  snapgpu_built_index_save(const snapgpu_built_index *bi, const char *directory);
+int  snapgpu_built_index_stats(const snapgpu_built_index *bi, snapgpu_index_build_stats *out);
+void snapgpu_built_index_destroy(snapgpu_built_index *bi);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,6 @@ run() { tag=$1; shift; ( timeout ${T:-200} "$@" > $O/$tag.out 2> $O/$tag.err; ec
 T=260 run p_f1_help_off python bench.py --workload paired --steps 2 --warmup 1 --feeders 1 --skip-cpu
 SNAPGPU_PAIRED_HELP_MIN=64 run p_f1_help_on python bench.py --workload paired --steps 2 --warmup 1 --feeders 1 --skip-cpu
 SNAPGPU_PAIRED_HELP_MIN=64 T=260 W=900 run p_f3_help_on python bench.py --workload paired --steps 6 --warmup 1 --feeders 3
-SNAPGPU_PAIRED_ALWAYS_EXACT=1 T=120 run p_f1_always_exact python bench.py --workload paired --steps 2 --warmup 1 --feeders 1 --skip-cpu
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES"; do
@@ -25,3 +24,5 @@ for f in glob.glob("$O/ppmc_*/bench_counter_collection.csv"):
 json.dump(dict(tot), open("$O/paired_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print(json.dumps(dict(tot), sort_keys=True))
 PY
+# last: the run that faulted in round 2 (a fault aborts the process; nothing after it depends on the GPU)
+SNAPGPU_PAIRED_ALWAYS_EXACT=1 AMD_LOG_LEVEL=1 T=150 run p_f1_always_exact python bench.py --workload paired --steps 2 --warmup 1 --feeders 1 --skip-cpu

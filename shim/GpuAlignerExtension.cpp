@@ -497,11 +497,13 @@ private:
             p.max_read_len = 400;                               // per-wave buffers; raise for longer reads (<= MAX_READ_LENGTH)
             const char *env = getenv("SNAPGPU_MAX_READ_LEN");
             if (env) p.max_read_len = (uint32_t)atoi(env);
-            // GPUs: all that are visible (SNAPGPU_SHIM_GPUS=<n> for fewer); feeders per GPU: SNAPGPU_SHIM_FEEDERS (default 2)
+            // GPUs: all that are visible, but never more than there are worker threads to feed them (SNAPGPU_SHIM_GPUS=<n> for fewer);
+            // feeders per GPU: SNAPGPU_SHIM_FEEDERS (default 2)
             int nDev = snapgpu_device_count();
             if (nDev < 1) nDev = 1;
             env = getenv("SNAPGPU_SHIM_GPUS");
             if (env && atoi(env) >= 1 && atoi(env) < nDev) nDev = atoi(env);
+            if (c->options->numThreads >= 1 && nDev > c->options->numThreads) nDev = c->options->numThreads;      // (-t: a GPU nobody feeds would only cost an index copy)
             int nFeed = 2;
             env = getenv("SNAPGPU_SHIM_FEEDERS");
             if (env && atoi(env) >= 1 && atoi(env) <= 8) nFeed = atoi(env);
@@ -512,18 +514,39 @@ private:
                 WriteErrorMessage("snapgpu_create_from_directory(%s) failed (%d): %s\n", c->options->indexDir, rc, snapgpu_last_error(NULL));
                 soft_exit(1);
             }
-            for (int d = 1; d < nDev; d++) {
-                rc = snapgpu_create_replica(first[0], d, 0, &first[d]);
-                if (rc != SNAPGPU_OK) {
-                    WriteErrorMessage("snapgpu_create_replica(device %d) failed (%d): %s\n", d, rc, snapgpu_last_error(first[0]));
-                    soft_exit(1);
+            // Further GPUs: same-size blobs filled by one RCCL broadcast.  If that is not to be had (librccl cannot be loaded, a
+            // communicator does not come up), each further GPU loads the directory itself; if even that fails, the run goes on with the
+            // GPUs that did come up -- a multi-GPU host without a working RCCL must not be worse off than a single-GPU one.
+            if (nDev > 1) {
+                int made = 1;
+                for (int d = 1; d < nDev; d++, made++) {
+                    rc = snapgpu_create_replica(first[0], d, 0, &first[d]);
+                    if (rc != SNAPGPU_OK) {
+                        WriteErrorMessage("snapgpu_create_replica(device %d) failed (%d): %s -- continuing with %d GPU(s)\n", d, rc, snapgpu_last_error(first[0]), made);
+                        break;
+                    }
                 }
+                nDev = made;
             }
             if (nDev > 1) {
                 rc = snapgpu_broadcast_index(first, nDev);
                 if (rc != SNAPGPU_OK) {
-                    WriteErrorMessage("snapgpu_broadcast_index over %d GPUs failed (%d): %s\n", nDev, rc, snapgpu_last_error(first[0]));
-                    soft_exit(1);
+                    WriteErrorMessage("snapgpu_broadcast_index over %d GPUs failed (%d): %s -- loading the index on each GPU instead\n", nDev, rc, snapgpu_last_error(first[0]));
+                    int kept = 1;
+                    for (int d = 1; d < nDev; d++) {
+                        snapgpu_destroy(first[d]);                  // its blobs were never filled
+                        first[d] = NULL;
+                    }
+                    for (int d = 1; d < nDev; d++) {
+                        snapgpu_ctx *own = NULL;
+                        rc = snapgpu_create_from_directory(c->options->indexDir, &p, d, &own);
+                        if (rc != SNAPGPU_OK) {
+                            WriteErrorMessage("snapgpu_create_from_directory on device %d failed (%d): %s -- continuing with %d GPU(s)\n", d, rc, snapgpu_last_error(NULL), kept);
+                            break;
+                        }
+                        first[kept++] = own;
+                    }
+                    nDev = kept;
                 }
             }
             int n = 0;

@@ -92,6 +92,31 @@ class IndexView(C.Structure):
     ]
 
 
+class IndexBuildParams(C.Structure):          # snapgpu_index_build_params
+    _fields_ = [
+        ("seed_len", C.c_uint32),
+        ("slack", C.c_double),
+        ("key_bytes", C.c_uint32),
+        ("chromosome_padding", C.c_uint32),
+        ("space_terminates_name", C.c_uint32),
+        ("name_terminators", C.c_char_p),
+        ("auto_alt", C.c_uint32),
+        ("max_alt_contig_size", C.c_int64),
+        ("alt_contig_names", C.POINTER(C.c_char_p)), ("n_alt_contig_names", C.c_uint32),
+        ("non_alt_contig_names", C.POINTER(C.c_char_p)), ("n_non_alt_contig_names", C.c_uint32),
+        ("alt_liftover_file", C.c_char_p),
+    ]
+
+
+class IndexBuildStats(C.Structure):           # snapgpu_index_build_stats
+    _fields_ = [(n, C.c_uint64) for n in ("n_bases", "n_seed_locations", "n_distinct_seeds", "n_repeated_seeds", "overflow_table_size",
+                                          "hash_table_slots", "hash_blob_bytes")] + \
+               [(n, C.c_double) for n in ("ms_keys", "ms_sort", "ms_runs", "ms_tables", "ms_total_device", "s_fasta")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class Params(C.Structure):
     _fields_ = [
         ("max_hits", C.c_uint32),

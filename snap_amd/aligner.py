@@ -52,6 +52,8 @@ EXPORTED_SYMBOLS = [
     "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
     "snapgpu_align_paired_secondary", "snapgpu_align_paired_secondary_device",
     "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag", "snapgpu_sam_fields_single", "snapgpu_sam_fields_single_device", "snapgpu_sam_fields_paired",
+    "snapgpu_default_index_build_params", "snapgpu_index_build", "snapgpu_index_build_from_fasta", "snapgpu_built_index_view",
+    "snapgpu_built_index_save", "snapgpu_built_index_stats", "snapgpu_built_index_destroy",
 ]
 
 
@@ -123,6 +125,25 @@ class BaseAligner:
             raise SnapGpuError("snapgpu_create failed (%d): %s" % (rc, self.lib.snapgpu_last_error(None).decode()))
         self.handle = handle
         self.device = device
+
+    @classmethod
+    def from_built_index(cls, built, index: GenomeIndex | None = None, params: Params | None = None, device: int = 0):
+        """A context over an index that snapgpu_index_build* left in HBM (snap_amd.index.BuiltIndex): the view is adopted as it is
+        (on_device = 1), nothing is copied and no file is read.  `built` must outlive the aligner."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self.index = index
+        self.params = params if params is not None else default_params()
+        self._keep = [built]
+        v = built.view()
+        handle = C.c_void_p()
+        rc = self.lib.snapgpu_create(C.byref(v), C.byref(self.params), device, C.byref(handle))
+        if rc != 0:
+            raise SnapGpuError("snapgpu_create over a built index failed (%d): %s" % (rc, self.lib.snapgpu_last_error(None).decode()))
+        self.handle = handle
+        self.device = device
+        self._after_replica()
+        return self
 
     def replica(self, device: int | None = None, share_index: bool = True):
         """Another context over the same index (include/snapgpu.h: snapgpu_create_replica): on this GPU sharing the resident blobs -- a

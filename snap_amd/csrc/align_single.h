@@ -141,7 +141,9 @@ struct SecCfg {
 // EXACT: the replay instantiation for reads whose banded affine-gap traceback left the band (`reserved` != 0 after the fast pass): every
 // affine-gap call goes through the layout-literal form of ag.h over ag_persist[0 / 1], the wave's images of the reference aligner's
 // affineGap / reverseAffineGap traceback arrays, zeroed by the kernel before the read -- the answer of a newly constructed reference aligner.
-template <int AGC, bool SEC = false, bool EXACT = false>
+// TIMED: the s_memtime phase timers (WaveCounters::cyc_*) are compiled in.  Each read of the clock drains lgkmcnt, ~40 of them per read, so
+// the kernels that are timed for throughput are built without (SNAPGPU_PHASE_TIMERS=1 selects the timed instantiation for a breakdown run).
+template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false>
 struct Aligner {
     // ---- constant for the launch
     // held by value: a reference member would make the kernel-argument struct escape through a
@@ -197,6 +199,8 @@ struct Aligner {
     __device__ __forceinline__ Aligner(const DevIndex &ix_, const DevTables *tab_, const AlignCfg &cfg_, WaveShared *ws)
         : ix(ix_), tab(tab_), cfg(cfg_), max_k(cfg_.max_k), agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0),
           all(ws->all), non_alt(ws->non_alt), primary(ws->primary), first_alt(ws->first_alt), cnt(ws->cnt) {}
+
+    static __device__ __forceinline__ uint64_t clk() { if constexpr (TIMED) return wave_clock(); else return 0; }
 
     // A traceback step outside the band reads what the reference object's array holds there.  For the FIRST call an object serves after
     // its construction that is zero -- exactly what the kernels read -- so only steps of later calls make the answer depend on the
@@ -680,7 +684,7 @@ struct Aligner {
                                 loc_offset = g2 != -1 ? po : 0;
                             }
                         }
-                        const uint64_t t_lv0 = wave_clock();
+                        const uint64_t t_lv0 = clk();
                         for (int half = 0; half < 2 && !HAM; half++) {
                             if (half == 1 && score1 == -1) break;
                             const int st = half == 0 ? 1 : -1;
@@ -704,7 +708,7 @@ struct Aligner {
                             }
                         }
                         if (!HAM) cnt.lv++;
-                        cnt.cyc_lv += wave_clock() - t_lv0;
+                        cnt.cyc_lv += clk() - t_lv0;
 
                         if (!HAM && score1 != -1 && score2 != -1) {
                             int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);     // :1148
@@ -712,7 +716,7 @@ struct Aligner {
                                 score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0;
                                 used_ag = 1;
                                 cnt.ag++;
-                                const uint64_t t_ag0 = wave_clock();
+                                const uint64_t t_ag0 = clk();
                                 AGParams agp{cfg.match_reward, cfg.sub_penalty, cfg.gap_open, cfg.gap_extend, cfg.five_bonus, cfg.three_bonus};
                                 for (int half = 0; half < 2; half++) {
                                     if (half == 0 && tail_start == read_len) continue;               // :1208
@@ -739,7 +743,7 @@ struct Aligner {
                                         score2 = a.n_edits; mp2 = a.match_probability; loc_offset = a.text_offset;
                                     }
                                 }
-                                cnt.cyc_ag += wave_clock() - t_ag0;
+                                cnt.cyc_ag += clk() - t_ag0;
                             }
                         }
 
@@ -850,10 +854,10 @@ struct Aligner {
     __device__ __forceinline__ bool seed_is_used(uint32_t i) const { return (seed_used[i >> 5] >> (i & 31)) & 1u; }
 
     __device__ __forceinline__ void align_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
-        const uint64_t t_read0 = wave_clock();
+        const uint64_t t_read0 = clk();
         ag_obj_used0 = ag_obj_used1 = 0;                                      // a newly constructed aligner for every read
         align_read_inner<false>(g_bases, g_quals, len);
-        cnt.cyc_total += wave_clock() - t_read0;
+        cnt.cyc_total += clk() - t_read0;
     }
     template <bool HAM>
     __device__ __forceinline__ void align_read_inner(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
@@ -939,9 +943,9 @@ struct Aligner {
             if (!seed.valid) continue;                                        // :524
 
             HitList hl[2];
-            const uint64_t t_lk0 = wave_clock();
+            const uint64_t t_lk0 = clk();
             lookup_seed(ix, seed, hl);
-            const uint64_t t_lk1 = wave_clock();
+            const uint64_t t_lk1 = clk();
             cnt.cyc_lookup += t_lk1 - t_lk0;
             cnt.lookups++;
             cnt.slots += hl[0].slots + hl[1].slots;
@@ -973,7 +977,7 @@ struct Aligner {
                     applied_either = true;
                 }
             }
-            cnt.cyc_hits += wave_clock() - t_lk1;
+            cnt.cyc_hits += clk() - t_lk1;
             next_seed += (uint32_t)seed_len;                                  // :676
 
             if (applied_either) {

@@ -26,7 +26,10 @@ struct AlignArgs {
     // the reference's traceback arrays kept per wave in `persist` (2 x ag_scratch_bytes(RL) per wave slot)
     uint32_t *flag_list, *flag_count;
     const uint32_t *remap, *n_remap;
+    uint32_t is_replay;               // this launch redoes reads an earlier launch of the same call already counted (the exact replay)
     uint8_t *persist; uint64_t persist_stride;
+    // heavy-first dequeue (order.h): work item i of the MAIN pass is read order[i] (a permutation of 0 .. n_reads); NULL = batch order
+    const uint32_t *order;
 };
 
 extern "C" {
@@ -36,6 +39,7 @@ void snapgpu_launch_single_sec_6(const AlignArgs *a, uint32_t blocks, size_t lds
 void snapgpu_launch_single_sec_0(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_3(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_0(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_exact_3_timed(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 }
 
 static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }

@@ -56,6 +56,7 @@ struct PairedArgs {
     uint32_t kmax_lv;
     // second pass over the pairs whose candidate buffers overflowed in the first (see launch_paired): work item i is pair remap[i]
     const uint32_t *remap, *n_remap;
+    uint32_t is_replay;                // the pairs of this launch were already counted by an earlier launch of the same call (second / third pass)
     // secondary results (k_align_paired<.., true> only): extra sections of a wave's slab, and the caller's buffers
     uint64_t off_sec, off_sec_ord, off_sec_key, off_ssec;
     SecCfg ssec_cfg;                   // the single-end aligner's lists
@@ -78,8 +79,6 @@ void snapgpu_launch_paired_6(const PairedArgs *a, uint32_t blocks, size_t lds_by
 void snapgpu_launch_paired_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_sec_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_sec_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
-void snapgpu_launch_pair_order(const DevIndex *ix, const uint8_t *bases, const uint64_t *offsets, uint32_t n_pairs, uint32_t max_big_hits,
-                               uint32_t *bucket, uint32_t *hist, uint32_t *order, unsigned long long *counters, uint32_t blocks, hipStream_t s);
 void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale, hipStream_t s);
 void snapgpu_launch_paired_exact_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_exact_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);

@@ -204,7 +204,12 @@ struct DevPL {
     static __device__ __forceinline__ double f64(double v) { return first_f64(v); }
     static __device__ __forceinline__ bool lane0() { return lane_id() == 0; }
     static __device__ __forceinline__ void sync() { WAVE_SYNC(); }
+    // phase timers of the paired path (PECounters::cyc_*): only in a -DSNAPGPU_PHASE_TIMERS build (each clock read drains lgkmcnt)
+#if defined(SNAPGPU_PHASE_TIMERS)
     static __device__ __forceinline__ uint64_t clock() { return wave_clock(); }
+#else
+    static __device__ __forceinline__ uint64_t clock() { return 0; }
+#endif
 
     // ---- HashTableHitSet queries, one lookup per lane (lookups are few: <= 30).  Each reproduces the scalar loop of paired.h:
     // those loops keep the FIRST lookup (lowest index) among equal best locations and only accept locations > 0.
@@ -680,8 +685,8 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
         if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
     }
-    if (lane == 0 && (!EXACT || !a.remap)) {          // (a replayed pair was already counted)
-        if (!a.remap) atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
+    if (lane == 0 && !(EXACT && a.is_replay)) {          // (a pair redone by the exact replay was already counted)
+        if (!a.is_replay) atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
         atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
         atomicAdd(&a.counters[3], (unsigned long long)(al.cnt.hits + core.sh->cnt.hits));
@@ -709,57 +714,4 @@ __global__ void k_collect_flagged(const snapgpu_paired_result *primary, uint32_t
     if (i >= n) return;
     const bool ov = (primary[i].flags & SNAPGPU_PAIR_POOL_OVERFLOW) != 0;
     if (stale ? (!ov && (primary[i].flags & SNAPGPU_PAIR_EXACT_REPLAY) != 0) : ov) list[atomicAdd(count, 1u)] = i;
-}
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// EXPERIMENTAL, off unless SNAPGPU_PAIRED_HEAVY_FIRST=1 when snapgpu_enable_paired runs (results verified identical; no gain measured yet, DESIGN.md
-// section 10).  A launch lasts until its slowest pair is done and the top 1 % of the pairs are ~90 % of the work, so the pairs
-// are dequeued heaviest first: weight = total hits of a pair's non-overlapping seeds (seeds the aligner would skip as too
-// popular count 0), bucketed by log2; a counting sort in descending bucket order gives the `remap` list of the main launch.
-// Results do not depend on the order (pairs are independent).
-template <int UNUSED>
-__global__ __launch_bounds__(256) void k_pair_weights(DevIndex ix, const uint8_t *bases, const uint64_t *offsets, uint32_t n_pairs,
-                                                      uint32_t max_big_hits, uint32_t *bucket, uint32_t *hist /* [34] */)
-{
-    const int lane = lane_id();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    const int seed_len = (int)ix.seed_len;
-    for (uint32_t i = wave; i < n_pairs; i += n_waves) {
-        uint64_t w = 0;
-        for (int r = 0; r < 2; r++) {
-            const uint64_t b = first_u64(offsets[2 * (size_t)i + r]), e = first_u64(offsets[2 * (size_t)i + r + 1]);
-            const int len = (int)(e - b);
-            for (int off = 0; off + seed_len <= len; off += seed_len) {
-                SeedBits seed = pack_seed(bases + b + off, ix.seed_len);
-                if (!seed.valid) continue;
-                HitList hl[2];
-                lookup_seed(ix, seed, hl);
-                for (int d = 0; d < 2; d++) {
-                    const int64_t nh = (int64_t)first_u64((uint64_t)hl[d].n_hits);
-                    if (nh > 0 && nh <= (int64_t)max_big_hits) w += (uint64_t)nh;
-                }
-            }
-        }
-        const uint32_t ww = w > 0xffffffffull ? 0xffffffffu : (uint32_t)w;
-        const uint32_t bk = ww == 0 ? 0u : 32u - (uint32_t)__clz(ww);      // 0 .. 32
-        if (lane == 0) { bucket[i] = bk; atomicAdd(&hist[bk], 1u); }
-    }
-}
-// hist[b] := first position of bucket b when buckets are laid out from the heaviest down; hist[33] := the number of pairs
-template <int UNUSED>
-__global__ void k_pair_weight_prefix(uint32_t *hist, unsigned long long *counters, uint32_t n_pairs)
-{
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int b = 32; b >= 0; b--) { const uint32_t c = hist[b]; hist[b] = acc; acc += c; }
-        hist[33] = acc;
-        atomicAdd(&counters[0], 2ull * n_pairs);                          // reads: the main launch runs in remap mode, which does not count them
-    }
-}
-template <int UNUSED>
-__global__ void k_pair_weight_scatter(const uint32_t *bucket, uint32_t n_pairs, uint32_t *hist, uint32_t *order)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_pairs) order[atomicAdd(&hist[bucket[i]], 1u)] = i;
 }

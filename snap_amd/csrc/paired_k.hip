@@ -32,16 +32,6 @@ extern "C" void snapgpu_launch_collect_flagged(const snapgpu_paired_result *prim
 {
     hipLaunchKernelGGL(k_collect_flagged<0>, dim3((n + 255) / 256), dim3(256), 0, s, primary, n, list, count, stale);
 }
-
-// experimental heavy-first ordering (paired_dev.h): order[0 .. n) and hist[33] = n are ready when these three have run
-extern "C" void snapgpu_launch_pair_order(const DevIndex *ix, const uint8_t *bases, const uint64_t *offsets, uint32_t n_pairs, uint32_t max_big_hits,
-                                          uint32_t *bucket, uint32_t *hist, uint32_t *order, unsigned long long *counters, uint32_t blocks, hipStream_t s)
-{
-    hipMemsetAsync(hist, 0, 34 * sizeof(uint32_t), s);
-    hipLaunchKernelGGL(k_pair_weights<0>, dim3(blocks), dim3(256), 0, s, *ix, bases, offsets, n_pairs, max_big_hits, bucket, hist);
-    hipLaunchKernelGGL(k_pair_weight_prefix<0>, dim3(1), dim3(64), 0, s, hist, counters, n_pairs);
-    hipLaunchKernelGGL(k_pair_weight_scatter<0>, dim3((n_pairs + 255) / 256), dim3(256), 0, s, (const uint32_t *)bucket, n_pairs, hist, order);
-}
 #endif
 
 #if PAIRED_AGC == 0 || PAIRED_AGC == 3     // exact replay of flagged pairs (paired_args.h: PairedArgs::persist): the 192-position register variant, or the LDS form

@@ -9,7 +9,7 @@
 #ifndef SNAPGPU_WAVES_PER_SIMD
 #define SNAPGPU_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 6 : 4)
 #endif
-template <int AGC, bool SEC, bool EXACT = false>
+template <int AGC, bool SEC, bool EXACT = false, bool TIMED = false>
 __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_single(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
     WaveShared *ws = (WaveShared *)(my + L.shared);
-    Aligner<AGC, SEC, EXACT> al(a.ix, a.tab, a.cfg, ws);
+    Aligner<AGC, SEC, EXACT, TIMED> al(a.ix, a.tab, a.cfg, ws);
     al.lane = lane;
     al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
     al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
@@ -58,8 +58,9 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         if (lane == 0) i = atomicAdd(a.work_counter, 1u);
         i = first_u32(i);
         if (i >= n_total) break;
+        if (a.remap) i = first_u32(a.remap[i]);
+        else if (a.order) i = first_u32(a.order[i]);
         if constexpr (EXACT) {          // a newly constructed reference aligner: both traceback arrays read as zero
-            if (a.remap) i = first_u32(a.remap[i]);
             if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
             if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
             al.ag_hw0 = al.ag_hw1 = 0;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
         if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
     }
-    if (lane == 0 && (!EXACT || !a.remap)) {          // (a replayed read was already counted by the fast pass)
+    if (lane == 0 && !a.is_replay) {          // (a replayed read was already counted by the fast pass)
         atomicAdd(&a.counters[0], (unsigned long long)n_done);
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
         atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);

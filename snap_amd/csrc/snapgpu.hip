@@ -21,6 +21,7 @@
 #include "align_single.h"
 #include "kernel_common.h"
 #include "single_kernel.h"
+#include "order.h"
 #include "paired_args.h"
 #include "cigar_lv.h"
 #include "cigar_ag.h"
@@ -269,6 +270,9 @@ struct snapgpu_ctx {
     // paired-end path with secondary results (both snapgpu_enable_paired and snapgpu_enable_secondary called): its own slabs
     // experimental: dequeue heavy pairs first (SNAPGPU_PAIRED_HEAVY_FIRST=1 at snapgpu_enable_paired; paired_dev.h)
     bool heavy_first = false;
+    // heavy-first dequeue of the single-end path (order.h): on unless SNAPGPU_SINGLE_HEAVY_FIRST=0
+    bool single_heavy_first = true;
+    bool phase_timers = false;        // SNAPGPU_PHASE_TIMERS=1: launch the instantiation that carries the s_memtime phase timers
     uint32_t *d_order = nullptr, *d_wbucket = nullptr, *d_whist = nullptr; size_t order_cap = 0;
     bool paired_sec = false;
     PairedArgs pargs_sec{}, pargs_sec_big{};
@@ -301,6 +305,8 @@ static int fail(snapgpu_ctx *ctx, int code, const std::string &msg) {
 }
 
 extern "C" int snapgpu_abi_version(void) { return SNAPGPU_ABI_VERSION; }
+// (index_build.hip reports through the same per-thread message as the functions of this file)
+extern "C" void snapgpu_set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
 
 extern "C" const char *snapgpu_last_error(const snapgpu_ctx *ctx) {
     if (ctx && !ctx->err.empty()) return ctx->err.c_str();
@@ -582,7 +588,7 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         ctx->view_meta.cigar_ops = nullptr;
     }
 
-    if (g_share_buckets_from && g_share_buckets_from->d_bucket_blob && idx->on_device) {     // second feeder context on this GPU: adopt
+    if (g_share_buckets_from && g_share_buckets_from->d_bucket_blob && idx->on_device && !getenv("SNAPGPU_NO_BUCKETS")) {     // second feeder context on this GPU: adopt
         ctx->owns_buckets = false;
         ctx->d_bucket_blob = g_share_buckets_from->d_bucket_blob; ctx->d_bucket_offset = g_share_buckets_from->d_bucket_offset;
         ctx->d_n_buckets = g_share_buckets_from->d_n_buckets; ctx->bucket_bytes = g_share_buckets_from->bucket_bytes;
@@ -654,6 +660,8 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         CRCHK(hipMalloc((void **)&ctx->d_exact_persist, (size_t)ctx->exact_slots * ctx->exact_persist_stride), SNAPGPU_E_NOMEM);
         CRCHK(hipMemsetAsync(ctx->d_exact_persist, 0, (size_t)ctx->exact_slots * ctx->exact_persist_stride, ctx->stream), SNAPGPU_E_NODEVICE);
     }
+    if (const char *e = getenv("SNAPGPU_SINGLE_HEAVY_FIRST")) ctx->single_heavy_first = atoi(e) != 0;
+    if (const char *e = getenv("SNAPGPU_PHASE_TIMERS")) ctx->phase_timers = atoi(e) != 0;
     CRCHK(hipMalloc((void **)&ctx->d_work, 256), SNAPGPU_E_NOMEM);
     CRCHK(hipMalloc((void **)&ctx->d_counters, sizeof(snapgpu_counters)), SNAPGPU_E_NOMEM);
     CRCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(snapgpu_counters), ctx->stream), SNAPGPU_E_NODEVICE);
@@ -1418,6 +1426,28 @@ extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
     return SNAPGPU_OK;
 }
 
+// heavy-first dequeue order of a batch (order.h): ctx->d_order[0 .. n_units) is ready on stream s when this returns
+static int launch_unit_order(snapgpu_ctx *ctx, const void *d_bases, const void *d_offsets, uint32_t n_units, uint32_t rpu, uint32_t max_hits, hipStream_t s)
+{
+    if (ctx->order_cap < n_units) {
+        if (ctx->d_order) (void)hipFree(ctx->d_order);
+        if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
+        ctx->d_order = ctx->d_wbucket = nullptr; ctx->order_cap = 0;
+        size_t cap = (size_t)n_units + n_units / 4 + 1024;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_order, cap * 4), SNAPGPU_E_NOMEM);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_wbucket, cap * 4), SNAPGPU_E_NOMEM);
+        ctx->order_cap = cap;
+    }
+    if (!ctx->d_whist) HIPCHK(ctx, hipMalloc((void **)&ctx->d_whist, 64 * 4), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_whist, 0, 34 * sizeof(uint32_t), s), SNAPGPU_E_LAUNCH);
+    hipLaunchKernelGGL(k_unit_weights<0>, dim3((unsigned)ctx->num_cus * 8), dim3(256), 0, s, ctx->ix, (const uint8_t *)d_bases, (const uint64_t *)d_offsets,
+                       n_units, rpu, max_hits, ctx->d_wbucket, ctx->d_whist);
+    hipLaunchKernelGGL(k_unit_weight_prefix<0>, dim3(1), dim3(64), 0, s, ctx->d_whist);
+    hipLaunchKernelGGL(k_unit_weight_scatter<0>, dim3((n_units + 255) / 256), dim3(256), 0, s, (const uint32_t *)ctx->d_wbucket, n_units, ctx->d_whist, ctx->d_order);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
 static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals, const void *d_offsets,
                         void *d_primary, void *d_first_alt, hipStream_t s,
                         void *d_secondary = nullptr, uint32_t sec_out_stride = 0, void *d_n_secondary = nullptr)
@@ -1429,6 +1459,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.sec_cfg = SecCfg{-1, -1, 0, 0}; a.sec_scratch = nullptr; a.sec_stride_bytes = 0; a.secondary = nullptr; a.sec_out_stride = 0; a.n_secondary = nullptr;
     a.flag_list = nullptr; a.flag_count = nullptr; a.remap = nullptr; a.n_remap = nullptr; a.persist = nullptr; a.persist_stride = 0;
+    a.is_replay = 0; a.order = nullptr;
     const bool always_exact = ctx->always_exact && ctx->d_exact_persist != nullptr;
     const bool exact = !always_exact && ctx->d_exact_persist != nullptr && !getenv("SNAPGPU_NO_EXACT_REPLAY");
     if (exact) {
@@ -1445,13 +1476,19 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     uint32_t blocks = ctx->n_wave_slots / 4;
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    if (ctx->single_heavy_first && n > ctx->n_wave_slots) {      // (inside the timed region: it is part of the pass)
+        const int orc = launch_unit_order(ctx, d_bases, d_offsets, n, 1, ctx->cfg.max_hits, s);
+        if (orc) return orc;
+        a.order = ctx->d_order;
+    }
     if (d_n_secondary) {
         a.sec_cfg = ctx->sec_cfg; a.sec_scratch = ctx->d_sec_scratch; a.sec_stride_bytes = ctx->sec_stride_bytes;
         a.secondary = (snapgpu_single_result *)d_secondary; a.sec_out_stride = sec_out_stride; a.n_secondary = (uint32_t *)d_n_secondary;
     }
     if (always_exact) {                 // one pass, exact by construction
         a.persist = ctx->d_exact_persist; a.persist_stride = ctx->exact_persist_stride;
-        snapgpu_launch_single_exact_3(&a, d_n_secondary ? 1 : 0, blocks, 4 * ctx->cfg.lds_per_wave, s);
+        if (ctx->phase_timers && !d_n_secondary) snapgpu_launch_single_exact_3_timed(&a, blocks, 4 * ctx->cfg.lds_per_wave, s);
+        else snapgpu_launch_single_exact_3(&a, d_n_secondary ? 1 : 0, blocks, 4 * ctx->cfg.lds_per_wave, s);
     } else if (d_n_secondary) {
         switch (ctx->ag_variant) {
         case 3:  snapgpu_launch_single_sec_3(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
@@ -1470,6 +1507,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     if (exact) {        // redo the flagged reads (usually none: the launch then ends at once) as a newly constructed reference aligner would
         AlignArgs x = a;
         x.flag_list = nullptr; x.flag_count = nullptr; x.remap = ctx->d_flag_list; x.n_remap = ctx->d_work + 4; x.work_counter = ctx->d_work + 3;
+        x.is_replay = 1; x.order = nullptr;
         x.persist = ctx->d_exact_persist; x.persist_stride = ctx->exact_persist_stride;
         if (ctx->ag_variant == 3) snapgpu_launch_single_exact_3(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
         else snapgpu_launch_single_exact_0(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
@@ -1825,10 +1863,10 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     if (ctx->d_pexact_persist) { (void)hipFree(ctx->d_pexact_persist); ctx->d_pexact_persist = nullptr; }
     if (ctx->d_help) { (void)hipFree(ctx->d_help); ctx->d_help = nullptr; }
     if (ctx->d_help_spec) { (void)hipFree(ctx->d_help_spec); ctx->d_help_spec = nullptr; }
-    // Phase-4 lists at least this long are offered to idle waves (SNAPGPU_PAIRED_HELP_MIN=<n>).  Off unless asked for: measured on the
-    // bench workload (profiles/r02f) it gains nothing -- 32 slots are always held by pairs that are merely long, the heaviest pair of
-    // the launch rarely gets one, and every pair scored speculatively counts its out-of-band traceback steps as "later call" ones.
-    ctx->help_min = 0;
+    // Phase-4 lists at least this long are offered to idle waves once a wave has run out of pairs (on-demand publication, paired_dev.h).
+    // On by default at 64 candidates since round 3: measured on the bench batch (256 Mb / 500 k pairs, profiles/r03a) 8.56 -> 5.66 s per
+    // launch with one context, same bytes, 500 k pairs equal to the reference.  SNAPGPU_PAIRED_HELP_MIN=<n> changes it, 0 turns it off.
+    ctx->help_min = 64;
     if (const char *e = getenv("SNAPGPU_PAIRED_HELP_MIN")) ctx->help_min = (uint32_t)strtoul(e, nullptr, 10);
     if (p.use_affine_gap && ctx->help_min != 0) {
         ctx->n_help = 32;
@@ -1904,19 +1942,10 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         default: snapgpu_launch_paired_0(&x, nblocks, lds, s); break;
         }
     };
-    if (ctx->heavy_first && !so) {         // experimental (paired_dev.h): heaviest pairs first, through the remap list
-        if (ctx->order_cap < n) {
-            if (ctx->d_order) (void)hipFree(ctx->d_order);
-            if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
-            ctx->d_order = ctx->d_wbucket = nullptr; ctx->order_cap = 0;
-            size_t cap = (size_t)n + n / 4 + 1024;
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_order, cap * 4), SNAPGPU_E_NOMEM);
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_wbucket, cap * 4), SNAPGPU_E_NOMEM);
-            ctx->order_cap = cap;
-        }
-        if (!ctx->d_whist) HIPCHK(ctx, hipMalloc((void **)&ctx->d_whist, 64 * 4), SNAPGPU_E_NOMEM);
-        snapgpu_launch_pair_order(&a.ix, a.bases, a.offsets, n, a.pcfg.max_big_hits, ctx->d_wbucket, ctx->d_whist, ctx->d_order, a.counters,
-                                  (uint32_t)ctx->num_cus * 4, s);
+    a.is_replay = 0;
+    if (ctx->heavy_first && !so) {         // experimental (order.h): heaviest pairs first, through the remap list
+        const int orc = launch_unit_order(ctx, d_bases, d_offsets, n, 2, a.pcfg.max_big_hits, s);
+        if (orc) return orc;
         a.remap = ctx->d_order; a.n_remap = ctx->d_whist + 33;
     }
     auto with_help = [&](PairedArgs &x) -> hipError_t {       // fresh help state for the launch that is about to start
@@ -1939,7 +1968,7 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         b.secondary = a.secondary; b.sec_out_stride = a.sec_out_stride; b.n_secondary = a.n_secondary;
         b.single_secondary = a.single_secondary; b.ssec_out_stride = a.ssec_out_stride; b.n_single_secondary = a.n_single_secondary;
         b.bases = a.bases; b.quals = a.quals; b.offsets = a.offsets; b.n_pairs = n; b.primary = a.primary; b.first_alt = a.first_alt;
-        b.work_counter = d_work2; b.counters = a.counters; b.remap = ctx->d_flag_list; b.n_remap = d_count;
+        b.work_counter = d_work2; b.counters = a.counters; b.remap = ctx->d_flag_list; b.n_remap = d_count; b.is_replay = 1;
         HIPCHK(ctx, with_help(b), SNAPGPU_E_LAUNCH);
         launch(b, (so ? ctx->p_sec_big_slots : ctx->p_big_slots) / 4);
         HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);

@@ -162,3 +162,94 @@ class GenomeIndex:
                            chromosome_padding=padding, overflow=overflow, hash_blob=hash_blob,
                            table_offset=offs, table_size=sizes, genome_padded=genome_padded,
                            n_bases=n_bases, contigs=contigs, directory=directory)
+
+
+def build_index(fasta: str, out_dir: str | None, seed_len: int = 20, slack: float = 0.3, key_bytes: int = 0, padding: int = 2000,
+                device: int = 0, alt_liftover_file: str | None = None, alt_contig_names=(), non_alt_contig_names=(), auto_alt: bool = True,
+                max_alt_contig_size: int = -1, space_terminates_name: bool = True, lib=None, keep: bool = False):
+    """`snap-aligner index <fasta> <out_dir> -s <seed_len> ...` with the build on the GPU (GenomeIndex::runIndexer,
+    SNAPLib/GenomeIndex.cpp:126-506; include/snapgpu.h: snapgpu_index_build_from_fasta / snapgpu_built_index_save).
+    Writes the reference's four files into out_dir (None: nothing is written) and returns the build's statistics; with keep=True returns
+    (stats, BuiltIndex) -- the index still resident in HBM, to hand to an aligner without going through the files."""
+    import ctypes as C
+    from .abi import IndexBuildParams, IndexBuildStats
+    if lib is None:
+        from .aligner import load_library
+        lib = load_library()
+    lib.snapgpu_index_build_from_fasta.argtypes = [C.c_char_p, C.POINTER(IndexBuildParams), C.c_int, C.POINTER(C.c_void_p)]
+    lib.snapgpu_built_index_save.argtypes = [C.c_void_p, C.c_char_p]
+    lib.snapgpu_built_index_stats.argtypes = [C.c_void_p, C.POINTER(IndexBuildStats)]
+    lib.snapgpu_built_index_destroy.argtypes = [C.c_void_p]
+    lib.snapgpu_built_index_destroy.restype = None
+    lib.snapgpu_default_index_build_params.argtypes = [C.POINTER(IndexBuildParams)]
+    lib.snapgpu_default_index_build_params.restype = None
+    lib.snapgpu_last_error.restype = C.c_char_p
+    lib.snapgpu_last_error.argtypes = [C.c_void_p]
+    bp = IndexBuildParams()
+    lib.snapgpu_default_index_build_params(C.byref(bp))
+    bp.seed_len, bp.slack, bp.key_bytes, bp.chromosome_padding = seed_len, slack, key_bytes, padding
+    bp.auto_alt = 1 if auto_alt else 0
+    bp.max_alt_contig_size = max_alt_contig_size
+    bp.space_terminates_name = 1 if space_terminates_name else 0
+    keepalive = []
+    if alt_liftover_file:
+        bp.alt_liftover_file = alt_liftover_file.encode()
+    for field, names in (("alt_contig_names", alt_contig_names), ("non_alt_contig_names", non_alt_contig_names)):
+        if names:
+            arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+            keepalive.append(arr)
+            setattr(bp, field, arr)
+            setattr(bp, "n_" + field, len(names))
+    h = C.c_void_p()
+    rc = lib.snapgpu_index_build_from_fasta(fasta.encode(), C.byref(bp), C.c_int(device), C.byref(h))
+    if rc != 0:
+        raise RuntimeError("snapgpu_index_build_from_fasta failed (%d): %s" % (rc, (lib.snapgpu_last_error(None) or b"").decode()))
+    try:
+        if out_dir is not None:
+            rc = lib.snapgpu_built_index_save(h, out_dir.encode())
+            if rc != 0:
+                raise RuntimeError("snapgpu_built_index_save failed (%d): %s" % (rc, (lib.snapgpu_last_error(None) or b"").decode()))
+        st = IndexBuildStats()
+        lib.snapgpu_built_index_stats(h, C.byref(st))
+    except BaseException:
+        lib.snapgpu_built_index_destroy(h)
+        raise
+    if keep:
+        return st.as_dict(), BuiltIndex(lib, h)
+    lib.snapgpu_built_index_destroy(h)
+    return st.as_dict()
+
+
+class BuiltIndex:
+    """An index built by snapgpu_index_build* and still resident in HBM (include/snapgpu.h: snapgpu_built_index)."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle = lib, handle
+
+    def view(self):
+        import ctypes as C
+        from .abi import IndexView
+        v = IndexView()
+        self.lib.snapgpu_built_index_view.argtypes = [C.c_void_p, C.POINTER(IndexView)]
+        rc = self.lib.snapgpu_built_index_view(self.handle, C.byref(v))
+        if rc != 0:
+            raise RuntimeError("snapgpu_built_index_view failed (%d)" % rc)
+        return v
+
+    def save(self, out_dir: str):
+        import ctypes as C
+        self.lib.snapgpu_built_index_save.argtypes = [C.c_void_p, C.c_char_p]
+        rc = self.lib.snapgpu_built_index_save(self.handle, out_dir.encode())
+        if rc != 0:
+            raise RuntimeError("snapgpu_built_index_save failed (%d)" % rc)
+
+    def close(self):
+        if self.handle:
+            self.lib.snapgpu_built_index_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

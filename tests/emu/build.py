@@ -19,7 +19,9 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fno-reorder-blocks", "-fno-reorder-
 
 
 def units():
-    u = [("snapgpu.o", os.path.join(CSRC, "snapgpu.hip"), []), ("cigar_k.o", os.path.join(CSRC, "cigar_k.hip"), [])]
+    u = [("snapgpu.o", os.path.join(CSRC, "snapgpu.hip"), []), ("cigar_k.o", os.path.join(CSRC, "cigar_k.hip"), []),
+         ("single_timed_k.o", os.path.join(CSRC, "single_timed_k.hip"), []),
+         ("index_build.o", os.path.join(CSRC, "index_build.hip"), [])]
     u += [("paired_k%d.o" % v, os.path.join(CSRC, "paired_k.hip"), ["-DPAIRED_AGC=%d" % v]) for v in (3, 4, 6, 0)]
     u += [("single_sec_k%d.o" % v, os.path.join(CSRC, "single_sec_k.hip"), ["-DSINGLE_AGC=%d" % v]) for v in (3, 4, 6, 0)]
     u += [("paired_sec_k%d.o" % v, os.path.join(CSRC, "paired_k.hip"), ["-DPAIRED_AGC=%d" % v, "-DPAIRED_SEC"]) for v in (3, 0)]
@@ -61,6 +63,10 @@ def build(verbose=False):
     tool_src = os.path.join(CSRC, "host", "snapgpu_sam.cpp")
     if not os.path.exists(TOOL) or os.path.getmtime(TOOL) < max(os.path.getmtime(tool_src), os.path.getmtime(LIB)):
         _run([CXX, "-O2", "-std=c++17", "-o", TOOL, tool_src, "-L" + BDIR, "-lsnapgpu_emu", "-Wl,-rpath," + BDIR, "-lpthread", "-lz"])
+    itool_src = os.path.join(CSRC, "host", "snapgpu_index.cpp")
+    itool = os.path.join(BDIR, "snapgpu-index-emu")
+    if not os.path.exists(itool) or os.path.getmtime(itool) < max(os.path.getmtime(itool_src), os.path.getmtime(LIB)):
+        _run([CXX, "-O2", "-std=c++17", "-o", itool, itool_src, "-L" + BDIR, "-lsnapgpu_emu", "-Wl,-rpath," + BDIR, "-lpthread"])
     return LIB
 
 

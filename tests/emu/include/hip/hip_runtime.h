@@ -107,6 +107,7 @@ static inline unsigned atomicOr(unsigned *p, unsigned v) { return __atomic_fetch
 static inline unsigned atomicExch(unsigned *p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned atomicSub(unsigned *p, unsigned v) { return __atomic_fetch_sub(p, v, __ATOMIC_SEQ_CST); }
 static inline unsigned atomicCAS(unsigned *p, unsigned expect, unsigned v) { __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return expect; }
+static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long expect, unsigned long long v) { __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return expect; }
 #include <sched.h>
 struct uint2 { uint32_t x, y; };
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }

@@ -389,6 +389,7 @@ int __tsan_atomic32_fetch_or(volatile int *p, int v, int) { return __atomic_fetc
 int __tsan_atomic32_exchange(volatile int *p, int v, int) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 int __tsan_atomic32_load(const volatile int *p, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }
 int __tsan_atomic32_compare_exchange_strong(volatile int *p, int *e, int d, int, int) { return __atomic_compare_exchange_n(p, e, d, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); }
+int __tsan_atomic64_compare_exchange_strong(volatile long *p, long *e, long d, int, int) { return __atomic_compare_exchange_n(p, e, d, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); }
 void __tsan_atomic32_store(volatile int *p, int v, int) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 void __tsan_atomic64_store(volatile long *p, long v, int) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 long __tsan_atomic64_load(const volatile long *p, int) { return __atomic_load_n(p, __ATOMIC_SEQ_CST); }

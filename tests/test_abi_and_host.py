@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = load_library()
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.snapgpu_abi_version() == 3
+    assert lib.snapgpu_abi_version() == 4
 
 
 def test_struct_layouts_match_header():

@@ -50,7 +50,7 @@ def test_emulated_library_exports_the_c_abi(emu):
     from snap_amd.aligner import EXPORTED_SYMBOLS
     for s in EXPORTED_SYMBOLS:
         assert hasattr(emu, s), s
-    assert emu.snapgpu_abi_version() == 3
+    assert emu.snapgpu_abi_version() == 4
 
 
 def test_emu_tables_and_seed_lookup(emu_aligner, golden_primitives):
@@ -341,3 +341,29 @@ def test_emu_sam_fields_device_pointer_form(emu, golden_index):
         assert (v == z["default_" + k][:n]).all(), k
     for i in range(n):
         assert util.cigar_text(ops[i], n_ops[i]) == util.cigar_text(z["default_ops"][i], z["default_n_ops"][i]), i
+
+
+def test_emu_index_builder_vs_reference(emu, tmp_path):
+    """the GPU index builder's directory against the reference's own `snap-aligner index` on the same FASTA --
+    same Genome file, same table sizes, same answers to every probed seed, same alignments (tests/index_build_util.py)."""
+    from tests.index_build_util import compare_with_reference
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built")
+    stats, _, d_gpu = compare_with_reference(tmp_path, lib=emu)
+    assert stats["n_repeated_seeds"] > 0 and stats["overflow_table_size"] > 0
+    # the index straight from HBM, without the files: build, adopt the view, align the reads of the file-based index
+    from snap_amd.index import build_index, GenomeIndex
+    from snap_amd.aligner import BaseAligner
+    st2, built = build_index(os.path.join(str(tmp_path), "g.fa"), None, lib=emu, keep=True)
+    assert st2["n_distinct_seeds"] == stats["n_distinct_seeds"]
+    ix = GenomeIndex.load_from_directory(d_gpu)
+    a_files = BaseAligner(ix, abi.default_params(max_k=8, max_read_len=112))
+    a_view = BaseAligner.from_built_index(built, ix, abi.default_params(max_k=8, max_read_len=112))
+    from snap_amd import synth
+    contigs = [(c.name, ix.genome[c.begin:c.begin + 20000]) for c in ix.contigs[:3]]
+    reads = synth.make_reads(3, contigs, 400, 100)
+    p1, _ = a_files.AlignRead(reads["bases"], reads["quals"], reads["offsets"])
+    p2, _ = a_view.AlignRead(reads["bases"], reads["quals"], reads["offsets"])
+    assert not util.compare_results(p1, p2)
+    a_files.close(); a_view.close(); built.close()
