@@ -37,28 +37,42 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def ensure_index(args, rank):
-    """Genome + SNAP index directory under /tmp, built once per box with the reference's own
-    `snap-aligner index` (the index is an input artefact in the reference's on-disk format; this
-    repo only loads it -- SURVEY.md section 2 row 5)."""
+def ensure_index(args, rank, device=0):
+    """Genome + SNAP index directory under /tmp, built once per box.  The directory is in the reference's on-disk format either way:
+    --indexer gpu (default) builds it with this repo's GPU index builder (include/snapgpu.h: snapgpu_index_build_from_fasta; parity with
+    the reference's builder: tests/test_zx_gpu_index_build.py) and ALSO returns the index still resident in HBM, so a one-GPU run aligns
+    over it without reading the files back; --indexer reference runs the reference's own `snap-aligner index`,
+    ~90 s at 256 Mb and ~20 minutes at GRCh38 scale.  The reference (cpu_baseline / parity_check) loads the same directory."""
     from snap_amd import synth
-    tag = "g%d_s%d_seed%d" % (args.genome_mb, args.seed_len, args.seed)
+    tag = "g%d_s%d_seed%d_%s" % (args.genome_mb, args.seed_len, args.seed, args.indexer)
     work = os.path.join(args.workdir, tag)
     done = os.path.join(work, "idx", "GenomeIndex")
     t0 = time.time()
     genome = synth.make_genome(args.seed, args.genome_mb * 1_000_000, n_contigs=max(1, min(24, args.genome_mb // 8)),
                                repeat_frac=0.30, max_copies=5000, repeat_len=(200, 3000), max_divergence=0.05)
     log("genome %d Mb generated in %.1fs" % (args.genome_mb, time.time() - t0))
+    built, info = None, {"indexer": args.indexer, "cached": os.path.exists(done)}
     if rank == 0 and not os.path.exists(done):
-        from oracle import ref          # reference index builder == the cpu_baseline's own set-up step
         os.makedirs(work, exist_ok=True)
         fa = os.path.join(work, "ref.fa")
-        synth.write_fasta(fa, genome)
         t1 = time.time()
-        ref.build_index(fa, os.path.join(work, "idx"), args.seed_len, threads=os.cpu_count() or 8)
-        log("reference index build: %.1fs" % (time.time() - t1))
+        synth.write_fasta(fa, genome)
+        info["s_fasta_written"] = time.time() - t1
+        t1 = time.time()
+        if args.indexer == "gpu":
+            from snap_amd.index import build_index
+            stats, built = build_index(fa, os.path.join(work, "idx"), seed_len=args.seed_len, device=device, keep=True)
+            info.update(stats)
+            info["s_build_and_save"] = time.time() - t1
+            log("GPU index build + save: %.1fs (device %.0f ms: seeds %.0f, sort %.0f, runs %.0f, tables %.0f; FASTA read %.1fs)"
+                % (time.time() - t1, stats["ms_total_device"], stats["ms_keys"], stats["ms_sort"], stats["ms_runs"], stats["ms_tables"], stats["s_fasta"]))
+        else:
+            from oracle import ref          # reference index builder == the cpu_baseline's own set-up step
+            ref.build_index(fa, os.path.join(work, "idx"), args.seed_len, threads=os.cpu_count() or 8)
+            info["s_build_and_save"] = time.time() - t1
+            log("reference index build: %.1fs" % (time.time() - t1))
         os.remove(fa)
-    return genome, os.path.join(work, "idx")
+    return genome, os.path.join(work, "idx"), built, info
 
 
 def algorithmic_bytes(c, read_len, n_reads, ref_walk_slots=None):
@@ -100,6 +114,7 @@ def main():
     ap.add_argument("--long-indel-frac", type=float, default=0.0, help="paired: fraction of reads with one extra indel event of length 1-10 (C5: 0.002)")
     ap.add_argument("--skip-refwalk", action="store_true", help="skip the untimed launches that count the reference's slot walk (roofline numerator)")
     ap.add_argument("--skip-breakdown", action="store_true", help="skip the untimed launch with phase timers (roofline.wave_cycle_breakdown)")
+    ap.add_argument("--indexer", choices=["gpu", "reference"], default="gpu", help="who builds the index directory (see ensure_index)")
     ap.add_argument("--skip-cpu", action="store_true")
     ap.add_argument("--skip-probe", action="store_true", help="skip the stand-alone index-probe measurement (roofline.probe)")
     ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
@@ -142,7 +157,7 @@ def main():
     # ---------------------------------------------------------------- set-up (untimed)
     # The index directory is built BEFORE the process group exists: a build can take minutes at GRCh38 scale, and a rank that sits in
     # a collective that long runs into the NCCL watchdog.  Ranks other than 0 wait for the directory's last file on the file system.
-    genome, idx_dir = ensure_index(args, rank)
+    genome, idx_dir, built, index_info = ensure_index(args, rank, local_rank)
     while rank != 0 and not os.path.exists(os.path.join(idx_dir, "GenomeIndex")):
         time.sleep(1.0)
     if world > 1 or force_dist:
@@ -151,17 +166,27 @@ def main():
         dist.barrier()
     params = abi.default_params(max_k=args.max_k, max_read_len=((args.read_len + 15) // 16) * 16)
     t0 = time.time()
-    if dist is None:
+    if dist is None and built is not None:      # the index this process has just built is still in HBM: adopt it, no file is read back
+        index = None
+        cls = ChimericPairedEndAligner if paired else BaseAligner
+        aligner = cls.from_built_index(built, None, params, device=local_rank, paired_params=pparams if paired else None)
+        keep = built
+        index_bytes = int(index_info["hash_blob_bytes"] + 4 * index_info["overflow_table_size"] + index_info["n_bases"] + 2048)
+    elif dist is None:
         index = GenomeIndex.load_from_directory(idx_dir)
         aligner = make_aligner(index, params, device=local_rank)
         keep = None
     else:
+        if built is not None:
+            built.close(); built = None
         index = GenomeIndex.load_from_directory(idx_dir) if rank == 0 else None
         index, blobs = sd.broadcast_index(index, dev)          # RCCL broadcast HBM -> HBM
         keep = blobs
         aligner = make_aligner(index, params, device=local_rank,
                                device_index_ptrs=(blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr()))
-    index_bytes = sum(int(x) for x in getattr(index, "_device_sizes", (index.hash_blob.size, index.overflow.size, index.genome_padded.size)))
+    if index is not None:
+        hb_, ow_, gb_ = getattr(index, "_device_sizes", (index.hash_blob.size, index.overflow.size, index.genome_padded.size))
+        index_bytes = int(hb_) + 4 * int(ow_) + int(gb_)
     log("rank %d: index resident in HBM after %.1fs" % (rank, time.time() - t0))
 
     # --batches DISTINCT read batches rotate through the timed steps (step k aligns batch k mod B), so that no step finds the previous
@@ -283,9 +308,25 @@ def main():
         timed.counters(reset=True)
         timed.align_device(n_units, d_bases.data_ptr(), d_quals.data_ptr(), d_offs.data_ptr(), d_prims[0].data_ptr())
         tc = timed.counters(reset=True)
+        try:        # where the launch's time goes wave by wave: finish-time distribution and the most expensive reads (profiles/)
+            lp = timed.launch_profile()
+            t0_ = int(lp["wave_start"][lp["wave_start"] > 0].min()); fin = (lp["wave_finish"].astype(np.int64) - t0_)
+            fin = np.sort(fin[lp["wave_finish"] > 0]); end_ = max(1, int(fin[-1]))
+            worst = np.sort(lp["wave_worst_read_cycles"].astype(np.int64))[::-1]
+            ag_of_worst = lp["wave_worst_read_ag_calls"][np.argsort(lp["wave_worst_read_cycles"])[::-1]]
+            launch_profile = {"waves": int(fin.size), "launch_cycles": end_,
+                              "wave_finish_fraction_of_launch": {"p10": float(fin[int(0.10 * fin.size)]) / end_, "p50": float(fin[fin.size // 2]) / end_,
+                                                                 "p90": float(fin[int(0.90 * fin.size)]) / end_, "p99": float(fin[int(0.99 * fin.size)]) / end_},
+                              "mean_wave_residency": float(fin.mean()) / end_,
+                              "worst_reads_fraction_of_launch": [float(x) / end_ for x in worst[:8]],
+                              "worst_reads_ag_calls": [int(x) for x in ag_of_worst[:8]],
+                              "read_cycles_log2_hist": {str(i): int(v) for i, v in enumerate(lp["read_cycles_log2_hist"]) if v}}
+        except Exception as e_:          # noqa: BLE001 -- diagnostics only
+            launch_profile = {"error": str(e_)}
         tot_c = max(1, tc.get("cycles_total", 0))
         breakdown = {"fractions": {k[7:]: tc[k] / tot_c for k in ("cycles_lookup", "cycles_hits", "cycles_lv", "cycles_ag") if k in tc},
                      "wave_cycles_per_read": tc.get("cycles_total", 0) / max(1, tc["n_reads"]),
+                     "launch_profile": launch_profile,
                      "source": "one untimed launch of k_align_single<3, false, true, TIMED> (SNAPGPU_PHASE_TIMERS=1) on batch 0; the timed kernels carry no timers"}
         timed.close()
 
@@ -336,13 +377,13 @@ def main():
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8 bases / int32 DP / f64 match probability", "data": "synthetic",
-        "config": {"workload": ("configs[2]: %d pairs of 2 x %d bp (FR, insert N(%g,%g^2), long-indel fraction %g) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
+        "config": {"workload": ("configs[2]: %d pairs of 2 x %d bp (FR, insert N(%g,%g^2), long-indel fraction %g) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d (directory in the reference's format), genome = seeded synthetic %d Mb with 30%% planted repeats"
                                 % (n_units, args.read_len, args.insert_mean, args.insert_sd, args.long_indel_frac, args.max_k, args.seed_len, args.genome_mb)) if paired else
-                               ("configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d built by the reference's indexer, genome = seeded synthetic %d Mb with 30%% planted repeats"
+                               ("configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d (directory in the reference's format), genome = seeded synthetic %d Mb with 30%% planted repeats"
                                 % (n, args.read_len, args.max_k, args.seed_len, args.genome_mb)),
                    "reads_per_gpu": n, "read_len": args.read_len, "index_bytes_hbm": index_bytes,
                    "parallelism": "reads sharded over %d GPU(s), index replicated%s" % (world, " by RCCL broadcast" if world > 1 else ""),
-                   "feeders_per_gpu": n_feed},
+                   "feeders_per_gpu": n_feed, "index_build": index_info},
         "roofline": {"kernel": "k_align_paired" if paired else "k_align_single", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "bytes_breakdown": parts, "avg_launch_ms": avg_ms,
@@ -364,6 +405,7 @@ def main():
         out["roofline"]["wave_cycle_breakdown"] = breakdown["fractions"]
         out["roofline"]["wave_cycles_per_read"] = breakdown["wave_cycles_per_read"]
         out["roofline"]["wave_cycle_breakdown_source"] = breakdown["source"]
+        out["roofline"]["launch_profile"] = breakdown["launch_profile"]
     elif counters.get("cycles_total", 0):      # (a -DSNAPGPU_PHASE_TIMERS build of the paired kernels)
         tot = counters["cycles_total"]
         out["roofline"]["wave_cycle_breakdown"] = {k[7:]: counters[k] / tot for k in

@@ -127,7 +127,7 @@ class BaseAligner:
         self.device = device
 
     @classmethod
-    def from_built_index(cls, built, index: GenomeIndex | None = None, params: Params | None = None, device: int = 0):
+    def from_built_index(cls, built, index: GenomeIndex | None = None, params: Params | None = None, device: int = 0, paired_params=None):
         """A context over an index that snapgpu_index_build* left in HBM (snap_amd.index.BuiltIndex): the view is adopted as it is
         (on_device = 1), nothing is copied and no file is read.  `built` must outlive the aligner."""
         self = cls.__new__(cls)
@@ -142,8 +142,11 @@ class BaseAligner:
             raise SnapGpuError("snapgpu_create over a built index failed (%d): %s" % (rc, self.lib.snapgpu_last_error(None).decode()))
         self.handle = handle
         self.device = device
-        self._after_replica()
+        self._after_built(paired_params)
         return self
+
+    def _after_built(self, paired_params):
+        pass
 
     def replica(self, device: int | None = None, share_index: bool = True):
         """Another context over the same index (include/snapgpu.h: snapgpu_create_replica): on this GPU sharing the resident blobs -- a
@@ -363,6 +366,19 @@ class BaseAligner:
         self._check(self.lib.snapgpu_get_counters(self.handle, C.byref(c), C.c_int(1 if reset else 0)), "snapgpu_get_counters")
         return c.as_dict()
 
+    def launch_profile(self):
+        """Diagnostics of the last single-end launch of a context created under SNAPGPU_PHASE_TIMERS=1: dict(read_cycles_log2_hist[64],
+        wave_start[S], wave_finish[S], wave_worst_read_cycles[S], wave_worst_read_ag_calls[S])."""
+        cap = 64 + 3 * 65536
+        buf = np.zeros(cap, dtype=np.uint64)
+        ns = C.c_uint32(0)
+        self.lib.snapgpu_debug_launch_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]
+        self._check(self.lib.snapgpu_debug_launch_profile(self.handle, buf.ctypes.data, C.c_uint64(cap), C.byref(ns)), "snapgpu_debug_launch_profile")
+        S = int(ns.value)
+        w = buf[64 + 2 * S:64 + 3 * S]
+        return dict(read_cycles_log2_hist=buf[:64].copy(), wave_start=buf[64:64 + S].copy(), wave_finish=buf[64 + S:64 + 2 * S].copy(),
+                    wave_worst_read_cycles=(w >> np.uint64(24)).copy(), wave_worst_read_ag_calls=(w & np.uint64(0xffffff)).copy())
+
     def kernel_time(self, reset: bool = False):
         ms = C.c_double(0); nl = C.c_uint64(0)
         self._check(self.lib.snapgpu_kernel_time(self.handle, C.byref(ms), C.byref(nl), C.c_int(1 if reset else 0)),
@@ -399,6 +415,13 @@ class ChimericPairedEndAligner(BaseAligner):
         self._check(self.lib.snapgpu_enable_paired(self.handle, C.byref(self.paired_params)), "snapgpu_enable_paired")
 
     def _after_replica(self):               # (a replica starts as a single-end context)
+        self._check(self.lib.snapgpu_enable_paired(self.handle, C.byref(self.paired_params)), "snapgpu_enable_paired")
+
+    def _after_built(self, paired_params):
+        from .abi import PairedParams, default_paired_params
+        self.paired_params = paired_params if paired_params is not None else default_paired_params()
+        self.lib.snapgpu_enable_paired.argtypes = [C.c_void_p, C.POINTER(PairedParams)]
+        self.lib.snapgpu_align_paired_device.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
         self._check(self.lib.snapgpu_enable_paired(self.handle, C.byref(self.paired_params)), "snapgpu_enable_paired")
 
     def align(self, bases: np.ndarray, quals: np.ndarray, offsets: np.ndarray):

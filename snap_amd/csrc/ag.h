@@ -43,6 +43,15 @@ struct AGResult {
 static __host__ __device__ __forceinline__ uint32_t ag_row_cells(uint32_t RL) { return ((RL + 7) / 8) * 8 + 512; }
 // LDS: H, H-1, E rows of int16
 static __host__ __device__ __forceinline__ uint32_t ag_lds_bytes(uint32_t RL) { return 3 * ag_row_cells(RL) * 2; }
+// The register forms (AGC chunks of 64 striped positions, ag_reg.h / ag_win.h) keep their rows in VGPRs; their LDS is tables only: the
+// windowed form's first-row values (2 B), pattern codes (1 B) per striped position and the text's codes, or the register form's stripe-end
+// table, vector tags (4 B per vector) and text codes -- well under a quarter of the three int16 rows of the LDS form.
+static __host__ __device__ __forceinline__ uint32_t ag_lds_bytes_reg(uint32_t RL, uint32_t agc) {
+    const uint32_t tot = 64 * agc, text = RL + 128;
+    const uint32_t win = 16 + 2 * tot + ((tot + 15) & ~15u) + text;            // ag_banded_win: fr16, pcode, tcode
+    const uint32_t reg = 64 + 4 * (tot / 8 + 8) + text;                        // ag_compute_reg: lds_end, lds_flag[num_vec], tcode
+    return ((win > reg ? win : reg) + 63) & ~63u;
+}
 // HBM scratch: one byte per cell, (RL + MAX_K) rows
 static __host__ __device__ __forceinline__ size_t ag_scratch_bytes(uint32_t RL) {
     return (size_t)(RL + 128) * ag_row_cells(RL);

@@ -55,6 +55,10 @@ struct AlignCfg {
     // BaseAligner::alignAffineGap whatever useAffineGap says (ChimericPairedEndAligner.cpp:330-360: the _ASSERT(useAffineGap) there is
     // compiled out of a release build).
     uint32_t ag_buffers;
+    // LDS bytes per wave for the affine-gap code: ag_lds_bytes(RL) where a kernel of this context can run the LDS form (AGC == 0: reads
+    // beyond the register variants, and the exact replay behind the 256- / 384-position variants), ag_lds_bytes_reg(RL, 3) where only the
+    // 192-position register forms run; 0 without affine-gap buffers.
+    uint32_t ag_lds;
 };
 
 struct __attribute__((aligned(16))) Elem {   // HashTableElement, BaseAligner.h:223-258

@@ -30,6 +30,12 @@ struct AlignArgs {
     uint8_t *persist; uint64_t persist_stride;
     // heavy-first dequeue (order.h): work item i of the MAIN pass is read order[i] (a permutation of 0 .. n_reads); NULL = batch order
     const uint32_t *order;
+    // TIMED instantiation only (SNAPGPU_PHASE_TIMERS=1; NULL otherwise): launch diagnostics, snapgpu_debug_launch_profile
+    //   [0, 64)                       reads by floor(log2(wave cycles spent on the read))
+    //   [64, 64 + S)                  clock when wave slot s took its first read      (S = wave slots of the launch)
+    //   [64 + S, 64 + 2S)             clock when wave slot s ran out of reads
+    //   [64 + 2S, 64 + 3S)            cycles of the slot's most expensive read << 24 | its affine-gap calls (capped)
+    unsigned long long *dbg; uint32_t dbg_slots;
 };
 
 extern "C" {
@@ -48,7 +54,8 @@ static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { re
 struct LdsLayout {
     uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, ag, shared, total;
 };
-static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uint32_t num_weight_lists, uint32_t kmax, uint32_t use_ag) {
+// ag_lds: bytes of LDS the affine-gap code of the kernel variant needs (AlignCfg::ag_lds; 0 = no affine-gap buffers)
+static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uint32_t num_weight_lists, uint32_t kmax, uint32_t ag_lds) {
     LdsLayout L; uint32_t o = 0;
     L.rd0 = o; o += RL; L.rd1 = o; o += RL; L.ql0 = o; o += RL; L.ql1 = o; o += RL;
     L.gw = o; o += (RL + 2 * WIN_PAD + 15) & ~15u;
@@ -56,7 +63,7 @@ static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uin
     L.wl_next = o; o += (num_weight_lists * 2 + 15) & ~15u;
     L.wl_prev = o; o += (num_weight_lists * 2 + 15) & ~15u;
     L.lv = o; o += (lv_lds_bytes(kmax, RL) + 15) & ~15u;
-    L.ag = o; if (use_ag) o += (ag_lds_bytes(RL) + 15) & ~15u;
+    L.ag = o; o += (ag_lds + 15) & ~15u;
     L.shared = o; o += ((uint32_t)sizeof(WaveShared) + 15) & ~15u;
     L.total = o;
     return L;

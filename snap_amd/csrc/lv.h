@@ -53,13 +53,22 @@ static __host__ __device__ __forceinline__ uint32_t lv_lds_bytes(uint32_t kmax, 
 // cell = ((L + 2) << 2) | action ; unset cells read as L = -2
 static __device__ __forceinline__ uint16_t lv_pack(int L, int act) { return (uint16_t)(((L + 2) << 2) | act); }
 
-template <typename PSeq, typename TSeq, typename QSeq>
+// Where the level triangle, the backtrace words and the mismatch bitmaps live: LDS (the normal case) or, TRI_LDS = false, a per-wave buffer
+// in HBM -- the paired-end kernel keeps an LDS triangle for limits up to AlignCfg::kmax only and sends the rare call with a larger limit
+// (indel-hinted candidates, up to 48 / 60: SURVEY.md 8 preamble) there, so that its LDS footprint allows 4 waves per SIMD.
+template <bool TRI_LDS> struct LvMem;
+template <> struct LvMem<true>  { typedef LDS_AS uint16_t U16; typedef LDS_AS uint32_t U32; typedef LDS_AS unsigned long long U64; typedef LDS_AS uint8_t U8; };
+template <> struct LvMem<false> { typedef uint16_t U16; typedef uint32_t U32; typedef unsigned long long U64; typedef uint8_t U8; };
+
+template <bool TRI_LDS = true, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ LVResult lv_compute_inl(
     const PSeq &P, const QSeq &Q, int pattern_len, const TSeq &T, int text_len, int k,
     uint16_t *lds_tri_generic, uint32_t kmax, const DevTables *tab, uint32_t pcap)
 {
+    typedef typename LvMem<TRI_LDS>::U16 M16; typedef typename LvMem<TRI_LDS>::U32 M32; typedef typename LvMem<TRI_LDS>::U64 M64;
+    typedef typename LvMem<TRI_LDS>::U8 M8;
     const int lane = lane_id();
-    LDS_AS uint16_t *lds_tri = (LDS_AS uint16_t *)lds_tri_generic;
+    M16 *lds_tri = (M16 *)lds_tri_generic;
     LVResult res;
     res.score = -1; res.match_probability = 0.0; res.net_indel = 0; res.total_indels = 0; res.text_span = 0;
     if (k < 0) return res;                                  // LandauVishkin.h:117
@@ -67,11 +76,11 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
     if (k > (int)kmax) k = (int)kmax;
     res.match_probability = 1.0;
 
-    LDS_AS uint32_t *bt = (LDS_AS uint32_t *)((LDS_AS uint8_t *)lds_tri + (((kmax + 1) * (kmax + 1) * 2 + 3) & ~3u));
+    M32 *bt = (M32 *)((M8 *)lds_tri + (((kmax + 1) * (kmax + 1) * 2 + 3) & ~3u));
     // Mismatch bitmaps, one per diagonal (row = visiting rank), built as a level first needs the diagonal: bit i is set when
     // pattern[i] != text[d+i] or i is past the end of the comparison, so "extend a run from x" is a count-trailing-zeros
     // instead of a byte loop (the reference's countPerfectMatch compares 8 bytes at a time for the same reason, :377-407).
-    LDS_AS unsigned long long *mask = (LDS_AS unsigned long long *)((LDS_AS uint8_t *)lds_tri + lv_tri_bytes(kmax));
+    M64 *mask = (M64 *)((M8 *)lds_tri + lv_tri_bytes(kmax));
     const int nw = (int)lv_mask_words(pcap);
     const int nwu = (pattern_len + 63) >> 6;                // words that can hold a compared position
     auto build_mask = [&](int r) {
@@ -111,8 +120,8 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
     int last_best_rank = -1;
     int e;
     for (e = 1; e <= k; e++) {
-        const LDS_AS uint16_t *prev_row = lds_tri + (e - 1) * (e - 1);
-        LDS_AS uint16_t *row = lds_tri + e * e;
+        const M16 *prev_row = lds_tri + (e - 1) * (e - 1);
+        M16 *row = lds_tri + e * e;
         int x_rank = 1 << 30, any_rank = 1 << 30;
         if (e == 1) build_mask(0);
         build_mask(2 * e - 1);
@@ -132,7 +141,7 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
                 int Lr = (adr <= e - 1) ? ((int)(prev_row[lv_rank(dr)] >> 2) - 2) : -2;
                 int tl = text_len - d;
                 const int end = pattern_len < tl ? pattern_len : tl;
-                const LDS_AS unsigned long long *m = mask + r * nw;
+                const M64 *m = mask + r * nw;
                 // position of the first mismatch at or after x on this diagonal (x itself when it cannot start a run)
                 auto extend = [&](int x) -> int {
                     if (x < 0 || x >= end) return x;
@@ -228,7 +237,7 @@ static __device__ __forceinline__ ByteSeq seq_uniform(const ByteSeq &s) {
 }
 template <class S> static __device__ __forceinline__ S seq_uniform(const S &s) { return s; }
 
-template <typename PSeq, typename TSeq, typename QSeq>
+template <bool TRI_LDS, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __attribute__((noinline)) LVResult lv_compute_fn(
     PSeq P_in, QSeq Q_in, int pattern_len, TSeq T_in, int text_len, int k,
     uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap)
@@ -238,17 +247,17 @@ static __device__ __attribute__((noinline)) LVResult lv_compute_fn(
     lds_tri = (uint16_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)lds_tri);
     kmax = first_u32(kmax); pcap = first_u32(pcap);
     tab = (const DevTables *)(uintptr_t)first_u64((uint64_t)(uintptr_t)tab);
-    return lv_compute_inl(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
+    return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
 }
 
-template <typename PSeq, typename TSeq, typename QSeq>
+template <bool TRI_LDS = true, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ LVResult lv_compute(
     const PSeq &P, const QSeq &Q, int pattern_len, const TSeq &T, int text_len, int k,
     uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap)
 {
 #if !defined(SNAPGPU_AG_LV_FUNCTIONS)
-    return lv_compute_inl(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
+    return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
 #else
-    return lv_compute_fn<PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
+    return lv_compute_fn<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
 #endif
 }

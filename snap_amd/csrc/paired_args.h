@@ -5,6 +5,13 @@
 #include "kernel_common.h"
 #include "paired.h"
 
+// waves per SIMD k_align_paired is compiled for (its __launch_bounds__) and the host sizes its grid for.  The 192-position variant (reads
+// up to ~170 bp): 4 = 128 VGPRs, under 10 KB of LDS per wave.  The variants that keep 4 / 6 chunks of affine-gap state in registers and
+// the LDS form (longer reads) stay at 2: their LDS footprint would not let more waves in anyway.
+#ifndef SNAPGPU_PAIRED_WAVES_PER_SIMD
+#define SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 4 : 2)
+#endif
+
 struct PairedLds { uint32_t single_total, rd, ql, lk, exhausted, miss, hs, list_head, seed_used, sh, total; };
 static __host__ __device__ __forceinline__ PairedLds paired_lds_layout(uint32_t single_total, uint32_t RL, uint32_t max_seeds) {
     PairedLds L; uint32_t o = (single_total + 15) & ~15u;
@@ -45,6 +52,7 @@ struct PairedArgs {
     uint8_t *scratch;                  // n_wave_slots * stride
     uint64_t stride;
     uint64_t off_single_agc, off_cand, off_mate0, off_mate1, off_anchor, off_agc, off_agc_order;   // offsets inside a wave's slab (single-end scratch first)
+    uint64_t off_lv_big;               // Landau-Vishkin working set for limits beyond the LDS triangle (paired_dev.h: DevPL::lv_big)
     uint32_t single_agc_cap;
     const uint8_t *bases, *quals;
     const uint64_t *offsets;           // [2n+1]

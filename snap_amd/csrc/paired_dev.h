@@ -182,7 +182,8 @@ struct DevPL {
     }
     const DevTables *tab;
     AGParams agp;
-    uint32_t kmax_lv;                  // what the LV triangle was sized for
+    uint32_t kmax_lv;                  // the largest limit a paired-end LV call can have: what lv_big is sized for (the LDS triangle: al->cfg.kmax)
+    uint16_t *lv_big;                  // per-wave HBM buffer of lv_lds_bytes(kmax_lv, RL) bytes for the calls whose limit exceeds the LDS triangle
     const uint8_t *g_bases[2], *g_quals[2];   // the pair's reads in global memory (for the single-end fallback)
     int g_len[2];
     WaveShared *ws;
@@ -365,7 +366,9 @@ struct DevPL {
 
     __device__ __forceinline__ LVOut lv(int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int k) {
         ByteSeq Ps{P, st}, Qs{Q, st}, Ts{T, st};
-        LVResult r = lv_compute(Ps, Qs, plen, Ts, tlen, k, al->lv_tri, kmax_lv, tab, al->cfg.RL);
+        // the LDS triangle serves limits up to cfg.kmax; a larger one (indel-hinted candidates only) works in the wave's HBM buffer
+        LVResult r = k <= (int)al->cfg.kmax ? lv_compute(Ps, Qs, plen, Ts, tlen, k, al->lv_tri, al->cfg.kmax, tab, al->cfg.RL)
+                                            : lv_compute<false>(Ps, Qs, plen, Ts, tlen, k, lv_big, kmax_lv, tab, al->cfg.RL);
         LVOut o;
         o.score = i32(r.score); o.mp = f64(r.match_probability); o.net_indel = i32(r.net_indel);
         o.total_indels = i32(r.total_indels); o.text_span = i32(r.text_span);
@@ -395,7 +398,7 @@ struct DevPL {
     // running bases in LDS (the LV triangle is idle here), entries scattered 64 at a time in index order.
     __device__ __forceinline__ void sort_candidates(const snapgpu_paired_result *c, uint32_t n, uint32_t *order) {
         const int lane = lane_id();
-        uint32_t *base = (uint32_t *)al->lv_tri;                     // >= (kmax+1)^2 * 2 bytes >= 2 KB for kmax >= 31; 512 counters needed
+        uint32_t *base = (uint32_t *)al->lv_tri;                     // the LV block of LDS: lv_lds_bytes(kmax >= 22, RL) >= 2 232 bytes; 512 counters needed
         uint32_t *hist = base;
         for (int k = lane; k < 512; k += WAVE) hist[k] = 0;
         WAVE_SYNC();
@@ -475,16 +478,17 @@ struct DevPL {
     }
 };
 
-// Scalar-heavy, latency-bound control flow: 2 waves per SIMD keeps 256 VGPRs available (no spills) and is what the LDS
-// footprint allows anyway.
+// Scalar-heavy, latency-bound control flow.  Rounds 1-2 ran it at 2 waves per SIMD (256 VGPRs, ~18 KB of LDS per wave); round 3 shrank
+// the LDS footprint to under 10 KB (Landau-Vishkin triangle for limits <= 22 only, the register affine-gap forms' tables instead of the
+// LDS form's rows) so that 4 waves per SIMD fit: SNAPGPU_PAIRED_WAVES_PER_SIMD (paired_args.h).
 template <int AGC, bool SEC, bool EXACT = false>
-__global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
+__global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_align_paired(PairedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id();
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
-    const LdsLayout SL = lds_layout(a.scfg.RL, a.scfg.num_weight_lists, a.scfg.kmax, a.scfg.ag_buffers);
+    const LdsLayout SL = lds_layout(a.scfg.RL, a.scfg.num_weight_lists, a.scfg.kmax, a.scfg.ag_lds);
     const PairedLds PLd = paired_lds_layout(SL.total, a.scfg.RL, a.pcfg.max_seeds);
     uint8_t *my = lds + (size_t)wave_in_block * PLd.total;
     uint8_t *sc = a.scratch + (size_t)wave_slot * a.stride;
@@ -515,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void k_align_paired(PairedArgs a)
         al.n_sec = 0; al.n_sec_raw = 0; al.sec_overflow = 0;
     }
     DevPL<AGC, SEC, EXACT> pl;
-    pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv;
+    pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv; pl.lv_big = (uint16_t *)(sc + a.off_lv_big);
     al.ag_persist0 = al.ag_persist1 = pl.ag_persist0 = pl.ag_persist1 = nullptr;
     al.ag_hw0 = al.ag_hw1 = pl.ag_hw0 = pl.ag_hw1 = 0;
     pl.help = EXACT ? nullptr : a.help; pl.n_help = a.n_help; pl.help_spec = a.help_spec; pl.help_spec_cap = a.help_spec_cap;

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     const int lane = lane_id();
     const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // uniform: keeps the LDS/scratch pointers in SGPRs
     const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
-    const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax, a.cfg.ag_buffers);
+    const LdsLayout L = lds_layout(a.cfg.RL, a.cfg.num_weight_lists, a.cfg.kmax, a.cfg.ag_lds);
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
     WaveShared *ws = (WaveShared *)(my + L.shared);
@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     // EXACT kernels run either over a list of flagged reads (remap: the replay pass behind the register variants for long reads) or, as
     // the main pass of the 192-position variant, over the whole batch
     const uint32_t n_total = a.remap ? first_u32(*a.n_remap) : a.n_reads;
+    unsigned long long dbg_worst = 0;
+    if constexpr (TIMED) { if (a.dbg && lane == 0 && wave_slot < a.dbg_slots) a.dbg[64 + wave_slot] = wave_clock(); }
     while (true) {
         uint32_t i = 0;
         if (lane == 0) i = atomicAdd(a.work_counter, 1u);
@@ -67,8 +69,17 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
             WAVE_SYNC();
         }
         uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
+        const uint64_t dbg_t0 = TIMED ? wave_clock() : 0; const uint64_t dbg_ag0 = al.cnt.ag;
         al.align_read(a.bases + b, a.quals + b, (int)(e - b));
         WAVE_SYNC();
+        if constexpr (TIMED) {
+            if (a.dbg) {
+                const unsigned long long cyc = wave_clock() - dbg_t0, nag = al.cnt.ag - dbg_ag0;
+                if (lane == 0) atomicAdd(&a.dbg[63 - __clzll((long long)(cyc | 1ull))], 1ull);
+                const unsigned long long packed = (cyc << 24) | (nag > 0xffffffull ? 0xffffffull : nag);
+                if (packed > dbg_worst) dbg_worst = packed;
+            }
+        }
         if constexpr (!EXACT) {         // traceback left the band somewhere: the exact pass redoes this read
             if (a.flag_list && (ws->primary.reserved & 0x40000000u) && lane == 0) a.flag_list[atomicAdd(a.flag_count, 1u)] = i;
         }
@@ -103,6 +114,9 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
             WAVE_SYNC();
         }
         n_done++;
+    }
+    if constexpr (TIMED) {
+        if (a.dbg && lane == 0 && wave_slot < a.dbg_slots) { a.dbg[64 + a.dbg_slots + wave_slot] = wave_clock(); a.dbg[64 + 2 * a.dbg_slots + wave_slot] = dbg_worst; }
     }
     if constexpr (EXACT) {              // leave the images zeroed for the next launch (the high-water marks live in registers)
         if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);

@@ -22,6 +22,7 @@
 #include "kernel_common.h"
 #include "single_kernel.h"
 #include "order.h"
+#include "lookup16.h"
 #include "paired_args.h"
 #include "cigar_lv.h"
 #include "cigar_ag.h"
@@ -274,6 +275,7 @@ struct snapgpu_ctx {
     bool single_heavy_first = true;
     bool phase_timers = false;        // SNAPGPU_PHASE_TIMERS=1: launch the instantiation that carries the s_memtime phase timers
     uint32_t *d_order = nullptr, *d_wbucket = nullptr, *d_whist = nullptr; size_t order_cap = 0;
+    unsigned long long *d_dbg = nullptr;          // phase_timers: launch diagnostics of the last single-end launch (kernel_common.h: AlignArgs::dbg)
     bool paired_sec = false;
     PairedArgs pargs_sec{}, pargs_sec_big{};
     uint8_t *d_pscratch_sec = nullptr, *d_pscratch_sec_big = nullptr;
@@ -429,6 +431,7 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_pexact_persist) (void)hipFree(ctx->d_pexact_persist);
     if (ctx->d_help) (void)hipFree(ctx->d_help);
     if (ctx->d_help_spec) (void)hipFree(ctx->d_help_spec);
+    if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
     if (ctx->d_whist) (void)hipFree(ctx->d_whist);
@@ -634,7 +637,8 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     }
     size_t ag_bytes = c.ag_buffers ? ag_scratch_bytes(c.RL) : 0;
     c.scratch_stride = ((size_t)c.ht_size * 2 + (size_t)c.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
-    LdsLayout L = lds_layout(c.RL, c.num_weight_lists, c.kmax, c.ag_buffers);
+    c.ag_lds = !c.ag_buffers ? 0u : (ctx->ag_variant == 3 ? ag_lds_bytes_reg(c.RL, 3) : ag_lds_bytes(c.RL));
+    LdsLayout L = lds_layout(c.RL, c.num_weight_lists, c.kmax, c.ag_lds);
     c.lds_per_wave = L.total;
 
     // waves in flight: a fixed number per CU, each with its own scratch slab
@@ -901,6 +905,22 @@ extern "C" int snapgpu_index_device_ptrs(snapgpu_ctx *ctx, void **hash_blob, voi
     return SNAPGPU_OK;
 }
 
+// the index-probe kernel: sixteen probes per wave pass (lookup16.h) for the shape the north star uses, k_lookup_seeds for every other
+static void launch_lookup(snapgpu_ctx *ctx, uint32_t n, const void *d_seeds, void *d_n_hits, void *d_hits, uint32_t max_hits_out,
+                          unsigned long long *d_counters, hipStream_t s)
+{
+    const uint32_t maxb = (uint32_t)ctx->num_cus * 8;                                   // 32 waves per CU
+    if (ctx->ix.bucket_blob && ctx->ix.seed_len == 20 && ctx->ix.key_bytes == 4 && ((uintptr_t)d_seeds & 3) == 0 && !getenv("SNAPGPU_LOOKUP8")) {
+        uint32_t blocks = (n + 31) / 32; if (blocks > maxb) blocks = maxb;
+        hipLaunchKernelGGL(k_lookup_seeds20, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
+                           (uint32_t *)d_hits, max_hits_out, d_counters);
+    } else {
+        uint32_t blocks = (n + 3) / 4; if (blocks > maxb) blocks = maxb;
+        hipLaunchKernelGGL(k_lookup_seeds, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
+                           (uint32_t *)d_hits, max_hits_out, d_counters);
+    }
+}
+
 extern "C" int snapgpu_lookup_seeds(snapgpu_ctx *ctx, uint32_t n, const char *seeds, int64_t *n_hits,
                                     uint32_t *hits, uint32_t max_hits_out)
 {
@@ -912,10 +932,7 @@ extern "C" int snapgpu_lookup_seeds(snapgpu_ctx *ctx, uint32_t n, const char *se
     if ((rc = ensure_stage(ctx, 0, sb)) || (rc = ensure_stage(ctx, 1, nb)) || (rc = ensure_stage(ctx, 2, hb))) return rc;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_stage[0], seeds, sb, hipMemcpyHostToDevice, ctx->stream), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemsetAsync(ctx->d_stage[2], 0, hb, ctx->stream), SNAPGPU_E_LAUNCH);
-    uint32_t blocks = (n + 3) / 4; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;
-    hipLaunchKernelGGL(k_lookup_seeds, dim3(blocks), dim3(256), 0, ctx->stream, ctx->ix, n,
-                       (const uint8_t *)ctx->d_stage[0], (long long *)ctx->d_stage[1], (uint32_t *)ctx->d_stage[2], max_hits_out,
-                       (unsigned long long *)nullptr);
+    launch_lookup(ctx, n, ctx->d_stage[0], ctx->d_stage[1], ctx->d_stage[2], max_hits_out, nullptr, ctx->stream);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(n_hits, ctx->d_stage[1], nb, hipMemcpyDeviceToHost, ctx->stream), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(hits, ctx->d_stage[2], hb, hipMemcpyDeviceToHost, ctx->stream), SNAPGPU_E_LAUNCH);
@@ -934,10 +951,8 @@ extern "C" int snapgpu_lookup_seeds_device(snapgpu_ctx *ctx, uint32_t n, const v
     if (n == 0) return SNAPGPU_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    uint32_t blocks = (n + 3) / 4; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;      // 32 waves per CU
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
-    hipLaunchKernelGGL(k_lookup_seeds, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
-                       (uint32_t *)d_hits, max_hits_out, ctx->d_counters);
+    launch_lookup(ctx, n, d_seeds, d_n_hits, d_hits, max_hits_out, ctx->d_counters, s);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
     if (!stream) return finish_timing(ctx);
@@ -1459,7 +1474,13 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.sec_cfg = SecCfg{-1, -1, 0, 0}; a.sec_scratch = nullptr; a.sec_stride_bytes = 0; a.secondary = nullptr; a.sec_out_stride = 0; a.n_secondary = nullptr;
     a.flag_list = nullptr; a.flag_count = nullptr; a.remap = nullptr; a.n_remap = nullptr; a.persist = nullptr; a.persist_stride = 0;
-    a.is_replay = 0; a.order = nullptr;
+    a.is_replay = 0; a.order = nullptr; a.dbg = nullptr; a.dbg_slots = 0;
+    if (ctx->phase_timers) {
+        const size_t words = 64 + 3 * (size_t)ctx->n_wave_slots;
+        if (!ctx->d_dbg) HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg, words * 8), SNAPGPU_E_NOMEM);
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg, 0, words * 8, s), SNAPGPU_E_LAUNCH);
+        a.dbg = ctx->d_dbg; a.dbg_slots = ctx->n_wave_slots;
+    }
     const bool always_exact = ctx->always_exact && ctx->d_exact_persist != nullptr;
     const bool exact = !always_exact && ctx->d_exact_persist != nullptr && !getenv("SNAPGPU_NO_EXACT_REPLAY");
     if (exact) {
@@ -1695,6 +1716,7 @@ static void paired_lay_out(PairedArgs &x, bool sec) {
     x.off_anchor = off; off += up((size_t)x.pcfg.pool_size * sizeof(PEAnchor));
     x.off_agc = off;    off += up((size_t)(x.pcfg.ag_cand_cap + 1) * sizeof(snapgpu_paired_result));
     x.off_agc_order = off; off += up((size_t)(x.pcfg.ag_cand_cap + 1) * 4);
+    x.off_lv_big = off; off += up((size_t)lv_lds_bytes(x.kmax_lv, sc.RL) + 64);
     if (sec) {
         x.off_sec = off;     off += up((size_t)(x.pcfg.sec_cap + 1) * sizeof(snapgpu_paired_result));
         x.off_sec_ord = off; off += up((size_t)(x.pcfg.sec_cap + 1) * 4);
@@ -1777,8 +1799,14 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     // LV limits: computeScoreLimit <= min(126, extraSearchDepth + maxK + maxKForIndels - 1) (IntersectingPairedEndAligner.cpp:3975-3988)
     uint32_t kmax_lv = p.max_k + p.extra_search_depth + (pp->max_k_for_indels ? pp->max_k_for_indels - 1 : 0);
     if (kmax_lv > 126) kmax_lv = 126;
-    if (kmax_lv < 31) kmax_lv = 31;                              // the LV triangle doubles as 2 KB of counters for the Phase-4 counting sort
-    sc.kmax = kmax_lv;
+    // The LDS triangle serves limits up to sc.kmax; the calls beyond that (indel-hinted candidates only) use a per-wave HBM buffer
+    // (paired_dev.h: DevPL::lv).  22 = the smallest kmax whose LDS block (2 232 bytes) also holds the 512 counters of the Phase-4 counting
+    // sort; a limit the single-end aligner of the fallback can reach (max_k + extra_search_depth) always stays in LDS.
+    uint32_t kmax_lds = p.max_k + p.extra_search_depth; if (kmax_lds < 22) kmax_lds = 22;
+    if (kmax_lds > kmax_lv) kmax_lds = kmax_lv;
+    if (kmax_lv < 22) kmax_lv = kmax_lds = 22;
+    if (const char *e = getenv("SNAPGPU_PAIRED_LV_LDS_KMAX")) { uint32_t v = (uint32_t)atoi(e); if (v >= 22 && v <= kmax_lv) kmax_lds = v; }
+    sc.kmax = kmax_lds;
     a.kmax_lv = kmax_lv;
     sc.ag_buffers = (sc.use_ag || (pp->use_soft_clipping && pp->enable_hamming_scoring_base_aligner)) ? 1u : 0u;
     a.scfg = sc;
@@ -1823,6 +1851,8 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         ctx->p_ag_variant = need <= 192 ? 3 : need <= 256 ? 4 : need <= 384 ? 6 : 0;
         if (getenv("SNAPGPU_AG_LDS")) ctx->p_ag_variant = 0;
     }
+    a.scfg.ag_lds = !sc.ag_buffers ? 0u : (ctx->p_ag_variant == 3 ? ag_lds_bytes_reg(sc.RL, 3) : ag_lds_bytes(sc.RL));
+    sc.ag_lds = a.scfg.ag_lds;
 
     paired_lay_out(a, false);
     // The reference doubles its affine-gap candidate buffers when they overflow and aligns the pair again
@@ -1834,11 +1864,11 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     big.single_agc_cap = a.single_agc_cap * 32;
     paired_lay_out(big, false);
 
-    LdsLayout SL = lds_layout(sc.RL, sc.num_weight_lists, sc.kmax, sc.ag_buffers);
+    LdsLayout SL = lds_layout(sc.RL, sc.num_weight_lists, sc.kmax, sc.ag_lds);
     PairedLds PL = paired_lds_layout(SL.total, sc.RL, c.max_seeds);
     ctx->p_lds_per_wave = PL.total;
     if ((size_t)4 * PL.total > 160 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "per-pair LDS state exceeds 40 KiB per wave");
-    int waves_per_cu = 8;
+    int waves_per_cu = 4 * SNAPGPU_PAIRED_WAVES_PER_SIMD(ctx->p_ag_variant);           // (paired_args.h: what k_align_paired is compiled for)
     if (const char *e = getenv("SNAPGPU_PAIRED_WAVES_PER_CU")) { int v = atoi(e); if (v >= 4 && v <= 16) waves_per_cu = v & ~3; }
     while (waves_per_cu > 4 && (size_t)waves_per_cu * PL.total > 160 * 1024) waves_per_cu -= 4;
     size_t free_b = 0, total_b = 0;
@@ -2130,6 +2160,19 @@ extern "C" int snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->d_counters, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream), SNAPGPU_E_LAUNCH);
     if (reset) HIPCHK(ctx, hipMemsetAsync(ctx->d_counters, 0, sizeof(*out), ctx->stream), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
+// Diagnostics of the last single-end launch of a context created under SNAPGPU_PHASE_TIMERS=1 (not part of the drop-in surface):
+// out[0 .. 64): reads by floor(log2(wave cycles)); then per wave slot: first-read clock, out-of-reads clock, (worst read's cycles << 24 | its
+// affine-gap calls).  n_words = 64 + 3 * *n_slots.  Returns SNAPGPU_E_INVALID when the context has no such data.
+extern "C" int snapgpu_debug_launch_profile(snapgpu_ctx *ctx, uint64_t *out, uint64_t cap_words, uint32_t *n_slots) {
+    if (!ctx || !out || !n_slots || !ctx->d_dbg) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_debug_launch_profile: no profile (SNAPGPU_PHASE_TIMERS=1 at snapgpu_create)");
+    const size_t words = 64 + 3 * (size_t)ctx->n_wave_slots;
+    if (cap_words < words) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_debug_launch_profile: buffer too small");
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    HIPCHK(ctx, hipMemcpy(out, ctx->d_dbg, words * 8, hipMemcpyDeviceToHost), SNAPGPU_E_NODEVICE);
+    *n_slots = ctx->n_wave_slots;
     return SNAPGPU_OK;
 }
 

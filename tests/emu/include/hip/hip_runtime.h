@@ -110,6 +110,7 @@ static inline unsigned atomicCAS(unsigned *p, unsigned expect, unsigned v) { __a
 static inline unsigned long long atomicCAS(unsigned long long *p, unsigned long long expect, unsigned long long v) { __atomic_compare_exchange_n(p, &expect, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); return expect; }
 #include <sched.h>
 struct uint2 { uint32_t x, y; };
+struct alignas(16) uint4 { uint32_t x, y, z, w; };
 static inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return (unsigned long long)(((unsigned __int128)a * b) >> 64); }
 static inline void emu_yield() { sched_yield(); }
 

@@ -57,6 +57,7 @@ def test_emu_tables_and_seed_lookup(emu_aligner, golden_primitives):
     import tests.test_gpu_parity as gp
     gp.test_tables_match_restatement(emu_aligner)
     gp.test_lookup_seeds_vs_reference_fixture(emu_aligner, golden_primitives)
+    gp.test_lookup_kernels_agree_counts_only_and_odd_batch_sizes(emu_aligner, golden_primitives)
 
 
 def test_emu_landau_vishkin(emu_aligner, golden_primitives):

@@ -58,6 +58,48 @@ def test_lookup_seeds_vs_reference_fixture(aligner, golden_primitives):
     assert (hits == z["seed_hits"]).all()
 
 
+def test_lookup_kernels_agree_counts_only_and_odd_batch_sizes(aligner, golden_primitives):
+    """The stand-alone probe kernel (lookup16.h: sixteen probes per wave pass) in its counts-only form (hit lists read, not stored) and
+    with batch sizes that leave the last pass partly empty, against the fixture; SNAPGPU_LOOKUP8 selects the eight-probe kernel, which
+    must give the same bytes."""
+    import os
+    z = golden_primitives
+    seeds = np.ascontiguousarray(z["seeds"], dtype=np.uint8)
+    exp_nh, exp_hits = z["seed_n_hits"], z["seed_hits"]
+    for n in (1, 7, 8, 9, 33, seeds.shape[0]):
+        nh, hits = aligner.lookupSeed32(seeds[:n], exp_hits.shape[2])
+        assert (nh == exp_nh[:n]).all() and (hits == exp_hits[:n]).all(), n
+    os.environ["SNAPGPU_LOOKUP8"] = "1"
+    try:
+        nh8, hits8 = aligner.lookupSeed32(seeds, exp_hits.shape[2])
+    finally:
+        del os.environ["SNAPGPU_LOOKUP8"]
+    assert (nh8 == exp_nh).all() and (hits8 == exp_hits).all()
+    # counts only, through the device-pointer entry (torch on hardware; under the emulator host memory is device memory)
+    n = seeds.shape[0]
+    try:
+        import torch
+        on_gpu = torch.cuda.is_available() and not os.environ.get("SNAPGPU_TEST_LIB") and "emu" not in str(getattr(aligner.lib, "_name", ""))
+    except Exception:
+        on_gpu = False
+    aligner.counters(reset=True)
+    if on_gpu:
+        d_seeds = torch.from_numpy(seeds.reshape(-1)).cuda()
+        d_nh = torch.zeros(2 * n, dtype=torch.int64, device="cuda")
+        aligner.lookup_device(n, d_seeds.data_ptr(), d_nh.data_ptr(), 0, 300)
+        got = d_nh.cpu().numpy().reshape(n, 2)
+    else:
+        flat = np.ascontiguousarray(seeds.reshape(-1))
+        got = np.zeros((n, 2), dtype=np.int64)
+        aligner.lookup_device(n, flat.ctypes.data, got.ctypes.data, 0, 300)
+    assert (got == exp_nh).all()
+    c = aligner.counters(reset=True)
+    valid = exp_nh[:, 0] >= 0
+    assert c["n_hash_table_lookups"] == int(valid.sum())
+    assert c["n_hits_consumed"] == int(np.minimum(np.maximum(exp_nh[valid], 0), 300).sum())
+    assert c["n_overflow_lists"] == int((exp_nh[valid] > 1).sum())
+
+
 def test_lv_known_answers_and_fixture(aligner, golden_primitives):
     texts = [c["text"].encode() for c in KATS["lv"]]
     pats = [c["pattern"].encode() for c in KATS["lv"]]
