@@ -39,7 +39,14 @@
 
 #include "../../../include/snapgpu.h"
 
-static void die(const char *msg, const char *arg = "") { fprintf(stderr, "snapgpu-sam: %s%s\n", msg, arg); exit(1); }
+// The output is written to "<out>.partial" and renamed when it is complete, so that a run that stops half way (an input error, one of the
+// unsupported paired -om corners below) never leaves a truncated SAM -- or a BAM without its end-of-file block -- under the name asked for.
+static std::string g_partial_path;
+static void die(const char *msg, const char *arg = "") {
+    fprintf(stderr, "snapgpu-sam: %s%s\n", msg, arg);
+    if (!g_partial_path.empty()) remove(g_partial_path.c_str());
+    exit(1);
+}
 
 struct Contig { std::string name; uint64_t begin; bool is_alt; int orig; };
 
@@ -954,8 +961,10 @@ int main(int argc, char **argv)
     }
     if (o.n_format <= 0) { unsigned hc = std::thread::hardware_concurrency(); o.n_format = (int)(hc > 16 ? 16 : (hc ? hc : 4)); }
 
-    FILE *out = fopen(out_path.c_str(), "wb");
-    if (!out) die("cannot create ", out_path.c_str());
+    const std::string partial_path = out_path + ".partial";
+    FILE *out = fopen(partial_path.c_str(), "wb");
+    if (!out) die("cannot create ", partial_path.c_str());
+    g_partial_path = partial_path;
     setvbuf(out, NULL, _IOFBF, 8u << 20);
     // header (SAM.cpp:1232-1295); @SQ lines go by ORIGINAL contig number: the index builder moves ALT contigs behind the regular ones
     // (FASTA.cpp:359-384), the header keeps the FASTA's order (getContigByOriginalContigNumber, SAM.cpp:1291)
@@ -1046,6 +1055,8 @@ int main(int argc, char **argv)
     for (auto &t : formatters) t.join();
     if (o.bam) { std::string eof; bgzf_append(eof, "", 0); if (fwrite(eof.data(), 1, eof.size(), out) != eof.size()) die("write error on ", out_path.c_str()); }     // the empty end-of-file block
     if (fclose(out) != 0) die("write error on ", out_path.c_str());
+    if (rename(partial_path.c_str(), out_path.c_str()) != 0) die("cannot rename the finished output to ", out_path.c_str());
+    g_partial_path.clear();
     for (size_t t = ctxs.size(); t-- > 0;) snapgpu_destroy(ctxs[t]);        // sharers before the owner of the blobs they share
     fprintf(stderr, "snapgpu-sam: %llu reads, %llu mapped records, %d GPU(s) x %d feeder(s), %d formatter thread(s)\n", total, mapped, o.n_gpus, o.ctx_per_gpu, o.n_format);
     return 0;

@@ -737,6 +737,7 @@ struct RcclApi {
     }
 };
 static RcclApi g_rccl;
+static std::once_flag g_rccl_once; static bool g_rccl_ok = false; static std::string g_rccl_why;      // (load() once, whatever thread gets there first)
 
 // The index of ctxs[0] into the (same-size, so far unfilled) blobs of ctxs[1 .. n): one ncclBroadcast per blob, root 0, all ranks driven
 // from this thread inside one group call (ncclCommInitAll communicators: one process, one rank per GPU).  Over xGMI a ring broadcast is
@@ -758,12 +759,17 @@ extern "C" int snapgpu_broadcast_index(snapgpu_ctx **ctxs, int n)
         for (int j = 0; j < i; j++) if (ctxs[j]->device == ctxs[i]->device) return fail(root, SNAPGPU_E_INVALID, "snapgpu_broadcast_index: two contexts on one device");
     }
     if (n == 1) return SNAPGPU_OK;
-    std::string why;
-    if (!g_rccl.load(why)) return fail(root, SNAPGPU_E_UNSUPPORTED, "snapgpu_broadcast_index: RCCL is not available (" + why + ")");
-    std::vector<int> devs((size_t)n); std::vector<ncclComm_t> comms((size_t)n, nullptr);
+    std::call_once(g_rccl_once, [] { g_rccl_ok = g_rccl.load(g_rccl_why); });
+    if (!g_rccl_ok) return fail(root, SNAPGPU_E_UNSUPPORTED, "snapgpu_broadcast_index: RCCL is not available (" + g_rccl_why + ")");
+    std::vector<int> devs((size_t)n);
+    struct Comms {                     // destroyed on every way out of this function
+        std::vector<ncclComm_t> v;
+        ~Comms() { for (auto c : v) if (c) g_rccl.CommDestroy(c); }
+    } comms_owner; comms_owner.v.assign((size_t)n, nullptr);
+    std::vector<ncclComm_t> &comms = comms_owner.v;
     for (int i = 0; i < n; i++) devs[(size_t)i] = ctxs[i]->device;
 #define NCCLCHK(call) do { ncclResult_t _r = (call); if (_r != ncclSuccess) { \
-        std::string m = std::string(#call) + ": " + g_rccl.GetErrorString(_r); for (auto c : comms) if (c) g_rccl.CommDestroy(c); return fail(root, SNAPGPU_E_LAUNCH, m); } } while (0)
+        std::string m = std::string(#call) + ": " + g_rccl.GetErrorString(_r); return fail(root, SNAPGPU_E_LAUNCH, m); } } while (0)
     NCCLCHK(g_rccl.CommInitAll(comms.data(), n, devs.data()));
     struct Blob { void *snapgpu_ctx::*p; size_t bytes; };
     const Blob blobs[3] = {{&snapgpu_ctx::d_hash, hash_bytes}, {&snapgpu_ctx::d_overflow, ovf_bytes}, {&snapgpu_ctx::d_genome_padded, gen_bytes}};
@@ -779,7 +785,7 @@ extern "C" int snapgpu_broadcast_index(snapgpu_ctx **ctxs, int n)
         HIPCHK(root, hipSetDevice(ctxs[i]->device), SNAPGPU_E_NODEVICE);
         HIPCHK(root, hipStreamSynchronize(ctxs[i]->stream), SNAPGPU_E_LAUNCH);
     }
-    for (auto c : comms) g_rccl.CommDestroy(c);
+    for (auto &c : comms) { if (c) g_rccl.CommDestroy(c); c = nullptr; }
 #undef NCCLCHK
     for (int i = 1; i < n; i++) {           // the replicas' own device-native tables, now that their slot arrays are there
         HIPCHK(root, hipSetDevice(ctxs[i]->device), SNAPGPU_E_NODEVICE);
