@@ -184,6 +184,7 @@ struct Aligner {
     uint32_t ag_obj_used0, ag_obj_used1;   // has affineGap / reverseAffineGap scored anything yet for this read (this pair, for the fallback)?
                                        // (two scalars, not an array: an index that is not a compile-time constant would pin the object in scratch)
     uint32_t max_k;                    // BaseAligner::maxK: cfg.max_k, or what setMaxK() last said (ChimericPairedEndAligner.cpp:278,301)
+    uint32_t ag_calls_unit;            // affine-gap calls since the unit (read; the paired kernel: pair) began -- see wave_set_priority
     // candidates for BaseAligner::alignAffineGap, collected by the Hamming pass only (BaseAligner.cpp:1445-1456)
     snapgpu_single_result *agc;
     uint32_t agc_cap, n_agc, agc_overflow;
@@ -720,6 +721,7 @@ struct Aligner {
                                 score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0;
                                 used_ag = 1;
                                 cnt.ag++;
+                                if (++ag_calls_unit == WAVE_PRIO_HEAVY_AFTER) wave_set_priority(1);
                                 const uint64_t t_ag0 = clk();
                                 AGParams agp{cfg.match_reward, cfg.sub_penalty, cfg.gap_open, cfg.gap_extend, cfg.five_bonus, cfg.three_bonus};
                                 for (int half = 0; half < 2; half++) {
@@ -860,7 +862,9 @@ struct Aligner {
     __device__ __forceinline__ void align_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         const uint64_t t_read0 = clk();
         ag_obj_used0 = ag_obj_used1 = 0;                                      // a newly constructed aligner for every read
+        ag_calls_unit = 0;
         align_read_inner<false>(g_bases, g_quals, len);
+        if (ag_calls_unit >= WAVE_PRIO_HEAVY_AFTER) wave_set_priority(0);
         cnt.cyc_total += clk() - t_read0;
     }
     template <bool HAM>

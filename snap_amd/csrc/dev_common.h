@@ -78,6 +78,15 @@ struct DevTables {
 // wave ballot as one compare into an SGPR pair (HIP's BALLOT() materialises the predicate in a VGPR first)
 #define BALLOT(pred) ((unsigned long long)__builtin_amdgcn_ballot_w64((bool)(pred)))
 
+// Issue priority of this wave among the waves of its SIMD (s_setprio, 0 .. 3).  A unit of work that turns out to be heavy -- a read out of
+// a diverged repeat family scored against hundreds of copies, a pair with thousands of Phase-4 candidates -- is what a launch ends on
+// (profiles/r03c: 65 of 1 M reads take 110-220 ms each while the average is 0.6 ms), and the SIMD it runs on is shared with up to five
+// other waves that are not issue-bound: raising the heavy wave's priority shortens the launch's critical path at no cost in throughput.
+#define WAVE_PRIO_HEAVY_AFTER 8        // affine-gap calls of one unit before its wave asks for priority
+static __device__ __forceinline__ void wave_set_priority(int heavy) {
+    if (heavy) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+}
+
 static __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 
 static __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src_lane = 0) {

@@ -5,11 +5,13 @@
 #include "kernel_common.h"
 #include "paired.h"
 
-// waves per SIMD k_align_paired is compiled for (its __launch_bounds__) and the host sizes its grid for.  The 192-position variant (reads
-// up to ~170 bp): 4 = 128 VGPRs, under 10 KB of LDS per wave.  The variants that keep 4 / 6 chunks of affine-gap state in registers and
-// the LDS form (longer reads) stay at 2: their LDS footprint would not let more waves in anyway.
+// waves per SIMD k_align_paired is compiled for (its __launch_bounds__) and the host sizes its grid for.  Round 3 made 4 possible for the
+// 192-position variant (LDS under 10 KB per wave: paired_dev.h) and measured it on the bench batch (profiles/r03c): at 128 VGPRs the kernel
+// spills 360 more dwords per lane and is 4 % slower with the same 8 waves per CU, 14 % slower with 16 (twice the slabs behind the same L2):
+// the paired-end kernel is bound by its scratch and slab traffic, not by latency hiding.  2 it stays; -DSNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)=...
+// rebuilds it otherwise.
 #ifndef SNAPGPU_PAIRED_WAVES_PER_SIMD
-#define SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 4 : 2)
+#define SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC) 2
 #endif
 
 struct PairedLds { uint32_t single_total, rd, ql, lk, exhausted, miss, hs, list_head, seed_used, sh, total; };

@@ -387,6 +387,7 @@ struct DevPL {
             if (ext > image) ext = image;
             if (st == 1) ag_hw0 = ext > ag_hw0 ? ext : ag_hw0; else ag_hw1 = ext > ag_hw1 ? ext : ag_hw1;
         }
+        if (++al->ag_calls_unit == WAVE_PRIO_HEAVY_AFTER * 8) wave_set_priority(1);          // (a pair: both mates, both halves, Phases 3 and 4)
         AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, Ps, Qs, plen, Ts, tlen, lim, read_len, is_rc, use_clip, al->ag_rows,
                                              EXACT ? (st == 1 ? ag_persist0 : ag_persist1) : al->ag_scratch, al->cfg.RL, tab);
         AGOut o;
@@ -478,9 +479,9 @@ struct DevPL {
     }
 };
 
-// Scalar-heavy, latency-bound control flow.  Rounds 1-2 ran it at 2 waves per SIMD (256 VGPRs, ~18 KB of LDS per wave); round 3 shrank
-// the LDS footprint to under 10 KB (Landau-Vishkin triangle for limits <= 22 only, the register affine-gap forms' tables instead of the
-// LDS form's rows) so that 4 waves per SIMD fit: SNAPGPU_PAIRED_WAVES_PER_SIMD (paired_args.h).
+// Scalar-heavy control flow at 2 waves per SIMD (256 VGPRs).  Its LDS footprint (under 10 KB per wave since round 3: Landau-Vishkin
+// triangle for limits <= 22 only, the register affine-gap forms' tables instead of the LDS form's rows) would allow 4; measured slower
+// (paired_args.h: SNAPGPU_PAIRED_WAVES_PER_SIMD).
 template <int AGC, bool SEC, bool EXACT = false>
 __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_align_paired(PairedArgs a)
 {
@@ -510,6 +511,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     al.agc = a.single_agc_cap ? (snapgpu_single_result *)(sc + a.off_single_agc) : nullptr;    // no buffer without affine gap (PairedAligner.cpp:570-577)
     al.agc_cap = a.single_agc_cap;
     al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    al.ag_calls_unit = 0;
 
     if constexpr (SEC) {            // secondary-result lists of the single-end aligner (as k_align_single<.., true> lays them out)
         al.sec_cfg = a.ssec_cfg;
@@ -597,6 +599,8 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
         }
         load_pair(i);
         pl.cur_pair = i;
+        if (al.ag_calls_unit >= WAVE_PRIO_HEAVY_AFTER * 8) wave_set_priority(0);
+        al.ag_calls_unit = 0;
         al.ag_obj_used0 = al.ag_obj_used1 = 0;          // the chimeric fallback's single-end aligner is one object for the whole pair
         {   // zero both results (fields the reference leaves unset read as 0 here)
             uint32_t *z0 = (uint32_t *)&core.sh->res, *z1 = (uint32_t *)&core.sh->alt;

@@ -67,6 +67,7 @@ EMU_NOINLINE int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row
 EMU_NOINLINE void __builtin_amdgcn_wave_barrier() { emu::xlane(emu::OP_BARRIER, 0, 0, 0, 0, EMU_SITE()); }
 static inline void __builtin_amdgcn_fence(int, const char *) {}
 static inline uint64_t __builtin_amdgcn_s_memtime() { return __builtin_ia32_rdtsc(); }
+static inline void __builtin_amdgcn_s_setprio(int) {}
 #define __ATOMIC_ACQ_REL_EMU 4
 
 EMU_NOINLINE int __shfl(int v, int src, int width = 64) { (void)width; return (int)emu::xlane(emu::OP_BPERMUTE, (uint32_t)v, src & 63, 0, 0, EMU_SITE()); }
