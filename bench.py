@@ -92,7 +92,7 @@ def algorithmic_bytes(c, read_len, n_reads, ref_walk_slots=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = auto: 4 single-end, 6 paired-end: a multiple of the feeders)")
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = auto: 6, a multiple of the feeders)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--genome-mb", type=int, default=256)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
@@ -105,7 +105,7 @@ def main():
                     help="weak (default): every GPU aligns --reads reads per step; strong: --reads is the whole job's batch, split evenly over the GPUs")
     ap.add_argument("--feeders", type=int, default=0,
                     help="contexts per GPU, each with its own stream and result buffer, that take the steps in turn so that consecutive "
-                         "batches overlap on the GPU (what snapgpu-sam's feeder threads do).  0 = auto: 2 for single-end, 3 for paired-end "
+                         "batches overlap on the GPU (what snapgpu-sam's feeder threads do).  0 = auto: 3 "
                          "(a launch ends with a tail of few, heavy reads / pairs that leaves most of the chip idle: measured, profiles/r02i, "
                          "1 -> 2 feeders: 4.20 -> 6.28 M reads/s single-end; 1 / 2 / 3 / 4 feeders: 119 / 174 / 210 / 189 k reads/s paired-end)")
     ap.add_argument("--batches", type=int, default=4, help="distinct read batches rotated through the timed steps")
@@ -122,7 +122,7 @@ def main():
                     help="single = configs[1] (the metric's config); paired = configs[2], 2x150 bp FR pairs through the paired-end path")
     args = ap.parse_args()
     if args.steps <= 0:
-        args.steps = 6 if args.workload == "paired" else 4
+        args.steps = 6
 
     # stdout carries exactly ONE JSON line: anything libraries print to fd 1 (RCCL prints a version
     # banner there) is sent to stderr instead; the JSON goes to the saved descriptor at the end.
@@ -213,7 +213,7 @@ def main():
     # buffer.  Feeder f runs steps f, f + F, f + 2F, ... from a host thread of its own (the C ABI call blocks until its batch is done),
     # so the tail of one batch -- a few heavy pairs on a few wavefronts -- overlaps the bulk of the next.  A step is still one pass of
     # the hot path over one batch, and exactly --steps of them are inside the timed region.
-    n_feed = args.feeders if args.feeders > 0 else (3 if paired else 2)
+    n_feed = args.feeders if args.feeders > 0 else 3
     n_feed = max(1, min(n_feed, max(1, args.steps)))
     feeders = [aligner] + [aligner.replica() for _ in range(n_feed - 1)]
     d_prims = [torch.zeros(n_units * res_dtype.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_feed)]

@@ -77,19 +77,14 @@ def test_lookup_kernels_agree_counts_only_and_odd_batch_sizes(aligner, golden_pr
     assert (nh8 == exp_nh).all() and (hits8 == exp_hits).all()
     # counts only, through the device-pointer entry (torch on hardware; under the emulator host memory is device memory)
     n = seeds.shape[0]
-    on_gpu = not hasattr(aligner.lib, "emu_total_ops")         # (the emulator's library exports its own counters)
-    if on_gpu:
-        torch = pytest.importorskip("torch")
+    # (device buffers through the HIP runtime libsnapgpu.so itself uses -- tests/util.HipBuffers -- never torch: its bundled runtime
+    #  cannot initialise the GPU once another copy of libamdhip64 owns it, and the attempt breaks later hipMallocs of this process)
+    hip = util.HipBuffers()
+    d_seeds = hip.upload(np.ascontiguousarray(seeds.reshape(-1)))
+    d_nh = hip.upload(np.zeros((n, 2), dtype=np.int64))
     aligner.counters(reset=True)
-    if on_gpu:
-        d_seeds = torch.from_numpy(seeds.reshape(-1)).cuda()
-        d_nh = torch.zeros(2 * n, dtype=torch.int64, device="cuda")
-        aligner.lookup_device(n, d_seeds.data_ptr(), d_nh.data_ptr(), 0, 300)
-        got = d_nh.cpu().numpy().reshape(n, 2)
-    else:
-        flat = np.ascontiguousarray(seeds.reshape(-1))
-        got = np.zeros((n, 2), dtype=np.int64)
-        aligner.lookup_device(n, flat.ctypes.data, got.ctypes.data, 0, 300)
+    aligner.lookup_device(n, d_seeds, d_nh, 0, 300)
+    got = hip.download(d_nh, np.zeros((n, 2), dtype=np.int64))
     assert (got == exp_nh).all()
     c = aligner.counters(reset=True)
     valid = exp_nh[:, 0] >= 0
