@@ -84,7 +84,10 @@ def algorithmic_bytes(c, read_len, n_reads, ref_walk_slots=None):
     probe = 8 * slots + 4 * c["n_overflow_lists"] + 4 * c["n_hits_consumed"]
     lv = c["n_lv_ref_bytes"]
     reads = (2 * read_len + 88) * n_reads
-    return probe + lv + reads, dict(probe=probe, lv_reference=lv, reads_and_results=reads,
+    # what the kernel actually stages per scored location since round 3: 27 plane words (216 B: planes.h) for Landau-Vishkin, and the byte
+    # window (read + 2 x 128 B) only where affine gap runs -- against (read - seed + 2k) reference BYTES the algorithm is entitled to
+    staged = 216 * c["n_lv_locations"] + (read_len + 256) * c["n_ag_locations"]
+    return probe + lv + reads, dict(probe=probe, lv_reference=lv, reads_and_results=reads, lv_reference_staged_bytes=staged,
                                     probe_layout_bytes=8 * c["n_hash_slots_probed"] + 4 * c["n_overflow_lists"] + 4 * c["n_hits_consumed"],
                                     probe_basis="reference slot walk, counted" if ref_walk_slots is not None else "the kernel's own table layout")
 

@@ -163,6 +163,9 @@ struct Aligner {
     uint16_t *wl_next, *wl_prev;
     uint16_t *lv_tri;
     int16_t  *ag_rows;      // H, H-1, E rows of the affine-gap DP
+    unsigned long long *rp; // bit planes of the read, both directions (planes.h); [dir][plane][read_plane_words(RL)]
+    unsigned long long *tp; // bit planes of the candidate's reference window; [plane][TEXT_PLANE_BLOCKS]
+    int tp_org;             // bit of tp that is genome[loc] of the staged candidate
     // ---- HBM scratch for this wave
     uint16_t *heads;
     Elem     *pool;
@@ -569,6 +572,37 @@ struct Aligner {
         WAVE_SYNC();
     }
 
+    // the candidate's window as bit planes: the blocks that hold genome[loc - WIN_PAD, loc + read_len + WIN_PAD), one coalesced load
+    __device__ __forceinline__ void stage_planes(int64_t loc) {
+        const int64_t bit0 = loc - WIN_PAD + (int64_t)ix.genome_pad;         // position in the padded genome = bit of the plane array
+        const int64_t blk0 = bit0 >> 6;
+        tp_org = (int)(bit0 & 63) + WIN_PAD;
+        if (lane < 3 * TEXT_PLANE_BLOCKS) {
+            const int b = lane / 3, pl = lane - 3 * b;
+            tp[pl * TEXT_PLANE_BLOCKS + b] = ix.planes[(blk0 + b) * 3 + pl];
+        }
+        WAVE_SYNC();
+    }
+    // bit planes of rd[dir][0 .. len): code bits, 'N' / 'n', any other byte (planes.h: LvPlanes)
+    __device__ __forceinline__ void build_read_planes(int len) {
+        const int rpw = (int)read_plane_words(cfg.RL);
+        for (int dir = 0; dir < 2; dir++) {
+            for (int w = 0; w < rpw; w++) {
+                const int i = w * 64 + lane;
+                const uint8_t c = i < len ? rd[dir][i] : (uint8_t)0;
+                const uint32_t v = base_value(c);
+                const bool in = i < len, non = v > 3u, nn = c == 'N' || c == 'n';
+                const unsigned long long p0 = BALLOT(in && (non ? c == 'n' : (v & 1u))), p1 = BALLOT(in && !non && (v & 2u));
+                const unsigned long long pn = BALLOT(in && nn), po = BALLOT(in && non && !nn);
+                if (lane == 0) {
+                    unsigned long long *base = rp + (size_t)dir * 4 * rpw;
+                    base[w] = p0; base[rpw + w] = p1; base[2 * rpw + w] = pn; base[3 * rpw + w] = po;
+                }
+            }
+        }
+        WAVE_SYNC();
+    }
+
     // ------------------------------------------------------------------ score()  (BaseAligner.cpp:918-1534)
     // returns true when a final answer has been written to `primary`.  HAM: the useHamming variant (gapless scoring with
     // clipping, candidates kept for alignAffineGap), used only by the paired-end fallback (ChimericPairedEndAligner.cpp:340).
@@ -657,7 +691,10 @@ struct Aligner {
                     int cand_seed_offset = (int)((EW(20 + (idx >> 1)) >> (16 * (idx & 1))) & 0xffffu);
 
                     if (substring_ok(loc, glen)) {
-                        stage_window(loc);
+                        // Landau-Vishkin works on bit planes (planes.h) when the context has them and the limit's 2k + 1 diagonals fit
+                        // the wave; the byte window is only staged for what reads bytes: the gapless walk, affine gap
+                        const bool lv_planes = !HAM && ix.planes != nullptr && limit_e <= 31;
+                        if (lv_planes) stage_planes(loc); else stage_window(loc);
                         const uint8_t *data = gw + WIN_PAD;                   // data[i] = genome[loc + i]
                         const int seed_len = (int)ix.seed_len;
                         const int seed_offset = cand_seed_offset;
@@ -698,7 +735,16 @@ struct Aligner {
                             const int tlen = half == 0 ? text_len : seed_offset + SNAPGPU_MAX_K;
                             const int lim = half == 0 ? limit_e : limit_e - score1;
                             ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
-                            LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab, cfg.RL);
+                            LvPlanes lp;
+                            if (lv_planes) {
+                                const int rpw = (int)read_plane_words(cfg.RL);
+                                const LDS_AS unsigned long long *rb = (const LDS_AS unsigned long long *)rp + (e_dir ? 4 * rpw : 0);
+                                const LDS_AS unsigned long long *tb = (const LDS_AS unsigned long long *)tp;
+                                lp.p0 = rb; lp.p1 = rb + rpw; lp.pn = rb + 2 * rpw; lp.po = rb + 3 * rpw;
+                                lp.t0 = tb; lp.t1 = tb + TEXT_PLANE_BLOCKS; lp.tn = tb + 2 * TEXT_PLANE_BLOCKS;
+                                lp.p_org = org; lp.t_org = tp_org + org; lp.st = st; lp.p_words = rpw; lp.t_words = TEXT_PLANE_BLOCKS;
+                            }
+                            LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab, cfg.RL, lv_planes ? &lp : nullptr);
                             // results are wave-uniform; say so, so they (and everything derived from them) live in SGPRs
                             r.score = (int)first_u32((uint32_t)r.score); r.net_indel = (int)first_u32((uint32_t)r.net_indel);
                             r.match_probability = first_f64(r.match_probability);
@@ -718,6 +764,7 @@ struct Aligner {
                         if (!HAM && score1 != -1 && score2 != -1) {
                             int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);     // :1148
                             if (cfg.use_ag && (score1 + score2 > max_k_same && e_lps <= (uint32_t)all.best_score)) {   // :1203
+                                if (lv_planes) stage_window(loc);             // affine gap reads bytes
                                 score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0;
                                 used_ag = 1;
                                 cnt.ag++;
@@ -901,6 +948,7 @@ struct Aligner {
         for (uint32_t i = lane; i < (cfg.RL + 31) / 32; i += WAVE) seed_used[i] = 0;
         WAVE_SYNC();
         if (n_count > max_k) return;                                          // :398
+        if (!HAM && ix.planes != nullptr) build_read_planes(len);
 
         if (n_count > 0) {                                                    // :407-420 block seeds containing a non-ACGT base
             int min_seed = 0;

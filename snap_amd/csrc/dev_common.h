@@ -59,6 +59,8 @@ struct DevIndex {
     const uint8_t  *bucket_blob;
     const uint64_t *bucket_offset;  // [n_hash_tables] byte offset of table t's buckets
     const uint64_t *n_buckets;      // [n_hash_tables]
+    // bit-plane shadow of the padded genome (planes.h): 3 words per 64 bases, block 0 = genome - genome_pad; NULL: not built
+    const unsigned long long *planes;
 };
 
 // Probability tables, computed on the host with host libm (LandauVishkin.cpp:716-763,

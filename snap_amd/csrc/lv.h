@@ -16,6 +16,7 @@
 // callers evaluate with one limit and threshold afterwards.
 #pragma once
 #include "dev_common.h"
+#include "planes.h"
 
 #define LV_ACT_X 0
 #define LV_ACT_D 1
@@ -60,10 +61,12 @@ template <bool TRI_LDS> struct LvMem;
 template <> struct LvMem<true>  { typedef LDS_AS uint16_t U16; typedef LDS_AS uint32_t U32; typedef LDS_AS unsigned long long U64; typedef LDS_AS uint8_t U8; };
 template <> struct LvMem<false> { typedef uint16_t U16; typedef uint32_t U32; typedef unsigned long long U64; typedef uint8_t U8; };
 
+// planes != NULL: the mismatch bitmaps come from bit planes of the pattern and the text (planes.h) -- every lane builds the bitmap of its
+// own diagonal, all 2k + 1 of them before the first level -- and P / T are not read at all; Q still is (the forward pass).
 template <bool TRI_LDS = true, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ LVResult lv_compute_inl(
     const PSeq &P, const QSeq &Q, int pattern_len, const TSeq &T, int text_len, int k,
-    uint16_t *lds_tri_generic, uint32_t kmax, const DevTables *tab, uint32_t pcap)
+    uint16_t *lds_tri_generic, uint32_t kmax, const DevTables *tab, uint32_t pcap, const LvPlanes *planes = nullptr)
 {
     typedef typename LvMem<TRI_LDS>::U16 M16; typedef typename LvMem<TRI_LDS>::U32 M32; typedef typename LvMem<TRI_LDS>::U64 M64;
     typedef typename LvMem<TRI_LDS>::U8 M8;
@@ -98,6 +101,19 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
     // ---- e = 0: the perfect-match prefix, compared 64 bytes per step by the whole wave
     const int end0 = pattern_len < text_len ? pattern_len : text_len;
     int run0 = 0;
+    if (planes != nullptr) {
+        // all bitmaps at once: lane r builds diagonal lv_diag(r); the perfect-match prefix is the first set bit of diagonal 0's
+        if (lane <= 2 * k) {
+            const int d = lv_diag(lane);
+            const int tl = text_len - d;
+            const int end = pattern_len < tl ? pattern_len : tl;
+            for (int w = 0; w < nwu; w++) mask[lane * nw + w] = lv_plane_mask_word(*planes, d, w, end);
+        }
+        WAVE_SYNC();
+        int first = end0;
+        for (int w = nwu - 1; w >= 0; w--) { const unsigned long long v = mask[w]; if (v) first = w * 64 + (int)__builtin_ctzll(v); }
+        run0 = (int)first_u32((uint32_t)first);
+    } else
     while (true) {
         int i = run0 + lane;
         bool same = (i < end0) && (P(i) == T(i));
@@ -123,10 +139,12 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
         const M16 *prev_row = lds_tri + (e - 1) * (e - 1);
         M16 *row = lds_tri + e * e;
         int x_rank = 1 << 30, any_rank = 1 << 30;
-        if (e == 1) build_mask(0);
-        build_mask(2 * e - 1);
-        build_mask(2 * e);
-        WAVE_SYNC();
+        if (planes == nullptr) {
+            if (e == 1) build_mask(0);
+            build_mask(2 * e - 1);
+            build_mask(2 * e);
+            WAVE_SYNC();
+        }
         for (int r0 = 0; r0 <= 2 * e; r0 += WAVE) {
             int r = r0 + lane;
             bool live = r <= 2 * e;
@@ -253,10 +271,10 @@ static __device__ __attribute__((noinline)) LVResult lv_compute_fn(
 template <bool TRI_LDS = true, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ LVResult lv_compute(
     const PSeq &P, const QSeq &Q, int pattern_len, const TSeq &T, int text_len, int k,
-    uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap)
+    uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap, const LvPlanes *planes = nullptr)
 {
 #if !defined(SNAPGPU_AG_LV_FUNCTIONS)
-    return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
+    return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, planes);
 #else
     return lv_compute_fn<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
 #endif

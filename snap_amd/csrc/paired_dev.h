@@ -505,6 +505,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     al.wl_prev = (uint16_t *)(my + SL.wl_prev);
     al.lv_tri = (uint16_t *)(my + SL.lv);
     al.ag_rows = (int16_t *)(my + SL.ag);
+    al.rp = (unsigned long long *)(my + SL.rp); al.tp = (unsigned long long *)(my + SL.tp);
     al.heads = (uint16_t *)sc;
     al.pool = (Elem *)(sc + (size_t)a.scfg.ht_size * 2);
     al.ag_scratch = sc + (size_t)a.scfg.ht_size * 2 + (size_t)a.scfg.pool_size * sizeof(Elem);

@@ -23,6 +23,7 @@
 #include "single_kernel.h"
 #include "order.h"
 #include "lookup16.h"
+#include "planes.h"
 #include "paired_args.h"
 #include "cigar_lv.h"
 #include "cigar_ag.h"
@@ -227,6 +228,7 @@ struct snapgpu_ctx {
     void *d_table_offset = nullptr, *d_table_size = nullptr, *d_contig_begin = nullptr;
     void *d_bucket_blob = nullptr, *d_bucket_offset = nullptr, *d_n_buckets = nullptr;      // device-native hash layout (bucket.h)
     bool owns_buckets = true; uint64_t bucket_bytes = 0;
+    unsigned long long *d_planes = nullptr; bool owns_planes = true; uint64_t plane_bytes = 0;     // bit-plane shadow of the genome (planes.h)
     void *d_proj = nullptr;           // [proj_begin u64 x n][cigar_start u32 x (n+1)][cigar_ops u32 x m][proj_rc u8 x n]
     PEProj proj{};
     DevTables *d_tab = nullptr;
@@ -432,6 +434,7 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_help) (void)hipFree(ctx->d_help);
     if (ctx->d_help_spec) (void)hipFree(ctx->d_help_spec);
     if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
+    if (ctx->d_planes && ctx->owns_planes) (void)hipFree(ctx->d_planes);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
     if (ctx->d_whist) (void)hipFree(ctx->d_whist);
@@ -446,6 +449,25 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
 
 // Device-native hash layout (bucket.h): built on the GPU from the reference's slot arrays once they are in HBM
 // (snapgpu_create for uploaded / adopted blobs, snapgpu_broadcast_index for the replicas it fills).
+// The bit-plane shadow of the genome (planes.h), from the byte genome already in HBM -- however it got there.  SNAPGPU_NO_PLANES=1: none
+// (Landau-Vishkin then compares bytes, as in rounds 1-2).
+static int build_planes(snapgpu_ctx *ctx)
+{
+    if (getenv("SNAPGPU_NO_PLANES")) return SNAPGPU_OK;
+    const uint64_t n_bytes = ctx->ix.n_bases + 2 * (uint64_t)ctx->ix.genome_pad;
+    const uint64_t n_blocks = (n_bytes + 63) / 64 + 32;
+    if (!ctx->d_planes) {
+        ctx->plane_bytes = n_blocks * 24;
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_planes, (size_t)ctx->plane_bytes), SNAPGPU_E_NOMEM);
+        ctx->owns_planes = true;
+    }
+    hipLaunchKernelGGL(k_genome_planes, dim3((unsigned)ctx->num_cus * 8), dim3(256), 0, ctx->stream, (const uint8_t *)ctx->d_genome_padded, n_bytes, n_blocks, ctx->d_planes);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_LAUNCH);
+    ctx->ix.planes = ctx->d_planes;
+    return SNAPGPU_OK;
+}
+
 static int build_buckets(snapgpu_ctx *ctx)
 {
     DevIndex &ix = ctx->ix;
@@ -546,7 +568,7 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     ix.table_offset = (const uint64_t *)ctx->d_table_offset;
     ix.table_size = (const uint64_t *)ctx->d_table_size;
     ix.contig_begin = (const uint64_t *)ctx->d_contig_begin;
-    ix.bucket_blob = nullptr; ix.bucket_offset = nullptr; ix.n_buckets = nullptr;
+    ix.bucket_blob = nullptr; ix.bucket_offset = nullptr; ix.n_buckets = nullptr; ix.planes = nullptr;
     {   // ALT-to-primary projections (used by the paired-end path's ALT liftover); absent data = "location 0, no CIGAR"
         const size_t n = idx->n_contigs;
         const uint32_t n_ops = (idx->contig_cigar_start && idx->cigar_ops && n) ? idx->contig_cigar_start[n] : 0;
@@ -600,6 +622,13 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     } else if (idx->on_device || idx->hash_blob != nullptr) {      // (blobs left unfilled wait for snapgpu_broadcast_index)
         const int brc = build_buckets(ctx);
         if (brc != SNAPGPU_OK) { snapgpu_destroy(ctx); return brc; }
+    }
+    if (g_share_buckets_from && g_share_buckets_from->d_planes && idx->on_device && !getenv("SNAPGPU_NO_PLANES")) {       // a feeder context: adopt the shadow too
+        ctx->d_planes = g_share_buckets_from->d_planes; ctx->owns_planes = false; ctx->plane_bytes = g_share_buckets_from->plane_bytes;
+        ix.planes = ctx->d_planes;
+    } else if (idx->on_device || idx->genome != nullptr) {
+        const int prc = build_planes(ctx);
+        if (prc != SNAPGPU_OK) { snapgpu_destroy(ctx); return prc; }
     }
 
     // ---- tables
@@ -791,6 +820,8 @@ extern "C" int snapgpu_broadcast_index(snapgpu_ctx **ctxs, int n)
         HIPCHK(root, hipSetDevice(ctxs[i]->device), SNAPGPU_E_NODEVICE);
         const int brc = build_buckets(ctxs[i]);
         if (brc != SNAPGPU_OK) return brc;
+        const int prc = build_planes(ctxs[i]);
+        if (prc != SNAPGPU_OK) return prc;
     }
     return SNAPGPU_OK;
 }
