@@ -258,13 +258,25 @@ template <class S> static __device__ __forceinline__ S seq_uniform(const S &s) {
 template <bool TRI_LDS, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __attribute__((noinline)) LVResult lv_compute_fn(
     PSeq P_in, QSeq Q_in, int pattern_len, TSeq T_in, int text_len, int k,
-    uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap)
+    uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap, uint64_t rp_lds, uint64_t tp_lds, uint32_t plane_geom, int p_org, int t_org)
 {
     const PSeq P = seq_uniform(P_in); const QSeq Q = seq_uniform(Q_in); const TSeq T = seq_uniform(T_in);
     pattern_len = (int)first_u32((uint32_t)pattern_len); text_len = (int)first_u32((uint32_t)text_len); k = (int)first_u32((uint32_t)k);
     lds_tri = (uint16_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)lds_tri);
     kmax = first_u32(kmax); pcap = first_u32(pcap);
     tab = (const DevTables *)(uintptr_t)first_u64((uint64_t)(uintptr_t)tab);
+    // bit planes (planes.h): LDS addresses of the pattern's and the text's planes (~0: none), words per plane << 16 / << 24 | stride + 1
+    rp_lds = first_u64(rp_lds); tp_lds = first_u64(tp_lds); plane_geom = first_u32(plane_geom);
+    p_org = (int)first_u32((uint32_t)p_org); t_org = (int)first_u32((uint32_t)t_org);
+    if (rp_lds != ~0ull) {
+        LvPlanes lp;
+        const int pw = (int)((plane_geom >> 16) & 0xffu), tw = (int)(plane_geom >> 24);
+        const LDS_AS unsigned long long *rb = (const LDS_AS unsigned long long *)(uintptr_t)rp_lds, *tb = (const LDS_AS unsigned long long *)(uintptr_t)tp_lds;
+        lp.p0 = rb; lp.p1 = rb + pw; lp.pn = rb + 2 * pw; lp.po = rb + 3 * pw;
+        lp.t0 = tb; lp.t1 = tb + tw; lp.tn = tb + 2 * tw;
+        lp.p_org = p_org; lp.t_org = t_org; lp.st = (int)(plane_geom & 0xffffu) - 1; lp.p_words = pw; lp.t_words = tw;
+        return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, &lp);
+    }
     return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
 }
 
@@ -276,6 +288,12 @@ static __device__ __forceinline__ LVResult lv_compute(
 #if !defined(SNAPGPU_AG_LV_FUNCTIONS)
     return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, planes);
 #else
-    return lv_compute_fn<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
+    // (the planes' LDS pointers cross the call as 32-bit LDS addresses)
+    if (planes != nullptr)
+        return lv_compute_fn<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap,
+                                                        (uint64_t)(uintptr_t)planes->p0, (uint64_t)(uintptr_t)planes->t0,
+                                                        (uint32_t)(planes->st + 1) | ((uint32_t)planes->p_words << 16) | ((uint32_t)planes->t_words << 24),
+                                                        planes->p_org, planes->t_org);
+    return lv_compute_fn<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, ~0ull, ~0ull, 0u, 0, 0);
 #endif
 }

@@ -79,7 +79,7 @@ def test_lookup_kernels_agree_counts_only_and_odd_batch_sizes(aligner, golden_pr
     n = seeds.shape[0]
     # (device buffers through the HIP runtime libsnapgpu.so itself uses -- tests/util.HipBuffers -- never torch: its bundled runtime
     #  cannot initialise the GPU once another copy of libamdhip64 owns it, and the attempt breaks later hipMallocs of this process)
-    hip = util.HipBuffers()
+    hip = util.HipBuffers(emu=hasattr(aligner.lib, "emu_total_ops"))
     d_seeds = hip.upload(np.ascontiguousarray(seeds.reshape(-1)))
     d_nh = hip.upload(np.zeros((n, 2), dtype=np.int64))
     aligner.counters(reset=True)

@@ -243,10 +243,13 @@ class HipBuffers:
     bundles its own libamdhip64) being able to initialise the GPU.  With the wavefront emulator (SNAPGPU_TEST_LIB)
     "device" memory is host memory and the emulator library's own hipMalloc shims are used."""
 
-    def __init__(self):
+    def __init__(self, emu=None):
         from snap_amd.aligner import load_library
         load_library()
         path = None
+        if emu:                             # the caller knows its library is the emulator's (libamdhip64 may be mapped by an earlier test)
+            self.emu, self.rt, self.live = True, None, []
+            return
         with open("/proc/self/maps") as f:
             for line in f:
                 if "libamdhip64" in line:
