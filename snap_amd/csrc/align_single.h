@@ -30,6 +30,7 @@
 #include "probe.h"
 #include "lv.h"
 #include "ag_win.h"
+#include "se_help.h"
 #include <stddef.h>
 #include "../../include/snapgpu.h"
 
@@ -59,6 +60,9 @@ struct AlignCfg {
     // beyond the register variants, and the exact replay behind the 256- / 384-position variants), ag_lds_bytes_reg(RL, 3) where only the
     // 192-position register forms run; 0 without affine-gap buffers.
     uint32_t ag_lds;
+    // se_help.h: a wave's list of candidates still to visit (se_items_cap words) and, per candidate-table element, where its candidates
+    // start in that list (pool_size words), at byte se_off of the wave's scratch slab; se_items_cap == 0: no help in this context
+    uint32_t se_items_cap; uint64_t se_off;
 };
 
 struct __attribute__((aligned(16))) Elem {   // HashTableElement, BaseAligner.h:223-258
@@ -164,7 +168,7 @@ struct Aligner {
     uint16_t *lv_tri;
     int16_t  *ag_rows;      // H, H-1, E rows of the affine-gap DP
     unsigned long long *rp; // bit planes of the read, both directions (planes.h); [dir][plane][read_plane_words(RL)]
-    unsigned long long *tp; // bit planes of the candidate's reference window; [plane][TEXT_PLANE_BLOCKS]
+    unsigned long long *tp; // bit planes of the candidate's reference window; [plane][text_plane_blocks(RL, WIN_PAD)]
     int tp_org;             // bit of tp that is genome[loc] of the staged candidate
     // ---- HBM scratch for this wave
     uint16_t *heads;
@@ -188,6 +192,13 @@ struct Aligner {
                                        // (two scalars, not an array: an index that is not a compile-time constant would pin the object in scratch)
     uint32_t max_k;                    // BaseAligner::maxK: cfg.max_k, or what setMaxK() last said (ChimericPairedEndAligner.cpp:278,301)
     uint32_t ag_calls_unit;            // affine-gap calls since the unit (read; the paired kernel: pair) began -- see wave_set_priority
+    // ---- help for heavy reads (se_help.h); all NULL / 0 where there is none (the paired-end kernel, the exact replay)
+    SEHelpSlot *se_slots; uint32_t se_n_slots; SESpec *se_spec; uint32_t se_spec_cap;
+    uint32_t *se_ctl;                  // [0] reads of the launch that are done, [1] waves that have run out of reads
+    uint32_t se_eager;                 // publish whether or not anybody is idle (tests)
+    uint32_t *se_items, *se_first;     // this wave's list / per-element start (HBM slab)
+    unsigned long long *se_diag;       // snapgpu_counters::reserved[1 .. 2]
+    int se_slot; uint32_t se_n, se_tried, cur_read; SESpec *se_mine;
     // candidates for BaseAligner::alignAffineGap, collected by the Hamming pass only (BaseAligner.cpp:1445-1456)
     snapgpu_single_result *agc;
     uint32_t agc_cap, n_agc, agc_overflow;
@@ -577,9 +588,10 @@ struct Aligner {
         const int64_t bit0 = loc - WIN_PAD + (int64_t)ix.genome_pad;         // position in the padded genome = bit of the plane array
         const int64_t blk0 = bit0 >> 6;
         tp_org = (int)(bit0 & 63) + WIN_PAD;
-        if (lane < 3 * TEXT_PLANE_BLOCKS) {
-            const int b = lane / 3, pl = lane - 3 * b;
-            tp[pl * TEXT_PLANE_BLOCKS + b] = ix.planes[(blk0 + b) * 3 + pl];
+        const int nb = (int)text_plane_blocks(cfg.RL, WIN_PAD);
+        for (int l = lane; l < 3 * nb; l += WAVE) {
+            const int b = l / 3, pl = l - 3 * b;
+            tp[pl * nb + b] = ix.planes[(blk0 + b) * 3 + pl];
         }
         WAVE_SYNC();
     }
@@ -601,6 +613,357 @@ struct Aligner {
             }
         }
         WAVE_SYNC();
+    }
+
+    // One candidate location, evaluated: what the body of BaseAligner::score computes for it before any bookkeeping (BaseAligner.cpp:
+    // 1108-1347) -- Landau-Vishkin on both sides of the seed, affine gap on both sides when that found more than maxKSame edits and the
+    // element can still matter.  A pure function of (read, location, direction, seed offset, limit, best_all); its only side effects are
+    // the work counters and the traceback-step notes (note_ag_call), which is what lets another wave do it (se_help.h).
+    struct CandEval { uint32_t sc; double mp; int64_t loc; int used_ag, clip_before, clip_after, ag_score; uint32_t lv_sum_high;
+                      int lv1, lv2; };     // what Landau-Vishkin alone said for the two sides (-1: above the limit, lv2 -2: not run)
+    template <bool HAM>
+    __device__ __forceinline__ CandEval eval_candidate(int64_t loc, int e_dir, uint32_t e_lps, int cand_seed_offset, int limit_e, uint32_t best_all) {
+        uint32_t lv_sum_high = 0;
+        int lv1 = -1, lv2 = -2;
+        uint32_t sc = (uint32_t)SNAPGPU_ScoreAboveLimit;
+        double mp = 0.0;
+        const int64_t glen = (int64_t)read_len + SNAPGPU_MAX_K;
+        int used_ag = 0, clip_before = 0, clip_after = 0, ag_score = -1;
+
+        if (substring_ok(loc, glen)) {
+            // Landau-Vishkin works on bit planes (planes.h) when the context has them and the limit's 2k + 1 diagonals fit
+            // the wave; the byte window is only staged for what reads bytes: the gapless walk, affine gap
+            const bool lv_planes = !HAM && ix.planes != nullptr && limit_e <= 31;
+            if (lv_planes) stage_planes(loc); else stage_window(loc);
+            const uint8_t *data = gw + WIN_PAD;                   // data[i] = genome[loc + i]
+            const int seed_len = (int)ix.seed_len;
+            const int seed_offset = cand_seed_offset;
+            const int tail_start = seed_offset + seed_len;
+            int ag1 = seed_len, ag2 = 0;
+            int score1 = 0, score2 = 0;
+            double mp1 = 1.0, mp2 = 1.0;
+            int loc_offset = 0;
+            const int text_len = read_len + SNAPGPU_MAX_K - tail_start;
+
+            // Two halves, one call site each for LV and AG (half 0: forward from the end of the seed
+            // over the tail of the read, :1160; half 1: backwards from the start of the seed over the
+            // reversed head of the read, :1169).  The backward text/pattern are the same bytes walked
+            // with stride -1, so LandauVishkin<1> and <-1> are one instantiation.
+            const uint8_t *rdd = e_dir ? rd[1] : rd[0], *qld = e_dir ? ql[1] : ql[0];
+            int g1 = 0, g2 = 0;                                     // score1Gapless / score2Gapless
+            if constexpr (HAM) {                                    // :1177-1199
+                if (tail_start != read_len) {
+                    int po;
+                    ag1 = gapless_score(+1, data + tail_start, rdd + tail_start, qld + tail_start, read_len - tail_start, read_len,
+                                        limit_e, &score1, &po, &mp1, &g1);
+                    ag1 += seed_len - read_len;
+                }
+                if (g1 != -1 && seed_offset != 0) {
+                    int po = 0;
+                    ag2 = gapless_score(-1, data + seed_offset - 1, rdd + seed_offset - 1, qld + seed_offset - 1, seed_offset, read_len,
+                                        limit_e - g1, &score2, &po, &mp2, &g2);
+                    ag2 -= read_len;
+                    loc_offset = g2 != -1 ? po : 0;
+                }
+            }
+            const uint64_t t_lv0 = clk();
+            for (int half = 0; half < 2 && !HAM; half++) {
+                if (half == 1 && score1 == -1) break;
+                const int st = half == 0 ? 1 : -1;
+                const int org = half == 0 ? tail_start : seed_offset - 1;
+                const int plen = half == 0 ? read_len - tail_start : seed_offset;
+                const int tlen = half == 0 ? text_len : seed_offset + SNAPGPU_MAX_K;
+                const int lim = half == 0 ? limit_e : limit_e - score1;
+                ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+                LvPlanes lp;
+                if (lv_planes) {
+                    const int rpw = (int)read_plane_words(cfg.RL);
+                    const LDS_AS unsigned long long *rb = (const LDS_AS unsigned long long *)rp + (e_dir ? 4 * rpw : 0);
+                    const LDS_AS unsigned long long *tb = (const LDS_AS unsigned long long *)tp;
+                    lp.p0 = rb; lp.p1 = rb + rpw; lp.pn = rb + 2 * rpw; lp.po = rb + 3 * rpw;
+                    const int tpb = (int)text_plane_blocks(cfg.RL, WIN_PAD);
+                    lp.t0 = tb; lp.t1 = tb + tpb; lp.tn = tb + 2 * tpb;
+                    lp.p_org = org; lp.t_org = tp_org + org; lp.st = st; lp.p_words = rpw; lp.t_words = tpb;
+                }
+                LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab, cfg.RL, lv_planes ? &lp : nullptr);
+                // results are wave-uniform; say so, so they (and everything derived from them) live in SGPRs
+                r.score = (int)first_u32((uint32_t)r.score); r.net_indel = (int)first_u32((uint32_t)r.net_indel);
+                r.match_probability = first_f64(r.match_probability);
+                if (half == 0) {
+                    score1 = r.score; mp1 = r.match_probability;
+                    ag1 = (seed_len + read_len - tail_start - score1) * cfg.match_reward - score1 * cfg.sub_penalty;
+                    cnt.lv_ref_bytes += (uint64_t)plen + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e));
+                } else {
+                    score2 = r.score; mp2 = r.match_probability; loc_offset = r.net_indel;
+                    ag2 = (seed_offset - score2) * cfg.match_reward - score2 * cfg.sub_penalty;
+                    cnt.lv_ref_bytes += (uint64_t)plen;
+                }
+            }
+            if (!HAM) cnt.lv++;
+            cnt.cyc_lv += clk() - t_lv0;
+            lv1 = score1; lv2 = score1 == -1 ? -2 : score2;
+
+            if (!HAM && score1 != -1 && score2 != -1) {
+                int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);     // :1148
+                lv_sum_high = score1 + score2 > max_k_same ? 1u : 0u;
+                if (cfg.use_ag && (lv_sum_high && e_lps <= best_all)) {   // :1203
+                    if (lv_planes) stage_window(loc);             // affine gap reads bytes
+                    score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0;
+                    used_ag = 1;
+                    cnt.ag++;
+                    if (++ag_calls_unit == WAVE_PRIO_HEAVY_AFTER) wave_set_priority(1);
+                    const uint64_t t_ag0 = clk();
+                    AGParams agp{cfg.match_reward, cfg.sub_penalty, cfg.gap_open, cfg.gap_extend, cfg.five_bonus, cfg.three_bonus};
+                    for (int half = 0; half < 2; half++) {
+                        if (half == 0 && tail_start == read_len) continue;               // :1208
+                        if (half == 1 && (score1 == -1 || seed_offset == 0)) break;      // :1244-1245
+                        const int st = half == 0 ? 1 : -1;
+                        const int org = half == 0 ? tail_start : seed_offset - 1;
+                        const int plen = half == 0 ? read_len - tail_start : seed_offset;
+                        const int lim = half == 0 ? limit_e : limit_e - score1;
+                        const int tlen = half == 0 ? text_len : seed_offset + lim;
+                        const bool banded = plen >= 3 * (2 * lim + 1);                   // :1213 / :1251
+                        ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+                        note_ag_extent(half, banded, plen, lim, tlen);
+                        AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, e_dir != 0,
+                                                      false, ag_rows, EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab);
+                        a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
+                        a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
+                        a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
+                        note_ag_call(half, (uint32_t)a.stale_reads);
+                        if (half == 0) {
+                            ag1 = a.ag_score + (seed_len - read_len); clip_after = a.pattern_offset;
+                            score1 = a.n_edits; mp1 = a.match_probability;
+                        } else {
+                            ag2 = a.ag_score - read_len; clip_before = a.pattern_offset;
+                            score2 = a.n_edits; mp2 = a.match_probability; loc_offset = a.text_offset;
+                        }
+                    }
+                    cnt.cyc_ag += clk() - t_ag0;
+                }
+            }
+
+            bool found = HAM ? (g1 != -1 && g2 != -1) : (score1 != -1 && score2 != -1);               // :1293
+            if (found && loc_offset != 0 && !substring_ok(loc + loc_offset, glen)) found = false;   // :1295-1301
+            if (found) {
+                sc = (uint32_t)(score1 + score2);
+                mp = mp1 * mp2 * tab->seed_prob;                  // :1314
+                loc += loc_offset;
+                ag_score = ag1 + ag2;
+            } else {
+                sc = (uint32_t)SNAPGPU_ScoreAboveLimit;
+                ag_score = SNAPGPU_ScoreAboveLimit;
+                mp = 0.0;
+            }
+        } else {
+            mp = 0.0;
+        }
+
+        CandEval ce; ce.sc = sc; ce.mp = mp; ce.loc = loc; ce.used_ag = used_ag; ce.clip_before = clip_before; ce.clip_after = clip_after;
+        ce.ag_score = ag_score; ce.lv_sum_high = lv_sum_high; ce.lv1 = lv1; ce.lv2 = lv2;
+        return ce;
+    }
+
+    // ------------------------------------------------------------------ help for heavy reads (se_help.h)
+    __device__ __forceinline__ bool se_wanted() const { return se_eager || XW::ld(se_ctl[1]) != 0u; }
+
+    // List what the forced walk still has to visit -- weight lists from wl down, first in first out, every unscored candidate of each
+    // element -- and offer it to the idle waves.
+    __device__ __forceinline__ void se_publish(uint32_t wl) {
+        se_tried = 1;
+        for (uint32_t i = (uint32_t)lane; i < n_used; i += WAVE) se_first[i] = 0xffffffffu;
+        WAVE_SYNC();
+        uint32_t n = 0;
+        for (uint32_t w = wl; w >= 1 && n + BUCKET <= cfg.se_items_cap; w--) {
+            uint16_t ei = get_next(sent(w));
+            while (ei < SENT_MIN && n + BUCKET <= cfg.se_items_cap) {
+                const uint32_t *ep = (const uint32_t *)&pool[ei];
+                const uint32_t v = lane < 4 ? ep[lane] : (lane == 4 ? ep[17] : 0u);          // used, scored, wnext | wprev << 16
+                const uint64_t used = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 1) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 0);
+                const uint64_t scored = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)v, 3) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, 2);
+                const uint16_t nxt = (uint16_t)((uint32_t)__builtin_amdgcn_readlane((int)v, 4) & 0xffffu);
+                const uint64_t m = used & ~scored;
+                if (lane == 0) se_first[ei] = n;
+                if (lane < BUCKET && ((m >> lane) & 1ull)) se_items[n + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint32_t)ei << 6) | (uint32_t)lane;
+                n += (uint32_t)__popcll(m);
+                ei = nxt;
+            }
+        }
+        WAVE_SYNC();
+        if (n < SE_HELP_MIN_ITEMS || n > se_spec_cap) return;
+        int s = -1;
+        if (lane == 0) {
+            for (uint32_t i = 0; i < se_n_slots; i++) if (atomicCAS(&se_slots[i].state, 0u, 3u) == 0u) { s = (int)i; break; }
+        }
+        s = (int)first_u32((uint32_t)s);
+        if (s < 0) return;
+        SEHelpSlot *slot = &se_slots[s];
+        SESpec *spec = se_spec + (size_t)s * se_spec_cap;
+        for (uint32_t t = (uint32_t)lane; t < n; t += WAVE) spec[t].state = 0u;
+        WAVE_SYNC();
+        if (lane == 0) {
+            const uint32_t w0 = atomicExch(&slot->next, SE_HELP_LOOKAHEAD), w1 = atomicExch(&slot->helpers, 0u);
+            if ((w0 ^ w1) == 0xFFFFFFF5u) atomicExch(&slot->helpers, 0u);      // (uses both return values: the exchanges have completed)
+            XW::st(slot->read, cur_read); XW::st(slot->n, n); XW::st(slot->owner_pos, 0u);
+            XW::st(slot->lim_alt, (int32_t)score_limit(true)); XW::st(slot->lim_non_alt, (int32_t)score_limit(false));
+            XW::st(slot->best_all, (uint32_t)all.best_score);
+            XW::st(*(uint64_t *)&slot->items, (uint64_t)(uintptr_t)se_items); XW::st(*(uint64_t *)&slot->pool, (uint64_t)(uintptr_t)pool);
+            XW::st(*(uint64_t *)&slot->spec, (uint64_t)(uintptr_t)spec);
+            XW::fence_release();                            // the candidate table, the list and the cleared records, for the other XCDs
+            atomicExch(&slot->state, 1u);
+            if (se_diag) atomicAdd(&se_diag[1], 1ull << 32);
+        }
+        WAVE_SYNC();
+        se_slot = s; se_n = n; se_mine = spec;
+    }
+
+    // The owner arrives at candidate idx of element ei: take what an idle wave stored for it, if that was computed from the inputs the
+    // owner has now; claim it otherwise (false: evaluate it here).
+    __device__ __forceinline__ bool se_take(uint16_t ei, int idx, uint64_t listed0, int limit_e, uint32_t e_lps, int64_t loc0, int cand_seed_offset, CandEval &ce) {
+        const uint32_t t0 = first_u32(se_first[ei]);
+        if (t0 == 0xffffffffu) return false;
+        const uint32_t t = t0 + (uint32_t)__popcll(listed0 & ((1ull << idx) - 1ull));
+        if (t >= se_n) return false;
+        SEHelpSlot *slot = &se_slots[se_slot];
+        SESpec *sp = &se_mine[t];
+        if (lane == 0) XW::st(slot->owner_pos, t + 1u);
+        const uint64_t t_w0 = wave_clock();
+        for (;;) {
+            uint32_t st = 0;
+            if (lane == 0) st = atomicCAS(&sp->state, 0u, 1u);
+            st = first_u32(st);
+            if (st == 0u) return false;                     // untouched: the owner's now
+            if (st == 2u) break;
+            XW::nap();
+            if (wave_clock() - t_w0 > 1200000000ull) {      // ~0.5 s on one candidate: stop relying on the slot, leave a trace
+                if (lane == 0 && se_diag) atomicAdd(&se_diag[0], 1ull);
+                se_abandon();
+                return false;
+            }
+        }
+        const int lim = XW::ld(sp->limit);
+        const uint32_t high = XW::ld(sp->lv_sum_high), best_then = XW::ld(sp->best_all);
+        const uint32_t n_lv = XW::ld(sp->n_lv);
+        uint32_t n_ag = XW::ld(sp->n_ag), stale = XW::ld(sp->stale);
+        uint64_t bytes = XW::ld(sp->lv_ref_bytes);
+        if (lim == limit_e) {
+            if (high && ((e_lps <= best_then) != (e_lps <= (uint32_t)all.best_score))) return false;  // the affine-gap decision (:1203) would differ
+            ce.sc = XW::ld(sp->sc); ce.mp = XW::ld(sp->mp); ce.loc = XW::ld(sp->loc); ce.used_ag = XW::ld(sp->used_ag);
+            ce.clip_before = XW::ld(sp->clip_before); ce.clip_after = XW::ld(sp->clip_after); ce.ag_score = XW::ld(sp->ag_score);
+        } else {
+            // Evaluated under a larger limit (limits only fall while a read is scored).  Landau-Vishkin's answers for e <= k do not depend on
+            // k (LandauVishkin.h:100-351; SURVEY.md Appendix C: 12 M comparisons), so what it says under the owner's limit follows: the
+            // same when the edits of both sides still fit, "above the limit" otherwise.  Affine gap is another matter -- its band is the limit --
+            // so an evaluation in which it ran, or would run now, is redone.
+            if (lim < limit_e || n_lv == 0u) return false;
+            const int lv1 = XW::ld(sp->lv1), lv2 = XW::ld(sp->lv2);
+            const int plen0 = read_len - (cand_seed_offset + (int)ix.seed_len), plen1 = cand_seed_offset;
+            const bool half1_runs = lv1 >= 0 && lv1 <= limit_e;
+            bytes = (uint64_t)plen0 + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e)) + (half1_runs ? (uint64_t)plen1 : 0ull);
+            if (half1_runs && lv2 >= 0 && lv1 + lv2 <= limit_e) {                 // both sides still fit
+                if (n_ag != 0u) return false;
+                if (high && e_lps <= (uint32_t)all.best_score) return false;       // affine gap would run now
+                ce.sc = XW::ld(sp->sc); ce.mp = XW::ld(sp->mp); ce.loc = XW::ld(sp->loc); ce.used_ag = 0;
+                ce.clip_before = 0; ce.clip_after = 0; ce.ag_score = XW::ld(sp->ag_score);
+            } else {                                                             // :1293-1347 with score1 or score2 == -1
+                ce.sc = (uint32_t)SNAPGPU_ScoreAboveLimit; ce.mp = 0.0; ce.loc = loc0; ce.used_ag = 0; ce.clip_before = 0; ce.clip_after = 0;
+                ce.ag_score = SNAPGPU_ScoreAboveLimit;
+                n_ag = 0; stale = 0;
+            }
+        }
+        ce.lv_sum_high = high; ce.lv1 = 0; ce.lv2 = 0;
+        cnt.lv += n_lv; cnt.ag += n_ag; cnt.lv_ref_bytes += bytes;
+        // a speculative evaluation cannot know what this read's aligner objects scored before: all of its out-of-band steps count as
+        // later-call ones, and from here on the objects count as used
+        ag_stale += stale; ag_replay += stale;
+        if (n_ag) { ag_obj_used0 = 1; ag_obj_used1 = 1; ag_calls_unit += n_ag; }
+        if (lane == 0 && se_diag) atomicAdd(&se_diag[1], 1ull);
+        return true;
+    }
+
+    __device__ __forceinline__ void se_abandon() {          // after a watchdog: the slot is retired for the rest of the launch
+        if (lane == 0) atomicExch(&se_slots[se_slot].state, 4u);
+        se_slot = -1;
+    }
+
+    // end of the read: no new helpers, wait for the attached ones to leave (they read this wave's candidate table), free the slot
+    __device__ __forceinline__ void se_close() {
+        SEHelpSlot *slot = &se_slots[se_slot];
+        uint32_t was = 0;
+        if (lane == 0) was = atomicExch(&slot->state, 2u);
+        was = first_u32(was);
+        bool gave_up = was != 1u;
+        const uint64_t t0 = wave_clock();
+        while (!gave_up) {
+            if (XW::aload(&slot->helpers) == 0u) break;
+            XW::nap();
+            if (wave_clock() - t0 > 4800000000ull) { if (lane == 0 && se_diag) atomicAdd(&se_diag[0], 1ull << 16); gave_up = true; }
+        }
+        if (lane == 0) atomicExch(&slot->state, gave_up ? 4u : 0u);
+        se_slot = -1;
+    }
+
+    // A wave that has run out of reads, attached to `slot` (the read is in this wave's LDS): evaluate candidates of the list until none
+    // are left or the owner closes.
+    __device__ __forceinline__ void se_help_slot(SEHelpSlot *slot) {
+        const uint32_t n = XW::ld(slot->n);
+        const int lim_alt = XW::ld(slot->lim_alt), lim_non_alt = XW::ld(slot->lim_non_alt);
+        const uint32_t best = XW::ld(slot->best_all);
+        const uint32_t *items = (const uint32_t *)(uintptr_t)XW::ld(*(const uint64_t *)&slot->items);
+        const Elem *opool = (const Elem *)(uintptr_t)XW::ld(*(const uint64_t *)&slot->pool);
+        SESpec *spec = (SESpec *)(uintptr_t)XW::ld(*(const uint64_t *)&slot->spec);
+        for (uint32_t it = 0; it <= n; it++) {
+            if (XW::aload(&slot->state) != 1u) break;
+            uint32_t c0 = 0;
+            if (lane == 0) c0 = atomicAdd(&slot->next, SE_HELP_CHUNK);
+            c0 = first_u32(c0);
+            if (c0 >= n) break;
+            const uint32_t c1 = c0 + SE_HELP_CHUNK < n ? c0 + SE_HELP_CHUNK : n;
+            for (uint32_t t = c0; t < c1; t++) {
+                if (t < XW::ld(slot->owner_pos)) continue;  // the owner is past it
+                uint32_t st = 1;
+                if (lane == 0) st = atomicCAS(&spec[t].state, 0u, 1u);
+                if (first_u32(st) != 0u) continue;
+                const uint32_t item = first_u32(items[t]);
+                const uint32_t ei = item >> 6; const int idx = (int)(item & 63u);
+                const uint32_t *ep = (const uint32_t *)&opool[ei];
+                const uint32_t ew = lane < (int)(sizeof(Elem) / 4) ? ep[lane] : 0u;
+                auto EW = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)ew, i); };
+                const int64_t e_base = (int64_t)(((uint64_t)EW(5) << 32) | EW(4));
+                const int e_dir = (int)((EW(18) >> 16) & 0xffu);
+                const uint32_t e_lps = EW(11);
+                const int cso = (int)((EW(20 + (idx >> 1)) >> (16 * (idx & 1))) & 0xffffu);
+                const int limit_e = (cfg.alt_aware && is_alt(e_base)) ? lim_alt : lim_non_alt;
+                CandEval ce; ce.sc = 0; ce.mp = 0; ce.loc = 0; ce.used_ag = 0; ce.clip_before = 0; ce.clip_after = 0; ce.ag_score = 0; ce.lv_sum_high = 0;
+                ce.lv1 = -1; ce.lv2 = -2;
+                uint32_t d_lv = 0, d_ag = 0, stale = 0; uint64_t d_bytes = 0;
+                int rec_limit = (int)0x80000000;            // (an element the owner would skip under this limit: a record nobody can use)
+                if ((int64_t)e_lps <= (int64_t)limit_e) {
+                    const uint64_t lv0 = cnt.lv, ag0 = cnt.ag, b0 = cnt.lv_ref_bytes;
+                    ag_stale = 0; ag_replay = 0; ag_obj_used0 = 1; ag_obj_used1 = 1;
+                    ce = eval_candidate<false>(e_base + idx, e_dir, e_lps, cso, limit_e, best);
+                    d_lv = (uint32_t)(cnt.lv - lv0); d_ag = (uint32_t)(cnt.ag - ag0); d_bytes = cnt.lv_ref_bytes - b0; stale = ag_stale;
+                    cnt.lv = lv0; cnt.ag = ag0; cnt.lv_ref_bytes = b0;        // (the owner counts what it uses)
+                    WAVE_SYNC();
+                    rec_limit = limit_e;
+                }
+                if (lane == 0) {
+                    SESpec *sp = &spec[t];
+                    XW::st(sp->limit, (int32_t)rec_limit); XW::st(sp->best_all, best); XW::st(sp->lv_sum_high, ce.lv_sum_high);
+                    XW::st(sp->sc, ce.sc); XW::st(sp->ag_score, (int32_t)ce.ag_score); XW::st(sp->used_ag, (int32_t)ce.used_ag);
+                    XW::st(sp->clip_before, (int32_t)ce.clip_before); XW::st(sp->clip_after, (int32_t)ce.clip_after);
+                    XW::st(sp->n_lv, d_lv); XW::st(sp->n_ag, d_ag); XW::st(sp->stale, stale);
+                    XW::st(sp->loc, ce.loc); XW::st(sp->mp, ce.mp); XW::st(sp->lv_ref_bytes, d_bytes);
+                    XW::st(sp->lv1, (int32_t)ce.lv1); XW::st(sp->lv2, (int32_t)ce.lv2);
+                    XW::stores_done();
+                    atomicExch(&sp->state, 2u);
+#if defined(SNAPGPU_WAVE_EMU)
+                    if (getenv("SNAPGPU_DEBUG_SE_HELP")) fprintf(stderr, "HELPED read %u item %u limit %d sc %u n_ag %u\n", XW::ld(slot->read), t, rec_limit, ce.sc, d_ag);
+#endif
+                }
+                WAVE_SYNC();
+            }
+        }
     }
 
     // ------------------------------------------------------------------ score()  (BaseAligner.cpp:918-1534)
@@ -649,6 +1012,9 @@ struct Aligner {
                 return false;
             }
 
+            if constexpr (!EXACT && !HAM) {             // idle waves can take over part of what is left of a forced walk (se_help.h)
+                if (force_result && se_slots != nullptr && se_slot < 0 && !se_tried && se_wanted()) se_publish(wl);
+            }
             uint16_t ei = get_next(sent(wl));
             Elem *e = &pool[ei];
             // The element (44 dwords) comes in with ONE coalesced load, lane i holding dword i; its fields are then lane reads.
@@ -656,7 +1022,7 @@ struct Aligner {
             // registers next to the stores.
             const uint32_t ew = lane < (int)(sizeof(Elem) / 4) ? ((const uint32_t *)e)[lane] : 0u;
             auto EW = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)ew, i); };
-            static_assert(offsetof(Elem, base) == 16 && offsetof(Elem, match_prob) == 32 && offsetof(Elem, lps) == 44 &&
+            static_assert(offsetof(Elem, wnext) == 68 && offsetof(Elem, base) == 16 && offsetof(Elem, match_prob) == 32 && offsetof(Elem, lps) == 44 &&
                           offsetof(Elem, best_score) == 48 && offsetof(Elem, hnext) == 72 && offsetof(Elem, dir) == 74 &&
                           offsetof(Elem, flags) == 75 && offsetof(Elem, cand_seed_offset) == 80, "Elem layout");
             int64_t e_base = (int64_t)(((uint64_t)EW(5) << 32) | EW(4));
@@ -669,6 +1035,7 @@ struct Aligner {
             int limit_e = score_limit(cfg.alt_aware && is_alt(e_base));      // :1084
             if ((int64_t)e_lps <= (int64_t)limit_e) {
                 uint64_t mask = ((uint64_t)EW(1) << 32) | EW(0);              // snapshot, :1088
+                const uint64_t listed0 = mask & ~e_scored;                    // the candidates this visit evaluates (what se_publish listed)
                 while (mask) {
                     int idx = __ffsll((long long)mask) - 1;
                     uint64_t bit = 1ull << idx;
@@ -684,137 +1051,13 @@ struct Aligner {
                     const int64_t orig_loc = loc, elem_loc = loc;
                     bool loc_non_alt = !cfg.alt_aware || !is_alt(loc);
 
-                    uint32_t sc = (uint32_t)SNAPGPU_ScoreAboveLimit;
-                    double mp = 0.0;
-                    const int64_t glen = (int64_t)read_len + SNAPGPU_MAX_K;
-                    int used_ag = 0, clip_before = 0, clip_after = 0, ag_score = -1;
                     int cand_seed_offset = (int)((EW(20 + (idx >> 1)) >> (16 * (idx & 1))) & 0xffffu);
-
-                    if (substring_ok(loc, glen)) {
-                        // Landau-Vishkin works on bit planes (planes.h) when the context has them and the limit's 2k + 1 diagonals fit
-                        // the wave; the byte window is only staged for what reads bytes: the gapless walk, affine gap
-                        const bool lv_planes = !HAM && ix.planes != nullptr && limit_e <= 31;
-                        if (lv_planes) stage_planes(loc); else stage_window(loc);
-                        const uint8_t *data = gw + WIN_PAD;                   // data[i] = genome[loc + i]
-                        const int seed_len = (int)ix.seed_len;
-                        const int seed_offset = cand_seed_offset;
-                        const int tail_start = seed_offset + seed_len;
-                        int ag1 = seed_len, ag2 = 0;
-                        int score1 = 0, score2 = 0;
-                        double mp1 = 1.0, mp2 = 1.0;
-                        int loc_offset = 0;
-                        const int text_len = read_len + SNAPGPU_MAX_K - tail_start;
-
-                        // Two halves, one call site each for LV and AG (half 0: forward from the end of the seed
-                        // over the tail of the read, :1160; half 1: backwards from the start of the seed over the
-                        // reversed head of the read, :1169).  The backward text/pattern are the same bytes walked
-                        // with stride -1, so LandauVishkin<1> and <-1> are one instantiation.
-                        const uint8_t *rdd = e_dir ? rd[1] : rd[0], *qld = e_dir ? ql[1] : ql[0];
-                        int g1 = 0, g2 = 0;                                     // score1Gapless / score2Gapless
-                        if constexpr (HAM) {                                    // :1177-1199
-                            if (tail_start != read_len) {
-                                int po;
-                                ag1 = gapless_score(+1, data + tail_start, rdd + tail_start, qld + tail_start, read_len - tail_start, read_len,
-                                                    limit_e, &score1, &po, &mp1, &g1);
-                                ag1 += seed_len - read_len;
-                            }
-                            if (g1 != -1 && seed_offset != 0) {
-                                int po = 0;
-                                ag2 = gapless_score(-1, data + seed_offset - 1, rdd + seed_offset - 1, qld + seed_offset - 1, seed_offset, read_len,
-                                                    limit_e - g1, &score2, &po, &mp2, &g2);
-                                ag2 -= read_len;
-                                loc_offset = g2 != -1 ? po : 0;
-                            }
-                        }
-                        const uint64_t t_lv0 = clk();
-                        for (int half = 0; half < 2 && !HAM; half++) {
-                            if (half == 1 && score1 == -1) break;
-                            const int st = half == 0 ? 1 : -1;
-                            const int org = half == 0 ? tail_start : seed_offset - 1;
-                            const int plen = half == 0 ? read_len - tail_start : seed_offset;
-                            const int tlen = half == 0 ? text_len : seed_offset + SNAPGPU_MAX_K;
-                            const int lim = half == 0 ? limit_e : limit_e - score1;
-                            ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
-                            LvPlanes lp;
-                            if (lv_planes) {
-                                const int rpw = (int)read_plane_words(cfg.RL);
-                                const LDS_AS unsigned long long *rb = (const LDS_AS unsigned long long *)rp + (e_dir ? 4 * rpw : 0);
-                                const LDS_AS unsigned long long *tb = (const LDS_AS unsigned long long *)tp;
-                                lp.p0 = rb; lp.p1 = rb + rpw; lp.pn = rb + 2 * rpw; lp.po = rb + 3 * rpw;
-                                lp.t0 = tb; lp.t1 = tb + TEXT_PLANE_BLOCKS; lp.tn = tb + 2 * TEXT_PLANE_BLOCKS;
-                                lp.p_org = org; lp.t_org = tp_org + org; lp.st = st; lp.p_words = rpw; lp.t_words = TEXT_PLANE_BLOCKS;
-                            }
-                            LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab, cfg.RL, lv_planes ? &lp : nullptr);
-                            // results are wave-uniform; say so, so they (and everything derived from them) live in SGPRs
-                            r.score = (int)first_u32((uint32_t)r.score); r.net_indel = (int)first_u32((uint32_t)r.net_indel);
-                            r.match_probability = first_f64(r.match_probability);
-                            if (half == 0) {
-                                score1 = r.score; mp1 = r.match_probability;
-                                ag1 = (seed_len + read_len - tail_start - score1) * cfg.match_reward - score1 * cfg.sub_penalty;
-                                cnt.lv_ref_bytes += (uint64_t)plen + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e));
-                            } else {
-                                score2 = r.score; mp2 = r.match_probability; loc_offset = r.net_indel;
-                                ag2 = (seed_offset - score2) * cfg.match_reward - score2 * cfg.sub_penalty;
-                                cnt.lv_ref_bytes += (uint64_t)plen;
-                            }
-                        }
-                        if (!HAM) cnt.lv++;
-                        cnt.cyc_lv += clk() - t_lv0;
-
-                        if (!HAM && score1 != -1 && score2 != -1) {
-                            int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);     // :1148
-                            if (cfg.use_ag && (score1 + score2 > max_k_same && e_lps <= (uint32_t)all.best_score)) {   // :1203
-                                if (lv_planes) stage_window(loc);             // affine gap reads bytes
-                                score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0;
-                                used_ag = 1;
-                                cnt.ag++;
-                                if (++ag_calls_unit == WAVE_PRIO_HEAVY_AFTER) wave_set_priority(1);
-                                const uint64_t t_ag0 = clk();
-                                AGParams agp{cfg.match_reward, cfg.sub_penalty, cfg.gap_open, cfg.gap_extend, cfg.five_bonus, cfg.three_bonus};
-                                for (int half = 0; half < 2; half++) {
-                                    if (half == 0 && tail_start == read_len) continue;               // :1208
-                                    if (half == 1 && (score1 == -1 || seed_offset == 0)) break;      // :1244-1245
-                                    const int st = half == 0 ? 1 : -1;
-                                    const int org = half == 0 ? tail_start : seed_offset - 1;
-                                    const int plen = half == 0 ? read_len - tail_start : seed_offset;
-                                    const int lim = half == 0 ? limit_e : limit_e - score1;
-                                    const int tlen = half == 0 ? text_len : seed_offset + lim;
-                                    const bool banded = plen >= 3 * (2 * lim + 1);                   // :1213 / :1251
-                                    ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
-                                    note_ag_extent(half, banded, plen, lim, tlen);
-                                    AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, e_dir != 0,
-                                                                  false, ag_rows, EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab);
-                                    a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
-                                    a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
-                                    a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
-                                    note_ag_call(half, (uint32_t)a.stale_reads);
-                                    if (half == 0) {
-                                        ag1 = a.ag_score + (seed_len - read_len); clip_after = a.pattern_offset;
-                                        score1 = a.n_edits; mp1 = a.match_probability;
-                                    } else {
-                                        ag2 = a.ag_score - read_len; clip_before = a.pattern_offset;
-                                        score2 = a.n_edits; mp2 = a.match_probability; loc_offset = a.text_offset;
-                                    }
-                                }
-                                cnt.cyc_ag += clk() - t_ag0;
-                            }
-                        }
-
-                        bool found = HAM ? (g1 != -1 && g2 != -1) : (score1 != -1 && score2 != -1);               // :1293
-                        if (found && loc_offset != 0 && !substring_ok(loc + loc_offset, glen)) found = false;   // :1295-1301
-                        if (found) {
-                            sc = (uint32_t)(score1 + score2);
-                            mp = mp1 * mp2 * tab->seed_prob;                  // :1314
-                            loc += loc_offset;
-                            ag_score = ag1 + ag2;
-                        } else {
-                            sc = (uint32_t)SNAPGPU_ScoreAboveLimit;
-                            ag_score = SNAPGPU_ScoreAboveLimit;
-                            mp = 0.0;
-                        }
-                    } else {
-                        mp = 0.0;
-                    }
+                    CandEval ce;
+                    bool have = false;
+                    if constexpr (!EXACT && !HAM) { if (se_slot >= 0) have = se_take(ei, idx, listed0, limit_e, e_lps, loc, cand_seed_offset, ce); }
+                    if (!have) ce = eval_candidate<HAM>(loc, e_dir, e_lps, cand_seed_offset, limit_e, (uint32_t)all.best_score);
+                    const uint32_t sc = ce.sc; const double mp = ce.mp; loc = ce.loc;
+                    const int used_ag = ce.used_ag, clip_before = ce.clip_before, clip_after = ce.clip_after, ag_score = ce.ag_score;
 
                     // ---- bookkeeping after scoring one candidate (:1349-1519)
                     uint32_t e_best = e_best_cur;
@@ -914,6 +1157,22 @@ struct Aligner {
         if (ag_calls_unit >= WAVE_PRIO_HEAVY_AFTER) wave_set_priority(0);
         cnt.cyc_total += clk() - t_read0;
     }
+    // the read into LDS, forward and reverse complement (BaseAligner.cpp:388-396); returns its number of 'N's
+    __device__ __forceinline__ uint32_t load_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
+        uint32_t n_count = 0;
+        for (int i0 = 0; i0 < len; i0 += WAVE) {
+            int i = i0 + lane;
+            uint8_t b = 0, q = 0;
+            if (i < len) {
+                b = g_bases[i]; q = g_quals[i];
+                rd[0][i] = b; ql[0][i] = q;
+                rd[1][len - 1 - i] = rc_base(b);
+                ql[1][len - 1 - i] = q;
+            }
+            n_count += (uint32_t)__popcll(BALLOT(i < len && b == 'N'));
+        }
+        return n_count;
+    }
     template <bool HAM>
     __device__ __forceinline__ void align_read_inner(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         read_len = len;
@@ -933,18 +1192,7 @@ struct Aligner {
         if (len < seed_len || len > (int)cfg.RL) return;                      // :360 (too long is rejected on the host)
 
         // load the read, build the reverse complement (:388-396)
-        uint32_t n_count = 0;
-        for (int i0 = 0; i0 < len; i0 += WAVE) {
-            int i = i0 + lane;
-            uint8_t b = 0, q = 0;
-            if (i < len) {
-                b = g_bases[i]; q = g_quals[i];
-                rd[0][i] = b; ql[0][i] = q;
-                rd[1][len - 1 - i] = rc_base(b);
-                ql[1][len - 1 - i] = q;
-            }
-            n_count += (uint32_t)__popcll(BALLOT(i < len && b == 'N'));
-        }
+        const uint32_t n_count = load_read(g_bases, g_quals, len);
         for (uint32_t i = lane; i < (cfg.RL + 31) / 32; i += WAVE) seed_used[i] = 0;
         WAVE_SYNC();
         if (n_count > max_k) return;                                          // :398
@@ -978,6 +1226,7 @@ struct Aligner {
         popular_seeds_skipped = 0;
         ag_stale = 0; ag_replay = 0;
         n_agc = 0; agc_overflow = 0;
+        se_tried = 0;
         bool finished = false;
 
         while (n_seeds_applied[0] + n_seeds_applied[1] < max_seeds_to_use) {
@@ -1041,6 +1290,7 @@ struct Aligner {
             }
         }
         if (!finished) score<HAM>(true);                                      // :734
+        if constexpr (!EXACT && !HAM) { if (se_slot >= 0) se_close(); }       // (before the candidate table is released: helpers read it)
         primary.score_prior_to_clipping = primary.score;                      // finalizeSecondaryResults, :2442
         primary.reserved = (ag_stale & 0x3fffffffu) | (ag_replay ? 0x40000000u : 0u);      // bit 30: the exact pass must redo this read
         release_candidates();

@@ -36,6 +36,8 @@ struct AlignArgs {
     //   [64 + S, 64 + 2S)             clock when wave slot s ran out of reads
     //   [64 + 2S, 64 + 3S)            cycles of the slot's most expensive read << 24 | its affine-gap calls (capped)
     unsigned long long *dbg; uint32_t dbg_slots;
+    // help for heavy reads (se_help.h): slots, one record array of se_spec_cap entries per slot, [done reads | idle waves]; NULL: none
+    SEHelpSlot *se_slots; uint32_t se_n_slots; SESpec *se_spec; uint32_t se_spec_cap; uint32_t *se_ctl; uint32_t se_eager;
 };
 
 extern "C" {
@@ -46,6 +48,7 @@ void snapgpu_launch_single_sec_0(const AlignArgs *a, uint32_t blocks, size_t lds
 void snapgpu_launch_single_exact_3(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_0(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_3_timed(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_3_timed(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 }
 
 static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }
@@ -67,7 +70,7 @@ static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uin
     L.ag = o; o += (ag_lds + 15) & ~15u;
     L.shared = o; o += ((uint32_t)sizeof(WaveShared) + 15) & ~15u;
     L.rp = o; o += (2 * 4 * read_plane_words(RL) * 8 + 15) & ~15u;          // read planes: [direction][code bit 0, code bit 1, N, other][word]
-    L.tp = o; o += (3 * TEXT_PLANE_BLOCKS * 8 + 15) & ~15u;                 // text planes of the candidate window: [plane][block]
+    L.tp = o; o += (3 * text_plane_blocks(RL, WIN_PAD) * 8 + 15) & ~15u;    // text planes of the candidate window: [plane][block]
     L.total = o;
     return L;
 }

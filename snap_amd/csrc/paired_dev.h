@@ -513,6 +513,8 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     al.agc_cap = a.single_agc_cap;
     al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     al.ag_calls_unit = 0;
+    al.se_slots = nullptr; al.se_n_slots = 0; al.se_spec = nullptr; al.se_spec_cap = 0; al.se_ctl = nullptr; al.se_eager = 0; al.se_diag = nullptr;
+    al.se_items = nullptr; al.se_first = nullptr; al.se_slot = -1; al.se_n = 0; al.se_tried = 0; al.cur_read = 0; al.se_mine = nullptr;      // (se_help.h: single-end path only)
 
     if constexpr (SEC) {            // secondary-result lists of the single-end aligner (as k_align_single<.., true> lays them out)
         al.sec_cfg = a.ssec_cfg;

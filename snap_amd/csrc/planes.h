@@ -17,7 +17,8 @@
 #include "dev_common.h"
 
 #define PLANE_WORDS_PER_BLOCK 3
-#define TEXT_PLANE_BLOCKS 9            // blocks staged per candidate window: 63 + WIN_PAD + RL + WIN_PAD bits, + 1 so that x[w + 1] exists
+// blocks of 64 bases staged per candidate window: up to 63 bits of misalignment + pad + read + pad, + 1 so that x[w + 1] exists
+static __host__ __device__ __forceinline__ uint32_t text_plane_blocks(uint32_t RL, uint32_t win_pad) { return (63 + 2 * win_pad + RL + 63) / 64 + 1; }
 
 // words per plane of a read: ceil(RL / 64) + 1 (the extra word lets a 64-bit window start anywhere: plane_bits_fwd)
 static __host__ __device__ __forceinline__ uint32_t read_plane_words(uint32_t RL) { return (RL + 63) / 64 + 1; }

@@ -50,6 +50,12 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     }
     al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t n_done = 0;
+    // help for heavy reads (se_help.h): not in the exact replay, not without the context's arrays
+    const bool se_on = !EXACT && a.se_slots != nullptr && a.cfg.se_items_cap != 0;
+    al.se_slots = se_on ? a.se_slots : nullptr; al.se_n_slots = a.se_n_slots; al.se_spec = a.se_spec; al.se_spec_cap = a.se_spec_cap;
+    al.se_ctl = a.se_ctl; al.se_eager = a.se_eager; al.se_diag = a.counters + 14;
+    al.se_items = (uint32_t *)(sc + a.cfg.se_off); al.se_first = al.se_items + a.cfg.se_items_cap;
+    al.se_slot = -1; al.se_n = 0; al.se_tried = 0; al.cur_read = 0; al.se_mine = nullptr;
 
     // EXACT kernels run either over a list of flagged reads (remap: the replay pass behind the register variants for long reads) or, as
     // the main pass of the 192-position variant, over the whole batch
@@ -69,6 +75,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
             al.ag_hw0 = al.ag_hw1 = 0;
             WAVE_SYNC();
         }
+        al.cur_read = i;
         uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
         const uint64_t dbg_t0 = TIMED ? wave_clock() : 0; const uint64_t dbg_ag0 = al.cnt.ag;
         al.align_read(a.bases + b, a.quals + b, (int)(e - b));
@@ -115,6 +122,53 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
             WAVE_SYNC();
         }
         n_done++;
+        if (se_on && lane == 0) atomicAdd(&a.se_ctl[0], 1u);
+    }
+    if constexpr (!EXACT) {
+        // Out of reads: until every read of the launch is done, evaluate candidates of the reads that have published their lists.
+        if (se_on) {
+            if (lane == 0) atomicAdd(&a.se_ctl[1], 1u);                   // one more idle wave: forced walks start publishing
+            const uint64_t t_idle0 = wave_clock();
+            for (uint32_t round = 0;; round++) {
+                if (XW::aload(&a.se_ctl[0]) >= n_total) break;
+                if ((round & 63u) == 0u && wave_clock() - t_idle0 > 48000000000ull) {      // ~20 s: stop waiting, leave a trace
+                    if (lane == 0) atomicAdd(&a.counters[14], 1ull << 32);
+                    break;
+                }
+                bool any = false;
+                for (uint32_t s = 0; s < a.se_n_slots; s++) {
+                    SEHelpSlot *slot = &a.se_slots[s];
+                    if (XW::aload(&slot->state) != 1u) continue;
+                    if (XW::aload(&slot->next) >= XW::ld(slot->n)) continue;
+                    // attach, THEN look at the state again (the owner does the mirror image: close, then look at the attach count)
+                    uint32_t before = 0;
+                    if (lane == 0) before = atomicAdd(&slot->helpers, 1u);
+                    before = first_u32(before);
+                    if (before < 0x7fffffffu && XW::aload(&slot->state) == 1u) {
+                        XW::fence_acquire();
+                        const uint32_t r = XW::ld(slot->read);
+                        if (r < a.n_reads) {
+                            const uint64_t rb = first_u64(a.offsets[r]), re = first_u64(a.offsets[r + 1]);
+                            const int len = (int)(re - rb);
+                            if (len >= (int)a.ix.seed_len && len <= (int)a.cfg.RL) {
+                                al.read_len = len;
+                                (void)al.load_read(a.bases + rb, a.quals + rb, len);
+                                WAVE_SYNC();
+                                if (a.ix.planes != nullptr) al.build_read_planes(len);
+                                al.se_help_slot(slot);
+                                any = true;
+                            }
+                        }
+                    }
+                    if (lane == 0) atomicSub(&slot->helpers, 1u);
+                }
+#ifdef SNAPGPU_WAVE_EMU
+                // (emulator: see paired_dev.h -- a wave that waits can keep the reads it waits for from ever starting)
+                if (!getenv("SNAPGPU_EMU_HELP_SPIN")) break;
+#endif
+                if (!any) { XW::nap(); XW::nap(); }
+            }
+        }
     }
     if constexpr (TIMED) {
         if (a.dbg && lane == 0 && wave_slot < a.dbg_slots) { a.dbg[64 + a.dbg_slots + wave_slot] = wave_clock(); a.dbg[64 + 2 * a.dbg_slots + wave_slot] = dbg_worst; }

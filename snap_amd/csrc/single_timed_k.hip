@@ -16,3 +16,9 @@ extern "C" void snapgpu_launch_single_exact_3_timed(const AlignArgs *a, uint32_t
 {
     hipLaunchKernelGGL((k_align_single<3, false, true, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
 }
+
+// the same for the fast form (the main pass when the help for heavy reads is on: se_help.h)
+extern "C" void snapgpu_launch_single_3_timed(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_align_single<3, false, false, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
+}

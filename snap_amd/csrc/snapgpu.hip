@@ -277,6 +277,10 @@ struct snapgpu_ctx {
     bool single_heavy_first = true;
     bool phase_timers = false;        // SNAPGPU_PHASE_TIMERS=1: launch the instantiation that carries the s_memtime phase timers
     uint32_t *d_order = nullptr, *d_wbucket = nullptr, *d_whist = nullptr; size_t order_cap = 0;
+    // help for heavy reads (se_help.h): on unless SNAPGPU_SINGLE_HELP=0 at snapgpu_create (then the 192-position variant runs the exact
+    // form as its main pass again, as in round 2)
+    bool single_help = true, single_help_eager = false;
+    SEHelpSlot *d_se_slots = nullptr; SESpec *d_se_spec = nullptr; uint32_t *d_se_ctl = nullptr; uint32_t se_spec_cap = 0;
     unsigned long long *d_dbg = nullptr;          // phase_timers: launch diagnostics of the last single-end launch (kernel_common.h: AlignArgs::dbg)
     bool paired_sec = false;
     PairedArgs pargs_sec{}, pargs_sec_big{};
@@ -434,6 +438,9 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_help) (void)hipFree(ctx->d_help);
     if (ctx->d_help_spec) (void)hipFree(ctx->d_help_spec);
     if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
+    if (ctx->d_se_slots) (void)hipFree(ctx->d_se_slots);
+    if (ctx->d_se_spec) (void)hipFree(ctx->d_se_spec);
+    if (ctx->d_se_ctl) (void)hipFree(ctx->d_se_ctl);
     if (ctx->d_planes && ctx->owns_planes) (void)hipFree(ctx->d_planes);
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
@@ -449,11 +456,14 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
 
 // Device-native hash layout (bucket.h): built on the GPU from the reference's slot arrays once they are in HBM
 // (snapgpu_create for uploaded / adopted blobs, snapgpu_broadcast_index for the replicas it fills).
-// The bit-plane shadow of the genome (planes.h), from the byte genome already in HBM -- however it got there.  SNAPGPU_NO_PLANES=1: none
-// (Landau-Vishkin then compares bytes, as in rounds 1-2).
+// The bit-plane shadow of the genome (planes.h), from the byte genome already in HBM -- however it got there.
+// Built, and used by Landau-Vishkin, when SNAPGPU_LV_PLANES=1 (and not SNAPGPU_NO_PLANES=1).  NOT the default: measured on the bench batch
+// (profiles/r03e) the plane form stages 2.7x fewer reference bytes per scored location but spends MORE instructions -- 1.59 M wave cycles
+// per read against 1.48 M, Landau-Vishkin 22 % of them against 16 %: most calls end after one or two levels, where the byte form has
+// built three or five bitmaps and the plane form all 2k + 1 -- for the same launch time.  DESIGN.md section 16.
 static int build_planes(snapgpu_ctx *ctx)
 {
-    if (getenv("SNAPGPU_NO_PLANES")) return SNAPGPU_OK;
+    if (getenv("SNAPGPU_NO_PLANES") || !getenv("SNAPGPU_LV_PLANES") || atoi(getenv("SNAPGPU_LV_PLANES")) == 0) return SNAPGPU_OK;
     const uint64_t n_bytes = ctx->ix.n_bases + 2 * (uint64_t)ctx->ix.genome_pad;
     const uint64_t n_blocks = (n_bytes + 63) / 64 + 32;
     if (!ctx->d_planes) {
@@ -623,7 +633,7 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         const int brc = build_buckets(ctx);
         if (brc != SNAPGPU_OK) { snapgpu_destroy(ctx); return brc; }
     }
-    if (g_share_buckets_from && g_share_buckets_from->d_planes && idx->on_device && !getenv("SNAPGPU_NO_PLANES")) {       // a feeder context: adopt the shadow too
+    if (g_share_buckets_from && g_share_buckets_from->d_planes && idx->on_device && !getenv("SNAPGPU_NO_PLANES") && getenv("SNAPGPU_LV_PLANES")) {       // a feeder context: adopt the shadow too
         ctx->d_planes = g_share_buckets_from->d_planes; ctx->owns_planes = false; ctx->plane_bytes = g_share_buckets_from->plane_bytes;
         ix.planes = ctx->d_planes;
     } else if (idx->on_device || idx->genome != nullptr) {
@@ -665,7 +675,11 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         if (getenv("SNAPGPU_AG_LDS")) ctx->ag_variant = 0;
     }
     size_t ag_bytes = c.ag_buffers ? ag_scratch_bytes(c.RL) : 0;
-    c.scratch_stride = ((size_t)c.ht_size * 2 + (size_t)c.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
+    if (const char *e = getenv("SNAPGPU_SINGLE_HELP")) ctx->single_help = atoi(e) != 0;
+    if (const char *e = getenv("SNAPGPU_SINGLE_HELP_EAGER")) ctx->single_help_eager = atoi(e) != 0;
+    c.se_items_cap = ctx->single_help ? 8192u : 0u;
+    c.se_off = ((size_t)c.ht_size * 2 + (size_t)c.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
+    c.scratch_stride = (c.se_off + ((size_t)c.se_items_cap + (c.se_items_cap ? c.pool_size : 0u)) * 4 + 255) & ~(size_t)255;
     c.ag_lds = !c.ag_buffers ? 0u : (ctx->ag_variant == 3 ? ag_lds_bytes_reg(c.RL, 3) : ag_lds_bytes(c.RL));
     LdsLayout L = lds_layout(c.RL, c.num_weight_lists, c.kmax, c.ag_lds);
     c.lds_per_wave = L.total;
@@ -687,7 +701,9 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         // Exactness of the banded affine-gap traceback.  192-position variant (reads up to ~170 bp): every wave keeps
         // the images of the reference objects' traceback arrays and the exact kernel is the only pass.  Longer reads: fast pass with the
         // arrays forgotten between calls + a replay of the flagged reads on 64 waves (kernel_common.h: AlignArgs::persist).
-        ctx->always_exact = ctx->ag_variant == 3 && !getenv("SNAPGPU_NO_ALWAYS_EXACT");
+        // (with the help for heavy reads on -- the default since round 3 -- the main pass is the fast form: an idle wave cannot take part in
+        //  a walk that is ordered through the traceback arrays its calls share)
+        ctx->always_exact = ctx->ag_variant == 3 && !getenv("SNAPGPU_NO_ALWAYS_EXACT") && !ctx->single_help;
         ctx->exact_slots = ctx->always_exact ? ctx->n_wave_slots : (ctx->n_wave_slots < 64 ? ctx->n_wave_slots : 64);
         ctx->exact_persist_stride = 2 * (uint64_t)((ag_bytes + 255) & ~(size_t)255);
         CRCHK(hipMalloc((void **)&ctx->d_exact_persist, (size_t)ctx->exact_slots * ctx->exact_persist_stride), SNAPGPU_E_NOMEM);
@@ -695,6 +711,12 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     }
     if (const char *e = getenv("SNAPGPU_SINGLE_HEAVY_FIRST")) ctx->single_heavy_first = atoi(e) != 0;
     if (const char *e = getenv("SNAPGPU_PHASE_TIMERS")) ctx->phase_timers = atoi(e) != 0;
+    if (ctx->single_help) {
+        ctx->se_spec_cap = c.se_items_cap;
+        CRCHK(hipMalloc((void **)&ctx->d_se_slots, SE_HELP_SLOTS * sizeof(SEHelpSlot)), SNAPGPU_E_NOMEM);
+        CRCHK(hipMalloc((void **)&ctx->d_se_spec, (size_t)SE_HELP_SLOTS * ctx->se_spec_cap * sizeof(SESpec)), SNAPGPU_E_NOMEM);
+        CRCHK(hipMalloc((void **)&ctx->d_se_ctl, 256), SNAPGPU_E_NOMEM);
+    }
     CRCHK(hipMalloc((void **)&ctx->d_work, 256), SNAPGPU_E_NOMEM);
     CRCHK(hipMalloc((void **)&ctx->d_counters, sizeof(snapgpu_counters)), SNAPGPU_E_NOMEM);
     CRCHK(hipMemsetAsync(ctx->d_counters, 0, sizeof(snapgpu_counters), ctx->stream), SNAPGPU_E_NODEVICE);
@@ -1512,6 +1534,13 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.sec_cfg = SecCfg{-1, -1, 0, 0}; a.sec_scratch = nullptr; a.sec_stride_bytes = 0; a.secondary = nullptr; a.sec_out_stride = 0; a.n_secondary = nullptr;
     a.flag_list = nullptr; a.flag_count = nullptr; a.remap = nullptr; a.n_remap = nullptr; a.persist = nullptr; a.persist_stride = 0;
     a.is_replay = 0; a.order = nullptr; a.dbg = nullptr; a.dbg_slots = 0;
+    a.se_slots = nullptr; a.se_n_slots = 0; a.se_spec = nullptr; a.se_spec_cap = 0; a.se_ctl = nullptr; a.se_eager = 0;
+    if (ctx->single_help && ctx->d_se_slots && !d_n_secondary) {            // (fresh protocol state for the launch that is about to start)
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_se_slots, 0, SE_HELP_SLOTS * sizeof(SEHelpSlot), s), SNAPGPU_E_LAUNCH);
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_se_ctl, 0, 256, s), SNAPGPU_E_LAUNCH);
+        a.se_slots = ctx->d_se_slots; a.se_n_slots = SE_HELP_SLOTS; a.se_spec = ctx->d_se_spec; a.se_spec_cap = ctx->se_spec_cap;
+        a.se_ctl = ctx->d_se_ctl; a.se_eager = ctx->single_help_eager ? 1u : 0u;
+    }
     if (ctx->phase_timers) {
         const size_t words = 64 + 3 * (size_t)ctx->n_wave_slots;
         if (!ctx->d_dbg) HIPCHK(ctx, hipMalloc((void **)&ctx->d_dbg, words * 8), SNAPGPU_E_NOMEM);
@@ -1556,7 +1585,9 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
         }
     } else
     switch (ctx->ag_variant) {
-    case 3:  hipLaunchKernelGGL((k_align_single<3, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
+    case 3:  if (ctx->phase_timers) snapgpu_launch_single_3_timed(&a, blocks, 4 * ctx->cfg.lds_per_wave, s);
+             else hipLaunchKernelGGL((k_align_single<3, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a);
+             break;
     case 4:  hipLaunchKernelGGL((k_align_single<4, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
     case 6:  hipLaunchKernelGGL((k_align_single<6, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
     default: hipLaunchKernelGGL((k_align_single<0, false>), dim3(blocks), dim3(256), 4 * ctx->cfg.lds_per_wave, s, a); break;
@@ -1565,7 +1596,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     if (exact) {        // redo the flagged reads (usually none: the launch then ends at once) as a newly constructed reference aligner would
         AlignArgs x = a;
         x.flag_list = nullptr; x.flag_count = nullptr; x.remap = ctx->d_flag_list; x.n_remap = ctx->d_work + 4; x.work_counter = ctx->d_work + 3;
-        x.is_replay = 1; x.order = nullptr;
+        x.is_replay = 1; x.order = nullptr; x.se_slots = nullptr; x.se_ctl = nullptr;
         x.persist = ctx->d_exact_persist; x.persist_stride = ctx->exact_persist_stride;
         if (ctx->ag_variant == 3) snapgpu_launch_single_exact_3(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
         else snapgpu_launch_single_exact_0(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);

@@ -368,3 +368,42 @@ def test_emu_index_builder_vs_reference(emu, tmp_path):
     p2, _ = a_view.AlignRead(reads["bases"], reads["quals"], reads["offsets"])
     assert not util.compare_results(p1, p2)
     a_files.close(); a_view.close(); built.close()
+
+
+def test_emu_single_end_help_for_heavy_reads(emu, monkeypatch, tmp_path):
+    """se_help.h: a forced walk's remaining candidates published for idle waves (here: published eagerly, so that the path runs whatever
+    the emulator's scheduling does), on reads out of diverged high-copy repeats.  Every read against the reference with fresh aligner
+    objects; the work counters must equal the reference's and those of a run without the help."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built")
+    from snap_amd import synth
+    from snap_amd.aligner import BaseAligner
+    from snap_amd.index import GenomeIndex
+    d = str(tmp_path)
+    g = synth.make_genome(13, 1_500_000, n_contigs=2, repeat_frac=0.85, max_copies=280, repeat_len=(400, 1500), max_divergence=0.03)
+    synth.write_fasta(d + "/g.fa", g)
+    ref.build_index(d + "/g.fa", d + "/idx", 20, threads=8)
+    ix = GenomeIndex.load_from_directory(d + "/idx")
+    reads = synth.make_reads(7, g, 160, 150)
+    params = abi.default_params(max_k=8, max_read_len=160)
+    with ref.fresh_objects():
+        exp, _, rc, _ = ref.RefIndex(d + "/idx").align_single(params, reads["bases"], reads["quals"], reads["offsets"], threads=8)
+    out = {}
+    for mode, env in (("eager", {"SNAPGPU_SINGLE_HELP_EAGER": "1"}), ("off", {"SNAPGPU_SINGLE_HELP": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        a = BaseAligner(ix, params)
+        a.counters(reset=True)
+        got, _ = a.AlignRead(reads["bases"], reads["quals"], reads["offsets"])
+        out[mode] = (got, a.counters())
+        a.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert not util.compare_results(exp, got), mode
+    ce, co = out["eager"][1], out["off"][1]
+    assert ce["help_lists_published"] > 0 and ce["help_answers_used"] > 0 and ce["help_watchdog_events"] == 0
+    assert co["help_lists_published"] == 0
+    for k in ("n_hash_table_lookups", "n_hits_consumed", "n_lv_locations", "n_ag_locations", "n_lv_ref_bytes"):
+        assert ce[k] == co[k], k
+    assert [ce["n_hash_table_lookups"], ce["n_lv_locations"], ce["n_ag_locations"]] == [rc["lookups"], rc["lv"], rc["ag"]]
