@@ -416,7 +416,11 @@ def main():
                                                   if k in counters}   # paired: lookup = Phase 1, hits = Phase 2 (set intersection), lv/ag = paired scoring
         out["roofline"]["wave_cycles_per_read"] = counters["cycles_total"] / max(1, counters["n_reads"])
     if paired:
-        out["roofline"]["phase4_help"] = {"watchdog_events": counters.get("help_watchdog_events", 0), "min_candidates": os.environ.get("SNAPGPU_PAIRED_HELP_MIN", "64 (default)")}
+        out["roofline"]["phase4_help"] = {"watchdog_events": counters.get("help_watchdog_events", 0), "min_candidates": os.environ.get("SNAPGPU_PAIRED_HELP_MIN", "64 (default)"),
+                                          "lists_published": counters.get("help_lists_published", 0), "answers_used": counters.get("help_answers_used", 0)}
+    else:       # se_help.h: forced walks published for idle waves, stored evaluations the owners' ordered walks took (summed over the timed launches)
+        out["roofline"]["heavy_read_help"] = {"enabled": os.environ.get("SNAPGPU_SINGLE_HELP", "1") != "0", "lists_published": counters.get("help_lists_published", 0),
+                                              "evaluations_taken": counters.get("help_answers_used", 0), "watchdog_events": counters.get("help_watchdog_events", 0)}
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:

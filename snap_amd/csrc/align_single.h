@@ -194,7 +194,7 @@ struct Aligner {
     uint32_t ag_calls_unit;            // affine-gap calls since the unit (read; the paired kernel: pair) began -- see wave_set_priority
     // ---- help for heavy reads (se_help.h); all NULL / 0 where there is none (the paired-end kernel, the exact replay)
     SEHelpSlot *se_slots; uint32_t se_n_slots; SESpec *se_spec; uint32_t se_spec_cap;
-    uint32_t *se_ctl;                  // [0] reads of the launch that are done, [1] waves that have run out of reads
+    uint32_t *se_ctl;                  // [0] reads of the launch that are done, [1] waves that have run out of reads, [2] lists open now
     uint32_t se_eager;                 // publish whether or not anybody is idle (tests)
     uint32_t *se_items, *se_first;     // this wave's list / per-element start (HBM slab)
     unsigned long long *se_diag;       // snapgpu_counters::reserved[1 .. 2]
@@ -811,6 +811,7 @@ struct Aligner {
             XW::st(*(uint64_t *)&slot->spec, (uint64_t)(uintptr_t)spec);
             XW::fence_release();                            // the candidate table, the list and the cleared records, for the other XCDs
             atomicExch(&slot->state, 1u);
+            atomicAdd(&se_ctl[2], 1u);
             if (se_diag) atomicAdd(&se_diag[1], 1ull << 32);
         }
         WAVE_SYNC();
@@ -882,7 +883,7 @@ struct Aligner {
     }
 
     __device__ __forceinline__ void se_abandon() {          // after a watchdog: the slot is retired for the rest of the launch
-        if (lane == 0) atomicExch(&se_slots[se_slot].state, 4u);
+        if (lane == 0) { atomicExch(&se_slots[se_slot].state, 4u); atomicSub(&se_ctl[2], 1u); }
         se_slot = -1;
     }
 
@@ -890,7 +891,7 @@ struct Aligner {
     __device__ __forceinline__ void se_close() {
         SEHelpSlot *slot = &se_slots[se_slot];
         uint32_t was = 0;
-        if (lane == 0) was = atomicExch(&slot->state, 2u);
+        if (lane == 0) { was = atomicExch(&slot->state, 2u); atomicSub(&se_ctl[2], 1u); }
         was = first_u32(was);
         bool gave_up = was != 1u;
         const uint64_t t0 = wave_clock();

@@ -28,6 +28,7 @@
 #define SE_HELP_MIN_ITEMS 48u          // fewer candidates left than this: not worth a publication
 #define SE_HELP_LOOKAHEAD 4u           // helpers start this many items ahead of the owner
 #define SE_HELP_CHUNK 2u
+#define SE_HELP_MAX_HELPERS 24u        // idle waves attached to one list at a time
 
 struct __attribute__((aligned(16))) SESpec {       // one candidate's evaluation
     uint32_t state;                    // 0 untouched, 1 somebody is evaluating it, 2 done
@@ -98,7 +99,7 @@ struct XW {
 #ifdef SNAPGPU_WAVE_EMU
         emu_yield();
 #else
-        __builtin_amdgcn_s_sleep(64);
+        __builtin_amdgcn_s_sleep(127);
 #endif
     }
 };

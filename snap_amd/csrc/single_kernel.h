@@ -129,44 +129,51 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         if (se_on) {
             if (lane == 0) atomicAdd(&a.se_ctl[1], 1u);                   // one more idle wave: forced walks start publishing
             const uint64_t t_idle0 = wave_clock();
+            // (Polling is done with plain device-scope LOADS of words that only atomics write -- a stale value merely postpones a decision, and
+            //  the attach below re-reads the state through the atomic unit -- and an idle wave sleeps ~30 us between looks while nothing is
+            //  published: thousands of idle waves scanning the slots with read-modify-write atomics were measured to slow the whole launch
+            //  down by half, profiles/r03f.)
             for (uint32_t round = 0;; round++) {
-                if (XW::aload(&a.se_ctl[0]) >= n_total) break;
+                if (XW::ld(a.se_ctl[0]) >= n_total) break;
                 if ((round & 63u) == 0u && wave_clock() - t_idle0 > 48000000000ull) {      // ~20 s: stop waiting, leave a trace
                     if (lane == 0) atomicAdd(&a.counters[14], 1ull << 32);
                     break;
                 }
                 bool any = false;
-                for (uint32_t s = 0; s < a.se_n_slots; s++) {
-                    SEHelpSlot *slot = &a.se_slots[s];
-                    if (XW::aload(&slot->state) != 1u) continue;
-                    if (XW::aload(&slot->next) >= XW::ld(slot->n)) continue;
-                    // attach, THEN look at the state again (the owner does the mirror image: close, then look at the attach count)
-                    uint32_t before = 0;
-                    if (lane == 0) before = atomicAdd(&slot->helpers, 1u);
-                    before = first_u32(before);
-                    if (before < 0x7fffffffu && XW::aload(&slot->state) == 1u) {
-                        XW::fence_acquire();
-                        const uint32_t r = XW::ld(slot->read);
-                        if (r < a.n_reads) {
-                            const uint64_t rb = first_u64(a.offsets[r]), re = first_u64(a.offsets[r + 1]);
-                            const int len = (int)(re - rb);
-                            if (len >= (int)a.ix.seed_len && len <= (int)a.cfg.RL) {
-                                al.read_len = len;
-                                (void)al.load_read(a.bases + rb, a.quals + rb, len);
-                                WAVE_SYNC();
-                                if (a.ix.planes != nullptr) al.build_read_planes(len);
-                                al.se_help_slot(slot);
-                                any = true;
+                if (XW::ld(a.se_ctl[2]) != 0u) {                              // lists open right now
+                    for (uint32_t s = 0; s < a.se_n_slots; s++) {
+                        SEHelpSlot *slot = &a.se_slots[s];
+                        if (XW::ld(slot->state) != 1u) continue;
+                        if (XW::ld(slot->next) >= XW::ld(slot->n)) continue;
+                        if (XW::ld(slot->helpers) >= SE_HELP_MAX_HELPERS) continue;
+                        // attach, THEN look at the state again (the owner does the mirror image: close, then look at the attach count)
+                        uint32_t before = 0;
+                        if (lane == 0) before = atomicAdd(&slot->helpers, 1u);
+                        before = first_u32(before);
+                        if (before < SE_HELP_MAX_HELPERS && XW::aload(&slot->state) == 1u) {
+                            XW::fence_acquire();
+                            const uint32_t r = XW::ld(slot->read);
+                            if (r < a.n_reads) {
+                                const uint64_t rb = first_u64(a.offsets[r]), re = first_u64(a.offsets[r + 1]);
+                                const int len = (int)(re - rb);
+                                if (len >= (int)a.ix.seed_len && len <= (int)a.cfg.RL) {
+                                    al.read_len = len;
+                                    (void)al.load_read(a.bases + rb, a.quals + rb, len);
+                                    WAVE_SYNC();
+                                    if (a.ix.planes != nullptr) al.build_read_planes(len);
+                                    al.se_help_slot(slot);
+                                    any = true;
+                                }
                             }
                         }
+                        if (lane == 0) atomicSub(&slot->helpers, 1u);
                     }
-                    if (lane == 0) atomicSub(&slot->helpers, 1u);
                 }
 #ifdef SNAPGPU_WAVE_EMU
                 // (emulator: see paired_dev.h -- a wave that waits can keep the reads it waits for from ever starting)
                 if (!getenv("SNAPGPU_EMU_HELP_SPIN")) break;
 #endif
-                if (!any) { XW::nap(); XW::nap(); }
+                if (!any) { for (int z = 0; z < 8; z++) XW::nap(); }
             }
         }
     }
