@@ -770,6 +770,18 @@ struct Aligner {
     // List what the forced walk still has to visit -- weight lists from wl down, first in first out, every unscored candidate of each
     // element -- and offer it to the idle waves.
     __device__ __forceinline__ void se_publish(uint32_t wl) {
+        // a slot first (the list is only worth building if there is one); none free: look again some elements further on
+        int s = -1;
+        if (lane == 0) {
+            const uint32_t start = (cur_read * 7u) % se_n_slots;
+            for (uint32_t k = 0; k < se_n_slots; k++) {
+                const uint32_t i = start + k < se_n_slots ? start + k : start + k - se_n_slots;
+                if (XW::ld_lane(se_slots[i].state) != 0u) continue;
+                if (atomicCAS(&se_slots[i].state, 0u, 3u) == 0u) { s = (int)i; break; }
+            }
+        }
+        s = (int)first_u32((uint32_t)s);
+        if (s < 0) { se_tried = 0x80000000u | 32u; return; }
         se_tried = 1;
         for (uint32_t i = (uint32_t)lane; i < n_used; i += WAVE) se_first[i] = 0xffffffffu;
         WAVE_SYNC();
@@ -790,13 +802,7 @@ struct Aligner {
             }
         }
         WAVE_SYNC();
-        if (n < SE_HELP_MIN_ITEMS || n > se_spec_cap) return;
-        int s = -1;
-        if (lane == 0) {
-            for (uint32_t i = 0; i < se_n_slots; i++) if (atomicCAS(&se_slots[i].state, 0u, 3u) == 0u) { s = (int)i; break; }
-        }
-        s = (int)first_u32((uint32_t)s);
-        if (s < 0) return;
+        if (n < SE_HELP_MIN_ITEMS || n > se_spec_cap) { if (lane == 0) atomicExch(&se_slots[s].state, 0u); return; }     // not worth it: give the slot back
         SEHelpSlot *slot = &se_slots[s];
         SESpec *spec = se_spec + (size_t)s * se_spec_cap;
         for (uint32_t t = (uint32_t)lane; t < n; t += WAVE) spec[t].state = 0u;
@@ -1014,7 +1020,10 @@ struct Aligner {
             }
 
             if constexpr (!EXACT && !HAM) {             // idle waves can take over part of what is left of a forced walk (se_help.h)
-                if (force_result && se_slots != nullptr && se_slot < 0 && !se_tried && se_wanted()) se_publish(wl);
+                if (force_result && se_slots != nullptr && se_slot < 0) {
+                    if (se_tried & 0x80000000u) { se_tried = (se_tried & 0x7fffffffu) > 1u ? se_tried - 1u : 0u; }     // (no slot was free: count down to the next look)
+                    else if (!se_tried && se_wanted()) se_publish(wl);
+                }
             }
             uint16_t ei = get_next(sent(wl));
             Elem *e = &pool[ei];

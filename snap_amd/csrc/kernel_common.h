@@ -38,6 +38,7 @@ struct AlignArgs {
     unsigned long long *dbg; uint32_t dbg_slots;
     // help for heavy reads (se_help.h): slots, one record array of se_spec_cap entries per slot, [done reads | idle waves]; NULL: none
     SEHelpSlot *se_slots; uint32_t se_n_slots; SESpec *se_spec; uint32_t se_spec_cap; uint32_t *se_ctl; uint32_t se_eager;
+    uint32_t se_keep;                 // every se_keep-th wave stays on as a helper when it runs out of reads (1: all)
 };
 
 extern "C" {

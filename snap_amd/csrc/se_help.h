@@ -24,11 +24,12 @@
 #pragma once
 #include "dev_common.h"
 
-#define SE_HELP_SLOTS 64u
+#define SE_HELP_SLOTS 384u            // lists open at a time: a launch of 1 M reads has ~300 reads of 50 ms and more (profiles/r03c)
 #define SE_HELP_MIN_ITEMS 48u          // fewer candidates left than this: not worth a publication
 #define SE_HELP_LOOKAHEAD 4u           // helpers start this many items ahead of the owner
 #define SE_HELP_CHUNK 2u
-#define SE_HELP_MAX_HELPERS 24u        // idle waves attached to one list at a time
+#define SE_HELP_MAX_HELPERS 16u        // idle waves attached to one list at a time
+#define SE_HELP_ITEMS_CAP 4096u        // candidates per published list (what is beyond stays with the owner)
 
 struct __attribute__((aligned(16))) SESpec {       // one candidate's evaluation
     uint32_t state;                    // 0 untouched, 1 somebody is evaluating it, 2 done
@@ -74,6 +75,14 @@ struct XW {
 #else
         if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, first_u64(__hip_atomic_load((const uint64_t *)&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
         else return __builtin_bit_cast(T, first_u32(__hip_atomic_load((const uint32_t *)&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+#endif
+    }
+    // the same load for code that only one lane runs (no broadcast)
+    static __device__ __forceinline__ uint32_t ld_lane(const uint32_t &x) {
+#ifdef SNAPGPU_WAVE_EMU
+        return __atomic_load_n(&x, __ATOMIC_SEQ_CST);
+#else
+        return __hip_atomic_load(&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     }
     static __device__ __forceinline__ void stores_done() {

@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     }
     if constexpr (!EXACT) {
         // Out of reads: until every read of the launch is done, evaluate candidates of the reads that have published their lists.
-        if (se_on) {
+        // Only every a.se_keep-th wave stays on as a helper; the others leave, so that their slots go to whatever launch is queued behind
+        // this one (another feeder's batch: measured with three feeders and every wave staying, 130 -> 179 ms per batch, profiles/r03g).
+        if (se_on && (a.se_keep <= 1u || wave_slot % a.se_keep == 0u)) {
             if (lane == 0) atomicAdd(&a.se_ctl[1], 1u);                   // one more idle wave: forced walks start publishing
             const uint64_t t_idle0 = wave_clock();
             // (Polling is done with plain device-scope LOADS of words that only atomics write -- a stale value merely postpones a decision, and
@@ -141,7 +143,9 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
                 }
                 bool any = false;
                 if (XW::ld(a.se_ctl[2]) != 0u) {                              // lists open right now
-                    for (uint32_t s = 0; s < a.se_n_slots; s++) {
+                    const uint32_t s_first = (wave_slot * 13u + round * 7u) % a.se_n_slots;      // (waves start their scan in different places)
+                    for (uint32_t k = 0; k < a.se_n_slots && !any; k++) {
+                        const uint32_t s = s_first + k < a.se_n_slots ? s_first + k : s_first + k - a.se_n_slots;
                         SEHelpSlot *slot = &a.se_slots[s];
                         if (XW::ld(slot->state) != 1u) continue;
                         if (XW::ld(slot->next) >= XW::ld(slot->n)) continue;

@@ -279,7 +279,7 @@ struct snapgpu_ctx {
     uint32_t *d_order = nullptr, *d_wbucket = nullptr, *d_whist = nullptr; size_t order_cap = 0;
     // help for heavy reads (se_help.h): on unless SNAPGPU_SINGLE_HELP=0 at snapgpu_create (then the 192-position variant runs the exact
     // form as its main pass again, as in round 2)
-    bool single_help = true, single_help_eager = false;
+    bool single_help = true, single_help_eager = false; uint32_t single_help_keep = 3;
     SEHelpSlot *d_se_slots = nullptr; SESpec *d_se_spec = nullptr; uint32_t *d_se_ctl = nullptr; uint32_t se_spec_cap = 0;
     unsigned long long *d_dbg = nullptr;          // phase_timers: launch diagnostics of the last single-end launch (kernel_common.h: AlignArgs::dbg)
     bool paired_sec = false;
@@ -677,7 +677,8 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     size_t ag_bytes = c.ag_buffers ? ag_scratch_bytes(c.RL) : 0;
     if (const char *e = getenv("SNAPGPU_SINGLE_HELP")) ctx->single_help = atoi(e) != 0;
     if (const char *e = getenv("SNAPGPU_SINGLE_HELP_EAGER")) ctx->single_help_eager = atoi(e) != 0;
-    c.se_items_cap = ctx->single_help ? 8192u : 0u;
+    if (const char *e = getenv("SNAPGPU_SINGLE_HELP_KEEP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->single_help_keep = (uint32_t)v; }
+    c.se_items_cap = ctx->single_help ? SE_HELP_ITEMS_CAP : 0u;
     c.se_off = ((size_t)c.ht_size * 2 + (size_t)c.pool_size * sizeof(Elem) + ag_bytes + 255) & ~(size_t)255;
     c.scratch_stride = (c.se_off + ((size_t)c.se_items_cap + (c.se_items_cap ? c.pool_size : 0u)) * 4 + 255) & ~(size_t)255;
     c.ag_lds = !c.ag_buffers ? 0u : (ctx->ag_variant == 3 ? ag_lds_bytes_reg(c.RL, 3) : ag_lds_bytes(c.RL));
@@ -1534,12 +1535,12 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.sec_cfg = SecCfg{-1, -1, 0, 0}; a.sec_scratch = nullptr; a.sec_stride_bytes = 0; a.secondary = nullptr; a.sec_out_stride = 0; a.n_secondary = nullptr;
     a.flag_list = nullptr; a.flag_count = nullptr; a.remap = nullptr; a.n_remap = nullptr; a.persist = nullptr; a.persist_stride = 0;
     a.is_replay = 0; a.order = nullptr; a.dbg = nullptr; a.dbg_slots = 0;
-    a.se_slots = nullptr; a.se_n_slots = 0; a.se_spec = nullptr; a.se_spec_cap = 0; a.se_ctl = nullptr; a.se_eager = 0;
+    a.se_slots = nullptr; a.se_n_slots = 0; a.se_spec = nullptr; a.se_spec_cap = 0; a.se_ctl = nullptr; a.se_eager = 0; a.se_keep = 1;
     if (ctx->single_help && ctx->d_se_slots && !d_n_secondary) {            // (fresh protocol state for the launch that is about to start)
         HIPCHK(ctx, hipMemsetAsync(ctx->d_se_slots, 0, SE_HELP_SLOTS * sizeof(SEHelpSlot), s), SNAPGPU_E_LAUNCH);
         HIPCHK(ctx, hipMemsetAsync(ctx->d_se_ctl, 0, 256, s), SNAPGPU_E_LAUNCH);
         a.se_slots = ctx->d_se_slots; a.se_n_slots = SE_HELP_SLOTS; a.se_spec = ctx->d_se_spec; a.se_spec_cap = ctx->se_spec_cap;
-        a.se_ctl = ctx->d_se_ctl; a.se_eager = ctx->single_help_eager ? 1u : 0u;
+        a.se_ctl = ctx->d_se_ctl; a.se_eager = ctx->single_help_eager ? 1u : 0u; a.se_keep = ctx->single_help_keep;
     }
     if (ctx->phase_timers) {
         const size_t words = 64 + 3 * (size_t)ctx->n_wave_slots;
