@@ -420,7 +420,10 @@ def main():
                                           "lists_published": counters.get("help_lists_published", 0), "answers_used": counters.get("help_answers_used", 0)}
     else:       # se_help.h: forced walks published for idle waves, stored evaluations the owners' ordered walks took (summed over the timed launches)
         out["roofline"]["heavy_read_help"] = {"enabled": os.environ.get("SNAPGPU_SINGLE_HELP", "1") != "0", "lists_published": counters.get("help_lists_published", 0),
-                                              "evaluations_taken": counters.get("help_answers_used", 0), "watchdog_events": counters.get("help_watchdog_events", 0)}
+                                              "evaluations_taken": counters.get("help_answers_used", 0), "watchdog_events": counters.get("help_watchdog_events", 0),
+                                              "evaluations_stored": counters.get("cycles_single_fallback", 0) >> 32,
+                                              "refused_other_band_or_decision": (counters.get("cycles_single_fallback", 0) >> 16) & 0xffff,
+                                              "refused_skipped_or_limit": counters.get("cycles_single_fallback", 0) & 0xffff}
     pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc):
         try:

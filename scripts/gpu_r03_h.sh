@@ -1,0 +1,8 @@
+# Round 3, eighth hardware call: the help for heavy single-end reads with enough slots; how many helpers to keep.
+O=gpurun_out/${1:-r03h}; mkdir -p $O
+run() { tag=$1; shift; ( timeout ${T:-300} "$@" > $O/$tag.out 2> $O/$tag.err; echo "rc=$?" >> $O/$tag.out ) ; echo "== $tag: $(tail -n 2 $O/$tag.out | tr '\n' ' ' | cut -c1-${W:-200}) $(grep -m1 -i 'fault\|error' $O/$tag.err | cut -c1-160)"; }
+SNAPGPU_SINGLE_HELP_KEEP=1 run f1_keep1 python bench.py --feeders 1 --steps 4 --skip-probe --skip-refwalk --cpu-sample 200000
+run f1_keep3 python bench.py --feeders 1 --steps 4 --skip-cpu --skip-probe --skip-refwalk --skip-breakdown
+run f3_keep3 python bench.py --skip-cpu --skip-probe --skip-refwalk --skip-breakdown
+SNAPGPU_SINGLE_HELP_KEEP=6 run f3_keep6 python bench.py --skip-cpu --skip-probe --skip-refwalk --skip-breakdown
+SNAPGPU_SINGLE_HELP_KEEP=6 run f2_keep6 python bench.py --feeders 2 --steps 4 --skip-cpu --skip-probe --skip-refwalk --skip-breakdown

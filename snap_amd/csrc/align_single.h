@@ -854,7 +854,7 @@ struct Aligner {
         uint32_t n_ag = XW::ld(sp->n_ag), stale = XW::ld(sp->stale);
         uint64_t bytes = XW::ld(sp->lv_ref_bytes);
         if (lim == limit_e) {
-            if (high && ((e_lps <= best_then) != (e_lps <= (uint32_t)all.best_score))) return false;  // the affine-gap decision (:1203) would differ
+            if (high && ((e_lps <= best_then) != (e_lps <= (uint32_t)all.best_score))) { if (lane == 0 && se_diag) atomicAdd(&se_diag[-1], 1ull << 16); return false; }  // the affine-gap decision (:1203) would differ
             ce.sc = XW::ld(sp->sc); ce.mp = XW::ld(sp->mp); ce.loc = XW::ld(sp->loc); ce.used_ag = XW::ld(sp->used_ag);
             ce.clip_before = XW::ld(sp->clip_before); ce.clip_after = XW::ld(sp->clip_after); ce.ag_score = XW::ld(sp->ag_score);
         } else {
@@ -862,14 +862,16 @@ struct Aligner {
             // k (LandauVishkin.h:100-351; SURVEY.md Appendix C: 12 M comparisons), so what it says under the owner's limit follows: the
             // same when the edits of both sides still fit, "above the limit" otherwise.  Affine gap is another matter -- its band is the limit --
             // so an evaluation in which it ran, or would run now, is redone.
-            if (lim < limit_e || n_lv == 0u) return false;
+            if (lim < limit_e || n_lv == 0u) { if (lane == 0 && se_diag) atomicAdd(&se_diag[-1], 1ull); return false; }
             const int lv1 = XW::ld(sp->lv1), lv2 = XW::ld(sp->lv2);
             const int plen0 = read_len - (cand_seed_offset + (int)ix.seed_len), plen1 = cand_seed_offset;
             const bool half1_runs = lv1 >= 0 && lv1 <= limit_e;
             bytes = (uint64_t)plen0 + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e)) + (half1_runs ? (uint64_t)plen1 : 0ull);
             if (half1_runs && lv2 >= 0 && lv1 + lv2 <= limit_e) {                 // both sides still fit
-                if (n_ag != 0u) return false;
-                if (high && e_lps <= (uint32_t)all.best_score) return false;       // affine gap would run now
+                if (n_ag != 0u || (high && e_lps <= (uint32_t)all.best_score)) {      // affine gap ran under another band, or would run now
+                    if (lane == 0 && se_diag) atomicAdd(&se_diag[-1], 1ull << 16);
+                    return false;
+                }
                 ce.sc = XW::ld(sp->sc); ce.mp = XW::ld(sp->mp); ce.loc = XW::ld(sp->loc); ce.used_ag = 0;
                 ce.clip_before = 0; ce.clip_after = 0; ce.ag_score = XW::ld(sp->ag_score);
             } else {                                                             // :1293-1347 with score1 or score2 == -1
@@ -964,6 +966,7 @@ struct Aligner {
                     XW::st(sp->lv1, (int32_t)ce.lv1); XW::st(sp->lv2, (int32_t)ce.lv2);
                     XW::stores_done();
                     atomicExch(&sp->state, 2u);
+                    if (se_diag) atomicAdd(&se_diag[-1], 1ull << 32);       // (snapgpu_counters::reserved[0]: evaluations stored << 32 | refused: limit | AG << 16)
 #if defined(SNAPGPU_WAVE_EMU)
                     if (getenv("SNAPGPU_DEBUG_SE_HELP")) fprintf(stderr, "HELPED read %u item %u limit %d sc %u n_ag %u\n", XW::ld(slot->read), t, rec_limit, ce.sc, d_ag);
 #endif

@@ -12,6 +12,8 @@
 #include <vector>
 #include <deque>
 #include <mutex>
+#include <atomic>
+#include <memory>
 
 #include "../../include/snapgpu.h"
 #include "dev_common.h"
@@ -280,6 +282,12 @@ struct snapgpu_ctx {
     // help for heavy reads (se_help.h): on unless SNAPGPU_SINGLE_HELP=0 at snapgpu_create (then the 192-position variant runs the exact
     // form as its main pass again, as in round 2)
     bool single_help = true, single_help_eager = false; uint32_t single_help_keep = 3;
+    // contexts over this index on this device (this one and the feeder replicas that share its blobs).  The help is for a context that
+    // has the GPU to itself: with several batches in flight the next batch's blocks want the wave slots idle helpers would sit on, and the
+    // tails overlap anyway (measured: three feeders 130 ms per batch without, 140-147 ms with: profiles/r03g, r03h) -- such launches run the
+    // exact form as their one pass, as in round 2.  SNAPGPU_SINGLE_HELP=1 forces the help on whatever the number of feeders, =0 off.
+    std::shared_ptr<std::atomic<int>> feeders;
+    int single_help_forced = -1;
     SEHelpSlot *d_se_slots = nullptr; SESpec *d_se_spec = nullptr; uint32_t *d_se_ctl = nullptr; uint32_t se_spec_cap = 0;
     unsigned long long *d_dbg = nullptr;          // phase_timers: launch diagnostics of the last single-end launch (kernel_common.h: AlignArgs::dbg)
     bool paired_sec = false;
@@ -437,6 +445,7 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_pexact_persist) (void)hipFree(ctx->d_pexact_persist);
     if (ctx->d_help) (void)hipFree(ctx->d_help);
     if (ctx->d_help_spec) (void)hipFree(ctx->d_help_spec);
+    if (ctx->feeders) ctx->feeders->fetch_sub(1);
     if (ctx->d_dbg) (void)hipFree(ctx->d_dbg);
     if (ctx->d_se_slots) (void)hipFree(ctx->d_se_slots);
     if (ctx->d_se_spec) (void)hipFree(ctx->d_se_spec);
@@ -675,7 +684,9 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         if (getenv("SNAPGPU_AG_LDS")) ctx->ag_variant = 0;
     }
     size_t ag_bytes = c.ag_buffers ? ag_scratch_bytes(c.RL) : 0;
-    if (const char *e = getenv("SNAPGPU_SINGLE_HELP")) ctx->single_help = atoi(e) != 0;
+    if (const char *e = getenv("SNAPGPU_SINGLE_HELP")) { ctx->single_help_forced = atoi(e) != 0 ? 1 : 0; ctx->single_help = ctx->single_help_forced != 0; }
+    if (g_share_buckets_from && g_share_buckets_from->feeders && idx->on_device) { ctx->feeders = g_share_buckets_from->feeders; ctx->feeders->fetch_add(1); }
+    else ctx->feeders = std::make_shared<std::atomic<int>>(1);
     if (const char *e = getenv("SNAPGPU_SINGLE_HELP_EAGER")) ctx->single_help_eager = atoi(e) != 0;
     if (const char *e = getenv("SNAPGPU_SINGLE_HELP_KEEP")) { int v = atoi(e); if (v >= 1 && v <= 64) ctx->single_help_keep = (uint32_t)v; }
     c.se_items_cap = ctx->single_help ? SE_HELP_ITEMS_CAP : 0u;
@@ -704,7 +715,8 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         // arrays forgotten between calls + a replay of the flagged reads on 64 waves (kernel_common.h: AlignArgs::persist).
         // (with the help for heavy reads on -- the default since round 3 -- the main pass is the fast form: an idle wave cannot take part in
         //  a walk that is ordered through the traceback arrays its calls share)
-        ctx->always_exact = ctx->ag_variant == 3 && !getenv("SNAPGPU_NO_ALWAYS_EXACT") && !ctx->single_help;
+        // (whether a launch runs the exact form as its main pass is decided per launch -- launch_align -- so the images are there for every wave)
+        ctx->always_exact = ctx->ag_variant == 3 && !getenv("SNAPGPU_NO_ALWAYS_EXACT");
         ctx->exact_slots = ctx->always_exact ? ctx->n_wave_slots : (ctx->n_wave_slots < 64 ? ctx->n_wave_slots : 64);
         ctx->exact_persist_stride = 2 * (uint64_t)((ag_bytes + 255) & ~(size_t)255);
         CRCHK(hipMalloc((void **)&ctx->d_exact_persist, (size_t)ctx->exact_slots * ctx->exact_persist_stride), SNAPGPU_E_NOMEM);
@@ -1536,7 +1548,9 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.flag_list = nullptr; a.flag_count = nullptr; a.remap = nullptr; a.n_remap = nullptr; a.persist = nullptr; a.persist_stride = 0;
     a.is_replay = 0; a.order = nullptr; a.dbg = nullptr; a.dbg_slots = 0;
     a.se_slots = nullptr; a.se_n_slots = 0; a.se_spec = nullptr; a.se_spec_cap = 0; a.se_ctl = nullptr; a.se_eager = 0; a.se_keep = 1;
-    if (ctx->single_help && ctx->d_se_slots && !d_n_secondary) {            // (fresh protocol state for the launch that is about to start)
+    const bool use_help = ctx->single_help && ctx->d_se_slots && !d_n_secondary &&
+                          (ctx->single_help_forced == 1 || (ctx->feeders && ctx->feeders->load() <= 1));
+    if (use_help) {                                                       // (fresh protocol state for the launch that is about to start)
         HIPCHK(ctx, hipMemsetAsync(ctx->d_se_slots, 0, SE_HELP_SLOTS * sizeof(SEHelpSlot), s), SNAPGPU_E_LAUNCH);
         HIPCHK(ctx, hipMemsetAsync(ctx->d_se_ctl, 0, 256, s), SNAPGPU_E_LAUNCH);
         a.se_slots = ctx->d_se_slots; a.se_n_slots = SE_HELP_SLOTS; a.se_spec = ctx->d_se_spec; a.se_spec_cap = ctx->se_spec_cap;
@@ -1548,7 +1562,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
         HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg, 0, words * 8, s), SNAPGPU_E_LAUNCH);
         a.dbg = ctx->d_dbg; a.dbg_slots = ctx->n_wave_slots;
     }
-    const bool always_exact = ctx->always_exact && ctx->d_exact_persist != nullptr;
+    const bool always_exact = ctx->always_exact && ctx->d_exact_persist != nullptr && !use_help;
     const bool exact = !always_exact && ctx->d_exact_persist != nullptr && !getenv("SNAPGPU_NO_EXACT_REPLAY");
     if (exact) {
         if (ctx->flag_list_cap < n) {
