@@ -75,6 +75,22 @@ def ensure_index(args, rank, device=0):
     return genome, os.path.join(work, "idx"), built, info
 
 
+def summarize_launch_profile(lp):
+    """Per-wave residency (out-of-reads clock minus first-read clock: the s_memtime counters of different XCDs are not synchronised, so
+    only differences inside one wave mean anything) and the most expensive reads of a launch of the TIMED instantiation."""
+    ok = (lp["wave_finish"] > 0) & (lp["wave_start"] > 0)
+    dur = np.sort((lp["wave_finish"][ok].astype(np.int64) - lp["wave_start"][ok].astype(np.int64)))
+    longest = max(1, int(dur[-1]))
+    worst_i = np.argsort(lp["wave_worst_read_cycles"])[::-1][:8]
+    return {"waves": int(dur.size), "longest_wave_cycles": longest,
+            "wave_residency_fraction_of_longest": {"p10": float(dur[int(0.10 * dur.size)]) / longest, "p50": float(dur[dur.size // 2]) / longest,
+                                                   "p90": float(dur[int(0.90 * dur.size)]) / longest, "p99": float(dur[int(0.99 * dur.size)]) / longest},
+            "mean_wave_residency": float(dur.mean()) / longest,
+            "worst_reads_fraction_of_longest_wave": [float(lp["wave_worst_read_cycles"][i]) / longest for i in worst_i],
+            "worst_reads_ag_calls": [int(lp["wave_worst_read_ag_calls"][i]) for i in worst_i],
+            "read_cycles_log2_hist": {str(i): int(v) for i, v in enumerate(lp["read_cycles_log2_hist"]) if v}}
+
+
 def algorithmic_bytes(c, read_len, n_reads, ref_walk_slots=None):
     """SURVEY.md 8(d) / DESIGN.md: bytes the algorithm is entitled to move for the work done.  The probe term is that of the REFERENCE's
     slot walk (8 B per slot its quadratic / linear probe examines), whatever layout the kernel actually reads: `ref_walk_slots` is that
@@ -313,17 +329,7 @@ def main():
         tc = timed.counters(reset=True)
         try:        # where the launch's time goes wave by wave: finish-time distribution and the most expensive reads (profiles/)
             lp = timed.launch_profile()
-            t0_ = int(lp["wave_start"][lp["wave_start"] > 0].min()); fin = (lp["wave_finish"].astype(np.int64) - t0_)
-            fin = np.sort(fin[lp["wave_finish"] > 0]); end_ = max(1, int(fin[-1]))
-            worst = np.sort(lp["wave_worst_read_cycles"].astype(np.int64))[::-1]
-            ag_of_worst = lp["wave_worst_read_ag_calls"][np.argsort(lp["wave_worst_read_cycles"])[::-1]]
-            launch_profile = {"waves": int(fin.size), "launch_cycles": end_,
-                              "wave_finish_fraction_of_launch": {"p10": float(fin[int(0.10 * fin.size)]) / end_, "p50": float(fin[fin.size // 2]) / end_,
-                                                                 "p90": float(fin[int(0.90 * fin.size)]) / end_, "p99": float(fin[int(0.99 * fin.size)]) / end_},
-                              "mean_wave_residency": float(fin.mean()) / end_,
-                              "worst_reads_fraction_of_launch": [float(x) / end_ for x in worst[:8]],
-                              "worst_reads_ag_calls": [int(x) for x in ag_of_worst[:8]],
-                              "read_cycles_log2_hist": {str(i): int(v) for i, v in enumerate(lp["read_cycles_log2_hist"]) if v}}
+            launch_profile = summarize_launch_profile(lp)
         except Exception as e_:          # noqa: BLE001 -- diagnostics only
             launch_profile = {"error": str(e_)}
         tot_c = max(1, tc.get("cycles_total", 0))
@@ -404,6 +410,11 @@ def main():
     }
     if probe is not None:
         out["roofline"]["probe"] = probe
+    if os.environ.get("SNAPGPU_PHASE_TIMERS") == "1" and not paired:      # a diagnostic run: the timed contexts themselves carry the timers
+        try:
+            out["roofline"]["launch_profile_of_last_timed_launch"] = summarize_launch_profile(aligner.launch_profile())
+        except Exception as e_:          # noqa: BLE001
+            out["roofline"]["launch_profile_of_last_timed_launch"] = {"error": str(e_)}
     if breakdown is not None:
         out["roofline"]["wave_cycle_breakdown"] = breakdown["fractions"]
         out["roofline"]["wave_cycles_per_read"] = breakdown["wave_cycles_per_read"]

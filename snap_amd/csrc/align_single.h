@@ -263,10 +263,21 @@ struct Aligner {
 
     // Genome::getSubstring(location, lengthNeeded) != NULL  (Genome.h:339-367)
     __device__ __forceinline__ bool substring_ok(int64_t loc, int64_t len) const {
+        if (!substring_in_range(loc, len)) return false;
+        return substring_ok_known(loc, len, first_u32(ix.genome[loc]) == 'n');
+    }
+    // the part of getSubstring that needs no memory: the window lies inside what the genome (and its padding) holds
+    __device__ __forceinline__ bool substring_in_range(int64_t loc, int64_t len) const {
         int64_t nb = (int64_t)ix.n_bases;
         if (loc > nb || loc + len > nb + 1000) return false;
-        if (loc < -(int64_t)ix.genome_pad) return false;                      // (cannot happen; keeps loads in bounds)
-        if (len <= (int64_t)ix.chromosome_padding && first_u32(ix.genome[loc]) != 'n') return true;
+        if (loc < -(int64_t)ix.genome_pad + WIN_PAD) return false;            // (cannot happen; keeps loads in bounds)
+        return true;
+    }
+    // ... and the rest, given whether genome[loc] is padding ('n'): the caller has usually just staged the window and reads that byte
+    // from LDS instead of making a dependent trip to HBM for it
+    __device__ __forceinline__ bool substring_ok_known(int64_t loc, int64_t len, bool first_is_pad) const {
+        int64_t nb = (int64_t)ix.n_bases;
+        if (len <= (int64_t)ix.chromosome_padding && !first_is_pad) return true;
         if (len == 0) return true;
         // getContigAtLocation: last contig whose beginning <= loc
         int lo = 0, hi = (int)ix.n_contigs - 1, found = -1;
@@ -630,11 +641,24 @@ struct Aligner {
         const int64_t glen = (int64_t)read_len + SNAPGPU_MAX_K;
         int used_ag = 0, clip_before = 0, clip_after = 0, ag_score = -1;
 
-        if (substring_ok(loc, glen)) {
-            // Landau-Vishkin works on bit planes (planes.h) when the context has them and the limit's 2k + 1 diagonals fit
-            // the wave; the byte window is only staged for what reads bytes: the gapless walk, affine gap
-            const bool lv_planes = !HAM && ix.planes != nullptr && limit_e <= 31;
-            if (lv_planes) stage_planes(loc); else stage_window(loc);
+        // Landau-Vishkin works on bit planes (planes.h) when the context has them and the limit's 2k + 1 diagonals fit
+        // the wave; the byte window is only staged for what reads bytes: the gapless walk, affine gap
+        const bool lv_planes = !HAM && ix.planes != nullptr && limit_e <= 31;
+        bool sub_ok = false;
+        if (substring_in_range(loc, glen)) {                 // Genome::getSubstring (Genome.h:339-367): its "is this padding" byte comes with the window
+            bool first_is_pad;
+            if (lv_planes) {
+                stage_planes(loc);
+                const int tpb = (int)text_plane_blocks(cfg.RL, WIN_PAD);
+                const unsigned long long wn = tp[2 * tpb + (tp_org >> 6)], w0 = tp[tp_org >> 6];
+                first_is_pad = (int)first_u32((uint32_t)(((wn & w0) >> (tp_org & 63)) & 1ull)) != 0;
+            } else {
+                stage_window(loc);
+                first_is_pad = first_u32(gw[WIN_PAD]) == 'n';
+            }
+            sub_ok = substring_ok_known(loc, glen, first_is_pad);
+        }
+        if (sub_ok) {
             const uint8_t *data = gw + WIN_PAD;                   // data[i] = genome[loc + i]
             const int seed_len = (int)ix.seed_len;
             const int seed_offset = cand_seed_offset;
