@@ -5,13 +5,15 @@
 #include "kernel_common.h"
 #include "paired.h"
 
-// waves per SIMD k_align_paired is compiled for (its __launch_bounds__) and the host sizes its grid for.  Round 3 made 4 possible for the
-// 192-position variant (LDS under 10 KB per wave: paired_dev.h) and measured it on the bench batch (profiles/r03c): at 128 VGPRs the kernel
-// spills 360 more dwords per lane and is 4 % slower with the same 8 waves per CU, 14 % slower with 16 (twice the slabs behind the same L2):
-// the paired-end kernel is bound by its scratch and slab traffic, not by latency hiding.  2 it stays; -DSNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)=...
-// rebuilds it otherwise.
+// waves per SIMD k_align_paired is compiled for (its __launch_bounds__) and the host sizes its grid for.  Round 3 shrank the LDS
+// footprint of the 192-position variant to under 10 KB per wave (paired_dev.h), which allows up to 4, and measured them on the bench
+// batch (profiles/r03c, r03l):
+//   4 (128 VGPRs, +360 spilled dwords per lane)   one context 6.58 s per batch against 5.66 s at 2: slower -- twice the slabs behind the same L2
+//   3 (168 VGPRs)                                  one context 5.62 s against 5.44 s; TWO feeders 4.99 s against 5.72 s, THREE 3.98 s against 4.2-4.4 s
+// i.e. the kernel is bound by its scratch / slab traffic, not by latency hiding, but a third wave per SIMD gives overlapping launches room.
+// 3 for that variant (the default runs three feeders); the variants with more affine-gap state in registers and the LDS form stay at 2.
 #ifndef SNAPGPU_PAIRED_WAVES_PER_SIMD
-#define SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC) 2
+#define SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 3 : 2)
 #endif
 
 struct PairedLds { uint32_t single_total, rd, ql, lk, exhausted, miss, hs, list_head, seed_used, sh, total; };

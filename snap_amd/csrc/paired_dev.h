@@ -479,9 +479,9 @@ struct DevPL {
     }
 };
 
-// Scalar-heavy control flow at 2 waves per SIMD (256 VGPRs).  Its LDS footprint (under 10 KB per wave since round 3: Landau-Vishkin
-// triangle for limits <= 22 only, the register affine-gap forms' tables instead of the LDS form's rows) would allow 4; measured slower
-// (paired_args.h: SNAPGPU_PAIRED_WAVES_PER_SIMD).
+// Scalar-heavy control flow; 3 waves per SIMD for the 192-position variant, 2 for the others: what its LDS footprint (under 10 KB per
+// wave since round 3: Landau-Vishkin triangle for limits <= 22 only, the register affine-gap forms' tables instead of the LDS form's rows)
+// allows and what was measured: paired_args.h, SNAPGPU_PAIRED_WAVES_PER_SIMD.
 template <int AGC, bool SEC, bool EXACT = false>
 __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_align_paired(PairedArgs a)
 {
