@@ -170,6 +170,8 @@ struct Aligner {
     unsigned long long *rp; // bit planes of the read, both directions (planes.h); [dir][plane][read_plane_words(RL)]
     unsigned long long *tp; // bit planes of the candidate's reference window; [plane][text_plane_blocks(RL, WIN_PAD)]
     int tp_org;             // bit of tp that is genome[loc] of the staged candidate
+    unsigned long long *lvp; // LDS work area of the prepared plane form (planes.h: lv_plane_work_words)
+    uint32_t rd_plain;      // bit dir: rd[dir] is all ACGT (its 'N' / other planes are empty)
     // ---- HBM scratch for this wave
     uint16_t *heads;
     Elem     *pool;
@@ -216,7 +218,9 @@ struct Aligner {
     WaveCounters &cnt;
 
     __device__ __forceinline__ Aligner(const DevIndex &ix_, const DevTables *tab_, const AlignCfg &cfg_, WaveShared *ws)
-        : ix(ix_), tab(tab_), cfg(cfg_), max_k(cfg_.max_k), agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0),
+        : ix(ix_), tab(tab_), cfg(cfg_), tp_org(0), rd_plain(0), ag_hw0(0), ag_hw1(0), read_len(0), popular_seeds_skipped(0),
+          ag_stale(0), ag_replay(0), ag_obj_used0(0), ag_obj_used1(0), max_k(cfg_.max_k), ag_calls_unit(0),
+          agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0), n_sec(0), n_sec_raw(0), sec_overflow(0),
           all(ws->all), non_alt(ws->non_alt), primary(ws->primary), first_alt(ws->first_alt), cnt(ws->cnt) {}
 
     static __device__ __forceinline__ uint64_t clk() { if constexpr (TIMED) return wave_clock(); else return 0; }
@@ -609,6 +613,7 @@ struct Aligner {
     // bit planes of rd[dir][0 .. len): code bits, 'N' / 'n', any other byte (planes.h: LvPlanes)
     __device__ __forceinline__ void build_read_planes(int len) {
         const int rpw = (int)read_plane_words(cfg.RL);
+        uint32_t not_plain = 0;
         for (int dir = 0; dir < 2; dir++) {
             for (int w = 0; w < rpw; w++) {
                 const int i = w * 64 + lane;
@@ -621,8 +626,10 @@ struct Aligner {
                     unsigned long long *base = rp + (size_t)dir * 4 * rpw;
                     base[w] = p0; base[rpw + w] = p1; base[2 * rpw + w] = pn; base[3 * rpw + w] = po;
                 }
+                if (pn | po) not_plain |= 1u << dir;
             }
         }
+        rd_plain = ~not_plain & 3u;
         WAVE_SYNC();
     }
 
@@ -647,15 +654,9 @@ struct Aligner {
         bool sub_ok = false;
         if (substring_in_range(loc, glen)) {                 // Genome::getSubstring (Genome.h:339-367): its "is this padding" byte comes with the window
             bool first_is_pad;
-            if (lv_planes) {
-                stage_planes(loc);
-                const int tpb = (int)text_plane_blocks(cfg.RL, WIN_PAD);
-                const unsigned long long wn = tp[2 * tpb + (tp_org >> 6)], w0 = tp[tp_org >> 6];
-                first_is_pad = (int)first_u32((uint32_t)(((wn & w0) >> (tp_org & 63)) & 1ull)) != 0;
-            } else {
-                stage_window(loc);
-                first_is_pad = first_u32(gw[WIN_PAD]) == 'n';
-            }
+            stage_window(loc);                               // (the first levels of Landau-Vishkin, the gapless walk and affine gap read bytes)
+            if (lv_planes) stage_planes(loc);
+            first_is_pad = first_u32(gw[WIN_PAD]) == 'n';
             sub_ok = substring_ok_known(loc, glen, first_is_pad);
         }
         if (sub_ok) {
@@ -708,6 +709,7 @@ struct Aligner {
                     const int tpb = (int)text_plane_blocks(cfg.RL, WIN_PAD);
                     lp.t0 = tb; lp.t1 = tb + tpb; lp.tn = tb + 2 * tpb;
                     lp.p_org = org; lp.t_org = tp_org + org; lp.st = st; lp.p_words = rpw; lp.t_words = tpb;
+                    lp.work = (LDS_AS unsigned long long *)lvp; lp.plain = ((rd_plain >> e_dir) & 1u) != 0;
                 }
                 LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab, cfg.RL, lv_planes ? &lp : nullptr);
                 // results are wave-uniform; say so, so they (and everything derived from them) live in SGPRs
@@ -1214,6 +1216,9 @@ struct Aligner {
     __device__ __forceinline__ void align_read_inner(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         read_len = len;
         if constexpr (SEC) { n_sec = 0; n_sec_raw = 0; sec_overflow = 0; }    // *nSecondaryResults = 0, :318-320
+        // what the callers read after ANY return, the early ones included (the Hamming retry of the chimeric fallback builds `reserved`
+        // from the step notes and looks at the candidate count: ChimericPairedEndAligner.cpp:273-274 starts both counts at 0 per read)
+        ag_stale = 0; ag_replay = 0; n_agc = 0; agc_overflow = 0;
         // result = NotFound (:334-344); remaining fields as a zero-initialised struct
         primary.status = SNAPGPU_NotFound; primary.direction = 0;
         primary.location = SNAPGPU_InvalidGenomeLocation32; primary.orig_location = 0;
@@ -1261,8 +1266,6 @@ struct Aligner {
         if (!cfg.alt_aware) non_alt.best_score = SNAPGPU_TooBigScoreValue;    // :325 (never re-initialised without ALT awareness)
         n_seeds_applied[0] = n_seeds_applied[1] = 0;
         popular_seeds_skipped = 0;
-        ag_stale = 0; ag_replay = 0;
-        n_agc = 0; agc_overflow = 0;
         se_tried = 0;
         bool finished = false;
 

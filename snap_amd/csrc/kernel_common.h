@@ -56,7 +56,7 @@ static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { re
 
 // LDS carve-out per wave; must match lds_bytes_per_wave() on the host.
 struct LdsLayout {
-    uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, ag, shared, rp, tp, total;
+    uint32_t rd0, rd1, ql0, ql1, gw, seed_used, wl_next, wl_prev, lv, ag, shared, rp, tp, lvp, total;
 };
 
 // ag_lds: bytes of LDS the affine-gap code of the kernel variant needs (AlignCfg::ag_lds; 0 = no affine-gap buffers)
@@ -72,6 +72,7 @@ static __host__ __device__ __forceinline__ LdsLayout lds_layout(uint32_t RL, uin
     L.shared = o; o += ((uint32_t)sizeof(WaveShared) + 15) & ~15u;
     L.rp = o; o += (2 * 4 * read_plane_words(RL) * 8 + 15) & ~15u;          // read planes: [direction][code bit 0, code bit 1, N, other][word]
     L.tp = o; o += (3 * text_plane_blocks(RL, WIN_PAD) * 8 + 15) & ~15u;    // text planes of the candidate window: [plane][block]
+    L.lvp = o; o += (lv_plane_work_words(RL) * 8 + 15) & ~15u;              // Landau-Vishkin's prepared plane words (planes.h)
     L.total = o;
     return L;
 }

@@ -28,6 +28,8 @@ struct ByteSeq {                 // s(i) = p[i*stride]
     __device__ __forceinline__ uint8_t operator()(int i) const { return p[i * stride]; }
 };
 
+#define LV_PLANES_FROM 3               // first level whose bitmaps come from planes (lv_compute_inl)
+
 struct LVResult {
     int    score;                // edit distance, or -1 (ScoreAboveLimit)
     double match_probability;
@@ -61,8 +63,9 @@ template <bool TRI_LDS> struct LvMem;
 template <> struct LvMem<true>  { typedef LDS_AS uint16_t U16; typedef LDS_AS uint32_t U32; typedef LDS_AS unsigned long long U64; typedef LDS_AS uint8_t U8; };
 template <> struct LvMem<false> { typedef uint16_t U16; typedef uint32_t U32; typedef unsigned long long U64; typedef uint8_t U8; };
 
-// planes != NULL: the mismatch bitmaps come from bit planes of the pattern and the text (planes.h) -- every lane builds the bitmap of its
-// own diagonal, all 2k + 1 of them before the first level -- and P / T are not read at all; Q still is (the forward pass).
+// planes != NULL: a call that is still running at level LV_PLANES_FROM gets ALL its remaining bitmaps from bit planes of the pattern and the
+// text (planes.h), every lane building the one of its own diagonal, instead of two byte-compared bitmaps per level: the perfect-match prefix
+// and the first levels -- where most calls end -- stay with the bytes, which are cheaper there (profiles/r03e).
 template <bool TRI_LDS = true, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ LVResult lv_compute_inl(
     const PSeq &P, const QSeq &Q, int pattern_len, const TSeq &T, int text_len, int k,
@@ -101,19 +104,6 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
     // ---- e = 0: the perfect-match prefix, compared 64 bytes per step by the whole wave
     const int end0 = pattern_len < text_len ? pattern_len : text_len;
     int run0 = 0;
-    if (planes != nullptr) {
-        // all bitmaps at once: lane r builds diagonal lv_diag(r); the perfect-match prefix is the first set bit of diagonal 0's
-        if (lane <= 2 * k) {
-            const int d = lv_diag(lane);
-            const int tl = text_len - d;
-            const int end = pattern_len < tl ? pattern_len : tl;
-            for (int w = 0; w < nwu; w++) mask[lane * nw + w] = lv_plane_mask_word(*planes, d, w, end);
-        }
-        WAVE_SYNC();
-        int first = end0;
-        for (int w = nwu - 1; w >= 0; w--) { const unsigned long long v = mask[w]; if (v) first = w * 64 + (int)__builtin_ctzll(v); }
-        run0 = (int)first_u32((uint32_t)first);
-    } else
     while (true) {
         int i = run0 + lane;
         bool same = (i < end0) && (P(i) == T(i));
@@ -139,10 +129,21 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
         const M16 *prev_row = lds_tri + (e - 1) * (e - 1);
         M16 *row = lds_tri + e * e;
         int x_rank = 1 << 30, any_rank = 1 << 30;
-        if (planes == nullptr) {
+        if (planes == nullptr || e < LV_PLANES_FROM) {
             if (e == 1) build_mask(0);
             build_mask(2 * e - 1);
             build_mask(2 * e);
+            WAVE_SYNC();
+        } else if (e == LV_PLANES_FROM) {
+            const int n_pw = nwu, n_sw = ((pattern_len + 2 * k + 63) >> 6) + 1;
+            lv_planes_prepare(*planes, k, pattern_len, n_pw, n_sw);
+            WAVE_SYNC();
+            if (lane <= 2 * k) {
+                const int d = lv_diag(lane);
+                const int tl = text_len - d;
+                const int end = pattern_len < tl ? pattern_len : tl;
+                for (int w = 0; w < nwu; w++) mask[lane * nw + w] = lv_planes_word(*planes, k, d, w, end, n_pw, n_sw);
+            }
             WAVE_SYNC();
         }
         for (int r0 = 0; r0 <= 2 * e; r0 += WAVE) {
@@ -258,7 +259,7 @@ template <class S> static __device__ __forceinline__ S seq_uniform(const S &s) {
 template <bool TRI_LDS, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __attribute__((noinline)) LVResult lv_compute_fn(
     PSeq P_in, QSeq Q_in, int pattern_len, TSeq T_in, int text_len, int k,
-    uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap, uint64_t rp_lds, uint64_t tp_lds, uint32_t plane_geom, int p_org, int t_org)
+    uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap, uint64_t rp_lds, uint64_t tp_lds, uint64_t work_lds, uint32_t plane_geom, int p_org, int t_org)
 {
     const PSeq P = seq_uniform(P_in); const QSeq Q = seq_uniform(Q_in); const TSeq T = seq_uniform(T_in);
     pattern_len = (int)first_u32((uint32_t)pattern_len); text_len = (int)first_u32((uint32_t)text_len); k = (int)first_u32((uint32_t)k);
@@ -266,15 +267,16 @@ static __device__ __attribute__((noinline)) LVResult lv_compute_fn(
     kmax = first_u32(kmax); pcap = first_u32(pcap);
     tab = (const DevTables *)(uintptr_t)first_u64((uint64_t)(uintptr_t)tab);
     // bit planes (planes.h): LDS addresses of the pattern's and the text's planes (~0: none), words per plane << 16 / << 24 | stride + 1
-    rp_lds = first_u64(rp_lds); tp_lds = first_u64(tp_lds); plane_geom = first_u32(plane_geom);
+    rp_lds = first_u64(rp_lds); tp_lds = first_u64(tp_lds); work_lds = first_u64(work_lds); plane_geom = first_u32(plane_geom);
     p_org = (int)first_u32((uint32_t)p_org); t_org = (int)first_u32((uint32_t)t_org);
     if (rp_lds != ~0ull) {
         LvPlanes lp;
-        const int pw = (int)((plane_geom >> 16) & 0xffu), tw = (int)(plane_geom >> 24);
+        const int pw = (int)((plane_geom >> 16) & 0x7fu), tw = (int)(plane_geom >> 24);
         const LDS_AS unsigned long long *rb = (const LDS_AS unsigned long long *)(uintptr_t)rp_lds, *tb = (const LDS_AS unsigned long long *)(uintptr_t)tp_lds;
         lp.p0 = rb; lp.p1 = rb + pw; lp.pn = rb + 2 * pw; lp.po = rb + 3 * pw;
         lp.t0 = tb; lp.t1 = tb + tw; lp.tn = tb + 2 * tw;
-        lp.p_org = p_org; lp.t_org = t_org; lp.st = (int)(plane_geom & 0xffffu) - 1; lp.p_words = pw; lp.t_words = tw;
+        lp.p_org = p_org; lp.t_org = t_org; lp.st = (int)(plane_geom & 0xffu) - 1; lp.p_words = pw; lp.t_words = tw;
+        lp.work = (LDS_AS unsigned long long *)(uintptr_t)work_lds; lp.plain = ((plane_geom >> 23) & 1u) != 0;
         return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, &lp);
     }
     return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
@@ -291,9 +293,9 @@ static __device__ __forceinline__ LVResult lv_compute(
     // (the planes' LDS pointers cross the call as 32-bit LDS addresses)
     if (planes != nullptr)
         return lv_compute_fn<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap,
-                                                        (uint64_t)(uintptr_t)planes->p0, (uint64_t)(uintptr_t)planes->t0,
-                                                        (uint32_t)(planes->st + 1) | ((uint32_t)planes->p_words << 16) | ((uint32_t)planes->t_words << 24),
+                                                        (uint64_t)(uintptr_t)planes->p0, (uint64_t)(uintptr_t)planes->t0, (uint64_t)(uintptr_t)planes->work,
+                                                        (uint32_t)(planes->st + 1) | ((uint32_t)planes->p_words << 16) | (planes->plain ? 1u << 23 : 0u) | ((uint32_t)planes->t_words << 24),
                                                         planes->p_org, planes->t_org);
-    return lv_compute_fn<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, ~0ull, ~0ull, 0u, 0, 0);
+    return lv_compute_fn<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, ~0ull, ~0ull, 0ull, 0u, 0, 0);
 #endif
 }

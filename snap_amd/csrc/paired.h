@@ -140,7 +140,9 @@ struct PESet {                         // ScoreSet, .h:614-700
 struct PEHelpSpec {
     int32_t  lim[2];                   // limit argument of the call for mate r; PE_SPEC_NONE: no call was made
     int32_t  score[2], g_off[2], cb[2], ca[2], ag[2], span[2];
-    uint32_t stale[2], n_ag[2];
+    uint32_t stale_fw[2], stale_bw[2];  // out-of-band traceback steps of the call's affineGap / reverseAffineGap object
+    uint32_t calls[2];                 // bit 0: affineGap was called, bit 1: reverseAffineGap was called
+    uint32_t n_ag[2];
     double   mp[2];
 };
 #define PE_SPEC_NONE (-0x7fffffff)
@@ -195,7 +197,7 @@ struct PairedCore {
     uint32_t stale_later = 0;          // steps outside the band in calls that were not their object's first (or speculative): the pair needs the exact pass
     uint32_t ag_obj_used0 = 0, ag_obj_used1 = 0;  // has affineGap / reverseAffineGap of the intersecting aligner scored anything yet for this pair?
     bool spec_mode = false;            // speculative scoring of Phase-4 candidates: work counters are left to the ordered walk
-    uint32_t spec_n_ag = 0;
+    uint32_t spec_n_ag = 0, spec_calls = 0, spec_stale_fw = 0, spec_stale_bw = 0;
     uint32_t spec_used = 0;            // answers the ordered walk took from speculative scoring (this pair)
     uint32_t help_min = 0xffffffffu;   // Phase-4 lists at least this long are offered to idle waves (PL::HELP only)
 
@@ -542,8 +544,20 @@ struct PairedCore {
     PE_FN void note_ag_call(int obj, uint32_t stale_steps) {
         stale += stale_steps;
         const uint32_t used = obj == 0 ? ag_obj_used0 : ag_obj_used1;
-        if (PL::ALWAYS_COUNT_STALE || spec_mode || used) stale_later += stale_steps;
-        if (!spec_mode) { if (obj == 0) ag_obj_used0 = 1; else ag_obj_used1 = 1; }
+        if (spec_mode) {                // no place in the order of calls yet: the owner books the call when it takes the answer (take_spec_calls)
+            spec_calls |= 1u << obj;
+            if (obj == 0) spec_stale_fw = stale_steps; else spec_stale_bw = stale_steps;
+            return;
+        }
+        if (PL::ALWAYS_COUNT_STALE || used) stale_later += stale_steps;
+        if (obj == 0) ag_obj_used0 = 1; else ag_obj_used1 = 1;
+    }
+    // An answer scored ahead of time is taken: its calls enter the order of the pair's calls here, exactly as if this wave had made them
+    // (which object had scored something before, which steps count) -- the flags of a pair do not depend on who scored its candidates.
+    PE_FN void take_spec_calls(const PEHelpSpec *sp, int r) {
+        const uint32_t calls = PL::spec_ld(sp->calls[r]);
+        if (calls & 1u) note_ag_call(0, PL::spec_ld(sp->stale_fw[r]));
+        if (calls & 2u) note_ag_call(1, PL::spec_ld(sp->stale_bw[r]));
     }
 
     // scoreLocationWithAffineGap (:3119-3280).  clip_before/clip_after/ag/ref_span are in/out like the reference's pointers.
@@ -1375,7 +1389,7 @@ struct PairedCore {
         const bool gl0 = ld(e->used_gapless_clipping[0]) != 0, gl1 = ld(e->used_gapless_clipping[1]) != 0;
         int lim0 = PE_SPEC_NONE, lim1 = PE_SPEC_NONE;
         int o_s[2] = {0, 0}, o_g[2] = {0, 0}, o_cb[2] = {0, 0}, o_ca[2] = {0, 0}, o_ag[2] = {0, 0}, o_span[2] = {0, 0};
-        uint32_t o_stale[2] = {0, 0}, o_nag[2] = {0, 0};
+        uint32_t o_sfw[2] = {0, 0}, o_sbw[2] = {0, 0}, o_calls[2] = {0, 0}, o_nag[2] = {0, 0};
         double o_mp[2] = {0.0, 0.0};
         if (gl0 || gl1) limit = PE_MAXK1;
         else if (lv_pair_score > best_pair_score + cfg.extra_depth && lv_pair_indels > 1) limit = cfg.max_k + cfg.extra_depth;
@@ -1388,11 +1402,11 @@ struct PairedCore {
                 int cb = ld(e->bases_clipped_before[0]), ca = ld(e->bases_clipped_after[0]), span = 0, ag = ld(e->ag_score[0]), off = 0;
                 double mp = ld(e->match_probability[0]);
                 lim0 = PL::i32(limit);
-                stale = 0; spec_n_ag = 0;
+                spec_n_ag = 0; spec_calls = 0; spec_stale_fw = 0; spec_stale_bw = 0;
                 score_ag(0, ld(e->direction[0]), ld(e->orig_location[0]), ld(e->seed_offset[0]), lim0, &s0, &mp, &off, &cb, &ca, &ag, &span);
                 s0 = PL::i32(s0);
                 o_s[0] = s0; o_g[0] = PL::i32(off); o_cb[0] = PL::i32(cb); o_ca[0] = PL::i32(ca); o_ag[0] = PL::i32(ag); o_span[0] = PL::i32(span);
-                o_mp[0] = PL::f64(mp); o_stale[0] = stale; o_nag[0] = spec_n_ag;
+                o_mp[0] = PL::f64(mp); o_sfw[0] = spec_stale_fw; o_sbw[0] = spec_stale_bw; o_calls[0] = spec_calls; o_nag[0] = spec_n_ag;
             }
             if (s0 != -1 && s0 <= PE_MAXK1 && !skip1) {
                 limit = limit - s0;
@@ -1400,10 +1414,10 @@ struct PairedCore {
                 int cb = ld(e->bases_clipped_before[1]), ca = ld(e->bases_clipped_after[1]), span = 0, ag = ld(e->ag_score[1]), off = 0;
                 double mp = ld(e->match_probability[1]);
                 lim1 = PL::i32(limit);
-                stale = 0; spec_n_ag = 0;
+                spec_n_ag = 0; spec_calls = 0; spec_stale_fw = 0; spec_stale_bw = 0;
                 score_ag(1, ld(e->direction[1]), ld(e->orig_location[1]), ld(e->seed_offset[1]), lim1, &s1, &mp, &off, &cb, &ca, &ag, &span);
                 o_s[1] = PL::i32(s1); o_g[1] = PL::i32(off); o_cb[1] = PL::i32(cb); o_ca[1] = PL::i32(ca); o_ag[1] = PL::i32(ag); o_span[1] = PL::i32(span);
-                o_mp[1] = PL::f64(mp); o_stale[1] = stale; o_nag[1] = spec_n_ag;
+                o_mp[1] = PL::f64(mp); o_sfw[1] = spec_stale_fw; o_sbw[1] = spec_stale_bw; o_calls[1] = spec_calls; o_nag[1] = spec_n_ag;
             }
             stale = stale_keep; stale_later = later_keep; spec_mode = mode_keep;
         }
@@ -1411,7 +1425,7 @@ struct PairedCore {
             for (int r = 0; r < 2; r++) {
                 PL::spec_st(sp->score[r], (int32_t)o_s[r]); PL::spec_st(sp->g_off[r], (int32_t)o_g[r]); PL::spec_st(sp->cb[r], (int32_t)o_cb[r]);
                 PL::spec_st(sp->ca[r], (int32_t)o_ca[r]); PL::spec_st(sp->ag[r], (int32_t)o_ag[r]); PL::spec_st(sp->span[r], (int32_t)o_span[r]);
-                PL::spec_st(sp->stale[r], o_stale[r]); PL::spec_st(sp->n_ag[r], o_nag[r]); PL::spec_st(sp->mp[r], o_mp[r]);
+                PL::spec_st(sp->stale_fw[r], o_sfw[r]); PL::spec_st(sp->stale_bw[r], o_sbw[r]); PL::spec_st(sp->calls[r], o_calls[r]); PL::spec_st(sp->n_ag[r], o_nag[r]); PL::spec_st(sp->mp[r], o_mp[r]);
             }
             PL::spec_st(sp->lim[0], (int32_t)lim0); PL::spec_st(sp->lim[1], (int32_t)lim1);
         }
@@ -1441,7 +1455,7 @@ struct PairedCore {
             int cb = ld(e->bases_clipped_before[0]), ca = ld(e->bases_clipped_after[0]), span = 0;
             if (sp != nullptr && PL::spec_ld(sp->lim[0]) == PL::i32(limit)) {      // scored ahead of time with exactly these arguments
                 s0 = PL::spec_ld(sp->score[0]); mp0 = PL::spec_ld(sp->mp[0]); g_off[0] = PL::spec_ld(sp->g_off[0]); cb = PL::spec_ld(sp->cb[0]);
-                ca = PL::spec_ld(sp->ca[0]); ag0 = PL::spec_ld(sp->ag[0]); span = PL::spec_ld(sp->span[0]); { const uint32_t ss = PL::spec_ld(sp->stale[0]); stale += ss; stale_later += ss; }
+                ca = PL::spec_ld(sp->ca[0]); ag0 = PL::spec_ld(sp->ag[0]); span = PL::spec_ld(sp->span[0]); take_spec_calls(sp, 0);
                 sh->cnt.ag += PL::spec_ld(sp->n_ag[0]); spec_used++;
             } else {
                 score_ag(0, ld(e->direction[0]), ld(e->orig_location[0]), ld(e->seed_offset[0]), PL::i32(limit), &s0, &mp0, &g_off[0], &cb, &ca, &ag0, &span);
@@ -1460,7 +1474,7 @@ struct PairedCore {
                 int cb = ld(e->bases_clipped_before[1]), ca = ld(e->bases_clipped_after[1]), span = 0;
                 if (sp != nullptr && PL::spec_ld(sp->lim[1]) == PL::i32(limit)) {
                     s1 = PL::spec_ld(sp->score[1]); mp1 = PL::spec_ld(sp->mp[1]); g_off[1] = PL::spec_ld(sp->g_off[1]); cb = PL::spec_ld(sp->cb[1]);
-                    ca = PL::spec_ld(sp->ca[1]); ag1 = PL::spec_ld(sp->ag[1]); span = PL::spec_ld(sp->span[1]); { const uint32_t ss = PL::spec_ld(sp->stale[1]); stale += ss; stale_later += ss; }
+                    ca = PL::spec_ld(sp->ca[1]); ag1 = PL::spec_ld(sp->ag[1]); span = PL::spec_ld(sp->span[1]); take_spec_calls(sp, 1);
                     sh->cnt.ag += PL::spec_ld(sp->n_ag[1]); spec_used++;
                 } else {
                     score_ag(1, ld(e->direction[1]), ld(e->orig_location[1]), ld(e->seed_offset[1]), PL::i32(limit), &s1, &mp1, &g_off[1], &cb, &ca, &ag1, &span);

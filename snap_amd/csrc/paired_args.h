@@ -81,7 +81,14 @@ struct PairedArgs {
     //  before it publishes; help_eager: publish whether or not anybody is idle)
     struct PEHelpSlot *help; uint32_t n_help; PEHelpSpec *help_spec; uint32_t help_spec_cap; uint32_t *help_done; uint32_t help_min;
     uint32_t help_eager;
+    // Exact replay that runs BESIDE the main pass (launch_paired): the main kernel (rq_mode 1) appends a pair to rq_list as soon as it has
+    // flagged it, the exact kernel (rq_mode 2, its own stream) takes pairs from the list while the main pass is still going and leaves
+    // when the main pass has finished every pair and the list is empty.  rq[0] entries appended, rq[1] entries taken, rq[2] pairs the main
+    // pass has finished, rq[3] diagnostics.  rq_list entries start as 0xFFFFFFFF.
+    uint32_t *rq, *rq_list; uint32_t rq_mode;
+    uint32_t dbg_flag_every;           // tests (SNAPGPU_DEBUG_PAIRED_FLAG_EVERY=<k>): the fast pass flags every k-th pair for the exact kernel as well
 };
+#define SNAPGPU_PAIR_REPLAYED_BESIDE 0x40000000u   // (internal, never leaves launch_paired: the pair was redone by the exact kernel beside the main pass)
 
 
 extern "C" {
@@ -91,7 +98,7 @@ void snapgpu_launch_paired_6(const PairedArgs *a, uint32_t blocks, size_t lds_by
 void snapgpu_launch_paired_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_sec_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_sec_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
-void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale, hipStream_t s);
+void snapgpu_launch_collect_flagged(snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale, hipStream_t s);
 void snapgpu_launch_paired_exact_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_exact_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_sec_exact_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);

@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     al.wl_prev = (uint16_t *)(my + SL.wl_prev);
     al.lv_tri = (uint16_t *)(my + SL.lv);
     al.ag_rows = (int16_t *)(my + SL.ag);
-    al.rp = (unsigned long long *)(my + SL.rp); al.tp = (unsigned long long *)(my + SL.tp);
+    al.rp = (unsigned long long *)(my + SL.rp); al.tp = (unsigned long long *)(my + SL.tp); al.lvp = (unsigned long long *)(my + SL.lvp);
     al.heads = (uint16_t *)sc;
     al.pool = (Elem *)(sc + (size_t)a.scfg.ht_size * 2);
     al.ag_scratch = sc + (size_t)a.scfg.ht_size * 2 + (size_t)a.scfg.pool_size * sizeof(Elem);
@@ -586,12 +586,47 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
         }
         WAVE_SYNC();
     };
+    using XP = DevPL<AGC, SEC, EXACT>;
     while (true) {
         uint32_t i = 0;
-        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
-        i = first_u32(i);
-        if (i >= n_total) break;
-        if (a.remap) i = first_u32(a.remap[i]);
+        if (EXACT && a.rq_mode == 2u) {
+            // pairs arrive while the main pass runs (PairedArgs::rq): take the next entry of the list, or wait for one, until the main pass
+            // has finished all of its pairs and every entry has been taken
+            const uint64_t t_wait0 = wave_clock();
+            uint32_t got = 0xFFFFFFFFu;
+            for (uint32_t round = 0;; round++) {
+                const uint32_t h = XP::aload(a.rq + 1), t = XP::aload(a.rq);
+                if (h < t) {
+                    uint32_t was = 0;
+                    if (lane == 0) was = atomicCAS(a.rq + 1, h, h + 1u);
+                    if (first_u32(was) != h) continue;                    // somebody else took entry h
+                    for (uint32_t w = 0;; w++) {                           // (the index lands right after the count: a very short wait)
+                        got = XP::aload(a.rq_list + h);
+                        if (got != 0xFFFFFFFFu || w > 4000000u) break;
+                        XP::nap();
+                    }
+                    if (got == 0xFFFFFFFFu) { if (lane == 0) atomicAdd(a.rq + 3, 1u); continue; }      // (never seen; the pair stays flagged for the pass after)
+                    break;
+                }
+                if (XP::aload(a.rq + 2) >= a.n_pairs) {                    // the main pass is through: is the list?  (appended before counted)
+                    if (XP::aload(a.rq + 1) >= XP::aload(a.rq)) break;
+                    continue;
+                }
+                if ((round & 63u) == 63u && wave_clock() - t_wait0 > 240000000000ull) {       // ~100 s: give up, leave a trace
+                    if (lane == 0) atomicAdd(a.rq + 3, 0x10000u);
+                    break;
+                }
+                XP::nap(); XP::nap(); XP::nap(); XP::nap();
+            }
+            if (got == 0xFFFFFFFFu) break;
+            XP::fence_acquire();
+            i = got;
+        } else {
+            if (lane == 0) i = atomicAdd(a.work_counter, 1u);
+            i = first_u32(i);
+            if (i >= n_total) break;
+            if (a.remap) i = first_u32(a.remap[i]);
+        }
         if constexpr (EXACT) {          // newly constructed reference aligners: all four traceback arrays read as zero
             if (pl.ag_hw0) wave_zero16(pl.ag_persist0, ((size_t)pl.ag_hw0 + 15) & ~(size_t)15);
             if (pl.ag_hw1) wave_zero16(pl.ag_persist1, ((size_t)pl.ag_hw1 + 15) & ~(size_t)15);
@@ -617,7 +652,8 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
         }
         core.align_pair(a.max_k_paired, a.max_k_single);
         core.sh->res.flags = (core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0) | (core.ref_dep ? SNAPGPU_PAIR_REF_BUFFER_DEPENDENT : 0) |
-                             ((EXACT || core.stale_later) ? SNAPGPU_PAIR_EXACT_REPLAY : 0);
+                             ((EXACT || core.stale_later || (a.dbg_flag_every != 0u && i % a.dbg_flag_every == 0u)) ? SNAPGPU_PAIR_EXACT_REPLAY : 0) |
+                             ((EXACT && a.rq_mode == 2u) ? SNAPGPU_PAIR_REPLAYED_BESIDE : 0);
         WAVE_SYNC();
         if constexpr (SEC) {        // paired secondary results: sec[sec_ord[k]] -> secondary[i * stride + k]
             const uint32_t n_sec = core.overflow ? 0u : core.n_sec;
@@ -644,6 +680,22 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
         }
         WAVE_SYNC();
         n_done++;
+        if (!EXACT && a.rq_mode == 1u) {
+            // a flagged pair goes to the exact kernel that runs beside this one: the pair's results first (the exact kernel writes the
+            // same records), then the index, then the count of finished pairs (the exact kernel leaves when that count is complete
+            // and the list is empty, so the index must be there before the pair is counted)
+            const uint32_t fl = first_u32(core.sh->res.flags);
+            if ((fl & SNAPGPU_PAIR_EXACT_REPLAY) != 0u && (fl & SNAPGPU_PAIR_POOL_OVERFLOW) == 0u) {
+                XP::stores_done();
+                XP::fence_release();
+                if (lane == 0) {
+                    const uint32_t slot = atomicAdd(a.rq, 1u);
+                    const uint32_t old = atomicExch(a.rq_list + slot, i);
+                    if (old != 0xFFFFFFFFu) atomicAdd(a.rq + 3, 0x1000000u);          // (uses the return value: the exchange has completed)
+                }
+            }
+            if (lane == 0) atomicAdd(a.rq + 2, 1u);
+        }
         if (!EXACT && a.help_done != nullptr && lane == 0) atomicAdd(a.help_done, 1u);
     }
     if constexpr (!EXACT) {
@@ -719,10 +771,12 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
 // pairs flagged SNAPGPU_PAIR_POOL_OVERFLOW by the first pass -> list for the second pass
 // (stale != 0: instead the pairs whose traceback left the band and whose pools did not overflow -> list for the exact pass)
 template <int UNUSED>
-__global__ void k_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale)
+__global__ void k_collect_flagged(snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const bool ov = (primary[i].flags & SNAPGPU_PAIR_POOL_OVERFLOW) != 0;
-    if (stale ? (!ov && (primary[i].flags & SNAPGPU_PAIR_EXACT_REPLAY) != 0) : ov) list[atomicAdd(count, 1u)] = i;
+    const uint32_t fl = primary[i].flags;
+    const bool ov = (fl & SNAPGPU_PAIR_POOL_OVERFLOW) != 0;
+    if (stale && (fl & SNAPGPU_PAIR_REPLAYED_BESIDE)) { primary[i].flags = fl & ~SNAPGPU_PAIR_REPLAYED_BESIDE; return; }   // already redone beside the main pass
+    if (stale ? (!ov && (fl & SNAPGPU_PAIR_EXACT_REPLAY) != 0) : ov) list[atomicAdd(count, 1u)] = i;
 }

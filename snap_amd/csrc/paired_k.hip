@@ -28,7 +28,7 @@ extern "C" void PE_CAT(snapgpu_launch_paired_, PAIRED_AGC)(const PairedArgs *a, 
 #endif
 
 #if PAIRED_AGC == 3 && !defined(PAIRED_SEC)
-extern "C" void snapgpu_launch_collect_flagged(const snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale, hipStream_t s)
+extern "C" void snapgpu_launch_collect_flagged(snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale, hipStream_t s)
 {
     hipLaunchKernelGGL(k_collect_flagged<0>, dim3((n + 255) / 256), dim3(256), 0, s, primary, n, list, count, stale);
 }

@@ -53,11 +53,62 @@ static __device__ __forceinline__ unsigned long long plane_bits_bwd(const W *x, 
 }
 
 // What lv_compute needs to build its bitmaps from planes: P(i) = pattern bit (p_org + st * i), T(j) = text bit (t_org + st * j).
+// The prepared form: what a call has to do once so that a diagonal's bitmap costs a few operations per word.
+//   pw[plane][m]  the pattern, oriented: bit i of word m = plane bit of P(64 m + i)
+//   sw[plane][m]  the text, oriented and shifted by K = the call's limit: bit j of the string = plane bit of T(j - K), so that diagonal d's
+//                 window for positions 64 w .. 64 w + 63 is the 64 bits starting at bit K + d + 64 w -- the same shift for every w of a lane
+// n_pw = ceil(pattern_len / 64), n_sw = ceil((pattern_len + 2 K) / 64) + 1 words per plane; `work` holds 4 n_pw + 3 n_sw words.
+static __host__ __device__ __forceinline__ uint32_t lv_plane_work_words(uint32_t RL) { const uint32_t n_pw = (RL + 63) / 64, n_sw = (RL + 62 + 63) / 64 + 2; return 4 * n_pw + 3 * n_sw; }
+
 struct LvPlanes {
     const LDS_AS unsigned long long *p0, *p1, *pn, *po;   // pattern: code bits (non-ACGT: bit 0 = the byte is 'n'), 'N' or 'n', any other byte
     const LDS_AS unsigned long long *t0, *t1, *tn;        // text: code bits ('n' : bit 0 set), not ACGT
     int p_org, t_org, st, p_words, t_words;
+    LDS_AS unsigned long long *work;                      // lv_plane_work_words(RL) words of LDS for the prepared form
+    bool plain;                                           // the pattern is all ACGT: its 'N' / other planes are empty
 };
+
+// once per call (every lane takes words of the job): the oriented pattern and the oriented, shifted text
+static __device__ __forceinline__ void lv_planes_prepare(const LvPlanes &pl, int K, int pattern_len, int n_pw, int n_sw) {
+    const int lane = lane_id();
+    LDS_AS unsigned long long *pw = pl.work, *sw = pl.work + 4 * n_pw;
+    const int n_p = (pl.plain ? 2 : 4) * n_pw, n_jobs = n_p + 3 * n_sw;
+    for (int j = lane; j < n_jobs; j += WAVE) {
+        if (j < n_p) {
+            const int plane = j / n_pw, m = j - plane * n_pw;
+            const LDS_AS unsigned long long *x = plane == 0 ? pl.p0 : plane == 1 ? pl.p1 : plane == 2 ? pl.pn : pl.po;
+            pw[plane * n_pw + m] = pl.st > 0 ? plane_bits_fwd(x, pl.p_org + 64 * m, pl.p_words) : plane_bits_bwd(x, pl.p_org - 64 * m, pl.p_words);
+        } else {
+            const int jj = j - n_p, plane = jj / n_sw, m = jj - plane * n_sw;
+            const LDS_AS unsigned long long *x = plane == 0 ? pl.t0 : plane == 1 ? pl.t1 : pl.tn;
+            sw[plane * n_sw + m] = pl.st > 0 ? plane_bits_fwd(x, pl.t_org - K + 64 * m, pl.t_words) : plane_bits_bwd(x, pl.t_org + K - 64 * m, pl.t_words);
+        }
+    }
+    (void)pattern_len;
+}
+// diagonal d's bitmap word w from the prepared form (same value as lv_plane_mask_word)
+static __device__ __forceinline__ unsigned long long lv_planes_word(const LvPlanes &pl, int K, int d, int w, int end, int n_pw, int n_sw) {
+    const LDS_AS unsigned long long *pw = pl.work, *sw = pl.work + 4 * n_pw;
+    const int sh = K + d, base = (sh >> 6) + w, s = sh & 63;
+    unsigned long long b[3];
+#pragma unroll
+    for (int plane = 0; plane < 3; plane++) {
+        const unsigned long long lo = sw[plane * n_sw + base], hi = sw[plane * n_sw + base + 1];
+        b[plane] = (lo >> s) | ((hi << 1) << (63 - s));
+    }
+    const unsigned long long a0 = pw[w], a1 = pw[n_pw + w];
+    unsigned long long eq = ~b[2] & ~((a0 ^ b[0]) | (a1 ^ b[1]));
+    if (!pl.plain) {
+        const unsigned long long an = pw[2 * n_pw + w], ao = pw[3 * n_pw + w];
+        eq = (eq & ~(an | ao)) | (an & b[2] & ~(a0 ^ b[0]));
+    }
+    unsigned long long mm = ~eq;
+    const int i0 = 64 * w;
+    if (end <= i0) mm = ~0ull;
+    else if (end < i0 + 64) mm |= ~0ull << (end - i0);
+    if (-d > i0) mm |= (-d >= i0 + 64) ? ~0ull : ((1ull << (-d - i0)) - 1ull);
+    return mm;
+}
 
 // bits i = 64 w .. 64 w + 63 of diagonal d's mismatch bitmap: set where i >= end, d + i < 0, or P(i) != T(d + i)  (lv.h: build_mask)
 static __device__ __forceinline__ unsigned long long lv_plane_mask_word(const LvPlanes &pl, int d, int w, int end) {

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     al.wl_prev = (uint16_t *)(my + L.wl_prev);
     al.lv_tri = (uint16_t *)(my + L.lv);
     al.ag_rows = (int16_t *)(my + L.ag);
-    al.rp = (unsigned long long *)(my + L.rp); al.tp = (unsigned long long *)(my + L.tp);
+    al.rp = (unsigned long long *)(my + L.rp); al.tp = (unsigned long long *)(my + L.tp); al.lvp = (unsigned long long *)(my + L.lvp);
     uint8_t *sc = a.scratch + (size_t)wave_slot * a.cfg.scratch_stride;
     al.heads = (uint16_t *)sc;
     al.pool = (Elem *)(sc + (size_t)a.cfg.ht_size * 2);

@@ -266,6 +266,8 @@ struct snapgpu_ctx {
     // exact replay of flagged reads / pairs: the reference's traceback arrays per replay wave (2 per read, 4 per pair)
     uint8_t *d_exact_persist = nullptr; uint64_t exact_persist_stride = 0; uint32_t exact_slots = 0;
     uint8_t *d_pexact_persist = nullptr; uint64_t pexact_persist_stride = 0; uint32_t pexact_slots = 0;
+    // the exact kernel beside the paired main pass (launch_paired, opt-in): its stream, fork / join events
+    hipStream_t replay_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int replay_beside = 0;
     // 192-position variant: the exact kernels ARE the main pass (every wave keeps the images; each unit clears what the last one wrote)
     bool always_exact = false, p_always_exact = false;
     // Phase-4 help (paired_dev.h): [done counter | slots] and the per-slot PEHelpSpec arrays
@@ -441,6 +443,9 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_pscratch_sec_big) (void)hipFree(ctx->d_pscratch_sec_big);
     for (int i = 0; i < 4; i++) if (ctx->d_psec_stage[i]) (void)hipFree(ctx->d_psec_stage[i]);
     if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
+    if (ctx->replay_stream) (void)hipStreamDestroy(ctx->replay_stream);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->d_exact_persist) (void)hipFree(ctx->d_exact_persist);
     if (ctx->d_pexact_persist) (void)hipFree(ctx->d_pexact_persist);
     if (ctx->d_help) (void)hipFree(ctx->d_help);
@@ -1569,7 +1574,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
             if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
             ctx->d_flag_list = nullptr; ctx->flag_list_cap = 0;
             size_t cap = (size_t)n + n / 4 + 1024;
-            HIPCHK(ctx, hipMalloc((void **)&ctx->d_flag_list, cap * 4), SNAPGPU_E_NOMEM);
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_flag_list, cap * 8), SNAPGPU_E_NOMEM);     // (second half: launch_paired's list of pairs for the exact kernel beside the main pass)
             ctx->flag_list_cap = cap;
         }
         a.flag_list = ctx->d_flag_list; a.flag_count = ctx->d_work + 4;
@@ -1999,6 +2004,12 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream), SNAPGPU_E_NODEVICE);
     }
     ctx->heavy_first = getenv("SNAPGPU_PAIRED_HEAVY_FIRST") != nullptr && atoi(getenv("SNAPGPU_PAIRED_HEAVY_FIRST")) != 0;
+    if (const char *e = getenv("SNAPGPU_PAIRED_REPLAY_BESIDE")) ctx->replay_beside = atoi(e) != 0 ? 1 : 0;
+    if (!ctx->replay_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->replay_stream, hipStreamNonBlocking), SNAPGPU_E_NODEVICE);
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming), SNAPGPU_E_NODEVICE);
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming), SNAPGPU_E_NODEVICE);
+    }
     ctx->paired = true;
     return setup_paired_secondary(ctx);
 }
@@ -2026,7 +2037,7 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         if (ctx->d_flag_list) (void)hipFree(ctx->d_flag_list);
         ctx->d_flag_list = nullptr; ctx->flag_list_cap = 0;
         size_t cap = (size_t)n + n / 4 + 1024;
-        HIPCHK(ctx, hipMalloc((void **)&ctx->d_flag_list, cap * 4), SNAPGPU_E_NOMEM);
+        HIPCHK(ctx, hipMalloc((void **)&ctx->d_flag_list, cap * 8), SNAPGPU_E_NOMEM);     // (second half: launch_paired's list of pairs for the exact kernel beside the main pass)
         ctx->flag_list_cap = cap;
     }
     uint32_t blocks = (so ? ctx->p_sec_slots : ctx->p_wave_slots) / 4;
@@ -2070,18 +2081,67 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         return hipMemsetAsync(ctx->d_help, 0, ctx->help_bytes, s);
     };
     HIPCHK(ctx, with_help(a), SNAPGPU_E_LAUNCH);
+    PairedArgs b = so ? ctx->pargs_sec_big : ctx->pargs_big;       // the second / third pass: a few waves over large slabs
+    b.ix = ctx->ix;
+    b.secondary = a.secondary; b.sec_out_stride = a.sec_out_stride; b.n_secondary = a.n_secondary;
+    b.single_secondary = a.single_secondary; b.ssec_out_stride = a.ssec_out_stride; b.n_single_secondary = a.n_single_secondary;
+    b.bases = a.bases; b.quals = a.quals; b.offsets = a.offsets; b.n_pairs = n; b.primary = a.primary; b.first_alt = a.first_alt;
+    b.counters = a.counters; b.is_replay = 1; b.rq = nullptr; b.rq_list = nullptr; b.rq_mode = 0;
+    // The exact replay BESIDE the main pass (PairedArgs::rq), SNAPGPU_PAIRED_REPLAY_BESIDE=1: flagged pairs are redone while the main pass
+    // is still running instead of in a launch of their own after it (6 pairs, 1.8 s of a 5.6 s call on the bench batch, profiles/r03z).
+    // OFF by default, for two measured reasons (profiles/r03p): (1) the pairs that get flagged are the heaviest ones, which the main pass
+    // finishes last, so little of the replay overlaps it -- one context 5.92 -> 5.53 s per 500 k pairs, not the 1.8 s; (2) a kernel that
+    // waits for another kernel is only safe while the two sit in different hardware queues: with three feeders (six streams over the
+    // runtime's four queues) a waiting exact kernel ended up in front of another context's main kernel and the launches advanced only by
+    // the list's watchdog.  Never used with more than one feeder, whatever the variable says.
+    bool beside = !so && !p_always && ctx->d_pexact_persist != nullptr && ctx->replay_stream != nullptr && !getenv("SNAPGPU_NO_EXACT_REPLAY") &&
+                  ctx->replay_beside == 1 && ctx->feeders->load() <= 1;
+    a.rq = nullptr; a.rq_list = nullptr; a.rq_mode = 0;
+    a.dbg_flag_every = b.dbg_flag_every = 0;
+    if (const char *e = getenv("SNAPGPU_DEBUG_PAIRED_FLAG_EVERY")) a.dbg_flag_every = b.dbg_flag_every = (uint32_t)strtoul(e, nullptr, 10);
+    PairedArgs xr = b;
+    uint32_t xr_blocks = 0;
+    if (beside) {
+        a.rq = ctx->d_work + 8; a.rq_list = ctx->d_flag_list + ctx->flag_list_cap; a.rq_mode = 1;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 8, 0, 16, s), SNAPGPU_E_LAUNCH);
+        HIPCHK(ctx, hipMemsetAsync(a.rq_list, 0xff, (size_t)n * 4, s), SNAPGPU_E_LAUNCH);
+        xr.rq = a.rq; xr.rq_list = a.rq_list; xr.rq_mode = 2;
+        xr.work_counter = ctx->d_work + 3; xr.remap = nullptr; xr.n_remap = nullptr;
+        xr.persist = ctx->d_pexact_persist; xr.persist_stride = ctx->pexact_persist_stride;
+        xr.help = nullptr; xr.n_help = 0; xr.help_spec = nullptr; xr.help_spec_cap = 0; xr.help_done = nullptr; xr.help_min = 0xffffffffu; xr.help_eager = 0;
+        uint32_t slots = ctx->p_big_slots; if (slots > ctx->pexact_slots) slots = ctx->pexact_slots;
+        xr_blocks = slots / 4;
+        // both kernels resident from the start: the exact kernel's blocks have the footprint of the main kernel's (same launch bounds, same
+        // LDS), so the main grid leaves them their wave slots
+        const uint32_t all_blocks = ctx->p_wave_slots / 4;
+        if (blocks + xr_blocks > all_blocks && all_blocks > 2 * xr_blocks) blocks = all_blocks - xr_blocks;
+    }
+    auto launch_beside = [&](hipStream_t st) {
+        if (ctx->p_ag_variant == 3) snapgpu_launch_paired_exact_3(&xr, xr_blocks, lds, st); else snapgpu_launch_paired_exact_0(&xr, xr_blocks, lds, st);
+    };
+#ifndef SNAPGPU_WAVE_EMU
+    if (beside) {                      // fork: the exact kernel goes first, on its own stream, behind everything `s` has been given so far
+        HIPCHK(ctx, hipEventRecord(ctx->ev_fork, s), SNAPGPU_E_LAUNCH);
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->replay_stream, ctx->ev_fork, 0), SNAPGPU_E_LAUNCH);
+        launch_beside(ctx->replay_stream);
+        HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_join, ctx->replay_stream), SNAPGPU_E_LAUNCH);
+    }
+#endif
     launch(a, blocks);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    if (beside) {
+#ifdef SNAPGPU_WAVE_EMU
+        launch_beside(s);              // (the emulator runs a kernel to its end at the launch: the list is complete when this one starts)
+#else
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0), SNAPGPU_E_LAUNCH);        // join
+#endif
+    }
     {   // second pass over the pairs the first flagged (usually none: the launch then ends at once)
         uint32_t *d_count = ctx->d_work + 2, *d_work2 = ctx->d_work + 1;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 1, 0, 8, s), SNAPGPU_E_LAUNCH);
-        snapgpu_launch_collect_flagged((const snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count, 0, s);
-        PairedArgs b = so ? ctx->pargs_sec_big : ctx->pargs_big;
-        b.ix = ctx->ix;
-        b.secondary = a.secondary; b.sec_out_stride = a.sec_out_stride; b.n_secondary = a.n_secondary;
-        b.single_secondary = a.single_secondary; b.ssec_out_stride = a.ssec_out_stride; b.n_single_secondary = a.n_single_secondary;
-        b.bases = a.bases; b.quals = a.quals; b.offsets = a.offsets; b.n_pairs = n; b.primary = a.primary; b.first_alt = a.first_alt;
-        b.work_counter = d_work2; b.counters = a.counters; b.remap = ctx->d_flag_list; b.n_remap = d_count; b.is_replay = 1;
+        snapgpu_launch_collect_flagged((snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count, 0, s);
+        b.work_counter = d_work2; b.remap = ctx->d_flag_list; b.n_remap = d_count;
         HIPCHK(ctx, with_help(b), SNAPGPU_E_LAUNCH);
         launch(b, (so ? ctx->p_sec_big_slots : ctx->p_big_slots) / 4);
         HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
@@ -2090,7 +2150,7 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         if (!p_always && ctx->d_pexact_persist && !getenv("SNAPGPU_NO_EXACT_REPLAY")) {
             uint32_t *d_count3 = ctx->d_work + 4, *d_work3 = ctx->d_work + 3;
             HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 3, 0, 8, s), SNAPGPU_E_LAUNCH);
-            snapgpu_launch_collect_flagged((const snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count3, 1, s);
+            snapgpu_launch_collect_flagged((snapgpu_paired_result *)d_primary, n, ctx->d_flag_list, d_count3, 1, s);
             PairedArgs x = b;
             x.work_counter = d_work3; x.remap = ctx->d_flag_list; x.n_remap = d_count3;
             x.persist = ctx->d_pexact_persist; x.persist_stride = ctx->pexact_persist_stride;

@@ -124,6 +124,7 @@ typedef struct emu_stream *hipStream_t;
 typedef struct emu_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 #define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
 struct hipDeviceProp_t {
     char name[256];
     char gcnArchName[256];
@@ -147,6 +148,8 @@ hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize();
 hipError_t hipEventCreate(hipEvent_t *e);
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned flags);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);

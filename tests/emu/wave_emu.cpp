@@ -445,6 +445,8 @@ hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event(); return hipSuccess; }
+hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = new emu_event(); return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }      // (every launch has run to its end when it returns)
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

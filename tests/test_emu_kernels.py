@@ -147,6 +147,14 @@ def test_emu_paired_end(emu):
     assert (alt["status"] == z[key + "_alt"]["status"][:n]).all()
 
 
+def test_emu_exact_replay_beside_the_main_pass(emu, monkeypatch):
+    """tests/test_gpu_paired.py::test_exact_replay_beside_the_main_pass on the emulated device (the exact kernel there starts when the main
+    kernel has ended: the list protocol, the markers and the pass after it, not the concurrency), first 150 golden pairs."""
+    import tests.test_gpu_paired as gp
+    gp.test_exact_replay_beside_the_main_pass(util.load_golden_index("paired_index.npz"), np.load(os.path.join(util.GOLDEN, "paired_reads.npz")),
+                                              monkeypatch, n=150)
+
+
 def test_emu_paired_end_lv_only_hamming_retry_uses_affine_gap(emu):
     """`use_affine_gap = 0` with soft clipping: the Hamming retry of the chimeric fallback still calls alignAffineGap
     (ChimericPairedEndAligner.cpp:330-360), so the affine-gap LDS rows and traceback slab must exist in that configuration
@@ -197,11 +205,17 @@ def test_emu_phase4_help_on_demand(emu, monkeypatch, eager):
     monkeypatch.setenv("SNAPGPU_PAIRED_HELP_MIN", "16")
     if eager:
         monkeypatch.setenv("SNAPGPU_PAIRED_HELP_EAGER", "1")
-    a = ChimericPairedEndAligner(GenomeIndex.load_from_directory(d + "/idx"), params, pparams)
+    gi = GenomeIndex.load_from_directory(d + "/idx")
+    a = ChimericPairedEndAligner(gi, params, pparams)
     try:
         a.counters(reset=True)
         got, _ = a.align(pairs["bases"], pairs["quals"], pairs["offsets"])
         c = a.counters()
+        a.close()
+        if eager:       # who scored a candidate leaves no trace: every byte (the informational flags too) as without help
+            monkeypatch.setenv("SNAPGPU_PAIRED_HELP_MIN", "0")
+            a = ChimericPairedEndAligner(gi, params, pparams)
+            alone, _ = a.align(pairs["bases"], pairs["quals"], pairs["offsets"])
     finally:
         a.close()
         shutil.rmtree(d, ignore_errors=True)
@@ -209,6 +223,7 @@ def test_emu_phase4_help_on_demand(emu, monkeypatch, eager):
     assert c["help_watchdog_events"] == 0
     if eager:
         assert c["help_lists_published"] > 0 and c["help_answers_used"] > 0
+        assert got.tobytes() == alone.tobytes()
 
 
 @pytest.mark.parametrize("seed_len,large", [(24, False), (22, True)])

@@ -71,6 +71,34 @@ def test_results_do_not_depend_on_batch_composition(pindex, golden_pairs):
     a.close()
 
 
+def test_exact_replay_beside_the_main_pass(pindex, golden_pairs, monkeypatch, n=None):
+    """launch_paired's exact kernel on its own stream, fed by the main kernel while it runs (PairedArgs::rq): with every fifth pair flagged
+    by the test hook, the records equal those of the launch-after-launch scheme byte for byte, equal the fixture, and the internal marker
+    does not leave the call.  (Also run twice per aligner: the list, its counters and the images are per call.)"""
+    z = golden_pairs
+    key = "default_d8_150_s0"
+    n = n or (z["o150"].size - 1) // 2
+    o = z["o150"][:2 * n + 1]
+    b, q = z["b150"].reshape(-1)[:int(o[-1])], z["q150"].reshape(-1)[:int(o[-1])]
+    from tests.test_paired_host import OPTS
+    kw, pkw = OPTS[key[:-len("_150_s0")]]
+    monkeypatch.setenv("SNAPGPU_DEBUG_PAIRED_FLAG_EVERY", "5")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SNAPGPU_PAIRED_REPLAY_BESIDE", mode)
+        a = _aligner(pindex, kw, pkw)
+        first, _ = a.align(b, q, o)
+        again, _ = a.align(b, q, o)
+        a.close()
+        assert first.tobytes() == again.tobytes()
+        out[mode] = first
+    assert out["1"].tobytes() == out["0"].tobytes()
+    got = out["1"]
+    assert ((got["flags"] & 4) != 0).sum() >= (n + 4) // 5 and (got["flags"] & ~np.uint32(7)).max() == 0      # 4: SNAPGPU_PAIR_EXACT_REPLAY
+    exp, _ = util.with_fresh_overrides(z[key + "_primary"], "pe_" + key + "_primary")
+    assert not compare_paired(exp[:n], got, verbose=3).any()
+
+
 @pytest.mark.parametrize("maxk,L,npairs", [(8, 150, 4000), (20, 250, 1500), (27, 150, 1500), (27, 420, 600)])   # 420 bp: the AGC = 0 kernel variant
 def test_align_paired_vs_reference_live(tmp_path, maxk, L, npairs):
     """C3 / C5-shaped inputs on a repeat-rich 3 Mb genome, diffed against the reference run on the box's host cores."""
