@@ -20,6 +20,8 @@
  *   snapgpu_compute_cigar_lv
  *       SAMFormat::computeCigar (LV variant)    SNAPLib/SAM.cpp:2354-2467
  *       LandauVishkinWithCigar::computeEditDistanceNormalized / computeEditDistance  SNAPLib/LandauVishkin.cpp:507-648 / 141-505
+ *   snapgpu_adjust_alignments
+ *       AlignmentAdjuster::AdjustAlignment      SNAPLib/AlignmentAdjuster.cpp:33-190 (the `-ae` step, BaseAligner.cpp:2444-2463)
  *   snapgpu_sam_fields_paired
  *       SAMFormat::writePairs / fillMateInfo    SNAPLib/SAM.cpp:1575-1895 / 1308-1421; SimpleReadWriter::writePairs SNAPLib/ReadWriter.cpp:345-520
  *   snapgpu_sam_fields_single
@@ -333,6 +335,20 @@ int  snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
                             int32_t *total_indels, int32_t *text_span);
 
 /*
+ * AlignmentAdjuster::AdjustAlignment (SNAPLib/AlignmentAdjuster.cpp:33-190) for a batch of results: what finalizeSecondaryResults does to
+ * the primary and to every secondary result before the -om filter when the aligner runs with -ae (BaseAligner.cpp:2444-2463), and what
+ * snapgpu_enable_secondary's adjust_alignments = 1 runs inside the alignment kernels.  Result i belongs to read
+ * data[off[i] .. off[i] + len[i]) (as given to AlignRead: forward strand, no clipping of its own).
+ *   in:  results[i].status / direction / location / score
+ *   out: results[i].score = the edit distance LandauVishkinWithCigar::computeEditDistanceNormalized finds (k = MAX_K - 1); location moved
+ *        and clipping_for_read_adjustment set when that alignment began with an indel; status = NotFound, location =
+ *        InvalidGenomeLocation32 when moving it would leave the contig (:139-148).  NotFound results are left alone.
+ * Host pointers; the genome is the one resident on the device.  Returns SNAPGPU_OK or a negative error.
+ */
+int  snapgpu_adjust_alignments(snapgpu_ctx *ctx, uint32_t n, const char *data, uint64_t data_bytes, const uint64_t *off, const int32_t *len,
+                               snapgpu_single_result *results);
+
+/*
  * The CIGAR of a written read (first step of result -> SAM record on the device):
  * SAMFormat::computeCigar, Landau-Vishkin variant (SNAPLib/SAM.cpp:2354-2467), over
  * LandauVishkinWithCigar::computeEditDistanceNormalized (SNAPLib/LandauVishkin.cpp:507-648, BAM_CIGAR_OPS format) -- what
@@ -468,7 +484,9 @@ typedef struct snapgpu_secondary_params {
     int32_t  max_edit_distance;    /* -om  maxSecondaryAlignmentAdditionalEditDistance, 0 <= om <= extra_search_depth   */
     int32_t  max_per_contig;       /* -mpc maxSecondaryAlignmentsPerContig, -1 = no limit                                */
     int64_t  max_results;          /* -omax maxSecondaryAlignments, 0x7fffffff                                           */
-    uint32_t adjust_alignments;    /* -ae (!ignoreAlignmentAdjustmentsForOm); must be 0 in this build                    */
+    uint32_t adjust_alignments;    /* -ae (!ignoreAlignmentAdjustmentsForOm): AlignmentAdjuster::AdjustAlignment on the primary and on
+                                      every secondary result before the -om filter (BaseAligner.cpp:2444-2463); single-end contexts only:
+                                      with snapgpu_enable_paired on the same context the call returns SNAPGPU_E_UNSUPPORTED               */
 } snapgpu_secondary_params;
 
 /* Sizes the per-wavefront secondary-result lists of `ctx` (2 * seeds * max_hits entries each: they cannot overflow, so the

@@ -41,6 +41,22 @@ def lib():
     return _lib
 
 
+class adjust_alignments:
+    """`with ref.adjust_alignments():` -- the reference aligners are constructed with ignoreAlignmentAdjustmentsForOm = false, i.e. `-ae`
+    (AlignerOptions.cpp:476): AlignmentAdjuster::AdjustAlignment runs on the primary and on every secondary result before the -om filter
+    (BaseAligner.cpp:2444-2463).  Single-end entry points only."""
+    def __init__(self, on=True):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = lib().snapref_get_adjust_alignments()
+        lib().snapref_set_adjust_alignments(1 if self.on else 0)
+        return self
+
+    def __exit__(self, *a):
+        lib().snapref_set_adjust_alignments(self.prev)
+
+
 class fresh_objects:
     """`with ref.fresh_objects():` -- every read / pair is aligned by reference aligner objects newly constructed in zero-filled memory
     (oracle/ref_driver.cpp: ZeroedArena), so the reference's answer is a function of the read alone and EVERY read can be compared
@@ -105,6 +121,16 @@ class RefIndex:
         if rc != 0:
             raise RuntimeError("snapref_compute_cigar_lv rc=%d" % rc)
         return dict(ops=ops, n_ops=n_ops, edit_distance=ed, add_front_clipping=afc, extra_clipped_after=after)
+
+    def adjust_alignments(self, data, off, length, results):
+        """AlignmentAdjuster::AdjustAlignment for a batch; see snapref_adjust_alignments.  Returns the adjusted copy of `results`."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(off, dtype=np.uint64); length = np.ascontiguousarray(length, dtype=np.int32)
+        out = np.ascontiguousarray(results, dtype=RESULT_DTYPE).copy()
+        rc = lib().snapref_adjust_alignments(self.handle, C.c_uint32(off.size), ptr(data), ptr(off), ptr(length), ptr(out))
+        if rc != 0:
+            raise RuntimeError("snapref_adjust_alignments rc=%d" % rc)
+        return out
 
     def compute_cigar_ag(self, data, quals, off, length, loc, extra_before, score, use_m: bool, fresh_object: bool = False,
                          ops_stride: int = 64, agparams=(1, 4, 6, 1)):

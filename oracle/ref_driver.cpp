@@ -34,6 +34,7 @@
 #include "IntersectingPairedEndAligner.h"
 #include "ChimericPairedEndAligner.h"
 #include "SAM.h"
+#include "AlignmentAdjuster.h"
 
 #include <pthread.h>
 #include <string.h>
@@ -281,6 +282,10 @@ private:
 static volatile int g_fresh_objects = 0;
 void snapref_set_fresh_objects(int on) { g_fresh_objects = on; }
 int snapref_get_fresh_objects(void) { return g_fresh_objects; }
+/* -ae (AlignerOptions.cpp:476): the aligners below are constructed with ignoreAlignmentAdjustmentsForOm = !g_adjust_alignments */
+static volatile int g_adjust_alignments = 0;
+void snapref_set_adjust_alignments(int on) { g_adjust_alignments = on; }
+int snapref_get_adjust_alignments(void) { return g_adjust_alignments; }
 
 struct AlignJob {
     GenomeIndex *index;
@@ -314,7 +319,7 @@ static void *align_thread(void *arg)
 #define NEW_SINGLE_ALIGNER() new (allocator) BaseAligner( \
         index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check, \
         p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, \
-        true /* ignoreAlignmentAdjustmentsForOm: the default, AlignerOptions.cpp:96 */, \
+        g_adjust_alignments == 0 /* ignoreAlignmentAdjustmentsForOm: true by default (AlignerOptions.cpp:96), false with -ae */, \
         p->alt_awareness != 0, p->emit_alt_alignments != 0, p->max_score_gap_to_prefer_non_alt, \
         -1 /* maxSecondaryAlignmentsPerContig */, NULL, NULL, \
         p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty, \
@@ -472,6 +477,33 @@ int snapref_compute_cigar_lv(void *vindex, uint32_t n, const char *data, const u
     return 0;
 }
 
+/* AlignmentAdjuster::AdjustAlignment (AlignmentAdjuster.cpp:33-190) for a batch: result i is (status, direction, location, score) of read
+ * data[off[i] .. off[i] + len[i]) -- a Read without clipping of its own, as AlignRead's caller in this driver makes them. */
+int snapref_adjust_alignments(void *vindex, uint32_t n, const char *data, const uint64_t *off, const int32_t *len, snapgpu_single_result *results)
+{
+    GenomeIndex *index = (GenomeIndex *)vindex;
+    AlignmentAdjuster adjuster(index->getGenome());
+    std::vector<char> bbuf(MAX_READ_LENGTH + 2 * SLACK, 0), qbuf(MAX_READ_LENGTH + 2 * SLACK, 'I');
+    for (uint32_t i = 0; i < n; i++) {
+        memcpy(&bbuf[SLACK], data + off[i], (size_t)len[i]);
+        Read read;
+        read.init("r", 1, &bbuf[SLACK], &qbuf[SLACK], (unsigned)len[i], NULL, 0);
+        SingleAlignmentResult r;
+        memset(&r, 0, sizeof(r));
+        r.status = (AlignmentResult)results[i].status;
+        r.direction = (Direction)results[i].direction;
+        r.location = GenomeLocation(results[i].location);
+        r.score = results[i].score;
+        r.clippingForReadAdjustment = 0;
+        adjuster.AdjustAlignment(&read, &r);
+        results[i].status = (int32_t)r.status;
+        results[i].location = (int64_t)GenomeLocationAsInt64(r.location);
+        results[i].score = r.score;
+        results[i].clipping_for_read_adjustment = r.clippingForReadAdjustment;
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------- secondary results (-om)
 
 struct SecJob {
@@ -503,7 +535,7 @@ static void *align_secondary_thread(void *arg)
 #define NEW_SEC_ALIGNER() new (allocator) BaseAligner( \
         index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check, \
         p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, \
-        true /* ignoreAlignmentAdjustmentsForOm */, p->alt_awareness != 0, p->emit_alt_alignments != 0, \
+        g_adjust_alignments == 0 /* ignoreAlignmentAdjustmentsForOm */, p->alt_awareness != 0, p->emit_alt_alignments != 0, \
         p->max_score_gap_to_prefer_non_alt, job->mpc, NULL, NULL, \
         p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty, \
         p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator)

@@ -301,11 +301,14 @@ public:
         if (c->index == NULL) {
             return false;                                   // I/O-only mode (SingleAligner.cpp:106-131): leave it to SNAP
         }
-        if (c->options->stopOnFirstHit || c->options->explorePopularSeeds ||
-            !c->ignoreAlignmentAdjustmentForOm || c->index->doesGenomeIndexHave64BitLocations()) {
-            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-f, -x, -ae or a 64-bit index)\n");
+        if (c->options->stopOnFirstHit || c->options->explorePopularSeeds || c->index->doesGenomeIndexHave64BitLocations()) {
+            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-f, -x or a 64-bit index)\n");
             soft_exit(1);
         }
+        // -ae (!ignoreAlignmentAdjustmentForOm): with -om the library adjusts primary and secondary results before its filter
+        // (snapgpu_secondary_params::adjust_alignments); without, finalizeSecondaryResults has only the primary to adjust
+        // (BaseAligner.cpp:2444-2452) and snapgpu_adjust_alignments does that to the batch
+        const bool adjustPrimaries = !c->ignoreAlignmentAdjustmentForOm;
         ensureContext(c, c->numSeedsFromCommandLine);
         const bool secondary = c->maxSecondaryAlignmentAdditionalEditDistance >= 0;      // -om
         if (secondary) ensureSecondary(c);
@@ -322,6 +325,7 @@ public:
         ReadWithOwnMemory *reads = (ReadWithOwnMemory *)BigAlloc((size_t)BATCH * sizeof(ReadWithOwnMemory));
         std::vector<char> bases, quals;
         std::vector<uint64_t> offs;
+        std::vector<int32_t> lens;
         std::vector<snapgpu_single_result> prim(BATCH), alt(BATCH);
         bool more = true;
         while (more) {
@@ -368,6 +372,11 @@ public:
                 }
             } else {
                 rc = snapgpu_align_single(slot->ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
+                if (rc == SNAPGPU_OK && adjustPrimaries) {
+                    lens.resize(n);
+                    for (unsigned i = 0; i < n; i++) lens[i] = (int32_t)(offs[i + 1] - offs[i]);
+                    rc = snapgpu_adjust_alignments(slot->ctx, n, &bases[0], (uint64_t)bases.size(), &offs[0], &lens[0], &prim[0]);
+                }
             }
             pthread_mutex_unlock(&slot->lock);
             if (rc != SNAPGPU_OK) {

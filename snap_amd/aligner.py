@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
     "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
     "snapgpu_align_paired_secondary", "snapgpu_align_paired_secondary_device",
-    "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag", "snapgpu_sam_fields_single", "snapgpu_sam_fields_single_device", "snapgpu_sam_fields_paired",
+    "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag", "snapgpu_adjust_alignments", "snapgpu_sam_fields_single", "snapgpu_sam_fields_single_device", "snapgpu_sam_fields_paired",
     "snapgpu_default_index_build_params", "snapgpu_index_build", "snapgpu_index_build_from_fasta", "snapgpu_built_index_view",
     "snapgpu_built_index_save", "snapgpu_built_index_stats", "snapgpu_built_index_destroy",
 ]
@@ -255,6 +255,17 @@ class BaseAligner:
             C.c_int(1 if use_m else 0), ptr(ops), C.c_uint32(ops_stride), ptr(n_ops), ptr(ed), ptr(afc), ptr(after)),
             "snapgpu_compute_cigar_lv")
         return dict(ops=ops, n_ops=n_ops, edit_distance=ed, add_front_clipping=afc, extra_clipped_after=after)
+
+    def AdjustAlignments(self, data, off, length, results):
+        """AlignmentAdjuster::AdjustAlignment (AlignmentAdjuster.cpp:33-190) for a batch (snapgpu_adjust_alignments): read i =
+        data[off[i] : off[i] + length[i]] as given to AlignRead; results (RESULT_DTYPE) carry status / direction / location / score in and
+        come back with status / location / score / clipping_for_read_adjustment adjusted.  Returns the adjusted copy."""
+        data = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+        off = np.ascontiguousarray(off, dtype=np.uint64); length = np.ascontiguousarray(length, dtype=np.int32)
+        out = np.ascontiguousarray(results, dtype=RESULT_DTYPE).copy()
+        self._check(self.lib.snapgpu_adjust_alignments(self.handle, C.c_uint32(off.size), ptr(data), C.c_uint64(data.size), ptr(off), ptr(length), ptr(out)),
+                    "snapgpu_adjust_alignments")
+        return out
 
     def computeCigarAffineGap(self, data, quals, off, length, loc, extra_before, score, use_m: bool = False, ops_stride: int = 64):
         """SAM.cpp:2470-2588 (the CIGAR of a read scored with affine gap) for a batch; see snapgpu_compute_cigar_ag.  score = the

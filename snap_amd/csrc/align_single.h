@@ -31,6 +31,7 @@
 #include "lv.h"
 #include "ag_win.h"
 #include "se_help.h"
+#include "adjust.h"
 #include <stddef.h>
 #include "../../include/snapgpu.h"
 
@@ -144,6 +145,8 @@ struct SecCfg {
     int32_t  mpc;                      // maxSecondaryAlignmentsPerContig (-1: unlimited)
     int64_t  omax;                     // maxSecondaryResults
     uint32_t cap;                      // entries of per-wave scratch
+    uint32_t adjust;                   // -ae: AlignmentAdjuster on the primary and on every secondary result before the filter (adjust.h)
+    uint64_t adj_off;                  // offset of adjust.h's scratch inside the wave's secondary-result slab
 };
 
 // EXACT: the replay instantiation for reads whose banded affine-gap traceback left the band (`reserved` != 0 after the fast pass): every
@@ -209,6 +212,7 @@ struct Aligner {
     snapgpu_single_result *sec;        // [sec_cfg.cap]
     uint32_t *sec_key, *sec_ord;       // [sec_cfg.cap] each
     uint32_t n_sec, n_sec_raw, sec_overflow;
+    uint8_t *adj_scratch;              // adjust.h (sec_cfg.adjust only)
     // Cold, wave-uniform state lives in LDS (WaveShared), not in registers: it is touched a few
     // times per candidate / per read, and keeping ~150 dwords of it live across the LV and
     // affine-gap code is what pushed the kernel to 1-2 waves per SIMD.  Every lane executes the
@@ -1369,9 +1373,32 @@ struct Aligner {
         WAVE_SYNC(); __threadfence_block();
     }
     __device__ __forceinline__ void finalize_secondary() {
+        int best = (int)first_u32((uint32_t)primary.score);
+        if (sec_cfg.adjust) {                                                          // :2444-2463 (-ae)
+            const AdjustScratch asc = adjust_scratch_at(adj_scratch, cfg.RL);
+            const AdjustIx aix = adjust_ix(ix);
+            {
+                const AdjustOut o = adjust_alignment(aix, rd[0], rd[1], read_len, (int)first_u32((uint32_t)primary.status), (int)first_u32((uint32_t)primary.direction),
+                                                     (long long)first_u64((uint64_t)primary.location), best, SNAPGPU_InvalidGenomeLocation32, asc);
+                primary.status = o.status; primary.location = o.location; primary.score = o.score; primary.clipping_for_read_adjustment = o.clipping;
+                best = o.status != SNAPGPU_NotFound ? o.score : SNAPGPU_TooBigScoreValue;
+            }
+            WAVE_SYNC(); __threadfence_block();
+            for (uint32_t i = 0; i < n_sec; i++) {
+                snapgpu_single_result *r = &sec[i];
+                const int sc0 = (int)first_u32((uint32_t)r->score);
+                const AdjustOut o = adjust_alignment(aix, rd[0], rd[1], read_len, (int)first_u32((uint32_t)r->status), (int)first_u32((uint32_t)r->direction),
+                                                     (long long)first_u64((uint64_t)r->location), sc0, SNAPGPU_InvalidGenomeLocation32, asc);
+                if (lane == 0) {
+                    r->score_prior_to_clipping = sc0;
+                    r->status = o.status; r->location = o.location; r->score = o.score; r->clipping_for_read_adjustment = o.clipping;
+                }
+                if (o.status != SNAPGPU_NotFound && o.score < best) best = o.score;
+            }
+            WAVE_SYNC(); __threadfence_block();
+        }
         uint32_t n = n_sec;
         if (n == 0) return;
-        const int best = (int)first_u32((uint32_t)primary.score);
         int worst = best + sec_cfg.om; if (worst > (int)max_k) worst = (int)max_k;     // :2465
         for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) { sec_ord[i] = i; sec_key[i] = (uint32_t)sec[i].score; }
         WAVE_SYNC(); __threadfence_block();
@@ -1387,7 +1414,7 @@ struct Aligner {
         WAVE_SYNC(); __threadfence_block();
         for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
             snapgpu_single_result *r = &sec[sec_ord[i]];
-            r->score_prior_to_clipping = r->score;
+            if (!sec_cfg.adjust) r->score_prior_to_clipping = r->score;                 // :2478-2480
             r->supplementary = (cfg.alt_aware && is_alt(r->location)) ? 1 : 0;
         }
         WAVE_SYNC(); __threadfence_block();

@@ -54,4 +54,14 @@ struct SamFieldsPairedArgs {
 extern "C" void snapgpu_launch_sam_fields_paired(const SamFieldsPairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 extern "C" void snapgpu_launch_cigar_ag(const CigarAGArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+// snapgpu_adjust_alignments: AlignmentAdjuster::AdjustAlignment for a batch of results (adjust.h), one wavefront per result
+struct AdjustArgs {
+    DevIndex ix;
+    uint32_t n, RL;
+    const uint8_t *data; const uint64_t *off; const int32_t *len;
+    snapgpu_single_result *results;   // in / out: status, direction, location, score -> status, location, score, clipping_for_read_adjustment
+    uint8_t *scratch; uint64_t scratch_stride;        // per wave: the read, its reverse complement (RL bytes each), then adjust_scratch_bytes(RL)
+    uint32_t *work_counter;
+};
+extern "C" void snapgpu_launch_adjust_alignments(const AdjustArgs *a, uint32_t blocks, hipStream_t s);
 extern "C" void snapgpu_launch_cigar_lv(const CigarArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);

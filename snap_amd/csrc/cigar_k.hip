@@ -5,6 +5,7 @@
 #include "cigar_lv.h"
 #include "cigar_ag.h"
 #include "sam_fields.h"
+#include "adjust.h"
 #include "cigar_args.h"
 
 __global__ __launch_bounds__(256) void k_cigar_lv(CigarArgs a)
@@ -184,4 +185,37 @@ __global__ __launch_bounds__(256, 4) void k_sam_fields_paired(SamFieldsPairedArg
 extern "C" void snapgpu_launch_sam_fields_paired(const SamFieldsPairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sam_fields_paired, dim3(blocks), dim3(256), lds_bytes, s, *a);
+}
+
+// AlignmentAdjuster::AdjustAlignment (adjust.h) for a batch: one wavefront per result, persistent grid
+__global__ __launch_bounds__(256) void k_adjust_alignments(AdjustArgs a)
+{
+    const int lane = lane_id();
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t wave_slot = blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave_in_block;
+    uint8_t *mine = a.scratch + (size_t)wave_slot * a.scratch_stride;
+    uint8_t *fwd = mine, *rc = mine + ((a.RL + 255) & ~255u);
+    const AdjustScratch sc = adjust_scratch_at(mine + 2 * (size_t)((a.RL + 255) & ~255u), a.RL);
+    const AdjustIx aix = adjust_ix(a.ix);
+    while (true) {
+        uint32_t i = 0;
+        if (lane == 0) i = atomicAdd(a.work_counter, 1u);
+        i = first_u32(i);
+        if (i >= a.n) break;
+        const uint64_t off = first_u64(a.off[i]);
+        const int len = (int)first_u32((uint32_t)a.len[i]);
+        for (int j = lane; j < len; j += WAVE) { const uint8_t b = a.data[off + j]; fwd[j] = b; rc[len - 1 - j] = rc_base(b); }
+        WAVE_SYNC(); __threadfence_block();
+        snapgpu_single_result *r = a.results + i;
+        const AdjustOut o = adjust_alignment(aix, fwd, rc, len, (int)first_u32((uint32_t)r->status), (int)first_u32((uint32_t)r->direction),
+                                             (long long)first_u64((uint64_t)r->location), (int)first_u32((uint32_t)r->score), SNAPGPU_InvalidGenomeLocation32, sc);
+        WAVE_SYNC();
+        if (lane == 0) { r->status = o.status; r->location = o.location; r->score = o.score; r->clipping_for_read_adjustment = o.clipping; }
+        WAVE_SYNC();
+    }
+}
+
+extern "C" void snapgpu_launch_adjust_alignments(const AdjustArgs *a, uint32_t blocks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_adjust_alignments, dim3(blocks), dim3(256), 0, s, *a);
 }

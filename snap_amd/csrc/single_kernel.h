@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         al.sec_key = (uint32_t *)(ss + (size_t)a.sec_cfg.cap * sizeof(snapgpu_single_result));
         al.sec_ord = al.sec_key + 2 * (size_t)a.sec_cfg.cap;
         al.n_sec = 0;
+        al.adj_scratch = a.sec_cfg.adjust ? ss + a.sec_cfg.adj_off : nullptr;
     }
     al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t n_done = 0;

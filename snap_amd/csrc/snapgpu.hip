@@ -1171,6 +1171,45 @@ extern "C" int snapgpu_compute_cigar_lv(snapgpu_ctx *ctx, uint32_t n, const char
     return sam_side_kernel_time(ctx);
 }
 
+// AlignmentAdjuster::AdjustAlignment for a batch of results (adjust.h, cigar_k.hip)
+extern "C" int snapgpu_adjust_alignments(snapgpu_ctx *ctx, uint32_t n, const char *data, uint64_t data_bytes, const uint64_t *off, const int32_t *len,
+                                         snapgpu_single_result *results)
+{
+    if (!ctx || (n && (!data || !off || !len || !results))) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_adjust_alignments: null argument");
+    if (n == 0) return SNAPGPU_OK;
+    uint32_t RL = 64;
+    for (uint32_t i = 0; i < n; i++) {
+        if (len[i] < 1 || len[i] > 4000) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_adjust_alignments: read length out of range");
+        if (off[i] + (uint64_t)len[i] > data_bytes) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_adjust_alignments: read outside the data buffer");
+        if (results[i].status != SNAPGPU_NotFound && (results[i].location < 0 || (uint64_t)results[i].location >= ctx->ix.n_bases))
+            return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_adjust_alignments: location outside the genome");
+        if (results[i].direction != 0 && results[i].direction != 1) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_adjust_alignments: direction must be 0 (forward) or 1 (reverse complement)");
+        if ((uint32_t)len[i] > RL) RL = (uint32_t)len[i];
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = ctx->stream;
+    uint32_t blocks = (uint32_t)ctx->num_cus * 4;
+    const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
+    const uint64_t stride = 2 * (uint64_t)((RL + 255) & ~255u) + ((adjust_scratch_bytes(RL) + 255) & ~(uint64_t)255);
+    DevBuf dd, doff, dlen, dres, dscr;
+    HIPCHK(ctx, dd.put(data, data_bytes, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, doff.put(off, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dlen.put(len, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dres.put(results, (size_t)n * sizeof(snapgpu_single_result), s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dscr.put(nullptr, (size_t)blocks * 4 * stride, s), SNAPGPU_E_NOMEM);
+    AdjustArgs a;
+    a.ix = ctx->ix; a.n = n; a.RL = RL; a.data = (const uint8_t *)dd.p; a.off = (const uint64_t *)doff.p; a.len = (const int32_t *)dlen.p;
+    a.results = (snapgpu_single_result *)dres.p; a.scratch = (uint8_t *)dscr.p; a.scratch_stride = stride; a.work_counter = ctx->d_work;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    snapgpu_launch_adjust_alignments(&a, blocks, s);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(results, dres.p, (size_t)n * sizeof(snapgpu_single_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    return sam_side_kernel_time(ctx);
+}
+
 // SAMFormat::computeCigar, affine-gap variant, for a batch of written reads (cigar_ag.h, cigar_k.hip).
 extern "C" int snapgpu_compute_cigar_ag(snapgpu_ctx *ctx, uint32_t n, const char *data, const char *quals, uint64_t data_bytes,
                                         const uint64_t *off, const int32_t *len, const int64_t *loc, const int32_t *extra_before,
@@ -1688,7 +1727,8 @@ extern "C" int snapgpu_enable_secondary(snapgpu_ctx *ctx, const snapgpu_secondar
         return fail(ctx, SNAPGPU_E_INVALID, "the max edit distance for secondary alignments (-om) cannot be bigger than the extra search depth (-D) (AlignerContext.cpp:784)");
     if (sp->max_results <= 0) return fail(ctx, SNAPGPU_E_INVALID, "-omax must be strictly positive (AlignerOptions.cpp:621)");
     if (sp->max_per_contig == 0 || sp->max_per_contig < -1) return fail(ctx, SNAPGPU_E_INVALID, "-mpc must be strictly positive, or -1 for no limit (AlignerOptions.cpp:650)");
-    if (sp->adjust_alignments) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "-ae (AlignmentAdjuster before the -om filter, BaseAligner.cpp:2444-2463) is not implemented");
+    if (sp->adjust_alignments && ctx->paired)
+        return fail(ctx, SNAPGPU_E_UNSUPPORTED, "-ae (AlignmentAdjuster before the -om filter) is implemented for BaseAligner::AlignRead (BaseAligner.cpp:2444-2463), not for the paired-end aligners (IntersectingPairedEndAligner.cpp:1298-1320)");
     HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
     // updateBestScore appends at most one entry per ScoreSet per scored candidate, and a read scores at most one candidate per
     // seed hit it applied: maxSeedsToUse * maxHits hits, two score sets (BaseAligner.cpp:451, 627, 1445-1468).
@@ -1699,10 +1739,12 @@ extern "C" int snapgpu_enable_secondary(snapgpu_ctx *ctx, const snapgpu_secondar
     if (cap > (1u << 20)) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "2 * seeds * max_hits > 2^20 secondary candidates per read is not supported");
     uint64_t stride = cap * sizeof(snapgpu_single_result) + cap * 3 * 4;
     stride = (stride + 255) & ~(uint64_t)255;
+    const uint64_t adj_off = stride;
+    if (sp->adjust_alignments) stride += (adjust_scratch_bytes(ctx->cfg.RL) + 255) & ~(uint64_t)255;     // adjust.h: the adjuster's Landau-Vishkin table, op list, staged read and window
     if (ctx->d_sec_scratch) { (void)hipFree(ctx->d_sec_scratch); ctx->d_sec_scratch = nullptr; }
     ctx->secondary = false;
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_sec_scratch, stride * ctx->n_wave_slots), SNAPGPU_E_NOMEM);
-    ctx->sec_cfg = SecCfg{sp->max_edit_distance, sp->max_per_contig, sp->max_results, (uint32_t)cap};
+    ctx->sec_cfg = SecCfg{sp->max_edit_distance, sp->max_per_contig, sp->max_results, (uint32_t)cap, sp->adjust_alignments ? 1u : 0u, adj_off};
     ctx->sec_stride_bytes = stride;
     ctx->secondary = true;
     return setup_paired_secondary(ctx);       // (if the paired-end path is enabled too)
@@ -1821,6 +1863,8 @@ static int setup_paired_secondary(snapgpu_ctx *ctx)
     if (ctx->d_pscratch_sec_big) { (void)hipFree(ctx->d_pscratch_sec_big); ctx->d_pscratch_sec_big = nullptr; }
     ctx->paired_sec = false;
     if (!ctx->paired || !ctx->secondary) return SNAPGPU_OK;
+    if (ctx->sec_cfg.adjust)
+        return fail(ctx, SNAPGPU_E_UNSUPPORTED, "-ae (AlignmentAdjuster before the -om filter) is implemented for BaseAligner::AlignRead, not for the paired-end aligners (IntersectingPairedEndAligner.cpp:1298-1320)");
     PairedArgs &a = ctx->pargs_sec;
     a = ctx->pargs;
     a.pcfg.om = ctx->sec_cfg.om; a.pcfg.mpc = ctx->sec_cfg.mpc; a.pcfg.omax = ctx->sec_cfg.omax;

@@ -1,0 +1,79 @@
+"""Inputs that exercise AlignmentAdjuster (SNAPLib/AlignmentAdjuster.cpp) -- shared by tests/test_gpu_adjust.py, the emulator twins and
+scripts/make_golden_adjust.py.  TEST INFRASTRUCTURE."""
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, np.uint8); _COMP[:] = ord("N")
+for _x, _y in zip(b"ACGT", b"TGCA"):
+    _COMP[_x] = _y
+
+
+def adjust_cases(seed, contigs, cstart, n, L):
+    """(bases[n, L], results[n]): read i is taken from the genome (a few substitutions, sometimes an indel), strand at random, and its
+    result places it at the true location shifted by -6 .. +6 (the adjuster then sees a leading deletion / insertion, sometimes several
+    times over); a quarter of the reads sit at the start of their contig and a quarter at its end (overhang; moves that leave the contig)."""
+    from snap_amd.abi import RESULT_DTYPE
+    rng = np.random.default_rng(seed)
+    b = np.zeros((n, L), np.uint8); res = np.zeros(n, dtype=RESULT_DTYPE)
+    for i in range(n):
+        ci = int(rng.integers(len(contigs))); g = contigs[ci][1]
+        where = i % 4
+        if where == 0: pos = int(rng.integers(0, 12))
+        elif where == 1: pos = len(g) - L - int(rng.integers(0, 12))
+        else: pos = int(rng.integers(20, len(g) - L - 20))
+        r = g[pos:pos + L].copy()
+        kind = int(rng.integers(0, 4))
+        if kind == 1 and pos + L + 4 < len(g):
+            at = int(rng.integers(2, L - 8)); d = int(rng.integers(1, 4))
+            r = np.concatenate([g[pos:pos + at], g[pos + at + d:pos + L + d]])
+        elif kind == 2:
+            at = int(rng.integers(2, L - 8)); d = int(rng.integers(1, 4))
+            r = np.concatenate([g[pos:pos + at], _ACGT[rng.integers(0, 4, d)], g[pos + at:pos + L - d]])
+        sub = rng.random(L) < 0.015
+        r[sub] = _ACGT[rng.integers(0, 4, int(sub.sum()))]
+        direction = int(rng.integers(0, 2))
+        b[i] = _COMP[r[::-1]] if direction else r
+        shift = int(rng.integers(-6, 7)) if rng.random() < 0.7 else 0
+        loc = cstart[ci] + pos + shift
+        if where == 0 and rng.random() < 0.3: loc = cstart[ci] - int(rng.integers(1, 8))
+        res["status"][i] = 1 if rng.random() < 0.97 else 0
+        res["direction"][i] = direction; res["location"][i] = loc; res["score"][i] = int(rng.integers(0, 9))
+    return b, res
+
+
+def adjust_reads(seed, contigs, n, L):
+    """reads for AlignRead with -ae: a third plain (substitutions + scattered indels), a third with an indel of 1-4 bases within the first
+    or last 6 bases, a third hanging 1-25 bases over the start or the end of their contig; half of them reverse-complemented"""
+    from snap_amd import synth
+    rng = np.random.default_rng(seed)
+    base = synth.make_reads(seed, contigs, n, L, sub=0.01, ins=0.002, dele=0.002)
+    b, q = base["bases"].copy(), base["quals"].copy()
+    for i in range(n):
+        kind = i % 3
+        if kind == 0: continue
+        ci = int(rng.integers(len(contigs))); g = contigs[ci][1]
+        if len(g) < 3 * L: continue
+        if kind == 1:
+            pos = int(rng.integers(50, len(g) - 2 * L - 50)); d = int(rng.integers(1, 5)); at = int(rng.integers(1, 7))
+            if rng.random() < 0.5: at = L - at - d
+            if rng.random() < 0.5: r = np.concatenate([g[pos:pos + at], g[pos + at + d:pos + L + d]])
+            else: r = np.concatenate([g[pos:pos + at], _ACGT[rng.integers(0, 4, d)], g[pos + at:pos + L - d]])
+        else:
+            over = int(rng.integers(1, 26))
+            if rng.random() < 0.5: r = np.concatenate([_ACGT[rng.integers(0, 4, over)], g[:L - over]])
+            else: r = np.concatenate([g[len(g) - (L - over):], _ACGT[rng.integers(0, 4, over)]])
+        r = r[:L].copy()
+        sub = rng.random(L) < 0.01
+        r[sub] = _ACGT[rng.integers(0, 4, int(sub.sum()))]
+        if rng.random() < 0.5: r = _COMP[r[::-1]]
+        b[i] = r
+    return b, q
+
+
+def golden_contigs(gi):
+    """the contigs of a loaded GenomeIndex as adjust_cases wants them: [(name, bases)], [begin]"""
+    nb = gi.n_bases
+    G = gi.genome_padded[(gi.genome_padded.size - nb) // 2:]
+    begins = [int(c.begin) for c in gi.contigs] + [int(nb)]
+    pad = gi.chromosome_padding
+    return [(c.name, G[begins[k]:begins[k + 1] - pad]) for k, c in enumerate(gi.contigs)], begins[:-1]

@@ -26,6 +26,7 @@
 #define __host__
 #define __global__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __shared__ __thread      /* (GNU TLS: no dynamic-initialisation wrapper call) */
 #define __restrict__ __restrict

@@ -422,3 +422,13 @@ def test_emu_single_end_help_for_heavy_reads(emu, monkeypatch, tmp_path):
     for k in ("n_hash_table_lookups", "n_hits_consumed", "n_lv_locations", "n_ag_locations", "n_lv_ref_bytes"):
         assert ce[k] == co[k], k
     assert [ce["n_hash_table_lookups"], ce["n_lv_locations"], ce["n_ag_locations"]] == [rc["lookups"], rc["lv"], rc["ag"]]
+
+
+def test_emu_alignment_adjuster(emu, golden_index):
+    """tests/test_gpu_adjust.py on the emulated device: the `-ae` adjuster item by item and inside finalizeSecondaryResults, against the
+    golden fixture of the compiled reference."""
+    import tests.test_gpu_adjust as ga
+    z = np.load(os.path.join(util.GOLDEN, "adjust.npz"))
+    ga.test_adjust_alignments_vs_reference_fixture(golden_index, z)
+    ga.test_secondary_with_adjustment_vs_reference_fixture(golden_index, z)
+    ga.test_adjustment_is_single_end_only(golden_index)

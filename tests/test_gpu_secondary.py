@@ -80,8 +80,6 @@ def test_secondary_argument_errors(golden_index):
             a.enable_secondary(1, max_results=0)
         with pytest.raises(SnapGpuError):
             a.enable_secondary(1, max_per_contig=0)
-        with pytest.raises(SnapGpuError):
-            a.enable_secondary(1, adjust_alignments=1)        # -ae: not built
         with pytest.raises(SnapGpuError):                     # not enabled
             a.AlignReadSecondary(np.zeros(100, np.uint8) + 65, np.zeros(100, np.uint8) + 70, np.array([0, 100], np.uint64))
     finally:
