@@ -102,6 +102,8 @@ def _unstable_names(workload, extra_params):
     (["-ea", "-D", "2"], {"emit_alt_alignments": 1, "extra_search_depth": 2}),
     (["-om", "1", "-omax", "4"], {"secondary": (1, 4, -1)}),                 # secondary alignments (SingleAligner.cpp:250-318)
     (["-D", "2", "-om", "2", "-mpc", "2"], {"extra_search_depth": 2, "secondary": (2, 0x7fffffff, 2)}),
+    (["-ae"], {}),                                                            # AlignmentAdjuster on the primary (BaseAligner.cpp:2444-2452)
+    (["-ae", "-om", "1"], {"secondary": (1, 0x7fffffff, -1)}),                # ... and on every secondary result, before the -om filter
 ])
 def test_sam_identical_to_reference_cli(workload, opts, params):
     d = workload["dir"]
