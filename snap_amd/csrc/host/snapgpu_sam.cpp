@@ -152,6 +152,7 @@ struct Options {
     size_t batch_reads = 65536;
     bool clip_front = false, clip_back = true;                             // -C-+ (ClipBack) is the default
     int om = -1, mpc = -1; long long omax = 0x7fffffff;
+    bool ae = false;                                                       // -ae: AlignmentAdjuster before the -om filter (single end only)
     int n_gpus = 0, ctx_per_gpu = 2, n_format = 0;
     uint32_t ops_stride = 64;
     bool bam = false;                                                      // -o x.bam: BAM records in BGZF blocks (SNAPLib/Bam.cpp)
@@ -402,7 +403,14 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
                 uint32_t need = stride; for (uint32_t v : nsec) if (v > need) need = v;
                 stride = need;
             }
-        } else rc = snapgpu_align_single(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data());
+        } else {
+            rc = snapgpu_align_single(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data());
+            if (rc == SNAPGPU_OK && o.ae) {                 // finalizeSecondaryResults has only the primary to adjust (BaseAligner.cpp:2444-2452)
+                std::vector<int32_t> lens(to_align.size());
+                for (size_t k = 0; k < to_align.size(); k++) lens[k] = (int32_t)(ao[k + 1] - ao[k]);
+                rc = snapgpu_adjust_alignments(ctx, (uint32_t)to_align.size(), ab.data(), (uint64_t)ab.size(), ao.data(), lens.data(), aligned_res.data());
+            }
+        }
         if (rc != SNAPGPU_OK) fail_rc(ctx, "alignment", rc);
         std::vector<uint32_t> slot(n, 0xffffffffu);
         for (size_t k = 0; k < to_align.size(); k++) { results[to_align[k]] = aligned_res[k]; slot[to_align[k]] = (uint32_t)k; }
@@ -883,7 +891,7 @@ int main(int argc, char **argv)
     Options o;
     o.paired = argc >= 2 && strcmp(argv[1], "paired") == 0;
     if (argc < (o.paired ? 5 : 4) || (!o.paired && strcmp(argv[1], "single") != 0))
-        die("usage: snapgpu-sam single <index-dir> <reads.fq> -o <out.sam|out.bam> | paired <index-dir> <r1.fq> <r2.fq> -o <out.sam|out.bam>  [-d N] [-G-] [-=] [-M] [-mrl N] [-b N] [-gpus N] [-q N] [-t N]");
+        die("usage: snapgpu-sam single <index-dir> <reads.fq> -o <out.sam|out.bam> | paired <index-dir> <r1.fq> <r2.fq> -o <out.sam|out.bam>  [-d N] [-G-] [-=] [-M] [-om N] [-omax N] [-mpc N] [-ae] [-ea] [-mrl N] [-b N] [-gpus N] [-q N] [-t N]");
     const std::string index_dir = argv[2], fastq = argv[3], fastq2 = o.paired ? argv[4] : "";
     std::string out_path;
     snapgpu_default_params(&o.p);
@@ -902,6 +910,7 @@ int main(int argc, char **argv)
         else if (a == "-om" && i + 1 < argc) o.om = atoi(argv[++i]);                       // secondary alignments (AlignerOptions.cpp:70-72)
         else if (a == "-omax" && i + 1 < argc) o.omax = atoll(argv[++i]);
         else if (a == "-mpc" && i + 1 < argc) o.mpc = atoi(argv[++i]);
+        else if (a == "-ae") o.ae = true;                                                    // AlignerOptions.cpp:476
         else if (a == "-ea") o.p.emit_alt_alignments = 1;                                  // the first ALT alignment as an extra record (SingleAligner.cpp:320-322)
         else if (a == "-D" && i + 1 < argc) o.p.extra_search_depth = (uint32_t)atoi(argv[++i]);
         else if (a == "-mrl" && i + 1 < argc) o.min_read_len = (unsigned)atoi(argv[++i]);
@@ -912,6 +921,8 @@ int main(int argc, char **argv)
         else die("option not supported: ", a.c_str());
     }
     if (out_path.empty()) die("-o <out.sam | out.bam> is required");
+    if (o.ae && o.paired) die("-ae is implemented for `single` only (the paired-end aligners' use of AlignmentAdjuster is not: DESIGN.md section 16)");
+    if (o.ae && o.clip_front) die("-ae with front clipping (-C+x) is not supported: the adjuster is restated for reads the reader has not clipped at the front");
     o.bam = out_path.size() > 4 && out_path.compare(out_path.size() - 4, 4, ".bam") == 0;     // by extension, like the reference (AlignerOptions.cpp)
     if (o.batch_reads < (o.paired ? 2u : 1u)) die("-b must be at least 1 (2 for paired)");
     if (o.paired) o.batch_reads &= ~(size_t)1;
@@ -954,7 +965,7 @@ int main(int argc, char **argv)
         if (o.paired) { rc = snapgpu_enable_paired(c, &o.pp); if (rc != SNAPGPU_OK) fail_rc(c, "snapgpu_enable_paired", rc); }
         if (o.om >= 0) {
             snapgpu_secondary_params sp; memset(&sp, 0, sizeof(sp));
-            sp.max_edit_distance = o.om; sp.max_per_contig = o.mpc; sp.max_results = o.omax; sp.adjust_alignments = 0;
+            sp.max_edit_distance = o.om; sp.max_per_contig = o.mpc; sp.max_results = o.omax; sp.adjust_alignments = o.ae ? 1u : 0u;
             rc = snapgpu_enable_secondary(c, &sp);
             if (rc != SNAPGPU_OK) fail_rc(c, "snapgpu_enable_secondary", rc);
         }

@@ -277,8 +277,10 @@ struct snapgpu_ctx {
     // paired-end path with secondary results (both snapgpu_enable_paired and snapgpu_enable_secondary called): its own slabs
     // experimental: dequeue heavy pairs first (SNAPGPU_PAIRED_HEAVY_FIRST=1 at snapgpu_enable_paired; paired_dev.h)
     bool heavy_first = false;
-    // heavy-first dequeue of the single-end path (order.h): on unless SNAPGPU_SINGLE_HEAVY_FIRST=0
-    bool single_heavy_first = true;
+    // heavy-first dequeue of the single-end path (order.h).  -1: where the context has the GPU to itself (one feeder: 226 -> 210 ms per launch,
+    // profiles/r03b); with three feeders the tails of the launches overlap anyway and the ordering pass plus "every launch starts with its
+    // heaviest reads" cost 12 % (7.93 M -> 8.93 M reads/s without it, profiles/r03q).  SNAPGPU_SINGLE_HEAVY_FIRST=0 / 1 decides for all launches.
+    int single_heavy_first = -1;
     bool phase_timers = false;        // SNAPGPU_PHASE_TIMERS=1: launch the instantiation that carries the s_memtime phase timers
     uint32_t *d_order = nullptr, *d_wbucket = nullptr, *d_whist = nullptr; size_t order_cap = 0;
     // help for heavy reads (se_help.h): on unless SNAPGPU_SINGLE_HELP=0 at snapgpu_create (then the 192-position variant runs the exact
@@ -727,7 +729,7 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         CRCHK(hipMalloc((void **)&ctx->d_exact_persist, (size_t)ctx->exact_slots * ctx->exact_persist_stride), SNAPGPU_E_NOMEM);
         CRCHK(hipMemsetAsync(ctx->d_exact_persist, 0, (size_t)ctx->exact_slots * ctx->exact_persist_stride, ctx->stream), SNAPGPU_E_NODEVICE);
     }
-    if (const char *e = getenv("SNAPGPU_SINGLE_HEAVY_FIRST")) ctx->single_heavy_first = atoi(e) != 0;
+    if (const char *e = getenv("SNAPGPU_SINGLE_HEAVY_FIRST")) ctx->single_heavy_first = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("SNAPGPU_PHASE_TIMERS")) ctx->phase_timers = atoi(e) != 0;
     if (ctx->single_help) {
         ctx->se_spec_cap = c.se_items_cap;
@@ -1622,7 +1624,8 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     uint32_t blocks = ctx->n_wave_slots / 4;
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
-    if (ctx->single_heavy_first && n > ctx->n_wave_slots) {      // (inside the timed region: it is part of the pass)
+    const bool heavy_first = ctx->single_heavy_first == 1 || (ctx->single_heavy_first < 0 && ctx->feeders && ctx->feeders->load() <= 1);
+    if (heavy_first && n > ctx->n_wave_slots) {                 // (inside the timed region: it is part of the pass)
         const int orc = launch_unit_order(ctx, d_bases, d_offsets, n, 1, ctx->cfg.max_hits, s);
         if (orc) return orc;
         a.order = ctx->d_order;

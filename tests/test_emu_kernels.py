@@ -256,7 +256,7 @@ def test_emu_sam_fields(emu, golden_index, tag):
     gc.check_sam_fields_against_reference_cli(golden_index, z, tag, step=3)
 
 
-@pytest.mark.parametrize("opts", [[], ["-G-", "-=", "-C++", "-b", "97"], ["-G-", "-ea", "-om", "1", "-omax", "4"]])     # -b 97: nine batches, the last one short; -C++: '#' heads
+@pytest.mark.parametrize("opts", [[], ["-G-", "-=", "-C++", "-b", "97"], ["-G-", "-ea", "-om", "1", "-omax", "4"], ["-ae"], ["-ae", "-om", "1"]])     # -b 97: nine batches, the last one short; -C++: '#' heads
                                                                                                                   # clipped too; -om / -ea: secondary and first-ALT records
 def test_emu_native_fastq_to_sam(emu, tmp_path, opts):
     """FASTQ in, SAM out: the native host program (snap_amd/csrc/host/snapgpu_sam.cpp, linked against the emulated library) writes the

@@ -92,7 +92,7 @@ def single_workload(tmp_path_factory):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
-@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"], ["-C++"], ["-om", "1", "-omax", "4"], ["-D", "2", "-om", "2", "-mpc", "2"], ["-ea", "-om", "1"]])
+@pytest.mark.parametrize("opts", [[], ["-G-"], ["-="], ["-d", "8"], ["-G-", "-=", "-d", "20"], ["-C++"], ["-om", "1", "-omax", "4"], ["-D", "2", "-om", "2", "-mpc", "2"], ["-ea", "-om", "1"], ["-ae"], ["-ae", "-om", "1"]])
 def test_native_fastq_to_sam_identical_to_reference_cli(single_workload, opts):
     assert os.path.exists(TOOL), "snap_amd/snapgpu-sam not built: run __graft_entry__.build()"
     d, index_dir, fastq = single_workload
