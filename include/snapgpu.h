@@ -85,7 +85,9 @@ typedef struct snapgpu_index_view {
     uint32_t key_bytes;            /* hashTableKeySize                                   */
     uint32_t n_hash_tables;
     uint32_t large_hash_table;     /* 1 = one entry holds fwd+rc values (valueCount 2)   */
-    uint32_t location_size;        /* must be 4 in this build                            */
+    uint32_t location_size;        /* 4: the blobs of a view hold 32-bit values.  (snapgpu_create_from_directory also takes index
+                                      directories written with 5 .. 8-byte locations -- what the indexer picks for seeds shorter than
+                                      20, GenomeIndex.cpp:446-453 -- and narrows their tables on load where every value fits 32 bits.) */
     uint32_t chromosome_padding;
     uint64_t overflow_table_size;  /* in 32-bit words                                    */
 

@@ -121,7 +121,7 @@ int snapref_lookup_seeds(void *vindex, uint32_t n, const char *seeds,
                          int64_t *n_hits, uint32_t *hits, uint32_t max_hits_out)
 {
     GenomeIndex *index = (GenomeIndex *)vindex;
-    if (index->doesGenomeIndexHave64BitLocations()) return SNAPGPU_E_UNSUPPORTED;
+    const bool wide = index->doesGenomeIndexHave64BitLocations();         // lookupSeed / overflowTable64 (GenomeIndex.cpp:2205-2328)
     unsigned seedLen = index->getSeedLength();
     for (uint32_t i = 0; i < n; i++) {
         const char *text = seeds + (size_t)i * seedLen;
@@ -130,6 +130,18 @@ int snapref_lookup_seeds(void *vindex, uint32_t n, const char *seeds,
             continue;
         }
         Seed seed(text, seedLen);
+        if (wide) {
+            _int64 nh64[2] = {0, 0};
+            const GenomeLocation *h64[2] = {NULL, NULL};
+            GenomeLocation single64[2];
+            index->lookupSeed(seed, &nh64[0], &h64[0], &nh64[1], &h64[1], &single64[0], &single64[1]);
+            for (int d = 0; d < 2; d++) {
+                n_hits[2 * i + d] = nh64[d];
+                _int64 lim = nh64[d] < (_int64)max_hits_out ? nh64[d] : (_int64)max_hits_out;
+                for (_int64 j = 0; j < lim; j++) hits[(size_t)(2 * i + d) * max_hits_out + j] = (uint32_t)GenomeLocationAsInt64(h64[d][j]);
+            }
+            continue;
+        }
         _int64 nh[2] = {0, 0};
         const unsigned *h[2] = {NULL, NULL};
         index->lookupSeed32(seed, &nh[0], &h[0], &nh[1], &h[1]);
@@ -239,12 +251,19 @@ int snapref_affine_gap(int dir, uint32_t n, const int32_t *agparams /* match,sub
     return 0;
 }
 
+/* InvalidGenomeLocation is all ones in as many bytes as the loaded index's locations have (GenomeIndex.cpp: it is set when an index
+ * loads); the C ABI has one sentinel, SNAPGPU_InvalidGenomeLocation32, whatever the files' location size. */
+static inline int64_t abi_location(GenomeLocation l)
+{
+    return l == InvalidGenomeLocation ? (int64_t)SNAPGPU_InvalidGenomeLocation32 : (int64_t)GenomeLocationAsInt64(l);
+}
+
 static void fill_result(snapgpu_single_result *o, const SingleAlignmentResult *r)
 {
     memset(o, 0, sizeof(*o));
     o->status = (int32_t)r->status;
     o->direction = (int32_t)r->direction;
-    o->location = (int64_t)GenomeLocationAsInt64(r->location);
+    o->location = abi_location(r->location);
     o->orig_location = (int64_t)GenomeLocationAsInt64(r->origLocation);
     o->score = r->score;
     o->score_prior_to_clipping = r->scorePriorToClipping;
@@ -386,7 +405,7 @@ int snapref_align_single(void *vindex, const snapgpu_params *p, uint32_t n, cons
 {
     snapref_init();
     GenomeIndex *index = (GenomeIndex *)vindex;
-    if (index->doesGenomeIndexHave64BitLocations()) return SNAPGPU_E_UNSUPPORTED;
+    /* (an index with 5 .. 8-byte locations: the reference aligners take their 64-bit branches; results are locations either way) */
     AlignJob job;
     job.index = index; job.p = p; job.n = n; job.bases = bases; job.quals = quals; job.offsets = offsets;
     job.primary = primary; job.first_alt = first_alt; job.next = 0; job.chunk = 256;
@@ -497,7 +516,7 @@ int snapref_adjust_alignments(void *vindex, uint32_t n, const char *data, const 
         r.clippingForReadAdjustment = 0;
         adjuster.AdjustAlignment(&read, &r);
         results[i].status = (int32_t)r.status;
-        results[i].location = (int64_t)GenomeLocationAsInt64(r.location);
+        results[i].location = abi_location(r.location);
         results[i].score = r.score;
         results[i].clipping_for_read_adjustment = r.clippingForReadAdjustment;
     }
@@ -599,7 +618,7 @@ int snapref_align_single_secondary(void *vindex, const snapgpu_params *p, int om
 {
     snapref_init();
     GenomeIndex *index = (GenomeIndex *)vindex;
-    if (index->doesGenomeIndexHave64BitLocations()) return SNAPGPU_E_UNSUPPORTED;
+    /* (an index with 5 .. 8-byte locations: the reference aligners take their 64-bit branches; results are locations either way) */
     g_index = index;                                            // SingleAlignmentResult::compareByContigAndScore reads it (AlignmentResult.cpp:31)
     SecJob job;
     job.index = index; job.p = p; job.om = om; job.omax = omax; job.mpc = mpc; job.n = n; job.bases = bases; job.quals = quals;
@@ -620,7 +639,7 @@ static void fill_paired(snapgpu_paired_result *o, const PairedAlignmentResult *r
     for (int i = 0; i < 2; i++) {
         o->status[i] = (int32_t)r->status[i];
         o->direction[i] = (int32_t)r->direction[i];
-        o->location[i] = (int64_t)GenomeLocationAsInt64(r->location[i]);
+        o->location[i] = abi_location(r->location[i]);
         o->orig_location[i] = (int64_t)GenomeLocationAsInt64(r->origLocation[i]);
         o->score[i] = r->score[i];
         o->score_prior_to_clipping[i] = r->scorePriorToClipping[i];
@@ -810,7 +829,7 @@ static int run_paired(void *vindex, const snapgpu_params *p, const snapgpu_paire
 {
     snapref_init();
     GenomeIndex *index = (GenomeIndex *)vindex;
-    if (index->doesGenomeIndexHave64BitLocations()) return SNAPGPU_E_UNSUPPORTED;
+    /* (an index with 5 .. 8-byte locations: the reference aligners take their 64-bit branches; results are locations either way) */
     g_index = index;                                   // AlignerContext.cpp:253 (used by compareByContigAndScore only)
     PairedJob job;
     job.index = index; job.p = p; job.pp = pp; job.stage = stage; job.n = n; job.bases = bases; job.quals = quals; job.offsets = offsets;

@@ -54,13 +54,16 @@ static volatile int g_nextWorker = 0;
 static bool g_pairedEnabled = false;
 static bool g_secondaryEnabled = false;
 
+// the C ABI has one "no location" value; the reference's InvalidGenomeLocation is all ones in as many bytes as the loaded index's locations have
+static inline GenomeLocation toSnapLocation(int64_t l) { return l == (int64_t)SNAPGPU_InvalidGenomeLocation32 ? InvalidGenomeLocation : GenomeLocation(l); }
+
 static void toSnapPaired(const snapgpu_paired_result &g, PairedAlignmentResult *r)
 {
     memset(r, 0, sizeof(*r));
     for (int i = 0; i < NUM_READS_PER_PAIR; i++) {
         r->status[i] = (AlignmentResult)g.status[i];
         r->direction[i] = g.direction[i];
-        r->location[i] = GenomeLocation(g.location[i]);
+        r->location[i] = toSnapLocation(g.location[i]);
         r->origLocation[i] = GenomeLocation(g.orig_location[i]);
         r->score[i] = g.score[i];
         r->scorePriorToClipping[i] = g.score_prior_to_clipping[i];
@@ -88,7 +91,7 @@ static void toSnap(const snapgpu_single_result &g, SingleAlignmentResult *r)
 {
     r->status = (AlignmentResult)g.status;
     r->direction = g.direction;
-    r->location = GenomeLocation(g.location);
+    r->location = toSnapLocation(g.location);
     r->origLocation = GenomeLocation(g.orig_location);
     r->score = g.score;
     r->scorePriorToClipping = g.score_prior_to_clipping;
@@ -120,9 +123,8 @@ public:
             return false;                                   // I/O-only mode: leave it to SNAP
         }
         PairedAlignerOptions *po = (PairedAlignerOptions *)c->options;
-        if (c->options->stopOnFirstHit || !c->ignoreAlignmentAdjustmentForOm ||
-            c->index->doesGenomeIndexHave64BitLocations() || po->inferSpacing) {
-            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-f, -ae, -ins or a 64-bit index)\n");
+        if (c->options->stopOnFirstHit || !c->ignoreAlignmentAdjustmentForOm || po->inferSpacing) {
+            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements for `paired` (-f, -ae, -ins)\n");
             soft_exit(1);
         }
         ensureContext(c, 25);
@@ -301,8 +303,8 @@ public:
         if (c->index == NULL) {
             return false;                                   // I/O-only mode (SingleAligner.cpp:106-131): leave it to SNAP
         }
-        if (c->options->stopOnFirstHit || c->options->explorePopularSeeds || c->index->doesGenomeIndexHave64BitLocations()) {
-            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-f, -x or a 64-bit index)\n");
+        if (c->options->stopOnFirstHit || c->options->explorePopularSeeds) {     // (an index with 5 .. 8-byte locations: snapgpu_create_from_directory narrows what fits 32 bits and refuses the rest)
+            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-f, -x)\n");
             soft_exit(1);
         }
         // -ae (!ignoreAlignmentAdjustmentForOm): with -om the library adjusts primary and secondary results before its filter

@@ -145,6 +145,23 @@ class BaseAligner:
         self._after_built(paired_params)
         return self
 
+    @classmethod
+    def from_directory(cls, directory: str, params: Params | None = None, device: int = 0):
+        """snapgpu_create_from_directory: the library's own loader of the reference's four index files (what the shim and snapgpu-sam use)."""
+        self = cls.__new__(cls)
+        self.lib = load_library()
+        self.index = None
+        self.params = params if params is not None else default_params()
+        self._keep = []
+        self.lib.snapgpu_create_from_directory.argtypes = [C.c_char_p, C.POINTER(Params), C.c_int, C.POINTER(C.c_void_p)]
+        handle = C.c_void_p()
+        rc = self.lib.snapgpu_create_from_directory(directory.encode(), C.byref(self.params), device, C.byref(handle))
+        if rc != 0:
+            raise SnapGpuError("snapgpu_create_from_directory failed (%d): %s" % (rc, self.lib.snapgpu_last_error(None).decode()))
+        self.handle = handle
+        self.device = device
+        return self
+
     def _after_built(self, paired_params):
         pass
 

@@ -895,8 +895,14 @@ extern "C" int snapgpu_create_from_directory(const char *index_dir, const snapgp
                &padding, &key_bytes, &hash_file_size, &small, &loc_size) != 10)               // GenomeIndex.cpp:1879
         return fail(nullptr, SNAPGPU_E_INVALID, "malformed GenomeIndex header");
     if (major != 7) return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "index major version is not 7 (GenomeIndex.h:170)");
-    if (loc_size != 4) return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "index uses 64-bit genome locations; only the 32-bit lookup path (seed >= 20) is implemented");
-    if ((long long)ovf.size() != overflow_size * 4) return fail(nullptr, SNAPGPU_E_INVALID, "OverflowTable size does not match the header");
+    // locationSize 5 .. 8 (GenomeIndex.cpp:446-453: what the indexer picks for seeds shorter than 20, or -locationSize): the reference then
+    // goes through lookupSeed / overflowTable64 (GenomeIndex.cpp:2205-2328), whose answers are those of lookupSeed32 over the same tables
+    // with wider values.  Where every value fits 32 bits -- genome + overflow table below 2^32 - 2 entries -- the tables are NARROWED here,
+    // slot for slot (same table sizes, same keys, so the same probe sequences), and the device keeps its one 32-bit layout; a genome that
+    // needs the wider values is refused.
+    if (loc_size < 4 || loc_size > 8) return fail(nullptr, SNAPGPU_E_INVALID, "GenomeIndex header: location size out of range");
+    const bool wide = loc_size > 4;
+    if ((long long)ovf.size() != overflow_size * (wide ? 8 : 4)) return fail(nullptr, SNAPGPU_E_INVALID, "OverflowTable size does not match the header");
 
     // Genome: "nBases nContigs flags\n", one line per contig, then nBases raw bytes (Genome.cpp:203-229)
     size_t pos = 0;
@@ -941,8 +947,22 @@ extern "C" int snapgpu_create_from_directory(const char *index_dir, const snapgp
     memcpy(genome_padded.data() + pad, gen.data() + pos, (size_t)n_bases);
     std::vector<uint8_t>().swap(gen);
 
+    if (wide) {
+        if ((unsigned long long)n_bases + (unsigned long long)overflow_size >= 0xfffffffeull)
+            return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "index uses 64-bit genome locations and its genome + overflow table do not fit 32-bit values: only indexes whose values fit are supported (they are narrowed on load)");
+        std::vector<uint8_t> narrow((size_t)overflow_size * 4);
+        for (long long i = 0; i < overflow_size; i++) {
+            uint64_t v; memcpy(&v, &ovf[(size_t)i * 8], 8);
+            if (v > 0xffffffffull) return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "OverflowTable entry does not fit 32 bits");
+            const uint32_t w = (uint32_t)v; memcpy(&narrow[(size_t)i * 4], &w, 4);
+        }
+        ovf.swap(narrow);
+    }
+
     // GenomeIndexHash: per table a 36-byte header then tableSize slots (HashTable.cpp:98-175)
     const uint32_t value_count = small ? 1 : 2, entry = 4 * value_count + (uint32_t)key_bytes;
+    const uint32_t src_entry = (uint32_t)loc_size * value_count + (uint32_t)key_bytes;
+    const uint64_t all_ones = loc_size == 8 ? ~0ull : ((1ull << (8 * loc_size)) - 1ull);
     std::vector<uint64_t> toff((size_t)n_tables), tsz((size_t)n_tables);
     std::vector<uint8_t> blob; blob.reserve(hash.size());
     size_t hp = 0;
@@ -951,13 +971,31 @@ extern "C" int snapgpu_create_from_directory(const char *index_dir, const snapgp
         uint32_t magic, ks, vs, vc; uint64_t table_size;
         memcpy(&magic, &hash[hp], 4); memcpy(&table_size, &hash[hp + 4], 8);
         memcpy(&ks, &hash[hp + 20], 4); memcpy(&vs, &hash[hp + 24], 4); memcpy(&vc, &hash[hp + 28], 4);
-        if (magic != 0xb111b010u || ks != (uint32_t)key_bytes || vs != 4 || vc != value_count)
+        if (magic != 0xb111b010u || ks != (uint32_t)key_bytes || vs != (uint32_t)loc_size || vc != value_count)
             return fail(nullptr, SNAPGPU_E_INVALID, "hash table header does not match the index header");
         hp += 32 + vs;
-        size_t nbytes = (size_t)table_size * entry;
+        size_t nbytes = (size_t)table_size * src_entry;
         if (hp + nbytes > hash.size()) return fail(nullptr, SNAPGPU_E_INVALID, "GenomeIndexHash truncated");
         toff[(size_t)t] = blob.size(); tsz[(size_t)t] = table_size;
-        blob.insert(blob.end(), hash.begin() + (long)hp, hash.begin() + (long)(hp + nbytes));
+        if (!wide) blob.insert(blob.end(), hash.begin() + (long)hp, hash.begin() + (long)(hp + nbytes));
+        else {              // slot for slot: [value x value_count][key] with values of loc_size bytes -> 4 bytes (all ones = unused, all ones - 1 = "the other strand only")
+            const size_t at = blob.size();
+            blob.resize(at + (size_t)table_size * entry);
+            for (uint64_t sl = 0; sl < table_size; sl++) {
+                const uint8_t *src = &hash[hp + (size_t)sl * src_entry];
+                uint8_t *dst = &blob[at + (size_t)sl * entry];
+                for (uint32_t k = 0; k < value_count; k++) {
+                    uint64_t v = 0; memcpy(&v, src + (size_t)k * (size_t)loc_size, (size_t)loc_size);
+                    uint32_t w;
+                    if (v == all_ones) w = 0xffffffffu;
+                    else if (v == all_ones - 1) w = 0xfffffffeu;
+                    else if (v < 0xfffffffeull) w = (uint32_t)v;
+                    else return fail(nullptr, SNAPGPU_E_UNSUPPORTED, "hash table value does not fit 32 bits");
+                    memcpy(dst + 4 * (size_t)k, &w, 4);
+                }
+                memcpy(dst + 4 * (size_t)value_count, src + (size_t)loc_size * value_count, (size_t)key_bytes);
+            }
+        }
         hp += nbytes;
     }
     std::vector<uint8_t>().swap(hash);
@@ -966,7 +1004,7 @@ extern "C" int snapgpu_create_from_directory(const char *index_dir, const snapgp
 
     snapgpu_index_view v; memset(&v, 0, sizeof(v));
     v.seed_len = (uint32_t)seed_len; v.key_bytes = (uint32_t)key_bytes; v.n_hash_tables = (uint32_t)n_tables;
-    v.large_hash_table = small ? 0 : 1; v.location_size = (uint32_t)loc_size; v.chromosome_padding = (uint32_t)padding;
+    v.large_hash_table = small ? 0 : 1; v.location_size = 4 /* (narrowed above where the files have wider values) */; v.chromosome_padding = (uint32_t)padding;
     v.overflow_table_size = (uint64_t)overflow_size;
     v.hash_blob = blob.data(); v.hash_blob_bytes = blob.size(); v.table_offset = toff.data(); v.table_size = tsz.data();
     v.overflow = (const uint32_t *)ovf.data(); v.genome = genome_padded.data() + pad; v.n_bases = (uint64_t)n_bases;

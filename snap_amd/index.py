@@ -97,10 +97,12 @@ class GenomeIndex:
          hash_file_size, small, location_size) = [int(x) for x in fields[:10]]
         if major != 7:
             raise ValueError("index major version %d != 7 (GenomeIndex.h:170)" % major)
-        if location_size != 4:
-            raise NotImplementedError(
-                "index has %d-byte genome locations; this build implements the 32-bit lookup "
-                "path (seed >= 20, GenomeIndex.cpp:446-453) only" % location_size)
+        if not 4 <= location_size <= 8:
+            raise ValueError("GenomeIndex header: location size %d" % location_size)
+        # 5 .. 8 bytes per location (what the indexer picks for seeds shorter than 20, GenomeIndex.cpp:446-453, or -locationSize): the
+        # reference then goes through lookupSeed / overflowTable64 (GenomeIndex.cpp:2205-2328).  Where every value fits 32 bits the
+        # tables are narrowed below, slot for slot, as snapgpu_create_from_directory does; a genome that needs wider values is refused.
+        wide = location_size > 4
 
         # --- Genome ---------------------------------------------------------------
         with open(os.path.join(directory, "Genome"), "rb") as f:
@@ -122,9 +124,14 @@ class GenomeIndex:
                 raise ValueError("Genome file truncated: %d of %d bases" % (got, n_bases))
 
         # --- OverflowTable --------------------------------------------------------
-        overflow = np.fromfile(os.path.join(directory, "OverflowTable"), dtype=np.uint32)
+        overflow = np.fromfile(os.path.join(directory, "OverflowTable"), dtype=np.uint64 if wide else np.uint32)
         if overflow.size != overflow_size:
             raise ValueError("OverflowTable has %d words, header says %d" % (overflow.size, overflow_size))
+        if wide:
+            if n_bases + overflow_size >= 0xfffffffe or (overflow.size and int(overflow.max()) > 0xffffffff):
+                raise NotImplementedError("index has %d-byte genome locations and its values do not fit 32 bits: only indexes whose "
+                                          "genome + overflow table stay below 2^32 - 2 are supported (narrowed on load)" % location_size)
+            overflow = overflow.astype(np.uint32)
         if overflow.size == 0:
             overflow = np.zeros(1, dtype=np.uint32)   # keep a valid pointer
 
@@ -132,6 +139,8 @@ class GenomeIndex:
         raw = np.fromfile(os.path.join(directory, "GenomeIndexHash"), dtype=np.uint8)
         value_count = 1 if small else 2
         entry = 4 * value_count + key_bytes
+        src_entry = location_size * value_count + key_bytes
+        all_ones = (1 << (8 * location_size)) - 1
         offs = np.zeros(n_tables, dtype=np.uint64)
         sizes = np.zeros(n_tables, dtype=np.uint64)
         pieces = []
@@ -143,14 +152,31 @@ class GenomeIndex:
                 raise ValueError("hash table %d: bad magic %#x" % (t, magic))
             table_size = int(raw[pos + 4:pos + 12].view(np.uint64)[0])
             ks, vs, vc = [int(x) for x in raw[pos + 20:pos + 32].view(np.uint32)]
-            if ks != key_bytes or vs != 4 or vc != value_count:
+            if ks != key_bytes or vs != location_size or vc != value_count:
                 raise ValueError("hash table %d: key/value sizes %d/%d/%d do not match header" % (t, ks, vs, vc))
             pos += 32 + vs                          # header + invalidValue
+            src_bytes = table_size * src_entry
             nbytes = table_size * entry
-            pieces.append(raw[pos:pos + nbytes])
+            if not wide:
+                pieces.append(raw[pos:pos + nbytes])
+            else:                                   # [value x value_count][key]: values of location_size bytes -> 4 (all ones = unused, all ones - 1 = other strand only)
+                src = raw[pos:pos + src_bytes].reshape(table_size, src_entry)
+                dst = np.zeros((table_size, entry), dtype=np.uint8)
+                for k in range(value_count):
+                    v = np.zeros(table_size, dtype=np.uint64)
+                    for b in range(location_size):
+                        v |= src[:, k * location_size + b].astype(np.uint64) << np.uint64(8 * b)
+                    w = v.copy()
+                    w[v == all_ones] = 0xffffffff
+                    w[v == all_ones - 1] = 0xfffffffe
+                    if ((v < all_ones - 1) & (v >= 0xfffffffe)).any():
+                        raise NotImplementedError("hash table value does not fit 32 bits")
+                    dst[:, 4 * k:4 * k + 4] = w.astype(np.uint32).view(np.uint8).reshape(table_size, 4)
+                dst[:, 4 * value_count:] = src[:, location_size * value_count:]
+                pieces.append(dst.reshape(-1))
             offs[t] = out_pos
             sizes[t] = table_size
-            pos += nbytes
+            pos += src_bytes
             out_pos += nbytes
         if pos != raw.size:
             raise ValueError("GenomeIndexHash: %d trailing bytes" % (raw.size - pos))
@@ -158,7 +184,7 @@ class GenomeIndex:
         hash_blob = np.concatenate(pieces + [np.zeros(16, dtype=np.uint8)])
 
         return GenomeIndex(seed_len=seed_len, key_bytes=key_bytes, n_hash_tables=n_tables,
-                           large=not small, location_size=location_size,
+                           large=not small, location_size=4,             # (narrowed above where the files have wider values)
                            chromosome_padding=padding, overflow=overflow, hash_blob=hash_blob,
                            table_offset=offs, table_size=sizes, genome_padded=genome_padded,
                            n_bases=n_bases, contigs=contigs, directory=directory)

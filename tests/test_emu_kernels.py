@@ -237,6 +237,26 @@ def test_emu_other_index_shapes(emu, tmp_path, seed_len, large):
     align_and_compare(str(tmp_path), seed_len, large, 600)
 
 
+@pytest.mark.parametrize("seed_len,large,extra,from_directory", [(16, False, [], False), (18, True, [], True), (20, False, ["-locationSize", "6"], True)])
+def test_emu_wide_location_indexes(emu, tmp_path, seed_len, large, extra, from_directory):
+    """Indexes whose files carry 5 .. 8-byte locations (seeds shorter than 20 get them by default): narrowed on load by the Python loader /
+    by snapgpu_create_from_directory; the probe and 500 reads against the reference, which goes through lookupSeed / overflowTable64."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.test_zy_gpu_index_shapes import align_and_compare
+    align_and_compare(str(tmp_path), seed_len, large, 500, extra=extra, from_directory=from_directory)
+
+
+def test_emu_paired_over_wide_location_index(emu, tmp_path):
+    """The paired-end path over an index with 5-byte locations (seed 16), 250 hard pairs against the reference."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.test_zy_gpu_index_shapes import paired_over_wide_index
+    paired_over_wide_index(str(tmp_path), 16, False, [], 250)
+
+
 def test_emu_compute_cigar_affine_gap(emu, emu_aligner):
     """SAMFormat::computeCigar, affine-gap variant (banded and full global alignment with traceback), on the emulated device: every
     third item of the reference fixture (tests/golden/cigar_ag.npz), both op alphabets."""

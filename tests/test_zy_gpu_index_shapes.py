@@ -14,23 +14,44 @@ from tests import util
 from oracle import ref
 
 SHAPES = [(24, False), (20, True), (22, True), (32, False)]
+# indexes whose files carry 5 .. 8-byte locations -- what the indexer picks by itself for seeds shorter than 20 (GenomeIndex.cpp:446-453), or
+# -locationSize: the reference then aligns through lookupSeed / overflowTable64 (GenomeIndex.cpp:2205-2328); here the tables are narrowed on load
+WIDE_SHAPES = [(16, False, []), (18, True, []), (19, False, []), (20, False, ["-locationSize", "6"]), (20, True, ["-locationSize", "7"])]      # (-locationSize 8: the reference's own indexer fails with bad_alloc)
 
 
-def align_and_compare(tmp, seed_len, large, n_reads, genome_bases=400_000):
+def align_and_compare(tmp, seed_len, large, n_reads, genome_bases=400_000, extra=(), from_directory=False):
     from snap_amd.aligner import BaseAligner
     from snap_amd.index import GenomeIndex
     g = synth.make_genome(91, genome_bases, n_contigs=2, repeat_frac=0.4, max_copies=100, n_run_frac=0.002)
     fa = os.path.join(tmp, "ref.fa"); synth.write_fasta(fa, g)
     d = os.path.join(tmp, "idx")
-    ref.build_index(fa, d, seed_len, threads=max(1, min(8, os.cpu_count() or 1)), large=large)
+    ref.build_index(fa, d, seed_len, threads=max(1, min(8, os.cpu_count() or 1)), large=large, extra=list(extra))
     ix = GenomeIndex.load_from_directory(d)
     assert ix.seed_len == seed_len and ix.large == large
     ri = ref.RefIndex(d)
+    if extra or seed_len < 20:
+        assert int(open(os.path.join(d, "GenomeIndex")).read().split()[9]) > 4          # the files do carry wide locations
+        # the index probe on its own: genome seeds and absent ones, counts and lists, both strands
+        rng = np.random.default_rng(seed_len)
+        cat = np.concatenate([c[1] for c in g])
+        starts = rng.integers(0, cat.size - seed_len, size=3000)
+        seeds = np.stack([cat[s:s + seed_len] for s in starts] + [synth._ACGT[rng.integers(0, 4, size=seed_len)] for _ in range(300)])
+        e_n, e_h = ri.lookup_seeds(seeds, max_hits_out=64)
+        a = BaseAligner.from_directory(d, abi.default_params(max_read_len=160, max_k=8)) if from_directory else BaseAligner(ix, abi.default_params(max_read_len=160, max_k=8))
+        try:
+            g_n, g_h = a.lookupSeed32(seeds, max_hits_out=64)
+        finally:
+            a.close()
+        assert (e_n == g_n).all()
+        lim = np.minimum(np.maximum(e_n, 0), 64)
+        for i in np.nonzero(lim.max(axis=1) > 0)[0]:
+            for dd in range(2):
+                assert (e_h[i, dd, :lim[i, dd]] == g_h[i, dd, :lim[i, dd]]).all(), (i, dd)
     p = abi.default_params(max_read_len=160, max_k=8)
     rd = synth.make_reads(5, g, n_reads, 150, sub=0.015, ins=0.002, dele=0.002, n_frac=0.0005)
     with ref.fresh_objects():           # the reference's answer as a function of the read alone: every read is compared
         pr, ar, cr, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=max(1, os.cpu_count() or 1))
-    a = BaseAligner(ix, p)
+    a = BaseAligner.from_directory(d, p) if from_directory else BaseAligner(ix, p)
     try:
         pg, ag = a.AlignRead(rd["bases"], rd["quals"], rd["offsets"])
         c = a.counters()
@@ -47,6 +68,42 @@ def align_and_compare(tmp, seed_len, large, n_reads, genome_bases=400_000):
 @pytest.mark.parametrize("seed_len,large", SHAPES)
 def test_index_shapes_vs_live_reference(tmp_path, seed_len, large):
     align_and_compare(str(tmp_path), seed_len, large, 8000, genome_bases=1_000_000)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+@pytest.mark.parametrize("seed_len,large,extra", WIDE_SHAPES)
+def test_wide_location_indexes_vs_live_reference(tmp_path, seed_len, large, extra):
+    align_and_compare(str(tmp_path), seed_len, large, 6000, genome_bases=1_000_000, extra=extra, from_directory=seed_len == 18)   # (18: through snapgpu_create_from_directory's narrowing)
+
+
+def paired_over_wide_index(tmp, seed_len, large, extra, n_pairs):
+    from snap_amd.aligner import ChimericPairedEndAligner
+    from snap_amd.index import GenomeIndex
+    from tests.pairs_util import hard_pairs, compare_paired
+    contigs = synth.make_genome(171, 1_000_000, n_contigs=3, repeat_frac=0.35, max_copies=200, n_run_frac=0.002)
+    fa = os.path.join(tmp, "g.fa"); synth.write_fasta(fa, contigs)
+    d = os.path.join(tmp, "idx")
+    ref.build_index(fa, d, seed_len=seed_len, threads=max(1, min(16, os.cpu_count() or 1)), large=large, extra=list(extra))
+    assert int(open(os.path.join(d, "GenomeIndex")).read().split()[9]) > 4
+    pr = hard_pairs(13, contigs, n_pairs, 150, insert_mean=400, insert_max=1000)
+    p = abi.default_params(max_k=8, max_read_len=160); pp = abi.default_paired_params(max_spacing=1000)
+    with ref.fresh_objects():
+        rp, ra, rcnt, _ = ref.RefIndex(d).align_paired(p, pp, pr["bases"], pr["quals"], pr["offsets"], threads=max(1, os.cpu_count() or 1), stage=0)
+    a = ChimericPairedEndAligner(GenomeIndex.load_from_directory(d), p, pp)
+    try:
+        gp, ga = a.align(pr["bases"], pr["quals"], pr["offsets"]); c = a.counters()
+    finally:
+        a.close()
+    assert not compare_paired(rp, gp, verbose=3).any()
+    assert (c["n_lv_locations"], c["n_ag_locations"]) == (rcnt["lv"], rcnt["ag"])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+@pytest.mark.parametrize("seed_len,large,extra", [(16, False, []), (18, True, [])])
+def test_paired_over_wide_location_index_vs_live_reference(tmp_path, seed_len, large, extra):
+    paired_over_wide_index(str(tmp_path), seed_len, large, extra, 2000)
 
 
 # ---- option sets beyond the ones the fixtures pin (-h, -n, -sc, -D, -d, scoring parameters, end bonuses, ALT gap), against the live reference
