@@ -286,9 +286,10 @@ def test_emu_native_fastq_to_sam(emu, tmp_path, opts):
         pytest.skip("oracle/_ref not built here")
     from tests.emu.build import TOOL
     from tests.test_zz_gpu_native_sam import make_workload, run_and_compare
-    index_dir, fastq = make_workload(str(tmp_path), 800, genome_bases=300_000)
+    n = 350 if "-ae" in opts else 800
+    index_dir, fastq = make_workload(str(tmp_path), n, genome_bases=300_000)
     env = dict(os.environ, SNAPGPU_EMU_CUS="4")
-    assert run_and_compare(TOOL, str(tmp_path), index_dir, fastq, opts, env=env, ref_opts=[o for o in opts if o not in ("-b", "97")]) > 800
+    assert run_and_compare(TOOL, str(tmp_path), index_dir, fastq, opts, env=env, ref_opts=[o for o in opts if o not in ("-b", "97")]) > n
 
 
 def test_emu_sam_fields_paired(emu):
@@ -448,7 +449,9 @@ def test_emu_alignment_adjuster(emu, golden_index):
     """tests/test_gpu_adjust.py on the emulated device: the `-ae` adjuster item by item and inside finalizeSecondaryResults, against the
     golden fixture of the compiled reference."""
     import tests.test_gpu_adjust as ga
-    z = np.load(os.path.join(util.GOLDEN, "adjust.npz"))
+    z = dict(np.load(os.path.join(util.GOLDEN, "adjust.npz")))
+    for k in ("read_bases", "read_quals", "primary", "secondary", "nsec"):
+        z[k] = z[k][:500]                                                     # (the first 500 of the 1 200 reads; all 3 000 adjuster items)
     ga.test_adjust_alignments_vs_reference_fixture(golden_index, z)
-    ga.test_secondary_with_adjustment_vs_reference_fixture(golden_index, z)
+    ga.test_secondary_with_adjustment_vs_reference_fixture(golden_index, z, min_changed=20)
     ga.test_adjustment_is_single_end_only(golden_index)

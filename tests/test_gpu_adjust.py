@@ -40,7 +40,7 @@ def test_adjust_alignments_vs_reference_fixture(golden_index, golden_adjust):
     assert (again["location"][keep] == got["location"][keep]).all() and (again["score"][keep] == got["score"][keep]).all()
 
 
-def test_secondary_with_adjustment_vs_reference_fixture(golden_index, golden_adjust):
+def test_secondary_with_adjustment_vs_reference_fixture(golden_index, golden_adjust, min_changed=50):
     from snap_amd.aligner import BaseAligner
     z = golden_adjust
     b, q = z["read_bases"], z["read_quals"]; n, L = b.shape
@@ -56,7 +56,7 @@ def test_secondary_with_adjustment_vs_reference_fixture(golden_index, golden_adj
     problems = util.compare_results(z["primary"], prim, "primary")
     problems += util.compare_secondary(z["secondary"], z["nsec"], sec, nsec, np.zeros(n, bool))
     assert not problems, problems[:10]
-    assert (prim["score"] != plain["score"]).sum() > 50                        # the adjuster did something on this input
+    assert (prim["score"] != plain["score"]).sum() > min_changed               # the adjuster did something on this input
     assert (plain["clipping_for_read_adjustment"] == 0).all()
 
 

@@ -389,11 +389,12 @@ def test_compute_cigar_restatement_vs_reference_fixture(golden_index):
     tests/golden/cigar_lv.npz (aligned reads, shifted reads with leading D / I, reads hanging off a contig, "*" cases)."""
     z = np.load(os.path.join(util.GOLDEN, "cigar_lv.npz"))
     for use_m in (0, 1):
-        o = util.oracle_compute_cigar_lv(golden_index, z["data"], z["off"], z["length"], z["loc"], z["extra_before"], bool(use_m), ops_stride=256)
+        sel = np.arange(len(z["off"]))[::1 if use_m == 0 else 3]            # (M instead of = / X changes the op alphabet only: every third item)
+        o = util.oracle_compute_cigar_lv(golden_index, z["data"], z["off"][sel], z["length"][sel], z["loc"][sel], z["extra_before"][sel], bool(use_m), ops_stride=256)
         pre = "m%d_" % use_m
         for k in ("n_ops", "edit_distance", "add_front_clipping", "extra_clipped_after"):
-            assert (o[k] == z[pre + k]).all(), k
-        for i in range(len(z["off"])):
-            assert util.cigar_text(o["ops"][i], o["n_ops"][i]) == util.cigar_text(z[pre + "ops"][i], z[pre + "n_ops"][i]), i
+            assert (o[k] == z[pre + k][sel]).all(), k
+        for j, i in enumerate(sel):
+            assert util.cigar_text(o["ops"][j], o["n_ops"][j]) == util.cigar_text(z[pre + "ops"][i], z[pre + "n_ops"][i]), i
     assert int((z["m0_add_front_clipping"] > 0).sum()) > 50 and int((z["m0_add_front_clipping"] < 0).sum()) > 50
     assert int((z["m0_extra_clipped_after"] > 0).sum()) > 30 and int((z["m0_n_ops"] < 0).sum()) >= 1
