@@ -452,6 +452,8 @@ def test_emu_alignment_adjuster(emu, golden_index):
     z = dict(np.load(os.path.join(util.GOLDEN, "adjust.npz")))
     for k in ("read_bases", "read_quals", "primary", "secondary", "nsec"):
         z[k] = z[k][:500]                                                     # (the first 500 of the 1 200 reads; all 3 000 adjuster items)
+    partial0, inactive0 = emu.emu_partial_ops(), emu.emu_inactive_reads()
     ga.test_adjust_alignments_vs_reference_fixture(golden_index, z)
     ga.test_secondary_with_adjustment_vs_reference_fixture(golden_index, z, min_changed=20)
+    assert emu.emu_partial_ops() == partial0 and emu.emu_inactive_reads() == inactive0      # the adjuster's control flow is wave-uniform
     ga.test_adjustment_is_single_end_only(golden_index)
