@@ -7,41 +7,6 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def adjust_reads(seed, contigs, n, L):
-    """reads that exercise AlignmentAdjuster: a third plain (substitutions + scattered indels), a third with an indel of 1-4 bases within
-    the first or last 6 bases, a third hanging 1-25 bases over the start or the end of their contig; half of everything reverse-complemented"""
-    from snap_amd import synth
-    rng = np.random.default_rng(seed)
-    base = synth.make_reads(seed, contigs, n, L, sub=0.01, ins=0.002, dele=0.002)
-    b, q = base["bases"].copy(), base["quals"].copy()
-    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    comp = np.zeros(256, np.uint8); comp[:] = ord("N")
-    for x, y in zip(b"ACGT", b"TGCA"): comp[x] = y
-    lens = [len(g) for _, g in contigs]
-    for i in range(n):
-        kind = i % 3
-        if kind == 0: continue
-        ci = int(rng.integers(len(contigs))); g = contigs[ci][1]
-        if len(g) < 3 * L: continue
-        if kind == 1:
-            pos = int(rng.integers(50, len(g) - 2 * L - 50)); d = int(rng.integers(1, 5)); at = int(rng.integers(1, 7))
-            if rng.random() < 0.5: at = L - at - d
-            if rng.random() < 0.5:                      # deletion of d bases from the read at `at`
-                r = np.concatenate([g[pos:pos + at], g[pos + at + d:pos + L + d]])
-            else:                                       # insertion of d bases
-                r = np.concatenate([g[pos:pos + at], acgt[rng.integers(0, 4, d)], g[pos + at:pos + L - d]])
-        else:
-            over = int(rng.integers(1, 26))
-            if rng.random() < 0.5: r = np.concatenate([acgt[rng.integers(0, 4, over)], g[:L - over]])
-            else: r = np.concatenate([g[len(g) - (L - over):], acgt[rng.integers(0, 4, over)]])
-        r = r[:L].copy()
-        sub = rng.random(L) < 0.01
-        r[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
-        if rng.random() < 0.5: r = comp[r[::-1]]
-        b[i] = r
-    return b, q
-
-
 if __name__ == "__main__":
     import snap_amd.aligner as al
     if os.environ.get("SNAPGPU_TEST_LIB", "emu") != "gpu":
@@ -51,6 +16,7 @@ if __name__ == "__main__":
     from snap_amd.aligner import BaseAligner
     from oracle import ref
     from tests import util
+    from tests.adjust_util import adjust_reads
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
     om = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     L = int(sys.argv[3]) if len(sys.argv) > 3 else 100

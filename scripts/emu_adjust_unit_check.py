@@ -7,41 +7,6 @@ sys.path.insert(0, ROOT)
 import numpy as np
 
 
-def make_cases(seed, contigs, cstart, n, L):
-    """(bases[n, L], results[n]) -- read i taken from the genome (with a few substitutions / an indel), strand at random, and a result that
-    places it at its true location shifted by a small amount"""
-    from snap_amd.abi import RESULT_DTYPE
-    rng = np.random.default_rng(seed)
-    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
-    comp = np.zeros(256, np.uint8); comp[:] = ord("N")
-    for x, y in zip(b"ACGT", b"TGCA"): comp[x] = y
-    b = np.zeros((n, L), np.uint8); res = np.zeros(n, dtype=RESULT_DTYPE)
-    for i in range(n):
-        ci = int(rng.integers(len(contigs))); g = contigs[ci][1]
-        where = i % 4
-        if where == 0: pos = int(rng.integers(0, 12))                          # at the start of the contig
-        elif where == 1: pos = len(g) - L - int(rng.integers(0, 12))           # at its end
-        else: pos = int(rng.integers(20, len(g) - L - 20))
-        r = g[pos:pos + L].copy()
-        kind = int(rng.integers(0, 4))
-        if kind == 1 and pos + L + 4 < len(g):                                 # deletion inside
-            at = int(rng.integers(2, L - 8)); d = int(rng.integers(1, 4))
-            r = np.concatenate([g[pos:pos + at], g[pos + at + d:pos + L + d]])
-        elif kind == 2:                                                        # insertion inside
-            at = int(rng.integers(2, L - 8)); d = int(rng.integers(1, 4))
-            r = np.concatenate([g[pos:pos + at], acgt[rng.integers(0, 4, d)], g[pos + at:pos + L - d]])
-        sub = rng.random(L) < 0.015
-        r[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
-        direction = int(rng.integers(0, 2))
-        b[i] = comp[r[::-1]] if direction else r                                # the read as the sequencer gave it
-        shift = int(rng.integers(-6, 7)) if rng.random() < 0.7 else 0
-        loc = cstart[ci] + pos + shift
-        if where == 0 and rng.random() < 0.3: loc = cstart[ci] - int(rng.integers(1, 8))      # starts before the contig
-        res["status"][i] = 1 if rng.random() < 0.97 else 0                     # SingleHit / NotFound
-        res["direction"][i] = direction; res["location"][i] = loc; res["score"][i] = int(rng.integers(0, 9))
-    return b, res
-
-
 if __name__ == "__main__":
     import snap_amd.aligner as al
     if os.environ.get("SNAPGPU_TEST_LIB", "emu") != "gpu":
@@ -50,6 +15,7 @@ if __name__ == "__main__":
     from snap_amd.index import GenomeIndex
     from snap_amd.aligner import BaseAligner
     from oracle import ref
+    from tests.adjust_util import adjust_cases as make_cases
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
     L = 100
     d = tempfile.mkdtemp(prefix="adjunit")
