@@ -154,7 +154,9 @@ struct SecCfg {
 // affineGap / reverseAffineGap traceback arrays, zeroed by the kernel before the read -- the answer of a newly constructed reference aligner.
 // TIMED: the s_memtime phase timers (WaveCounters::cyc_*) are compiled in.  Each read of the clock drains lgkmcnt, ~40 of them per read, so
 // the kernels that are timed for throughput are built without (SNAPGPU_PHASE_TIMERS=1 selects the timed instantiation for a breakdown run).
-template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false>
+// PLANES: the plane Landau-Vishkin (planes.h; SNAPGPU_LV_PLANES=1) is compiled in.  Its own instantiations (single_planes_k.hip): carried by
+// every kernel it cost the default ones 110-120 bytes of scratch per lane (exact form 520 -> 408, fast form 712 -> 592) for an option that is off.
+template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false, bool PLANES = false>
 struct Aligner {
     // ---- constant for the launch
     // held by value: a reference member would make the kernel-argument struct escape through a
@@ -654,7 +656,7 @@ struct Aligner {
 
         // Landau-Vishkin works on bit planes (planes.h) when the context has them and the limit's 2k + 1 diagonals fit
         // the wave; the byte window is only staged for what reads bytes: the gapless walk, affine gap
-        const bool lv_planes = !HAM && ix.planes != nullptr && limit_e <= 31;
+        const bool lv_planes = PLANES && !HAM && ix.planes != nullptr && limit_e <= 31;
         bool sub_ok = false;
         if (substring_in_range(loc, glen)) {                 // Genome::getSubstring (Genome.h:339-367): its "is this padding" byte comes with the window
             bool first_is_pad;
@@ -1242,7 +1244,7 @@ struct Aligner {
         for (uint32_t i = lane; i < (cfg.RL + 31) / 32; i += WAVE) seed_used[i] = 0;
         WAVE_SYNC();
         if (n_count > max_k) return;                                          // :398
-        if (!HAM && ix.planes != nullptr) build_read_planes(len);
+        if (PLANES && !HAM && ix.planes != nullptr) build_read_planes(len);
 
         if (n_count > 0) {                                                    // :407-420 block seeds containing a non-ACGT base
             int min_seed = 0;

@@ -50,6 +50,13 @@ void snapgpu_launch_single_exact_3(const AlignArgs *a, int sec, uint32_t blocks,
 void snapgpu_launch_single_exact_0(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_3_timed(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_3_timed(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+// single_planes_k.hip: the instantiations that carry the plane Landau-Vishkin (SNAPGPU_LV_PLANES=1)
+void snapgpu_launch_single_planes_3(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_planes_4(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_planes_6(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_planes_0(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_exact_planes_3(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_exact_planes_0(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 }
 
 static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }

@@ -9,7 +9,7 @@
 #ifndef SNAPGPU_WAVES_PER_SIMD
 #define SNAPGPU_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 6 : 4)
 #endif
-template <int AGC, bool SEC, bool EXACT = false, bool TIMED = false>
+template <int AGC, bool SEC, bool EXACT = false, bool TIMED = false, bool PLANES = false>
 __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_single(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
     WaveShared *ws = (WaveShared *)(my + L.shared);
-    Aligner<AGC, SEC, EXACT, TIMED> al(a.ix, a.tab, a.cfg, ws);
+    Aligner<AGC, SEC, EXACT, TIMED, PLANES> al(a.ix, a.tab, a.cfg, ws);
     al.lane = lane;
     al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
     al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
                                     al.read_len = len;
                                     (void)al.load_read(a.bases + rb, a.quals + rb, len);
                                     WAVE_SYNC();
-                                    if (a.ix.planes != nullptr) al.build_read_planes(len);
+                                    if (PLANES && a.ix.planes != nullptr) al.build_read_planes(len);
                                     al.se_help_slot(slot);
                                     any = true;
                                 }

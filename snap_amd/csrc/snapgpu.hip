@@ -1672,10 +1672,20 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
         a.sec_cfg = ctx->sec_cfg; a.sec_scratch = ctx->d_sec_scratch; a.sec_stride_bytes = ctx->sec_stride_bytes;
         a.secondary = (snapgpu_single_result *)d_secondary; a.sec_out_stride = sec_out_stride; a.n_secondary = (uint32_t *)d_n_secondary;
     }
+    // (the instantiations that carry the plane Landau-Vishkin: plain launches of a context created under SNAPGPU_LV_PLANES=1)
+    const bool planes_k = ctx->ix.planes != nullptr && !d_n_secondary && !ctx->phase_timers;
     if (always_exact) {                 // one pass, exact by construction
         a.persist = ctx->d_exact_persist; a.persist_stride = ctx->exact_persist_stride;
         if (ctx->phase_timers && !d_n_secondary) snapgpu_launch_single_exact_3_timed(&a, blocks, 4 * ctx->cfg.lds_per_wave, s);
+        else if (planes_k) snapgpu_launch_single_exact_planes_3(&a, blocks, 4 * ctx->cfg.lds_per_wave, s);
         else snapgpu_launch_single_exact_3(&a, d_n_secondary ? 1 : 0, blocks, 4 * ctx->cfg.lds_per_wave, s);
+    } else if (planes_k) {
+        switch (ctx->ag_variant) {
+        case 3:  snapgpu_launch_single_planes_3(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
+        case 4:  snapgpu_launch_single_planes_4(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
+        case 6:  snapgpu_launch_single_planes_6(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
+        default: snapgpu_launch_single_planes_0(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
+        }
     } else if (d_n_secondary) {
         switch (ctx->ag_variant) {
         case 3:  snapgpu_launch_single_sec_3(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;
@@ -1698,7 +1708,9 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
         x.flag_list = nullptr; x.flag_count = nullptr; x.remap = ctx->d_flag_list; x.n_remap = ctx->d_work + 4; x.work_counter = ctx->d_work + 3;
         x.is_replay = 1; x.order = nullptr; x.se_slots = nullptr; x.se_ctl = nullptr;
         x.persist = ctx->d_exact_persist; x.persist_stride = ctx->exact_persist_stride;
-        if (ctx->ag_variant == 3) snapgpu_launch_single_exact_3(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
+        if (planes_k) { if (ctx->ag_variant == 3) snapgpu_launch_single_exact_planes_3(&x, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
+                        else snapgpu_launch_single_exact_planes_0(&x, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s); }
+        else if (ctx->ag_variant == 3) snapgpu_launch_single_exact_3(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
         else snapgpu_launch_single_exact_0(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
         HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     }

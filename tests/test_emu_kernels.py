@@ -84,6 +84,36 @@ def test_emu_align_read_vs_reference_fixture(emu, golden_index, golden_reads, na
     assert emu.emu_inactive_reads() == inactive0
 
 
+def test_emu_plane_landau_vishkin_instantiations(emu, golden_index, golden_reads, monkeypatch):
+    """SNAPGPU_LV_PLANES=1: the context builds the bit-plane shadow of the genome and its plain launches go to the instantiations that
+    carry the plane Landau-Vishkin (single_planes_k.hip: fast form + help, exact form): the first 1 000 golden reads per length, every
+    field, as the default kernels -- and the same bytes as a context without planes."""
+    import tests.test_gpu_parity as gp
+    from snap_amd.aligner import BaseAligner
+    sub = {k: (golden_reads[k][:1000] if k[0] in "bq" else golden_reads[k]) for k in golden_reads.files}
+    b, q = sub["b150"], sub["q150"]
+    offs = np.arange(b.shape[0] + 1, dtype=np.uint64) * 150
+    out = {}
+    for planes in ("1", "0"):
+        monkeypatch.setenv("SNAPGPU_LV_PLANES", planes)
+        for help_on in ("1", "0"):                                            # help on: fast form + replay; off: the exact form as the one pass
+            monkeypatch.setenv("SNAPGPU_SINGLE_HELP", help_on)
+            a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+            try:
+                prim, alt = a.AlignRead(b, q, offs)
+            finally:
+                a.close()
+            out[planes + help_on] = prim
+    exp, _ = util.with_fresh_overrides(golden_reads["default_d8_150_primary"], "default_d8_150_primary")
+    for k, prim in out.items():
+        assert not util.compare_results(exp[:1000], prim), k
+    mask = np.uint32(0x3fffffff)
+    for f in out["11"].dtype.names:
+        if f != "reserved":
+            assert (out["11"][f] == out["01"][f]).all() and (out["10"][f] == out["00"][f]).all(), f
+    assert ((out["11"]["reserved"] & mask) == (out["01"]["reserved"] & mask)).all()
+
+
 def test_emu_ragged_and_degenerate_reads(emu, golden_index):
     import tests.test_gpu_parity as gp
     gp.test_ragged_and_degenerate_reads(golden_index)
