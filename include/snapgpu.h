@@ -453,6 +453,22 @@ int  snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
                         int32_t *n_edits, double *match_probability);
 
 /*
+ * The same problems as CALLS IN ORDER ON ONE OBJECT (test entry): problem i is the i-th computeScore / computeScoreBanded call of one
+ * newly constructed AffineGapVectorized<dir>, whose backtraceAction array (AffineGapVectorized.h:1374) starts zeroed and keeps what
+ * every call wrote -- so a banded traceback step outside the band of call i reads what calls 0 .. i-1 left there (:740-788), as it does
+ * in the reference.  One wavefront, the exact form of the kernels (the form the replay passes run).  stale_steps[i] (may be NULL) =
+ * how many such steps call i made.  Arguments otherwise as snapgpu_affine_gap.
+ */
+int  snapgpu_affine_gap_sequence(snapgpu_ctx *ctx, int dir, uint32_t n,
+                                 const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
+                                 const char *patterns, const char *quals, uint64_t patterns_bytes,
+                                 const uint32_t *pat_off, const int32_t *pat_len,
+                                 const int32_t *w, const int32_t *score_init, const uint8_t *is_rc,
+                                 const uint8_t *banded, const uint8_t *use_clipping_optimizations,
+                                 int32_t *ag_score, int32_t *text_offset, int32_t *pattern_offset,
+                                 int32_t *n_edits, double *match_probability, int32_t *stale_steps);
+
+/*
  * BaseAligner::AlignRead for a batch of n reads.
  *   bases/quals: concatenated read bytes (upper-case ACGTN / Phred+33), host pointers
  *   offsets:     [n+1] byte offsets; read i is bases[offsets[i] .. offsets[i+1])

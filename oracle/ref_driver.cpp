@@ -216,6 +216,28 @@ int snapref_landau_vishkin(int dir, uint32_t n,
 
 struct AGParams { int match, sub, open, ext, five, three; };
 
+/* "Fresh object" mode (VERDICT r01, parity exclusion): with snapref_set_fresh_objects(1) every read / pair is aligned by aligner objects
+ * that were constructed, just before the call, inside a ZERO-FILLED arena -- what a newly started reference thread would use for its first
+ * read.  The reference's answer is then a function of the read alone (its banded affine gap can trace back through cells an earlier call
+ * left in the object, AffineGapVectorized.h:740-788 over :1374; see DESIGN.md "Reference nondeterminism"), so every read can be compared,
+ * none excluded.  BigAllocator::allocate is virtual (BigAlloc.h:95): the arena below hands out zeroed memory it can take back. */
+class ZeroedArena : public BigAllocator {
+public:
+    ZeroedArena(size_t cap_) : BigAllocator(0, 16), cap(cap_ + 4096), used(0) { base = (char *)calloc(cap, 1); }
+    ~ZeroedArena() { free(base); }
+    virtual void *allocate(size_t amount) {
+        size_t a = (amount + 63) & ~(size_t)63;
+        if (used + a > cap) { fprintf(stderr, "ref_driver: ZeroedArena overflow (%zu + %zu > %zu)\n", used, a, cap); abort(); }
+        void *r = base + used; used += a; return r;
+    }
+    void reset() { memset(base, 0, used); used = 0; }          // everything handed out since the last reset reads as zero again
+private:
+    char *base; size_t cap, used;
+};
+static volatile int g_fresh_objects = 0;
+void snapref_set_fresh_objects(int on) { g_fresh_objects = on; }
+int snapref_get_fresh_objects(void) { return g_fresh_objects; }
+
 int snapref_affine_gap(int dir, uint32_t n, const int32_t *agparams /* match,sub,open,ext,5',3' */,
                        const char *texts, const uint32_t *text_off, const int32_t *text_len,
                        const char *patterns, const char *quals, const uint32_t *pat_off, const int32_t *pat_len,
@@ -225,9 +247,11 @@ int snapref_affine_gap(int dir, uint32_t n, const int32_t *agparams /* match,sub
                        int32_t *n_edits, double *match_probability)
 {
     snapref_init();
-    // 16-byte granularity exactly as SingleAligner.cpp:147 ("FIXME: Used larger allocation granularity for __m128i")
-    BigAllocator *alloc = new BigAllocator(AffineGapVectorized<1>::getBigAllocatorReservation() +
-                                           AffineGapVectorized<-1>::getBigAllocatorReservation() + 4096, 16);
+    // 16-byte granularity exactly as SingleAligner.cpp:147 ("FIXME: Used larger allocation granularity for __m128i").
+    // The n problems are calls IN ORDER on these two objects; with snapref_set_fresh_objects(1) the objects live in zero-filled memory,
+    // so what an out-of-band traceback step of problem i reads is what problems 0 .. i-1 left there and nothing else.
+    const size_t ag_reservation = AffineGapVectorized<1>::getBigAllocatorReservation() + AffineGapVectorized<-1>::getBigAllocatorReservation() + 4096;
+    BigAllocator *alloc = g_fresh_objects ? (BigAllocator *)new ZeroedArena(ag_reservation + (1 << 16)) : new BigAllocator(ag_reservation, 16);
     AffineGapVectorized<1> *fwd = new (alloc) AffineGapVectorized<1>(agparams[0], agparams[1], agparams[2], agparams[3], agparams[4], agparams[5]);
     AffineGapVectorized<-1> *bwd = new (alloc) AffineGapVectorized<-1>(agparams[0], agparams[1], agparams[2], agparams[3], agparams[4], agparams[5]);
     PaddedProblem pp;
@@ -280,27 +304,6 @@ static void fill_result(snapgpu_single_result *o, const SingleAlignmentResult *r
     o->popular_seeds_skipped = r->popularSeedsSkipped;
 }
 
-/* "Fresh object" mode (VERDICT r01, parity exclusion): with snapref_set_fresh_objects(1) every read / pair is aligned by aligner objects
- * that were constructed, just before the call, inside a ZERO-FILLED arena -- what a newly started reference thread would use for its first
- * read.  The reference's answer is then a function of the read alone (its banded affine gap can trace back through cells an earlier call
- * left in the object, AffineGapVectorized.h:740-788 over :1374; see DESIGN.md "Reference nondeterminism"), so every read can be compared,
- * none excluded.  BigAllocator::allocate is virtual (BigAlloc.h:95): the arena below hands out zeroed memory it can take back. */
-class ZeroedArena : public BigAllocator {
-public:
-    ZeroedArena(size_t cap_) : BigAllocator(0, 16), cap(cap_ + 4096), used(0) { base = (char *)calloc(cap, 1); }
-    ~ZeroedArena() { free(base); }
-    virtual void *allocate(size_t amount) {
-        size_t a = (amount + 63) & ~(size_t)63;
-        if (used + a > cap) { fprintf(stderr, "ref_driver: ZeroedArena overflow (%zu + %zu > %zu)\n", used, a, cap); abort(); }
-        void *r = base + used; used += a; return r;
-    }
-    void reset() { memset(base, 0, used); used = 0; }          // everything handed out since the last reset reads as zero again
-private:
-    char *base; size_t cap, used;
-};
-static volatile int g_fresh_objects = 0;
-void snapref_set_fresh_objects(int on) { g_fresh_objects = on; }
-int snapref_get_fresh_objects(void) { return g_fresh_objects; }
 /* -ae (AlignerOptions.cpp:476): the aligners below are constructed with ignoreAlignmentAdjustmentsForOm = !g_adjust_alignments */
 static volatile int g_adjust_alignments = 0;
 void snapref_set_adjust_alignments(int on) { g_adjust_alignments = on; }

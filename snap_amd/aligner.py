@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
     "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
     "snapgpu_align_paired_secondary", "snapgpu_align_paired_secondary_device",
-    "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag", "snapgpu_adjust_alignments", "snapgpu_sam_fields_single", "snapgpu_sam_fields_single_device", "snapgpu_sam_fields_paired",
+    "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag", "snapgpu_adjust_alignments", "snapgpu_affine_gap_sequence", "snapgpu_sam_fields_single", "snapgpu_sam_fields_single_device", "snapgpu_sam_fields_paired",
     "snapgpu_default_index_build_params", "snapgpu_index_build", "snapgpu_index_build_from_fasta", "snapgpu_built_index_view",
     "snapgpu_built_index_save", "snapgpu_built_index_stats", "snapgpu_built_index_destroy",
 ]
@@ -236,7 +236,9 @@ class BaseAligner:
         return dict(score=score, match_probability=prob, net_indel=net, total_indels=tot, text_span=span)
 
     # ---- AffineGapVectorized<dir>::computeScore[Banded] --------------------------------
-    def computeScoreAffine(self, direction: int, texts, patterns, quals, w, score_init, is_rc, banded, use_clip=None):
+    def computeScoreAffine(self, direction: int, texts, patterns, quals, w, score_init, is_rc, banded, use_clip=None, sequence: bool = False):
+        """sequence=True: the problems are calls in order on ONE newly constructed object (snapgpu_affine_gap_sequence); the result then
+        also has stale_steps."""
         n = len(texts)
         tbuf, toff, tlen = _pack(texts)
         if direction == -1:
@@ -250,6 +252,13 @@ class BaseAligner:
         use_clip = np.zeros(n, np.uint8) if use_clip is None else np.ascontiguousarray(use_clip, dtype=np.uint8)
         ag = np.zeros(n, np.int32); to = np.zeros(n, np.int32); po = np.zeros(n, np.int32)
         ne = np.zeros(n, np.int32); prob = np.zeros(n, np.float64)
+        if sequence:
+            stale = np.zeros(n, np.int32)
+            self._check(self.lib.snapgpu_affine_gap_sequence(
+                self.handle, C.c_int(direction), C.c_uint32(n), ptr(tbuf), C.c_uint64(tbuf.size), ptr(toff), ptr(tlen),
+                ptr(pbuf), ptr(qbuf), C.c_uint64(pbuf.size), ptr(poff), ptr(plen), ptr(w), ptr(score_init),
+                ptr(is_rc), ptr(banded), ptr(use_clip), ptr(ag), ptr(to), ptr(po), ptr(ne), ptr(prob), ptr(stale)), "snapgpu_affine_gap_sequence")
+            return dict(ag_score=ag, text_offset=to, pattern_offset=po, n_edits=ne, match_probability=prob, stale_steps=stale)
         self._check(self.lib.snapgpu_affine_gap(
             self.handle, C.c_int(direction), C.c_uint32(n), ptr(tbuf), C.c_uint64(tbuf.size), ptr(toff), ptr(tlen),
             ptr(pbuf), ptr(qbuf), C.c_uint64(pbuf.size), ptr(poff), ptr(plen), ptr(w), ptr(score_init),

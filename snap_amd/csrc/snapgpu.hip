@@ -214,6 +214,40 @@ __global__ __launch_bounds__(64) void k_ag_batch(AGBatchArgs a)
     }
 }
 
+// The same problems as CALLS IN ORDER ON ONE OBJECT: one wave, the exact form (ag.h: EXACT) over one image of the object's traceback array
+// that starts zeroed and is kept from call to call -- what a newly constructed AffineGapVectorized<dir> answers for the sequence, the
+// out-of-band traceback steps that read what an earlier call left behind included.  (Test entry: snapgpu_affine_gap_sequence.)
+template <int AGC>
+__global__ __launch_bounds__(64) void k_ag_sequence(AGBatchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    int16_t *rows = (int16_t *)lds;
+    uint8_t *bt = a.scratch;
+    for (uint32_t i = 0; i < a.n; i++) {
+        int plen = a.pat_len[i], tlen = a.text_len[i];
+        const uint8_t *p = a.patterns + a.pat_off[i];
+        const uint8_t *q = a.quals + a.pat_off[i];
+        const uint8_t *t = a.texts + a.text_off[i];
+        AGResult r;
+        if (a.dir == 1) {
+            ByteSeq P{p, 1}, Q{q, 1}, T{t, 1};
+            r = ag_dispatch<AGC, true>(a.banded[i] != 0, 1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
+                                       (int)a.use_clip[i], rows, bt, a.RL, a.tab);
+        } else {
+            ByteSeq P{p, 1}, Q{q, 1}, T{t - 1, -1};
+            r = ag_dispatch<AGC, true>(a.banded[i] != 0, -1, a.prm, P, Q, plen, T, tlen, a.w[i], a.score_init[i], a.is_rc[i] != 0,
+                                       (int)a.use_clip[i], rows, bt, a.RL, a.tab);
+        }
+        WAVE_SYNC(); __threadfence_block();
+        if (lane == 0) {
+            a.ag_score[i] = r.ag_score; a.text_offset[i] = r.text_offset; a.pattern_offset[i] = r.pattern_offset;
+            a.n_edits[i] = r.n_edits; a.prob[i] = r.match_probability;
+            if (a.stale) a.stale[i] = r.stale_reads;
+        }
+    }
+}
+
 // =====================================================================================
 // host side
 // =====================================================================================
@@ -1520,14 +1554,14 @@ extern "C" int snapgpu_sam_fields_paired(snapgpu_ctx *ctx, uint32_t n_pairs, con
     return sam_side_kernel_time(ctx);
 }
 
-extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
-                                  const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
-                                  const char *patterns, const char *quals, uint64_t patterns_bytes,
-                                  const uint32_t *pat_off, const int32_t *pat_len,
-                                  const int32_t *w, const int32_t *score_init, const uint8_t *is_rc,
-                                  const uint8_t *banded, const uint8_t *use_clip,
-                                  int32_t *ag_score, int32_t *text_offset, int32_t *pattern_offset,
-                                  int32_t *n_edits, double *match_probability)
+static int affine_gap_batch(snapgpu_ctx *ctx, int dir, uint32_t n,
+                            const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
+                            const char *patterns, const char *quals, uint64_t patterns_bytes,
+                            const uint32_t *pat_off, const int32_t *pat_len,
+                            const int32_t *w, const int32_t *score_init, const uint8_t *is_rc,
+                            const uint8_t *banded, const uint8_t *use_clip,
+                            int32_t *ag_score, int32_t *text_offset, int32_t *pattern_offset,
+                            int32_t *n_edits, double *match_probability, bool sequence, int32_t *stale_steps)
 {
     if (!ctx || (dir != 1 && dir != -1)) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_affine_gap: bad argument");
     if (n == 0) return SNAPGPU_OK;
@@ -1543,7 +1577,8 @@ extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
     hipStream_t s = ctx->stream;
     const uint32_t waves_per_block = 1;
     uint32_t blocks = n; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;
-    DevBuf dt, dto, dtl, dp, dq, dpo, dpl, dw, dsi, drc, dbd, dcl, dscratch, o1, o2, o3, o4, o5;
+    if (sequence) blocks = 1;
+    DevBuf dt, dto, dtl, dp, dq, dpo, dpl, dw, dsi, drc, dbd, dcl, dscratch, o1, o2, o3, o4, o5, o6;
     HIPCHK(ctx, dt.put(texts, texts_bytes, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, dto.put(text_off, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, dtl.put(text_len, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
@@ -1564,6 +1599,8 @@ extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
     HIPCHK(ctx, o3.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, o4.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, o5.put(nullptr, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    if (stale_steps) HIPCHK(ctx, o6.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    if (sequence) HIPCHK(ctx, hipMemsetAsync(dscratch.p, 0, ag_scratch_bytes(RL), s), SNAPGPU_E_LAUNCH);      // a newly constructed object: the array reads as zero
     AGBatchArgs a;
     a.dir = dir; a.n = n; a.RL = RL;
     a.prm = AGParams{ctx->cfg.match_reward, ctx->cfg.sub_penalty, ctx->cfg.gap_open, ctx->cfg.gap_extend, ctx->cfg.five_bonus, ctx->cfg.three_bonus};
@@ -1573,7 +1610,7 @@ extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
     a.is_rc = (const uint8_t *)drc.p; a.banded = (const uint8_t *)dbd.p; a.use_clip = (const uint8_t *)dcl.p;
     a.scratch = (uint8_t *)dscratch.p;
     a.ag_score = (int32_t *)o1.p; a.text_offset = (int32_t *)o2.p; a.pattern_offset = (int32_t *)o3.p;
-    a.n_edits = (int32_t *)o4.p; a.prob = (double *)o5.p; a.tab = ctx->d_tab; a.stale = nullptr;
+    a.n_edits = (int32_t *)o4.p; a.prob = (double *)o5.p; a.tab = ctx->d_tab; a.stale = stale_steps ? (int32_t *)o6.p : nullptr;
     uint32_t lds = (ag_lds_bytes(RL) + 15) & ~15u;
     // variant by the largest striped layout in this batch (chunks of 64 positions)
     int need = 0;
@@ -1583,6 +1620,10 @@ extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
         if (ns * sl > need) need = ns * sl;
     }
     if (getenv("SNAPGPU_AG_LDS")) need = 1 << 20;
+    if (sequence) {
+        if (need <= 192) hipLaunchKernelGGL(k_ag_sequence<3>, dim3(1), dim3(64), lds, s, a);
+        else             hipLaunchKernelGGL(k_ag_sequence<0>, dim3(1), dim3(64), lds, s, a);          // (the exact replay has these two forms)
+    } else
     if (need <= 192)      hipLaunchKernelGGL(k_ag_batch<3>, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
     else if (need <= 256) hipLaunchKernelGGL(k_ag_batch<4>, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
     else if (need <= 384) hipLaunchKernelGGL(k_ag_batch<6>, dim3(blocks), dim3(64 * waves_per_block), waves_per_block * lds, s, a);
@@ -1593,8 +1634,35 @@ extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
     HIPCHK(ctx, hipMemcpyAsync(pattern_offset, o3.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(n_edits, o4.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemcpyAsync(match_probability, o5.p, (size_t)n * 8, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    if (stale_steps) HIPCHK(ctx, hipMemcpyAsync(stale_steps, o6.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
     return SNAPGPU_OK;
+}
+
+extern "C" int snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
+                                  const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
+                                  const char *patterns, const char *quals, uint64_t patterns_bytes,
+                                  const uint32_t *pat_off, const int32_t *pat_len,
+                                  const int32_t *w, const int32_t *score_init, const uint8_t *is_rc,
+                                  const uint8_t *banded, const uint8_t *use_clip,
+                                  int32_t *ag_score, int32_t *text_offset, int32_t *pattern_offset,
+                                  int32_t *n_edits, double *match_probability)
+{
+    return affine_gap_batch(ctx, dir, n, texts, texts_bytes, text_off, text_len, patterns, quals, patterns_bytes, pat_off, pat_len, w, score_init, is_rc,
+                            banded, use_clip, ag_score, text_offset, pattern_offset, n_edits, match_probability, false, nullptr);
+}
+
+extern "C" int snapgpu_affine_gap_sequence(snapgpu_ctx *ctx, int dir, uint32_t n,
+                                           const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,
+                                           const char *patterns, const char *quals, uint64_t patterns_bytes,
+                                           const uint32_t *pat_off, const int32_t *pat_len,
+                                           const int32_t *w, const int32_t *score_init, const uint8_t *is_rc,
+                                           const uint8_t *banded, const uint8_t *use_clip,
+                                           int32_t *ag_score, int32_t *text_offset, int32_t *pattern_offset,
+                                           int32_t *n_edits, double *match_probability, int32_t *stale_steps)
+{
+    return affine_gap_batch(ctx, dir, n, texts, texts_bytes, text_off, text_len, patterns, quals, patterns_bytes, pat_off, pat_len, w, score_init, is_rc,
+                            banded, use_clip, ag_score, text_offset, pattern_offset, n_edits, match_probability, true, stale_steps);
 }
 
 // heavy-first dequeue order of a batch (order.h): ctx->d_order[0 .. n_units) is ready on stream s when this returns

@@ -77,3 +77,27 @@ def golden_contigs(gi):
     begins = [int(c.begin) for c in gi.contigs] + [int(nb)]
     pad = gi.chromosome_padding
     return [(c.name, G[begins[k]:begins[k + 1] - pad]) for k, c in enumerate(gi.contigs)], begins[:-1]
+
+
+def ag_call_sequence(seed, n, max_len=150):
+    """n affine-gap problems meant to be CALLS IN ORDER ON ONE OBJECT (snapgpu_affine_gap_sequence): most carry an indel about as long as
+    the band is wide, which is what sends a banded traceback out of its band -- where it reads what earlier calls left in the array.
+    Returns (texts, patterns, quals, w, score_init, is_rc, banded)."""
+    rng = np.random.default_rng(seed)
+    texts, pats, quals, ws, sis, rcs, bands = [], [], [], [], [], [], []
+    for _ in range(n):
+        L = int(rng.integers(30, max_len))
+        t = bytes(rng.choice(list(b"ACGT"), size=L + 80).astype(np.uint8))
+        p = bytearray(t[:L])
+        w = int(rng.integers(1, 14))
+        if rng.random() < 0.8:
+            j = int(rng.integers(2, max(3, L - 2))); d = max(1, w + int(rng.integers(-2, 3)))
+            if rng.random() < 0.5: del p[j:j + d]
+            else: p[j:j] = bytes(rng.choice(list(b"ACGT"), size=d).astype(np.uint8))
+        for _e in range(int(rng.integers(0, 4))):
+            j = int(rng.integers(0, len(p))); p[j] = b"ACGT"[rng.integers(0, 4)]
+        p = bytes(p[:L]) if len(p) >= 8 else bytes(t[:8])
+        texts.append(t[:min(len(t), len(p) + 60)]); pats.append(p); quals.append(bytes(rng.integers(35, 74, size=len(p)).astype(np.uint8)))
+        ws.append(w); sis.append(int(rng.integers(1, 60))); rcs.append(int(rng.integers(0, 2)))
+        bands.append(1 if len(p) >= 3 * (2 * w + 1) else 0)
+    return texts, pats, quals, ws, sis, rcs, bands

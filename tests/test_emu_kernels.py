@@ -287,6 +287,14 @@ def test_emu_paired_over_wide_location_index(emu, tmp_path):
     paired_over_wide_index(str(tmp_path), 16, False, [], 250)
 
 
+def test_emu_affine_gap_call_sequences(emu, emu_aligner):
+    """The exact (image-keeping) affine-gap forms against the reference's history-dependent answers: the first third of each call sequence
+    of tests/golden/ag_sequence.npz (400 calls through the 192-position register form, 166 through the LDS form, both directions)."""
+    import tests.test_gpu_parity as gp
+    z = np.load(os.path.join(util.GOLDEN, "ag_sequence.npz"), allow_pickle=True)
+    assert gp.check_affine_gap_call_sequences(emu_aligner, z, step=3) > 8
+
+
 def test_emu_compute_cigar_affine_gap(emu, emu_aligner):
     """SAMFormat::computeCigar, affine-gap variant (banded and full global alignment with traceback), on the emulated device: every
     third item of the reference fixture (tests/golden/cigar_ag.npz), both op alphabets."""

@@ -139,6 +139,39 @@ def test_affine_gap_vs_reference_fixture(aligner, golden_primitives):
     assert n_checked > 1000
 
 
+def check_affine_gap_call_sequences(aligner, z, tags=("short", "long"), step=1):
+    """tests/golden/ag_sequence.npz (scripts/make_golden_ag_sequence.py): affine-gap problems as calls in order on ONE newly constructed
+    reference object; snapgpu_affine_gap_sequence -- one wave, the exact form over an image of the object's array kept from call to call --
+    must give the reference's answer for EVERY call, the ones whose traceback read what earlier calls left behind included."""
+    n_dep = 0
+    for tag in tags:
+        n = len(z[tag + "_texts"]) // step
+        texts, pats, quals = list(z[tag + "_texts"][:n]), list(z[tag + "_pats"][:n]), list(z[tag + "_quals"][:n])
+        for d in (1, -1):
+            tt = [t if d == 1 else t[::-1] for t in texts]
+            got = aligner.computeScoreAffine(d, tt, pats, quals, z[tag + "_w"][:n], z[tag + "_si"][:n], z[tag + "_rc"][:n], z[tag + "_banded"][:n], sequence=True)
+            pre = "%s%+d_" % (tag, d)
+            assert (got["ag_score"] == z[pre + "ag_score"][:n]).all(), (tag, d)
+            ok = z[pre + "ag_score"][:n] != -1
+            for key in ("text_offset", "pattern_offset", "n_edits", "match_probability"):
+                assert (got[key][ok] == z[pre + key][:n][ok]).all(), (tag, d, key)
+            dep = z[pre + "depends_on_history"][:n]
+            assert (got["stale_steps"][dep] > 0).all()                      # an answer can only depend on earlier calls through such steps
+            n_dep += int(dep.sum())
+    return n_dep
+
+
+def test_affine_gap_call_sequences_vs_reference_fixture(golden_index):
+    from snap_amd.aligner import BaseAligner
+    import os
+    z = np.load(os.path.join(util.GOLDEN, "ag_sequence.npz"), allow_pickle=True)
+    a = BaseAligner(golden_index, abi.default_params(max_k=8, max_read_len=160))
+    try:
+        assert check_affine_gap_call_sequences(a, z) > 40
+    finally:
+        a.close()
+
+
 def test_affine_gap_clipping_modes_vs_restatement(aligner):
     """Seeded fuzz over the three clipping modes (0 off, 1 useClippingOptimizations, 2 = with useAltLiftover), banded/full and
     window/register forms, both directions, against the C restatement (itself pinned to the reference by tests/test_oracle.py)."""
