@@ -20,6 +20,7 @@
 #include "probe.h"
 #include "lv.h"
 #include "ag_win.h"
+#include "ag_resolve.h"
 #include "align_single.h"
 #include "kernel_common.h"
 #include "single_kernel.h"
@@ -245,6 +246,49 @@ __global__ __launch_bounds__(64) void k_ag_sequence(AGBatchArgs a)
             a.n_edits[i] = r.n_edits; a.prob[i] = r.match_probability;
             if (a.stale) a.stale[i] = r.stale_reads;
         }
+    }
+}
+
+// The sequence again, WITHOUT an image kept from call to call: every call in the fast form (a step outside the band reads 0 and is
+// counted), and a call that made such steps is answered exactly by ag_resolve.h from the list of the calls before it.
+__global__ __launch_bounds__(64) void k_ag_sequence_resolve(AGBatchArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id();
+    int16_t *rows = (int16_t *)lds;
+    const uint32_t image_bytes = (uint32_t)ag_scratch_bytes(a.RL);
+    uint8_t *bt = a.scratch, *image = a.scratch + image_bytes, *other = a.scratch + 2 * (size_t)image_bytes;
+    auto problem = [&](uint32_t i) -> AGProblem {
+        AGProblem x;
+        x.p = a.patterns + a.pat_off[i]; x.q = a.quals + a.pat_off[i]; x.t = a.texts + a.text_off[i];
+        x.plen = a.pat_len[i]; x.tlen = a.text_len[i]; x.w = a.w[i]; x.score_init = a.score_init[i];
+        x.banded = a.banded[i] != 0; x.is_rc = a.is_rc[i] != 0; x.use_clip = (int)a.use_clip[i];
+        return x;
+    };
+    for (uint32_t i = 0; i < a.n; i++) {
+        const AGProblem x = problem(i);
+        AGResult r;
+        if (a.dir == 1) {
+            ByteSeq P{x.p, 1}, Q{x.q, 1}, T{x.t, 1};
+            r = ag_compute<false>(x.banded, 1, a.prm, P, Q, x.plen, T, x.tlen, x.w, x.score_init, x.is_rc, x.use_clip, rows, bt, a.RL, a.tab);
+        } else {
+            ByteSeq P{x.p, 1}, Q{x.q, 1}, T{x.t - 1, -1};
+            r = ag_compute<false>(x.banded, -1, a.prm, P, Q, x.plen, T, x.tlen, x.w, x.score_init, x.is_rc, x.use_clip, rows, bt, a.RL, a.tab);
+        }
+        WAVE_SYNC(); __threadfence_block();
+        int stale = r.stale_reads;
+        if (stale > 0 && i > 0) {                    // (the object's first call reads zeros outside its band: the fast form's answer is the exact one)
+            AGResult ex; uint32_t steps = 0;
+            const bool ok = ag_resolve_call(a.dir, a.prm, x, (int)i, [&](int c) { return problem((uint32_t)c); }, rows, image, other, image_bytes, a.RL, a.tab, &ex, &steps);
+            if (ok) r = ex; else r.ag_score = -2;        // (test entry: an unresolved call shows)
+            stale = (stale & 0xffff) | (int)(steps << 16);       // (and how many cells it took: stale_steps[i] >> 16)
+        }
+        if (lane == 0) {
+            a.ag_score[i] = r.ag_score; a.text_offset[i] = r.text_offset; a.pattern_offset[i] = r.pattern_offset;
+            a.n_edits[i] = r.n_edits; a.prob[i] = r.match_probability;
+            if (a.stale) a.stale[i] = stale;
+        }
+        WAVE_SYNC();
     }
 }
 
@@ -1593,7 +1637,7 @@ static int affine_gap_batch(snapgpu_ctx *ctx, int dir, uint32_t n,
     std::vector<uint8_t> zeros;
     if (!use_clip) { zeros.assign(n, 0); use_clip = zeros.data(); }
     HIPCHK(ctx, dcl.put(use_clip, (size_t)n, s), SNAPGPU_E_NOMEM);
-    HIPCHK(ctx, dscratch.put(nullptr, (size_t)blocks * waves_per_block * ag_scratch_bytes(RL), s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dscratch.put(nullptr, (size_t)(sequence ? 3 : blocks * waves_per_block) * ag_scratch_bytes(RL), s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, o1.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, o2.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, o3.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
@@ -1620,7 +1664,9 @@ static int affine_gap_batch(snapgpu_ctx *ctx, int dir, uint32_t n,
         if (ns * sl > need) need = ns * sl;
     }
     if (getenv("SNAPGPU_AG_LDS")) need = 1 << 20;
-    if (sequence) {
+    if (sequence && getenv("SNAPGPU_AG_SEQUENCE_RESOLVE") && atoi(getenv("SNAPGPU_AG_SEQUENCE_RESOLVE")) != 0)
+        hipLaunchKernelGGL(k_ag_sequence_resolve, dim3(1), dim3(64), lds, s, a);                        // (no image kept: ag_resolve.h)
+    else if (sequence) {
         if (need <= 192) hipLaunchKernelGGL(k_ag_sequence<3>, dim3(1), dim3(64), lds, s, a);
         else             hipLaunchKernelGGL(k_ag_sequence<0>, dim3(1), dim3(64), lds, s, a);          // (the exact replay has these two forms)
     } else

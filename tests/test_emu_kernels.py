@@ -295,6 +295,12 @@ def test_emu_affine_gap_call_sequences(emu, emu_aligner):
     assert gp.check_affine_gap_call_sequences(emu_aligner, z, step=3) > 8
 
 
+def test_emu_affine_gap_call_sequences_without_an_image(emu, golden_index, monkeypatch):
+    """ag_resolve.h on the emulated device: the first 400 calls of the short-pattern sequence with no image kept (SNAPGPU_AG_SEQUENCE_RESOLVE=1)."""
+    import tests.test_gpu_parity as gp
+    gp.test_affine_gap_call_sequences_without_an_image(golden_index, monkeypatch, step=3, tags=("short",))
+
+
 def test_emu_compute_cigar_affine_gap(emu, emu_aligner):
     """SAMFormat::computeCigar, affine-gap variant (banded and full global alignment with traceback), on the emulated device: every
     third item of the reference fixture (tests/golden/cigar_ag.npz), both op alphabets."""
