@@ -45,8 +45,8 @@ static __device__ __forceinline__ bool ag_call_covers(bool banded, int pattern_l
     return k < nk;
 }
 
-// One problem of a sequence, as the callers hold it (byte strings in the direction's own orientation).
-struct AGProblem { const uint8_t *p, *q, *t; int plen, tlen, w, score_init; bool banded, is_rc; int use_clip; };
+// One call as its caller holds it: first element and step of the pattern (and its qualities) and of the text.
+struct AGProblem { const uint8_t *p, *q, *t; int pst, tst; int plen, tlen, w, score_init; bool banded, is_rc; int use_clip; };
 
 // `prob(c)` returns call c of the object (0 <= c < n_earlier: the calls made before this one, oldest first).
 // image / other: two buffers of image_bytes each; rows: the LDS form's H / H-1 / E rows (ag_lds_bytes(RL) of the LDS form).
@@ -58,14 +58,9 @@ static __device__ __forceinline__ bool ag_resolve_call(int dir, const AGParams &
 {
     const int lane = lane_id();
     auto run = [&](const AGProblem &c, uint8_t *img, uint32_t *pending) -> AGResult {
-        if (dir == 1) {
-            ByteSeq P{c.p, 1}, Q{c.q, 1}, T{c.t, 1};
-            return pending ? ag_compute<true, true>(c.banded, 1, prm, P, Q, c.plen, T, c.tlen, c.w, c.score_init, c.is_rc, c.use_clip, rows, img, RL, tab, pending)
-                           : ag_compute<true, false>(c.banded, 1, prm, P, Q, c.plen, T, c.tlen, c.w, c.score_init, c.is_rc, c.use_clip, rows, img, RL, tab);
-        }
-        ByteSeq P{c.p, 1}, Q{c.q, 1}, T{c.t - 1, -1};
-        return pending ? ag_compute<true, true>(c.banded, -1, prm, P, Q, c.plen, T, c.tlen, c.w, c.score_init, c.is_rc, c.use_clip, rows, img, RL, tab, pending)
-                       : ag_compute<true, false>(c.banded, -1, prm, P, Q, c.plen, T, c.tlen, c.w, c.score_init, c.is_rc, c.use_clip, rows, img, RL, tab);
+        ByteSeq P{c.p, c.pst}, Q{c.q, c.pst}, T{c.t, c.tst};
+        return pending ? ag_compute<true, true>(c.banded, dir, prm, P, Q, c.plen, T, c.tlen, c.w, c.score_init, c.is_rc, c.use_clip, rows, img, RL, tab, pending)
+                       : ag_compute<true, false>(c.banded, dir, prm, P, Q, c.plen, T, c.tlen, c.w, c.score_init, c.is_rc, c.use_clip, rows, img, RL, tab);
     };
     // 1. everything this call can address is unknown
     {
@@ -105,3 +100,32 @@ static __device__ __forceinline__ bool ag_resolve_call(int dir, const AGParams &
     *steps_out = steps;
     return false;
 }
+
+// ---- the aligners' form: the object's calls of the read as 16-byte records, the read and the genome by pointer
+struct AgCall { int64_t loc; int16_t org, plen, tlen; uint16_t lim_flags; };       // lim_flags: limit | direction << 8 | use_clip << 9 | banded << 10
+struct AgCallCtx {                             // what turns a record into a problem again (by value: see adjust.h on why not a reference)
+    const uint8_t *rd0, *rd1, *ql0, *ql1;      // the read and its reverse complement, qualities in the same orientations
+    const uint8_t *genome;                     // base 0
+    int read_len, st;                          // score_init of every call; +1: affineGap (forward half), -1: reverseAffineGap
+};
+static __device__ __forceinline__ AGProblem ag_call_problem(const AgCallCtx &c, int64_t loc, int org, int plen, int tlen, int lim, int dir, int use_clip, bool banded) {
+    AGProblem x;
+    x.p = (dir ? c.rd1 : c.rd0) + org; x.q = (dir ? c.ql1 : c.ql0) + org; x.t = c.genome + loc + org; x.pst = c.st; x.tst = c.st;
+    x.plen = plen; x.tlen = tlen; x.w = lim; x.score_init = c.read_len; x.banded = banded; x.is_rc = dir != 0; x.use_clip = use_clip;
+    return x;
+}
+// (not inlined: a rare path that must not take part in the register allocation of the kernel's hot loops)
+static __device__ __attribute__((noinline)) bool ag_resolve_from_list(const AgCallCtx c, const AGParams prm, const AGProblem x, const AgCall *list, int n_earlier,
+                                                                      int16_t *rows, uint8_t *image, uint8_t *other, uint32_t image_bytes, uint32_t RL,
+                                                                      const DevTables *tab, AGResult *out)
+{
+    uint32_t steps = 0;
+    return ag_resolve_call(c.st, prm, x, n_earlier, [&](int k) {
+                               const int64_t l = (int64_t)first_u64((uint64_t)list[k].loc);
+                               const uint32_t w0 = first_u32(((const uint32_t *)&list[k])[2]), w1 = first_u32(((const uint32_t *)&list[k])[3]);
+                               const uint32_t lf = w1 >> 16;
+                               return ag_call_problem(c, l, (int)(int16_t)(w0 & 0xffffu), (int)(int16_t)(w0 >> 16), (int)(int16_t)(w1 & 0xffffu), (int)(lf & 0xffu),
+                                                      (int)((lf >> 8) & 1u), (int)((lf >> 9) & 1u), ((lf >> 10) & 1u) != 0);
+                           }, rows, image, other, image_bytes, RL, tab, out, &steps);
+}
+

@@ -32,6 +32,7 @@
 #include "ag_win.h"
 #include "se_help.h"
 #include "adjust.h"
+#include "ag_resolve.h"
 #include <stddef.h>
 #include "../../include/snapgpu.h"
 
@@ -156,7 +157,9 @@ struct SecCfg {
 // the kernels that are timed for throughput are built without (SNAPGPU_PHASE_TIMERS=1 selects the timed instantiation for a breakdown run).
 // PLANES: the plane Landau-Vishkin (planes.h; SNAPGPU_LV_PLANES=1) is compiled in.  Its own instantiations (single_planes_k.hip): carried by
 // every kernel it cost the default ones 110-120 bytes of scratch per lane (exact form 520 -> 408, fast form 712 -> 592) for an option that is off.
-template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false, bool PLANES = false>
+// RESOLVE (its own instantiations, single_resolve_k.hip; SNAPGPU_SINGLE_RESOLVE=1): the fast form answers a call that leaves its band on the
+// spot, from the list of the object's earlier calls of the read (ag_resolve.h) -- no traceback images, nothing to replay.
+template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false, bool PLANES = false, bool RESOLVE = false>
 struct Aligner {
     // ---- constant for the launch
     // held by value: a reference member would make the kernel-argument struct escape through a
@@ -215,6 +218,8 @@ struct Aligner {
     uint32_t *sec_key, *sec_ord;       // [sec_cfg.cap] each
     uint32_t n_sec, n_sec_raw, sec_overflow;
     uint8_t *adj_scratch;              // adjust.h (sec_cfg.adjust only)
+    // RESOLVE only: the wave's slab [calls of object 0 | calls of object 1 | H, H-1, E rows of the LDS form | image | second image]
+    uint8_t *rs_base; uint32_t rs_n0, rs_n1, rs_over;
     // Cold, wave-uniform state lives in LDS (WaveShared), not in registers: it is touched a few
     // times per candidate / per read, and keeping ~150 dwords of it live across the LV and
     // affine-gap code is what pushed the kernel to 1-2 waves per SIMD.  Every lane executes the
@@ -227,6 +232,7 @@ struct Aligner {
         : ix(ix_), tab(tab_), cfg(cfg_), tp_org(0), rd_plain(0), ag_hw0(0), ag_hw1(0), read_len(0), popular_seeds_skipped(0),
           ag_stale(0), ag_replay(0), ag_obj_used0(0), ag_obj_used1(0), max_k(cfg_.max_k), ag_calls_unit(0),
           agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0), n_sec(0), n_sec_raw(0), sec_overflow(0),
+          rs_base(nullptr), rs_n0(0), rs_n1(0), rs_over(0),
           all(ws->all), non_alt(ws->non_alt), primary(ws->primary), first_alt(ws->first_alt), cnt(ws->cnt) {}
 
     static __device__ __forceinline__ uint64_t clk() { if constexpr (TIMED) return wave_clock(); else return 0; }
@@ -251,6 +257,45 @@ struct Aligner {
             if (ext > image) ext = image;
             if (obj == 0) ag_hw0 = ext > ag_hw0 ? ext : ag_hw0; else ag_hw1 = ext > ag_hw1 ? ext : ag_hw1;
         }
+    }
+
+    // RESOLVE: the lists of the read's affine-gap calls (ag_resolve.h: AgCall), one per object
+    static __host__ __device__ __forceinline__ uint32_t rs_log_cap() { return 2048u; }
+    static __host__ __device__ __forceinline__ size_t rs_slab_bytes(uint32_t RL) {
+        return 2 * (size_t)rs_log_cap() * sizeof(AgCall) + (((size_t)ag_lds_bytes(RL) + 255) & ~(size_t)255) + 2 * ((ag_scratch_bytes(RL) + 255) & ~(size_t)255);
+    }
+    // after a call of object `obj` (0: affineGap, the forward half; 1: reverseAffineGap): if its traceback left the band and the object has
+    // scored something for this read before, get the exact answer now; then the call joins the object's list
+    __device__ __forceinline__ AGResult resolve_and_log(int obj, int dir, int64_t loc, int org, int plen, int lim, int tlen, int use_clip, bool banded,
+                                                        const AGParams &agp, AGResult a) {
+        AgCall *log = (AgCall *)rs_base + (obj == 0 ? 0u : rs_log_cap());
+        const uint32_t n = obj == 0 ? rs_n0 : rs_n1;
+        const uint32_t used = obj == 0 ? ag_obj_used0 : ag_obj_used1;
+        if (a.stale_reads > 0 && used && !rs_over) {
+            int16_t *rows = (int16_t *)(rs_base + 2 * (size_t)rs_log_cap() * sizeof(AgCall));
+            uint8_t *image = (uint8_t *)rows + (((size_t)ag_lds_bytes(cfg.RL) + 255) & ~(size_t)255);
+            const uint32_t image_bytes = (uint32_t)ag_scratch_bytes(cfg.RL);
+            uint8_t *other = image + ((image_bytes + 255u) & ~255u);
+            AgCallCtx c; c.rd0 = rd[0]; c.rd1 = rd[1]; c.ql0 = ql[0]; c.ql1 = ql[1]; c.genome = ix.genome; c.read_len = read_len; c.st = obj == 0 ? 1 : -1;
+            AGResult ex;
+            if (ag_resolve_from_list(c, agp, ag_call_problem(c, loc, org, plen, tlen, lim, dir, use_clip, banded), log, (int)n, rows, image, other, image_bytes, cfg.RL, tab, &ex)) {
+                a.ag_score = (int)first_u32((uint32_t)ex.ag_score); a.n_edits = (int)first_u32((uint32_t)ex.n_edits);
+                a.pattern_offset = (int)first_u32((uint32_t)ex.pattern_offset); a.text_offset = (int)first_u32((uint32_t)ex.text_offset);
+                a.match_probability = first_f64(ex.match_probability);
+                a.stale_reads = 0;                               // answered: nothing left for a replay
+            }
+        }
+        if (lim < 0) return a;                                  // (a call with a negative limit returns at once and writes nothing: ag.h)
+        if (n < rs_log_cap()) {
+            if (lane == 0) {
+                AgCall e; e.loc = loc; e.org = (int16_t)org; e.plen = (int16_t)plen; e.tlen = (int16_t)tlen;
+                e.lim_flags = (uint16_t)((uint32_t)(lim & 0xff) | ((uint32_t)(dir ? 1 : 0) << 8) | ((uint32_t)(use_clip ? 1 : 0) << 9) | ((uint32_t)(banded ? 1 : 0) << 10));
+                log[n] = e;
+            }
+            if (obj == 0) rs_n0 = n + 1; else rs_n1 = n + 1;
+            WAVE_SYNC(); __threadfence_block();
+        } else rs_over = 1;                                     // (a longer list: later calls that leave the band are flagged for the replay as before)
+        return a;
     }
 
     // ------------------------------------------------------------------ helpers
@@ -762,6 +807,7 @@ struct Aligner {
                         a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
                         a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
                         a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
+                        if constexpr (RESOLVE) a = resolve_and_log(half, e_dir, loc, org, plen, lim, tlen, 0, banded, agp, a);
                         note_ag_call(half, (uint32_t)a.stale_reads);
                         if (half == 0) {
                             ag1 = a.ag_score + (seed_len - read_len); clip_after = a.pattern_offset;
@@ -1197,6 +1243,7 @@ struct Aligner {
     __device__ __forceinline__ void align_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         const uint64_t t_read0 = clk();
         ag_obj_used0 = ag_obj_used1 = 0;                                      // a newly constructed aligner for every read
+        if constexpr (RESOLVE) { rs_n0 = rs_n1 = 0; rs_over = 0; }
         ag_calls_unit = 0;
         align_read_inner<false>(g_bases, g_quals, len);
         if (ag_calls_unit >= WAVE_PRIO_HEAVY_AFTER) wave_set_priority(0);
@@ -1499,6 +1546,7 @@ struct Aligner {
             a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
             a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
             a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
+            if constexpr (RESOLVE) a = resolve_and_log(half, dir, loc, org, plen, lim, tlen, half == 0 ? 1 : 0, banded, agp, a);
             note_ag_call(half, (uint32_t)a.stale_reads);
             if (half == 0) {
                 ag1 = a.ag_score + (seed_len - read_len); *clip_after = a.pattern_offset; score1 = a.n_edits; mp1 = a.match_probability;

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "snap_amd", "csrc")
-BDIR = os.path.join(HERE, "_build")
+BDIR = os.environ.get("SNAPGPU_EMU_BDIR") or os.path.join(HERE, "_build")      # (SNAPGPU_EMU_BDIR: a second build beside a test run that is using the first)
 LIB = os.path.join(BDIR, "libsnapgpu_emu.so")
 TOOL = os.path.join(BDIR, "snapgpu-sam-emu")
 CXX = os.environ.get("CXX", "g++")
@@ -25,6 +25,7 @@ def units():
     u += [("paired_k%d.o" % v, os.path.join(CSRC, "paired_k.hip"), ["-DPAIRED_AGC=%d" % v]) for v in (3, 4, 6, 0)]
     u += [("single_sec_k%d.o" % v, os.path.join(CSRC, "single_sec_k.hip"), ["-DSINGLE_AGC=%d" % v]) for v in (3, 4, 6, 0)]
     u += [("single_planes_k%d.o" % v, os.path.join(CSRC, "single_planes_k.hip"), ["-DSINGLE_AGC=%d" % v]) for v in (3, 4, 6, 0)]
+    u += [("single_resolve_k.o", os.path.join(CSRC, "single_resolve_k.hip"), [])]
     u += [("paired_sec_k%d.o" % v, os.path.join(CSRC, "paired_k.hip"), ["-DPAIRED_AGC=%d" % v, "-DPAIRED_SEC"]) for v in (3, 0)]
     # -fsanitize=thread only for its instrumentation: wave_emu.cpp supplies the __tsan_* hooks (stores become rendezvous points)
     u = [(o, src, fl + ["-fsanitize=thread", "--param", "tsan-instrument-func-entry-exit=0"]) for (o, src, fl) in u]
