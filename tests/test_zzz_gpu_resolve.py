@@ -44,5 +44,8 @@ def check_resolve_on_fixture(golden_index, golden_reads, monkeypatch, sets=(("de
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("SNAPGPU_TEST_UNMEASURED") != "1" and not os.environ.get("SNAPGPU_TEST_LIB"),
+                    reason="the RESOLVE instantiation has not run on hardware yet (written after the round's GPU minutes were spent): "
+                           "SNAPGPU_TEST_UNMEASURED=1 runs it; the emulator twin runs in the CPU suite")
 def test_calls_leaving_the_band_are_answered_in_place(golden_index, golden_reads, monkeypatch):
     assert check_resolve_on_fixture(golden_index, golden_reads, monkeypatch) >= 2       # (the fixture does hold reads the fast form alone gets flagged)
