@@ -159,8 +159,14 @@ struct SecCfg {
 // every kernel it cost the default ones 110-120 bytes of scratch per lane (exact form 520 -> 408, fast form 712 -> 592) for an option that is off.
 // RESOLVE (its own instantiations, single_resolve_k.hip; SNAPGPU_SINGLE_RESOLVE=1): the fast form answers a call that leaves its band on the
 // spot, from the list of the object's earlier calls of the read (ag_resolve.h) -- no traceback images, nothing to replay.
+// (the RESOLVE instantiations' extra state as a base class: empty otherwise, so that the other instantiations' object is what it was)
+struct AlignerResolveState { uint8_t *rs_base; uint32_t rs_n0, rs_n1, rs_over; };   // the wave's slab [calls of object 0 | calls of object 1 | H, H-1, E rows of the LDS form | image | second image]
+struct AlignerNoResolveState {};
+template <bool RESOLVE> struct AlignerResolveBase { using type = AlignerNoResolveState; };
+template <> struct AlignerResolveBase<true> { using type = AlignerResolveState; };
+
 template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false, bool PLANES = false, bool RESOLVE = false>
-struct Aligner {
+struct Aligner : AlignerResolveBase<RESOLVE>::type {
     // ---- constant for the launch
     // held by value: a reference member would make the kernel-argument struct escape through a
     // flat pointer and pin this whole object (ScoreSets, results, counters) in scratch memory
@@ -218,8 +224,6 @@ struct Aligner {
     uint32_t *sec_key, *sec_ord;       // [sec_cfg.cap] each
     uint32_t n_sec, n_sec_raw, sec_overflow;
     uint8_t *adj_scratch;              // adjust.h (sec_cfg.adjust only)
-    // RESOLVE only: the wave's slab [calls of object 0 | calls of object 1 | H, H-1, E rows of the LDS form | image | second image]
-    uint8_t *rs_base; uint32_t rs_n0, rs_n1, rs_over;
     // Cold, wave-uniform state lives in LDS (WaveShared), not in registers: it is touched a few
     // times per candidate / per read, and keeping ~150 dwords of it live across the LV and
     // affine-gap code is what pushed the kernel to 1-2 waves per SIMD.  Every lane executes the
@@ -232,8 +236,9 @@ struct Aligner {
         : ix(ix_), tab(tab_), cfg(cfg_), tp_org(0), rd_plain(0), ag_hw0(0), ag_hw1(0), read_len(0), popular_seeds_skipped(0),
           ag_stale(0), ag_replay(0), ag_obj_used0(0), ag_obj_used1(0), max_k(cfg_.max_k), ag_calls_unit(0),
           agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0), n_sec(0), n_sec_raw(0), sec_overflow(0),
-          rs_base(nullptr), rs_n0(0), rs_n1(0), rs_over(0),
-          all(ws->all), non_alt(ws->non_alt), primary(ws->primary), first_alt(ws->first_alt), cnt(ws->cnt) {}
+          all(ws->all), non_alt(ws->non_alt), primary(ws->primary), first_alt(ws->first_alt), cnt(ws->cnt) {
+        if constexpr (RESOLVE) { this->rs_base = nullptr; this->rs_n0 = this->rs_n1 = 0; this->rs_over = 0; }
+    }
 
     static __device__ __forceinline__ uint64_t clk() { if constexpr (TIMED) return wave_clock(); else return 0; }
 
@@ -268,11 +273,11 @@ struct Aligner {
     // scored something for this read before, get the exact answer now; then the call joins the object's list
     __device__ __forceinline__ AGResult resolve_and_log(int obj, int dir, int64_t loc, int org, int plen, int lim, int tlen, int use_clip, bool banded,
                                                         const AGParams &agp, AGResult a) {
-        AgCall *log = (AgCall *)rs_base + (obj == 0 ? 0u : rs_log_cap());
-        const uint32_t n = obj == 0 ? rs_n0 : rs_n1;
+        AgCall *log = (AgCall *)this->rs_base + (obj == 0 ? 0u : rs_log_cap());
+        const uint32_t n = obj == 0 ? this->rs_n0 : this->rs_n1;
         const uint32_t used = obj == 0 ? ag_obj_used0 : ag_obj_used1;
-        if (a.stale_reads > 0 && used && !rs_over) {
-            int16_t *rows = (int16_t *)(rs_base + 2 * (size_t)rs_log_cap() * sizeof(AgCall));
+        if (a.stale_reads > 0 && used && !this->rs_over) {
+            int16_t *rows = (int16_t *)(this->rs_base + 2 * (size_t)rs_log_cap() * sizeof(AgCall));
             uint8_t *image = (uint8_t *)rows + (((size_t)ag_lds_bytes(cfg.RL) + 255) & ~(size_t)255);
             const uint32_t image_bytes = (uint32_t)ag_scratch_bytes(cfg.RL);
             uint8_t *other = image + ((image_bytes + 255u) & ~255u);
@@ -292,9 +297,9 @@ struct Aligner {
                 e.lim_flags = (uint16_t)((uint32_t)(lim & 0xff) | ((uint32_t)(dir ? 1 : 0) << 8) | ((uint32_t)(use_clip ? 1 : 0) << 9) | ((uint32_t)(banded ? 1 : 0) << 10));
                 log[n] = e;
             }
-            if (obj == 0) rs_n0 = n + 1; else rs_n1 = n + 1;
+            if (obj == 0) this->rs_n0 = n + 1; else this->rs_n1 = n + 1;
             WAVE_SYNC(); __threadfence_block();
-        } else rs_over = 1;                                     // (a longer list: later calls that leave the band are flagged for the replay as before)
+        } else this->rs_over = 1;                                     // (a longer list: later calls that leave the band are flagged for the replay as before)
         return a;
     }
 
@@ -1243,7 +1248,7 @@ struct Aligner {
     __device__ __forceinline__ void align_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         const uint64_t t_read0 = clk();
         ag_obj_used0 = ag_obj_used1 = 0;                                      // a newly constructed aligner for every read
-        if constexpr (RESOLVE) { rs_n0 = rs_n1 = 0; rs_over = 0; }
+        if constexpr (RESOLVE) { this->rs_n0 = this->rs_n1 = 0; this->rs_over = 0; }
         ag_calls_unit = 0;
         align_read_inner<false>(g_bases, g_quals, len);
         if (ag_calls_unit >= WAVE_PRIO_HEAVY_AFTER) wave_set_priority(0);
