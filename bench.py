@@ -5,8 +5,15 @@ One "step" = one pass of BaseAligner::AlignRead (reference defaults, -d 8, seed 
 of synthetic 150 bp reads whose bytes already sit in HBM when the clock starts; results stay in
 HBM.  Workload = BASELINE.json configs[1] ("1M synthetic 150 bp single-end reads vs GRCh38,
 seed=20, maxDist=8, 1xMI355X") with GRCh38 replaced by the seeded synthetic genome BASELINE.md
-prescribes when GRCh38 is unavailable (no network here): --genome-mb (default 256) Mb, 30 % of
-bases in planted repeat families (copy number 2-5000, 0-5 % divergence).
+prescribes when GRCh38 is unavailable (no network here): --genome-mb Mb (default: 3100 = GRCh38
+scale, a ~31 GB index built on the GPU in the reference's format and kept resident in HBM, when the
+device has >= 64 GB free; 256 otherwise, and the line says so), 30 % of bases in planted repeat
+families (copy number 2-5000, 0-5 % divergence).
+
+The default one-GPU run adds two short legs to the same JSON line (skip with --no-extra-legs):
+  paired       configs[2] (2x150 bp pairs through the paired-end path) over the SAME resident
+               index: value, ms_per_step, parity_check and cpu_baseline of its own
+  genome_256mb the single-end line on the 256 Mb stand-in of rounds 1-3, for continuity
 
 N > 1: one process per GPU (torch.distributed.run), reads sharded (each rank aligns its own
 --reads reads: weak scaling), no data-path collective; the index is read by rank 0 and
@@ -33,11 +40,26 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md "Chip-level parameters")
 
 
+_T_PROCESS = time.time()
+
+
 def log(*a):
-    print("[bench]", *a, file=sys.stderr, flush=True)
+    print("[bench +%.1fs]" % (time.time() - _T_PROCESS), *a, file=sys.stderr, flush=True)
 
 
-def ensure_index(args, rank, device=0):
+def kernel_source_hash():
+    """sha256 over the device sources (snap_amd/csrc/*.h, *.hip; not host/), first 16 hex digits: what a committed PMC summary must carry
+    for bench.py to replay its counters next to this build's timings (scripts/pmc_collect.py writes it)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "snap_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip")):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def ensure_index(args, rank, device=0, multi=False):
     """Genome + SNAP index directory under /tmp, built once per box.  The directory is in the reference's on-disk format either way:
     --indexer gpu (default) builds it with this repo's GPU index builder (include/snapgpu.h: snapgpu_index_build_from_fasta; parity with
     the reference's builder: tests/test_zx_gpu_index_build.py) and ALSO returns the index still resident in HBM, so a one-GPU run aligns
@@ -52,7 +74,10 @@ def ensure_index(args, rank, device=0):
                                repeat_frac=0.30, max_copies=5000, repeat_len=(200, 3000), max_divergence=0.05)
     log("genome %d Mb generated in %.1fs" % (args.genome_mb, time.time() - t0))
     built, info = None, {"indexer": args.indexer, "cached": os.path.exists(done)}
-    if rank == 0 and not os.path.exists(done):
+    # A one-GPU run whose directory is already there (an earlier run on this box) still BUILDS the index in HBM -- 9 s at 3.1 Gb against
+    # reading 31 GB of files back and copying them up -- and just does not save it again.
+    rebuild_in_hbm = os.path.exists(done) and args.indexer == "gpu" and not multi
+    if rank == 0 and (not os.path.exists(done) or rebuild_in_hbm):
         os.makedirs(work, exist_ok=True)
         fa = os.path.join(work, "ref.fa")
         t1 = time.time()
@@ -61,11 +86,11 @@ def ensure_index(args, rank, device=0):
         t1 = time.time()
         if args.indexer == "gpu":
             from snap_amd.index import build_index
-            stats, built = build_index(fa, os.path.join(work, "idx"), seed_len=args.seed_len, device=device, keep=True)
+            stats, built = build_index(fa, None if rebuild_in_hbm else os.path.join(work, "idx"), seed_len=args.seed_len, device=device, keep=True)
             info.update(stats)
             info["s_build_and_save"] = time.time() - t1
-            log("GPU index build + save: %.1fs (device %.0f ms: seeds %.0f, sort %.0f, runs %.0f, tables %.0f; FASTA read %.1fs)"
-                % (time.time() - t1, stats["ms_total_device"], stats["ms_keys"], stats["ms_sort"], stats["ms_runs"], stats["ms_tables"], stats["s_fasta"]))
+            log("GPU index build%s: %.1fs (device %.0f ms: seeds %.0f, sort %.0f, runs %.0f, tables %.0f; FASTA read %.1fs)"
+                % ("" if rebuild_in_hbm else " + save", time.time() - t1, stats["ms_total_device"], stats["ms_keys"], stats["ms_sort"], stats["ms_runs"], stats["ms_tables"], stats["s_fasta"]))
         else:
             from oracle import ref          # reference index builder == the cpu_baseline's own set-up step
             ref.build_index(fa, os.path.join(work, "idx"), args.seed_len, threads=os.cpu_count() or 8)
@@ -108,18 +133,21 @@ def algorithmic_bytes(c, read_len, n_reads, ref_walk_slots=None):
                                     probe_basis="reference slot walk, counted" if ref_walk_slots is not None else "the kernel's own table layout")
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=0, help="timed steps (0 = auto: 6, a multiple of the feeders)")
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--genome-mb", type=int, default=256)
+    ap.add_argument("--genome-mb", type=int, default=0,
+                    help="synthetic genome size in Mb; 0 = auto: 3100 (GRCh38 scale, ~31 GB index in HBM) when the device has >= 64 GB free and the "
+                         "host >= 48 GB available, else the 256 Mb stand-in")
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--seed-len", type=int, default=20)
     ap.add_argument("--max-k", type=int, default=8)
     ap.add_argument("--seed", type=int, default=20260925)
-    ap.add_argument("--cpu-sample", type=int, default=0, help="reads for the CPU baseline (0 = auto, ~10-30 s)")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="reads (pairs) for the CPU baseline (0 = auto: >= 15 s of reference work, over as many of the rotated batches as that takes)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target seconds of reference work for the CPU baseline when --cpu-sample is 0")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): every GPU aligns --reads reads per step; strong: --reads is the whole job's batch, split evenly over the GPUs")
     ap.add_argument("--feeders", type=int, default=0,
@@ -139,77 +167,102 @@ def main():
     ap.add_argument("--workdir", default=os.environ.get("SNAP_BENCH_DIR", "/tmp/snap_bench"))
     ap.add_argument("--workload", choices=["single", "paired"], default="single",
                     help="single = configs[1] (the metric's config); paired = configs[2], 2x150 bp FR pairs through the paired-end path")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="one GPU, --workload single only: do not add the short paired-end leg (`paired`) and the 256 Mb leg (`genome_256mb`)")
+    ap.add_argument("--paired-leg-steps", type=int, default=3, help="timed steps of the extra paired-end leg")
+    ap.add_argument("--standin-mb", type=int, default=256, help="genome size of the extra `genome_256mb` leg (tests shrink it)")
+    args = ap.parse_args(argv)
     if args.steps <= 0:
         args.steps = 6
+    return args
 
-    # stdout carries exactly ONE JSON line: anything libraries print to fd 1 (RCCL prints a version
-    # banner there) is sent to stderr instead; the JSON goes to the saved descriptor at the end.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
 
+class Bed:
+    """One genome's set-up, shared by the legs that run over it: the synthetic genome, the index directory (the reference's format), the
+    index resident in HBM and the context that owns it (`owner`; every other context of a leg is a replica over the same blobs)."""
+    pass
+
+
+def make_bed(args, env, paired_owner):
+    import torch
+    from snap_amd import abi
+    from snap_amd import dist as sd
+    from snap_amd.aligner import BaseAligner, ChimericPairedEndAligner
+    from snap_amd.index import GenomeIndex
+    rank, world, local_rank, dev = env["rank"], env["world"], env["local_rank"], env["dev"]
+    bed = Bed()
+    bed.args = args
+    bed.pparams = abi.default_paired_params()
+    cls = ChimericPairedEndAligner if paired_owner else BaseAligner
+    # The index directory is built BEFORE the process group exists: a build can take minutes at GRCh38 scale, and a rank that sits in
+    # a collective that long runs into the NCCL watchdog.  Ranks other than 0 wait for the directory's last file on the file system.
+    bed.genome, bed.idx_dir, built, bed.index_info = ensure_index(args, rank, local_rank, multi=world > 1 or env["force_dist"])
+    while rank != 0 and not os.path.exists(os.path.join(bed.idx_dir, "GenomeIndex")):
+        time.sleep(1.0)
+    if (world > 1 or env["force_dist"]) and env.get("dist") is None:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env["dist"] = sd.init_process_group("nccl")
+        env["dist"].barrier()
+    dist = env.get("dist")
+    bed.params = abi.default_params(max_k=args.max_k, max_read_len=((args.read_len + 15) // 16) * 16)
+    t0 = time.time()
+    index = None
+    if dist is None and built is not None:      # the index this process has just built is still in HBM: adopt it, no file is read back
+        bed.owner = cls.from_built_index(built, None, bed.params, device=local_rank, paired_params=bed.pparams if paired_owner else None)
+        bed.keep = built
+        bed.index_bytes = int(bed.index_info["hash_blob_bytes"] + 4 * bed.index_info["overflow_table_size"] + bed.index_info["n_bases"] + 2048)
+    elif dist is None:
+        index = GenomeIndex.load_from_directory(bed.idx_dir)
+        bed.owner = cls(index, bed.params, bed.pparams, device=local_rank) if paired_owner else cls(index, bed.params, device=local_rank)
+        bed.keep = None
+    else:
+        if built is not None:
+            built.close(); built = None
+        index = GenomeIndex.load_from_directory(bed.idx_dir) if rank == 0 else None
+        index, blobs = sd.broadcast_index(index, dev)          # RCCL broadcast HBM -> HBM
+        bed.keep = blobs
+        ptrs = (blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr())
+        bed.owner = (cls(index, bed.params, bed.pparams, device=local_rank, device_index_ptrs=ptrs) if paired_owner
+                     else cls(index, bed.params, device=local_rank, device_index_ptrs=ptrs))
+    if index is not None:
+        hb_, ow_, gb_ = getattr(index, "_device_sizes", (index.hash_blob.size, index.overflow.size, index.genome_padded.size))
+        bed.index_bytes = int(hb_) + 4 * int(ow_) + int(gb_)
+    log("rank %d: %d Mb genome, index (%.1f GB) resident in HBM after %.1fs" % (rank, args.genome_mb, bed.index_bytes / 1e9, time.time() - t0))
+    return bed
+
+
+def close_bed(bed):
+    import torch
+    bed.owner.close()
+    keep = bed.keep
+    bed.keep = None
+    if keep is not None and hasattr(keep, "close"):
+        keep.close()
+    del keep
+    bed.genome = None
+    bed.ref_index = None
+    torch.cuda.empty_cache()
+
+
+def run_leg(args, env, bed, workload, primary):
+    """One leg = warm-up + exactly args.steps timed steps of `workload` over `bed`, then (rank 0) the untimed diagnostics, the CPU baseline
+    and the parity check.  Returns the JSON object on rank 0, None elsewhere."""
     import torch
     from snap_amd import abi, synth
     from snap_amd import dist as sd
     from snap_amd.aligner import BaseAligner, ChimericPairedEndAligner
-    from snap_amd.index import GenomeIndex
-    paired = args.workload == "paired"
-    pparams = abi.default_paired_params()
+    rank, world, local_rank, dev, dist = env["rank"], env["world"], env["local_rank"], env["dev"], env.get("dist")
+    paired = workload == "paired"
+    params, pparams, genome, idx_dir, index_info, index_bytes = bed.params, bed.pparams, bed.genome, bed.idx_dir, bed.index_info, bed.index_bytes
+    owner_is_paired = isinstance(bed.owner, ChimericPairedEndAligner)
 
-    def make_aligner(index, params, **kw):
-        return ChimericPairedEndAligner(index, params, pparams, **kw) if paired else BaseAligner(index, params, **kw)
-
-    rank, world, local_rank = sd.env_rank_world()
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
-    if args.scaling == "strong":        # the whole job's batch split over the ranks (each rank still draws its own reads: they are i.i.d.)
-        args.reads = max(2, (args.reads // max(1, world)) & ~1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    force_dist = os.environ.get("SNAP_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ   # exercise the RCCL path on one GPU
-
-    # ---------------------------------------------------------------- set-up (untimed)
-    # The index directory is built BEFORE the process group exists: a build can take minutes at GRCh38 scale, and a rank that sits in
-    # a collective that long runs into the NCCL watchdog.  Ranks other than 0 wait for the directory's last file on the file system.
-    genome, idx_dir, built, index_info = ensure_index(args, rank, local_rank)
-    while rank != 0 and not os.path.exists(os.path.join(idx_dir, "GenomeIndex")):
-        time.sleep(1.0)
-    if world > 1 or force_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist = sd.init_process_group("nccl")
-        dist.barrier()
-    params = abi.default_params(max_k=args.max_k, max_read_len=((args.read_len + 15) // 16) * 16)
-    t0 = time.time()
-    if dist is None and built is not None:      # the index this process has just built is still in HBM: adopt it, no file is read back
-        index = None
-        cls = ChimericPairedEndAligner if paired else BaseAligner
-        aligner = cls.from_built_index(built, None, params, device=local_rank, paired_params=pparams if paired else None)
-        keep = built
-        index_bytes = int(index_info["hash_blob_bytes"] + 4 * index_info["overflow_table_size"] + index_info["n_bases"] + 2048)
-    elif dist is None:
-        index = GenomeIndex.load_from_directory(idx_dir)
-        aligner = make_aligner(index, params, device=local_rank)
-        keep = None
-    else:
-        if built is not None:
-            built.close(); built = None
-        index = GenomeIndex.load_from_directory(idx_dir) if rank == 0 else None
-        index, blobs = sd.broadcast_index(index, dev)          # RCCL broadcast HBM -> HBM
-        keep = blobs
-        aligner = make_aligner(index, params, device=local_rank,
-                               device_index_ptrs=(blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr()))
-    if index is not None:
-        hb_, ow_, gb_ = getattr(index, "_device_sizes", (index.hash_blob.size, index.overflow.size, index.genome_padded.size))
-        index_bytes = int(hb_) + 4 * int(ow_) + int(gb_)
-    log("rank %d: index resident in HBM after %.1fs" % (rank, time.time() - t0))
+    def new_context():
+        if paired and not owner_is_paired:
+            return ChimericPairedEndAligner.over(bed.owner, pparams)
+        return bed.owner.replica()
 
     # --batches DISTINCT read batches rotate through the timed steps (step k aligns batch k mod B), so that no step finds the previous
-    # step's probes / reference windows in L2 or MALL by construction.  Batch 0 is the one the parity check and the CPU baseline use.
+    # step's probes / reference windows in L2 or MALL by construction.  Batch 0 is the first one the parity check and the CPU baseline use.
     n_batches = max(1, min(args.batches, args.steps))
 
     def make_batch(b):
@@ -220,7 +273,7 @@ def main():
         return synth.make_reads(sd_, genome, args.reads, args.read_len)   # 1% sub, .05% ins/del, 50% RC, Q20-40
     t0 = time.time()
     batches = [make_batch(b) for b in range(n_batches)]
-    log("%d read batch(es) generated in %.1fs" % (n_batches, time.time() - t0))
+    log("%s: %d read batch(es) generated in %.1fs" % (workload, n_batches, time.time() - t0))
     reads = batches[0]
     n = args.reads                      # reads per GPU per step (a pair is two reads)
     n_units = n // 2 if paired else n   # alignment problems per launch
@@ -234,7 +287,9 @@ def main():
     # the hot path over one batch, and exactly --steps of them are inside the timed region.
     n_feed = args.feeders if args.feeders > 0 else 3
     n_feed = max(1, min(n_feed, max(1, args.steps)))
-    feeders = [aligner] + [aligner.replica() for _ in range(n_feed - 1)]
+    own_first = paired == owner_is_paired           # the bed's owner is itself a context of this leg's kind
+    feeders = ([bed.owner] if own_first else []) + [new_context() for _ in range(n_feed - (1 if own_first else 0))]
+    aligner = feeders[0]
     d_prims = [torch.zeros(n_units * res_dtype.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_feed)]
     d_prim = d_prims[0]
     torch.cuda.synchronize()
@@ -280,6 +335,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     if dist is not None:
         elapsed = sd.max_over_ranks(elapsed, dev)
+    log("%s: %d timed steps in %.2fs" % (workload, args.steps, elapsed))
 
     counters = {}
     kernel_ms, launches = 0.0, 0
@@ -296,18 +352,33 @@ def main():
     for d_other in d_prims[1:]:
         if not torch.equal(d_other, d_prim):
             raise SystemExit("bench.py: two feeders disagree on the same batch")
+
+    def close_leg():
+        for a_ in feeders:
+            if a_ is not bed.owner:
+                a_.close()
     if rank != 0:
-        return
+        close_leg()
+        return None
+
+    def gpu_results_of_batch(b):          # untimed: the timed kernel's answer for batch b (parity check over more than batch 0)
+        if b == 0:
+            return prim
+        db, dq, do = d_batches[b]
+        aligner.align_device(n_units, db.data_ptr(), dq.data_ptr(), do.data_ptr(), d_prims[0].data_ptr())
+        torch.cuda.synchronize()
+        return np.frombuffer(d_prims[0].cpu().numpy().tobytes(), dtype=res_dtype)
 
     # ---------------------------------------------------------------- the reference's slot walk, counted (the numerator SURVEY.md 8(d) defines)
     # The timed contexts probe the device-native bucket tables (one 64-byte line per strand); the ALGORITHMIC bytes of a lookup are those of
     # the reference's walk over its own slot arrays (8 B per slot examined).  One untimed launch per distinct batch on a context that keeps
     # the reference layout (SNAPGPU_NO_BUCKETS=1) counts exactly those slots for exactly these reads.
     ref_walk_slots = None
+    walker = None
     if not args.skip_refwalk:
         os.environ["SNAPGPU_NO_BUCKETS"] = "1"
         try:
-            walker = aligner.replica()
+            walker = new_context()
         finally:
             del os.environ["SNAPGPU_NO_BUCKETS"]
         walker.counters(reset=True)
@@ -315,7 +386,6 @@ def main():
             walker.align_device(n_units, db.data_ptr(), dq.data_ptr(), do.data_ptr(), d_prims[0].data_ptr())
         wc = walker.counters(reset=True)
         ref_walk_slots = wc["n_hash_slots_probed"] / len(d_batches)
-        walker.close()
     # ---------------------------------------------------------------- where the wave cycles go: one launch of the instantiation that carries the phase timers
     breakdown = None
     if not args.skip_breakdown and not paired:
@@ -340,8 +410,11 @@ def main():
         timed.close()
 
     # ---------------------------------------------------------------- the index-probe kernel on its own (north_star: HBM roofline of the probe)
-    # k_lookup_seeds over >= 10^7 seeds drawn from the bench reads (every 13th offset of every read), hit lists read as BaseAligner
-    # consumes them (at most -h 300 per direction) but not stored; timed with hipEvents on the launch stream inside libsnapgpu.so.
+    # k_lookup_seeds -- the lookupSeed32 entry of the C ABI, NOT a stage of AlignRead (the align kernel probes inline) -- over >= 10^7 seeds
+    # drawn from the bench reads (every 13th offset of every read), hit lists read as BaseAligner consumes them (at most -h 300 per
+    # direction) but not stored; timed with hipEvents on the launch stream inside libsnapgpu.so.  Numerator = the REFERENCE's slot walk for
+    # these seeds (8 B per slot its probe sequence examines, counted by the same kernel on a context that keeps the reference's table
+    # layout), as SURVEY.md 8(d) defines it; the 64-byte bucket lines the timed kernel actually reads are reported beside it.
     probe = None
     if not paired and not args.skip_probe:
         L, S = args.read_len, args.seed_len
@@ -358,18 +431,31 @@ def main():
         for _ in range(reps):
             aligner.lookup_device(n_seeds, d_seeds.data_ptr(), d_nh.data_ptr(), 0, 300)
         pc = aligner.counters(reset=True); pms, pl = aligner.kernel_time(reset=True)
-        pb = (8 * pc["n_hash_slots_probed"] + 4 * pc["n_overflow_lists"] + 4 * pc["n_hits_consumed"] + S * n_seeds * reps + 16 * n_seeds * reps) / reps
+        per_rep = {k_: v_ / reps for k_, v_ in pc.items()}
+        lists_hits_io = 4 * per_rep["n_overflow_lists"] + 4 * per_rep["n_hits_consumed"] + S * n_seeds + 16 * n_seeds
+        layout_bytes = 8 * per_rep["n_hash_slots_probed"] + lists_hits_io          # 8 x 8 B = the 64-byte bucket line per strand
+        ref_slots = None
+        if walker is not None:
+            walker.counters(reset=True)
+            walker.lookup_device(n_seeds, d_seeds.data_ptr(), d_nh.data_ptr(), 0, 300)
+            ref_slots = walker.counters(reset=True)["n_hash_slots_probed"]
+        pb = (8 * ref_slots + lists_hits_io) if ref_slots is not None else layout_bytes
         pavg = pms / max(1, pl)
-        probe = {"kernel": "k_lookup_seeds", "seeds_per_launch": n_seeds, "avg_launch_ms": pavg, "lookups_per_s": n_seeds / (pavg * 1e-3),
+        probe = {"kernel": "k_lookup_seeds (the C ABI's lookupSeed32 entry; not a stage of AlignRead, which probes inline)",
+                 "seeds_per_launch": n_seeds, "avg_launch_ms": pavg, "lookups_per_s": n_seeds / (pavg * 1e-3),
                  "algorithmic_bytes_per_launch": pb, "achieved": pb / (pavg * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": pb / (pavg * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "slots_per_lookup": pc["n_hash_slots_probed"] / max(1, pc["n_hash_table_lookups"]),
-                 "hits_per_lookup": pc["n_hits_consumed"] / max(1, pc["n_hash_table_lookups"]),
+                 "numerator_basis": "reference slot walk, counted (8 B per slot examined)" if ref_slots is not None else "the kernel's own table layout (64-byte bucket lines)",
+                 "bucket_line_bytes_per_launch": layout_bytes, "frac_bucket_lines": layout_bytes / (pavg * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "ref_slots_per_lookup": (ref_slots / max(1, per_rep["n_hash_table_lookups"])) if ref_slots is not None else None,
+                 "hits_per_lookup": per_rep["n_hits_consumed"] / max(1, per_rep["n_hash_table_lookups"]),
                  # the sector-level figure SURVEY.md 8(d) asks for next to the algorithmic one: every slot walk touches whole 64 B lines.
                  # Lower bound on lines: one per direction for the walk + one per 16 hits read + one for the seed text / counts
-                 "min_64B_lines_per_lookup": 2 + pc["n_hits_consumed"] / max(1, pc["n_hash_table_lookups"]) / 16 + pc["n_overflow_lists"] / max(1, pc["n_hash_table_lookups"]),
-                 "note": "algorithmic bytes = 8 B per slot examined + 4 B per overflow count word + 4 B per hit read + seed text in + hit counts out"}
+                 "min_64B_lines_per_lookup": 2 + per_rep["n_hits_consumed"] / max(1, per_rep["n_hash_table_lookups"]) / 16 + per_rep["n_overflow_lists"] / max(1, per_rep["n_hash_table_lookups"]),
+                 "note": "algorithmic bytes = 8 B per slot the reference's walk examines + 4 B per overflow count word + 4 B per hit read + seed text in + hit counts out"}
         del d_seeds, d_nh
+    if walker is not None:
+        walker.close()
 
     # ---------------------------------------------------------------- report (rank 0)
     total_reads = n * world * args.steps
@@ -380,19 +466,22 @@ def main():
     # (with several feeders the launches overlap, so each one's hipEvent time is longer than its share of the chip: the rate is then
     #  taken over the step time, bytes of one batch / (elapsed / steps))
     achieved = alg_bytes / ((avg_ms if n_feed == 1 else 1e3 * elapsed / args.steps) * 1e-3) / 1e9
+    genome_desc = ("seeded synthetic %d Mb genome with 30%% planted repeats (GRCh38 scale: GRCh38 itself is unavailable here)" % args.genome_mb if args.genome_mb >= 3000
+                   else "seeded synthetic %d Mb genome with 30%% planted repeats (stand-in: %s)" % (args.genome_mb, env.get("genome_choice", "--genome-mb")))
     out = {
         "metric": "aligned reads/sec (whole node), 150 bp %s vs synthetic %d Mb genome (GRCh38 unavailable), seed=20, maxDist=%d"
                   % ("paired-end (2x150 FR pairs)" if paired else "single-end", args.genome_mb, args.max_k),
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8 bases / int32 DP / f64 match probability", "data": "synthetic",
-        "config": {"workload": ("configs[2]: %d pairs of 2 x %d bp (FR, insert N(%g,%g^2), long-indel fraction %g) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d (directory in the reference's format), genome = seeded synthetic %d Mb with 30%% planted repeats"
-                                % (n_units, args.read_len, args.insert_mean, args.insert_sd, args.long_indel_frac, args.max_k, args.seed_len, args.genome_mb)) if paired else
-                               ("configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d (directory in the reference's format), genome = seeded synthetic %d Mb with 30%% planted repeats"
-                                % (n, args.read_len, args.max_k, args.seed_len, args.genome_mb)),
+        "config": {"workload": ("configs[2]: %d pairs of 2 x %d bp (FR, insert N(%g,%g^2), long-indel fraction %g) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d (directory in the reference's format), genome = %s"
+                                % (n_units, args.read_len, args.insert_mean, args.insert_sd, args.long_indel_frac, args.max_k, args.seed_len, genome_desc)) if paired else
+                               ("configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d (directory in the reference's format), genome = %s"
+                                % (n, args.read_len, args.max_k, args.seed_len, genome_desc)),
+                   "genome_mb": args.genome_mb, "genome_choice": env.get("genome_choice", "--genome-mb"),
                    "reads_per_gpu": n, "read_len": args.read_len, "index_bytes_hbm": index_bytes,
                    "parallelism": "reads sharded over %d GPU(s), index replicated%s" % (world, " by RCCL broadcast" if world > 1 else ""),
-                   "feeders_per_gpu": n_feed, "index_build": index_info},
+                   "feeders_per_gpu": n_feed, "index_build": index_info, "kernel_source_hash": kernel_source_hash()},
         "roofline": {"kernel": "k_align_paired" if paired else "k_align_single", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "bytes_breakdown": parts, "avg_launch_ms": avg_ms,
@@ -435,63 +524,61 @@ def main():
                                               "evaluations_stored": counters.get("cycles_single_fallback", 0) >> 32,
                                               "refused_other_band_or_decision": (counters.get("cycles_single_fallback", 0) >> 16) & 0xffff,
                                               "refused_skipped_or_limit": counters.get("cycles_single_fallback", 0) & 0xffff}
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if os.path.exists(pmc):
-        try:
-            t = json.load(open(pmc))
-            if t.get("reads_per_launch") == n and t.get("genome_mb") == args.genome_mb and t.get("workload", "single") == args.workload:
-                # PMC counters need their own rocprofv3 --pmc passes (scripts/gpu_pmc_traffic.sh); what is reported here is REPLAYED from
-                # the committed summary of the last such pass and says which build / profile directory it came from
-                out["roofline"]["traffic"] = t.get("hbm_bytes_per_launch")
-                out["roofline"]["traffic_source"] = "replayed from profiles/pmc_latest.json (rocprofv3 --pmc pass '%s'), not measured in this run" % t.get("source", "?")
-                if t.get("valu_insts_per_launch"):
-                    # the LV / affine-gap work is integer VALU, not HBM.  Wave-level VALU instructions of one launch
-                    # (rocprofv3 --pmc SQ_INSTS_VALU, profiles/) over this run's launch time, against the issue peak of the chip:
-                    # 256 CUs x 4 SIMD32s, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: v_fma_f32 wave64 =
-                    # 2 cycles), 2.4 GHz  =>  256 * 4 * 2.4e9 / 2 = 1228.8 G wave-instructions/s
-                    peak = 256 * 4 * 2.4e9 / 2 / 1e9
-                    ach = t["valu_insts_per_launch"] / ((avg_ms if n_feed == 1 else 1e3 * elapsed / args.steps) * 1e-3) / 1e9
-                    out["roofline"]["valu_issue"] = {"achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
-                                                     "valu_insts_per_read": t["valu_insts_per_launch"] / n,
-                                                     "salu_insts_per_read": t.get("salu_insts_per_launch", 0) / n,
-                                                     "source": "instruction counts replayed from profiles/pmc_latest.json ('%s'); time per batch of this run" % t.get("source", "?")}
-        except Exception:
-            pass
+    attach_pmc(out, args, workload, n, n_feed, avg_ms, elapsed)
 
     if world == 1 and not args.skip_cpu:
         from oracle import ref                                       # cpu_baseline leg only
         cores = os.cpu_count() or 1
-        ri = ref.RefIndex(idx_dir)
-        L = args.read_len
+        t0 = time.time()
+        ri = getattr(bed, "ref_index", None)
+        if ri is None:
+            ri = bed.ref_index = ref.RefIndex(idx_dir)
+            log("%s: reference loaded the index directory in %.1fs" % (workload, time.time() - t0))
+        per_unit = 2 if paired else 1
+
+        def sample_arrays(k):          # the first k alignment problems of batches 0, 1, ... concatenated (reads of a pair stay together)
+            bs, qs, os_, base, left, b = [], [], [0], 0, k, 0
+            while left > 0:
+                bt = batches[b]
+                take = min(left, n_units)
+                ro = bt["offsets"].astype(np.int64)
+                end = int(ro[per_unit * take])
+                bs.append(bt["bases"].reshape(-1)[:end]); qs.append(bt["quals"].reshape(-1)[:end])
+                os_.append(ro[1:per_unit * take + 1] + base)
+                base += end; left -= take; b += 1
+            return (np.concatenate(bs), np.concatenate(qs), np.concatenate([np.asarray(o_, dtype=np.int64).reshape(-1) for o_ in os_]).astype(np.uint64))
 
         def run_ref(k):             # k = alignment problems (reads, or pairs)
+            sb, sq, so = sample_arrays(k)
             if paired:
-                return ri.align_paired(params, pparams, reads["bases"][:2 * k], reads["quals"][:2 * k], reads["offsets"][:2 * k + 1], threads=cores, stage=0)
-            return ri.align_single(params, reads["bases"][:k], reads["quals"][:k], reads["offsets"][:k + 1], threads=cores)
-        sample = args.cpu_sample or min(n_units, 50_000)
-        pr, _, _, secs = run_ref(sample)
-        if not args.cpu_sample:                                      # scale the sample to ~15 s of CPU work
+                return ri.align_paired(params, pparams, sb, sq, so, threads=cores, stage=0), (sb, sq, so)
+            return ri.align_single(params, sb, sq, so, threads=cores), (sb, sq, so)
+        cap = n_units * n_batches
+        sample = min(cap, args.cpu_sample or min(n_units, 50_000))
+        (pr, _, _, secs), arrs = run_ref(sample)
+        if not args.cpu_sample:                                      # scale the sample to >= --cpu-seconds of reference work (capped by the batches there are)
             rate = sample / secs
-            sample = int(min(n_units, max(sample, rate * 15)))
-            pr, _, _, secs = run_ref(sample)
-        per = 2 if paired else 1
-        out["cpu_baseline"] = {"value": per * sample / secs, "unit": "reads/s", "cores": cores, "kind": "reference",
-                               "sample": "first %d %s of the same batch, %s via oracle/_ref (SNAP 2.0.5 built -O3), %d threads, align phase only"
+            sample = int(min(cap, max(sample, rate * args.cpu_seconds * 1.1)))
+            (pr, _, _, secs), arrs = run_ref(sample)
+        log("%s: reference aligned %d %s in %.1fs" % (workload, sample, "pairs" if paired else "reads", secs))
+        out["cpu_baseline"] = {"value": per_unit * sample / secs, "unit": "reads/s", "cores": cores, "kind": "reference", "seconds": secs,
+                               "sample": "first %d %s of the rotated batches (batch 0 first), %s via oracle/_ref (SNAP 2.0.5 built -O3), %d threads, align phase only"
                                          % (sample, "pairs" if paired else "reads", "ChimericPairedEndAligner::align" if paired else "BaseAligner::AlignRead", cores)}
         # The baseline's results double as a parity check of the timed GPU output: EVERY unit of the sample is compared, none excluded.
         # The reads / pairs whose banded affine-gap traceback left the band (`reserved` != 0) were redone on the GPU the way a newly
         # constructed reference aligner does them (exact replay); for those the expectation is the reference run with fresh objects
         # (oracle/ref_driver.cpp: ZeroedArena), because the long-lived objects of the timed run answer such reads from their history.
-        flagged = (prim["reserved"][:sample] & 0x3fffffff) != 0         # any traceback step outside the band (superset of what was replayed)
-        replayed = ((prim["flags"][:sample] & 4) != 0) if paired else ((prim["reserved"][:sample] & 0x80000000) != 0)
+        gpu = np.concatenate([gpu_results_of_batch(b)[:min(n_units, sample - b * n_units)] for b in range((sample + n_units - 1) // n_units)])
+        sb, sq, so = arrs
+        flagged = (gpu["reserved"] & 0x3fffffff) != 0         # any traceback step outside the band (superset of what was replayed)
+        replayed = ((gpu["flags"] & 4) != 0) if paired else ((gpu["reserved"] & 0x80000000) != 0)
         fi = np.nonzero(flagged)[0]
         history_dependent = 0
         if fi.size:
-            per_unit = 2 if paired else 1
-            ro = reads["offsets"].astype(np.int64)
+            ro = so.astype(np.int64)
             sel = np.concatenate([np.arange(per_unit * i, per_unit * i + per_unit) for i in fi])
-            fb = np.concatenate([reads["bases"].reshape(-1)[ro[j]:ro[j + 1]] for j in sel])
-            fq = np.concatenate([reads["quals"].reshape(-1)[ro[j]:ro[j + 1]] for j in sel])
+            fb = np.concatenate([sb[ro[j]:ro[j + 1]] for j in sel])
+            fq = np.concatenate([sq[ro[j]:ro[j + 1]] for j in sel])
             fo = np.concatenate([[0], np.cumsum([ro[j + 1] - ro[j] for j in sel])]).astype(np.uint64)
             with ref.fresh_objects():
                 if paired:
@@ -508,17 +595,147 @@ def main():
             pr[fi] = fr
         if paired:
             from tests.pairs_util import compare_paired
-            bad = compare_paired(pr, prim[:sample], verbose=0)
+            bad = compare_paired(pr, gpu, verbose=0)
             out["parity_check"] = {"pairs": sample, "mismatching_pairs": int(bad.sum()), "excluded": 0, "exact_replayed": int(replayed.sum()), "left_the_band": int(flagged.sum()),
                                    "of_which_reference_history_dependent": history_dependent}
         else:
             from tests.util import compare_results
-            problems = compare_results(pr, prim[:sample])
+            problems = compare_results(pr, gpu)
             out["parity_check"] = {"reads": sample, "mismatching_fields": problems, "excluded": 0, "exact_replayed": int(replayed.sum()), "left_the_band": int(flagged.sum()),
                                    "of_which_reference_history_dependent": history_dependent}
-    os.write(json_fd, (json.dumps(out) + "\n").encode())
-    aligner.close()
-    del keep
+    close_leg()
+    del d_batches, d_prims
+    torch.cuda.empty_cache()
+    return out
+
+
+def attach_pmc(out, args, workload, n, n_feed, avg_ms, elapsed):
+    """roofline.traffic / roofline.valu_issue: PMC counters need their own rocprofv3 --pmc passes (scripts/pmc_collect.py); what is reported
+    here is REPLAYED from the committed summary of the last such pass -- and only when that summary was taken from THIS build's device
+    sources (kernel_source_hash), on this workload, genome size and feeder count; otherwise both stay null and the line says why."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(pmc):
+        return
+    try:
+        t = json.load(open(pmc))
+        ents = t.get("entries", [t])
+        want = kernel_source_hash()
+        for e in ents:
+            if e.get("workload", "single") != workload or e.get("reads_per_launch") != n or e.get("genome_mb") != args.genome_mb:
+                continue
+            if e.get("kernel_source_hash") != want:
+                out["roofline"]["traffic_source"] = ("profiles/pmc_latest.json has a pass for this workload, but of other device sources (%s, this build: %s): not replayed"
+                                                     % (e.get("kernel_source_hash", "no hash"), want))
+                continue
+            out["roofline"]["traffic"] = e.get("hbm_bytes_per_launch")
+            out["roofline"]["traffic_source"] = ("replayed from profiles/pmc_latest.json (rocprofv3 --pmc passes '%s' of this build's device sources, hash %s, %s feeder(s)), not measured in this run"
+                                                 % (e.get("source", "?"), want, e.get("feeders", "?")))
+            out["roofline"]["traffic_fetch_write_kb"] = [e.get("fetch_size_kb"), e.get("write_size_kb")]
+            if e.get("valu_insts_per_launch"):
+                # SURVEY.md 8(d): the LV / affine-gap work is integer VALU, not HBM.  Wave-level VALU instructions of one launch
+                # (rocprofv3 --pmc SQ_INSTS_VALU, profiles/) over this run's launch time, against the issue peak of the chip:
+                # 256 CUs x 4 SIMD32s, a wave64 VALU instruction issues over 2 cycles (MI355X_MICROARCH.md: v_fma_f32 wave64 =
+                # 2 cycles), 2.4 GHz  =>  256 * 4 * 2.4e9 / 2 = 1228.8 G wave-instructions/s
+                peak = 256 * 4 * 2.4e9 / 2 / 1e9
+                ach = e["valu_insts_per_launch"] / ((avg_ms if n_feed == 1 else 1e3 * elapsed / args.steps) * 1e-3) / 1e9
+                vi = {"achieved": ach, "peak": peak, "unit": "G wave-instructions/s", "frac": ach / peak,
+                      "valu_insts_per_read": e["valu_insts_per_launch"] / n, "salu_insts_per_read": e.get("salu_insts_per_launch", 0) / n,
+                      "source": "instruction counts replayed from profiles/pmc_latest.json ('%s'); time per batch of this run" % e.get("source", "?")}
+                if e.get("thread_cycles_valu") and e.get("valu_insts_per_launch"):
+                    # SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = lanes active per VALU instruction (x4 cycles per wave64 instruction on a SIMD16 pass)
+                    vi["active_lanes_per_valu_inst"] = e["thread_cycles_valu"] / e["valu_insts_per_launch"] / e.get("thread_cycles_per_lane_inst", 1.0)
+                if e.get("wave_cycles"):
+                    vi["active_fraction_of_wave_cycles"] = e.get("active_inst_any", 0) / e["wave_cycles"]
+                    vi["waiting_fraction_of_wave_cycles"] = e.get("wait_inst_any", 0) / e["wave_cycles"]
+                out["roofline"]["valu_issue"] = vi
+            if e.get("probe_fetch_size_kb") and "probe" in out["roofline"]:
+                out["roofline"]["probe"]["traffic"] = e["probe_fetch_size_kb"] * 1024.0
+                out["roofline"]["probe"]["traffic_source"] = "FETCH_SIZE of k_lookup_seeds, same passes"
+            break
+    except Exception as e_:          # noqa: BLE001 -- the replay is optional
+        out["roofline"]["traffic_source"] = "profiles/pmc_latest.json unreadable: %s" % e_
+
+
+def compact_leg(o):
+    """What an extra leg contributes to the line."""
+    keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step") if k in o}
+    keep["config"] = {k: o["config"][k] for k in ("workload", "genome_mb", "feeders_per_gpu", "index_bytes_hbm") if k in o["config"]}
+    r = o["roofline"]
+    keep["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_ms",
+                                          "achieved_basis", "per_read", "valu_issue", "phase4_help") if k in r}
+    for k in ("cpu_baseline", "parity_check", "aligned_fraction"):
+        if k in o:
+            keep[k] = o[k]
+    return keep
+
+
+def main():
+    args = parse_args()
+    # stdout carries exactly ONE JSON line: anything libraries print to fd 1 (RCCL prints a version
+    # banner there) is sent to stderr instead; the JSON goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    import copy
+    import torch
+    from snap_amd import dist as sd
+    rank, world, local_rank = sd.env_rank_world()
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU implementation")
+    if args.scaling == "strong":        # the whole job's batch split over the ranks (each rank still draws its own reads: they are i.i.d.)
+        args.reads = max(2, (args.reads // max(1, world)) & ~1)
+    torch.cuda.set_device(local_rank)
+    env = {"rank": rank, "world": world, "local_rank": local_rank, "dev": torch.device("cuda", local_rank), "dist": None,
+           "force_dist": os.environ.get("SNAP_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ}   # exercise the RCCL path on one GPU
+    if args.genome_mb <= 0:             # auto: the metric's scale where it fits (every MI355X: 288 GB), the stand-in elsewhere
+        free_b, _tot = torch.cuda.mem_get_info(local_rank)
+        try:
+            import psutil
+            host_avail = psutil.virtual_memory().available
+        except Exception:          # noqa: BLE001
+            host_avail = 1 << 62
+        # (host: each rank holds the 3.1 GB genome + its read batches; rank 0 also the FASTA text while it writes it)
+        fits = free_b >= 64e9 and host_avail >= 8e9 * world + 40e9
+        args.genome_mb = 3100 if fits else 256
+        env["genome_choice"] = ("auto: GRCh38 scale (device has %.0f GB free)" % (free_b / 1e9) if fits
+                                else "auto: the 256 Mb stand-in, because the device has %.0f GB free / the host %.0f GB available (3100 Mb needs 64 / 48)" % (free_b / 1e9, host_avail / 1e9))
+        log(env["genome_choice"])
+
+    # ---------------------------------------------------------------- the line's own leg
+    bed = make_bed(args, env, paired_owner=args.workload == "paired")
+    out = run_leg(args, env, bed, args.workload, primary=True)
+    extra = world == 1 and not env["force_dist"] and args.workload == "single" and not args.no_extra_legs
+    if extra and rank == 0:
+        # ---------------------------------------------------------------- configs[2] over the same resident index (so that C3 is in the driver's line)
+        try:
+            pa = copy.copy(args)
+            pa.steps, pa.warmup, pa.batches = max(1, args.paired_leg_steps), 1, min(args.batches, max(1, args.paired_leg_steps))
+            pa.skip_refwalk = pa.skip_breakdown = pa.skip_probe = True
+            pa.cpu_sample = 0
+            out["paired"] = compact_leg(run_leg(pa, env, bed, "paired", primary=False))
+        except BaseException as e_:          # noqa: BLE001 -- the line's own leg must survive a failing extra
+            out["paired"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+    close_bed(bed)
+    if extra and rank == 0 and args.genome_mb != args.standin_mb:
+        # ---------------------------------------------------------------- the 256 Mb stand-in of rounds 1-3, same command otherwise
+        try:
+            sa = copy.copy(args)
+            sa.genome_mb = args.standin_mb
+            sa.skip_breakdown = sa.skip_probe = True
+            sa.cpu_seconds = min(args.cpu_seconds, 5.0)
+            env2 = dict(env); env2["genome_choice"] = "the stand-in of rounds 1-3, kept for continuity"
+            bed2 = make_bed(sa, env2, paired_owner=False)
+            out["genome_256mb"] = compact_leg(run_leg(sa, env2, bed2, "single", primary=False))
+            close_bed(bed2)
+        except BaseException as e_:          # noqa: BLE001
+            out["genome_256mb"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+    if rank == 0:
+        out["bench_wall_s"] = time.time() - _T_PROCESS
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

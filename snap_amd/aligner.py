@@ -454,6 +454,20 @@ class ChimericPairedEndAligner(BaseAligner):
     def _after_replica(self):               # (a replica starts as a single-end context)
         self._check(self.lib.snapgpu_enable_paired(self.handle, C.byref(self.paired_params)), "snapgpu_enable_paired")
 
+    @classmethod
+    def over(cls, base: "BaseAligner", paired_params=None):
+        """A paired-end context over the index another context (single-end or paired) already has resident on its GPU:
+        snapgpu_create_replica(share_index = 1) + snapgpu_enable_paired.  `base` must outlive it (it owns the blobs)."""
+        from .abi import PairedParams, default_paired_params
+        proto = cls.__new__(cls)
+        proto.__dict__.update(base.__dict__)
+        proto.paired_params = paired_params if paired_params is not None else default_paired_params()
+        proto.lib.snapgpu_enable_paired.argtypes = [C.c_void_p, C.POINTER(PairedParams)]
+        proto.lib.snapgpu_align_paired_device.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
+        other = BaseAligner.replica(proto)
+        proto.handle = None                 # (the prototype borrowed base's handle: it must not destroy it)
+        return other
+
     def _after_built(self, paired_params):
         from .abi import PairedParams, default_paired_params
         self.paired_params = paired_params if paired_params is not None else default_paired_params()
