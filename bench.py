@@ -155,7 +155,7 @@ def parse_args(argv=None):
                          "batches overlap on the GPU (what snapgpu-sam's feeder threads do).  0 = auto: 3 "
                          "(a launch ends with a tail of few, heavy reads / pairs that leaves most of the chip idle: measured, profiles/r02i, "
                          "1 -> 2 feeders: 4.20 -> 6.28 M reads/s single-end; 1 / 2 / 3 / 4 feeders: 119 / 174 / 210 / 189 k reads/s paired-end)")
-    ap.add_argument("--batches", type=int, default=4, help="distinct read batches rotated through the timed steps")
+    ap.add_argument("--batches", type=int, default=6, help="distinct read batches rotated through the timed steps")
     ap.add_argument("--insert-mean", type=float, default=400.0, help="paired: insert size mean (C3: 400; C5 as SURVEY.md 8(d) defines it: 600)")
     ap.add_argument("--insert-sd", type=float, default=50.0, help="paired: insert size s.d. (C3: 50; C5: 80)")
     ap.add_argument("--long-indel-frac", type=float, default=0.0, help="paired: fraction of reads with one extra indel event of length 1-10 (C5: 0.002)")
@@ -272,7 +272,9 @@ def run_leg(args, env, bed, workload, primary):
                                     long_indel_frac=args.long_indel_frac)
         return synth.make_reads(sd_, genome, args.reads, args.read_len)   # 1% sub, .05% ins/del, 50% RC, Q20-40
     t0 = time.time()
-    batches = [make_batch(b) for b in range(n_batches)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=n_batches) as ex:          # (numpy releases the GIL in the large operations: the batches are drawn side by side)
+        batches = list(ex.map(make_batch, range(n_batches)))
     log("%s: %d read batch(es) generated in %.1fs" % (workload, n_batches, time.time() - t0))
     reads = batches[0]
     n = args.reads                      # reads per GPU per step (a pair is two reads)
@@ -556,10 +558,12 @@ def run_leg(args, env, bed, workload, primary):
         cap = n_units * n_batches
         sample = min(cap, args.cpu_sample or min(n_units, 50_000))
         (pr, _, _, secs), arrs = run_ref(sample)
-        if not args.cpu_sample:                                      # scale the sample to >= --cpu-seconds of reference work (capped by the batches there are)
-            rate = sample / secs
-            sample = int(min(cap, max(sample, rate * args.cpu_seconds * 1.1)))
-            (pr, _, _, secs), arrs = run_ref(sample)
+        if not args.cpu_sample:         # grow the sample until it is >= --cpu-seconds of reference work (a small first sample under-estimates the
+            for _ in range(3):          # rate: 256 threads each construct their aligner first), capped by the distinct batches there are
+                if secs >= 0.9 * args.cpu_seconds or sample >= cap:
+                    break
+                sample = int(min(cap, max(2 * sample, sample / secs * args.cpu_seconds * 1.15)))
+                (pr, _, _, secs), arrs = run_ref(sample)
         log("%s: reference aligned %d %s in %.1fs" % (workload, sample, "pairs" if paired else "reads", secs))
         out["cpu_baseline"] = {"value": per_unit * sample / secs, "unit": "reads/s", "cores": cores, "kind": "reference", "seconds": secs,
                                "sample": "first %d %s of the rotated batches (batch 0 first), %s via oracle/_ref (SNAP 2.0.5 built -O3), %d threads, align phase only"
@@ -644,6 +648,13 @@ def attach_pmc(out, args, workload, n, n_feed, avg_ms, elapsed):
                 if e.get("thread_cycles_valu") and e.get("valu_insts_per_launch"):
                     # SQ_THREAD_CYCLES_VALU / SQ_INSTS_VALU = lanes active per VALU instruction (x4 cycles per wave64 instruction on a SIMD16 pass)
                     vi["active_lanes_per_valu_inst"] = e["thread_cycles_valu"] / e["valu_insts_per_launch"] / e.get("thread_cycles_per_lane_inst", 1.0)
+                if e.get("active_inst_valu"):
+                    # SQ_ACTIVE_INST_VALU counts quad-cycles (MI355X_MICROARCH.md) and comes out at 1.0 per VALU instruction of this kernel:
+                    # a wave64 integer VALU instruction keeps its SIMD's VALU busy for 4 cycles.  Busy fraction of the chip's 1 024 SIMDs
+                    # over this run's time per batch, at the 2.4 GHz peak clock (a lower sustained clock makes the true figure higher)
+                    t_batch = (avg_ms if n_feed == 1 else 1e3 * elapsed / args.steps) * 1e-3
+                    vi["valu_busy_frac_at_2p4GHz"] = e["active_inst_valu"] * 4.0 / (256 * 4 * 2.4e9 * t_batch)
+                    vi["quad_cycles_per_valu_inst"] = e["active_inst_valu"] / e["valu_insts_per_launch"]
                 if e.get("wave_cycles"):
                     vi["active_fraction_of_wave_cycles"] = e.get("active_inst_any", 0) / e["wave_cycles"]
                     vi["waiting_fraction_of_wave_cycles"] = e.get("wait_inst_any", 0) / e["wave_cycles"]
