@@ -346,6 +346,10 @@ int  snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
  *        and clipping_for_read_adjustment set when that alignment began with an indel; status = NotFound, location =
  *        InvalidGenomeLocation32 when moving it would leave the contig (:139-148).  NotFound results are left alone.
  * Host pointers; the genome is the one resident on the device.  Returns SNAPGPU_OK or a negative error.
+ * LIMITATION: the read is taken as one the reader has NOT clipped.  The reference settles a contig-end overhang on the start of the UNCLIPPED
+ * buffer (AlignmentAdjuster.cpp:167), which differs from the clipped start for an RC result of a back-clipped read and for a forward result
+ * of a front-clipped one; this interface is not given the unclipped bytes.  The callers that ship with the library (shim/, snapgpu-sam)
+ * therefore refuse -ae for a read the reader actually clipped (run them with -C--).
  */
 int  snapgpu_adjust_alignments(snapgpu_ctx *ctx, uint32_t n, const char *data, uint64_t data_bytes, const uint64_t *off, const int32_t *len,
                                snapgpu_single_result *results);

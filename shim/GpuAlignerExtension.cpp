@@ -64,7 +64,7 @@ static void toSnapPaired(const snapgpu_paired_result &g, PairedAlignmentResult *
         r->status[i] = (AlignmentResult)g.status[i];
         r->direction[i] = g.direction[i];
         r->location[i] = toSnapLocation(g.location[i]);
-        r->origLocation[i] = GenomeLocation(g.orig_location[i]);
+        r->origLocation[i] = toSnapLocation(g.orig_location[i]);      // (an Invalid32 must become the index's own InvalidGenomeLocation with 5 .. 8-byte locations too)
         r->score[i] = g.score[i];
         r->scorePriorToClipping[i] = g.score_prior_to_clipping[i];
         r->mapq[i] = g.mapq[i];
@@ -92,7 +92,7 @@ static void toSnap(const snapgpu_single_result &g, SingleAlignmentResult *r)
     r->status = (AlignmentResult)g.status;
     r->direction = g.direction;
     r->location = toSnapLocation(g.location);
-    r->origLocation = GenomeLocation(g.orig_location);
+    r->origLocation = toSnapLocation(g.orig_location);
     r->score = g.score;
     r->scorePriorToClipping = g.score_prior_to_clipping;
     r->mapq = g.mapq;
@@ -353,6 +353,13 @@ public:
                         c->stats->uselessReads++;
                     }
                     continue;
+                }
+                // -ae: the device adjuster is restated for a Read the reader has not clipped (snap_amd/csrc/adjust.h: the reference settles a
+                // contig-end overhang on the UNCLIPPED buffer, AlignmentAdjuster.cpp:167, which the C ABI is not given).  A read that
+                // actually got clipped under -ae is refused rather than answered differently; -C-- switches the reader's clipping off.
+                if (!c->ignoreAlignmentAdjustmentForOm && read->getDataLength() != read->getUnclippedLength()) {
+                    WriteErrorMessage("snapgpu shim: -ae with a quality-clipped read (%.*s) is not supported: run with -C--\n", (int)read->getIdLength(), read->getId());
+                    soft_exit(1);
                 }
                 new (&reads[n]) ReadWithOwnMemory(*read);
                 bases.insert(bases.end(), read->getData(), read->getData() + read->getDataLength());

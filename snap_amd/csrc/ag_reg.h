@@ -29,13 +29,18 @@
 
 #define AG_NEG (-(1 << 29))
 #define AG_BIG (1 << 17)
+#define AG_HUGE (1 << 28)
+// lane L gets src[L-1]; lane 0 gets 0 (bound_ctrl): foldable into the consumer, no `old` register to set up
+static __device__ __forceinline__ int ag_shr1z(int src) {
+    return __builtin_amdgcn_update_dpp(0, src, 0x138, 0xF, 0xF, true);   // wave_shr:1 bound_ctrl:1
+}
 
 template <int CTRL, int ROW_MASK>
 static __device__ __forceinline__ int ag_dpp_max(int v) {
-    // old == v: lanes without a source keep their own value, for which max() is the identity; this
-    // is also the shape LLVM's DPP combiner folds into a single v_max_i32_dpp (no constant to
-    // materialise, one hazard nop instead of two)
-    int t = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+    // old == INT_MIN, the identity of max: lanes without a source (or rows the mask leaves out) get it, so the result there is v -- and
+    // this is the shape LLVM's DPP combiner folds into ONE v_max_i32_dpp.  (With old == v, as this read until round 4, every step came out
+    // as v_mov + v_mov_dpp + v_max: 18 VALU instructions for the row maximum instead of 6.)
+    int t = __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, ROW_MASK, 0xF, false);
     return t > v ? t : v;
 }
 // inclusive prefix max over the 64 lanes (GFX9 DPP scan)
@@ -129,6 +134,9 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     const int pe_glob = pattern_len - 1, pe_glob_c = pe_glob >> 6, pe_glob_l = pe_glob & 63;
 
     for (int i = 0; i < text_len; i++) {
+#if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
+        { extern unsigned long long g_agwin_stats[64]; if (lane == 0) { __atomic_fetch_add(&g_agwin_stats[32 + (BANDED ? 1 : 0) * 4 + (AGC > 3 ? 3 : AGC)], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_agwin_stats[40 + (BANDED ? 1 : 0)], (unsigned long long)(num_seg * seg_len), __ATOMIC_RELAXED); } }
+#endif
         const int tb = (int)first_u32(tcode[i]);
         int band_beg = 0, band_end = pattern_len - 1;
         if (BANDED) {
@@ -266,6 +274,9 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
                         btr[c] |= (upd && cont[c]) ? 32 : 0;
                     }
                 }
+#if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
+                { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[48 + (BANDED ? 8 : 0) + r], 1, __ATOMIC_RELAXED); }
+#endif
                 if (!round_complete) break;
             }
             fin = BANDED ? X0 : 0;

@@ -17,12 +17,16 @@
 //   * traceback bytes are 64 per row; the row's wbase goes to an LDS table for the traceback.
 #pragma once
 #include "ag_reg.h"
+#ifndef SNAPGPU_AG_DUP
+#define SNAPGPU_AG_DUP 0         // measurement builds only (scripts/ab_bench.py): 1 / 2 / 3 run the prologue / the row loop / the traceback of the window form twice
+#endif
 
+// The row loop of rounds 1-3, kept for A/B runs and as the statement of what the rewritten loop must equal (-DSNAPGPU_AG_WIN_V1 selects it).
 // EXACT (replay of flagged reads, ag.h): bt_scratch_in is the wave's image of one reference object's traceback array; cells go where the
 // reference puts them -- byte (row * numVec * numSeg + vector) * 8 + SSE element -- only evaluated cells are written, and the traceback
 // reads whatever the array holds.
 template <bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
-static __device__ __forceinline__ AGResult ag_banded_win(
+static __device__ __forceinline__ AGResult ag_banded_win_v1(
     int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
@@ -382,6 +386,439 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     return res;
 }
 
+// EXACT (replay of flagged reads, ag.h): bt_scratch_in is the wave's image of one reference object's traceback array; cells go where the
+// reference puts them -- byte (row * numVec * numSeg + vector) * 8 + SSE element -- only evaluated cells are written, and the traceback
+// reads whatever the array holds.
+template <bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
+static __device__ __forceinline__ AGResult ag_banded_win(
+    int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
+    const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
+    int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
+    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes)
+{
+    const int lane = lane_id();
+    AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
+    res.match_probability = 1.0; res.stale_reads = 0;
+    const int match = prm.match_reward, sub = -prm.sub_penalty;
+    const int gap_open = prm.gap_open + prm.gap_extend, gap_ext = prm.gap_extend;
+    const int tot = num_seg * seg_len;
+    // LDS tables (the H/E rows of the LDS formulation are not used here): what the row loop would otherwise recompute or
+    // reload -- first-row H per position, base codes of pattern and text.  (The window base of row i needs no table: the
+    // window slides whenever the band start enters the next segment, so it is seg_len * (max(i - w, 0) / seg_len).)
+    LDS_AS int16_t  *fr16 = (LDS_AS int16_t *)(lds_rows + 8);               // [tot]   first_row(p)
+    LDS_AS uint8_t  *pcode = (LDS_AS uint8_t *)(fr16 + ((tot + 7) & ~7));  // [tot]   base_value(P(p)), 5 beyond the pattern
+    LDS_AS uint8_t  *tcode = pcode + ((tot + 15) & ~15);                   // [text_len] base_value(T(i))
+
+    int end_bonus;
+    if (!is_rc) end_bonus = dir == -1 ? prm.five_bonus : prm.three_bonus;
+    else        end_bonus = dir == -1 ? prm.three_bonus : prm.five_bonus;
+
+    // lane constants: which of the (up to) two window segments, stripe l and vector k inside it
+    const int segsel = lane / seg_len;                          // 0, 1 (>= 2: lane beyond the two segments)
+    const int rr = lane - segsel * seg_len;
+    const int l = rr / num_vec, k = rr - l * num_vec;
+    const bool is_x_lane = segsel == 1 && l == 0;                // stripe 0 of the window's second segment: where the F carried over enters
+    const BtSink sink = bt_sink(bt_scratch, bt_bytes);
+    const int nv_tot8 = num_vec * num_seg * 8;                   // EXACT: bytes per row of the reference's array
+    const int flat_lane = segsel * seg_len + k * 8 + l;          // EXACT: byte of this lane's cell inside the window's two segments
+
+    // value of the reference's first-row H at position p, incl. the stale scoreFirstRow[] inheritance
+    auto first_row = [&](int p) -> int {
+        if (p >= tot) return 0;
+        int pi = p;
+        if (p >= pattern_len) {
+            int j2 = p / seg_len, r2 = p - j2 * seg_len, l2 = r2 / num_vec, k2 = r2 - l2 * num_vec;
+            pi = -1;
+            for (int v = j2 * num_vec + k2 - 1; v >= 0; v--) {
+                int q = (v / num_vec) * seg_len + l2 * num_vec + (v % num_vec);
+                if (q < pattern_len) { pi = q; break; }
+            }
+            if (pi < 0) return 0;
+        }
+        int x = score_init - gap_open - pi * gap_ext;
+        return x > 0 ? x : 0;
+    };
+#if SNAPGPU_AG_DUP == 1
+    for (int rep_ = 0; rep_ < 2; rep_++) {
+#else
+    {
+#endif
+    for (int p0 = 0; p0 < tot; p0 += WAVE) {
+        const int p = p0 + lane;
+        if (p < tot) {
+            fr16[p] = (int16_t)first_row(p);
+            pcode[p] = (uint8_t)(p < pattern_len ? base_value(P(p)) : 5u);
+        }
+    }
+    for (int i0 = 0; i0 < text_len; i0 += WAVE) {
+        const int i = i0 + lane;
+        if (i < text_len) tcode[i] = (uint8_t)base_value(T(i));
+    }
+    WAVE_SYNC();
+    }
+
+    // ---------------------------------------------------------------------------------------------------------------------------------
+    // The row loop (round 4).  The single-end kernel is bound by VALU issue (profiles/r04b: SQ_ACTIVE_INST_VALU = 79 % of the SIMDs'
+    // cycles, 4 cycles per wave64 instruction) and this loop is half of it, so a row is written for the fewest VECTOR instructions:
+    //   * every per-lane predicate that depends on wave-uniform row state only (which lanes are inside the band, which hold vector 0 of a
+    //     stripe, ...) is a 64-bit mask computed on the scalar unit and consumed through lane_in() -- no v_cmp, no v_cndmask chains;
+    //   * the four traceback bits are kept as four scalar masks (ballots come out of the compares that are needed anyway), OR-ed on the
+    //     scalar unit when lazy F revises them, and turned into the byte once, after lazy F;
+    //   * per-lane constants of the call (k * ext, (p - 1) * ext + tag, the bpermute source of the lazy-F gather ...) live in registers,
+    //     with "not this lane" folded in as a huge offset, so that a select becomes the max / subtract that follows it anyway;
+    //   * the first-pass F chain is three zero-filled wave shifts and one v_max3 (stripes carry a tag that grows with the lane, so what is
+    //     shifted in from an earlier stripe always loses);
+    //   * the common lazy-F outcome -- no lane continues: the reference leaves each segment's loop after vector 0 -- is one scalar test,
+    //     and only vector-0 lanes take the new H; anything else goes the general way (fold / more_rounds below, as in rounds 1-3).
+    // ISA count of the common row (two segments): profiles/r04c.  Results: bit for bit those of the loop it replaces (ag_banded_win_v1).
+    // ---------------------------------------------------------------------------------------------------------------------------------
+    int best_global = -1, best_global_text = -1, best_local = -1, best_local_text = -1, best_local_pat = -1;
+#if SNAPGPU_AG_DUP == 2
+    for (int rep_ = 0; rep_ < 2; rep_++) {
+    best_global = -1; best_global_text = -1; best_local = -1; best_local_text = -1; best_local_pat = -1;
+#else
+    {
+#endif
+    int wbase = 0, jbase = 0;
+    int Hp = lane < tot ? (int)fr16[lane] : 0, Hm = 0, E = 0;
+    int pbv = lane < tot ? (int)pcode[lane] : 5;
+    int left_h = 0;
+    // H / H-1 of the global-alignment cell (position pattern_len-1) once it has left the window: the
+    // reference keeps reading its stale value on the row(s) after the band has passed the pattern end
+    int gl_p = 0, gl_m = 0;
+
+
+    // ---- masks of the call (wave-uniform)
+    const unsigned long long S0 = seg_len >= 64 ? ~0ull : ((1ull << seg_len) - 1ull);            // lanes of the window's first segment
+    const unsigned long long S1 = seg_len >= 64 ? 0ull : (S0 << seg_len);                          // ... of its second segment (2 * seg_len <= 64)
+    // (lanes with k < n, n = 0 .. num_vec <= 4, from the lanes with k == 0: scalar shifts and ORs of values -- a lambda that captured the
+    //  masks by reference became a table in scratch memory, and everything downstream of its loads vector code)
+    const unsigned long long Kz = first_u64(BALLOT(k == 0));
+    const unsigned long long Klt2 = Kz | (Kz << 1), Klt3 = Klt2 | (Kz << 2);
+    auto kmask = [=](int n) -> unsigned long long { return n >= num_vec ? ~0ull : (n >= 3 ? Klt3 : (n == 2 ? Klt2 : (n == 1 ? Kz : 0ull))); };
+    auto vmask = [=](int wb) -> unsigned long long { const int nvl = tot - wb; return nvl >= 64 ? ~0ull : (nvl <= 0 ? 0ull : ((1ull << nvl) - 1ull)); };
+    unsigned long long V = vmask(0);                                                                 // lanes with p < tot
+    const unsigned long long Xm = first_u64(BALLOT(is_x_lane));
+    // ---- per-lane constants of the call
+    const int tagl = (segsel * 8 + l) * AG_BIG;                  // grows with the lane: what a wave shift brings in from an earlier stripe loses
+    const int c_kext = -k * gap_ext;                             // F entering a stripe is 0: F(k) >= -k * ext
+    const int c_lazy = l == 0 ? AG_HUGE : k * gap_ext;           // lazy F: f = max(f_in - c_lazy, 0)   (stripe 0 gets no F from the left)
+    const int c_x = is_x_lane ? k * gap_ext : AG_HUGE;           // the F carried over from the first segment: max(fk, X0 - c_x)
+    const int c_src = (segsel * seg_len + (l - 1) * num_vec - 1) * 4;      // lazy-F gather: byte address of lane (stripe l - 1, vector nk - 1) is c_src + 4 * nk
+    int c_pt = lane * gap_ext + tagl;                            // p * ext + tag           (p = wbase + lane: + seg_len * ext per slide)
+    int c_pm = k == 0 ? AG_HUGE : (lane - 1) * gap_ext + tagl;   // (p - 1) * ext + tag, "no F from the left" for vector 0
+    int v_else = pbv == 5 ? -32768 : (pbv == 4 ? -1 : sub);      // profile entry of this lane's pattern base against a text base that differs from it
+    const int c_prev = (l == 0 ? lane : lane - num_vec) * 4;     // lazy F, rounds 1 .. 6: the same vector one stripe to the left (stripe 0: itself)
+    int nk_addr = 0, stepv = 0, nk_key = -1;                     // per-lane values that follow (nk0, nk1): the gather address of round 0, nk * ext of the lane's segment
+    uint32_t tb4 = 0;
+
+    for (int i = 0; i < text_len; i++) {
+        if ((i & 3) == 0) tb4 = first_u32(*(LDS_AS const uint32_t *)(tcode + i));       // four rows' text codes per LDS read (tcode is 16-byte aligned; the tail reads slack)
+        const int tb = (int)((tb4 >> (8 * (i & 3))) & 0xffu);
+        const int band_beg = i - w > 0 ? i - w : 0;
+        const int band_end = i + w < pattern_len - 1 ? i + w : pattern_len - 1;
+        if ((jbase + 1) * seg_len <= band_beg) {                // slide the window by one segment
+            left_h = __builtin_amdgcn_readlane(Hp, seg_len - 1);
+            if (pattern_len - 1 >= wbase && pattern_len - 1 < wbase + seg_len) {
+                gl_p = __builtin_amdgcn_readlane(Hp, pattern_len - 1 - wbase);
+                gl_m = __builtin_amdgcn_readlane(Hm, pattern_len - 1 - wbase);
+            }
+            int nHp = __shfl_down(Hp, seg_len), nHm = __shfl_down(Hm, seg_len), nE = __shfl_down(E, seg_len);
+            int npb = __shfl_down(pbv, seg_len);
+            wbase += seg_len; jbase++;
+            if (lane >= WAVE - seg_len) {                       // positions entering the window
+                const int p = wbase + lane;
+                const int fr = p < tot ? (int)fr16[p] : 0;
+                nHp = (i & 1) ? 0 : fr;                         // Hptr is H on even rows, Hminus1 on odd rows
+                nHm = (i & 1) ? fr : 0;
+                nE = 0;
+                npb = p < tot ? (int)pcode[p] : 5;
+            }
+            Hp = nHp; Hm = nHm; E = nE; pbv = npb;
+            V = vmask(wbase);
+            c_pt += seg_len * gap_ext; c_pm += seg_len * gap_ext;
+            v_else = pbv == 5 ? -32768 : (pbv == 4 ? -1 : sub);
+        }
+        int h_init0 = score_init;
+        if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
+        // The reference finishes segment j (first pass, then lazy F) before it starts segment j + 1, and the only thing that crosses
+        // over is X, the F that left segment j's last stripe, which enters stripe 0 of segment j + 1.  Everything else of the two
+        // first passes is independent, so both segments go through ONE first pass (each lane knows its segment), the few stripe-0
+        // lanes of the second segment take X in afterwards (F only ever raises the values derived from it), and the first lazy-F round
+        // -- the only one in all but a few rows -- runs for both segments at once.
+        const int two = ((jbase + 1) * seg_len <= band_end) ? 1 : 0;
+        int nk0 = band_end - wbase + 1; if (nk0 > num_vec) nk0 = num_vec;
+        int nk1 = 0;
+        if (two) { nk1 = band_end - (wbase + seg_len) + 1; if (nk1 > num_vec) nk1 = num_vec; }
+        const unsigned long long inseg_mask = ((kmask(nk0) & S0) | (kmask(nk1) & S1)) & V;      // valid && segsel <= two && k < nk(segment)
+        const bool inseg = lane_in(inseg_mask);
+
+        // ---------------- first pass, both segments (:483-531)
+        int lane0_in;                                              // H(i-1, p-1) of window lane 0: the reference's segment-start rule (:461-476)
+        if (wbase == 0) lane0_in = h_init0;
+        else lane0_in = (band_beg > wbase) ? 0 : left_h;
+        const int h_in = ag_shr1(lane0_in, Hp);
+        int prof;
+        if (tb > 3) prof = pbv == 5 ? -32768 : -1;                 // (an 'N' of the text: rare)
+        else prof = pbv == tb ? match : v_else;
+        const int m = h_in > 0 ? ag_sat16(h_in + prof) : 0;
+        const int e = E;
+        unsigned long long M1 = BALLOT(e > m);                     // traceback bit 1: E wins over the diagonal
+        const int hpp = m > e ? m : e;
+        const int e2 = e - gap_ext;
+        int tmp = m - gap_open; if (tmp < 0) tmp = 0;
+        const unsigned long long M4 = BALLOT(e2 > tmp);            // bit 4: E extends
+        // first-pass F along the (at most 4) vectors of a stripe: F(k) = max_{j<k} (tmp_j - (k-1-j)*ext), a max of tmp_j + p_j*ext over
+        // the (at most 3) lanes to the left that belong to the same stripe
+        int fk = c_kext;
+        if (num_vec > 1) {
+            const int g = inseg ? tmp + c_pt : AG_NEG;
+            const int a1 = ag_shr1z(g);
+            int pm = a1;
+            if (num_vec > 2) {
+                const int a2 = ag_shr1z(a1);
+                pm = a2 > pm ? a2 : pm;
+                if (num_vec > 3) { const int a3 = ag_shr1z(a2); pm = a3 > pm ? a3 : pm; }
+            }
+            const int a = pm - c_pm;
+            fk = a > fk ? a : fk;
+        }
+        int X0 = 0;
+        if (two) {
+            // X after the first segment's lazy F, assuming -- as in all but a few rows -- that its first round is also its last:
+            // the F that left stripe 7 in the first pass (:538).  It enters stripe 0 of the second segment (f = X, :571).
+            const int f2p0 = fk - gap_ext;
+            const int endv_a = f2p0 > tmp ? f2p0 : tmp;
+            const int f7 = __builtin_amdgcn_readlane(endv_a, nk0 - 1 + 7 * num_vec);
+            X0 = f7 > 0 ? f7 : 0;
+            const int fkp = X0 - c_x;
+            fk = fkp > fk ? fkp : fk;
+        }
+        unsigned long long M2 = BALLOT(fk > hpp);                  // bit 2: F wins
+        const int hp = fk > hpp ? fk : hpp;
+        const int f2p = fk - gap_ext;
+        unsigned long long M32 = BALLOT(f2p > tmp);                // bit 32: F extends
+        int endv = inseg ? (f2p > tmp ? f2p : tmp) : 0;
+        Hm = inseg ? hp : Hm;
+        E = inseg ? (e2 > tmp ? e2 : tmp) : E;
+
+        // ---------------- lazy F (:534-569): up to 7 rounds per segment.  Round r brings each stripe the F that left the stripe r + 1 to
+        // its left in the first pass, decayed by r whole stripes (the reference's per-round  vF = max(vF - nk*ext, 0)  composes to that),
+        // and is applied to vectors 0 .. jlim, jlim = the first vector in which no SSE lane's F goes on (:560; all of them when every
+        // vector has such a lane: the round is complete and the next one runs).  On real reads a row goes through ~3 rounds of its first
+        // segment and all 7 of its second (whole SSE vectors are evaluated, so the stripes of the second segment that lie beyond the band
+        // hold small stale H and F runs through all of them): the rounds, not the first pass, are most of a row, so a round is kept to a
+        // gather, four max / subtract and one compare:
+        //   * what a round offers lane (l, k) is u_r(l, k) = u_{r-1}(l - 1, k) - nk * ext: ONE gather from the lane num_vec to the left
+        //     (stripe 0 reads itself and stays at "nothing"), f_r = max(u_r, 0);
+        //   * only  Fx = max of the offers a lane took  is tracked.  H after lazy F is max(H_fp, Fx); traceback bit 2 (F wins) was set in some
+        //     round iff Fx > H_fp; bit 32 (F goes on: f_r - ext > max(max(H, f_r) - open, 0) in the round that offered f_r) was set in some
+        //     round iff Fx > T_fp = max(H_fp - (open - ext), ext) -- the FIRST offer above T_fp also beats every earlier offer minus
+        //     (open - ext), and no offer below T_fp can go on; (open - ext = the gap-open penalty > 0: the caller sends a zero penalty to v1)
+        //   * "F goes on" in round r, which decides jlim and whether round r + 1 runs, is f_r > Tr, Tr = max(T_fp, Fx - (open - ext)) kept
+        //     incrementally.
+        // X, the F that leaves the first segment's last stripe into stripe 0 of the second (:538, :571), grows with every round the first
+        // segment runs; when it has, the second segment's stripe-0 cells are redone before that segment's rounds start.
+        const int d_open = gap_open - gap_ext;
+        int T_fp = Hm - d_open; if (T_fp < gap_ext) T_fp = gap_ext;
+        int Fx = 0;
+        {
+            const int key = nk0 | (nk1 << 8);
+            if (key != nk_key) {                                    // (changes on a handful of rows per call)
+                nk_key = key;
+                const int nkl = lane_in(S0) ? nk0 : nk1;
+                nk_addr = c_src + 4 * nkl;
+                stepv = l == 0 ? 0 : nkl * gap_ext;
+            }
+            auto fold = [&](unsigned long long cm, int nk, int *jlim) -> bool {          // cm: lanes of ONE segment (shifted down) whose F goes on; returns round_complete
+                cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
+                const uint32_t full = (1u << nk) - 1u;
+                const uint32_t low = (uint32_t)cm & full;
+                if (low == full) { *jlim = nk - 1; return true; }
+                *jlim = (int)__builtin_ctz(~low);
+                return false;
+            };
+            int u = __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy;           // round 0's offer, both segments (the second's is redone below when X grew)
+            int Tr = T_fp;
+            bool u_dirty = false;
+            auto rounds = [&](int s, int nk, unsigned long long ins_mask) {
+                const int step = nk * gap_ext;
+                int src7 = s * seg_len + nk - 1 + 6 * num_vec, decay = step;        // (round 1 looks at stripe 6's last vector)
+                for (int r = 0; r < 7; r++) {
+                    if (r > 0) {
+                        if (s == 0 && two) {                                         // X: what this round brings to the segment's end
+                            const int f7 = __builtin_amdgcn_readlane(endv, src7) - decay;
+                            if (f7 > X0) X0 = f7;
+                            src7 -= num_vec; decay += step;
+                        }
+                        u = __builtin_amdgcn_ds_bpermute(c_prev, u) - stepv;
+                        u_dirty = true;
+                    }
+#if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
+                    { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[16 + s * 8 + r], 1, __ATOMIC_RELAXED); }
+#endif
+                    const int f = u > 0 ? u : 0;
+                    int jlim;
+                    const bool complete = fold((BALLOT(f > Tr) & ins_mask) >> (s * seg_len), nk, &jlim);
+                    const int fm = lane_in(complete ? ins_mask : (ins_mask & kmask(jlim + 1))) ? f : 0;
+                    Fx = fm > Fx ? fm : Fx;
+                    const int tq = fm - d_open;
+                    Tr = tq > Tr ? tq : Tr;
+                    if (!complete) break;
+                }
+            };
+            const int X_first = X0;
+            if (nk0 > 0) rounds(0, nk0, inseg_mask & S0);
+            if (two) {
+                if (X0 != X_first) {
+                    // stripe 0 of the second segment again, with the final X (values derived from F only go up with it)
+                    const unsigned long long xlm = Xm & inseg_mask;
+                    const bool xl = lane_in(xlm);
+                    const int fkp = X0 - c_x;
+                    const int fkx = fkp > fk ? fkp : fk;
+                    const int hpx = fkx > hpp ? fkx : hpp;
+                    const int evx = (fkx - gap_ext) > tmp ? (fkx - gap_ext) : tmp;
+                    M2 = (M2 & ~xlm) | (BALLOT(fkx > hpp) & xlm);
+                    M32 = (M32 & ~xlm) | (BALLOT((fkx - gap_ext) > tmp) & xlm);
+                    Hm = xl ? hpx : Hm;
+                    endv = xl ? evx : endv;
+                    T_fp = Hm - d_open; if (T_fp < gap_ext) T_fp = gap_ext;
+                    Tr = T_fp;
+                    u_dirty = true;                                                  // (the stripe-0 ends are what stripe 1 is offered)
+                }
+                if (u_dirty) u = __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy;     // round 0's offer again: the first segment's later rounds shifted it away
+                rounds(1, nk1, inseg_mask & S1);
+            }
+            M2 |= BALLOT(Fx > Hm);
+            M32 |= BALLOT(Fx > T_fp);
+            Hm = Fx > Hm ? Fx : Hm;
+        }
+
+        // the traceback byte, once, from the four masks
+        const int btr = (lane_in(M1) ? 1 : 0) | (lane_in(M4) ? 4 : 0) | (lane_in(M2) ? 2 : 0) | (lane_in(M32) ? 32 : 0);
+        // (uniform row pointer + zero-extended 32-bit lane offset: the form that selects the SGPR-base store; with a sign-extended
+        //  lane the address lives in a VGPR pair, which the 80-VGPR build spills and reloads -- with a vmcnt(0) wait -- every row)
+        if constexpr (EXACT) {
+            if (inseg) bt_store(sink, (uint32_t)(i * nv_tot8 + jbase * seg_len), (uint32_t)flat_lane, (uint32_t)btr);
+        } else {
+            bt_store(sink, (uint32_t)i * 64u, (uint32_t)lane, (uint32_t)btr);       // (lanes outside the band write what they have; the traceback never reads them)
+        }
+        const int mxv = inseg ? Hm : 0;
+        const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
+        if (band_end == pattern_len - 1) {
+            int gscore = pattern_len - 1 >= wbase ? __builtin_amdgcn_readlane(Hm, pattern_len - 1 >= wbase ? pattern_len - 1 - wbase : 0) : gl_m;
+            if (gscore >= best_global) { best_global = gscore; best_global_text = i; }
+        }
+        if (max_row == 0) break;
+        if (max_row > best_local) {
+            unsigned long long mk = BALLOT(Hm == max_row) & inseg_mask;
+            best_local_pat = mk ? wbase + 63 - __clzll((long long)mk) : -1;
+            best_local = max_row; best_local_text = i;
+        }
+        { int t = Hm; Hm = Hp; Hp = t; }
+        { int t = gl_m; gl_m = gl_p; gl_p = t; }
+    }
+    WAVE_SYNC();
+    }
+
+    // ---------------- local vs global (:643-730)
+    int score, pat_off, text_off;
+    if (best_local != best_global && best_local >= best_global + end_bonus) {
+        pat_off = best_local_pat; text_off = best_local_text; score = best_local;
+        if (use_clipping) {
+            int pa = pat_off - 1, ta = text_off, cnt = 0;
+            while (pa + 1 != pattern_len && P(pa + 1) == T(ta + 1)) { cnt++; pa++; ta++; }
+            if (cnt >= 3) { pat_off = pa; text_off = ta; }
+            else {
+                pa = pat_off + 1; ta = text_off; cnt = 0;
+                while (pa < pattern_len && P(pa) == T(ta)) { cnt++; pa++; ta++; }
+                if (cnt >= 3) { pat_off = pa - 1; text_off = ta - 1; }
+            }
+            if (use_clipping != 2 && pat_off == best_local_pat && text_off == best_local_text) {   // 2 = useAltLiftover: no quality-aware step (:1212)
+                pa = pat_off;
+                while (pa != pattern_len - 1 && Q(pa) >= 65 && Q(pa + 1) >= 65) pa++;
+                if (pa == pattern_len - 1) pat_off = pa;
+                else if (pa >= pat_off + 2) {
+                    int tmp_off = pa + 1, cnt_hq = 0, rem = pattern_len - tmp_off;
+                    while (tmp_off != pattern_len - 1) { if (Q(tmp_off) >= 65) cnt_hq++; tmp_off++; }
+                    if (((float)cnt_hq) / (float)rem < 0.1f) pat_off = pa;
+                }
+            }
+        }
+    } else {
+        pat_off = pattern_len - 1; text_off = best_global_text; score = best_global;
+    }
+    res.text_offset = text_off; res.pattern_offset = pat_off;
+
+#if SNAPGPU_AG_DUP == 3
+    const int text_off_dup = text_off, pat_off_dup = pat_off;
+    for (int rep_ = 0; rep_ < 2; rep_++) { text_off = text_off_dup; pat_off = pat_off_dup; res.stale_reads = 0;
+#else
+    {
+#endif
+    if (score > score_init) {                                          // traceback, :732-815
+        double prob = 1.0;
+        int row = text_off, col = pat_off;
+        int action = 0, prev_action = 0, action_count = 1, n_matches = 0, n_mismatches = 0, n_gaps = 0;
+        while (row >= 0 && col >= 0) {
+            const int rt = row - lane, ct = col - lane;
+            const bool ok = rt >= 0 && ct >= 0;
+            bool computed = false;
+            int wb = 0;
+            if (ok) {
+                int bb = rt - w > 0 ? rt - w : 0, be = rt + w < pattern_len - 1 ? rt + w : pattern_len - 1;
+                int cj = ct / seg_len, ck = (ct - cj * seg_len) % num_vec;
+                computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
+                wb = (bb / seg_len) * seg_len;
+            }
+            int cell;
+            if constexpr (EXACT) {
+                int vi = 0, li = 0;
+                if (ok) { const int cj = ct / seg_len, cr = ct - cj * seg_len; vi = cj * num_vec + cr % num_vec; li = cr / num_vec; }
+                const uint32_t at = (uint32_t)rt * (uint32_t)nv_tot8 + (uint32_t)(vi * 8 + li);
+                cell = (ok && at < bt_bytes) ? (int)bt_scratch[at] : 0;
+            } else {
+                cell = computed ? (int)bt_scratch[(size_t)rt * 64 + (ct - wb)] : 0;
+            }
+            int pbyte = ok ? (int)P(ct) : 0, tbyte = ok ? (int)T(rt) : 0, qbyte = ok ? (int)Q(ct) : 0;
+            int info = cell | ((ok && !computed) ? 0x100 : 0) | ((pbyte != tbyte) ? 0x200 : 0) | (qbyte << 16);
+            for (int t = 0; t < WAVE && row >= 0 && col >= 0; t++) {
+                const int inf = __builtin_amdgcn_readlane(info, t);
+                if (inf & 0x100) res.stale_reads++;
+                action = ((inf & 0xff) >> (action << 1)) & 3;
+                bool left_diagonal = false;
+                if (action == 0) {
+                    if (inf & 0x200) { prob *= tab->phred[(inf >> 16) & 0xff]; n_mismatches++; }
+                    else n_matches++;
+                    row--; col--;
+                } else if (action == 1) {
+                    row--; left_diagonal = true;
+                } else {
+                    col--; action = 2; left_diagonal = true;
+                }
+                if (prev_action != 0) {
+                    if (prev_action == action) action_count++;
+                    else { n_gaps += action_count; prob *= tab->indel[action_count]; action_count = 1; }
+                }
+                prev_action = action;
+                if (left_diagonal) break;
+            }
+        }
+        if (row >= 0) { action_count = row + 1; n_gaps += action_count; prob *= tab->indel[action_count]; }
+        if (col >= 0) { action_count = col + 1; n_gaps += action_count; prob *= tab->indel[action_count]; }
+        res.n_edits = n_mismatches + n_gaps;
+        prob *= tab->perfect[n_matches];
+        text_off += 1; pat_off += 1;
+        res.text_offset = pattern_len - text_off;
+        res.pattern_offset = pattern_len - pat_off;
+        prob *= tab->indel[res.pattern_offset];
+        res.match_probability = prob;
+        res.ag_score = score;
+    }
+    }
+    return res;
+}
+
 // AGC > 0: register formulation with AGC chunks of 64 positions (the host guarantees it fits);
 // AGC == 0: the LDS formulation of ag.h (any pattern length up to RL).
 template <int AGC, bool EXACT, typename PSeq, typename TSeq, typename QSeq>
@@ -402,9 +839,17 @@ static __device__ __forceinline__ AGResult ag_dispatch_inl(
             (EXACT && (size_t)text_len * (size_t)(num_seg * seg_len) > ag_scratch_bytes(RL))) {
             __builtin_trap();                                             // host sizing bug: fail loudly
         }
+        if (banded && 2 * seg_len <= 64 && prm.gap_open <= 0)        // (the rewritten row loop assumes a positive gap-open penalty: see its lazy-F notes)
+            return ag_banded_win_v1<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                           lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
         if (banded && 2 * seg_len <= 64)        // the band's two segments fit one wavefront: sliding-window form
+#if defined(SNAPGPU_AG_WIN_V1)
+            return ag_banded_win_v1<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                           lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
+#else
             return ag_banded_win<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                         lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
+#endif
         if (banded)
             return ag_compute_reg<AGC, true, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                                     lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));

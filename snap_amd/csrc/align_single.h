@@ -1016,8 +1016,12 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 uint32_t st = 1;
                 if (lane == 0) st = atomicCAS(&spec[t].state, 0u, 1u);
                 if (first_u32(st) != 0u) continue;
+                // (after a watchdog the owner retires the slot and reuses its list and pool for its next read while a stalled helper may
+                //  still be here: look at the state again before every item, and never follow an element index outside the pool)
+                if (XW::aload(&slot->state) != 1u) break;
                 const uint32_t item = first_u32(items[t]);
                 const uint32_t ei = item >> 6; const int idx = (int)(item & 63u);
+                if (ei >= cfg.pool_size) continue;
                 const uint32_t *ep = (const uint32_t *)&opool[ei];
                 const uint32_t ew = lane < (int)(sizeof(Elem) / 4) ? ep[lane] : 0u;
                 auto EW = [&](int i) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)ew, i); };
@@ -1030,7 +1034,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 ce.lv1 = -1; ce.lv2 = -2;
                 uint32_t d_lv = 0, d_ag = 0, stale = 0; uint64_t d_bytes = 0;
                 int rec_limit = (int)0x80000000;            // (an element the owner would skip under this limit: a record nobody can use)
-                if ((int64_t)e_lps <= (int64_t)limit_e) {
+                if ((int64_t)e_lps <= (int64_t)limit_e && e_base >= 0 && (uint64_t)(e_base + idx) < (uint64_t)ix.n_bases && idx < 48 && cso >= 0 && cso <= read_len) {
                     const uint64_t lv0 = cnt.lv, ag0 = cnt.ag, b0 = cnt.lv_ref_bytes;
                     ag_stale = 0; ag_replay = 0; ag_obj_used0 = 1; ag_obj_used1 = 1;
                     ce = eval_candidate<false>(e_base + idx, e_dir, e_lps, cso, limit_e, best);

@@ -6,6 +6,14 @@
 // emulation).  State that the reference keeps in its per-thread aligner object lives in
 // LDS (hot) or in a per-wave slab of HBM scratch (large, L2-resident).
 #pragma once
+// Landau-Vishkin and the affine-gap forms as ONE function per kernel (lv.h: lv_compute_fn, ag_win.h: ag_dispatch_fn) instead of one inlined
+// copy per call site: the paired-end kernels since round 2; the single-end kernels since round 4 -- the row loops then get a register
+// allocation of their own instead of sharing the caller's 80 VGPRs / 100 SGPRs (the inlined row loop reloaded ~60 spilled SGPRs per row),
+// measured +2 .. 3 % (profiles/r04c: 9.07 -> 9.34 M reads/s with the old row loop, 9.85 -> 10.07 M with the new).  -DSNAPGPU_AG_LV_INLINE
+// builds the inlined form.
+#if !defined(SNAPGPU_AG_LV_INLINE) && !defined(SNAPGPU_AG_LV_FUNCTIONS)
+#define SNAPGPU_AG_LV_FUNCTIONS 1
+#endif
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -141,6 +149,16 @@ static __device__ __forceinline__ void bt_store(const BtSink &s, uint32_t uoff, 
     s.base[(size_t)uoff + voff] = (uint8_t)val;
 #else
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)val, s.rsrc, (int)voff, (int)first_u32(uoff), 0);
+#endif
+}
+
+// A wave-uniform 64-bit lane mask as a per-lane predicate at no VALU cost: the mask goes to VCC (or stays in its SGPR pair) and the consumer is
+// a v_cndmask_b32_e64 / an exec update that reads it directly (llvm.amdgcn.inverse.ballot).  `mask` must be wave-uniform.
+static __device__ __forceinline__ bool lane_in(unsigned long long mask) {
+#if defined(SNAPGPU_WAVE_EMU)
+    return ((mask >> lane_id()) & 1ull) != 0ull;
+#else
+    return __builtin_amdgcn_inverse_ballot_w64(mask);
 #endif
 }
 

@@ -376,6 +376,10 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
     std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
     for (size_t i = 0; i < n; i++) {
         if (clip_read(o, b, i, front_clip[i], data_len[i])) {
+            // (-ae: the adjuster is restated for reads the reader has not clipped -- adjust.h; the reference settles a contig-end overhang on
+            //  the UNCLIPPED buffer, AlignmentAdjuster.cpp:167 -- so a read that actually got clipped is refused, not answered differently)
+            if (o.ae && (front_clip[i] != 0 || (uint64_t)data_len[i] != b.offsets[i + 1] - b.offsets[i]))
+                die("-ae with a quality-clipped read is not supported (the adjuster works on reads the reader has not clipped): run with -C--");
             to_align.push_back((uint32_t)i);
             const char *q = b.quals.data() + b.offsets[i] + front_clip[i], *s = b.bases.data() + b.offsets[i] + front_clip[i];
             ab.insert(ab.end(), s, s + data_len[i]); aq.insert(aq.end(), q, q + data_len[i]); ao.push_back(ab.size());

@@ -195,6 +195,15 @@ __global__ __launch_bounds__(256) void k_ib_run_need(const uint32_t *run_start, 
 }
 // ---------------------------------------------------------------- 4. overflow table and hash tables
 // element i of a repeated seed goes to its list, last occurrence first ("reverse sorted ... it's necessary for correct functioning", :763)
+// The total of `need` in 64 bits: the 32-bit scan above wraps silently when a multi-Gb, highly repetitive genome asks for 2^32 or more
+// overflow words, and the address-space check after it must see the true total (GenomeIndex.cpp:684 / :777 fail there).
+__global__ __launch_bounds__(256) void k_ib_sum64(const uint32_t *need, uint32_t n_runs, unsigned long long *total)
+{
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_runs; i += (uint64_t)gridDim.x * blockDim.x) acc += need[i];
+    if (acc) atomicAdd(total, acc);          // (at most one atomic per thread of a persistent grid)
+}
+
 __global__ __launch_bounds__(256) void k_ib_fill_overflow(const uint32_t *vals, const uint32_t *head, const uint32_t *heads_before, uint64_t m,
                                                           const uint32_t *run_start, const uint32_t *ovf_off, uint32_t *overflow)
 {

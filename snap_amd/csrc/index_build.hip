@@ -188,6 +188,7 @@ static int ib_build_on_device(snapgpu_built_index *bi, double slack)
     // ---- 3. runs of equal seeds
     uint32_t *d_head = nullptr, *d_before = nullptr, *d_run_start = nullptr, *d_need = nullptr, *d_ovf_off = nullptr;
     uint32_t n_runs = 0, ovf_words = 0;
+    unsigned long long ovf_words64 = 0;
     if (m) {
         IBCHK(mem.alloc(&d_head, (size_t)m * 4), SNAPGPU_E_NOMEM);
         IBCHK(mem.alloc(&d_before, (size_t)m * 4), SNAPGPU_E_NOMEM);
@@ -205,10 +206,15 @@ static int ib_build_on_device(snapgpu_built_index *bi, double slack)
         rc = ib_exclusive_scan(d_need, n_runs, d_ovf_off, d_partial, d_total, grid, s);
         if (rc) return rc;
         IBCHK(hipMemcpyAsync(&ovf_words, d_total, 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+        // the same total in 64 bits (d_total has 64 bytes: the second half is free): a wrapped 32-bit scan must not pass the check below
+        unsigned long long *d_sum64 = (unsigned long long *)(d_total + 8);
+        IBCHK(hipMemsetAsync(d_sum64, 0, 8, s), SNAPGPU_E_LAUNCH);
+        hipLaunchKernelGGL(k_ib_sum64, dim3(grid), dim3(256), 0, s, (const uint32_t *)d_need, n_runs, d_sum64);
+        IBCHK(hipMemcpyAsync(&ovf_words64, d_sum64, 8, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
         IBCHK(hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
     }
     // value = nBases + overflow index must stay below the two reserved values (GenomeIndex.cpp:777)
-    if ((uint64_t)ovf_words + n_bases >= 0xFFFFFFFFull - 15) return ib_fail(SNAPGPU_E_UNSUPPORTED, "not enough 32-bit address space for genome + overflow table (GenomeIndex.cpp:777): larger seed or location size needed");
+    if (ovf_words64 + n_bases >= 0xFFFFFFFFull - 15 || ovf_words64 != ovf_words) return ib_fail(SNAPGPU_E_UNSUPPORTED, "not enough 32-bit address space for genome + overflow table (GenomeIndex.cpp:777): larger seed or location size needed");
     bi->stats.n_distinct_seeds = n_runs; bi->overflow_words = ovf_words; bi->stats.overflow_table_size = ovf_words;
     IBCHK(hipEventRecord(ev[3], s), SNAPGPU_E_LAUNCH);
 

@@ -553,13 +553,19 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
 // Device-native hash layout (bucket.h): built on the GPU from the reference's slot arrays once they are in HBM
 // (snapgpu_create for uploaded / adopted blobs, snapgpu_broadcast_index for the replicas it fills).
 // The bit-plane shadow of the genome (planes.h), from the byte genome already in HBM -- however it got there.
+// SNAPGPU_LV_PLANES=<non-zero> and not SNAPGPU_NO_PLANES: one parse for the context that builds the shadow and the feeders that adopt it
+static bool lv_planes_wanted() {
+    const char *e = getenv("SNAPGPU_LV_PLANES");
+    return !getenv("SNAPGPU_NO_PLANES") && e && atoi(e) != 0;
+}
+
 // Built, and used by Landau-Vishkin, when SNAPGPU_LV_PLANES=1 (and not SNAPGPU_NO_PLANES=1).  NOT the default: measured on the bench batch
 // (profiles/r03e) the plane form stages 2.7x fewer reference bytes per scored location but spends MORE instructions -- 1.59 M wave cycles
 // per read against 1.48 M, Landau-Vishkin 22 % of them against 16 %: most calls end after one or two levels, where the byte form has
 // built three or five bitmaps and the plane form all 2k + 1 -- for the same launch time.  DESIGN.md section 16.
 static int build_planes(snapgpu_ctx *ctx)
 {
-    if (getenv("SNAPGPU_NO_PLANES") || !getenv("SNAPGPU_LV_PLANES") || atoi(getenv("SNAPGPU_LV_PLANES")) == 0) return SNAPGPU_OK;
+    if (!lv_planes_wanted()) return SNAPGPU_OK;
     const uint64_t n_bytes = ctx->ix.n_bases + 2 * (uint64_t)ctx->ix.genome_pad;
     const uint64_t n_blocks = (n_bytes + 63) / 64 + 32;
     if (!ctx->d_planes) {
@@ -729,7 +735,7 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         const int brc = build_buckets(ctx);
         if (brc != SNAPGPU_OK) { snapgpu_destroy(ctx); return brc; }
     }
-    if (g_share_buckets_from && g_share_buckets_from->d_planes && idx->on_device && !getenv("SNAPGPU_NO_PLANES") && getenv("SNAPGPU_LV_PLANES")) {       // a feeder context: adopt the shadow too
+    if (g_share_buckets_from && g_share_buckets_from->d_planes && idx->on_device && lv_planes_wanted()) {       // a feeder context: adopt the shadow too
         ctx->d_planes = g_share_buckets_from->d_planes; ctx->owns_planes = false; ctx->plane_bytes = g_share_buckets_from->plane_bytes;
         ix.planes = ctx->d_planes;
     } else if (idx->on_device || idx->genome != nullptr) {
