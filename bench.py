@@ -169,7 +169,7 @@ def parse_args(argv=None):
                     help="single = configs[1] (the metric's config); paired = configs[2], 2x150 bp FR pairs through the paired-end path")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="one GPU, --workload single only: do not add the short paired-end leg (`paired`) and the 256 Mb leg (`genome_256mb`)")
-    ap.add_argument("--paired-leg-steps", type=int, default=3, help="timed steps of the extra paired-end leg")
+    ap.add_argument("--paired-leg-steps", type=int, default=6, help="timed steps of the extra paired-end leg")
     ap.add_argument("--standin-mb", type=int, default=256, help="genome size of the extra `genome_256mb` leg (tests shrink it)")
     args = ap.parse_args(argv)
     if args.steps <= 0:

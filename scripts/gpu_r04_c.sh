@@ -13,7 +13,7 @@ except Exception as e:
 PY
 }
 for v in ${VARIANTS:-v1inl v2inl v1fn v2fn}; do
-  run s_$v python scripts/ab_bench.py run $v --genome-mb 256 --no-extra-legs --steps 12 --warmup 3 --skip-probe --skip-refwalk --cpu-seconds 3
+  run s_$v python scripts/ab_bench.py run $v --genome-mb 256 --no-extra-legs --steps 12 --warmup 3 --skip-probe --skip-refwalk --cpu-seconds ${CPUS:-3}
 done
 for v in ${PVARIANTS:-v1inl v2inl}; do
   run p_$v python scripts/ab_bench.py run $v --genome-mb 256 --workload paired --no-extra-legs --steps 3 --warmup 1 --cpu-seconds 3

@@ -509,6 +509,8 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int c_pm = k == 0 ? AG_HUGE : (lane - 1) * gap_ext + tagl;   // (p - 1) * ext + tag, "no F from the left" for vector 0
     int v_else = pbv == 5 ? -32768 : (pbv == 4 ? -1 : sub);      // profile entry of this lane's pattern base against a text base that differs from it
     const int c_prev = (l == 0 ? lane : lane - num_vec) * 4;     // lazy F, rounds 1 .. 6: the same vector one stripe to the left (stripe 0: itself)
+    const unsigned long long Lmid = first_u64(BALLOT(segsel == 1 && l >= 1 && l <= 6));   // the second segment's stripes whose ends are offered to somebody
+    int c_ls = 0, c_g = 0;                                        // (follow nk like stepv: the closed form of the second segment's lazy F)
     int nk_addr = 0, stepv = 0, nk_key = -1;                     // per-lane values that follow (nk0, nk1): the gather address of round 0, nk * ext of the lane's segment
     uint32_t tb4 = 0;
 
@@ -546,7 +548,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         // first passes is independent, so both segments go through ONE first pass (each lane knows its segment), the few stripe-0
         // lanes of the second segment take X in afterwards (F only ever raises the values derived from it), and the first lazy-F round
         // -- the only one in all but a few rows -- runs for both segments at once.
-        const int two = ((jbase + 1) * seg_len <= band_end) ? 1 : 0;
+        const bool two = (jbase + 1) * seg_len <= band_end;
         int nk0 = band_end - wbase + 1; if (nk0 > num_vec) nk0 = num_vec;
         int nk1 = 0;
         if (two) { nk1 = band_end - (wbase + seg_len) + 1; if (nk1 > num_vec) nk1 = num_vec; }
@@ -629,6 +631,8 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 const int nkl = lane_in(S0) ? nk0 : nk1;
                 nk_addr = c_src + 4 * nkl;
                 stepv = l == 0 ? 0 : nkl * gap_ext;
+                c_ls = l * nkl * gap_ext;                           // a stripe end's origin: e_l + l * nk * ext
+                c_g = l == 0 ? AG_HUGE : c_ls - stepv - c_kext;     // what lies between stripe 0's end and cell (l, k): ((l - 1) * nk + k) * ext
             }
             auto fold = [&](unsigned long long cm, int nk, int *jlim) -> bool {          // cm: lanes of ONE segment (shifted down) whose F goes on; returns round_complete
                 cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
@@ -638,12 +642,15 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 *jlim = (int)__builtin_ctz(~low);
                 return false;
             };
-            int u = __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy;           // round 0's offer, both segments (the second's is redone below when X grew)
-            int Tr = T_fp;
+            int u = __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy;           // round 0's offer, both segments (the second's is redone below when it was shifted away)
             bool u_dirty = false;
-            auto rounds = [&](int s, int nk, unsigned long long ins_mask) {
+            int Fx0 = 0, Fx1 = 0;                                                    // the largest offer taken, first / second segment (every round runs over all lanes)
+            // A complete round applies to every lane of the segment: no select, and lanes outside the segment may collect what they like
+            // (they are masked once, below).  Only the round that stops the walk selects its vectors 0 .. jlim.
+            auto rounds = [&](int s, int nk, unsigned long long ins_mask, int &Fxs) {
                 const int step = nk * gap_ext;
                 int src7 = s * seg_len + nk - 1 + 6 * num_vec, decay = step;        // (round 1 looks at stripe 6's last vector)
+                int Tr = T_fp;
                 for (int r = 0; r < 7; r++) {
                     if (r > 0) {
                         if (s == 0 && two) {                                         // X: what this round brings to the segment's end
@@ -657,18 +664,22 @@ static __device__ __forceinline__ AGResult ag_banded_win(
 #if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
                     { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[16 + s * 8 + r], 1, __ATOMIC_RELAXED); }
 #endif
-                    const int f = u > 0 ? u : 0;
                     int jlim;
-                    const bool complete = fold((BALLOT(f > Tr) & ins_mask) >> (s * seg_len), nk, &jlim);
-                    const int fm = lane_in(complete ? ins_mask : (ins_mask & kmask(jlim + 1))) ? f : 0;
-                    Fx = fm > Fx ? fm : Fx;
-                    const int tq = fm - d_open;
+                    const bool complete = fold((BALLOT(u > Tr) & ins_mask) >> (s * seg_len), nk, &jlim);      // (an offer <= 0 is never above Tr >= 0)
+                    if (!complete) {
+                        const int fm = lane_in(ins_mask & kmask(jlim + 1)) ? u : 0;
+                        Fxs = fm > Fxs ? fm : Fxs;
+                        break;
+                    }
+                    Fxs = u > Fxs ? u : Fxs;
+                    const int tq = u - d_open;
                     Tr = tq > Tr ? tq : Tr;
-                    if (!complete) break;
                 }
             };
             const int X_first = X0;
-            if (nk0 > 0) rounds(0, nk0, inseg_mask & S0);
+            const unsigned long long ins0 = inseg_mask & S0, ins1 = inseg_mask & S1;
+            if (nk0 > 0) rounds(0, nk0, ins0, Fx0);
+            int Fx = lane_in(ins0) ? Fx0 : 0;
             if (two) {
                 if (X0 != X_first) {
                     // stripe 0 of the second segment again, with the final X (values derived from F only go up with it)
@@ -683,11 +694,31 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                     Hm = xl ? hpx : Hm;
                     endv = xl ? evx : endv;
                     T_fp = Hm - d_open; if (T_fp < gap_ext) T_fp = gap_ext;
-                    Tr = T_fp;
                     u_dirty = true;                                                  // (the stripe-0 ends are what stripe 1 is offered)
                 }
-                if (u_dirty) u = __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy;     // round 0's offer again: the first segment's later rounds shifted it away
-                rounds(1, nk1, inseg_mask & S1);
+                // The second segment usually runs all seven rounds -- its stripes 1 .. 7 lie beyond the band, hold small stale H, and the
+                // F that entered stripe 0 from the first segment runs through all of them -- and then what every cell ends up with is
+                // that one flow: e0, the F leaving stripe 0, decayed by the cells in between.  Two ballots say when that is so:
+                //   (A) no later stripe end beats it at its own origin (e_j + j * nk * ext <= e0, j = 1 .. 6), so for every cell the offer
+                //       that started in stripe 0 is the largest it gets;
+                //   (B) that offer is above T_fp in every cell of stripes 1 .. 7: the cell (r + 1, k) then goes on in round r whatever it
+                //       was offered before (smaller, by (A)), every vector has such a cell, all seven rounds are complete and apply to
+                //       every cell -- and Fx is the stripe-0 offer itself.
+                // Otherwise the rounds run as for the first segment.
+                const int e0 = __builtin_amdgcn_readlane(endv, seg_len + nk1 - 1);
+                const unsigned long long endm = ((Kz << (nk1 - 1)) & Lmid) & ins1;
+                const int g0 = e0 - c_g;
+                const unsigned long long insL = ins1 & ~Xm;
+                if ((BALLOT(endv + c_ls > e0) & endm) == 0ull && (BALLOT(g0 > T_fp) & insL) == insL) {
+#if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
+                    { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[4], 1, __ATOMIC_RELAXED); }
+#endif
+                    Fx = lane_in(insL) ? g0 : Fx;
+                } else {
+                    if (u_dirty) u = __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy;     // round 0's offer again: the first segment's later rounds shifted it away
+                    rounds(1, nk1, ins1, Fx1);
+                    Fx = lane_in(ins1) ? Fx1 : Fx;
+                }
             }
             M2 |= BALLOT(Fx > Hm);
             M32 |= BALLOT(Fx > T_fp);
