@@ -337,6 +337,20 @@ int  snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
                             int32_t *total_indels, int32_t *text_span);
 
 /*
+ * -f and -x of the single-end aligner (AlignerOptions.cpp:571-574; BaseAligner::setStopOnFirstHit / setExplorePopularSeeds as
+ * SingleAligner.cpp:179-180 calls them after constructing each BaseAligner):
+ *   stop_on_first_hit      AlignRead stops at the first location it scores within maxK and reports it with status MultipleHits and
+ *                          MAPQ 0 (BaseAligner.cpp:1490-1505)
+ *   explore_popular_seeds  a seed with more than maxHits hits in a direction is not skipped: its first maxHits hits are applied
+ *                          (BaseAligner.cpp:574, :625)
+ * They apply to this context's single-end entry points (snapgpu_align_single*, with or without secondary results).  The paired-end
+ * aligners never see them in the reference either -- PairedAligner.cpp sets neither on the BaseAligner inside ChimericPairedEndAligner, and
+ * IntersectingPairedEndAligner's stopOnFirstHit stays false (IntersectingPairedEndAligner.cpp:66) -- so snapgpu_align_paired* ignores them.
+ * Both 0 by default.  Returns SNAPGPU_OK.
+ */
+int  snapgpu_set_aligner_flags(snapgpu_ctx *ctx, int stop_on_first_hit, int explore_popular_seeds);
+
+/*
  * AlignmentAdjuster::AdjustAlignment (SNAPLib/AlignmentAdjuster.cpp:33-190) for a batch of results: what finalizeSecondaryResults does to
  * the primary and to every secondary result before the -om filter when the aligner runs with -ae (BaseAligner.cpp:2444-2463), and what
  * snapgpu_enable_secondary's adjust_alignments = 1 runs inside the alignment kernels.  Result i belongs to read

@@ -57,6 +57,22 @@ class adjust_alignments:
         lib().snapref_set_adjust_alignments(self.prev)
 
 
+class aligner_flags:
+    """`with ref.aligner_flags(stop_on_first_hit=True, explore_popular_seeds=False):` -- -f / -x for the BaseAligner objects snapref_align_single*
+    construct inside the block (BaseAligner::setStopOnFirstHit / setExplorePopularSeeds, as SingleAligner.cpp:179-180 calls them)."""
+
+    def __init__(self, stop_on_first_hit: bool = False, explore_popular_seeds: bool = False):
+        self.f, self.x = stop_on_first_hit, explore_popular_seeds
+
+    def __enter__(self):
+        lib().snapref_set_aligner_flags(C.c_int(1 if self.f else 0), C.c_int(1 if self.x else 0))
+        return self
+
+    def __exit__(self, *exc):
+        lib().snapref_set_aligner_flags(C.c_int(0), C.c_int(0))
+        return False
+
+
 class fresh_objects:
     """`with ref.fresh_objects():` -- every read / pair is aligned by reference aligner objects newly constructed in zero-filled memory
     (oracle/ref_driver.cpp: ZeroedArena), so the reference's answer is a function of the read alone and EVERY read can be compared

@@ -234,6 +234,10 @@ public:
 private:
     char *base; size_t cap, used;
 };
+/* -f / -x for the aligners snapref_align_single* construct: applied as SingleAligner.cpp:179-180 applies them, after each construction */
+static volatile int g_stop_on_first_hit = 0, g_explore_popular_seeds = 0;
+void snapref_set_aligner_flags(int stop_on_first_hit, int explore_popular_seeds) { g_stop_on_first_hit = stop_on_first_hit; g_explore_popular_seeds = explore_popular_seeds; }
+static inline BaseAligner *with_flags(BaseAligner *a) { a->setStopOnFirstHit(g_stop_on_first_hit != 0); a->setExplorePopularSeeds(g_explore_popular_seeds != 0); return a; }
 static volatile int g_fresh_objects = 0;
 void snapref_set_fresh_objects(int on) { g_fresh_objects = on; }
 int snapref_get_fresh_objects(void) { return g_fresh_objects; }
@@ -338,14 +342,14 @@ static void *align_thread(void *arg)
                                                 p->num_seeds, p->seed_coverage, -1, p->extra_search_depth) + 4096;
     ZeroedArena *arena = fresh ? new ZeroedArena(reservation + (1 << 20)) : NULL;
     BigAllocator *allocator = fresh ? (BigAllocator *)arena : new BigAllocator(reservation, 16);
-#define NEW_SINGLE_ALIGNER() new (allocator) BaseAligner( \
+#define NEW_SINGLE_ALIGNER() with_flags(new (allocator) BaseAligner( \
         index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check, \
         p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, \
         g_adjust_alignments == 0 /* ignoreAlignmentAdjustmentsForOm: true by default (AlignerOptions.cpp:96), false with -ae */, \
         p->alt_awareness != 0, p->emit_alt_alignments != 0, p->max_score_gap_to_prefer_non_alt, \
         -1 /* maxSecondaryAlignmentsPerContig */, NULL, NULL, \
         p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty, \
-        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator)
+        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator))
     BaseAligner *aligner = NEW_SINGLE_ALIGNER();
     _int64 acc_lookups = 0, acc_lv = 0, acc_ag = 0;
 
@@ -554,13 +558,13 @@ static void *align_secondary_thread(void *arg)
                                                 p->num_seeds, p->seed_coverage, job->mpc, p->extra_search_depth) + 4096;
     ZeroedArena *arena = fresh ? new ZeroedArena(reservation + (1 << 20)) : NULL;
     BigAllocator *allocator = fresh ? (BigAllocator *)arena : new BigAllocator(reservation, 16);
-#define NEW_SEC_ALIGNER() new (allocator) BaseAligner( \
+#define NEW_SEC_ALIGNER() with_flags(new (allocator) BaseAligner( \
         index, p->max_hits, p->max_k, maxReadSize, p->num_seeds, p->seed_coverage, p->min_weight_to_check, \
         p->extra_search_depth, DisabledOptimizations(), p->use_affine_gap != 0, \
         g_adjust_alignments == 0 /* ignoreAlignmentAdjustmentsForOm */, p->alt_awareness != 0, p->emit_alt_alignments != 0, \
         p->max_score_gap_to_prefer_non_alt, job->mpc, NULL, NULL, \
         p->match_reward, p->sub_penalty, p->gap_open_penalty, p->gap_extend_penalty, \
-        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator)
+        p->five_prime_end_bonus, p->three_prime_end_bonus, NULL, allocator))
     BaseAligner *aligner = NEW_SEC_ALIGNER();
     std::vector<char> bbuf(MAX_READ_LENGTH + 2 * SLACK, 0), qbuf(MAX_READ_LENGTH + 2 * SLACK, 0);
     // the result buffer of SingleAligner.cpp:176-190: [0] primary, [1..] secondary; doubled when AlignRead says it is too small

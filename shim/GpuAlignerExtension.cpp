@@ -123,8 +123,8 @@ public:
             return false;                                   // I/O-only mode: leave it to SNAP
         }
         PairedAlignerOptions *po = (PairedAlignerOptions *)c->options;
-        if (c->options->stopOnFirstHit || !c->ignoreAlignmentAdjustmentForOm || po->inferSpacing) {
-            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements for `paired` (-f, -ae, -ins)\n");
+        if (!c->ignoreAlignmentAdjustmentForOm || po->inferSpacing) {      // (-f / -x: accepted and without effect, as in the reference's paired-end aligners)
+            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements for `paired` (-ae, -ins)\n");
             soft_exit(1);
         }
         ensureContext(c, 25);
@@ -302,10 +302,6 @@ public:
     {
         if (c->index == NULL) {
             return false;                                   // I/O-only mode (SingleAligner.cpp:106-131): leave it to SNAP
-        }
-        if (c->options->stopOnFirstHit || c->options->explorePopularSeeds) {     // (an index with 5 .. 8-byte locations: snapgpu_create_from_directory narrows what fits 32 bits and refuses the rest)
-            WriteErrorMessage("snap-aligner-gpu: option outside what libsnapgpu implements (-f, -x)\n");
-            soft_exit(1);
         }
         // -ae (!ignoreAlignmentAdjustmentForOm): with -om the library adjusts primary and secondary results before its filter
         // (snapgpu_secondary_params::adjust_alignments); without, finalizeSecondaryResults has only the primary to adjust
@@ -578,6 +574,9 @@ private:
                             soft_exit(1);
                         }
                     }
+                    // -f / -x: SingleAligner.cpp:179-180 sets them on every BaseAligner it constructs; the paired-end contexts ignore them, as
+                    // the reference's paired-end aligners do (include/snapgpu.h: snapgpu_set_aligner_flags)
+                    snapgpu_set_aligner_flags(ctx, c->options->stopOnFirstHit ? 1 : 0, c->options->explorePopularSeeds ? 1 : 0);
                     slots[n].ctx = ctx;
                     pthread_mutex_init(&slots[n].lock, NULL);
                     n++;

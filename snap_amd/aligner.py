@@ -362,6 +362,12 @@ class BaseAligner:
         return primary, first_alt
 
     # ---- BaseAligner::AlignRead with secondary results (-om / -omax / -mpc) --------------
+    def set_flags(self, stop_on_first_hit: bool = False, explore_popular_seeds: bool = False):
+        """-f / -x: BaseAligner::setStopOnFirstHit / setExplorePopularSeeds (SingleAligner.cpp:179-180) for this context's single-end calls."""
+        self.lib.snapgpu_set_aligner_flags.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        self._check(self.lib.snapgpu_set_aligner_flags(self.handle, C.c_int(1 if stop_on_first_hit else 0), C.c_int(1 if explore_popular_seeds else 0)),
+                    "snapgpu_set_aligner_flags")
+
     def enable_secondary(self, max_edit_distance: int, max_results: int = 0x7fffffff, max_per_contig: int = -1,
                          adjust_alignments: int = 0):
         from .abi import secondary_params

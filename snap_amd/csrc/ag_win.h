@@ -508,6 +508,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int c_pt = lane * gap_ext + tagl;                            // p * ext + tag           (p = wbase + lane: + seg_len * ext per slide)
     int c_pm = k == 0 ? AG_HUGE : (lane - 1) * gap_ext + tagl;   // (p - 1) * ext + tag, "no F from the left" for vector 0
     int v_else = pbv == 5 ? -32768 : (pbv == 4 ? -1 : sub);      // profile entry of this lane's pattern base against a text base that differs from it
+    int v_else_n = pbv == 5 ? -32768 : -1;                       // ... against an 'N' of the text
     const int c_prev = (l == 0 ? lane : lane - num_vec) * 4;     // lazy F, rounds 1 .. 6: the same vector one stripe to the left (stripe 0: itself)
     const unsigned long long Lmid = first_u64(BALLOT(segsel == 1 && l >= 1 && l <= 6));   // the second segment's stripes whose ends are offered to somebody
     int c_ls = 0, c_g = 0;                                        // (follow nk like stepv: the closed form of the second segment's lazy F)
@@ -540,6 +541,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             V = vmask(wbase);
             c_pt += seg_len * gap_ext; c_pm += seg_len * gap_ext;
             v_else = pbv == 5 ? -32768 : (pbv == 4 ? -1 : sub);
+            v_else_n = pbv == 5 ? -32768 : -1;
         }
         int h_init0 = score_init;
         if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
@@ -560,9 +562,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         if (wbase == 0) lane0_in = h_init0;
         else lane0_in = (band_beg > wbase) ? 0 : left_h;
         const int h_in = ag_shr1(lane0_in, Hp);
-        int prof;
-        if (tb > 3) prof = pbv == 5 ? -32768 : -1;                 // (an 'N' of the text: rare)
-        else prof = pbv == tb ? match : v_else;
+        const int prof = tb > 3 ? v_else_n : (pbv == tb ? match : v_else);       // (tb > 3: an 'N' of the text)
         const int m = h_in > 0 ? ag_sat16(h_in + prof) : 0;
         const int e = E;
         unsigned long long M1 = BALLOT(e > m);                     // traceback bit 1: E wins over the diagonal
@@ -734,17 +734,30 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         } else {
             bt_store(sink, (uint32_t)i * 64u, (uint32_t)lane, (uint32_t)btr);       // (lanes outside the band write what they have; the traceback never reads them)
         }
-        const int mxv = inseg ? Hm : 0;
-        const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
         if (band_end == pattern_len - 1) {
             int gscore = pattern_len - 1 >= wbase ? __builtin_amdgcn_readlane(Hm, pattern_len - 1 >= wbase ? pattern_len - 1 - wbase : 0) : gl_m;
             if (gscore >= best_global) { best_global = gscore; best_global_text = i; }
         }
-        if (max_row == 0) break;
-        if (max_row > best_local) {
-            unsigned long long mk = BALLOT(Hm == max_row) & inseg_mask;
-            best_local_pat = mk ? wbase + 63 - __clzll((long long)mk) : -1;
-            best_local = max_row; best_local_text = i;
+        // The row maximum (:the loop ends on a row of zeros; a new best local score moves the local end).  Which cells beat the best so far is
+        // one compare; along an alignment it is ONE cell (the diagonal's), whose value is then the row maximum -- a readlane instead of a
+        // six-step reduction and a second ballot; no cell: only "is the row all zero" is left to ask; several: the reduction, as before.
+        const unsigned long long gtm = BALLOT(Hm > best_local) & inseg_mask;
+        if (gtm == 0ull) {
+            if ((BALLOT(Hm != 0) & inseg_mask) == 0ull) break;                       // max_row == 0
+        } else if ((gtm & (gtm - 1ull)) == 0ull) {
+            const int lb = (int)__builtin_ctzll(gtm);
+            const int max_row = __builtin_amdgcn_readlane(Hm, lb);                   // (> best_local >= -1)
+            if (max_row == 0) break;
+            best_local_pat = wbase + lb; best_local = max_row; best_local_text = i;
+        } else {
+            const int mxv = inseg ? Hm : 0;
+            const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
+            if (max_row == 0) break;
+            if (max_row > best_local) {
+                unsigned long long mk = BALLOT(Hm == max_row) & inseg_mask;
+                best_local_pat = mk ? wbase + 63 - __clzll((long long)mk) : -1;
+                best_local = max_row; best_local_text = i;
+            }
         }
         { int t = Hm; Hm = Hp; Hp = t; }
         { int t = gl_m; gl_m = gl_p; gl_p = t; }

@@ -65,6 +65,10 @@ struct AlignCfg {
     // se_help.h: a wave's list of candidates still to visit (se_items_cap words) and, per candidate-table element, where its candidates
     // start in that list (pool_size words), at byte se_off of the wave's scratch slab; se_items_cap == 0: no help in this context
     uint32_t se_items_cap; uint64_t se_off;
+    // -f / -x (AlignerOptions.cpp:571-574; BaseAligner::setStopOnFirstHit / setExplorePopularSeeds, SingleAligner.cpp:179-180): stop at the
+    // first location within maxK and report it as MultipleHits with MAPQ 0 (BaseAligner.cpp:1490-1505); apply the first maxHits hits of a
+    // seed with more than maxHits of them instead of skipping it (:574)
+    uint32_t stop_on_first_hit, explore_popular_seeds;
 };
 
 struct __attribute__((aligned(16))) Elem {   // HashTableElement, BaseAligner.h:223-258
@@ -1220,6 +1224,14 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                     }
                     if (HAM && agc != nullptr && n_agc >= agc_cap) { agc_overflow = 1; return true; }   // :1475 (the caller grows the buffer and retries)
 
+                    // -f (:1490-1505): the first location within maxK ends the search; MultipleHits and MAPQ 0, because nothing says it is the best
+                    if (cfg.stop_on_first_hit && ((uint32_t)all.best_score <= max_k || (HAM && all.best_score != SNAPGPU_UnusedScoreValue))) {
+                        if (cfg.alt_aware) fill_result(non_alt, primary); else fill_result(all, primary);
+                        primary.status = SNAPGPU_MultipleHits; primary.mapq = 0;
+                        first_alt.status = SNAPGPU_NotFound;
+                        WAVE_SYNC();
+                        return true;
+                    }
                     // early out: nothing can rescue MAPQ once the candidates' total probability reaches 4.9 (:1512)
                     double p_chk = cfg.alt_aware ? non_alt.p_all : all.p_all;
                     if (!SEC && p_chk >= 4.9) {                                                 // (&& -1 == maxEditDistanceForSecondaryResults)
@@ -1362,11 +1374,11 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 const int64_t dir_n_hits = dir ? hl[1].n_hits : hl[0].n_hits;
                 const uint32_t dir_singleton = dir ? hl[1].singleton : hl[0].singleton;
                 const uint32_t *dir_hits = dir ? hl[1].hits : hl[0].hits;
-                if (dir_n_hits > (int64_t)cfg.max_hits) {                 // too popular, :574-579
+                if (dir_n_hits > (int64_t)cfg.max_hits && !cfg.explore_popular_seeds) {                 // too popular, :574-579
                     popular_seeds_skipped++;
                 } else {
                     uint32_t offset = dir == 0 ? next_seed : (uint32_t)(len - seed_len) - next_seed;   // :591-606
-                    int64_t limit = dir_n_hits;
+                    int64_t limit = dir_n_hits < (int64_t)cfg.max_hits ? dir_n_hits : (int64_t)cfg.max_hits;      // :625 (only -x gets here with more than maxHits)
                     if (limit > 1) cnt.overflow_lists++;
                     cnt.hits += (uint64_t)limit;
                     for (int64_t c0 = 0; c0 < limit; c0 += WAVE) {

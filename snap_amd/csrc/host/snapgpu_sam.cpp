@@ -153,6 +153,7 @@ struct Options {
     bool clip_front = false, clip_back = true;                             // -C-+ (ClipBack) is the default
     int om = -1, mpc = -1; long long omax = 0x7fffffff;
     bool ae = false;                                                       // -ae: AlignmentAdjuster before the -om filter (single end only)
+    bool stop_on_first_hit = false, explore_popular_seeds = false;         // -f, -x (single end; the paired-end aligners ignore them, as the reference's do)
     int n_gpus = 0, ctx_per_gpu = 2, n_format = 0;
     uint32_t ops_stride = 64;
     bool bam = false;                                                      // -o x.bam: BAM records in BGZF blocks (SNAPLib/Bam.cpp)
@@ -915,6 +916,8 @@ int main(int argc, char **argv)
         else if (a == "-omax" && i + 1 < argc) o.omax = atoll(argv[++i]);
         else if (a == "-mpc" && i + 1 < argc) o.mpc = atoi(argv[++i]);
         else if (a == "-ae") o.ae = true;                                                    // AlignerOptions.cpp:476
+        else if (a == "-f") o.stop_on_first_hit = true;                                      // AlignerOptions.cpp:573
+        else if (a == "-x") o.explore_popular_seeds = true;                                  // AlignerOptions.cpp:570
         else if (a == "-ea") o.p.emit_alt_alignments = 1;                                  // the first ALT alignment as an extra record (SingleAligner.cpp:320-322)
         else if (a == "-D" && i + 1 < argc) o.p.extra_search_depth = (uint32_t)atoi(argv[++i]);
         else if (a == "-mrl" && i + 1 < argc) o.min_read_len = (unsigned)atoi(argv[++i]);
@@ -966,6 +969,7 @@ int main(int argc, char **argv)
     snapgpu_default_paired_params(&o.pp);
     o.pp.min_read_length = o.min_read_len;
     for (snapgpu_ctx *c : ctxs) {
+        snapgpu_set_aligner_flags(c, o.stop_on_first_hit ? 1 : 0, o.explore_popular_seeds ? 1 : 0);      // -f, -x (single-end launches only)
         if (o.paired) { rc = snapgpu_enable_paired(c, &o.pp); if (rc != SNAPGPU_OK) fail_rc(c, "snapgpu_enable_paired", rc); }
         if (o.om >= 0) {
             snapgpu_secondary_params sp; memset(&sp, 0, sizeof(sp));

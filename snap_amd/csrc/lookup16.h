@@ -19,19 +19,38 @@
 
 struct __attribute__((packed, aligned(4))) LkWords4 { uint32_t a, b, c, d; };      // four consecutive words at a 4-byte aligned address
 
-__global__ __launch_bounds__(256) void k_lookup_seeds20(DevIndex ix, uint32_t n, const uint8_t *seeds, long long *n_hits, uint32_t *hits,
-                                                        uint32_t max_hits_out, unsigned long long *counters)
+#ifndef LK_CHUNK
+#define LK_CHUNK 4              // passes (of eight seeds) a wave takes per visit to the work counter
+#endif
+#ifndef LK_DEPTH
+#define LK_DEPTH 4              // 16-byte list loads per lane in flight in the long-list loop (LK_DEPTH * 16 hits per group per round)
+#endif
+#ifdef LK_MINBLOCKS
+__global__ __launch_bounds__(256, LK_MINBLOCKS) void k_lookup_seeds20(
+#else
+__global__ __launch_bounds__(256) void k_lookup_seeds20(
+#endif
+DevIndex ix, uint32_t n, const uint8_t *seeds, long long *n_hits, uint32_t *hits,
+                                                        uint32_t max_hits_out, unsigned long long *counters, uint32_t *work)
 {
     const int lane = lane_id();
-    const uint32_t wave = (uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
-    const uint32_t n_waves = (uint32_t)((gridDim.x * blockDim.x) >> 6);
     const int q = lane >> 2, e = lane & 3;                 // probe group, lane inside it
     const int sidx = q >> 1, dir = q & 1;                  // which of the pass's eight seeds, which strand
     const uint32_t n_bases32 = (uint32_t)ix.n_bases;
     const uint64_t ovf_last = ix.overflow_size ? ix.overflow_size - 1 : 0;
     unsigned long long c_lookups = 0, c_lines = 0, c_hits = 0, c_lists = 0;
     uint32_t sink = 0;
-    for (uint32_t base = wave * 8; base < n; base += n_waves * 8) {
+    // Passes are handed out by an atomic counter, LK_CHUNK at a time: with a fixed stride per wave the launch lasts as long as the waves that
+    // start late -- the grid asks for 32 waves per CU and the kernel's registers let 20 .. 24 be resident, so a quarter of the waves began
+    // their share when the others were done (round 3).
+    const uint64_t n_passes = ((uint64_t)n + 7) / 8;
+    for (;;) {
+      uint32_t chunk0 = 0;
+      if (lane == 0) chunk0 = atomicAdd(work, (uint32_t)LK_CHUNK);
+      chunk0 = first_u32(chunk0);
+      if ((uint64_t)chunk0 >= n_passes) break;
+      for (uint32_t pass = chunk0; pass < chunk0 + LK_CHUNK && (uint64_t)pass < n_passes; pass++) {
+        const uint32_t base = pass * 8;
         const uint32_t n_here = n - base < 8 ? n - base : 8;
         // ---- the pass's text: 5 dwords per seed
         uint32_t w = 0x4e4e4e4eu;                                              // 'NNNN'
@@ -123,23 +142,38 @@ __global__ __launch_bounds__(256) void k_lookup_seeds20(DevIndex ix, uint32_t n,
                 if (j >= 0 && j < lim) { if (dst) dst[j] = hv[c]; else sink ^= hv[c]; }
             }
         }
-        // ---- the rest of the long lists, 16 hits per group per step, every group that still has some
+        // ---- the rest of the long lists: 16 hits per group per step, FOUR steps' loads issued before the first is consumed.  A pass lasts as
+        // long as its longest list (-h 300: 19 steps for a popular seed, and with sixteen lookups per pass most passes hold one), and a step
+        // that waits for its own load before the next is issued pays the full memory latency 19 times over (round 3: 4.2 G lookups/s, 1.0 TB/s
+        // at the memory side).  The addresses are known up front, so the loads of a whole 64-hit stretch go out together.
         long long next = 15;
         while (BALLOT(is_list && next < lim)) {
-            if (is_list && next < lim) {
-                const long long j = next + 4 * e;
-                uint64_t at = (uint64_t)ofs + 1u + (uint64_t)j;
-                if (j < lim) {
-                    if (j + 3 < lim && at + 3 <= ovf_last) {
-                        const LkWords4 x = *(const LkWords4 *)(ix.overflow + at);
+            LkWords4 xs[LK_DEPTH];
+            bool wide[LK_DEPTH];
+#pragma unroll
+            for (int c4 = 0; c4 < LK_DEPTH; c4++) {
+                const long long j = next + 16 * c4 + 4 * e;
+                const uint64_t at = (uint64_t)ofs + 1u + (uint64_t)j;
+                wide[c4] = is_list && j + 3 < lim && at + 3 <= ovf_last;
+                xs[c4] = LkWords4{0u, 0u, 0u, 0u};
+                if (wide[c4]) xs[c4] = *(const LkWords4 *)(ix.overflow + at);
+            }
+#pragma unroll
+            for (int c4 = 0; c4 < LK_DEPTH; c4++) {
+                const long long j = next + 16 * c4 + 4 * e;
+                const uint64_t at = (uint64_t)ofs + 1u + (uint64_t)j;
+                if (is_list && j < lim) {
+                    if (wide[c4]) {
+                        const LkWords4 x = xs[c4];
                         if (dst) { dst[j] = x.a; dst[j + 1] = x.b; dst[j + 2] = x.c; dst[j + 3] = x.d; } else sink ^= x.a ^ x.b ^ x.c ^ x.d;
                     } else {
                         for (int c = 0; c < 4 && j + c < lim; c++) { const uint32_t hvv = ix.overflow[at + (uint64_t)c]; if (dst) dst[j + c] = hvv; else sink ^= hvv; }
                     }
                 }
             }
-            next += 16;
+            next += 16 * LK_DEPTH;
         }
+      }
     }
     if (sink == 0xDEADBEEFu && n == 0xFFFFFFFFu) n_hits[0] = (long long)sink;       // keeps the hit loads alive when nothing is stored
     if (counters) {

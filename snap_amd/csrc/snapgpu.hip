@@ -370,6 +370,7 @@ struct snapgpu_ctx {
     // tails overlap anyway (measured: three feeders 130 ms per batch without, 140-147 ms with: profiles/r03g, r03h) -- such launches run the
     // exact form as their one pass, as in round 2.  SNAPGPU_SINGLE_HELP=1 forces the help on whatever the number of feeders, =0 off.
     std::shared_ptr<std::atomic<int>> feeders;
+    uint32_t stop_on_first_hit = 0, explore_popular_seeds = 0;      // snapgpu_set_aligner_flags: the single-end launches' -f / -x
     int single_help_forced = -1;
     SEHelpSlot *d_se_slots = nullptr; SESpec *d_se_spec = nullptr; uint32_t *d_se_ctl = nullptr; uint32_t se_spec_cap = 0;
     unsigned long long *d_dbg = nullptr;          // phase_timers: launch diagnostics of the last single-end launch (kernel_common.h: AlignArgs::dbg)
@@ -404,6 +405,14 @@ static int fail(snapgpu_ctx *ctx, int code, const std::string &msg) {
 }
 
 extern "C" int snapgpu_abi_version(void) { return SNAPGPU_ABI_VERSION; }
+
+extern "C" int snapgpu_set_aligner_flags(snapgpu_ctx *ctx, int stop_on_first_hit, int explore_popular_seeds)
+{
+    if (!ctx) return SNAPGPU_E_INVALID;
+    ctx->stop_on_first_hit = stop_on_first_hit ? 1u : 0u;
+    ctx->explore_popular_seeds = explore_popular_seeds ? 1u : 0u;
+    return SNAPGPU_OK;
+}
 // (index_build.hip reports through the same per-thread message as the functions of this file)
 extern "C" void snapgpu_set_last_error(const char *msg) { g_last_error = msg ? msg : ""; }
 
@@ -1121,8 +1130,9 @@ static void launch_lookup(snapgpu_ctx *ctx, uint32_t n, const void *d_seeds, voi
     const uint32_t maxb = (uint32_t)ctx->num_cus * 8;                                   // 32 waves per CU
     if (ctx->ix.bucket_blob && ctx->ix.seed_len == 20 && ctx->ix.key_bytes == 4 && ((uintptr_t)d_seeds & 3) == 0 && !getenv("SNAPGPU_LOOKUP8")) {
         uint32_t blocks = (n + 31) / 32; if (blocks > maxb) blocks = maxb;
+        (void)hipMemsetAsync(ctx->d_work + 40, 0, 4, s);                                   // the kernel's pass counter
         hipLaunchKernelGGL(k_lookup_seeds20, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
-                           (uint32_t *)d_hits, max_hits_out, d_counters);
+                           (uint32_t *)d_hits, max_hits_out, d_counters, ctx->d_work + 40);
     } else {
         uint32_t blocks = (n + 3) / 4; if (blocks > maxb) blocks = maxb;
         hipLaunchKernelGGL(k_lookup_seeds, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
@@ -1755,6 +1765,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.ix = ctx->ix; a.cfg = ctx->cfg; a.tab = ctx->d_tab; a.scratch = ctx->d_scratch;
     a.bases = (const uint8_t *)d_bases; a.quals = (const uint8_t *)d_quals; a.offsets = (const uint64_t *)d_offsets;
     a.n_reads = n; a.primary = (snapgpu_single_result *)d_primary; a.first_alt = (snapgpu_single_result *)d_first_alt;
+    a.cfg.stop_on_first_hit = ctx->stop_on_first_hit; a.cfg.explore_popular_seeds = ctx->explore_popular_seeds;
     a.work_counter = ctx->d_work; a.counters = ctx->d_counters;
     a.sec_cfg = SecCfg{-1, -1, 0, 0}; a.sec_scratch = nullptr; a.sec_stride_bytes = 0; a.secondary = nullptr; a.sec_out_stride = 0; a.n_secondary = nullptr;
     a.flag_list = nullptr; a.flag_count = nullptr; a.remap = nullptr; a.n_remap = nullptr; a.persist = nullptr; a.persist_stride = 0;

@@ -508,3 +508,14 @@ def test_emu_alignment_adjuster(emu, golden_index):
     ga.test_secondary_with_adjustment_vs_reference_fixture(golden_index, z, min_changed=20)
     assert emu.emu_partial_ops() == partial0 and emu.emu_inactive_reads() == inactive0      # the adjuster's control flow is wave-uniform
     ga.test_adjustment_is_single_end_only(golden_index)
+
+
+def test_emu_stop_on_first_hit_and_explore_popular_seeds(emu, tmp_path):
+    """tests/test_gpu_flags.py on the emulated device: -f / -x against the compiled reference running with the same flags (a smaller workload)."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built here")
+    import tests.test_gpu_flags as gf
+    partial0 = emu.emu_partial_ops()
+    gf.check_flags_vs_live_reference(tmp_path, n_reads=700, genome_bases=600_000, with_secondary=False)
+    assert emu.emu_partial_ops() == partial0
