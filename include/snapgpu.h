@@ -363,7 +363,7 @@ int  snapgpu_set_aligner_flags(snapgpu_ctx *ctx, int stop_on_first_hit, int expl
  * LIMITATION: the read is taken as one the reader has NOT clipped.  The reference settles a contig-end overhang on the start of the UNCLIPPED
  * buffer (AlignmentAdjuster.cpp:167), which differs from the clipped start for an RC result of a back-clipped read and for a forward result
  * of a front-clipped one; this interface is not given the unclipped bytes.  The callers that ship with the library (shim/, snapgpu-sam)
- * therefore refuse -ae for a read the reader actually clipped (run them with -C--).
+ * therefore refuse, under -ae, a read the reader actually clipped whose alignment reaches the end of its contig (run them with -C--).
  */
 int  snapgpu_adjust_alignments(snapgpu_ctx *ctx, uint32_t n, const char *data, uint64_t data_bytes, const uint64_t *off, const int32_t *len,
                                snapgpu_single_result *results);

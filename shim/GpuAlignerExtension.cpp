@@ -350,13 +350,6 @@ public:
                     }
                     continue;
                 }
-                // -ae: the device adjuster is restated for a Read the reader has not clipped (snap_amd/csrc/adjust.h: the reference settles a
-                // contig-end overhang on the UNCLIPPED buffer, AlignmentAdjuster.cpp:167, which the C ABI is not given).  A read that
-                // actually got clipped under -ae is refused rather than answered differently; -C-- switches the reader's clipping off.
-                if (!c->ignoreAlignmentAdjustmentForOm && read->getDataLength() != read->getUnclippedLength()) {
-                    WriteErrorMessage("snapgpu shim: -ae with a quality-clipped read (%.*s) is not supported: run with -C--\n", (int)read->getIdLength(), read->getId());
-                    soft_exit(1);
-                }
                 new (&reads[n]) ReadWithOwnMemory(*read);
                 bases.insert(bases.end(), read->getData(), read->getData() + read->getDataLength());
                 quals.insert(quals.end(), read->getQuality(), read->getQuality() + read->getDataLength());
@@ -381,6 +374,19 @@ public:
                     lens.resize(n);
                     for (unsigned i = 0; i < n; i++) lens[i] = (int32_t)(offs[i + 1] - offs[i]);
                     rc = snapgpu_adjust_alignments(slot->ctx, n, &bases[0], (uint64_t)bases.size(), &offs[0], &lens[0], &prim[0]);
+                    // The device adjuster is restated for a Read the reader has not clipped (snap_amd/csrc/adjust.h): the reference settles a
+                    // contig-end overhang on the UNCLIPPED buffer (AlignmentAdjuster.cpp:167), which only differs for a clipped read that
+                    // hangs over the end of its contig.  Such a read is refused rather than answered differently (-C-- avoids it).
+                    for (uint32_t i = 0; rc == SNAPGPU_OK && i < n; i++) {
+                        Read *rd = &reads[i];
+                        if (rd->getDataLength() == rd->getUnclippedLength() || prim[i].status == SNAPGPU_NotFound) continue;
+                        const Genome::Contig *ct = c->index->getGenome()->getContigAtLocation(GenomeLocation(prim[i].location));
+                        if (ct != NULL && prim[i].location + (int64_t)rd->getDataLength() + (int64_t)c->maxDist + 2 >
+                                          GenomeLocationAsInt64(ct->beginningLocation) + ct->length - c->index->getGenome()->getChromosomePadding()) {
+                            WriteErrorMessage("snapgpu shim: -ae: a quality-clipped read hangs over the end of its contig, which the adjuster does not reproduce (run with -C--)\n");
+                            soft_exit(1);
+                        }
+                    }
                 }
             }
             pthread_mutex_unlock(&slot->lock);

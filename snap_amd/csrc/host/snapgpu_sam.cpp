@@ -34,6 +34,11 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <chrono>
 #include <vector>
 #include <zlib.h>                        // gzread reads plain and gzip-compressed FASTQ alike (the reference takes .gz input too)
 
@@ -127,19 +132,113 @@ static bool next_read(LineReader &in, Batch &b, uint32_t max_read_len)
     const char *s; size_t n;
     do { if (!in.line(s, n)) return false; } while (n == 0);
     if (s[0] != '@') die("FASTQ record does not start with '@': ", std::string(s, n).c_str());
+    const size_t id_at = b.names.size();
     b.names.append(s + 1, n - 1); b.name_off.push_back((uint32_t)b.names.size());
-    const std::string id(s + 1, n - 1);
-    if (!in.line(s, n)) die("truncated FASTQ record: ", id.c_str());
+    auto id = [&]() { return std::string(b.names.data() + id_at, b.names.size() - id_at); };      // (only built for an error message)
+    if (!in.line(s, n)) die("truncated FASTQ record: ", id().c_str());
     const size_t len = n;
-    if (len > max_read_len) die("read longer than max_read_len (400; set SNAPGPU_MAX_READ_LEN, at most 1000): ", id.c_str());
+    if (len > max_read_len) die("read longer than max_read_len (400; set SNAPGPU_MAX_READ_LEN, at most 1000): ", id().c_str());
     b.bases.insert(b.bases.end(), s, s + n);
-    if (!in.line(s, n)) die("truncated FASTQ record: ", id.c_str());
-    if (n == 0 || s[0] != '+') die("FASTQ record without '+' line: ", id.c_str());
-    if (!in.line(s, n)) die("truncated FASTQ record: ", id.c_str());
-    if (n != len) die("FASTQ sequence and quality lengths differ: ", id.c_str());
+    if (!in.line(s, n)) die("truncated FASTQ record: ", id().c_str());
+    if (n == 0 || s[0] != '+') die("FASTQ record without '+' line: ", id().c_str());
+    if (!in.line(s, n)) die("truncated FASTQ record: ", id().c_str());
+    if (n != len) die("FASTQ sequence and quality lengths differ: ", id().c_str());
     b.quals.insert(b.quals.end(), s, s + n);
     b.offsets.push_back(b.bases.size());
     return true;
+}
+
+// ---------------------------------------------------------------------------------------- plain FASTQ, read by many threads
+// A plain (not gzip) FASTQ file is mapped and indexed by line count -- one pass, the chunks counted side by side -- so that record r is line
+// 4 r and any thread can parse any batch of records on its own (FASTQ.h:67 / ReadSupplierQueue.h:76: the reference's reader hands buffers
+// to a queue of supplier threads for the same reason).  A file whose lines do not come in fours (blank lines between records, which the
+// sequential reader skips) is read by the sequential reader instead; -seqread forces that reader.
+struct MappedFastq {
+    const char *p = NULL; size_t n = 0;
+    static const size_t CHUNK = 1u << 20;
+    std::vector<uint64_t> lines_before;       // lines that start before chunk c (c = 0 .. n_chunks)
+    uint64_t n_lines = 0;
+    bool open(const char *path) {
+        const int fd = ::open(path, O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) { ::close(fd); return false; }
+        unsigned char magic[2] = {0, 0};
+        if (pread(fd, magic, 2, 0) != 2 || (magic[0] == 0x1f && magic[1] == 0x8b)) { ::close(fd); return false; }      // gzip: the sequential reader
+        void *m = mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return false;
+        madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        p = (const char *)m; n = (size_t)st.st_size;
+        return true;
+    }
+    void close() { if (p) munmap((void *)p, n); p = NULL; }
+    // count the newlines of every chunk with `threads` threads; false when the lines do not come in fours
+    bool index(int threads) {
+        const size_t n_chunks = (n + CHUNK - 1) / CHUNK;
+        std::vector<uint64_t> cnt(n_chunks, 0);
+        std::atomic<size_t> next(0);
+        std::vector<std::thread> ts;
+        for (int t = 0; t < threads; t++)
+            ts.emplace_back([&] {
+                for (;;) {
+                    const size_t c = next.fetch_add(1);
+                    if (c >= n_chunks) break;
+                    const char *q = p + c * CHUNK, *e = p + (c + 1 == n_chunks ? n : (c + 1) * CHUNK);
+                    uint64_t k = 0;
+                    while (q < e) { const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q)); if (!nl) break; k++; q = nl + 1; }
+                    cnt[c] = k;
+                }
+            });
+        for (auto &t : ts) t.join();
+        lines_before.assign(n_chunks + 1, 0);
+        for (size_t c = 0; c < n_chunks; c++) lines_before[c + 1] = lines_before[c] + cnt[c];
+        n_lines = lines_before[n_chunks] + (p[n - 1] != '\n' ? 1 : 0);          // (a last line without its newline)
+        return n_lines % 4 == 0;
+    }
+    // byte offset of the start of line L (0-based; L < n_lines)
+    size_t line_start(uint64_t L) const {
+        if (L == 0) return 0;
+        // the chunk in which newline number L (1-based) lies: lines_before[c] < L <= lines_before[c + 1]
+        size_t lo = 0, hi = lines_before.size() - 1;
+        while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (lines_before[mid] < L) lo = mid; else hi = mid; }
+        const char *q = p + lo * CHUNK, *e = p + n;
+        uint64_t k = lines_before[lo];
+        while (q < e) { const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q)); if (!nl) break; q = nl + 1; if (++k == L) return (size_t)(q - p); }
+        return n;
+    }
+};
+
+// `count` records starting at byte `at` of a mapped file, appended to the batch (every `step`-th slot when two files are interleaved is the
+// caller's business: paired batches call this per record).  Returns the byte after the last record.
+static inline size_t parse_mapped_record(const MappedFastq &f, size_t at, Batch &b, uint32_t max_read_len)
+{
+    const char *p = f.p, *e = f.p + f.n;
+    auto line = [&](const char *&s, size_t &n) -> bool {
+        if (at >= f.n) return false;
+        const char *q = p + at;
+        const char *nl = (const char *)memchr(q, '\n', (size_t)(e - q));
+        s = q; n = nl ? (size_t)(nl - q) : (size_t)(e - q); at += n + (nl ? 1 : 0);
+        if (n > 0 && s[n - 1] == '\r') n--;
+        return true;
+    };
+    const char *s; size_t n;
+    if (!line(s, n)) die("truncated FASTQ file");
+    if (n == 0 || s[0] != '@') die("FASTQ record does not start with '@' (blank lines between records? -seqread reads such files): ", std::string(s, n < 80 ? n : 80).c_str());
+    const size_t id_at = b.names.size();
+    b.names.append(s + 1, n - 1); b.name_off.push_back((uint32_t)b.names.size());
+    auto id = [&]() { return std::string(b.names.data() + id_at, b.names.size() - id_at); };
+    if (!line(s, n)) die("truncated FASTQ record: ", id().c_str());
+    const size_t len = n;
+    if (len > max_read_len) die("read longer than max_read_len (400; set SNAPGPU_MAX_READ_LEN, at most 1000): ", id().c_str());
+    b.bases.insert(b.bases.end(), s, s + n);
+    if (!line(s, n)) die("truncated FASTQ record: ", id().c_str());
+    if (n == 0 || s[0] != '+') die("FASTQ record without '+' line: ", id().c_str());
+    if (!line(s, n)) die("truncated FASTQ record: ", id().c_str());
+    if (n != len) die("FASTQ sequence and quality lengths differ: ", id().c_str());
+    b.quals.insert(b.quals.end(), s, s + n);
+    b.offsets.push_back(b.bases.size());
+    return at;
 }
 
 // ---------------------------------------------------------------------------------------- options, shared state
@@ -154,7 +253,8 @@ struct Options {
     int om = -1, mpc = -1; long long omax = 0x7fffffff;
     bool ae = false;                                                       // -ae: AlignmentAdjuster before the -om filter (single end only)
     bool stop_on_first_hit = false, explore_popular_seeds = false;         // -f, -x (single end; the paired-end aligners ignore them, as the reference's do)
-    int n_gpus = 0, ctx_per_gpu = 2, n_format = 0;
+    int n_gpus = 0, ctx_per_gpu = 2, n_format = 0, n_parse = 0;
+    bool seqread = false;                                                  // -seqread: the sequential FASTQ reader even for a plain file
     uint32_t ops_stride = 64;
     bool bam = false;                                                      // -o x.bam: BAM records in BGZF blocks (SNAPLib/Bam.cpp)
 };
@@ -377,10 +477,6 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
     std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
     for (size_t i = 0; i < n; i++) {
         if (clip_read(o, b, i, front_clip[i], data_len[i])) {
-            // (-ae: the adjuster is restated for reads the reader has not clipped -- adjust.h; the reference settles a contig-end overhang on
-            //  the UNCLIPPED buffer, AlignmentAdjuster.cpp:167 -- so a read that actually got clipped is refused, not answered differently)
-            if (o.ae && (front_clip[i] != 0 || (uint64_t)data_len[i] != b.offsets[i + 1] - b.offsets[i]))
-                die("-ae with a quality-clipped read is not supported (the adjuster works on reads the reader has not clipped): run with -C--");
             to_align.push_back((uint32_t)i);
             const char *q = b.quals.data() + b.offsets[i] + front_clip[i], *s = b.bases.data() + b.offsets[i] + front_clip[i];
             ab.insert(ab.end(), s, s + data_len[i]); aq.insert(aq.end(), q, q + data_len[i]); ao.push_back(ab.size());
@@ -414,6 +510,18 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
                 std::vector<int32_t> lens(to_align.size());
                 for (size_t k = 0; k < to_align.size(); k++) lens[k] = (int32_t)(ao[k + 1] - ao[k]);
                 rc = snapgpu_adjust_alignments(ctx, (uint32_t)to_align.size(), ab.data(), (uint64_t)ab.size(), ao.data(), lens.data(), aligned_res.data());
+                // The adjuster is restated for reads the reader has not clipped (adjust.h): the reference settles a contig-end overhang on the
+                // UNCLIPPED buffer (AlignmentAdjuster.cpp:167), which only differs for a clipped read that hangs over the end of its contig.
+                // Such a read is refused rather than answered differently (-C-- switches the reader's clipping off).
+                for (size_t a = 0; rc == SNAPGPU_OK && a < to_align.size(); a++) {
+                    const size_t i = to_align[a];
+                    if (front_clip[i] == 0 && (uint64_t)data_len[i] == b.offsets[i + 1] - b.offsets[i]) continue;
+                    const snapgpu_single_result &r = aligned_res[a];
+                    if (r.status == SNAPGPU_NotFound) continue;
+                    const int c = h_contig_at(r.location);
+                    if (c >= 0 && r.location + data_len[i] + (long long)o.p.max_k + 2 > h_contig_end(c) - (long long)g_padding)
+                        die("-ae: a quality-clipped read hangs over the end of its contig, which the adjuster does not reproduce (run with -C--)");
+                }
             }
         }
         if (rc != SNAPGPU_OK) fail_rc(ctx, "alignment", rc);
@@ -925,6 +1033,8 @@ int main(int argc, char **argv)
         else if (a == "-gpus" && i + 1 < argc) o.n_gpus = atoi(argv[++i]);
         else if (a == "-q" && i + 1 < argc) o.ctx_per_gpu = atoi(argv[++i]);
         else if (a == "-t" && i + 1 < argc) o.n_format = atoi(argv[++i]);  // host threads that format records (the reference's -t counts aligner threads)
+        else if (a == "-tp" && i + 1 < argc) o.n_parse = atoi(argv[++i]);  // host threads that parse a plain FASTQ file
+        else if (a == "-seqread") o.seqread = true;
         else die("option not supported: ", a.c_str());
     }
     if (out_path.empty()) die("-o <out.sam | out.bam> is required");
@@ -937,6 +1047,7 @@ int main(int argc, char **argv)
     // cigar ops per record: about 2 * edits + soft clips; grown on demand when a record needs more (with_growing_stride)
     { uint32_t need = 2 * (o.p.max_k + o.p.extra_search_depth) + 8; o.ops_stride = 64; while (o.ops_stride < need) o.ops_stride *= 2; }
 
+    const auto t_process = std::chrono::steady_clock::now();
     std::vector<Contig> contigs; uint64_t n_bases = 0; uint32_t padding = 0;
     load_contigs(index_dir, contigs, n_bases, padding);
     g_contigs = &contigs; g_n_bases = n_bases; g_padding = padding;
@@ -978,7 +1089,11 @@ int main(int argc, char **argv)
             if (rc != SNAPGPU_OK) fail_rc(c, "snapgpu_enable_secondary", rc);
         }
     }
-    if (o.n_format <= 0) { unsigned hc = std::thread::hardware_concurrency(); o.n_format = (int)(hc > 16 ? 16 : (hc ? hc : 4)); }
+    // host threads: formatting a record is ~1 us of text work, so one GPU's ~5 M records/s want a few dozen formatters (the cap of 16 of
+    // rounds 2-3 was the pipeline's bottleneck on a 256-thread host); parsers likewise
+    { const unsigned hc = std::thread::hardware_concurrency() ? std::thread::hardware_concurrency() : 8;
+      if (o.n_format <= 0) { unsigned v = hc / 3; o.n_format = (int)(v < 4 ? 4 : (v > 64 ? 64 : v)); }
+      if (o.n_parse <= 0) { unsigned v = hc / 8; o.n_parse = (int)(v < 2 ? 2 : (v > 24 ? 24 : v)); } }
 
     const std::string partial_path = out_path + ".partial";
     FILE *out = fopen(partial_path.c_str(), "wb");
@@ -1011,13 +1126,52 @@ int main(int argc, char **argv)
         } else if (fwrite(text.data(), 1, text.size(), out) != text.size()) die("write error on ", out_path.c_str());
     }
 
+    const auto t_ready = std::chrono::steady_clock::now();                  // the index is resident, the contexts exist: the streaming part starts here
     // ---- the pipeline
     Queue<Work *> q_parsed(ctxs.size() * 2 + 2), q_aligned((size_t)o.n_format * 2 + 2);
     std::mutex done_m; std::condition_variable done_cv; std::map<uint64_t, Work *> done;
     std::atomic<uint64_t> n_batches(0); std::atomic<bool> reader_done(false);
     unsigned long long total = 0, mapped = 0;
 
-    std::thread reader([&] {
+    // ---- input: a plain FASTQ file is mapped, indexed by line count and parsed batch by batch by o.n_parse threads; gzip input, -seqread
+    // and files whose lines do not come in fours go through the sequential reader
+    MappedFastq mf, mf2;
+    bool use_map = !o.seqread && mf.open(fastq.c_str()) && (!o.paired || mf2.open(fastq2.c_str()));
+    if (use_map) {
+        const auto t0 = std::chrono::steady_clock::now();
+        use_map = mf.index(o.n_parse) && (!o.paired || mf2.index(o.n_parse));
+        if (use_map && o.paired && mf.n_lines != mf2.n_lines) die(mf.n_lines > mf2.n_lines ? "the second FASTQ file has fewer reads than the first" : "the second FASTQ file has more reads than the first");
+        if (use_map && getenv("SNAPGPU_SAM_VERBOSE")) fprintf(stderr, "snapgpu-sam: %llu FASTQ records indexed in %.2f s\n", (unsigned long long)(mf.n_lines / 4), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    if (!use_map) { mf.close(); mf2.close(); }
+    std::vector<std::thread> parsers;
+    std::thread reader;
+    if (use_map) {
+        const uint64_t n_records = mf.n_lines / 4;
+        const uint64_t per_batch = o.paired ? o.batch_reads / 2 : o.batch_reads;           // records of EACH file per batch
+        const uint64_t n_units = (n_records + per_batch - 1) / per_batch;
+        n_batches = n_units; reader_done = true;
+        std::shared_ptr<std::atomic<uint64_t>> next_unit = std::make_shared<std::atomic<uint64_t>>(0);
+        std::shared_ptr<std::atomic<int>> parsers_left = std::make_shared<std::atomic<int>>(o.n_parse);
+        for (int t = 0; t < o.n_parse; t++)
+            parsers.emplace_back([&, next_unit, parsers_left, n_records, per_batch, n_units] {
+                for (;;) {
+                    const uint64_t u = next_unit->fetch_add(1);
+                    if (u >= n_units) break;
+                    const uint64_t r0 = u * per_batch, r1 = r0 + per_batch < n_records ? r0 + per_batch : n_records;
+                    Work *w = new Work();
+                    w->b.clear(); w->b.seq = u; w->bam = o.bam;
+                    size_t at = mf.line_start(4 * r0), at2 = o.paired ? mf2.line_start(4 * r0) : 0;
+                    for (uint64_t r = r0; r < r1; r++) {
+                        at = parse_mapped_record(mf, at, w->b, o.p.max_read_len);
+                        if (o.paired) at2 = parse_mapped_record(mf2, at2, w->b, o.p.max_read_len);
+                    }
+                    q_parsed.push(w);
+                }
+                if (--*parsers_left == 0) { q_parsed.close(); std::lock_guard<std::mutex> l(done_m); done_cv.notify_all(); }
+            });
+    } else
+    reader = std::thread([&] {
         LineReader in, in2;
         in.open(fastq.c_str());
         if (o.paired) in2.open(fastq2.c_str());
@@ -1069,7 +1223,9 @@ int main(int argc, char **argv)
         total += w->b.n(); mapped += w->mapped;
         delete w;
     }
-    reader.join();
+    if (reader.joinable()) reader.join();
+    for (auto &t : parsers) t.join();
+    mf.close(); mf2.close();
     for (auto &t : feeders) t.join();
     for (auto &t : formatters) t.join();
     if (o.bam) { std::string eof; bgzf_append(eof, "", 0); if (fwrite(eof.data(), 1, eof.size(), out) != eof.size()) die("write error on ", out_path.c_str()); }     // the empty end-of-file block
@@ -1078,5 +1234,11 @@ int main(int argc, char **argv)
     g_partial_path.clear();
     for (size_t t = ctxs.size(); t-- > 0;) snapgpu_destroy(ctxs[t]);        // sharers before the owner of the blobs they share
     fprintf(stderr, "snapgpu-sam: %llu reads, %llu mapped records, %d GPU(s) x %d feeder(s), %d formatter thread(s)\n", total, mapped, o.n_gpus, o.ctx_per_gpu, o.n_format);
+    {   // (AlignerContext.cpp:489-543 prints reads/s over the alignment phase, the index load apart: the same split here)
+        const auto t_end = std::chrono::steady_clock::now();
+        const double s_load = std::chrono::duration<double>(t_ready - t_process).count(), s_stream = std::chrono::duration<double>(t_end - t_ready).count();
+        fprintf(stderr, "snapgpu-sam: index resident after %.2f s; FASTQ -> %s in %.2f s = %.0f reads/s (%s reader, %d parser thread(s))\n", s_load, o.bam ? "BAM" : "SAM", s_stream,
+                s_stream > 0 ? (double)total / s_stream : 0.0, use_map ? "mapped" : "sequential", use_map ? o.n_parse : 1);
+    }
     return 0;
 }

@@ -19,9 +19,6 @@
 
 struct __attribute__((packed, aligned(4))) LkWords4 { uint32_t a, b, c, d; };      // four consecutive words at a 4-byte aligned address
 
-#ifndef LK_CHUNK
-#define LK_CHUNK 4              // passes (of eight seeds) a wave takes per visit to the work counter
-#endif
 #ifndef LK_DEPTH
 #define LK_DEPTH 4              // 16-byte list loads per lane in flight in the long-list loop (LK_DEPTH * 16 hits per group per round)
 #endif
@@ -31,7 +28,7 @@ __global__ __launch_bounds__(256, LK_MINBLOCKS) void k_lookup_seeds20(
 __global__ __launch_bounds__(256) void k_lookup_seeds20(
 #endif
 DevIndex ix, uint32_t n, const uint8_t *seeds, long long *n_hits, uint32_t *hits,
-                                                        uint32_t max_hits_out, unsigned long long *counters, uint32_t *work)
+                                                        uint32_t max_hits_out, unsigned long long *counters)
 {
     const int lane = lane_id();
     const int q = lane >> 2, e = lane & 3;                 // probe group, lane inside it
@@ -40,17 +37,14 @@ DevIndex ix, uint32_t n, const uint8_t *seeds, long long *n_hits, uint32_t *hits
     const uint64_t ovf_last = ix.overflow_size ? ix.overflow_size - 1 : 0;
     unsigned long long c_lookups = 0, c_lines = 0, c_hits = 0, c_lists = 0;
     uint32_t sink = 0;
-    // Passes are handed out by an atomic counter, LK_CHUNK at a time: with a fixed stride per wave the launch lasts as long as the waves that
-    // start late -- the grid asks for 32 waves per CU and the kernel's registers let 20 .. 24 be resident, so a quarter of the waves began
-    // their share when the others were done (round 3).
-    const uint64_t n_passes = ((uint64_t)n + 7) / 8;
-    for (;;) {
-      uint32_t chunk0 = 0;
-      if (lane == 0) chunk0 = atomicAdd(work, (uint32_t)LK_CHUNK);
-      chunk0 = first_u32(chunk0);
-      if ((uint64_t)chunk0 >= n_passes) break;
-      for (uint32_t pass = chunk0; pass < chunk0 + LK_CHUNK && (uint64_t)pass < n_passes; pass++) {
-        const uint32_t base = pass * 8;
+    // (a fixed stride per wave: the host sizes the grid to what is resident at once -- hipOccupancyMaxActiveBlocksPerMultiprocessor -- so that
+    //  every wave starts at the beginning and does an equal share.  Round 3 launched 32 waves per CU where the registers let 20 .. 24 run, and
+    //  the launch lasted as long as the quarter that started late; handing passes out with an atomic counter instead was measured TWICE AS
+    //  SLOW (profiles/r04i: 344 k same-address device-scope atomics in 2 ms).)
+    const uint32_t wave = (uint32_t)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const uint32_t n_waves = (uint32_t)((gridDim.x * blockDim.x) >> 6);
+    {
+      for (uint32_t base = wave * 8; base < n; base += n_waves * 8) {
         const uint32_t n_here = n - base < 8 ? n - base : 8;
         // ---- the pass's text: 5 dwords per seed
         uint32_t w = 0x4e4e4e4eu;                                              // 'NNNN'

@@ -1130,9 +1130,18 @@ static void launch_lookup(snapgpu_ctx *ctx, uint32_t n, const void *d_seeds, voi
     const uint32_t maxb = (uint32_t)ctx->num_cus * 8;                                   // 32 waves per CU
     if (ctx->ix.bucket_blob && ctx->ix.seed_len == 20 && ctx->ix.key_bytes == 4 && ((uintptr_t)d_seeds & 3) == 0 && !getenv("SNAPGPU_LOOKUP8")) {
         uint32_t blocks = (n + 31) / 32; if (blocks > maxb) blocks = maxb;
-        (void)hipMemsetAsync(ctx->d_work + 40, 0, 4, s);                                   // the kernel's pass counter
+        // as many blocks as are resident at once (see the kernel): every wave then does an equal share of the passes from the start
+        static int resident_per_cu = 0;
+        if (resident_per_cu == 0) {
+            int nb = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lookup_seeds20, 256, 0) != hipSuccess || nb <= 0) nb = 4;
+            if (const char *e = getenv("SNAPGPU_LOOKUP_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) nb = v; }
+            resident_per_cu = nb > 8 ? 8 : nb;
+        }
+        const uint32_t fit = (uint32_t)ctx->num_cus * (uint32_t)resident_per_cu;
+        if (blocks > fit) blocks = fit;
         hipLaunchKernelGGL(k_lookup_seeds20, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
-                           (uint32_t *)d_hits, max_hits_out, d_counters, ctx->d_work + 40);
+                           (uint32_t *)d_hits, max_hits_out, d_counters);
     } else {
         uint32_t blocks = (n + 3) / 4; if (blocks > maxb) blocks = maxb;
         hipLaunchKernelGGL(k_lookup_seeds, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
