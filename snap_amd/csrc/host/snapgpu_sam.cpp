@@ -248,12 +248,12 @@ struct Options {
     snapgpu_paired_params pp;
     bool use_m = true;                                                     // AlignerOptions.cpp:58
     unsigned min_read_len = 50;                                            // -mrl
-    size_t batch_reads = 65536;
+    size_t batch_reads = 131072;
     bool clip_front = false, clip_back = true;                             // -C-+ (ClipBack) is the default
     int om = -1, mpc = -1; long long omax = 0x7fffffff;
     bool ae = false;                                                       // -ae: AlignmentAdjuster before the -om filter (single end only)
     bool stop_on_first_hit = false, explore_popular_seeds = false;         // -f, -x (single end; the paired-end aligners ignore them, as the reference's do)
-    int n_gpus = 0, ctx_per_gpu = 2, n_format = 0, n_parse = 0;
+    int n_gpus = 0, ctx_per_gpu = 3, n_format = 0, n_parse = 0;
     bool seqread = false;                                                  // -seqread: the sequential FASTQ reader even for a plain file
     uint32_t ops_stride = 64;
     bool bam = false;                                                      // -o x.bam: BAM records in BGZF blocks (SNAPLib/Bam.cpp)

@@ -297,7 +297,39 @@ __global__ __launch_bounds__(64) void k_ag_sequence_resolve(AGBatchArgs a)
 static thread_local std::string g_last_error;
 static thread_local const struct snapgpu_ctx *g_share_buckets_from = nullptr;      // snapgpu_create_replica(share_index): adopt these bucket tables
 
+struct DevPool {
+    struct Slot { void *p; size_t cap; bool busy; };
+    std::vector<Slot> slots;
+    std::mutex m;
+    void *acquire(size_t bytes, hipError_t *err) {
+        std::lock_guard<std::mutex> l(m);
+        int best = -1;
+        for (size_t i = 0; i < slots.size(); i++)
+            if (!slots[i].busy && slots[i].cap >= bytes && slots[i].cap <= 4 * bytes + 65536 && (best < 0 || slots[i].cap < slots[(size_t)best].cap)) best = (int)i;
+        if (best >= 0) { slots[(size_t)best].busy = true; *err = hipSuccess; return slots[(size_t)best].p; }
+        void *p = nullptr;
+        const size_t cap = bytes + bytes / 4 + 256;
+        *err = hipMalloc(&p, cap);
+        if (*err != hipSuccess) {                    // (make room: drop what is idle, try once more)
+            for (auto &s : slots) if (!s.busy && s.p) { (void)hipFree(s.p); s.p = nullptr; s.cap = 0; }
+            *err = hipMalloc(&p, cap);
+            if (*err != hipSuccess) return nullptr;
+        }
+        slots.push_back(Slot{p, cap, true});
+        return p;
+    }
+    void release(void *p) {
+        std::lock_guard<std::mutex> l(m);
+        for (auto &s : slots) if (s.p == p) { s.busy = false; return; }
+    }
+    void free_all() {
+        std::lock_guard<std::mutex> l(m);
+        for (auto &s : slots) if (s.p) (void)hipFree(s.p);
+        slots.clear();
+    }
+};
 struct snapgpu_ctx {
+    DevPool pool;                           // device buffers of the host-pointer entry points, kept between calls
     int device = -1;
     hipStream_t stream = nullptr;
     DevIndex ix{};
@@ -550,6 +582,7 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->d_order) (void)hipFree(ctx->d_order);
     if (ctx->d_wbucket) (void)hipFree(ctx->d_wbucket);
     if (ctx->d_whist) (void)hipFree(ctx->d_whist);
+    ctx->pool.free_all();
     if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     for (int i = 0; i < 5; i++) if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
@@ -1188,11 +1221,25 @@ extern "C" int snapgpu_lookup_seeds_device(snapgpu_ctx *ctx, uint32_t n, const v
 }
 
 // small RAII helper for per-call device buffers of the (test-oriented) batch primitives
+// Device buffers of the host-pointer entry points.  Until round 4 each call hipMalloc'ed its buffers and hipFree'd them on return -- fifteen
+// of them in snapgpu_sam_fields_single, half a gigabyte of per-wave scratch among them, and every hipFree synchronises the device: at 65 536
+// reads per batch snapgpu-sam spent ~200 ms per batch there against ~25 ms of kernels (profiles/r04j: 0.58 M reads/s end to end).  Now a
+// context keeps what it has allocated: a buffer goes back to the context's pool when the call returns and the next call of a similar size
+// takes it again.  (Calls on one context are serial, and every entry point synchronises its stream before it returns.)
+static thread_local DevPool *t_pool = nullptr;       // the pool of the context whose entry point this thread is in
+struct PoolScope {
+    DevPool *prev;
+    explicit PoolScope(DevPool *p) : prev(t_pool) { t_pool = p; }
+    ~PoolScope() { t_pool = prev; }
+};
 struct DevBuf {
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevPool *from = nullptr;
+    ~DevBuf() { if (p) { if (from) from->release(p); else (void)hipFree(p); } }
     hipError_t put(const void *src, size_t bytes, hipStream_t s) {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+        hipError_t e;
+        if (t_pool) { from = t_pool; p = from->acquire(bytes ? bytes : 16, &e); }
+        else e = hipMalloc(&p, bytes ? bytes : 16);
         if (e != hipSuccess) return e;
         if (src && bytes) return hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s);
         return hipSuccess;
@@ -1216,6 +1263,7 @@ extern "C" int snapgpu_landau_vishkin(snapgpu_ctx *ctx, int dir, uint32_t n,
         if (kk > (int)kmax) kmax = (uint32_t)kk;
     }
     hipStream_t s = ctx->stream;
+    PoolScope pool_scope(&ctx->pool);
     DevBuf dt, dto, dtl, dp, dq, dpo, dpl, dk, ds, dpr, dni, dti, dts;
     HIPCHK(ctx, dt.put(texts, texts_bytes, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, dto.put(text_off, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
@@ -1289,6 +1337,7 @@ extern "C" int snapgpu_compute_cigar_lv(snapgpu_ctx *ctx, uint32_t n, const char
     const uint32_t per_wave = lvc_lds_bytes(RL);
     uint32_t blocks = (uint32_t)ctx->num_cus * 4;                    // persistent grid: 16 waves per CU
     const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
+    PoolScope pool_scope(&ctx->pool);
     DevBuf dd, doff, dlen, dloc, dxb, dscr, dops, dno, ded, dafc, dxa;
     HIPCHK(ctx, dd.put(data, data_bytes, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, doff.put(off, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
@@ -1342,6 +1391,7 @@ extern "C" int snapgpu_adjust_alignments(snapgpu_ctx *ctx, uint32_t n, const cha
     uint32_t blocks = (uint32_t)ctx->num_cus * 4;
     const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     const uint64_t stride = 2 * (uint64_t)((RL + 255) & ~255u) + ((adjust_scratch_bytes(RL) + 255) & ~(uint64_t)255);
+    PoolScope pool_scope(&ctx->pool);
     DevBuf dd, doff, dlen, dres, dscr;
     HIPCHK(ctx, dd.put(data, data_bytes, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, doff.put(off, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
@@ -1390,6 +1440,7 @@ extern "C" int snapgpu_compute_cigar_ag(snapgpu_ctx *ctx, uint32_t n, const char
     uint32_t blocks = (uint32_t)ctx->num_cus * 4;
     const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     const uint64_t scratch_stride = (agc_scratch_bytes(RL) + 255) & ~(uint64_t)255;
+    PoolScope pool_scope(&ctx->pool);
     DevBuf dd, dq, doff, dlen, dloc, dxb, dsc, dscr, dops, dno, ded, dafc, dxa, dti, dst;
     HIPCHK(ctx, dd.put(data, data_bytes, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, dq.put(quals, data_bytes, s), SNAPGPU_E_NOMEM);
@@ -1464,6 +1515,7 @@ extern "C" int snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const cha
     const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     const uint64_t scratch_stride = ((2 * (uint64_t)RL + 255) & ~(uint64_t)255) + ((lvc_scratch_bytes() + 255) & ~255u) + ((agc_scratch_bytes(RL) + 255) & ~(uint64_t)255);
     const uint64_t total = offsets[n];
+    PoolScope pool_scope(&ctx->pool);
     DevBuf db, dq, doff, dfc, ddl, dres, dscr, dflag, dctg, dpos, dmq, dops, dno, dnm, dst;
     HIPCHK(ctx, db.put(bases, total, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, dq.put(quals, total, s), SNAPGPU_E_NOMEM);
@@ -1529,6 +1581,7 @@ extern "C" int snapgpu_sam_fields_single_device(snapgpu_ctx *ctx, uint32_t n, ui
     uint32_t blocks = (uint32_t)ctx->num_cus * 4;
     const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     const uint64_t scratch_stride = ((2 * (uint64_t)RL + 255) & ~(uint64_t)255) + ((lvc_scratch_bytes() + 255) & ~255u) + ((agc_scratch_bytes(RL) + 255) & ~(uint64_t)255);
+    PoolScope pool_scope(&ctx->pool);
     DevBuf dscr;
     HIPCHK(ctx, dscr.put(nullptr, (size_t)blocks * 4 * scratch_stride, s), SNAPGPU_E_NOMEM);
     SamFieldsArgs a;
@@ -1584,6 +1637,7 @@ extern "C" int snapgpu_sam_fields_paired(snapgpu_ctx *ctx, uint32_t n_pairs, con
     const uint32_t need = (n_pairs + 3) / 4; if (blocks > need) blocks = need;
     const uint64_t scratch_stride = ((2 * (uint64_t)RL + 255) & ~(uint64_t)255) + ((lvc_scratch_bytes() + 255) & ~255u) + ((agc_scratch_bytes(RL) + 255) & ~(uint64_t)255);
     const uint64_t total = offsets[n];
+    PoolScope pool_scope(&ctx->pool);
     DevBuf db, dq, doff, dfc, ddl, dres, dscr, dflag, dctg, dpos, dmq, dops, dno, dnm, drn, dpn, dtl, dfw, dst;
     HIPCHK(ctx, db.put(bases, total, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, dq.put(quals, total, s), SNAPGPU_E_NOMEM);
@@ -1655,6 +1709,7 @@ static int affine_gap_batch(snapgpu_ctx *ctx, int dir, uint32_t n,
     const uint32_t waves_per_block = 1;
     uint32_t blocks = n; uint32_t maxb = (uint32_t)ctx->num_cus * 8; if (blocks > maxb) blocks = maxb;
     if (sequence) blocks = 1;
+    PoolScope pool_scope(&ctx->pool);
     DevBuf dt, dto, dtl, dp, dq, dpo, dpl, dw, dsi, drc, dbd, dcl, dscratch, o1, o2, o3, o4, o5, o6;
     HIPCHK(ctx, dt.put(texts, texts_bytes, s), SNAPGPU_E_NOMEM);
     HIPCHK(ctx, dto.put(text_off, (size_t)n * 4, s), SNAPGPU_E_NOMEM);

@@ -135,6 +135,7 @@ struct hipDeviceProp_t {
     int warpSize;
 };
 
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int *nb, K, int, size_t) { *nb = 8; return hipSuccess; }      // (no occupancy on the emulated device: any grid runs)
 hipError_t hipGetDeviceCount(int *n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d);

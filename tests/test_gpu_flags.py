@@ -43,7 +43,7 @@ def check_flags_vs_live_reference(tmp_path, n_reads=6000, genome_bases=1_500_000
                 a.enable_secondary(1)
                 pgs, ags, sgs, ngs = a.AlignReadSecondary(rd["bases"][:1500], rd["quals"][:1500], rd["offsets"][:1501])
                 assert not util.compare_results(prs, pgs), (f, x, "with -om 1")
-                assert not util.compare_secondary(srs, nrs, sgs, ngs, None), (f, x, "with -om 1")
+                assert not util.compare_secondary(srs, nrs, sgs, ngs, np.zeros(len(nrs), bool)), (f, x, "with -om 1")
         finally:
             a.close()
         changed[(f, x)] = int(sum(1 for k in ("status", "location", "score", "mapq") if (pr[k] != base[k]).any()))
