@@ -24,6 +24,7 @@ ap.add_argument("--skip-reference", action="store_true")
 ap.add_argument("--shim", action="store_true")
 ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
 ap.add_argument("--keep", action="store_true")
+ap.add_argument("--tool-args", default="", help="extra arguments for snapgpu-sam, one string")
 a = ap.parse_args()
 n = a.n
 
@@ -85,7 +86,7 @@ def run(tag, cmd, env=None):
     t1 = time.time()
     nrec, hx = hash_records(sam) if r.returncode == 0 else (0, "")
     o = {"rc": r.returncode, "wall_s": dt, "reads_per_s_wall": n / dt, "records": nrec, "records_hash": hx, "hash_s": time.time() - t1,
-         "sam_bytes": os.path.getsize(sam) if os.path.exists(sam) else 0, "tool_tail": [l[:300] for l in txt.strip().splitlines()[-3:]]}
+         "sam_bytes": os.path.getsize(sam) if os.path.exists(sam) else 0, "tool_tail": [l[:300] for l in txt.strip().splitlines()[-4:]]}
     m = re.search(r"index resident after ([\d.]+) s; FASTQ -> \w+ in ([\d.]+) s = (\d+) reads/s", txt)
     if m:
         o["index_load_s"], o["stream_s"], o["reads_per_s_streaming"] = float(m.group(1)), float(m.group(2)), float(m.group(3))
@@ -95,7 +96,9 @@ def run(tag, cmd, env=None):
         os.remove(sam)
 
 
-run("snapgpu_sam", [os.path.join(ROOT, "snap_amd", "snapgpu-sam"), "single", idx, fq, "-d", "8"], env=dict(os.environ, SNAPGPU_SAM_VERBOSE="1"))
+run("snapgpu_sam", [os.path.join(ROOT, "snap_amd", "snapgpu-sam"), "single", idx, fq, "-d", "8"] + a.tool_args.split(), env=dict(os.environ, SNAPGPU_SAM_VERBOSE="1"))
+for extra in [x for x in os.environ.get("E2E_SWEEP", "").split(";") if x.strip()]:          # e.g. E2E_SWEEP="-b 1048576 -q 3;-b 1048576 -q 4"
+    run("snapgpu_sam " + extra.strip(), [os.path.join(ROOT, "snap_amd", "snapgpu-sam"), "single", idx, fq, "-d", "8"] + extra.split(), env=dict(os.environ, SNAPGPU_SAM_VERBOSE="1"))
 if a.shim:
     run("snap_aligner_gpu_shim", [os.path.join(ROOT, "oracle", "_ref", "snap-aligner-gpu"), "single", idx, fq, "-d", "8", "-t", "8"])
 if not a.skip_reference:

@@ -7,6 +7,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from snap_amd import abi, synth
 from snap_amd.aligner import BaseAligner
+if os.environ.get("SNAPGPU_AB_LIB"):            # an A/B build of the library (scripts/ab_bench.py build <name>): measurement only
+    import snap_amd.aligner as _al
+    _al.LIB_PATH = os.path.abspath(os.environ["SNAPGPU_AB_LIB"]); _al._lib = None
 from snap_amd.index import GenomeIndex
 from oracle import ref
 

@@ -78,7 +78,11 @@ extern "C" void snapgpu_launch_cigar_ag(const CigarAGArgs *a, uint32_t blocks, s
 }
 
 // result -> computed fields of the SAM record (sam_fields.h): one wavefront per read
-__global__ __launch_bounds__(256, 4) void k_sam_fields(SamFieldsArgs a)
+#ifndef SAMF_WAVES
+#define SAMF_WAVES 8            // waves per SIMD the SAM-field kernels are built for (blocks of four waves: as many blocks per CU).  The kernels are
+                                // latency-bound (8 of 64 lanes in the affine-gap CIGAR): 4.32 M reads/s at 4 (131 VGPRs, rounds 2-3), 5.31 M at 6, 5.73 M at 8 (profiles/r04n)
+#endif
+__global__ __launch_bounds__(256, SAMF_WAVES) void k_sam_fields(SamFieldsArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id();
@@ -127,7 +131,7 @@ extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t block
 }
 
 // paired-end writer: both reads of a pair by one wavefront, then SAMFormat::fillMateInfo for each (sam_fields.h)
-__global__ __launch_bounds__(256, 4) void k_sam_fields_paired(SamFieldsPairedArgs a)
+__global__ __launch_bounds__(256, SAMF_WAVES) void k_sam_fields_paired(SamFieldsPairedArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int lane = lane_id();

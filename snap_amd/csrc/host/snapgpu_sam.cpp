@@ -47,6 +47,13 @@
 // The output is written to "<out>.partial" and renamed when it is complete, so that a run that stops half way (an input error, one of the
 // unsupported paired -om corners below) never leaves a truncated SAM -- or a BAM without its end-of-file block -- under the name asked for.
 static std::string g_partial_path;
+// where the host threads' time goes (SNAPGPU_SAM_VERBOSE=1 prints it): nanoseconds summed over the threads of a kind
+static std::atomic<unsigned long long> g_ns_prep(0), g_ns_align(0), g_ns_mid(0), g_ns_samcall(0), g_ns_format(0), g_ns_write(0), g_ns_parse(0);
+struct StageTimer {
+    std::atomic<unsigned long long> &acc; std::chrono::steady_clock::time_point t0;
+    explicit StageTimer(std::atomic<unsigned long long> &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~StageTimer() { acc += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
 static void die(const char *msg, const char *arg = "") {
     fprintf(stderr, "snapgpu-sam: %s%s\n", msg, arg);
     if (!g_partial_path.empty()) remove(g_partial_path.c_str());
@@ -274,6 +281,9 @@ struct Work {                                // a batch on its way through the p
     std::vector<uint32_t> pu_pair; std::vector<char> pu_secondary;       // per pair unit: the pair it belongs to, flag 0x100
     std::vector<uint32_t> su_read;                                       // per single unit: the read (2 * pair + mate)
     std::vector<int32_t> s_flag, s_contig, s_mapq, s_n_ops, s_nm; std::vector<int64_t> s_pos; std::vector<uint32_t> s_ops; uint32_t s_ops_stride = 64;
+    // single end: what prepare_single() leaves for the feeder
+    bool prepared = false;
+    std::vector<int32_t> front_clip, data_len; std::vector<uint32_t> to_align; std::vector<char> ab, aq; std::vector<uint64_t> ao;
     std::string text;                        // the formatted records (BAM: BGZF blocks)
     bool bam = false;
     unsigned long long mapped = 0;
@@ -468,20 +478,34 @@ template <class F> static void with_growing_stride(Work &w, size_t n_rec, F call
     }
 }
 
-static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
+// Read::clip and the useless-read filter for a batch, and the reads to align gathered into one buffer: host work that does not need the GPU,
+// done by the parser threads where there are several (the feeder threads' time belongs to the device)
+static void prepare_single(const Options &o, Work &w)
 {
     const Batch &b = w.b;
     const size_t n = b.n();
-    std::vector<int32_t> front_clip(n, 0), data_len(n, 0);
-    std::vector<uint32_t> to_align;
-    std::vector<char> ab, aq; std::vector<uint64_t> ao(1, 0);
+    w.front_clip.assign(n, 0); w.data_len.assign(n, 0); w.to_align.clear(); w.ab.clear(); w.aq.clear(); w.ao.assign(1, 0);
+    w.ab.reserve(b.bases.size()); w.aq.reserve(b.quals.size()); w.ao.reserve(n + 1); w.to_align.reserve(n);
     for (size_t i = 0; i < n; i++) {
-        if (clip_read(o, b, i, front_clip[i], data_len[i])) {
-            to_align.push_back((uint32_t)i);
-            const char *q = b.quals.data() + b.offsets[i] + front_clip[i], *s = b.bases.data() + b.offsets[i] + front_clip[i];
-            ab.insert(ab.end(), s, s + data_len[i]); aq.insert(aq.end(), q, q + data_len[i]); ao.push_back(ab.size());
+        if (clip_read(o, b, i, w.front_clip[i], w.data_len[i])) {
+            w.to_align.push_back((uint32_t)i);
+            const char *q = b.quals.data() + b.offsets[i] + w.front_clip[i], *s = b.bases.data() + b.offsets[i] + w.front_clip[i];
+            w.ab.insert(w.ab.end(), s, s + w.data_len[i]); w.aq.insert(w.aq.end(), q, q + w.data_len[i]); w.ao.push_back(w.ab.size());
         }
     }
+    w.prepared = true;
+}
+
+static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
+{
+    auto t_stage = std::chrono::steady_clock::now();
+    auto lap = [&](std::atomic<unsigned long long> &acc) { const auto t = std::chrono::steady_clock::now(); acc += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(t - t_stage).count(); t_stage = t; };
+    const Batch &b = w.b;
+    const size_t n = b.n();
+    if (!w.prepared) prepare_single(o, w);            // (the parser threads of the mapped reader have done it already)
+    std::vector<int32_t> &front_clip = w.front_clip, &data_len = w.data_len;
+    std::vector<uint32_t> &to_align = w.to_align;
+    std::vector<char> &ab = w.ab, &aq = w.aq; std::vector<uint64_t> &ao = w.ao;
     std::vector<snapgpu_single_result> results(n), aligned_res(to_align.size()), alt_res(to_align.size());
     for (size_t i = 0; i < n; i++) {                                       // SingleAligner.cpp:215-225
         memset(&results[i], 0, sizeof(results[i]));
@@ -494,6 +518,7 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
     if (!to_align.empty()) {
         std::vector<snapgpu_single_result> sec; std::vector<uint32_t> nsec(to_align.size(), 0);
         uint32_t stride = 0;
+        lap(g_ns_prep);
         if (o.om >= 0) {
             stride = 8;
             for (;;) {
@@ -525,6 +550,7 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
             }
         }
         if (rc != SNAPGPU_OK) fail_rc(ctx, "alignment", rc);
+        lap(g_ns_align);
         std::vector<uint32_t> slot(n, 0xffffffffu);
         for (size_t k = 0; k < to_align.size(); k++) { results[to_align[k]] = aligned_res[k]; slot[to_align[k]] = (uint32_t)k; }
         for (size_t i = 0; i < n; i++) {
@@ -551,6 +577,7 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
     w.flag.assign(nr, 0); w.contig.assign(nr, 0); w.mapq.assign(nr, 0); w.n_ops.assign(nr, 0); w.nm.assign(nr, 0); w.pos.assign(nr, 0);
     std::vector<int32_t> stale(nr);
     w.ops_stride = o.ops_stride;
+    lap(g_ns_mid);
     with_growing_stride(w, nr, [&] {
         int rc2 = one_to_one
             ? snapgpu_sam_fields_single(ctx, (uint32_t)nr, b.bases.data(), b.quals.data(), b.offsets.data(), front_clip.data(), data_len.data(), rec_res.data(),
@@ -560,6 +587,7 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
                                         w.flag.data(), w.contig.data(), w.pos.data(), w.mapq.data(), w.ops.data(), w.ops_stride, w.n_ops.data(), w.nm.data(), stale.data());
         if (rc2 != SNAPGPU_OK) fail_rc(ctx, "snapgpu_sam_fields_single", rc2);
     });
+    lap(g_ns_samcall);
     for (size_t r = 0; r < nr; r++) if (w.rec_secondary[r]) w.flag[r] |= 0x100;                  // SAM_SECONDARY (createSAMLine, SAM.cpp:1477-1479)
 }
 
@@ -1160,12 +1188,15 @@ int main(int argc, char **argv)
                     if (u >= n_units) break;
                     const uint64_t r0 = u * per_batch, r1 = r0 + per_batch < n_records ? r0 + per_batch : n_records;
                     Work *w = new Work();
+                    StageTimer *pt = new StageTimer(g_ns_parse);
                     w->b.clear(); w->b.seq = u; w->bam = o.bam;
                     size_t at = mf.line_start(4 * r0), at2 = o.paired ? mf2.line_start(4 * r0) : 0;
                     for (uint64_t r = r0; r < r1; r++) {
                         at = parse_mapped_record(mf, at, w->b, o.p.max_read_len);
                         if (o.paired) at2 = parse_mapped_record(mf2, at2, w->b, o.p.max_read_len);
                     }
+                    if (!o.paired) prepare_single(o, *w);
+                    delete pt;
                     q_parsed.push(w);
                 }
                 if (--*parsers_left == 0) { q_parsed.close(); std::lock_guard<std::mutex> l(done_m); done_cv.notify_all(); }
@@ -1206,7 +1237,7 @@ int main(int argc, char **argv)
         formatters.emplace_back([&] {
             Work *w;
             while (q_aligned.pop(w)) {
-                if (o.paired) format_paired(contigs, *w); else format_single(contigs, *w);
+                { StageTimer st(g_ns_format); if (o.paired) format_paired(contigs, *w); else format_single(contigs, *w); }
                 if (o.bam) { std::string z; z.reserve(w->text.size() / 3 + 64); bgzf_append(z, w->text.data(), w->text.size()); w->text.swap(z); }
                 std::lock_guard<std::mutex> l(done_m); done[w->b.seq] = w; done_cv.notify_all();
             }
@@ -1219,7 +1250,7 @@ int main(int argc, char **argv)
             if (!done.count(next)) break;
             w = done[next]; done.erase(next);
         }
-        if (fwrite(w->text.data(), 1, w->text.size(), out) != w->text.size()) die("write error on ", out_path.c_str());
+        { StageTimer st(g_ns_write); if (fwrite(w->text.data(), 1, w->text.size(), out) != w->text.size()) die("write error on ", out_path.c_str()); }
         total += w->b.n(); mapped += w->mapped;
         delete w;
     }
@@ -1239,6 +1270,9 @@ int main(int argc, char **argv)
         const double s_load = std::chrono::duration<double>(t_ready - t_process).count(), s_stream = std::chrono::duration<double>(t_end - t_ready).count();
         fprintf(stderr, "snapgpu-sam: index resident after %.2f s; FASTQ -> %s in %.2f s = %.0f reads/s (%s reader, %d parser thread(s))\n", s_load, o.bam ? "BAM" : "SAM", s_stream,
                 s_stream > 0 ? (double)total / s_stream : 0.0, use_map ? "mapped" : "sequential", use_map ? o.n_parse : 1);
+        if (getenv("SNAPGPU_SAM_VERBOSE"))
+            fprintf(stderr, "snapgpu-sam: thread-seconds: parse %.2f | feeders: prepare %.2f, align call %.2f, records %.2f, SAM-fields call %.2f | format %.2f | write %.2f\n",
+                    g_ns_parse.load() * 1e-9, g_ns_prep.load() * 1e-9, g_ns_align.load() * 1e-9, g_ns_mid.load() * 1e-9, g_ns_samcall.load() * 1e-9, g_ns_format.load() * 1e-9, g_ns_write.load() * 1e-9);
     }
     return 0;
 }

@@ -1226,7 +1226,9 @@ extern "C" int snapgpu_lookup_seeds_device(snapgpu_ctx *ctx, uint32_t n, const v
 // reads per batch snapgpu-sam spent ~200 ms per batch there against ~25 ms of kernels (profiles/r04j: 0.58 M reads/s end to end).  Now a
 // context keeps what it has allocated: a buffer goes back to the context's pool when the call returns and the next call of a similar size
 // takes it again.  (Calls on one context are serial, and every entry point synchronises its stream before it returns.)
-static thread_local DevPool *t_pool = nullptr;       // the pool of the context whose entry point this thread is in
+static thread_local DevPool *t_pool = nullptr;
+// blocks per CU of the SAM-field kernels' persistent grids (SNAPGPU_SAMF_BLOCKS_PER_CU: measurement knob; default 8 = the kernels' launch bounds)
+static uint32_t samf_blocks_per_cu() { static int v = 0; if (!v) { const char *e = getenv("SNAPGPU_SAMF_BLOCKS_PER_CU"); v = e ? atoi(e) : 8; if (v < 1 || v > 8) v = 8; } return (uint32_t)v; }       // the pool of the context whose entry point this thread is in
 struct PoolScope {
     DevPool *prev;
     explicit PoolScope(DevPool *p) : prev(t_pool) { t_pool = p; }
@@ -1511,7 +1513,7 @@ extern "C" int snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const cha
     hipStream_t s = ctx->stream;
     const uint32_t per_wave = agc_lds_bytes(RL);
     if ((size_t)4 * per_wave > 64 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "snapgpu_sam_fields_single: reads too long for the LDS rows");
-    uint32_t blocks = (uint32_t)ctx->num_cus * 4;
+    uint32_t blocks = (uint32_t)ctx->num_cus * samf_blocks_per_cu();
     const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     const uint64_t scratch_stride = ((2 * (uint64_t)RL + 255) & ~(uint64_t)255) + ((lvc_scratch_bytes() + 255) & ~255u) + ((agc_scratch_bytes(RL) + 255) & ~(uint64_t)255);
     const uint64_t total = offsets[n];
@@ -1578,7 +1580,7 @@ extern "C" int snapgpu_sam_fields_single_device(snapgpu_ctx *ctx, uint32_t n, ui
     const uint32_t RL = max_read_len < 64 ? 64 : max_read_len;
     const uint32_t per_wave = agc_lds_bytes(RL);
     if ((size_t)4 * per_wave > 64 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "snapgpu_sam_fields_single_device: reads too long for the LDS rows");
-    uint32_t blocks = (uint32_t)ctx->num_cus * 4;
+    uint32_t blocks = (uint32_t)ctx->num_cus * samf_blocks_per_cu();
     const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     const uint64_t scratch_stride = ((2 * (uint64_t)RL + 255) & ~(uint64_t)255) + ((lvc_scratch_bytes() + 255) & ~255u) + ((agc_scratch_bytes(RL) + 255) & ~(uint64_t)255);
     PoolScope pool_scope(&ctx->pool);
@@ -1633,7 +1635,7 @@ extern "C" int snapgpu_sam_fields_paired(snapgpu_ctx *ctx, uint32_t n_pairs, con
     hipStream_t s = ctx->stream;
     const uint32_t per_wave = agc_lds_bytes(RL);
     if ((size_t)4 * per_wave > 64 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "snapgpu_sam_fields_paired: reads too long for the LDS rows");
-    uint32_t blocks = (uint32_t)ctx->num_cus * 4;
+    uint32_t blocks = (uint32_t)ctx->num_cus * samf_blocks_per_cu();
     const uint32_t need = (n_pairs + 3) / 4; if (blocks > need) blocks = need;
     const uint64_t scratch_stride = ((2 * (uint64_t)RL + 255) & ~(uint64_t)255) + ((lvc_scratch_bytes() + 255) & ~255u) + ((agc_scratch_bytes(RL) + 255) & ~(uint64_t)255);
     const uint64_t total = offsets[n];
