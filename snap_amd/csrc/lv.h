@@ -287,7 +287,7 @@ static __device__ __forceinline__ LVResult lv_compute(
     const PSeq &P, const QSeq &Q, int pattern_len, const TSeq &T, int text_len, int k,
     uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap, const LvPlanes *planes = nullptr)
 {
-#if !defined(SNAPGPU_AG_LV_FUNCTIONS)
+#if !defined(SNAPGPU_AG_LV_FUNCTIONS) || (defined(SNAPGPU_LV_INLINE) && !defined(PAIRED_AGC))      // (SNAPGPU_LV_INLINE: LV inlined in the single-end kernels, affine gap still a function)
     return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, planes);
 #else
     // (the planes' LDS pointers cross the call as 32-bit LDS addresses)

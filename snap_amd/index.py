@@ -136,8 +136,42 @@ class GenomeIndex:
             overflow = np.zeros(1, dtype=np.uint32)   # keep a valid pointer
 
         # --- GenomeIndexHash ------------------------------------------------------
-        raw = np.fromfile(os.path.join(directory, "GenomeIndexHash"), dtype=np.uint8)
         value_count = 1 if small else 2
+        if not wide:
+            # 4-byte locations (the north star's shape; ~25 GB at GRCh38 scale): every table's slots are read straight into their place in
+            # ONE array -- the file is never held a second time (reading it whole and concatenating the tables cost twice its size in host
+            # memory on the rank that loads the directory before the broadcast)
+            entry = 4 * value_count + key_bytes
+            path = os.path.join(directory, "GenomeIndexHash")
+            fsize = os.path.getsize(path)
+            hdr_bytes = n_tables * (32 + location_size)
+            hash_blob = np.zeros(fsize - hdr_bytes + 16, dtype=np.uint8)        # 16 bytes of slack: 8-byte device loads of the last slot stay in bounds
+            offs = np.zeros(n_tables, dtype=np.uint64)
+            sizes = np.zeros(n_tables, dtype=np.uint64)
+            out_pos = 0
+            with open(path, "rb") as f:
+                for t in range(n_tables):
+                    h = np.frombuffer(f.read(32 + location_size), dtype=np.uint8)
+                    if h.size != 32 + location_size or int(h[0:4].view(np.uint32)[0]) != HASH_MAGIC:
+                        raise ValueError("hash table %d: bad header" % t)
+                    table_size = int(h[4:12].view(np.uint64)[0])
+                    ks, vs, vc = [int(x) for x in h[20:32].view(np.uint32)]
+                    if ks != key_bytes or vs != location_size or vc != value_count:
+                        raise ValueError("hash table %d: key/value sizes %d/%d/%d do not match header" % (t, ks, vs, vc))
+                    nbytes = table_size * entry
+                    got = f.readinto(memoryview(hash_blob)[out_pos:out_pos + nbytes])
+                    if got != nbytes:
+                        raise ValueError("GenomeIndexHash truncated in table %d" % t)
+                    offs[t] = out_pos; sizes[t] = table_size
+                    out_pos += nbytes
+                if f.read(1):
+                    raise ValueError("GenomeIndexHash: trailing bytes")
+            if out_pos + 16 != hash_blob.size:
+                raise ValueError("GenomeIndexHash: %d bytes of tables, file says %d" % (out_pos, hash_blob.size - 16))
+            return GenomeIndex(seed_len=seed_len, key_bytes=key_bytes, n_hash_tables=n_tables, large=not small, location_size=4,
+                               chromosome_padding=padding, overflow=overflow, hash_blob=hash_blob, table_offset=offs, table_size=sizes,
+                               genome_padded=genome_padded, n_bases=n_bases, contigs=contigs, directory=directory)
+        raw = np.fromfile(os.path.join(directory, "GenomeIndexHash"), dtype=np.uint8)
         entry = 4 * value_count + key_bytes
         src_entry = location_size * value_count + key_bytes
         all_ones = (1 << (8 * location_size)) - 1

@@ -76,8 +76,14 @@ def _unstable_names(workload, extra_params):
     idx = GenomeIndex.load_from_directory(workload["index"])
     extra_params = dict(extra_params)
     secondary = extra_params.pop("secondary", None)         # (-om, -omax, -mpc)
+    flags = extra_params.pop("flags", None)                 # (-f, -x)
+    max_hits = extra_params.pop("max_hits", None)
     p = abi.default_params(max_read_len=400, **extra_params)
+    if max_hits is not None:
+        p.max_hits = max_hits
     a = BaseAligner(idx, p)
+    if flags:
+        a.set_flags(stop_on_first_hit=flags[0], explore_popular_seeds=flags[1])
     def clip(s):                                            # ClipBack (the CLI default, -C-+): drop the trailing '#' run
         n = len(s[1])
         while n > 0 and s[1][n - 1] == ord("#"):
@@ -104,6 +110,8 @@ def _unstable_names(workload, extra_params):
     (["-D", "2", "-om", "2", "-mpc", "2"], {"extra_search_depth": 2, "secondary": (2, 0x7fffffff, 2)}),
     (["-ae"], {}),                                                            # AlignmentAdjuster on the primary (BaseAligner.cpp:2444-2452)
     (["-ae", "-om", "1"], {"secondary": (1, 0x7fffffff, -1)}),                # ... and on every secondary result, before the -om filter
+    (["-f"], {"flags": (True, False)}),                                       # stopOnFirstHit (snapgpu_set_aligner_flags, round 4)
+    (["-x", "-h", "20"], {"flags": (False, True), "max_hits": 20}),           # explorePopularSeeds, with a -h low enough for it to matter
 ])
 def test_sam_identical_to_reference_cli(workload, opts, params):
     d = workload["dir"]
@@ -132,8 +140,9 @@ def test_sam_identical_to_reference_cli(workload, opts, params):
 
 
 def test_shim_fails_loudly_on_unsupported_option(workload):
-    r = subprocess.run([GPU_CLI, "single", workload["index"], workload["fastq"], "-o", os.path.join(workload["dir"], "x.sam"),
-                        "-f"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=300)
+    # (-ins, inferSpacing, is not implemented for the paired-end path: the shim must say so, not run the reference's aligner instead)
+    r = subprocess.run([GPU_CLI, "paired", workload["index"], workload["fastq"], workload["fastq"], "-o", os.path.join(workload["dir"], "x.sam"),
+                        "-ins"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=300)
     assert r.returncode != 0
     assert b"libsnapgpu" in r.stdout
 
