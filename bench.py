@@ -273,7 +273,9 @@ def run_leg(args, env, bed, workload, primary):
         return synth.make_reads(sd_, genome, args.reads, args.read_len)   # 1% sub, .05% ins/del, 50% RC, Q20-40
     t0 = time.time()
     from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=n_batches) as ex:          # (numpy releases the GIL in the large operations: the batches are drawn side by side)
+    # (numpy releases the GIL in the large operations: the batches are drawn side by side -- ~5 GB of temporaries each, so fewer at a time
+    #  when several ranks share the host)
+    with ThreadPoolExecutor(max_workers=max(1, min(n_batches, 6 if world == 1 else 2))) as ex:
         batches = list(ex.map(make_batch, range(n_batches)))
     log("%s: %d read batch(es) generated in %.1fs" % (workload, n_batches, time.time() - t0))
     reads = batches[0]
@@ -710,10 +712,10 @@ def main():
         except Exception:          # noqa: BLE001
             host_avail = 1 << 62
         # (host: each rank holds the 3.1 GB genome + its read batches; rank 0 also the FASTA text while it writes it)
-        fits = free_b >= 64e9 and host_avail >= 8e9 * world + 40e9
+        fits = free_b >= 64e9 and host_avail >= 20e9 * world + 40e9
         args.genome_mb = 3100 if fits else 256
         env["genome_choice"] = ("auto: GRCh38 scale (device has %.0f GB free)" % (free_b / 1e9) if fits
-                                else "auto: the 256 Mb stand-in, because the device has %.0f GB free / the host %.0f GB available (3100 Mb needs 64 / 48)" % (free_b / 1e9, host_avail / 1e9))
+                                else "auto: the 256 Mb stand-in, because the device has %.0f GB free / the host %.0f GB available (3100 Mb needs 64 GB of HBM and 40 + 20 per rank GB of host memory)" % (free_b / 1e9, host_avail / 1e9))
         log(env["genome_choice"])
 
     # ---------------------------------------------------------------- the line's own leg
