@@ -519,3 +519,54 @@ def test_emu_stop_on_first_hit_and_explore_popular_seeds(emu, tmp_path):
     partial0 = emu.emu_partial_ops()
     gf.check_flags_vs_live_reference(tmp_path, n_reads=700, genome_bases=600_000, with_secondary=False)
     assert emu.emu_partial_ops() == partial0
+
+
+def test_emu_native_fastq_readers_agree(emu, tmp_path):
+    """snapgpu-sam's mapped, multi-threaded FASTQ reader (round 4) and its sequential reader write the same file whatever the shape of the
+    input: CRLF line ends, no newline at the end, blank lines between records and gzip (both fall back to the sequential reader), -seqread,
+    one or many parser threads, batches that end inside the file's chunks; and the mapped reader refuses what the sequential one refuses."""
+    import gzip
+    import subprocess
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.emu.build import TOOL
+    from tests.test_zz_gpu_native_sam import make_workload, sam_lines
+    d = str(tmp_path)
+    index_dir, fastq = make_workload(d, 260, genome_bases=300_000)
+    raw = open(fastq, "rb").read()
+    recs = raw.split(b"\n")
+    assert recs[-1] == b"" and (len(recs) - 1) % 4 == 0
+    variants = {"plain": raw,
+                "crlf": raw.replace(b"\n", b"\r\n"),
+                "no_final_newline": raw[:-1],
+                "blank_lines": b"\n".join(b"\n".join(recs[i:i + 4]) + (b"\n" if (i // 4) % 7 == 3 else b"") for i in range(0, len(recs) - 1, 4)) + b"\n"}
+    env = dict(os.environ, SNAPGPU_EMU_CUS="4", SNAPGPU_SAM_VERBOSE="1")
+
+    def run(path, opts, expect_reader):
+        out = os.path.join(d, "o_%d.sam" % len(os.listdir(d)))
+        r = subprocess.run([TOOL, "single", index_dir, path, "-o", out] + opts, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=1200, env=env)
+        assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+        assert ("(%s reader" % expect_reader).encode() in r.stdout, r.stdout.decode(errors="replace")[-600:]
+        return sam_lines(out)
+    paths = {}
+    for k, v in variants.items():
+        paths[k] = os.path.join(d, k + ".fq"); open(paths[k], "wb").write(v)
+    paths["gz"] = os.path.join(d, "plain.fq.gz")
+    with gzip.open(paths["gz"], "wb") as f:
+        f.write(raw)
+    want = run(paths["plain"], ["-seqread"], "sequential")
+    assert len(want) > 260
+    assert run(paths["plain"], [], "mapped") == want
+    assert run(paths["plain"], ["-tp", "1", "-b", "97"], "mapped") == want          # batches of 97 records cut the file's 1 MB chunks anywhere
+    assert run(paths["plain"], ["-tp", "7", "-b", "31"], "mapped") == want
+    assert run(paths["crlf"], [], "mapped") == want
+    assert run(paths["no_final_newline"], ["-b", "50"], "mapped") == want
+    assert run(paths["blank_lines"], [], "sequential") == want                       # lines do not come in fours: the sequential reader takes over
+    assert run(paths["gz"], [], "sequential") == want
+    # a malformed record is refused by both readers (the mapped one names the way out)
+    bad = os.path.join(d, "bad.fq")
+    open(bad, "wb").write(raw.replace(b"\n+\n", b"\n-\n", 1))
+    for opts in ([], ["-seqread"]):
+        r = subprocess.run([TOOL, "single", index_dir, bad, "-o", os.path.join(d, "bad.sam")] + opts, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=600, env=env)
+        assert r.returncode != 0 and b"'+' line" in r.stdout
