@@ -89,6 +89,12 @@ static int score_limit(const A *a, int for_alt) {                       /* :2556
     return (int)(v < MAXK - 1 ? v : MAXK - 1);
 }
 
+/* -f / -x (BaseAligner::setStopOnFirstHit / setExplorePopularSeeds, SingleAligner.cpp:179-180): set for the calls that follow, like
+ * oracle/ref_driver.cpp's snapref_set_aligner_flags.  Single-end AlignRead only (the chimeric fallback's aligner never gets them). */
+static int g_stop_on_first_hit = 0, g_explore_popular_seeds = 0;
+static __thread int t_flags_apply = 0;                                  /* 1 inside oracle_align_read (the single-end AlignRead proper) */
+void oracle_set_aligner_flags(int stop_on_first_hit, int explore_popular_seeds) { g_stop_on_first_hit = stop_on_first_hit; g_explore_popular_seeds = explore_popular_seeds; }
+
 static int contig_at(const oracle_genome *g, int64_t loc) {             /* Genome::getContigAtLocation, Genome.cpp:574 */
     int lo = 0, hi = (int)g->n_contigs - 1, found = -1;
     while (lo <= hi) {
@@ -433,6 +439,12 @@ static int score(A *a, int force_result) {
                 e->match_prob = mp; e->best_score = sc;
                 update_best(a, &a->all, loc, orig_loc, sc, ag_score, mp, e->dir, used_ag, clip_before, clip_after, seed_offset);
                 if (loc_non_alt) update_best(a, &a->non_alt, loc, orig_loc, sc, ag_score, mp, e->dir, used_ag, clip_before, clip_after, seed_offset);
+                if (g_stop_on_first_hit && !(!t_flags_apply) && ((uint32_t)a->all.best_score <= (uint32_t)a->max_k)) {          /* -f, :1490-1505 */
+                    fill_result(a, p->alt_awareness ? &a->non_alt : &a->all, a->primary);
+                    a->primary->status = SNAPGPU_MultipleHits; a->primary->mapq = 0;
+                    a->first_alt->status = SNAPGPU_NotFound;
+                    return 1;
+                }
                 {   /* nothing can rescue MAPQ once the candidates' total probability reaches 4.9 -- unless secondary results are wanted, :1512 */
                     double chk = p->alt_awareness ? a->non_alt.p_all : a->all.p_all;
                     if (chk >= 4.9 && a->om < 0) {
@@ -702,7 +714,9 @@ int oracle_align_read(const oracle_index *ix, const oracle_genome *g, const snap
         mine = calloc(2 * cap, 1);
         oracle_ag_bind_objects(mine, mine + cap, cap);
     }
+    t_flags_apply = 1;
     int rc = align_read_ex(ix, g, p, (int)p->max_k, 0, bases, quals, len, primary, first_alt, sp, secondary, sec_room, n_secondary, stale, NULL);
+    t_flags_apply = 0;
     if (mine) { oracle_ag_bind_objects(NULL, NULL, 0); free(mine); }
     return rc;
 }
@@ -798,11 +812,12 @@ static int align_read_ex(const oracle_index *ix, const oracle_genome *g, const s
         oracle_lookup_seed(ix, sb, srcv, n_hits, hits, single_v, slots);
         int applied_either = 0;
         for (int dir = 0; dir < 2; dir++) {
-            if (n_hits[dir] > (int64_t)p->max_hits) {                                                                   /* too popular, :574-579 */
+            if (n_hits[dir] > (int64_t)p->max_hits && !(g_explore_popular_seeds && !(!t_flags_apply))) {             /* too popular, :574-579 (-x: not skipped) */
                 a.popular_skipped++;
             } else {
                 uint32_t offset = dir == 0 ? next_seed : (uint32_t)(len - seed_len) - next_seed;                        /* :591-606 */
-                for (int64_t i = 0; i < n_hits[dir]; i++) apply_hit(&a, n_hits[dir] == 1 ? single_v[dir] : hits[dir][i], offset, dir);
+                const int64_t limit_hits = n_hits[dir] < (int64_t)p->max_hits ? n_hits[dir] : (int64_t)p->max_hits;    /* :625 */
+                for (int64_t i = 0; i < limit_hits; i++) apply_hit(&a, n_hits[dir] == 1 ? single_v[dir] : hits[dir][i], offset, dir);
                 n_applied[dir]++; a.cur_round_lps[dir]++;
                 applied_either = 1;
             }

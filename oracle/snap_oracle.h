@@ -62,4 +62,7 @@ typedef struct oracle_genome {          /* what Genome holds for the aligner and
 #ifdef __cplusplus
 }
 #endif
+/* -f / -x for the oracle_align_read* calls that follow (align_oracle.c) */
+void oracle_set_aligner_flags(int stop_on_first_hit, int explore_popular_seeds);
+
 #endif

@@ -398,3 +398,36 @@ def test_compute_cigar_restatement_vs_reference_fixture(golden_index):
             assert util.cigar_text(o["ops"][j], o["n_ops"][j]) == util.cigar_text(z[pre + "ops"][i], z[pre + "n_ops"][i]), i
     assert int((z["m0_add_front_clipping"] > 0).sum()) > 50 and int((z["m0_add_front_clipping"] < 0).sum()) > 50
     assert int((z["m0_extra_clipped_after"] > 0).sum()) > 30 and int((z["m0_n_ops"] < 0).sum()) >= 1
+
+
+def test_restatement_stop_on_first_hit_and_explore_popular_seeds_vs_live_reference(tmp_path):
+    """-f / -x in oracle/align_oracle.c (oracle_set_aligner_flags) against the compiled reference running with the same flags: every read,
+    every field, on a repeat-rich genome with a low -h (so that -x changes what is found)."""
+    import os
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not built here")
+    from snap_amd import abi, synth
+    from snap_amd.index import GenomeIndex
+    g = synth.make_genome(4711, 600_000, n_contigs=2, repeat_frac=0.5, max_copies=900, repeat_len=(150, 1200), max_divergence=0.03)
+    fa = str(tmp_path / "ref.fa"); synth.write_fasta(fa, g)
+    ref.build_index(fa, str(tmp_path / "idx"), 20, threads=max(1, os.cpu_count() or 1))
+    ix = GenomeIndex.load_from_directory(str(tmp_path / "idx"))
+    ri = ref.RefIndex(str(tmp_path / "idx"))
+    p = abi.default_params(max_k=8, max_read_len=160)
+    p.max_hits = 40
+    rd = synth.make_reads(4712, g, 1500, 120, sub=0.02, ins=0.001, dele=0.001)
+    lib = util.oracle_lib()
+    with ref.fresh_objects():
+        base, _, _, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=os.cpu_count() or 1)
+    for f, x in ((True, False), (False, True), (True, True)):
+        with ref.fresh_objects(), ref.aligner_flags(stop_on_first_hit=f, explore_popular_seeds=x):
+            pr, ar, _, _ = ri.align_single(p, rd["bases"], rd["quals"], rd["offsets"], threads=os.cpu_count() or 1)
+        lib.oracle_set_aligner_flags(1 if f else 0, 1 if x else 0)
+        try:
+            po, ao = util.oracle_align_reads(ix, p, rd["bases"], rd["quals"], rd["offsets"])
+        finally:
+            lib.oracle_set_aligner_flags(0, 0)
+        assert not util.compare_results(pr, po), (f, x)
+        assert not util.compare_results(ar, ao, what="first_alt"), (f, x)
+        assert any((pr[k] != base[k]).any() for k in ("status", "location", "score", "mapq")), (f, x)      # (the flags do something here)
