@@ -489,16 +489,24 @@ static __device__ __forceinline__ AGResult ag_banded_win(
 
 
     // ---- masks of the call (wave-uniform)
-    const unsigned long long S0 = seg_len >= 64 ? ~0ull : ((1ull << seg_len) - 1ull);            // lanes of the window's first segment
-    const unsigned long long S1 = seg_len >= 64 ? 0ull : (S0 << seg_len);                          // ... of its second segment (2 * seg_len <= 64)
-    // (lanes with k < n, n = 0 .. num_vec <= 4, from the lanes with k == 0: scalar shifts and ORs of values -- a lambda that captured the
-    //  masks by reference became a table in scratch memory, and everything downstream of its loads vector code)
+    // (Only Kz -- the lanes with k == 0 -- is kept; the other masks of the call are two or three scalar instructions from seg_len / num_vec
+    //  wherever they are used: kept as values they were 14 more SGPRs alive across the row loop, and the loop spilled and reloaded SGPRs --
+    //  the traceback store's buffer descriptor among them -- with ~10 v_writelane / v_readlane per row.  A lambda that captured masks by
+    //  reference even became a table in scratch memory, and everything downstream of its loads vector code.)
     const unsigned long long Kz = first_u64(BALLOT(k == 0));
-    const unsigned long long Klt2 = Kz | (Kz << 1), Klt3 = Klt2 | (Kz << 2);
-    auto kmask = [=](int n) -> unsigned long long { return n >= num_vec ? ~0ull : (n >= 3 ? Klt3 : (n == 2 ? Klt2 : (n == 1 ? Kz : 0ull))); };
+    auto seg0 = [=]() -> unsigned long long { return seg_len >= 64 ? ~0ull : ((1ull << seg_len) - 1ull); };            // lanes of the window's first segment
+    auto seg1 = [=]() -> unsigned long long { return seg_len >= 64 ? 0ull : (((1ull << seg_len) - 1ull) << seg_len); };   // ... of its second (2 * seg_len <= 64)
+    auto kmask = [=](int n) -> unsigned long long {                                                                       // lanes with k < n (n = 0 .. num_vec <= 4)
+        if (n >= num_vec) return ~0ull;
+        unsigned long long m = n >= 1 ? Kz : 0ull;
+        if (n >= 2) m |= Kz << 1;
+        if (n >= 3) m |= Kz << 2;
+        return m;
+    };
     auto vmask = [=](int wb) -> unsigned long long { const int nvl = tot - wb; return nvl >= 64 ? ~0ull : (nvl <= 0 ? 0ull : ((1ull << nvl) - 1ull)); };
+    auto xmask = [=]() -> unsigned long long { return seg_len >= 64 ? 0ull : (((1ull << num_vec) - 1ull) << seg_len); };   // stripe 0 of the second segment: where the F carried over enters
+    auto lmid = [=]() -> unsigned long long { return seg_len >= 64 ? 0ull : (((1ull << (6 * num_vec)) - 1ull) << (seg_len + num_vec)); };   // the second segment's stripes 1 .. 6
     unsigned long long V = vmask(0);                                                                 // lanes with p < tot
-    const unsigned long long Xm = first_u64(BALLOT(is_x_lane));
     // ---- per-lane constants of the call
     const int tagl = (segsel * 8 + l) * AG_BIG;                  // grows with the lane: what a wave shift brings in from an earlier stripe loses
     const int c_kext = -k * gap_ext;                             // F entering a stripe is 0: F(k) >= -k * ext
@@ -510,7 +518,6 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int v_else = pbv == 5 ? -32768 : (pbv == 4 ? -1 : sub);      // profile entry of this lane's pattern base against a text base that differs from it
     int v_else_n = pbv == 5 ? -32768 : -1;                       // ... against an 'N' of the text
     const int c_prev = (l == 0 ? lane : lane - num_vec) * 4;     // lazy F, rounds 1 .. 6: the same vector one stripe to the left (stripe 0: itself)
-    const unsigned long long Lmid = first_u64(BALLOT(segsel == 1 && l >= 1 && l <= 6));   // the second segment's stripes whose ends are offered to somebody
     int c_ls = 0, c_g = 0;                                        // (follow nk like stepv: the closed form of the second segment's lazy F)
     int nk_addr = 0, stepv = 0, nk_key = -1;                     // per-lane values that follow (nk0, nk1): the gather address of round 0, nk * ext of the lane's segment
     uint32_t tb4 = 0;
@@ -554,7 +561,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         int nk0 = band_end - wbase + 1; if (nk0 > num_vec) nk0 = num_vec;
         int nk1 = 0;
         if (two) { nk1 = band_end - (wbase + seg_len) + 1; if (nk1 > num_vec) nk1 = num_vec; }
-        const unsigned long long inseg_mask = ((kmask(nk0) & S0) | (kmask(nk1) & S1)) & V;      // valid && segsel <= two && k < nk(segment)
+        const unsigned long long inseg_mask = ((kmask(nk0) & seg0()) | (kmask(nk1) & seg1())) & V;      // valid && segsel <= two && k < nk(segment)
         const bool inseg = lane_in(inseg_mask);
 
         // ---------------- first pass, both segments (:483-531)
@@ -628,7 +635,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             const int key = nk0 | (nk1 << 8);
             if (key != nk_key) {                                    // (changes on a handful of rows per call)
                 nk_key = key;
-                const int nkl = lane_in(S0) ? nk0 : nk1;
+                const int nkl = lane_in(seg0()) ? nk0 : nk1;
                 nk_addr = c_src + 4 * nkl;
                 stepv = l == 0 ? 0 : nkl * gap_ext;
                 c_ls = l * nkl * gap_ext;                           // a stripe end's origin: e_l + l * nk * ext
@@ -651,6 +658,9 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 const int step = nk * gap_ext;
                 int src7 = s * seg_len + nk - 1 + 6 * num_vec, decay = step;        // (round 1 looks at stripe 6's last vector)
                 int Tr = T_fp;
+#ifdef AGW_ROLLED_ROUNDS
+#pragma nounroll            // (measured: the rolled loop is 2 % slower than the fourteen unrolled copies, profiles/r04u)
+#endif
                 for (int r = 0; r < 7; r++) {
                     if (r > 0) {
                         if (s == 0 && two) {                                         // X: what this round brings to the segment's end
@@ -677,13 +687,13 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 }
             };
             const int X_first = X0;
-            const unsigned long long ins0 = inseg_mask & S0, ins1 = inseg_mask & S1;
+            const unsigned long long ins0 = inseg_mask & seg0(), ins1 = inseg_mask & seg1();
             if (nk0 > 0) rounds(0, nk0, ins0, Fx0);
             int Fx = lane_in(ins0) ? Fx0 : 0;
             if (two) {
                 if (X0 != X_first) {
                     // stripe 0 of the second segment again, with the final X (values derived from F only go up with it)
-                    const unsigned long long xlm = Xm & inseg_mask;
+                    const unsigned long long xlm = xmask() & inseg_mask;
                     const bool xl = lane_in(xlm);
                     const int fkp = X0 - c_x;
                     const int fkx = fkp > fk ? fkp : fk;
@@ -706,9 +716,9 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 //       every cell -- and Fx is the stripe-0 offer itself.
                 // Otherwise the rounds run as for the first segment.
                 const int e0 = __builtin_amdgcn_readlane(endv, seg_len + nk1 - 1);
-                const unsigned long long endm = ((Kz << (nk1 - 1)) & Lmid) & ins1;
+                const unsigned long long endm = ((Kz << (nk1 - 1)) & lmid()) & ins1;
                 const int g0 = e0 - c_g;
-                const unsigned long long insL = ins1 & ~Xm;
+                const unsigned long long insL = ins1 & ~xmask();
                 if ((BALLOT(endv + c_ls > e0) & endm) == 0ull && (BALLOT(g0 > T_fp) & insL) == insL) {
 #if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
                     { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[4], 1, __ATOMIC_RELAXED); }
