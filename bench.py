@@ -748,6 +748,11 @@ def main():
             out["genome_256mb"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
     if rank == 0:
         out["bench_wall_s"] = time.time() - _T_PROCESS
+        try:
+            import resource
+            out["host_peak_rss_gb"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6          # (rank 0: the rank that loads / builds the index)
+        except Exception:          # noqa: BLE001
+            pass
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
