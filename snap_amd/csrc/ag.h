@@ -76,7 +76,7 @@ template <bool EXACT = false, bool RES = false, typename PSeq, typename TSeq, ty
 static __device__ __forceinline__ AGResult ag_compute(
     bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
-    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab, uint32_t *pending_at = nullptr)
+    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab, uint32_t *pending_at = nullptr, uint32_t bt_tag = 0)
 {
     if constexpr (RES) *pending_at = AG_NO_CELL;
     const int lane = lane_id();
@@ -198,7 +198,7 @@ static __device__ __forceinline__ AGResult ag_compute(
                     mx = hp > mx ? hp : mx;
                     int f2 = ag_sat16(fk - gap_ext);
                     if (f2 > tmp) bt |= 32;
-                    bt_row[cell] = (uint8_t)bt;
+                    bt_row[cell] = (uint8_t)(bt | (EXACT ? (int)bt_tag : 0));
                 }
                 // carry the prefix max past this step: take it from the last vector row of the step
                 int last_inc = __shfl(inc, 56 + sl);
@@ -320,6 +320,7 @@ static __device__ __forceinline__ AGResult ag_compute(
                 computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
             }
             int bits = (EXACT || computed) ? (int)first_u32(bt_scratch[(size_t)row * row_cells + vi * 8 + li]) : 0;
+            if constexpr (EXACT && !RES) bits = bt_cell(bits, bt_tag);             // (a cell of an earlier read is a zeroed cell: dev_common.h)
             if constexpr (RES) {
                 if (!computed && bits == AG_CELL_UNKNOWN) { *pending_at = (uint32_t)((size_t)row * row_cells + vi * 8 + li); res.ag_score = -1; return res; }
             }

@@ -74,7 +74,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
     int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
-    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes)
+    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes, uint32_t bt_tag = 0)
 {
     const int lane = lane_id();
     AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
@@ -286,7 +286,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
 
 #pragma unroll
         for (int c = 0; c < AGC; c++) if (c >= row_c_lo && c <= row_c_hi && did[c]) {
-            if constexpr (EXACT) bt_store(sink, (uint32_t)(i * row_stride), (uint32_t)((pos[c].j() * num_vec + pos[c].k()) * 8 + pos[c].l()), (uint32_t)btr[c]);
+            if constexpr (EXACT) bt_store(sink, (uint32_t)(i * row_stride), (uint32_t)((pos[c].j() * num_vec + pos[c].k()) * 8 + pos[c].l()), (uint32_t)btr[c] | bt_tag);
             else bt_store(sink, (uint32_t)(i * row_stride), (uint32_t)(c * 64 + lane), (uint32_t)btr[c]);
         }
         const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
@@ -363,7 +363,7 @@ static __device__ __forceinline__ AGResult ag_compute_reg(
                 int vi = 0, li = 0;
                 if (ok) { const int cj = ct / seg_len, cr = ct - cj * seg_len; vi = cj * num_vec + cr % num_vec; li = cr / num_vec; }
                 const uint32_t at = (uint32_t)rt * (uint32_t)row_stride + (uint32_t)(vi * 8 + li);
-                cell = (ok && at < bt_bytes) ? (int)bt_scratch[at] : 0;
+                cell = (ok && at < bt_bytes) ? bt_cell((int)bt_scratch[at], bt_tag) : 0;
             } else {
                 cell = computed ? (int)bt_scratch[(size_t)rt * row_stride + ct] : 0;
             }

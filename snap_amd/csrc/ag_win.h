@@ -16,6 +16,7 @@
 //     forward) except H(i-1, wbase-1) on the row of the slide, which is kept in a scalar;
 //   * traceback bytes are 64 per row; the row's wbase goes to an LDS table for the traceback.
 #pragma once
+#include <type_traits>
 #include "ag_reg.h"
 #ifndef SNAPGPU_AG_DUP
 #define SNAPGPU_AG_DUP 0         // measurement builds only (scripts/ab_bench.py): 1 / 2 / 3 run the prologue / the row loop / the traceback of the window form twice
@@ -30,7 +31,7 @@ static __device__ __forceinline__ AGResult ag_banded_win_v1(
     int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
-    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes)
+    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes, uint32_t bt_tag = 0)
 {
     const int lane = lane_id();
     AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
@@ -275,7 +276,7 @@ static __device__ __forceinline__ AGResult ag_banded_win_v1(
         // (uniform row pointer + zero-extended 32-bit lane offset: the form that selects the SGPR-base store; with a sign-extended
         //  lane the address lives in a VGPR pair, which the 80-VGPR build spills and reloads -- with a vmcnt(0) wait -- every row)
         if constexpr (EXACT) {
-            if (did) bt_store(sink, (uint32_t)(i * nv_tot8 + jbase * seg_len), (uint32_t)flat_lane, (uint32_t)btr);
+            if (did) bt_store(sink, (uint32_t)(i * nv_tot8 + jbase * seg_len), (uint32_t)flat_lane, (uint32_t)btr | bt_tag);
         } else {
             bt_store(sink, (uint32_t)i * 64u, (uint32_t)lane, (uint32_t)btr);       // (lanes outside the band write 0; the traceback never reads them)
         }
@@ -344,7 +345,7 @@ static __device__ __forceinline__ AGResult ag_banded_win_v1(
                 int vi = 0, li = 0;
                 if (ok) { const int cj = ct / seg_len, cr = ct - cj * seg_len; vi = cj * num_vec + cr % num_vec; li = cr / num_vec; }
                 const uint32_t at = (uint32_t)rt * (uint32_t)nv_tot8 + (uint32_t)(vi * 8 + li);
-                cell = (ok && at < bt_bytes) ? (int)bt_scratch[at] : 0;
+                cell = (ok && at < bt_bytes) ? bt_cell((int)bt_scratch[at], bt_tag) : 0;
             } else {
                 cell = computed ? (int)bt_scratch[(size_t)rt * 64 + (ct - wb)] : 0;
             }
@@ -389,14 +390,20 @@ static __device__ __forceinline__ AGResult ag_banded_win_v1(
 // EXACT (replay of flagged reads, ag.h): bt_scratch_in is the wave's image of one reference object's traceback array; cells go where the
 // reference puts them -- byte (row * numVec * numSeg + vector) * 8 + SSE element -- only evaluated cells are written, and the traceback
 // reads whatever the array holds.
-template <bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
+// FULL: the UNBANDED computation (AffineGapVectorized.h:914-1112) of a pattern whose striped layout is one segment of at most 64 positions
+// (num_vec <= 8) -- the head of a read before an early seed, a third of all rows on 150-bp reads.  It is the banded row with a band that
+// covers everything and a window that never slides: one segment, nk = num_vec on every row, no X; the reference's eighth lazy-F round
+// has no stripe left to bring anything from.  (Until round 4 these calls went through ag_compute_reg<1, false>, whose rounds cost four
+// times as much.)
+template <bool EXACT = false, bool FULL = false, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_banded_win(
     int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
-    const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
+    const TSeq &T, int text_len, int w_in, int score_init, bool is_rc, int use_clipping,
     int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
-    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes)
+    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes, uint32_t bt_tag = 0)
 {
     const int lane = lane_id();
+    const int w = FULL ? (1 << 20) : w_in;                       // (FULL: the band is everything, on every row and in the traceback's "was this cell computed")
     AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
     res.match_probability = 1.0; res.stale_reads = 0;
     const int match = prm.match_reward, sub = -prm.sub_penalty;
@@ -498,10 +505,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     auto seg1 = [=]() -> unsigned long long { return seg_len >= 64 ? 0ull : (((1ull << seg_len) - 1ull) << seg_len); };   // ... of its second (2 * seg_len <= 64)
     auto kmask = [=](int n) -> unsigned long long {                                                                       // lanes with k < n (n = 0 .. num_vec <= 4)
         if (n >= num_vec) return ~0ull;
-        unsigned long long m = n >= 1 ? Kz : 0ull;
-        if (n >= 2) m |= Kz << 1;
-        if (n >= 3) m |= Kz << 2;
-        return m;
+        return (Kz << n) - Kz;                 // every k == 0 lane b becomes the lanes b .. b + n - 1 (n < num_vec: the runs do not meet, nothing borrows)
     };
     auto vmask = [=](int wb) -> unsigned long long { const int nvl = tot - wb; return nvl >= 64 ? ~0ull : (nvl <= 0 ? 0ull : ((1ull << nvl) - 1ull)); };
     auto xmask = [=]() -> unsigned long long { return seg_len >= 64 ? 0ull : (((1ull << num_vec) - 1ull) << seg_len); };   // stripe 0 of the second segment: where the F carried over enters
@@ -519,15 +523,39 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int v_else_n = pbv == 5 ? -32768 : -1;                       // ... against an 'N' of the text
     const int c_prev = (l == 0 ? lane : lane - num_vec) * 4;     // lazy F, rounds 1 .. 6: the same vector one stripe to the left (stripe 0: itself)
     int c_ls = 0, c_g = 0;                                        // (follow nk like stepv: the closed form of the second segment's lazy F)
+    unsigned long long KM0 = 0ull, KM1 = 0ull, KE1 = 0ull, KL1 = 0ull;   // masks that follow (nk0, nk1) like the per-lane values below: the band's lanes of either segment, the second segment's stripe ends / stripes 1 .. 7
     int nk_addr = 0, stepv = 0, nk_key = -1;                     // per-lane values that follow (nk0, nk1): the gather address of round 0, nk * ext of the lane's segment
     uint32_t tb4 = 0;
 
+    // open - ext, in a VECTOR register on purpose: every lazy-F round subtracts it, the row loop has more wave-uniform values than SGPRs, and as an
+    // SGPR it was the one the allocator spilled -- a v_readlane per round to get it back.
+#if defined(SNAPGPU_WAVE_EMU)
+    const int d_open = gap_open - gap_ext;
+#else
+    int d_open;
+    asm("v_mov_b32 %0, %1" : "=v"(d_open) : "s"(gap_open - gap_ext));
+#endif
+    EMU_STAT(8, 1);
     for (int i = 0; i < text_len; i++) {
+        EMU_STAT(9, 1);
+#if defined(SNAPGPU_AG_DUMMY) && !defined(SNAPGPU_WAVE_EMU)
+        // measurement scaffolding (scripts/ab_bench.py): 32 more scalar (1) / vector (2) instructions per row -- which of the two the row loop's time follows
+        {
+#if SNAPGPU_AG_DUMMY == 1
+            int ds_ = i;
+            asm volatile(".rept 32\n s_add_u32 %0, %0, 1\n .endr" : "+s"(ds_) : : "scc");
+#else
+            int dv_ = lane;
+            asm volatile(".rept 32\n v_add_u32 %0, %0, 1\n .endr" : "+v"(dv_));
+#endif
+        }
+#endif
         if ((i & 3) == 0) tb4 = first_u32(*(LDS_AS const uint32_t *)(tcode + i));       // four rows' text codes per LDS read (tcode is 16-byte aligned; the tail reads slack)
         const int tb = (int)((tb4 >> (8 * (i & 3))) & 0xffu);
-        const int band_beg = i - w > 0 ? i - w : 0;
-        const int band_end = i + w < pattern_len - 1 ? i + w : pattern_len - 1;
-        if ((jbase + 1) * seg_len <= band_beg) {                // slide the window by one segment
+        const int band_beg = FULL ? 0 : (i - w > 0 ? i - w : 0);
+        const int band_end = FULL ? pattern_len - 1 : (i + w < pattern_len - 1 ? i + w : pattern_len - 1);
+        if (!FULL && __builtin_expect((jbase + 1) * seg_len <= band_beg, 0)) {       // slide the window by one segment (one row in twenty)
+            EMU_STAT(10, 1);
             left_h = __builtin_amdgcn_readlane(Hp, seg_len - 1);
             if (pattern_len - 1 >= wbase && pattern_len - 1 < wbase + seg_len) {
                 gl_p = __builtin_amdgcn_readlane(Hp, pattern_len - 1 - wbase);
@@ -557,11 +585,27 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         // first passes is independent, so both segments go through ONE first pass (each lane knows its segment), the few stripe-0
         // lanes of the second segment take X in afterwards (F only ever raises the values derived from it), and the first lazy-F round
         // -- the only one in all but a few rows -- runs for both segments at once.
-        const bool two = (jbase + 1) * seg_len <= band_end;
-        int nk0 = band_end - wbase + 1; if (nk0 > num_vec) nk0 = num_vec;
-        int nk1 = 0;
-        if (two) { nk1 = band_end - (wbase + seg_len) + 1; if (nk1 > num_vec) nk1 = num_vec; }
-        const unsigned long long inseg_mask = ((kmask(nk0) & seg0()) | (kmask(nk1) & seg1())) & V;      // valid && segsel <= two && k < nk(segment)
+        const int t0 = band_end - wbase + 1;                       // cells of the band from the window's start on (wbase = jbase * seg_len)
+        const int nk0 = t0 < num_vec ? t0 : num_vec;
+        int nk1 = t0 - seg_len; if (nk1 > num_vec) nk1 = num_vec; if (nk1 < 0 || FULL) nk1 = 0;    // (FULL: one segment, known at compile time)
+        const bool two = !FULL && nk1 > 0;                                  // (jbase + 1) * seg_len <= band_end
+        {
+            const int key = nk0 | (nk1 << 8);
+            if (__builtin_expect(key != nk_key, 0)) {               // (changes on one row in six; a row's scalar instructions are as scarce as its vector ones)
+                EMU_STAT(14, 1);
+                nk_key = key;
+                const int nkl = lane_in(seg0()) ? nk0 : nk1;
+                nk_addr = c_src + 4 * nkl;
+                stepv = l == 0 ? 0 : nkl * gap_ext;
+                c_ls = l * nkl * gap_ext;                           // a stripe end's origin: e_l + l * nk * ext
+                c_g = l == 0 ? AG_HUGE : c_ls - stepv - c_kext;     // what lies between stripe 0's end and cell (l, k): ((l - 1) * nk + k) * ext
+                KM0 = kmask(nk0) & seg0(); KM1 = kmask(nk1) & seg1();
+                KE1 = nk1 > 0 ? ((Kz << (nk1 - 1)) & lmid()) & KM1 : 0ull;
+                KL1 = KM1 & ~xmask();
+            }
+        }
+        const unsigned long long ins0 = KM0 & V, ins1 = KM1 & V;                                        // valid && k < nk(segment), per segment
+        const unsigned long long inseg_mask = ins0 | ins1;
         const bool inseg = lane_in(inseg_mask);
 
         // ---------------- first pass, both segments (:483-531)
@@ -579,21 +623,27 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         const unsigned long long M4 = BALLOT(e2 > tmp);            // bit 4: E extends
         // first-pass F along the (at most 4) vectors of a stripe: F(k) = max_{j<k} (tmp_j - (k-1-j)*ext), a max of tmp_j + p_j*ext over
         // the (at most 3) lanes to the left that belong to the same stripe
-        int fk = c_kext;
-        if (num_vec > 1) {
+        // (always three shifts: with fewer vectors per stripe the extra ones bring cells of an earlier stripe, whose tag loses -- as it
+        //  already does for the lanes with k < 3 of a four-vector stripe; three tests of num_vec per row cost more than the two instructions)
+        int fk;
+        {
             const int g = inseg ? tmp + c_pt : AG_NEG;
             const int a1 = ag_shr1z(g);
-            int pm = a1;
-            if (num_vec > 2) {
-                const int a2 = ag_shr1z(a1);
-                pm = a2 > pm ? a2 : pm;
-                if (num_vec > 3) { const int a3 = ag_shr1z(a2); pm = a3 > pm ? a3 : pm; }
+            const int a2 = ag_shr1z(a1);
+            const int a3 = ag_shr1z(a2);
+            int pm = a2 > a1 ? a2 : a1;
+            pm = a3 > pm ? a3 : pm;
+            if (FULL && num_vec > 4) {                               // (up to 8 vectors per stripe: four more cells to the left)
+                const int a4 = ag_shr1z(a3), a5 = ag_shr1z(a4), a6 = ag_shr1z(a5), a7 = ag_shr1z(a6);
+                const int q = a5 > a4 ? a5 : a4, q2 = a7 > a6 ? a7 : a6;
+                pm = q > pm ? q : pm; pm = q2 > pm ? q2 : pm;
             }
             const int a = pm - c_pm;
-            fk = a > fk ? a : fk;
+            fk = a > c_kext ? a : c_kext;
         }
         int X0 = 0;
         if (two) {
+            EMU_STAT(12, 1);
             // X after the first segment's lazy F, assuming -- as in all but a few rows -- that its first round is also its last:
             // the F that left stripe 7 in the first pass (:538).  It enters stripe 0 of the second segment (f = X, :571).
             const int f2p0 = fk - gap_ext;
@@ -628,70 +678,66 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         //     incrementally.
         // X, the F that leaves the first segment's last stripe into stripe 0 of the second (:538, :571), grows with every round the first
         // segment runs; when it has, the second segment's stripe-0 cells are redone before that segment's rounds start.
-        const int d_open = gap_open - gap_ext;
         int T_fp = Hm - d_open; if (T_fp < gap_ext) T_fp = gap_ext;
         int Fx = 0;
         {
-            const int key = nk0 | (nk1 << 8);
-            if (key != nk_key) {                                    // (changes on a handful of rows per call)
-                nk_key = key;
-                const int nkl = lane_in(seg0()) ? nk0 : nk1;
-                nk_addr = c_src + 4 * nkl;
-                stepv = l == 0 ? 0 : nkl * gap_ext;
-                c_ls = l * nkl * gap_ext;                           // a stripe end's origin: e_l + l * nk * ext
-                c_g = l == 0 ? AG_HUGE : c_ls - stepv - c_kext;     // what lies between stripe 0's end and cell (l, k): ((l - 1) * nk + k) * ext
-            }
-            auto fold = [&](unsigned long long cm, int nk, int *jlim) -> bool {          // cm: lanes of ONE segment (shifted down) whose F goes on; returns round_complete
-                cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
-                const uint32_t full = (1u << nk) - 1u;
-                const uint32_t low = (uint32_t)cm & full;
-                if (low == full) { *jlim = nk - 1; return true; }
-                *jlim = (int)__builtin_ctz(~low);
-                return false;
-            };
-            int u = __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy;           // round 0's offer, both segments (the second's is redone below when it was shifted away)
-            bool u_dirty = false;
+            const int u0 = __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy;    // round 0's offer, both segments
+            const int wv = endv + c_ls;                                              // a stripe end at its origin (the first segment's X; the second's closed form)
+            int u = u0;
             int Fx0 = 0, Fx1 = 0;                                                    // the largest offer taken, first / second segment (every round runs over all lanes)
             // A complete round applies to every lane of the segment: no select, and lanes outside the segment may collect what they like
             // (they are masked once, below).  Only the round that stops the walk selects its vectors 0 .. jlim.
+            // "Every vector 0 .. nk - 1 has a lane whose F goes on" is an OR over the (at most 8) stripes of the segment: the segment's
+            // lanes fit 32 bits, three shift / or pairs fold them onto stripe 0.
+            // X, what round r >= 1 brings to the first segment's end, is endv(stripe 7 - r, vector nk - 1) - r * step = wv there - 7 * step:
+            // the rounds keep the largest wv they pass (a readlane and a max), the subtraction happens once.
+            // (Written as nested calls, one instantiation per round, not as a loop with a break: unrolled, the loop's exits came out as
+            //  flag registers set, tested and tested again -- five scalar instructions and two branches per round.)
             auto rounds = [&](int s, int nk, unsigned long long ins_mask, int &Fxs) {
-                const int step = nk * gap_ext;
-                int src7 = s * seg_len + nk - 1 + 6 * num_vec, decay = step;        // (round 1 looks at stripe 6's last vector)
+                const uint32_t full = (1u << nk) - 1u;
+                int src7 = s * seg_len + nk - 1 + 6 * num_vec;                       // (round 1 looks at stripe 6's last vector)
+                int Wm = -AG_HUGE;
                 int Tr = T_fp;
-#ifdef AGW_ROLLED_ROUNDS
-#pragma nounroll            // (measured: the rolled loop is 2 % slower than the fourteen unrolled copies, profiles/r04u)
-#endif
-                for (int r = 0; r < 7; r++) {
-                    if (r > 0) {
-                        if (s == 0 && two) {                                         // X: what this round brings to the segment's end
-                            const int f7 = __builtin_amdgcn_readlane(endv, src7) - decay;
-                            if (f7 > X0) X0 = f7;
-                            src7 -= num_vec; decay += step;
-                        }
-                        u = __builtin_amdgcn_ds_bpermute(c_prev, u) - stepv;
-                        u_dirty = true;
-                    }
+                // (The next round's gather needs this round's OFFER, not its verdict: it is issued before the verdict's ballot-and-fold chain so
+                //  that the two latencies overlap; when the verdict stops the walk one gather was for nothing.)
+                auto round = [&](auto &self, auto rc, int u_cur) -> void {
+                    constexpr int r = decltype(rc)::value;
 #if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
                     { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[16 + s * 8 + r], 1, __ATOMIC_RELAXED); }
 #endif
-                    int jlim;
-                    const bool complete = fold((BALLOT(u > Tr) & ins_mask) >> (s * seg_len), nk, &jlim);      // (an offer <= 0 is never above Tr >= 0)
-                    if (!complete) {
-                        const int fm = lane_in(ins_mask & kmask(jlim + 1)) ? u : 0;
+                    int u_next = 0;
+                    if constexpr (r < 6) u_next = __builtin_amdgcn_ds_bpermute(c_prev, u_cur);
+                    const unsigned long long go = BALLOT(u_cur > Tr) & ins_mask;     // (an offer <= 0 is never above Tr >= 0)
+                    typename std::conditional<FULL, unsigned long long, uint32_t>::type cm = s == 0 ? go : (go >> seg_len);      // (a banded segment's lanes fit 32 bits)
+                    cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
+                    const uint32_t low = (uint32_t)cm & full;
+                    if (__builtin_expect(low != full, 0)) {                          // the round stops at vector jlim: the walk ends
+                        const int jlim = (int)__builtin_ctz(~low);
+                        const int fm = lane_in(ins_mask & kmask(jlim + 1)) ? u_cur : 0;
                         Fxs = fm > Fxs ? fm : Fxs;
-                        break;
+                    } else {
+                        Fxs = u_cur > Fxs ? u_cur : Fxs;
+                        if constexpr (r < 6) {
+                            const int tq = u_cur - d_open;
+                            Tr = tq > Tr ? tq : Tr;
+                            if (s == 0) {                                            // (kept whether or not there is a second segment: X0 is only read when there is)
+                                const int w7 = __builtin_amdgcn_readlane(wv, src7);
+                                Wm = w7 > Wm ? w7 : Wm;
+                                src7 -= num_vec;
+                            }
+                            self(self, std::integral_constant<int, r + 1>{}, u_next - stepv);
+                        }
                     }
-                    Fxs = u > Fxs ? u : Fxs;
-                    const int tq = u - d_open;
-                    Tr = tq > Tr ? tq : Tr;
-                }
+                };
+                round(round, std::integral_constant<int, 0>{}, u);
+                if (s == 0) { const int xr = Wm - 7 * nk * gap_ext; if (xr > X0) X0 = xr; }
             };
             const int X_first = X0;
-            const unsigned long long ins0 = inseg_mask & seg0(), ins1 = inseg_mask & seg1();
             if (nk0 > 0) rounds(0, nk0, ins0, Fx0);
             int Fx = lane_in(ins0) ? Fx0 : 0;
             if (two) {
                 if (X0 != X_first) {
+                    EMU_STAT(11, 1);
                     // stripe 0 of the second segment again, with the final X (values derived from F only go up with it)
                     const unsigned long long xlm = xmask() & inseg_mask;
                     const bool xl = lane_in(xlm);
@@ -704,7 +750,6 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                     Hm = xl ? hpx : Hm;
                     endv = xl ? evx : endv;
                     T_fp = Hm - d_open; if (T_fp < gap_ext) T_fp = gap_ext;
-                    u_dirty = true;                                                  // (the stripe-0 ends are what stripe 1 is offered)
                 }
                 // The second segment usually runs all seven rounds -- its stripes 1 .. 7 lie beyond the band, hold small stale H, and the
                 // F that entered stripe 0 from the first segment runs through all of them -- and then what every cell ends up with is
@@ -716,16 +761,17 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 //       every cell -- and Fx is the stripe-0 offer itself.
                 // Otherwise the rounds run as for the first segment.
                 const int e0 = __builtin_amdgcn_readlane(endv, seg_len + nk1 - 1);
-                const unsigned long long endm = ((Kz << (nk1 - 1)) & lmid()) & ins1;
+                const unsigned long long endm = KE1 & V;
                 const int g0 = e0 - c_g;
-                const unsigned long long insL = ins1 & ~xmask();
-                if ((BALLOT(endv + c_ls > e0) & endm) == 0ull && (BALLOT(g0 > T_fp) & insL) == insL) {
+                const unsigned long long insL = KL1 & V;
+                if ((BALLOT(wv > e0) & endm) == 0ull && (BALLOT(g0 > T_fp) & insL) == insL) {     // (endm: stripes 1 .. 6, whose endv the new X did not touch)
 #if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
                     { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[4], 1, __ATOMIC_RELAXED); }
 #endif
                     Fx = lane_in(insL) ? g0 : Fx;
                 } else {
-                    if (u_dirty) u = __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy;     // round 0's offer again: the first segment's later rounds shifted it away
+                    if ((BALLOT(wv > e0) & endm) != 0ull) EMU_STAT(15, 1); else EMU_STAT(16, 1);
+                    u = X0 != X_first ? __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy : u0;     // round 0's offer again (gathered anew when X moved the stripe-0 ends)
                     rounds(1, nk1, ins1, Fx1);
                     Fx = lane_in(ins1) ? Fx1 : Fx;
                 }
@@ -740,7 +786,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         // (uniform row pointer + zero-extended 32-bit lane offset: the form that selects the SGPR-base store; with a sign-extended
         //  lane the address lives in a VGPR pair, which the 80-VGPR build spills and reloads -- with a vmcnt(0) wait -- every row)
         if constexpr (EXACT) {
-            if (inseg) bt_store(sink, (uint32_t)(i * nv_tot8 + jbase * seg_len), (uint32_t)flat_lane, (uint32_t)btr);
+            if (inseg) bt_store(sink, (uint32_t)(i * nv_tot8 + jbase * seg_len), (uint32_t)flat_lane, (uint32_t)btr | bt_tag);
         } else {
             bt_store(sink, (uint32_t)i * 64u, (uint32_t)lane, (uint32_t)btr);       // (lanes outside the band write what they have; the traceback never reads them)
         }
@@ -815,6 +861,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         int row = text_off, col = pat_off;
         int action = 0, prev_action = 0, action_count = 1, n_matches = 0, n_mismatches = 0, n_gaps = 0;
         while (row >= 0 && col >= 0) {
+            EMU_STAT(13, 1);
             const int rt = row - lane, ct = col - lane;
             const bool ok = rt >= 0 && ct >= 0;
             bool computed = false;
@@ -830,13 +877,36 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 int vi = 0, li = 0;
                 if (ok) { const int cj = ct / seg_len, cr = ct - cj * seg_len; vi = cj * num_vec + cr % num_vec; li = cr / num_vec; }
                 const uint32_t at = (uint32_t)rt * (uint32_t)nv_tot8 + (uint32_t)(vi * 8 + li);
-                cell = (ok && at < bt_bytes) ? (int)bt_scratch[at] : 0;
+                cell = (ok && at < bt_bytes) ? bt_cell((int)bt_scratch[at], bt_tag) : 0;
             } else {
                 cell = computed ? (int)bt_scratch[(size_t)rt * 64 + (ct - wb)] : 0;
             }
             int pbyte = ok ? (int)P(ct) : 0, tbyte = ok ? (int)T(rt) : 0, qbyte = ok ? (int)Q(ct) : 0;
             int info = cell | ((ok && !computed) ? 0x100 : 0) | ((pbyte != tbyte) ? 0x200 : 0) | (qbyte << 16);
             for (int t = 0; t < WAVE && row >= 0 && col >= 0; t++) {
+                // Along an alignment most steps are diagonal steps out of the match state, one after the other: such a run is taken at once --
+                // how far it goes is a ballot, its matches and mismatches are population counts, and only its mismatches (whose quality
+                // terms enter the FP64 product in path order) are visited one by one.  Everything else goes through the step below, as before:
+                // 130 serial steps of ~18 scalar instructions per call were 7 % of the kernel's scalar instructions.
+                if (action == 0 && prev_action == 0) {
+                    const unsigned long long nz = BALLOT((info & 3) != 0) >> t;
+                    int run = nz ? (int)__builtin_ctzll(nz) : WAVE - t;
+                    const int room = (row < col ? row : col) + 1;
+                    if (run > room) run = room;
+                    if (run > 0) {
+                        const unsigned long long rm = (run >= 64 ? ~0ull : ((1ull << run) - 1ull)) << t;
+                        unsigned long long mm = BALLOT((info & 0x200) != 0) & rm;
+                        res.stale_reads += (int)__popcll(BALLOT((info & 0x100) != 0) & rm);
+                        const int nmm = (int)__popcll(mm);
+                        n_mismatches += nmm; n_matches += run - nmm;
+                        while (mm) {
+                            const int tl = (int)__builtin_ctzll(mm); mm &= mm - 1ull;
+                            prob *= tab->phred[(__builtin_amdgcn_readlane(info, tl) >> 16) & 0xff];
+                        }
+                        row -= run; col -= run; t += run - 1;
+                        continue;
+                    }
+                }
                 const int inf = __builtin_amdgcn_readlane(info, t);
                 if (inf & 0x100) res.stale_reads++;
                 action = ((inf & 0xff) >> (action << 1)) & 3;
@@ -879,7 +949,7 @@ template <int AGC, bool EXACT, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_dispatch_inl(
     bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
-    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
+    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab, uint32_t bt_tag = 0)
 {
     if constexpr (AGC > 0) {
         AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
@@ -895,26 +965,29 @@ static __device__ __forceinline__ AGResult ag_dispatch_inl(
         }
         if (banded && 2 * seg_len <= 64 && prm.gap_open <= 0)        // (the rewritten row loop assumes a positive gap-open penalty: see its lazy-F notes)
             return ag_banded_win_v1<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                           lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
+                                           lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
         if (banded && 2 * seg_len <= 64)        // the band's two segments fit one wavefront: sliding-window form
 #if defined(SNAPGPU_AG_WIN_V1)
             return ag_banded_win_v1<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                           lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
+                                           lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
 #else
             return ag_banded_win<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                        lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
+                                        lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
 #endif
         if (banded)
             return ag_compute_reg<AGC, true, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                                    lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
-        if (num_seg * seg_len <= 64)            // short pattern (e.g. the read's head before an early seed): one chunk, no chunk loops
+                                                    lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
+        if (num_seg * seg_len <= 64 && prm.gap_open > 0)        // short pattern (e.g. the read's head before an early seed): the window form's row, band = everything
+            return ag_banded_win<EXACT, true>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                              lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
+        if (num_seg * seg_len <= 64)            // ... with a zero gap-open penalty: the chunked form with one chunk
             return ag_compute_reg<1, false, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                                   lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
+                                                   lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
         return ag_compute_reg<AGC, false, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                                 lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL));
+                                                 lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
     } else {
         return ag_compute<EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
-                                 lds_rows, bt_scratch, RL, tab);
+                                 lds_rows, bt_scratch, RL, tab, nullptr, bt_tag);
     }
 }
 
@@ -932,6 +1005,7 @@ static __device__ __attribute__((noinline)) AGResult ag_dispatch_fn(
 {
     flags = first_u32(flags);
     const bool banded = (flags & 1u) != 0, is_rc = (flags & 2u) != 0;
+    const uint32_t bt_tag = (flags >> 8) & 0xFFu;               // EXACT: the tag of the read whose image cells count (dev_common.h: bt_cell)
     const int dir = (flags & 4u) ? -1 : 1;
     AGParams prm;
     prm.match_reward = (int)first_u32((uint32_t)prm_in.match_reward); prm.sub_penalty = (int)first_u32((uint32_t)prm_in.sub_penalty);
@@ -945,19 +1019,19 @@ static __device__ __attribute__((noinline)) AGResult ag_dispatch_fn(
     RL = first_u32(RL);
     tab = (const DevTables *)(uintptr_t)first_u64((uint64_t)(uintptr_t)tab);
     return ag_dispatch_inl<AGC, EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
-                                       lds_rows, bt_scratch, RL, tab);
+                                       lds_rows, bt_scratch, RL, tab, bt_tag);
 }
 
 template <int AGC, bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_dispatch(
     bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
-    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab)
+    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab, uint32_t bt_tag = 0)
 {
 #if !defined(SNAPGPU_AG_LV_FUNCTIONS)
-    return ag_dispatch_inl<AGC, EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping, lds_rows, bt_scratch, RL, tab);
+    return ag_dispatch_inl<AGC, EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping, lds_rows, bt_scratch, RL, tab, bt_tag);
 #else
-    const uint32_t flags = (banded ? 1u : 0u) | (is_rc ? 2u : 0u) | (dir == -1 ? 4u : 0u);
+    const uint32_t flags = (banded ? 1u : 0u) | (is_rc ? 2u : 0u) | (dir == -1 ? 4u : 0u) | (bt_tag << 8);
     return ag_dispatch_fn<AGC, EXACT, PSeq, TSeq, QSeq>(flags, prm, P, Q, pattern_len, T, text_len, w, score_init, use_clipping, lds_rows, bt_scratch, RL, tab);
 #endif
 }

@@ -196,6 +196,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     uint8_t  *ag_scratch;
     uint8_t  *ag_persist0, *ag_persist1;   // EXACT only: images of the forward object's (affineGap) and the backward object's (reverseAffineGap) array
     uint32_t ag_hw0, ag_hw1;               // EXACT only: bytes of each image written since it was last zeroed (what the next read must clear)
+    uint32_t ag_epoch, ag_tag;             // EXACT only: reads since the images were last cleared (1 .. 15) and its tag bits (dev_common.h: bt_cell): cells of other reads read as zero
     // ---- per-read state (wave-uniform)
     int lane;
     int read_len;
@@ -237,7 +238,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     WaveCounters &cnt;
 
     __device__ __forceinline__ Aligner(const DevIndex &ix_, const DevTables *tab_, const AlignCfg &cfg_, WaveShared *ws)
-        : ix(ix_), tab(tab_), cfg(cfg_), tp_org(0), rd_plain(0), ag_hw0(0), ag_hw1(0), read_len(0), popular_seeds_skipped(0),
+        : ix(ix_), tab(tab_), cfg(cfg_), tp_org(0), rd_plain(0), ag_hw0(0), ag_hw1(0), ag_epoch(0), ag_tag(0), read_len(0), popular_seeds_skipped(0),
           ag_stale(0), ag_replay(0), ag_obj_used0(0), ag_obj_used1(0), max_k(cfg_.max_k), ag_calls_unit(0),
           agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0), n_sec(0), n_sec_raw(0), sec_overflow(0),
           all(ws->all), non_alt(ws->non_alt), primary(ws->primary), first_alt(ws->first_alt), cnt(ws->cnt) {
@@ -254,6 +255,20 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         const uint32_t used = obj == 0 ? ag_obj_used0 : ag_obj_used1;
         if (EXACT || used) ag_replay += stale_steps;
         if (obj == 0) ag_obj_used0 = 1; else ag_obj_used1 = 1;
+    }
+
+    // EXACT: a new read = newly constructed reference aligners, whose traceback arrays read as zero.  The images are cleared once per
+    // fifteen reads; in between a read's cells carry its tag and everybody else's read as zero (dev_common.h: bt_cell).
+    __device__ __forceinline__ void new_read_images() {
+        if constexpr (EXACT) {
+            if (++ag_epoch == 16u) {
+                if (ag_hw0) wave_zero16(ag_persist0, ((size_t)ag_hw0 + 15) & ~(size_t)15);
+                if (ag_hw1) wave_zero16(ag_persist1, ((size_t)ag_hw1 + 15) & ~(size_t)15);
+                ag_hw0 = ag_hw1 = 0; ag_epoch = 1u;
+                WAVE_SYNC();
+            }
+            ag_tag = bt_tag_bits(ag_epoch);
+        }
     }
 
     // EXACT: how far into its object's array a call can write: text_len rows of numVec * numSeg * 8 bytes (ag_dims)
@@ -776,7 +791,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 const int plen = half == 0 ? read_len - tail_start : seed_offset;
                 const int tlen = half == 0 ? text_len : seed_offset + SNAPGPU_MAX_K;
                 const int lim = half == 0 ? limit_e : limit_e - score1;
-                ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+                const LdsSeq P = lds_seq(ByteSeq{rdd + org, st}), Q = lds_seq(ByteSeq{qld + org, st}), T = lds_seq(ByteSeq{data + org, st});     // (read, qualities, window: LDS)
                 LvPlanes lp;
                 if (lv_planes) {
                     const int rpw = (int)read_plane_words(cfg.RL);
@@ -826,10 +841,10 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                         const int lim = half == 0 ? limit_e : limit_e - score1;
                         const int tlen = half == 0 ? text_len : seed_offset + lim;
                         const bool banded = plen >= 3 * (2 * lim + 1);                   // :1213 / :1251
-                        ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+                        const LdsSeq P = lds_seq(ByteSeq{rdd + org, st}), Q = lds_seq(ByteSeq{qld + org, st}), T = lds_seq(ByteSeq{data + org, st});
                         note_ag_extent(half, banded, plen, lim, tlen);
                         AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, e_dir != 0,
-                                                      false, ag_rows, EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab);
+                                                      false, ag_rows, EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab, EXACT ? ag_tag : 0u);
                         a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
                         a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
                         a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
@@ -1577,10 +1592,10 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             const int lim = half == 0 ? limit : limit - score1;
             const int tlen = half == 0 ? (int)(glen - tail_start) : seed_offset + lim;
             const bool banded = plen >= 3 * (2 * lim + 1);
-            ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
+            const LdsSeq P = lds_seq(ByteSeq{rdd + org, st}), Q = lds_seq(ByteSeq{qld + org, st}), T = lds_seq(ByteSeq{data + org, st});
             note_ag_extent(half, banded, plen, lim, tlen);
             AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, dir != 0, half == 0, ag_rows,
-                                                 EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab);
+                                                 EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab, EXACT ? ag_tag : 0u);
             a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
             a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
             a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);

@@ -142,6 +142,14 @@ static __device__ __forceinline__ BtSink bt_sink(uint8_t *ubase, uint32_t n_byte
 #endif
     return s;
 }
+// EXACT traceback images (ag.h): a cell's byte uses bits 0, 1, 2 and 5; the other four carry the TAG of the read that wrote it (1 .. 15, the
+// wave's read counter modulo 15), and a cell whose tag is not the current read's reads as zero -- which is what "every read starts with
+// zeroed arrays" means.  The images are then cleared once per fifteen reads instead of once per read (57 KB of stores per read, half of
+// the kernel's HBM writes: profiles/r04z).  Tag 0 = untagged images (the one-call test entries, the resolver's own images).
+#define BT_TAG_MASK 0xD8u
+static __host__ __device__ __forceinline__ uint32_t bt_tag_bits(uint32_t epoch) { return ((epoch & 3u) << 3) | ((epoch & 12u) << 4); }
+static __device__ __forceinline__ int bt_cell(int raw, uint32_t tag) { return ((uint32_t)raw & BT_TAG_MASK) == tag ? (raw & 0x27) : 0; }
+
 // sink[uoff + voff] = val   (uoff wave-uniform, voff per lane)
 static __device__ __forceinline__ void bt_store(const BtSink &s, uint32_t uoff, uint32_t voff, uint32_t val) {
 #if defined(SNAPGPU_WAVE_EMU)
@@ -151,6 +159,15 @@ static __device__ __forceinline__ void bt_store(const BtSink &s, uint32_t uoff, 
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)val, s.rsrc, (int)voff, (int)first_u32(uoff), 0);
 #endif
 }
+
+// Event counters of the wavefront emulator's build only (tests/emu, scripts/emu_stats.py: how many Landau-Vishkin levels, affine-gap rows, lazy-F
+// rounds ... a read costs): nothing in a device build.
+#if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
+extern unsigned long long g_emu_stats[64];
+#define EMU_STAT(i, n) do { if (lane_id() == 0) __atomic_fetch_add(&g_emu_stats[i], (unsigned long long)(n), __ATOMIC_RELAXED); } while (0)
+#else
+#define EMU_STAT(i, n) do { } while (0)
+#endif
 
 // A wave-uniform 64-bit lane mask as a per-lane predicate at no VALU cost: the mask goes to VCC (or stays in its SGPR pair) and the consumer is
 // a v_cndmask_b32_e64 / an exec update that reads it directly (llvm.amdgcn.inverse.ballot).  `mask` must be wave-uniform.

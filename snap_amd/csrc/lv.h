@@ -28,6 +28,19 @@ struct ByteSeq {                 // s(i) = p[i*stride]
     __device__ __forceinline__ uint8_t operator()(int i) const { return p[i * stride]; }
 };
 
+// The same, for bytes that are known to lie in LDS -- the kernels' reads, qualities and reference window do.  Landau-Vishkin and affine gap
+// are functions (ag_win.h: ag_dispatch_fn); across a call a generic pointer is all the compiler knows and every P(i) / T(i) becomes a FLAT
+// load (both counters, the vector-memory path); as LdsSeq it is a ds_read_u8.
+struct LdsSeq {
+    LDS_AS const uint8_t *p;
+    int stride;
+    __device__ __forceinline__ uint8_t operator()(int i) const { return p[i * stride]; }
+};
+// (No "is this pointer LDS" test here: the callers pass base + origin with origin = -1 for an empty backward half, and a generic pointer one
+//  byte below LDS address 0 -- wave 0's read buffer starts there -- is outside the LDS aperture although its low 32 bits are the right LDS
+//  address.  Such a test stopped the paired-end kernel on hardware, profiles/r04w.)
+static __device__ __forceinline__ LdsSeq lds_seq(const ByteSeq &s) { return LdsSeq{(LDS_AS const uint8_t *)s.p, s.stride}; }
+
 #define LV_PLANES_FROM 3               // first level whose bitmaps come from planes (lv_compute_inl)
 
 struct LVResult {
@@ -81,6 +94,7 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
     if (k > 126) k = 126;                                   // :142
     if (k > (int)kmax) k = (int)kmax;
     res.match_probability = 1.0;
+    EMU_STAT(0, 1);
 
     M32 *bt = (M32 *)((M8 *)lds_tri + (((kmax + 1) * (kmax + 1) * 2 + 3) & ~3u));
     // Mismatch bitmaps, one per diagonal (row = visiting rank), built as a level first needs the diagonal: bit i is set when
@@ -113,6 +127,7 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
     }
     if (run0 > end0) run0 = end0;
     if (run0 == end0) {                                     // :170-185
+        EMU_STAT(1, 1);
         int result = pattern_len > end0 ? pattern_len - end0 : 0;
         res.match_probability = tab->perfect[pattern_len];
         if (result > k) { res.score = -1; return res; }
@@ -129,12 +144,14 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
         const M16 *prev_row = lds_tri + (e - 1) * (e - 1);
         M16 *row = lds_tri + e * e;
         int x_rank = 1 << 30, any_rank = 1 << 30;
+        EMU_STAT(2, 1);
         if (planes == nullptr || e < LV_PLANES_FROM) {
             if (e == 1) build_mask(0);
             build_mask(2 * e - 1);
             build_mask(2 * e);
             WAVE_SYNC();
         } else if (e == LV_PLANES_FROM) {
+            EMU_STAT(3, 1);
             const int n_pw = nwu, n_sw = ((pattern_len + 2 * k + 63) >> 6) + 1;
             lv_planes_prepare(*planes, k, pattern_len, n_pw, n_sw);
             WAVE_SYNC();
@@ -189,7 +206,7 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
         if (x_rank != (1 << 30)) { last_best_rank = x_rank; break; }       // :243-248 (goto got_answer)
         if (any_rank != (1 << 30)) { last_best_rank = any_rank; break; }   // :253-264
     }
-    if (last_best_rank < 0) { res.score = -1; return res; }                // :267-269 (probability stays 1.0)
+    if (last_best_rank < 0) { EMU_STAT(4, 1); res.score = -1; return res; }                // :267-269 (probability stays 1.0)
 
     // ---- backtrace (:286-304): uniform, every lane walks the same path
     {
@@ -246,6 +263,7 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
         res.match_probability = prob;
         res.net_indel = net; res.total_indels = total; res.text_span = span;
     }
+    EMU_STAT(5, 1); EMU_STAT(6, e);
     res.score = e;
     return res;
 }
@@ -253,6 +271,13 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
 // One copy of the Landau-Vishkin code per kernel (see ag_win.h: ag_dispatch_fn for the why); wave-uniform arguments are made scalar on entry.
 static __device__ __forceinline__ ByteSeq seq_uniform(const ByteSeq &s) {
     return ByteSeq{(const uint8_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)s.p), (int)first_u32((uint32_t)s.stride)};
+}
+static __device__ __forceinline__ LdsSeq seq_uniform(const LdsSeq &s) {
+#if defined(SNAPGPU_WAVE_EMU)
+    return LdsSeq{(const uint8_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)s.p), (int)first_u32((uint32_t)s.stride)};
+#else
+    return LdsSeq{(LDS_AS const uint8_t *)(uintptr_t)first_u32((uint32_t)(uintptr_t)s.p), (int)first_u32((uint32_t)s.stride)};
+#endif
 }
 template <class S> static __device__ __forceinline__ S seq_uniform(const S &s) { return s; }
 

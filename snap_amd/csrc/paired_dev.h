@@ -22,6 +22,7 @@ struct DevPL {
     Aligner<AGC, SEC, EXACT> *al;      // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
     uint8_t *ag_persist0, *ag_persist1;
     uint32_t ag_hw0, ag_hw1;           // EXACT: bytes of each image written since it was last zeroed
+    uint32_t ag_epoch, ag_tag;         // EXACT: pairs since the images were last cleared (1 .. 15), its tag bits (dev_common.h: bt_cell)
     // Phase-4 help (not in the exact replay: there the affine-gap calls of a pair are ordered through the traceback arrays they share)
     static const bool HELP = !EXACT;
     static const bool ALWAYS_COUNT_STALE = EXACT;
@@ -365,7 +366,7 @@ struct DevPL {
     __device__ __forceinline__ double perfect(int n) const { return tab->perfect[n]; }
 
     __device__ __forceinline__ LVOut lv(int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int k) {
-        ByteSeq Ps{P, st}, Qs{Q, st}, Ts{T, st};
+        const LdsSeq Ps = lds_seq(ByteSeq{P, st}), Qs = lds_seq(ByteSeq{Q, st}), Ts = lds_seq(ByteSeq{T, st});      // (reads, qualities and the window are LDS: lv.h LdsSeq)
         // the LDS triangle serves limits up to cfg.kmax; a larger one (indel-hinted candidates only) works in the wave's HBM buffer
         LVResult r = k <= (int)al->cfg.kmax ? lv_compute(Ps, Qs, plen, Ts, tlen, k, al->lv_tri, al->cfg.kmax, tab, al->cfg.RL)
                                             : lv_compute<false>(Ps, Qs, plen, Ts, tlen, k, lv_big, kmax_lv, tab, al->cfg.RL);
@@ -376,7 +377,7 @@ struct DevPL {
     }
     __device__ __forceinline__ AGOut ag(bool banded, int st, const uint8_t *P, const uint8_t *Q, int plen, const uint8_t *T, int tlen, int lim,
                                         int read_len, bool is_rc, int use_clip) {
-        ByteSeq Ps{P, st}, Qs{Q, st}, Ts{T, st};
+        const LdsSeq Ps = lds_seq(ByteSeq{P, st}), Qs = lds_seq(ByteSeq{Q, st}), Ts = lds_seq(ByteSeq{T, st});
         if constexpr (EXACT) {
             int nv, sl, ns;
             ag_dims(banded, plen, lim > 126 ? 126 : (lim < 0 ? 0 : lim), &nv, &sl, &ns);
@@ -389,7 +390,7 @@ struct DevPL {
         }
         if (++al->ag_calls_unit == WAVE_PRIO_HEAVY_AFTER * 8) wave_set_priority(1);          // (a pair: both mates, both halves, Phases 3 and 4)
         AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, Ps, Qs, plen, Ts, tlen, lim, read_len, is_rc, use_clip, al->ag_rows,
-                                             EXACT ? (st == 1 ? ag_persist0 : ag_persist1) : al->ag_scratch, al->cfg.RL, tab);
+                                             EXACT ? (st == 1 ? ag_persist0 : ag_persist1) : al->ag_scratch, al->cfg.RL, tab, EXACT ? ag_tag : 0u);
         AGOut o;
         o.ag_score = i32(a.ag_score); o.text_offset = i32(a.text_offset); o.pattern_offset = i32(a.pattern_offset);
         o.n_edits = i32(a.n_edits); o.mp = f64(a.match_probability); o.stale = i32(a.stale_reads);
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv; pl.lv_big = (uint16_t *)(sc + a.off_lv_big);
     al.ag_persist0 = al.ag_persist1 = pl.ag_persist0 = pl.ag_persist1 = nullptr;
     al.ag_hw0 = al.ag_hw1 = pl.ag_hw0 = pl.ag_hw1 = 0;
+    pl.ag_epoch = 0; pl.ag_tag = 0;
     pl.help = EXACT ? nullptr : a.help; pl.n_help = a.n_help; pl.help_spec = a.help_spec; pl.help_spec_cap = a.help_spec_cap;
     pl.help_idle = a.help_done ? a.help_done + 1 : nullptr; pl.help_eager = a.help_eager != 0;
     pl.cur_pair = 0; pl.my_slot = -1; pl.diag = a.counters + 13;
@@ -627,13 +629,16 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
             if (i >= n_total) break;
             if (a.remap) i = first_u32(a.remap[i]);
         }
-        if constexpr (EXACT) {          // newly constructed reference aligners: all four traceback arrays read as zero
-            if (pl.ag_hw0) wave_zero16(pl.ag_persist0, ((size_t)pl.ag_hw0 + 15) & ~(size_t)15);
-            if (pl.ag_hw1) wave_zero16(pl.ag_persist1, ((size_t)pl.ag_hw1 + 15) & ~(size_t)15);
-            if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
-            if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
-            pl.ag_hw0 = pl.ag_hw1 = al.ag_hw0 = al.ag_hw1 = 0;
-            WAVE_SYNC();
+        if constexpr (EXACT) {          // newly constructed reference aligners: all four traceback arrays read as zero -- cleared once per
+            if (++pl.ag_epoch == 16u) { // fifteen pairs; in between, cells that do not carry this pair's tag read as zero (dev_common.h: bt_cell)
+                if (pl.ag_hw0) wave_zero16(pl.ag_persist0, ((size_t)pl.ag_hw0 + 15) & ~(size_t)15);
+                if (pl.ag_hw1) wave_zero16(pl.ag_persist1, ((size_t)pl.ag_hw1 + 15) & ~(size_t)15);
+                if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
+                if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
+                pl.ag_hw0 = pl.ag_hw1 = al.ag_hw0 = al.ag_hw1 = 0; pl.ag_epoch = 1u;
+                WAVE_SYNC();
+            }
+            pl.ag_tag = al.ag_tag = bt_tag_bits(pl.ag_epoch);
         }
         load_pair(i);
         pl.cur_pair = i;

@@ -71,12 +71,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         if (i >= n_total) break;
         if (a.remap) i = first_u32(a.remap[i]);
         else if (a.order) i = first_u32(a.order[i]);
-        if constexpr (EXACT) {          // a newly constructed reference aligner: both traceback arrays read as zero
-            if (al.ag_hw0) wave_zero16(al.ag_persist0, ((size_t)al.ag_hw0 + 15) & ~(size_t)15);
-            if (al.ag_hw1) wave_zero16(al.ag_persist1, ((size_t)al.ag_hw1 + 15) & ~(size_t)15);
-            al.ag_hw0 = al.ag_hw1 = 0;
-            WAVE_SYNC();
-        }
+        al.new_read_images();           // EXACT: a newly constructed reference aligner: both traceback arrays read as zero
         al.cur_read = i;
         uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
         const uint64_t dbg_t0 = TIMED ? wave_clock() : 0; const uint64_t dbg_ag0 = al.cnt.ag;
