@@ -260,7 +260,7 @@ struct Options {
     int om = -1, mpc = -1; long long omax = 0x7fffffff;
     bool ae = false;                                                       // -ae: AlignmentAdjuster before the -om filter (single end only)
     bool stop_on_first_hit = false, explore_popular_seeds = false;         // -f, -x (single end; the paired-end aligners ignore them, as the reference's do)
-    int n_gpus = 0, ctx_per_gpu = 3, n_format = 0, n_parse = 0;
+    int n_gpus = 0, ctx_per_gpu = 0, n_format = 0, n_parse = 0;
     bool seqread = false;                                                  // -seqread: the sequential FASTQ reader even for a plain file
     uint32_t ops_stride = 64;
     bool bam = false;                                                      // -o x.bam: BAM records in BGZF blocks (SNAPLib/Bam.cpp)
@@ -1071,6 +1071,10 @@ int main(int argc, char **argv)
     o.bam = out_path.size() > 4 && out_path.compare(out_path.size() - 4, 4, ".bam") == 0;     // by extension, like the reference (AlignerOptions.cpp)
     if (o.batch_reads < (o.paired ? 2u : 1u)) die("-b must be at least 1 (2 for paired)");
     if (o.paired) o.batch_reads &= ~(size_t)1;
+    // feeders per GPU: a launch lasts as long as its slowest read (~150 ms when the batch holds one of the heavy ones), so batches of 131 072
+    // reads need several launches in flight to keep the chip busy: 20 M reads go through at 2.24 / 2.47 / 2.50 M reads/s with 3 / 6 / 8
+    // feeders (profiles/r04zy).  The paired-end launches are long already.
+    if (o.ctx_per_gpu == 0) o.ctx_per_gpu = o.paired ? 3 : 6;
     if (o.ctx_per_gpu < 1 || o.ctx_per_gpu > 8) die("-q must be in [1, 8]");
     // cigar ops per record: about 2 * edits + soft clips; grown on demand when a record needs more (with_growing_stride)
     { uint32_t need = 2 * (o.p.max_k + o.p.extra_search_depth) + 8; o.ops_stride = 64; while (o.ops_stride < need) o.ops_stride *= 2; }
