@@ -11,6 +11,11 @@
 // LDS as int16[vector][8], one traceback byte per cell goes to a per-wave slab of HBM scratch.  8 of 64 lanes compute; the
 // banded form -- the common case, taken when patternLen >= 3 (2k + 1) -- touches about two vectors per text row, so a 150 bp
 // read costs ~10^4 wave instructions, against ~10^5 for its alignment.  (Packing 8 reads into a wave is the obvious next step.)
+// Round 4: the row loops keep the row's traceback bytes in LDS while the row is worked on (first pass, then lazy F's read-modify-write of
+// the same cells) and hand the finished row to the HBM slab with one store -- the slab used to be read and written cell by cell INSIDE the
+// lazy-F loop, a ~1 us HBM round trip per vector and round, which is what a read cost (5.7 M reads/s for the whole chip, three times the
+// wave cycles of the alignment itself: profiles/r04n, r04zy).  The traceback fetches 64 cells up the diagonal per load instead of one
+// cell per step.
 //
 // Reference nondeterminism: the banded traceback may step to a cell the call did not evaluate and then reads what an EARLIER call
 // left in the object's backtraceAction array (:811-824 over :1441).  Here such a cell reads 0 and the item is flagged `stale`.
@@ -33,7 +38,7 @@ static __host__ __device__ __forceinline__ size_t agc_scratch_bytes(uint32_t RL)
 }
 static __host__ __device__ __forceinline__ uint32_t agc_lds_bytes(uint32_t RL) {
     const uint32_t a = (RL + 15) & ~15u, t = (RL + LVC_MAX_K + 15) & ~15u, h = (agc_positions(RL) * 2 + 15) & ~15u;
-    return 2 * a + t + 3 * h;                                                                                             // pattern, quality, text, H, H-1, E
+    return 2 * a + t + 3 * h + ((agc_positions(RL) + 15) & ~15u);                                                         // pattern, quality, text, H, H-1, E, the row's traceback bytes
 }
 
 static __device__ __forceinline__ int agc_sat(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }             // _mm_adds/_mm_subs_epi16
@@ -42,6 +47,7 @@ struct AGCState {
     const uint8_t *pat, *qual, *txt;         // LDS
     int16_t *H, *Hm1, *E;                    // LDS, [vector][8]
     uint8_t *bt;                             // HBM scratch: [row][vector][8]
+    uint8_t *bt_row;                         // LDS: the bytes of the row being computed, [vector][8]
     uint32_t *res;                           // HBM scratch: action | count << 2
     int bt_stride;                           // bytes per row
     AGCParams prm;
@@ -70,19 +76,27 @@ static __device__ __forceinline__ AGCOut agc_traceback_and_emit(const AGCState &
         int row = text_used, col = plen - 1;
         int action = AGC_ACT_M, prev = AGC_ACT_X, count = 1;
         while (row >= 0 && col >= 0) {
+            // one load fetches the next 64 cells up the diagonal; they are consumed for as long as the path keeps stepping diagonally
+            const int rt = row - lane, ct = col - lane;
             bool evaluated = true;
-            const int b = cell(row, col, &evaluated);
-            if (!evaluated) o.stale = true;
-            action = (b >> (action << 1)) & 3;
-            if (action == AGC_ACT_M) { row--; col--; }
-            else if (action == AGC_ACT_D) { row--; }
-            else { col--; action = AGC_ACT_I; }
-            if (prev == action) count++;
-            else if (prev != AGC_ACT_X) {
-                if (lane == 0) s.res[n_res] = (uint32_t)prev | ((uint32_t)count << 2);
-                n_res++; count = 1;
+            const int bl = (rt >= 0 && ct >= 0) ? cell(rt, ct, &evaluated) : 0;
+            const int info = (bl & 0xff) | (evaluated ? 0 : 0x100);
+            for (int t = 0; t < WAVE && row >= 0 && col >= 0; t++) {
+                const int b = __builtin_amdgcn_readlane(info, t);
+                if (b & 0x100) o.stale = true;
+                action = ((b & 0xff) >> (action << 1)) & 3;
+                bool left_diagonal = false;
+                if (action == AGC_ACT_M) { row--; col--; }
+                else if (action == AGC_ACT_D) { row--; left_diagonal = true; }
+                else { col--; action = AGC_ACT_I; left_diagonal = true; }
+                if (prev == action) count++;
+                else if (prev != AGC_ACT_X) {
+                    if (lane == 0) s.res[n_res] = (uint32_t)prev | ((uint32_t)count << 2);
+                    n_res++; count = 1;
+                }
+                prev = action;
+                if (left_diagonal) break;
             }
-            prev = action;
         }
         if (prev == action) { if (lane == 0) s.res[n_res] = (uint32_t)prev | ((uint32_t)count << 2); n_res++; }                 // :433-437
         if (row >= 0) { if (lane == 0) s.res[n_res] = (uint32_t)AGC_ACT_D | ((uint32_t)(row + 1) << 2); n_res++; }              // :439-444
@@ -193,7 +207,7 @@ static __device__ __forceinline__ AGCOut agc_full(const AGCState &s, int plen, i
     int score = -32768, text_used = -1;
     for (int i = 0; i < tlen; i++) {
         const int tb = (int)base_value(s.txt[i]);
-        uint8_t *btrow = s.bt + (size_t)i * s.bt_stride;
+        uint8_t *btrow = s.bt_row;                                           // (LDS; goes to s.bt + i * s.bt_stride when the row is done)
         int f = -32768;
         int h = __shfl_up((int)Hp[(num_vec - 1) * 8 + el], 1);
         const int h_init = i > 0 ? -(open + (i - 1) * ext) : 0;
@@ -237,15 +251,17 @@ static __device__ __forceinline__ AGCOut agc_full(const AGCState &s, int plen, i
             }
         }
         WAVE_SYNC();
+        for (int x = lane; x < num_vec * 8; x += WAVE) s.bt[(size_t)i * s.bt_stride + x] = btrow[x];                     // the finished row
+        WAVE_SYNC();
         const int g = (int)first_u32((uint32_t)(int)Hm[((plen - 1) % num_vec) * 8 + (plen - 1) / num_vec]);              // :341-346
         if (g >= score) { score = g; text_used = i; }
         { int16_t *t = Hm; Hm = Hp; Hp = t; }
     }
     WAVE_SYNC();
     if (!(score > -32768)) { AGCOut o; o.n_edits = -1; o.net_del = 0; o.tail_ins = 0; o.n_ops = 0; o.stale = false; return o; }
-    auto cell = [&](int row, int col, bool *evaluated) -> int {
+    auto cell = [&](int row, int col, bool *evaluated) -> int {                 // (per lane)
         *evaluated = true;
-        return (int)first_u32((uint32_t)s.bt[(size_t)row * s.bt_stride + (col % num_vec) * 8 + col / num_vec]);
+        return (int)s.bt[(size_t)row * s.bt_stride + (col % num_vec) * 8 + col / num_vec];
     };
     return agc_traceback_and_emit(s, plen, text_used, use_m, cell, ops, ops_cap);
 }
@@ -274,7 +290,7 @@ static __device__ __forceinline__ AGCOut agc_banded(const AGCState &s, int plen,
     int score = score_init, text_used = -1;
     for (int i = 0; i < tlen; i++) {
         const int tb = (int)base_value(s.txt[i]);
-        uint8_t *btrow = s.bt + (size_t)i * s.bt_stride;
+        uint8_t *btrow = s.bt_row;                                           // (LDS; the evaluated vectors go to s.bt + i * s.bt_stride when the row is done)
         int f = 0, X = 0;
         const int band_beg = i - w > 0 ? i - w : 0;
         const int band_end = i + w < plen - 1 ? i + w : plen - 1;
@@ -332,6 +348,13 @@ static __device__ __forceinline__ AGCOut agc_banded(const AGCState &s, int plen,
             f = el == 0 ? X : 0;                                            // :783
         }
         WAVE_SYNC();
+        {   // the finished row: the vectors this row evaluated are a contiguous range (every vector of segments seg_beg .. seg_end - 1, and
+            // of the last segment those that start inside the band); nothing else of the slab's row is touched
+            const int k_last = band_end - seg_end * seg_len < num_vec - 1 ? band_end - seg_end * seg_len : num_vec - 1;
+            const int x0 = seg_beg * num_vec * 8, x1 = (seg_end * num_vec + k_last + 1) * 8;
+            for (int x = x0 + lane; x < x1; x += WAVE) s.bt[(size_t)i * s.bt_stride + x] = btrow[x];
+            WAVE_SYNC();
+        }
         if (band_end == plen - 1) {                                         // :803-815
             const int vec = (band_end / seg_len) * num_vec + (band_end % seg_len) % num_vec, e_i = (band_end % seg_len) / num_vec;
             const int g = (int)first_u32((uint32_t)(int)Hm[vec * 8 + e_i]);
@@ -342,12 +365,12 @@ static __device__ __forceinline__ AGCOut agc_banded(const AGCState &s, int plen,
     WAVE_SYNC();
     // score >= scoreInit > 0 always (:802).  With textUsed == -1 (no row beat scoreInit) the walk below does nothing and the result
     // is "the whole pattern is a tail insertion", which computeGlobalScoreNormalized takes as a failed band (:1074).
-    auto cell = [&](int row, int col, bool *evaluated) -> int {
+    auto cell = [&](int row, int col, bool *evaluated) -> int {                 // (per lane)
         const int bb = row - w > 0 ? row - w : 0, be = row + w < plen - 1 ? row + w : plen - 1;
         const int sg = col / seg_len, v = (col % seg_len) % num_vec;
         *evaluated = sg >= bb / seg_len && sg <= be / seg_len && sg * seg_len + v <= be;
         if (!*evaluated) return 0;
-        return (int)first_u32((uint32_t)s.bt[(size_t)row * s.bt_stride + (sg * num_vec + v) * 8 + (col % seg_len) / num_vec]);
+        return (int)s.bt[(size_t)row * s.bt_stride + (sg * num_vec + v) * 8 + (col % seg_len) / num_vec];
     };
     return agc_traceback_and_emit(s, plen, text_used, use_m, cell, ops, ops_cap);
 }
@@ -387,6 +410,7 @@ static __device__ __forceinline__ CigarAGItemOut cigar_ag_item(const DevIndex &i
     s.pat = lp; s.qual = lq; s.txt = lt;
     s.H = (int16_t *)(lds + 2 * a + t); s.Hm1 = (int16_t *)(lds + 2 * a + t + h); s.E = (int16_t *)(lds + 2 * a + t + 2 * h);
     s.bt = scratch; s.bt_stride = (int)agc_positions(RL);
+    s.bt_row = lds + 2 * a + t + 3 * h;
     s.res = (uint32_t *)(scratch + (size_t)agc_rows(RL) * agc_positions(RL));
     s.prm = prm;
     const long long readable = nb + (long long)ix.genome_pad - loc;
