@@ -4,7 +4,7 @@ traceback steps -- counted by the wavefront emulator's build of the device code 
 exists in a device build).  Runs the 1 000 committed 150-bp golden reads (tests/golden/tiny_reads.npz) through k_align_single and prints
 the counters per read.  Builds its own copy of the emulator library under /tmp/snapgpu_emu_stats (-DSNAPGPU_AG_WIN_STATS).
 
-    python scripts/emu_stats.py [n_reads] [--bench-like]
+    python scripts/emu_stats.py [n_reads] [--bench-like] [--sam]
 --bench-like: reads drawn from the fixture genome the way bench.py draws them (synth.make_reads with its defaults: 1 % substitutions, 0.05 %
 insertions and deletions), checked against the C restatement (oracle/) instead of the committed reference results.
 """
@@ -22,7 +22,9 @@ import tests.emu.build as eb                           # noqa: E402
 
 NAMES = {0: "LV calls", 1: "LV calls ending in the perfect-match prefix", 2: "LV levels (e >= 1)", 3: "LV calls reaching the planes level", 4: "LV calls above the limit",
          5: "LV calls with an answer at e >= 1", 6: "sum of e over those", 8: "affine-gap window calls", 9: "affine-gap window rows", 10: "window slides",
-         11: "rows whose X changed after the first segment's rounds", 12: "rows with two segments", 13: "traceback gathers (64 cells each)", 14: "rows on which (nk0, nk1) changed"}
+         11: "rows whose X changed after the first segment's rounds", 15: "second segments in rounds because a later stripe end beats stripe 0's flow", 16: "... because some cell's offer is below T_fp",
+         32: "SAM: affine-gap CIGAR items", 33: "SAM: banded calls", 34: "SAM: full (unbanded) calls", 35: "SAM: banded rows", 36: "SAM: full rows",
+         37: "SAM: banded first-pass vectors", 38: "SAM: banded lazy-F vector steps", 39: "SAM: full first-pass vectors", 40: "SAM: full lazy-F vector steps", 41: "SAM: traceback gathers", 12: "rows with two segments", 13: "traceback gathers (64 cells each)", 14: "rows on which (nk0, nk1) changed"}
 
 
 def main():
@@ -62,6 +64,9 @@ def main():
     else:
         bad = util.compare_results(z["default_d8_150_primary"][:n], prim, exclude=z["default_d8_150_unstable"][:n])
     assert not bad, bad
+    if "--sam" in sys.argv:                  # the SAM side over the same reads: SAMFormat::computeCigar's affine-gap variant (cigar_ag.h)
+        nrd = len(prim)
+        a.samFields(b, q, offs, np.zeros(nrd, np.int32), np.full(nrd, 150, np.int32), prim)
     a.close()
     h = C.CDLL(lib_path)
     st = (C.c_ulonglong * 64).in_dll(h, "g_emu_stats")

@@ -19,8 +19,8 @@ fi
 [ -n "$SAM_CHECK_ONLY" ] && exit 0
 N=${SAM_CAT:-20}; k=0; while [ $k -lt $N ]; do cat $I/single.fq; k=$((k+1)); done > $W/big.fq
 for rep in ${SAM_REPS:-1 2}; do
-  for which in new old; do
-    tool=$T; [ $which = old ] && tool=$OLD
+  for which in ${SAM_WHICH:-new old}; do
+    tool=$T; [ $which = old ] && tool=$OLD; [ $which = mid ] && tool=snap_amd/ab/mid/snapgpu-sam
     SNAPGPU_SAM_VERBOSE=1 timeout 100 $tool single $I/index $W/big.fq -d 8 -o $W/big.sam > $O/time_${which}_$rep.txt 2>&1
     echo "== $which ($rep): $(grep -o 'FASTQ -> SAM in .*reads/s' $O/time_${which}_$rep.txt) | $(grep -o 'feeders: .*' $O/time_${which}_$rep.txt | cut -c1-110)"
   done

@@ -77,6 +77,7 @@ static __device__ __forceinline__ AGCOut agc_traceback_and_emit(const AGCState &
         int action = AGC_ACT_M, prev = AGC_ACT_X, count = 1;
         while (row >= 0 && col >= 0) {
             // one load fetches the next 64 cells up the diagonal; they are consumed for as long as the path keeps stepping diagonally
+            EMU_STAT(41, 1);
             const int rt = row - lane, ct = col - lane;
             bool evaluated = true;
             const int bl = (rt >= 0 && ct >= 0) ? cell(rt, ct, &evaluated) : 0;
@@ -205,7 +206,9 @@ static __device__ __forceinline__ AGCOut agc_full(const AGCState &s, int plen, i
     }
     WAVE_SYNC();
     int score = -32768, text_used = -1;
+    EMU_STAT(34, 1);
     for (int i = 0; i < tlen; i++) {
+        EMU_STAT(36, 1); EMU_STAT(39, num_vec);
         const int tb = (int)base_value(s.txt[i]);
         uint8_t *btrow = s.bt_row;                                           // (LDS; goes to s.bt + i * s.bt_stride when the row is done)
         int f = -32768;
@@ -239,6 +242,7 @@ static __device__ __forceinline__ AGCOut agc_full(const AGCState &s, int plen, i
             f = __shfl_up(f, 1);
             if (el == 0) f = -32768;
             for (int j = 0; j < num_vec; j++) {
+                EMU_STAT(40, 1);
                 int hh = (int)Hm[j * 8 + el];
                 int bt = (int)btrow[j * 8 + el];
                 { const int t = f > hh ? 2 : 0; bt = t | (bt & ~t); }
@@ -288,7 +292,10 @@ static __device__ __forceinline__ AGCOut agc_banded(const AGCState &s, int plen,
     }
     WAVE_SYNC();
     int score = score_init, text_used = -1;
+    int idle_rows = 0;                                                      // rows since the band left the last segment (see the end of the loop)
+    EMU_STAT(33, 1);
     for (int i = 0; i < tlen; i++) {
+        EMU_STAT(35, 1);
         const int tb = (int)base_value(s.txt[i]);
         uint8_t *btrow = s.bt_row;                                           // (LDS; the evaluated vectors go to s.bt + i * s.bt_stride when the row is done)
         int f = 0, X = 0;
@@ -304,6 +311,7 @@ static __device__ __forceinline__ AGCOut agc_banded(const AGCState &s, int plen,
             if (el == 0) h = h_init;
             for (int k = 0; k < num_vec && j * seg_len + k <= band_end; k++) {
                 const int vi = (j * num_vec + k) * 8 + el;
+                EMU_STAT(37, 1);
                 const int m = agc_sat(h + agc_profile(s, tb, j * seg_len + el * num_vec + k, plen));
                 int e = (int)s.E[vi];
                 int bt = e > m ? 1 : 0;
@@ -334,6 +342,7 @@ static __device__ __forceinline__ AGCOut agc_banded(const AGCState &s, int plen,
                 if (el == 0) f = 0;
                 for (int v = 0; v < num_vec && j * seg_len + v <= band_end; v++) {
                     const int vi = (j * num_vec + v) * 8 + el;
+                    EMU_STAT(38, 1);
                     int hh = (int)Hm[vi];
                     int bt = (int)btrow[vi];
                     { const int t = f > hh ? 2 : 0; bt = t | (bt & ~t); }
@@ -361,10 +370,140 @@ static __device__ __forceinline__ AGCOut agc_banded(const AGCState &s, int plen,
             if (g > score) { score = g; text_used = i; }
         }
         { int16_t *t = Hm; Hm = Hp; Hp = t; }
+        // Once the band's start has left the last segment a row evaluates nothing: all it does is look at the pattern-end cell of the
+        // buffer the swap hands it -- the rows of two and of one row ago, in turn.  After two such rows both have been looked at and the
+        // remaining ~100 rows of the text (plen + LVC_MAX_K of them) cannot change score or text_used: stop.
+        if (seg_beg > seg_end && ++idle_rows == 2) break;
     }
     WAVE_SYNC();
     // score >= scoreInit > 0 always (:802).  With textUsed == -1 (no row beat scoreInit) the walk below does nothing and the result
     // is "the whole pattern is a tail insertion", which computeGlobalScoreNormalized takes as a failed band (:1074).
+    auto cell = [&](int row, int col, bool *evaluated) -> int {                 // (per lane)
+        const int bb = row - w > 0 ? row - w : 0, be = row + w < plen - 1 ? row + w : plen - 1;
+        const int sg = col / seg_len, v = (col % seg_len) % num_vec;
+        *evaluated = sg >= bb / seg_len && sg <= be / seg_len && sg * seg_len + v <= be;
+        if (!*evaluated) return 0;
+        return (int)s.bt[(size_t)row * s.bt_stride + (sg * num_vec + v) * 8 + (col % seg_len) / num_vec];
+    };
+    return agc_traceback_and_emit(s, plen, text_used, use_m, cell, ops, ops_cap);
+}
+
+// computeGlobalScoreBanded once more, with the vectors of a segment side by side: lane = vector k * 8 + SSE element el (num_vec <= 8).
+// The reference visits a segment's vectors one after the other, and so did agc_banded above -- 8 lanes, 4.2 lazy-F steps per first-pass
+// vector, three LDS round trips per step.  But within a row only F runs along the vectors: the diagonal input of vector k is the
+// PREVIOUS row's H of vector k - 1, E is the cell's own, so the first pass of all vectors is one step plus a (K - 1)-step hand-over of F
+// from lane group to lane group; and in a lazy-F round what reaches vector v is the round's incoming F minus v * ext (the round never
+// raises F), so a round is one step for all vectors, the reference's "stop at the first vector in which no element's F goes on" is a
+// ballot, and every cell's H / E / traceback byte stays in ITS lane's registers from the first pass to the end of the lazy rounds.
+// Same operations on the same values in the reference's order where order matters; results identical to agc_banded (tests: the
+// reference's fixtures, tests/golden/cigar_ag.npz, sam_fields*.npz, the FASTQ -> SAM identity tests).
+static __device__ __forceinline__ AGCOut agc_banded_par(const AGCState &s, int plen, int tlen, int w, int score_init, bool use_m,
+                                                        uint32_t *ops, int ops_cap)
+{
+    const int lane = lane_id(), el = lane & 7, k = lane >> 3;
+    const int open = s.prm.gap_open, ext = s.prm.gap_ext;
+    if (w > LVC_MAX_K - 1) w = LVC_MAX_K - 1;
+    const int bw = 2 * w + 1 < plen ? 2 * w + 1 : plen;
+    const int num_vec = (bw + 7) / 8, seg_len = num_vec * 8, num_seg = (plen + seg_len - 1) / seg_len;      // (the caller guarantees num_vec <= 8)
+    int16_t *Hp = s.H, *Hm = s.Hm1;
+    {   // first row (:611-628), as in agc_banded
+        const bool st = lane < 8;
+        int sfr = 0;
+        for (int sg = 0; sg < num_seg; sg++)
+            for (int v = 0; v < num_vec; v++) {
+                const int p = sg * seg_len + el * num_vec + v;
+                if (p < plen) { const int x = score_init - (open + p * ext); sfr = x > 0 ? x : 0; }
+                if (st) { Hp[(sg * num_vec + v) * 8 + el] = (int16_t)sfr; Hm[(sg * num_vec + v) * 8 + el] = 0; s.E[(sg * num_vec + v) * 8 + el] = 0; }
+            }
+    }
+    WAVE_SYNC();
+    int score = score_init, text_used = -1;
+    int idle_rows = 0;
+    EMU_STAT(33, 1);
+    for (int i = 0; i < tlen; i++) {
+        EMU_STAT(35, 1);
+        const int tb = (int)base_value(s.txt[i]);
+        int fcar = 0, X = 0;                                                // F entering the segment (element 0 only: X of the segment before)
+        const int band_beg = i - w > 0 ? i - w : 0;
+        const int band_end = i + w < plen - 1 ? i + w : plen - 1;
+        const int seg_beg = band_beg / seg_len, seg_end = band_end / seg_len;
+        for (int j = seg_beg; j <= seg_end; j++) {
+            const int K = band_end - j * seg_len + 1 < num_vec ? band_end - j * seg_len + 1 : num_vec;     // vectors this row evaluates in the segment
+            const bool act = k < K;
+            const int kk_ = k < num_vec ? k : num_vec - 1;                  // (lanes beyond the segment's vectors compute on vector num_vec - 1's data and store nothing)
+            const int vi = (j * num_vec + kk_) * 8 + el;
+            EMU_STAT(37, 1);
+            int h_init;
+            if (j == 0) h_init = (int)(int16_t)(i > 0 ? score_init - (open + (i - 1) * ext) : score_init);
+            else if (band_beg > j * seg_len) h_init = 0;
+            else h_init = (int)first_u32((uint32_t)(int)Hp[(j * num_vec - 1) * 8 + 7]);
+            // diagonal input: vector 0 takes the segment's LAST vector of the previous row one element down (element 0: h_init), vector k > 0 the previous row's vector k - 1
+            const int hsrc = kk_ == 0 ? (j * num_vec + num_vec - 1) * 8 + (el > 0 ? el - 1 : 0) : vi - 8;
+            int h = (int)Hp[hsrc];
+            if (kk_ == 0 && el == 0) h = h_init;
+            const int m = agc_sat(h + agc_profile(s, tb, j * seg_len + el * num_vec + kk_, plen));
+            const int e = (int)s.E[vi];
+            const int me = m > e ? m : e;
+            int bt = e > m ? 1 : 0;
+            const int e2 = agc_sat(e - ext);
+            const int temp = agc_sat(m - open);
+            if (e2 > temp) bt |= 4;
+            const int e_new = e2 > temp ? e2 : temp;
+            // F along the vectors: f_0 = what the segment before left (element 0) or 0; f_{k+1} = max(sat(f_k - ext), temp_k)
+            int fk = fcar;
+            for (int st_ = 1; st_ < K; st_++) {
+                const int fo = agc_sat(fk - ext);
+                const int fn = fo > temp ? fo : temp;                       // (valid in the lanes of vector st_ - 1)
+                const int up = __shfl_up(fn, 8);
+                if (k >= st_) fk = up;
+            }
+            if (fk > me) bt |= 2;
+            int hv = me > fk ? me : fk;
+            const int f2 = agc_sat(fk - ext);
+            if (f2 > temp) bt |= 32;
+            const int fout = f2 > temp ? f2 : temp;
+            // lazy F (:737-781): the F that left the segment's last evaluated vector, element by element
+            int f = __shfl(fout, (K - 1) * 8 + el);
+            for (int kk = 0; kk < 7; kk++) {
+                EMU_STAT(38, 1);
+                {   // X = max(X, f >> 14 bytes): element 0 takes element 7 (:745)
+                    const int f7 = __builtin_amdgcn_readlane(f, 7);
+                    X = X > f7 ? X : f7;
+                }
+                int fin = __shfl_up(f, 1);
+                if (el == 0) fin = 0;
+                int fv = fin - kk_ * ext; if (fv < -32768) fv = -32768;     // kk_ saturating steps down from the round's incoming F
+                const bool f_wins = fv > hv;
+                const int hh = f_wins ? fv : hv;
+                const int temp2 = agc_sat(hh - open);
+                const int fnx = agc_sat(fv - ext);
+                const bool cont = fnx > temp2;
+                // the round stops after the first vector in which no element's F goes on; that vector is still updated
+                const unsigned long long cm = BALLOT(cont && act);
+                int vstop = K;                                              // K: no such vector, the round is complete
+                for (int v = 0; v < K; v++) if (((cm >> (8 * v)) & 0xffull) == 0ull) { vstop = v; break; }
+                if (act && k <= vstop) {
+                    if (f_wins) bt |= 2;
+                    hv = hh;
+                    if (cont) bt |= 32;
+                }
+                if (vstop < K) break;
+                int fe = fin - K * ext; if (fe < -32768) fe = -32768;       // F after the round's K vectors
+                f = fe;
+            }
+            fcar = el == 0 ? X : 0;                                         // :783
+            if (act) { Hm[vi] = (int16_t)hv; s.E[vi] = (int16_t)e_new; s.bt[(size_t)i * s.bt_stride + vi] = (uint8_t)bt; }
+            WAVE_SYNC();
+        }
+        if (band_end == plen - 1) {                                         // :803-815
+            const int vec = (band_end / seg_len) * num_vec + (band_end % seg_len) % num_vec, e_i = (band_end % seg_len) / num_vec;
+            const int g = (int)first_u32((uint32_t)(int)Hm[vec * 8 + e_i]);
+            if (g > score) { score = g; text_used = i; }
+        }
+        { int16_t *t = Hm; Hm = Hp; Hp = t; }
+        if (seg_beg > seg_end && ++idle_rows == 2) break;                   // (see agc_banded)
+    }
+    WAVE_SYNC();
     auto cell = [&](int row, int col, bool *evaluated) -> int {                 // (per lane)
         const int bb = row - w > 0 ? row - w : 0, be = row + w < plen - 1 ? row + w : plen - 1;
         const int sg = col / seg_len, v = (col % seg_len) % num_vec;
@@ -404,6 +543,7 @@ static __device__ __forceinline__ CigarAGItemOut cigar_ag_item(const DevIndex &i
         else ok = cend > loc + data_len;
         if (!ok) { o.n_ops = -1; return o; }
     }
+    EMU_STAT(32, 1);
     AGCState s;
     const uint32_t a = (RL + 15) & ~15u, t = (RL + LVC_MAX_K + 15) & ~15u, h = (agc_positions(RL) * 2 + 15) & ~15u;
     uint8_t *lp = lds, *lq = lds + a, *lt = lds + 2 * a;
@@ -423,7 +563,9 @@ static __device__ __forceinline__ CigarAGItemOut cigar_ag_item(const DevIndex &i
         const int plen = (int)(data_len - o.extra_after), tlen = plen + LVC_MAX_K;
         AGCOut r;
         if (plen >= 3 * (2 * k + 1)) {                                                                   // AffineGapVectorized.cpp:1068-1079
-            r = agc_banded(s, plen, tlen, k, AGC_MAX_READ_LENGTH, use_m, ops, ops_cap);
+            // (2k + 1 <= 64 positions per segment: the vectors of a segment side by side; wider bands -- k >= 32 -- one vector at a time)
+            r = k <= 31 ? agc_banded_par(s, plen, tlen, k, AGC_MAX_READ_LENGTH, use_m, ops, ops_cap)
+                        : agc_banded(s, plen, tlen, k, AGC_MAX_READ_LENGTH, use_m, ops, ops_cap);
             WAVE_SYNC();
             if (r.n_edits < 0 || r.n_edits > k || r.tail_ins >= plen) r = agc_full(s, plen, tlen, use_m, ops, ops_cap);     // "failed band"
         } else r = agc_full(s, plen, tlen, use_m, ops, ops_cap);
