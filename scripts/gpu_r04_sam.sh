@@ -1,7 +1,7 @@
 #!/bin/bash
 # r04sam: the SAM side after cigar_ag.h's row bytes moved to LDS and its traceback fetches 64 cells per load -- no Python on the box:
 # snap_amd/snapgpu-sam (this build) and snap_amd/ab/old/snapgpu-sam (the build before) over an index and FASTQ files made in the build
-# container (gpurun_in/sam_check: a 4 Mb genome indexed by the reference's indexer, 100 000 reads, 10 000 pairs), records compared with the
+# container by scripts/make_sam_check.py (gpurun_in/sam_check: a 4 Mb genome indexed by the reference's indexer, 100 000 reads, 10 000 pairs), records compared with the
 # reference CLI's (-t 1: its order is the input's; md5 of every line but @PG, computed in the build container), then both builds timed on
 # the reads SAM_CAT times over (default 20: 2 M reads; 200: 20 M).
 T=${SAM_TOOL:-snap_amd/snapgpu-sam}; OLD=${SAM_TOOL_OLD:-snap_amd/ab/old/snapgpu-sam}
