@@ -189,3 +189,38 @@ def test_multi_context_exports_argument_contract_two_processes():
         assert d["replica_null"] == -1 and d["replica_out"] in (None, 1234)          # SNAPGPU_E_INVALID, *out untouched or NULL
         assert d["bcast_null"] == -1 and d["bcast_zero"] == -1 and d["bcast_null_ctx"] == -1
         assert "snapgpu_broadcast_index" in d["err"]
+
+
+def test_kernel_source_hash_covers_the_timed_kernels_sources_only(tmp_path, monkeypatch):
+    """bench.py replays PMC counters only next to the build they were taken on: the hash must move with every source the align kernels are
+    compiled from (their translation units' include closure + the host launcher) and must NOT move with the SAM-side / index-builder
+    sources, which are not part of those kernels."""
+    import shutil
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "repo"
+    shutil.copytree(os.path.join(root, "snap_amd", "csrc"), fake / "snap_amd" / "csrc", ignore=shutil.ignore_patterns("host"))
+    monkeypatch.setattr(bench, "ROOT", str(fake))
+    h0 = bench.kernel_source_hash()
+    assert h0 == hashlib_of_repo(root, bench)
+
+    def touched(name):
+        p = fake / "snap_amd" / "csrc" / name
+        old = p.read_bytes()
+        p.write_bytes(old + b"\n// x\n")
+        h = bench.kernel_source_hash()
+        p.write_bytes(old)
+        return h
+    for name in ("ag_win.h", "lv.h", "align_single.h", "dev_common.h", "paired.h", "paired_dev.h", "single_kernel.h", "probe.h", "bucket.h", "snapgpu.hip", "single_timed_k.hip", "paired_k.hip"):
+        assert touched(name) != h0, name
+    for name in ("cigar_ag.h", "sam_fields.h", "cigar_k.hip", "index_build.h", "index_build.hip"):
+        assert touched(name) == h0, name
+
+
+def hashlib_of_repo(root, bench):
+    saved = bench.ROOT
+    try:
+        bench.ROOT = root
+        return bench.kernel_source_hash()
+    finally:
+        bench.ROOT = saved
