@@ -697,12 +697,20 @@ static void gpu_paired(const Options &o, snapgpu_ctx *ctx, Work &w)
         w.ops.assign(nrec * (size_t)w.ops_stride, 0); w.s_ops.assign(ns * (size_t)w.s_ops_stride, 0);
         auto ag_branch = [&](int used_ag, int score) { return o.p.use_affine_gap && (used_ag != 0 || score > 0); };
         // the state a written record leaves on its Read: `passed_len` is the data length the record was computed with
-        auto leave_behind = [&](size_t rd, bool more, bool ag, int status_in, int flag, int64_t pos, int n_ops, const uint32_t *ops, int clipped_before, int passed_len) {
+        // (`hr` / `paired_rec`: the result the record was computed from, for the two cases in which the record alone does not say what it left
+        //  behind -- a record given up after clipping adjustments, and a reverse-complement record at the first base of a contig, whose leading
+        //  soft clip may have been cut short there: the record loop is then run on the host for that one record, with the Read's state as it
+        //  is, and ITS back clipping is what the next record of the read starts from.  Until round 4 these two cases stopped the program.)
+        auto leave_behind = [&](size_t rd, bool more, bool ag, int status_in, int flag, int64_t pos, int n_ops, const uint32_t *ops, int clipped_before, int passed_len,
+                                const HostRes &hr, bool paired_rec) {
             if (!more || !ag) return;
             const size_t U = (size_t)(b.offsets[rd + 1] - b.offsets[rd]);
-            if ((flag & 0x4) && status_in != SNAPGPU_NotFound) die("paired -om / -ea: a record was given up after clipping adjustments and the read has further records (unsupported corner)");
+            if (((flag & 0x4) && status_in != SNAPGPU_NotFound) || ((flag & 0x10) && n_ops > 0 && pos == 1)) {
+                carry[rd] = host_record(o, ctx, b.bases.data() + b.offsets[rd], b.quals.data() + b.offsets[rd], (int)U, front_clip[rd], data_len[rd], carry[rd], hr, paired_rec).back_after;
+                if (getenv("SNAPGPU_SAM_VERBOSE")) fprintf(stderr, "snapgpu-sam: one record's state recomputed on the host (%s), back clipping left: %d\n", (flag & 0x4) ? "given up after clipping adjustments" : "reverse complement at the first base of a contig", carry[rd]);
+                return;
+            }
             if (!(flag & 0x10) || n_ops <= 0) return;
-            if (pos == 1) die("paired -om / -ea: a reverse-complement record at the first base of a contig followed by further records of the read (unsupported corner)");
             const int lead = (ops[0] & 15u) == 4u ? (int)(ops[0] >> 4) : 0;
             const int left = lead - ((int)U - passed_len - front_clip[rd]) - clipped_before;
             if (left < 0) die("internal error: leading soft clip shorter than the read's own clipping");
@@ -777,8 +785,10 @@ static void gpu_paired(const Options &o, snapgpu_ctx *ctx, Work &w)
                         w.flag[dst] = f[src] | (w.pu_secondary[u] ? 0x100 : 0); w.contig[dst] = c[src]; w.pos[dst] = ps[src]; w.mapq[dst] = mq[src]; w.n_ops[dst] = no[src];
                         w.nm[dst] = nm[src]; w.rnext[dst] = rn[src]; w.pnext[dst] = pn[src]; w.tlen[dst] = tl[src];
                         memcpy(&w.ops[dst * (size_t)w.ops_stride], &ops[src * (size_t)w.ops_stride], (size_t)w.ops_stride * 4);
+                        const HostRes hr = {rr[x].status[v], rr[x].direction[v], rr[x].score[v], rr[x].mapq[v], rr[x].clipping_for_read_adjustment[v], rr[x].used_affine_gap_scoring[v],
+                                            rr[x].bases_clipped_before[v], rr[x].bases_clipped_after[v], rr[x].supplementary[v], (long long)rr[x].location[v]};
                         leave_behind(2 * k + v, j + 1 < per_pair[k].size(), ag_branch(rr[x].used_affine_gap_scoring[v], rr[x].score[v]), rr[x].status[v], f[src], ps[src], no[src],
-                                     &ops[src * (size_t)w.ops_stride], rr[x].bases_clipped_before[v], rdl[src]);
+                                     &ops[src * (size_t)w.ops_stride], rr[x].bases_clipped_before[v], rdl[src], hr, true);
                     }
                 }
             }
@@ -805,7 +815,9 @@ static void gpu_paired(const Options &o, snapgpu_ctx *ctx, Work &w)
                     memcpy(&w.s_ops[r * (size_t)w.s_ops_stride], &ops[x * (size_t)w.s_ops_stride], (size_t)w.s_ops_stride * 4);
                     // (a single-end record is written without the aligner's soft clipping unless it went through the affine-gap writer: sam_fields.h)
                     const bool ag = ag_branch(rr[x].used_affine_gap_scoring, rr[x].score);
-                    leave_behind(rd, j + 1 < per_pair[k].size(), ag, rr[x].status, f[x], ps[x], no[x], &ops[x * (size_t)w.s_ops_stride], ag ? rr[x].bases_clipped_before : 0, sdl[x]);
+                    const HostRes hr = {rr[x].status, rr[x].direction, rr[x].score, rr[x].mapq, rr[x].clipping_for_read_adjustment, rr[x].used_affine_gap_scoring, rr[x].bases_clipped_before,
+                                        rr[x].bases_clipped_after, rr[x].supplementary, (long long)rr[x].location};
+                    leave_behind(rd, j + 1 < per_pair[k].size(), ag, rr[x].status, f[x], ps[x], no[x], &ops[x * (size_t)w.s_ops_stride], ag ? rr[x].bases_clipped_before : 0, sdl[x], hr, false);
                 }
             }
         }

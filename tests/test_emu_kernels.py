@@ -380,6 +380,23 @@ def test_emu_native_paired_secondary_and_alt_records(emu, tmp_path):
     assert run_and_compare_paired(TOOL, d2, index_dir, fq, ["-ea"], env=env) > 160
 
 
+def test_emu_native_paired_records_after_a_reverse_complement_record_at_a_contig_start(emu, tmp_path):
+    """`snapgpu-sam paired -om`: a read whose record is reverse-complement at POS 1 and has further records after it (the writer recomputes that
+    record's Read state on the host instead of stopping): the reference CLI's file, line for line, and the case does occur in the workload."""
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    import subprocess
+    from tests.emu.build import TOOL
+    from tests.test_zz_gpu_native_sam import make_contig_start_workload, run_and_compare_paired
+    env = dict(os.environ, SNAPGPU_EMU_CUS="4", SNAPGPU_SAM_VERBOSE="1")
+    d = str(tmp_path)
+    index_dir, fq = make_contig_start_workload(d, 40)
+    assert run_and_compare_paired(TOOL, d, index_dir, fq, ["-om", "3", "-D", "3"], env=env) > 160
+    r = subprocess.run([TOOL, "paired", index_dir, fq[0], fq[1], "-om", "3", "-D", "3", "-o", os.path.join(d, "again.sam")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+    assert r.returncode == 0 and r.stdout.decode().count("recomputed on the host") >= 1
+
+
 def test_emu_native_fastq_to_bam(emu, tmp_path):
     """`-o x.bam`: header, reference table and records of the native program's BAM (decompressed) equal the reference CLI's, single end
     (with secondary records) and paired end."""

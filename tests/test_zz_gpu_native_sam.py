@@ -124,6 +124,51 @@ def make_paired_workload(d, n_pairs, genome_bases=600_000):
     return index_dir, fq
 
 
+def make_contig_start_workload(d, reps, seed=5):
+    """Pairs whose one mate is the reverse complement of a contig's FIRST 150 bases (its record: flag 0x10, POS 1) while the other lies a few hundred
+    bases further on in an orientation that is no proper pair, over a genome in which the start of two contigs also occurs, slightly mutated,
+    inside another one: under -om the read has further records after the one at POS 1 -- the case in which the record alone does not say what
+    back clipping it left on the Read (snapgpu_sam.cpp: leave_behind), which stopped the program until round 4."""
+    rng = np.random.default_rng(seed)
+    comp = np.zeros(256, np.uint8)
+    for a, b in zip(b"ACGTN", b"TGCAN"):
+        comp[a] = b
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    g = [(n, b.copy()) for n, b in synth.make_genome(11, 300_000, n_contigs=3, repeat_frac=0.0)]
+    for ci, at in ((1, 50_000), (2, 70_000)):
+        blk = g[ci][1][:700].copy()
+        mut = rng.random(700) < 0.01
+        blk[mut] = acgt[rng.integers(0, 4, size=int(mut.sum()))]
+        g[0][1][at:at + 700] = blk
+    fasta = os.path.join(d, "g.fa"); synth.write_fasta(fasta, g)
+    index_dir = os.path.join(d, "index")
+    ref.build_index(fasta, index_dir, seed_len=20, threads=max(1, min(8, os.cpu_count() or 1)))
+
+    def mutate(seq, nsub):
+        s = seq.copy()
+        for j in rng.integers(20, len(s) - 20, size=nsub):
+            s[j] = acgt[(np.searchsorted(np.sort(acgt), s[j]) + 1) % 4]
+        return s
+    fq = [os.path.join(d, "r1.fq"), os.path.join(d, "r2.fq")]
+    n = 0
+    with open(fq[0], "wb") as f1, open(fq[1], "wb") as f2:
+        for ci in (1, 2):
+            c = g[ci][1]
+            for rep in range(reps):
+                nsub, li = int(rng.integers(1, 4)), int(rng.integers(0, 3))
+                left = mutate(c[0:150], nsub)
+                if li:                                                      # extra bases at the reference-left end: a leading insertion of the RC alignment
+                    left = np.concatenate([acgt[rng.integers(0, 4, size=li)], left[:150 - li]])
+                b = comp[left[::-1]]
+                off = int(rng.integers(260, 420))
+                a = mutate(c[off:off + 150], int(rng.integers(0, 3)))
+                if rep % 2: a = comp[a[::-1]]
+                x, y = (a, b) if rep % 4 < 2 else (b, a)
+                q = b"I" * 150
+                f1.write(b"@c%d/1\n" % n + x.tobytes() + b"\n+\n" + q + b"\n"); f2.write(b"@c%d/2\n" % n + y.tobytes() + b"\n+\n" + q + b"\n"); n += 1
+    return index_dir, fq
+
+
 def run_and_compare_paired(tool, d, index_dir, fq, opts, env=None):
     tag = "_".join(o.strip("-") or "eq" for o in opts) or "default"
     out_ref, out_new = os.path.join(d, "pref_%s.sam" % tag), os.path.join(d, "pnew_%s.sam" % tag)
