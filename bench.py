@@ -10,10 +10,16 @@ scale, a ~31 GB index built on the GPU in the reference's format and kept reside
 device has >= 64 GB free; 256 otherwise, and the line says so), 30 % of bases in planted repeat
 families (copy number 2-5000, 0-5 % divergence).
 
-The default one-GPU run adds two short legs to the same JSON line (skip with --no-extra-legs):
+The default one-GPU run adds three legs to the same JSON line (skip with --no-extra-legs):
   paired       configs[2] (2x150 bp pairs through the paired-end path) over the SAME resident
                index: value, ms_per_step, parity_check and cpu_baseline of its own
-  genome_256mb the single-end line on the 256 Mb stand-in of rounds 1-3, for continuity
+  c5           configs[4] on one GPU (2x250 bp pairs, -d 20, insert N(600, 80^2), 0.2 % long
+               indels: the affine-gap code at limit 21), contexts with options of their own over
+               the same resident index; parity_check and cpu_baseline of its own
+  e2e          the PRODUCT rate: --e2e-reads reads as a FASTQ file through snap_amd/snapgpu-sam
+               (FASTQ in, SAM out, index load reported apart), the reference CLI's own Reads/s on
+               the first --e2e-ref-reads of them beside it, records compared by hash
+  genome_256mb (--standin-leg) the single-end line on the 256 Mb stand-in of rounds 1-3
 
 N > 1: one process per GPU (torch.distributed.run), reads sharded (each rank aligns its own
 --reads reads: weak scaling), no data-path collective; the index is read by rank 0 and
@@ -186,6 +192,14 @@ def parse_args(argv=None):
                     help="one GPU, --workload single only: do not add the short paired-end leg (`paired`) and the 256 Mb leg (`genome_256mb`)")
     ap.add_argument("--paired-leg-steps", type=int, default=6, help="timed steps of the extra paired-end leg")
     ap.add_argument("--standin-mb", type=int, default=256, help="genome size of the extra `genome_256mb` leg (tests shrink it)")
+    ap.add_argument("--standin-leg", action="store_true", help="add the `genome_256mb` leg (the line of rounds 1-3 on the 256 Mb stand-in; in the default run until round 4)")
+    ap.add_argument("--no-c5-leg", action="store_true", help="do not add the `c5` leg (configs[4] on one GPU: 2 x 250 bp pairs, -d 20, insert N(600, 80^2), 0.2 % long indels)")
+    ap.add_argument("--c5-leg-steps", type=int, default=3)
+    ap.add_argument("--c5-reads", type=int, default=200_000, help="reads per step of the c5 leg")
+    ap.add_argument("--no-e2e-leg", action="store_true", help="do not add the `e2e` leg (FASTQ -> SAM through snap_amd/snapgpu-sam)")
+    ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the e2e leg's FASTQ")
+    ap.add_argument("--e2e-ref-reads", type=int, default=1_000_000, help="leading reads of that FASTQ the reference CLI aligns beside it (its own Reads/s; records compared)")
+    ap.add_argument("--e2e-tool-args", default="", help="extra arguments for snapgpu-sam in the e2e leg, one string")
     args = ap.parse_args(argv)
     if args.steps <= 0:
         args.steps = 6
@@ -219,7 +233,7 @@ def make_bed(args, env, paired_owner):
         env["dist"] = sd.init_process_group("nccl")
         env["dist"].barrier()
     dist = env.get("dist")
-    bed.params = abi.default_params(max_k=args.max_k, max_read_len=((args.read_len + 15) // 16) * 16)
+    bed.params = bed.owner_params = abi.default_params(max_k=args.max_k, max_read_len=((args.read_len + 15) // 16) * 16)
     t0 = time.time()
     index = None
     if dist is None and built is not None:      # the index this process has just built is still in HBM: adopt it, no file is read back
@@ -271,10 +285,13 @@ def run_leg(args, env, bed, workload, primary):
     params, pparams, genome, idx_dir, index_info, index_bytes = bed.params, bed.pparams, bed.genome, bed.idx_dir, bed.index_info, bed.index_bytes
     owner_is_paired = isinstance(bed.owner, ChimericPairedEndAligner)
 
+    # a leg whose options differ from the owner's (the c5 leg: -d 20, 250 bp reads) gets contexts of its own over the owner's resident index
+    p_over = params if params is not getattr(bed, "owner_params", params) else None
+
     def new_context():
         if paired and not owner_is_paired:
-            return ChimericPairedEndAligner.over(bed.owner, pparams)
-        return bed.owner.replica()
+            return ChimericPairedEndAligner.over(bed.owner, pparams, params=p_over)
+        return bed.owner.replica(params=p_over)
 
     # --batches DISTINCT read batches rotate through the timed steps (step k aligns batch k mod B), so that no step finds the previous
     # step's probes / reference windows in L2 or MALL by construction.  Batch 0 is the first one the parity check and the CPU baseline use.
@@ -306,18 +323,23 @@ def run_leg(args, env, bed, workload, primary):
     # the hot path over one batch, and exactly --steps of them are inside the timed region.
     n_feed = args.feeders if args.feeders > 0 else 3
     n_feed = max(1, min(n_feed, max(1, args.steps)))
-    own_first = paired == owner_is_paired           # the bed's owner is itself a context of this leg's kind
+    own_first = paired == owner_is_paired and p_over is None      # the bed's owner is itself a context of this leg's kind (and options)
     feeders = ([bed.owner] if own_first else []) + [new_context() for _ in range(n_feed - (1 if own_first else 0))]
     aligner = feeders[0]
     d_prims = [torch.zeros(n_units * res_dtype.itemsize, dtype=torch.uint8, device=dev) for _ in range(n_feed)]
     d_prim = d_prims[0]
     torch.cuda.synchronize()
 
-    def run_steps(k_steps, only_batch=None):
+    call_ms = []                        # host-side duration of every align call of the timed region (the call blocks until its launch is done)
+
+    def run_steps(k_steps, only_batch=None, record=None):
         def feed(f):
             for k in range(f, k_steps, n_feed):
                 db, dq, do = d_batches[(k % n_batches) if only_batch is None else only_batch]
+                t_c = time.perf_counter()
                 feeders[f].align_device(n_units, db.data_ptr(), dq.data_ptr(), do.data_ptr(), d_prims[f].data_ptr())
+                if record is not None:
+                    record.append(1e3 * (time.perf_counter() - t_c))      # (list.append is atomic under the GIL)
         if n_feed == 1:
             feed(0)
             return
@@ -347,7 +369,7 @@ def run_leg(args, env, bed, workload, primary):
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
-    run_steps(args.steps)
+    run_steps(args.steps, record=call_ms)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -488,13 +510,13 @@ def run_leg(args, env, bed, workload, primary):
     genome_desc = ("seeded synthetic %d Mb genome with 30%% planted repeats (GRCh38 scale: GRCh38 itself is unavailable here)" % args.genome_mb if args.genome_mb >= 3000
                    else "seeded synthetic %d Mb genome with 30%% planted repeats (stand-in: %s)" % (args.genome_mb, env.get("genome_choice", "--genome-mb")))
     out = {
-        "metric": "aligned reads/sec (whole node), 150 bp %s vs synthetic %d Mb genome (GRCh38 unavailable), seed=20, maxDist=%d"
-                  % ("paired-end (2x150 FR pairs)" if paired else "single-end", args.genome_mb, args.max_k),
+        "metric": "aligned reads/sec (whole node), %d bp %s vs synthetic %d Mb genome (GRCh38 unavailable), seed=20, maxDist=%d"
+                  % (args.read_len, "paired-end (2x%d FR pairs)" % args.read_len if paired else "single-end", args.genome_mb, args.max_k),
         "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "u8 bases / int32 DP / f64 match probability", "data": "synthetic",
-        "config": {"workload": ("configs[2]: %d pairs of 2 x %d bp (FR, insert N(%g,%g^2), long-indel fraction %g) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d (directory in the reference's format), genome = %s"
-                                % (n_units, args.read_len, args.insert_mean, args.insert_sd, args.long_indel_frac, args.max_k, args.seed_len, genome_desc)) if paired else
+        "config": {"workload": ("%s: %d pairs of 2 x %d bp (FR, insert N(%g,%g^2), long-indel fraction %g) per GPU per step, ChimericPairedEndAligner over IntersectingPairedEndAligner defaults (-n 8 -H 4000 -s 0 1000 -i 40, affine gap + soft clipping on), -d %d, index seed %d (directory in the reference's format), genome = %s"
+                                % ("configs[4] on one GPU" if getattr(args, "pmc_tag", "") == "c5" else "configs[2]", n_units, args.read_len, args.insert_mean, args.insert_sd, args.long_indel_frac, args.max_k, args.seed_len, genome_desc)) if paired else
                                ("configs[1]: %d x %d bp single-end reads per GPU per step, BaseAligner::AlignRead defaults (-n 25 -h 300 -D 1, affine gap on, ALT-aware), -d %d, index seed %d (directory in the reference's format), genome = %s"
                                 % (n, args.read_len, args.max_k, args.seed_len, genome_desc)),
                    "genome_mb": args.genome_mb, "genome_choice": env.get("genome_choice", "--genome-mb"),
@@ -543,7 +565,8 @@ def run_leg(args, env, bed, workload, primary):
                                               "evaluations_stored": counters.get("cycles_single_fallback", 0) >> 32,
                                               "refused_other_band_or_decision": (counters.get("cycles_single_fallback", 0) >> 16) & 0xffff,
                                               "refused_skipped_or_limit": counters.get("cycles_single_fallback", 0) & 0xffff}
-    attach_pmc(out, args, workload, n, n_feed, avg_ms, elapsed)
+    attach_pmc(out, args, getattr(args, "pmc_tag", workload), n, n_feed, avg_ms, elapsed)
+    finish_roofline(out, call_ms, elapsed, args.steps)
 
     if world == 1 and not args.skip_cpu:
         from oracle import ref                                       # cpu_baseline leg only
@@ -676,6 +699,22 @@ def attach_pmc(out, args, workload, n, n_feed, avg_ms, elapsed):
                     vi["active_fraction_of_wave_cycles"] = e.get("active_inst_any", 0) / e["wave_cycles"]
                     vi["waiting_fraction_of_wave_cycles"] = e.get("wait_inst_any", 0) / e["wave_cycles"]
                 out["roofline"]["valu_issue"] = vi
+                out["roofline"]["valu_issue_frac"] = vi["frac"]
+                if e.get("salu_insts_per_launch"):
+                    # The scalar unit: ONE scalar-ALU instruction can issue per CU per cycle (a CU's arbiter visits one of its four SIMDs
+                    # each cycle and issues at most one instruction per category from that SIMD's waves; the CU has one scalar ALU --
+                    # MI355X_MICROARCH.md / cdna_hip_programming.md "1 scalar unit per CU"), so the chip's scalar issue peak is
+                    # 256 CUs x 2.4 GHz = 614.4 G wave-instructions/s (lower at the sustained clock, which makes the true fraction higher).
+                    t_batch = (avg_ms if n_feed == 1 else 1e3 * elapsed / args.steps) * 1e-3
+                    s_peak = 256 * 2.4e9 / 1e9
+                    s_ach = e["salu_insts_per_launch"] / t_batch / 1e9
+                    out["roofline"]["salu_issue"] = {"achieved": s_ach, "peak": s_peak, "unit": "G wave-instructions/s", "frac": s_ach / s_peak,
+                                                     "salu_insts_per_read": e["salu_insts_per_launch"] / n,
+                                                     "peak_derivation": "256 CUs x 1 scalar-ALU issue per CU per cycle x 2.4 GHz peak clock",
+                                                     "source": vi["source"]}
+                    out["roofline"]["salu_issue_frac"] = s_ach / s_peak
+                if e.get("wave_cycles") and e.get("wait_any"):
+                    out["roofline"]["wait_any_frac_of_wave_cycles"] = e["wait_any"] / e["wave_cycles"]
             if e.get("probe_fetch_size_kb") and "probe" in out["roofline"]:
                 out["roofline"]["probe"]["traffic"] = e["probe_fetch_size_kb"] * 1024.0
                 out["roofline"]["probe"]["traffic_source"] = "FETCH_SIZE of k_lookup_seeds, same passes"
@@ -684,13 +723,152 @@ def attach_pmc(out, args, workload, n, n_feed, avg_ms, elapsed):
         out["roofline"]["traffic_source"] = "profiles/pmc_latest.json unreadable: %s" % e_
 
 
+def finish_roofline(out, call_ms, elapsed, steps):
+    """What the line says ABOUT its roofline numbers: which resource the kernel is closest to by the counters (`bound`), the figures a reader
+    needs as top-level scalars of `roofline` (the driver's record keeps scalars), and the spread of the launches' durations."""
+    r = out["roofline"]
+    if call_ms:
+        cm = sorted(call_ms)
+        r["launch_ms_min"], r["launch_ms_median"], r["launch_ms_max"] = cm[0], cm[len(cm) // 2], cm[-1]
+        r["launch_ms_basis"] = "host wall time of each blocking align call of the timed region (%d calls); avg_launch_ms is the hipEvent average of the same launches" % len(cm)
+    if isinstance(r.get("probe"), dict):
+        r["probe_frac"] = r["probe"].get("frac")
+        r["probe_frac_bucket_lines"] = r["probe"].get("frac_bucket_lines")
+    lp = r.get("launch_profile")
+    if isinstance(lp, dict) and "mean_wave_residency" in lp:
+        r["mean_wave_residency"] = lp["mean_wave_residency"]
+    fr = {"hbm": r.get("frac") or 0.0}
+    if r.get("traffic"):
+        r["traffic_frac_of_hbm_peak"] = r["traffic"] / (1e-3 * 1e3 * elapsed / steps) / 1e9 / HBM_PEAK_GBS
+        r["traffic_over_algorithmic"] = r["traffic"] / max(1.0, r["algorithmic_bytes_per_launch"])
+        fr["hbm (measured traffic)"] = r["traffic_frac_of_hbm_peak"]
+    if r.get("valu_issue_frac") is not None:
+        fr["valu_issue"] = r["valu_issue_frac"]
+    if r.get("salu_issue_frac") is not None:
+        fr["salu_issue"] = r["salu_issue_frac"]
+    # `frac` / `achieved` / `peak` stay the HBM figures the metric asks for (SURVEY.md 8(d)); `bound` names the roof the counters put the
+    # kernel closest to, which for this integer / control-flow path is an instruction-issue roof, not the HBM one
+    r["nominal_bound"] = "hbm"
+    r["bound"] = max(fr, key=lambda k: fr[k]) if len(fr) > 1 else "hbm (no PMC pass of this build: issue fractions unknown)"
+    r["bound_fractions"] = fr
+
+
+def run_e2e(args, idx_dir, genome):
+    """The `e2e` object: the product rate.  --e2e-reads bench reads are written as a FASTQ file, `snap_amd/snapgpu-sam single` (the C++ host
+    program over the C ABI: FASTQ batches in, alignment AND SAM fields on the GPU, SAM text out) aligns them over the SAME index directory
+    the line's own leg used (its own process: it loads the directory itself and says how long that took), and the unmodified reference CLI
+    (oracle/_ref/snap-aligner, all host threads) aligns the first --e2e-ref-reads of them: its own `Reads/s` figure is the baseline beside
+    `value`, and an order-independent hash of its records (sum of xxh3-64 of every line) must equal that of snapgpu-sam's records for the
+    same reads.  Reference side of the path: FASTQ.h:67, ReadSupplierQueue.h:76, SAM.cpp:1898-2354."""
+    import re
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from snap_amd import synth
+    n, n_ref, L = args.e2e_reads, min(args.e2e_ref_reads, args.e2e_reads), args.read_len
+    work = os.path.dirname(idx_dir)
+    fq, fq_ref = os.path.join(work, "e2e.fq"), os.path.join(work, "e2e_ref.fq")
+    o = {"metric": "FASTQ -> SAM reads/s (snap_amd/snapgpu-sam single, index resident, index load reported apart)", "unit": "reads/s", "reads": n,
+         "genome_mb": args.genome_mb}
+    t0 = time.time()
+    PIECE, name_w = 1_000_000, 11                # names "r" + 10 digits
+    rec_w = 1 + name_w + 1 + L + 3 + L + 1
+
+    def piece(k):
+        m = min(PIECE, n - k * PIECE)
+        rd = synth.make_reads(args.seed + 500_000 + 7919 * k, genome, m, L)
+        rec = np.empty((m, rec_w), dtype=np.uint8)
+        rec[:, 0] = ord("@"); rec[:, 1] = ord("r")
+        ids = np.arange(k * PIECE, k * PIECE + m, dtype=np.int64)
+        for d in range(10):
+            rec[:, 2 + 9 - d] = ord("0") + (ids // 10 ** d) % 10
+        c = 1 + name_w
+        rec[:, c] = 10; rec[:, c + 1:c + 1 + L] = rd["bases"]; c += 1 + L
+        rec[:, c] = 10; rec[:, c + 1] = ord("+"); rec[:, c + 2] = 10; c += 3
+        rec[:, c:c + L] = rd["quals"]; rec[:, c + L] = 10
+        return rec.tobytes()
+    with open(fq, "wb") as f, open(fq_ref, "wb") as fr, ThreadPoolExecutor(max_workers=min(12, os.cpu_count() or 4)) as ex:
+        done = 0
+        for raw in ex.map(piece, range((n + PIECE - 1) // PIECE)):
+            f.write(raw)
+            if done < n_ref:
+                fr.write(raw[:min(len(raw), (n_ref - done) * rec_w)])
+            done += len(raw) // rec_w
+    o["fastq_write_s"] = time.time() - t0
+    log("e2e: %d reads written as FASTQ in %.1fs" % (n, o["fastq_write_s"]))
+
+    def hash_records(sam, first=None):
+        import xxhash
+        h, nrec, names_ok = 0, 0, True
+        with open(sam, "rb", buffering=1 << 24) as f:
+            for line in f:
+                if line[:1] == b"@":
+                    continue
+                if first is not None:
+                    if nrec >= first:
+                        break
+                    if int(line[1:11]) >= first:           # (snapgpu-sam writes in input order: the first `first` records are the subset's)
+                        names_ok = False
+                h = (h + xxhash.xxh3_64_intdigest(line)) & 0xFFFFFFFFFFFFFFFF
+                nrec += 1
+        return nrec, "%016x" % h, names_ok
+    sam, sam_ref = os.path.join(work, "e2e.sam"), os.path.join(work, "e2e_ref.sam")
+    tool = os.path.join(ROOT, "snap_amd", "snapgpu-sam")
+    t0 = time.time()
+    r = subprocess.run([tool, "single", idx_dir, fq, "-d", str(args.max_k), "-o", sam] + args.e2e_tool_args.split(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       stdin=subprocess.DEVNULL, timeout=900, env=dict(os.environ, SNAPGPU_SAM_VERBOSE="1"))
+    o["tool_wall_s"] = time.time() - t0
+    txt = r.stdout.decode(errors="replace")
+    o["tool_tail"] = [l[:400] for l in txt.strip().splitlines()[-4:]]
+    if r.returncode != 0:
+        raise RuntimeError("snapgpu-sam failed (%d): %s" % (r.returncode, txt[-600:]))
+    m = re.search(r"index resident after ([\d.]+) s; FASTQ -> \w+ in ([\d.]+) s = (\d+) reads/s", txt)
+    if not m:
+        raise RuntimeError("snapgpu-sam printed no rate: %s" % txt[-400:])
+    o["index_load_s"], o["stream_s"], o["value"] = float(m.group(1)), float(m.group(2)), float(m.group(3))
+    o["reads_per_s_wall_incl_index_load"] = n / o["tool_wall_s"]
+    log("e2e: snapgpu-sam %.0f reads/s (index load %.1fs, stream %.1fs)" % (o["value"], o["index_load_s"], o["stream_s"]))
+    nrec, hx_sub, names_ok = hash_records(sam, first=n_ref)
+    o["sam_bytes"] = os.path.getsize(sam)
+    os.remove(sam); os.remove(fq)
+    ref_tool = os.path.join(ROOT, "oracle", "_ref", "snap-aligner")
+    if os.path.exists(ref_tool):
+        t0 = time.time()
+        r2 = subprocess.run([ref_tool, "single", idx_dir, fq_ref, "-d", str(args.max_k), "-t", str(os.cpu_count() or 8), "-o", sam_ref], stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=1200)
+        o["reference_cli"] = {"wall_s": time.time() - t0, "reads": n_ref, "threads": os.cpu_count() or 8}
+        t2 = r2.stdout.decode(errors="replace")
+        tail = t2.strip().splitlines()[-1] if t2.strip() else ""
+        nums = re.findall(r"[\d,]+", tail)          # the summary line: total, aligned ..., reads/s, time
+        try:
+            o["reference_cli"]["reads_per_s_own_figure"] = int(nums[-2].replace(",", ""))
+        except Exception:          # noqa: BLE001
+            o["reference_cli"]["tail"] = tail[:300]
+        if r2.returncode == 0:
+            nr2, hx_ref, _ = hash_records(sam_ref)
+            o["records_compared"] = nr2
+            o["records_hash"], o["reference_records_hash"] = hx_sub, hx_ref
+            o["identical_records"] = bool(hx_sub == hx_ref and nr2 == nrec == n_ref and names_ok)
+            if o["reference_cli"].get("reads_per_s_own_figure"):
+                o["speedup_vs_reference_cli_own_figure"] = o["value"] / o["reference_cli"]["reads_per_s_own_figure"]
+        else:
+            o["reference_cli"]["error"] = t2[-400:]
+        if os.path.exists(sam_ref):
+            os.remove(sam_ref)
+    else:
+        o["reference_cli"] = {"error": "oracle/_ref/snap-aligner not built"}
+    os.remove(fq_ref)
+    return o
+
+
 def compact_leg(o):
     """What an extra leg contributes to the line."""
     keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step") if k in o}
     keep["config"] = {k: o["config"][k] for k in ("workload", "genome_mb", "feeders_per_gpu", "index_bytes_hbm") if k in o["config"]}
     r = o["roofline"]
-    keep["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes_per_launch", "avg_launch_ms",
-                                          "achieved_basis", "per_read", "valu_issue", "phase4_help") if k in r}
+    keep["roofline"] = {k: r[k] for k in ("kernel", "bound", "nominal_bound", "bound_fractions", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_over_algorithmic",
+                                          "algorithmic_bytes_per_launch", "avg_launch_ms", "launch_ms_min", "launch_ms_median", "launch_ms_max",
+                                          "achieved_basis", "per_read", "valu_issue", "valu_issue_frac", "salu_issue", "salu_issue_frac", "wait_any_frac_of_wave_cycles",
+                                          "phase4_help") if k in r}
     for k in ("cpu_baseline", "parity_check", "aligned_fraction"):
         if k in o:
             keep[k] = o[k]
@@ -747,8 +925,33 @@ def main():
             out["paired"] = compact_leg(run_leg(pa, env, bed, "paired", primary=False))
         except BaseException as e_:          # noqa: BLE001 -- the line's own leg must survive a failing extra
             out["paired"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+        # ---------------------------------------------------------------- configs[4] on one GPU (2 x 250 bp, -d 20, affine gap: AffineGapVectorized at limit 21)
+        if not args.no_c5_leg:
+            try:
+                from snap_amd import abi as _abi
+                ca = copy.copy(args)
+                ca.read_len, ca.max_k, ca.insert_mean, ca.insert_sd, ca.long_indel_frac = 250, 20, 600.0, 80.0, 0.002
+                ca.reads = args.c5_reads
+                ca.steps, ca.warmup, ca.batches = max(1, args.c5_leg_steps), 1, min(args.batches, max(1, args.c5_leg_steps))
+                ca.skip_refwalk = ca.skip_breakdown = ca.skip_probe = True
+                ca.cpu_sample, ca.cpu_seconds, ca.pmc_tag = 0, min(args.cpu_seconds, 12.0), "c5"
+                bed_c5 = copy.copy(bed)
+                bed_c5.params = _abi.default_params(max_k=20, max_read_len=256)
+                bed_c5.ref_index = getattr(bed, "ref_index", None)
+                out["c5"] = compact_leg(run_leg(ca, env, bed_c5, "paired", primary=False))
+                bed.ref_index = getattr(bed_c5, "ref_index", None)
+            except BaseException as e_:          # noqa: BLE001
+                out["c5"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+    idx_dir_main, genome_main = bed.idx_dir, bed.genome
     close_bed(bed)
-    if extra and rank == 0 and args.genome_mb != args.standin_mb:
+    if extra and rank == 0 and not args.no_e2e_leg:
+        # ---------------------------------------------------------------- the product rate: FASTQ -> SAM through snap_amd/snapgpu-sam over the same index directory
+        try:
+            out["e2e"] = run_e2e(args, idx_dir_main, genome_main)
+        except BaseException as e_:          # noqa: BLE001
+            out["e2e"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+    genome_main = None
+    if extra and rank == 0 and args.standin_leg and args.genome_mb != args.standin_mb:
         # ---------------------------------------------------------------- the 256 Mb stand-in of rounds 1-3, same command otherwise
         try:
             sa = copy.copy(args)

@@ -289,12 +289,16 @@ int  snapgpu_create_from_directory(const char *index_dir, const snapgpu_params *
  *                                                  thread on the same GPU; destroy it before src)
  *                                share_index == 0  same-size blobs are allocated on `device` and left unfilled for snapgpu_broadcast_index
  *                              (snapgpu_enable_paired / _secondary are per context: call them on the replica as on src)
+ *   snapgpu_create_replica_with_params   the same, with options of its own (`p` NULL: src's): one resident index serving several
+ *                              option sets at once -- the reference's equivalent is a second `snap-aligner` command line of a comma-
+ *                              separated run over the index it keeps loaded (SNAPLib/CommandProcessor.cpp: the index cache, -d per run)
  *   snapgpu_broadcast_index    fills the blobs of ctxs[1 .. n) from ctxs[0] (the one that read the index) with one RCCL broadcast per blob
  *                              over xGMI -- the only collective of the whole path; reads never cross GPUs.  n == 1 is a no-op.
  *                              SNAPGPU_E_UNSUPPORTED when librccl cannot be loaded (the caller may then load the directory per device).
  */
 int  snapgpu_device_count(void);
 int  snapgpu_create_replica(const snapgpu_ctx *src, int device, int share_index, snapgpu_ctx **out);
+int  snapgpu_create_replica_with_params(const snapgpu_ctx *src, int device, int share_index, const snapgpu_params *p, snapgpu_ctx **out);
 int  snapgpu_broadcast_index(snapgpu_ctx **ctxs, int n);
 
 /* Device pointers of the context's index blobs, so that a caller that owns the

@@ -165,21 +165,25 @@ class BaseAligner:
     def _after_built(self, paired_params):
         pass
 
-    def replica(self, device: int | None = None, share_index: bool = True):
+    def replica(self, device: int | None = None, share_index: bool = True, params: Params | None = None):
         """Another context over the same index (include/snapgpu.h: snapgpu_create_replica): on this GPU sharing the resident blobs -- a
         second feeder, so that two batches can be in flight -- or on another GPU with blobs of its own (to be filled by
         snapgpu_broadcast_index).  The analogue of the reference's one-aligner-per-thread over one shared GenomeIndex
-        (SNAPLib/AlignerContext.cpp: runTask)."""
-        self.lib.snapgpu_create_replica.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        (SNAPLib/AlignerContext.cpp: runTask).  `params`: options of its own for the new context (snapgpu_create_replica_with_params),
+        e.g. another -d over the one resident index."""
+        self.lib.snapgpu_create_replica_with_params.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_void_p)]
         h = C.c_void_p()
         dev = self.device if device is None else device
-        rc = self.lib.snapgpu_create_replica(self.handle, C.c_int(dev), C.c_int(1 if share_index else 0), C.byref(h))
+        rc = self.lib.snapgpu_create_replica_with_params(self.handle, C.c_int(dev), C.c_int(1 if share_index else 0),
+                                                         C.byref(params) if params is not None else None, C.byref(h))
         if rc != 0:
             raise SnapGpuError("snapgpu_create_replica failed (%d): %s" % (rc, self.lib.snapgpu_last_error(self.handle).decode()))
         other = type(self).__new__(type(self))
         other.__dict__.update(self.__dict__)
         other.handle = h
         other.device = dev
+        if params is not None:
+            other.params = params
         other._after_replica()
         return other
 
@@ -461,7 +465,7 @@ class ChimericPairedEndAligner(BaseAligner):
         self._check(self.lib.snapgpu_enable_paired(self.handle, C.byref(self.paired_params)), "snapgpu_enable_paired")
 
     @classmethod
-    def over(cls, base: "BaseAligner", paired_params=None):
+    def over(cls, base: "BaseAligner", paired_params=None, params: Params | None = None):
         """A paired-end context over the index another context (single-end or paired) already has resident on its GPU:
         snapgpu_create_replica(share_index = 1) + snapgpu_enable_paired.  `base` must outlive it (it owns the blobs)."""
         from .abi import PairedParams, default_paired_params
@@ -470,8 +474,10 @@ class ChimericPairedEndAligner(BaseAligner):
         proto.paired_params = paired_params if paired_params is not None else default_paired_params()
         proto.lib.snapgpu_enable_paired.argtypes = [C.c_void_p, C.POINTER(PairedParams)]
         proto.lib.snapgpu_align_paired_device.argtypes = [C.c_void_p, C.c_uint32] + [C.c_void_p] * 6
-        other = BaseAligner.replica(proto)
-        proto.handle = None                 # (the prototype borrowed base's handle: it must not destroy it)
+        try:
+            other = BaseAligner.replica(proto, params=params)
+        finally:
+            proto.handle = None             # (the prototype borrowed base's handle: it must never destroy it, whatever the replica call did)
         return other
 
     def _after_built(self, paired_params):

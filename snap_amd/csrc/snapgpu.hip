@@ -890,6 +890,11 @@ extern "C" int snapgpu_device_count(void) {
 
 extern "C" int snapgpu_create_replica(const snapgpu_ctx *src, int device, int share_index, snapgpu_ctx **out)
 {
+    return snapgpu_create_replica_with_params(src, device, share_index, nullptr, out);
+}
+
+extern "C" int snapgpu_create_replica_with_params(const snapgpu_ctx *src, int device, int share_index, const snapgpu_params *p, snapgpu_ctx **out)
+{
     if (!src || !out) return fail(nullptr, SNAPGPU_E_INVALID, "snapgpu_create_replica: null argument");
     *out = nullptr;
     if (share_index && device != src->device) return fail(nullptr, SNAPGPU_E_INVALID, "snapgpu_create_replica: index blobs can only be shared on the device that holds them");
@@ -909,7 +914,7 @@ extern "C" int snapgpu_create_replica(const snapgpu_ctx *src, int device, int sh
         v.hash_blob = nullptr; v.overflow = nullptr; v.genome = nullptr;
     }
     g_share_buckets_from = share_index ? src : nullptr;
-    const int rc = snapgpu_create(&v, &src->params, device, out);
+    const int rc = snapgpu_create(&v, p ? p : &src->params, device, out);
     g_share_buckets_from = nullptr;
     return rc;
 }

@@ -34,17 +34,21 @@ def _run(cmd, env=None, timeout=600):
 
 @pytest.mark.gpu
 def test_bench_line_with_its_extra_legs_small():
-    """The default-shaped run (single-end leg + the paired-end leg over the same resident index + the stand-in leg), every sampled read and
-    pair compared with the compiled reference inside bench.py itself."""
-    o = _run([sys.executable, "bench.py"] + SMALL + ["--paired-leg-steps", "2", "--standin-mb", "12", "--cpu-seconds", "1"])
+    """The default-shaped run (single-end leg + the paired-end and c5 legs over the same resident index + the FASTQ -> SAM leg through
+    snap_amd/snapgpu-sam, plus the opt-in stand-in leg), every sampled read and pair compared with the compiled reference inside bench.py
+    itself, the e2e leg's records with the reference CLI's."""
+    o = _run([sys.executable, "bench.py"] + SMALL + ["--paired-leg-steps", "2", "--standin-leg", "--standin-mb", "12", "--cpu-seconds", "1",
+                                                     "--c5-reads", "6000", "--c5-leg-steps", "2", "--e2e-reads", "300000", "--e2e-ref-reads", "100000"], timeout=900)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
               "roofline", "cpu_baseline", "parity_check"):
         assert k in o, k
     assert o["n_gpus"] == 1 and o["steps"] == 3 and o["value"] > 0 and o["unit"] == "reads/s"
     assert o["config"]["genome_mb"] == 24 and o["config"]["kernel_source_hash"]
     rf = o["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "probe"):
+    for k in ("bound", "nominal_bound", "achieved", "peak", "unit", "frac", "traffic", "probe", "probe_frac", "launch_ms_min", "launch_ms_median", "launch_ms_max",
+              "mean_wave_residency"):
         assert k in rf, k
+    assert rf["launch_ms_min"] <= rf["launch_ms_median"] <= rf["launch_ms_max"]
     assert rf["probe"]["numerator_basis"].startswith("reference slot walk")
     assert rf["probe"]["algorithmic_bytes_per_launch"] <= rf["probe"]["bucket_line_bytes_per_launch"] * 1.5
     pc = o["parity_check"]
@@ -54,6 +58,14 @@ def test_bench_line_with_its_extra_legs_small():
     assert "error" not in p, p
     assert p["value"] > 0 and p["parity_check"]["mismatching_pairs"] == 0 and p["parity_check"]["pairs"] >= 10000 and p["cpu_baseline"]["value"] > 0
     assert p["config"]["index_bytes_hbm"] == o["config"]["index_bytes_hbm"]           # the same resident index
+    c5 = o["c5"]
+    assert "error" not in c5, c5
+    assert c5["value"] > 0 and c5["parity_check"]["mismatching_pairs"] == 0 and c5["parity_check"]["pairs"] >= 3000 and c5["cpu_baseline"]["value"] > 0
+    assert "2 x 250 bp" in c5["config"]["workload"] and "-d 20" in c5["config"]["workload"]
+    e = o["e2e"]
+    assert "error" not in e, e
+    assert e["value"] > 0 and e["reads"] == 300000 and e["identical_records"] is True and e["records_compared"] == 100000
+    assert e["reference_cli"]["reads_per_s_own_figure"] > 0
     g = o["genome_256mb"]
     assert "error" not in g, g
     assert g["config"]["genome_mb"] == 12 and g["value"] > 0 and g["parity_check"]["mismatching_fields"] == []
@@ -68,5 +80,5 @@ def test_bench_multi_gpu_path_on_one_rank():
               "bench.py", "--gpus", "1"] + SMALL + ["--skip-probe", "--skip-refwalk", "--skip-breakdown", "--cpu-seconds", "1"],
              env={"SNAP_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert o["n_gpus"] == 1 and o["value"] > 0
-    assert "paired" not in o and "genome_256mb" not in o                               # the extra legs belong to the plain one-GPU run
+    assert "paired" not in o and "genome_256mb" not in o and "e2e" not in o and "c5" not in o                               # the extra legs belong to the plain one-GPU run
     assert o["parity_check"]["mismatching_fields"] == [] and o["parity_check"]["reads"] >= 20000
