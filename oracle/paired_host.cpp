@@ -64,10 +64,12 @@ struct HostPL {
     template <class T> static T spec_ld(const T &x) { return x; }
     static const bool SECONDARY = true;
     // (never called: the scalar definitions in paired.h are what the host runs)
-    bool hs_first(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *) { return true; }
-    bool hs_next_lower(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *) { return false; }
-    bool hs_next_le(PELookup *, PEHitSetHdr *, int64_t, int64_t *, uint32_t *) { return false; }
-    uint32_t hs_best_possible(PELookup *, PEHitSetHdr *, uint32_t *) { return 0; }
+    void hs_begin_walk(PELookup *, PEHitSetHdr *, int) {}
+    template <class R> void hint_indels(R *, uint32_t, uint32_t, int) {}
+    bool hs_first(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *, uint32_t) { return true; }
+    bool hs_next_lower(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *, uint32_t) { return false; }
+    bool hs_next_le(PELookup *, PEHitSetHdr *, int64_t, int64_t *, uint32_t *, uint32_t) { return false; }
+    uint32_t hs_best_possible(PELookup *, PEHitSetHdr *, uint32_t *, uint32_t) { return 0; }
 
     bool lookup(const uint8_t *text, PEHits out[2]) {
         uint64_t bases, rc;

@@ -31,7 +31,8 @@
 //   mapq(pAll,pBest,popular) computeMAPQ;   seed_prob()  pow(1-SNP_PROB, seedLen);  phred/indel/perfect tables
 //   align_single(...)        the single-end aligner of the chimeric fallback
 //   FAST_HITSET + hs_*(...)  optional lane-parallel versions of the four HashTableHitSet queries (the scalar ones below are
-//                            the definition; the device runs one lookup per lane)
+//                            the definition; the device runs one lookup per lane, the hits it is about to need staged in LDS)
+//   hs_begin_walk(...)       a set starts its Phase-2 walk (role 0: the read with fewer hits, 1: its mate); no-op on the host
 #pragma once
 #include <stdint.h>
 #include "../../include/snapgpu.h"
@@ -46,6 +47,7 @@
 #define PE_NOT_YET_SCORED  (-2)        // ScoringMateCandidate::LocationNotYetScored
 #define PE_MERGE_DIST      31          // maxMergeDistance, IntersectingPairedEndAligner.cpp:3990
 #define PE_MAXK1           (SNAPGPU_MAX_K - 1)
+#define PE_MRING           32          // mates the Phase-2 walk can look back at without going to the pool (device: LDS)
 
 struct PEHits {                        // one direction of a seed lookup
     const uint32_t *hits;              // overflow list when n_hits > 1 (descending)
@@ -91,8 +93,10 @@ struct PELookup {                      // HashTableLookup<unsigned>, Intersectin
     uint32_t singleton;
     uint32_t is_single;
     uint32_t which_disjoint;
+    int32_t  wbase;                    // device only: index of the first hit in this lookup's LDS window (paired_dev.h), -1 = nothing staged
+    uint32_t pad;
 };
-struct PEHitSetHdr { int64_t most_recent; uint32_t n_used; int32_t cur_disjoint; };
+struct PEHitSetHdr { int64_t most_recent; uint32_t n_used; int32_t cur_disjoint; uint32_t win_role; uint32_t pad; };   // win_role: which LDS window block the set walks with (device)
 
 struct PECand {                        // ScoringCandidate, .h:560-611
     int64_t  loc;                      // readWithFewerHitsGenomeLocation
@@ -170,6 +174,7 @@ struct PairedCore {
     PEHitSetHdr *hs;                   // [4]
     int32_t     *list_head;            // [SNAPGPU_MAX_K + 1]   scoringCandidates[]
     uint32_t    *seed_used;            // bitmap over seed start offsets
+    uint32_t    *mring = nullptr;      // [2 * PE_MRING] (location, best possible score) of the last PE_MRING mates of the set pair being walked; NULL: none
     PEShared    *sh;
     // the two reads, both orientations (LDS on the device).  reversedRead[][] of the reference is rd walked with stride -1.
     const uint8_t *rd[2][2], *ql[2][2];
@@ -241,7 +246,7 @@ struct PairedCore {
 
     // returns true when the set is EMPTY (the reference returns !anyFound), :3720-3746
     PE_FN bool hs_first(int s, int64_t *loc, uint32_t *seed_offset) {
-        if constexpr (PL::FAST_HITSET) return pl.hs_first(lks(s), &hs[s], loc, seed_offset);
+        if constexpr (PL::FAST_HITSET) return pl.hs_first(lks(s), &hs[s], loc, seed_offset, cfg.max_seeds);
         bool any = false;
         *loc = 0;
         const uint32_t n = ld(hs[s].n_used);
@@ -258,7 +263,7 @@ struct PairedCore {
     }
 
     PE_FN bool hs_next_lower(int s, int64_t *loc, uint32_t *seed_offset) {                              // getNextLowerHit, :3750-3816
-        if constexpr (PL::FAST_HITSET) return pl.hs_next_lower(lks(s), &hs[s], loc, seed_offset);
+        if constexpr (PL::FAST_HITSET) return pl.hs_next_lower(lks(s), &hs[s], loc, seed_offset, cfg.max_seeds);
         int64_t found = 0;
         bool any = false;
         const uint32_t n = ld(hs[s].n_used);
@@ -287,7 +292,7 @@ struct PairedCore {
     }
 
     PE_FN bool hs_next_le(int s, int64_t max_loc, int64_t *loc, uint32_t *seed_offset) {                // getNextHitLessThanOrEqualTo, :3628-3717
-        if constexpr (PL::FAST_HITSET) return pl.hs_next_le(lks(s), &hs[s], max_loc, loc, seed_offset);
+        if constexpr (PL::FAST_HITSET) return pl.hs_next_le(lks(s), &hs[s], max_loc, loc, seed_offset, cfg.max_seeds);
         bool any = false;
         int64_t best = 0;
         const uint32_t n = ld(hs[s].n_used);
@@ -319,7 +324,7 @@ struct PairedCore {
     }
 
     PE_FN uint32_t hs_best_possible(int s) {                                                             // computeBestPossibleScoreForCurrentHit, :3585-3625
-        if constexpr (PL::FAST_HITSET) return pl.hs_best_possible(lks(s), &hs[s], exh(s));
+        if constexpr (PL::FAST_HITSET) return pl.hs_best_possible(lks(s), &hs[s], exh(s), cfg.max_seeds);
         const int cd = ld(hs[s].cur_disjoint);
         for (int i = 0; i <= cd; i++) st(miss[i], ld(exh(s)[i]));
         const uint32_t n = ld(hs[s].n_used);
@@ -673,6 +678,10 @@ struct PairedCore {
         PL::sync();
     }
 
+    PE_FN void mring_put(uint32_t i, int64_t loc, uint32_t bp) {
+        if (mring == nullptr) return;
+        st(mring[2 * (i % PE_MRING)], (uint32_t)loc); st(mring[2 * (i % PE_MRING) + 1], bp);
+    }
     PE_FN bool seed_is_used(int i) const { return (ld(seed_used[i >> 5]) >> (i & 31)) & 1u; }
     PE_FN void seed_set_used(int i) { st(seed_used[i >> 5], ld(seed_used[i >> 5]) | (1u << (i & 31))); }
 
@@ -759,19 +768,23 @@ struct PairedCore {
         const uint64_t t_p2 = PL::clock();
         sh->cnt.cyc_lookup += t_p2 - t_p1;
         int max_used_list = 0;
+        uint32_t n_cand0 = 0;                       // candidates of set pair 0 (they come first in cand[])
         for (int sp = 0; sp < 2; sp++) {
             // set pair 0 = read0 FORWARD + read1 RC, set pair 1 = read0 RC + read1 FORWARD
             const int s_fewer = 2 * fewer + set_dir(sp, fewer), s_more = 2 * more + set_dir(sp, more);
             int64_t loc_f, loc_m = SNAPGPU_InvalidGenomeLocation32;
             uint32_t so_f = 0, so_m = 0;
             bool out_of_more = false;
+            int64_t last_mate_loc = 0;              // mate[sp][n_mate[sp] - 1].loc (the walk looks back at it in every step)
+            if (sp == 1) n_cand0 = n_cand;
+            pl.hs_begin_walk(lks(s_fewer), &hs[s_fewer], 0); pl.hs_begin_walk(lks(s_more), &hs[s_more], 1);
             if (hs_first(s_fewer, &loc_f, &so_f)) continue;
             for (;;) {
                 if (loc_m > loc_f + (int64_t)cfg.max_spacing) {
                     if (!hs_next_le(s_more, loc_f + (int64_t)cfg.max_spacing, &loc_m, &so_m)) break;
                 }
                 if ((loc_m + (int64_t)cfg.max_spacing < loc_f || out_of_more) &&
-                    (0 == n_mate[sp] || !within(ld(mate[sp][n_mate[sp] - 1].loc), loc_f, cfg.max_spacing))) {
+                    (0 == n_mate[sp] || !within(last_mate_loc, loc_f, cfg.max_spacing))) {
                     if (out_of_more) break;
                     if (!hs_next_le(s_fewer, loc_m + (int64_t)cfg.max_spacing, &loc_f, &so_f)) break;
                     continue;
@@ -786,14 +799,18 @@ struct PairedCore {
                         m->clip_after = 0; m->ag_score = 0; m->lv_indels = 0; m->big_indel = 0; m->ref_span = 0;
                     }
                     PL::sync();
+                    mring_put(n_mate[sp], loc_m, bp);
+                    last_mate_loc = loc_m;
                     n_mate[sp]++;
                     if (!hs_next_lower(s_more, &loc_m, &so_m)) { loc_m = 0; out_of_more = true; break; }
                 }
                 const int bp_f = (int)hs_best_possible(s_fewer);
                 int lowest_mate = cfg.max_k + cfg.extra_depth;
                 for (int i = (int)n_mate[sp] - 1; i >= 0; i--) {
-                    if (ld(mate[sp][i].loc) > loc_f + (int64_t)cfg.max_spacing) break;
-                    int b = ld(mate[sp][i].best_possible);
+                    int64_t ml; int b;
+                    if (mring != nullptr && (int)n_mate[sp] - 1 - i < PE_MRING) { ml = (int64_t)ld(mring[2 * (i % PE_MRING)]); b = (int)ld(mring[2 * (i % PE_MRING) + 1]); }
+                    else { ml = ld(mate[sp][i].loc); b = ld(mate[sp][i].best_possible); }
+                    if (ml > loc_f + (int64_t)cfg.max_spacing) break;
                     if (b < lowest_mate) lowest_mate = b;
                 }
                 if (lowest_mate + bp_f <= cfg.max_k + cfg.extra_depth) {
@@ -816,7 +833,12 @@ struct PairedCore {
         }
 
         // ---- Phase 2a: seed-hinted indels raise the limit for candidates that sit close together (:743-801); not in alignHamming
-        if (!hamming) {
+        if (!hamming && PL::FAST_HITSET) {
+            // (each list is strictly descending, which gives the loops below a closed form: paired_dev.h: hint_indels)
+            for (int sp = 0; sp < 2; sp++) pl.hint_indels(mate[sp], 0u, n_mate[sp], cfg.max_k_for_indels);
+            pl.hint_indels(cand, 0u, n_cand0, cfg.max_k_for_indels);
+            pl.hint_indels(cand, n_cand0, n_cand - n_cand0, cfg.max_k_for_indels);
+        } else if (!hamming) {
             for (int sp = 0; sp < 2; sp++) {
                 int bottom = 0, top = 1;
                 while (top < (int)n_mate[sp]) {

@@ -219,107 +219,166 @@ struct DevPL {
     //  detected: Operand has incorrect register class  V_CMP_NE_U32_e32 0, $src_shared_base"; the scalar queries are used there)
     static const bool FAST_HITSET = AGC != 0;
     static const bool SECONDARY = SEC;
-    static __device__ __forceinline__ uint32_t lk_hit(const PELookup *l, int64_t i) { return l->is_single ? l->singleton : l->hits[i]; }
-    // wave arg-max of v over lanes with ok set; returns the winning lane (lowest lane among equals) or -1
-    static __device__ __forceinline__ int wave_argmax(bool ok, int64_t v, int64_t *best) {
-        int64_t m = ok ? v : -1;
-        for (int o = 32; o >= 1; o >>= 1) {
-            int64_t t = ((int64_t)__shfl_xor((int)(m >> 32), o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)m, o);
-            m = t > m ? t : m;
+    // The hits a walk is about to need are STAGED IN LDS, HS_W of them per lookup (the Landau-Vishkin block is idle during Phase 2: two window
+    // blocks of max_seeds x HS_W words, one per set of the set pair being walked).  Every query below looks at hits[cur - 1 .. cur + 1] of its
+    // lookups, and a walk moves `cur` forward one hit at a time, so a lane reloads its window -- one burst of HS_W independent loads from the
+    // overflow table -- once per HS_W - 2 steps instead of waiting for one or two dependent HBM round trips in EVERY step (profiles/r05a: the
+    // set intersection was 42 % of the paired kernel's wave cycles, ~3 600 cycles per hit).  Only the binary search of hs_next_le, which jumps,
+    // probes the table directly.  Locations are 32-bit on the device (snapgpu.hip refuses larger genomes), so the arithmetic is too.
+    uint32_t hs_w;                     // HS_W: 16 where 2 x max_seeds x 16 words fit the Landau-Vishkin block, else 8
+    __device__ __forceinline__ uint32_t *hs_win(const PEHitSetHdr *h, uint32_t max_seeds) const {
+        return (uint32_t *)al->lv_tri + 2 * PE_MRING + (size_t)ld(h->win_role) * max_seeds * hs_w + (size_t)lane_id() * hs_w;      // (lanes >= max_seeds never use theirs)
+    }
+    __device__ __forceinline__ void hs_begin_walk(PELookup *lk, PEHitSetHdr *h, int role) {
+        const int lane = lane_id();
+        st(h->win_role, (uint32_t)role);
+        if (lane < (int)ld(h->n_used)) lk[lane].wbase = -1;
+        WAVE_SYNC();
+    }
+    // window of lane's lookup covers hit indices [lo, hi] (already clamped to the list)?  If not, stage [lo, lo + HS_W) -- all the loads of
+    // all the lanes that need one go out together, one wait.
+    template <int W> __device__ __forceinline__ void hs_stage_w(PELookup *l, uint32_t *win, bool need, uint32_t lo, uint32_t nh) {
+        if (BALLOT(need)) {
+            if (need) {
+                const uint32_t *src = l->hits + lo;
+                const uint32_t n = nh - lo;
+                uint32_t v[W];
+#pragma unroll
+                for (int j = 0; j < W; j++) v[j] = src[(uint32_t)j < n ? (uint32_t)j : n - 1u];      // (n >= 1; entries past the list repeat its last hit and are never read)
+#pragma unroll
+                for (int j = 0; j < W; j++) win[j] = v[j];
+                l->wbase = (int32_t)lo;
+            }
+            WAVE_SYNC();
         }
-        m = (int64_t)first_u64((uint64_t)m);
-        uint64_t who = BALLOT(ok && v == m);
+    }
+    __device__ __forceinline__ void hs_stage(PELookup *l, uint32_t *win, bool act, uint32_t lo, uint32_t hi, uint32_t nh) {
+        const int32_t wb = l->wbase;
+        const bool need = act && hi >= lo && !l->is_single && (wb < 0 || lo < (uint32_t)wb || hi >= (uint32_t)wb + hs_w);
+        if (hs_w == 16u) hs_stage_w<16>(l, win, need, lo, nh); else hs_stage_w<8>(l, win, need, lo, nh);
+    }
+    // hits[i] of lane's lookup; i must be inside the staged window (or the lookup a singleton)
+    static __device__ __forceinline__ uint32_t hs_get(const PELookup *l, const uint32_t *win, uint32_t i) {
+        return l->is_single ? l->singleton : win[i - (uint32_t)l->wbase];
+    }
+    // wave arg-max of v (> 0) over lanes with ok set; returns the winning lane (lowest lane among equals) or -1
+    static __device__ __forceinline__ int wave_argmax32(bool ok, uint32_t v, uint32_t *best) {
+        uint32_t m = ok ? v : 0u;
+        for (int o = 16; o >= 1; o >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m, o); m = t > m ? t : m; }      // (lookups live in lanes 0 .. 29)
+        m = first_u32(m);
+        const uint64_t who = BALLOT(ok && v == m);
         *best = m;
         return who ? __ffsll((long long)who) - 1 : -1;
     }
-    __device__ __forceinline__ bool hs_first(PELookup *lk, PEHitSetHdr *h, int64_t *loc, uint32_t *seed_offset) {
+    __device__ __forceinline__ bool hs_first(PELookup *lk, PEHitSetHdr *h, int64_t *loc, uint32_t *seed_offset, uint32_t max_seeds) {
         const int lane = lane_id();
         const uint32_t n = ld(h->n_used);
-        const PELookup *l = &lk[lane < (int)n ? lane : 0];
-        bool ok = lane < (int)n && l->n_hits > 0;
-        uint32_t so = l->seed_offset;
-        int64_t v = ok ? (int64_t)(uint32_t)(lk_hit(l, 0) - so) : -1;
-        ok = ok && v > 0;
-        int64_t best;
-        int w = wave_argmax(ok, v, &best);
+        PELookup *l = &lk[lane < (int)n ? lane : 0];
+        uint32_t *win = hs_win(h, max_seeds);
+        const uint32_t nh = (uint32_t)l->n_hits;
+        bool ok = lane < (int)n && nh > 0;
+        hs_stage(l, win, ok, 0u, nh > 1u ? 1u : 0u, nh);
+        const uint32_t so = l->seed_offset;
+        const uint32_t v = ok ? hs_get(l, win, 0u) - so : 0u;
+        ok = ok && v > 0u;
+        uint32_t best;
+        const int w = wave_argmax32(ok, v, &best);
         *loc = 0;
         if (w < 0) return true;
-        *loc = best;
+        *loc = (int64_t)best;
         *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)so, w);
-        st(h->most_recent, best);
+        st(h->most_recent, (int64_t)best);
         return false;
     }
-    __device__ __forceinline__ bool hs_next_lower(PELookup *lk, PEHitSetHdr *h, int64_t *loc, uint32_t *seed_offset) {
+    __device__ __forceinline__ bool hs_next_lower(PELookup *lk, PEHitSetHdr *h, int64_t *loc, uint32_t *seed_offset, uint32_t max_seeds) {
         const int lane = lane_id();
         const uint32_t n = ld(h->n_used);
-        const int64_t recent = ld(h->most_recent);
+        const uint32_t recent = (uint32_t)ld(h->most_recent);
         PELookup *l = &lk[lane < (int)n ? lane : 0];
+        uint32_t *win = hs_win(h, max_seeds);
         const bool act = lane < (int)n;
-        int64_t cur = l->cur;
-        const int64_t nh = l->n_hits;
+        uint32_t cur = (uint32_t)l->cur;
+        const uint32_t nh = (uint32_t)l->n_hits;
         const uint32_t so = l->seed_offset;
         bool live = act && cur != nh;
-        int64_t hv = live ? (int64_t)lk_hit(l, cur) : 0;
+        hs_stage(l, win, live, cur > 0u ? cur - 1u : 0u, cur + 1u < nh ? cur + 1u : cur, nh);
+        uint32_t hv = live ? hs_get(l, win, cur) : 0u;
         if (live && hv - so == recent) {
             cur++;
-            l->cur = cur;
+            l->cur = (int64_t)cur;
             live = cur != nh;
-            if (live) hv = (int64_t)lk_hit(l, cur);
+            if (live) hv = hs_get(l, win, cur);
         }
         WAVE_SYNC();
-        bool ok = live && hv >= (int64_t)so && hv - so > 0;
-        int64_t best;
-        int w = wave_argmax(ok, hv - so, &best);
+        const bool ok = live && hv >= so && hv - so > 0u;
+        uint32_t best;
+        const int w = wave_argmax32(ok, hv - so, &best);
         if (w < 0) return false;
-        *loc = best;
+        *loc = (int64_t)best;
         *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)so, w);
-        st(h->most_recent, best);
+        st(h->most_recent, (int64_t)best);
         return true;
     }
-    __device__ __forceinline__ bool hs_next_le(PELookup *lk, PEHitSetHdr *h, int64_t max_loc, int64_t *loc, uint32_t *seed_offset) {
+    __device__ __forceinline__ bool hs_next_le(PELookup *lk, PEHitSetHdr *h, int64_t max_loc, int64_t *loc, uint32_t *seed_offset, uint32_t max_seeds) {
         const int lane = lane_id();
         const uint32_t n = ld(h->n_used);
         PELookup *l = &lk[lane < (int)n ? lane : 0];
+        const uint32_t *win = hs_win(h, max_seeds);
         const bool act = lane < (int)n;
         const uint32_t so = l->seed_offset;
         const int64_t max_this = max_loc + so;
+        const bool single = l->is_single != 0;
+        const int32_t wb = l->wbase;
+        const uint32_t wcap = hs_w;
+        // hits[i], from the window where it holds i (the answer is often a few hits further on), else from the table
+        auto peek = [&](int64_t i) -> int64_t {
+            if (single) return (int64_t)l->singleton;
+            if (wb >= 0 && i >= (int64_t)wb && i < (int64_t)wb + (int64_t)wcap) return (int64_t)win[i - wb];
+            return (int64_t)l->hits[i];
+        };
         int64_t lo = l->cur, hi = act ? l->n_hits - 1 : -1;
         if (!act) lo = 0;
+        if (act && !single && wb >= 0) {                 // the last staged hit at or below the bound: the answer is inside the window
+            const int64_t wend = ((int64_t)wb + (int64_t)wcap < l->n_hits ? (int64_t)wb + (int64_t)wcap : l->n_hits) - 1;
+            if (wend >= lo && (int64_t)win[wend - wb] <= max_this) hi = wend;
+        }
         bool found = false;
-        int64_t v = 0;
+        uint32_t v = 0;
         while (BALLOT(lo <= hi && !found)) {
             if (lo <= hi && !found) {
-                int64_t probe = (lo + hi) / 2;
-                int64_t ph = (int64_t)lk_hit(l, probe);
-                if (ph <= max_this && (probe == 0 || (int64_t)lk_hit(l, probe - 1) > max_this)) {
-                    found = true; v = ph - so;
+                const int64_t probe = (lo + hi) / 2;
+                const int64_t ph = peek(probe);
+                if (ph <= max_this && (probe == 0 || peek(probe - 1) > max_this)) {
+                    found = true; v = (uint32_t)ph - so;
                     l->cur = probe;
                 } else if (ph > max_this) lo = probe + 1; else hi = probe - 1;
             }
         }
         if (act && !found) l->cur = l->n_hits;
         WAVE_SYNC();
-        int64_t best;
-        int w = wave_argmax(found && v > 0, v, &best);
+        uint32_t best;
+        const int w = wave_argmax32(found && v > 0u, v, &best);
         if (w < 0) return false;
-        *loc = best;
+        *loc = (int64_t)best;
         *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)so, w);
-        st(h->most_recent, best);
+        st(h->most_recent, (int64_t)best);
         return true;
     }
-    __device__ __forceinline__ uint32_t hs_best_possible(PELookup *lk, PEHitSetHdr *h, uint32_t *exhausted) {
+    __device__ __forceinline__ uint32_t hs_best_possible(PELookup *lk, PEHitSetHdr *h, uint32_t *exhausted, uint32_t max_seeds) {
         const int lane = lane_id();
         const uint32_t n = ld(h->n_used);
         const int cd = ld(h->cur_disjoint);
         const int64_t recent = ld(h->most_recent);
-        const PELookup *l = &lk[lane < (int)n ? lane : 0];
+        PELookup *l = &lk[lane < (int)n ? lane : 0];
+        uint32_t *win = hs_win(h, max_seeds);
         const bool act = lane < (int)n;
-        const int64_t cur = l->cur, nh = l->n_hits;
+        const uint32_t cur = (uint32_t)l->cur, nh = (uint32_t)l->n_hits;
         const int64_t target = recent + l->seed_offset;
+        hs_stage(l, win, act && nh > 0u, cur > 0u ? cur - 1u : 0u, cur < nh ? cur : nh - 1u, nh);
         bool close = false;
         if (act) {
-            if (cur != nh) { int64_t a = (int64_t)lk_hit(l, cur); int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
-            if (!close && cur != 0) { int64_t a = (int64_t)lk_hit(l, cur - 1); int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
+            if (cur != nh) { const int64_t a = (int64_t)hs_get(l, win, cur); const int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
+            if (!close && cur != 0u) { const int64_t a = (int64_t)hs_get(l, win, cur - 1u); const int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
         }
         const uint32_t wd = l->which_disjoint;
         uint32_t best = 0;
@@ -328,6 +387,39 @@ struct DevPL {
             if (m > best) best = m;
         }
         return best;
+    }
+
+    // Phase 2a (IntersectingPairedEndAligner.cpp:743-801): entries of a strictly descending list that lie within maxKForIndels of one
+    // another raise each other's largestBigIndelDetected to their distance.  The reference's two-pointer loop (paired.h has it) compares
+    // entry i, as `top`, once -- with the farthest earlier entry within the distance, B(i) -- and, as `bottom`, with every later entry up to
+    // the farthest within the distance, T(i), but only from the moment its predecessor stopped being `bottom`, i.e. only if T(i) > T(i - 1).
+    // So big(i) = max(loc[B(i)] - loc[i], T(i) > max(i, T(i - 1)) ? loc[i] - loc[T(i)] : 0)  -- checked against the loop on 200 000 random
+    // lists, and by every paired-end parity test -- which 64 entries compute side by side instead of one entry per two dependent loads.
+    template <class R> __device__ __forceinline__ void hint_indels(R *r, uint32_t first, uint32_t n, int K) {
+        const int lane = lane_id();
+        r += first;
+        uint32_t carry_t = 0;                                   // T(i - 1) for the first lane of a chunk (0 for i = 0)
+        for (uint32_t base = 0; base < n; base += WAVE) {
+            const uint32_t i = base + (uint32_t)lane;
+            const bool act = i < n;
+            const int64_t li = act ? (int64_t)r[i].loc : 0;
+            uint32_t t = i, b = i;
+            for (uint32_t step = 1; step < (uint32_t)K + 1u; step++) {
+                const bool fw = act && t == i + step - 1u && i + step < n;
+                const bool bw = act && b == i - step + 1u && i >= step;
+                if (!BALLOT(fw || bw)) break;
+                if (fw && li - (int64_t)r[i + step].loc < (int64_t)K) t = i + step;
+                if (bw && (int64_t)r[i - step].loc - li < (int64_t)K) b = i - step;
+            }
+            uint32_t prev_t = (uint32_t)__shfl_up((int)t, 1);
+            if (lane == 0) prev_t = carry_t;
+            carry_t = (uint32_t)__builtin_amdgcn_readlane((int)t, WAVE - 1);
+            int64_t big = 0;
+            if (act && b < i) big = (int64_t)r[b].loc - li;
+            if (act && t > i && t > prev_t) { const int64_t d = li - (int64_t)r[t].loc; big = d > big ? d : big; }
+            if (act && big > 0) r[i].big_indel = (decltype(r[i].big_indel))big;
+            WAVE_SYNC();
+        }
     }
 
     __device__ __forceinline__ bool lookup(const uint8_t *text, PEHits out[2]) {
@@ -532,6 +624,9 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     pl.help = EXACT ? nullptr : a.help; pl.n_help = a.n_help; pl.help_spec = a.help_spec; pl.help_spec_cap = a.help_spec_cap;
     pl.help_idle = a.help_done ? a.help_done + 1 : nullptr; pl.help_eager = a.help_eager != 0;
     pl.cur_pair = 0; pl.my_slot = -1; pl.diag = a.counters + 13;
+    // the Landau-Vishkin block of LDS during Phase 2: [mate ring: 2 x PE_MRING words][two window blocks of max_seeds x hs_w words]
+    // (snapgpu_enable_paired: kmax >= 22 -> 2 232 bytes, max_seeds <= 30, so windows of 8 always fit)
+    pl.hs_w = 8u * PE_MRING + 2u * a.pcfg.max_seeds * 16u * 4u <= lv_lds_bytes(a.scfg.kmax, a.scfg.RL) ? 16u : 8u;
     if constexpr (EXACT) {
         uint8_t *pb = a.persist + (size_t)wave_slot * a.persist_stride;
         const size_t q = (size_t)(a.persist_stride / 4);
@@ -548,6 +643,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     core.list_head = (int32_t *)(my + PLd.list_head);
     core.seed_used = (uint32_t *)(my + PLd.seed_used);
     core.sh = (PEShared *)(my + PLd.sh);
+    core.mring = (uint32_t *)(my + SL.lv);
     core.cand = (PECand *)(sc + a.off_cand);
     core.mate[0] = (PEMate *)(sc + a.off_mate0);
     core.mate[1] = (PEMate *)(sc + a.off_mate1);
