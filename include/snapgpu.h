@@ -444,6 +444,25 @@ int  snapgpu_sam_fields_single_device(snapgpu_ctx *ctx, uint32_t n, uint32_t max
                                       void *d_n_ops, void *d_nm, void *d_reference_history_dependent, void *stream);
 
 /*
+ * The single-end path of a SAM writer in ONE call: BaseAligner::AlignRead (SingleAligner.cpp:250) over the clipped reads, then what
+ * SimpleReadWriter::writeReads computes for each read's primary result (snapgpu_sam_fields_single) -- with the batch uploaded once and
+ * the results handed from the align kernel to the SAM-field kernel in HBM.  Host pointers.
+ *   bases / quals / offsets   the UNCLIPPED reads; front_clip / data_len: Read::clip's outcome (the aligner sees
+ *                             bases[offsets[i] + front_clip[i] .. + data_len[i]), the SAM-field kernel the whole read)
+ *   skip[i] != 0              the read is not given to the aligner (too short, too many Ns: SingleAligner.cpp:211-232) and is written unaligned
+ *   results / first_alt       [n] out, each may be NULL: the SingleAlignmentResults, for a caller that wants them (first_alt NULL also
+ *                             means the first-ALT result is not computed into a caller-visible buffer)
+ *   flag .. reference_history_dependent   as snapgpu_sam_fields_single (a cigar that does not fit ops_stride: n_ops -1, nm -2)
+ * The context must be a plain single-end one (no snapgpu_enable_secondary / _paired).  With secondary results, -ae or ALT records to
+ * write, use the two calls it replaces.
+ */
+int  snapgpu_align_sam_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, const char *quals, const uint64_t *offsets,
+                              const int32_t *front_clip, const int32_t *data_len, const uint8_t *skip, int use_m,
+                              snapgpu_single_result *results, snapgpu_single_result *first_alt,
+                              int32_t *flag, int32_t *contig, int64_t *pos, int32_t *mapq, uint32_t *ops, uint32_t ops_stride,
+                              int32_t *n_ops, int32_t *nm, int32_t *reference_history_dependent);
+
+/*
  * The paired-end writer: for the primary PairedAlignmentResult of each pair, the computed fields of BOTH SAM records -- what
  * SAMFormat::writePairs (SNAPLib/SAM.cpp:1575-1895: createSAMLine and the cigar with its leading-indel loop per mate, :1636-1715) and
  * SAMFormat::fillMateInfo (:1308-1421: pairing flags, RNEXT / PNEXT, the signed template length from the clipped starts and the cigars'

@@ -51,7 +51,7 @@ EXPORTED_SYMBOLS = [
     "snapgpu_align_single_device", "snapgpu_get_counters", "snapgpu_kernel_time",
     "snapgpu_enable_secondary", "snapgpu_align_single_secondary", "snapgpu_align_single_secondary_device",
     "snapgpu_align_paired_secondary", "snapgpu_align_paired_secondary_device",
-    "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag", "snapgpu_adjust_alignments", "snapgpu_set_aligner_flags", "snapgpu_affine_gap_sequence", "snapgpu_sam_fields_single", "snapgpu_sam_fields_single_device", "snapgpu_sam_fields_paired",
+    "snapgpu_compute_cigar_lv", "snapgpu_compute_cigar_ag", "snapgpu_adjust_alignments", "snapgpu_set_aligner_flags", "snapgpu_affine_gap_sequence", "snapgpu_sam_fields_single", "snapgpu_sam_fields_single_device", "snapgpu_sam_fields_paired", "snapgpu_align_sam_single", "snapgpu_create_replica_with_params",
     "snapgpu_default_index_build_params", "snapgpu_index_build", "snapgpu_index_build_from_fasta", "snapgpu_built_index_view",
     "snapgpu_built_index_save", "snapgpu_built_index_stats", "snapgpu_built_index_destroy",
 ]

@@ -255,7 +255,7 @@ struct Options {
     snapgpu_paired_params pp;
     bool use_m = true;                                                     // AlignerOptions.cpp:58
     unsigned min_read_len = 50;                                            // -mrl
-    size_t batch_reads = 131072;
+    size_t batch_reads = 0;                                                // -b; 0 = auto (main)
     bool clip_front = false, clip_back = true;                             // -C-+ (ClipBack) is the default
     int om = -1, mpc = -1; long long omax = 0x7fffffff;
     bool ae = false;                                                       // -ae: AlignmentAdjuster before the -om filter (single end only)
@@ -284,6 +284,8 @@ struct Work {                                // a batch on its way through the p
     // single end: what prepare_single() leaves for the feeder
     bool prepared = false;
     std::vector<int32_t> front_clip, data_len; std::vector<uint32_t> to_align; std::vector<char> ab, aq; std::vector<uint64_t> ao;
+    std::vector<uint8_t> skip;               // single end: read i is not given to the aligner (the fused call's argument)
+    uint32_t max_len = 0;                    // the longest read of the batch (unclipped): picks the context's read-length class
     std::string text;                        // the formatted records (BAM: BGZF blocks)
     bool bam = false;
     unsigned long long mapped = 0;
@@ -463,6 +465,43 @@ static void host_mate_info(const HostRec &me, const HostRec &mate, bool first_in
 }
 
 // ---------------------------------------------------------------------------------------- GPU stage
+// Contexts of one feeder thread, by READ-LENGTH CLASS.  The aligner's answers do not depend on the buffer size it was built for
+// (BaseAligner's maxReadSize only sizes its arrays), but the kernel variant does: reads up to 160 bp run the 192-position affine-gap
+// variant at six waves per SIMD, up to 256 bp the 256-position one, the command line's maximum (400 by default, as the reference's
+// MAX_READ_LENGTH) the 384-position one at four -- which a run of 150 bp reads used to pay for (profiles/r05a: k_align_single<6> was 76 %
+// of the GPU time of FASTQ -> SAM).  The class-0 context of every feeder exists from the start; a longer batch makes its feeder create
+// the next class over the same resident index (snapgpu_create_replica_with_params), once.
+static const uint32_t RL_CLASS[3] = {160, 256, 0};                       // (0: the command line's maximum)
+struct FeederCtx {
+    snapgpu_ctx *c[3] = {NULL, NULL, NULL};
+    snapgpu_ctx *owner = NULL; int device = 0;                             // whose index blobs they share
+};
+static uint32_t class_len(const Options &o, int k) { return RL_CLASS[k] && RL_CLASS[k] < o.p.max_read_len ? RL_CLASS[k] : o.p.max_read_len; }
+static void configure_ctx(const Options &o, snapgpu_ctx *c)
+{
+    snapgpu_set_aligner_flags(c, o.stop_on_first_hit ? 1 : 0, o.explore_popular_seeds ? 1 : 0);      // -f, -x (single-end launches only)
+    if (o.paired) { int rc = snapgpu_enable_paired(c, &o.pp); if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_enable_paired failed (%d): %s\n", rc, snapgpu_last_error(c)); exit(1); } }
+    if (o.om >= 0) {
+        snapgpu_secondary_params sp; memset(&sp, 0, sizeof(sp));
+        sp.max_edit_distance = o.om; sp.max_per_contig = o.mpc; sp.max_results = o.omax; sp.adjust_alignments = o.ae ? 1u : 0u;
+        int rc = snapgpu_enable_secondary(c, &sp);
+        if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_enable_secondary failed (%d): %s\n", rc, snapgpu_last_error(c)); exit(1); }
+    }
+}
+static snapgpu_ctx *ctx_for(const Options &o, FeederCtx &f, uint32_t max_len)
+{
+    int k = 0;
+    while (k < 2 && max_len > class_len(o, k)) k++;
+    while (k < 2 && class_len(o, k) == class_len(o, k + 1) && f.c[k] == NULL) k++;     // (classes that coincide: use the one that exists)
+    if (f.c[k]) return f.c[k];
+    for (int j = 0; j < 3; j++) if (f.c[j] && class_len(o, j) == class_len(o, k)) return f.c[k] = f.c[j];
+    snapgpu_params p = o.p; p.max_read_len = class_len(o, k);
+    int rc = snapgpu_create_replica_with_params(f.owner, f.device, 1, &p, &f.c[k]);
+    if (rc != SNAPGPU_OK) { fprintf(stderr, "snapgpu-sam: snapgpu_create_replica_with_params failed (%d): %s\n", rc, snapgpu_last_error(f.owner)); exit(1); }
+    configure_ctx(o, f.c[k]);
+    return f.c[k];
+}
+
 // A cigar that does not fit ops_stride comes back as n_ops = -1 with nm = -2 (the reference's "cigarBuf too small" never happens: its
 // buffer is large): call again with a larger stride rather than print a wrong record.
 template <class F> static void with_growing_stride(Work &w, size_t n_rec, F call)
@@ -484,11 +523,17 @@ static void prepare_single(const Options &o, Work &w)
 {
     const Batch &b = w.b;
     const size_t n = b.n();
-    w.front_clip.assign(n, 0); w.data_len.assign(n, 0); w.to_align.clear(); w.ab.clear(); w.aq.clear(); w.ao.assign(1, 0);
-    w.ab.reserve(b.bases.size()); w.aq.reserve(b.quals.size()); w.ao.reserve(n + 1); w.to_align.reserve(n);
+    w.front_clip.assign(n, 0); w.data_len.assign(n, 0); w.skip.assign(n, 1); w.to_align.clear(); w.ab.clear(); w.aq.clear(); w.ao.assign(1, 0);
+    const bool fused = o.om < 0 && !o.ae;               // gpu_single's one-call path works on the batch itself: nothing to gather
+    if (!fused) { w.ab.reserve(b.bases.size()); w.aq.reserve(b.quals.size()); w.ao.reserve(n + 1); }
+    w.to_align.reserve(n);
+    w.max_len = 0;
     for (size_t i = 0; i < n; i++) {
+        const uint32_t U = (uint32_t)(b.offsets[i + 1] - b.offsets[i]);
+        if (U > w.max_len) w.max_len = U;
         if (clip_read(o, b, i, w.front_clip[i], w.data_len[i])) {
-            w.to_align.push_back((uint32_t)i);
+            w.to_align.push_back((uint32_t)i); w.skip[i] = 0;
+            if (fused) continue;
             const char *q = b.quals.data() + b.offsets[i] + w.front_clip[i], *s = b.bases.data() + b.offsets[i] + w.front_clip[i];
             w.ab.insert(w.ab.end(), s, s + w.data_len[i]); w.aq.insert(w.aq.end(), q, q + w.data_len[i]); w.ao.push_back(w.ab.size());
         }
@@ -496,13 +541,39 @@ static void prepare_single(const Options &o, Work &w)
     w.prepared = true;
 }
 
-static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
+static bool g_index_has_alt = false;        // the index has ALT contigs: only then can a first-ALT result (an extra record) exist
+static void gpu_single(const Options &o, FeederCtx &fc, Work &w)
 {
     auto t_stage = std::chrono::steady_clock::now();
     auto lap = [&](std::atomic<unsigned long long> &acc) { const auto t = std::chrono::steady_clock::now(); acc += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(t - t_stage).count(); t_stage = t; };
     const Batch &b = w.b;
     const size_t n = b.n();
     if (!w.prepared) prepare_single(o, w);            // (the parser threads of the mapped reader have done it already)
+    snapgpu_ctx *ctx = ctx_for(o, fc, w.max_len);
+    // ---- the common case in ONE call (snapgpu_align_sam_single): no secondary results, no -ae; one record per read unless a first-ALT result turns up
+    std::vector<snapgpu_single_result> fused_res, fused_alt;
+    bool fused_done = false;
+    if (o.om < 0 && !o.ae && n > 0) {
+        const bool want_alt = o.p.alt_awareness && g_index_has_alt;
+        if (want_alt) { fused_res.resize(n); fused_alt.resize(n); }
+        w.rec_read.resize(n); for (size_t i = 0; i < n; i++) w.rec_read[i] = (uint32_t)i;
+        w.rec_secondary.assign(n, 0);
+        w.flag.assign(n, 0); w.contig.assign(n, 0); w.mapq.assign(n, 0); w.n_ops.assign(n, 0); w.nm.assign(n, 0); w.pos.assign(n, 0);
+        std::vector<int32_t> stale(n);
+        w.ops_stride = o.ops_stride;
+        lap(g_ns_prep);
+        with_growing_stride(w, n, [&] {
+            int rc2 = snapgpu_align_sam_single(ctx, (uint32_t)n, b.bases.data(), b.quals.data(), b.offsets.data(), w.front_clip.data(), w.data_len.data(), w.skip.data(),
+                                               o.use_m ? 1 : 0, want_alt ? fused_res.data() : NULL, want_alt ? fused_alt.data() : NULL,
+                                               w.flag.data(), w.contig.data(), w.pos.data(), w.mapq.data(), w.ops.data(), w.ops_stride, w.n_ops.data(), w.nm.data(), stale.data());
+            if (rc2 != SNAPGPU_OK) fail_rc(ctx, "snapgpu_align_sam_single", rc2);
+        });
+        lap(g_ns_align);
+        bool any_alt = false;
+        if (want_alt) for (size_t i = 0; i < n && !any_alt; i++) any_alt = !w.skip[i] && fused_alt[i].status != SNAPGPU_NotFound;
+        if (!any_alt) return;
+        fused_done = true;                             // (rare: ALT records to add -- the records are built below from the results, as after the two-call path)
+    }
     std::vector<int32_t> &front_clip = w.front_clip, &data_len = w.data_len;
     std::vector<uint32_t> &to_align = w.to_align;
     std::vector<char> &ab = w.ab, &aq = w.aq; std::vector<uint64_t> &ao = w.ao;
@@ -515,7 +586,13 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
     std::vector<snapgpu_single_result> rec_res;
     w.rec_read.clear(); w.rec_secondary.clear();
     int rc;
-    if (!to_align.empty()) {
+    if (fused_done) {                                  // the alignment is done: results per read, straight from the one call
+        for (size_t i = 0; i < n; i++) {
+            if (!w.skip[i]) results[i] = fused_res[i];
+            w.rec_read.push_back((uint32_t)i); w.rec_secondary.push_back(0); rec_res.push_back(results[i]);
+            if (!w.skip[i] && fused_alt[i].status != SNAPGPU_NotFound) { w.rec_read.push_back((uint32_t)i); w.rec_secondary.push_back(1); rec_res.push_back(fused_alt[i]); }
+        }
+    } else if (!to_align.empty()) {
         std::vector<snapgpu_single_result> sec; std::vector<uint32_t> nsec(to_align.size(), 0);
         uint32_t stride = 0;
         lap(g_ns_prep);
@@ -591,10 +668,13 @@ static void gpu_single(const Options &o, snapgpu_ctx *ctx, Work &w)
     for (size_t r = 0; r < nr; r++) if (w.rec_secondary[r]) w.flag[r] |= 0x100;                  // SAM_SECONDARY (createSAMLine, SAM.cpp:1477-1479)
 }
 
-static void gpu_paired(const Options &o, snapgpu_ctx *ctx, Work &w)
+static void gpu_paired(const Options &o, FeederCtx &fc, Work &w)
 {
     const Batch &b = w.b;
     const size_t n = b.n(), np = n / 2;
+    w.max_len = 0;
+    for (size_t i = 0; i < n; i++) { const uint32_t U = (uint32_t)(b.offsets[i + 1] - b.offsets[i]); if (U > w.max_len) w.max_len = U; }
+    snapgpu_ctx *ctx = ctx_for(o, fc, w.max_len);
     std::vector<int32_t> front_clip(n, 0), data_len(n, 0);
     std::vector<char> useful(n, 0);
     for (size_t i = 0; i < n; i++) useful[i] = clip_read(o, b, i, front_clip[i], data_len[i]);
@@ -1081,15 +1161,20 @@ int main(int argc, char **argv)
     if (o.ae && o.paired) die("-ae is implemented for `single` only (the paired-end aligners' use of AlignmentAdjuster is not: DESIGN.md section 16)");
     if (o.ae && o.clip_front) die("-ae with front clipping (-C+x) is not supported: the adjuster is restated for reads the reader has not clipped at the front");
     o.bam = out_path.size() > 4 && out_path.compare(out_path.size() - 4, 4, ".bam") == 0;     // by extension, like the reference (AlignerOptions.cpp)
+    const bool batch_auto = o.batch_reads == 0;
+    if (batch_auto) o.batch_reads = 262144;                                // (the mapped reader, which knows the file's size, picks below)
     if (o.batch_reads < (o.paired ? 2u : 1u)) die("-b must be at least 1 (2 for paired)");
     if (o.paired) o.batch_reads &= ~(size_t)1;
     // feeders per GPU: a launch lasts as long as its slowest read (~150 ms when the batch holds one of the heavy ones), so batches of 131 072
     // reads need several launches in flight to keep the chip busy: 20 M reads go through at 2.24 / 2.47 / 2.50 M reads/s with 3 / 6 / 8
     // feeders (profiles/r04zy).  The paired-end launches are long already.
-    if (o.ctx_per_gpu == 0) o.ctx_per_gpu = o.paired ? 3 : 6;
+    // Round 5: a single-end batch is 1 M reads where the file has them (bench.py's launch size: the tail of a launch then costs 10 %, not
+    // half of it), goes through ONE call per batch (snapgpu_align_sam_single) and the 192-position kernel variant: four feeders cover the
+    // copies of one batch with the kernels of the others.
+    if (o.ctx_per_gpu == 0) o.ctx_per_gpu = o.paired ? 3 : 4;
     if (o.ctx_per_gpu < 1 || o.ctx_per_gpu > 8) die("-q must be in [1, 8]");
     // cigar ops per record: about 2 * edits + soft clips; grown on demand when a record needs more (with_growing_stride)
-    { uint32_t need = 2 * (o.p.max_k + o.p.extra_search_depth) + 8; o.ops_stride = 64; while (o.ops_stride < need) o.ops_stride *= 2; }
+    { uint32_t need = 2 * (o.p.max_k + o.p.extra_search_depth) + 8; o.ops_stride = (need + 3u) & ~3u; if (o.ops_stride < 16) o.ops_stride = 16; }
 
     const auto t_process = std::chrono::steady_clock::now();
     std::vector<Contig> contigs; uint64_t n_bases = 0; uint32_t padding = 0;
@@ -1101,7 +1186,12 @@ int main(int argc, char **argv)
     if (visible <= 0) { snapgpu_ctx *none = NULL; int rc = snapgpu_create_from_directory(index_dir.c_str(), &o.p, 0, &none); fail_rc(none, "snapgpu_create_from_directory", rc); }
     if (o.n_gpus <= 0 || o.n_gpus > visible) o.n_gpus = visible;
     std::vector<snapgpu_ctx *> primary((size_t)o.n_gpus, NULL);
-    int rc = snapgpu_create_from_directory(index_dir.c_str(), &o.p, 0, &primary[0]);
+    snapgpu_default_paired_params(&o.pp);
+    o.pp.min_read_length = o.min_read_len;
+    for (const Contig &c : contigs) if (c.is_alt) g_index_has_alt = true;
+    // every context starts in read-length class 0 (FeederCtx): the index owner too
+    snapgpu_params p0 = o.p; p0.max_read_len = class_len(o, 0);
+    int rc = snapgpu_create_from_directory(index_dir.c_str(), &p0, 0, &primary[0]);
     if (rc != SNAPGPU_OK) fail_rc(primary[0], "snapgpu_create_from_directory", rc);
     for (int g = 1; g < o.n_gpus; g++) {
         rc = snapgpu_create_replica(primary[0], g, 0, &primary[(size_t)g]);
@@ -1111,26 +1201,17 @@ int main(int argc, char **argv)
         rc = snapgpu_broadcast_index(primary.data(), o.n_gpus);
         if (rc != SNAPGPU_OK) fail_rc(primary[0], "snapgpu_broadcast_index", rc);
     }
-    std::vector<snapgpu_ctx *> ctxs;                                        // one per feeder thread
+    std::vector<FeederCtx> fctx;                                            // one per feeder thread
     for (int g = 0; g < o.n_gpus; g++) {
-        ctxs.push_back(primary[(size_t)g]);
-        for (int k = 1; k < o.ctx_per_gpu; k++) {
-            snapgpu_ctx *c = NULL;
-            rc = snapgpu_create_replica(primary[(size_t)g], g, 1, &c);
-            if (rc != SNAPGPU_OK) fail_rc(primary[(size_t)g], "snapgpu_create_replica", rc);
-            ctxs.push_back(c);
-        }
-    }
-    snapgpu_default_paired_params(&o.pp);
-    o.pp.min_read_length = o.min_read_len;
-    for (snapgpu_ctx *c : ctxs) {
-        snapgpu_set_aligner_flags(c, o.stop_on_first_hit ? 1 : 0, o.explore_popular_seeds ? 1 : 0);      // -f, -x (single-end launches only)
-        if (o.paired) { rc = snapgpu_enable_paired(c, &o.pp); if (rc != SNAPGPU_OK) fail_rc(c, "snapgpu_enable_paired", rc); }
-        if (o.om >= 0) {
-            snapgpu_secondary_params sp; memset(&sp, 0, sizeof(sp));
-            sp.max_edit_distance = o.om; sp.max_per_contig = o.mpc; sp.max_results = o.omax; sp.adjust_alignments = o.ae ? 1u : 0u;
-            rc = snapgpu_enable_secondary(c, &sp);
-            if (rc != SNAPGPU_OK) fail_rc(c, "snapgpu_enable_secondary", rc);
+        for (int k = 0; k < o.ctx_per_gpu; k++) {
+            FeederCtx f; f.owner = primary[(size_t)g]; f.device = g;
+            if (k == 0) f.c[0] = primary[(size_t)g];
+            else {
+                rc = snapgpu_create_replica(primary[(size_t)g], g, 1, &f.c[0]);
+                if (rc != SNAPGPU_OK) fail_rc(primary[(size_t)g], "snapgpu_create_replica", rc);
+            }
+            configure_ctx(o, f.c[0]);
+            fctx.push_back(f);
         }
     }
     // host threads: formatting a record is ~1 us of text work, so one GPU's ~5 M records/s want a few dozen formatters (the cap of 16 of
@@ -1172,7 +1253,7 @@ int main(int argc, char **argv)
 
     const auto t_ready = std::chrono::steady_clock::now();                  // the index is resident, the contexts exist: the streaming part starts here
     // ---- the pipeline
-    Queue<Work *> q_parsed(ctxs.size() * 2 + 2), q_aligned((size_t)o.n_format * 2 + 2);
+    Queue<Work *> q_parsed(fctx.size() * 2 + 2), q_aligned((size_t)o.n_format * 2 + 2);
     std::mutex done_m; std::condition_variable done_cv; std::map<uint64_t, Work *> done;
     std::atomic<uint64_t> n_batches(0); std::atomic<bool> reader_done(false);
     unsigned long long total = 0, mapped = 0;
@@ -1192,6 +1273,13 @@ int main(int argc, char **argv)
     std::thread reader;
     if (use_map) {
         const uint64_t n_records = mf.n_lines / 4;
+        if (batch_auto) {       // enough batches to keep every feeder busy (four each), each as large as that allows: 64 K .. 1 M reads (pairs: .. 512 K reads)
+            const uint64_t total_reads = o.paired ? 2 * n_records : n_records;
+            uint64_t v = total_reads / (4 * (uint64_t)fctx.size());
+            const uint64_t cap = o.paired ? 524288 : 1048576;
+            v = v < 65536 ? 65536 : (v > cap ? cap : v);
+            o.batch_reads = (size_t)(v & ~(uint64_t)1);
+        }
         const uint64_t per_batch = o.paired ? o.batch_reads / 2 : o.batch_reads;           // records of EACH file per batch
         const uint64_t n_units = (n_records + per_batch - 1) / per_batch;
         n_batches = n_units; reader_done = true;
@@ -1242,11 +1330,11 @@ int main(int argc, char **argv)
         { std::lock_guard<std::mutex> l(done_m); done_cv.notify_all(); }
     });
     std::vector<std::thread> feeders, formatters;
-    std::atomic<int> feeders_left((int)ctxs.size());
-    for (size_t t = 0; t < ctxs.size(); t++)
+    std::atomic<int> feeders_left((int)fctx.size());
+    for (size_t t = 0; t < fctx.size(); t++)
         feeders.emplace_back([&, t] {
             Work *w;
-            while (q_parsed.pop(w)) { if (o.paired) gpu_paired(o, ctxs[t], *w); else gpu_single(o, ctxs[t], *w); q_aligned.push(w); }
+            while (q_parsed.pop(w)) { if (o.paired) gpu_paired(o, fctx[t], *w); else gpu_single(o, fctx[t], *w); q_aligned.push(w); }
             if (--feeders_left == 0) q_aligned.close();
         });
     for (int t = 0; t < o.n_format; t++)
@@ -1279,7 +1367,15 @@ int main(int argc, char **argv)
     if (fclose(out) != 0) die("write error on ", out_path.c_str());
     if (rename(partial_path.c_str(), out_path.c_str()) != 0) die("cannot rename the finished output to ", out_path.c_str());
     g_partial_path.clear();
-    for (size_t t = ctxs.size(); t-- > 0;) snapgpu_destroy(ctxs[t]);        // sharers before the owner of the blobs they share
+    for (size_t t = fctx.size(); t-- > 0;) {                                // sharers before the owner of the blobs they share
+        for (int k = 2; k >= 0; k--) {
+            snapgpu_ctx *c = fctx[t].c[k];
+            if (!c || c == fctx[t].owner) continue;
+            bool seen = false; for (int j = 0; j < k; j++) seen = seen || fctx[t].c[j] == c;
+            if (!seen) snapgpu_destroy(c);
+        }
+    }
+    for (size_t g = primary.size(); g-- > 0;) snapgpu_destroy(primary[g]);
     fprintf(stderr, "snapgpu-sam: %llu reads, %llu mapped records, %d GPU(s) x %d feeder(s), %d formatter thread(s)\n", total, mapped, o.n_gpus, o.ctx_per_gpu, o.n_format);
     {   // (AlignerContext.cpp:489-543 prints reads/s over the alignment phase, the index load apart: the same split here)
         const auto t_end = std::chrono::steady_clock::now();

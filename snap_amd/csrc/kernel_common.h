@@ -41,6 +41,10 @@ struct AlignArgs {
     // help for heavy reads (se_help.h): slots, one record array of se_spec_cap entries per slot, [done reads | idle waves]; NULL: none
     SEHelpSlot *se_slots; uint32_t se_n_slots; SESpec *se_spec; uint32_t se_spec_cap; uint32_t *se_ctl; uint32_t se_eager;
     uint32_t se_keep;                 // every se_keep-th wave stays on as a helper when it runs out of reads (1: all)
+    // Read::clip's outcome applied on the device (snapgpu_align_sam_single: one upload serves the aligner and the SAM-field kernel, which
+    // wants the unclipped read): read i is bases[offsets[i] + front_clip[i] .. + data_len[i]); skip[i] != 0: the read is not given to the
+    // aligner at all (SingleAligner.cpp:211-232) and gets the result the reference writes for it.  NULL: offsets say it all.
+    const int32_t *front_clip, *data_len; const uint8_t *skip;
 };
 
 extern "C" {

@@ -245,8 +245,20 @@ struct PairedCore {
     }
 
     // returns true when the set is EMPTY (the reference returns !anyFound), :3720-3746
+#if defined(SNAPGPU_PT_PHASE2)
+    // diagnostic build (with -DSNAPGPU_PHASE_TIMERS): where Phase 2's cycles go -- cycles_lookup = the hit-set queries, cycles_lv = the
+    // best-possible-score computations, cycles_ag = mate / candidate records, cycles_single_fallback = Phase 2a; the counters' usual
+    // meanings are switched off (PT2_OFF)
+#define PT2_T0() const uint64_t pt2_t0 = PL::clock()
+#define PT2_ADD(f) sh->cnt.f += PL::clock() - pt2_t0
+#define PT2_OFF(x) ((void)0)
+#else
+#define PT2_T0() ((void)0)
+#define PT2_ADD(f) ((void)0)
+#define PT2_OFF(x) x
+#endif
     PE_FN bool hs_first(int s, int64_t *loc, uint32_t *seed_offset) {
-        if constexpr (PL::FAST_HITSET) return pl.hs_first(lks(s), &hs[s], loc, seed_offset, cfg.max_seeds);
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_first(lks(s), &hs[s], loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
         bool any = false;
         *loc = 0;
         const uint32_t n = ld(hs[s].n_used);
@@ -263,7 +275,7 @@ struct PairedCore {
     }
 
     PE_FN bool hs_next_lower(int s, int64_t *loc, uint32_t *seed_offset) {                              // getNextLowerHit, :3750-3816
-        if constexpr (PL::FAST_HITSET) return pl.hs_next_lower(lks(s), &hs[s], loc, seed_offset, cfg.max_seeds);
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_lower(lks(s), &hs[s], loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
         int64_t found = 0;
         bool any = false;
         const uint32_t n = ld(hs[s].n_used);
@@ -292,7 +304,7 @@ struct PairedCore {
     }
 
     PE_FN bool hs_next_le(int s, int64_t max_loc, int64_t *loc, uint32_t *seed_offset) {                // getNextHitLessThanOrEqualTo, :3628-3717
-        if constexpr (PL::FAST_HITSET) return pl.hs_next_le(lks(s), &hs[s], max_loc, loc, seed_offset, cfg.max_seeds);
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_le(lks(s), &hs[s], max_loc, loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
         bool any = false;
         int64_t best = 0;
         const uint32_t n = ld(hs[s].n_used);
@@ -324,7 +336,7 @@ struct PairedCore {
     }
 
     PE_FN uint32_t hs_best_possible(int s) {                                                             // computeBestPossibleScoreForCurrentHit, :3585-3625
-        if constexpr (PL::FAST_HITSET) return pl.hs_best_possible(lks(s), &hs[s], exh(s), cfg.max_seeds);
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const uint32_t r = pl.hs_best_possible(lks(s), &hs[s], exh(s), cfg.max_seeds); PT2_ADD(cyc_lv); return r; }
         const int cd = ld(hs[s].cur_disjoint);
         for (int i = 0; i <= cd; i++) st(miss[i], ld(exh(s)[i]));
         const uint32_t n = ld(hs[s].n_used);
@@ -496,7 +508,7 @@ struct PairedCore {
         } else {
             mp1 = 1.0;                               // (unused)
         }
-        sh->cnt.cyc_lv += PL::clock() - t_lv;
+        PT2_OFF(sh->cnt.cyc_lv += PL::clock() - t_lv);
         sh->cnt.lv_ref_bytes += (uint64_t)(rl - tail) + (uint64_t)(2 * (limit < 0 ? 0 : limit)) + (uint64_t)seed_offset;
         o.offset = off;
         if (off != 0 && !pl.substring_ok(loc + off, glen)) score2 = -1;                               // :3364-3375
@@ -603,7 +615,7 @@ struct PairedCore {
                 if (score2 == -1) *offset = 0;
             }
         }
-        sh->cnt.cyc_ag += PL::clock() - t_ag;
+        PT2_OFF(sh->cnt.cyc_ag += PL::clock() - t_ag);
         if (score1 != -1 && score2 != -1) {
             *score = score1 + score2;
             *mp = mp1 * mp2 * pl.seed_prob();
@@ -766,7 +778,7 @@ struct PairedCore {
 
         // ---- Phase 2: walk both set pairs from high to low locations, collect candidates (:527-741)
         const uint64_t t_p2 = PL::clock();
-        sh->cnt.cyc_lookup += t_p2 - t_p1;
+        PT2_OFF(sh->cnt.cyc_lookup += t_p2 - t_p1);
         int max_used_list = 0;
         uint32_t n_cand0 = 0;                       // candidates of set pair 0 (they come first in cand[])
         for (int sp = 0; sp < 2; sp++) {
@@ -792,6 +804,7 @@ struct PairedCore {
                 while (loc_m + (int64_t)cfg.max_spacing >= loc_f && !out_of_more) {
                     uint32_t bp = hs_best_possible(s_more);
                     if (n_mate[sp] >= cfg.pool_size / 2) { overflow = 1; return; }
+                    PT2_T0();
                     PEMate *m = &mate[sp][n_mate[sp]];
                     if (PL::lane0()) {                                                                             // ScoringMateCandidate::init
                         m->loc = loc_m; m->best_possible = (int32_t)bp; m->seed_offset = so_m; m->score = PE_NOT_YET_SCORED;
@@ -802,9 +815,11 @@ struct PairedCore {
                     mring_put(n_mate[sp], loc_m, bp);
                     last_mate_loc = loc_m;
                     n_mate[sp]++;
+                    PT2_ADD(cyc_ag);
                     if (!hs_next_lower(s_more, &loc_m, &so_m)) { loc_m = 0; out_of_more = true; break; }
                 }
                 const int bp_f = (int)hs_best_possible(s_fewer);
+                PT2_T0();
                 int lowest_mate = cfg.max_k + cfg.extra_depth;
                 for (int i = (int)n_mate[sp] - 1; i >= 0; i--) {
                     int64_t ml; int b;
@@ -828,11 +843,13 @@ struct PairedCore {
                     n_cand++;
                     if (list > max_used_list) max_used_list = list;
                 }
+                PT2_ADD(cyc_ag);
                 if (!hs_next_lower(s_fewer, &loc_f, &so_f)) break;
             }
         }
 
         // ---- Phase 2a: seed-hinted indels raise the limit for candidates that sit close together (:743-801); not in alignHamming
+        PT2_T0();
         if (!hamming && PL::FAST_HITSET) {
             // (each list is strictly descending, which gives the loops below a closed form: paired_dev.h: hint_indels)
             for (int sp = 0; sp < 2; sp++) pl.hint_indels(mate[sp], 0u, n_mate[sp], cfg.max_k_for_indels);
@@ -873,6 +890,7 @@ struct PairedCore {
         }
 
         // ---- Phase 3: score candidates in order of their best possible score (:803-1190)
+        PT2_ADD(cyc_single);
         sh->cnt.cyc_intersect += PL::clock() - t_p2;
         int cur_list = 0;
         bool done = false;
@@ -1622,7 +1640,7 @@ struct PairedCore {
                 if (want_sec() && ssec_out != nullptr && sec_base < ssec_stride) { sec_dst = ssec_out + sec_base; sec_room = ssec_stride - sec_base; }
                 const uint32_t room32 = sec_base < 32u ? 32u - sec_base : 0u;       // what PairedAligner.cpp:566's initial buffer would have left
                 uint32_t n_this = pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
-                sh->cnt.cyc_single += PL::clock() - t_s;
+                PT2_OFF(sh->cnt.cyc_single += PL::clock() - t_s);
                 stale += single[r].reserved & 0x3fffffffu; stale_later += (single[r].reserved & 0x40000000u) ? 1u : 0u;
                 bool used_hamming = false;
                 if (cfg.use_soft_clip && cfg.enable_hamming_base) {

@@ -74,6 +74,17 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         al.new_read_images();           // EXACT: a newly constructed reference aligner: both traceback arrays read as zero
         al.cur_read = i;
         uint64_t b = first_u64(a.offsets[i]), e = first_u64(a.offsets[i + 1]);
+        if (a.front_clip) {
+            b += (uint64_t)first_u32((uint32_t)a.front_clip[i]); e = b + (uint64_t)first_u32((uint32_t)a.data_len[i]);
+            if (a.skip && first_u32((uint32_t)a.skip[i]) != 0u) {         // not given to the aligner (SingleAligner.cpp:215-225): NotFound, no location, score -1
+                const int nd = (int)(sizeof(snapgpu_single_result) / 4);
+                if (lane < nd) { ((uint32_t *)&a.primary[i])[lane] = 0u; if (a.first_alt) ((uint32_t *)&a.first_alt[i])[lane] = 0u; }
+                WAVE_SYNC();                                              // (one wave's stores reach memory in issue order: the fields below land on the zeros)
+                if (lane == 0) { a.primary[i].status = SNAPGPU_NotFound; a.primary[i].location = SNAPGPU_InvalidGenomeLocation32; a.primary[i].score = -1; }
+                if (se_on && lane == 0) atomicAdd(&a.se_ctl[0], 1u);
+                continue;
+            }
+        }
         const uint64_t dbg_t0 = TIMED ? wave_clock() : 0; const uint64_t dbg_ag0 = al.cnt.ag;
         al.align_read(a.bases + b, a.quals + b, (int)(e - b));
         WAVE_SYNC();
@@ -155,7 +166,8 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
                             XW::fence_acquire();
                             const uint32_t r = XW::ld(slot->read);
                             if (r < a.n_reads) {
-                                const uint64_t rb = first_u64(a.offsets[r]), re = first_u64(a.offsets[r + 1]);
+                                uint64_t rb = first_u64(a.offsets[r]), re = first_u64(a.offsets[r + 1]);
+                                if (a.front_clip) { rb += (uint64_t)first_u32((uint32_t)a.front_clip[r]); re = rb + (uint64_t)first_u32((uint32_t)a.data_len[r]); }
                                 const int len = (int)(re - rb);
                                 if (len >= (int)a.ix.seed_len && len <= (int)a.cfg.RL) {
                                     al.read_len = len;

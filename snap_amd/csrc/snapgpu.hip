@@ -357,6 +357,7 @@ struct snapgpu_ctx {
     uint64_t kernel_launches = 0;
     int num_cus = 0;
     int ag_variant = 0;               // chunks of 64 striped positions the affine-gap kernel variant holds in registers (0 = LDS form)
+    const int32_t *clip_front = nullptr, *clip_len = nullptr; const uint8_t *clip_skip = nullptr;    // snapgpu_align_sam_single: Read::clip's outcome for the launch in hand (device)
     // secondary results (snapgpu_enable_secondary)
     bool secondary = false;
     SecCfg sec_cfg{};
@@ -1243,10 +1244,10 @@ struct DevBuf {
     void *p = nullptr;
     DevPool *from = nullptr;
     ~DevBuf() { if (p) { if (from) from->release(p); else (void)hipFree(p); } }
-    hipError_t put(const void *src, size_t bytes, hipStream_t s) {
+    hipError_t put(const void *src, size_t bytes, hipStream_t s, size_t slack = 0) {      // slack: bytes allocated beyond what is copied
         hipError_t e;
-        if (t_pool) { from = t_pool; p = from->acquire(bytes ? bytes : 16, &e); }
-        else e = hipMalloc(&p, bytes ? bytes : 16);
+        if (t_pool) { from = t_pool; p = from->acquire(bytes + slack ? bytes + slack : 16, &e); }
+        else e = hipMalloc(&p, bytes + slack ? bytes + slack : 16);
         if (e != hipSuccess) return e;
         if (src && bytes) return hipMemcpyAsync(p, src, bytes, hipMemcpyHostToDevice, s);
         return hipSuccess;
@@ -1611,6 +1612,99 @@ extern "C" int snapgpu_sam_fields_single_device(snapgpu_ctx *ctx, uint32_t n, ui
     return sam_side_kernel_time(ctx);
 }
 
+static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals, const void *d_offsets,
+                        void *d_primary, void *d_first_alt, hipStream_t s, void *d_secondary, uint32_t sec_out_stride, void *d_n_secondary);
+
+// The single-end path of a SAM writer in one call, device-resident in between: ONE upload of the batch (the unclipped reads, Read::clip's
+// outcome, which reads the aligner is given), BaseAligner::AlignRead over the clipped reads, the SAM fields of every read from the results
+// where the align kernel left them, one download of the fields.  What snapgpu_align_single followed by snapgpu_sam_fields_single does with
+// two uploads of the reads and a round trip of the results (profiles/r04zy: the feeders' time was those copies and calls).
+extern "C" int snapgpu_align_sam_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, const char *quals, const uint64_t *offsets,
+                                        const int32_t *front_clip, const int32_t *data_len, const uint8_t *skip, int use_m,
+                                        snapgpu_single_result *results, snapgpu_single_result *first_alt,
+                                        int32_t *flag, int32_t *contig, int64_t *pos, int32_t *mapq, uint32_t *ops, uint32_t ops_stride,
+                                        int32_t *n_ops, int32_t *nm, int32_t *reference_history_dependent)
+{
+    if (!ctx || (n && (!bases || !quals || !offsets || !front_clip || !data_len || !skip || !flag || !contig || !pos || !mapq || !ops || !n_ops || !nm ||
+                       !reference_history_dependent)))
+        return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_sam_single: null argument");
+    if (ops_stride < 3) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_sam_single: ops_stride must be at least 3");
+    if (ctx->secondary || ctx->paired) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_sam_single: a plain single-end context is needed (no snapgpu_enable_secondary / _paired)");
+    if (n == 0) return SNAPGPU_OK;
+    uint32_t RL = 64;
+    for (uint32_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > AGC_MAX_READ_LENGTH)
+            return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_sam_single: read length out of range");
+        const int64_t U = (int64_t)(offsets[i + 1] - offsets[i]);
+        if (front_clip[i] < 0 || data_len[i] < 0 || (int64_t)front_clip[i] + data_len[i] > U)
+            return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_sam_single: clipping outside the read");
+        if (!skip[i] && (uint32_t)data_len[i] > ctx->params.max_read_len)
+            return fail(ctx, SNAPGPU_E_INVALID, "read longer than max_read_len given at snapgpu_create (BaseAligner.cpp:354-358)");
+        if ((uint32_t)U > RL) RL = (uint32_t)U;
+    }
+    HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
+    hipStream_t s = ctx->stream;
+    const uint32_t per_wave = agc_lds_bytes(RL);
+    if ((size_t)4 * per_wave > 64 * 1024) return fail(ctx, SNAPGPU_E_UNSUPPORTED, "snapgpu_align_sam_single: reads too long for the LDS rows");
+    uint32_t blocks = (uint32_t)ctx->num_cus * samf_blocks_per_cu();
+    const uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
+    const uint64_t scratch_stride = ((2 * (uint64_t)RL + 255) & ~(uint64_t)255) + ((lvc_scratch_bytes() + 255) & ~255u) + ((agc_scratch_bytes(RL) + 255) & ~(uint64_t)255);
+    const uint64_t total = offsets[n];
+    PoolScope pool_scope(&ctx->pool);
+    DevBuf db, dq, doff, dfc, ddl, dsk, dres, dalt, dscr, dflag, dctg, dpos, dmq, dops, dno, dnm, dst;
+    HIPCHK(ctx, db.put(bases, total, s, 16), SNAPGPU_E_NOMEM);          // (16 bytes of slack behind the reads, as snapgpu_align_single's staging has)
+    HIPCHK(ctx, dq.put(quals, total, s, 16), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, doff.put(offsets, (size_t)(n + 1) * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dfc.put(front_clip, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, ddl.put(data_len, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dsk.put(skip, (size_t)n, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dres.put(nullptr, (size_t)n * sizeof(snapgpu_single_result), s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dalt.put(nullptr, (size_t)n * sizeof(snapgpu_single_result), s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dscr.put(nullptr, (size_t)blocks * 4 * scratch_stride, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dflag.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dctg.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dpos.put(nullptr, (size_t)n * 8, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dmq.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dops.put(nullptr, (size_t)n * ops_stride * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dno.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dnm.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, dst.put(nullptr, (size_t)n * 4, s), SNAPGPU_E_NOMEM);
+    HIPCHK(ctx, hipMemsetAsync(dops.p, 0, (size_t)n * ops_stride * 4, s), SNAPGPU_E_LAUNCH);
+    ctx->clip_front = (const int32_t *)dfc.p; ctx->clip_len = (const int32_t *)ddl.p; ctx->clip_skip = (const uint8_t *)dsk.p;
+    int rc = launch_align(ctx, n, db.p, dq.p, doff.p, dres.p, first_alt ? dalt.p : nullptr, s, nullptr, 0, nullptr);
+    ctx->clip_front = ctx->clip_len = nullptr; ctx->clip_skip = nullptr;
+    if (rc) return rc;
+    rc = finish_timing(ctx);                // (the align launch's own hipEvent time, before the events are reused)
+    if (rc) return rc;
+    SamFieldsArgs a;
+    a.ix = ctx->ix;
+    a.prm.match = (int)ctx->params.match_reward; a.prm.sub = -(int)ctx->params.sub_penalty;
+    a.prm.gap_open = (int)ctx->params.gap_open_penalty + (int)ctx->params.gap_extend_penalty; a.prm.gap_ext = (int)ctx->params.gap_extend_penalty;
+    a.n = n; a.RL = RL; a.ops_stride = ops_stride; a.use_m = use_m ? 1u : 0u; a.use_affine_gap = ctx->params.use_affine_gap ? 1u : 0u;
+    a.bases = (const uint8_t *)db.p; a.quals = (const uint8_t *)dq.p; a.offsets = (const uint64_t *)doff.p;
+    a.front_clip = (const int32_t *)dfc.p; a.data_len = (const int32_t *)ddl.p; a.results = (const snapgpu_single_result *)dres.p;
+    a.scratch = (uint8_t *)dscr.p; a.scratch_stride = scratch_stride; a.work_counter = ctx->d_work;
+    a.flag = (int32_t *)dflag.p; a.contig = (int32_t *)dctg.p; a.pos = (int64_t *)dpos.p; a.mapq = (int32_t *)dmq.p;
+    a.ops = (uint32_t *)dops.p; a.n_ops = (int32_t *)dno.p; a.nm = (int32_t *)dnm.p; a.stale = (int32_t *)dst.p;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    snapgpu_launch_sam_fields(&a, blocks, (size_t)4 * per_wave, s);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
+    if (results) HIPCHK(ctx, hipMemcpyAsync(results, dres.p, (size_t)n * sizeof(snapgpu_single_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    if (first_alt) HIPCHK(ctx, hipMemcpyAsync(first_alt, dalt.p, (size_t)n * sizeof(snapgpu_single_result), hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(flag, dflag.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(contig, dctg.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(pos, dpos.p, (size_t)n * 8, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(mapq, dmq.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ops, dops.p, (size_t)n * ops_stride * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(n_ops, dno.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(nm, dnm.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(reference_history_dependent, dst.p, (size_t)n * 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
+    HIPCHK(ctx, hipStreamSynchronize(s), SNAPGPU_E_LAUNCH);
+    return sam_side_kernel_time(ctx);
+}
+
 // paired-end writer: results -> the computed fields of both SAM records of each pair (sam_fields.h, cigar_k.hip)
 extern "C" int snapgpu_sam_fields_paired(snapgpu_ctx *ctx, uint32_t n_pairs, const char *bases, const char *quals, const uint64_t *offsets,
                                          const int32_t *front_clip, const int32_t *data_len, const snapgpu_paired_result *results, int use_m,
@@ -1842,6 +1936,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.flag_list = nullptr; a.flag_count = nullptr; a.remap = nullptr; a.n_remap = nullptr; a.persist = nullptr; a.persist_stride = 0;
     a.is_replay = 0; a.order = nullptr; a.dbg = nullptr; a.dbg_slots = 0;
     a.se_slots = nullptr; a.se_n_slots = 0; a.se_spec = nullptr; a.se_spec_cap = 0; a.se_ctl = nullptr; a.se_eager = 0; a.se_keep = 1;
+    a.front_clip = ctx->clip_front; a.data_len = ctx->clip_len; a.skip = ctx->clip_skip;
     // (SNAPGPU_SINGLE_RESOLVE=1: plain launches go to the instantiation that answers calls leaving their band in place; it runs alone --
     //  the helpers' records do not carry what the call lists need -- and what it could not answer is still flagged and replayed)
     const bool resolve_k = ctx->d_resolve != nullptr && !d_n_secondary && !ctx->phase_timers;
