@@ -54,29 +54,30 @@ def log(*a):
 
 
 def kernel_source_hash():
-    """sha256, first 16 hex digits, over the sources the TIMED kernels are compiled from: the include closure of the translation units that
-    define k_align_single / k_align_paired (snap_amd/csrc/single_*_k.hip, paired_k.hip: quoted includes, transitively) plus snapgpu.hip, the
-    host side that sizes and launches them.  What a committed PMC summary must carry for bench.py to replay its counters next to this
-    build's timings (scripts/pmc_collect.py writes it).  The SAM-side and index-builder sources (cigar_k.hip, cigar_ag.h, sam_fields.h,
-    index_build.*) are not part of those kernels and are not hashed: a change there leaves the align kernels' machine code as it was.
-    (Until the end of round 4 the hash covered every file of snap_amd/csrc; profiles/pmc_latest.json says which definition stamped it.)"""
+    """sha256, first 16 hex digits, over what the TIMED kernels are compiled from: the include closure (quoted includes, resolved relative to
+    the including file, so include/snapgpu.h is in it) of the translation units that define k_align_single / k_align_paired
+    (snap_amd/csrc/single_*_k.hip, paired_k.hip), snapgpu.hip -- the host side that sizes and launches them -- and the compile flags that are
+    not fixed in __graft_entry__.build_library (SNAPGPU_BUILD_FLAGS).  What a committed PMC summary must carry for bench.py to replay its
+    counters next to this build's timings (scripts/pmc_collect.py writes it).  The SAM-side and index-builder sources (cigar_k.hip,
+    cigar_ag.h, sam_fields.h, index_build.*) are not part of those kernels and are not hashed."""
     import hashlib
     import re
     d = os.path.join(ROOT, "snap_amd", "csrc")
-    seen, todo = set(), [f for f in sorted(os.listdir(d)) if re.match(r"(single_.*_k|paired_k)\.hip$", f)] + ["snapgpu.hip"]
-    roots = set(todo)
+    roots = [os.path.join(d, f) for f in sorted(os.listdir(d)) if re.match(r"(single_.*_k|paired_k)\.hip$", f)] + [os.path.join(d, "snapgpu.hip")]
+    seen, todo = set(), list(roots)
     while todo:
-        f = todo.pop()
-        if f in seen or not os.path.exists(os.path.join(d, f)):
+        f = os.path.normpath(todo.pop())
+        if f in seen or not os.path.exists(f):
             continue
         seen.add(f)
-        if f == "snapgpu.hip":
+        if os.path.basename(f) == "snapgpu.hip":
             continue                                    # (its own text is hashed; what it includes beyond the align kernels' closure is the SAM side)
-        for inc in re.findall(r'^\s*#\s*include\s+"([^"/]+)"', open(os.path.join(d, f), errors="replace").read(), re.M):
-            todo.append(inc)
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(f, errors="replace").read(), re.M):
+            todo.append(os.path.join(os.path.dirname(f), inc))
     h = hashlib.sha256()
     for f in sorted(seen):
-        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+        h.update(os.path.relpath(f, ROOT).encode()); h.update(open(f, "rb").read())
+    h.update(("flags:" + " ".join(os.environ.get("SNAPGPU_BUILD_FLAGS", "").split())).encode())
     return h.hexdigest()[:16]
 
 

@@ -64,6 +64,7 @@ struct HostPL {
     template <class T> static T spec_ld(const T &x) { return x; }
     static const bool SECONDARY = true;
     // (never called: the scalar definitions in paired.h are what the host runs)
+    static void lds(const void *) {}
     void hs_begin_walk(PELookup *, PEHitSetHdr *, int) {}
     template <class R> void hint_indels(R *, uint32_t, uint32_t, int) {}
     bool hs_first(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *, uint32_t) { return true; }

@@ -35,13 +35,15 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--groups", type=int, default=len(GROUPS), help="only the first N counter groups")
     ap.add_argument("--timeout", type=int, default=240)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per launch (bench.py --reads)")
+    ap.add_argument("--tag", default="", help="the entry's workload label when it is not --workload (bench.py's c5 leg: --tag c5 -- --read-len 250 --max-k 20 ...)")
     ap.add_argument("rest", nargs="*")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     from bench import kernel_source_hash
     env = dict(os.environ, TMPDIR="/tmp")
     bench = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(a.steps), "--warmup", "0", "--batches", "2", "--skip-cpu", "--skip-refwalk",
-             "--skip-breakdown", "--no-extra-legs", "--genome-mb", str(a.genome_mb), "--workload", a.workload] + (["--feeders", str(a.feeders)] if a.feeders else []) + a.rest
+             "--skip-breakdown", "--no-extra-legs", "--genome-mb", str(a.genome_mb), "--workload", a.workload, "--reads", str(a.reads)] + (["--feeders", str(a.feeders)] if a.feeders else []) + a.rest
     tot = collections.defaultdict(float)
     rows = collections.defaultdict(int)
     meta = {}
@@ -76,8 +78,8 @@ def main():
 
     def per_launch(key, c):
         return tot[(key, c)] / rows[(key, c)] if rows.get((key, c)) else None
-    n = 1_000_000
-    e = {"workload": a.workload, "genome_mb": a.genome_mb, "reads_per_launch": n, "feeders": a.feeders or 3, "kernel": dom[1], "kernel_resources": meta.get(dom),
+    n = a.reads
+    e = {"workload": a.tag or a.workload, "genome_mb": a.genome_mb, "reads_per_launch": n, "feeders": a.feeders or 3, "kernel": dom[1], "kernel_resources": meta.get(dom),
          "kernel_source_hash": kernel_source_hash(), "dispatches_per_pass": rows.get((dom, "FETCH_SIZE")),
          "source": "%s: scripts/pmc_collect.py, %d separate rocprofv3 --pmc passes (counters only) of `%s`; per dispatch of the dominant instantiation"
                    % (a.out, min(a.groups, len(GROUPS)), " ".join(os.path.basename(x) if x.endswith("bench.py") else x for x in bench[1:])),

@@ -368,6 +368,24 @@ public:
                     if (rc != SNAPGPU_W_SECONDARY_TRUNCATED) break;
                     for (unsigned i = 0; i < n; i++) if (nSec[i] > secStride) secStride = nSec[i];
                 }
+                // -ae with -om: the adjuster ran inside the call (snapgpu_secondary_params::adjust_alignments) on the primary and on every
+                // secondary result, with the same limitation as below: a quality-clipped read whose result reaches the end of its contig
+                // is refused, not answered differently
+                for (uint32_t i = 0; rc == SNAPGPU_OK && adjustPrimaries && i < n; i++) {
+                    Read *rd = &reads[i];
+                    if (rd->getDataLength() == rd->getUnclippedLength()) continue;
+                    const uint32_t ns = nSec[i] < secStride ? nSec[i] : secStride;
+                    for (uint32_t j = 0; j <= ns; j++) {
+                        const snapgpu_single_result &r = j == 0 ? prim[i] : sec[(size_t)i * secStride + (j - 1)];
+                        if (r.status == SNAPGPU_NotFound) continue;
+                        const Genome::Contig *ct = c->index->getGenome()->getContigAtLocation(GenomeLocation(r.location));
+                        if (ct != NULL && r.location + (int64_t)rd->getDataLength() + (int64_t)c->maxDist + 2 >
+                                          GenomeLocationAsInt64(ct->beginningLocation) + ct->length - c->index->getGenome()->getChromosomePadding()) {
+                            WriteErrorMessage("snapgpu shim: -ae: a quality-clipped read hangs over the end of its contig, which the adjuster does not reproduce (run with -C--)\n");
+                            soft_exit(1);
+                        }
+                    }
+                }
             } else {
                 rc = snapgpu_align_single(slot->ctx, n, &bases[0], &quals[0], &offs[0], &prim[0], &alt[0]);
                 if (rc == SNAPGPU_OK && adjustPrimaries) {

@@ -653,7 +653,16 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     }
 
     // stage genome[loc - WIN_PAD, loc + read_len + WIN_PAD) into LDS with coalesced loads
+    // (this pointer is LDS: said out loud for the kernels in which this object lives in memory -- the paired-end one, which passes its
+    //  address around -- and its pointers come back from there as generic ones: flat stores that wait for every load and store in flight)
+    template <class T> static __device__ __forceinline__ T *lds_ptr(T *p) {
+#ifndef SNAPGPU_WAVE_EMU
+        __builtin_assume(__builtin_amdgcn_is_shared((const void *)p));
+#endif
+        return p;
+    }
     __device__ __forceinline__ void stage_window(int64_t loc) {
+        uint8_t *const gw = lds_ptr(this->gw);
         const int total = read_len + 2 * WIN_PAD;
         const uint8_t *src = ix.genome + (loc - WIN_PAD);
         // 4 bytes per lane where the source is 4-byte aligned; byte loads at the ragged ends

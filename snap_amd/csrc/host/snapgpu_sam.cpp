@@ -606,6 +606,19 @@ static void gpu_single(const Options &o, FeederCtx &fc, Work &w)
                 uint32_t need = stride; for (uint32_t v : nsec) if (v > need) need = v;
                 stride = need;
             }
+            // -ae with -om: the adjuster ran inside the call (finalizeSecondaryResults, BaseAligner.cpp:2444-2463) on the primary AND on
+            // every secondary result, with the limitation described below for the primary: refuse the same reads here
+            for (size_t a = 0; o.ae && rc == SNAPGPU_OK && a < to_align.size(); a++) {
+                const size_t i = to_align[a];
+                if (front_clip[i] == 0 && (uint64_t)data_len[i] == b.offsets[i + 1] - b.offsets[i]) continue;      // the reader clipped nothing
+                for (uint32_t j = 0; j <= (nsec[a] < stride ? nsec[a] : stride); j++) {
+                    const snapgpu_single_result &r = j == 0 ? aligned_res[a] : sec[a * (size_t)stride + (j - 1)];
+                    if (r.status == SNAPGPU_NotFound) continue;
+                    const int c = h_contig_at(r.location);
+                    if (c >= 0 && r.location + data_len[i] + (long long)o.p.max_k + 2 > h_contig_end(c) - (long long)g_padding)
+                        die("-ae: a quality-clipped read hangs over the end of its contig, which the adjuster does not reproduce (run with -C--)");
+                }
+            }
         } else {
             rc = snapgpu_align_single(ctx, (uint32_t)to_align.size(), ab.data(), aq.data(), ao.data(), aligned_res.data(), alt_res.data());
             if (rc == SNAPGPU_OK && o.ae) {                 // finalizeSecondaryResults has only the primary to adjust (BaseAligner.cpp:2444-2452)

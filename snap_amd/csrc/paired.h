@@ -219,29 +219,41 @@ struct PairedCore {
     static PE_FN int set_dir(int set_pair, int which_read) { return (set_pair == 0) ? which_read : 1 - which_read; }   // setPairDirection
 
     // ------------------------------------------------------------------ HashTableHitSet
-    PE_FN PELookup *lks(int s) const { return lk + (size_t)s * cfg.max_seeds; }
-    PE_FN uint32_t *exh(int s) const { return exhausted + (size_t)s * cfg.max_seeds; }
+    // The hot per-pair arrays are LDS on the device, and every access to them must be an LDS instruction: the pointers live in this object
+    // (which sits in scratch memory: its address escapes), and a pointer loaded back from memory is a GENERIC one -- a flat_load / flat_store
+    // that waits for vmcnt(0) AND lgkmcnt(0), i.e. for every store to the candidate pools in HBM that is still on its way (profiles/r05b: the
+    // set intersection at 40 % of the kernel's wave cycles with windows or without).  PL::lds() tells the compiler what the pointer is
+    // (the device: llvm.assume(llvm.amdgcn.is.shared(p)), which address-space inference follows; the host: nothing).
+    template <class T> static PE_FN T *L(T *p) { PL::lds((const void *)p); return p; }
+    PE_FN PELookup *lks(int s) const { return L(lk) + (size_t)s * cfg.max_seeds; }
+    PE_FN uint32_t *exh(int s) const { return L(exhausted) + (size_t)s * cfg.max_seeds; }
+    PE_FN PEHitSetHdr *HS() const { return L(hs); }
+    PE_FN int32_t *LH() const { return L(list_head); }
+    PE_FN uint32_t *MISS() const { return L(miss); }
+    PE_FN uint32_t *SU() const { return L(seed_used); }
+    PE_FN uint32_t *MR() const { return L(mring); }
+    PE_FN PEShared *S() const { return L(sh); }
     PE_FN uint32_t hit(const PELookup *l, int64_t i) const {
         return ld(l->is_single) ? ld(l->singleton) : ld(l->hits[i]);
     }
 
-    PE_FN void hs_init(int s) { st(hs[s].n_used, 0); st(hs[s].cur_disjoint, -1); }                    // :3516-3527
+    PE_FN void hs_init(int s) { st(HS()[s].n_used, 0); st(HS()[s].cur_disjoint, -1); }                    // :3516-3527
 
     PE_FN void hs_record(int s, uint32_t seed_offset, const PEHits &h, bool begins) {                  // recordLookup, :3536-3579
-        int cd = ld(hs[s].cur_disjoint);
-        if (begins) { cd++; st(hs[s].cur_disjoint, cd); st(exh(s)[cd], 0); }
+        int cd = ld(HS()[s].cur_disjoint);
+        if (begins) { cd++; st(HS()[s].cur_disjoint, cd); st(exh(s)[cd], 0); }
         if (h.n_hits == 0) {
             st(exh(s)[cd], ld(exh(s)[cd]) + 1);
             return;
         }
-        uint32_t n = ld(hs[s].n_used);
+        uint32_t n = ld(HS()[s].n_used);
         PELookup *l = &lks(s)[n];
         st(l->hits, h.hits); st(l->singleton, h.singleton); st(l->is_single, h.n_hits == 1 ? 1u : 0u);
         st(l->seed_offset, seed_offset); st(l->cur, 0); st(l->which_disjoint, (uint32_t)cd);
         int64_t nh = h.n_hits;
         while (nh > 0 && hit(l, nh - 1) < seed_offset) nh--;      // hits before the start of the genome are meaningless (:3562)
         st(l->n_hits, nh);
-        st(hs[s].n_used, n + 1);
+        st(HS()[s].n_used, n + 1);
     }
 
     // returns true when the set is EMPTY (the reference returns !anyFound), :3720-3746
@@ -250,7 +262,7 @@ struct PairedCore {
     // best-possible-score computations, cycles_ag = mate / candidate records, cycles_single_fallback = Phase 2a; the counters' usual
     // meanings are switched off (PT2_OFF)
 #define PT2_T0() const uint64_t pt2_t0 = PL::clock()
-#define PT2_ADD(f) sh->cnt.f += PL::clock() - pt2_t0
+#define PT2_ADD(f) S()->cnt.f += PL::clock() - pt2_t0
 #define PT2_OFF(x) ((void)0)
 #else
 #define PT2_T0() ((void)0)
@@ -258,10 +270,10 @@ struct PairedCore {
 #define PT2_OFF(x) x
 #endif
     PE_FN bool hs_first(int s, int64_t *loc, uint32_t *seed_offset) {
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_first(lks(s), &hs[s], loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_first(lks(s), &HS()[s], loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
         bool any = false;
         *loc = 0;
-        const uint32_t n = ld(hs[s].n_used);
+        const uint32_t n = ld(HS()[s].n_used);
         for (uint32_t i = 0; i < n; i++) {
             const PELookup *l = &lks(s)[i];
             if (ld(l->n_hits) > 0) {
@@ -270,16 +282,16 @@ struct PairedCore {
                 if (v > *loc) { *loc = v; *seed_offset = so; any = true; }
             }
         }
-        if (any) st(hs[s].most_recent, *loc);
+        if (any) st(HS()[s].most_recent, *loc);
         return !any;
     }
 
     PE_FN bool hs_next_lower(int s, int64_t *loc, uint32_t *seed_offset) {                              // getNextLowerHit, :3750-3816
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_lower(lks(s), &hs[s], loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_lower(lks(s), &HS()[s], loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
         int64_t found = 0;
         bool any = false;
-        const uint32_t n = ld(hs[s].n_used);
-        const int64_t recent = ld(hs[s].most_recent);
+        const uint32_t n = ld(HS()[s].n_used);
+        const int64_t recent = ld(HS()[s].most_recent);
         for (uint32_t i = 0; i < n; i++) {
             PELookup *l = &lks(s)[i];
             int64_t cur = ld(l->cur);
@@ -299,15 +311,15 @@ struct PairedCore {
                 any = true;
             }
         }
-        if (any) st(hs[s].most_recent, found);
+        if (any) st(HS()[s].most_recent, found);
         return any;
     }
 
     PE_FN bool hs_next_le(int s, int64_t max_loc, int64_t *loc, uint32_t *seed_offset) {                // getNextHitLessThanOrEqualTo, :3628-3717
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_le(lks(s), &hs[s], max_loc, loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_le(lks(s), &HS()[s], max_loc, loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
         bool any = false;
         int64_t best = 0;
-        const uint32_t n = ld(hs[s].n_used);
+        const uint32_t n = ld(HS()[s].n_used);
         for (uint32_t i = 0; i < n; i++) {
             PELookup *l = &lks(s)[i];
             int64_t lo = ld(l->cur), hi = ld(l->n_hits) - 1;
@@ -331,26 +343,26 @@ struct PairedCore {
             }
             if (lo > hi) st(l->cur, ld(l->n_hits));
         }
-        if (any) st(hs[s].most_recent, best);
+        if (any) st(HS()[s].most_recent, best);
         return any;
     }
 
     PE_FN uint32_t hs_best_possible(int s) {                                                             // computeBestPossibleScoreForCurrentHit, :3585-3625
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const uint32_t r = pl.hs_best_possible(lks(s), &hs[s], exh(s), cfg.max_seeds); PT2_ADD(cyc_lv); return r; }
-        const int cd = ld(hs[s].cur_disjoint);
-        for (int i = 0; i <= cd; i++) st(miss[i], ld(exh(s)[i]));
-        const uint32_t n = ld(hs[s].n_used);
-        const int64_t recent = ld(hs[s].most_recent);
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const uint32_t r = pl.hs_best_possible(lks(s), &HS()[s], exh(s), cfg.max_seeds); PT2_ADD(cyc_lv); return r; }
+        const int cd = ld(HS()[s].cur_disjoint);
+        for (int i = 0; i <= cd; i++) st(MISS()[i], ld(exh(s)[i]));
+        const uint32_t n = ld(HS()[s].n_used);
+        const int64_t recent = ld(HS()[s].most_recent);
         for (uint32_t i = 0; i < n; i++) {
             const PELookup *l = &lks(s)[i];
             const int64_t cur = ld(l->cur), nh = ld(l->n_hits);
             const int64_t target = recent + ld(l->seed_offset);
             bool close = (cur != nh && within((int64_t)hit(l, cur), target, PE_MERGE_DIST)) ||
                          (cur != 0 && within((int64_t)hit(l, cur - 1), target, PE_MERGE_DIST));
-            if (!close) { uint32_t w = ld(l->which_disjoint); st(miss[w], ld(miss[w]) + 1); }
+            if (!close) { uint32_t w = ld(l->which_disjoint); st(MISS()[w], ld(MISS()[w]) + 1); }
         }
         uint32_t best = 0;
-        for (int i = 0; i <= cd; i++) { uint32_t m = ld(miss[i]); if (m > best) best = m; }
+        for (int i = 0; i <= cd; i++) { uint32_t m = ld(MISS()[i]); if (m > best) best = m; }
         return best;
     }
 
@@ -432,7 +444,7 @@ struct PairedCore {
     }
 
     PE_FN int score_limit(bool non_alt, int64_t big_indel) const {                                       // computeScoreLimit, :3975-3988
-        const PESet &a = sh->all, &n = sh->non_alt;
+        const PESet &a = S()->all, &n = S()->non_alt;
         int64_t inner;
         if (non_alt) {
             int64_t x = (int64_t)a.best_pair_score + cfg.max_gap_alt;
@@ -493,9 +505,9 @@ struct PairedCore {
         if (!pl.substring_ok(loc, glen)) { o.score = -1; o.mp = 0; o.ag_score = -1; return; }
         o.clip_before = 0; o.clip_after = 0;
         const uint8_t *data = pl.window(loc, rl);
-        const uint8_t *R = rd[which][dir], *Qd = ql[which][dir];
+        const uint8_t *R = L(rd[which][dir]), *Qd = L(ql[which][dir]);
         const int tail = seed_offset + sl;
-        sh->cnt.lv++;
+        S()->cnt.lv++;
         const uint64_t t_lv = PL::clock();
         LVOut a = pl.lv(+1, R + tail, Qd + tail, rl - tail, data + tail, (int)(glen - tail), limit);
         int score1 = a.score, score2 = 0, off = 0, ind2 = 0, span2 = 0;
@@ -508,8 +520,8 @@ struct PairedCore {
         } else {
             mp1 = 1.0;                               // (unused)
         }
-        PT2_OFF(sh->cnt.cyc_lv += PL::clock() - t_lv);
-        sh->cnt.lv_ref_bytes += (uint64_t)(rl - tail) + (uint64_t)(2 * (limit < 0 ? 0 : limit)) + (uint64_t)seed_offset;
+        PT2_OFF(S()->cnt.cyc_lv += PL::clock() - t_lv);
+        S()->cnt.lv_ref_bytes += (uint64_t)(rl - tail) + (uint64_t)(2 * (limit < 0 ? 0 : limit)) + (uint64_t)seed_offset;
         o.offset = off;
         if (off != 0 && !pl.substring_ok(loc + off, glen)) score2 = -1;                               // :3364-3375
         if (score1 != -1 && score2 != -1) {
@@ -531,7 +543,7 @@ struct PairedCore {
         if (!pl.substring_ok(loc, glen)) { o.score = -1; o.mp = 0; o.ag_score = -1; return; }
         o.clip_before = 0; o.clip_after = 0;
         const uint8_t *data = pl.window(loc, rl);
-        const uint8_t *R = rd[which][dir], *Qd = ql[which][dir];
+        const uint8_t *R = L(rd[which][dir]), *Qd = L(ql[which][dir]);
         const int tail = seed_offset + sl;
         int score1 = 0, score2 = 0, g1 = 0, g2 = 0, ag1 = sl, ag2 = 0, po = 0;
         double mp1 = 1.0, mp2 = 1.0;
@@ -586,7 +598,7 @@ struct PairedCore {
         if (!pl.substring_ok(loc, glen)) { *score = -1; *mp = 0; *ag_score = -1; return; }
         *clip_before = 0; *clip_after = 0;
         const uint8_t *data = pl.window(loc, rl);
-        const uint8_t *R = rd[which][dir], *Qd = ql[which][dir];
+        const uint8_t *R = L(rd[which][dir]), *Qd = L(ql[which][dir]);
         const int tail = seed_offset + sl;
         const int clip = cfg.use_soft_clip ? 1 : 0;
         int score1 = 0, score2 = 0, ag1 = sl, ag2 = 0;
@@ -602,7 +614,7 @@ struct PairedCore {
             AGOut a = pl.ag(banded, +1, R + tail, Qd + tail, plen, data + tail, (int)(glen - tail), limit, rl, dir != 0, clip);
             note_ag_call(0, (uint32_t)a.stale);
             ag1 = a.ag_score + (sl - rl); text_rem = a.text_offset; *clip_after = a.pattern_offset; score1 = a.n_edits; mp1 = a.mp;
-            if (spec_mode) spec_n_ag++; else sh->cnt.ag++;
+            if (spec_mode) spec_n_ag++; else S()->cnt.ag++;
         }
         if (score1 != -1) {
             if (seed_offset != 0) {
@@ -615,7 +627,7 @@ struct PairedCore {
                 if (score2 == -1) *offset = 0;
             }
         }
-        PT2_OFF(sh->cnt.cyc_ag += PL::clock() - t_ag);
+        PT2_OFF(S()->cnt.cyc_ag += PL::clock() - t_ag);
         if (score1 != -1 && score2 != -1) {
             *score = score1 + score2;
             *mp = mp1 * mp2 * pl.seed_prob();
@@ -692,15 +704,15 @@ struct PairedCore {
 
     PE_FN void mring_put(uint32_t i, int64_t loc, uint32_t bp) {
         if (mring == nullptr) return;
-        st(mring[2 * (i % PE_MRING)], (uint32_t)loc); st(mring[2 * (i % PE_MRING) + 1], bp);
+        st(MR()[2 * (i % PE_MRING)], (uint32_t)loc); st(MR()[2 * (i % PE_MRING) + 1], bp);
     }
-    PE_FN bool seed_is_used(int i) const { return (ld(seed_used[i >> 5]) >> (i & 31)) & 1u; }
-    PE_FN void seed_set_used(int i) { st(seed_used[i >> 5], ld(seed_used[i >> 5]) | (1u << (i & 31))); }
+    PE_FN bool seed_is_used(int i) const { return (ld(SU()[i >> 5]) >> (i & 31)) & 1u; }
+    PE_FN void seed_set_used(int i) { st(SU()[i >> 5], ld(SU()[i >> 5]) | (1u << (i & 31))); }
 
     // ------------------------------------------------------------------ Phases 1-3 (alignLandauVishkin / alignHamming)
     PE_FN void phases123(bool hamming) {
-        snapgpu_paired_result &res = sh->res, &alt = sh->alt;
-        PESet &all = sh->all, &non_alt = sh->non_alt;
+        snapgpu_paired_result &res = S()->res, &alt = S()->alt;
+        PESet &all = S()->all, &non_alt = S()->non_alt;
         alt.status[0] = alt.status[1] = SNAPGPU_NotFound;
         if (!hamming) { alt.ref_span[0] = alt.ref_span[1] = 0; res.ref_span[0] = res.ref_span[1] = 0; res.liftover[0] = res.liftover[1] = 0; }
         for (int r = 0; r < 2; r++) {
@@ -717,7 +729,7 @@ struct PairedCore {
         if (max_seeds > (int)cfg.max_seeds) max_seeds = (int)cfg.max_seeds;
 
         n_cand = 0; n_mate[0] = n_mate[1] = 0; n_anchor = 0;
-        for (int k = 0; k <= cfg.max_k + cfg.extra_depth; k++) st(list_head[k], -1);
+        for (int k = 0; k <= cfg.max_k + cfg.extra_depth; k++) st(LH()[k], -1);
         set_init(all); set_init(non_alt);
 
         if (read_len[0] < sl || read_len[1] < sl) return;                                                             // :343
@@ -726,7 +738,7 @@ struct PairedCore {
         for (int w = 0; w < 2; w++) {
             popular[w] = 0;
             for (int d = 0; d < 2; d++) hs_init(2 * w + d);
-            n_count += pl.count_n(rd[w][0], read_len[w]);
+            n_count += pl.count_n(L(rd[w][0]), read_len[w]);
         }
         if ((int)n_count > cfg.max_k) return;                                                                         // :385
 
@@ -738,7 +750,7 @@ struct PairedCore {
             uint32_t wrap = 0;
             const int n_possible = read_len[w] - sl + 1;
             const int mx = read_len[0] > read_len[1] ? read_len[0] : read_len[1];
-            for (int i = 0; i < (mx + 31) / 32; i++) st(seed_used[i], 0);
+            for (int i = 0; i < (mx + 31) / 32; i++) st(SU()[i], 0);
             bool begins[2] = {true, true};
             while (lookups < n_possible && lookups < max_seeds) {
                 if (next_seed >= n_possible) {
@@ -751,15 +763,15 @@ struct PairedCore {
                 if (next_seed >= n_possible) continue;
                 seed_set_used(next_seed);
                 PEHits h[2];
-                if (!pl.lookup(rd[w][0] + next_seed, h)) { next_seed++; continue; }                                // seed with an N, :454
-                sh->cnt.lookups++;
+                if (!pl.lookup(L(rd[w][0]) + next_seed, h)) { next_seed++; continue; }                                // seed with an N, :454
+                S()->cnt.lookups++;
                 lookups++;
                 for (int d = 0; d < 2; d++) {
                     const int offset = d == 0 ? next_seed : read_len[w] - sl - next_seed;
                     if (h[d].n_hits < (int64_t)cfg.max_big_hits) {
                         total_hits[w][d] += h[d].n_hits;
-                        sh->cnt.hits += (uint64_t)h[d].n_hits;                 // the hit lists this pair is entitled to read (roofline byte model)
-                        if (h[d].n_hits > 1) sh->cnt.overflow_lists++;
+                        S()->cnt.hits += (uint64_t)h[d].n_hits;                 // the hit lists this pair is entitled to read (roofline byte model)
+                        if (h[d].n_hits > 1) S()->cnt.overflow_lists++;
                         hs_record(2 * w + d, (uint32_t)offset, h[d], begins[d]);
                         begins[d] = false;
                     } else {
@@ -778,7 +790,7 @@ struct PairedCore {
 
         // ---- Phase 2: walk both set pairs from high to low locations, collect candidates (:527-741)
         const uint64_t t_p2 = PL::clock();
-        PT2_OFF(sh->cnt.cyc_lookup += t_p2 - t_p1);
+        PT2_OFF(S()->cnt.cyc_lookup += t_p2 - t_p1);
         int max_used_list = 0;
         uint32_t n_cand0 = 0;                       // candidates of set pair 0 (they come first in cand[])
         for (int sp = 0; sp < 2; sp++) {
@@ -789,7 +801,7 @@ struct PairedCore {
             bool out_of_more = false;
             int64_t last_mate_loc = 0;              // mate[sp][n_mate[sp] - 1].loc (the walk looks back at it in every step)
             if (sp == 1) n_cand0 = n_cand;
-            pl.hs_begin_walk(lks(s_fewer), &hs[s_fewer], 0); pl.hs_begin_walk(lks(s_more), &hs[s_more], 1);
+            pl.hs_begin_walk(lks(s_fewer), &HS()[s_fewer], 0); pl.hs_begin_walk(lks(s_more), &HS()[s_more], 1);
             if (hs_first(s_fewer, &loc_f, &so_f)) continue;
             for (;;) {
                 if (loc_m > loc_f + (int64_t)cfg.max_spacing) {
@@ -823,7 +835,7 @@ struct PairedCore {
                 int lowest_mate = cfg.max_k + cfg.extra_depth;
                 for (int i = (int)n_mate[sp] - 1; i >= 0; i--) {
                     int64_t ml; int b;
-                    if (mring != nullptr && (int)n_mate[sp] - 1 - i < PE_MRING) { ml = (int64_t)ld(mring[2 * (i % PE_MRING)]); b = (int)ld(mring[2 * (i % PE_MRING) + 1]); }
+                    if (mring != nullptr && (int)n_mate[sp] - 1 - i < PE_MRING) { ml = (int64_t)ld(MR()[2 * (i % PE_MRING)]); b = (int)ld(MR()[2 * (i % PE_MRING) + 1]); }
                     else { ml = ld(mate[sp][i].loc); b = ld(mate[sp][i].best_possible); }
                     if (ml > loc_f + (int64_t)cfg.max_spacing) break;
                     if (b < lowest_mate) lowest_mate = b;
@@ -832,14 +844,14 @@ struct PairedCore {
                     if (n_cand >= cfg.pool_size) { overflow = 1; return; }
                     const int list = lowest_mate + bp_f;
                     PECand *c = &cand[n_cand];
-                    const int32_t old_head = ld(list_head[list]);
+                    const int32_t old_head = ld(LH()[list]);
                     if (PL::lane0()) {                                                                             // ScoringCandidate::init
                         c->loc = loc_f; c->set_pair = (uint32_t)sp; c->mate_index = n_mate[sp] - 1; c->seed_offset = so_f;
                         c->best_possible = (uint32_t)bp_f; c->next = old_head; c->anchor = -1; c->used_gapless = 0; c->clip_before = 0;
                         c->clip_after = 0; c->ag_score = 0; c->lv_indels = 0; c->match_prob = 1.0; c->big_indel = 0; c->ref_span = 0;
                     }
                     PL::sync();
-                    st(list_head[list], (int32_t)n_cand);
+                    st(LH()[list], (int32_t)n_cand);
                     n_cand++;
                     if (list > max_used_list) max_used_list = list;
                 }
@@ -891,7 +903,7 @@ struct PairedCore {
 
         // ---- Phase 3: score candidates in order of their best possible score (:803-1190)
         PT2_ADD(cyc_single);
-        sh->cnt.cyc_intersect += PL::clock() - t_p2;
+        S()->cnt.cyc_intersect += PL::clock() - t_p2;
         int cur_list = 0;
         bool done = false;
         while (!done && cur_list <= max_used_list) {
@@ -903,7 +915,7 @@ struct PairedCore {
                 int lim = cfg.extra_depth + (cfg.max_k < z ? cfg.max_k : z);
                 if (cur_list > PL::i32(lim)) break;
             }
-            const int ci = ld(list_head[cur_list]);
+            const int ci = ld(LH()[cur_list]);
             if (ci < 0) { cur_list++; continue; }
             PECand *c = &cand[ci];
             const int64_t c_loc = ld(c->loc);
@@ -912,7 +924,7 @@ struct PairedCore {
             const uint32_t c_so = ld(c->seed_offset);
             const bool non_alt_aln = !cfg.alt_aware || !pl.is_alt(c_loc);
             int limit = score_limit(non_alt_aln, hamming ? 0 : c_big);
-            if (cur_list > limit) { st(list_head[cur_list], ld(c->next)); continue; }
+            if (cur_list > limit) { st(LH()[cur_list], ld(c->next)); continue; }
 
             LocScore f;
             f.reset(0, 0, 0, 0);
@@ -1055,7 +1067,7 @@ struct PairedCore {
                 }
             }
             if (done) break;
-            st(list_head[cur_list], ld(c->next));
+            st(LH()[cur_list], ld(c->next));
         }
 
         // ---- emit (:1192-1262)
@@ -1148,12 +1160,12 @@ struct PairedCore {
 
     // ------------------------------------------------------------------ Phase 4 (alignAffineGap, :2489-2970)
     PE_FN void phase4() {
-        snapgpu_paired_result &res = sh->res, &alt = sh->alt;
-        PESet &all = sh->all, &non_alt = sh->non_alt;
+        snapgpu_paired_result &res = S()->res, &alt = S()->alt;
+        PESet &all = S()->all, &non_alt = S()->non_alt;
         if (res.status[0] == SNAPGPU_NotFound || res.status[1] == SNAPGPU_NotFound) return;
         const int sl = cfg.seed_len;
         if (read_len[0] < sl || read_len[1] < sl) return;
-        uint32_t n_count = pl.count_n(rd[0][0], read_len[0]) + pl.count_n(rd[1][0], read_len[1]);
+        uint32_t n_count = pl.count_n(L(rd[0][0]), read_len[0]) + pl.count_n(L(rd[1][0]), read_len[1]);
         if ((int)n_count > cfg.max_k) return;
 
         const int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);
@@ -1342,7 +1354,7 @@ struct PairedCore {
         if (!pl.substring_ok(loc, glen)) { *score = -1; *mp = 0; *ag_score = -1; return; }
         *clip_before = 0; *clip_after = 0;
         const uint8_t *data = pl.window(loc, rl);
-        const uint8_t *R = rd[which][dir], *Qd = ql[which][dir];
+        const uint8_t *R = L(rd[which][dir]), *Qd = L(ql[which][dir]);
         const int clip = 2;                                    // useSoftClip (the caller's condition) + useAltLiftover
         int score1 = 0, score2 = 0;
         double mp2 = 1.0;
@@ -1373,7 +1385,7 @@ struct PairedCore {
 
     // the tail of alignAffineGap (:2866-2968): project an ALT alignment onto the primary assembly and rescore it there
     PE_FN void alt_liftover() {
-        snapgpu_paired_result &res = sh->res, &alt = sh->alt;
+        snapgpu_paired_result &res = S()->res, &alt = S()->alt;
         int best_alt = 0x7fffffff, best_res = 0x7fffffff, alt_proj_contig = -1, res_contig = -1;
         bool res_is_alt = false;
         if (alt.status[0] != SNAPGPU_NotFound && alt.status[1] != SNAPGPU_NotFound) {
@@ -1392,7 +1404,7 @@ struct PairedCore {
         bool found[2] = {true, true};
         int new_dir[2], new_so[2], new_mapq[2];
         int64_t new_loc[2];
-        sh->saved = res;
+        S()->saved = res;
         const snapgpu_paired_result &src = res_is_alt ? res : alt;
         const int cc = contig_num(src.location[0]);
         const int proj_dir = (cc >= 0 && ld(cfg.proj.proj_rc[cc])) ? 1 : 0;                                   // isProjContigRC
@@ -1415,7 +1427,7 @@ struct PairedCore {
             res.ag_score[r] = ag; res.ref_span[r] = span;
             if (sc != -1 && sc <= PE_MAXK1) res.location[r] += off; else res.status[r] = SNAPGPU_NotFound;
         }
-        if (res.status[0] == SNAPGPU_NotFound || res.status[1] == SNAPGPU_NotFound) res = sh->saved;          // no liftover alignment: keep the ALT one
+        if (res.status[0] == SNAPGPU_NotFound || res.status[1] == SNAPGPU_NotFound) res = S()->saved;          // no liftover alignment: keep the ALT one
     }
 
     // body of the candidate loop of alignAffineGap (:2736-2823)
@@ -1474,8 +1486,8 @@ struct PairedCore {
 
     PE_FN void phase4_candidate(snapgpu_paired_result *e, int &limit, int best_pair_score, const bool skip[2], int g_off[2],
                                 const PEHelpSpec *sp = nullptr) {
-        snapgpu_paired_result &res = sh->res;
-        PESet &A = sh->all, &N = sh->non_alt;
+        snapgpu_paired_result &res = S()->res;
+        PESet &A = S()->all, &N = S()->non_alt;
         int s0 = ld(e->score[0]), s1 = ld(e->score[1]);
         const int lv_pair_score = s0 + s1;
         const int lv_pair_indels = ld(e->lv_indels[0]) + ld(e->lv_indels[1]);
@@ -1496,7 +1508,7 @@ struct PairedCore {
             if (sp != nullptr && PL::spec_ld(sp->lim[0]) == PL::i32(limit)) {      // scored ahead of time with exactly these arguments
                 s0 = PL::spec_ld(sp->score[0]); mp0 = PL::spec_ld(sp->mp[0]); g_off[0] = PL::spec_ld(sp->g_off[0]); cb = PL::spec_ld(sp->cb[0]);
                 ca = PL::spec_ld(sp->ca[0]); ag0 = PL::spec_ld(sp->ag[0]); span = PL::spec_ld(sp->span[0]); take_spec_calls(sp, 0);
-                sh->cnt.ag += PL::spec_ld(sp->n_ag[0]); spec_used++;
+                S()->cnt.ag += PL::spec_ld(sp->n_ag[0]); spec_used++;
             } else {
                 score_ag(0, ld(e->direction[0]), ld(e->orig_location[0]), ld(e->seed_offset[0]), PL::i32(limit), &s0, &mp0, &g_off[0], &cb, &ca, &ag0, &span);
             }
@@ -1515,7 +1527,7 @@ struct PairedCore {
                 if (sp != nullptr && PL::spec_ld(sp->lim[1]) == PL::i32(limit)) {
                     s1 = PL::spec_ld(sp->score[1]); mp1 = PL::spec_ld(sp->mp[1]); g_off[1] = PL::spec_ld(sp->g_off[1]); cb = PL::spec_ld(sp->cb[1]);
                     ca = PL::spec_ld(sp->ca[1]); ag1 = PL::spec_ld(sp->ag[1]); span = PL::spec_ld(sp->span[1]); take_spec_calls(sp, 1);
-                    sh->cnt.ag += PL::spec_ld(sp->n_ag[1]); spec_used++;
+                    S()->cnt.ag += PL::spec_ld(sp->n_ag[1]); spec_used++;
                 } else {
                     score_ag(1, ld(e->direction[1]), ld(e->orig_location[1]), ld(e->seed_offset[1]), PL::i32(limit), &s1, &mp1, &g_off[1], &cb, &ca, &ag1, &span);
                 }
@@ -1543,7 +1555,7 @@ struct PairedCore {
         phases123(false);
         if (overflow) return;
         if (!cfg.use_ag) return;
-        if (cfg.use_soft_clip && (sh->res.status[0] == SNAPGPU_NotFound || sh->res.status[1] == SNAPGPU_NotFound)) {
+        if (cfg.use_soft_clip && (S()->res.status[0] == SNAPGPU_NotFound || S()->res.status[1] == SNAPGPU_NotFound)) {
             phases123(true);
             if (overflow) return;
         }
@@ -1551,7 +1563,7 @@ struct PairedCore {
     }
 
     // ------------------------------------------------------------------ ChimericPairedEndAligner::align (ChimericPairedEndAligner.cpp:126-448)
-    // max_k_paired = maxKPairedEnd, max_k_single = maxKSingleEnd = maxK / 2 (:81).  Results in sh->res / sh->alt.
+    // max_k_paired = maxKPairedEnd, max_k_single = maxKSingleEnd = maxK / 2 (:81).  Results in S()->res / S()->alt.
     PE_FN void read_not_aligned(snapgpu_paired_result &res, snapgpu_paired_result &alt, int r, bool touch_pair_flag) {      // :281-296 / :392-406
         res.status[r] = SNAPGPU_NotFound; res.mapq[r] = 0; res.direction[r] = 0; res.location[r] = SNAPGPU_InvalidGenomeLocation32;
         res.score[r] = 0; res.used_affine_gap_scoring[r] = 0; res.bases_clipped_before[r] = 0; res.bases_clipped_after[r] = 0;
@@ -1565,12 +1577,12 @@ struct PairedCore {
         n_sec = 0; n_ssec[0] = n_ssec[1] = 0; ref_dep = 0;                                                              // :151-153
         const uint64_t t_all = PL::clock();
         align_pair_inner(max_k_paired, max_k_single);
-        sh->cnt.cyc_total += PL::clock() - t_all;
-        sh->res.reserved = stale;                           // not in the reference: see snapgpu_paired_result.reserved
+        S()->cnt.cyc_total += PL::clock() - t_all;
+        S()->res.reserved = stale;                           // not in the reference: see snapgpu_paired_result.reserved
     }
 
     PE_FN void align_pair_inner(int max_k_paired, int max_k_single) {
-        snapgpu_paired_result &res = sh->res, &alt = sh->alt;
+        snapgpu_paired_result &res = S()->res, &alt = S()->alt;
         res.status[0] = res.status[1] = SNAPGPU_NotFound;
         for (int r = 0; r < 2; r++) {
             res.used_affine_gap_scoring[r] = 0; res.bases_clipped_before[r] = 0; res.bases_clipped_after[r] = 0;
@@ -1617,7 +1629,7 @@ struct PairedCore {
             if (res.status[0] != SNAPGPU_NotFound && res.status[1] != SNAPGPU_NotFound) res.ag_forced_single_aligner_call = 1;
         }
 
-        snapgpu_single_result *single = sh->single, *single_alt = sh->single_alt;
+        snapgpu_single_result *single = S()->single, *single_alt = S()->single_alt;
         for (int r = 0; r < 2; r++) { single[r].status = SNAPGPU_NotFound; single[r].mapq = 0; single[r].score = 0; single[r].ag_score = 0; }
         int single_ag = 0;
         bool choose_single_mapq = true;
@@ -1640,7 +1652,7 @@ struct PairedCore {
                 if (want_sec() && ssec_out != nullptr && sec_base < ssec_stride) { sec_dst = ssec_out + sec_base; sec_room = ssec_stride - sec_base; }
                 const uint32_t room32 = sec_base < 32u ? 32u - sec_base : 0u;       // what PairedAligner.cpp:566's initial buffer would have left
                 uint32_t n_this = pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
-                PT2_OFF(sh->cnt.cyc_single += PL::clock() - t_s);
+                PT2_OFF(S()->cnt.cyc_single += PL::clock() - t_s);
                 stale += single[r].reserved & 0x3fffffffu; stale_later += (single[r].reserved & 0x40000000u) ? 1u : 0u;
                 bool used_hamming = false;
                 if (cfg.use_soft_clip && cfg.enable_hamming_base) {

@@ -202,6 +202,14 @@ struct DevPL {
         if (lane_id() == 0) x = v;
         WAVE_SYNC();
     }
+    // this pointer points into LDS (paired.h: PairedCore::L)
+    static __device__ __forceinline__ void lds(const void *p) {
+#ifndef SNAPGPU_WAVE_EMU
+        __builtin_assume(__builtin_amdgcn_is_shared(p));
+#else
+        (void)p;
+#endif
+    }
     static __device__ __forceinline__ int i32(int v) { return (int)first_u32((uint32_t)v); }
     static __device__ __forceinline__ double f64(double v) { return first_f64(v); }
     static __device__ __forceinline__ bool lane0() { return lane_id() == 0; }
@@ -227,7 +235,8 @@ struct DevPL {
     // probes the table directly.  Locations are 32-bit on the device (snapgpu.hip refuses larger genomes), so the arithmetic is too.
     uint32_t hs_w;                     // HS_W: 16 where 2 x max_seeds x 16 words fit the Landau-Vishkin block, else 8
     __device__ __forceinline__ uint32_t *hs_win(const PEHitSetHdr *h, uint32_t max_seeds) const {
-        return (uint32_t *)al->lv_tri + 2 * PE_MRING + (size_t)ld(h->win_role) * max_seeds * hs_w + (size_t)lane_id() * hs_w;      // (lanes >= max_seeds never use theirs)
+        uint32_t *blk = (uint32_t *)al->lv_tri; lds(blk);
+        return blk + 2 * PE_MRING + (size_t)ld(h->win_role) * max_seeds * hs_w + (size_t)lane_id() * hs_w;      // (lanes >= max_seeds never use theirs)
     }
     __device__ __forceinline__ void hs_begin_walk(PELookup *lk, PEHitSetHdr *h, int role) {
         const int lane = lane_id();
@@ -447,7 +456,8 @@ struct DevPL {
     __device__ __forceinline__ const uint8_t *window(int64_t loc, int read_len) {
         al->read_len = read_len;
         al->stage_window(loc);
-        return al->gw + WIN_PAD;
+        uint8_t *g = al->gw; lds(g);
+        return g + WIN_PAD;
     }
     __device__ __forceinline__ bool is_alt(int64_t loc) const { return al->is_alt(loc); }
     __device__ __forceinline__ bool substring_ok(int64_t loc, int64_t len) const { return al->substring_ok(loc, len); }
@@ -657,7 +667,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
         core.sec_ord = (uint32_t *)(sc + a.off_sec_ord);
         core.sec_key = (uint32_t *)(sc + a.off_sec_key);
     }
-    core.sh->cnt = PECounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    core.S()->cnt = PECounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint8_t *prd = my + PLd.rd, *pql = my + PLd.ql;
     const uint32_t RL = a.scfg.RL;
     uint64_t n_done = 0;
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
         al.ag_calls_unit = 0;
         al.ag_obj_used0 = al.ag_obj_used1 = 0;          // the chimeric fallback's single-end aligner is one object for the whole pair
         {   // zero both results (fields the reference leaves unset read as 0 here)
-            uint32_t *z0 = (uint32_t *)&core.sh->res, *z1 = (uint32_t *)&core.sh->alt;
+            uint32_t *z0 = (uint32_t *)&core.S()->res, *z1 = (uint32_t *)&core.S()->alt;
             const int nd = (int)(sizeof(snapgpu_paired_result) / 4);
             if (lane < nd) { z0[lane] = 0; z1[lane] = 0; }
         }
@@ -752,7 +762,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
             core.ssec_stride = a.ssec_out_stride;
         }
         core.align_pair(a.max_k_paired, a.max_k_single);
-        core.sh->res.flags = (core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0) | (core.ref_dep ? SNAPGPU_PAIR_REF_BUFFER_DEPENDENT : 0) |
+        core.S()->res.flags = (core.overflow ? SNAPGPU_PAIR_POOL_OVERFLOW : 0) | (core.ref_dep ? SNAPGPU_PAIR_REF_BUFFER_DEPENDENT : 0) |
                              ((EXACT || core.stale_later || (a.dbg_flag_every != 0u && i % a.dbg_flag_every == 0u)) ? SNAPGPU_PAIR_EXACT_REPLAY : 0) |
                              ((EXACT && a.rq_mode == 2u) ? SNAPGPU_PAIR_REPLAYED_BESIDE : 0);
         WAVE_SYNC();
@@ -773,7 +783,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
             WAVE_SYNC();
         }
         {
-            const uint32_t *src = (const uint32_t *)&core.sh->res, *src2 = (const uint32_t *)&core.sh->alt;
+            const uint32_t *src = (const uint32_t *)&core.S()->res, *src2 = (const uint32_t *)&core.S()->alt;
             uint32_t *dst = (uint32_t *)&a.primary[i];
             const int nd = (int)(sizeof(snapgpu_paired_result) / 4);
             if (lane < nd) dst[lane] = src[lane];
@@ -785,7 +795,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
             // a flagged pair goes to the exact kernel that runs beside this one: the pair's results first (the exact kernel writes the
             // same records), then the index, then the count of finished pairs (the exact kernel leaves when that count is complete
             // and the list is empty, so the index must be there before the pair is counted)
-            const uint32_t fl = first_u32(core.sh->res.flags);
+            const uint32_t fl = first_u32(core.S()->res.flags);
             if ((fl & SNAPGPU_PAIR_EXACT_REPLAY) != 0u && (fl & SNAPGPU_PAIR_POOL_OVERFLOW) == 0u) {
                 XP::stores_done();
                 XP::fence_release();
@@ -853,19 +863,19 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
         if (!a.is_replay) atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
         atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
         atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
-        atomicAdd(&a.counters[3], (unsigned long long)(al.cnt.hits + core.sh->cnt.hits));
-        atomicAdd(&a.counters[4], (unsigned long long)(al.cnt.overflow_lists + core.sh->cnt.overflow_lists));
-        atomicAdd(&a.counters[5], (unsigned long long)(al.cnt.lv + core.sh->cnt.lv));
-        atomicAdd(&a.counters[6], (unsigned long long)(al.cnt.ag + core.sh->cnt.ag));
-        atomicAdd(&a.counters[7], (unsigned long long)(al.cnt.lv_ref_bytes + core.sh->cnt.lv_ref_bytes));
+        atomicAdd(&a.counters[3], (unsigned long long)(al.cnt.hits + core.S()->cnt.hits));
+        atomicAdd(&a.counters[4], (unsigned long long)(al.cnt.overflow_lists + core.S()->cnt.overflow_lists));
+        atomicAdd(&a.counters[5], (unsigned long long)(al.cnt.lv + core.S()->cnt.lv));
+        atomicAdd(&a.counters[6], (unsigned long long)(al.cnt.ag + core.S()->cnt.ag));
+        atomicAdd(&a.counters[7], (unsigned long long)(al.cnt.lv_ref_bytes + core.S()->cnt.lv_ref_bytes));
         // phase cycles of the paired path: lookup = Phase 1, hits = Phase 2 (intersection), lv / ag = paired scoring only,
         // reserved[0] = the single-end fallback as a whole
-        atomicAdd(&a.counters[8], (unsigned long long)core.sh->cnt.cyc_lookup);
-        atomicAdd(&a.counters[9], (unsigned long long)core.sh->cnt.cyc_intersect);
-        atomicAdd(&a.counters[10], (unsigned long long)core.sh->cnt.cyc_lv);
-        atomicAdd(&a.counters[11], (unsigned long long)core.sh->cnt.cyc_ag);
-        atomicAdd(&a.counters[12], (unsigned long long)core.sh->cnt.cyc_total);
-        atomicAdd(&a.counters[13], (unsigned long long)core.sh->cnt.cyc_single);
+        atomicAdd(&a.counters[8], (unsigned long long)core.S()->cnt.cyc_lookup);
+        atomicAdd(&a.counters[9], (unsigned long long)core.S()->cnt.cyc_intersect);
+        atomicAdd(&a.counters[10], (unsigned long long)core.S()->cnt.cyc_lv);
+        atomicAdd(&a.counters[11], (unsigned long long)core.S()->cnt.cyc_ag);
+        atomicAdd(&a.counters[12], (unsigned long long)core.S()->cnt.cyc_total);
+        atomicAdd(&a.counters[13], (unsigned long long)core.S()->cnt.cyc_single);
     }
 }
 

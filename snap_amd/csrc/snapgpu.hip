@@ -318,9 +318,21 @@ struct DevPool {
         slots.push_back(Slot{p, cap, true});
         return p;
     }
+    // (a buffer comes back with whatever its last user left in it: DevBuf memory is UNINITIALISED, every kernel clears what it needs)
+    // Idle buffers are kept for the next call of a similar size, but not without bound: batches of varying size (a last short one, a retry
+    // with a larger cigar stride, one-read calls of the host record loop) would otherwise leave gigabytes of per-wave scratch pinned next to
+    // the index.  More than MAX_IDLE idle buffers, or more than MAX_IDLE_BYTES of them: the largest idle ones go.
+    static const size_t MAX_IDLE = 24, MAX_IDLE_BYTES = (size_t)6 << 30;
     void release(void *p) {
         std::lock_guard<std::mutex> l(m);
-        for (auto &s : slots) if (s.p == p) { s.busy = false; return; }
+        for (auto &s : slots) if (s.p == p) { s.busy = false; break; }
+        for (;;) {
+            size_t n_idle = 0, bytes = 0; int big = -1;
+            for (size_t i = 0; i < slots.size(); i++) if (!slots[i].busy && slots[i].p) { n_idle++; bytes += slots[i].cap; if (big < 0 || slots[i].cap > slots[(size_t)big].cap) big = (int)i; }
+            if (big < 0 || (n_idle <= MAX_IDLE && bytes <= MAX_IDLE_BYTES)) break;
+            (void)hipFree(slots[(size_t)big].p);
+            slots.erase(slots.begin() + big);
+        }
     }
     void free_all() {
         std::lock_guard<std::mutex> l(m);
@@ -356,6 +368,7 @@ struct snapgpu_ctx {
     double kernel_ms = 0.0;
     uint64_t kernel_launches = 0;
     int num_cus = 0;
+    int lookup_blocks_per_cu = 0;     // resident blocks per CU of k_lookup_seeds20 on this context's device (launch_lookup)
     int ag_variant = 0;               // chunks of 64 striped positions the affine-gap kernel variant holds in registers (0 = LDS form)
     const int32_t *clip_front = nullptr, *clip_len = nullptr; const uint8_t *clip_skip = nullptr;    // snapgpu_align_sam_single: Read::clip's outcome for the launch in hand (device)
     // secondary results (snapgpu_enable_secondary)
@@ -1170,14 +1183,14 @@ static void launch_lookup(snapgpu_ctx *ctx, uint32_t n, const void *d_seeds, voi
     if (ctx->ix.bucket_blob && ctx->ix.seed_len == 20 && ctx->ix.key_bytes == 4 && ((uintptr_t)d_seeds & 3) == 0 && !getenv("SNAPGPU_LOOKUP8")) {
         uint32_t blocks = (n + 31) / 32; if (blocks > maxb) blocks = maxb;
         // as many blocks as are resident at once (see the kernel): every wave then does an equal share of the passes from the start
-        static int resident_per_cu = 0;
-        if (resident_per_cu == 0) {
+        // (per context: contexts live on different devices and are driven by different threads)
+        if (ctx->lookup_blocks_per_cu == 0) {
             int nb = 0;
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lookup_seeds20, 256, 0) != hipSuccess || nb <= 0) nb = 4;
             if (const char *e = getenv("SNAPGPU_LOOKUP_BLOCKS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 8) nb = v; }
-            resident_per_cu = nb > 8 ? 8 : nb;
+            ctx->lookup_blocks_per_cu = nb > 8 ? 8 : nb;
         }
-        const uint32_t fit = (uint32_t)ctx->num_cus * (uint32_t)resident_per_cu;
+        const uint32_t fit = (uint32_t)ctx->num_cus * (uint32_t)ctx->lookup_blocks_per_cu;
         if (blocks > fit) blocks = fit;
         hipLaunchKernelGGL(k_lookup_seeds20, dim3(blocks), dim3(256), 0, s, ctx->ix, n, (const uint8_t *)d_seeds, (long long *)d_n_hits,
                            (uint32_t *)d_hits, max_hits_out, d_counters);
@@ -1978,6 +1991,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
         a.order = ctx->d_order;
     }
     if (d_n_secondary) {
+        if (!ctx->d_sec_scratch) HIPCHK(ctx, hipMalloc((void **)&ctx->d_sec_scratch, ctx->sec_stride_bytes * ctx->n_wave_slots), SNAPGPU_E_NOMEM);
         a.sec_cfg = ctx->sec_cfg; a.sec_scratch = ctx->d_sec_scratch; a.sec_stride_bytes = ctx->sec_stride_bytes;
         a.secondary = (snapgpu_single_result *)d_secondary; a.sec_out_stride = sec_out_stride; a.n_secondary = (uint32_t *)d_n_secondary;
     }
@@ -2107,7 +2121,9 @@ extern "C" int snapgpu_enable_secondary(snapgpu_ctx *ctx, const snapgpu_secondar
     if (sp->adjust_alignments) stride += (adjust_scratch_bytes(ctx->cfg.RL) + 255) & ~(uint64_t)255;     // adjust.h: the adjuster's Landau-Vishkin table, op list, staged read and window
     if (ctx->d_sec_scratch) { (void)hipFree(ctx->d_sec_scratch); ctx->d_sec_scratch = nullptr; }
     ctx->secondary = false;
-    HIPCHK(ctx, hipMalloc((void **)&ctx->d_sec_scratch, stride * ctx->n_wave_slots), SNAPGPU_E_NOMEM);
+    // (the per-wave lists of the SINGLE-END launches: ~1.5 MB x 6 144 wave slots at the defaults.  A context that has the paired-end path
+    //  enabled keeps its single-end aligner's lists in the paired slab and gets these on its first single-end launch with secondary results.)
+    if (!ctx->paired) HIPCHK(ctx, hipMalloc((void **)&ctx->d_sec_scratch, stride * ctx->n_wave_slots), SNAPGPU_E_NOMEM);
     ctx->sec_cfg = SecCfg{sp->max_edit_distance, sp->max_per_contig, sp->max_results, (uint32_t)cap, sp->adjust_alignments ? 1u : 0u, adj_off};
     ctx->sec_stride_bytes = stride;
     ctx->secondary = true;

@@ -200,12 +200,16 @@ def test_kernel_source_hash_covers_the_timed_kernels_sources_only(tmp_path, monk
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     fake = tmp_path / "repo"
     shutil.copytree(os.path.join(root, "snap_amd", "csrc"), fake / "snap_amd" / "csrc", ignore=shutil.ignore_patterns("host"))
+    shutil.copytree(os.path.join(root, "include"), fake / "include")
+    monkeypatch.delenv("SNAPGPU_BUILD_FLAGS", raising=False)
     monkeypatch.setattr(bench, "ROOT", str(fake))
     h0 = bench.kernel_source_hash()
     assert h0 == hashlib_of_repo(root, bench)
 
     def touched(name):
         p = fake / "snap_amd" / "csrc" / name
+        if name.startswith("include/"):
+            p = fake / name
         old = p.read_bytes()
         p.write_bytes(old + b"\n// x\n")
         h = bench.kernel_source_hash()
@@ -215,6 +219,9 @@ def test_kernel_source_hash_covers_the_timed_kernels_sources_only(tmp_path, monk
         assert touched(name) != h0, name
     for name in ("cigar_ag.h", "sam_fields.h", "cigar_k.hip", "index_build.h", "index_build.hip"):
         assert touched(name) == h0, name
+    assert touched("include/snapgpu.h") != h0                 # (the ABI structs and constants the kernels are compiled against)
+    monkeypatch.setenv("SNAPGPU_BUILD_FLAGS", "-DSNAPGPU_WAVES_PER_SIMD(AGC)=5")
+    assert bench.kernel_source_hash() != h0                   # another build of the same sources is another build
 
 
 def hashlib_of_repo(root, bench):
