@@ -84,22 +84,42 @@ def kernel_source_hash():
 def ensure_index(args, rank, device=0, multi=False):
     """Genome + SNAP index directory under /tmp, built once per box.  The directory is in the reference's on-disk format either way:
     --indexer gpu (default) builds it with this repo's GPU index builder (include/snapgpu.h: snapgpu_index_build_from_fasta; parity with
-    the reference's builder: tests/test_zx_gpu_index_build.py) and ALSO returns the index still resident in HBM, so a one-GPU run aligns
+    the reference's builder: tests/test_zx_gpu_index_build.py) and ALSO returns the index still resident in HBM, so that the run aligns
     over it without reading the files back; --indexer reference runs the reference's own `snap-aligner index`,
-    ~90 s at 256 Mb and ~20 minutes at GRCh38 scale.  The reference (cpu_baseline / parity_check) loads the same directory."""
+    ~90 s at 256 Mb and ~20 minutes at GRCh38 scale.  The reference (cpu_baseline / parity_check) loads the same directory.
+    N > 1 (`multi`): rank 0 draws the genome ONCE and leaves it in a file the other ranks map (they need it to draw their own reads),
+    builds the index in its HBM and keeps it there for the RCCL broadcast -- no 31 GB directory is written or read back on that path
+    (only a one-GPU run has a CPU baseline that needs one)."""
     from snap_amd import synth
     tag = "g%d_s%d_seed%d_%s" % (args.genome_mb, args.seed_len, args.seed, args.indexer)
     work = os.path.join(args.workdir, tag)
     done = os.path.join(work, "idx", "GenomeIndex")
+    job = os.environ.get("MASTER_PORT", "0") + "_" + os.environ.get("TORCHELASTIC_RUN_ID", "x")
+    ready = os.path.join(work, "ready_%s" % job)             # rank 0 -> the others: genome file written, index built
+    gfile = os.path.join(work, "genome_%s" % job)
     t0 = time.time()
-    genome = synth.make_genome(args.seed, args.genome_mb * 1_000_000, n_contigs=max(1, min(24, args.genome_mb // 8)),
-                               repeat_frac=0.30, max_copies=5000, repeat_len=(200, 3000), max_divergence=0.05)
-    log("genome %d Mb generated in %.1fs" % (args.genome_mb, time.time() - t0))
+    if rank == 0 or not multi:
+        genome = synth.make_genome(args.seed, args.genome_mb * 1_000_000, n_contigs=max(1, min(24, args.genome_mb // 8)),
+                                   repeat_frac=0.30, max_copies=5000, repeat_len=(200, 3000), max_divergence=0.05)
+        log("genome %d Mb generated in %.1fs" % (args.genome_mb, time.time() - t0))
+        if multi:
+            os.makedirs(work, exist_ok=True)
+            np.concatenate([g for _, g in genome]).tofile(gfile + ".u8")
+            json.dump([[nm, int(len(g))] for nm, g in genome], open(gfile + ".json", "w"))
+    else:
+        while not os.path.exists(ready):
+            time.sleep(0.5)
+        meta = json.load(open(gfile + ".json"))
+        flat = np.memmap(gfile + ".u8", dtype=np.uint8, mode="r")
+        genome, at = [], 0
+        for nm, ln in meta:
+            genome.append((nm, flat[at:at + ln])); at += ln
+        log("rank %d: genome mapped from rank 0's file in %.1fs" % (rank, time.time() - t0))
     built, info = None, {"indexer": args.indexer, "cached": os.path.exists(done)}
-    # A one-GPU run whose directory is already there (an earlier run on this box) still BUILDS the index in HBM -- 9 s at 3.1 Gb against
-    # reading 31 GB of files back and copying them up -- and just does not save it again.
-    rebuild_in_hbm = os.path.exists(done) and args.indexer == "gpu" and not multi
-    if rank == 0 and (not os.path.exists(done) or rebuild_in_hbm):
+    # A run whose directory is already there (an earlier run on this box) still BUILDS the index in HBM -- 9 s at 3.1 Gb against reading
+    # 31 GB of files back and copying them up -- and just does not save it again; an N > 1 run never saves one.
+    in_hbm_only = args.indexer == "gpu" and (os.path.exists(done) or multi)
+    if rank == 0 and (not os.path.exists(done) or in_hbm_only):
         os.makedirs(work, exist_ok=True)
         fa = os.path.join(work, "ref.fa")
         t1 = time.time()
@@ -108,17 +128,19 @@ def ensure_index(args, rank, device=0, multi=False):
         t1 = time.time()
         if args.indexer == "gpu":
             from snap_amd.index import build_index
-            stats, built = build_index(fa, None if rebuild_in_hbm else os.path.join(work, "idx"), seed_len=args.seed_len, device=device, keep=True)
+            stats, built = build_index(fa, None if in_hbm_only else os.path.join(work, "idx"), seed_len=args.seed_len, device=device, keep=True)
             info.update(stats)
             info["s_build_and_save"] = time.time() - t1
             log("GPU index build%s: %.1fs (device %.0f ms: seeds %.0f, sort %.0f, runs %.0f, tables %.0f; FASTA read %.1fs)"
-                % ("" if rebuild_in_hbm else " + save", time.time() - t1, stats["ms_total_device"], stats["ms_keys"], stats["ms_sort"], stats["ms_runs"], stats["ms_tables"], stats["s_fasta"]))
+                % ("" if in_hbm_only else " + save", time.time() - t1, stats["ms_total_device"], stats["ms_keys"], stats["ms_sort"], stats["ms_runs"], stats["ms_tables"], stats["s_fasta"]))
         else:
             from oracle import ref          # reference index builder == the cpu_baseline's own set-up step
             ref.build_index(fa, os.path.join(work, "idx"), args.seed_len, threads=os.cpu_count() or 8)
             info["s_build_and_save"] = time.time() - t1
             log("reference index build: %.1fs" % (time.time() - t1))
         os.remove(fa)
+    if multi and rank == 0:
+        open(ready, "w").write("ok")
     return genome, os.path.join(work, "idx"), built, info
 
 
@@ -227,8 +249,6 @@ def make_bed(args, env, paired_owner):
     # The index directory is built BEFORE the process group exists: a build can take minutes at GRCh38 scale, and a rank that sits in
     # a collective that long runs into the NCCL watchdog.  Ranks other than 0 wait for the directory's last file on the file system.
     bed.genome, bed.idx_dir, built, bed.index_info = ensure_index(args, rank, local_rank, multi=world > 1 or env["force_dist"])
-    while rank != 0 and not os.path.exists(os.path.join(bed.idx_dir, "GenomeIndex")):
-        time.sleep(1.0)
     if (world > 1 or env["force_dist"]) and env.get("dist") is None:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env["dist"] = sd.init_process_group("nccl")
@@ -246,11 +266,17 @@ def make_bed(args, env, paired_owner):
         bed.owner = cls(index, bed.params, bed.pparams, device=local_rank) if paired_owner else cls(index, bed.params, device=local_rank)
         bed.keep = None
     else:
-        if built is not None:
-            built.close(); built = None
-        index = GenomeIndex.load_from_directory(bed.idx_dir) if rank == 0 else None
-        index, blobs = sd.broadcast_index(index, dev)          # RCCL broadcast HBM -> HBM
-        bed.keep = blobs
+        # N > 1: the index rank 0 has just built is in ITS HBM: the RCCL broadcast reads it there (no file, no host copy); a rank 0 without
+        # one (--indexer reference) loads the directory and sends it up in pinned pieces (snap_amd/dist.py)
+        src_ptrs = None
+        if rank == 0 and built is not None:
+            v = built.view()
+            index = sd.index_meta_from_view(v)
+            src_ptrs = (int(v.hash_blob), int(v.overflow), int(v.genome) - int(v.genome_pad))
+        elif rank == 0:
+            index = GenomeIndex.load_from_directory(bed.idx_dir)
+        index, blobs = sd.broadcast_index(index, dev, src_device_ptrs=src_ptrs)          # RCCL broadcast HBM -> HBM
+        bed.keep = (blobs, built)                  # (rank 0's tensors are views of the built index: it must outlive them)
         ptrs = (blobs[0].data_ptr(), blobs[1].data_ptr(), blobs[2].data_ptr())
         bed.owner = (cls(index, bed.params, bed.pparams, device=local_rank, device_index_ptrs=ptrs) if paired_owner
                      else cls(index, bed.params, device=local_rank, device_index_ptrs=ptrs))
@@ -266,6 +292,10 @@ def close_bed(bed):
     bed.owner.close()
     keep = bed.keep
     bed.keep = None
+    if isinstance(keep, tuple):                    # (blob tensors, the built index they may be views of)
+        blobs_, built_ = keep
+        del blobs_
+        keep = built_
     if keep is not None and hasattr(keep, "close"):
         keep.close()
     del keep

@@ -24,7 +24,7 @@ NAMES = {0: "LV calls", 1: "LV calls ending in the perfect-match prefix", 2: "LV
          5: "LV calls with an answer at e >= 1", 6: "sum of e over those", 8: "affine-gap window calls", 9: "affine-gap window rows", 10: "window slides",
          11: "rows whose X changed after the first segment's rounds", 15: "second segments in rounds because a later stripe end beats stripe 0's flow", 16: "... because some cell's offer is below T_fp",
          32: "SAM: affine-gap CIGAR items", 33: "SAM: banded calls", 34: "SAM: full (unbanded) calls", 35: "SAM: banded rows", 36: "SAM: full rows",
-         37: "SAM: banded first-pass vectors", 38: "SAM: banded lazy-F vector steps", 39: "SAM: full first-pass vectors", 40: "SAM: full lazy-F vector steps", 41: "SAM: traceback gathers", 12: "rows with two segments", 13: "traceback gathers (64 cells each)", 14: "rows on which (nk0, nk1) changed"}
+         37: "SAM: banded first-pass vectors", 38: "SAM: banded lazy-F vector steps", 39: "SAM: full first-pass vectors", 40: "SAM: full lazy-F vector steps", 41: "SAM: traceback gathers", 42: "SAM: banded calls whose row loop k_samf_dp8 had run", 12: "rows with two segments", 13: "traceback gathers (64 cells each)", 14: "rows on which (nk0, nk1) changed"}
 
 
 def main():

@@ -514,12 +514,44 @@ static __device__ __forceinline__ AGCOut agc_banded_par(const AGCState &s, int p
     return agc_traceback_and_emit(s, plen, text_used, use_m, cell, ops, ops_cap);
 }
 
+// ---- the banded row loop done AHEAD of the record, eight reads to a wavefront (cigar_k.hip: k_samf_dp8) ------------------------------------
+// The row loop is ~90 % of a record's instructions, and for the reads a run mostly consists of -- edit distance k <= 3, i.e. a band of at
+// most 7 cells, ONE SSE vector per segment -- it keeps 8 of 64 lanes busy.  k_samf_dp8 runs exactly that case (num_vec == 1, the first
+// attempt of a read that lies inside its contig) for eight reads side by side, one read per 8-lane group, and leaves per read what the rest
+// of the record needs from the loop: textUsed and the traceback bytes of the cells each row evaluated (at most two segments: 16 bytes a row).
+// cigar_ag_item takes them instead of running agc_banded_par when the call it is about to make IS that call (same pattern length, limit,
+// location, orientation and clipping); anything else -- wider bands, a retry after a leading indel, a read at a contig's end, a failed band --
+// is computed here as before.  The loop below is agc_banded with num_vec == 1, value for value.
+struct SamfPre { int32_t valid, plen, w, bcb; int64_t loc; int32_t score, text_used, dir, rows, pad0, pad1; };
+static_assert(sizeof(SamfPre) == 48, "SamfPre layout");
+#define SAMF_PRE_ROW 16
+static __host__ __device__ __forceinline__ uint32_t samf_pre_rows(uint32_t RL) { return RL + 16; }
+static __host__ __device__ __forceinline__ size_t samf_pre_stride(uint32_t RL) { return (sizeof(SamfPre) + (size_t)samf_pre_rows(RL) * SAMF_PRE_ROW + 63) & ~(size_t)63; }
+#define SAMF_PRE_MAX_W 3                     // 2 w + 1 <= 8: one vector per segment
+
+// the rest of computeGlobalScoreBanded for a call whose row loop k_samf_dp8 has run
+static __device__ __forceinline__ AGCOut agc_from_pre(const AGCState &s, int plen, int w, const SamfPre *pre, bool use_m, uint32_t *ops, int ops_cap)
+{
+    const int text_used = (int)first_u32((uint32_t)pre->text_used);
+    const uint8_t *bt = (const uint8_t *)(pre + 1);
+    EMU_STAT(42, 1);
+    auto cell = [&](int row, int col, bool *evaluated) -> int {                 // (per lane)
+        const int bb = row - w > 0 ? row - w : 0, be = row + w < plen - 1 ? row + w : plen - 1;
+        const int sg = col >> 3;
+        *evaluated = sg >= (bb >> 3) && sg <= (be >> 3) && (sg << 3) <= be;
+        if (!*evaluated) return 0;
+        return (int)bt[(size_t)row * SAMF_PRE_ROW + (size_t)((sg - (bb >> 3)) << 3) + (size_t)(col & 7)];
+    };
+    return agc_traceback_and_emit(s, plen, text_used, use_m, cell, ops, ops_cap);
+}
+
 // computeGlobalScoreNormalized (:1043-1128) + SAMFormat::computeCigar, affine-gap variant (SAM.cpp:2470-2588)
 struct CigarAGItemOut { int n_ops, edit_distance, add_front_clipping, tail_ins, stale; long long extra_after; };
 
 static __device__ __forceinline__ CigarAGItemOut cigar_ag_item(const DevIndex &ix, const AGCParams &prm, const uint8_t *data, const uint8_t *quality,
                                                                long long data_len, int k, long long extra_before, long long loc, bool use_m,
-                                                               uint8_t *lds, uint32_t RL, uint8_t *scratch, uint32_t *ops, int ops_cap)
+                                                               uint8_t *lds, uint32_t RL, uint8_t *scratch, uint32_t *ops, int ops_cap,
+                                                               const SamfPre *pre = nullptr)
 {
     const int lane = lane_id();
     CigarAGItemOut o; o.n_ops = 0; o.edit_distance = 0; o.add_front_clipping = 0; o.tail_ins = 0; o.stale = 0; o.extra_after = 0;
@@ -564,7 +596,10 @@ static __device__ __forceinline__ CigarAGItemOut cigar_ag_item(const DevIndex &i
         AGCOut r;
         if (plen >= 3 * (2 * k + 1)) {                                                                   // AffineGapVectorized.cpp:1068-1079
             // (2k + 1 <= 64 positions per segment: the vectors of a segment side by side; wider bands -- k >= 32 -- one vector at a time)
-            r = k <= 31 ? agc_banded_par(s, plen, tlen, k, AGC_MAX_READ_LENGTH, use_m, ops, ops_cap)
+            const bool have_pre = pre != nullptr && pass == 0 && extra_before == 0 && k <= SAMF_PRE_MAX_W && first_u32((uint32_t)pre->valid) == 1u &&
+                                  (int)first_u32((uint32_t)pre->plen) == plen && (int)first_u32((uint32_t)pre->w) == k && (long long)first_u64((uint64_t)pre->loc) == loc;
+            r = have_pre ? agc_from_pre(s, plen, k, pre, use_m, ops, ops_cap)
+              : k <= 31 ? agc_banded_par(s, plen, tlen, k, AGC_MAX_READ_LENGTH, use_m, ops, ops_cap)
                         : agc_banded(s, plen, tlen, k, AGC_MAX_READ_LENGTH, use_m, ops, ops_cap);
             WAVE_SYNC();
             if (r.n_edits < 0 || r.n_edits > k || r.tail_ins >= plen) r = agc_full(s, plen, tlen, use_m, ops, ops_cap);     // "failed band"

@@ -35,6 +35,8 @@ struct SamFieldsArgs {
     uint8_t *scratch; uint64_t scratch_stride;
     uint32_t *work_counter;
     int32_t *flag; int32_t *contig; int64_t *pos; int32_t *mapq; uint32_t *ops; int32_t *n_ops; int32_t *nm; int32_t *stale;
+    // the banded row loops run ahead of the records, eight reads to a wavefront (cigar_ag.h: SamfPre; k_samf_dp8): n * pre_stride bytes, or NULL
+    uint8_t *pre; uint64_t pre_stride; uint32_t *pre_counter;
 };
 
 struct SamFieldsPairedArgs {
@@ -53,6 +55,8 @@ struct SamFieldsPairedArgs {
 
 extern "C" void snapgpu_launch_sam_fields_paired(const SamFieldsPairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+extern "C" void snapgpu_launch_samf_dp8(const SamFieldsArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+extern "C" size_t snapgpu_samf_dp8_lds_per_wave(uint32_t RL);
 extern "C" void snapgpu_launch_cigar_ag(const CigarAGArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 // snapgpu_adjust_alignments: AlignmentAdjuster::AdjustAlignment for a batch of results (adjust.h), one wavefront per result
 struct AdjustArgs {

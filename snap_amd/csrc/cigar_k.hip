@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256, SAMF_WAVES) void k_sam_fields(SamFieldsArgs a)
         }
         uint32_t *ops = a.ops + (size_t)i * a.ops_stride;
         const int F0 = (int)first_u32((uint32_t)a.front_clip[i]), D0 = (int)first_u32((uint32_t)a.data_len[i]);
+        const SamfPre *pre = a.pre ? (const SamfPre *)(a.pre + (size_t)i * a.pre_stride) : nullptr;
         const SamFieldsOut o = sam_fields_single_item(a.ix, prm, a.use_affine_gap != 0, a.use_m != 0, a.bases + b, a.quals + b, (int)(e - b), F0, D0, r,
-                                                      my, a.RL, oriented, lv_cells, ag_scratch, ops, (int)a.ops_stride);
+                                                      my, a.RL, oriented, lv_cells, ag_scratch, ops, (int)a.ops_stride, false, pre);
         if (lane == 0) {
             a.flag[i] = o.flag; a.contig[i] = o.contig; a.pos[i] = o.pos; a.mapq[i] = o.mapq; a.n_ops[i] = o.n_ops; a.nm[i] = o.nm; a.stale[i] = o.stale;
         }
@@ -128,6 +129,190 @@ __global__ __launch_bounds__(256, SAMF_WAVES) void k_sam_fields(SamFieldsArgs a)
 extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
 {
     hipLaunchKernelGGL(k_sam_fields, dim3(blocks), dim3(256), lds_bytes, s, *a);
+}
+
+// ---- the banded row loops of a batch's records, eight reads to a wavefront (cigar_ag.h: SamfPre) -------------------------------------------
+// One read per 8-lane group g = lane / 8, lane el = lane % 8 = the SSE element.  A group takes part when its read's FIRST affine-gap cigar call
+// (sam_fields_single_item's attempt 0 -> cigar_ag_item's pass 0) is a banded call with one vector per segment and nothing unusual about it;
+// what it computes is agc_banded (cigar_ag.h) with num_vec == 1: the same operations on the same values, in the reference's order.
+// LDS per group: the oriented, clipped read; the reference text the rows need; H of the previous row, H of this row, E (int16 per position).
+static __host__ __device__ __forceinline__ uint32_t samf_dp8_hn(uint32_t RL) { return (RL + 7u) & ~7u; }
+static __host__ __device__ __forceinline__ uint32_t samf_dp8_group_bytes(uint32_t RL) {
+    return ((RL + 15u) & ~15u) + ((samf_pre_rows(RL) + 15u) & ~15u) + 3u * 2u * samf_dp8_hn(RL);
+}
+extern "C" size_t snapgpu_samf_dp8_lds_per_wave(uint32_t RL) { return (size_t)8 * samf_dp8_group_bytes(RL); }
+
+__global__ __launch_bounds__(256) void k_samf_dp8(SamFieldsArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int lane = lane_id(), el = lane & 7, g = lane >> 3;
+    const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t RL = a.RL, HN = samf_dp8_hn(RL), GB = samf_dp8_group_bytes(RL);
+    uint8_t *mine = lds + (size_t)wave_in_block * 8u * GB + (size_t)g * GB;
+    uint8_t *pat = mine, *txt = mine + ((RL + 15u) & ~15u);
+    int16_t *Hb = (int16_t *)(txt + ((samf_pre_rows(RL) + 15u) & ~15u));          // [2][HN], then E[HN]
+    int16_t *E = Hb + 2 * HN;
+    const int open = a.prm.gap_open, ext = a.prm.gap_ext, score_init = AGC_MAX_READ_LENGTH;
+    const unsigned long long gmask = 0xffull << (8 * g);
+    const long long nb = (long long)a.ix.n_bases;
+    while (true) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.pre_counter, 8u);
+        base = first_u32(base);
+        if (base >= a.n) break;
+        const uint32_t r = base + (uint32_t)g;
+        // ---- is this read's first cigar call the case this kernel runs?  (sam_fields_single_item attempt 0, cigar_ag_item pass 0)
+        bool elig = r < a.n;
+        int plen = 0, w = 0, dir = 0, bcb = 0, U = 0;
+        long long loc = 0;
+        uint64_t rb = 0;
+        SamfPre *pre = (SamfPre *)(a.pre + (size_t)(elig ? r : base) * a.pre_stride);
+        if (elig) {
+            const snapgpu_single_result *rp = &a.results[r];
+            rb = a.offsets[r]; U = (int)(a.offsets[r + 1] - rb);
+            const int status = rp->status, score = rp->score, F0 = a.front_clip[r], D0 = a.data_len[r], addF = rp->clipping_for_read_adjustment;
+            loc = rp->location; dir = rp->direction;
+            const bool ag_branch = a.use_affine_gap != 0 && (rp->used_affine_gap_scoring != 0 || score > 0);
+            const int front = F0 + addF, dlen = D0 - addF;
+            int clipped = dlen, bca;
+            if (dir == 1) { bcb = U - clipped - front; bca = front; } else { bcb = front; bca = U - clipped - bcb; }
+            bcb += rp->bases_clipped_before; bca += rp->bases_clipped_after; clipped -= rp->bases_clipped_before + rp->bases_clipped_after;
+            elig = status != SNAPGPU_NotFound && ag_branch && loc >= 0 && loc < nb && score >= 0 && score <= SAMF_PRE_MAX_W && U <= (int)RL &&
+                   clipped >= 3 * (2 * score + 1) && bcb >= 0 && bcb + clipped <= U && dlen >= 0;
+            if (elig) {
+                int lo = 0, hi = (int)a.ix.n_contigs - 1, c = -1;                   // Genome::getContigAtLocation
+                while (lo <= hi) { const int mid = (lo + hi) >> 1; if ((long long)a.ix.contig_begin[mid] <= loc) { c = mid; lo = mid + 1; } else hi = mid - 1; }
+                const long long cend = c < 0 ? 0 : (c == (int)a.ix.n_contigs - 1 ? nb : (long long)a.ix.contig_begin[c + 1]);
+                // inside its contig as the writer sees it (no `extra`), clear of the contig's end as the cigar sees it (no extra_after), substring there
+                elig = c >= 0 && loc + dlen <= cend && loc + clipped <= cend - (long long)a.ix.chromosome_padding && cend > loc + clipped;
+            }
+            plen = clipped; w = score;
+        }
+        const int rows_cap = (int)samf_pre_rows(RL);
+        if (el == 0 && r < a.n) pre->valid = 0;
+        if (!BALLOT(elig)) continue;
+        // ---- stage the group's read (as SAM prints it, clipped) and reference text
+        {
+            // (loop bounds are the wave's maximum over the eligible groups, so that the wave's control flow stays uniform)
+            int m = elig ? plen : 0;
+            for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(m, o); m = t > m ? t : m; }
+            const int top = (int)first_u32((uint32_t)m);
+            for (int j = el; j < top; j += 8) {
+                if (elig && j < plen) {
+                    const int x = bcb + j;
+                    pat[j] = dir == 1 ? rc_base(a.bases[rb + (uint64_t)(U - 1 - x)]) : a.bases[rb + (uint64_t)x];
+                }
+            }
+            const long long readable = nb + (long long)a.ix.genome_pad - loc;
+            for (int j = el; j < top + 16 && j < rows_cap; j += 8) {
+                if (elig && j < plen + 16) txt[j] = j < readable ? a.ix.genome[loc + j] : (uint8_t)0;
+            }
+        }
+        // ---- first row (AffineGapVectorized.cpp:611-628): a lane's scoreFirstRow keeps its last value past the pattern's end
+        const int num_seg = (plen + 7) >> 3;
+        {
+            int sfr = 0;
+            int ns_top = elig ? num_seg : 0;
+            for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(ns_top, o); ns_top = t > ns_top ? t : ns_top; }
+            ns_top = (int)first_u32((uint32_t)ns_top);
+            for (int sg = 0; sg < ns_top; sg++) {
+                const int p = sg * 8 + el;
+                if (elig && sg < num_seg) {
+                    if (p < plen) { const int x = score_init - (open + p * ext); sfr = x > 0 ? x : 0; }
+                    Hb[p] = (int16_t)sfr; Hb[HN + p] = 0; E[p] = 0;
+                }
+            }
+        }
+        WAVE_SYNC();
+        int score = score_init, text_used = -1, idle_rows = 0, cur = 0;
+        bool going = elig;
+        const int tlen = plen + LVC_MAX_K;
+        uint8_t *btout = (uint8_t *)(pre + 1);
+        for (int i = 0; ; i++) {
+            if (going && (i >= tlen || i >= rows_cap)) going = false;
+            if (!BALLOT(going)) break;
+            int16_t *Hp = Hb + (cur ? HN : 0), *Hm = Hb + (cur ? 0 : HN);
+            const int tb = going ? (int)base_value(txt[i]) : 4;
+            int f = 0, X = 0;
+            const int band_beg = i - w > 0 ? i - w : 0;
+            const int band_end = i + w < plen - 1 ? i + w : plen - 1;
+            const int seg_beg = band_beg >> 3, seg_end = band_end >> 3;
+            for (int jj = 0; jj < 2; jj++) {
+                const int j = seg_beg + jj;
+                const bool act = going && j <= seg_end;
+                const int vi = act ? j * 8 + el : el;
+                // diagonal input: the previous row's H one element down; element 0 takes h_init (:639-657)
+                int h = __shfl_up(act ? (int)Hp[vi] : 0, 1);
+                if (el == 0) {
+                    if (j == 0) h = (int)(int16_t)(i > 0 ? score_init - (open + (i - 1) * ext) : score_init);
+                    else if (band_beg > j * 8) h = 0;
+                    else h = act ? (int)Hp[j * 8 - 1] : 0;
+                }
+                int prof;
+                {
+                    const int p = j * 8 + el;
+                    if (!act || p >= plen) prof = -32768;
+                    else { const int pb = (int)base_value(pat[p]); prof = (tb > 3 || pb > 3) ? -1 : (tb == pb ? a.prm.match : a.prm.sub); }
+                }
+                const int m = agc_sat(h + prof);
+                int e = act ? (int)E[vi] : 0;
+                int bt = e > m ? 1 : 0;
+                int hv = m > e ? m : e;
+                { const int t = f > hv ? 2 : 0; bt = t | (bt & ~t); }
+                hv = hv > f ? hv : f;
+                e = agc_sat(e - ext);
+                const int temp = agc_sat(m - open);
+                if (e > temp) bt |= 4;
+                e = e > temp ? e : temp;
+                if (act) E[vi] = (int16_t)e;
+                f = agc_sat(f - ext);
+                if (f > temp) bt |= 32;
+                f = f > temp ? f : temp;
+                // lazy F (:737-781): up to seven rounds, each stops at the first (here: the only) vector in which no element's F goes on
+                bool lz = act;
+                for (int kk = 0; kk < 7; kk++) {
+                    if (!BALLOT(lz)) break;
+                    const int f7 = __shfl(f, (lane & ~7) + 7);
+                    int fin = __shfl_up(f, 1);
+                    if (lz) {
+                        X = X > f7 ? X : f7;
+                        if (el == 0) fin = 0;
+                        { const int t = fin > hv ? 2 : 0; bt = t | (bt & ~t); }
+                        hv = hv > fin ? hv : fin;
+                        const int temp2 = agc_sat(hv - open);
+                        fin = agc_sat(fin - ext);
+                        if (fin > temp2) bt |= 32;
+                        f = fin;
+                    }
+                    const bool cont = lz && f > agc_sat(hv - open);
+                    if ((BALLOT(cont) & gmask) == 0ull) lz = false;
+                }
+                if (act) {
+                    Hm[vi] = (int16_t)hv;
+                    btout[(size_t)i * SAMF_PRE_ROW + (size_t)(jj * 8 + el)] = (uint8_t)bt;
+                    f = el == 0 ? X : 0;                                    // :783
+                }
+            }
+            WAVE_SYNC();
+            if (going && band_end == plen - 1) {                            // :803-815
+                const int gsc = (int)Hm[(band_end >> 3) * 8 + (band_end & 7)];
+                if (gsc > score) { score = gsc; text_used = i; }
+            }
+            cur ^= 1;
+            if (going && seg_beg > seg_end && ++idle_rows == 2) going = false;       // (see agc_banded)
+            WAVE_SYNC();
+        }
+        if (elig && el == 0) {
+            pre->plen = plen; pre->w = w; pre->bcb = bcb; pre->loc = loc; pre->score = score; pre->text_used = text_used; pre->dir = dir; pre->rows = rows_cap;
+            pre->valid = 1;
+        }
+        WAVE_SYNC();
+    }
+}
+
+extern "C" void snapgpu_launch_samf_dp8(const SamFieldsArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_samf_dp8, dim3(blocks), dim3(256), lds_bytes, s, *a);
 }
 
 // paired-end writer: both reads of a pair by one wavefront, then SAMFormat::fillMateInfo for each (sam_fields.h)

@@ -43,7 +43,8 @@ static __device__ __forceinline__ long long samf_contig_end(const DevIndex &ix, 
 static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
     const DevIndex &ix, const AGCParams &agp, bool use_affine_gap, bool use_m,
     const uint8_t *bases, const uint8_t *quals, int U, int F0, int D0, const snapgpu_single_result &res,
-    uint8_t *lds, uint32_t RL, uint8_t *oriented, uint32_t *lv_cells, uint8_t *ag_scratch, uint32_t *ops, int ops_cap, bool paired = false)
+    uint8_t *lds, uint32_t RL, uint8_t *oriented, uint32_t *lv_cells, uint8_t *ag_scratch, uint32_t *ops, int ops_cap, bool paired = false,
+    const SamfPre *pre = nullptr)
 {
     const int lane = lane_id();
     SamFieldsOut o; o.flag = 0; o.contig = -1; o.mapq = 0; o.n_ops = -1; o.nm = -1; o.stale = 0; o.pos = 0;
@@ -103,7 +104,9 @@ static __device__ __forceinline__ SamFieldsOut sam_fields_single_item(
             int ed;
             int tail = 0;
             if (ag_branch) {
-                const CigarAGItemOut r = cigar_ag_item(ix, agp, cd, cq, clipped_len, res.score, extra, loc, use_m, lds, RL, ag_scratch, ops, ops_cap);
+                // (the first attempt's row loop may have been run ahead of time: cigar_ag.h, SamfPre -- for this orientation and clipping only)
+                const SamfPre *use_pre = (pre != nullptr && attempt == 0 && (int)first_u32((uint32_t)pre->dir) == dir && (int)first_u32((uint32_t)pre->bcb) == bcb) ? pre : nullptr;
+                const CigarAGItemOut r = cigar_ag_item(ix, agp, cd, cq, clipped_len, res.score, extra, loc, use_m, lds, RL, ag_scratch, ops, ops_cap, use_pre);
                 ed = r.edit_distance; afc = r.add_front_clipping; extra_after = r.extra_after; tail = r.tail_ins; n_ops = r.n_ops;
                 if (r.stale) o.stale = 1;
             } else {

@@ -1506,6 +1506,27 @@ extern "C" int snapgpu_compute_cigar_ag(snapgpu_ctx *ctx, uint32_t n, const char
     return sam_side_kernel_time(ctx);
 }
 
+// The banded row loops of a batch's records ahead of the records themselves, eight reads to a wavefront (cigar_ag.h: SamfPre, cigar_k.hip:
+// k_samf_dp8): fills a.pre / a.pre_stride / a.pre_counter and launches the kernel on `s`.  `buf` keeps the per-read results alive until the
+// caller has synchronised.  SNAPGPU_SAMF_DP8=0 (measurement knob) or reads beyond 400 bp: nothing is launched and a.pre stays NULL.
+static bool samf_dp8_enabled() { static int v = -1; if (v < 0) { const char *e = getenv("SNAPGPU_SAMF_DP8"); v = e ? (atoi(e) != 0 ? 1 : 0) : 1; } return v == 1; }
+static int launch_samf_dp8(snapgpu_ctx *ctx, SamFieldsArgs &a, DevBuf &buf, hipStream_t s)
+{
+    a.pre = nullptr; a.pre_stride = 0; a.pre_counter = ctx->d_work + 2;
+    if (!samf_dp8_enabled() || !a.use_affine_gap || a.RL > 400 || a.n == 0) return SNAPGPU_OK;
+    const size_t stride = samf_pre_stride(a.RL);
+    HIPCHK(ctx, buf.put(nullptr, (size_t)a.n * stride, s), SNAPGPU_E_NOMEM);
+    a.pre = (uint8_t *)buf.p; a.pre_stride = stride;
+    const size_t lds = 4 * snapgpu_samf_dp8_lds_per_wave(a.RL);
+    uint32_t per_cu = (uint32_t)((size_t)160 * 1024 / (lds ? lds : 1)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
+    uint32_t blocks = (uint32_t)ctx->num_cus * per_cu;
+    const uint32_t need = (a.n + 31) / 32; if (blocks > need) blocks = need;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_work + 2, 0, 4, s), SNAPGPU_E_LAUNCH);
+    snapgpu_launch_samf_dp8(&a, blocks, lds, s);
+    HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
+    return SNAPGPU_OK;
+}
+
 // result -> FLAG / RNAME index / POS / MAPQ / CIGAR / NM of the SAM record (sam_fields.h, cigar_k.hip)
 extern "C" int snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const char *bases, const char *quals, const uint64_t *offsets,
                                          const int32_t *front_clip, const int32_t *data_len, const snapgpu_single_result *results, int use_m,
@@ -1566,6 +1587,8 @@ extern "C" int snapgpu_sam_fields_single(snapgpu_ctx *ctx, uint32_t n, const cha
     a.ops = (uint32_t *)dops.p; a.n_ops = (int32_t *)dno.p; a.nm = (int32_t *)dnm.p; a.stale = (int32_t *)dst.p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    DevBuf dpre;
+    { const int prc = launch_samf_dp8(ctx, a, dpre, s); if (prc) return prc; }
     snapgpu_launch_sam_fields(&a, blocks, (size_t)4 * per_wave, s);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
@@ -1618,6 +1641,8 @@ extern "C" int snapgpu_sam_fields_single_device(snapgpu_ctx *ctx, uint32_t n, ui
     HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipMemsetAsync(d_ops, 0, (size_t)n * ops_stride * 4, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    DevBuf dpre;
+    { const int prc = launch_samf_dp8(ctx, a, dpre, s); if (prc) return prc; }
     snapgpu_launch_sam_fields(&a, blocks, (size_t)4 * per_wave, s);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);
@@ -1701,6 +1726,8 @@ extern "C" int snapgpu_align_sam_single(snapgpu_ctx *ctx, uint32_t n, const char
     a.ops = (uint32_t *)dops.p; a.n_ops = (int32_t *)dno.p; a.nm = (int32_t *)dnm.p; a.stale = (int32_t *)dst.p;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_work, 0, 4, s), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
+    DevBuf dpre;
+    { const int prc = launch_samf_dp8(ctx, a, dpre, s); if (prc) return prc; }
     snapgpu_launch_sam_fields(&a, blocks, (size_t)4 * per_wave, s);
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     HIPCHK(ctx, hipEventRecord(ctx->ev1, s), SNAPGPU_E_LAUNCH);

@@ -38,13 +38,57 @@ def init_process_group(backend: str):
 INDEX_META_FIELDS = ("seed_len", "key_bytes", "n_hash_tables", "large", "location_size", "chromosome_padding", "n_bases")
 
 
-def broadcast_index(index, device, src: int = 0):
+class _DevicePtrArray:
+    """A device allocation somebody else owns (the index blobs of a context) as something torch.as_tensor can wrap without copying."""
+
+    def __init__(self, ptr: int, nbytes: int, typestr: str, itemsize: int):
+        self.__cuda_array_interface__ = {"data": (int(ptr), False), "shape": (int(nbytes) // itemsize,), "typestr": typestr, "version": 2}
+
+
+def index_meta_from_view(view):
+    """The small host-side part of a GenomeIndex (header fields, table offsets / sizes, contig table) from a snapgpu_index_view whose
+    blobs live on the device -- what snap_amd.index.BuiltIndex.view() returns for an index the GPU has just built.  The blob arrays
+    of the result are empty; `_device_sizes` carries their sizes."""
+    import ctypes as C
+    from .index import Contig, GenomeIndex
+    nt, nc = int(view.n_hash_tables), int(view.n_contigs)
+    toff = np.ctypeslib.as_array(C.cast(view.table_offset, C.POINTER(C.c_uint64)), shape=(nt,)).copy()
+    tsz = np.ctypeslib.as_array(C.cast(view.table_size, C.POINTER(C.c_uint64)), shape=(nt,)).copy()
+    cb = np.ctypeslib.as_array(C.cast(view.contig_begin, C.POINTER(C.c_uint64)), shape=(nc,)).copy() if nc else np.zeros(0, np.uint64)
+    first_alt = int(view.first_alt_location)
+    contigs = [Contig(int(b), int(b) >= first_alt, i, "contig%d" % i) for i, b in enumerate(cb)]
+    if view.contig_proj_begin and view.contig_cigar_start and nc:          # ALT-to-primary projections (an index built with an -altLiftoverFile)
+        pb = np.ctypeslib.as_array(C.cast(view.contig_proj_begin, C.POINTER(C.c_uint64)), shape=(nc,))
+        prc = np.ctypeslib.as_array(C.cast(view.contig_proj_rc, C.POINTER(C.c_uint8)), shape=(nc,)) if view.contig_proj_rc else np.zeros(nc, np.uint8)
+        cst = np.ctypeslib.as_array(C.cast(view.contig_cigar_start, C.POINTER(C.c_uint32)), shape=(nc + 1,))
+        cops = np.ctypeslib.as_array(C.cast(view.cigar_ops, C.POINTER(C.c_uint32)), shape=(max(1, int(cst[nc])),)) if view.cigar_ops else np.zeros(1, np.uint32)
+        for i, c in enumerate(contigs):
+            c.proj_begin, c.proj_rc = int(pb[i]), bool(prc[i])
+            c.proj_cigar = "".join("%d%s" % (int(o) >> 8, chr(int(o) & 0xff)) for o in cops[int(cst[i]):int(cst[i + 1])]) or "*"
+    ix = GenomeIndex(seed_len=int(view.seed_len), key_bytes=int(view.key_bytes), n_hash_tables=nt, large=bool(view.large_hash_table),
+                     location_size=int(view.location_size), chromosome_padding=int(view.chromosome_padding),
+                     overflow=np.zeros(0, dtype=np.uint32), hash_blob=np.zeros(0, dtype=np.uint8), table_offset=toff, table_size=tsz,
+                     genome_padded=np.zeros(0, dtype=np.uint8), n_bases=int(view.n_bases), contigs=contigs)
+    ix._device_sizes = (int(view.hash_blob_bytes), int(view.overflow_table_size), int(view.n_bases) + 2 * int(view.genome_pad))
+    return ix
+
+
+def broadcast_index(index, device, src: int = 0, src_device_ptrs=None, chunk_bytes: int = 1 << 30):
     """Replicate a GenomeIndex from rank `src` to every rank.
 
-    `index` is the loaded GenomeIndex on rank src and None elsewhere.  Returns
+    `index` is the GenomeIndex on rank src and None elsewhere.  Returns
     (index_with_small_host_arrays, (hash_t, overflow_t, genome_padded_t)): the three big blobs as
     uint8/int32 torch tensors on `device` (each rank's HBM for nccl), filled by dist.broadcast.
     Small metadata (table offsets/sizes, contig table) travels as one int64 tensor.
+
+    Where the blobs come from on rank src:
+      src_device_ptrs = (hash, overflow, genome_with_pad) device pointers: the index is ALREADY in src's HBM (it built it there, or
+        a context holds it): the broadcast reads it in place -- no host copy, no file -- and the returned tensors on src are views
+        of that memory (the owner must outlive them);
+      otherwise `index` holds them in host memory: they go up in pieces of `chunk_bytes` through one pinned staging buffer, each piece
+        broadcast as soon as it is up, so that rank src never holds more than the index arrays plus one piece (the one-tensor
+        `.to(device)` of a 25 GB pageable array took a second host copy of it: 91.6 GB peak at GRCh38 scale, profiles/r04z).
+    Either way a blob travels in pieces of at most chunk_bytes: one RCCL broadcast per piece.
     """
     import torch
     import torch.distributed as dist
@@ -52,8 +96,11 @@ def broadcast_index(index, device, src: int = 0):
     rank = dist.get_rank()
     is_src = rank == src
     if is_src:
+        sizes = getattr(index, "_device_sizes", None) if src_device_ptrs is not None else None
+        if sizes is None:
+            sizes = (index.hash_blob.size, index.overflow.size, index.genome_padded.size)
         hdr = np.array([getattr(index, f) if f != "large" else int(index.large) for f in INDEX_META_FIELDS]
-                       + [index.hash_blob.size, index.overflow.size, index.genome_padded.size, len(index.contigs)],
+                       + [int(sizes[0]), int(sizes[1]), int(sizes[2]), len(index.contigs)],
                        dtype=np.int64)
     else:
         hdr = np.zeros(len(INDEX_META_FIELDS) + 4, dtype=np.int64)
@@ -88,15 +135,33 @@ def broadcast_index(index, device, src: int = 0):
     proj = tp.cpu().numpy()
 
     blobs = []
-    for name, n, dt in (("hash_blob", hash_n, torch.uint8), ("overflow", ovf_n, torch.int32), ("genome_padded", gen_n, torch.uint8)):
-        if is_src:
-            arr = getattr(index, name)
-            src_t = torch.from_numpy(arr.view(np.int32) if dt == torch.int32 else arr)
-            buf = src_t.to(device)                       # host -> this rank's HBM
+    on_gpu = torch.device(device).type == "cuda"
+    staging = None
+    for k, (name, n, dt) in enumerate((("hash_blob", hash_n, torch.uint8), ("overflow", ovf_n, torch.int32), ("genome_padded", gen_n, torch.uint8))):
+        item = 4 if dt == torch.int32 else 1
+        host = None
+        if is_src and src_device_ptrs is not None:
+            buf = torch.as_tensor(_DevicePtrArray(src_device_ptrs[k], n * item, "<i4" if item == 4 else "|u1", item), device=device)
         else:
             buf = torch.empty(n, dtype=dt, device=device)
-        dist.broadcast(buf, src)                         # RCCL broadcast over xGMI, HBM to HBM
+            if is_src:
+                arr = getattr(index, name)
+                host = torch.from_numpy(arr.view(np.int32) if dt == torch.int32 else arr)
+        step = max(1, int(chunk_bytes) // item)
+        for i in range(0, n, step):
+            j = min(n, i + step)
+            if host is not None:                         # host -> this rank's HBM, one piece through the pinned staging buffer
+                if on_gpu:
+                    if staging is None:
+                        staging = torch.empty(int(chunk_bytes), dtype=torch.uint8, pin_memory=True)
+                    st = staging[:(j - i) * item].view(dt)
+                    st.copy_(host[i:j])
+                    buf[i:j].copy_(st, non_blocking=False)
+                else:
+                    buf[i:j].copy_(host[i:j])
+            dist.broadcast(buf[i:j], src)                # RCCL broadcast over xGMI, HBM to HBM
         blobs.append(buf)
+    del staging
 
     if is_src:
         out_index = index

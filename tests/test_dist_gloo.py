@@ -26,6 +26,10 @@ WORKER = textwrap.dedent("""
     assert [c.begin for c in ix.contigs] == [c.begin for c in full.contigs]
     assert ix.first_alt_location == full.first_alt_location and ix.n_bases == full.n_bases
     assert all((a == b).all() for a, b in zip(ix.projection_arrays(), full.projection_arrays()))
+    # the blobs in pieces (what a 25 GB hash blob does: one broadcast per piece through one staging buffer) -- same bytes
+    ixc, (hc, oc, gc) = sd.broadcast_index(index, dev, chunk_bytes=4096)
+    assert (hc.numpy() == full.hash_blob).all() and (oc.numpy().view(np.uint32) == full.overflow).all() and (gc.numpy() == full.genome_padded).all()
+    assert ixc._device_sizes == ix._device_sizes == (full.hash_blob.size, full.overflow.size, full.genome_padded.size)
     lift = load_golden_index("paired_alt_index.npz")
     ix2, _ = sd.broadcast_index(lift if rank == 0 else None, dev)
     assert all((a == b).all() for a, b in zip(ix2.projection_arrays(), lift.projection_arrays()))
