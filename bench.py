@@ -81,7 +81,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def ensure_index(args, rank, device=0, multi=False):
+def ensure_index(args, rank, device=0, multi=False, need_dir=True):
     """Genome + SNAP index directory under /tmp, built once per box.  The directory is in the reference's on-disk format either way:
     --indexer gpu (default) builds it with this repo's GPU index builder (include/snapgpu.h: snapgpu_index_build_from_fasta; parity with
     the reference's builder: tests/test_zx_gpu_index_build.py) and ALSO returns the index still resident in HBM, so that the run aligns
@@ -118,7 +118,7 @@ def ensure_index(args, rank, device=0, multi=False):
     built, info = None, {"indexer": args.indexer, "cached": os.path.exists(done)}
     # A run whose directory is already there (an earlier run on this box) still BUILDS the index in HBM -- 9 s at 3.1 Gb against reading
     # 31 GB of files back and copying them up -- and just does not save it again; an N > 1 run never saves one.
-    in_hbm_only = args.indexer == "gpu" and (os.path.exists(done) or multi)
+    in_hbm_only = args.indexer == "gpu" and (os.path.exists(done) or (multi and not need_dir))
     if rank == 0 and (not os.path.exists(done) or in_hbm_only):
         os.makedirs(work, exist_ok=True)
         fa = os.path.join(work, "ref.fa")
@@ -248,7 +248,9 @@ def make_bed(args, env, paired_owner):
     cls = ChimericPairedEndAligner if paired_owner else BaseAligner
     # The index directory is built BEFORE the process group exists: a build can take minutes at GRCh38 scale, and a rank that sits in
     # a collective that long runs into the NCCL watchdog.  Ranks other than 0 wait for the directory's last file on the file system.
-    bed.genome, bed.idx_dir, built, bed.index_info = ensure_index(args, rank, local_rank, multi=world > 1 or env["force_dist"])
+    # (the directory itself is only needed where the reference runs beside the GPU: the CPU baseline of a one-process run)
+    bed.genome, bed.idx_dir, built, bed.index_info = ensure_index(args, rank, local_rank, multi=world > 1 or env["force_dist"],
+                                                                  need_dir=world == 1 and not args.skip_cpu)
     if (world > 1 or env["force_dist"]) and env.get("dist") is None:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env["dist"] = sd.init_process_group("nccl")
@@ -283,7 +285,10 @@ def make_bed(args, env, paired_owner):
     if index is not None:
         hb_, ow_, gb_ = getattr(index, "_device_sizes", (index.hash_blob.size, index.overflow.size, index.genome_padded.size))
         bed.index_bytes = int(hb_) + 4 * int(ow_) + int(gb_)
-    log("rank %d: %d Mb genome, index (%.1f GB) resident in HBM after %.1fs" % (rank, args.genome_mb, bed.index_bytes / 1e9, time.time() - t0))
+    bed.index_resident_s = time.time() - t0          # adopting / loading / broadcasting the blobs (the build itself: config.index_build)
+    bed.index_path = ("adopted from the GPU build" if dist is None and built is not None else "loaded from the directory" if dist is None
+                      else "RCCL broadcast from rank 0's HBM (built there)" if built is not None or rank != 0 else "RCCL broadcast, rank 0 loaded the directory")
+    log("rank %d: %d Mb genome, index (%.1f GB) resident in HBM after %.1fs" % (rank, args.genome_mb, bed.index_bytes / 1e9, bed.index_resident_s))
     return bed
 
 
@@ -553,7 +558,8 @@ def run_leg(args, env, bed, workload, primary):
                    "genome_mb": args.genome_mb, "genome_choice": env.get("genome_choice", "--genome-mb"),
                    "reads_per_gpu": n, "read_len": args.read_len, "index_bytes_hbm": index_bytes,
                    "parallelism": "reads sharded over %d GPU(s), index replicated%s" % (world, " by RCCL broadcast" if world > 1 else ""),
-                   "feeders_per_gpu": n_feed, "index_build": index_info, "kernel_source_hash": kernel_source_hash()},
+                   "feeders_per_gpu": n_feed, "index_build": index_info, "index_resident_s": getattr(bed, "index_resident_s", None),
+                   "index_path": getattr(bed, "index_path", None), "kernel_source_hash": kernel_source_hash()},
         "roofline": {"kernel": "k_align_paired" if paired else "k_align_single", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "bytes_breakdown": parts, "avg_launch_ms": avg_ms,
