@@ -22,7 +22,8 @@
 #define SNAPGPU_AG_DUP 0         // measurement builds only (scripts/ab_bench.py): 1 / 2 / 3 run the prologue / the row loop / the traceback of the window form twice
 #endif
 
-// The row loop of rounds 1-3, kept for A/B runs and as the statement of what the rewritten loop must equal (-DSNAPGPU_AG_WIN_V1 selects it).
+// The row loop of rounds 1-3: the statement of what the rewritten loop must equal, and the loop a ZERO gap-open penalty still takes (the
+// rewritten loop's lazy-F rules assume open > extend: ag_dispatch).
 // EXACT (replay of flagged reads, ag.h): bt_scratch_in is the wave's image of one reference object's traceback array; cells go where the
 // reference puts them -- byte (row * numVec * numSeg + vector) * 8 + SSE element -- only evaluated cells are written, and the traceback
 // reads whatever the array holds.
@@ -967,13 +968,8 @@ static __device__ __forceinline__ AGResult ag_dispatch_inl(
             return ag_banded_win_v1<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                            lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
         if (banded && 2 * seg_len <= 64)        // the band's two segments fit one wavefront: sliding-window form
-#if defined(SNAPGPU_AG_WIN_V1)
-            return ag_banded_win_v1<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                           lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
-#else
             return ag_banded_win<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                         lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
-#endif
         if (banded)
             return ag_compute_reg<AGC, true, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                                     lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);

@@ -656,7 +656,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     // (this pointer is LDS: said out loud for the kernels in which this object lives in memory -- the paired-end one, which passes its
     //  address around -- and its pointers come back from there as generic ones: flat stores that wait for every load and store in flight)
     template <class T> static __device__ __forceinline__ T *lds_ptr(T *p) {
-#ifndef SNAPGPU_WAVE_EMU
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNAPGPU_WAVE_EMU)
         __builtin_assume(__builtin_amdgcn_is_shared((const void *)p));
 #endif
         return p;
@@ -776,24 +776,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 }
             }
             const uint64_t t_lv0 = clk();
-#if defined(SNAPGPU_AG_LV_FUNCTIONS) && defined(SNAPGPU_LV_ONE_CALL)      // (measured 23 % SLOWER than two calls: profiles/r04r -- off)
-            const bool lv_one_call = !HAM && !lv_planes;          // both halves in one function call (lv.h: lv_compute2_fn)
-            if (lv_one_call) {
-                LVResult2 r2 = lv_compute2_fn(rdd, qld, data, read_len, tail_start, seed_offset, text_len, limit_e, SNAPGPU_MAX_K, lv_tri, cfg.kmax, tab, cfg.RL);
-                score1 = (int)first_u32((uint32_t)r2.a.score); mp1 = first_f64(r2.a.match_probability);
-                ag1 = (seed_len + read_len - tail_start - score1) * cfg.match_reward - score1 * cfg.sub_penalty;
-                cnt.lv_ref_bytes += (uint64_t)(read_len - tail_start) + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e));
-                if (score1 != -1) {
-                    score2 = (int)first_u32((uint32_t)r2.b.score); mp2 = first_f64(r2.b.match_probability);
-                    loc_offset = (int)first_u32((uint32_t)r2.b.net_indel);
-                    ag2 = (seed_offset - score2) * cfg.match_reward - score2 * cfg.sub_penalty;
-                    cnt.lv_ref_bytes += (uint64_t)seed_offset;
-                }
-            }
-#else
-            const bool lv_one_call = false;
-#endif
-            for (int half = 0; half < 2 && !HAM && !lv_one_call; half++) {
+            for (int half = 0; half < 2 && !HAM; half++) {
                 if (half == 1 && score1 == -1) break;
                 const int st = half == 0 ? 1 : -1;
                 const int org = half == 0 ? tail_start : seed_offset - 1;

@@ -325,38 +325,3 @@ static __device__ __forceinline__ LVResult lv_compute(
 #endif
 }
 
-// (-DSNAPGPU_LV_ONE_CALL only: measured 23 % slower than two calls of lv_compute_fn, profiles/r04r -- kept as the record of the experiment.)
-// Both halves of a candidate's Landau-Vishkin scoring in ONE call (BaseAligner.cpp:1160-1175: forward from the end of the seed over the
-// tail of the read, then -- unless that was above the limit -- backwards from the start of the seed over the head, with what is left of the
-// limit).  A call of a function from the single-end kernel costs its caller ~230 v_writelane / v_readlane of live SGPRs (the aligner
-// object does not fit 100 SGPRs), Landau-Vishkin is called twice per scored location and ~20 times per read: one call instead of two.
-// rdd / qld: the read and its qualities in the candidate's direction; data[i] = genome[loc + i]; max_k_pad = MAX_K (the backward text's slack).
-struct LVResult2 { LVResult a, b; };
-static __device__ __attribute__((noinline)) LVResult2 lv_compute2_fn(
-    const uint8_t *rdd_in, const uint8_t *qld_in, const uint8_t *data_in, int read_len, int tail_start, int seed_offset, int text_len, int limit,
-    int max_k_pad, uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap)
-{
-    const uint8_t *rdd = (const uint8_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)rdd_in);
-    const uint8_t *qld = (const uint8_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)qld_in);
-    const uint8_t *data = (const uint8_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)data_in);
-    read_len = (int)first_u32((uint32_t)read_len); tail_start = (int)first_u32((uint32_t)tail_start); seed_offset = (int)first_u32((uint32_t)seed_offset);
-    text_len = (int)first_u32((uint32_t)text_len); limit = (int)first_u32((uint32_t)limit); max_k_pad = (int)first_u32((uint32_t)max_k_pad);
-    lds_tri = (uint16_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)lds_tri);
-    kmax = first_u32(kmax); pcap = first_u32(pcap);
-    tab = (const DevTables *)(uintptr_t)first_u64((uint64_t)(uintptr_t)tab);
-    LVResult2 out;
-    out.b.score = -2; out.b.match_probability = 1.0; out.b.net_indel = 0; out.b.total_indels = 0; out.b.text_span = 0;       // -2: not run
-    int lim = limit;
-    for (int half = 0; half < 2; half++) {
-        const int st = half == 0 ? 1 : -1;
-        const int org = half == 0 ? tail_start : seed_offset - 1;
-        const int plen = half == 0 ? read_len - tail_start : seed_offset;
-        const int tlen = half == 0 ? text_len : seed_offset + max_k_pad;
-        ByteSeq P{rdd + org, st}, Q{qld + org, st}, T{data + org, st};
-        LVResult r = lv_compute_inl<true>(P, Q, plen, T, tlen, lim, lds_tri, kmax, tab, pcap);
-        r.score = (int)first_u32((uint32_t)r.score);
-        if (half == 0) { out.a = r; if (r.score == -1) break; lim = limit - r.score; }
-        else out.b = r;
-    }
-    return out;
-}

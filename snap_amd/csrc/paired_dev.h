@@ -204,7 +204,7 @@ struct DevPL {
     }
     // this pointer points into LDS (paired.h: PairedCore::L)
     static __device__ __forceinline__ void lds(const void *p) {
-#ifndef SNAPGPU_WAVE_EMU
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNAPGPU_WAVE_EMU)
         __builtin_assume(__builtin_amdgcn_is_shared(p));
 #else
         (void)p;
