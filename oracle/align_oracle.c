@@ -1,3 +1,5 @@
+#include <stdio.h>
+#include <stdlib.h>
 /*
  * align_oracle.c -- TEST INFRASTRUCTURE ONLY.
  *
@@ -562,7 +564,8 @@ static void score_location_ag(A *a, int dir, int64_t loc, int seed_offset, int l
         if (score2 == -1) *offset = 0;
     }
     if (score1 != -1 && score2 != -1) {
-        *score = score1 + score2; *mp = mp1 * mp2 * oracle_seed_prob(seed_len); *ag_score = ag1 + ag2;
+        /* :907: seedLen is the unsigned member here, so pow() is libm's pow(double, double) -- not the powi of :1314 (snap_oracle.c) */
+        *score = score1 + score2; *mp = mp1 * mp2 * oracle_seed_prob_pow(seed_len); *ag_score = ag1 + ag2;
     } else {
         *score = -1; *ag_score = -1; *mp = 0.0;
     }

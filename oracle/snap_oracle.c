@@ -79,6 +79,14 @@ double oracle_seed_prob(int seed_len)
     return y;
 }
 
+double oracle_seed_prob_pow(int seed_len)
+{
+    /* BaseAligner.cpp:907 (scoreLocationWithAffineGap, reached through alignAffineGap): the same expression, but seedLen is the
+     * `unsigned` member there (BaseAligner.h:434) -- no local int shadows it as at :1141 -- so the call resolves to <cmath>'s promoting
+     * template, i.e. libm's pow(double, double): one ulp below the powi value at seed 20. */
+    return pow(1 - 0.001, (double)seed_len);
+}
+
 int oracle_compute_mapq(double p_all, double p_best, int score, int popular_seeds_skipped)   /* mapq.h:31-68 */
 {
     (void)score;

@@ -16,6 +16,7 @@ const double *oracle_phred_table(void);      /* [256]  */
 const double *oracle_indel_table(void);      /* [10001] */
 const double *oracle_perfect_table(void);    /* [1001] */
 double oracle_seed_prob(int seed_len);
+double oracle_seed_prob_pow(int seed_len);      /* the libm-pow twin: BaseAligner.cpp:907 */
 int    oracle_compute_mapq(double p_all, double p_best, int score, int popular_seeds_skipped);
 unsigned oracle_wrapped_next_seed(unsigned seed_len, unsigned wrap_count);
 

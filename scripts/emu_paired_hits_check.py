@@ -21,6 +21,7 @@ from oracle import ref
 from tests.pairs_util import compare_paired
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+only = sys.argv[2] if len(sys.argv) > 2 else None
 d = tempfile.mkdtemp(prefix="emuhits")
 g = synth.make_genome(23, 1_500_000, n_contigs=2, repeat_frac=0.75, max_copies=900, repeat_len=(300, 1500), max_divergence=0.02)
 synth.write_fasta(d + "/g.fa", g)
@@ -30,6 +31,8 @@ rix = ref.RefIndex(d + "/idx")
 bad_total = 0
 for tag, pkw in (("n8", {}), ("coverage", dict(num_seeds=0, seed_coverage=4.0)), ("narrow", dict(min_spacing=50, max_spacing=350, num_seeds=12)),
                  ("indels", dict(num_seeds=16))):
+    if only and tag != only:
+        continue
     # "indels": deletions of 2 .. 30 bases in most reads, so that seeds either side of one hit 2 .. 30 apart: the seed-hinted indel limits of Phase 2a
     pairs = synth.make_pairs(7 + len(tag), g, n, 150, long_indel_frac=0.8 if tag == "indels" else 0.0, long_indel_max=30)
     params, pparams = abi.default_params(max_k=12 if tag == "indels" else 8, max_read_len=160), abi.default_paired_params(**pkw)

@@ -1602,7 +1602,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         }
         if (score1 != -1 && score2 != -1) {
             *score = score1 + score2;
-            *mp = mp1 * mp2 * tab->seed_prob;
+            *mp = mp1 * mp2 * tab->seed_prob_pow;             // :907: pow(double, unsigned) -- libm's pow, not the powi of :1314 (dev_common.h: DevTables)
             *ag_score = ag1 + ag2;
         } else {
             *score = -1; *ag_score = -1; *mp = 0.0;

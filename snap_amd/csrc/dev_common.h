@@ -81,7 +81,11 @@ struct DevTables {
     double indel[N_INDEL_PROB];      // lv_indelProbabilities
     double perfect[N_PERFECT_PROB];  // lv_perfectMatchProbability
     double mapq_threshold[72];       // x <= mapq_threshold[m]  <=>  (int)(-10*log10(x)) >= m  (host log10)
-    double seed_prob;                // pow(1 - SNP_PROB, seedLen), BaseAligner.cpp:1314
+    double seed_prob;                // pow(1 - SNP_PROB, seedLen) where seedLen is an int: std::pow(double, int) == __builtin_powi in the reference's C++98
+                                     // build (BaseAligner.cpp:1314 after :1141, IntersectingPairedEndAligner.cpp:3272 / :3379 / :3487 after their local `int seedLen`)
+    double seed_prob_pow;            // the same expression where seedLen is the `unsigned` MEMBER (BaseAligner.cpp:907, BaseAligner.h:434): that call goes
+                                     // to the promoting template, i.e. libm's pow(double, double) -- one ulp away at seed 20 (0x1.f5db509cb1434p-1 against
+                                     // ...435p-1), which decides ties between equally good candidates of BaseAligner::alignAffineGap
     uint32_t wrapped_seed[33];       // GetWrappedNextSeedToTest(seedLen, wrapCount), SeedSequencer.cpp:36-109
 };
 

@@ -862,7 +862,12 @@ struct PairedCore {
 
         // ---- Phase 2a: seed-hinted indels raise the limit for candidates that sit close together (:743-801); not in alignHamming
         PT2_T0();
-        if (!hamming && PL::FAST_HITSET) {
+#if defined(SNAPGPU_WAVE_EMU)
+        const bool dbg_seq_hints = getenv("SNAPGPU_DEBUG_SEQ_HINTS") != nullptr;      // (emulator: the reference's two-pointer loops instead of the closed form)
+#else
+        const bool dbg_seq_hints = false;
+#endif
+        if (!hamming && PL::FAST_HITSET && !dbg_seq_hints) {
             // (each list is strictly descending, which gives the loops below a closed form: paired_dev.h: hint_indels)
             for (int sp = 0; sp < 2; sp++) pl.hint_indels(mate[sp], 0u, n_mate[sp], cfg.max_k_for_indels);
             pl.hint_indels(cand, 0u, n_cand0, cfg.max_k_for_indels);

@@ -502,6 +502,7 @@ static void build_tables(DevTables &t, unsigned seed_len) {
     t.perfect[0] = 1.0;
     for (int i = 1; i < N_PERFECT_PROB; i++) t.perfect[i] = t.perfect[i - 1] * (1 - SNP_PROB);
     t.seed_prob = powi_like_libgcc(1 - SNP_PROB, (int)seed_len);
+    t.seed_prob_pow = pow(1 - SNP_PROB, (double)seed_len);      // (host libm, as the reference's: see DevTables)
 
     // MAPQ thresholds: threshold[m] = largest x with (int)(-10*log10(x)) >= m, found by bisection
     // over the ordered bit patterns of positive doubles with the HOST log10 (mapq.h:53-59).

@@ -586,3 +586,9 @@ def test_emu_native_fastq_readers_agree(emu, tmp_path):
     for opts in ([],):
         r = subprocess.run([TOOL, "single", index_dir, bad, "-o", os.path.join(d, "bad.sam")] + opts, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=600, env=env)
         assert r.returncode != 0 and b"'+' line" in r.stdout
+
+
+def test_emu_hamming_fallback_tie_broken_by_the_seed_probability(emu):
+    """tests/test_gpu_paired.py's regression for BaseAligner.cpp:907 (libm pow against powi: one ulp that decides a 78-way tie) on the emulated device."""
+    import tests.test_gpu_paired as gp
+    gp.test_hamming_fallback_ties_are_broken_by_the_last_bit_of_the_seed_probability()

@@ -241,3 +241,36 @@ def test_paired_secondary_needs_both_enabled():
             a.align_secondary(np.zeros(200, np.uint8) + 65, np.zeros(200, np.uint8) + 70, np.array([0, 100, 200], np.uint64))
     finally:
         a.close()
+
+
+def test_hamming_fallback_ties_are_broken_by_the_last_bit_of_the_seed_probability():
+    """A pair found in round 5 by scripts/emu_paired_hits_check.py (a genome of high-copy repeats, reads with long deletions): the chimeric
+    fallback's Hamming retry keeps 78 candidates that BaseAligner::alignAffineGap rescores to the same score, and which of them wins is
+    decided by the LAST BIT of the match probability -- where BaseAligner::scoreLocationWithAffineGap's `pow(1 - SNP_PROB, seedLen)`
+    (BaseAligner.cpp:907: seedLen is the unsigned member there, so libm's pow) is one ulp below the `pow(double, int)` = powi of
+    BaseAligner.cpp:1314.  tests/golden/hamming_tie_pair.npz holds the pair; the genome is regenerated from its seed, the expectation is the
+    compiled reference with fresh aligner objects."""
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not on this box")
+    import shutil
+    import tempfile
+    from snap_amd.aligner import ChimericPairedEndAligner
+    from snap_amd.index import GenomeIndex
+    z = np.load(os.path.join(util.GOLDEN, "hamming_tie_pair.npz"))
+    d = tempfile.mkdtemp(prefix="hamtie")
+    try:
+        g = synth.make_genome(23, 1_500_000, n_contigs=2, repeat_frac=0.75, max_copies=900, repeat_len=(300, 1500), max_divergence=0.02)
+        synth.write_fasta(d + "/g.fa", g)
+        ref.build_index(d + "/g.fa", d + "/idx", 20, threads=8)
+        params, pparams = abi.default_params(max_k=12, max_read_len=160), abi.default_paired_params(num_seeds=16)
+        with ref.fresh_objects():
+            exp = ref.RefIndex(d + "/idx").align_paired(params, pparams, z["b"], z["q"], z["o"], threads=1, stage=0)[0]
+        assert exp["aligned_as_pair"][0] == 0 and exp["status"][0][1] == 2 and exp["location"][0][1] == 1429937        # the case is the case
+        a = ChimericPairedEndAligner(GenomeIndex.load_from_directory(d + "/idx"), params, pparams)
+        try:
+            got, _ = a.align(z["b"], z["q"], z["o"])
+        finally:
+            a.close()
+        assert not compare_paired(exp, got, verbose=3).any()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
