@@ -524,23 +524,24 @@ static __device__ __forceinline__ AGCOut agc_banded_par(const AGCState &s, int p
 // is computed here as before.  The loop below is agc_banded with num_vec == 1, value for value.
 struct SamfPre { int32_t valid, plen, w, bcb; int64_t loc; int32_t score, text_used, dir, rows, pad0, pad1; };
 static_assert(sizeof(SamfPre) == 48, "SamfPre layout");
-#define SAMF_PRE_ROW 16
+#define SAMF_PRE_ROW 32                      // traceback bytes a row can evaluate: two segments x two vectors x 8
 static __host__ __device__ __forceinline__ uint32_t samf_pre_rows(uint32_t RL) { return RL + 16; }
 static __host__ __device__ __forceinline__ size_t samf_pre_stride(uint32_t RL) { return (sizeof(SamfPre) + (size_t)samf_pre_rows(RL) * SAMF_PRE_ROW + 63) & ~(size_t)63; }
-#define SAMF_PRE_MAX_W 3                     // 2 w + 1 <= 8: one vector per segment
+#define SAMF_PRE_MAX_W 7                     // 2 w + 1 <= 16: at most two vectors per segment
 
 // the rest of computeGlobalScoreBanded for a call whose row loop k_samf_dp8 has run
 static __device__ __forceinline__ AGCOut agc_from_pre(const AGCState &s, int plen, int w, const SamfPre *pre, bool use_m, uint32_t *ops, int ops_cap)
 {
     const int text_used = (int)first_u32((uint32_t)pre->text_used);
     const uint8_t *bt = (const uint8_t *)(pre + 1);
+    const int bw = 2 * w + 1 < plen ? 2 * w + 1 : plen, nv = (bw + 7) >> 3, seg_len = nv * 8;
     EMU_STAT(42, 1);
     auto cell = [&](int row, int col, bool *evaluated) -> int {                 // (per lane)
         const int bb = row - w > 0 ? row - w : 0, be = row + w < plen - 1 ? row + w : plen - 1;
-        const int sg = col >> 3;
-        *evaluated = sg >= (bb >> 3) && sg <= (be >> 3) && (sg << 3) <= be;
+        const int sg = col / seg_len, v = (col % seg_len) % nv;
+        *evaluated = sg >= bb / seg_len && sg <= be / seg_len && sg * seg_len + v <= be;
         if (!*evaluated) return 0;
-        return (int)bt[(size_t)row * SAMF_PRE_ROW + (size_t)((sg - (bb >> 3)) << 3) + (size_t)(col & 7)];
+        return (int)bt[(size_t)row * SAMF_PRE_ROW + (size_t)((sg - bb / seg_len) * seg_len + v * 8 + (col % seg_len) / nv)];
     };
     return agc_traceback_and_emit(s, plen, text_used, use_m, cell, ops, ops_cap);
 }

@@ -133,10 +133,11 @@ extern "C" void snapgpu_launch_sam_fields(const SamFieldsArgs *a, uint32_t block
 
 // ---- the banded row loops of a batch's records, eight reads to a wavefront (cigar_ag.h: SamfPre) -------------------------------------------
 // One read per 8-lane group g = lane / 8, lane el = lane % 8 = the SSE element.  A group takes part when its read's FIRST affine-gap cigar call
-// (sam_fields_single_item's attempt 0 -> cigar_ag_item's pass 0) is a banded call with one vector per segment and nothing unusual about it;
-// what it computes is agc_banded (cigar_ag.h) with num_vec == 1: the same operations on the same values, in the reference's order.
+// (sam_fields_single_item's attempt 0 -> cigar_ag_item's pass 0) is a banded call with at most two vectors per segment (edit distance <= 7)
+// and nothing unusual about it; what it computes is agc_banded (cigar_ag.h) with the group's lanes as the eight lanes that store: the same
+// operations on the same values, in the reference's order (a segment's vectors one after the other, as the SSE code visits them).
 // LDS per group: the oriented, clipped read; the reference text the rows need; H of the previous row, H of this row, E (int16 per position).
-static __host__ __device__ __forceinline__ uint32_t samf_dp8_hn(uint32_t RL) { return (RL + 7u) & ~7u; }
+static __host__ __device__ __forceinline__ uint32_t samf_dp8_hn(uint32_t RL) { return (RL + 15u) & ~15u; }
 static __host__ __device__ __forceinline__ uint32_t samf_dp8_group_bytes(uint32_t RL) {
     return ((RL + 15u) & ~15u) + ((samf_pre_rows(RL) + 15u) & ~15u) + 3u * 2u * samf_dp8_hn(RL);
 }
@@ -191,6 +192,9 @@ __global__ __launch_bounds__(256) void k_samf_dp8(SamFieldsArgs a)
         const int rows_cap = (int)samf_pre_rows(RL);
         if (el == 0 && r < a.n) pre->valid = 0;
         if (!BALLOT(elig)) continue;
+        // the group's shape: vectors per segment (1 or 2), segment length, segments
+        const int bw = 2 * w + 1 < plen ? 2 * w + 1 : plen;
+        const int nv = elig ? (bw + 7) >> 3 : 1, seg_len = nv * 8, num_seg = elig ? (plen + seg_len - 1) / seg_len : 0;
         // ---- stage the group's read (as SAM prints it, clipped) and reference text
         {
             // (loop bounds are the wave's maximum over the eligible groups, so that the wave's control flow stays uniform)
@@ -209,17 +213,18 @@ __global__ __launch_bounds__(256) void k_samf_dp8(SamFieldsArgs a)
             }
         }
         // ---- first row (AffineGapVectorized.cpp:611-628): a lane's scoreFirstRow keeps its last value past the pattern's end
-        const int num_seg = (plen + 7) >> 3;
         {
             int sfr = 0;
-            int ns_top = elig ? num_seg : 0;
+            int ns_top = num_seg;
             for (int o = 32; o >= 1; o >>= 1) { const int t = __shfl_xor(ns_top, o); ns_top = t > ns_top ? t : ns_top; }
             ns_top = (int)first_u32((uint32_t)ns_top);
             for (int sg = 0; sg < ns_top; sg++) {
-                const int p = sg * 8 + el;
-                if (elig && sg < num_seg) {
-                    if (p < plen) { const int x = score_init - (open + p * ext); sfr = x > 0 ? x : 0; }
-                    Hb[p] = (int16_t)sfr; Hb[HN + p] = 0; E[p] = 0;
+                for (int v = 0; v < 2; v++) {
+                    if (elig && sg < num_seg && v < nv) {
+                        const int p = sg * seg_len + el * nv + v, x8 = (sg * nv + v) * 8 + el;
+                        if (p < plen) { const int x = score_init - (open + p * ext); sfr = x > 0 ? x : 0; }
+                        Hb[x8] = (int16_t)sfr; Hb[HN + x8] = 0; E[x8] = 0;
+                    }
                 }
             }
         }
@@ -236,39 +241,46 @@ __global__ __launch_bounds__(256) void k_samf_dp8(SamFieldsArgs a)
             int f = 0, X = 0;
             const int band_beg = i - w > 0 ? i - w : 0;
             const int band_end = i + w < plen - 1 ? i + w : plen - 1;
-            const int seg_beg = band_beg >> 3, seg_end = band_end >> 3;
+            const int seg_beg = band_beg / seg_len, seg_end = band_end / seg_len;
             for (int jj = 0; jj < 2; jj++) {
                 const int j = seg_beg + jj;
                 const bool act = going && j <= seg_end;
-                const int vi = act ? j * 8 + el : el;
-                // diagonal input: the previous row's H one element down; element 0 takes h_init (:639-657)
-                int h = __shfl_up(act ? (int)Hp[vi] : 0, 1);
+                // diagonal input: the previous row's H of the segment's LAST vector one element down; element 0 takes h_init (:639-657)
+                int h = __shfl_up(act ? (int)Hp[(j * nv + nv - 1) * 8 + el] : 0, 1);
                 if (el == 0) {
                     if (j == 0) h = (int)(int16_t)(i > 0 ? score_init - (open + (i - 1) * ext) : score_init);
-                    else if (band_beg > j * 8) h = 0;
-                    else h = act ? (int)Hp[j * 8 - 1] : 0;
+                    else if (band_beg > j * seg_len) h = 0;
+                    else h = act ? (int)Hp[(j * nv - 1) * 8 + 7] : 0;
                 }
-                int prof;
-                {
-                    const int p = j * 8 + el;
-                    if (!act || p >= plen) prof = -32768;
-                    else { const int pb = (int)base_value(pat[p]); prof = (tb > 3 || pb > 3) ? -1 : (tb == pb ? a.prm.match : a.prm.sub); }
+                int hv[2] = {0, 0}, btk[2] = {0, 0};
+                bool ka[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {                               // first pass over the segment's vectors (:659-735)
+                    ka[k] = act && k < nv && j * seg_len + k <= band_end;
+                    if (ka[k]) {
+                        const int vi = (j * nv + k) * 8 + el, p = j * seg_len + el * nv + k;
+                        int prof;
+                        if (p >= plen) prof = -32768;
+                        else { const int pb = (int)base_value(pat[p]); prof = (tb > 3 || pb > 3) ? -1 : (tb == pb ? a.prm.match : a.prm.sub); }
+                        const int m = agc_sat(h + prof);
+                        int e = (int)E[vi];
+                        int bt = e > m ? 1 : 0;
+                        int hh = m > e ? m : e;
+                        { const int t = f > hh ? 2 : 0; bt = t | (bt & ~t); }
+                        hh = hh > f ? hh : f;
+                        const int hnext = (int)Hp[vi];
+                        e = agc_sat(e - ext);
+                        const int temp = agc_sat(m - open);
+                        if (e > temp) bt |= 4;
+                        e = e > temp ? e : temp;
+                        E[vi] = (int16_t)e;
+                        f = agc_sat(f - ext);
+                        if (f > temp) bt |= 32;
+                        f = f > temp ? f : temp;
+                        hv[k] = hh; btk[k] = bt; h = hnext;
+                    }
                 }
-                const int m = agc_sat(h + prof);
-                int e = act ? (int)E[vi] : 0;
-                int bt = e > m ? 1 : 0;
-                int hv = m > e ? m : e;
-                { const int t = f > hv ? 2 : 0; bt = t | (bt & ~t); }
-                hv = hv > f ? hv : f;
-                e = agc_sat(e - ext);
-                const int temp = agc_sat(m - open);
-                if (e > temp) bt |= 4;
-                e = e > temp ? e : temp;
-                if (act) E[vi] = (int16_t)e;
-                f = agc_sat(f - ext);
-                if (f > temp) bt |= 32;
-                f = f > temp ? f : temp;
-                // lazy F (:737-781): up to seven rounds, each stops at the first (here: the only) vector in which no element's F goes on
+                // lazy F (:737-781): up to seven rounds; a round stops after the first vector in which no element's F goes on
                 bool lz = act;
                 for (int kk = 0; kk < 7; kk++) {
                     if (!BALLOT(lz)) break;
@@ -276,26 +288,36 @@ __global__ __launch_bounds__(256) void k_samf_dp8(SamFieldsArgs a)
                     int fin = __shfl_up(f, 1);
                     if (lz) {
                         X = X > f7 ? X : f7;
-                        if (el == 0) fin = 0;
-                        { const int t = fin > hv ? 2 : 0; bt = t | (bt & ~t); }
-                        hv = hv > fin ? hv : fin;
-                        const int temp2 = agc_sat(hv - open);
-                        fin = agc_sat(fin - ext);
-                        if (fin > temp2) bt |= 32;
-                        f = fin;
+                        f = el == 0 ? 0 : fin;
                     }
-                    const bool cont = lz && f > agc_sat(hv - open);
-                    if ((BALLOT(cont) & gmask) == 0ull) lz = false;
+#pragma unroll
+                    for (int v = 0; v < 2; v++) {
+                        const bool kv = lz && ka[v];
+                        if (kv) {
+                            int hh = hv[v], bt = btk[v];
+                            { const int t = f > hh ? 2 : 0; bt = t | (bt & ~t); }
+                            hh = hh > f ? hh : f;
+                            const int temp = agc_sat(hh - open);
+                            f = agc_sat(f - ext);
+                            if (f > temp) bt |= 32;
+                            hv[v] = hh; btk[v] = bt;
+                        }
+                        const bool cont = kv && f > agc_sat(hv[v] - open);
+                        const unsigned long long cm = BALLOT(cont);
+                        if (kv && (cm & gmask) == 0ull) lz = false;         // (the vectors after it are not touched in this round, nor in any round after)
+                    }
                 }
                 if (act) {
-                    Hm[vi] = (int16_t)hv;
-                    btout[(size_t)i * SAMF_PRE_ROW + (size_t)(jj * 8 + el)] = (uint8_t)bt;
+#pragma unroll
+                    for (int k = 0; k < 2; k++)
+                        if (ka[k]) { Hm[(j * nv + k) * 8 + el] = (int16_t)hv[k]; btout[(size_t)i * SAMF_PRE_ROW + (size_t)(jj * seg_len + k * 8 + el)] = (uint8_t)btk[k]; }
                     f = el == 0 ? X : 0;                                    // :783
                 }
             }
             WAVE_SYNC();
             if (going && band_end == plen - 1) {                            // :803-815
-                const int gsc = (int)Hm[(band_end >> 3) * 8 + (band_end & 7)];
+                const int vec = (band_end / seg_len) * nv + (band_end % seg_len) % nv, e_i = (band_end % seg_len) / nv;
+                const int gsc = (int)Hm[vec * 8 + e_i];
                 if (gsc > score) { score = gsc; text_used = i; }
             }
             cur ^= 1;

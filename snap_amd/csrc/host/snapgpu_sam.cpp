@@ -256,6 +256,7 @@ struct Options {
     bool use_m = true;                                                     // AlignerOptions.cpp:58
     unsigned min_read_len = 50;                                            // -mrl
     size_t batch_reads = 0;                                                // -b; 0 = auto (main)
+    size_t group = 0;                                                      // -g: single-end batches per GPU call (0 = auto: up to ~1 M reads)
     bool clip_front = false, clip_back = true;                             // -C-+ (ClipBack) is the default
     int om = -1, mpc = -1; long long omax = 0x7fffffff;
     bool ae = false;                                                       // -ae: AlignmentAdjuster before the -om filter (single end only)
@@ -299,6 +300,17 @@ template <class T> struct Queue {            // bounded multi-producer multi-con
         std::unique_lock<std::mutex> l(m); not_empty.wait(l, [&] { return !q.empty() || closed; });
         if (q.empty()) return false;
         v = std::move(q.front()); q.pop_front(); not_full.notify_one(); return true;
+    }
+    // up to `want` items: waits for the first; takes what else is there, and waits a little (`grace`) for the rest while producers are alive
+    size_t pop_upto(std::vector<T> &out, size_t want, std::chrono::milliseconds grace) {
+        std::unique_lock<std::mutex> l(m); not_empty.wait(l, [&] { return !q.empty() || closed; });
+        const auto until = std::chrono::steady_clock::now() + grace;
+        for (;;) {
+            while (!q.empty() && out.size() < want) { out.push_back(std::move(q.front())); q.pop_front(); not_full.notify_one(); }
+            if (out.size() >= want || closed || out.empty()) break;
+            if (not_empty.wait_until(l, until, [&] { return !q.empty() || closed; }) == false) break;
+        }
+        return out.size();
     }
     void close() { std::lock_guard<std::mutex> l(m); closed = true; not_empty.notify_all(); }
 };
@@ -679,6 +691,68 @@ static void gpu_single(const Options &o, FeederCtx &fc, Work &w)
     });
     lap(g_ns_samcall);
     for (size_t r = 0; r < nr; r++) if (w.rec_secondary[r]) w.flag[r] |= 0x100;                  // SAM_SECONDARY (createSAMLine, SAM.cpp:1477-1479)
+}
+
+// Several batches in ONE GPU call.  The host stages want fine grain -- a batch is parsed by one thread and formatted by one thread, so the
+// pipeline fills and drains in the time ONE batch takes -- and the GPU wants ~1 M reads per launch (a launch ends on its slowest read).
+// So the batches stay small (131 072 reads) and a feeder hands `-g` of them to snapgpu_align_sam_single as one batch: inputs gathered into
+// the feeder's own buffers, outputs scattered back to the batches they belong to, which then go on to the formatters separately.
+// Anything but the one-call path (secondary results, -ae, a first-ALT record in the group) is done batch by batch as before.
+struct GroupBuf {
+    std::vector<char> b, q; std::vector<uint64_t> off; std::vector<int32_t> fc, dl, flag, contig, mapq, n_ops, nm, stale; std::vector<uint8_t> skip;
+    std::vector<int64_t> pos; std::vector<uint32_t> ops; std::vector<snapgpu_single_result> res, alt;
+};
+static void gpu_single_group(const Options &o, FeederCtx &fc, std::vector<Work *> &ws, GroupBuf &g)
+{
+    const bool fusable = o.om < 0 && !o.ae;
+    if (ws.size() == 1 || !fusable) { for (Work *w : ws) gpu_single(o, fc, *w); return; }
+    auto t_stage = std::chrono::steady_clock::now();
+    auto lap = [&](std::atomic<unsigned long long> &acc) { const auto t = std::chrono::steady_clock::now(); acc += (unsigned long long)std::chrono::duration_cast<std::chrono::nanoseconds>(t - t_stage).count(); t_stage = t; };
+    size_t n = 0, nbytes = 0; uint32_t max_len = 0;
+    for (Work *w : ws) { if (!w->prepared) prepare_single(o, *w); n += w->b.n(); nbytes += w->b.bases.size(); if (w->max_len > max_len) max_len = w->max_len; }
+    if (n == 0) { for (Work *w : ws) gpu_single(o, fc, *w); return; }
+    snapgpu_ctx *ctx = ctx_for(o, fc, max_len);
+    g.b.resize(nbytes); g.q.resize(nbytes); g.off.resize(n + 1); g.fc.resize(n); g.dl.resize(n); g.skip.resize(n);
+    size_t at = 0, ab = 0;
+    for (Work *w : ws) {
+        const Batch &b = w->b; const size_t m = b.n();
+        memcpy(g.b.data() + ab, b.bases.data(), b.bases.size()); memcpy(g.q.data() + ab, b.quals.data(), b.quals.size());
+        for (size_t i = 0; i < m; i++) g.off[at + i] = b.offsets[i] + ab;
+        memcpy(g.fc.data() + at, w->front_clip.data(), m * 4); memcpy(g.dl.data() + at, w->data_len.data(), m * 4); memcpy(g.skip.data() + at, w->skip.data(), m);
+        at += m; ab += b.bases.size();
+    }
+    g.off[n] = ab;
+    const bool want_alt = o.p.alt_awareness && g_index_has_alt;
+    if (want_alt) { g.res.resize(n); g.alt.resize(n); }
+    g.flag.resize(n); g.contig.resize(n); g.mapq.resize(n); g.n_ops.resize(n); g.nm.resize(n); g.stale.resize(n); g.pos.resize(n);
+    uint32_t stride = o.ops_stride;
+    lap(g_ns_prep);
+    for (;;) {
+        g.ops.assign(n * (size_t)stride, 0);
+        const int rc = snapgpu_align_sam_single(ctx, (uint32_t)n, g.b.data(), g.q.data(), g.off.data(), g.fc.data(), g.dl.data(), g.skip.data(), o.use_m ? 1 : 0,
+                                                want_alt ? g.res.data() : NULL, want_alt ? g.alt.data() : NULL,
+                                                g.flag.data(), g.contig.data(), g.pos.data(), g.mapq.data(), g.ops.data(), stride, g.n_ops.data(), g.nm.data(), g.stale.data());
+        if (rc != SNAPGPU_OK) fail_rc(ctx, "snapgpu_align_sam_single", rc);
+        bool too_small = false;
+        for (size_t i = 0; i < n && !too_small; i++) too_small = g.nm[i] == -2;
+        if (!too_small) break;
+        if (stride >= 4096) die("a cigar needs more than 4096 operations");
+        stride *= 4;
+    }
+    lap(g_ns_align);
+    if (want_alt) for (size_t i = 0; i < n; i++) if (!g.skip[i] && g.alt[i].status != SNAPGPU_NotFound) { for (Work *w : ws) gpu_single(o, fc, *w); return; }   // (rare: ALT records: batch by batch)
+    at = 0;
+    for (Work *w : ws) {
+        const size_t m = w->b.n();
+        w->rec_read.resize(m); for (size_t i = 0; i < m; i++) w->rec_read[i] = (uint32_t)i;
+        w->rec_secondary.assign(m, 0);
+        w->flag.assign(g.flag.begin() + (long)at, g.flag.begin() + (long)(at + m)); w->contig.assign(g.contig.begin() + (long)at, g.contig.begin() + (long)(at + m));
+        w->mapq.assign(g.mapq.begin() + (long)at, g.mapq.begin() + (long)(at + m)); w->n_ops.assign(g.n_ops.begin() + (long)at, g.n_ops.begin() + (long)(at + m));
+        w->nm.assign(g.nm.begin() + (long)at, g.nm.begin() + (long)(at + m)); w->pos.assign(g.pos.begin() + (long)at, g.pos.begin() + (long)(at + m));
+        w->ops_stride = stride; w->ops.assign(g.ops.begin() + (long)(at * stride), g.ops.begin() + (long)((at + m) * stride));
+        at += m;
+    }
+    lap(g_ns_mid);
 }
 
 static void gpu_paired(const Options &o, FeederCtx &fc, Work &w)
@@ -1163,6 +1237,7 @@ int main(int argc, char **argv)
         else if (a == "-D" && i + 1 < argc) o.p.extra_search_depth = (uint32_t)atoi(argv[++i]);
         else if (a == "-mrl" && i + 1 < argc) o.min_read_len = (unsigned)atoi(argv[++i]);
         else if (a == "-b" && i + 1 < argc) o.batch_reads = (size_t)atoll(argv[++i]);
+        else if (a == "-g" && i + 1 < argc) o.group = (size_t)atoll(argv[++i]);
         else if (a == "-gpus" && i + 1 < argc) o.n_gpus = atoi(argv[++i]);
         else if (a == "-q" && i + 1 < argc) o.ctx_per_gpu = atoi(argv[++i]);
         else if (a == "-t" && i + 1 < argc) o.n_format = atoi(argv[++i]);  // host threads that format records (the reference's -t counts aligner threads)
@@ -1266,7 +1341,11 @@ int main(int argc, char **argv)
 
     const auto t_ready = std::chrono::steady_clock::now();                  // the index is resident, the contexts exist: the streaming part starts here
     // ---- the pipeline
-    Queue<Work *> q_parsed(fctx.size() * 2 + 2), q_aligned((size_t)o.n_format * 2 + 2);
+    // single-end batches per GPU call: enough to make ~1 M reads, but never so many that the feeders of a small file have nothing to share
+    size_t group = o.group ? o.group : (o.paired ? 1 : 8);
+    if (group < 1) group = 1;
+    if (group > 64) group = 64;
+    Queue<Work *> q_parsed(fctx.size() * (o.paired ? 2 : group + 2) + 2), q_aligned((size_t)o.n_format * 2 + 2 + group * fctx.size());
     std::mutex done_m; std::condition_variable done_cv; std::map<uint64_t, Work *> done;
     std::atomic<uint64_t> n_batches(0); std::atomic<bool> reader_done(false);
     unsigned long long total = 0, mapped = 0;
@@ -1286,13 +1365,11 @@ int main(int argc, char **argv)
     std::thread reader;
     if (use_map) {
         const uint64_t n_records = mf.n_lines / 4;
-        if (batch_auto) {       // enough batches to keep every feeder busy (four each), each as large as that allows: 64 K .. 1 M reads (pairs: .. 512 K reads)
-            const uint64_t total_reads = o.paired ? 2 * n_records : n_records;
-            uint64_t v = total_reads / (4 * (uint64_t)fctx.size());
-            const uint64_t cap = o.paired ? 524288 : 1048576;
-            v = v < 65536 ? 65536 : (v > cap ? cap : v);
+        if (batch_auto && o.paired) {       // enough batches to keep every feeder busy (four each), each as large as that allows: 64 K .. 512 K reads
+            uint64_t v = 2 * n_records / (4 * (uint64_t)fctx.size());
+            v = v < 65536 ? 65536 : (v > 524288 ? 524288 : v);
             o.batch_reads = (size_t)(v & ~(uint64_t)1);
-        }
+        } else if (batch_auto) o.batch_reads = 131072;       // (single end: small batches for the host stages, grouped for the GPU: gpu_single_group)
         const uint64_t per_batch = o.paired ? o.batch_reads / 2 : o.batch_reads;           // records of EACH file per batch
         const uint64_t n_units = (n_records + per_batch - 1) / per_batch;
         n_batches = n_units; reader_done = true;
@@ -1346,8 +1423,18 @@ int main(int argc, char **argv)
     std::atomic<int> feeders_left((int)fctx.size());
     for (size_t t = 0; t < fctx.size(); t++)
         feeders.emplace_back([&, t] {
-            Work *w;
-            while (q_parsed.pop(w)) { if (o.paired) gpu_paired(o, fctx[t], *w); else gpu_single(o, fctx[t], *w); q_aligned.push(w); }
+            if (o.paired) {
+                Work *w;
+                while (q_parsed.pop(w)) { gpu_paired(o, fctx[t], *w); q_aligned.push(w); }
+            } else {
+                GroupBuf gb; std::vector<Work *> ws;
+                for (;;) {
+                    ws.clear();
+                    if (q_parsed.pop_upto(ws, group, std::chrono::milliseconds(20)) == 0) break;
+                    gpu_single_group(o, fctx[t], ws, gb);
+                    for (Work *w : ws) q_aligned.push(w);
+                }
+            }
             if (--feeders_left == 0) q_aligned.close();
         });
     for (int t = 0; t < o.n_format; t++)
