@@ -65,12 +65,13 @@ struct HostPL {
     static const bool SECONDARY = true;
     // (never called: the scalar definitions in paired.h are what the host runs)
     static void lds(const void *) {}
-    void hs_begin_walk(PELookup *, PEHitSetHdr *, int) {}
+    struct HSCursor {};
+    void hs_begin_walk(PELookup *, PEHitSetHdr *, int, uint32_t, HSCursor &) {}
     template <class R> void hint_indels(R *, uint32_t, uint32_t, int) {}
-    bool hs_first(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *, uint32_t) { return true; }
-    bool hs_next_lower(PELookup *, PEHitSetHdr *, int64_t *, uint32_t *, uint32_t) { return false; }
-    bool hs_next_le(PELookup *, PEHitSetHdr *, int64_t, int64_t *, uint32_t *, uint32_t) { return false; }
-    uint32_t hs_best_possible(PELookup *, PEHitSetHdr *, uint32_t *, uint32_t) { return 0; }
+    bool hs_first(HSCursor &, int64_t *, uint32_t *) { return true; }
+    bool hs_next_lower(HSCursor &, int64_t *, uint32_t *) { return false; }
+    bool hs_next_le(HSCursor &, int64_t, int64_t *, uint32_t *) { return false; }
+    uint32_t hs_best_possible(HSCursor &, uint32_t *) { return 0; }
 
     bool lookup(const uint8_t *text, PEHits out[2]) {
         uint64_t bases, rc;

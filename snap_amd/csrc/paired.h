@@ -93,10 +93,8 @@ struct PELookup {                      // HashTableLookup<unsigned>, Intersectin
     uint32_t singleton;
     uint32_t is_single;
     uint32_t which_disjoint;
-    int32_t  wbase;                    // device only: index of the first hit in this lookup's LDS window (paired_dev.h), -1 = nothing staged
-    uint32_t pad;
 };
-struct PEHitSetHdr { int64_t most_recent; uint32_t n_used; int32_t cur_disjoint; uint32_t win_role; uint32_t pad; };   // win_role: which LDS window block the set walks with (device)
+struct PEHitSetHdr { int64_t most_recent; uint32_t n_used; int32_t cur_disjoint; };
 
 struct PECand {                        // ScoringCandidate, .h:560-611
     int64_t  loc;                      // readWithFewerHitsGenomeLocation
@@ -269,8 +267,10 @@ struct PairedCore {
 #define PT2_ADD(f) ((void)0)
 #define PT2_OFF(x) x
 #endif
-    PE_FN bool hs_first(int s, int64_t *loc, uint32_t *seed_offset) {
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_first(lks(s), &HS()[s], loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
+    // (FAST_HITSET: the walk's cursors live in registers for the length of the walk -- PL::HSCursor, filled by hs_begin_walk; the lookups'
+    //  records in LDS are not written back: nothing reads a hit set after its walk)
+    PE_FN bool hs_first(int s, int64_t *loc, uint32_t *seed_offset, typename PL::HSCursor &c) {
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_first(c, loc, seed_offset); PT2_ADD(cyc_lookup); return r; }
         bool any = false;
         *loc = 0;
         const uint32_t n = ld(HS()[s].n_used);
@@ -286,8 +286,8 @@ struct PairedCore {
         return !any;
     }
 
-    PE_FN bool hs_next_lower(int s, int64_t *loc, uint32_t *seed_offset) {                              // getNextLowerHit, :3750-3816
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_lower(lks(s), &HS()[s], loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
+    PE_FN bool hs_next_lower(int s, int64_t *loc, uint32_t *seed_offset, typename PL::HSCursor &c) {     // getNextLowerHit, :3750-3816
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_lower(c, loc, seed_offset); PT2_ADD(cyc_lookup); return r; }
         int64_t found = 0;
         bool any = false;
         const uint32_t n = ld(HS()[s].n_used);
@@ -315,8 +315,8 @@ struct PairedCore {
         return any;
     }
 
-    PE_FN bool hs_next_le(int s, int64_t max_loc, int64_t *loc, uint32_t *seed_offset) {                // getNextHitLessThanOrEqualTo, :3628-3717
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_le(lks(s), &HS()[s], max_loc, loc, seed_offset, cfg.max_seeds); PT2_ADD(cyc_lookup); return r; }
+    PE_FN bool hs_next_le(int s, int64_t max_loc, int64_t *loc, uint32_t *seed_offset, typename PL::HSCursor &c) {   // getNextHitLessThanOrEqualTo, :3628-3717
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_le(c, max_loc, loc, seed_offset); PT2_ADD(cyc_lookup); return r; }
         bool any = false;
         int64_t best = 0;
         const uint32_t n = ld(HS()[s].n_used);
@@ -347,8 +347,8 @@ struct PairedCore {
         return any;
     }
 
-    PE_FN uint32_t hs_best_possible(int s) {                                                             // computeBestPossibleScoreForCurrentHit, :3585-3625
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const uint32_t r = pl.hs_best_possible(lks(s), &HS()[s], exh(s), cfg.max_seeds); PT2_ADD(cyc_lv); return r; }
+    PE_FN uint32_t hs_best_possible(int s, typename PL::HSCursor &c) {                                   // computeBestPossibleScoreForCurrentHit, :3585-3625
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const uint32_t r = pl.hs_best_possible(c, exh(s)); PT2_ADD(cyc_lv); return r; }
         const int cd = ld(HS()[s].cur_disjoint);
         for (int i = 0; i <= cd; i++) st(MISS()[i], ld(exh(s)[i]));
         const uint32_t n = ld(HS()[s].n_used);
@@ -801,20 +801,21 @@ struct PairedCore {
             bool out_of_more = false;
             int64_t last_mate_loc = 0;              // mate[sp][n_mate[sp] - 1].loc (the walk looks back at it in every step)
             if (sp == 1) n_cand0 = n_cand;
-            pl.hs_begin_walk(lks(s_fewer), &HS()[s_fewer], 0); pl.hs_begin_walk(lks(s_more), &HS()[s_more], 1);
-            if (hs_first(s_fewer, &loc_f, &so_f)) continue;
+            typename PL::HSCursor cf, cm;
+            pl.hs_begin_walk(lks(s_fewer), &HS()[s_fewer], 0, cfg.max_seeds, cf); pl.hs_begin_walk(lks(s_more), &HS()[s_more], 1, cfg.max_seeds, cm);
+            if (hs_first(s_fewer, &loc_f, &so_f, cf)) continue;
             for (;;) {
                 if (loc_m > loc_f + (int64_t)cfg.max_spacing) {
-                    if (!hs_next_le(s_more, loc_f + (int64_t)cfg.max_spacing, &loc_m, &so_m)) break;
+                    if (!hs_next_le(s_more, loc_f + (int64_t)cfg.max_spacing, &loc_m, &so_m, cm)) break;
                 }
                 if ((loc_m + (int64_t)cfg.max_spacing < loc_f || out_of_more) &&
                     (0 == n_mate[sp] || !within(last_mate_loc, loc_f, cfg.max_spacing))) {
                     if (out_of_more) break;
-                    if (!hs_next_le(s_fewer, loc_m + (int64_t)cfg.max_spacing, &loc_f, &so_f)) break;
+                    if (!hs_next_le(s_fewer, loc_m + (int64_t)cfg.max_spacing, &loc_f, &so_f, cf)) break;
                     continue;
                 }
                 while (loc_m + (int64_t)cfg.max_spacing >= loc_f && !out_of_more) {
-                    uint32_t bp = hs_best_possible(s_more);
+                    uint32_t bp = hs_best_possible(s_more, cm);
                     if (n_mate[sp] >= cfg.pool_size / 2) { overflow = 1; return; }
                     PT2_T0();
                     PEMate *m = &mate[sp][n_mate[sp]];
@@ -828,9 +829,9 @@ struct PairedCore {
                     last_mate_loc = loc_m;
                     n_mate[sp]++;
                     PT2_ADD(cyc_ag);
-                    if (!hs_next_lower(s_more, &loc_m, &so_m)) { loc_m = 0; out_of_more = true; break; }
+                    if (!hs_next_lower(s_more, &loc_m, &so_m, cm)) { loc_m = 0; out_of_more = true; break; }
                 }
-                const int bp_f = (int)hs_best_possible(s_fewer);
+                const int bp_f = (int)hs_best_possible(s_fewer, cf);
                 PT2_T0();
                 int lowest_mate = cfg.max_k + cfg.extra_depth;
                 for (int i = (int)n_mate[sp] - 1; i >= 0; i--) {
@@ -856,7 +857,7 @@ struct PairedCore {
                     if (list > max_used_list) max_used_list = list;
                 }
                 PT2_ADD(cyc_ag);
-                if (!hs_next_lower(s_fewer, &loc_f, &so_f)) break;
+                if (!hs_next_lower(s_fewer, &loc_f, &so_f, cf)) break;
             }
         }
 

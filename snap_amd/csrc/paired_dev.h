@@ -233,43 +233,48 @@ struct DevPL {
     // overflow table -- once per HS_W - 2 steps instead of waiting for one or two dependent HBM round trips in EVERY step (profiles/r05a: the
     // set intersection was 42 % of the paired kernel's wave cycles, ~3 600 cycles per hit).  Only the binary search of hs_next_le, which jumps,
     // probes the table directly.  Locations are 32-bit on the device (snapgpu.hip refuses larger genomes), so the arithmetic is too.
-    uint32_t hs_w;                     // HS_W: 16 where 2 x max_seeds x 16 words fit the Landau-Vishkin block, else 8
-    __device__ __forceinline__ uint32_t *hs_win(const PEHitSetHdr *h, uint32_t max_seeds) const {
-        uint32_t *blk = (uint32_t *)al->lv_tri; lds(blk);
-        return blk + 2 * PE_MRING + (size_t)ld(h->win_role) * max_seeds * hs_w + (size_t)lane_id() * hs_w;      // (lanes >= max_seeds never use theirs)
-    }
-    __device__ __forceinline__ void hs_begin_walk(PELookup *lk, PEHitSetHdr *h, int role) {
+    uint32_t hs_w;                     // HS_W: 16 where 2 x max_seeds x 16 words (+ the mate ring) fit the Landau-Vishkin block, else 8
+    // A walk's cursors, in REGISTERS for the length of the walk: lane n < n_used is lookup n of the set (its cursor, hit count, seed offset,
+    // disjoint group, where its list is and which part of it is staged), the header's words are wave-uniform scalars.  The queries used to
+    // re-read all of this from LDS -- eight loads and their waits per query, three queries per step -- and write `cur` / most_recent back.
+    struct HSCursor {
+        uint32_t cur, nh, so, wd, singleton; bool single, act;
+        int32_t wbase; const uint32_t *hits; uint32_t *win;      // per lane: staged window [wbase, wbase + hs_w) of hits[] (LDS)
+        uint32_t n_used, recent; int cd;                         // wave-uniform
+    };
+    __device__ __forceinline__ void hs_begin_walk(PELookup *lk, PEHitSetHdr *h, int role, uint32_t max_seeds, HSCursor &c) {
         const int lane = lane_id();
-        st(h->win_role, (uint32_t)role);
-        if (lane < (int)ld(h->n_used)) lk[lane].wbase = -1;
-        WAVE_SYNC();
+        c.n_used = ld(h->n_used); c.cd = ld(h->cur_disjoint); c.recent = 0u;
+        c.act = lane < (int)c.n_used;
+        const PELookup *l = &lk[c.act ? lane : 0];
+        c.cur = 0u; c.nh = c.act ? (uint32_t)l->n_hits : 0u; c.so = l->seed_offset; c.wd = l->which_disjoint;
+        c.single = l->is_single != 0; c.singleton = l->singleton; c.hits = l->hits; c.wbase = -1;
+        uint32_t *blk = (uint32_t *)al->lv_tri; lds(blk);
+        c.win = blk + 2 * PE_MRING + (size_t)role * max_seeds * hs_w + (size_t)(c.act ? lane : 0) * hs_w;
     }
     // window of lane's lookup covers hit indices [lo, hi] (already clamped to the list)?  If not, stage [lo, lo + HS_W) -- all the loads of
     // all the lanes that need one go out together, one wait.
-    template <int W> __device__ __forceinline__ void hs_stage_w(PELookup *l, uint32_t *win, bool need, uint32_t lo, uint32_t nh) {
+    template <int W> static __device__ __forceinline__ void hs_stage_w(HSCursor &c, bool need, uint32_t lo) {
         if (BALLOT(need)) {
             if (need) {
-                const uint32_t *src = l->hits + lo;
-                const uint32_t n = nh - lo;
+                const uint32_t *src = c.hits + lo;
+                const uint32_t n = c.nh - lo;
                 uint32_t v[W];
 #pragma unroll
                 for (int j = 0; j < W; j++) v[j] = src[(uint32_t)j < n ? (uint32_t)j : n - 1u];      // (n >= 1; entries past the list repeat its last hit and are never read)
 #pragma unroll
-                for (int j = 0; j < W; j++) win[j] = v[j];
-                l->wbase = (int32_t)lo;
+                for (int j = 0; j < W; j++) c.win[j] = v[j];
+                c.wbase = (int32_t)lo;
             }
             WAVE_SYNC();
         }
     }
-    __device__ __forceinline__ void hs_stage(PELookup *l, uint32_t *win, bool act, uint32_t lo, uint32_t hi, uint32_t nh) {
-        const int32_t wb = l->wbase;
-        const bool need = act && hi >= lo && !l->is_single && (wb < 0 || lo < (uint32_t)wb || hi >= (uint32_t)wb + hs_w);
-        if (hs_w == 16u) hs_stage_w<16>(l, win, need, lo, nh); else hs_stage_w<8>(l, win, need, lo, nh);
+    __device__ __forceinline__ void hs_stage(HSCursor &c, bool want, uint32_t lo, uint32_t hi) {
+        const bool need = want && hi >= lo && !c.single && (c.wbase < 0 || lo < (uint32_t)c.wbase || hi >= (uint32_t)c.wbase + hs_w);
+        if (hs_w == 16u) hs_stage_w<16>(c, need, lo); else hs_stage_w<8>(c, need, lo);
     }
     // hits[i] of lane's lookup; i must be inside the staged window (or the lookup a singleton)
-    static __device__ __forceinline__ uint32_t hs_get(const PELookup *l, const uint32_t *win, uint32_t i) {
-        return l->is_single ? l->singleton : win[i - (uint32_t)l->wbase];
-    }
+    static __device__ __forceinline__ uint32_t hs_get(const HSCursor &c, uint32_t i) { return c.single ? c.singleton : c.win[i - (uint32_t)c.wbase]; }
     // wave arg-max of v (> 0) over lanes with ok set; returns the winning lane (lowest lane among equals) or -1
     static __device__ __forceinline__ int wave_argmax32(bool ok, uint32_t v, uint32_t *best) {
         uint32_t m = ok ? v : 0u;
@@ -279,77 +284,51 @@ struct DevPL {
         *best = m;
         return who ? __ffsll((long long)who) - 1 : -1;
     }
-    __device__ __forceinline__ bool hs_first(PELookup *lk, PEHitSetHdr *h, int64_t *loc, uint32_t *seed_offset, uint32_t max_seeds) {
-        const int lane = lane_id();
-        const uint32_t n = ld(h->n_used);
-        PELookup *l = &lk[lane < (int)n ? lane : 0];
-        uint32_t *win = hs_win(h, max_seeds);
-        const uint32_t nh = (uint32_t)l->n_hits;
-        bool ok = lane < (int)n && nh > 0;
-        hs_stage(l, win, ok, 0u, nh > 1u ? 1u : 0u, nh);
-        const uint32_t so = l->seed_offset;
-        const uint32_t v = ok ? hs_get(l, win, 0u) - so : 0u;
+    __device__ __forceinline__ bool hs_first(HSCursor &c, int64_t *loc, uint32_t *seed_offset) {
+        bool ok = c.act && c.nh > 0u;
+        hs_stage(c, ok, 0u, c.nh > 1u ? 1u : 0u);
+        const uint32_t v = ok ? hs_get(c, 0u) - c.so : 0u;
         ok = ok && v > 0u;
         uint32_t best;
         const int w = wave_argmax32(ok, v, &best);
         *loc = 0;
         if (w < 0) return true;
         *loc = (int64_t)best;
-        *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)so, w);
-        st(h->most_recent, (int64_t)best);
+        *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)c.so, w);
+        c.recent = best;
         return false;
     }
-    __device__ __forceinline__ bool hs_next_lower(PELookup *lk, PEHitSetHdr *h, int64_t *loc, uint32_t *seed_offset, uint32_t max_seeds) {
-        const int lane = lane_id();
-        const uint32_t n = ld(h->n_used);
-        const uint32_t recent = (uint32_t)ld(h->most_recent);
-        PELookup *l = &lk[lane < (int)n ? lane : 0];
-        uint32_t *win = hs_win(h, max_seeds);
-        const bool act = lane < (int)n;
-        uint32_t cur = (uint32_t)l->cur;
-        const uint32_t nh = (uint32_t)l->n_hits;
-        const uint32_t so = l->seed_offset;
-        bool live = act && cur != nh;
-        hs_stage(l, win, live, cur > 0u ? cur - 1u : 0u, cur + 1u < nh ? cur + 1u : cur, nh);
-        uint32_t hv = live ? hs_get(l, win, cur) : 0u;
-        if (live && hv - so == recent) {
-            cur++;
-            l->cur = (int64_t)cur;
-            live = cur != nh;
-            if (live) hv = hs_get(l, win, cur);
+    __device__ __forceinline__ bool hs_next_lower(HSCursor &c, int64_t *loc, uint32_t *seed_offset) {
+        bool live = c.act && c.cur != c.nh;
+        hs_stage(c, live, c.cur > 0u ? c.cur - 1u : 0u, c.cur + 1u < c.nh ? c.cur + 1u : c.cur);
+        uint32_t hv = live ? hs_get(c, c.cur) : 0u;
+        if (live && hv - c.so == c.recent) {
+            c.cur++;
+            live = c.cur != c.nh;
+            if (live) hv = hs_get(c, c.cur);
         }
-        WAVE_SYNC();
-        const bool ok = live && hv >= so && hv - so > 0u;
+        const bool ok = live && hv >= c.so && hv - c.so > 0u;
         uint32_t best;
-        const int w = wave_argmax32(ok, hv - so, &best);
+        const int w = wave_argmax32(ok, hv - c.so, &best);
         if (w < 0) return false;
         *loc = (int64_t)best;
-        *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)so, w);
-        st(h->most_recent, (int64_t)best);
+        *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)c.so, w);
+        c.recent = best;
         return true;
     }
-    __device__ __forceinline__ bool hs_next_le(PELookup *lk, PEHitSetHdr *h, int64_t max_loc, int64_t *loc, uint32_t *seed_offset, uint32_t max_seeds) {
-        const int lane = lane_id();
-        const uint32_t n = ld(h->n_used);
-        PELookup *l = &lk[lane < (int)n ? lane : 0];
-        const uint32_t *win = hs_win(h, max_seeds);
-        const bool act = lane < (int)n;
-        const uint32_t so = l->seed_offset;
-        const int64_t max_this = max_loc + so;
-        const bool single = l->is_single != 0;
-        const int32_t wb = l->wbase;
+    __device__ __forceinline__ bool hs_next_le(HSCursor &c, int64_t max_loc, int64_t *loc, uint32_t *seed_offset) {
+        const int64_t max_this = max_loc + c.so;
         const uint32_t wcap = hs_w;
         // hits[i], from the window where it holds i (the answer is often a few hits further on), else from the table
         auto peek = [&](int64_t i) -> int64_t {
-            if (single) return (int64_t)l->singleton;
-            if (wb >= 0 && i >= (int64_t)wb && i < (int64_t)wb + (int64_t)wcap) return (int64_t)win[i - wb];
-            return (int64_t)l->hits[i];
+            if (c.single) return (int64_t)c.singleton;
+            if (c.wbase >= 0 && i >= (int64_t)c.wbase && i < (int64_t)c.wbase + (int64_t)wcap) return (int64_t)c.win[i - c.wbase];
+            return (int64_t)c.hits[i];
         };
-        int64_t lo = l->cur, hi = act ? l->n_hits - 1 : -1;
-        if (!act) lo = 0;
-        if (act && !single && wb >= 0) {                 // the last staged hit at or below the bound: the answer is inside the window
-            const int64_t wend = ((int64_t)wb + (int64_t)wcap < l->n_hits ? (int64_t)wb + (int64_t)wcap : l->n_hits) - 1;
-            if (wend >= lo && (int64_t)win[wend - wb] <= max_this) hi = wend;
+        int64_t lo = c.act ? (int64_t)c.cur : 0, hi = c.act ? (int64_t)c.nh - 1 : -1;
+        if (c.act && !c.single && c.wbase >= 0) {        // the last staged hit at or below the bound: the answer is inside the window
+            const int64_t wend = ((int64_t)c.wbase + (int64_t)wcap < (int64_t)c.nh ? (int64_t)c.wbase + (int64_t)wcap : (int64_t)c.nh) - 1;
+            if (wend >= lo && (int64_t)c.win[wend - c.wbase] <= max_this) hi = wend;
         }
         bool found = false;
         uint32_t v = 0;
@@ -358,41 +337,31 @@ struct DevPL {
                 const int64_t probe = (lo + hi) / 2;
                 const int64_t ph = peek(probe);
                 if (ph <= max_this && (probe == 0 || peek(probe - 1) > max_this)) {
-                    found = true; v = (uint32_t)ph - so;
-                    l->cur = probe;
+                    found = true; v = (uint32_t)ph - c.so;
+                    c.cur = (uint32_t)probe;
                 } else if (ph > max_this) lo = probe + 1; else hi = probe - 1;
             }
         }
-        if (act && !found) l->cur = l->n_hits;
-        WAVE_SYNC();
+        if (c.act && !found) c.cur = c.nh;
         uint32_t best;
         const int w = wave_argmax32(found && v > 0u, v, &best);
         if (w < 0) return false;
         *loc = (int64_t)best;
-        *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)so, w);
-        st(h->most_recent, (int64_t)best);
+        *seed_offset = (uint32_t)__builtin_amdgcn_readlane((int)c.so, w);
+        c.recent = best;
         return true;
     }
-    __device__ __forceinline__ uint32_t hs_best_possible(PELookup *lk, PEHitSetHdr *h, uint32_t *exhausted, uint32_t max_seeds) {
-        const int lane = lane_id();
-        const uint32_t n = ld(h->n_used);
-        const int cd = ld(h->cur_disjoint);
-        const int64_t recent = ld(h->most_recent);
-        PELookup *l = &lk[lane < (int)n ? lane : 0];
-        uint32_t *win = hs_win(h, max_seeds);
-        const bool act = lane < (int)n;
-        const uint32_t cur = (uint32_t)l->cur, nh = (uint32_t)l->n_hits;
-        const int64_t target = recent + l->seed_offset;
-        hs_stage(l, win, act && nh > 0u, cur > 0u ? cur - 1u : 0u, cur < nh ? cur : nh - 1u, nh);
+    __device__ __forceinline__ uint32_t hs_best_possible(HSCursor &c, uint32_t *exhausted) {
+        const int64_t target = (int64_t)c.recent + c.so;
+        hs_stage(c, c.act && c.nh > 0u, c.cur > 0u ? c.cur - 1u : 0u, c.cur < c.nh ? c.cur : c.nh - 1u);
         bool close = false;
-        if (act) {
-            if (cur != nh) { const int64_t a = (int64_t)hs_get(l, win, cur); const int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
-            if (!close && cur != 0u) { const int64_t a = (int64_t)hs_get(l, win, cur - 1u); const int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
+        if (c.act) {
+            if (c.cur != c.nh) { const int64_t a = (int64_t)hs_get(c, c.cur); const int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
+            if (!close && c.cur != 0u) { const int64_t a = (int64_t)hs_get(c, c.cur - 1u); const int64_t d = a > target ? a - target : target - a; close = d <= PE_MERGE_DIST; }
         }
-        const uint32_t wd = l->which_disjoint;
         uint32_t best = 0;
-        for (int d = 0; d <= cd; d++) {
-            uint32_t m = ld(exhausted[d]) + (uint32_t)__popcll(BALLOT(act && !close && wd == (uint32_t)d));
+        for (int d = 0; d <= c.cd; d++) {
+            uint32_t m = ld(exhausted[d]) + (uint32_t)__popcll(BALLOT(c.act && !close && c.wd == (uint32_t)d));
             if (m > best) best = m;
         }
         return best;
