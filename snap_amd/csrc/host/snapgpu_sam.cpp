@@ -1256,10 +1256,10 @@ int main(int argc, char **argv)
     // feeders per GPU: a launch lasts as long as its slowest read (~150 ms when the batch holds one of the heavy ones), so batches of 131 072
     // reads need several launches in flight to keep the chip busy: 20 M reads go through at 2.24 / 2.47 / 2.50 M reads/s with 3 / 6 / 8
     // feeders (profiles/r04zy).  The paired-end launches are long already.
-    // Round 5: a single-end batch is 1 M reads where the file has them (bench.py's launch size: the tail of a launch then costs 10 %, not
-    // half of it), goes through ONE call per batch (snapgpu_align_sam_single) and the 192-position kernel variant: four feeders cover the
-    // copies of one batch with the kernels of the others.
-    if (o.ctx_per_gpu == 0) o.ctx_per_gpu = o.paired ? 3 : 4;
+    // Round 5: the GPU gets ~1 M single-end reads per call (gpu_single_group: bench.py's launch size -- the tail of a launch then costs 10 %,
+    // not half of it) through ONE call (snapgpu_align_sam_single) and the 192-position kernel variant: three feeders cover the
+    // copies of one batch with the kernels of the others (20 M reads: 4.78 / 4.56 / 4.74 M reads/s with 3 / 4 / 6 feeders, profiles/r05g).
+    if (o.ctx_per_gpu == 0) o.ctx_per_gpu = 3;
     if (o.ctx_per_gpu < 1 || o.ctx_per_gpu > 8) die("-q must be in [1, 8]");
     // cigar ops per record: about 2 * edits + soft clips; grown on demand when a record needs more (with_growing_stride)
     { uint32_t need = 2 * (o.p.max_k + o.p.extra_search_depth) + 8; o.ops_stride = (need + 3u) & ~3u; if (o.ops_stride < 16) o.ops_stride = 16; }

@@ -322,7 +322,7 @@ struct DevPool {
     // Idle buffers are kept for the next call of a similar size, but not without bound: batches of varying size (a last short one, a retry
     // with a larger cigar stride, one-read calls of the host record loop) would otherwise leave gigabytes of per-wave scratch pinned next to
     // the index.  More than MAX_IDLE idle buffers, or more than MAX_IDLE_BYTES of them: the largest idle ones go.
-    static const size_t MAX_IDLE = 24, MAX_IDLE_BYTES = (size_t)6 << 30;
+    static const size_t MAX_IDLE = 24, MAX_IDLE_BYTES = (size_t)20 << 30;     // (a 1 M-read call of snapgpu_align_sam_single keeps ~8 GB: 5.9 GB of row-loop results among them)
     void release(void *p) {
         std::lock_guard<std::mutex> l(m);
         for (auto &s : slots) if (s.p == p) { s.busy = false; break; }
