@@ -141,7 +141,18 @@ def broadcast_index(index, device, src: int = 0, src_device_ptrs=None, chunk_byt
         item = 4 if dt == torch.int32 else 1
         host = None
         if is_src and src_device_ptrs is not None:
-            buf = torch.as_tensor(_DevicePtrArray(src_device_ptrs[k], n * item, "<i4" if item == 4 else "|u1", item), device=device)
+            try:
+                buf = torch.as_tensor(_DevicePtrArray(src_device_ptrs[k], n * item, "<i4" if item == 4 else "|u1", item), device=device)
+                if buf.data_ptr() != int(src_device_ptrs[k]) or buf.numel() != n:
+                    raise RuntimeError("torch.as_tensor copied the blob")
+            except Exception:          # noqa: BLE001 -- a torch build without the array interface: one device-to-device copy into a tensor of its own
+                import ctypes as C
+                buf = torch.empty(n, dtype=dt, device=device)
+                hip = C.CDLL("libamdhip64.so")
+                hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+                torch.cuda.synchronize()
+                if hip.hipMemcpy(C.c_void_p(buf.data_ptr()), C.c_void_p(int(src_device_ptrs[k])), C.c_size_t(n * item), 3) != 0:      # hipMemcpyDeviceToDevice
+                    raise RuntimeError("hipMemcpy of the index blob failed")
         else:
             buf = torch.empty(n, dtype=dt, device=device)
             if is_src:
