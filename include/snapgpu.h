@@ -631,8 +631,8 @@ int  snapgpu_get_counters(snapgpu_ctx *ctx, snapgpu_counters *out, int reset);
 int  snapgpu_kernel_time(snapgpu_ctx *ctx, double *total_ms, uint64_t *n_launches, int reset);
 
 /* ------------------------------------------------------------------------------------------------------------------------------
- * The index builder on the GPU.  Replaces, for the index shape the north star uses (4-byte locations, 4-byte
- * hash keys, small tables: `snap-aligner index <fasta> <dir> -s 16..24 [-keysize 4]`, in particular the default -s 20),
+ * The index builder on the GPU.  Replaces, for 4-byte locations and small tables -- the index shape the north star
+ * uses: `snap-aligner index <fasta> <dir> -s 8..31 [-keysize 2..8]`, in particular the default -s 20 and the reference's own default -s 24,
  *   GenomeIndex::runIndexer            SNAPLib/GenomeIndex.cpp:126-506   options, FASTA -> Genome
  *   ReadFASTAGenome                    SNAPLib/FASTA.cpp:188-409         contigs, 'n' padding, ALT contigs last, upper-casing
  *   GenomeIndex::BuildIndexToDirectory SNAPLib/GenomeIndex.cpp:527-1022  hash tables + overflow table, the four files

@@ -20,7 +20,7 @@ static void usage()
             "usage: snapgpu-index <input.fa> <output-dir> [options]\n"
             "  -s <n>              seed length (default 20; the reference's default is 24)\n"
             "  -h <slack>          hash table slack (default 0.3)\n"
-            "  -keysize <n>        hash key size in bytes (default: from the seed length; this builder writes key size 4)\n"
+            "  -keysize <n>        hash key size in bytes (default: from the seed length, as the reference picks it)\n"
             "  -p<n>               chromosome padding (default 2000)\n"
             "  -B<chars>           contig names end at any of these characters\n"
             "  -bSpace / -bSpace-  contig names end at the first blank or tab (default on)\n"

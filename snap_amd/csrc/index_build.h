@@ -14,7 +14,8 @@
 //                        tables ARE the reference's format: its loader reads them, and the device-native buckets are built from them
 //                        like from any other index.
 // Slot placement differs from a reference build (it depends on insertion order there too); lookup results do not.
-// Shape built here: 4-byte locations, 4-byte keys, small tables (seed 16..24 with key size 4; -s 20 is the north star's index).
+// Shape built here: 4-byte locations, small tables, any key size the reference accepts for the seed (GenomeIndex.cpp:437-460; -s 20 with its
+// 4-byte keys is the north star's index and keeps the one-compare-and-swap insert; other key sizes claim slots in a bit array, below).
 // Everything is wave-level: no block barriers, LDS only per wave.
 #pragma once
 #include "dev_common.h"
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void k_ib_table_bounds(const uint64_t *keys, c
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > n_tables) return;
     if (t == n_tables) { first_run[t] = n_runs; return; }
-    const uint64_t bound = (uint64_t)t << key_bits;
+    const uint64_t bound = key_bits >= 64 ? 0ull : (uint64_t)t << key_bits;       // (64 key bits: one table, t = 0)
     uint32_t lo = 0, hi = n_runs;                      // first run with key >= bound
     while (lo < hi) {
         const uint32_t mid = lo + (hi - lo) / 2;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(256) void k_ib_insert(const uint64_t *keys, const u
     for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t s = run_start[r], len = run_start[r + 1] - s;
         const uint64_t seed = keys[s];
-        const uint32_t key = (uint32_t)(seed & ((1ull << key_bits) - 1ull));
+        const uint32_t key = (uint32_t)(seed & ((1ull << key_bits) - 1ull));      // (this kernel: key_bits == 32)
         const uint32_t t = (uint32_t)(seed >> key_bits);
         const uint32_t value = len == 1 ? vals[s] : n_bases32 + ovf_off[r];          // < nBases: the location; else nBases + overflow index (:2173-2201)
         const uint64_t size = table_size[t];
@@ -259,6 +260,48 @@ __global__ __launch_bounds__(256) void k_ib_insert(const uint64_t *keys, const u
         for (;;) {
             const unsigned long long old = atomicCAS(&slots[idx], (unsigned long long)IB_EMPTY_SLOT, entry);
             if (old == IB_EMPTY_SLOT) break;
+            probes++;
+            if (probes > size + 5) { atomicAdd(fail, 1u); break; }
+            idx = probes < 5 ? (idx + probes * probes) % size : (idx + 1) % size;
+        }
+    }
+}
+
+// The same for entries that are not 8 bytes wide (key sizes other than 4: the reference's default for seeds above 21 is 5 or more,
+// GenomeIndex.cpp:437): entries then straddle words, so a slot is claimed in a bit array (one bit per slot of the whole blob) and its bytes --
+// value, then key_bytes of key, little endian (HashTable.h:148-156) -- are written by the one thread that claimed it.  The invariant is the
+// same: a claimed slot stays claimed, so no key has an empty slot before it on its probe sequence.
+__global__ __launch_bounds__(256) void k_ib_fill_empty_wide(uint32_t *words, uint64_t n_words, uint32_t entry_bytes)
+{
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t w = 0;
+        for (uint32_t b = 0; b < 4; b++) if ((4 * i + b) % entry_bytes < 4) w |= 0xffu << (8 * b);      // value bytes 0xff, key bytes 0 (HashTable.cpp:63-70)
+        words[i] = w;
+    }
+}
+__global__ __launch_bounds__(256) void k_ib_insert_wide(const uint64_t *keys, const uint32_t *vals, const uint32_t *run_start, const uint32_t *ovf_off,
+                                                        uint32_t n_runs, uint32_t key_bits, uint32_t n_bases32, uint8_t *blob, uint32_t entry_bytes,
+                                                        uint32_t *claim, const uint64_t *table_slot0, const uint64_t *table_size, uint32_t *fail)
+{
+    const uint64_t key_mask = key_bits >= 64 ? ~0ull : ((1ull << key_bits) - 1ull);
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_runs; r += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t s = run_start[r], len = run_start[r + 1] - s;
+        const uint64_t seed = keys[s];
+        const uint64_t key = seed & key_mask;
+        const uint32_t t = key_bits >= 64 ? 0u : (uint32_t)(seed >> key_bits);
+        const uint32_t value = len == 1 ? vals[s] : n_bases32 + ovf_off[r];
+        const uint64_t size = table_size[t], slot0 = table_slot0[t];
+        uint64_t idx = murmur_finalizer(key) % size;
+        uint64_t probes = 0;
+        for (;;) {
+            const uint64_t g = slot0 + idx;
+            const uint32_t bit = 1u << (g & 31);
+            if (!(atomicOr(&claim[g >> 5], bit) & bit)) {
+                uint8_t *e = blob + g * entry_bytes;
+                for (uint32_t b = 0; b < 4; b++) e[b] = (uint8_t)(value >> (8 * b));
+                for (uint32_t b = 4; b < entry_bytes; b++) e[b] = (uint8_t)(key >> (8 * (b - 4)));
+                break;
+            }
             probes++;
             if (probes > size + 5) { atomicAdd(fail, 1u); break; }
             idx = probes < 5 ? (idx + probes * probes) % size : (idx + 1) % size;

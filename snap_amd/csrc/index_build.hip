@@ -116,6 +116,7 @@ int ib_exclusive_scan(const uint32_t *in, uint64_t n, uint32_t *out, uint32_t *p
 static int ib_build_on_device(snapgpu_built_index *bi, double slack)
 {
     const uint32_t L = bi->seed_len, key_bits = bi->key_bytes * 8;
+    const uint32_t entry_bytes = 4 + bi->key_bytes;             // one 4-byte value, then the key (HashTable.h:148-156)
     const uint64_t n_bases = bi->n_bases;
     // locations [0, nBases - seedLen - 1): the last chunk of the reference's scan ends there (GenomeIndex.cpp:667-670, 1455)
     const uint64_t n_locs = n_bases > (uint64_t)L + 1 ? n_bases - L - 1 : 0;
@@ -238,14 +239,15 @@ static int ib_build_on_device(snapgpu_built_index *bi, double slack)
         if (biased < 100) biased = 100;
         if ((uint64_t)biased <= count) biased = (unsigned)(count + count / 8 + 8);       // (cannot happen with slack > 0; never build a full table)
         bi->table_size[t] = biased; bi->table_used[t] = count;
-        slot0[t] = total_slots; bi->table_offset[t] = total_slots * 8;
+        slot0[t] = total_slots; bi->table_offset[t] = total_slots * entry_bytes;
         total_slots += biased;
     }
-    bi->hash_bytes = total_slots * 8; bi->stats.hash_table_slots = total_slots; bi->stats.hash_blob_bytes = bi->hash_bytes;
+    bi->hash_bytes = total_slots * entry_bytes; bi->stats.hash_table_slots = total_slots; bi->stats.hash_blob_bytes = bi->hash_bytes;
     IBCHK(hipMalloc((void **)&bi->d_hash, (size_t)bi->hash_bytes + 64), SNAPGPU_E_NOMEM);
     IBCHK(hipMalloc((void **)&bi->d_overflow, ((size_t)ovf_words + 4) * 4), SNAPGPU_E_NOMEM);
     IBCHK(hipMemsetAsync(bi->d_overflow, 0, ((size_t)ovf_words + 4) * 4, s), SNAPGPU_E_LAUNCH);
-    hipLaunchKernelGGL(k_ib_fill_empty, dim3(grid), dim3(256), 0, s, bi->d_hash, total_slots + 8);
+    if (entry_bytes == 8) hipLaunchKernelGGL(k_ib_fill_empty, dim3(grid), dim3(256), 0, s, bi->d_hash, total_slots + 8);
+    else hipLaunchKernelGGL(k_ib_fill_empty_wide, dim3(grid), dim3(256), 0, s, (uint32_t *)bi->d_hash, (total_slots * entry_bytes + 63) / 4, entry_bytes);
     if (m) {
         uint64_t *d_slot0 = nullptr, *d_tsize = nullptr; uint32_t *d_fail = nullptr;
         IBCHK(mem.alloc(&d_slot0, (size_t)n_tables * 8), SNAPGPU_E_NOMEM);
@@ -256,8 +258,18 @@ static int ib_build_on_device(snapgpu_built_index *bi, double slack)
         IBCHK(hipMemsetAsync(d_fail, 0, 4, s), SNAPGPU_E_LAUNCH);
         hipLaunchKernelGGL(k_ib_fill_overflow, dim3(grid), dim3(256), 0, s, d_vals, (const uint32_t *)d_head, (const uint32_t *)d_before, m,
                            (const uint32_t *)d_run_start, (const uint32_t *)d_ovf_off, bi->d_overflow);
-        hipLaunchKernelGGL(k_ib_insert, dim3(grid), dim3(256), 0, s, d_keys, d_vals, (const uint32_t *)d_run_start, (const uint32_t *)d_ovf_off, n_runs,
-                           key_bits, (uint32_t)n_bases, bi->d_hash, (const uint64_t *)d_slot0, (const uint64_t *)d_tsize, d_fail);
+        if (entry_bytes == 8) {
+            hipLaunchKernelGGL(k_ib_insert, dim3(grid), dim3(256), 0, s, d_keys, d_vals, (const uint32_t *)d_run_start, (const uint32_t *)d_ovf_off, n_runs,
+                               key_bits, (uint32_t)n_bases, bi->d_hash, (const uint64_t *)d_slot0, (const uint64_t *)d_tsize, d_fail);
+        } else {
+            uint32_t *d_claim = nullptr;
+            const size_t claim_bytes = (size_t)(total_slots / 32 + 1) * 4;
+            IBCHK(mem.alloc(&d_claim, claim_bytes), SNAPGPU_E_NOMEM);
+            IBCHK(hipMemsetAsync(d_claim, 0, claim_bytes, s), SNAPGPU_E_LAUNCH);
+            hipLaunchKernelGGL(k_ib_insert_wide, dim3(grid), dim3(256), 0, s, d_keys, d_vals, (const uint32_t *)d_run_start, (const uint32_t *)d_ovf_off,
+                               n_runs, key_bits, (uint32_t)n_bases, (uint8_t *)bi->d_hash, entry_bytes, d_claim, (const uint64_t *)d_slot0,
+                               (const uint64_t *)d_tsize, d_fail);
+        }
         IBCHK(hipGetLastError(), SNAPGPU_E_LAUNCH);
         uint32_t failed = 0;
         IBCHK(hipMemcpyAsync(&failed, d_fail, 4, hipMemcpyDeviceToHost, s), SNAPGPU_E_LAUNCH);
@@ -294,7 +306,9 @@ static int ib_check_shape(const snapgpu_index_build_params *bp, uint32_t *key_by
     if (kb == 0) { kb = (bp->seed_len + 2) / 4 - 1; if (kb < 2) kb = 2; }                                  // GenomeIndex.cpp:437
     if (bp->seed_len * 2 < kb * 8) return ib_fail(SNAPGPU_E_INVALID, "the seed must be big enough to fill the key (GenomeIndex.cpp:452)");
     if (bp->seed_len * 2 - kb * 8 > 16) return ib_fail(SNAPGPU_E_INVALID, "more than 4^8 hash tables: bigger key size or smaller seed (GenomeIndex.cpp:458)");
-    if (kb != 4) return ib_fail(SNAPGPU_E_UNSUPPORTED, "the GPU index builder writes 4-byte keys (seed 18-21, or -keysize 4 with seed 16-24); use the reference's indexer for other shapes");
+    if (kb < 2 || kb > 8) return ib_fail(SNAPGPU_E_INVALID, "key size must be between 2 and 8 bytes (GenomeIndex.cpp:437, HashTable.h:148)");
+    // a seed of 32 T's is the value this builder marks "no seed at this location" with (index_build.h: IB_INVALID_KEY)
+    if (bp->seed_len == 32) return ib_fail(SNAPGPU_E_UNSUPPORTED, "the GPU index builder takes seeds up to 31 bases; use the reference's indexer for -s 32");
     if (bp->seed_len < 20) {
         // the reference picks 5-byte locations below seed 20 unless told otherwise (GenomeIndex.cpp:442-449); this builder always writes 4
     }
@@ -567,9 +581,9 @@ extern "C" int snapgpu_built_index_save(const snapgpu_built_index *bi, const cha
             const uint64_t size = bi->table_size[t], used = bi->table_used[t];
             if (!ib_write_all(f, &magic, 4) || !ib_write_all(f, &size, 8) || !ib_write_all(f, &used, 8) || !ib_write_all(f, &ks, 4) ||
                 !ib_write_all(f, &vs, 4) || !ib_write_all(f, &vc, 4) || !ib_write_all(f, &inv, 4)) { fclose(f); return ib_fail(SNAPGPU_E_INVALID, "write failed (GenomeIndexHash)"); }
-            rc = ib_copy_out(f, (const uint8_t *)bi->d_hash + bi->table_offset[t], (size_t)size * 8, buf);
+            rc = ib_copy_out(f, (const uint8_t *)bi->d_hash + bi->table_offset[t], (size_t)size * (4 + ks), buf);
             if (rc) { fclose(f); return rc; }
-            hash_file_bytes += 36 + (size_t)size * 8;
+            hash_file_bytes += 36 + (size_t)size * (4 + ks);
         }
         fclose(f);
     }

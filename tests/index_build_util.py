@@ -65,8 +65,13 @@ def compare_with_reference(tmpdir, lib=None, seed_len=20, fasta=None, n_reads=30
     assert os.path.getsize(os.path.join(d_ref, "OverflowTable")) == os.path.getsize(os.path.join(d_gpu, "OverflowTable"))
     ia, ib = GenomeIndex.load_from_directory(d_ref), GenomeIndex.load_from_directory(d_gpu)
     assert (ia.table_size == ib.table_size).all()
-    assert stats["n_distinct_seeds"] == sum(int(np.count_nonzero(ib.hash_blob[int(o):int(o) + int(n) * 8].view(np.uint32)[0::2] != 0xffffffff))
-                                            for o, n in zip(ib.table_offset, ib.table_size))
+    eb = ib.entry_bytes
+
+    def used_slots(o, n):
+        e = np.asarray(ib.hash_blob[int(o):int(o) + int(n) * eb]).reshape(int(n), eb)
+        return int(np.count_nonzero((e[:, :4] != 0xff).any(axis=1)))
+
+    assert stats["n_distinct_seeds"] == sum(used_slots(o, n) for o, n in zip(ib.table_offset, ib.table_size))
 
     # ---- lookups, answered by the reference over both directories
     ra, rb = ref.RefIndex(d_ref), ref.RefIndex(d_gpu)

@@ -474,6 +474,33 @@ def test_emu_index_builder_vs_reference(emu, tmp_path):
     a_files.close(); a_view.close(); built.close()
 
 
+@pytest.mark.parametrize("seed_len,kw,extra", [(24, {}, []), (22, {}, []), (17, {}, ["-locationSize", "4"]), (26, {}, []), (31, {}, []),
+                                               (20, dict(key_bytes=3), ["-keysize", "3"]), (12, {}, ["-locationSize", "4"])])
+def test_emu_index_builder_key_sizes_vs_reference(emu, tmp_path, seed_len, kw, extra):
+    """Key sizes other than 4 (GenomeIndex.cpp:437: the default for -s 24 is 5): entries that straddle words, claimed through the bit array
+    (index_build.h: k_ib_insert_wide).  Same checks as above -- and the library's own lookup over the built directory."""
+    from tests.index_build_util import compare_with_reference
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built")
+    stats, d_ref, d_gpu = compare_with_reference(tmp_path, lib=emu, seed_len=seed_len, extra_ref=extra, n_reads=600, **kw)
+    want = kw.get("key_bytes") or max(2, (seed_len + 2) // 4 - 1)
+    assert int(open(os.path.join(d_gpu, "GenomeIndex")).read().split()[6]) == want
+    from snap_amd.index import GenomeIndex
+    from snap_amd.aligner import BaseAligner
+    from snap_amd import synth
+    ix = GenomeIndex.load_from_directory(d_gpu)
+    contigs = [(c.name, ix.genome[c.begin:c.begin + 20000]) for c in ix.contigs[:3]]
+    reads = synth.make_reads(3, contigs, 300, 100)
+    params = abi.default_params(max_k=8, max_read_len=112)
+    with ref.fresh_objects():
+        exp = ref.RefIndex(d_ref).align_single(params, reads["bases"], reads["quals"], reads["offsets"], threads=4)[0]
+    a = BaseAligner(ix, params)
+    got, _ = a.AlignRead(reads["bases"], reads["quals"], reads["offsets"])
+    a.close()
+    assert not util.compare_results(exp, got), util.compare_results(exp, got)
+
+
 def test_emu_single_end_help_for_heavy_reads(emu, monkeypatch, tmp_path):
     """se_help.h: a forced walk's remaining candidates published for idle waves (here: published eagerly, so that the path runs whatever
     the emulator's scheduling does), on reads out of diverged high-copy repeats.  Every read against the reference with fresh aligner

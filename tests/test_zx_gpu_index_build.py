@@ -21,7 +21,9 @@ def _need_ref():
     return ref
 
 
-@pytest.mark.parametrize("seed_len,kw,extra", [(20, {}, []), (18, {}, ["-locationSize", "4"]), (22, dict(key_bytes=4), ["-keysize", "4"])])
+@pytest.mark.parametrize("seed_len,kw,extra", [(20, {}, []), (18, {}, ["-locationSize", "4"]), (22, dict(key_bytes=4), ["-keysize", "4"]),
+                                               # key sizes other than 4 (index_build.h: k_ib_insert_wide); -s 24 -> 5 is the reference's default shape (GenomeIndex.cpp:437)
+                                               (24, {}, []), (26, {}, []), (17, {}, ["-locationSize", "4"])])
 def test_built_directory_equals_the_reference_indexer(tmp_path, seed_len, kw, extra):
     _need_ref()
     from tests.index_build_util import compare_with_reference
