@@ -36,9 +36,9 @@ def main():
     ap.add_argument("--groups", type=int, default=len(GROUPS), help="only the first N counter groups")
     ap.add_argument("--timeout", type=int, default=240)
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per launch (bench.py --reads)")
-    ap.add_argument("--tag", default="", help="the entry's workload label when it is not --workload (bench.py's c5 leg: --tag c5 -- --read-len 250 --max-k 20 ...)")
-    ap.add_argument("rest", nargs="*")
-    a = ap.parse_args()
+    ap.add_argument("--tag", default="", help="the entry's workload label when it is not --workload (bench.py's c5 leg: --tag c5 --read-len 250 --max-k 20 ...)")
+    a, a.rest = ap.parse_known_args()               # anything else goes to bench.py (--read-len 250 --max-k 20 ...)
+    a.rest = [x for x in a.rest if x != "--"]
     os.makedirs(a.out, exist_ok=True)
     from bench import kernel_source_hash
     env = dict(os.environ, TMPDIR="/tmp")
