@@ -333,6 +333,25 @@ class BaseAligner:
             ptr(stale)), "snapgpu_sam_fields_single")
         return dict(flag=flag, contig=contig, pos=pos, mapq=mapq, ops=ops, n_ops=n_ops, nm=nm, stale=stale)
 
+    def alignSam(self, bases, quals, offsets, front_clip, data_len, skip, use_m: bool = False, ops_stride: int = 64):
+        """The single-end path of a SAM writer in one call (snapgpu_align_sam_single): BaseAligner::AlignRead over the clipped reads
+        (SingleAligner.cpp:250) and SimpleReadWriter::writeReads' computed fields for each primary result, the batch uploaded once.
+        bases / quals / offsets: the unclipped reads; front_clip / data_len: Read::clip's outcome; skip[i] != 0: the read is not given to
+        the aligner (SingleAligner.cpp:211-232).  Returns (results, first_alt, dict(flag, contig, pos, mapq, ops, n_ops, nm, stale))."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8).reshape(-1); quals = np.ascontiguousarray(quals, dtype=np.uint8).reshape(-1)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        front_clip = np.ascontiguousarray(front_clip, dtype=np.int32); data_len = np.ascontiguousarray(data_len, dtype=np.int32)
+        skip = np.ascontiguousarray(skip, dtype=np.uint8)
+        n = offsets.size - 1
+        results = np.zeros(n, dtype=RESULT_DTYPE); first_alt = np.zeros(n, dtype=RESULT_DTYPE)
+        flag = np.zeros(n, np.int32); contig = np.zeros(n, np.int32); pos = np.zeros(n, np.int64); mapq = np.zeros(n, np.int32)
+        ops = np.zeros((n, ops_stride), dtype=np.uint32); n_ops = np.zeros(n, np.int32); nm = np.zeros(n, np.int32); stale = np.zeros(n, np.int32)
+        self._check(self.lib.snapgpu_align_sam_single(
+            self.handle, C.c_uint32(n), ptr(bases), ptr(quals), ptr(offsets), ptr(front_clip), ptr(data_len), ptr(skip),
+            C.c_int(1 if use_m else 0), ptr(results), ptr(first_alt), ptr(flag), ptr(contig), ptr(pos), ptr(mapq), ptr(ops),
+            C.c_uint32(ops_stride), ptr(n_ops), ptr(nm), ptr(stale)), "snapgpu_align_sam_single")
+        return results, first_alt, dict(flag=flag, contig=contig, pos=pos, mapq=mapq, ops=ops, n_ops=n_ops, nm=nm, stale=stale)
+
     def samFieldsPaired(self, bases, quals, offsets, front_clip, data_len, results, use_m: bool = False, ops_stride: int = 64):
         """SAMFormat::writePairs + fillMateInfo up to the point of printing (see snapgpu_sam_fields_paired).  offsets has 2 n + 1
         entries (read 0 and read 1 of each pair); results: PAIRED_RESULT_DTYPE array of n."""

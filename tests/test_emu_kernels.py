@@ -327,6 +327,15 @@ def test_emu_sam_fields(emu, golden_index, tag):
     gc.check_sam_fields_against_reference_cli(golden_index, z, tag, step=3)
 
 
+@pytest.mark.parametrize("tag", ["default", "clipfront"])
+def test_emu_align_sam_single(emu, golden_index, tag):
+    """snapgpu_align_sam_single on the emulated device: results = the reference aligner's, fields = the reference CLI's, and both equal to
+    the two calls it replaces (the first 500 reads of the fixture)."""
+    import tests.test_zz_gpu_cigar as gc
+    z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
+    gc.check_align_sam_single_against_reference_cli(golden_index, z, tag, n=500)
+
+
 @pytest.mark.parametrize("opts", [[], ["-G-", "-=", "-C++", "-b", "97"], ["-G-", "-ea", "-om", "1", "-omax", "4"], ["-ae"], ["-ae", "-om", "1"]])     # -b 97: nine batches, the last one short; -C++: '#' heads
                                                                                                                   # clipped too; -om / -ea: secondary and first-ALT records
 def test_emu_native_fastq_to_sam(emu, tmp_path, opts):

@@ -245,6 +245,51 @@ def test_sam_fields_vs_reference_cli_fixture(golden_index, tag):
     assert int((got["flag"] & 4 != 0).sum()) > 100 and int((got["flag"] & 16 != 0).sum()) > 1000
 
 
+def check_align_sam_single_against_reference_cli(golden_index, z, tag, n=None):
+    """snapgpu_align_sam_single -- one upload, the align kernel applying Read::clip's outcome itself, results handed to the SAM-field kernels
+    (k_samf_dp8 + k_sam_fields) in HBM -- from the unclipped reads alone: the SingleAlignmentResults must be the reference aligner's and the
+    fields what the unmodified reference CLI printed (the same fixture as above, which keeps both).  Also against the two calls it replaces."""
+    from snap_amd.aligner import BaseAligner
+    kw = dict(use_affine_gap=0) if "lvonly" in tag else {}
+    prm = abi.default_params(max_read_len=400, **kw)                       # the CLI's defaults: -d 27 (scripts/make_golden_sam_fields.py)
+    n = n or len(z[tag + "_front_clip"])
+    offs = z["offsets"][:n + 1]
+    bases, quals = z["bases"][:int(offs[-1])], z["quals"][:int(offs[-1])]
+    fc, dl = z[tag + "_front_clip"][:n], z[tag + "_data_len"][:n]
+    # SingleAligner.cpp:211-232: shorter than -mrl 50 or more Ns than maxDist: not given to the aligner
+    skip = np.array([dl[i] < 50 or int((bases[int(offs[i]) + fc[i]:int(offs[i]) + fc[i] + dl[i]] == ord("N")).sum()) > int(prm.max_k) for i in range(n)], dtype=np.uint8)
+    a = BaseAligner(golden_index, prm)
+    try:
+        res, alt, got = a.alignSam(bases, quals, offs, fc, dl, skip, bool(z[tag + "_use_m"]))
+        exp = z[tag + "_results"][:n]
+        keep = np.nonzero(skip == 0)[0]
+        bad = util.compare_results(exp[keep], res[keep])
+        assert not bad, (tag, bad[:3] if isinstance(bad, list) else bad)
+        assert (res["status"][skip != 0] == 0).all() and (res["score"][skip != 0] == -1).all()          # NotFound, as the reference's writer sees them
+        for k in ("flag", "contig", "pos", "mapq", "nm", "n_ops"):
+            ne = np.nonzero(got[k] != z[tag + "_" + k][:n])[0]
+            assert ne.size == 0, (tag, k, ne[:5], got[k][ne[:5]], z[tag + "_" + k][:n][ne[:5]])
+        for i in range(n):
+            assert util.cigar_text(got["ops"][i], got["n_ops"][i]) == util.cigar_text(z[tag + "_ops"][i], z[tag + "_n_ops"][i]), (tag, i)
+        two = a.samFields(bases, quals, offs, fc, dl, res, bool(z[tag + "_use_m"]))
+        for k in ("flag", "contig", "pos", "mapq", "nm", "n_ops", "stale"):
+            assert (two[k] == got[k]).all(), (tag, k)
+        assert (two["ops"] == got["ops"]).all()
+        # an empty batch is a call like any other
+        r0, _, g0 = a.alignSam(bases[:0], quals[:0], np.zeros(1, np.uint64), fc[:0], dl[:0], skip[:0])
+        assert r0.size == 0 and g0["flag"].size == 0
+    finally:
+        a.close()
+    return int((skip != 0).sum())
+
+
+@pytest.mark.parametrize("tag", ["default", "lvonly", "eqx", "clipfront"])
+def test_align_sam_single_vs_reference_cli_fixture(golden_index, tag):
+    import os
+    z = np.load(os.path.join(util.GOLDEN, "sam_fields.npz"))
+    assert check_align_sam_single_against_reference_cli(golden_index, z, tag) > 10
+
+
 # ---------------------------------------------------------------------------------------------- paired-end writer
 def check_sam_fields_paired_against_reference_cli(z, tag, n_pairs=None):
     """All 9 computed fields of both records of each pair and the order of the two records, as the unmodified reference CLI printed them
