@@ -25,6 +25,7 @@ ap.add_argument("--shim", action="store_true")
 ap.add_argument("--threads", type=int, default=os.cpu_count() or 8)
 ap.add_argument("--keep", action="store_true")
 ap.add_argument("--tool-args", default="", help="extra arguments for snapgpu-sam, one string")
+ap.add_argument("--no-hash", action="store_true", help="do not hash the records of the sweep's runs (the first run is always hashed)")
 a = ap.parse_args()
 n = a.n
 
@@ -77,14 +78,14 @@ def hash_records(sam):
     return nrec, "%016x" % h
 
 
-def run(tag, cmd, env=None):
-    sam = os.path.join(work, tag + ".sam")
+def run(tag, cmd, env=None, hash_it=True):
+    sam = os.path.join(work, re.sub(r"[^A-Za-z0-9_.-]", "_", tag) + ".sam")
     t0 = time.time()
     r = subprocess.run(cmd + ["-o", sam], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=1500, env=env)
     dt = time.time() - t0
     txt = r.stdout.decode(errors="replace")
     t1 = time.time()
-    nrec, hx = hash_records(sam) if r.returncode == 0 else (0, "")
+    nrec, hx = hash_records(sam) if (r.returncode == 0 and hash_it) else (0, "")
     o = {"rc": r.returncode, "wall_s": dt, "reads_per_s_wall": n / dt, "records": nrec, "records_hash": hx, "hash_s": time.time() - t1,
          "sam_bytes": os.path.getsize(sam) if os.path.exists(sam) else 0, "tool_tail": [l[:300] for l in txt.strip().splitlines()[-4:]]}
     m = re.search(r"index resident after ([\d.]+) s; FASTQ -> \w+ in ([\d.]+) s = (\d+) reads/s", txt)
@@ -97,8 +98,11 @@ def run(tag, cmd, env=None):
 
 
 run("snapgpu_sam", [os.path.join(ROOT, "snap_amd", "snapgpu-sam"), "single", idx, fq, "-d", "8"] + a.tool_args.split(), env=dict(os.environ, SNAPGPU_SAM_VERBOSE="1"))
-for extra in [x for x in os.environ.get("E2E_SWEEP", "").split(";") if x.strip()]:          # e.g. E2E_SWEEP="-b 1048576 -q 3;-b 1048576 -q 4"
-    run("snapgpu_sam " + extra.strip(), [os.path.join(ROOT, "snap_amd", "snapgpu-sam"), "single", idx, fq, "-d", "8"] + extra.split(), env=dict(os.environ, SNAPGPU_SAM_VERBOSE="1"))
+for k, extra in enumerate([x for x in os.environ.get("E2E_SWEEP", "").split(";") if x.strip()]):          # e.g. E2E_SWEEP="-b 1048576 -q 3;SNAPGPU_SAM_PIN=0 -q 4"
+    toks = extra.split()
+    envs = {t.split("=", 1)[0]: t.split("=", 1)[1] for t in toks if re.match(r"^[A-Z_0-9]+=", t)}          # leading NAME=VALUE words go to the environment
+    run("snapgpu_sam #%d %s" % (k, extra.strip()), [os.path.join(ROOT, "snap_amd", "snapgpu-sam"), "single", idx, fq, "-d", "8"] + [t for t in toks if not re.match(r"^[A-Z_0-9]+=", t)],
+        env=dict(os.environ, SNAPGPU_SAM_VERBOSE="1", **envs), hash_it=not a.no_hash)
 if a.shim:
     run("snap_aligner_gpu_shim", [os.path.join(ROOT, "oracle", "_ref", "snap-aligner-gpu"), "single", idx, fq, "-d", "8", "-t", "8"])
 if not a.skip_reference:

@@ -40,6 +40,7 @@
 #include <unistd.h>
 #include <chrono>
 #include <vector>
+#include <dlfcn.h>
 #include <zlib.h>                        // gzread reads plain and gzip-compressed FASTQ alike (the reference takes .gz input too)
 
 #include "../../../include/snapgpu.h"
@@ -698,9 +699,38 @@ static void gpu_single(const Options &o, FeederCtx &fc, Work &w)
 // So the batches stay small (131 072 reads) and a feeder hands `-g` of them to snapgpu_align_sam_single as one batch: inputs gathered into
 // the feeder's own buffers, outputs scattered back to the batches they belong to, which then go on to the formatters separately.
 // Anything but the one-call path (secondary results, -ae, a first-ALT record in the group) is done batch by batch as before.
+// The group's buffers are the feeder's own and live as long as it does, so they are worth page-locking: the library takes any host pointer,
+// and a pageable one goes through the runtime's staging buffers at a fraction of the link's rate -- ~0.4 GB per call of 1 M reads, up and
+// down.  The tool talks to the library through the C ABI only; the HIP runtime the library brought into the process is looked up by name
+// (none in the emulator's build of the tool: the buffers then stay pageable).  SNAPGPU_SAM_PIN=0 turns it off.
+struct PinnedRange {
+    void *p = nullptr; size_t bytes = 0;
+    typedef int (*reg_fn)(void *, size_t, unsigned); typedef int (*unreg_fn)(void *);
+    static reg_fn reg() { static reg_fn f = (getenv("SNAPGPU_SAM_PIN") && atoi(getenv("SNAPGPU_SAM_PIN")) == 0) ? nullptr : (reg_fn)dlsym(RTLD_DEFAULT, "hipHostRegister"); return f; }
+    static unreg_fn unreg() { static unreg_fn f = (unreg_fn)dlsym(RTLD_DEFAULT, "hipHostUnregister"); return f; }
+    void release() { if (p && unreg()) (void)unreg()(p); p = nullptr; bytes = 0; }
+    // the vector's storage as it is now (after the call's resizes): registered again only when it moved or grew
+    template <typename T> void cover(std::vector<T> &v) {
+        void *q = (void *)v.data(); const size_t b = v.capacity() * sizeof(T);
+        if (q == p && b == bytes) return;
+        release();
+        static const size_t min_bytes = getenv("SNAPGPU_SAM_PIN_MIN") ? (size_t)atoll(getenv("SNAPGPU_SAM_PIN_MIN")) : ((size_t)1 << 20);
+        if (!reg() || !unreg() || b < min_bytes || b == 0) return;
+        if (reg()(q, b, 1u /* hipHostRegisterPortable */) == 0) { p = q; bytes = b; }
+    }
+    ~PinnedRange() { release(); }
+};
 struct GroupBuf {
     std::vector<char> b, q; std::vector<uint64_t> off; std::vector<int32_t> fc, dl, flag, contig, mapq, n_ops, nm, stale; std::vector<uint8_t> skip;
     std::vector<int64_t> pos; std::vector<uint32_t> ops; std::vector<snapgpu_single_result> res, alt;
+    PinnedRange pin[16];
+    // resize without ever letting a vector move while its storage is registered: growth releases the registration first (and takes headroom)
+    template <typename T> static void fit(std::vector<T> &v, size_t n, PinnedRange &r) { if (n > v.capacity()) { r.release(); v.reserve(n + n / 4); } v.resize(n); }
+    void pin_all() {
+        pin[0].cover(b); pin[1].cover(q); pin[2].cover(off); pin[3].cover(fc); pin[4].cover(dl); pin[5].cover(flag); pin[6].cover(contig); pin[7].cover(mapq);
+        pin[8].cover(n_ops); pin[9].cover(nm); pin[10].cover(stale); pin[11].cover(skip); pin[12].cover(pos); pin[13].cover(ops); pin[14].cover(res); pin[15].cover(alt);
+    }
+    ~GroupBuf() { for (auto &r : pin) r.release(); }          // (before the vectors go)
 };
 static void gpu_single_group(const Options &o, FeederCtx &fc, std::vector<Work *> &ws, GroupBuf &g)
 {
@@ -712,7 +742,8 @@ static void gpu_single_group(const Options &o, FeederCtx &fc, std::vector<Work *
     for (Work *w : ws) { if (!w->prepared) prepare_single(o, *w); n += w->b.n(); nbytes += w->b.bases.size(); if (w->max_len > max_len) max_len = w->max_len; }
     if (n == 0) { for (Work *w : ws) gpu_single(o, fc, *w); return; }
     snapgpu_ctx *ctx = ctx_for(o, fc, max_len);
-    g.b.resize(nbytes); g.q.resize(nbytes); g.off.resize(n + 1); g.fc.resize(n); g.dl.resize(n); g.skip.resize(n);
+    GroupBuf::fit(g.b, nbytes, g.pin[0]); GroupBuf::fit(g.q, nbytes, g.pin[1]); GroupBuf::fit(g.off, n + 1, g.pin[2]); GroupBuf::fit(g.fc, n, g.pin[3]);
+    GroupBuf::fit(g.dl, n, g.pin[4]); GroupBuf::fit(g.skip, n, g.pin[11]);
     size_t at = 0, ab = 0;
     for (Work *w : ws) {
         const Batch &b = w->b; const size_t m = b.n();
@@ -723,12 +754,14 @@ static void gpu_single_group(const Options &o, FeederCtx &fc, std::vector<Work *
     }
     g.off[n] = ab;
     const bool want_alt = o.p.alt_awareness && g_index_has_alt;
-    if (want_alt) { g.res.resize(n); g.alt.resize(n); }
-    g.flag.resize(n); g.contig.resize(n); g.mapq.resize(n); g.n_ops.resize(n); g.nm.resize(n); g.stale.resize(n); g.pos.resize(n);
+    if (want_alt) { GroupBuf::fit(g.res, n, g.pin[14]); GroupBuf::fit(g.alt, n, g.pin[15]); }
+    GroupBuf::fit(g.flag, n, g.pin[5]); GroupBuf::fit(g.contig, n, g.pin[6]); GroupBuf::fit(g.mapq, n, g.pin[7]); GroupBuf::fit(g.n_ops, n, g.pin[8]);
+    GroupBuf::fit(g.nm, n, g.pin[9]); GroupBuf::fit(g.stale, n, g.pin[10]); GroupBuf::fit(g.pos, n, g.pin[12]);
     uint32_t stride = o.ops_stride;
     lap(g_ns_prep);
     for (;;) {
-        g.ops.assign(n * (size_t)stride, 0);
+        GroupBuf::fit(g.ops, 0, g.pin[13]); GroupBuf::fit(g.ops, n * (size_t)stride, g.pin[13]);      // (zero-filled: resize from empty)
+        g.pin_all();
         const int rc = snapgpu_align_sam_single(ctx, (uint32_t)n, g.b.data(), g.q.data(), g.off.data(), g.fc.data(), g.dl.data(), g.skip.data(), o.use_m ? 1 : 0,
                                                 want_alt ? g.res.data() : NULL, want_alt ? g.alt.data() : NULL,
                                                 g.flag.data(), g.contig.data(), g.pos.data(), g.mapq.data(), g.ops.data(), stride, g.n_ops.data(), g.nm.data(), g.stale.data());

@@ -64,7 +64,7 @@ def build(verbose=False):
     # the native FASTQ -> SAM host program, linked against the emulated library (same source as snap_amd/snapgpu-sam)
     tool_src = os.path.join(CSRC, "host", "snapgpu_sam.cpp")
     if not os.path.exists(TOOL) or os.path.getmtime(TOOL) < max(os.path.getmtime(tool_src), os.path.getmtime(LIB)):
-        _run([CXX, "-O2", "-std=c++17", "-o", TOOL, tool_src, "-L" + BDIR, "-lsnapgpu_emu", "-Wl,-rpath," + BDIR, "-lpthread", "-lz"])
+        _run([CXX, "-O2", "-std=c++17", "-o", TOOL, tool_src, "-L" + BDIR, "-lsnapgpu_emu", "-Wl,-rpath," + BDIR, "-lpthread", "-lz", "-ldl"])
     itool_src = os.path.join(CSRC, "host", "snapgpu_index.cpp")
     itool = os.path.join(BDIR, "snapgpu-index-emu")
     if not os.path.exists(itool) or os.path.getmtime(itool) < max(os.path.getmtime(itool_src), os.path.getmtime(LIB)):

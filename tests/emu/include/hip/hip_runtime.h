@@ -141,6 +141,8 @@ hipError_t hipSetDevice(int d);
 hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int d);
 hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
+extern "C" hipError_t hipHostRegister(void *p, size_t n, unsigned flags);       // (C linkage as in the real runtime: the native tool finds them by name)
+extern "C" hipError_t hipHostUnregister(void *p);
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind k);
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st = nullptr);
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st = nullptr);

@@ -22,6 +22,7 @@
 #include <thread>
 #include <vector>
 #include <mutex>
+#include <map>
 
 extern "C" void emu_switch(void **save_sp, void *new_sp);
 asm(".text\n"
@@ -436,6 +437,27 @@ hipError_t hipMalloc(void **p, size_t n)
     return hipSuccess;
 }
 hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+// Page-locking of host ranges (the native tool pins its group buffers): nothing to lock here, but the calls are checked -- a range must not
+// overlap one that is registered, an unregister must name a registered start -- and counted (SNAPGPU_EMU_PIN_REPORT=1: a line at exit).
+namespace { std::mutex g_pin_mu; std::map<uintptr_t, size_t> g_pins; unsigned long long g_pin_calls = 0, g_pin_bytes = 0; bool g_pin_report_armed = false; }
+hipError_t hipHostRegister(void *p, size_t n, unsigned)
+{
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    const uintptr_t a = (uintptr_t)p;
+    for (auto &r : g_pins) if (a < r.first + r.second && r.first < a + n) { fprintf(stderr, "emu: hipHostRegister of a range that overlaps a registered one\n"); abort(); }
+    g_pins[a] = n; g_pin_calls++; g_pin_bytes += n;
+    if (!g_pin_report_armed && getenv("SNAPGPU_EMU_PIN_REPORT")) {
+        g_pin_report_armed = true;
+        atexit([] { fprintf(stderr, "emu: hipHostRegister calls %llu, bytes %llu, still registered at exit %zu\n", g_pin_calls, g_pin_bytes, g_pins.size()); });
+    }
+    return hipSuccess;
+}
+hipError_t hipHostUnregister(void *p)
+{
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    if (!g_pins.erase((uintptr_t)p)) { fprintf(stderr, "emu: hipHostUnregister of a pointer that is not registered\n"); abort(); }
+    return hipSuccess;
+}
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { if (n) memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { if (n) memset(d, v, n); return hipSuccess; }

@@ -352,6 +352,35 @@ def test_emu_native_fastq_to_sam(emu, tmp_path, opts):
     assert run_and_compare(TOOL, str(tmp_path), index_dir, fastq, opts, env=env, ref_opts=[o for o in opts if o not in ("-b", "97")]) > n
 
 
+def test_emu_native_tool_pins_its_group_buffers(emu, tmp_path):
+    """snapgpu-sam page-locks the buffers it hands to snapgpu_align_sam_single (hipHostRegister, looked up by name).  The emulated runtime
+    checks the calls -- no overlapping registration, every unregister names a registered start -- and reports at exit: ranges were
+    registered, none is left; and the file is still the reference CLI's (groups of two 61-read batches of ragged reads, two feeders)."""
+    import subprocess
+    from oracle import ref
+    if not ref.available() or not os.path.exists(ref.CLI_PATH):
+        pytest.skip("oracle/_ref not built here")
+    from tests.emu.build import TOOL
+    from tests.test_zz_gpu_native_sam import make_workload, sam_lines
+    d = str(tmp_path)
+    index_dir, fastq = make_workload(d, 400, genome_bases=300_000)
+    env = dict(os.environ, SNAPGPU_EMU_CUS="4", SNAPGPU_SAM_PIN_MIN="1", SNAPGPU_EMU_PIN_REPORT="1")
+    r = subprocess.run([ref.CLI_PATH, "single", index_dir, fastq, "-o", os.path.join(d, "ref.sam"), "-t", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, stdin=subprocess.DEVNULL, timeout=600)
+    assert r.returncode == 0
+    r = subprocess.run([TOOL, "single", index_dir, fastq, "-o", os.path.join(d, "new.sam"), "-b", "61", "-g", "2", "-q", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       stdin=subprocess.DEVNULL, timeout=1800, env=env)
+    out = r.stdout.decode(errors="replace")
+    assert r.returncode == 0, out[-2000:]
+    assert sam_lines(os.path.join(d, "ref.sam"), False) == sam_lines(os.path.join(d, "new.sam"), False)
+    line = [x for x in out.splitlines() if x.startswith("emu: hipHostRegister calls")]
+    assert line, out[-2000:]
+    calls, left = int(line[0].split("calls")[1].split(",")[0]), int(line[0].rsplit(" ", 1)[1])
+    assert calls >= 8 and left == 0, line[0]
+    r = subprocess.run([TOOL, "single", index_dir, fastq, "-o", os.path.join(d, "y.sam"), "-b", "200"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       stdin=subprocess.DEVNULL, timeout=1800, env=dict(env, SNAPGPU_SAM_PIN="0"))
+    assert r.returncode == 0 and b"hipHostRegister calls" not in r.stdout
+
+
 def test_emu_sam_fields_paired(emu):
     """The paired-end writer on the emulated device (k_sam_fields_paired: both mates' records + SAMFormat::fillMateInfo + print order):
     the first 400 pairs of the fixture parsed from the unmodified reference CLI's `paired` output, all 9 computed fields."""

@@ -99,6 +99,16 @@ def test_native_fastq_to_sam_identical_to_reference_cli(single_workload, opts):
     assert run_and_compare(TOOL, d, index_dir, fastq, opts) > 8000           # (with -om: secondary records too, flag 0x100)
 
 
+@pytest.mark.gpu
+@pytest.mark.skipif(not ref.available() or not os.path.exists(ref.CLI_PATH), reason="oracle/_ref not on this box")
+def test_native_fastq_to_sam_with_page_locked_group_buffers(single_workload):
+    """The tool registers the buffers it hands to snapgpu_align_sam_single with the HIP runtime (hipHostRegister) when they are big; here
+    every one is (SNAPGPU_SAM_PIN_MIN=1), over groups of two 1 000-read batches and two feeders -- and with the registration off."""
+    d, index_dir, fastq = single_workload
+    for env in (dict(os.environ, SNAPGPU_SAM_PIN_MIN="1"), dict(os.environ, SNAPGPU_SAM_PIN="0")):
+        assert run_and_compare(TOOL, d, index_dir, fastq, ["-b", "1000", "-g", "2", "-q", "2"], env=env, ref_opts=[]) > 8000
+
+
 def make_paired_workload(d, n_pairs, genome_bases=600_000):
     from tests.pairs_util import hard_pairs
     contigs = synth.make_genome(178, genome_bases, n_contigs=3, repeat_frac=0.15)
