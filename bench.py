@@ -213,11 +213,11 @@ def parse_args(argv=None):
                     help="single = configs[1] (the metric's config); paired = configs[2], 2x150 bp FR pairs through the paired-end path")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="one GPU, --workload single only: do not add the short paired-end leg (`paired`) and the 256 Mb leg (`genome_256mb`)")
-    ap.add_argument("--paired-leg-steps", type=int, default=6, help="timed steps of the extra paired-end leg")
+    ap.add_argument("--paired-leg-steps", type=int, default=10, help="timed steps of the extra paired-end leg")
     ap.add_argument("--standin-mb", type=int, default=256, help="genome size of the extra `genome_256mb` leg (tests shrink it)")
     ap.add_argument("--standin-leg", action="store_true", help="add the `genome_256mb` leg (the line of rounds 1-3 on the 256 Mb stand-in; in the default run until round 4)")
     ap.add_argument("--no-c5-leg", action="store_true", help="do not add the `c5` leg (configs[4] on one GPU: 2 x 250 bp pairs, -d 20, insert N(600, 80^2), 0.2 % long indels)")
-    ap.add_argument("--c5-leg-steps", type=int, default=3)
+    ap.add_argument("--c5-leg-steps", type=int, default=6)
     ap.add_argument("--c5-reads", type=int, default=200_000, help="reads per step of the c5 leg")
     ap.add_argument("--no-e2e-leg", action="store_true", help="do not add the `e2e` leg (FASTQ -> SAM through snap_amd/snapgpu-sam)")
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the e2e leg's FASTQ")
@@ -367,6 +367,7 @@ def run_leg(args, env, bed, workload, primary):
     torch.cuda.synchronize()
 
     call_ms = []                        # host-side duration of every align call of the timed region (the call blocks until its launch is done)
+    event_ms = []                       # hipEvent duration of the same launches, one entry per call (read from the context right after the call)
 
     def run_steps(k_steps, only_batch=None, record=None):
         def feed(f):
@@ -376,6 +377,8 @@ def run_leg(args, env, bed, workload, primary):
                 feeders[f].align_device(n_units, db.data_ptr(), dq.data_ptr(), do.data_ptr(), d_prims[f].data_ptr())
                 if record is not None:
                     record.append(1e3 * (time.perf_counter() - t_c))      # (list.append is atomic under the GIL)
+                    ms_k, nl_k = feeders[f].kernel_time(reset=True)       # this context's launches since its last call: this call's
+                    event_ms.append((ms_k, nl_k))
         if n_feed == 1:
             feed(0)
             return
@@ -415,12 +418,10 @@ def run_leg(args, env, bed, workload, primary):
     log("%s: %d timed steps in %.2fs" % (workload, args.steps, elapsed))
 
     counters = {}
-    kernel_ms, launches = 0.0, 0
+    kernel_ms, launches = sum(m_ for m_, _ in event_ms), sum(n_ for _, n_ in event_ms)
     for a_ in feeders:
         for k_, v_ in a_.counters().items():
             counters[k_] = counters.get(k_, 0) + v_
-        ms_, nl_ = a_.kernel_time()
-        kernel_ms += ms_; launches += nl_
     # a dedicated, untimed step: EVERY feeder aligns batch 0 -- their results must be the same bytes, and they are what the parity check
     # below compares with the reference
     run_steps(n_feed, only_batch=0)
@@ -603,7 +604,7 @@ def run_leg(args, env, bed, workload, primary):
                                               "refused_other_band_or_decision": (counters.get("cycles_single_fallback", 0) >> 16) & 0xffff,
                                               "refused_skipped_or_limit": counters.get("cycles_single_fallback", 0) & 0xffff}
     attach_pmc(out, args, getattr(args, "pmc_tag", workload), n, n_feed, avg_ms, elapsed)
-    finish_roofline(out, call_ms, elapsed, args.steps)
+    finish_roofline(out, call_ms, elapsed, args.steps, [m_ for m_, _ in event_ms])
 
     if world == 1 and not args.skip_cpu:
         from oracle import ref                                       # cpu_baseline leg only
@@ -760,14 +761,20 @@ def attach_pmc(out, args, workload, n, n_feed, avg_ms, elapsed):
         out["roofline"]["traffic_source"] = "profiles/pmc_latest.json unreadable: %s" % e_
 
 
-def finish_roofline(out, call_ms, elapsed, steps):
+def finish_roofline(out, call_ms, elapsed, steps, event_ms=()):
     """What the line says ABOUT its roofline numbers: which resource the kernel is closest to by the counters (`bound`), the figures a reader
     needs as top-level scalars of `roofline` (the driver's record keeps scalars), and the spread of the launches' durations."""
     r = out["roofline"]
     if call_ms:
+        # two different quantities (VERDICT r05 item 6): how long the HOST waited in each blocking align call -- with other feeders' launches
+        # queued on the same GPU in front of it -- and how long each call's launches lasted by hipEvents on their stream
         cm = sorted(call_ms)
-        r["launch_ms_min"], r["launch_ms_median"], r["launch_ms_max"] = cm[0], cm[len(cm) // 2], cm[-1]
-        r["launch_ms_basis"] = "host wall time of each blocking align call of the timed region (%d calls); avg_launch_ms is the hipEvent average of the same launches" % len(cm)
+        r["blocking_call_ms_min"], r["blocking_call_ms_median"], r["blocking_call_ms_max"] = cm[0], cm[len(cm) // 2], cm[-1]
+        r["blocking_call_ms_basis"] = "host wall time of each blocking align call of the timed region (%d calls; the call's own launches AND whatever other feeders had queued in front)" % len(cm)
+    if event_ms:
+        em = sorted(event_ms)
+        r["launch_event_ms_min"], r["launch_event_ms_median"], r["launch_event_ms_max"] = em[0], em[len(em) // 2], em[-1]
+        r["launch_event_ms_basis"] = "hipEvent time of the launches of each align call of the timed region (%d calls); avg_launch_ms is their average per launch" % len(em)
     if isinstance(r.get("probe"), dict):
         r["probe_frac"] = r["probe"].get("frac")
         r["probe_frac_bucket_lines"] = r["probe"].get("frac_bucket_lines")
@@ -897,13 +904,57 @@ def run_e2e(args, idx_dir, genome):
     return o
 
 
+def parity_verdict(out):
+    """Which legs of the line disagree with the reference (empty: none), and -- because the driver's record keeps scalars of `config` and
+    `roofline` but only the key names of everything else -- the parity figures and the legs' values lifted into `config` as scalars."""
+    cfg, fails = out["config"], []
+
+    def one(tag, leg):
+        if not isinstance(leg, dict):
+            return
+        if "error" in leg and "value" not in leg:
+            cfg[tag + "error"] = str(leg["error"])[:200]
+            fails.append("%sleg failed: %s" % (tag, str(leg["error"])[:120]))
+            return
+        if tag:
+            cfg[tag + "value"] = leg.get("value")
+        if isinstance(leg.get("cpu_baseline"), dict):
+            cfg[tag + "cpu_baseline_value"] = leg["cpu_baseline"].get("value")
+        pc = leg.get("parity_check")
+        if isinstance(pc, dict):
+            units = pc.get("reads", pc.get("pairs"))
+            mm = pc.get("mismatching_pairs") if "mismatching_pairs" in pc else len(pc.get("mismatching_fields") or [])
+            cfg[tag + "parity_units"], cfg[tag + "parity_mismatching"] = units, mm
+            cfg[tag + "parity_exact_replayed"] = pc.get("exact_replayed")
+            if mm:
+                fails.append("%sparity_check: %s" % (tag, json.dumps(pc)[:300]))
+    one("", out)
+    for tag in ("paired", "c5", "genome_256mb"):
+        if tag in out:
+            one(tag + "_", out[tag])
+    e = out.get("e2e")
+    if isinstance(e, dict):
+        if "error" in e and "value" not in e:
+            cfg["e2e_error"] = str(e["error"])[:200]
+            fails.append("e2e leg failed: %s" % str(e["error"])[:120])
+        else:
+            for k in ("value", "value_min", "value_median", "index_load_s", "records_compared", "identical_records"):
+                if k in e:
+                    cfg["e2e_" + k] = e[k]
+            if e.get("identical_records") is False:
+                fails.append("e2e: records differ from the reference CLI's (%s vs %s)" % (e.get("records_hash"), e.get("reference_records_hash")))
+    cfg["parity_failures"] = len(fails)
+    return fails
+
+
 def compact_leg(o):
     """What an extra leg contributes to the line."""
     keep = {k: o[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step") if k in o}
     keep["config"] = {k: o["config"][k] for k in ("workload", "genome_mb", "feeders_per_gpu", "index_bytes_hbm") if k in o["config"]}
     r = o["roofline"]
     keep["roofline"] = {k: r[k] for k in ("kernel", "bound", "nominal_bound", "bound_fractions", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "traffic_over_algorithmic",
-                                          "algorithmic_bytes_per_launch", "avg_launch_ms", "launch_ms_min", "launch_ms_median", "launch_ms_max",
+                                          "algorithmic_bytes_per_launch", "avg_launch_ms", "blocking_call_ms_min", "blocking_call_ms_median", "blocking_call_ms_max",
+                                          "launch_event_ms_min", "launch_event_ms_median", "launch_event_ms_max",
                                           "achieved_basis", "per_read", "valu_issue", "valu_issue_frac", "salu_issue", "salu_issue_frac", "wait_any_frac_of_wave_cycles",
                                           "phase4_help") if k in r}
     for k in ("cpu_baseline", "parity_check", "aligned_fraction"):
@@ -1001,7 +1052,9 @@ def main():
             close_bed(bed2)
         except BaseException as e_:          # noqa: BLE001
             out["genome_256mb"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+    failures = []
     if rank == 0:
+        failures = parity_verdict(out)
         out["bench_wall_s"] = time.time() - _T_PROCESS
         try:
             import resource
@@ -1009,6 +1062,10 @@ def main():
         except Exception:          # noqa: BLE001
             pass
         os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if failures:              # the line is written (it says what differed), and the process fails: a parity regression must not look like a clean run
+        log("PARITY FAILURE: " + "; ".join(failures))
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(3)
 
 
 if __name__ == "__main__":

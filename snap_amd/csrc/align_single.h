@@ -198,7 +198,9 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     uint32_t ag_hw0, ag_hw1;               // EXACT only: bytes of each image written since it was last zeroed (what the next read must clear)
     uint32_t ag_epoch, ag_tag;             // EXACT only: reads since the images were last cleared (1 .. 15) and its tag bits (dev_common.h: bt_cell): cells of other reads read as zero
     // ---- per-read state (wave-uniform)
-    int lane;
+    // (not a stored value: in the paired-end kernel this object lives in LDS, one per WAVE -- paired_args.h: PE_FRAME_BYTES)
+    struct LaneId { __device__ __forceinline__ operator int() const { return lane_id(); } };
+    LaneId lane;
     int read_len;
     uint32_t n_used;
     uint32_t highest_used_weight_list;

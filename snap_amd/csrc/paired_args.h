@@ -16,7 +16,12 @@
 #define SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 3 : 2)
 #endif
 
-struct PairedLds { uint32_t single_total, rd, ql, lk, exhausted, miss, hs, list_head, seed_used, sh, total; };
+// PE_FRAME_BYTES: the wave's FRAME -- the three objects of the kernel (the single-end Aligner, DevPL, PairedCore: wave-uniform state, one pair
+// per wave) live in LDS, not in per-lane private memory: as locals their addresses escape (dynamic indices, the objects point at one another),
+// the compiler keeps them in scratch, and 1.9 KB per LANE of scratch -- 120 KB per wave, behind the same L2 as the candidate pools -- is what
+// 94 % of the kernel's wave cycles waited for (profiles/r05zz).  k_align_paired static_asserts that they fit.
+#define PE_FRAME_BYTES 2048u
+struct PairedLds { uint32_t single_total, rd, ql, lk, exhausted, miss, hs, list_head, seed_used, sh, frame, total; };
 static __host__ __device__ __forceinline__ PairedLds paired_lds_layout(uint32_t single_total, uint32_t RL, uint32_t max_seeds) {
     PairedLds L; uint32_t o = (single_total + 15) & ~15u;
     L.single_total = o;
@@ -29,6 +34,7 @@ static __host__ __device__ __forceinline__ PairedLds paired_lds_layout(uint32_t 
     L.list_head = o; o += ((SNAPGPU_MAX_K + 1) * 4 + 15) & ~15u;
     L.seed_used = o; o += (((RL + 31) / 32) * 4 + 15) & ~15u;
     L.sh = o; o += ((uint32_t)sizeof(PEShared) + 15) & ~15u;
+    L.frame = o; o += PE_FRAME_BYTES;
     L.total = o;
     return L;
 }

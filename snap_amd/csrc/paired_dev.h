@@ -13,6 +13,7 @@
 #include "kernel_common.h"
 #include "paired.h"
 #include "paired_args.h"
+#include <new>
 
 // EXACT: the replay instantiation for pairs whose banded affine-gap traceback left the band (align_single.h: Aligner<.., EXACT>):
 // ag_persist[0 / 1] are the wave's images of IntersectingPairedEndAligner's affineGap / reverseAffineGap traceback arrays, the
@@ -567,8 +568,12 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     uint8_t *sc = a.scratch + (size_t)wave_slot * a.stride;
 
     WaveShared *ws = (WaveShared *)(my + SL.shared);
-    Aligner<AGC, SEC, EXACT> al(a.ix, a.tab, a.scfg, ws);
-    al.lane = lane;
+    // the wave's frame (paired_args.h: PE_FRAME_BYTES): the three objects are constructed in LDS
+    typedef Aligner<AGC, SEC, EXACT> AL_T; typedef DevPL<AGC, SEC, EXACT> PL_T; typedef PairedCore<PL_T> CORE_T;
+    constexpr uint32_t AL_SZ = ((uint32_t)sizeof(AL_T) + 15u) & ~15u, PL_SZ = ((uint32_t)sizeof(PL_T) + 15u) & ~15u;
+    static_assert(AL_SZ + PL_SZ + sizeof(CORE_T) <= PE_FRAME_BYTES, "the wave's frame does not fit PE_FRAME_BYTES");
+    uint8_t *frame = my + PLd.frame;
+    AL_T &al = *new (frame) AL_T(a.ix, a.tab, a.scfg, ws);
     al.rd[0] = my + SL.rd0; al.rd[1] = my + SL.rd1;
     al.ql[0] = my + SL.ql0; al.ql[1] = my + SL.ql1;
     al.gw = my + SL.gw;
@@ -595,7 +600,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
         al.sec_ord = al.sec_key + 2 * (size_t)a.ssec_cfg.cap;
         al.n_sec = 0; al.n_sec_raw = 0; al.sec_overflow = 0;
     }
-    DevPL<AGC, SEC, EXACT> pl;
+    PL_T &pl = *new (frame + AL_SZ) PL_T;
     pl.al = &al; pl.tab = a.tab; pl.ws = ws; pl.kmax_lv = a.kmax_lv; pl.lv_big = (uint16_t *)(sc + a.off_lv_big);
     al.ag_persist0 = al.ag_persist1 = pl.ag_persist0 = pl.ag_persist1 = nullptr;
     al.ag_hw0 = al.ag_hw1 = pl.ag_hw0 = pl.ag_hw1 = 0;
@@ -613,7 +618,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     }
     pl.agp = AGParams{a.scfg.match_reward, a.scfg.sub_penalty, a.scfg.gap_open, a.scfg.gap_extend, a.scfg.five_bonus, a.scfg.three_bonus};
 
-    PairedCore<DevPL<AGC, SEC, EXACT>> core(pl, a.pcfg);
+    CORE_T &core = *new (frame + AL_SZ + PL_SZ) CORE_T(pl, a.pcfg);
     core.help_min = a.help_min;
     core.lk = (PELookup *)(my + PLd.lk);
     core.exhausted = (uint32_t *)(my + PLd.exhausted);

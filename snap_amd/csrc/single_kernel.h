@@ -21,7 +21,6 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
 
     WaveShared *ws = (WaveShared *)(my + L.shared);
     Aligner<AGC, SEC, EXACT, TIMED, PLANES, RESOLVE> al(a.ix, a.tab, a.cfg, ws);
-    al.lane = lane;
     al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
     al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
     al.gw = my + L.gw;
@@ -88,6 +87,12 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         const uint64_t dbg_t0 = TIMED ? wave_clock() : 0; const uint64_t dbg_ag0 = al.cnt.ag;
         al.align_read(a.bases + b, a.quals + b, (int)(e - b));
         WAVE_SYNC();
+#if defined(SNAPGPU_TEST_BREAK_PARITY)
+        // TEST BUILDS ONLY (snap_amd/ab/libsnapgpu_broken.so, tests/test_zzzz_gpu_bench.py): a kernel that answers differently from the
+        // reference, so that the bench line's "fails loudly" path can be exercised on the hardware
+        if (i % 997u == 7u && lane == 0) ws->primary.mapq ^= 1;
+        WAVE_SYNC();
+#endif
         if constexpr (TIMED) {
             if (a.dbg) {
                 const unsigned long long cyc = wave_clock() - dbg_t0, nag = al.cnt.ag - dbg_ag0;

@@ -45,10 +45,17 @@ def test_bench_line_with_its_extra_legs_small():
     assert o["n_gpus"] == 1 and o["steps"] == 3 and o["value"] > 0 and o["unit"] == "reads/s"
     assert o["config"]["genome_mb"] == 24 and o["config"]["kernel_source_hash"]
     rf = o["roofline"]
-    for k in ("bound", "nominal_bound", "achieved", "peak", "unit", "frac", "traffic", "probe", "probe_frac", "launch_ms_min", "launch_ms_median", "launch_ms_max",
-              "mean_wave_residency"):
+    for k in ("bound", "nominal_bound", "achieved", "peak", "unit", "frac", "traffic", "probe", "probe_frac", "blocking_call_ms_min", "blocking_call_ms_median", "blocking_call_ms_max",
+              "launch_event_ms_min", "launch_event_ms_median", "launch_event_ms_max", "mean_wave_residency"):
         assert k in rf, k
-    assert rf["launch_ms_min"] <= rf["launch_ms_median"] <= rf["launch_ms_max"]
+    assert rf["blocking_call_ms_min"] <= rf["blocking_call_ms_median"] <= rf["blocking_call_ms_max"]
+    assert rf["launch_event_ms_min"] <= rf["launch_event_ms_median"] <= rf["launch_event_ms_max"]
+    # the parity figures and the legs' values as scalars of `config` (what the driver's record keeps)
+    cf = o["config"]
+    assert cf["parity_failures"] == 0 and cf["parity_units"] >= 20000 and cf["parity_mismatching"] == 0
+    assert cf["paired_value"] == o["paired"]["value"] and cf["paired_parity_mismatching"] == 0 and cf["paired_parity_units"] >= 10000
+    assert cf["c5_value"] == o["c5"]["value"] and cf["c5_parity_mismatching"] == 0
+    assert cf["e2e_value"] == o["e2e"]["value"] and cf["e2e_identical_records"] is True
     assert rf["probe"]["numerator_basis"].startswith("reference slot walk")
     assert rf["probe"]["algorithmic_bytes_per_launch"] <= rf["probe"]["bucket_line_bytes_per_launch"] * 1.5
     pc = o["parity_check"]
@@ -69,6 +76,27 @@ def test_bench_line_with_its_extra_legs_small():
     g = o["genome_256mb"]
     assert "error" not in g, g
     assert g["config"]["genome_mb"] == 12 and g["value"] > 0 and g["parity_check"]["mismatching_fields"] == []
+
+
+@pytest.mark.gpu
+def test_bench_fails_loudly_on_a_kernel_that_answers_differently():
+    """snap_amd/ab/libsnapgpu_broken.so (__graft_entry__.build_broken_variant: the product's objects with ONE translation unit rebuilt
+    -DSNAPGPU_TEST_BREAK_PARITY, which flips the MAPQ's low bit of every 997th read in the single-end kernel the bench times) under
+    bench.py: the line is still written and says what differed, and the process exits non-zero."""
+    lib = os.path.join(ROOT, "snap_amd", "ab", "libsnapgpu_broken.so")
+    if not os.path.exists(lib):
+        pytest.skip("the broken variant was not built (python -c 'import __graft_entry__ as g; g.build_broken_variant()')")
+    e = dict(os.environ)
+    e["SNAP_BENCH_DIR"] = e.get("SNAP_BENCH_DIR", "/tmp/snap_bench_test")
+    r = subprocess.run([sys.executable, "scripts/ab_bench.py", "run", "broken"] + SMALL + ["--no-extra-legs", "--cpu-seconds", "1", "--skip-probe", "--skip-refwalk",
+                                                                                          "--skip-breakdown"], cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 3, (r.returncode, r.stderr.decode(errors="replace")[-2000:])
+    assert b"PARITY FAILURE" in r.stderr
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    o = json.loads(lines[0])
+    assert o["config"]["parity_failures"] == 1 and o["config"]["parity_mismatching"] >= 1
+    assert any("mapq" in str(f) for f in o["parity_check"]["mismatching_fields"])
 
 
 @pytest.mark.gpu
