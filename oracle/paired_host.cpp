@@ -39,6 +39,7 @@ static int g_use_restatement = 0;
 extern "C" void pairedhost_use_restatement(int on) { g_use_restatement = on; }
 
 struct HostPL {
+    typedef HostPL *SelfPtr;
     const snapgpu_index_view *ix;
     oracle_index oix;
     oracle_ag_params agp;

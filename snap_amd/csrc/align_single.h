@@ -175,25 +175,26 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     // held by value: a reference member would make the kernel-argument struct escape through a
     // flat pointer and pin this whole object (ScoreSets, results, counters) in scratch memory
     const DevIndex ix;
-    const DevTables *tab;
+    GP<const DevTables> tab;
     const AlignCfg cfg;
     // ---- LDS carve-out for this wave
-    uint8_t  *rd[2];        // bases, forward / reverse complement
-    uint8_t  *ql[2];        // qualities in the same orientation
-    uint8_t  *gw;           // reference window: gw[x] = genome[win_loc - WIN_PAD + x]
-    uint32_t *seed_used;
-    uint16_t *wl_next, *wl_prev;
-    uint16_t *lv_tri;
-    int16_t  *ag_rows;      // H, H-1, E rows of the affine-gap DP
-    unsigned long long *rp; // bit planes of the read, both directions (planes.h); [dir][plane][read_plane_words(RL)]
-    unsigned long long *tp; // bit planes of the candidate's reference window; [plane][text_plane_blocks(RL, WIN_PAD)]
+    // (LP<T> / GP<T>, dev_common.h: pointers stored with their address space)
+    LP<uint8_t>  rd[2];     // bases, forward / reverse complement
+    LP<uint8_t>  ql[2];     // qualities in the same orientation
+    LP<uint8_t>  gw;        // reference window: gw[x] = genome[win_loc - WIN_PAD + x]
+    LP<uint32_t> seed_used;
+    LP<uint16_t> wl_next, wl_prev;
+    LP<uint16_t> lv_tri;
+    LP<int16_t>  ag_rows;   // H, H-1, E rows of the affine-gap DP
+    LP<unsigned long long> rp; // bit planes of the read, both directions (planes.h); [dir][plane][read_plane_words(RL)]
+    LP<unsigned long long> tp; // bit planes of the candidate's reference window; [plane][text_plane_blocks(RL, WIN_PAD)]
     int tp_org;             // bit of tp that is genome[loc] of the staged candidate
-    unsigned long long *lvp; // LDS work area of the prepared plane form (planes.h: lv_plane_work_words)
+    LP<unsigned long long> lvp; // LDS work area of the prepared plane form (planes.h: lv_plane_work_words)
     uint32_t rd_plain;      // bit dir: rd[dir] is all ACGT (its 'N' / other planes are empty)
     // ---- HBM scratch for this wave
-    uint16_t *heads;
-    Elem     *pool;
-    uint8_t  *ag_scratch;
+    GP<uint16_t> heads;
+    GP<Elem>     pool;
+    GP<uint8_t>  ag_scratch;
     uint8_t  *ag_persist0, *ag_persist1;   // EXACT only: images of the forward object's (affineGap) and the backward object's (reverseAffineGap) array
     uint32_t ag_hw0, ag_hw1;               // EXACT only: bytes of each image written since it was last zeroed (what the next read must clear)
     uint32_t ag_epoch, ag_tag;             // EXACT only: reads since the images were last cleared (1 .. 15) and its tag bits (dev_common.h: bt_cell): cells of other reads read as zero
@@ -223,7 +224,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     unsigned long long *se_diag;       // snapgpu_counters::reserved[1 .. 2]
     int se_slot; uint32_t se_n, se_tried, cur_read; SESpec *se_mine;
     // candidates for BaseAligner::alignAffineGap, collected by the Hamming pass only (BaseAligner.cpp:1445-1456)
-    snapgpu_single_result *agc;
+    GP<snapgpu_single_result> agc;
     uint32_t agc_cap, n_agc, agc_overflow;
     // secondary results (SEC only): the list AlignRead appends to, then finalizeSecondaryResults' working arrays
     SecCfg sec_cfg;
@@ -235,15 +236,20 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     // times per candidate / per read, and keeping ~150 dwords of it live across the LV and
     // affine-gap code is what pushed the kernel to 1-2 waves per SIMD.  Every lane executes the
     // same stores with the same values (uniform control flow), so no lane guard is needed.
-    ScoreSet &all, &non_alt;
-    snapgpu_single_result &primary, &first_alt;
-    WaveCounters &cnt;
+    // (Accessors over ONE stored LDS address, not reference members: where this object itself lives in memory -- the paired-end kernel keeps it
+    //  in LDS -- a reference member is a pointer loaded back from there, i.e. a generic one, and every access through it a FLAT instruction.)
+    LDS_AS WaveShared *ws_;
+    __device__ __forceinline__ ScoreSet &all() const { return *(ScoreSet *)&ws_->all; }
+    __device__ __forceinline__ ScoreSet &non_alt() const { return *(ScoreSet *)&ws_->non_alt; }
+    __device__ __forceinline__ snapgpu_single_result &primary() const { return *(snapgpu_single_result *)&ws_->primary; }
+    __device__ __forceinline__ snapgpu_single_result &first_alt() const { return *(snapgpu_single_result *)&ws_->first_alt; }
+    __device__ __forceinline__ WaveCounters &cnt() const { return *(WaveCounters *)&ws_->cnt; }
 
     __device__ __forceinline__ Aligner(const DevIndex &ix_, const DevTables *tab_, const AlignCfg &cfg_, WaveShared *ws)
         : ix(ix_), tab(tab_), cfg(cfg_), tp_org(0), rd_plain(0), ag_hw0(0), ag_hw1(0), ag_epoch(0), ag_tag(0), read_len(0), popular_seeds_skipped(0),
           ag_stale(0), ag_replay(0), ag_obj_used0(0), ag_obj_used1(0), max_k(cfg_.max_k), ag_calls_unit(0),
           agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0), n_sec(0), n_sec_raw(0), sec_overflow(0),
-          all(ws->all), non_alt(ws->non_alt), primary(ws->primary), first_alt(ws->first_alt), cnt(ws->cnt) {
+          ws_((LDS_AS WaveShared *)ws) {
         if constexpr (RESOLVE) { this->rs_base = nullptr; this->rs_n0 = this->rs_n1 = 0; this->rs_over = 0; }
     }
 
@@ -330,12 +336,12 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     __device__ __forceinline__ int score_limit(bool for_alt) const {          // BaseAligner.cpp:2556-2570
         int64_t inner;
         if (for_alt) {
-            int64_t g = cfg.max_gap_alt < non_alt.best_score ? cfg.max_gap_alt : non_alt.best_score;
-            int64_t b = (int64_t)non_alt.best_score - g;
-            inner = all.best_score < b ? all.best_score : b;
+            int64_t g = cfg.max_gap_alt < non_alt().best_score ? cfg.max_gap_alt : non_alt().best_score;
+            int64_t b = (int64_t)non_alt().best_score - g;
+            inner = all().best_score < b ? all().best_score : b;
         } else {
-            int64_t a = (int64_t)all.best_score + cfg.max_gap_alt;
-            inner = a < non_alt.best_score ? a : non_alt.best_score;
+            int64_t a = (int64_t)all().best_score + cfg.max_gap_alt;
+            inner = a < non_alt().best_score ? a : non_alt().best_score;
         }
         int64_t m = (int64_t)max_k < inner ? (int64_t)max_k : inner;
         int64_t v = (int64_t)cfg.extra_depth + m;
@@ -345,7 +351,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     // Genome::getSubstring(location, lengthNeeded) != NULL  (Genome.h:339-367)
     __device__ __forceinline__ bool substring_ok(int64_t loc, int64_t len) const {
         if (!substring_in_range(loc, len)) return false;
-        return substring_ok_known(loc, len, first_u32(ix.genome[loc]) == 'n');
+        return substring_ok_known(loc, len, first_u32(((const G(uint8_t) *)ix.genome)[loc]) == 'n');
     }
     // the part of getSubstring that needs no memory: the window lies inside what the genome (and its padding) holds
     __device__ __forceinline__ bool substring_in_range(int64_t loc, int64_t len) const {
@@ -364,12 +370,12 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         int lo = 0, hi = (int)ix.n_contigs - 1, found = -1;
         while (lo <= hi) {
             int mid = (lo + hi) >> 1;
-            uint64_t b = first_u64(ix.contig_begin[mid]);
+            uint64_t b = first_u64(((const G(uint64_t) *)ix.contig_begin)[mid]);
             if ((int64_t)b <= loc) { found = mid; lo = mid + 1; } else { hi = mid - 1; }
         }
         if (found < 0) return false;
-        int64_t cbeg = (int64_t)first_u64(ix.contig_begin[found]);
-        int64_t cend = found == (int)ix.n_contigs - 1 ? nb : (int64_t)first_u64(ix.contig_begin[found + 1]);
+        int64_t cbeg = (int64_t)first_u64(((const G(uint64_t) *)ix.contig_begin)[found]);
+        int64_t cend = found == (int)ix.n_contigs - 1 ? nb : (int64_t)first_u64(((const G(uint64_t) *)ix.contig_begin)[found + 1]);
         if (cend <= loc + len) return false;
         (void)cbeg;
         return true;
@@ -664,16 +670,16 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         return p;
     }
     __device__ __forceinline__ void stage_window(int64_t loc) {
-        uint8_t *const gw = lds_ptr(this->gw);
+        uint8_t *const gw = this->gw;
         const int total = read_len + 2 * WIN_PAD;
-        const uint8_t *src = ix.genome + (loc - WIN_PAD);
+        const G(uint8_t) *src = (const G(uint8_t) *)ix.genome + (loc - WIN_PAD);       // (HBM, said out loud: where this object lives in LDS the pointer comes back generic)
         // 4 bytes per lane where the source is 4-byte aligned; byte loads at the ragged ends
         uintptr_t a = (uintptr_t)src;
         int head = (int)((4 - (a & 3)) & 3);
         if (head > total) head = total;
         if (lane < head) gw[lane] = src[lane];
         int words = (total - head) >> 2;
-        const uint32_t *s32 = (const uint32_t *)(src + head);
+        const G(uint32_t) *s32 = (const G(uint32_t) *)(src + head);
         for (int w = lane; w < words; w += WAVE) {
             uint32_t v = s32[w];
             uint8_t *d = gw + head + 4 * w;
@@ -789,13 +795,13 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 LvPlanes lp;
                 if (lv_planes) {
                     const int rpw = (int)read_plane_words(cfg.RL);
-                    const LDS_AS unsigned long long *rb = (const LDS_AS unsigned long long *)rp + (e_dir ? 4 * rpw : 0);
-                    const LDS_AS unsigned long long *tb = (const LDS_AS unsigned long long *)tp;
+                    const LDS_AS unsigned long long *rb = (const LDS_AS unsigned long long *)(unsigned long long *)rp + (e_dir ? 4 * rpw : 0);
+                    const LDS_AS unsigned long long *tb = (const LDS_AS unsigned long long *)(unsigned long long *)tp;
                     lp.p0 = rb; lp.p1 = rb + rpw; lp.pn = rb + 2 * rpw; lp.po = rb + 3 * rpw;
                     const int tpb = (int)text_plane_blocks(cfg.RL, WIN_PAD);
                     lp.t0 = tb; lp.t1 = tb + tpb; lp.tn = tb + 2 * tpb;
                     lp.p_org = org; lp.t_org = tp_org + org; lp.st = st; lp.p_words = rpw; lp.t_words = tpb;
-                    lp.work = (LDS_AS unsigned long long *)lvp; lp.plain = ((rd_plain >> e_dir) & 1u) != 0;
+                    lp.work = (LDS_AS unsigned long long *)(unsigned long long *)lvp; lp.plain = ((rd_plain >> e_dir) & 1u) != 0;
                 }
                 LVResult r = lv_compute(P, Q, plen, T, tlen, lim, lv_tri, cfg.kmax, tab, cfg.RL, lv_planes ? &lp : nullptr);
                 // results are wave-uniform; say so, so they (and everything derived from them) live in SGPRs
@@ -804,15 +810,15 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 if (half == 0) {
                     score1 = r.score; mp1 = r.match_probability;
                     ag1 = (seed_len + read_len - tail_start - score1) * cfg.match_reward - score1 * cfg.sub_penalty;
-                    cnt.lv_ref_bytes += (uint64_t)plen + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e));
+                    cnt().lv_ref_bytes += (uint64_t)plen + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e));
                 } else {
                     score2 = r.score; mp2 = r.match_probability; loc_offset = r.net_indel;
                     ag2 = (seed_offset - score2) * cfg.match_reward - score2 * cfg.sub_penalty;
-                    cnt.lv_ref_bytes += (uint64_t)plen;
+                    cnt().lv_ref_bytes += (uint64_t)plen;
                 }
             }
-            if (!HAM) cnt.lv++;
-            cnt.cyc_lv += clk() - t_lv0;
+            if (!HAM) cnt().lv++;
+            cnt().cyc_lv += clk() - t_lv0;
             lv1 = score1; lv2 = score1 == -1 ? -2 : score2;
 
             if (!HAM && score1 != -1 && score2 != -1) {
@@ -822,7 +828,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                     if (lv_planes) stage_window(loc);             // affine gap reads bytes
                     score1 = 0; score2 = 0; ag1 = seed_len; ag2 = 0;
                     used_ag = 1;
-                    cnt.ag++;
+                    cnt().ag++;
                     if (++ag_calls_unit == WAVE_PRIO_HEAVY_AFTER) wave_set_priority(1);
                     const uint64_t t_ag0 = clk();
                     AGParams agp{cfg.match_reward, cfg.sub_penalty, cfg.gap_open, cfg.gap_extend, cfg.five_bonus, cfg.three_bonus};
@@ -838,7 +844,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                         const LdsSeq P = lds_seq(ByteSeq{rdd + org, st}), Q = lds_seq(ByteSeq{qld + org, st}), T = lds_seq(ByteSeq{data + org, st});
                         note_ag_extent(half, banded, plen, lim, tlen);
                         AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, e_dir != 0,
-                                                      false, ag_rows, EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab, EXACT ? ag_tag : 0u);
+                                                      false, ag_rows, EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : (uint8_t *)ag_scratch, cfg.RL, tab, EXACT ? ag_tag : 0u);
                         a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
                         a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
                         a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
@@ -852,7 +858,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                             score2 = a.n_edits; mp2 = a.match_probability; loc_offset = a.text_offset;
                         }
                     }
-                    cnt.cyc_ag += clk() - t_ag0;
+                    cnt().cyc_ag += clk() - t_ag0;
                 }
             }
 
@@ -925,8 +931,8 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             if ((w0 ^ w1) == 0xFFFFFFF5u) atomicExch(&slot->helpers, 0u);      // (uses both return values: the exchanges have completed)
             XW::st(slot->read, cur_read); XW::st(slot->n, n); XW::st(slot->owner_pos, 0u);
             XW::st(slot->lim_alt, (int32_t)score_limit(true)); XW::st(slot->lim_non_alt, (int32_t)score_limit(false));
-            XW::st(slot->best_all, (uint32_t)all.best_score);
-            XW::st(*(uint64_t *)&slot->items, (uint64_t)(uintptr_t)se_items); XW::st(*(uint64_t *)&slot->pool, (uint64_t)(uintptr_t)pool);
+            XW::st(slot->best_all, (uint32_t)all().best_score);
+            XW::st(*(uint64_t *)&slot->items, (uint64_t)(uintptr_t)se_items); XW::st(*(uint64_t *)&slot->pool, (uint64_t)(uintptr_t)(Elem *)pool);
             XW::st(*(uint64_t *)&slot->spec, (uint64_t)(uintptr_t)spec);
             XW::fence_release();                            // the candidate table, the list and the cleared records, for the other XCDs
             atomicExch(&slot->state, 1u);
@@ -967,7 +973,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         uint32_t n_ag = XW::ld(sp->n_ag), stale = XW::ld(sp->stale);
         uint64_t bytes = XW::ld(sp->lv_ref_bytes);
         if (lim == limit_e) {
-            if (high && ((e_lps <= best_then) != (e_lps <= (uint32_t)all.best_score))) { if (lane == 0 && se_diag) atomicAdd(&se_diag[-1], 1ull << 16); return false; }  // the affine-gap decision (:1203) would differ
+            if (high && ((e_lps <= best_then) != (e_lps <= (uint32_t)all().best_score))) { if (lane == 0 && se_diag) atomicAdd(&se_diag[-1], 1ull << 16); return false; }  // the affine-gap decision (:1203) would differ
             ce.sc = XW::ld(sp->sc); ce.mp = XW::ld(sp->mp); ce.loc = XW::ld(sp->loc); ce.used_ag = XW::ld(sp->used_ag);
             ce.clip_before = XW::ld(sp->clip_before); ce.clip_after = XW::ld(sp->clip_after); ce.ag_score = XW::ld(sp->ag_score);
         } else {
@@ -981,7 +987,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             const bool half1_runs = lv1 >= 0 && lv1 <= limit_e;
             bytes = (uint64_t)plen0 + (uint64_t)(2 * (limit_e < 0 ? 0 : limit_e)) + (half1_runs ? (uint64_t)plen1 : 0ull);
             if (half1_runs && lv2 >= 0 && lv1 + lv2 <= limit_e) {                 // both sides still fit
-                if (n_ag != 0u || (high && e_lps <= (uint32_t)all.best_score)) {      // affine gap ran under another band, or would run now
+                if (n_ag != 0u || (high && e_lps <= (uint32_t)all().best_score)) {      // affine gap ran under another band, or would run now
                     if (lane == 0 && se_diag) atomicAdd(&se_diag[-1], 1ull << 16);
                     return false;
                 }
@@ -994,7 +1000,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             }
         }
         ce.lv_sum_high = high; ce.lv1 = 0; ce.lv2 = 0;
-        cnt.lv += n_lv; cnt.ag += n_ag; cnt.lv_ref_bytes += bytes;
+        cnt().lv += n_lv; cnt().ag += n_ag; cnt().lv_ref_bytes += bytes;
         // a speculative evaluation cannot know what this read's aligner objects scored before: all of its out-of-band steps count as
         // later-call ones, and from here on the objects count as used
         ag_stale += stale; ag_replay += stale;
@@ -1065,11 +1071,11 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 uint32_t d_lv = 0, d_ag = 0, stale = 0; uint64_t d_bytes = 0;
                 int rec_limit = (int)0x80000000;            // (an element the owner would skip under this limit: a record nobody can use)
                 if ((int64_t)e_lps <= (int64_t)limit_e && e_base >= 0 && (uint64_t)(e_base + idx) < (uint64_t)ix.n_bases && idx < 48 && cso >= 0 && cso <= read_len) {
-                    const uint64_t lv0 = cnt.lv, ag0 = cnt.ag, b0 = cnt.lv_ref_bytes;
+                    const uint64_t lv0 = cnt().lv, ag0 = cnt().ag, b0 = cnt().lv_ref_bytes;
                     ag_stale = 0; ag_replay = 0; ag_obj_used0 = 1; ag_obj_used1 = 1;
                     ce = eval_candidate<false>(e_base + idx, e_dir, e_lps, cso, limit_e, best);
-                    d_lv = (uint32_t)(cnt.lv - lv0); d_ag = (uint32_t)(cnt.ag - ag0); d_bytes = cnt.lv_ref_bytes - b0; stale = ag_stale;
-                    cnt.lv = lv0; cnt.ag = ag0; cnt.lv_ref_bytes = b0;        // (the owner counts what it uses)
+                    d_lv = (uint32_t)(cnt().lv - lv0); d_ag = (uint32_t)(cnt().ag - ag0); d_bytes = cnt().lv_ref_bytes - b0; stale = ag_stale;
+                    cnt().lv = lv0; cnt().ag = ag0; cnt().lv_ref_bytes = b0;        // (the owner counts what it uses)
                     WAVE_SYNC();
                     rec_limit = limit_e;
                 }
@@ -1114,23 +1120,23 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 if (wl < cfg.min_weight) {
                     // :1034-1056
                     bool fin_all;          // (a flag, not a pointer: selecting between &all and &non_alt would pin both in scratch)
-                    first_alt.status = SNAPGPU_NotFound;
-                    if (!cfg.alt_aware || non_alt.best_score > all.best_score + cfg.max_gap_alt) {
+                    first_alt().status = SNAPGPU_NotFound;
+                    if (!cfg.alt_aware || non_alt().best_score > all().best_score + cfg.max_gap_alt) {
                         fin_all = true;
                     } else {
                         fin_all = false;
-                        if (cfg.emit_alt && all.best_score <= non_alt.best_score && all.best_loc != non_alt.best_loc) {
-                            fill_result(all, first_alt);
+                        if (cfg.emit_alt && all().best_score <= non_alt().best_score && all().best_loc != non_alt().best_loc) {
+                            fill_result(all(), first_alt());
                         }
                     }
-                    const int fin_best = fin_all ? all.best_score : non_alt.best_score;
-                    primary.score = fin_best;
+                    const int fin_best = fin_all ? all().best_score : non_alt().best_score;
+                    primary().score = fin_best;
                     if ((uint32_t)fin_best <= max_k || (HAM && fin_best != SNAPGPU_UnusedScoreValue)) {          // :1048
-                        if (fin_all) fill_result(all, primary); else fill_result(non_alt, primary);
-                        primary.supplementary = 0;
+                        if (fin_all) fill_result(all(), primary()); else fill_result(non_alt(), primary());
+                        primary().supplementary = 0;
                     } else {
-                        primary.status = SNAPGPU_NotFound;
-                        primary.mapq = 0;
+                        primary().status = SNAPGPU_NotFound;
+                        primary().mapq = 0;
                     }
                     return true;
                 }
@@ -1185,7 +1191,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                     CandEval ce;
                     bool have = false;
                     if constexpr (!EXACT && !HAM) { if (se_slot >= 0) have = se_take(ei, idx, listed0, limit_e, e_lps, loc, cand_seed_offset, ce); }
-                    if (!have) ce = eval_candidate<HAM>(loc, e_dir, e_lps, cand_seed_offset, limit_e, (uint32_t)all.best_score);
+                    if (!have) ce = eval_candidate<HAM>(loc, e_dir, e_lps, cand_seed_offset, limit_e, (uint32_t)all().best_score);
                     const uint32_t sc = ce.sc; const double mp = ce.mp; loc = ce.loc;
                     const int used_ag = ce.used_ag, clip_before = ce.clip_before, clip_after = ce.clip_after, ag_score = ce.ag_score;
 
@@ -1226,8 +1232,8 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                                 double n_mp = first_f64(ne->match_prob);
                                 if (HAM && n_mp >= mp) continue;                             // :1418
                                 if (n_best < sc || (n_best == sc && n_mp >= mp)) continue;   // :1421
-                                double v = all.p_all - n_mp; all.p_all = v > 0.0 ? v : 0.0;    // updateProbabilitiesForNearbyMatch
-                                if (loc_non_alt) { double u = non_alt.p_all - n_mp; non_alt.p_all = u > 0.0 ? u : 0.0; }
+                                double v = all().p_all - n_mp; all().p_all = v > 0.0 ? v : 0.0;    // updateProbabilitiesForNearbyMatch
+                                if (loc_non_alt) { double u = non_alt().p_all - n_mp; non_alt().p_all = u > 0.0 ? u : 0.0; }
                                 any_nearby = true;
                                 if (lane == 0) ne->match_prob = 0;
                                 WAVE_SYNC();
@@ -1237,32 +1243,32 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
 
                     // updateProbabilitiesForNewMatch (:2137-2141): two separate FP64 operations
                     {
-                        double v = all.p_all - e_mp; v = v > 0.0 ? v : 0.0; all.p_all = v + mp;
-                        if (loc_non_alt) { double u = non_alt.p_all - e_mp; u = u > 0.0 ? u : 0.0; non_alt.p_all = u + mp; }
+                        double v = all().p_all - e_mp; v = v > 0.0 ? v : 0.0; all().p_all = v + mp;
+                        if (loc_non_alt) { double u = non_alt().p_all - e_mp; u = u > 0.0 ? u : 0.0; non_alt().p_all = u + mp; }
                     }
                     e_mp_cur = mp; e_best_cur = sc;
                     if (lane == 0) { e->match_prob = mp; e->best_score = sc; }
                     WAVE_SYNC();
 
-                    update_best<HAM>(all, loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
+                    update_best<HAM>(all(), loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
                     if (loc_non_alt) {
-                        update_best<HAM>(non_alt, loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
+                        update_best<HAM>(non_alt(), loc, orig_loc, sc, ag_score, mp, e, e_dir, used_ag, clip_before, clip_after, cand_seed_offset, mp);
                     }
                     if (HAM && agc != nullptr && n_agc >= agc_cap) { agc_overflow = 1; return true; }   // :1475 (the caller grows the buffer and retries)
 
                     // -f (:1490-1505): the first location within maxK ends the search; MultipleHits and MAPQ 0, because nothing says it is the best
-                    if (cfg.stop_on_first_hit && ((uint32_t)all.best_score <= max_k || (HAM && all.best_score != SNAPGPU_UnusedScoreValue))) {
-                        if (cfg.alt_aware) fill_result(non_alt, primary); else fill_result(all, primary);
-                        primary.status = SNAPGPU_MultipleHits; primary.mapq = 0;
-                        first_alt.status = SNAPGPU_NotFound;
+                    if (cfg.stop_on_first_hit && ((uint32_t)all().best_score <= max_k || (HAM && all().best_score != SNAPGPU_UnusedScoreValue))) {
+                        if (cfg.alt_aware) fill_result(non_alt(), primary()); else fill_result(all(), primary());
+                        primary().status = SNAPGPU_MultipleHits; primary().mapq = 0;
+                        first_alt().status = SNAPGPU_NotFound;
                         WAVE_SYNC();
                         return true;
                     }
                     // early out: nothing can rescue MAPQ once the candidates' total probability reaches 4.9 (:1512)
-                    double p_chk = cfg.alt_aware ? non_alt.p_all : all.p_all;
+                    double p_chk = cfg.alt_aware ? non_alt().p_all : all().p_all;
                     if (!SEC && p_chk >= 4.9) {                                                 // (&& -1 == maxEditDistanceForSecondaryResults)
-                        if (cfg.alt_aware) fill_result(non_alt, primary); else fill_result(all, primary);
-                        first_alt.status = SNAPGPU_NotFound;
+                        if (cfg.alt_aware) fill_result(non_alt(), primary()); else fill_result(all(), primary());
+                        first_alt().status = SNAPGPU_NotFound;
                         return true;
                     }
                 }
@@ -1294,7 +1300,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         ag_calls_unit = 0;
         align_read_inner<false>(g_bases, g_quals, len);
         if (ag_calls_unit >= WAVE_PRIO_HEAVY_AFTER) wave_set_priority(0);
-        cnt.cyc_total += clk() - t_read0;
+        cnt().cyc_total += clk() - t_read0;
     }
     // the read into LDS, forward and reverse complement (BaseAligner.cpp:388-396); returns its number of 'N's
     __device__ __forceinline__ uint32_t load_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
@@ -1320,15 +1326,15 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         // from the step notes and looks at the candidate count: ChimericPairedEndAligner.cpp:273-274 starts both counts at 0 per read)
         ag_stale = 0; ag_replay = 0; n_agc = 0; agc_overflow = 0;
         // result = NotFound (:334-344); remaining fields as a zero-initialised struct
-        primary.status = SNAPGPU_NotFound; primary.direction = 0;
-        primary.location = SNAPGPU_InvalidGenomeLocation32; primary.orig_location = 0;
-        primary.score = SNAPGPU_UnusedScoreValue; primary.score_prior_to_clipping = 0; primary.mapq = 0;
-        primary.clipping_for_read_adjustment = 0; primary.used_affine_gap_scoring = 0;
-        primary.bases_clipped_before = 0; primary.bases_clipped_after = 0; primary.ag_score = 0;
-        primary.supplementary = 0; primary.seed_offset = 0; primary.match_probability = 0.0;
-        primary.probability_all_candidates = 0.0; primary.popular_seeds_skipped = 0; primary.reserved = 0;
-        first_alt = primary;
-        first_alt.location = 0; first_alt.score = 0;
+        primary().status = SNAPGPU_NotFound; primary().direction = 0;
+        primary().location = SNAPGPU_InvalidGenomeLocation32; primary().orig_location = 0;
+        primary().score = SNAPGPU_UnusedScoreValue; primary().score_prior_to_clipping = 0; primary().mapq = 0;
+        primary().clipping_for_read_adjustment = 0; primary().used_affine_gap_scoring = 0;
+        primary().bases_clipped_before = 0; primary().bases_clipped_after = 0; primary().ag_score = 0;
+        primary().supplementary = 0; primary().seed_offset = 0; primary().match_probability = 0.0;
+        primary().probability_all_candidates = 0.0; primary().popular_seeds_skipped = 0; primary().reserved = 0;
+        first_alt() = primary();
+        first_alt().location = 0; first_alt().score = 0;
 
         const int seed_len = (int)ix.seed_len;
         if (len < seed_len || len > (int)cfg.RL) return;                      // :360 (too long is rejected on the host)
@@ -1361,9 +1367,9 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         wrap_count = 0;
         lps_unseen[0] = lps_unseen[1] = 0;
         cur_round_lps[0] = cur_round_lps[1] = 0;
-        all.init();
-        non_alt.init();
-        if (!cfg.alt_aware) non_alt.best_score = SNAPGPU_TooBigScoreValue;    // :325 (never re-initialised without ALT awareness)
+        all().init();
+        non_alt().init();
+        if (!cfg.alt_aware) non_alt().best_score = SNAPGPU_TooBigScoreValue;    // :325 (never re-initialised without ALT awareness)
         n_seeds_applied[0] = n_seeds_applied[1] = 0;
         popular_seeds_skipped = 0;
         se_tried = 0;
@@ -1391,9 +1397,9 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             const uint64_t t_lk0 = clk();
             lookup_seed(ix, seed, hl);
             const uint64_t t_lk1 = clk();
-            cnt.cyc_lookup += t_lk1 - t_lk0;
-            cnt.lookups++;
-            cnt.slots += hl[0].slots + hl[1].slots;
+            cnt().cyc_lookup += t_lk1 - t_lk0;
+            cnt().lookups++;
+            cnt().slots += hl[0].slots + hl[1].slots;
 
             bool applied_either = false;
             for (int dir = 0; dir < 2; dir++) {
@@ -1405,8 +1411,8 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 } else {
                     uint32_t offset = dir == 0 ? next_seed : (uint32_t)(len - seed_len) - next_seed;   // :591-606
                     int64_t limit = dir_n_hits < (int64_t)cfg.max_hits ? dir_n_hits : (int64_t)cfg.max_hits;      // :625 (only -x gets here with more than maxHits)
-                    if (limit > 1) cnt.overflow_lists++;
-                    cnt.hits += (uint64_t)limit;
+                    if (limit > 1) cnt().overflow_lists++;
+                    cnt().hits += (uint64_t)limit;
                     for (int64_t c0 = 0; c0 < limit; c0 += WAVE) {
                         // one coalesced load of up to 64 hits, then consume them in stored order
                         uint32_t mine = 0;
@@ -1422,7 +1428,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                     applied_either = true;
                 }
             }
-            cnt.cyc_hits += clk() - t_lk1;
+            cnt().cyc_hits += clk() - t_lk1;
             next_seed += (uint32_t)seed_len;                                  // :676
 
             if (applied_either) {
@@ -1431,8 +1437,8 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         }
         if (!finished) score<HAM>(true);                                      // :734
         if constexpr (!EXACT && !HAM) { if (se_slot >= 0) se_close(); }       // (before the candidate table is released: helpers read it)
-        primary.score_prior_to_clipping = primary.score;                      // finalizeSecondaryResults, :2442
-        primary.reserved = (ag_stale & 0x3fffffffu) | (ag_replay ? 0x40000000u : 0u);      // bit 30: the exact pass must redo this read
+        primary().score_prior_to_clipping = primary().score;                      // finalizeSecondaryResults, :2442
+        primary().reserved = (ag_stale & 0x3fffffffu) | (ag_replay ? 0x40000000u : 0u);      // bit 30: the exact pass must redo this read
         release_candidates();
         if constexpr (SEC) { n_sec_raw = n_sec; finalize_secondary(); }
     }
@@ -1469,14 +1475,14 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         WAVE_SYNC(); __threadfence_block();
     }
     __device__ __forceinline__ void finalize_secondary() {
-        int best = (int)first_u32((uint32_t)primary.score);
+        int best = (int)first_u32((uint32_t)primary().score);
         if (sec_cfg.adjust) {                                                          // :2444-2463 (-ae)
             const AdjustScratch asc = adjust_scratch_at(adj_scratch, cfg.RL);
             const AdjustIx aix = adjust_ix(ix);
             {
-                const AdjustOut o = adjust_alignment(aix, rd[0], rd[1], read_len, (int)first_u32((uint32_t)primary.status), (int)first_u32((uint32_t)primary.direction),
-                                                     (long long)first_u64((uint64_t)primary.location), best, SNAPGPU_InvalidGenomeLocation32, asc);
-                primary.status = o.status; primary.location = o.location; primary.score = o.score; primary.clipping_for_read_adjustment = o.clipping;
+                const AdjustOut o = adjust_alignment(aix, rd[0], rd[1], read_len, (int)first_u32((uint32_t)primary().status), (int)first_u32((uint32_t)primary().direction),
+                                                     (long long)first_u64((uint64_t)primary().location), best, SNAPGPU_InvalidGenomeLocation32, asc);
+                primary().status = o.status; primary().location = o.location; primary().score = o.score; primary().clipping_for_read_adjustment = o.clipping;
                 best = o.status != SNAPGPU_NotFound ? o.score : SNAPGPU_TooBigScoreValue;
             }
             WAVE_SYNC(); __threadfence_block();
@@ -1514,8 +1520,8 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             r->supplementary = (cfg.alt_aware && is_alt(r->location)) ? 1 : 0;
         }
         WAVE_SYNC(); __threadfence_block();
-        if (sec_cfg.mpc > 0 && primary.status != SNAPGPU_NotFound && n > 0) {           // :2487-2547
-            const int primary_contig = contig_of(primary.location);
+        if (sec_cfg.mpc > 0 && primary().status != SNAPGPU_NotFound && n > 0) {           // :2487-2547
+            const int primary_contig = contig_of(primary().location);
             // key = (contig, score); scores here are <= max_k <= 127
             for (uint32_t i = (uint32_t)lane; i < n; i += WAVE) {
                 const uint32_t me = sec_ord[i];
@@ -1589,7 +1595,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             const LdsSeq P = lds_seq(ByteSeq{rdd + org, st}), Q = lds_seq(ByteSeq{qld + org, st}), T = lds_seq(ByteSeq{data + org, st});
             note_ag_extent(half, banded, plen, lim, tlen);
             AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, P, Q, plen, T, tlen, lim, read_len, dir != 0, half == 0, ag_rows,
-                                                 EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : ag_scratch, cfg.RL, tab, EXACT ? ag_tag : 0u);
+                                                 EXACT ? (half == 0 ? ag_persist0 : ag_persist1) : (uint8_t *)ag_scratch, cfg.RL, tab, EXACT ? ag_tag : 0u);
             a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
             a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
             a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
@@ -1633,60 +1639,60 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     // ------------------------------------------------------------------ BaseAligner::alignAffineGap (BaseAligner.cpp:1537-1792)
     // Runs on `primary` / `first_alt` and the candidates the preceding Hamming pass collected; the read is still in LDS.
     __device__ __forceinline__ void align_affine_gap(ScoreSet &A, ScoreSet &N) {
-        if (primary.status == SNAPGPU_NotFound) return;
+        if (primary().status == SNAPGPU_NotFound) return;
         uint32_t n_count = 0;
         for (int i0 = 0; i0 < read_len; i0 += WAVE) {
             int i = i0 + lane;
             n_count += (uint32_t)__popcll(BALLOT(i < read_len && rd[0][i] == 'N'));
         }
         if (n_count > max_k) return;
-        const int best_score = (int)first_u32((uint32_t)primary.score);
+        const int best_score = (int)first_u32((uint32_t)primary().score);
         int limit = SNAPGPU_MAX_K - 1, limit_alt = SNAPGPU_MAX_K - 1;
         int g_off = 0;
         bool skip = false;
-        const double old_p = primary.match_probability;
-        const double old_p_alt = first_alt.status != SNAPGPU_NotFound ? first_alt.match_probability : 0.0;
+        const double old_p = primary().match_probability;
+        const double old_p_alt = first_alt().status != SNAPGPU_NotFound ? first_alt().match_probability : 0.0;
         const int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);
 
-        primary.used_affine_gap_scoring = 0;
-        if (primary.score > max_k_same) {
-            primary.used_affine_gap_scoring = 1;
-            int sc, cb = primary.bases_clipped_before, ca = primary.bases_clipped_after, ag = primary.ag_score;
-            double mp = primary.match_probability;
-            score_location_ag(primary.direction, primary.orig_location, primary.seed_offset, limit, &sc, &mp, &g_off, &cb, &ca, &ag);
-            primary.score = sc; primary.match_probability = mp; primary.bases_clipped_before = cb; primary.bases_clipped_after = ca; primary.ag_score = ag;
-            if (sc != -1) primary.location = primary.orig_location + g_off; else primary.status = SNAPGPU_NotFound;
+        primary().used_affine_gap_scoring = 0;
+        if (primary().score > max_k_same) {
+            primary().used_affine_gap_scoring = 1;
+            int sc, cb = primary().bases_clipped_before, ca = primary().bases_clipped_after, ag = primary().ag_score;
+            double mp = primary().match_probability;
+            score_location_ag(primary().direction, primary().orig_location, primary().seed_offset, limit, &sc, &mp, &g_off, &cb, &ca, &ag);
+            primary().score = sc; primary().match_probability = mp; primary().bases_clipped_before = cb; primary().bases_clipped_after = ca; primary().ag_score = ag;
+            if (sc != -1) primary().location = primary().orig_location + g_off; else primary().status = SNAPGPU_NotFound;
         } else {
             skip = true;
         }
-        if (first_alt.status != SNAPGPU_NotFound && first_alt.score > max_k_same) {
-            first_alt.used_affine_gap_scoring = 1;
-            int sc, cb = first_alt.bases_clipped_before, ca = first_alt.bases_clipped_after, ag = first_alt.ag_score;
-            double mp = first_alt.match_probability;
-            score_location_ag(first_alt.direction, first_alt.orig_location, first_alt.seed_offset, limit_alt, &sc, &mp, &g_off, &cb, &ca, &ag);
-            first_alt.score = sc; first_alt.match_probability = mp; first_alt.bases_clipped_before = cb; first_alt.bases_clipped_after = ca; first_alt.ag_score = ag;
-            if (sc != -1) first_alt.location = first_alt.orig_location + g_off; else first_alt.status = SNAPGPU_NotFound;
+        if (first_alt().status != SNAPGPU_NotFound && first_alt().score > max_k_same) {
+            first_alt().used_affine_gap_scoring = 1;
+            int sc, cb = first_alt().bases_clipped_before, ca = first_alt().bases_clipped_after, ag = first_alt().ag_score;
+            double mp = first_alt().match_probability;
+            score_location_ag(first_alt().direction, first_alt().orig_location, first_alt().seed_offset, limit_alt, &sc, &mp, &g_off, &cb, &ca, &ag);
+            first_alt().score = sc; first_alt().match_probability = mp; first_alt().bases_clipped_before = cb; first_alt().bases_clipped_after = ca; first_alt().ag_score = ag;
+            if (sc != -1) first_alt().location = first_alt().orig_location + g_off; else first_alt().status = SNAPGPU_NotFound;
         }
-        if (primary.status == SNAPGPU_NotFound || primary.score > SNAPGPU_MAX_K - 1) {
-            primary.location = SNAPGPU_InvalidGenomeLocation32; primary.mapq = 0; primary.score = -1; primary.status = SNAPGPU_NotFound;
-            primary.clipping_for_read_adjustment = 0; primary.used_affine_gap_scoring = 0; primary.bases_clipped_before = 0;
-            primary.bases_clipped_after = 0; primary.ag_score = -1; primary.seed_offset = 0; primary.match_probability = 0.0;
-            first_alt.status = SNAPGPU_NotFound;
+        if (primary().status == SNAPGPU_NotFound || primary().score > SNAPGPU_MAX_K - 1) {
+            primary().location = SNAPGPU_InvalidGenomeLocation32; primary().mapq = 0; primary().score = -1; primary().status = SNAPGPU_NotFound;
+            primary().clipping_for_read_adjustment = 0; primary().used_affine_gap_scoring = 0; primary().bases_clipped_before = 0;
+            primary().bases_clipped_after = 0; primary().ag_score = -1; primary().seed_offset = 0; primary().match_probability = 0.0;
+            first_alt().status = SNAPGPU_NotFound;
             return;
         }
 
-        bool non_alt_aln = !cfg.alt_aware || !is_alt(primary.location);
-        set_from_result(A, primary);
+        bool non_alt_aln = !cfg.alt_aware || !is_alt(primary().location);
+        set_from_result(A, primary());
         bool alt_best = false;
-        if (first_alt.status != SNAPGPU_NotFound) {
-            alt_best = set_update_from(A, first_alt.location, first_alt.orig_location, first_alt.direction, first_alt.score,
-                                       first_alt.used_affine_gap_scoring, first_alt.bases_clipped_before, first_alt.bases_clipped_after,
-                                       first_alt.ag_score, first_alt.seed_offset, first_alt.match_probability);
+        if (first_alt().status != SNAPGPU_NotFound) {
+            alt_best = set_update_from(A, first_alt().location, first_alt().orig_location, first_alt().direction, first_alt().score,
+                                       first_alt().used_affine_gap_scoring, first_alt().bases_clipped_before, first_alt().bases_clipped_after,
+                                       first_alt().ag_score, first_alt().seed_offset, first_alt().match_probability);
         }
-        if (non_alt_aln) set_from_result(N, primary); else N.init();
+        if (non_alt_aln) set_from_result(N, primary()); else N.init();
         if (!skip) {
-            const double new_p = primary.match_probability;
-            if (alt_best) { set_sub_all(A, old_p_alt); A.p_best = first_alt.match_probability; A.p_all += first_alt.match_probability; }
+            const double new_p = primary().match_probability;
+            if (alt_best) { set_sub_all(A, old_p_alt); A.p_best = first_alt().match_probability; A.p_all += first_alt().match_probability; }
             else          { set_sub_all(A, old_p); A.p_best = new_p; A.p_all += new_p; }
             if (non_alt_aln) { set_sub_all(N, old_p); N.p_best = new_p; N.p_all += new_p; }
         }
@@ -1723,7 +1729,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                 sc = (int)first_u32((uint32_t)sc);
                 if (sc != -1 && sc <= SNAPGPU_MAX_K - 1) {
                     const int64_t new_loc = c_orig + g_off;
-                    if (primary.location == new_loc) continue;                                   // same alignment again: do not lower MAPQ
+                    if (primary().location == new_loc) continue;                                   // same alignment again: do not lower MAPQ
                     set_sub_all(A, c_old_p);
                     set_update_from(A, new_loc, c_orig, c_dir, sc, 1, cb, ca, ag, c_so, mp);
                     if (c_non_alt) { set_sub_all(N, c_old_p); set_update_from(N, new_loc, c_orig, c_dir, sc, 1, cb, ca, ag, c_so, mp); }
@@ -1733,16 +1739,16 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         }
 
         const bool emit_all = !cfg.alt_aware || N.best_score > A.best_score + cfg.max_gap_alt;
-        const uint32_t pop = primary.popular_seeds_skipped, pop_alt = first_alt.popular_seeds_skipped;
+        const uint32_t pop = primary().popular_seeds_skipped, pop_alt = first_alt().popular_seeds_skipped;
         const uint32_t saved_pop = popular_seeds_skipped;
         popular_seeds_skipped = pop;
-        if (emit_all) fill_result(A, primary); else fill_result(N, primary);
+        if (emit_all) fill_result(A, primary()); else fill_result(N, primary());
         if (cfg.alt_aware && !emit_all && A.best_loc != N.best_loc) {
             popular_seeds_skipped = pop_alt;
-            fill_result(A, first_alt);
-            first_alt.supplementary = 1;
+            fill_result(A, first_alt());
+            first_alt().supplementary = 1;
         } else {
-            first_alt.status = SNAPGPU_NotFound;
+            first_alt().status = SNAPGPU_NotFound;
         }
         popular_seeds_skipped = saved_pop;
     }

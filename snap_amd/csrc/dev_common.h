@@ -38,6 +38,41 @@
 // on through another lane (per-thread alias analysis cannot see that dependence).  A pure
 // compiler barrier does that without emitting s_waitcnt vmcnt(0), which a
 // __builtin_amdgcn_fence would (it made every DP row wait for its traceback stores).
+// Pointers known to point into HBM (the per-wave pools, the index blobs): the paired-end kernel keeps its objects in LDS, and a pointer loaded
+// back from an object is a GENERIC one -- every access through it a FLAT instruction, which counts on vmcnt AND lgkmcnt, so that a wait for
+// an LDS read also waits for every load and store to the pools that is still on its way.  Declared G(T) * the members are global pointers
+// and the accesses global_load / global_store.  (Host passes and the emulator: plain pointers, same layout.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNAPGPU_WAVE_EMU)
+#define GLB_AS __attribute__((address_space(1)))
+#else
+#define GLB_AS
+#endif
+#define G(T) GLB_AS T
+// the value type behind an lvalue that may carry an address space (what a wave-uniform load of it returns)
+template <class T> struct strip_as { typedef T type; };
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SNAPGPU_WAVE_EMU)
+template <class T> struct strip_as<__attribute__((address_space(1))) T> { typedef T type; };
+template <class T> struct strip_as<__attribute__((address_space(3))) T> { typedef T type; };
+#endif
+
+// Pointer MEMBERS of the kernels' objects: stored with their address space (LDS: 32 bits; HBM: global), handed out as the plain pointers the
+// code works with -- the cast back is an addrspacecast FROM a known space, which the compiler's address-space inference follows through the
+// (inlined) users, so the accesses are ds_* / global_* instructions wherever the object itself lives.
+template <class T> struct LP {
+    LDS_AS T *p;
+    LP() = default;
+    __host__ __device__ __forceinline__ LP(T *q) : p((LDS_AS T *)q) {}
+    __host__ __device__ __forceinline__ operator T *() const { return (T *)p; }
+    __host__ __device__ __forceinline__ T *operator->() const { return (T *)p; }
+};
+template <class T> struct GP {
+    GLB_AS T *p;
+    GP() = default;
+    __host__ __device__ __forceinline__ GP(T *q) : p((GLB_AS T *)q) {}
+    __host__ __device__ __forceinline__ operator T *() const { return (T *)p; }
+    __host__ __device__ __forceinline__ T *operator->() const { return (T *)p; }
+};
+
 #define WAVE_SYNC()                                                   \
     do {                                                              \
         asm volatile("" ::: "memory");                                \

@@ -43,6 +43,10 @@
 #define PE_FN __device__ __forceinline__
 #endif
 
+#ifndef G
+#define G(T) T                         // (device builds: dev_common.h -- a type known to live in HBM)
+#endif
+
 #define PE_MAX_SEEDS       30          // MAX_MAX_SEEDS, IntersectingPairedEndAligner.h:216
 #define PE_NOT_YET_SCORED  (-2)        // ScoringMateCandidate::LocationNotYetScored
 #define PE_MERGE_DIST      31          // maxMergeDistance, IntersectingPairedEndAligner.cpp:3990
@@ -50,7 +54,7 @@
 #define PE_MRING           32          // mates the Phase-2 walk can look back at without going to the pool (device: LDS)
 
 struct PEHits {                        // one direction of a seed lookup
-    const uint32_t *hits;              // overflow list when n_hits > 1 (descending)
+    const G(uint32_t) *hits;              // overflow list when n_hits > 1 (descending)
     int64_t  n_hits;
     uint32_t singleton;                // the hit when n_hits == 1
 };
@@ -86,7 +90,7 @@ struct PECfg {
 };
 
 struct PELookup {                      // HashTableLookup<unsigned>, IntersectingPairedEndAligner.h:247
-    const uint32_t *hits;
+    const G(uint32_t) *hits;
     int64_t  n_hits;                   // after trimming (:3562)
     int64_t  cur;                      // currentHitForIntersection
     uint32_t seed_offset;
@@ -163,7 +167,7 @@ struct AGOut { int ag_score, text_offset, pattern_offset, n_edits; double mp; in
 
 template <class PL>
 struct PairedCore {
-    PL &pl;
+    typename PL::SelfPtr pl;           // the platform object (device: an LDS address, stored as such -- dev_common.h: LP)
     const PECfg cfg;
     // hot per-pair arrays (LDS on the device)
     PELookup    *lk;                   // [4][cfg.max_seeds]   set = 2*whichRead + dir
@@ -178,16 +182,17 @@ struct PairedCore {
     const uint8_t *rd[2][2], *ql[2][2];
     int read_len[2];
     // per-wave pools in HBM scratch
-    PECand   *cand;                    // [cfg.pool_size]
-    PEMate   *mate[2];                 // [cfg.pool_size / 2] each
-    PEAnchor *anchor;                  // [cfg.pool_size]
-    snapgpu_paired_result *agc;        // [cfg.ag_cand_cap]   lvCandidatesForAffineGap
-    uint32_t *agc_order;               // [cfg.ag_cand_cap]   the order Phase 4 visits them in
-    snapgpu_paired_result *sec;        // [cfg.sec_cap]       secondaryResults of IntersectingPairedEndAligner::align
-    uint32_t *sec_ord, *sec_key;       // [cfg.sec_cap], [2 * cfg.sec_cap]   index list / sort keys of the final filtering
+    // (G(T): HBM -- the device build's accesses through these are global loads / stores, not flat ones: dev_common.h)
+    G(PECand)   *cand;                 // [cfg.pool_size]
+    G(PEMate)   *mate[2];              // [cfg.pool_size / 2] each
+    G(PEAnchor) *anchor;               // [cfg.pool_size]
+    G(snapgpu_paired_result) *agc;     // [cfg.ag_cand_cap]   lvCandidatesForAffineGap
+    G(uint32_t) *agc_order;            // [cfg.ag_cand_cap]   the order Phase 4 visits them in
+    G(snapgpu_paired_result) *sec;     // [cfg.sec_cap]       secondaryResults of IntersectingPairedEndAligner::align
+    G(uint32_t) *sec_ord, *sec_key;    // [cfg.sec_cap], [2 * cfg.sec_cap]   index list / sort keys of the final filtering
     uint32_t n_sec;
     // single-end secondary results of the chimeric fallback go straight to the caller's buffer (read 0's, then read 1's)
-    snapgpu_single_result *ssec_out;   // [ssec_stride] for this pair, or NULL
+    G(snapgpu_single_result) *ssec_out;   // [ssec_stride] for this pair, or NULL
     uint32_t ssec_stride;
     uint32_t n_ssec[2];
     uint32_t ref_dep;                  // SNAPGPU_PAIR_REF_BUFFER_DEPENDENT
@@ -204,10 +209,10 @@ struct PairedCore {
     uint32_t spec_used = 0;            // answers the ordered walk took from speculative scoring (this pair)
     uint32_t help_min = 0xffffffffu;   // Phase-4 lists at least this long are offered to idle waves (PL::HELP only)
 
-    PE_FN PairedCore(PL &pl_, const PECfg &c) : pl(pl_), cfg(c) {}
+    PE_FN PairedCore(PL &pl_, const PECfg &c) : pl(&pl_), cfg(c) {}
 
-    template <class T> static PE_FN T ld(const T &x) { return PL::ld(x); }
-    template <class T, class V> static PE_FN void st(T &x, V v) { PL::st(x, (T)v); }
+    template <class T> static PE_FN auto ld(const T &x) -> decltype(PL::ld(x)) { return PL::ld(x); }
+    template <class T, class V> static PE_FN void st(T &x, V v) { PL::st(x, (decltype(PL::ld(x)))v); }
 
     // secondary results wanted?  Compile-time off in the default kernel (PL::SECONDARY), so that it carries none of that code.
     PE_FN bool want_sec() const { return PL::SECONDARY && cfg.om != -1; }
@@ -270,7 +275,7 @@ struct PairedCore {
     // (FAST_HITSET: the walk's cursors live in registers for the length of the walk -- PL::HSCursor, filled by hs_begin_walk; the lookups'
     //  records in LDS are not written back: nothing reads a hit set after its walk)
     PE_FN bool hs_first(int s, int64_t *loc, uint32_t *seed_offset, typename PL::HSCursor &c) {
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_first(c, loc, seed_offset); PT2_ADD(cyc_lookup); return r; }
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl->hs_first(c, loc, seed_offset); PT2_ADD(cyc_lookup); return r; }
         bool any = false;
         *loc = 0;
         const uint32_t n = ld(HS()[s].n_used);
@@ -287,7 +292,7 @@ struct PairedCore {
     }
 
     PE_FN bool hs_next_lower(int s, int64_t *loc, uint32_t *seed_offset, typename PL::HSCursor &c) {     // getNextLowerHit, :3750-3816
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_lower(c, loc, seed_offset); PT2_ADD(cyc_lookup); return r; }
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl->hs_next_lower(c, loc, seed_offset); PT2_ADD(cyc_lookup); return r; }
         int64_t found = 0;
         bool any = false;
         const uint32_t n = ld(HS()[s].n_used);
@@ -316,7 +321,7 @@ struct PairedCore {
     }
 
     PE_FN bool hs_next_le(int s, int64_t max_loc, int64_t *loc, uint32_t *seed_offset, typename PL::HSCursor &c) {   // getNextHitLessThanOrEqualTo, :3628-3717
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl.hs_next_le(c, max_loc, loc, seed_offset); PT2_ADD(cyc_lookup); return r; }
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const bool r = pl->hs_next_le(c, max_loc, loc, seed_offset); PT2_ADD(cyc_lookup); return r; }
         bool any = false;
         int64_t best = 0;
         const uint32_t n = ld(HS()[s].n_used);
@@ -348,7 +353,7 @@ struct PairedCore {
     }
 
     PE_FN uint32_t hs_best_possible(int s, typename PL::HSCursor &c) {                                   // computeBestPossibleScoreForCurrentHit, :3585-3625
-        if constexpr (PL::FAST_HITSET) { PT2_T0(); const uint32_t r = pl.hs_best_possible(c, exh(s)); PT2_ADD(cyc_lv); return r; }
+        if constexpr (PL::FAST_HITSET) { PT2_T0(); const uint32_t r = pl->hs_best_possible(c, exh(s)); PT2_ADD(cyc_lv); return r; }
         const int cd = ld(HS()[s].cur_disjoint);
         for (int i = 0; i <= cd; i++) st(MISS()[i], ld(exh(s)[i]));
         const uint32_t n = ld(HS()[s].n_used);
@@ -393,8 +398,8 @@ struct PairedCore {
     PE_FN bool set_update(PESet &s, int pair_score, int pair_ag, double pair_p, int fewer_score, int fewer_off, int ci, int mi, int set_pair) {
         s.p_all += pair_p;
         if (pair_ag > s.best_pair_ag || (pair_ag == s.best_pair_ag && pair_p > s.p_best)) {
-            const PECand *c = &cand[ci];
-            const PEMate *m = &mate[set_pair][mi];
+            const G(PECand) *c = &cand[ci];
+            const G(PEMate) *m = &mate[set_pair][mi];
             s.best_pair_score = pair_score; s.best_pair_ag = pair_ag; s.p_best = pair_p;
             const int f = fewer, mo = more;
             s.loc[f] = ld(c->loc) + fewer_off;            s.loc[mo] = ld(m->loc) + ld(m->genome_offset);
@@ -415,7 +420,7 @@ struct PairedCore {
         return false;
     }
     // updateBestHitIfNeeded(PairedAlignmentResult*), :3928-3954.  `r` lives in the Phase-4 candidate buffer.
-    PE_FN bool set_update_from(PESet &s, int pair_score, int pair_ag, double pair_p, const snapgpu_paired_result *r) {
+    PE_FN bool set_update_from(PESet &s, int pair_score, int pair_ag, double pair_p, const G(snapgpu_paired_result) *r) {
         s.p_all += pair_p;
         if (pair_ag > s.best_pair_ag || (pair_ag == s.best_pair_ag && pair_p > s.p_best)) {
             s.best_pair_score = pair_score; s.best_pair_ag = pair_ag; s.p_best = pair_p;
@@ -433,7 +438,7 @@ struct PairedCore {
     PE_FN void set_fill(const PESet &s, snapgpu_paired_result &r, const uint32_t pop[2]) {             // fillInResult, :3957-3972
         for (int i = 0; i < 2; i++) {
             r.location[i] = s.loc[i]; r.orig_location[i] = s.orig[i]; r.direction[i] = s.dir[i];
-            r.mapq[i] = pl.mapq(s.p_all, s.p_best, (int)(pop[0] + pop[1]));
+            r.mapq[i] = pl->mapq(s.p_all, s.p_best, (int)(pop[0] + pop[1]));
             r.status[i] = r.mapq[i] > 10 ? SNAPGPU_SingleHit : SNAPGPU_MultipleHits;                  // MAPQ_LIMIT_FOR_SINGLE_HIT
             r.score[i] = (int32_t)s.score[i]; r.clipping_for_read_adjustment[i] = 0; r.used_affine_gap_scoring[i] = s.used_ag[i];
             r.used_gapless_clipping[i] = s.gapless[i]; r.bases_clipped_before[i] = s.clip_before[i]; r.bases_clipped_after[i] = s.clip_after[i];
@@ -475,14 +480,14 @@ struct PairedCore {
             int ne = 0, nm = 0;
             double p = 1.0;
             for (int i = 0; i <= best_i; i++) {
-                if (P[i * st] != T[i * st]) { ne++; p *= pl.phred(Q[i * st]); } else nm++;
+                if (P[i * st] != T[i * st]) { ne++; p *= pl->phred(Q[i * st]); } else nm++;
             }
-            p *= pl.perfect(nm);
+            p *= pl->perfect(nm);
             int clipped = plen - (best_i + 1);
             *pattern_offset = clipped;
             *n_gapless = ne <= limit ? ne : -1;
             *n_edits = ne + clipped;
-            p *= pl.indel(clipped);
+            p *= pl->indel(clipped);
             *mp = PL::f64(p);
             return PL::i32(best);
         }
@@ -502,19 +507,19 @@ struct PairedCore {
         const int rl = read_len[which], sl = cfg.seed_len;
         const int64_t glen = (int64_t)rl + SNAPGPU_MAX_K;
         o.offset = 0; o.ref_span = 0; o.gapless = false;
-        if (!pl.substring_ok(loc, glen)) { o.score = -1; o.mp = 0; o.ag_score = -1; return; }
+        if (!pl->substring_ok(loc, glen)) { o.score = -1; o.mp = 0; o.ag_score = -1; return; }
         o.clip_before = 0; o.clip_after = 0;
-        const uint8_t *data = pl.window(loc, rl);
+        const uint8_t *data = pl->window(loc, rl);
         const uint8_t *R = L(rd[which][dir]), *Qd = L(ql[which][dir]);
         const int tail = seed_offset + sl;
         S()->cnt.lv++;
         const uint64_t t_lv = PL::clock();
-        LVOut a = pl.lv(+1, R + tail, Qd + tail, rl - tail, data + tail, (int)(glen - tail), limit);
+        LVOut a = pl->lv(+1, R + tail, Qd + tail, rl - tail, data + tail, (int)(glen - tail), limit);
         int score1 = a.score, score2 = 0, off = 0, ind2 = 0, span2 = 0;
         double mp1 = a.mp, mp2 = 1.0;
         int ag1 = (sl + rl - tail - score1) * cfg.match_reward - score1 * cfg.sub_penalty, ag2 = 0;
         if (score1 != -1) {
-            LVOut b = pl.lv(-1, R + seed_offset - 1, Qd + seed_offset - 1, seed_offset, data + seed_offset - 1, seed_offset + SNAPGPU_MAX_K, limit - score1);
+            LVOut b = pl->lv(-1, R + seed_offset - 1, Qd + seed_offset - 1, seed_offset, data + seed_offset - 1, seed_offset + SNAPGPU_MAX_K, limit - score1);
             score2 = b.score; mp2 = b.mp; off = b.net_indel; ind2 = b.total_indels; span2 = b.text_span;
             ag2 = (seed_offset - score2) * cfg.match_reward - score2 * cfg.sub_penalty;
         } else {
@@ -523,10 +528,10 @@ struct PairedCore {
         PT2_OFF(S()->cnt.cyc_lv += PL::clock() - t_lv);
         S()->cnt.lv_ref_bytes += (uint64_t)(rl - tail) + (uint64_t)(2 * (limit < 0 ? 0 : limit)) + (uint64_t)seed_offset;
         o.offset = off;
-        if (off != 0 && !pl.substring_ok(loc + off, glen)) score2 = -1;                               // :3364-3375
+        if (off != 0 && !pl->substring_ok(loc + off, glen)) score2 = -1;                               // :3364-3375
         if (score1 != -1 && score2 != -1) {
             o.score = score1 + score2;
-            o.mp = mp1 * mp2 * pl.seed_prob();
+            o.mp = mp1 * mp2 * pl->seed_prob();
             o.ag_score = ag1 + ag2;
             o.ref_span = a.text_span + sl + span2;
             o.lv_indels = a.total_indels + ind2;
@@ -540,9 +545,9 @@ struct PairedCore {
         const int rl = read_len[which], sl = cfg.seed_len;
         const int64_t glen = (int64_t)rl + SNAPGPU_MAX_K;
         o.offset = 0; o.gapless = false;
-        if (!pl.substring_ok(loc, glen)) { o.score = -1; o.mp = 0; o.ag_score = -1; return; }
+        if (!pl->substring_ok(loc, glen)) { o.score = -1; o.mp = 0; o.ag_score = -1; return; }
         o.clip_before = 0; o.clip_after = 0;
-        const uint8_t *data = pl.window(loc, rl);
+        const uint8_t *data = pl->window(loc, rl);
         const uint8_t *R = L(rd[which][dir]), *Qd = L(ql[which][dir]);
         const int tail = seed_offset + sl;
         int score1 = 0, score2 = 0, g1 = 0, g2 = 0, ag1 = sl, ag2 = 0, po = 0;
@@ -559,7 +564,7 @@ struct PairedCore {
         }
         if (g1 != -1 && g2 != -1) {
             o.score = score1 + score2;
-            o.mp = mp1 * mp2 * pl.seed_prob();
+            o.mp = mp1 * mp2 * pl->seed_prob();
             o.ag_score = ag1 + ag2;
             o.score_gapless = g1 + g2;
             o.gapless = true;
@@ -583,7 +588,7 @@ struct PairedCore {
     }
     // An answer scored ahead of time is taken: its calls enter the order of the pair's calls here, exactly as if this wave had made them
     // (which object had scored something before, which steps count) -- the flags of a pair do not depend on who scored its candidates.
-    PE_FN void take_spec_calls(const PEHelpSpec *sp, int r) {
+    PE_FN void take_spec_calls(const G(PEHelpSpec) *sp, int r) {
         const uint32_t calls = PL::spec_ld(sp->calls[r]);
         if (calls & 1u) note_ag_call(0, PL::spec_ld(sp->stale_fw[r]));
         if (calls & 2u) note_ag_call(1, PL::spec_ld(sp->stale_bw[r]));
@@ -595,9 +600,9 @@ struct PairedCore {
         const int rl = read_len[which], sl = cfg.seed_len;
         const int64_t glen = (int64_t)rl + SNAPGPU_MAX_K;
         *offset = 0; *ref_span = 0;
-        if (!pl.substring_ok(loc, glen)) { *score = -1; *mp = 0; *ag_score = -1; return; }
+        if (!pl->substring_ok(loc, glen)) { *score = -1; *mp = 0; *ag_score = -1; return; }
         *clip_before = 0; *clip_after = 0;
-        const uint8_t *data = pl.window(loc, rl);
+        const uint8_t *data = pl->window(loc, rl);
         const uint8_t *R = L(rd[which][dir]), *Qd = L(ql[which][dir]);
         const int tail = seed_offset + sl;
         const int clip = cfg.use_soft_clip ? 1 : 0;
@@ -606,12 +611,12 @@ struct PairedCore {
         int text_rem = rl - tail;
         const uint64_t t_ag = PL::clock();
 #ifdef PE_AG_STATS
-        pl.note_ag(which, dir, loc, seed_offset, limit);
+        pl->note_ag(which, dir, loc, seed_offset, limit);
 #endif
         if (tail != rl) {
             const int plen = rl - tail;
             const bool banded = plen >= 3 * (2 * limit + 1);
-            AGOut a = pl.ag(banded, +1, R + tail, Qd + tail, plen, data + tail, (int)(glen - tail), limit, rl, dir != 0, clip);
+            AGOut a = pl->ag(banded, +1, R + tail, Qd + tail, plen, data + tail, (int)(glen - tail), limit, rl, dir != 0, clip);
             note_ag_call(0, (uint32_t)a.stale);
             ag1 = a.ag_score + (sl - rl); text_rem = a.text_offset; *clip_after = a.pattern_offset; score1 = a.n_edits; mp1 = a.mp;
             if (spec_mode) spec_n_ag++; else S()->cnt.ag++;
@@ -620,7 +625,7 @@ struct PairedCore {
             if (seed_offset != 0) {
                 const int left = limit - score1;
                 const bool banded = seed_offset >= 3 * (2 * left + 1);
-                AGOut b = pl.ag(banded, -1, R + seed_offset - 1, Qd + seed_offset - 1, seed_offset, data + seed_offset - 1, seed_offset + left, left,
+                AGOut b = pl->ag(banded, -1, R + seed_offset - 1, Qd + seed_offset - 1, seed_offset, data + seed_offset - 1, seed_offset + left, left,
                                 rl, dir != 0, clip);
                 note_ag_call(1, (uint32_t)b.stale);
                 ag2 = b.ag_score - rl; *offset = b.text_offset; *clip_before = b.pattern_offset; score2 = b.n_edits; mp2 = b.mp;
@@ -630,7 +635,7 @@ struct PairedCore {
         PT2_OFF(S()->cnt.cyc_ag += PL::clock() - t_ag);
         if (score1 != -1 && score2 != -1) {
             *score = score1 + score2;
-            *mp = mp1 * mp2 * pl.seed_prob();
+            *mp = mp1 * mp2 * pl->seed_prob();
             *ref_span = (seed_offset - *offset) + sl + (rl - tail - text_rem);
             *ag_score = ag1 + ag2;
         } else {
@@ -653,7 +658,7 @@ struct PairedCore {
     }
 
     // copy of the current best of `s` into a Phase-4 candidate slot (:1032-1058)
-    PE_FN void agc_from_set(snapgpu_paired_result *e, const PESet &s) {
+    PE_FN void agc_from_set(G(snapgpu_paired_result) *e, const PESet &s) {
         if (PL::lane0()) {
             e->aligned_as_pair = 1;
             for (int r = 0; r < 2; r++) {
@@ -668,9 +673,9 @@ struct PairedCore {
         PL::sync();
     }
     // the pair just scored into a Phase-4 candidate slot (:1134-1164)
-    PE_FN void agc_from_pair(snapgpu_paired_result *e, int ci, int mi, int set_pair, int fewer_score, int fewer_off) {
-        const PECand *c = &cand[ci];
-        const PEMate *m = &mate[set_pair][mi];
+    PE_FN void agc_from_pair(G(snapgpu_paired_result) *e, int ci, int mi, int set_pair, int fewer_score, int fewer_off) {
+        const G(PECand) *c = &cand[ci];
+        const G(PEMate) *m = &mate[set_pair][mi];
         const int f = fewer, mo = more;
         int64_t c_loc = ld(c->loc), m_loc = ld(m->loc);
         int m_off = ld(m->genome_offset), m_score = ld(m->score);
@@ -738,7 +743,7 @@ struct PairedCore {
         for (int w = 0; w < 2; w++) {
             popular[w] = 0;
             for (int d = 0; d < 2; d++) hs_init(2 * w + d);
-            n_count += pl.count_n(L(rd[w][0]), read_len[w]);
+            n_count += pl->count_n(L(rd[w][0]), read_len[w]);
         }
         if ((int)n_count > cfg.max_k) return;                                                                         // :385
 
@@ -757,13 +762,13 @@ struct PairedCore {
                     wrap++;
                     begins[0] = begins[1] = true;
                     if (wrap >= (uint32_t)sl) break;
-                    next_seed = (int)pl.wrapped_seed(wrap);
+                    next_seed = (int)pl->wrapped_seed(wrap);
                 }
                 while (next_seed < n_possible && seed_is_used(next_seed)) next_seed++;
                 if (next_seed >= n_possible) continue;
                 seed_set_used(next_seed);
                 PEHits h[2];
-                if (!pl.lookup(L(rd[w][0]) + next_seed, h)) { next_seed++; continue; }                                // seed with an N, :454
+                if (!pl->lookup(L(rd[w][0]) + next_seed, h)) { next_seed++; continue; }                                // seed with an N, :454
                 S()->cnt.lookups++;
                 lookups++;
                 for (int d = 0; d < 2; d++) {
@@ -802,7 +807,7 @@ struct PairedCore {
             int64_t last_mate_loc = 0;              // mate[sp][n_mate[sp] - 1].loc (the walk looks back at it in every step)
             if (sp == 1) n_cand0 = n_cand;
             typename PL::HSCursor cf, cm;
-            pl.hs_begin_walk(lks(s_fewer), &HS()[s_fewer], 0, cfg.max_seeds, cf); pl.hs_begin_walk(lks(s_more), &HS()[s_more], 1, cfg.max_seeds, cm);
+            pl->hs_begin_walk(lks(s_fewer), &HS()[s_fewer], 0, cfg.max_seeds, cf); pl->hs_begin_walk(lks(s_more), &HS()[s_more], 1, cfg.max_seeds, cm);
             if (hs_first(s_fewer, &loc_f, &so_f, cf)) continue;
             for (;;) {
                 if (loc_m > loc_f + (int64_t)cfg.max_spacing) {
@@ -818,7 +823,7 @@ struct PairedCore {
                     uint32_t bp = hs_best_possible(s_more, cm);
                     if (n_mate[sp] >= cfg.pool_size / 2) { overflow = 1; return; }
                     PT2_T0();
-                    PEMate *m = &mate[sp][n_mate[sp]];
+                    G(PEMate) *m = &mate[sp][n_mate[sp]];
                     if (PL::lane0()) {                                                                             // ScoringMateCandidate::init
                         m->loc = loc_m; m->best_possible = (int32_t)bp; m->seed_offset = so_m; m->score = PE_NOT_YET_SCORED;
                         m->score_limit = -1; m->match_prob = 0; m->genome_offset = 0; m->used_gapless = 0; m->clip_before = 0;
@@ -844,7 +849,7 @@ struct PairedCore {
                 if (lowest_mate + bp_f <= cfg.max_k + cfg.extra_depth) {
                     if (n_cand >= cfg.pool_size) { overflow = 1; return; }
                     const int list = lowest_mate + bp_f;
-                    PECand *c = &cand[n_cand];
+                    G(PECand) *c = &cand[n_cand];
                     const int32_t old_head = ld(LH()[list]);
                     if (PL::lane0()) {                                                                             // ScoringCandidate::init
                         c->loc = loc_f; c->set_pair = (uint32_t)sp; c->mate_index = n_mate[sp] - 1; c->seed_offset = so_f;
@@ -870,9 +875,9 @@ struct PairedCore {
 #endif
         if (!hamming && PL::FAST_HITSET && !dbg_seq_hints) {
             // (each list is strictly descending, which gives the loops below a closed form: paired_dev.h: hint_indels)
-            for (int sp = 0; sp < 2; sp++) pl.hint_indels(mate[sp], 0u, n_mate[sp], cfg.max_k_for_indels);
-            pl.hint_indels(cand, 0u, n_cand0, cfg.max_k_for_indels);
-            pl.hint_indels(cand, n_cand0, n_cand - n_cand0, cfg.max_k_for_indels);
+            for (int sp = 0; sp < 2; sp++) pl->hint_indels(mate[sp], 0u, n_mate[sp], cfg.max_k_for_indels);
+            pl->hint_indels(cand, 0u, n_cand0, cfg.max_k_for_indels);
+            pl->hint_indels(cand, n_cand0, n_cand - n_cand0, cfg.max_k_for_indels);
         } else if (!hamming) {
             for (int sp = 0; sp < 2; sp++) {
                 int bottom = 0, top = 1;
@@ -923,12 +928,12 @@ struct PairedCore {
             }
             const int ci = ld(LH()[cur_list]);
             if (ci < 0) { cur_list++; continue; }
-            PECand *c = &cand[ci];
+            G(PECand) *c = &cand[ci];
             const int64_t c_loc = ld(c->loc);
             const int sp = (int)ld(c->set_pair);
             const int c_big = ld(c->big_indel);
             const uint32_t c_so = ld(c->seed_offset);
-            const bool non_alt_aln = !cfg.alt_aware || !pl.is_alt(c_loc);
+            const bool non_alt_aln = !cfg.alt_aware || !pl->is_alt(c_loc);
             int limit = score_limit(non_alt_aln, hamming ? 0 : c_big);
             if (cur_list > limit) { st(LH()[cur_list], ld(c->next)); continue; }
 
@@ -949,7 +954,7 @@ struct PairedCore {
             if (fewer_score != -1) {
                 uint32_t mi = ld(c->mate_index);
                 for (;;) {
-                    PEMate *m = &mate[sp][mi];
+                    G(PEMate) *m = &mate[sp][mi];
                     const int64_t m_loc = ld(m->loc);
                     if (!hamming) {
                         int64_t mb = ld(m->big_indel);
@@ -1002,13 +1007,13 @@ struct PairedCore {
                             if (ai < 0) {
                                 if (n_anchor >= cfg.pool_size) { overflow = 1; return; }
                                 ai = (int)n_anchor++;
-                                PEAnchor *an = &anchor[ai];
+                                G(PEAnchor) *an = &anchor[ai];
                                 if (PL::lane0()) { an->loc_more = new_more; an->loc_fewer = new_fewer; an->match_prob = pair_p; an->pair_score = pair_score; an->pair_ag = pair_ag; }
                                 PL::sync();
                                 eliminated = false; old_p = 0;
                                 st(c->anchor, ai);
                             } else {                                                                               // MergeAnchor::checkMerge, :3820-3876
-                                PEAnchor *an = &anchor[ai];
+                                G(PEAnchor) *an = &anchor[ai];
                                 const int64_t a_more = ld(an->loc_more), a_fewer = ld(an->loc_fewer);
                                 if (a_more == SNAPGPU_InvalidGenomeLocation32 || !(dist(a_more, new_more) < 50 && dist(a_fewer, new_fewer) < 50)) {
                                     if (PL::lane0()) { an->loc_more = new_more; an->loc_fewer = new_fewer; an->match_prob = pair_p; an->pair_score = pair_score; an->pair_ag = pair_ag; }
@@ -1098,7 +1103,7 @@ struct PairedCore {
     // with ignoreAlignmentAdjustmentsForOm (the default).  Works on an index list; the records move once, when they are emitted.
     // stable sort of sec_ord[0..n) by sec_key[sec_ord[.]]: what glibc's merge-sorting qsort leaves.
     PE_FN void sec_stable_sort(uint32_t n) {
-        uint32_t *tmp = sec_key + cfg.sec_cap;
+        G(uint32_t) *tmp = sec_key + cfg.sec_cap;
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t me = ld(sec_ord[i]), k = ld(sec_key[me]);
             uint32_t rank = 0;
@@ -1113,7 +1118,7 @@ struct PairedCore {
     PE_FN void finalize_secondary(int best_pair_score, const snapgpu_paired_result &res) {
         uint32_t n = n_sec;
         for (uint32_t i = 0; i < n; i++) {
-            snapgpu_paired_result *e = &sec[i];
+            G(snapgpu_paired_result) *e = &sec[i];
             const int s0 = ld(e->score[0]), s1 = ld(e->score[1]);
             if (PL::lane0()) { e->score_prior_to_clipping[0] = s0; e->score_prior_to_clipping[1] = s1; }
             st(sec_ord[i], i); st(sec_key[i], (uint32_t)(s0 + s1));
@@ -1162,7 +1167,7 @@ struct PairedCore {
         n_sec = n;
     }
     // secondary result k of this pair, after the filtering
-    PE_FN const snapgpu_paired_result *secondary(uint32_t k) const { return &sec[ld(sec_ord[k])]; }
+    PE_FN const G(snapgpu_paired_result) *secondary(uint32_t k) const { return &sec[ld(sec_ord[k])]; }
 
     // ------------------------------------------------------------------ Phase 4 (alignAffineGap, :2489-2970)
     PE_FN void phase4() {
@@ -1171,7 +1176,7 @@ struct PairedCore {
         if (res.status[0] == SNAPGPU_NotFound || res.status[1] == SNAPGPU_NotFound) return;
         const int sl = cfg.seed_len;
         if (read_len[0] < sl || read_len[1] < sl) return;
-        uint32_t n_count = pl.count_n(L(rd[0][0]), read_len[0]) + pl.count_n(L(rd[1][0]), read_len[1]);
+        uint32_t n_count = pl->count_n(L(rd[0][0]), read_len[0]) + pl->count_n(L(rd[1][0]), read_len[1]);
         if ((int)n_count > cfg.max_k) return;
 
         const int max_k_same = cfg.gap_open / (cfg.sub_penalty - cfg.gap_extend);
@@ -1221,7 +1226,7 @@ struct PairedCore {
         }
 
         PESet &A = all, &N = non_alt;
-        bool non_alt_aln = !cfg.alt_aware || !pl.is_alt(res.location[0]);
+        bool non_alt_aln = !cfg.alt_aware || !pl->is_alt(res.location[0]);
         set_init_from(A, res);
         bool alt_best = false;
         if (alt.status[0] != SNAPGPU_NotFound && alt.status[1] != SNAPGPU_NotFound) {
@@ -1259,8 +1264,8 @@ struct PairedCore {
             limit = (cfg.max_k < best_pair_score ? cfg.max_k : best_pair_score) + cfg.extra_depth;
             // qsort(compareByScore) is glibc's stable merge sort here: visit candidates by (pair score, insertion index).
             // pl.sort_candidates writes that order (a stable counting sort on the key kept in `reserved`) to agc_order.
-            pl.sort_candidates(agc, n_agc, agc_order);
-            PEHelpSpec *spec = nullptr;
+            pl->sort_candidates(agc, n_agc, agc_order);
+            G(PEHelpSpec) *spec = nullptr;
             uint32_t spec_from = 0;
             spec_used = 0;
             for (uint32_t t = 0; t < n_agc; t++) {
@@ -1270,15 +1275,15 @@ struct PairedCore {
                     // whichever long pair came first while every wave was still busy.  Candidates t .. n_agc - 1 are then scored
                     // speculatively under the limit the walk has arrived with, by this wave and the idle ones, before the walk goes on
                     // and consumes the answers (struct PEHelpSpec).  Looked at every 16 candidates.
-                    if (spec == nullptr && (t & 15u) == 0u && n_agc - t >= help_min && pl.help_wanted()) {
-                        spec = pl.help_phase4(*this, n_agc, t, PL::i32(limit), best_pair_score, skip);
+                    if (spec == nullptr && (t & 15u) == 0u && n_agc - t >= help_min && pl->help_wanted()) {
+                        spec = pl->help_phase4(*this, n_agc, t, PL::i32(limit), best_pair_score, skip);
                         spec_from = t;
                     }
                 }
-                snapgpu_paired_result *e = &agc[ld(agc_order[t])];
+                G(snapgpu_paired_result) *e = &agc[ld(agc_order[t])];
                 phase4_candidate(e, limit, best_pair_score, skip, g_off, (spec && t >= spec_from) ? &spec[t] : nullptr);
             }
-            if constexpr (PL::HELP) { if (spec) pl.help_done(spec_used); }
+            if constexpr (PL::HELP) { if (spec) pl->help_done(spec_used); }
         }
 
         const bool emit_all = !cfg.alt_aware || N.best_pair_score > A.best_pair_score + cfg.max_gap_alt;
@@ -1357,21 +1362,21 @@ struct PairedCore {
         const int rl = read_len[which];
         const int64_t glen = (int64_t)rl + SNAPGPU_MAX_K;
         *offset = 0; *ref_span = 0;
-        if (!pl.substring_ok(loc, glen)) { *score = -1; *mp = 0; *ag_score = -1; return; }
+        if (!pl->substring_ok(loc, glen)) { *score = -1; *mp = 0; *ag_score = -1; return; }
         *clip_before = 0; *clip_after = 0;
-        const uint8_t *data = pl.window(loc, rl);
+        const uint8_t *data = pl->window(loc, rl);
         const uint8_t *R = L(rd[which][dir]), *Qd = L(ql[which][dir]);
         const int clip = 2;                                    // useSoftClip (the caller's condition) + useAltLiftover
         int score1 = 0, score2 = 0;
         double mp2 = 1.0;
-        AGOut a = pl.ag(rl >= 3 * (2 * limit + 1), +1, R, Qd, rl, data, (int)glen, limit, rl, dir != 0, clip);
+        AGOut a = pl->ag(rl >= 3 * (2 * limit + 1), +1, R, Qd, rl, data, (int)glen, limit, rl, dir != 0, clip);
         note_ag_call(0, (uint32_t)a.stale);
         const int text_rem = a.text_offset;
         *clip_after = a.pattern_offset; score1 = a.n_edits;
         if (score1 != -1 && score1 <= PE_MAXK1) {
             const int left = score1;
             const int plen = rl - *clip_after;
-            AGOut b = pl.ag(plen >= 3 * (2 * left + 1), -1, R + (rl - 1 - *clip_after), Qd + (rl - 1 - *clip_after), plen,
+            AGOut b = pl->ag(plen >= 3 * (2 * left + 1), -1, R + (rl - 1 - *clip_after), Qd + (rl - 1 - *clip_after), plen,
                             data + (rl - text_rem - 1), rl - text_rem, left, rl, dir != 0, clip);
             note_ag_call(1, (uint32_t)b.stale);
             *clip_before = b.pattern_offset; score2 = b.n_edits; mp2 = b.mp;
@@ -1402,7 +1407,7 @@ struct PairedCore {
         if (res.status[0] != SNAPGPU_NotFound && res.status[1] != SNAPGPU_NotFound) {
             best_res = res.score[0] + res.score[1];
             res_contig = contig_num(res.location[0]);
-            res_is_alt = cfg.alt_aware && pl.is_alt(res.location[0]) && pl.is_alt(res.location[1]);
+            res_is_alt = cfg.alt_aware && pl->is_alt(res.location[0]) && pl->is_alt(res.location[1]);
         }
         const bool use = cfg.alt_aware && ((best_alt < best_res && alt_proj_contig != res_contig) || res_is_alt);
         if (!PL::i32(use ? 1 : 0)) return;
@@ -1439,7 +1444,7 @@ struct PairedCore {
     // body of the candidate loop of alignAffineGap (:2736-2823)
     // One candidate scored ahead of the ordered walk: the limit bookkeeping of phase4_candidate up to its two scoreLocationWithAffineGap
     // calls, entered with limit `L`; nothing but *sp is written (the candidate record, the score sets and the work counters stay as they are).
-    PE_FN void spec_candidate(const snapgpu_paired_result *e, PEHelpSpec *sp, int L, int best_pair_score, bool skip0, bool skip1) {
+    PE_FN void spec_candidate(const G(snapgpu_paired_result) *e, G(PEHelpSpec) *sp, int L, int best_pair_score, bool skip0, bool skip1) {
         int limit = L;
         int s0 = ld(e->score[0]), s1 = ld(e->score[1]);
         const int lv_pair_score = s0 + s1;
@@ -1490,8 +1495,8 @@ struct PairedCore {
         PL::sync();
     }
 
-    PE_FN void phase4_candidate(snapgpu_paired_result *e, int &limit, int best_pair_score, const bool skip[2], int g_off[2],
-                                const PEHelpSpec *sp = nullptr) {
+    PE_FN void phase4_candidate(G(snapgpu_paired_result) *e, int &limit, int best_pair_score, const bool skip[2], int g_off[2],
+                                const G(PEHelpSpec) *sp = nullptr) {
         snapgpu_paired_result &res = S()->res;
         PESet &A = S()->all, &N = S()->non_alt;
         int s0 = ld(e->score[0]), s1 = ld(e->score[1]);
@@ -1502,7 +1507,7 @@ struct PairedCore {
         else if (lv_pair_score > best_pair_score + cfg.extra_depth && lv_pair_indels > 1) limit = cfg.max_k + cfg.extra_depth;
         if (!(lv_pair_score <= best_pair_score + cfg.extra_depth || lv_pair_indels > 1 || gl0 || gl1)) return;
 
-        const bool non_alt_aln = !cfg.alt_aware || !pl.is_alt(ld(e->location[0]));
+        const bool non_alt_aln = !cfg.alt_aware || !pl->is_alt(ld(e->location[0]));
         double mp0 = ld(e->match_probability[0]), mp1 = ld(e->match_probability[1]);
         const double old_p = mp0 * mp1;
         int ag0 = ld(e->ag_score[0]), ag1 = ld(e->ag_score[1]);
@@ -1654,19 +1659,19 @@ struct PairedCore {
                 const uint64_t t_s = PL::clock();
                 // single-end secondary results land behind read 0's (ChimericPairedEndAligner.cpp:308-312: "it's either 0 or all we've seen")
                 const uint32_t sec_base = n_ssec[0];
-                snapgpu_single_result *sec_dst = nullptr; uint32_t sec_room = 0;
+                G(snapgpu_single_result) *sec_dst = nullptr; uint32_t sec_room = 0;
                 if (want_sec() && ssec_out != nullptr && sec_base < ssec_stride) { sec_dst = ssec_out + sec_base; sec_room = ssec_stride - sec_base; }
                 const uint32_t room32 = sec_base < 32u ? 32u - sec_base : 0u;       // what PairedAligner.cpp:566's initial buffer would have left
-                uint32_t n_this = pl.align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
+                uint32_t n_this = pl->align_single(r, PL::i32(max_k_read), false, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
                 PT2_OFF(S()->cnt.cyc_single += PL::clock() - t_s);
                 stale += single[r].reserved & 0x3fffffffu; stale_later += (single[r].reserved & 0x40000000u) ? 1u : 0u;
                 bool used_hamming = false;
                 if (cfg.use_soft_clip && cfg.enable_hamming_base) {
                     if (single[r].status == SNAPGPU_NotFound && res.status[r] == SNAPGPU_NotFound) {                  // :330-360
                         used_hamming = true;
-                        n_this = pl.align_single(r, PL::i32(max_k_read), true, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
+                        n_this = pl->align_single(r, PL::i32(max_k_read), true, single[r], single_alt[r], want_sec(), sec_dst, sec_room, room32);
                         // the reference drops this call's "buffer too small" on the floor (:339-343): see SNAPGPU_PAIR_REF_BUFFER_DEPENDENT
-                        if (want_sec() && pl.single_raw_secondary() > room32) ref_dep = 1;
+                        if (want_sec() && pl->single_raw_secondary() > room32) ref_dep = 1;
                         stale += single[r].reserved & 0x3fffffffu; stale_later += (single[r].reserved & 0x40000000u) ? 1u : 0u;
                         if (single[r].reserved & 0x80000000u) { overflow = 1; return; }      // candidate buffer of the single-end aligner overflowed
                     }

@@ -20,17 +20,18 @@
 // single-end aligner of the chimeric fallback has its own two; the kernel zeroes all four before each pair.
 template <int AGC, bool SEC = false, bool EXACT = false>
 struct DevPL {
-    Aligner<AGC, SEC, EXACT> *al;      // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
+    typedef LP<DevPL> SelfPtr;
+    LP<Aligner<AGC, SEC, EXACT>> al;      // single-end aligner of this wave (shares gw / lv_tri / ag_rows / ag_scratch)
     uint8_t *ag_persist0, *ag_persist1;
     uint32_t ag_hw0, ag_hw1;           // EXACT: bytes of each image written since it was last zeroed
     uint32_t ag_epoch, ag_tag;         // EXACT: pairs since the images were last cleared (1 .. 15), its tag bits (dev_common.h: bt_cell)
     // Phase-4 help (not in the exact replay: there the affine-gap calls of a pair are ordered through the traceback arrays they share)
     static const bool HELP = !EXACT;
     static const bool ALWAYS_COUNT_STALE = EXACT;
-    PEHelpSlot *help; uint32_t n_help; PEHelpSpec *help_spec; uint32_t help_spec_cap;
-    const uint32_t *help_idle; bool help_eager;      // waves of the launch that have run out of pairs (nullptr: no helpers); publish regardless
+    G(PEHelpSlot) *help; uint32_t n_help; G(PEHelpSpec) *help_spec; uint32_t help_spec_cap;
+    const G(uint32_t) *help_idle; bool help_eager;      // waves of the launch that have run out of pairs (nullptr: no helpers); publish regardless
     uint32_t cur_pair; int my_slot;
-    unsigned long long *diag;          // snapgpu_counters::reserved: [1] waits that ran into the watchdog, [2] what the last one saw
+    G(unsigned long long) *diag;       // snapgpu_counters::reserved: [1] waits that ran into the watchdog, [2] what the last one saw
     // Cross-wave traffic is kept off the cache-wide fences (an agent-scope release writes back the whole L2 of the XCD, an acquire
     // invalidates it -- once per helped pair / per attach is fine, once per chunk of candidates is not): the speculative answers travel
     // in device-scope (sc1, write-through) stores and loads, ordered against the chunk's `done` count by a plain vmcnt(0) wait.
@@ -38,23 +39,27 @@ struct DevPL {
     // touched by read-modify-write atomics: set with an exchange whose return value is waited for, read with a compare-and-swap that
     // cannot succeed (`atomicAdd(p, 0)` is folded into an atomic LOAD by the compiler, and a load or a store may take another road to
     // memory than the atomic unit: a store followed by an add on the same word was seen to be applied after it).
-    static __device__ __forceinline__ uint32_t aload(uint32_t *p) { return first_u32(lane_id() == 0 ? atomicCAS(p, 0xFFFFFFF5u, 0xFFFFFFF5u) : 0u); }
-    template <class T> static __device__ __forceinline__ void spec_st(T &x, T v) {
+    template <class P> static __device__ __forceinline__ uint32_t aload(P *p) { return first_u32(lane_id() == 0 ? atomicCAS(p, 0xFFFFFFF5u, 0xFFFFFFF5u) : 0u); }
+    // (x: an lvalue in HBM, possibly typed as such -- dev_common.h: G(T))
+    template <class T, class W> static __device__ __forceinline__ void spec_st(T &x, W v_in) {
+        typedef typename strip_as<T>::type V;
+        const V v = (V)v_in;
 #ifdef SNAPGPU_WAVE_EMU
-        if constexpr (sizeof(T) == 8) __atomic_store_n((uint64_t *)&x, __builtin_bit_cast(uint64_t, v), __ATOMIC_SEQ_CST);
+        if constexpr (sizeof(V) == 8) __atomic_store_n((uint64_t *)&x, __builtin_bit_cast(uint64_t, v), __ATOMIC_SEQ_CST);
         else __atomic_store_n((uint32_t *)&x, __builtin_bit_cast(uint32_t, v), __ATOMIC_SEQ_CST);
 #else
-        if constexpr (sizeof(T) == 8) __hip_atomic_store((uint64_t *)&x, __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else __hip_atomic_store((uint32_t *)&x, __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (sizeof(V) == 8) __hip_atomic_store((GLB_AS uint64_t *)&x, __builtin_bit_cast(uint64_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store((GLB_AS uint32_t *)&x, __builtin_bit_cast(uint32_t, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
     }
-    template <class T> static __device__ __forceinline__ T spec_ld(const T &x) {
+    template <class T> static __device__ __forceinline__ typename strip_as<T>::type spec_ld(const T &x) {
+        typedef typename strip_as<T>::type V;
 #ifdef SNAPGPU_WAVE_EMU
-        if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, first_u64(__atomic_load_n((const uint64_t *)&x, __ATOMIC_SEQ_CST)));
-        else return __builtin_bit_cast(T, first_u32(__atomic_load_n((const uint32_t *)&x, __ATOMIC_SEQ_CST)));
+        if constexpr (sizeof(V) == 8) return __builtin_bit_cast(V, first_u64(__atomic_load_n((const uint64_t *)&x, __ATOMIC_SEQ_CST)));
+        else return __builtin_bit_cast(V, first_u32(__atomic_load_n((const uint32_t *)&x, __ATOMIC_SEQ_CST)));
 #else
-        if constexpr (sizeof(T) == 8) return __builtin_bit_cast(T, first_u64(__hip_atomic_load((const uint64_t *)&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-        else return __builtin_bit_cast(T, first_u32(__hip_atomic_load((const uint32_t *)&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        if constexpr (sizeof(V) == 8) return __builtin_bit_cast(V, first_u64(__hip_atomic_load((const GLB_AS uint64_t *)&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+        else return __builtin_bit_cast(V, first_u32(__hip_atomic_load((const GLB_AS uint32_t *)&x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
 #endif
     }
     static __device__ __forceinline__ void stores_done() {                 // every store this wave has issued has been acknowledged
@@ -87,17 +92,17 @@ struct DevPL {
     // (the slot's fields are read with device-scope loads: a plain load may be served by this CU's L1 with what the slot held for an
     //  earlier pair -- even in the wave that has just stored them, if another wave of the CU had the line cached)
     // a helper's view of the slot (the owner passes its own values: it never reads back what it has just published)
-    template <class Core> __device__ __forceinline__ void help_work(Core &core, PEHelpSlot *slot) {
+    template <class Core> __device__ __forceinline__ void help_work(Core &core, G(PEHelpSlot) *slot) {
         const uint32_t n = spec_ld(slot->n);
         const int L = spec_ld(slot->limit), best = spec_ld(slot->best);
         const bool s0 = spec_ld(slot->skip0) != 0, s1 = spec_ld(slot->skip1) != 0;
-        const snapgpu_paired_result *agc = (const snapgpu_paired_result *)(uintptr_t)spec_ld(*(const uint64_t *)&slot->agc);
-        const uint32_t *order = (const uint32_t *)(uintptr_t)spec_ld(*(const uint64_t *)&slot->order);
-        PEHelpSpec *spec = (PEHelpSpec *)(uintptr_t)spec_ld(*(const uint64_t *)&slot->spec);
+        const G(snapgpu_paired_result) *agc = (const G(snapgpu_paired_result) *)(uintptr_t)spec_ld(*(const G(uint64_t) *)&slot->agc);
+        const G(uint32_t) *order = (const G(uint32_t) *)(uintptr_t)spec_ld(*(const G(uint64_t) *)&slot->order);
+        G(PEHelpSpec) *spec = (G(PEHelpSpec) *)(uintptr_t)spec_ld(*(const G(uint64_t) *)&slot->spec);
         help_chunks(core, slot, n, L, best, s0, s1, agc, order, spec);
     }
-    template <class Core> __device__ __forceinline__ void help_chunks(Core &core, PEHelpSlot *slot, uint32_t n, int L, int best, bool s0, bool s1,
-                                                                      const snapgpu_paired_result *agc, const uint32_t *order, PEHelpSpec *spec) {
+    template <class Core> __device__ __forceinline__ void help_chunks(Core &core, G(PEHelpSlot) *slot, uint32_t n, int L, int best, bool s0, bool s1,
+                                                                      const G(snapgpu_paired_result) *agc, const G(uint32_t) *order, G(PEHelpSpec) *spec) {
         for (uint32_t it = 0; it <= n / PE_HELP_CHUNK + 1u; it++) {
             uint32_t c0 = 0;
             if (lane_id() == 0) c0 = atomicAdd(&slot->next, PE_HELP_CHUNK);
@@ -116,7 +121,7 @@ struct DevPL {
         return help_idle != nullptr && spec_ld(*help_idle) != 0u;
     }
     // candidates first .. n - 1 of the sorted list (spec is indexed by position in the list, so spec[first ..] are the ones filled in)
-    template <class Core> __device__ __forceinline__ PEHelpSpec *help_phase4(Core &core, uint32_t n, uint32_t first, int limit, int best, const bool skip[2]) {
+    template <class Core> __device__ __forceinline__ G(PEHelpSpec) *help_phase4(Core &core, uint32_t n, uint32_t first, int limit, int best, const bool skip[2]) {
         my_slot = -1;
         if (help == nullptr || n > help_spec_cap) return nullptr;
         int s = -1;
@@ -125,16 +130,16 @@ struct DevPL {
         }
         s = (int)first_u32((uint32_t)s);
         if (s < 0) return nullptr;                          // every slot is taken: this pair goes through its list alone
-        PEHelpSlot *slot = &help[s];
-        PEHelpSpec *spec = help_spec + (size_t)s * help_spec_cap;
+        G(PEHelpSlot) *slot = &help[s];
+        G(PEHelpSpec) *spec = help_spec + (size_t)s * help_spec_cap;
         if (lane_id() == 0) {
             const uint32_t w0 = atomicExch(&slot->next, first), w1 = atomicExch(&slot->done, 0u);
             if ((w0 ^ w1) == 0xFFFFFFF5u) atomicExch(&slot->done, 0u);          // (uses both return values: the exchanges have completed)
             spec_st(slot->pair, cur_pair); spec_st(slot->n, n);
             spec_st(slot->limit, (int32_t)limit); spec_st(slot->best, (int32_t)best);
             spec_st(slot->skip0, skip[0] ? 1u : 0u); spec_st(slot->skip1, skip[1] ? 1u : 0u);
-            spec_st(*(uint64_t *)&slot->agc, (uint64_t)(uintptr_t)core.agc); spec_st(*(uint64_t *)&slot->order, (uint64_t)(uintptr_t)core.agc_order);
-            spec_st(*(uint64_t *)&slot->spec, (uint64_t)(uintptr_t)spec);
+            spec_st(*(G(uint64_t) *)&slot->agc, (uint64_t)(uintptr_t)core.agc); spec_st(*(G(uint64_t) *)&slot->order, (uint64_t)(uintptr_t)core.agc_order);
+            spec_st(*(G(uint64_t) *)&slot->spec, (uint64_t)(uintptr_t)spec);
             fence_release();                                // the candidate records and their order, for the other XCDs
             atomicExch(&slot->state, 1u);
         }
@@ -182,7 +187,7 @@ struct DevPL {
         }
         my_slot = -1;
     }
-    const DevTables *tab;
+    GP<const DevTables> tab;
     AGParams agp;
     uint32_t kmax_lv;                  // the largest limit a paired-end LV call can have: what lv_big is sized for (the LDS triangle: al->cfg.kmax)
     uint16_t *lv_big;                  // per-wave HBM buffer of lv_lds_bytes(kmax_lv, RL) bytes for the calls whose limit exceeds the LDS triangle
@@ -190,17 +195,19 @@ struct DevPL {
     int g_len[2];
     WaveShared *ws;
 
-    template <class T> static __device__ __forceinline__ T ld(const T &x) {
-        if constexpr (sizeof(T) == 8) {
-            return __builtin_bit_cast(T, first_u64(__builtin_bit_cast(uint64_t, x)));
-        } else if constexpr (sizeof(T) == 4) {
-            return __builtin_bit_cast(T, first_u32(__builtin_bit_cast(uint32_t, x)));
+    template <class T> static __device__ __forceinline__ typename strip_as<T>::type ld(const T &x) {
+        typedef typename strip_as<T>::type V;
+        const V v = x;
+        if constexpr (sizeof(V) == 8) {
+            return __builtin_bit_cast(V, first_u64(__builtin_bit_cast(uint64_t, v)));
+        } else if constexpr (sizeof(V) == 4) {
+            return __builtin_bit_cast(V, first_u32(__builtin_bit_cast(uint32_t, v)));
         } else {
-            return (T)first_u32((uint32_t)x);
+            return (V)first_u32((uint32_t)v);
         }
     }
-    template <class T> static __device__ __forceinline__ void st(T &x, T v) {
-        if (lane_id() == 0) x = v;
+    template <class T, class W> static __device__ __forceinline__ void st(T &x, W v) {
+        if (lane_id() == 0) x = (typename strip_as<T>::type)v;
         WAVE_SYNC();
     }
     // this pointer points into LDS (paired.h: PairedCore::L)
@@ -240,7 +247,7 @@ struct DevPL {
     // re-read all of this from LDS -- eight loads and their waits per query, three queries per step -- and write `cur` / most_recent back.
     struct HSCursor {
         uint32_t cur, nh, so, wd, singleton; bool single, act;
-        int32_t wbase; const uint32_t *hits; uint32_t *win;      // per lane: staged window [wbase, wbase + hs_w) of hits[] (LDS)
+        int32_t wbase; const G(uint32_t) *hits; uint32_t *win;      // per lane: staged window [wbase, wbase + hs_w) of hits[] (LDS)
         uint32_t n_used, recent; int cd;                         // wave-uniform
     };
     __device__ __forceinline__ void hs_begin_walk(PELookup *lk, PEHitSetHdr *h, int role, uint32_t max_seeds, HSCursor &c) {
@@ -250,7 +257,7 @@ struct DevPL {
         const PELookup *l = &lk[c.act ? lane : 0];
         c.cur = 0u; c.nh = c.act ? (uint32_t)l->n_hits : 0u; c.so = l->seed_offset; c.wd = l->which_disjoint;
         c.single = l->is_single != 0; c.singleton = l->singleton; c.hits = l->hits; c.wbase = -1;
-        uint32_t *blk = (uint32_t *)al->lv_tri; lds(blk);
+        uint32_t *blk = (uint32_t *)(uint16_t *)al->lv_tri;
         c.win = blk + 2 * PE_MRING + (size_t)role * max_seeds * hs_w + (size_t)(c.act ? lane : 0) * hs_w;
     }
     // window of lane's lookup covers hit indices [lo, hi] (already clamped to the list)?  If not, stage [lo, lo + HS_W) -- all the loads of
@@ -258,7 +265,7 @@ struct DevPL {
     template <int W> static __device__ __forceinline__ void hs_stage_w(HSCursor &c, bool need, uint32_t lo) {
         if (BALLOT(need)) {
             if (need) {
-                const uint32_t *src = c.hits + lo;
+                const G(uint32_t) *src = c.hits + lo;
                 const uint32_t n = c.nh - lo;
                 uint32_t v[W];
 #pragma unroll
@@ -406,10 +413,10 @@ struct DevPL {
         if (!seed.valid) return false;
         HitList hl[2];
         lookup_seed(al->ix, seed, hl);
-        out[0].hits = hl[0].hits; out[0].n_hits = hl[0].n_hits; out[0].singleton = hl[0].singleton;
-        out[1].hits = hl[1].hits; out[1].n_hits = hl[1].n_hits; out[1].singleton = hl[1].singleton;
-        al->cnt.lookups++;
-        al->cnt.slots += hl[0].slots + hl[1].slots;
+        out[0].hits = (const G(uint32_t) *)hl[0].hits; out[0].n_hits = hl[0].n_hits; out[0].singleton = hl[0].singleton;
+        out[1].hits = (const G(uint32_t) *)hl[1].hits; out[1].n_hits = hl[1].n_hits; out[1].singleton = hl[1].singleton;
+        al->cnt().lookups++;
+        al->cnt().slots += hl[0].slots + hl[1].slots;
         return true;
     }
     __device__ __forceinline__ uint32_t wrapped_seed(uint32_t wrap) const { return tab->wrapped_seed[wrap]; }
@@ -426,7 +433,7 @@ struct DevPL {
     __device__ __forceinline__ const uint8_t *window(int64_t loc, int read_len) {
         al->read_len = read_len;
         al->stage_window(loc);
-        uint8_t *g = al->gw; lds(g);
+        uint8_t *g = al->gw;
         return g + WIN_PAD;
     }
     __device__ __forceinline__ bool is_alt(int64_t loc) const { return al->is_alt(loc); }
@@ -462,7 +469,7 @@ struct DevPL {
         }
         if (++al->ag_calls_unit == WAVE_PRIO_HEAVY_AFTER * 8) wave_set_priority(1);          // (a pair: both mates, both halves, Phases 3 and 4)
         AGResult a = ag_dispatch<AGC, EXACT>(banded, st, agp, Ps, Qs, plen, Ts, tlen, lim, read_len, is_rc, use_clip, al->ag_rows,
-                                             EXACT ? (st == 1 ? ag_persist0 : ag_persist1) : al->ag_scratch, al->cfg.RL, tab, EXACT ? ag_tag : 0u);
+                                             EXACT ? (st == 1 ? ag_persist0 : ag_persist1) : (uint8_t *)al->ag_scratch, al->cfg.RL, tab, EXACT ? ag_tag : 0u);
         AGOut o;
         o.ag_score = i32(a.ag_score); o.text_offset = i32(a.text_offset); o.pattern_offset = i32(a.pattern_offset);
         o.n_edits = i32(a.n_edits); o.mp = f64(a.match_probability); o.stale = i32(a.stale_reads);
@@ -470,9 +477,9 @@ struct DevPL {
     }
     // Stable counting sort of the Phase-4 candidates by pair score (the key kept in `reserved`, < 512): histogram and
     // running bases in LDS (the LV triangle is idle here), entries scattered 64 at a time in index order.
-    __device__ __forceinline__ void sort_candidates(const snapgpu_paired_result *c, uint32_t n, uint32_t *order) {
+    __device__ __forceinline__ void sort_candidates(const G(snapgpu_paired_result) *c, uint32_t n, G(uint32_t) *order) {
         const int lane = lane_id();
-        uint32_t *base = (uint32_t *)al->lv_tri;                     // the LV block of LDS: lv_lds_bytes(kmax >= 22, RL) >= 2 232 bytes; 512 counters needed
+        uint32_t *base = (uint32_t *)(uint16_t *)al->lv_tri;                     // the LV block of LDS: lv_lds_bytes(kmax >= 22, RL) >= 2 232 bytes; 512 counters needed
         uint32_t *hist = base;
         for (int k = lane; k < 512; k += WAVE) hist[k] = 0;
         WAVE_SYNC();
@@ -513,7 +520,7 @@ struct DevPL {
     // (AlignRead(..., useHamming) followed by BaseAligner::alignAffineGap on the candidates it collected).
     // Returns the number of secondary results the read has (SEC only); the first min(that, sec_room) are copied to sec_out.
     __device__ __forceinline__ uint32_t align_single(int r, int max_k, bool hamming, snapgpu_single_result &res, snapgpu_single_result &alt,
-                                                     bool want_secondary, snapgpu_single_result *sec_out, uint32_t sec_room, uint32_t room32) {
+                                                     bool want_secondary, G(snapgpu_single_result) *sec_out, uint32_t sec_room, uint32_t room32) {
         (void)want_secondary; (void)room32;
         al->max_k = (uint32_t)max_k;
         if (!hamming) {
@@ -521,11 +528,11 @@ struct DevPL {
         } else {
             al->template align_read_inner<true>(g_bases[r], g_quals[r], g_len[r]);
             if (!al->agc_overflow) al->align_affine_gap(ws->ag_all, ws->ag_non_alt);
-            al->primary.reserved = (al->ag_stale & 0x3fffffffu) | (al->ag_replay ? 0x40000000u : 0u);
+            al->primary().reserved = (al->ag_stale & 0x3fffffffu) | (al->ag_replay ? 0x40000000u : 0u);
         }
         WAVE_SYNC();
-        res = al->primary;
-        alt = al->first_alt;
+        res = al->primary();
+        alt = al->first_alt();
         if (al->agc_overflow) res.reserved |= 0x80000000u;
         WAVE_SYNC();
         if constexpr (SEC) {
@@ -537,7 +544,7 @@ struct DevPL {
             for (uint32_t k0 = 0; k0 < n_out; k0 += 2) {                         // two 22-dword records per pass
                 const uint32_t k = k0 + (uint32_t)(lane >> 5);
                 const int w = lane & 31;
-                if (k < n_out && w < nd) ((uint32_t *)&sec_out[k])[w] = ((const uint32_t *)&al->sec[al->sec_ord[k]])[w];
+                if (k < n_out && w < nd) ((G(uint32_t) *)&sec_out[k])[w] = ((const uint32_t *)&al->sec[al->sec_ord[k]])[w];
             }
             WAVE_SYNC();
             return n;
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     al.ag_scratch = sc + (size_t)a.scfg.ht_size * 2 + (size_t)a.scfg.pool_size * sizeof(Elem);
     al.agc = a.single_agc_cap ? (snapgpu_single_result *)(sc + a.off_single_agc) : nullptr;    // no buffer without affine gap (PairedAligner.cpp:570-577)
     al.agc_cap = a.single_agc_cap;
-    al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    al.cnt() = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     al.ag_calls_unit = 0;
     al.se_slots = nullptr; al.se_n_slots = 0; al.se_spec = nullptr; al.se_spec_cap = 0; al.se_ctl = nullptr; al.se_eager = 0; al.se_diag = nullptr;
     al.se_items = nullptr; al.se_first = nullptr; al.se_slot = -1; al.se_n = 0; al.se_tried = 0; al.cur_read = 0; al.se_mine = nullptr;      // (se_help.h: single-end path only)
@@ -605,9 +612,9 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     al.ag_persist0 = al.ag_persist1 = pl.ag_persist0 = pl.ag_persist1 = nullptr;
     al.ag_hw0 = al.ag_hw1 = pl.ag_hw0 = pl.ag_hw1 = 0;
     pl.ag_epoch = 0; pl.ag_tag = 0;
-    pl.help = EXACT ? nullptr : a.help; pl.n_help = a.n_help; pl.help_spec = a.help_spec; pl.help_spec_cap = a.help_spec_cap;
-    pl.help_idle = a.help_done ? a.help_done + 1 : nullptr; pl.help_eager = a.help_eager != 0;
-    pl.cur_pair = 0; pl.my_slot = -1; pl.diag = a.counters + 13;
+    pl.help = EXACT ? nullptr : (G(PEHelpSlot) *)a.help; pl.n_help = a.n_help; pl.help_spec = (G(PEHelpSpec) *)a.help_spec; pl.help_spec_cap = a.help_spec_cap;
+    pl.help_idle = a.help_done ? (const G(uint32_t) *)(a.help_done + 1) : nullptr; pl.help_eager = a.help_eager != 0;
+    pl.cur_pair = 0; pl.my_slot = -1; pl.diag = (G(unsigned long long) *)(a.counters + 13);
     // the Landau-Vishkin block of LDS during Phase 2: [mate ring: 2 x PE_MRING words][two window blocks of max_seeds x hs_w words]
     // (snapgpu_enable_paired: kmax >= 22 -> 2 232 bytes, max_seeds <= 30, so windows of 8 always fit)
     pl.hs_w = 8u * PE_MRING + 2u * a.pcfg.max_seeds * 16u * 4u <= lv_lds_bytes(a.scfg.kmax, a.scfg.RL) ? 16u : 8u;
@@ -628,18 +635,18 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     core.seed_used = (uint32_t *)(my + PLd.seed_used);
     core.sh = (PEShared *)(my + PLd.sh);
     core.mring = (uint32_t *)(my + SL.lv);
-    core.cand = (PECand *)(sc + a.off_cand);
-    core.mate[0] = (PEMate *)(sc + a.off_mate0);
-    core.mate[1] = (PEMate *)(sc + a.off_mate1);
-    core.anchor = (PEAnchor *)(sc + a.off_anchor);
-    core.agc = (snapgpu_paired_result *)(sc + a.off_agc);
-    core.agc_order = (uint32_t *)(sc + a.off_agc_order);
+    core.cand = (G(PECand) *)(sc + a.off_cand);
+    core.mate[0] = (G(PEMate) *)(sc + a.off_mate0);
+    core.mate[1] = (G(PEMate) *)(sc + a.off_mate1);
+    core.anchor = (G(PEAnchor) *)(sc + a.off_anchor);
+    core.agc = (G(snapgpu_paired_result) *)(sc + a.off_agc);
+    core.agc_order = (G(uint32_t) *)(sc + a.off_agc_order);
     core.sec = nullptr; core.sec_ord = nullptr; core.sec_key = nullptr; core.n_sec = 0;
     core.ssec_out = nullptr; core.ssec_stride = 0; core.n_ssec[0] = core.n_ssec[1] = 0; core.ref_dep = 0;
     if constexpr (SEC) {
-        core.sec = (snapgpu_paired_result *)(sc + a.off_sec);
-        core.sec_ord = (uint32_t *)(sc + a.off_sec_ord);
-        core.sec_key = (uint32_t *)(sc + a.off_sec_key);
+        core.sec = (G(snapgpu_paired_result) *)(sc + a.off_sec);
+        core.sec_ord = (G(uint32_t) *)(sc + a.off_sec_ord);
+        core.sec_key = (G(uint32_t) *)(sc + a.off_sec_key);
     }
     core.S()->cnt = PECounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint8_t *prd = my + PLd.rd, *pql = my + PLd.ql;
@@ -732,7 +739,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
         }
         WAVE_SYNC();
         if constexpr (SEC) {
-            core.ssec_out = a.ssec_out_stride ? a.single_secondary + (size_t)i * a.ssec_out_stride : nullptr;
+            core.ssec_out = a.ssec_out_stride ? (G(snapgpu_single_result) *)(a.single_secondary + (size_t)i * a.ssec_out_stride) : nullptr;
             core.ssec_stride = a.ssec_out_stride;
         }
         core.align_pair(a.max_k_paired, a.max_k_single);
@@ -750,7 +757,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
             const uint32_t n_out = n_sec < a.sec_out_stride ? n_sec : a.sec_out_stride;
             const int nd = (int)(sizeof(snapgpu_paired_result) / 4);       // 52 dwords
             for (uint32_t k = 0; k < n_out; k++) {
-                const uint32_t *src = (const uint32_t *)core.secondary(k);
+                const G(uint32_t) *src = (const G(uint32_t) *)core.secondary(k);
                 uint32_t *dst = (uint32_t *)&a.secondary[(size_t)i * a.sec_out_stride + k];
                 if (lane < nd) dst[lane] = src[lane];
             }
@@ -799,7 +806,7 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
                 }
                 bool any = false;
                 for (uint32_t s = 0; s < a.n_help; s++) {
-                    PEHelpSlot *slot = &a.help[s];
+                    G(PEHelpSlot) *slot = (G(PEHelpSlot) *)&a.help[s];
                     if (DevPL<AGC, SEC, EXACT>::aload(&slot->pair) >= a.n_pairs) continue;
                     // (every cross-wave read of the slot goes through an L2 atomic until the acquire fence below: a plain load may be
                     //  served by this CU's L1 with what the slot held for an earlier pair)
@@ -835,13 +842,13 @@ __global__ __launch_bounds__(256, SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC)) void k_ali
     }
     if (lane == 0 && !(EXACT && a.is_replay)) {          // (a pair redone by the exact replay was already counted)
         if (!a.is_replay) atomicAdd(&a.counters[0], (unsigned long long)(2 * n_done));
-        atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
-        atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
-        atomicAdd(&a.counters[3], (unsigned long long)(al.cnt.hits + core.S()->cnt.hits));
-        atomicAdd(&a.counters[4], (unsigned long long)(al.cnt.overflow_lists + core.S()->cnt.overflow_lists));
-        atomicAdd(&a.counters[5], (unsigned long long)(al.cnt.lv + core.S()->cnt.lv));
-        atomicAdd(&a.counters[6], (unsigned long long)(al.cnt.ag + core.S()->cnt.ag));
-        atomicAdd(&a.counters[7], (unsigned long long)(al.cnt.lv_ref_bytes + core.S()->cnt.lv_ref_bytes));
+        atomicAdd(&a.counters[1], (unsigned long long)al.cnt().lookups);
+        atomicAdd(&a.counters[2], (unsigned long long)al.cnt().slots);
+        atomicAdd(&a.counters[3], (unsigned long long)(al.cnt().hits + core.S()->cnt.hits));
+        atomicAdd(&a.counters[4], (unsigned long long)(al.cnt().overflow_lists + core.S()->cnt.overflow_lists));
+        atomicAdd(&a.counters[5], (unsigned long long)(al.cnt().lv + core.S()->cnt.lv));
+        atomicAdd(&a.counters[6], (unsigned long long)(al.cnt().ag + core.S()->cnt.ag));
+        atomicAdd(&a.counters[7], (unsigned long long)(al.cnt().lv_ref_bytes + core.S()->cnt.lv_ref_bytes));
         // phase cycles of the paired path: lookup = Phase 1, hits = Phase 2 (intersection), lv / ag = paired scoring only,
         // reserved[0] = the single-end fallback as a whole
         atomicAdd(&a.counters[8], (unsigned long long)core.S()->cnt.cyc_lookup);

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         al.adj_scratch = a.sec_cfg.adjust ? ss + a.sec_cfg.adj_off : nullptr;
     }
     if constexpr (RESOLVE) al.rs_base = a.rs + (size_t)wave_slot * a.rs_stride;
-    al.cnt = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    al.cnt() = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t n_done = 0;
     // help for heavy reads (se_help.h): not in the exact replay, not without the context's arrays
     const bool se_on = !EXACT && a.se_slots != nullptr && a.cfg.se_items_cap != 0;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
                 continue;
             }
         }
-        const uint64_t dbg_t0 = TIMED ? wave_clock() : 0; const uint64_t dbg_ag0 = al.cnt.ag;
+        const uint64_t dbg_t0 = TIMED ? wave_clock() : 0; const uint64_t dbg_ag0 = al.cnt().ag;
         al.align_read(a.bases + b, a.quals + b, (int)(e - b));
         WAVE_SYNC();
 #if defined(SNAPGPU_TEST_BREAK_PARITY)
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
 #endif
         if constexpr (TIMED) {
             if (a.dbg) {
-                const unsigned long long cyc = wave_clock() - dbg_t0, nag = al.cnt.ag - dbg_ag0;
+                const unsigned long long cyc = wave_clock() - dbg_t0, nag = al.cnt().ag - dbg_ag0;
                 if (lane == 0) atomicAdd(&a.dbg[63 - __clzll((long long)(cyc | 1ull))], 1ull);
                 const unsigned long long packed = (cyc << 24) | (nag > 0xffffffull ? 0xffffffull : nag);
                 if (packed > dbg_worst) dbg_worst = packed;
@@ -204,18 +204,18 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     }
     if (lane == 0 && !a.is_replay) {          // (a replayed read was already counted by the fast pass)
         atomicAdd(&a.counters[0], (unsigned long long)n_done);
-        atomicAdd(&a.counters[1], (unsigned long long)al.cnt.lookups);
-        atomicAdd(&a.counters[2], (unsigned long long)al.cnt.slots);
-        atomicAdd(&a.counters[3], (unsigned long long)al.cnt.hits);
-        atomicAdd(&a.counters[4], (unsigned long long)al.cnt.overflow_lists);
-        atomicAdd(&a.counters[5], (unsigned long long)al.cnt.lv);
-        atomicAdd(&a.counters[6], (unsigned long long)al.cnt.ag);
-        atomicAdd(&a.counters[7], (unsigned long long)al.cnt.lv_ref_bytes);
-        atomicAdd(&a.counters[8], (unsigned long long)al.cnt.cyc_lookup);
-        atomicAdd(&a.counters[9], (unsigned long long)al.cnt.cyc_hits);
-        atomicAdd(&a.counters[10], (unsigned long long)al.cnt.cyc_lv);
-        atomicAdd(&a.counters[11], (unsigned long long)al.cnt.cyc_ag);
-        atomicAdd(&a.counters[12], (unsigned long long)al.cnt.cyc_total);
+        atomicAdd(&a.counters[1], (unsigned long long)al.cnt().lookups);
+        atomicAdd(&a.counters[2], (unsigned long long)al.cnt().slots);
+        atomicAdd(&a.counters[3], (unsigned long long)al.cnt().hits);
+        atomicAdd(&a.counters[4], (unsigned long long)al.cnt().overflow_lists);
+        atomicAdd(&a.counters[5], (unsigned long long)al.cnt().lv);
+        atomicAdd(&a.counters[6], (unsigned long long)al.cnt().ag);
+        atomicAdd(&a.counters[7], (unsigned long long)al.cnt().lv_ref_bytes);
+        atomicAdd(&a.counters[8], (unsigned long long)al.cnt().cyc_lookup);
+        atomicAdd(&a.counters[9], (unsigned long long)al.cnt().cyc_hits);
+        atomicAdd(&a.counters[10], (unsigned long long)al.cnt().cyc_lv);
+        atomicAdd(&a.counters[11], (unsigned long long)al.cnt().cyc_ag);
+        atomicAdd(&a.counters[12], (unsigned long long)al.cnt().cyc_total);
     }
 }
 
