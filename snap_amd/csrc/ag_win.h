@@ -944,6 +944,307 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     return res;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The window form for WIDE bands (round 6): 32 < segLen <= 64, i.e. limits 13 .. 31 -- every banded call of the `-d 20` configuration
+// (BASELINE configs[4]: limit 22, segLen 48) and the gapless-clipped Phase-4 calls of the paired-end path (limit 30, segLen 64).  The band's two
+// segments no longer fit one wavefront side by side, so each lives in a register set of its own: lane L < segLen of set A is position
+// wbase + L (segment jbase), of set B position wbase + segLen + L (segment jbase + 1) -- the same (stripe, vector) in both, so every per-lane
+// constant of the call is shared.  A row is two segment passes, in the reference's order (segment j's first pass and lazy F, then X -- the F
+// that left its last stripe -- into stripe 0 of segment j + 1, AffineGapVectorized.h:461-571); a slide moves B into A.  Until this form these
+// calls went through ag_compute_reg<AGC, true>, whose row walks AGC chunks of 64 positions through LDS-staged lazy-F rounds (~1 600 wave
+// instructions per row; on the `c5` leg 86 % of the paired kernel's wave cycles, profiles/r06b).  The statement of the arithmetic is
+// ag_banded_win_v1's (no closed forms, any gap-open penalty); results: bit for bit those of ag_compute_reg / ag.h.
+template <bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
+static __device__ __forceinline__ AGResult ag_banded_win2(
+    int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
+    const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
+    int16_t *lds_rows, uint8_t *bt_scratch, const DevTables *tab,
+    int num_vec, int seg_len, int num_seg, uint32_t bt_bytes, uint32_t bt_tag = 0)
+{
+    const int lane = lane_id();
+    AGResult res; res.ag_score = -1; res.text_offset = -1; res.pattern_offset = -1; res.n_edits = -1;
+    res.match_probability = 1.0; res.stale_reads = 0;
+    const int match = prm.match_reward, sub = -prm.sub_penalty;
+    const int gap_open = prm.gap_open + prm.gap_extend, gap_ext = prm.gap_extend;
+    const int tot = num_seg * seg_len;
+    LDS_AS int16_t  *fr16 = (LDS_AS int16_t *)(lds_rows + 8);               // [tot]   first_row(p)        (the tables of ag_banded_win)
+    LDS_AS uint8_t  *pcode = (LDS_AS uint8_t *)(fr16 + ((tot + 7) & ~7));  // [tot]   base_value(P(p)), 5 beyond the pattern
+    LDS_AS uint8_t  *tcode = pcode + ((tot + 15) & ~15);                   // [text_len] base_value(T(i))
+
+    int end_bonus;
+    if (!is_rc) end_bonus = dir == -1 ? prm.five_bonus : prm.three_bonus;
+    else        end_bonus = dir == -1 ? prm.three_bonus : prm.five_bonus;
+
+    // lane constants: stripe l and vector k of the lane's cell inside ITS segment (the same in both register sets)
+    const bool seg_lane = lane < seg_len;
+    const int l = lane / num_vec, k = lane - l * num_vec;
+    const BtSink sink = bt_sink(bt_scratch, bt_bytes);
+    const int nv_tot8 = num_vec * num_seg * 8;                   // EXACT: bytes per row of the reference's array
+    const int flat_lane = k * 8 + l;                             // EXACT: byte of this lane's cell inside its segment
+
+    auto first_row = [&](int p) -> int {                         // the reference's first-row H at position p, incl. the stale scoreFirstRow[] inheritance
+        if (p >= tot) return 0;
+        int pi = p;
+        if (p >= pattern_len) {
+            int j2 = p / seg_len, r2 = p - j2 * seg_len, l2 = r2 / num_vec, k2 = r2 - l2 * num_vec;
+            pi = -1;
+            for (int v = j2 * num_vec + k2 - 1; v >= 0; v--) {
+                int q = (v / num_vec) * seg_len + l2 * num_vec + (v % num_vec);
+                if (q < pattern_len) { pi = q; break; }
+            }
+            if (pi < 0) return 0;
+        }
+        int x = score_init - gap_open - pi * gap_ext;
+        return x > 0 ? x : 0;
+    };
+    for (int p0 = 0; p0 < tot; p0 += WAVE) {
+        const int p = p0 + lane;
+        if (p < tot) {
+            fr16[p] = (int16_t)first_row(p);
+            pcode[p] = (uint8_t)(p < pattern_len ? base_value(P(p)) : 5u);
+        }
+    }
+    for (int i0 = 0; i0 < text_len; i0 += WAVE) {
+        const int i = i0 + lane;
+        if (i < text_len) tcode[i] = (uint8_t)base_value(T(i));
+    }
+    WAVE_SYNC();
+
+    // a segment's registers as the reference's never-touched cells hold them on row i: Hptr is H (first-row values) on even rows, Hminus1 (zero) on odd ones
+    auto fresh = [&](int seg_start, int row, int &Hp, int &Hm, int &E, int &pbv) {
+        const int p = seg_start + lane;
+        const bool v = seg_lane && p < tot;
+        const int fr = v ? (int)fr16[p] : 0;
+        Hp = (row & 1) ? 0 : fr; Hm = (row & 1) ? fr : 0; E = 0;
+        pbv = v ? (int)pcode[p] : 5;
+    };
+    int wbase = 0, jbase = 0;
+    int HpA, HmA, EA, pbvA, HpB, HmB, EB, pbvB;
+    fresh(0, 0, HpA, HmA, EA, pbvA);
+    fresh(seg_len, 0, HpB, HmB, EB, pbvB);
+    int left_h = 0;
+    int gl_p = 0, gl_m = 0;          // H / H-1 of the global-alignment cell (position pattern_len - 1) once it has left the window
+    int best_global = -1, best_global_text = -1, best_local = -1, best_local_text = -1, best_local_pat = -1;
+
+    for (int i = 0; i < text_len; i++) {
+        const int tb = (int)first_u32(tcode[i]);
+        const int band_beg = i - w > 0 ? i - w : 0;
+        const int band_end = i + w < pattern_len - 1 ? i + w : pattern_len - 1;
+        if ((jbase + 1) * seg_len <= band_beg) {                // slide: segment jbase leaves, B becomes A, the next segment enters fresh
+            left_h = __builtin_amdgcn_readlane(HpA, seg_len - 1);
+            if (pattern_len - 1 >= wbase && pattern_len - 1 < wbase + seg_len) {
+                gl_p = __builtin_amdgcn_readlane(HpA, pattern_len - 1 - wbase);
+                gl_m = __builtin_amdgcn_readlane(HmA, pattern_len - 1 - wbase);
+            }
+            HpA = HpB; HmA = HmB; EA = EB; pbvA = pbvB;
+            wbase += seg_len; jbase++;
+            fresh(wbase + seg_len, i, HpB, HmB, EB, pbvB);
+        }
+        int h_init0 = score_init;
+        if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
+        const bool two = (jbase + 1) * seg_len <= band_end;
+        int nk0 = band_end - wbase + 1; if (nk0 > num_vec) nk0 = num_vec;
+        int nk1 = 0;
+        if (two) { nk1 = band_end - (wbase + seg_len) + 1; if (nk1 > num_vec) nk1 = num_vec; }
+
+        // One segment of the row (AffineGapVectorized.h:483-569): first pass, then up to seven lazy-F rounds.  X_in: the F that enters stripe 0
+        // (0 for the row's first segment); X: the F that has left the segment's last stripe so far (kept for the first segment only).
+        int X = 0;
+        auto seg_pass = [&](int seg_start, int nk, int lane0_in, int X_in, bool keep_X, int &Hp, int &Hm, int &E, int pbv, int &btr, bool &ins_out) {
+            const int p = seg_start + lane;
+            const bool inseg = seg_lane && p < tot && k < nk;
+            const int h_in = ag_shr1(lane0_in, Hp);
+            const int prof = pbv == 5 ? -32768 : ((tb > 3 || pbv > 3) ? -1 : (tb == pbv ? match : sub));
+            const int m = h_in > 0 ? ag_sat16(h_in + prof) : 0;
+            const int e = E;
+            const int bt_e0 = e > m ? 1 : 0;
+            const int hpp = m > e ? m : e;
+            const int e2 = e - gap_ext;
+            int tmp = m - gap_open; if (tmp < 0) tmp = 0;
+            const int bt_e = bt_e0 | (e2 > tmp ? 4 : 0);
+            // first-pass F along the (at most 8) vectors of a stripe: F(k) = max_{j<k} (tmp_j - (k-1-j)*ext), a prefix max of tmp_j + p_j*ext over
+            // the lanes to the left that belong to the same stripe -- three shift-and-max steps
+            int g = inseg ? tmp + p * gap_ext : AG_NEG;
+            { const int a = ag_shr1(AG_NEG, g); if (k >= 1) g = a > g ? a : g; }
+            { const int b = ag_shr1(AG_NEG, ag_shr1(AG_NEG, g)); if (k >= 2) g = b > g ? b : g; }
+            if (num_vec > 4) { const int c = ag_shr1(AG_NEG, ag_shr1(AG_NEG, ag_shr1(AG_NEG, ag_shr1(AG_NEG, g)))); if (k >= 4) g = c > g ? c : g; }
+            const int pm = ag_shr1(AG_NEG, g);
+            int fk = -k * gap_ext;
+            if (k >= 1) { const int a = pm - (p - 1) * gap_ext; fk = a > fk ? a : fk; }
+            { const int fx = X_in - k * gap_ext; fk = (l == 0 && fx > fk) ? fx : fk; }          // (X_in >= 0: for X_in == 0 this is fk itself)
+            int bt = bt_e | (fk > hpp ? 2 : 0);
+            const int hp = fk > hpp ? fk : hpp;
+            const int f2p = fk - gap_ext;
+            bt |= f2p > tmp ? 32 : 0;
+            const int endv = inseg ? (f2p > tmp ? f2p : tmp) : 0;
+            Hm = inseg ? hp : Hm;
+            E = inseg ? (e2 > tmp ? e2 : tmp) : E;
+            btr = inseg ? bt : 0;
+            ins_out = inseg;
+            const unsigned long long ins_mask = BALLOT(inseg);
+            const uint32_t full = (1u << nk) - 1u;
+            const int decay_step = nk * gap_ext;
+            int decay = 0;
+            int src7 = nk - 1 + 7 * num_vec;                        // stripe 7 - r's last vector
+            int src_addr = (nk - 1 + (l - 1) * num_vec) * 4;        // ds_bpermute byte address: the last vector of the stripe r + 1 to the left
+            int ls = l - 1;
+            for (int r = 0; r < 7; r++, decay += decay_step, src7 -= num_vec, src_addr -= num_vec * 4, ls--) {
+                if (keep_X) {
+                    const int f7 = __builtin_amdgcn_readlane(endv, src7) - decay;
+                    if (f7 > X) X = f7;
+                }
+                int f_in = __builtin_amdgcn_ds_bpermute(src_addr, endv) - decay;
+                if (ls < 0 || f_in < 0) f_in = 0;
+                int f = f_in - k * gap_ext; if (f < 0) f = 0;
+                const int hn = Hm > f ? Hm : f;
+                const int t2 = hn > gap_open ? hn - gap_open : 0;
+                const int f2 = f > gap_ext ? f - gap_ext : 0;
+                const bool cont = inseg && (f2 > t2);
+                unsigned long long cm = __builtin_amdgcn_ballot_w64(f2 > t2) & ins_mask;
+                cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);       // "some SSE lane of vector kk goes on" in bit kk
+                const uint32_t low = (uint32_t)cm & full;
+                const int jstar = low == full ? 64 : (int)__builtin_ctz(~low);
+                const bool complete = jstar >= nk;
+                const int jlim = complete ? nk - 1 : jstar;
+                const bool upd = inseg && k <= jlim;
+                btr |= (upd && f > Hm) ? 2 : 0;
+                Hm = (upd && f > Hm) ? f : Hm;
+                btr |= (upd && cont) ? 32 : 0;
+                if (!complete) break;
+            }
+        };
+        int lane0_in;                                              // H(i-1, p-1) of the window's first cell: the reference's segment-start rule (:461-476)
+        if (wbase == 0) lane0_in = h_init0;
+        else lane0_in = (band_beg > wbase) ? 0 : left_h;
+        int btrA = 0, btrB = 0; bool insA = false, insB = false;
+        seg_pass(wbase, nk0, lane0_in, 0, true, HpA, HmA, EA, pbvA, btrA, insA);
+        if (two) {
+            const int lastA = __builtin_amdgcn_readlane(HpA, seg_len - 1);     // H(i-1) of the cell before segment B's first
+            const int X_in = X;
+            seg_pass(wbase + seg_len, nk1, lastA, X_in, false, HpB, HmB, EB, pbvB, btrB, insB);
+        }
+
+        if constexpr (EXACT) {
+            if (insA) bt_store(sink, (uint32_t)(i * nv_tot8 + jbase * seg_len), (uint32_t)flat_lane, (uint32_t)btrA | bt_tag);
+            if (insB) bt_store(sink, (uint32_t)(i * nv_tot8 + (jbase + 1) * seg_len), (uint32_t)flat_lane, (uint32_t)btrB | bt_tag);
+        } else {
+            bt_store(sink, (uint32_t)i * 128u, (uint32_t)lane, (uint32_t)btrA);
+            if (two) bt_store(sink, (uint32_t)i * 128u + 64u, (uint32_t)lane, (uint32_t)btrB);
+        }
+        const int mxA = insA ? HmA : 0, mxB = insB ? HmB : 0;
+        const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxA > mxB ? mxA : mxB), 63);
+        if (band_end == pattern_len - 1) {
+            const int gp = pattern_len - 1 - wbase;
+            int gscore;
+            if (gp < 0) gscore = gl_m;
+            else if (gp < seg_len) gscore = __builtin_amdgcn_readlane(HmA, gp);
+            else gscore = __builtin_amdgcn_readlane(HmB, gp - seg_len);
+            if (gscore >= best_global) { best_global = gscore; best_global_text = i; }
+        }
+        if (max_row == 0) break;
+        if (max_row > best_local) {
+            const unsigned long long mkB = BALLOT(insB && HmB == max_row), mkA = BALLOT(insA && HmA == max_row);
+            best_local_pat = mkB ? wbase + seg_len + 63 - __clzll((long long)mkB) : (mkA ? wbase + 63 - __clzll((long long)mkA) : -1);
+            best_local = max_row; best_local_text = i;
+        }
+        { int t = HmA; HmA = HpA; HpA = t; }
+        { int t = HmB; HmB = HpB; HpB = t; }
+        { int t = gl_m; gl_m = gl_p; gl_p = t; }
+    }
+    WAVE_SYNC();
+
+    // ---------------- local vs global (:643-730)
+    int score, pat_off, text_off;
+    if (best_local != best_global && best_local >= best_global + end_bonus) {
+        pat_off = best_local_pat; text_off = best_local_text; score = best_local;
+        if (use_clipping) {
+            int pa = pat_off - 1, ta = text_off, cnt = 0;
+            while (pa + 1 != pattern_len && P(pa + 1) == T(ta + 1)) { cnt++; pa++; ta++; }
+            if (cnt >= 3) { pat_off = pa; text_off = ta; }
+            else {
+                pa = pat_off + 1; ta = text_off; cnt = 0;
+                while (pa < pattern_len && P(pa) == T(ta)) { cnt++; pa++; ta++; }
+                if (cnt >= 3) { pat_off = pa - 1; text_off = ta - 1; }
+            }
+            if (use_clipping != 2 && pat_off == best_local_pat && text_off == best_local_text) {   // 2 = useAltLiftover: no quality-aware step (:1212)
+                pa = pat_off;
+                while (pa != pattern_len - 1 && Q(pa) >= 65 && Q(pa + 1) >= 65) pa++;
+                if (pa == pattern_len - 1) pat_off = pa;
+                else if (pa >= pat_off + 2) {
+                    int tmp_off = pa + 1, cnt_hq = 0, rem = pattern_len - tmp_off;
+                    while (tmp_off != pattern_len - 1) { if (Q(tmp_off) >= 65) cnt_hq++; tmp_off++; }
+                    if (((float)cnt_hq) / (float)rem < 0.1f) pat_off = pa;
+                }
+            }
+        }
+    } else {
+        pat_off = pattern_len - 1; text_off = best_global_text; score = best_global;
+    }
+    res.text_offset = text_off; res.pattern_offset = pat_off;
+
+    if (score > score_init) {                                          // traceback, :732-815
+        double prob = 1.0;
+        int row = text_off, col = pat_off;
+        int action = 0, prev_action = 0, action_count = 1, n_matches = 0, n_mismatches = 0, n_gaps = 0;
+        while (row >= 0 && col >= 0) {
+            const int rt = row - lane, ct = col - lane;
+            const bool ok = rt >= 0 && ct >= 0;
+            bool computed = false;
+            int wb = 0;
+            if (ok) {
+                int bb = rt - w > 0 ? rt - w : 0, be = rt + w < pattern_len - 1 ? rt + w : pattern_len - 1;
+                int cj = ct / seg_len, ck = (ct - cj * seg_len) % num_vec;
+                computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
+                wb = (bb / seg_len) * seg_len;
+            }
+            int cell;
+            if constexpr (EXACT) {
+                int vi = 0, li = 0;
+                if (ok) { const int cj = ct / seg_len, cr = ct - cj * seg_len; vi = cj * num_vec + cr % num_vec; li = cr / num_vec; }
+                const uint32_t at = (uint32_t)rt * (uint32_t)nv_tot8 + (uint32_t)(vi * 8 + li);
+                cell = (ok && at < bt_bytes) ? bt_cell((int)bt_scratch[at], bt_tag) : 0;
+            } else {
+                const int d = ct - wb;                                 // 0 .. 2 * seg_len - 1: segment A's bytes at 0, segment B's at 64
+                cell = computed ? (int)bt_scratch[(size_t)rt * 128 + (d < seg_len ? d : 64 + d - seg_len)] : 0;
+            }
+            int pbyte = ok ? (int)P(ct) : 0, tbyte = ok ? (int)T(rt) : 0, qbyte = ok ? (int)Q(ct) : 0;
+            int info = cell | ((ok && !computed) ? 0x100 : 0) | ((pbyte != tbyte) ? 0x200 : 0) | (qbyte << 16);
+            for (int t = 0; t < WAVE && row >= 0 && col >= 0; t++) {
+                const int inf = __builtin_amdgcn_readlane(info, t);
+                if (inf & 0x100) res.stale_reads++;
+                action = ((inf & 0xff) >> (action << 1)) & 3;
+                bool left_diagonal = false;
+                if (action == 0) {
+                    if (inf & 0x200) { prob *= tab->phred[(inf >> 16) & 0xff]; n_mismatches++; }
+                    else n_matches++;
+                    row--; col--;
+                } else if (action == 1) {
+                    row--; left_diagonal = true;
+                } else {
+                    col--; action = 2; left_diagonal = true;
+                }
+                if (prev_action != 0) {
+                    if (prev_action == action) action_count++;
+                    else { n_gaps += action_count; prob *= tab->indel[action_count]; action_count = 1; }
+                }
+                prev_action = action;
+                if (left_diagonal) break;
+            }
+        }
+        if (row >= 0) { action_count = row + 1; n_gaps += action_count; prob *= tab->indel[action_count]; }
+        if (col >= 0) { action_count = col + 1; n_gaps += action_count; prob *= tab->indel[action_count]; }
+        res.n_edits = n_mismatches + n_gaps;
+        prob *= tab->perfect[n_matches];
+        text_off += 1; pat_off += 1;
+        res.text_offset = pattern_len - text_off;
+        res.pattern_offset = pattern_len - pat_off;
+        prob *= tab->indel[res.pattern_offset];
+        res.match_probability = prob;
+        res.ag_score = score;
+    }
+    return res;
+}
+
 // AGC > 0: register formulation with AGC chunks of 64 positions (the host guarantees it fits);
 // AGC == 0: the LDS formulation of ag.h (any pattern length up to RL).
 template <int AGC, bool EXACT, typename PSeq, typename TSeq, typename QSeq>
@@ -970,6 +1271,11 @@ static __device__ __forceinline__ AGResult ag_dispatch_inl(
         if (banded && 2 * seg_len <= 64)        // the band's two segments fit one wavefront: sliding-window form
             return ag_banded_win<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                         lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
+#if !defined(SNAPGPU_NO_AG_WIN2)
+        if (banded && seg_len <= 64 && (size_t)text_len * 128u <= ag_scratch_bytes(RL))        // wide bands (limits 13 .. 31): one segment per register set
+            return ag_banded_win2<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                         lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
+#endif
         if (banded)
             return ag_compute_reg<AGC, true, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                                     lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);

@@ -79,17 +79,17 @@ def golden_contigs(gi):
     return [(c.name, G[begins[k]:begins[k + 1] - pad]) for k, c in enumerate(gi.contigs)], begins[:-1]
 
 
-def ag_call_sequence(seed, n, max_len=150):
+def ag_call_sequence(seed, n, max_len=150, w_range=(1, 14), min_len=30):
     """n affine-gap problems meant to be CALLS IN ORDER ON ONE OBJECT (snapgpu_affine_gap_sequence): most carry an indel about as long as
     the band is wide, which is what sends a banded traceback out of its band -- where it reads what earlier calls left in the array.
     Returns (texts, patterns, quals, w, score_init, is_rc, banded)."""
     rng = np.random.default_rng(seed)
     texts, pats, quals, ws, sis, rcs, bands = [], [], [], [], [], [], []
     for _ in range(n):
-        L = int(rng.integers(30, max_len))
+        L = int(rng.integers(min_len, max_len))
         t = bytes(rng.choice(list(b"ACGT"), size=L + 80).astype(np.uint8))
         p = bytearray(t[:L])
-        w = int(rng.integers(1, 14))
+        w = int(rng.integers(*w_range))
         if rng.random() < 0.8:
             j = int(rng.integers(2, max(3, L - 2))); d = max(1, w + int(rng.integers(-2, 3)))
             if rng.random() < 0.5: del p[j:j + d]

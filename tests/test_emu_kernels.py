@@ -295,6 +295,19 @@ def test_emu_affine_gap_call_sequences(emu, emu_aligner):
     assert gp.check_affine_gap_call_sequences(emu_aligner, z, step=4) > 5
 
 
+def test_emu_affine_gap_wide_bands(emu, golden_index):
+    """ag_banded_win2 (w 13 .. 31) on the emulated device: 260 fuzzed problems against the restatement in the three batch instantiations,
+    and the first half of the wide-band call sequence of the reference (exact form)."""
+    import tests.test_gpu_parity as gp
+    from snap_amd.aligner import BaseAligner
+    a = BaseAligner(golden_index, abi.default_params(max_k=20, max_read_len=400))
+    try:
+        assert gp.check_affine_gap_wide_bands(a, n=260) > 300
+    finally:
+        a.close()
+    gp.test_affine_gap_wide_band_call_sequences_vs_reference_fixture(golden_index, step=2)
+
+
 def test_emu_affine_gap_call_sequences_without_an_image(emu, golden_index, monkeypatch):
     """ag_resolve.h on the emulated device: the first 400 calls of the short-pattern sequence with no image kept (SNAPGPU_AG_SEQUENCE_RESOLVE=1)."""
     import tests.test_gpu_parity as gp

@@ -173,6 +173,75 @@ def test_affine_gap_call_sequences_vs_reference_fixture(golden_index):
         a.close()
 
 
+def check_affine_gap_wide_bands(aligner, n=1200, seed=1001, max_len=380):
+    """Seeded fuzz over WIDE bands (w 13 .. 31: segments of 40 .. 64 positions -- ag_win.h: ag_banded_win2, every banded call of `-d 20` and the
+    limit-30 calls of the paired path), patterns up to 380 bases (the 192-, 256- and 384-position instantiations), three clipping modes, both
+    directions, against the C restatement (pinned to the reference by tests/test_oracle.py)."""
+    rng = np.random.default_rng(seed)
+    texts, pats, quals, ws, sis, rcs, bands, clips = [], [], [], [], [], [], [], []
+    for _ in range(n):
+        w = int(rng.integers(13, 32))
+        L = int(rng.integers(3 * (2 * w + 1), max(3 * (2 * w + 1) + 1, max_len)))
+        t = bytes(rng.choice(list(b"ACGT"), size=L + 80).astype(np.uint8))
+        p = bytearray(t[:L])
+        for _e in range(int(rng.integers(0, 8))):
+            j = int(rng.integers(0, len(p)))
+            r = rng.random()
+            if r < 0.5: p[j] = b"ACGT"[rng.integers(0, 4)]
+            elif r < 0.75 and len(p) > 1: del p[j:j + int(rng.integers(1, max(2, w // 2)))]
+            else: p[j:j] = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, max(2, w // 2)))).astype(np.uint8))
+        if rng.random() < 0.3:
+            k = int(rng.integers(3, max(4, L // 3)))
+            p[len(p) - k:] = bytes(rng.choice(list(b"ACGT"), size=k).astype(np.uint8))
+        p = bytes(p[:L])
+        if len(p) < 3 * (2 * w + 1): p = p + t[len(p):3 * (2 * w + 1)]
+        texts.append(t[:len(p) + w]); pats.append(p)
+        quals.append(bytes(rng.integers(35, 74, size=len(p), dtype=np.uint8)))
+        ws.append(w); sis.append(int(rng.integers(20, 400))); rcs.append(int(rng.integers(0, 2)))
+        bands.append(1); clips.append(int(rng.integers(0, 3)))
+    n_cmp = 0
+    order = np.argsort([len(p) for p in pats], kind="stable")
+    for lo, hi in ((0, 193), (193, 257), (257, 1 << 20)):                 # one call per instantiation of the batch kernel
+        sel = [int(i) for i in order if lo <= -(-len(pats[i]) // (-(-(2 * ws[i] + 1) // 8) * 8)) * (-(-(2 * ws[i] + 1) // 8) * 8) < hi]
+        if not sel: continue
+        for d in (1, -1):
+            tt = [texts[i] if d == 1 else texts[i][::-1] for i in sel]
+            got = aligner.computeScoreAffine(d, tt, [pats[i] for i in sel], [quals[i] for i in sel], [ws[i] for i in sel], [sis[i] for i in sel],
+                                             [rcs[i] for i in sel], [bands[i] for i in sel], [clips[i] for i in sel])
+            for x, i in enumerate(sel):
+                o = util.oracle_ag(d, 1, tt[x], pats[i], quals[i], ws[i], sis[i], rcs[i], clips[i])
+                if o["stale_reads"]:
+                    continue
+                n_cmp += 1
+                assert got["ag_score"][x] == o["ag_score"], (d, i, len(pats[i]), ws[i])
+                if o["ag_score"] != -1:
+                    for key in ("text_offset", "pattern_offset", "n_edits", "match_probability"):
+                        assert got[key][x] == o[key], (d, i, key, clips[i], len(pats[i]), ws[i])
+    return n_cmp
+
+
+def test_affine_gap_wide_bands_vs_restatement(golden_index):
+    from snap_amd.aligner import BaseAligner
+    a = BaseAligner(golden_index, abi.default_params(max_k=20, max_read_len=400))
+    try:
+        assert check_affine_gap_wide_bands(a) > 1500
+    finally:
+        a.close()
+
+
+def test_affine_gap_wide_band_call_sequences_vs_reference_fixture(golden_index, step=1):
+    """tests/golden/ag_sequence_wide.npz (scripts/make_golden_ag_sequence_wide.py): calls in order on one reference object with w 13 .. 31 --
+    the exact (image-keeping) instantiation of ag_banded_win2."""
+    from snap_amd.aligner import BaseAligner
+    import os
+    z = np.load(os.path.join(util.GOLDEN, "ag_sequence_wide.npz"), allow_pickle=True)
+    a = BaseAligner(golden_index, abi.default_params(max_k=20, max_read_len=200))
+    try:
+        assert check_affine_gap_call_sequences(a, z, tags=("wide",), step=step) >= (4 if step == 1 else 0)
+    finally:
+        a.close()
+
+
 def test_affine_gap_call_sequences_without_an_image(golden_index, monkeypatch, step=1, tags=("short", "long")):
     """ag_resolve.h: the same sequences with NO image kept from call to call -- every call in the fast form, a call that stepped outside its
     band answered from the list of the calls before it (the byte the latest earlier call wrote at each cell it reads): the reference's
