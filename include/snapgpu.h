@@ -499,9 +499,6 @@ int  snapgpu_affine_gap(snapgpu_ctx *ctx, int dir, uint32_t n,
  * every call wrote -- so a banded traceback step outside the band of call i reads what calls 0 .. i-1 left there (:740-788), as it does
  * in the reference.  One wavefront, the exact form of the kernels (the form the replay passes run).  stale_steps[i] (may be NULL) =
  * how many such steps call i made.  Arguments otherwise as snapgpu_affine_gap.
- * With SNAPGPU_AG_SEQUENCE_RESOLVE=1 in the environment no image is kept: every call runs in the fast form and a call that stepped
- * outside its band is answered by ag_resolve.h from the list of the calls before it (stale_steps[i] >> 16 = cells it had to find;
- * ag_score -2 = not resolved within the step limit) -- same answers.
  */
 int  snapgpu_affine_gap_sequence(snapgpu_ctx *ctx, int dir, uint32_t n,
                                  const char *texts, uint64_t texts_bytes, const uint32_t *text_off, const int32_t *text_len,

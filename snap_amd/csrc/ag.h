@@ -68,17 +68,12 @@ static __device__ __forceinline__ int wave_max_i32(int v) {
 // object's backtraceAction array (AffineGapVectorized.h:1374) -- same flat addressing (row * numVec * numSeg + vector, SSE element), zeroed
 // when the read starts and kept across the calls of the read -- and the traceback reads whatever that array holds, so a step outside the
 // band of this call sees what an EARLIER call for the same read left there, exactly as a newly constructed reference aligner does.
-// RES (with EXACT; ag_resolve.h): cells the caller does not know yet hold AG_CELL_UNKNOWN; a traceback step that reads one outside the
-// band stops the call and reports the cell's address in *pending_at (AG_NO_CELL: the traceback finished).
-#define AG_CELL_UNKNOWN 0xFF
-#define AG_NO_CELL 0xFFFFFFFFu
-template <bool EXACT = false, bool RES = false, typename PSeq, typename TSeq, typename QSeq>
+template <bool EXACT = false, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __forceinline__ AGResult ag_compute(
     bool banded, int dir, const AGParams &prm, const PSeq &P, const QSeq &Q, int pattern_len,
     const TSeq &T, int text_len, int w, int score_init, bool is_rc, int use_clipping,
-    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab, uint32_t *pending_at = nullptr, uint32_t bt_tag = 0)
+    int16_t *lds_rows, uint8_t *bt_scratch, uint32_t RL, const DevTables *tab, uint32_t bt_tag = 0)
 {
-    if constexpr (RES) *pending_at = AG_NO_CELL;
     const int lane = lane_id();
     const int sl = lane & 7;            // SSE lane emulated by this wavefront lane
     const int kk = lane >> 3;           // vector within the current step of 8 vectors
@@ -320,10 +315,7 @@ static __device__ __forceinline__ AGResult ag_compute(
                 computed = cj >= bb / seg_len && cj <= be / seg_len && cj * seg_len + ck <= be;
             }
             int bits = (EXACT || computed) ? (int)first_u32(bt_scratch[(size_t)row * row_cells + vi * 8 + li]) : 0;
-            if constexpr (EXACT && !RES) bits = bt_cell(bits, bt_tag);             // (a cell of an earlier read is a zeroed cell: dev_common.h)
-            if constexpr (RES) {
-                if (!computed && bits == AG_CELL_UNKNOWN) { *pending_at = (uint32_t)((size_t)row * row_cells + vi * 8 + li); res.ag_score = -1; return res; }
-            }
+            if constexpr (EXACT) bits = bt_cell(bits, bt_tag);             // (a cell of an earlier read is a zeroed cell: dev_common.h)
             if (!computed) res.stale_reads++;
             action = (bits >> (action << 1)) & 3;
             if (action == 0) {

@@ -523,6 +523,11 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int v_else = pbv == 5 ? -32768 : (pbv == 4 ? -1 : sub);      // profile entry of this lane's pattern base against a text base that differs from it
     int v_else_n = pbv == 5 ? -32768 : -1;                       // ... against an 'N' of the text
     const int c_prev = (l == 0 ? lane : lane - num_vec) * 4;     // lazy F, rounds 1 .. 6: the same vector one stripe to the left (stripe 0: itself)
+    // lazy F, "does vector k have an SSE lane whose F goes on": lane k < num_vec holds the (at most 8) lanes of vector k of a segment -- k + l' * num_vec --
+    // as a mask, so that the verdict of a round is ONE vector AND + compare of the round's ballot against it (lanes >= num_vec: 0) instead of three
+    // shift / or pairs on the scalar unit, which is what bounds this kernel (round 6: ~6 of a round's ~20 scalar instructions)
+    typename std::conditional<FULL, unsigned long long, uint32_t>::type kgrp = 0;
+    if (lane < num_vec) for (int l2 = 0; l2 < 8; l2++) kgrp |= (decltype(kgrp))1 << (lane + l2 * num_vec);
     int c_ls = 0, c_g = 0;                                        // (follow nk like stepv: the closed form of the second segment's lazy F)
     unsigned long long KM0 = 0ull, KM1 = 0ull, KE1 = 0ull, KL1 = 0ull;   // masks that follow (nk0, nk1) like the per-lane values below: the band's lanes of either segment, the second segment's stripe ends / stripes 1 .. 7
     int nk_addr = 0, stepv = 0, nk_key = -1;                     // per-lane values that follow (nk0, nk1): the gather address of round 0, nk * ext of the lane's segment
@@ -710,8 +715,12 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                     if constexpr (r < 6) u_next = __builtin_amdgcn_ds_bpermute(c_prev, u_cur);
                     const unsigned long long go = BALLOT(u_cur > Tr) & ins_mask;     // (an offer <= 0 is never above Tr >= 0)
                     typename std::conditional<FULL, unsigned long long, uint32_t>::type cm = s == 0 ? go : (go >> seg_len);      // (a banded segment's lanes fit 32 bits)
+#if defined(SNAPGPU_AG_FOLD_SCALAR)                                                    // (measurement builds: the fold of rounds 4 - 5)
                     cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
                     const uint32_t low = (uint32_t)cm & full;
+#else
+                    const uint32_t low = (uint32_t)BALLOT((cm & kgrp) != 0);         // bit k: vector k goes on (k < nk: ins_mask holds nothing else; lanes >= num_vec: kgrp == 0)
+#endif
                     if (__builtin_expect(low != full, 0)) {                          // the round stops at vector jlim: the walk ends
                         const int jlim = (int)__builtin_ctz(~low);
                         const int fm = lane_in(ins_mask & kmask(jlim + 1)) ? u_cur : 0;
@@ -981,6 +990,8 @@ static __device__ __forceinline__ AGResult ag_banded_win2(
     const BtSink sink = bt_sink(bt_scratch, bt_bytes);
     const int nv_tot8 = num_vec * num_seg * 8;                   // EXACT: bytes per row of the reference's array
     const int flat_lane = k * 8 + l;                             // EXACT: byte of this lane's cell inside its segment
+    unsigned long long kgrp = 0ull;                              // lane k < num_vec: the lanes of vector k in the segment's eight stripes
+    if (lane < num_vec) for (int l2 = 0; l2 < 8; l2++) kgrp |= 1ull << (lane + l2 * num_vec);
 
     auto first_row = [&](int p) -> int {                         // the reference's first-row H at position p, incl. the stale scoreFirstRow[] inheritance
         if (p >= tot) return 0;
@@ -1101,8 +1112,7 @@ static __device__ __forceinline__ AGResult ag_banded_win2(
                 const int f2 = f > gap_ext ? f - gap_ext : 0;
                 const bool cont = inseg && (f2 > t2);
                 unsigned long long cm = __builtin_amdgcn_ballot_w64(f2 > t2) & ins_mask;
-                cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);       // "some SSE lane of vector kk goes on" in bit kk
-                const uint32_t low = (uint32_t)cm & full;
+                const uint32_t low = (uint32_t)BALLOT((cm & kgrp) != 0ull);                          // "some SSE lane of vector kk goes on" in bit kk (see ag_banded_win: kgrp)
                 const int jstar = low == full ? 64 : (int)__builtin_ctz(~low);
                 const bool complete = jstar >= nk;
                 const int jlim = complete ? nk - 1 : jstar;
@@ -1265,6 +1275,19 @@ static __device__ __forceinline__ AGResult ag_dispatch_inl(
             (EXACT && (size_t)text_len * (size_t)(num_seg * seg_len) > ag_scratch_bytes(RL))) {
             __builtin_trap();                                             // host sizing bug: fail loudly
         }
+#if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
+        {   // which form takes the call (scripts/emu_stats.py, emu_paired_stats.py): calls / rows / positions per form, and the unbanded register calls by chunk count
+            extern unsigned long long g_agform_stats[64];
+            const int tot_ = num_seg * seg_len;
+            const int f = banded ? (2 * seg_len <= 64 ? 1 : (seg_len <= 64 ? 2 : 3)) : (tot_ <= 64 ? 4 : 6);
+            if (lane_id() == 0) {
+                __atomic_fetch_add(&g_agform_stats[f], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_agform_stats[8 + f], (unsigned long long)text_len, __ATOMIC_RELAXED);
+                __atomic_fetch_add(&g_agform_stats[16 + f], (unsigned long long)tot_, __ATOMIC_RELAXED);
+                if (f == 6) { __atomic_fetch_add(&g_agform_stats[24 + ((tot_ + 63) >> 6)], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_agform_stats[32 + ((tot_ + 63) >> 6)], (unsigned long long)text_len, __ATOMIC_RELAXED); }
+                __atomic_fetch_add(&g_agform_stats[40 + (ww > 15 ? 15 : ww)], 1, __ATOMIC_RELAXED);
+            }
+        }
+#endif
         if (banded && 2 * seg_len <= 64 && prm.gap_open <= 0)        // (the rewritten row loop assumes a positive gap-open penalty: see its lazy-F notes)
             return ag_banded_win_v1<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                            lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
@@ -1289,7 +1312,7 @@ static __device__ __forceinline__ AGResult ag_dispatch_inl(
                                                  lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
     } else {
         return ag_compute<EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
-                                 lds_rows, bt_scratch, RL, tab, nullptr, bt_tag);
+                                 lds_rows, bt_scratch, RL, tab, bt_tag);
     }
 }
 

@@ -32,7 +32,6 @@
 #include "ag_win.h"
 #include "se_help.h"
 #include "adjust.h"
-#include "ag_resolve.h"
 #include <stddef.h>
 #include "../../include/snapgpu.h"
 
@@ -161,16 +160,8 @@ struct SecCfg {
 // the kernels that are timed for throughput are built without (SNAPGPU_PHASE_TIMERS=1 selects the timed instantiation for a breakdown run).
 // PLANES: the plane Landau-Vishkin (planes.h; SNAPGPU_LV_PLANES=1) is compiled in.  Its own instantiations (single_planes_k.hip): carried by
 // every kernel it cost the default ones 110-120 bytes of scratch per lane (exact form 520 -> 408, fast form 712 -> 592) for an option that is off.
-// RESOLVE (its own instantiations, single_resolve_k.hip; SNAPGPU_SINGLE_RESOLVE=1): the fast form answers a call that leaves its band on the
-// spot, from the list of the object's earlier calls of the read (ag_resolve.h) -- no traceback images, nothing to replay.
-// (the RESOLVE instantiations' extra state as a base class: empty otherwise, so that the other instantiations' object is what it was)
-struct AlignerResolveState { uint8_t *rs_base; uint32_t rs_n0, rs_n1, rs_over; };   // the wave's slab [calls of object 0 | calls of object 1 | H, H-1, E rows of the LDS form | image | second image]
-struct AlignerNoResolveState {};
-template <bool RESOLVE> struct AlignerResolveBase { using type = AlignerNoResolveState; };
-template <> struct AlignerResolveBase<true> { using type = AlignerResolveState; };
-
-template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false, bool PLANES = false, bool RESOLVE = false>
-struct Aligner : AlignerResolveBase<RESOLVE>::type {
+template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false, bool PLANES = false>
+struct Aligner {
     // ---- constant for the launch
     // held by value: a reference member would make the kernel-argument struct escape through a
     // flat pointer and pin this whole object (ScoreSets, results, counters) in scratch memory
@@ -249,9 +240,7 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         : ix(ix_), tab(tab_), cfg(cfg_), tp_org(0), rd_plain(0), ag_hw0(0), ag_hw1(0), ag_epoch(0), ag_tag(0), read_len(0), popular_seeds_skipped(0),
           ag_stale(0), ag_replay(0), ag_obj_used0(0), ag_obj_used1(0), max_k(cfg_.max_k), ag_calls_unit(0),
           agc(nullptr), agc_cap(0), n_agc(0), agc_overflow(0), n_sec(0), n_sec_raw(0), sec_overflow(0),
-          ws_((LDS_AS WaveShared *)ws) {
-        if constexpr (RESOLVE) { this->rs_base = nullptr; this->rs_n0 = this->rs_n1 = 0; this->rs_over = 0; }
-    }
+          ws_((LDS_AS WaveShared *)ws) {}
 
     static __device__ __forceinline__ uint64_t clk() { if constexpr (TIMED) return wave_clock(); else return 0; }
 
@@ -289,45 +278,6 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             if (ext > image) ext = image;
             if (obj == 0) ag_hw0 = ext > ag_hw0 ? ext : ag_hw0; else ag_hw1 = ext > ag_hw1 ? ext : ag_hw1;
         }
-    }
-
-    // RESOLVE: the lists of the read's affine-gap calls (ag_resolve.h: AgCall), one per object
-    static __host__ __device__ __forceinline__ uint32_t rs_log_cap() { return 2048u; }
-    static __host__ __device__ __forceinline__ size_t rs_slab_bytes(uint32_t RL) {
-        return 2 * (size_t)rs_log_cap() * sizeof(AgCall) + (((size_t)ag_lds_bytes(RL) + 255) & ~(size_t)255) + 2 * ((ag_scratch_bytes(RL) + 255) & ~(size_t)255);
-    }
-    // after a call of object `obj` (0: affineGap, the forward half; 1: reverseAffineGap): if its traceback left the band and the object has
-    // scored something for this read before, get the exact answer now; then the call joins the object's list
-    __device__ __forceinline__ AGResult resolve_and_log(int obj, int dir, int64_t loc, int org, int plen, int lim, int tlen, int use_clip, bool banded,
-                                                        const AGParams &agp, AGResult a) {
-        AgCall *log = (AgCall *)this->rs_base + (obj == 0 ? 0u : rs_log_cap());
-        const uint32_t n = obj == 0 ? this->rs_n0 : this->rs_n1;
-        const uint32_t used = obj == 0 ? ag_obj_used0 : ag_obj_used1;
-        if (a.stale_reads > 0 && used && !this->rs_over) {
-            int16_t *rows = (int16_t *)(this->rs_base + 2 * (size_t)rs_log_cap() * sizeof(AgCall));
-            uint8_t *image = (uint8_t *)rows + (((size_t)ag_lds_bytes(cfg.RL) + 255) & ~(size_t)255);
-            const uint32_t image_bytes = (uint32_t)ag_scratch_bytes(cfg.RL);
-            uint8_t *other = image + ((image_bytes + 255u) & ~255u);
-            AgCallCtx c; c.rd0 = rd[0]; c.rd1 = rd[1]; c.ql0 = ql[0]; c.ql1 = ql[1]; c.genome = ix.genome; c.read_len = read_len; c.st = obj == 0 ? 1 : -1;
-            AGResult ex;
-            if (ag_resolve_from_list(c, agp, ag_call_problem(c, loc, org, plen, tlen, lim, dir, use_clip, banded), log, (int)n, rows, image, other, image_bytes, cfg.RL, tab, &ex)) {
-                a.ag_score = (int)first_u32((uint32_t)ex.ag_score); a.n_edits = (int)first_u32((uint32_t)ex.n_edits);
-                a.pattern_offset = (int)first_u32((uint32_t)ex.pattern_offset); a.text_offset = (int)first_u32((uint32_t)ex.text_offset);
-                a.match_probability = first_f64(ex.match_probability);
-                a.stale_reads = 0;                               // answered: nothing left for a replay
-            }
-        }
-        if (lim < 0) return a;                                  // (a call with a negative limit returns at once and writes nothing: ag.h)
-        if (n < rs_log_cap()) {
-            if (lane == 0) {
-                AgCall e; e.loc = loc; e.org = (int16_t)org; e.plen = (int16_t)plen; e.tlen = (int16_t)tlen;
-                e.lim_flags = (uint16_t)((uint32_t)(lim & 0xff) | ((uint32_t)(dir ? 1 : 0) << 8) | ((uint32_t)(use_clip ? 1 : 0) << 9) | ((uint32_t)(banded ? 1 : 0) << 10));
-                log[n] = e;
-            }
-            if (obj == 0) this->rs_n0 = n + 1; else this->rs_n1 = n + 1;
-            WAVE_SYNC(); __threadfence_block();
-        } else this->rs_over = 1;                                     // (a longer list: later calls that leave the band are flagged for the replay as before)
-        return a;
     }
 
     // ------------------------------------------------------------------ helpers
@@ -848,7 +798,6 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
                         a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
                         a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
                         a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
-                        if constexpr (RESOLVE) a = resolve_and_log(half, e_dir, loc, org, plen, lim, tlen, 0, banded, agp, a);
                         note_ag_call(half, (uint32_t)a.stale_reads);
                         if (half == 0) {
                             ag1 = a.ag_score + (seed_len - read_len); clip_after = a.pattern_offset;
@@ -1296,7 +1245,6 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
     __device__ __forceinline__ void align_read(const uint8_t *g_bases, const uint8_t *g_quals, int len) {
         const uint64_t t_read0 = clk();
         ag_obj_used0 = ag_obj_used1 = 0;                                      // a newly constructed aligner for every read
-        if constexpr (RESOLVE) { this->rs_n0 = this->rs_n1 = 0; this->rs_over = 0; }
         ag_calls_unit = 0;
         align_read_inner<false>(g_bases, g_quals, len);
         if (ag_calls_unit >= WAVE_PRIO_HEAVY_AFTER) wave_set_priority(0);
@@ -1373,16 +1321,17 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
         n_seeds_applied[0] = n_seeds_applied[1] = 0;
         popular_seeds_skipped = 0;
         se_tried = 0;
-        bool finished = false;
 
-        while (n_seeds_applied[0] + n_seeds_applied[1] < max_seeds_to_use) {
+        // ONE call site for score(): it is inlined (a call would pin this object in memory), and the reference's three sites -- after a seed's
+        // hits, when the seeds have wrapped seedLen times (:466), after the loop (:734) -- were three copies of the whole scoring code in the
+        // kernel (12 400 instructions against a 64 KB instruction cache).  `force`: this is one of the two final calls.
+        while (true) {
+            bool force = false, applied_either = false;
+            if (n_seeds_applied[0] + n_seeds_applied[1] >= max_seeds_to_use) force = true;                                     // the loop's condition failed: :734
+            else if (next_seed >= n_possible_seeds && wrap_count + 1 >= (uint32_t)seed_len) { wrap_count++; force = true; }    // :455-470
+            if (!force) do {                                                  // (one seed; `continue` = on to the next one, nothing to score)
             if (next_seed >= n_possible_seeds) {                              // wrapping, :455-504
                 wrap_count++;
-                if (wrap_count >= (uint32_t)seed_len) {
-                    score<HAM>(true);
-                    finished = true;
-                    break;
-                }
                 next_seed = tab->wrapped_seed[wrap_count];
                 cur_round_lps[0] = cur_round_lps[1] = 0;
             }
@@ -1401,7 +1350,6 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             cnt().lookups++;
             cnt().slots += hl[0].slots + hl[1].slots;
 
-            bool applied_either = false;
             for (int dir = 0; dir < 2; dir++) {
                 const int64_t dir_n_hits = dir ? hl[1].n_hits : hl[0].n_hits;
                 const uint32_t dir_singleton = dir ? hl[1].singleton : hl[0].singleton;
@@ -1430,12 +1378,11 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             }
             cnt().cyc_hits += clk() - t_lk1;
             next_seed += (uint32_t)seed_len;                                  // :676
-
-            if (applied_either) {
-                if (score<HAM>(false)) { finished = true; break; }
+            } while (0);
+            if (force || applied_either) {
+                if (score<HAM>(force) || force) break;
             }
         }
-        if (!finished) score<HAM>(true);                                      // :734
         if constexpr (!EXACT && !HAM) { if (se_slot >= 0) se_close(); }       // (before the candidate table is released: helpers read it)
         primary().score_prior_to_clipping = primary().score;                      // finalizeSecondaryResults, :2442
         primary().reserved = (ag_stale & 0x3fffffffu) | (ag_replay ? 0x40000000u : 0u);      // bit 30: the exact pass must redo this read
@@ -1599,7 +1546,6 @@ struct Aligner : AlignerResolveBase<RESOLVE>::type {
             a.ag_score = (int)first_u32((uint32_t)a.ag_score); a.n_edits = (int)first_u32((uint32_t)a.n_edits);
             a.pattern_offset = (int)first_u32((uint32_t)a.pattern_offset); a.text_offset = (int)first_u32((uint32_t)a.text_offset);
             a.stale_reads = (int)first_u32((uint32_t)a.stale_reads); a.match_probability = first_f64(a.match_probability);
-            if constexpr (RESOLVE) a = resolve_and_log(half, dir, loc, org, plen, lim, tlen, half == 0 ? 1 : 0, banded, agp, a);
             note_ag_call(half, (uint32_t)a.stale_reads);
             if (half == 0) {
                 ag1 = a.ag_score + (seed_len - read_len); *clip_after = a.pattern_offset; score1 = a.n_edits; mp1 = a.match_probability;

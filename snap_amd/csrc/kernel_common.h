@@ -28,8 +28,6 @@ struct AlignArgs {
     const uint32_t *remap, *n_remap;
     uint32_t is_replay;               // this launch redoes reads an earlier launch of the same call already counted (the exact replay)
     uint8_t *persist; uint64_t persist_stride;
-    // RESOLVE instantiations (single_resolve_k.hip): per wave slot the lists of a read's affine-gap calls and ag_resolve.h's work space
-    uint8_t *rs; uint64_t rs_stride;
     // heavy-first dequeue (order.h): work item i of the MAIN pass is read order[i] (a permutation of 0 .. n_reads); NULL = batch order
     const uint32_t *order;
     // TIMED instantiation only (SNAPGPU_PHASE_TIMERS=1; NULL otherwise): launch diagnostics, snapgpu_debug_launch_profile
@@ -63,8 +61,6 @@ void snapgpu_launch_single_planes_6(const AlignArgs *a, uint32_t blocks, size_t 
 void snapgpu_launch_single_planes_0(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_planes_3(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_planes_0(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
-// single_resolve_k.hip: the fast form that answers calls that leave their band in place (SNAPGPU_SINGLE_RESOLVE=1; 192-position variant)
-void snapgpu_launch_single_resolve_3(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 }
 
 static __device__ __forceinline__ uint32_t align_up(uint32_t v, uint32_t a) { return (v + a - 1) & ~(a - 1); }

@@ -9,7 +9,7 @@
 #ifndef SNAPGPU_WAVES_PER_SIMD
 #define SNAPGPU_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 6 : 4)
 #endif
-template <int AGC, bool SEC, bool EXACT = false, bool TIMED = false, bool PLANES = false, bool RESOLVE = false>
+template <int AGC, bool SEC, bool EXACT = false, bool TIMED = false, bool PLANES = false>
 __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_single(AlignArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
     WaveShared *ws = (WaveShared *)(my + L.shared);
-    Aligner<AGC, SEC, EXACT, TIMED, PLANES, RESOLVE> al(a.ix, a.tab, a.cfg, ws);
+    Aligner<AGC, SEC, EXACT, TIMED, PLANES> al(a.ix, a.tab, a.cfg, ws);
     al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
     al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
     al.gw = my + L.gw;
@@ -48,7 +48,6 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
         al.n_sec = 0;
         al.adj_scratch = a.sec_cfg.adjust ? ss + a.sec_cfg.adj_off : nullptr;
     }
-    if constexpr (RESOLVE) al.rs_base = a.rs + (size_t)wave_slot * a.rs_stride;
     al.cnt() = WaveCounters{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t n_done = 0;
     // help for heavy reads (se_help.h): not in the exact replay, not without the context's arrays

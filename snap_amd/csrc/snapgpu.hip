@@ -20,7 +20,6 @@
 #include "probe.h"
 #include "lv.h"
 #include "ag_win.h"
-#include "ag_resolve.h"
 #include "align_single.h"
 #include "kernel_common.h"
 #include "single_kernel.h"
@@ -249,47 +248,6 @@ __global__ __launch_bounds__(64) void k_ag_sequence(AGBatchArgs a)
     }
 }
 
-// The sequence again, WITHOUT an image kept from call to call: every call in the fast form (a step outside the band reads 0 and is
-// counted), and a call that made such steps is answered exactly by ag_resolve.h from the list of the calls before it.
-__global__ __launch_bounds__(64) void k_ag_sequence_resolve(AGBatchArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int lane = lane_id();
-    int16_t *rows = (int16_t *)lds;
-    const uint32_t image_bytes = (uint32_t)ag_scratch_bytes(a.RL);
-    uint8_t *bt = a.scratch, *image = a.scratch + image_bytes, *other = a.scratch + 2 * (size_t)image_bytes;
-    auto problem = [&](uint32_t i) -> AGProblem {
-        AGProblem x;
-        x.p = a.patterns + a.pat_off[i]; x.q = a.quals + a.pat_off[i]; x.pst = 1;
-        if (a.dir == 1) { x.t = a.texts + a.text_off[i]; x.tst = 1; } else { x.t = a.texts + a.text_off[i] - 1; x.tst = -1; }
-        x.plen = a.pat_len[i]; x.tlen = a.text_len[i]; x.w = a.w[i]; x.score_init = a.score_init[i];
-        x.banded = a.banded[i] != 0; x.is_rc = a.is_rc[i] != 0; x.use_clip = (int)a.use_clip[i];
-        return x;
-    };
-    for (uint32_t i = 0; i < a.n; i++) {
-        const AGProblem x = problem(i);
-        AGResult r;
-        {
-            ByteSeq P{x.p, x.pst}, Q{x.q, x.pst}, T{x.t, x.tst};
-            r = ag_compute<false>(x.banded, a.dir, a.prm, P, Q, x.plen, T, x.tlen, x.w, x.score_init, x.is_rc, x.use_clip, rows, bt, a.RL, a.tab);
-        }
-        WAVE_SYNC(); __threadfence_block();
-        int stale = r.stale_reads;
-        if (stale > 0 && i > 0) {                    // (the object's first call reads zeros outside its band: the fast form's answer is the exact one)
-            AGResult ex; uint32_t steps = 0;
-            const bool ok = ag_resolve_call(a.dir, a.prm, x, (int)i, [&](int c) { return problem((uint32_t)c); }, rows, image, other, image_bytes, a.RL, a.tab, &ex, &steps);
-            if (ok) r = ex; else r.ag_score = -2;        // (test entry: an unresolved call shows)
-            stale = (stale & 0xffff) | (int)(steps << 16);       // (and how many cells it took: stale_steps[i] >> 16)
-        }
-        if (lane == 0) {
-            a.ag_score[i] = r.ag_score; a.text_offset[i] = r.text_offset; a.pattern_offset[i] = r.pattern_offset;
-            a.n_edits[i] = r.n_edits; a.prob[i] = r.match_probability;
-            if (a.stale) a.stale[i] = stale;
-        }
-        WAVE_SYNC();
-    }
-}
-
 // =====================================================================================
 // host side
 // =====================================================================================
@@ -387,9 +345,6 @@ struct snapgpu_ctx {
     uint32_t *d_flag_list = nullptr; size_t flag_list_cap = 0;
     // exact replay of flagged reads / pairs: the reference's traceback arrays per replay wave (2 per read, 4 per pair)
     uint8_t *d_exact_persist = nullptr; uint64_t exact_persist_stride = 0; uint32_t exact_slots = 0;
-    // SNAPGPU_SINGLE_RESOLVE=1 (192-position variant): the fast form answers calls that leave their band in place (ag_resolve.h); per wave
-    // slot the lists of a read's affine-gap calls and the resolver's work space
-    uint8_t *d_resolve = nullptr; uint64_t resolve_stride = 0;
     uint8_t *d_pexact_persist = nullptr; uint64_t pexact_persist_stride = 0; uint32_t pexact_slots = 0;
     // the exact kernel beside the paired main pass (launch_paired, opt-in): its stream, fork / join events
     hipStream_t replay_stream = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; int replay_beside = 0;
@@ -584,7 +539,6 @@ extern "C" void snapgpu_destroy(snapgpu_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->d_exact_persist) (void)hipFree(ctx->d_exact_persist);
-    if (ctx->d_resolve) (void)hipFree(ctx->d_resolve);
     if (ctx->d_pexact_persist) (void)hipFree(ctx->d_pexact_persist);
     if (ctx->d_help) (void)hipFree(ctx->d_help);
     if (ctx->d_help_spec) (void)hipFree(ctx->d_help_spec);
@@ -873,12 +827,6 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
         CRCHK(hipMemsetAsync(ctx->d_exact_persist, 0, (size_t)ctx->exact_slots * ctx->exact_persist_stride, ctx->stream), SNAPGPU_E_NODEVICE);
     }
     if (const char *e = getenv("SNAPGPU_SINGLE_HEAVY_FIRST")) ctx->single_heavy_first = atoi(e) != 0 ? 1 : 0;
-    if (const char *e = getenv("SNAPGPU_SINGLE_RESOLVE")) {
-        if (atoi(e) != 0 && ctx->ag_variant == 3 && p->use_affine_gap) {
-            ctx->resolve_stride = (Aligner<3, false, false, false, false, true>::rs_slab_bytes(ctx->cfg.RL) + 255) & ~(uint64_t)255;
-            CRCHK(hipMalloc((void **)&ctx->d_resolve, (size_t)ctx->n_wave_slots * ctx->resolve_stride), SNAPGPU_E_NOMEM);
-        }
-    }
     if (const char *e = getenv("SNAPGPU_PHASE_TIMERS")) ctx->phase_timers = atoi(e) != 0;
     if (ctx->single_help) {
         ctx->se_spec_cap = c.se_items_cap;
@@ -1894,9 +1842,7 @@ static int affine_gap_batch(snapgpu_ctx *ctx, int dir, uint32_t n,
         if (ns * sl > need) need = ns * sl;
     }
     if (getenv("SNAPGPU_AG_LDS")) need = 1 << 20;
-    if (sequence && getenv("SNAPGPU_AG_SEQUENCE_RESOLVE") && atoi(getenv("SNAPGPU_AG_SEQUENCE_RESOLVE")) != 0)
-        hipLaunchKernelGGL(k_ag_sequence_resolve, dim3(1), dim3(64), lds, s, a);                        // (no image kept: ag_resolve.h)
-    else if (sequence) {
+    if (sequence) {
         if (need <= 192) hipLaunchKernelGGL(k_ag_sequence<3>, dim3(1), dim3(64), lds, s, a);
         else             hipLaunchKernelGGL(k_ag_sequence<0>, dim3(1), dim3(64), lds, s, a);          // (the exact replay has these two forms)
     } else
@@ -1978,11 +1924,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
     a.is_replay = 0; a.order = nullptr; a.dbg = nullptr; a.dbg_slots = 0;
     a.se_slots = nullptr; a.se_n_slots = 0; a.se_spec = nullptr; a.se_spec_cap = 0; a.se_ctl = nullptr; a.se_eager = 0; a.se_keep = 1;
     a.front_clip = ctx->clip_front; a.data_len = ctx->clip_len; a.skip = ctx->clip_skip;
-    // (SNAPGPU_SINGLE_RESOLVE=1: plain launches go to the instantiation that answers calls leaving their band in place; it runs alone --
-    //  the helpers' records do not carry what the call lists need -- and what it could not answer is still flagged and replayed)
-    const bool resolve_k = ctx->d_resolve != nullptr && !d_n_secondary && !ctx->phase_timers;
-    a.rs = ctx->d_resolve; a.rs_stride = ctx->resolve_stride;
-    const bool use_help = !resolve_k && ctx->single_help && ctx->d_se_slots && !d_n_secondary &&
+    const bool use_help = ctx->single_help && ctx->d_se_slots && !d_n_secondary &&
                           (ctx->single_help_forced == 1 || (ctx->feeders && ctx->feeders->load() <= 1));
     if (use_help) {                                                       // (fresh protocol state for the launch that is about to start)
         HIPCHK(ctx, hipMemsetAsync(ctx->d_se_slots, 0, SE_HELP_SLOTS * sizeof(SEHelpSlot), s), SNAPGPU_E_LAUNCH);
@@ -1996,7 +1938,7 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
         HIPCHK(ctx, hipMemsetAsync(ctx->d_dbg, 0, words * 8, s), SNAPGPU_E_LAUNCH);
         a.dbg = ctx->d_dbg; a.dbg_slots = ctx->n_wave_slots;
     }
-    const bool always_exact = ctx->always_exact && ctx->d_exact_persist != nullptr && !use_help && !resolve_k;
+    const bool always_exact = ctx->always_exact && ctx->d_exact_persist != nullptr && !use_help;
     const bool exact = !always_exact && ctx->d_exact_persist != nullptr && !getenv("SNAPGPU_NO_EXACT_REPLAY");
     if (exact) {
         if (ctx->flag_list_cap < n) {
@@ -2030,8 +1972,6 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
         if (ctx->phase_timers && !d_n_secondary) snapgpu_launch_single_exact_3_timed(&a, blocks, 4 * ctx->cfg.lds_per_wave, s);
         else if (planes_k) snapgpu_launch_single_exact_planes_3(&a, blocks, 4 * ctx->cfg.lds_per_wave, s);
         else snapgpu_launch_single_exact_3(&a, d_n_secondary ? 1 : 0, blocks, 4 * ctx->cfg.lds_per_wave, s);
-    } else if (resolve_k) {
-        snapgpu_launch_single_resolve_3(&a, blocks, 4 * ctx->cfg.lds_per_wave, s);
     } else if (planes_k) {
         switch (ctx->ag_variant) {
         case 3:  snapgpu_launch_single_planes_3(&a, blocks, 4 * ctx->cfg.lds_per_wave, s); break;

@@ -25,7 +25,6 @@ def units():
     u += [("paired_k%d.o" % v, os.path.join(CSRC, "paired_k.hip"), ["-DPAIRED_AGC=%d" % v]) for v in (3, 4, 6, 0)]
     u += [("single_sec_k%d.o" % v, os.path.join(CSRC, "single_sec_k.hip"), ["-DSINGLE_AGC=%d" % v]) for v in (3, 4, 6, 0)]
     u += [("single_planes_k%d.o" % v, os.path.join(CSRC, "single_planes_k.hip"), ["-DSINGLE_AGC=%d" % v]) for v in (3, 4, 6, 0)]
-    u += [("single_resolve_k.o", os.path.join(CSRC, "single_resolve_k.hip"), [])]
     u += [("paired_sec_k%d.o" % v, os.path.join(CSRC, "paired_k.hip"), ["-DPAIRED_AGC=%d" % v, "-DPAIRED_SEC"]) for v in (3, 0)]
     # -fsanitize=thread only for its instrumentation: wave_emu.cpp supplies the __tsan_* hooks (stores become rendezvous points)
     u = [(o, src, fl + ["-fsanitize=thread", "--param", "tsan-instrument-func-entry-exit=0"]) for (o, src, fl) in u]

@@ -308,19 +308,6 @@ def test_emu_affine_gap_wide_bands(emu, golden_index):
     gp.test_affine_gap_wide_band_call_sequences_vs_reference_fixture(golden_index, step=2)
 
 
-def test_emu_affine_gap_call_sequences_without_an_image(emu, golden_index, monkeypatch):
-    """ag_resolve.h on the emulated device: the first 400 calls of the short-pattern sequence with no image kept (SNAPGPU_AG_SEQUENCE_RESOLVE=1)."""
-    import tests.test_gpu_parity as gp
-    gp.test_affine_gap_call_sequences_without_an_image(golden_index, monkeypatch, step=3, tags=("short",))
-
-
-def test_emu_calls_leaving_the_band_answered_in_place(emu, golden_index, golden_reads, monkeypatch):
-    """tests/test_zzz_gpu_resolve.py on the emulated device (SNAPGPU_SINGLE_RESOLVE=1: ag_resolve.h inside the single-end fast form; the
-    first 1 200 golden 100 bp reads at -d 8, replay switched off)."""
-    from tests.test_zzz_gpu_resolve import check_resolve_on_fixture
-    assert check_resolve_on_fixture(golden_index, golden_reads, monkeypatch, sets=(("default_d8", dict(max_k=8)),), n_reads=1200) >= 2    # (reads 627 and 1028)
-
-
 def test_emu_compute_cigar_affine_gap(emu, emu_aligner):
     """SAMFormat::computeCigar, affine-gap variant (banded and full global alignment with traceback), on the emulated device: every
     third item of the reference fixture (tests/golden/cigar_ag.npz), both op alphabets."""

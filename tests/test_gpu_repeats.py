@@ -124,4 +124,4 @@ def test_single_end_repeat_families_vs_reference_live(repeat_bed, exact, n=20000
         a.close()
     assert not util.compare_results(exp, got)
     # repeat families: many reads have equally good placements (diverged copies: 18 % of the aligned reads on this genome; exact copies: more)
-    assert (got["mapq"][got["status"] != 0] <= 3).mean() > (0.3 if exact else 0.1)
+    assert (got["mapq"][got["status"] != 0] <= 3).mean() > (0.2 if exact else 0.1)
