@@ -115,6 +115,15 @@ def gcov_counts(gcda_stem, want_fn=None):
     return cnt, fn_of
 
 
+_srcs = {}
+
+
+def _src(base):
+    if base not in _srcs:
+        _srcs[base] = open(os.path.join(CSRC, base), errors="replace").read().splitlines()
+    return _srcs[base]
+
+
 def short(name):
     name = re.sub(r"\(.*", "", name)
     name = re.sub(r"<[^<>]*(<[^<>]*>[^<>]*)*>", "<>", name)
@@ -191,7 +200,11 @@ def main():
                                                                                                         sc(self_[f]), self_[f]["valu"] + self_[f]["lane"]))
     print("\ntop %d lines by scalar instructions: scalar | vector+lane | runs per read | copies" % top)
     for key, d in sorted(by_line.items(), key=lambda x: -sc(x[1]))[:top]:
-        print("  %-16s %5d  %7.0f %7.0f   runs %8.2f  copies %3d" % (key[0], key[1], sc(d), d["valu"] + d["lane"], cnt.get(key, 0) / 64.0 / n, len(copies[key])))
+        try:
+            text = _src(key[0])[key[1] - 1].strip()[:110]
+        except Exception:
+            text = ""
+        print("  %-16s %5d  %7.0f %7.0f   runs %8.2f  copies %3d   | %s" % (key[0], key[1], sc(d), d["valu"] + d["lane"], cnt.get(key, 0) / 64.0 / n, len(copies[key]), text))
 
 
 if __name__ == "__main__":

@@ -490,6 +490,12 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int wbase = 0, jbase = 0;
     int Hp = lane < tot ? (int)fr16[lane] : 0, Hm = 0, E = 0;
     int pbv = lane < tot ? (int)pcode[lane] : 5;
+    // The best local score (:the row maximum that beats every earlier row's, its row, the HIGHEST position holding it) without a per-row reduction:
+    // every position keeps  (its best H << 16) | (0xFFFF - the first row that reached it)  -- one shift-or, one select, one unsigned max per row, no
+    // scalar instruction -- and the order of that word is the reference's: a larger H wins, then the earlier row.  The wave-wide maximum of the words,
+    // taken once after the loop, is the best local score and its row; the highest position that holds that word is its column.  Positions that
+    // slide out of the window leave their word's maximum in `dpk` (+ `dpos`); H <= 32767 (ag_sat16), rows < 65535.
+    uint32_t lpk = 0u, dpk = 0u; int dpos = -1;
     int left_h = 0;
     // H / H-1 of the global-alignment cell (position pattern_len-1) once it has left the window: the
     // reference keeps reading its stale value on the row(s) after the band has passed the pattern end
@@ -531,6 +537,11 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int c_ls = 0, c_g = 0;                                        // (follow nk like stepv: the closed form of the second segment's lazy F)
     unsigned long long KM0 = 0ull, KM1 = 0ull, KE1 = 0ull, KL1 = 0ull;   // masks that follow (nk0, nk1) like the per-lane values below: the band's lanes of either segment, the second segment's stripe ends / stripes 1 .. 7
     int nk_addr = 0, stepv = 0, nk_key = -1;                     // per-lane values that follow (nk0, nk1): the gather address of round 0, nk * ext of the lane's segment
+    // ... and the masks that follow (nk0, nk1) AND the window (V changes when it slides; a slide resets nk_key): the band's valid lanes per segment, and kgrp
+    // restricted to them (a round's ballot then needs no AND with the segment's lanes on the scalar unit)
+    unsigned long long ins0 = 0ull, ins1 = 0ull, inseg_mask = 0ull;
+    decltype(kgrp) kg0 = 0; unsigned long long kg1 = 0ull;     // (kg1 at the second segment's own lanes: a round's ballot is tested in place, not shifted down first)
+    uint32_t full0 = 0u, full1 = 0u; int src7_0 = 0, c7x = 0;   // (1 << nk) - 1 per segment; round 1's stripe-6 lane and 7 * nk0 * ext of the first segment's X
     uint32_t tb4 = 0;
 
     // open - ext, in a VECTOR register on purpose: every lazy-F round subtracts it, the row loop has more wave-uniform values than SGPRs, and as an
@@ -567,8 +578,17 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 gl_p = __builtin_amdgcn_readlane(Hp, pattern_len - 1 - wbase);
                 gl_m = __builtin_amdgcn_readlane(Hm, pattern_len - 1 - wbase);
             }
+            {   // the departing positions' best word (a later group's positions are higher: it wins a tie)
+                const uint32_t dv = lane < seg_len ? lpk : 0u;
+                const uint32_t dmx = (uint32_t)__builtin_amdgcn_readlane(ag_prefix_max((int)dv), 63);      // (words are below 2^31: the signed maximum is the unsigned one)
+                if (dmx != 0u && dmx >= dpk) {
+                    const unsigned long long mk = BALLOT(dv == dmx);
+                    dpk = dmx; dpos = wbase + 63 - __clzll((long long)mk);
+                }
+            }
             int nHp = __shfl_down(Hp, seg_len), nHm = __shfl_down(Hm, seg_len), nE = __shfl_down(E, seg_len);
             int npb = __shfl_down(pbv, seg_len);
+            uint32_t nlpk = (uint32_t)__shfl_down((int)lpk, seg_len);
             wbase += seg_len; jbase++;
             if (lane >= WAVE - seg_len) {                       // positions entering the window
                 const int p = wbase + lane;
@@ -577,12 +597,14 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 nHm = (i & 1) ? fr : 0;
                 nE = 0;
                 npb = p < tot ? (int)pcode[p] : 5;
+                nlpk = 0u;
             }
-            Hp = nHp; Hm = nHm; E = nE; pbv = npb;
+            Hp = nHp; Hm = nHm; E = nE; pbv = npb; lpk = nlpk;
             V = vmask(wbase);
             c_pt += seg_len * gap_ext; c_pm += seg_len * gap_ext;
             v_else = pbv == 5 ? -32768 : (pbv == 4 ? -1 : sub);
             v_else_n = pbv == 5 ? -32768 : -1;
+            nk_key = -1;                                        // (V moved: the masks below are recomputed)
         }
         int h_init0 = score_init;
         if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
@@ -608,10 +630,13 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 KM0 = kmask(nk0) & seg0(); KM1 = kmask(nk1) & seg1();
                 KE1 = nk1 > 0 ? ((Kz << (nk1 - 1)) & lmid()) & KM1 : 0ull;
                 KL1 = KM1 & ~xmask();
+                ins0 = KM0 & V; ins1 = KM1 & V;                      // valid && k < nk(segment), per segment
+                inseg_mask = ins0 | ins1;
+                kg0 = kgrp & (decltype(kgrp))ins0; kg1 = FULL ? 0ull : (((unsigned long long)kgrp << seg_len) & ins1);
+                full0 = (1u << nk0) - 1u; full1 = (1u << nk1) - 1u;
+                src7_0 = nk0 - 1 + 6 * num_vec; c7x = 7 * nk0 * gap_ext;
             }
         }
-        const unsigned long long ins0 = KM0 & V, ins1 = KM1 & V;                                        // valid && k < nk(segment), per segment
-        const unsigned long long inseg_mask = ins0 | ins1;
         const bool inseg = lane_in(inseg_mask);
 
         // ---------------- first pass, both segments (:483-531)
@@ -699,9 +724,9 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             // the rounds keep the largest wv they pass (a readlane and a max), the subtraction happens once.
             // (Written as nested calls, one instantiation per round, not as a loop with a break: unrolled, the loop's exits came out as
             //  flag registers set, tested and tested again -- five scalar instructions and two branches per round.)
-            auto rounds = [&](int s, int nk, unsigned long long ins_mask, int &Fxs) {
-                const uint32_t full = (1u << nk) - 1u;
-                int src7 = s * seg_len + nk - 1 + 6 * num_vec;                       // (round 1 looks at stripe 6's last vector)
+            auto rounds = [&](auto sc, int nk, uint32_t full, unsigned long long ins_mask, auto kgs, int &Fxs) {
+                constexpr int s = decltype(sc)::value;
+                int src7 = src7_0;                                                   // (round 1 looks at stripe 6's last vector; first segment only)
                 int Wm = -AG_HUGE;
                 int Tr = T_fp;
                 // (The next round's gather needs this round's OFFER, not its verdict: it is issued before the verdict's ballot-and-fold chain so
@@ -713,17 +738,22 @@ static __device__ __forceinline__ AGResult ag_banded_win(
 #endif
                     int u_next = 0;
                     if constexpr (r < 6) u_next = __builtin_amdgcn_ds_bpermute(c_prev, u_cur);
-                    const unsigned long long go = BALLOT(u_cur > Tr) & ins_mask;     // (an offer <= 0 is never above Tr >= 0)
+                    const unsigned long long go = BALLOT(u_cur > Tr);                // (an offer <= 0 is never above Tr >= 0; lanes outside the segment's band: masked by kgs)
+#if defined(SNAPGPU_AG_FOLD_SCALAR)
                     typename std::conditional<FULL, unsigned long long, uint32_t>::type cm = s == 0 ? go : (go >> seg_len);      // (a banded segment's lanes fit 32 bits)
+#else
+                    const auto cm = (decltype(kgs))go;                               // (first segment of a banded call: its lanes fit 32 bits; second: tested where they are)
+#endif
 #if defined(SNAPGPU_AG_FOLD_SCALAR)                                                    // (measurement builds: the fold of rounds 4 - 5)
+                    cm &= (decltype(cm))(s == 0 ? ins_mask : (ins_mask >> seg_len));
                     cm |= cm >> num_vec; cm |= cm >> (2 * num_vec); cm |= cm >> (4 * num_vec);
                     const uint32_t low = (uint32_t)cm & full;
 #else
-                    const uint32_t low = (uint32_t)BALLOT((cm & kgrp) != 0);         // bit k: vector k goes on (k < nk: ins_mask holds nothing else; lanes >= num_vec: kgrp == 0)
+                    const uint32_t low = (uint32_t)BALLOT((cm & kgs) != 0);          // bit k: vector k goes on (kgs: lane k < nk holds the band's valid lanes of vector k; every other lane 0)
 #endif
                     if (__builtin_expect(low != full, 0)) {                          // the round stops at vector jlim: the walk ends
                         const int jlim = (int)__builtin_ctz(~low);
-                        const int fm = lane_in(ins_mask & kmask(jlim + 1)) ? u_cur : 0;
+                        const int fm = (k <= jlim && lane_in(ins_mask)) ? u_cur : 0;   // (vectors 0 .. jlim of the segment: a vector compare against the lane's k, not a mask built on the scalar unit)
                         Fxs = fm > Fxs ? fm : Fxs;
                     } else {
                         Fxs = u_cur > Fxs ? u_cur : Fxs;
@@ -740,10 +770,10 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                     }
                 };
                 round(round, std::integral_constant<int, 0>{}, u);
-                if (s == 0) { const int xr = Wm - 7 * nk * gap_ext; if (xr > X0) X0 = xr; }
+                if (s == 0) { const int xr = Wm - c7x; if (xr > X0) X0 = xr; }
             };
             const int X_first = X0;
-            if (nk0 > 0) rounds(0, nk0, ins0, Fx0);
+            if (nk0 > 0) rounds(std::integral_constant<int, 0>{}, nk0, full0, ins0, kg0, Fx0);
             int Fx = lane_in(ins0) ? Fx0 : 0;
             if (two) {
                 if (X0 != X_first) {
@@ -782,7 +812,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 } else {
                     if ((BALLOT(wv > e0) & endm) != 0ull) EMU_STAT(15, 1); else EMU_STAT(16, 1);
                     u = X0 != X_first ? __builtin_amdgcn_ds_bpermute(nk_addr, endv) - c_lazy : u0;     // round 0's offer again (gathered anew when X moved the stripe-0 ends)
-                    rounds(1, nk1, ins1, Fx1);
+                    rounds(std::integral_constant<int, 1>{}, nk1, full1, ins1, kg1, Fx1);
                     Fx = lane_in(ins1) ? Fx1 : Fx;
                 }
             }
@@ -804,29 +834,24 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             int gscore = pattern_len - 1 >= wbase ? __builtin_amdgcn_readlane(Hm, pattern_len - 1 >= wbase ? pattern_len - 1 - wbase : 0) : gl_m;
             if (gscore >= best_global) { best_global = gscore; best_global_text = i; }
         }
-        // The row maximum (:the loop ends on a row of zeros; a new best local score moves the local end).  Which cells beat the best so far is
-        // one compare; along an alignment it is ONE cell (the diagonal's), whose value is then the row maximum -- a readlane instead of a
-        // six-step reduction and a second ballot; no cell: only "is the row all zero" is left to ask; several: the reduction, as before.
-        const unsigned long long gtm = BALLOT(Hm > best_local) & inseg_mask;
-        if (gtm == 0ull) {
-            if ((BALLOT(Hm != 0) & inseg_mask) == 0ull) break;                       // max_row == 0
-        } else if ((gtm & (gtm - 1ull)) == 0ull) {
-            const int lb = (int)__builtin_ctzll(gtm);
-            const int max_row = __builtin_amdgcn_readlane(Hm, lb);                   // (> best_local >= -1)
-            if (max_row == 0) break;
-            best_local_pat = wbase + lb; best_local = max_row; best_local_text = i;
-        } else {
-            const int mxv = inseg ? Hm : 0;
-            const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxv), 63);
-            if (max_row == 0) break;
-            if (max_row > best_local) {
-                unsigned long long mk = BALLOT(Hm == max_row) & inseg_mask;
-                best_local_pat = mk ? wbase + 63 - __clzll((long long)mk) : -1;
-                best_local = max_row; best_local_text = i;
-            }
+        // The loop ends on a row of zeros (:max_row == 0); otherwise every position notes its best (see lpk).
+        {
+            const uint32_t t = ((uint32_t)Hm << 16) | (uint32_t)(0xFFFF - i);
+            const uint32_t tin = inseg ? t : 0u;
+            if (BALLOT(tin > 0xFFFFu) == 0ull) break;                                // max_row == 0: no evaluated cell of the row holds anything
+            lpk = tin > lpk ? tin : lpk;
         }
         { int t = Hm; Hm = Hp; Hp = t; }
         { int t = gl_m; gl_m = gl_p; gl_p = t; }
+    }
+    {   // the best local score, its row and column from the positions' words (the window's positions are higher than every departed one: they win a tie)
+        const uint32_t wmx = (uint32_t)__builtin_amdgcn_readlane(ag_prefix_max((int)lpk), 63);
+        uint32_t bpk = dpk; int bpos = dpos;
+        if (wmx != 0u && wmx >= dpk) {
+            const unsigned long long mk = BALLOT(lpk == wmx);
+            bpk = wmx; bpos = wbase + 63 - __clzll((long long)mk);
+        }
+        if (bpk != 0u) { best_local = (int)(bpk >> 16); best_local_text = 0xFFFF - (int)(bpk & 0xFFFFu); best_local_pat = bpos; }
     }
     WAVE_SYNC();
     }
