@@ -536,13 +536,26 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     if (lane < num_vec) for (int l2 = 0; l2 < 8; l2++) kgrp |= (decltype(kgrp))1 << (lane + l2 * num_vec);
     int c_ls = 0, c_g = 0;                                        // (follow nk like stepv: the closed form of the second segment's lazy F)
     unsigned long long KM0 = 0ull, KM1 = 0ull, KE1 = 0ull, KL1 = 0ull;   // masks that follow (nk0, nk1) like the per-lane values below: the band's lanes of either segment, the second segment's stripe ends / stripes 1 .. 7
-    int nk_addr = 0, stepv = 0, nk_key = -1;                     // per-lane values that follow (nk0, nk1): the gather address of round 0, nk * ext of the lane's segment
+    int nk_addr = 0, stepv = 0;                     // per-lane values that follow (nk0, nk1): the gather address of round 0, nk * ext of the lane's segment
     // ... and the masks that follow (nk0, nk1) AND the window (V changes when it slides; a slide resets nk_key): the band's valid lanes per segment, and kgrp
     // restricted to them (a round's ballot then needs no AND with the segment's lanes on the scalar unit)
     unsigned long long ins0 = 0ull, ins1 = 0ull, inseg_mask = 0ull;
     decltype(kgrp) kg0 = 0; unsigned long long kg1 = 0ull;     // (kg1 at the second segment's own lanes: a round's ballot is tested in place, not shifted down first)
     uint32_t full0 = 0u, full1 = 0u; int src7_0 = 0, c7x = 0;   // (1 << nk) - 1 per segment; round 1's stripe-6 lane and 7 * nk0 * ext of the first segment's X
-    uint32_t tb4 = 0;
+    // The row's own scalars, kept incrementally (round 6: the scalar unit bounds the kernel; recomputed from i every row they were ~45 scalar instructions):
+    //   be        band_end = min(i + w, pattern_len - 1): + 1 per row until it reaches the pattern's end;
+    //   be_next   the band_end at which (nk0, nk1) next change -- the per-(nk0, nk1) block below runs when be reaches it (a slide, which moves the
+    //             window under the band, forces it) -- so nk0 / nk1 / two and everything derived from them are only touched there;
+    //   slide_at  the row on which the window slides next: (jbase + 1) * seg_len <= band_beg  <=>  i >= (jbase + 1) * seg_len + w;
+    //   l0, hi    H(i-1, p-1) of window lane 0 for this row and, while the window is at the pattern's start, the first-column value of the next:
+    //             score_init, then max(score_init - open - (i - 1) * ext, 0); after a slide the H that left the window on the slide's row, then 0.
+    const int pe1 = pattern_len - 1;
+    int be = FULL ? pe1 : (w < pe1 ? w : pe1) - 1;                // (the row's first statement adds the row's step)
+    int be_next = -(1 << 30);
+    int slide_at = FULL ? (1 << 30) : seg_len + w;
+    int l0 = score_init, hi = score_init - gap_open > 0 ? score_init - gap_open : 0;
+    int nk0 = 0, nk1 = 0, f7_lane = 0, e0_lane = 0; bool two = false;
+    int tcv = 0;                                                 // base codes of 64 text rows, lane j: row (i & ~63) + j
 
     // open - ext, in a VECTOR register on purpose: every lazy-F round subtracts it, the row loop has more wave-uniform values than SGPRs, and as an
     // SGPR it was the one the allocator spilled -- a v_readlane per round to get it back.
@@ -567,11 +580,10 @@ static __device__ __forceinline__ AGResult ag_banded_win(
 #endif
         }
 #endif
-        if ((i & 3) == 0) tb4 = first_u32(*(LDS_AS const uint32_t *)(tcode + i));       // four rows' text codes per LDS read (tcode is 16-byte aligned; the tail reads slack)
-        const int tb = (int)((tb4 >> (8 * (i & 3))) & 0xffu);
-        const int band_beg = FULL ? 0 : (i - w > 0 ? i - w : 0);
-        const int band_end = FULL ? pattern_len - 1 : (i + w < pattern_len - 1 ? i + w : pattern_len - 1);
-        if (!FULL && __builtin_expect((jbase + 1) * seg_len <= band_beg, 0)) {       // slide the window by one segment (one row in twenty)
+        if (__builtin_expect((i & 63) == 0, 0)) tcv = i + lane < text_len ? (int)tcode[i + lane] : 0;      // 64 rows' text codes per LDS read
+        const int tb = __builtin_amdgcn_readlane(tcv, i & 63);
+        if (!FULL) { be = be + 1 < pe1 ? be + 1 : pe1; }
+        if (!FULL && __builtin_expect(i >= slide_at, 0)) {                           // slide the window by one segment (one row in twenty)
             EMU_STAT(10, 1);
             left_h = __builtin_amdgcn_readlane(Hp, seg_len - 1);
             if (pattern_len - 1 >= wbase && pattern_len - 1 < wbase + seg_len) {
@@ -604,24 +616,26 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             c_pt += seg_len * gap_ext; c_pm += seg_len * gap_ext;
             v_else = pbv == 5 ? -32768 : (pbv == 4 ? -1 : sub);
             v_else_n = pbv == 5 ? -32768 : -1;
-            nk_key = -1;                                        // (V moved: the masks below are recomputed)
+            slide_at += seg_len;
+            be_next = -(1 << 30);                               // (V and wbase moved: the block below runs)
+            l0 = left_h; hi = 0;
         }
-        int h_init0 = score_init;
-        if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
         // The reference finishes segment j (first pass, then lazy F) before it starts segment j + 1, and the only thing that crosses
         // over is X, the F that left segment j's last stripe, which enters stripe 0 of segment j + 1.  Everything else of the two
         // first passes is independent, so both segments go through ONE first pass (each lane knows its segment), the few stripe-0
         // lanes of the second segment take X in afterwards (F only ever raises the values derived from it), and the first lazy-F round
         // -- the only one in all but a few rows -- runs for both segments at once.
-        const int t0 = band_end - wbase + 1;                       // cells of the band from the window's start on (wbase = jbase * seg_len)
-        const int nk0 = t0 < num_vec ? t0 : num_vec;
-        int nk1 = t0 - seg_len; if (nk1 > num_vec) nk1 = num_vec; if (nk1 < 0 || FULL) nk1 = 0;    // (FULL: one segment, known at compile time)
-        const bool two = !FULL && nk1 > 0;                                  // (jbase + 1) * seg_len <= band_end
         {
-            const int key = nk0 | (nk1 << 8);
-            if (__builtin_expect(key != nk_key, 0)) {               // (changes on one row in six; a row's scalar instructions are as scarce as its vector ones)
+            if (__builtin_expect(be >= be_next, 0)) {               // (nk0, nk1) change here (one row in six), or the window has just moved
                 EMU_STAT(14, 1);
-                nk_key = key;
+                const int t0 = be - wbase + 1;                      // cells of the band from the window's start on (wbase = jbase * seg_len)
+                nk0 = t0 < num_vec ? t0 : num_vec;
+                nk1 = t0 - seg_len; if (nk1 > num_vec) nk1 = num_vec; if (nk1 < 0 || FULL) nk1 = 0;    // (FULL: one segment, known at compile time)
+                two = !FULL && nk1 > 0;                             // (jbase + 1) * seg_len <= band_end
+                // when they change next: while the first segment's vectors fill up (t0 < num_vec) and while the second's do (seg_len < t0 < seg_len + num_vec) every
+                // row; in between at t0 = seg_len + 1; afterwards not before the window slides
+                be_next = FULL ? (1 << 30) : (t0 < num_vec ? be + 1 : (t0 <= seg_len ? be + (seg_len + 1 - t0) : (t0 < seg_len + num_vec ? be + 1 : (1 << 30))));
+                f7_lane = nk0 - 1 + 7 * num_vec; e0_lane = seg_len + nk1 - 1;
                 const int nkl = lane_in(seg0()) ? nk0 : nk1;
                 nk_addr = c_src + 4 * nkl;
                 stepv = l == 0 ? 0 : nkl * gap_ext;
@@ -640,9 +654,8 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         const bool inseg = lane_in(inseg_mask);
 
         // ---------------- first pass, both segments (:483-531)
-        int lane0_in;                                              // H(i-1, p-1) of window lane 0: the reference's segment-start rule (:461-476)
-        if (wbase == 0) lane0_in = h_init0;
-        else lane0_in = (band_beg > wbase) ? 0 : left_h;
+        const int lane0_in = l0;                                   // H(i-1, p-1) of window lane 0: the reference's segment-start rule (:461-476)
+        l0 = hi; hi = hi > gap_ext ? hi - gap_ext : 0;
         const int h_in = ag_shr1(lane0_in, Hp);
         const int prof = tb > 3 ? v_else_n : (pbv == tb ? match : v_else);       // (tb > 3: an 'N' of the text)
         const int m = h_in > 0 ? ag_sat16(h_in + prof) : 0;
@@ -679,7 +692,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
             // the F that left stripe 7 in the first pass (:538).  It enters stripe 0 of the second segment (f = X, :571).
             const int f2p0 = fk - gap_ext;
             const int endv_a = f2p0 > tmp ? f2p0 : tmp;
-            const int f7 = __builtin_amdgcn_readlane(endv_a, nk0 - 1 + 7 * num_vec);
+            const int f7 = __builtin_amdgcn_readlane(endv_a, f7_lane);
             X0 = f7 > 0 ? f7 : 0;
             const int fkp = X0 - c_x;
             fk = fkp > fk ? fkp : fk;
@@ -800,7 +813,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                 //       was offered before (smaller, by (A)), every vector has such a cell, all seven rounds are complete and apply to
                 //       every cell -- and Fx is the stripe-0 offer itself.
                 // Otherwise the rounds run as for the first segment.
-                const int e0 = __builtin_amdgcn_readlane(endv, seg_len + nk1 - 1);
+                const int e0 = __builtin_amdgcn_readlane(endv, e0_lane);
                 const unsigned long long endm = KE1 & V;
                 const int g0 = e0 - c_g;
                 const unsigned long long insL = KL1 & V;
@@ -830,7 +843,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         } else {
             bt_store(sink, (uint32_t)i * 64u, (uint32_t)lane, (uint32_t)btr);       // (lanes outside the band write what they have; the traceback never reads them)
         }
-        if (band_end == pattern_len - 1) {
+        if (be == pe1) {
             int gscore = pattern_len - 1 >= wbase ? __builtin_amdgcn_readlane(Hm, pattern_len - 1 >= wbase ? pattern_len - 1 - wbase : 0) : gl_m;
             if (gscore >= best_global) { best_global = gscore; best_global_text = i; }
         }
