@@ -156,10 +156,22 @@ def main():
         al._lib, al.LIB_PATH = None, lib_path
         from snap_amd import abi, synth
         from tests import util
-        ix = util.load_golden_index()
-        pad = (ix.genome_padded.size - ix.n_bases) // 2
-        ends = [c.begin for c in ix.contigs[1:]] + [ix.n_bases]
-        contigs = [(c.name, ix.genome_padded[pad + c.begin: pad + e - ix.chromosome_padding]) for c, e in zip(ix.contigs, ends)]
+        if "genome-mb" in opt:             # a genome drawn the way bench.py draws its own (30 % planted repeats), indexed by the reference's indexer
+            from oracle import ref
+            from snap_amd.index import GenomeIndex
+            mb = int(opt["genome-mb"])
+            d = "/tmp/snapgpu_dyn_genome_%d" % mb
+            contigs = synth.make_genome(20260925, mb * 1_000_000, n_contigs=max(1, min(24, mb // 8)), repeat_frac=0.30, max_copies=5000, repeat_len=(200, 3000), max_divergence=0.05)
+            if not os.path.exists(os.path.join(d, "ix", "GenomeIndexHash")):
+                os.makedirs(d, exist_ok=True)
+                synth.write_fasta(os.path.join(d, "g.fa"), contigs)
+                ref.build_index(os.path.join(d, "g.fa"), os.path.join(d, "ix"), seed_len=20, threads=8)
+            ix = GenomeIndex.load_from_directory(os.path.join(d, "ix"))
+        else:
+            ix = util.load_golden_index()
+            pad = (ix.genome_padded.size - ix.n_bases) // 2
+            ends = [c.begin for c in ix.contigs[1:]] + [ix.n_bases]
+            contigs = [(c.name, ix.genome_padded[pad + c.begin: pad + e - ix.chromosome_padding]) for c, e in zip(ix.contigs, ends)]
         if mode == "run-single":
             os.environ["SNAPGPU_SINGLE_HELP"] = "0"          # the bench's path (several feeders): one pass of the exact form, no help protocol
             from snap_amd.aligner import BaseAligner

@@ -1074,12 +1074,25 @@ static __device__ __forceinline__ AGResult ag_banded_win2(
     int left_h = 0;
     int gl_p = 0, gl_m = 0;          // H / H-1 of the global-alignment cell (position pattern_len - 1) once it has left the window
     int best_global = -1, best_global_text = -1, best_local = -1, best_local_text = -1, best_local_pat = -1;
+    // (as in ag_banded_win: the best local score through one word per position, the row's band scalars kept incrementally, 64 text codes per LDS read)
+    uint32_t lpkA = 0u, lpkB = 0u, dpk = 0u; int dpos = -1;
+    const int pe1 = pattern_len - 1;
+    int be = (w < pe1 ? w : pe1) - 1;
+    int slide_at = seg_len + w;
+    int l0 = score_init, hi = score_init - gap_open > 0 ? score_init - gap_open : 0;
+    int tcv = 0;
 
     for (int i = 0; i < text_len; i++) {
-        const int tb = (int)first_u32(tcode[i]);
-        const int band_beg = i - w > 0 ? i - w : 0;
-        const int band_end = i + w < pattern_len - 1 ? i + w : pattern_len - 1;
-        if ((jbase + 1) * seg_len <= band_beg) {                // slide: segment jbase leaves, B becomes A, the next segment enters fresh
+        if (__builtin_expect((i & 63) == 0, 0)) tcv = i + lane < text_len ? (int)tcode[i + lane] : 0;
+        const int tb = __builtin_amdgcn_readlane(tcv, i & 63);
+        be = be + 1 < pe1 ? be + 1 : pe1;
+        const int band_end = be;
+        if (__builtin_expect(i >= slide_at, 0)) {               // slide ((jbase + 1) * seg_len <= band_beg): segment jbase leaves, B becomes A, the next segment enters fresh
+            {   // the departing segment's best word (a later segment's positions are higher: it wins a tie)
+                const uint32_t dmx = (uint32_t)__builtin_amdgcn_readlane(ag_prefix_max((int)lpkA), 63);
+                if (dmx != 0u && dmx >= dpk) { const unsigned long long mk = BALLOT(lpkA == dmx); dpk = dmx; dpos = wbase + 63 - __clzll((long long)mk); }
+                lpkA = lpkB; lpkB = 0u;
+            }
             left_h = __builtin_amdgcn_readlane(HpA, seg_len - 1);
             if (pattern_len - 1 >= wbase && pattern_len - 1 < wbase + seg_len) {
                 gl_p = __builtin_amdgcn_readlane(HpA, pattern_len - 1 - wbase);
@@ -1088,9 +1101,9 @@ static __device__ __forceinline__ AGResult ag_banded_win2(
             HpA = HpB; HmA = HmB; EA = EB; pbvA = pbvB;
             wbase += seg_len; jbase++;
             fresh(wbase + seg_len, i, HpB, HmB, EB, pbvB);
+            slide_at += seg_len;
+            l0 = left_h; hi = 0;
         }
-        int h_init0 = score_init;
-        if (i > 0) { int v = score_init - gap_open - (i - 1) * gap_ext; h_init0 = v > 0 ? v : 0; }
         const bool two = (jbase + 1) * seg_len <= band_end;
         int nk0 = band_end - wbase + 1; if (nk0 > num_vec) nk0 = num_vec;
         int nk1 = 0;
@@ -1161,9 +1174,8 @@ static __device__ __forceinline__ AGResult ag_banded_win2(
                 if (!complete) break;
             }
         };
-        int lane0_in;                                              // H(i-1, p-1) of the window's first cell: the reference's segment-start rule (:461-476)
-        if (wbase == 0) lane0_in = h_init0;
-        else lane0_in = (band_beg > wbase) ? 0 : left_h;
+        const int lane0_in = l0;                                   // H(i-1, p-1) of the window's first cell: the reference's segment-start rule (:461-476); see ag_banded_win
+        l0 = hi; hi = hi > gap_ext ? hi - gap_ext : 0;
         int btrA = 0, btrB = 0; bool insA = false, insB = false;
         seg_pass(wbase, nk0, lane0_in, 0, true, HpA, HmA, EA, pbvA, btrA, insA);
         if (two) {
@@ -1179,9 +1191,7 @@ static __device__ __forceinline__ AGResult ag_banded_win2(
             bt_store(sink, (uint32_t)i * 128u, (uint32_t)lane, (uint32_t)btrA);
             if (two) bt_store(sink, (uint32_t)i * 128u + 64u, (uint32_t)lane, (uint32_t)btrB);
         }
-        const int mxA = insA ? HmA : 0, mxB = insB ? HmB : 0;
-        const int max_row = __builtin_amdgcn_readlane(ag_prefix_max(mxA > mxB ? mxA : mxB), 63);
-        if (band_end == pattern_len - 1) {
+        if (band_end == pe1) {
             const int gp = pattern_len - 1 - wbase;
             int gscore;
             if (gp < 0) gscore = gl_m;
@@ -1189,15 +1199,22 @@ static __device__ __forceinline__ AGResult ag_banded_win2(
             else gscore = __builtin_amdgcn_readlane(HmB, gp - seg_len);
             if (gscore >= best_global) { best_global = gscore; best_global_text = i; }
         }
-        if (max_row == 0) break;
-        if (max_row > best_local) {
-            const unsigned long long mkB = BALLOT(insB && HmB == max_row), mkA = BALLOT(insA && HmA == max_row);
-            best_local_pat = mkB ? wbase + seg_len + 63 - __clzll((long long)mkB) : (mkA ? wbase + 63 - __clzll((long long)mkA) : -1);
-            best_local = max_row; best_local_text = i;
+        {
+            const uint32_t rowc = (uint32_t)(0xFFFF - i);
+            const uint32_t tA = insA ? (((uint32_t)HmA << 16) | rowc) : 0u, tB = insB ? (((uint32_t)HmB << 16) | rowc) : 0u;
+            if (BALLOT((tA | tB) > 0xFFFFu) == 0ull) break;                          // max_row == 0
+            lpkA = tA > lpkA ? tA : lpkA; lpkB = tB > lpkB ? tB : lpkB;
         }
         { int t = HmA; HmA = HpA; HpA = t; }
         { int t = HmB; HmB = HpB; HpB = t; }
         { int t = gl_m; gl_m = gl_p; gl_p = t; }
+    }
+    {   // the best local score, its row and column from the positions' words: segment B's positions are the highest, then A's, then the departed ones
+        uint32_t bpk = dpk; int bpos = dpos;
+        const uint32_t wa = (uint32_t)__builtin_amdgcn_readlane(ag_prefix_max((int)lpkA), 63), wb = (uint32_t)__builtin_amdgcn_readlane(ag_prefix_max((int)lpkB), 63);
+        if (wa != 0u && wa >= bpk) { const unsigned long long mk = BALLOT(lpkA == wa); bpk = wa; bpos = wbase + 63 - __clzll((long long)mk); }
+        if (wb != 0u && wb >= bpk) { const unsigned long long mk = BALLOT(lpkB == wb); bpk = wb; bpos = wbase + seg_len + 63 - __clzll((long long)mk); }
+        if (bpk != 0u) { best_local = (int)(bpk >> 16); best_local_text = 0xFFFF - (int)(bpk & 0xFFFFu); best_local_pat = bpos; }
     }
     WAVE_SYNC();
 

@@ -160,8 +160,17 @@ struct SecCfg {
 // the kernels that are timed for throughput are built without (SNAPGPU_PHASE_TIMERS=1 selects the timed instantiation for a breakdown run).
 // PLANES: the plane Landau-Vishkin (planes.h; SNAPGPU_LV_PLANES=1) is compiled in.  Its own instantiations (single_planes_k.hip): carried by
 // every kernel it cost the default ones 110-120 bytes of scratch per lane (exact form 520 -> 408, fast form 712 -> 592) for an option that is off.
-template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false, bool PLANES = false>
-struct Aligner {
+// REGDIR: the candidate table's DIRECTORY in a vector register -- lane j holds the key (bucket number * 2 + direction) of element j, j < 64 -- so that
+// findElement, which the reference does once per seed hit and which was two dependent HBM loads here (the u16 head, then the chained element), is one compare and
+// a ballot while the read has at most 64 buckets (nearly every read); the HBM hash is built when the 65th arrives and used from then on.  Only where this
+// object lives in registers (k_align_single): in the paired-end kernel it is one LDS object per wave and has no per-lane members.
+struct AlignerDirState { uint32_t dirkey; };
+struct AlignerNoDirState {};
+template <bool REGDIR> struct AlignerDirBase { using type = AlignerNoDirState; };
+template <> struct AlignerDirBase<true> { using type = AlignerDirState; };
+
+template <int AGC, bool SEC = false, bool EXACT = false, bool TIMED = false, bool PLANES = false, bool REGDIR = false>
+struct Aligner : AlignerDirBase<REGDIR>::type {
     // ---- constant for the launch
     // held by value: a reference member would make the kernel-argument struct escape through a
     // flat pointer and pin this whole object (ScoreSets, results, counters) in scratch memory
@@ -368,9 +377,20 @@ struct Aligner {
         return (uint32_t)(k >> 40) & (cfg.ht_size - 1);
     }
     // findElement (BaseAligner.cpp:1811-1840): returns element index or 0xFFFF
+    static __device__ __forceinline__ uint32_t dir_key(int64_t base, int dir) { return (uint32_t)(((uint64_t)base / BUCKET) * 2 + (uint64_t)dir); }   // (locations fit 32 bits: < 2^28)
+#ifndef SNAPGPU_DIR_CAP
+#define SNAPGPU_DIR_CAP 64            // (test builds lower it so that ordinary fixtures cross the directory-to-hash transition)
+#endif
+    static constexpr uint32_t DIR_CAP = SNAPGPU_DIR_CAP;
     __device__ __forceinline__ uint16_t find_element(int64_t loc, int dir) const {
         int64_t low = (int64_t)((uint64_t)loc % BUCKET);
         int64_t base = loc - low;
+        if constexpr (REGDIR) {
+            if (n_used <= DIR_CAP) {                                          // the whole table is in the directory
+                const unsigned long long m = BALLOT(this->dirkey == dir_key(base, dir));
+                return m ? (uint16_t)__builtin_ctzll(m) : (uint16_t)0xFFFF;
+            }
+        }
         uint16_t h = (uint16_t)first_u32(heads[head_slot(base, dir)]);
         while (h != 0) {
             // base (dwords 4,5) and hnext|dir|flags (dword 18) of the chained element in one load instead of three dependent ones
@@ -388,6 +408,7 @@ struct Aligner {
     __device__ __forceinline__ void clear_candidates() {                     // BaseAligner.cpp:2332-2339
         n_used = 0;
         highest_used_weight_list = 0;
+        if constexpr (REGDIR) this->dirkey = 0xFFFFFFFFu;
         for (uint32_t i = lane; i < cfg.num_weight_lists; i += WAVE) {
             wl_next[i] = sent(i); wl_prev[i] = sent(i);
         }
@@ -396,6 +417,7 @@ struct Aligner {
 
     // undo the head-table entries of this read (lane-parallel)
     __device__ __forceinline__ void release_candidates() {
+        if (REGDIR && n_used <= DIR_CAP) return;                              // (the hash was never built)
         for (uint32_t i = lane; i < n_used; i += WAVE) {
             heads[head_slot(pool[i].base, pool[i].dir)] = 0;
         }
@@ -424,7 +446,21 @@ struct Aligner {
         n_used++;
         Elem *e = &pool[ei];
         uint32_t hs = head_slot(base, dir);
-        uint16_t old_head = (uint16_t)first_u32(heads[hs]);
+        uint16_t old_head = 0;
+        bool hashed = true;
+        if constexpr (REGDIR) {
+            if (ei < DIR_CAP) { this->dirkey = lane == (int)ei ? dir_key(base, dir) : this->dirkey; hashed = false; }
+            else if (ei == DIR_CAP) {                                         // the directory is full: the hash takes over, starting with what the directory holds
+                for (uint32_t j = 0; j < DIR_CAP; j++) {
+                    uint64_t k = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)this->dirkey, (int)j) * 0x9E3779B97F4A7C15ull;
+                    const uint32_t hj = (uint32_t)(k >> 40) & (cfg.ht_size - 1);
+                    const uint16_t oh = (uint16_t)first_u32(heads[hj]);
+                    if (lane == 0) { pool[j].hnext = oh; heads[hj] = (uint16_t)(j + 1); }
+                    WAVE_SYNC();
+                }
+            }
+        }
+        if (hashed) old_head = (uint16_t)first_u32(heads[hs]);
         if (lane == 0) {
             e->used = 1ull << low;
             e->scored = 0;
@@ -439,7 +475,7 @@ struct Aligner {
             e->best_loc = 0; e->seed_offset = 0;
             e->cand_seed_offset[low] = (uint16_t)seed_offset;
             e->hnext = old_head;
-            heads[hs] = (uint16_t)(ei + 1);
+            if (hashed) heads[hs] = (uint16_t)(ei + 1);
         }
         WAVE_SYNC();
         list_push_tail(1, ei);

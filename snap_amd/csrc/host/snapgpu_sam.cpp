@@ -264,6 +264,7 @@ struct Options {
     bool stop_on_first_hit = false, explore_popular_seeds = false;         // -f, -x (single end; the paired-end aligners ignore them, as the reference's do)
     int n_gpus = 0, ctx_per_gpu = 0, n_format = 0, n_parse = 0;
     bool seqread = false;                                                  // -seqread: the sequential FASTQ reader even for a plain file
+    int passes = 1;                                                        // -passes N (measurement): stream the input N times over the resident index
     uint32_t ops_stride = 64;
     bool bam = false;                                                      // -o x.bam: BAM records in BGZF blocks (SNAPLib/Bam.cpp)
 };
@@ -1276,6 +1277,7 @@ int main(int argc, char **argv)
         else if (a == "-t" && i + 1 < argc) o.n_format = atoi(argv[++i]);  // host threads that format records (the reference's -t counts aligner threads)
         else if (a == "-tp" && i + 1 < argc) o.n_parse = atoi(argv[++i]);  // host threads that parse a plain FASTQ file
         else if (a == "-seqread") o.seqread = true;
+        else if (a == "-passes" && i + 1 < argc) o.passes = atoi(argv[++i]);   // (measurement: the whole FASTQ -> SAM stream N times over the resident index; the output is the last pass's)
         else die("option not supported: ", a.c_str());
     }
     if (out_path.empty()) die("-o <out.sam | out.bam> is required");
@@ -1341,6 +1343,14 @@ int main(int argc, char **argv)
       if (o.n_format <= 0) { unsigned v = hc / 3; o.n_format = (int)(v < 4 ? 4 : (v > 64 ? 64 : v)); }
       if (o.n_parse <= 0) { unsigned v = hc / 8; o.n_parse = (int)(v < 2 ? 2 : (v > 24 ? 24 : v)); } }
 
+    if (o.passes < 1 || o.passes > 100) die("-passes must be in [1, 100]");
+    unsigned long long total = 0, mapped = 0;
+    bool use_map = false;
+    auto t_ready = std::chrono::steady_clock::now();
+    double s_load = 0.0;
+    std::vector<double> pass_s;
+    for (int pass = 0; pass < o.passes; pass++) {
+    total = 0; mapped = 0;
     const std::string partial_path = out_path + ".partial";
     FILE *out = fopen(partial_path.c_str(), "wb");
     if (!out) die("cannot create ", partial_path.c_str());
@@ -1372,7 +1382,8 @@ int main(int argc, char **argv)
         } else if (fwrite(text.data(), 1, text.size(), out) != text.size()) die("write error on ", out_path.c_str());
     }
 
-    const auto t_ready = std::chrono::steady_clock::now();                  // the index is resident, the contexts exist: the streaming part starts here
+    t_ready = std::chrono::steady_clock::now();                             // the index is resident, the contexts exist: the streaming part starts here
+    if (pass == 0) s_load = std::chrono::duration<double>(t_ready - t_process).count();
     // ---- the pipeline
     // single-end batches per GPU call: enough to make ~1 M reads, but never so many that the feeders of a small file have nothing to share
     size_t group = o.group ? o.group : (o.paired ? 1 : 8);
@@ -1381,12 +1392,11 @@ int main(int argc, char **argv)
     Queue<Work *> q_parsed(fctx.size() * (o.paired ? 2 : group + 2) + 2), q_aligned((size_t)o.n_format * 2 + 2 + group * fctx.size());
     std::mutex done_m; std::condition_variable done_cv; std::map<uint64_t, Work *> done;
     std::atomic<uint64_t> n_batches(0); std::atomic<bool> reader_done(false);
-    unsigned long long total = 0, mapped = 0;
 
     // ---- input: a plain FASTQ file is mapped, indexed by line count and parsed batch by batch by o.n_parse threads; gzip input, -seqread
     // and files whose lines do not come in fours go through the sequential reader
     MappedFastq mf, mf2;
-    bool use_map = !o.seqread && mf.open(fastq.c_str()) && (!o.paired || mf2.open(fastq2.c_str()));
+    use_map = !o.seqread && mf.open(fastq.c_str()) && (!o.paired || mf2.open(fastq2.c_str()));
     if (use_map) {
         const auto t0 = std::chrono::steady_clock::now();
         use_map = mf.index(o.n_parse) && (!o.paired || mf2.index(o.n_parse));
@@ -1500,6 +1510,9 @@ int main(int argc, char **argv)
     if (fclose(out) != 0) die("write error on ", out_path.c_str());
     if (rename(partial_path.c_str(), out_path.c_str()) != 0) die("cannot rename the finished output to ", out_path.c_str());
     g_partial_path.clear();
+    pass_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count());
+    if (o.passes > 1) fprintf(stderr, "snapgpu-sam: pass %d of %d: %llu reads in %.3f s = %.0f reads/s\n", pass + 1, o.passes, total, pass_s.back(), pass_s.back() > 0 ? (double)total / pass_s.back() : 0.0);
+    }
     for (size_t t = fctx.size(); t-- > 0;) {                                // sharers before the owner of the blobs they share
         for (int k = 2; k >= 0; k--) {
             snapgpu_ctx *c = fctx[t].c[k];
@@ -1511,13 +1524,18 @@ int main(int argc, char **argv)
     for (size_t g = primary.size(); g-- > 0;) snapgpu_destroy(primary[g]);
     fprintf(stderr, "snapgpu-sam: %llu reads, %llu mapped records, %d GPU(s) x %d feeder(s), %d formatter thread(s)\n", total, mapped, o.n_gpus, o.ctx_per_gpu, o.n_format);
     {   // (AlignerContext.cpp:489-543 prints reads/s over the alignment phase, the index load apart: the same split here)
-        const auto t_end = std::chrono::steady_clock::now();
-        const double s_load = std::chrono::duration<double>(t_ready - t_process).count(), s_stream = std::chrono::duration<double>(t_end - t_ready).count();
+        const double s_stream = pass_s.back();                              // (the last pass; with -passes N each pass printed its own line above)
         fprintf(stderr, "snapgpu-sam: index resident after %.2f s; FASTQ -> %s in %.2f s = %.0f reads/s (%s reader, %d parser thread(s))\n", s_load, o.bam ? "BAM" : "SAM", s_stream,
                 s_stream > 0 ? (double)total / s_stream : 0.0, use_map ? "mapped" : "sequential", use_map ? o.n_parse : 1);
-        if (getenv("SNAPGPU_SAM_VERBOSE"))
+        if (getenv("SNAPGPU_SAM_VERBOSE")) {
             fprintf(stderr, "snapgpu-sam: thread-seconds: parse %.2f | feeders: prepare %.2f, align call %.2f, records %.2f, SAM-fields call %.2f | format %.2f | write %.2f\n",
                     g_ns_parse.load() * 1e-9, g_ns_prep.load() * 1e-9, g_ns_align.load() * 1e-9, g_ns_mid.load() * 1e-9, g_ns_samcall.load() * 1e-9, g_ns_format.load() * 1e-9, g_ns_write.load() * 1e-9);
+            // the same per THREAD and per PASS: the wall time each stage would take alone with its threads (a stage near the pass's own time is the pipeline's limit)
+            const double np = (double)o.passes, nf = (double)fctx.size();
+            fprintf(stderr, "snapgpu-sam: wall per pass if alone: parse %.2f s (%d threads) | feeders (%d): prepare %.2f, align call %.2f, records %.2f, SAM-fields call %.2f | format %.2f s (%d threads) | write %.2f s (1 thread)\n",
+                    g_ns_parse.load() * 1e-9 / np / (use_map ? o.n_parse : 1), use_map ? o.n_parse : 1, (int)fctx.size(), g_ns_prep.load() * 1e-9 / np / nf, g_ns_align.load() * 1e-9 / np / nf,
+                    g_ns_mid.load() * 1e-9 / np / nf, g_ns_samcall.load() * 1e-9 / np / nf, g_ns_format.load() * 1e-9 / np / o.n_format, o.n_format, g_ns_write.load() * 1e-9 / np);
+        }
     }
     return 0;
 }

@@ -20,7 +20,11 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
     WaveShared *ws = (WaveShared *)(my + L.shared);
+#if defined(SNAPGPU_NO_REGDIR)
     Aligner<AGC, SEC, EXACT, TIMED, PLANES> al(a.ix, a.tab, a.cfg, ws);
+#else
+    Aligner<AGC, SEC, EXACT, TIMED, PLANES, true> al(a.ix, a.tab, a.cfg, ws);       // (REGDIR: the candidate table's directory in a vector register)
+#endif
     al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
     al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;
     al.gw = my + L.gw;

@@ -1003,7 +1003,14 @@ static int stream_files_to_device(const std::vector<LoadJob> &jobs, int device, 
         for (uint64_t o = 0; o < j.bytes; o += PIECE) slices.push_back(Slice{j.fd, j.file_off + o, j.dev + o, j.bytes - o < PIECE ? j.bytes - o : PIECE});
     int n_threads = 12;
     if (const char *e = getenv("SNAPGPU_LOAD_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) n_threads = v; }
-    if ((size_t)n_threads > slices.size()) n_threads = (int)(slices.size() ? slices.size() : 1);
+    uint64_t total_bytes = 0, largest = 0;
+    for (const Slice &sl : slices) { total_bytes += sl.n; if (sl.n > largest) largest = sl.n; }
+    {   // a small directory: no more threads (and page-locked pieces) than it has 64 MB of data for, pieces no larger than its largest slice
+        const uint64_t by_size = (total_bytes + PIECE - 1) / PIECE;
+        if ((uint64_t)n_threads > by_size) n_threads = (int)(by_size ? by_size : 1);
+    }
+    const size_t piece_bytes = (size_t)(((largest ? largest : 1) + 4095) & ~(uint64_t)4095);
+    const bool want_pin = !(getenv("SNAPGPU_LOAD_PIN") && atoi(getenv("SNAPGPU_LOAD_PIN")) == 0);
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
     std::mutex err_mu;
@@ -1012,8 +1019,8 @@ static int stream_files_to_device(const std::vector<LoadJob> &jobs, int device, 
         void *buf = nullptr;
         hipStream_t st = nullptr;
         bool pinned = false;
-        if (posix_memalign(&buf, 4096, (size_t)PIECE) != 0 || !buf) { failed = 1; return; }
-        pinned = hipHostRegister(buf, (size_t)PIECE, 0) == hipSuccess;            // (not page-locked: the copy still works, slower)
+        if (posix_memalign(&buf, 4096, piece_bytes) != 0 || !buf) { failed = 1; return; }
+        pinned = want_pin && hipHostRegister(buf, piece_bytes, 0) == hipSuccess;   // (not page-locked: the copy still works, slower)
         if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { failed = 1; if (pinned) (void)hipHostUnregister(buf); free(buf); return; }
         while (!failed.load()) {
             const size_t k = next.fetch_add(1);

@@ -377,7 +377,7 @@ def test_emu_native_tool_pins_its_group_buffers(emu, tmp_path):
     calls, left = int(line[0].split("calls")[1].split(",")[0]), int(line[0].rsplit(" ", 1)[1])
     assert calls >= 8 and left == 0, line[0]
     r = subprocess.run([TOOL, "single", index_dir, fastq, "-o", os.path.join(d, "y.sam"), "-b", "200"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                       stdin=subprocess.DEVNULL, timeout=1800, env=dict(env, SNAPGPU_SAM_PIN="0"))
+                       stdin=subprocess.DEVNULL, timeout=1800, env=dict(env, SNAPGPU_SAM_PIN="0", SNAPGPU_LOAD_PIN="0"))       # (neither the tool's buffers nor the index loader's pieces)
     assert r.returncode == 0 and b"hipHostRegister calls" not in r.stdout
 
 
