@@ -1325,7 +1325,13 @@ static __device__ __forceinline__ AGResult ag_dispatch_inl(
         if (ww < 0) return res;                                           // :325 / :890
         int num_vec, seg_len, num_seg;
         ag_dims(banded, pattern_len, ww, &num_vec, &seg_len, &num_seg);
-        if (num_seg * seg_len > 64 * AGC || num_vec > 1023 || num_seg > 255 ||
+        // AGC 4 and 6 (reads beyond ~170 bp): since round 6 these kernels keep THREE chunks of 64 positions in registers like AGC 3 -- every banded call with a
+        // band half-width up to 31 goes through the window forms below, whatever the pattern length, and what is left for the chunked register form are the
+        // unbanded calls (pattern shorter than 3 * (2w + 1)): at most 134 positions at -d 20; BASELINE configs[4] has none beyond 128 (scripts/emu_paired_stats.py) --
+        // and a call that needs more than 192 positions takes the LDS form of ag.h, which these contexts have the LDS for (ag_lds_bytes(RL)).  The kernels
+        // that used to carry 256 / 384 positions of H, H-1, E in VGPRs (128 / 256 VGPRs, 4 / 2 waves per SIMD) run at AGC 3's occupancy.
+        constexpr int CH = AGC > 3 ? 3 : AGC;
+        if (num_vec > 1023 || num_seg > 255 ||
             (size_t)text_len * (size_t)(((num_seg * seg_len + 63) >> 6) * 64) > ag_scratch_bytes(RL) ||
             (EXACT && (size_t)text_len * (size_t)(num_seg * seg_len) > ag_scratch_bytes(RL))) {
             __builtin_trap();                                             // host sizing bug: fail loudly
@@ -1340,6 +1346,7 @@ static __device__ __forceinline__ AGResult ag_dispatch_inl(
                 __atomic_fetch_add(&g_agform_stats[16 + f], (unsigned long long)tot_, __ATOMIC_RELAXED);
                 if (f == 6) { __atomic_fetch_add(&g_agform_stats[24 + ((tot_ + 63) >> 6)], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&g_agform_stats[32 + ((tot_ + 63) >> 6)], (unsigned long long)text_len, __ATOMIC_RELAXED); }
                 __atomic_fetch_add(&g_agform_stats[40 + (ww > 15 ? 15 : ww)], 1, __ATOMIC_RELAXED);
+                __atomic_fetch_add(&g_agform_stats[56 + (ww >= 32 ? 1 : 0) + (tot_ > 192 ? 2 : 0) + (tot_ > 256 ? 2 : 0)], 1, __ATOMIC_RELAXED);     // [56] w < 32 && tot <= 192 ... [61] w >= 32 && tot > 256
             }
         }
 #endif
@@ -1354,17 +1361,23 @@ static __device__ __forceinline__ AGResult ag_dispatch_inl(
             return ag_banded_win2<EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                          lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
 #endif
+        if (num_seg * seg_len > 64 * CH) {
+            if constexpr (AGC > 3)
+                return ag_compute<EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
+                                         lds_rows, bt_scratch, RL, tab, bt_tag);
+            else __builtin_trap();                                        // host sizing bug: fail loudly
+        }
         if (banded)
-            return ag_compute_reg<AGC, true, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                                    lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
+            return ag_compute_reg<CH, true, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                                   lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
         if (num_seg * seg_len <= 64 && prm.gap_open > 0)        // short pattern (e.g. the read's head before an early seed): the window form's row, band = everything
             return ag_banded_win<EXACT, true>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                               lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
         if (num_seg * seg_len <= 64)            // ... with a zero gap-open penalty: the chunked form with one chunk
             return ag_compute_reg<1, false, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
                                                    lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
-        return ag_compute_reg<AGC, false, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
-                                                 lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
+        return ag_compute_reg<CH, false, EXACT>(dir, prm, P, Q, pattern_len, T, text_len, ww, score_init, is_rc, use_clipping,
+                                                lds_rows, bt_scratch, tab, num_vec, seg_len, num_seg, (uint32_t)ag_scratch_bytes(RL), bt_tag);
     } else {
         return ag_compute<EXACT>(banded, dir, prm, P, Q, pattern_len, T, text_len, w, score_init, is_rc, use_clipping,
                                  lds_rows, bt_scratch, RL, tab, bt_tag);

@@ -50,6 +50,7 @@
 static std::string g_partial_path;
 // where the host threads' time goes (SNAPGPU_SAM_VERBOSE=1 prints it): nanoseconds summed over the threads of a kind
 static std::atomic<unsigned long long> g_ns_prep(0), g_ns_align(0), g_ns_mid(0), g_ns_samcall(0), g_ns_format(0), g_ns_write(0), g_ns_parse(0);
+static std::atomic<unsigned long long> g_ns_wait_in(0), g_ns_wait_out(0), g_ns_wait_writer(0);      // feeders waiting for parsed batches / for room behind them; the writer waiting for the next batch in order
 struct StageTimer {
     std::atomic<unsigned long long> &acc; std::chrono::steady_clock::time_point t0;
     explicit StageTimer(std::atomic<unsigned long long> &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
@@ -1473,9 +1474,9 @@ int main(int argc, char **argv)
                 GroupBuf gb; std::vector<Work *> ws;
                 for (;;) {
                     ws.clear();
-                    if (q_parsed.pop_upto(ws, group, std::chrono::milliseconds(20)) == 0) break;
+                    { StageTimer st(g_ns_wait_in); if (q_parsed.pop_upto(ws, group, std::chrono::milliseconds(20)) == 0) break; }
                     gpu_single_group(o, fctx[t], ws, gb);
-                    for (Work *w : ws) q_aligned.push(w);
+                    { StageTimer st(g_ns_wait_out); for (Work *w : ws) q_aligned.push(w); }
                 }
             }
             if (--feeders_left == 0) q_aligned.close();
@@ -1492,6 +1493,7 @@ int main(int argc, char **argv)
     for (uint64_t next = 0;; next++) {                                      // the writer: batches in input order
         Work *w = NULL;
         {
+            StageTimer st(g_ns_wait_writer);
             std::unique_lock<std::mutex> l(done_m);
             done_cv.wait(l, [&] { return done.count(next) || (reader_done && next >= n_batches); });
             if (!done.count(next)) break;
@@ -1532,6 +1534,8 @@ int main(int argc, char **argv)
                     g_ns_parse.load() * 1e-9, g_ns_prep.load() * 1e-9, g_ns_align.load() * 1e-9, g_ns_mid.load() * 1e-9, g_ns_samcall.load() * 1e-9, g_ns_format.load() * 1e-9, g_ns_write.load() * 1e-9);
             // the same per THREAD and per PASS: the wall time each stage would take alone with its threads (a stage near the pass's own time is the pipeline's limit)
             const double np = (double)o.passes, nf = (double)fctx.size();
+            fprintf(stderr, "snapgpu-sam: waiting, per pass: each feeder %.2f s for parsed batches and %.2f s for room in the formatters' queue; the writer %.2f s for the next batch in order\n",
+                    g_ns_wait_in.load() * 1e-9 / np / nf, g_ns_wait_out.load() * 1e-9 / np / nf, g_ns_wait_writer.load() * 1e-9 / np);
             fprintf(stderr, "snapgpu-sam: wall per pass if alone: parse %.2f s (%d threads) | feeders (%d): prepare %.2f, align call %.2f, records %.2f, SAM-fields call %.2f | format %.2f s (%d threads) | write %.2f s (1 thread)\n",
                     g_ns_parse.load() * 1e-9 / np / (use_map ? o.n_parse : 1), use_map ? o.n_parse : 1, (int)fctx.size(), g_ns_prep.load() * 1e-9 / np / nf, g_ns_align.load() * 1e-9 / np / nf,
                     g_ns_mid.load() * 1e-9 / np / nf, g_ns_samcall.load() * 1e-9 / np / nf, g_ns_format.load() * 1e-9 / np / o.n_format, o.n_format, g_ns_write.load() * 1e-9 / np);

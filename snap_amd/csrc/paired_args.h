@@ -13,7 +13,7 @@
 // i.e. the kernel is bound by its scratch / slab traffic, not by latency hiding, but a third wave per SIMD gives overlapping launches room.
 // 3 for that variant (the default runs three feeders); the variants with more affine-gap state in registers and the LDS form stay at 2.
 #ifndef SNAPGPU_PAIRED_WAVES_PER_SIMD
-#define SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 3 : 2)
+#define SNAPGPU_PAIRED_WAVES_PER_SIMD(AGC) ((AGC) != 0 ? 3 : 2)     // (round 6: AGC 4 / 6 keep three chunks in registers like AGC 3, ag_win.h: ag_dispatch_inl)
 #endif
 
 // PE_FRAME_BYTES: the wave's FRAME -- the three objects of the kernel (the single-end Aligner, DevPL, PairedCore: wave-uniform state, one pair

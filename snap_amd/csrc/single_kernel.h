@@ -7,7 +7,7 @@
 // of cold state spilled): measured 3.96 M reads/s against 3.74-3.80 M at 4 and 3.79 M at 5 waves (profiles/r01g).  The variants
 // with more affine-gap state in registers stay at 4 (128 VGPRs); their LDS footprint caps occupancy first anyway.
 #ifndef SNAPGPU_WAVES_PER_SIMD
-#define SNAPGPU_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 6 : 4)
+#define SNAPGPU_WAVES_PER_SIMD(AGC) ((AGC) != 0 ? 6 : 4)            // (round 6: AGC 4 / 6 keep three chunks in registers like AGC 3, ag_win.h: ag_dispatch_inl)
 #endif
 template <int AGC, bool SEC, bool EXACT = false, bool TIMED = false, bool PLANES = false>
 __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_single(AlignArgs a)
@@ -20,10 +20,13 @@ __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_sing
     uint8_t *my = lds + (size_t)wave_in_block * L.total;
 
     WaveShared *ws = (WaveShared *)(my + L.shared);
-#if defined(SNAPGPU_NO_REGDIR)
+#if !defined(SNAPGPU_REGDIR)
     Aligner<AGC, SEC, EXACT, TIMED, PLANES> al(a.ix, a.tab, a.cfg, ws);
 #else
-    Aligner<AGC, SEC, EXACT, TIMED, PLANES, true> al(a.ix, a.tab, a.cfg, ws);       // (REGDIR: the candidate table's directory in a vector register)
+    // (measurement builds: the candidate table's directory in a vector register -- align_single.h: REGDIR.  It takes findElement's two dependent HBM loads
+    //  away and was 1.5 % SLOWER on the bench batch, 15.0 against 15.3 M reads/s, profiles/r06f: five more spilled VGPRs, and the loads it removes are not what
+    //  the hit phase waits for)
+    Aligner<AGC, SEC, EXACT, TIMED, PLANES, true> al(a.ix, a.tab, a.cfg, ws);
 #endif
     al.rd[0] = my + L.rd0; al.rd[1] = my + L.rd1;
     al.ql[0] = my + L.ql0; al.ql[1] = my + L.ql1;

@@ -179,7 +179,8 @@ def check_affine_gap_wide_bands(aligner, n=1200, seed=1001, max_len=380):
     rng = np.random.default_rng(seed)
     texts, pats, quals, ws, sis, rcs, bands, clips = [], [], [], [], [], [], [], []
     for _ in range(n):
-        w = int(rng.integers(13, 32))
+        big = _ % 5 == 4                  # a fifth of the problems beyond the window forms: w 32 .. 45 (banded, segments of 72 .. 96 positions) -- more than
+        w = int(rng.integers(32, 46)) if big else int(rng.integers(13, 32))      # 192 positions: the LDS form inside the 256- / 384-position instantiations (round 6)
         L = int(rng.integers(3 * (2 * w + 1), max(3 * (2 * w + 1) + 1, max_len)))
         t = bytes(rng.choice(list(b"ACGT"), size=L + 80).astype(np.uint8))
         p = bytearray(t[:L])
@@ -197,18 +198,22 @@ def check_affine_gap_wide_bands(aligner, n=1200, seed=1001, max_len=380):
         texts.append(t[:len(p) + w]); pats.append(p)
         quals.append(bytes(rng.integers(35, 74, size=len(p), dtype=np.uint8)))
         ws.append(w); sis.append(int(rng.integers(20, 400))); rcs.append(int(rng.integers(0, 2)))
-        bands.append(1); clips.append(int(rng.integers(0, 3)))
+        bands.append(0 if (big and _ % 10 == 9) else 1); clips.append(int(rng.integers(0, 3)))        # (and some of those as full, unbanded problems)
     n_cmp = 0
     order = np.argsort([len(p) for p in pats], kind="stable")
     for lo, hi in ((0, 193), (193, 257), (257, 1 << 20)):                 # one call per instantiation of the batch kernel
-        sel = [int(i) for i in order if lo <= -(-len(pats[i]) // (-(-(2 * ws[i] + 1) // 8) * 8)) * (-(-(2 * ws[i] + 1) // 8) * 8) < hi]
+        def positions(i):                 # num_seg * seg_len of the problem (ag_dims)
+            if not bands[i]: return -(-len(pats[i]) // 8) * 8
+            sl = -(-(2 * ws[i] + 1) // 8) * 8
+            return -(-len(pats[i]) // sl) * sl
+        sel = [int(i) for i in order if lo <= positions(i) < hi]
         if not sel: continue
         for d in (1, -1):
             tt = [texts[i] if d == 1 else texts[i][::-1] for i in sel]
             got = aligner.computeScoreAffine(d, tt, [pats[i] for i in sel], [quals[i] for i in sel], [ws[i] for i in sel], [sis[i] for i in sel],
                                              [rcs[i] for i in sel], [bands[i] for i in sel], [clips[i] for i in sel])
             for x, i in enumerate(sel):
-                o = util.oracle_ag(d, 1, tt[x], pats[i], quals[i], ws[i], sis[i], rcs[i], clips[i])
+                o = util.oracle_ag(d, bands[i], tt[x], pats[i], quals[i], ws[i], sis[i], rcs[i], clips[i])
                 if o["stale_reads"]:
                     continue
                 n_cmp += 1
