@@ -1350,6 +1350,10 @@ int main(int argc, char **argv)
     auto t_ready = std::chrono::steady_clock::now();
     double s_load = 0.0;
     std::vector<double> pass_s;
+    // (a written batch is freed by its own thread: ~100 MB of vectors per batch go back to the kernel page by page, 15 - 20 ms each, and on the writer's
+    //  thread -- the one stage that is serial -- that was half of a pass: profiles/r06g)
+    Queue<Work *> q_dead(4096);
+    std::thread reaper([&] { Work *w; while (q_dead.pop(w)) delete w; });
     for (int pass = 0; pass < o.passes; pass++) {
     total = 0; mapped = 0;
     const std::string partial_path = out_path + ".partial";
@@ -1501,7 +1505,7 @@ int main(int argc, char **argv)
         }
         { StageTimer st(g_ns_write); if (fwrite(w->text.data(), 1, w->text.size(), out) != w->text.size()) die("write error on ", out_path.c_str()); }
         total += w->b.n(); mapped += w->mapped;
-        delete w;
+        q_dead.push(w);
     }
     if (reader.joinable()) reader.join();
     for (auto &t : parsers) t.join();
@@ -1515,6 +1519,7 @@ int main(int argc, char **argv)
     pass_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count());
     if (o.passes > 1) fprintf(stderr, "snapgpu-sam: pass %d of %d: %llu reads in %.3f s = %.0f reads/s\n", pass + 1, o.passes, total, pass_s.back(), pass_s.back() > 0 ? (double)total / pass_s.back() : 0.0);
     }
+    q_dead.close(); reaper.join();
     for (size_t t = fctx.size(); t-- > 0;) {                                // sharers before the owner of the blobs they share
         for (int k = 2; k >= 0; k--) {
             snapgpu_ctx *c = fctx[t].c[k];

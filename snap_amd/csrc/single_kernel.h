@@ -7,7 +7,7 @@
 // of cold state spilled): measured 3.96 M reads/s against 3.74-3.80 M at 4 and 3.79 M at 5 waves (profiles/r01g).  The variants
 // with more affine-gap state in registers stay at 4 (128 VGPRs); their LDS footprint caps occupancy first anyway.
 #ifndef SNAPGPU_WAVES_PER_SIMD
-#define SNAPGPU_WAVES_PER_SIMD(AGC) ((AGC) != 0 ? 6 : 4)            // (round 6: AGC 4 / 6 keep three chunks in registers like AGC 3, ag_win.h: ag_dispatch_inl)
+#define SNAPGPU_WAVES_PER_SIMD(AGC) ((AGC) == 3 ? 6 : 4)            // (AGC 4 / 6 -- which since round 6 keep three chunks in registers like AGC 3 -- at 6: 250 bp / -d 20 reads 5.10 against 5.29 M reads/s at 4, profiles/r06g)
 #endif
 template <int AGC, bool SEC, bool EXACT = false, bool TIMED = false, bool PLANES = false>
 __global__ __launch_bounds__(256, SNAPGPU_WAVES_PER_SIMD(AGC)) void k_align_single(AlignArgs a)

@@ -805,7 +805,7 @@ extern "C" int snapgpu_create(const snapgpu_index_view *idx, const snapgpu_param
     c.lds_per_wave = L.total;
 
     // waves in flight: a fixed number per CU, each with its own scratch slab
-    int waves_per_cu = ctx->ag_variant != 0 ? 24 : 16;               // 4 SIMDs x the kernel's waves per SIMD (single_kernel.h)
+    int waves_per_cu = ctx->ag_variant == 3 ? 24 : 16;               // 4 SIMDs x the kernel's waves per SIMD (single_kernel.h)
     if (const char *e = getenv("SNAPGPU_WAVES_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 32) waves_per_cu = v; }
     // LDS limit: 160 KiB per CU
     while (waves_per_cu > 1 && (size_t)waves_per_cu * L.total > 160 * 1024) waves_per_cu--;
