@@ -293,6 +293,28 @@ struct Work {                                // a batch on its way through the p
     std::string text;                        // the formatted records (BAM: BGZF blocks)
     bool bam = false;
     unsigned long long mapped = 0;
+    // as newly constructed, but every vector keeps its capacity (WorkPool)
+    void reset() {
+        b.clear(); b.seq = 0;
+        rec_read.clear(); rec_secondary.clear(); flag.clear(); contig.clear(); mapq.clear(); n_ops.clear(); nm.clear(); rnext.clear(); first_written.clear();
+        pos.clear(); pnext.clear(); tlen.clear(); ops.clear(); ops_stride = 64;
+        emit.clear(); pu_pair.clear(); pu_secondary.clear(); su_read.clear();
+        s_flag.clear(); s_contig.clear(); s_mapq.clear(); s_n_ops.clear(); s_nm.clear(); s_pos.clear(); s_ops.clear(); s_ops_stride = 64;
+        prepared = false; front_clip.clear(); data_len.clear(); to_align.clear(); ab.clear(); aq.clear(); ao.clear(); skip.clear();
+        max_len = 0; text.clear(); bam = false; mapped = 0;
+    }
+};
+
+// Batches are RECYCLED: a batch of 131 072 reads is ~100 MB of vectors (read text, record fields, cigar operations, the formatted records), and allocating
+// them anew for every batch meant ~15 GB of fresh pages per 20 M reads -- page faults in the parser / feeder / formatter threads and an munmap per vector
+// when the batch was freed, all serialised on the process's address-space lock (freeing on the writer's thread cost half a pass; freeing on a thread of its
+// own slowed the feeders' calls by a half instead: profiles/r06g, r06h).  A recycled batch is as newly constructed except for its vectors' capacity.
+struct WorkPool {
+    std::mutex m; std::vector<Work *> free_list; size_t cap;
+    explicit WorkPool(size_t c) : cap(c) {}
+    Work *get() { { std::lock_guard<std::mutex> l(m); if (!free_list.empty()) { Work *w = free_list.back(); free_list.pop_back(); return w; } } return new Work(); }
+    void put(Work *w) { w->reset(); { std::lock_guard<std::mutex> l(m); if (free_list.size() < cap) { free_list.push_back(w); return; } } delete w; }
+    ~WorkPool() { for (Work *w : free_list) delete w; }
 };
 
 template <class T> struct Queue {            // bounded multi-producer multi-consumer queue; close() lets consumers drain and stop
@@ -1350,10 +1372,7 @@ int main(int argc, char **argv)
     auto t_ready = std::chrono::steady_clock::now();
     double s_load = 0.0;
     std::vector<double> pass_s;
-    // (a written batch is freed by its own thread: ~100 MB of vectors per batch go back to the kernel page by page, 15 - 20 ms each, and on the writer's
-    //  thread -- the one stage that is serial -- that was half of a pass: profiles/r06g)
-    Queue<Work *> q_dead(4096);
-    std::thread reaper([&] { Work *w; while (q_dead.pop(w)) delete w; });
+    WorkPool pool(256);
     for (int pass = 0; pass < o.passes; pass++) {
     total = 0; mapped = 0;
     const std::string partial_path = out_path + ".partial";
@@ -1429,7 +1448,7 @@ int main(int argc, char **argv)
                     const uint64_t u = next_unit->fetch_add(1);
                     if (u >= n_units) break;
                     const uint64_t r0 = u * per_batch, r1 = r0 + per_batch < n_records ? r0 + per_batch : n_records;
-                    Work *w = new Work();
+                    Work *w = pool.get();
                     StageTimer *pt = new StageTimer(g_ns_parse);
                     w->b.clear(); w->b.seq = u; w->bam = o.bam;
                     size_t at = mf.line_start(4 * r0), at2 = o.paired ? mf2.line_start(4 * r0) : 0;
@@ -1451,14 +1470,14 @@ int main(int argc, char **argv)
         uint64_t seq = 0;
         bool eof = false;
         while (!eof) {
-            Work *w = new Work();
+            Work *w = pool.get();
             w->b.clear(); w->b.seq = seq; w->bam = o.bam;
             while (w->b.n() < o.batch_reads) {
                 if (!next_read(in, w->b, o.p.max_read_len)) { eof = true; break; }
                 if (o.paired && !next_read(in2, w->b, o.p.max_read_len)) die("the second FASTQ file has fewer reads than the first");
             }
             if (eof && o.paired) { Batch probe; probe.clear(); if (next_read(in2, probe, o.p.max_read_len)) die("the second FASTQ file has more reads than the first"); }
-            if (w->b.n() == 0) { delete w; break; }
+            if (w->b.n() == 0) { pool.put(w); break; }
             seq++;
             q_parsed.push(w);
         }
@@ -1505,7 +1524,7 @@ int main(int argc, char **argv)
         }
         { StageTimer st(g_ns_write); if (fwrite(w->text.data(), 1, w->text.size(), out) != w->text.size()) die("write error on ", out_path.c_str()); }
         total += w->b.n(); mapped += w->mapped;
-        q_dead.push(w);
+        pool.put(w);
     }
     if (reader.joinable()) reader.join();
     for (auto &t : parsers) t.join();
@@ -1519,7 +1538,6 @@ int main(int argc, char **argv)
     pass_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count());
     if (o.passes > 1) fprintf(stderr, "snapgpu-sam: pass %d of %d: %llu reads in %.3f s = %.0f reads/s\n", pass + 1, o.passes, total, pass_s.back(), pass_s.back() > 0 ? (double)total / pass_s.back() : 0.0);
     }
-    q_dead.close(); reaper.join();
     for (size_t t = fctx.size(); t-- > 0;) {                                // sharers before the owner of the blobs they share
         for (int k = 2; k >= 0; k--) {
             snapgpu_ctx *c = fctx[t].c[k];
