@@ -141,6 +141,10 @@ def main():
     unit, asm_flags, src = "single_sec_k3", ["-DSINGLE_AGC=3"], "single_sec_k.hip"
     kern = ["k_align_singleILi3ELb0ELb1ELb0ELb0EE", "lv_compute_fn", "ag_dispatch_fnILi3ELb1E"]
     gfn = None
+    if mode.endswith("paired"):          # the paired-end kernel of the read length's class (2 x 150: AGC 3; 2 x 250: AGC 4), fast form
+        agc = 3 if read_len <= 170 else 6
+        unit, asm_flags, src = "paired_k%d" % agc, ["-DPAIRED_AGC=%d" % agc], "paired_k.hip"
+        kern = ["k_align_pairedILi%dELb0ELb0E" % agc, "lv_compute_fn", "ag_dispatch_fnILi%dELb0E" % agc]
     if mode.startswith("run-"):          # the child: run the workload on the coverage build; the counters are written when the process exits
         import tests.emu.build as eb
         os.makedirs(COV, exist_ok=True)
@@ -180,6 +184,16 @@ def main():
             offs = np.arange(n + 1, dtype=np.uint64) * read_len
             a.AlignRead(rd["bases"], rd["quals"], offs)
             print("ran %d reads; counters: %s" % (n, a.counters()))
+            a.close()
+        else:
+            from snap_amd.aligner import ChimericPairedEndAligner
+            if read_len > 170:
+                pr = synth.make_pairs(20260925, contigs, n, read_len, insert_mean=600, insert_sd=80, long_indel_frac=0.002)
+            else:
+                pr = synth.make_pairs(20260925, contigs, n, read_len)
+            a = ChimericPairedEndAligner(ix, abi.default_params(max_k=max_k, max_read_len=((read_len + 31) // 32) * 32), abi.default_paired_params())
+            a.align(pr["bases"].reshape(-1), pr["quals"].reshape(-1), pr["offsets"])
+            print("ran %d pairs; counters: %s" % (n, a.counters()))
             a.close()
         return
     subprocess.run([sys.executable, os.path.abspath(__file__), "run-" + mode] + sys.argv[2:], check=True)

@@ -56,6 +56,9 @@ def main():
         if fs[f]:
             print("  %-52s calls %7d (%.2f / pair)  rows %9d (%.0f / call)  positions / call %.0f" % (nm, fs[f], fs[f] / n, fs[8 + f], fs[8 + f] / fs[f], fs[16 + f] / fs[f]))
     print("  unbanded > 64 by 64-position chunks: " + "  ".join("%d chunks: %d calls, %d rows" % (c, fs[24 + c], fs[32 + c]) for c in range(8) if fs[24 + c]))
+    aw = (C.c_ulonglong * 64).in_dll(h, "g_agwin_stats")
+    if aw[5]:
+        print("  wide window (win2): %d rows; lazy-F rounds per row: first segment %.2f, second segment %.2f; second segments answered in closed form: %d (%.0f %% of rows)" % (aw[5], aw[6] / aw[5], aw[8] / aw[5], aw[7], 100.0 * aw[7] / aw[5]))
     print("  calls by (w >= 32, positions > 192, > 256): " + " ".join("%s:%d" % (("w<32" if not (k & 1) else "w>=32") + ("/<=192" if k < 2 else ("/<=256" if k < 4 else "/>256")), fs[56 + k]) for k in range(6)))
     print("  calls by band half-width w (15 = 15 and above): " + " ".join("%d:%d" % (w, fs[40 + w]) for w in range(16) if fs[40 + w]))
 

@@ -1085,6 +1085,9 @@ static __device__ __forceinline__ AGResult ag_banded_win2(
     for (int i = 0; i < text_len; i++) {
         if (__builtin_expect((i & 63) == 0, 0)) tcv = i + lane < text_len ? (int)tcode[i + lane] : 0;
         const int tb = __builtin_amdgcn_readlane(tcv, i & 63);
+#if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
+        { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[5], 1, __ATOMIC_RELAXED); }
+#endif
         be = be + 1 < pe1 ? be + 1 : pe1;
         const int band_end = be;
         if (__builtin_expect(i >= slide_at, 0)) {               // slide ((jbase + 1) * seg_len <= band_beg): segment jbase leaves, B becomes A, the next segment enters fresh
@@ -1150,7 +1153,30 @@ static __device__ __forceinline__ AGResult ag_banded_win2(
             int src7 = nk - 1 + 7 * num_vec;                        // stripe 7 - r's last vector
             int src_addr = (nk - 1 + (l - 1) * num_vec) * 4;        // ds_bpermute byte address: the last vector of the stripe r + 1 to the left
             int ls = l - 1;
+            if (!keep_X && gap_open > gap_ext) {
+                // The second segment usually runs all seven rounds: its stripes 1 .. 7 lie beyond the band, hold small stale H, and the F that entered
+                // stripe 0 runs through all of them -- what every cell then ends up with is that one flow, e0 (the F leaving stripe 0) decayed by the cells
+                // in between.  The two tests of ag_banded_win say when that is so (its notes have the argument): (A) no later stripe end beats e0 at its
+                // own origin, (B) the flow is above T_fp = max(H - open, ext) in every cell of stripes 1 .. 7 -- then the seven rounds are this select.
+                const int e0 = __builtin_amdgcn_readlane(endv, nk - 1);
+                const int wv = endv + l * decay_step;
+                const int g0 = e0 - ((l - 1) * nk + k) * gap_ext;
+                int T_fp = Hm - (gap_open - gap_ext); if (T_fp < gap_ext) T_fp = gap_ext;
+                const bool insL = inseg && l >= 1;
+                if (BALLOT(insL && l <= 6 && k == nk - 1 && wv > e0) == 0ull && BALLOT(insL && !(g0 > T_fp)) == 0ull) {
+#if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
+                    { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[7], 1, __ATOMIC_RELAXED); }
+#endif
+                    btr |= (insL && g0 > Hm) ? 2 : 0;
+                    btr |= insL ? 32 : 0;
+                    Hm = (insL && g0 > Hm) ? g0 : Hm;
+                    return;
+                }
+            }
             for (int r = 0; r < 7; r++, decay += decay_step, src7 -= num_vec, src_addr -= num_vec * 4, ls--) {
+#if defined(SNAPGPU_WAVE_EMU) && defined(SNAPGPU_AG_WIN_STATS)
+                { extern unsigned long long g_agwin_stats[64]; if (lane == 0) __atomic_fetch_add(&g_agwin_stats[keep_X ? 6 : 8], 1, __ATOMIC_RELAXED); }
+#endif
                 if (keep_X) {
                     const int f7 = __builtin_amdgcn_readlane(endv, src7) - decay;
                     if (f7 > X) X = f7;

@@ -1513,6 +1513,8 @@ int main(int argc, char **argv)
                 std::lock_guard<std::mutex> l(done_m); done[w->b.seq] = w; done_cv.notify_all();
             }
         });
+    const auto t_pipe = std::chrono::steady_clock::now();
+    double t_first_s = -1.0;
     for (uint64_t next = 0;; next++) {                                      // the writer: batches in input order
         Work *w = NULL;
         {
@@ -1523,19 +1525,26 @@ int main(int argc, char **argv)
             w = done[next]; done.erase(next);
         }
         { StageTimer st(g_ns_write); if (fwrite(w->text.data(), 1, w->text.size(), out) != w->text.size()) die("write error on ", out_path.c_str()); }
+        if (t_first_s < 0) t_first_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count();
         total += w->b.n(); mapped += w->mapped;
         pool.put(w);
     }
+    const auto t_written = std::chrono::steady_clock::now();
     if (reader.joinable()) reader.join();
     for (auto &t : parsers) t.join();
     mf.close(); mf2.close();
     for (auto &t : feeders) t.join();
     for (auto &t : formatters) t.join();
+    const auto t_joined = std::chrono::steady_clock::now();
     if (o.bam) { std::string eof; bgzf_append(eof, "", 0); if (fwrite(eof.data(), 1, eof.size(), out) != eof.size()) die("write error on ", out_path.c_str()); }     // the empty end-of-file block
     if (fclose(out) != 0) die("write error on ", out_path.c_str());
     if (rename(partial_path.c_str(), out_path.c_str()) != 0) die("cannot rename the finished output to ", out_path.c_str());
     g_partial_path.clear();
     pass_s.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ready).count());
+    if (getenv("SNAPGPU_SAM_VERBOSE"))
+        fprintf(stderr, "snapgpu-sam: pass %d timeline: pipeline up at %.3f s, first batch written at %.3f s, last at %.3f s, threads joined at %.3f s, file closed and renamed at %.3f s\n", pass + 1,
+                std::chrono::duration<double>(t_pipe - t_ready).count(), t_first_s, std::chrono::duration<double>(t_written - t_ready).count(),
+                std::chrono::duration<double>(t_joined - t_ready).count(), pass_s.back());
     if (o.passes > 1) fprintf(stderr, "snapgpu-sam: pass %d of %d: %llu reads in %.3f s = %.0f reads/s\n", pass + 1, o.passes, total, pass_s.back(), pass_s.back() > 0 ? (double)total / pass_s.back() : 0.0);
     }
     for (size_t t = fctx.size(); t-- > 0;) {                                // sharers before the owner of the blobs they share
