@@ -52,6 +52,8 @@ void snapgpu_launch_single_sec_6(const AlignArgs *a, uint32_t blocks, size_t lds
 void snapgpu_launch_single_sec_0(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_3(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_0(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_exact_4(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_single_exact_6(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_exact_3_timed(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_single_3_timed(const AlignArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 // single_planes_k.hip: the instantiations that carry the plane Landau-Vishkin (SNAPGPU_LV_PLANES=1)

@@ -107,6 +107,8 @@ void snapgpu_launch_paired_sec_0(const PairedArgs *a, uint32_t blocks, size_t ld
 void snapgpu_launch_collect_flagged(snapgpu_paired_result *primary, uint32_t n, uint32_t *list, uint32_t *count, int stale, hipStream_t s);
 void snapgpu_launch_paired_exact_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_exact_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_paired_exact_4(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
+void snapgpu_launch_paired_exact_6(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_sec_exact_3(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 void snapgpu_launch_paired_sec_exact_0(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s);
 }

@@ -34,7 +34,10 @@ extern "C" void snapgpu_launch_collect_flagged(snapgpu_paired_result *primary, u
 }
 #endif
 
-#if PAIRED_AGC == 0 || PAIRED_AGC == 3     // exact replay of flagged pairs (paired_args.h: PairedArgs::persist): the 192-position register variant, or the LDS form
+// exact replay of flagged pairs (paired_args.h: PairedArgs::persist): every variant has its exact twin since round 6 -- AGC 4 / 6 are AGC 3's code plus the LDS form beyond 192
+// positions, and replaying a long-read batch's flagged pairs (the heavy ones, as a rule) through the LDS form alone took longer than the batch's main pass (profiles/r06y);
+// the secondary-results units exist for AGC 3 and 0 only
+#if !defined(PAIRED_SEC) || PAIRED_AGC == 0 || PAIRED_AGC == 3
 #ifdef PAIRED_SEC
 extern "C" void PE_CAT(snapgpu_launch_paired_sec_exact_, PAIRED_AGC)(const PairedArgs *a, uint32_t blocks, size_t lds_bytes, hipStream_t s)
 {

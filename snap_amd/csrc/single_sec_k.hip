@@ -21,8 +21,8 @@ extern "C" void SE_CAT(snapgpu_launch_single_sec_, SINGLE_AGC)(const AlignArgs *
     hipLaunchKernelGGL((k_align_single<SINGLE_AGC, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);
 }
 
-#if SINGLE_AGC == 0 || SINGLE_AGC == 3
-// exact replay of flagged reads (kernel_common.h: AlignArgs::flag_list): the 192-position register variant, or the LDS form for everything longer
+#if 1
+// exact replay of flagged reads (kernel_common.h: AlignArgs::flag_list): every variant has its exact twin since round 6 (AGC 4 / 6 are AGC 3's code plus the LDS form beyond 192 positions)
 extern "C" void SE_CAT(snapgpu_launch_single_exact_, SINGLE_AGC)(const AlignArgs *a, int sec, uint32_t blocks, size_t lds_bytes, hipStream_t s)
 {
     if (sec) hipLaunchKernelGGL((k_align_single<SINGLE_AGC, true, true>), dim3(blocks), dim3(256), lds_bytes, s, *a);

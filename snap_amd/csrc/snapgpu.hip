@@ -2194,6 +2194,8 @@ static int launch_align(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const
         if (planes_k) { if (ctx->ag_variant == 3) snapgpu_launch_single_exact_planes_3(&x, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
                         else snapgpu_launch_single_exact_planes_0(&x, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s); }
         else if (ctx->ag_variant == 3) snapgpu_launch_single_exact_3(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
+        else if (ctx->ag_variant == 4) snapgpu_launch_single_exact_4(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
+        else if (ctx->ag_variant == 6) snapgpu_launch_single_exact_6(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
         else snapgpu_launch_single_exact_0(&x, d_n_secondary ? 1 : 0, ctx->exact_slots / 4, 4 * ctx->cfg.lds_per_wave, s);
         HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
     }
@@ -2601,6 +2603,16 @@ struct PairedSecOut {          // device buffers of a call that wants secondary 
     void *single_secondary; uint32_t single_stride; void *n_single_secondary;
 };
 
+// the exact twin of the context's paired-end kernel variant (paired_k.hip)
+static void launch_paired_exact(int variant, const PairedArgs *x, uint32_t blocks, size_t lds, hipStream_t s) {
+    switch (variant) {
+    case 3:  snapgpu_launch_paired_exact_3(x, blocks, lds, s); break;
+    case 4:  snapgpu_launch_paired_exact_4(x, blocks, lds, s); break;
+    case 6:  snapgpu_launch_paired_exact_6(x, blocks, lds, s); break;
+    default: snapgpu_launch_paired_exact_0(x, blocks, lds, s); break;
+    }
+}
+
 static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals, const void *d_offsets,
                          void *d_primary, void *d_first_alt, hipStream_t s, const PairedSecOut *so = nullptr)
 {
@@ -2699,7 +2711,7 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         if (blocks + xr_blocks > all_blocks && all_blocks > 2 * xr_blocks) blocks = all_blocks - xr_blocks;
     }
     auto launch_beside = [&](hipStream_t st) {
-        if (ctx->p_ag_variant == 3) snapgpu_launch_paired_exact_3(&xr, xr_blocks, lds, st); else snapgpu_launch_paired_exact_0(&xr, xr_blocks, lds, st);
+        launch_paired_exact(ctx->p_ag_variant, &xr, xr_blocks, lds, st);
     };
 #ifndef SNAPGPU_WAVE_EMU
     if (beside) {                      // fork: the exact kernel goes first, on its own stream, behind everything `s` has been given so far
@@ -2739,8 +2751,8 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
             x.help = nullptr; x.n_help = 0; x.help_done = nullptr; x.help_min = 0xffffffffu;
             uint32_t slots = so ? ctx->p_sec_big_slots : ctx->p_big_slots;
             if (slots > ctx->pexact_slots) slots = ctx->pexact_slots;
-            if (ctx->p_ag_variant == 3) { if (so) snapgpu_launch_paired_sec_exact_3(&x, slots / 4, lds, s); else snapgpu_launch_paired_exact_3(&x, slots / 4, lds, s); }
-            else { if (so) snapgpu_launch_paired_sec_exact_0(&x, slots / 4, lds, s); else snapgpu_launch_paired_exact_0(&x, slots / 4, lds, s); }
+            if (so) { if (ctx->p_ag_variant == 3) snapgpu_launch_paired_sec_exact_3(&x, slots / 4, lds, s); else snapgpu_launch_paired_sec_exact_0(&x, slots / 4, lds, s); }
+            else launch_paired_exact(ctx->p_ag_variant, &x, slots / 4, lds, s);
         }
     }
     HIPCHK(ctx, hipGetLastError(), SNAPGPU_E_LAUNCH);
