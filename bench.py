@@ -217,7 +217,7 @@ def parse_args(argv=None):
     ap.add_argument("--standin-mb", type=int, default=256, help="genome size of the extra `genome_256mb` leg (tests shrink it)")
     ap.add_argument("--standin-leg", action="store_true", help="add the `genome_256mb` leg (the line of rounds 1-3 on the 256 Mb stand-in; in the default run until round 4)")
     ap.add_argument("--no-c5-leg", action="store_true", help="do not add the `c5` leg (configs[4] on one GPU: 2 x 250 bp pairs, -d 20, insert N(600, 80^2), 0.2 % long indels)")
-    ap.add_argument("--c5-leg-steps", type=int, default=6)
+    ap.add_argument("--c5-leg-steps", type=int, default=12)
     ap.add_argument("--c5-reads", type=int, default=200_000, help="reads per step of the c5 leg")
     ap.add_argument("--no-e2e-leg", action="store_true", help="do not add the `e2e` leg (FASTQ -> SAM through snap_amd/snapgpu-sam)")
     ap.add_argument("--e2e-reads", type=int, default=20_000_000, help="reads of the e2e leg's FASTQ")
