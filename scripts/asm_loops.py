@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Static instruction mix of the loops of one function in a gfx950 assembly listing (hipcc --cuda-device-only -S): every backward branch
 closes a loop; per loop the number of vector / scalar / LDS / memory / scratch / lane-spill instructions in its body.  Used to see which
-loop bodies the scalar unit pays for.
+loop bodies the scalar unit pays for (HISTORY.md section 17).
 
     python scripts/asm_loops.py file.s <function-name-substring> [min-body-size]
 """

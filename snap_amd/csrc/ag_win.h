@@ -556,6 +556,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
     int l0 = score_init, hi = score_init - gap_open > 0 ? score_init - gap_open : 0;
     int nk0 = 0, nk1 = 0, f7_lane = 0, e0_lane = 0; bool two = false;
     int tcv = 0;                                                 // base codes of 64 text rows, lane j: row (i & ~63) + j
+    int row_off = 0;                                             // EXACT: i * nv_tot8, the row's offset in the reference object's array
 
     // open - ext, in a VECTOR register on purpose: every lazy-F round subtracts it, the row loop has more wave-uniform values than SGPRs, and as an
     // SGPR it was the one the allocator spilled -- a v_readlane per round to get it back.
@@ -773,7 +774,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                         if constexpr (r < 6) {
                             const int tq = u_cur - d_open;
                             Tr = tq > Tr ? tq : Tr;
-                            if (s == 0) {                                            // (kept whether or not there is a second segment: X0 is only read when there is)
+                            if (s == 0 && !FULL) {                                   // (kept whether or not the row has a second segment: X0 is only read when it has; FULL never has)
                                 const int w7 = __builtin_amdgcn_readlane(wv, src7);
                                 Wm = w7 > Wm ? w7 : Wm;
                                 src7 -= num_vec;
@@ -783,7 +784,7 @@ static __device__ __forceinline__ AGResult ag_banded_win(
                     }
                 };
                 round(round, std::integral_constant<int, 0>{}, u);
-                if (s == 0) { const int xr = Wm - c7x; if (xr > X0) X0 = xr; }
+                if (s == 0 && !FULL) { const int xr = Wm - c7x; if (xr > X0) X0 = xr; }
             };
             const int X_first = X0;
             if (nk0 > 0) rounds(std::integral_constant<int, 0>{}, nk0, full0, ins0, kg0, Fx0);
@@ -839,7 +840,8 @@ static __device__ __forceinline__ AGResult ag_banded_win(
         // (uniform row pointer + zero-extended 32-bit lane offset: the form that selects the SGPR-base store; with a sign-extended
         //  lane the address lives in a VGPR pair, which the 80-VGPR build spills and reloads -- with a vmcnt(0) wait -- every row)
         if constexpr (EXACT) {
-            if (inseg) bt_store(sink, (uint32_t)(i * nv_tot8 + jbase * seg_len), (uint32_t)flat_lane, (uint32_t)btr | bt_tag);
+            if (inseg) bt_store(sink, (uint32_t)(row_off + wbase), (uint32_t)flat_lane, (uint32_t)btr | bt_tag);   // (i * nv_tot8 + jbase * seg_len, kept incrementally)
+            row_off += nv_tot8;
         } else {
             bt_store(sink, (uint32_t)i * 64u, (uint32_t)lane, (uint32_t)btr);       // (lanes outside the band write what they have; the traceback never reads them)
         }
