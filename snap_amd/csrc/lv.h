@@ -107,11 +107,15 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
         const int d = lv_diag(r);
         const int tl = text_len - d;
         const int end = pattern_len < tl ? pattern_len : tl;
+        // (the words are collected per lane -- lane w keeps word w -- and stored by ONE masked store: a store by lane 0 per word was an exec save / restore on
+        //  the scalar unit per word)
+        unsigned long long mine = 0ull;
         for (int w = 0; w < nwu; w++) {
             const int i = w * 64 + lane;
             const bool mm = i >= end || d + i < 0 || P(i) != T(d + i);     // (text before its start is never part of a run: L(e,d) >= -d)
             const unsigned long long m = BALLOT(mm);
-            if (lane == 0) mask[r * nw + w] = m;
+            mine = lane == (w & 63) ? m : mine;
+            if ((w & 63) == 63 || w == nwu - 1) { const int w0 = w & ~63; if (w0 + lane <= w) mask[r * nw + w0 + lane] = mine; }
         }
     };
 
@@ -197,10 +201,12 @@ static __device__ __forceinline__ LVResult lv_compute_inl(
                 reached = (best == pattern_len);
                 row[r] = lv_pack(best, act);
             }
-            uint64_t mx = BALLOT(reached && act == LV_ACT_X);
-            uint64_t ma = BALLOT(reached);
-            if (mx && x_rank == (1 << 30)) x_rank = r0 + __ffsll((long long)mx) - 1;
-            if (ma && any_rank == (1 << 30)) any_rank = r0 + __ffsll((long long)ma) - 1;
+            const uint64_t ma = BALLOT(reached);
+            if (__builtin_expect(ma != 0ull, 0)) {                 // (one level per call: the other levels pay one compare here, not the two selects)
+                const uint64_t mx = BALLOT(reached && act == LV_ACT_X);
+                if (mx && x_rank == (1 << 30)) x_rank = r0 + __ffsll((long long)mx) - 1;
+                if (any_rank == (1 << 30)) any_rank = r0 + __ffsll((long long)ma) - 1;
+            }
         }
         WAVE_SYNC();
         if (x_rank != (1 << 30)) { last_best_rank = x_rank; break; }       // :243-248 (goto got_answer)
@@ -281,6 +287,20 @@ static __device__ __forceinline__ LdsSeq seq_uniform(const LdsSeq &s) {
 }
 template <class S> static __device__ __forceinline__ S seq_uniform(const S &s) { return s; }
 
+// (the call without bit planes -- every call of the default kernels -- has its own entry: nine dwords of plane arguments fewer to move into VGPRs at the
+//  call site and back into SGPRs on entry, twenty times per read)
+template <bool TRI_LDS, typename PSeq, typename TSeq, typename QSeq>
+static __device__ __attribute__((noinline)) LVResult lv_compute_fn_np(
+    PSeq P_in, QSeq Q_in, int pattern_len, TSeq T_in, int text_len, int k, uint16_t *lds_tri, uint32_t kmax, const DevTables *tab, uint32_t pcap)
+{
+    const PSeq P = seq_uniform(P_in); const QSeq Q = seq_uniform(Q_in); const TSeq T = seq_uniform(T_in);
+    pattern_len = (int)first_u32((uint32_t)pattern_len); text_len = (int)first_u32((uint32_t)text_len); k = (int)first_u32((uint32_t)k);
+    lds_tri = (uint16_t *)(uintptr_t)first_u64((uint64_t)(uintptr_t)lds_tri);
+    kmax = first_u32(kmax); pcap = first_u32(pcap);
+    tab = (const DevTables *)(uintptr_t)first_u64((uint64_t)(uintptr_t)tab);
+    return lv_compute_inl<TRI_LDS>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, nullptr);
+}
+
 template <bool TRI_LDS, typename PSeq, typename TSeq, typename QSeq>
 static __device__ __attribute__((noinline)) LVResult lv_compute_fn(
     PSeq P_in, QSeq Q_in, int pattern_len, TSeq T_in, int text_len, int k,
@@ -321,7 +341,7 @@ static __device__ __forceinline__ LVResult lv_compute(
                                                         (uint64_t)(uintptr_t)planes->p0, (uint64_t)(uintptr_t)planes->t0, (uint64_t)(uintptr_t)planes->work,
                                                         (uint32_t)(planes->st + 1) | ((uint32_t)planes->p_words << 16) | (planes->plain ? 1u << 23 : 0u) | ((uint32_t)planes->t_words << 24),
                                                         planes->p_org, planes->t_org);
-    return lv_compute_fn<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap, ~0ull, ~0ull, 0ull, 0u, 0, 0);
+    return lv_compute_fn_np<TRI_LDS, PSeq, TSeq, QSeq>(P, Q, pattern_len, T, text_len, k, lds_tri, kmax, tab, pcap);
 #endif
 }
 
