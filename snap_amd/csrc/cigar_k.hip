@@ -208,8 +208,8 @@ __global__ __launch_bounds__(256) void k_samf_dp8(SamFieldsArgs a)
                 }
             }
             const long long readable = nb + (long long)a.ix.genome_pad - loc;
-            for (int j = el; j < top + 16 && j < rows_cap; j += 8) {
-                if (elig && j < plen + 16) txt[j] = j < readable ? a.ix.genome[loc + j] : (uint8_t)0;
+            for (int j = el; j < top + LVC_MAX_K && j < rows_cap; j += 8) {     // (every row the loop below can reach: plen + LVC_MAX_K of them, as cigar_ag_item stages)
+                if (elig && j < plen + LVC_MAX_K) txt[j] = j < readable ? a.ix.genome[loc + j] : (uint8_t)0;
             }
         }
         // ---- first row (AffineGapVectorized.cpp:611-628): a lane's scoreFirstRow keeps its last value past the pattern's end

@@ -1442,6 +1442,9 @@ int main(int argc, char **argv)
         const uint64_t per_batch = o.paired ? o.batch_reads / 2 : o.batch_reads;           // records of EACH file per batch
         const uint64_t n_units = (n_records + per_batch - 1) / per_batch;
         n_batches = n_units; reader_done = true;
+        // (a small file: no feeder takes more batches per call than leaves the others their share -- with every batch available at once the first feeder
+        //  to wake would otherwise take eight and a file of a million reads would run on one feeder of one GPU)
+        if (!o.group) { const size_t share = (size_t)(n_units / (uint64_t)fctx.size()); if (group > (share ? share : 1)) group = share ? share : 1; }
         std::shared_ptr<std::atomic<uint64_t>> next_unit = std::make_shared<std::atomic<uint64_t>>(0);
         std::shared_ptr<std::atomic<int>> parsers_left = std::make_shared<std::atomic<int>>(o.n_parse);
         for (int t = 0; t < o.n_parse; t++)

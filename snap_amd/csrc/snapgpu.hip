@@ -260,7 +260,7 @@ static thread_local std::string g_last_error;
 static thread_local const struct snapgpu_ctx *g_share_buckets_from = nullptr;      // snapgpu_create_replica(share_index): adopt these bucket tables
 
 struct DevPool {
-    struct Slot { void *p; size_t cap; bool busy; };
+    struct Slot { void *p; size_t cap; bool busy; unsigned long long stamp; };
     std::vector<Slot> slots;
     std::mutex m;
     void *acquire(size_t bytes, hipError_t *err) {
@@ -277,24 +277,38 @@ struct DevPool {
             *err = hipMalloc(&p, cap);
             if (*err != hipSuccess) return nullptr;
         }
-        slots.push_back(Slot{p, cap, true});
+        slots.push_back(Slot{p, cap, true, 0ull});
         return p;
     }
     // (a buffer comes back with whatever its last user left in it: DevBuf memory is UNINITIALISED, every kernel clears what it needs)
     // Idle buffers are kept for the next call of a similar size, but not without bound: batches of varying size (a last short one, a retry
     // with a larger cigar stride, one-read calls of the host record loop) would otherwise leave gigabytes of per-wave scratch pinned next to
     // the index.  More than MAX_IDLE idle buffers, or more than MAX_IDLE_BYTES of them: the largest idle ones go.
-    static const size_t MAX_IDLE = 24, MAX_IDLE_BYTES = (size_t)20 << 30;     // (a 1 M-read call of snapgpu_align_sam_single keeps ~8 GB: 5.9 GB of row-loop results among them)
+    static const size_t MAX_IDLE = 40, MAX_IDLE_BYTES = (size_t)24 << 30;     // (a 1 M-read call of snapgpu_align_sam_single parks 18 buffers, ~8 GB: 5.9 GB of row-loop results among them)
+    unsigned long long tick = 0;
     void release(void *p) {
-        std::lock_guard<std::mutex> l(m);
-        for (auto &s : slots) if (s.p == p) { s.busy = false; break; }
-        for (;;) {
-            size_t n_idle = 0, bytes = 0; int big = -1;
-            for (size_t i = 0; i < slots.size(); i++) if (!slots[i].busy && slots[i].p) { n_idle++; bytes += slots[i].cap; if (big < 0 || slots[i].cap > slots[(size_t)big].cap) big = (int)i; }
-            if (big < 0 || (n_idle <= MAX_IDLE && bytes <= MAX_IDLE_BYTES)) break;
-            (void)hipFree(slots[(size_t)big].p);
-            slots.erase(slots.begin() + big);
+        // Too many idle buffers: the SMALLEST go (cheap to allocate again; dropping the largest, as rounds 4 - 5 did, meant a hipMalloc / hipFree of the multi-GB
+        // row-loop buffer per call for a context that alternates between call shapes).  Too many idle BYTES: the least recently released go.  hipFree
+        // synchronises the device: it is called after the pool's lock is dropped.
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> l(m);
+            for (auto &s : slots) if (s.p == p) { s.busy = false; s.stamp = ++tick; break; }
+            for (;;) {
+                size_t n_idle = 0, bytes = 0; int small = -1, old = -1;
+                for (size_t i = 0; i < slots.size(); i++) if (!slots[i].busy && slots[i].p) {
+                    n_idle++; bytes += slots[i].cap;
+                    if (small < 0 || slots[i].cap < slots[(size_t)small].cap) small = (int)i;
+                    if (old < 0 || slots[i].stamp < slots[(size_t)old].stamp) old = (int)i;
+                }
+                int victim = -1;
+                if (n_idle > MAX_IDLE) victim = small; else if (bytes > MAX_IDLE_BYTES) victim = old;
+                if (victim < 0) break;
+                drop.push_back(slots[(size_t)victim].p);
+                slots.erase(slots.begin() + victim);
+            }
         }
+        for (void *q : drop) (void)hipFree(q);
     }
     void free_all() {
         std::lock_guard<std::mutex> l(m);
@@ -1653,10 +1667,15 @@ static int launch_samf_dp8(snapgpu_ctx *ctx, SamFieldsArgs &a, DevBuf &buf, hipS
 {
     a.pre = nullptr; a.pre_stride = 0; a.pre_counter = ctx->d_work + 2;
     if (!samf_dp8_enabled() || !a.use_affine_gap || a.RL > 400 || a.n == 0) return SNAPGPU_OK;
+    // Best effort (a.pre == NULL is a valid mode: k_sam_fields then runs the row loops itself): not beyond the 64 KiB of LDS per workgroup that k_sam_fields is
+    // held to, not beyond a bounded pre-buffer (5 - 13 KB per read: a fraction of what is free, 12 GiB at most), and an allocation that fails is not an error.
     const size_t stride = samf_pre_stride(a.RL);
-    HIPCHK(ctx, buf.put(nullptr, (size_t)a.n * stride, s), SNAPGPU_E_NOMEM);
-    a.pre = (uint8_t *)buf.p; a.pre_stride = stride;
     const size_t lds = 4 * snapgpu_samf_dp8_lds_per_wave(a.RL);
+    if (lds > 64 * 1024) return SNAPGPU_OK;
+    const size_t want = (size_t)a.n * stride;
+    if (want > ((size_t)12 << 30)) return SNAPGPU_OK;
+    if (buf.put(nullptr, want, s) != hipSuccess) { (void)hipGetLastError(); buf.p = nullptr; return SNAPGPU_OK; }
+    a.pre = (uint8_t *)buf.p; a.pre_stride = stride;
     uint32_t per_cu = (uint32_t)((size_t)160 * 1024 / (lds ? lds : 1)); if (per_cu > 8) per_cu = 8; if (per_cu < 1) per_cu = 1;
     uint32_t blocks = (uint32_t)ctx->num_cus * per_cu;
     const uint32_t need = (a.n + 31) / 32; if (blocks > need) blocks = need;
