@@ -34,7 +34,7 @@ def main():
     os.makedirs(eb.BDIR, exist_ok=True)
     stats_src = os.path.join(eb.BDIR, "stats.cpp")
     with open(stats_src, "w") as f:
-        f.write("unsigned long long g_emu_stats[64]; unsigned long long g_agwin_stats[64];\n")
+        f.write("unsigned long long g_emu_stats[64]; unsigned long long g_agwin_stats[64]; unsigned long long g_agform_stats[64];\n")
     eb.FLAGS.append("-DSNAPGPU_AG_WIN_STATS")
     base_units = eb.units
     eb.units = lambda: base_units() + [("stats.o", stats_src, [])]
