@@ -12,6 +12,7 @@
 #include <vector>
 #include <deque>
 #include <mutex>
+#include <chrono>
 #include <atomic>
 #include <memory>
 #include <thread>
@@ -397,6 +398,7 @@ struct snapgpu_ctx {
     PairedArgs pargs_sec{}, pargs_sec_big{};
     uint8_t *d_pscratch_sec = nullptr, *d_pscratch_sec_big = nullptr;
     uint32_t p_sec_slots = 0, p_sec_big_slots = 0;
+    int paired_share = 1;               // calls in flight on the device when this context's current paired-end call began (PairedInFlight)
     void *d_psec_stage[4] = {nullptr, nullptr, nullptr, nullptr};      // paired secondary, counts, single secondary, counts
     size_t psec_stage_cap[4] = {0, 0, 0, 0};
     // what snapgpu_create was given, minus the blobs: lets snapgpu_create_replica build another context over the same index
@@ -2632,6 +2634,55 @@ static void launch_paired_exact(int variant, const PairedArgs *x, uint32_t block
     }
 }
 
+// Paired-end calls in flight on each device, and the part of the chip one of them asks for (round 6, profiles/r06q - r06s).  The paired kernel
+// is a persistent grid: one that asks for every wave slot of the chip while other feeders' kernels are resident has blocks PENDING until
+// those kernels end, and a pending block of an earlier launch keeps the small launches behind it (the second pass, the exact replay, the
+// next main pass of another feeder) from starting: the kernel-trace timeline of three feeders showed the chip with one kernel running 27 %
+// of the time and replays running alone.  With each grid sized to its share every feeder's kernel is resident at once and the follow-up
+// launches start at once: 357 - 466 k -> 586 - 590 k reads/s paired, 187 -> 262 k with secondary results (256 Mb, three feeders; four:
+// 619 - 643 k).  One call in flight: the whole chip; two: half each; three or more: a third each (measured: a third each is as good with
+// four to six feeders, the kernels then queue).  Single-end launches keep whole-chip grids: their kernels are short (~200 ms for three
+// feeders' batches), and smaller grids measured slower (8 of 24 waves per CU each: 14.96 -> 12.86 M reads/s, profiles/r06s).
+// SNAPGPU_PAIRED_GRID_SHARE=<n> fixes the divisor (1 = every launch asks for the whole chip, as before).  Calls on a caller's stream return
+// before their kernels end and so count only while they are being enqueued.
+struct PairedGate {                      // per device
+    std::mutex mu; int inflight = 0, peak = 0; std::chrono::steady_clock::time_point peak_at;
+};
+static PairedGate g_paired_gate[64];
+struct PairedInFlight {
+    PairedGate *g = nullptr; int share = 1;
+    explicit PairedInFlight(const snapgpu_ctx *ctx) {
+        if (!ctx || ctx->device < 0 || ctx->device >= 64) return;
+        g = &g_paired_gate[ctx->device];
+        const auto now = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lk(g->mu);
+        const int cur = ++g->inflight;
+        // feeders that start together (a barrier, the first batches of a run) would see 1, 2, 3 ... calls in flight: the concurrency of the
+        // last two seconds stands in for what the count is about to become
+        const bool fresh = g->peak > 0 && std::chrono::duration<double>(now - g->peak_at).count() < 2.0;
+        share = fresh && g->peak > cur ? g->peak : cur;
+        if (cur >= g->peak || !fresh) { g->peak = cur; g->peak_at = now; }
+    }
+    ~PairedInFlight() {
+        if (!g) return;
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (g->inflight >= g->peak) { g->peak = g->inflight; g->peak_at = std::chrono::steady_clock::now(); }
+        --g->inflight;
+    }
+    PairedInFlight(const PairedInFlight &) = delete; PairedInFlight &operator=(const PairedInFlight &) = delete;
+};
+static uint32_t paired_grid_share(const snapgpu_ctx *ctx, uint32_t all_blocks) {
+    int share = ctx->paired_share;
+    if (share > 3) share = 3;
+    if (const char *e = getenv("SNAPGPU_PAIRED_GRID_SHARE")) { int v = atoi(e); if (v >= 1 && v <= 16) share = v; }
+    if (share < 1) share = 1;
+    double over = 1.0;                  // (experiments: SNAPGPU_PAIRED_GRID_OVER=1.5 -> every launch asks for 1.5 shares)
+    if (const char *e = getenv("SNAPGPU_PAIRED_GRID_OVER")) { double v = atof(e); if (v >= 0.25 && v <= 4.0) over = v; }
+    double f = over / (double)share; if (f > 1.0) f = 1.0;
+    const uint32_t b = (uint32_t)((double)all_blocks * f + 0.999);
+    return b ? (b > all_blocks ? all_blocks : b) : 1;
+}
+
 static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, const void *d_quals, const void *d_offsets,
                          void *d_primary, void *d_first_alt, hipStream_t s, const PairedSecOut *so = nullptr)
 {
@@ -2653,7 +2704,7 @@ static int launch_paired(snapgpu_ctx *ctx, uint32_t n, const void *d_bases, cons
         HIPCHK(ctx, hipMalloc((void **)&ctx->d_flag_list, cap * 8), SNAPGPU_E_NOMEM);     // (second half: launch_paired's list of pairs for the exact kernel beside the main pass)
         ctx->flag_list_cap = cap;
     }
-    uint32_t blocks = (so ? ctx->p_sec_slots : ctx->p_wave_slots) / 4;
+    uint32_t blocks = paired_grid_share(ctx, (so ? ctx->p_sec_slots : ctx->p_wave_slots) / 4);
     uint32_t need = (n + 3) / 4; if (blocks > need) blocks = need;
     HIPCHK(ctx, hipEventRecord(ctx->ev0, s), SNAPGPU_E_LAUNCH);
     const size_t lds = (size_t)4 * ctx->p_lds_per_wave;
@@ -2785,6 +2836,7 @@ extern "C" int snapgpu_align_paired_device(snapgpu_ctx *ctx, uint32_t n_pairs, c
     if (!ctx || !d_bases || !d_quals || !d_offsets || !d_primary) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_paired_device: null argument");
     if (!ctx->paired) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_paired has not been called on this context");
     if (n_pairs == 0) return SNAPGPU_OK;
+    const PairedInFlight in_flight(ctx); ctx->paired_share = in_flight.share;      // (paired_grid_share: this call's launches ask for their share of the chip)
     HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     int rc = launch_paired(ctx, n_pairs, d_bases, d_quals, d_offsets, d_primary, d_first_alt, s);
@@ -2805,6 +2857,7 @@ extern "C" int snapgpu_align_paired(snapgpu_ctx *ctx, uint32_t n_pairs, const ch
         if (offsets[i + 1] - offsets[i] > ctx->params.max_read_len)
             return fail(ctx, SNAPGPU_E_INVALID, "read longer than max_read_len given at snapgpu_create (IntersectingPairedEndAligner.cpp:361-365)");
     }
+    const PairedInFlight in_flight(ctx); ctx->paired_share = in_flight.share;      // (paired_grid_share: this call's launches ask for their share of the chip)
     HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
     size_t nb = (size_t)offsets[nr];
     int rc;
@@ -2838,6 +2891,7 @@ extern "C" int snapgpu_align_paired_secondary_device(snapgpu_ctx *ctx, uint32_t 
         return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_align_paired_secondary_device: null argument");
     if (!ctx->paired_sec) return fail(ctx, SNAPGPU_E_INVALID, "snapgpu_enable_paired and snapgpu_enable_secondary must both have been called on this context");
     if (n_pairs == 0) return SNAPGPU_OK;
+    const PairedInFlight in_flight(ctx); ctx->paired_share = in_flight.share;      // (paired_grid_share: this call's launches ask for their share of the chip)
     HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
     PairedSecOut so{d_secondary, secondary_stride, d_n_secondary, d_single_secondary, single_stride, d_n_single_secondary};
@@ -2873,6 +2927,7 @@ extern "C" int snapgpu_align_paired_secondary(snapgpu_ctx *ctx, uint32_t n_pairs
         if (offsets[i + 1] - offsets[i] > ctx->params.max_read_len)
             return fail(ctx, SNAPGPU_E_INVALID, "read longer than max_read_len given at snapgpu_create (IntersectingPairedEndAligner.cpp:361-365)");
     }
+    const PairedInFlight in_flight(ctx); ctx->paired_share = in_flight.share;      // (paired_grid_share: this call's launches ask for their share of the chip)
     HIPCHK(ctx, hipSetDevice(ctx->device), SNAPGPU_E_NODEVICE);
     size_t nb = (size_t)offsets[nr];
     const size_t sec_bytes = (size_t)n_pairs * secondary_stride * sizeof(snapgpu_paired_result);

@@ -88,3 +88,43 @@ def test_paired_feeders_two_batches_in_flight():
     finally:
         b.close()
         a.close()
+
+
+@pytest.mark.gpu
+def test_paired_grid_share_three_feeders_same_bytes(monkeypatch):
+    """snapgpu.hip: paired_grid_share -- a paired-end launch asks for its share of the chip (calls in flight on the device, at most three
+    shares; SNAPGPU_PAIRED_GRID_SHARE fixes the divisor).  The grid's size is scheduling only: three feeders aligning the same 1 500 pairs
+    at the same time, and one context under divisors 1, 3 and 7, produce the bytes of the fixture's reference results."""
+    from snap_amd.aligner import ChimericPairedEndAligner
+    from tests.pairs_util import compare_paired
+    import os
+    zp = np.load(os.path.join(util.GOLDEN, "paired_reads.npz"))
+    a = ChimericPairedEndAligner(util.load_golden_index("paired_index.npz"), abi.default_params(max_k=8, max_read_len=160),
+                                 abi.default_paired_params())
+    feeders = [a, a.replica(), a.replica()]
+    try:
+        n_avail = (len(zp["o150"]) - 1) // 2
+        n_pairs = min(3000, n_avail)
+        o = zp["o150"][:2 * n_pairs + 1]
+        bases, quals = zp["b150"][:int(o[-1])], zp["q150"][:int(o[-1])]
+        exp, _ = util.with_fresh_overrides(zp["default_d8_150_s0_primary"], "pe_default_d8_150_s0_primary")
+        out = {}
+
+        def run(al, key):
+            for rep in range(2):            # (the second call starts while the others' first calls are in flight)
+                out[key, rep] = al.align(bases, quals, o)[0]
+        ts = [threading.Thread(target=run, args=(f, i)) for i, f in enumerate(feeders)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for k, v in out.items():
+            assert v.tobytes() == out[0, 0].tobytes(), k
+        assert not compare_paired(exp[:n_pairs], out[0, 0], verbose=0).any()
+        for share in ("1", "3", "7"):
+            monkeypatch.setenv("SNAPGPU_PAIRED_GRID_SHARE", share)
+            assert a.align(bases, quals, o)[0].tobytes() == out[0, 0].tobytes(), share
+    finally:
+        for f in feeders[1:]:
+            f.close()
+        a.close()
