@@ -213,7 +213,7 @@ def parse_args(argv=None):
                     help="single = configs[1] (the metric's config); paired = configs[2], 2x150 bp FR pairs through the paired-end path")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="one GPU, --workload single only: do not add the short paired-end leg (`paired`) and the 256 Mb leg (`genome_256mb`)")
-    ap.add_argument("--paired-leg-steps", type=int, default=10, help="timed steps of the extra paired-end leg")
+    ap.add_argument("--paired-leg-steps", type=int, default=12, help="timed steps of the extra paired-end leg")
     ap.add_argument("--standin-mb", type=int, default=256, help="genome size of the extra `genome_256mb` leg (tests shrink it)")
     ap.add_argument("--standin-leg", action="store_true", help="add the `genome_256mb` leg (the line of rounds 1-3 on the 256 Mb stand-in; in the default run until round 4)")
     ap.add_argument("--no-c5-leg", action="store_true", help="do not add the `c5` leg (configs[4] on one GPU: 2 x 250 bp pairs, -d 20, insert N(600, 80^2), 0.2 % long indels)")

@@ -2571,6 +2571,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     slots &= ~3u;
     if ((size_t)slots * a.stride > free_b / 2) return fail(ctx, SNAPGPU_E_NOMEM, "not enough device memory for the paired-end candidate pools (lower -H / -mcp or set SNAPGPU_PAIRED_POOL)");
     ctx->p_wave_slots = slots;
+    if (getenv("SNAPGPU_VERBOSE")) fprintf(stderr, "snapgpu: paired-end context: %u wave slots (%d per CU asked) x %.2f MB of pools, %.1f GB free before; second-pass slabs %.1f MB each; LDS %u B per wave\n", slots, waves_per_cu, a.stride / 1e6, free_b / 1e9, big.stride / 1e6, (unsigned)PL.total);
     HIPCHK(ctx, hipMalloc((void **)&ctx->d_pscratch, (size_t)slots * a.stride), SNAPGPU_E_NOMEM);
     // only the single-end head tables must start zeroed
     for (uint32_t w = 0; w < slots; w++)
