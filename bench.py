@@ -38,6 +38,10 @@ import os
 import sys
 import time
 
+# (before torch starts the HIP runtime: eight hardware queues for the feeders' streams instead of four -- snapgpu.hip: snapgpu_hw_queues; libsnapgpu.so sets
+#  the same default itself when it is loaded first, as in snapgpu-sam and the shim)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

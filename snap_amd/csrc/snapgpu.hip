@@ -425,6 +425,13 @@ static int fail(snapgpu_ctx *ctx, int code, const std::string &msg) {
     return code;
 }
 
+// The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and a hardware queue runs its kernels in
+// order: two feeders whose streams land on one queue take turns, whatever their grids ask for.  Seen in the driver's bench command, whose paired-end
+// legs come after the single-end leg's contexts (profiles/r06zzz: blocking call 7.6 s around 4.4 s of kernels, 410 k reads/s where the same leg alone
+// ran at 544 k) and with GPU_MAX_HW_QUEUES=2 (362 k, profiles/r06v).  So: a context has ONE stream unless it asked for the replay beside the main
+// pass, and the library asks for 8 hardware queues when it is loaded before the runtime starts (a value in the environment wins).
+__attribute__((constructor)) static void snapgpu_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" int snapgpu_abi_version(void) { return SNAPGPU_ABI_VERSION; }
 
 extern "C" int snapgpu_set_aligner_flags(snapgpu_ctx *ctx, int stop_on_first_hit, int explore_popular_seeds)
@@ -2611,7 +2618,7 @@ extern "C" int snapgpu_enable_paired(snapgpu_ctx *ctx, const snapgpu_paired_para
     }
     ctx->heavy_first = getenv("SNAPGPU_PAIRED_HEAVY_FIRST") != nullptr && atoi(getenv("SNAPGPU_PAIRED_HEAVY_FIRST")) != 0;
     if (const char *e = getenv("SNAPGPU_PAIRED_REPLAY_BESIDE")) ctx->replay_beside = atoi(e) != 0 ? 1 : 0;
-    if (!ctx->replay_stream) {
+    if (!ctx->replay_stream && ctx->replay_beside == 1) {      // (only a context that asked for the replay beside the main pass has the second stream: see snapgpu_hw_queues)
         HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->replay_stream, hipStreamNonBlocking), SNAPGPU_E_NODEVICE);
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming), SNAPGPU_E_NODEVICE);
         HIPCHK(ctx, hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming), SNAPGPU_E_NODEVICE);
