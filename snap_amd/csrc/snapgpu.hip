@@ -2642,17 +2642,18 @@ static void launch_paired_exact(int variant, const PairedArgs *x, uint32_t block
     }
 }
 
-// Paired-end calls in flight on each device, and the part of the chip one of them asks for (round 6, profiles/r06q - r06s).  The paired kernel
+// Paired-end calls in flight on each device, and the part of the chip one of them asks for (round 6, profiles/r06q - r06w).  The paired kernel
 // is a persistent grid: one that asks for every wave slot of the chip while other feeders' kernels are resident has blocks PENDING until
-// those kernels end, and a pending block of an earlier launch keeps the small launches behind it (the second pass, the exact replay, the
-// next main pass of another feeder) from starting: the kernel-trace timeline of three feeders showed the chip with one kernel running 27 %
-// of the time and replays running alone.  With each grid sized to its share every feeder's kernel is resident at once and the follow-up
-// launches start at once: 357 - 466 k -> 586 - 590 k reads/s paired, 187 -> 262 k with secondary results (256 Mb, three feeders; four:
-// 619 - 643 k).  One call in flight: the whole chip; two: half each; three or more: a third each (measured: a third each is as good with
-// four to six feeders, the kernels then queue).  Single-end launches keep whole-chip grids: their kernels are short (~200 ms for three
-// feeders' batches), and smaller grids measured slower (8 of 24 waves per CU each: 14.96 -> 12.86 M reads/s, profiles/r06s).
-// SNAPGPU_PAIRED_GRID_SHARE=<n> fixes the divisor (1 = every launch asks for the whole chip, as before).  Calls on a caller's stream return
-// before their kernels end and so count only while they are being enqueued.
+// those kernels end.  The kernel-trace timeline of three feeders showed the chip with one kernel running 27 % of the time and replays running
+// alone; with each grid sized to a share (`slots / calls in flight`, at most three shares) every feeder's kernel is resident at once: 357 - 466 k
+// -> 586 - 604 k reads/s paired, 187 -> 267 k configs[4] (256 Mb, three feeders).  Half of that was the hardware queues (snapgpu_hw_queues): a
+// pending block holds back whatever shares ITS queue.  With one stream per context on a queue of its own, a launch asks for 1.5 shares: the
+// pending half fills the slots a feeder leaves idle while its replay (a few waves, 0.5 - 2 s) runs -- against exact shares +4.5 % / +5.5 % paired
+// and +7.5 % configs[4] at 256 Mb / 3 100 Mb (profiles/r06w; 2 shares and the whole chip: better at one genome size, worse at the other).
+// Single-end launches keep whole-chip grids: their calls are one short kernel each, and smaller grids measured slower (8 of 24 waves per CU each:
+// 14.96 -> 12.86 M reads/s, profiles/r06s).  SNAPGPU_PAIRED_GRID_SHARE=<n> fixes the divisor, SNAPGPU_PAIRED_GRID_OVER=<x> the shares asked
+// for (SHARE=1: every launch asks for the whole chip, as before).  Calls on a caller's stream return before their kernels end and so count only
+// while they are being enqueued.
 struct PairedGate {                      // per device
     std::mutex mu; int inflight = 0, peak = 0; std::chrono::steady_clock::time_point peak_at;
 };
@@ -2684,7 +2685,7 @@ static uint32_t paired_grid_share(const snapgpu_ctx *ctx, uint32_t all_blocks) {
     if (share > 3) share = 3;
     if (const char *e = getenv("SNAPGPU_PAIRED_GRID_SHARE")) { int v = atoi(e); if (v >= 1 && v <= 16) share = v; }
     if (share < 1) share = 1;
-    double over = 1.0;                  // (experiments: SNAPGPU_PAIRED_GRID_OVER=1.5 -> every launch asks for 1.5 shares)
+    double over = 1.5;                  // shares asked for (above)
     if (const char *e = getenv("SNAPGPU_PAIRED_GRID_OVER")) { double v = atof(e); if (v >= 0.25 && v <= 4.0) over = v; }
     double f = over / (double)share; if (f > 1.0) f = 1.0;
     const uint32_t b = (uint32_t)((double)all_blocks * f + 0.999);
