@@ -212,6 +212,32 @@ def test_emu_feeders_share_one_index(emu):
     mc.test_paired_feeders_two_batches_in_flight()
 
 
+def test_emu_paired_grid_share_is_scheduling_only(emu, monkeypatch):
+    """snapgpu.hip: paired_grid_share on the emulated device (3 workgroups of wave slots): whatever part of them a launch asks for --
+    SNAPGPU_PAIRED_GRID_SHARE 1 / 2 / 16 (never less than one workgroup), SNAPGPU_PAIRED_GRID_OVER 0.25 / 4 -- the results are the same bytes,
+    and the fixture's."""
+    from tests.pairs_util import compare_paired
+    from snap_amd.aligner import ChimericPairedEndAligner
+    z = np.load(os.path.join(util.GOLDEN, "paired_reads.npz"))
+    n = 48
+    o = z["o150"][:2 * n + 1]
+    b, q = z["b150"].reshape(-1)[:int(o[-1])], z["q150"].reshape(-1)[:int(o[-1])]
+    a = ChimericPairedEndAligner(util.load_golden_index("paired_index.npz"), abi.default_params(max_k=8, max_read_len=160), abi.default_paired_params())
+    try:
+        base = a.align(b, q, o)[0]
+        for share, over in (("1", None), ("2", None), ("16", None), (None, "0.25"), ("2", "4")):
+            for k_, v_ in (("SNAPGPU_PAIRED_GRID_SHARE", share), ("SNAPGPU_PAIRED_GRID_OVER", over)):
+                if v_ is None:
+                    monkeypatch.delenv(k_, raising=False)
+                else:
+                    monkeypatch.setenv(k_, v_)
+            assert a.align(b, q, o)[0].tobytes() == base.tobytes(), (share, over)
+    finally:
+        a.close()
+    exp, _ = util.with_fresh_overrides(z["default_d8_150_s0_primary"], "pe_default_d8_150_s0_primary")
+    assert not compare_paired(exp[:n], base, verbose=3).any()
+
+
 @pytest.mark.parametrize("eager", [False, True])
 def test_emu_phase4_help_on_demand(emu, monkeypatch, eager):
     """The Phase-4 help slots (paired_dev.h), published on demand / eagerly, on pairs that have long candidate lists (a genome built of
